@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the DAS hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|small]
+
+One "step" = one full-frame delay-and-sum of the workload (default: BASELINE config C3 -- 256-element
+array, 256-transmit full-synthetic-aperture, 1024 x 1024 Cartesian scan, T = 2816, complex64 channel
+data, lanczos3, no apodization, scalar sound speed) with the channel data
+already resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per GPU) the SAME
+image is split into N contiguous slabs of the linear pixel index, every rank beamforms its slab from
+its own replica of the data, and the slabs are gathered with one RCCL all_gather -- inside the timed
+region (strong scaling of one frame).
+
+Rank 0 prints ONE JSON line: metric/value/unit per BASELINE.json plus
+  "roofline":     algorithmic HBM bytes per launch / measured kernel time (hipEvents on the launch stream)
+  "cpu_baseline": the C restatement of the reference's CPU branch (oracle/, kind "port") timed on this
+                  host's cores on a pixel-subsampled image (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+FP32_PEAK_TFLOPS = 157.3       # fp32 vector peak (same guide)
+FLOP_PER_PAIR = {"nearest": 17, "linear": 24, "cubic": 42, "lanczos3": 54}   # SURVEY.md section 8d flop model
+
+
+def workload(name: str):
+    """Geometry of the BASELINE configs."""
+    from qups_amd import geometry as G
+    c0 = 1540.0
+    if name == "c3":      # 256 el FSA, 1024^2, lanczos3
+        fc, N, pitch, nx, nz, T, interp = 5e6, 256, 0.2e-3, 1024, 1024, 2816, "lanczos3"
+        lam = c0 / fc
+        Pr, nrm = G.linear_array(N, pitch)
+        Pv, Nv, opt = G.sequence_args("FSA", tx_pos=Pr, tx_normals=nrm)
+        x = (np.arange(nx) - (nx - 1) / 2) * lam / 4
+        z = 2e-3 + np.arange(nz) * lam / 4
+        label = "C3: 256-el FSA (256 Tx x 256 Rx), 1024x1024 ScanCartesian lambda/4, T=2816, complex64, lanczos3"
+    elif name == "c2":    # 128 el, 128 PW, 512^2, cubic
+        fc, N, pitch, nx, nz, T, interp = 5e6, 128, 0.3e-3, 512, 512, 2048, "cubic"
+        lam = c0 / fc
+        Pr, nrm = G.linear_array(N, pitch)
+        th = np.deg2rad(np.linspace(-25, 25, 128))
+        Pv, Nv, opt = G.sequence_args("PW", focus=np.stack([np.sin(th), 0 * th, np.cos(th)]))
+        x = (np.arange(nx) - (nx - 1) / 2) * lam / 4
+        z = 2e-3 + np.arange(nz) * lam / 4
+        label = "C2: 128-el, 128 plane waves, 512x512 ScanCartesian lambda/4, T=2048, complex64, cubic"
+    elif name == "small":  # quick plumbing check
+        fc, N, pitch, nx, nz, T, interp = 5e6, 32, 0.3e-3, 128, 256, 1024, "lanczos3"
+        lam = c0 / fc
+        Pr, nrm = G.linear_array(N, pitch)
+        Pv, Nv, opt = G.sequence_args("FSA", tx_pos=Pr, tx_normals=nrm)
+        x = (np.arange(nx) - (nx - 1) / 2) * lam / 4
+        z = 2e-3 + np.arange(nz) * lam / 4
+        label = "small: 32-el FSA, 256x128, T=1024, complex64, lanczos3"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    Pi = G.scan_cartesian(x, z)
+    M = Nv.shape[1] if Nv.shape[1] > 1 else Pv.shape[1]
+    return dict(name=name, label=label, Pi=Pi, Pr=Pr, Pv=Pv, Nv=Nv, opt=opt, T=T, N=N, M=M, fs=4 * fc, c0=c0,
+                interp=interp, I1=nz, I2=nx)
+
+
+def cpu_baseline(w, x_host, budget_s=15.0):
+    """Time the C oracle (port of the reference CPU branch) on a pixel-subsampled image."""
+    from oracle import das_ref
+    nthreads = das_ref.lib().das_ref_max_threads()
+
+    def run(step):
+        Pi = w["Pi"][:, ::step, ::step, :]
+        t = time.perf_counter()
+        das_ref.das_spec("DAS", Pi, w["Pr"], w["Pv"], w["Nv"], x_host, 0.0, w["fs"], w["c0"],
+                         VS="plane-waves" not in w["opt"], DV="diverging-waves" in w["opt"], interp=w["interp"],
+                         prec="single", timing=True)
+        return das_ref.LAST_SECONDS, Pi.shape[1] * Pi.shape[2]
+
+    t, npx = run(32)                                   # calibration
+    rate = npx / max(t, 1e-6)
+    want = rate * budget_s
+    step = int(np.clip(np.ceil(np.sqrt(w["I1"] * w["I2"] / max(want, 1.0))), 1, 32))
+    t, npx = run(step)
+    return {"value": round(npx / t / 1e6, 6), "unit": "Mpixel/s", "cores": int(nthreads), "kind": "port",
+            "seconds": round(t, 3),
+            "sample": f"every {step}th pixel per axis of the same image ({npx} px), full {w['N']}x{w['M']} aperture, "
+                      f"float32, OpenMP x{nthreads}; full-frame time extrapolated: {w['I1'] * w['I2'] / (npx / t):.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 tiled")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from qups_amd import DasPlan, build_problem, parse_options, _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device(f"cuda:{local}")
+
+    w = workload(args.workload)
+    T, N, M = w["T"], w["N"], w["M"]
+    I = w["I1"] * w["I2"]
+    g = torch.Generator(device=dev).manual_seed(1234)     # same data on every rank (replicated input)
+    xc = torch.view_as_complex(torch.randn((M, N, T, 2), generator=g, device=dev, dtype=torch.float32))
+    opts = parse_options(xc, list(w["opt"]) + ["interp", w["interp"]])
+    prob = build_problem("DAS", w["Pi"], w["Pr"], w["Pv"], w["Nv"], (T, N, M), 0.0, w["fs"], w["c0"], opts)
+    b, e = I * rank // world, I * (rank + 1) // world       # contiguous slab of the linear pixel index
+    plan = DasPlan(prob, device=dev, kernel=args.kernel, i_begin=b, i_count=e - b)
+    equal = (I % world == 0)
+    out = torch.empty(I, dtype=torch.complex64, device=dev) if world > 1 else None
+
+    def step():
+        y = plan.execute_colmajor(xc, 1).reshape(-1)
+        if world > 1:
+            if equal:
+                dist.all_gather_into_tensor(out, y)
+            else:
+                parts = [torch.empty(I * (r + 1) // world - I * r // world, dtype=y.dtype, device=dev) for r in range(world)]
+                dist.all_gather(parts, y)
+        return y
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+
+    # kernel-only time (hipEvents on the launch stream), outside the timed region
+    plan.set_timing(True)
+    kms = []
+    for _ in range(max(2, min(args.steps, 5))):
+        plan.execute_colmajor(xc, 1)
+        kms.append(plan.last_kernel_ms())
+    plan.set_timing(False)
+    kernel_ms = float(np.mean(kms))
+    fallback = plan.fallback_tiles()
+
+    if rank == 0:
+        ms = el / args.steps * 1e3
+        pairs = I * N * M
+        alg_bytes = (T * N * M * 8 + 12 * I + 8 * I) / world      # per launch (per rank): x + Pi + y  (SURVEY 8d "B")
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", f"traffic_{w['name']}.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        info = _lib.device_info(local)
+        rec = {
+            "metric": "beamformed Mpixels/sec (1024^2 px, 256x256 Tx/Rx)" if w["name"] == "c3" else "beamformed Mpixels/sec",
+            "value": round(I / (el / args.steps) / 1e6, 4), "unit": "Mpixel/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["label"], "pixels": I, "pairs_per_frame": pairs, "kernel": plan.kernel,
+                       "fallback_tiles": fallback, "parallelism": f"pixel-slab x{world} + RCCL all_gather" if world > 1 else "1 GPU",
+                       "device": info["name"], "cu": info["cu_count"]},
+            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                         "traffic": traffic, "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes": int(alg_bytes),
+                         "note": "compulsory-traffic accounting: this path is FP32-VALU / LDS-gather bound "
+                                 "(~2.5e3 flop/byte), see also valu_frac",
+                         "gpairs_per_s": round(pairs / world / (kernel_ms * 1e-3) / 1e9, 3),
+                         "valu_tflops_model": round(pairs / world * FLOP_PER_PAIR[w["interp"]] / (kernel_ms * 1e-3) / 1e12, 3),
+                         "valu_frac": round(pairs / world * FLOP_PER_PAIR[w["interp"]] / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)},
+        }
+        if world == 1 and not args.no_cpu:
+            try:
+                xh = torch.view_as_real(xc).cpu().numpy().view(np.complex64).reshape(M, N, T).transpose(2, 1, 0)
+                rec["cpu_baseline"] = cpu_baseline(w, xh)
+            except Exception as ex:  # report, never hide
+                rec["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"FAILED: {ex!r}"}
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

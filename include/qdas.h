@@ -1,0 +1,186 @@
+/* qdas.h -- C ABI of libqdas.so: MI355X-native delay-and-sum beamforming engine.
+ *
+ * Drop-in boundary for ONE reference call site: the device launch inside
+ * `das_spec` (reference kern/das_spec.m:279-306 builds the kernel object and
+ * uploads the size constants; kern/das_spec.m:372 is the per-frame launch
+ *
+ *     y{f} = k.feval(yg, Pi, Pr, Pv, Nv, apod, cinv, [cstride, astride],
+ *                    x(:,:,:,f), [fs, fmod]);
+ *
+ * of `DAS` / `DASf` / `DASh`, reference src/bf.cu:144-172), plus the `delays`
+ * variant (kern/das_spec.m:377, src/bf.cu:209-298) and -- as the "next" row --
+ * the split-delay launch of `wsinterpd2[f|h]` (kern/wsinterpd2.m:236,
+ * src/interpd.cu:449-476) used by bfDAS/bfDASLUT.
+ *
+ * Everything is plain C: pointers, sizes, no torch / HIP types in signatures
+ * (`stream` is a `hipStream_t` passed as `void*`; NULL = the default stream).
+ * All arrays use MATLAB (column-major) memory order exactly as the reference
+ * kernel ABI does.  Functions return 0 on success, a QDAS_E* code otherwise;
+ * `qdas_last_error()` returns a thread-local message (the MEX shim maps it to
+ * mexErrMsgIdAndTxt("QUPS:das_spec:...")).  The library never frees or keeps
+ * caller memory beyond a call, except device copies it makes itself.
+ */
+#ifndef QDAS_H
+#define QDAS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QDAS_VERSION 100
+
+/* ---- data precision: the reference's kernel postfix (kern/das_spec.m:218-222) */
+#define QDAS_F64 0 /* 'DAS'  : double2 data/apod/y, double geometry + time            */
+#define QDAS_F32 1 /* 'DASf' : float2  data/apod/y, float  geometry + time            */
+#define QDAS_F16 2 /* 'DASh' : half2   data/apod/y (passed as ushort2), float geometry */
+
+/* ---- QUPS_BF_FLAG bit layout (reference kern/das_spec.m:198-213, src/bf.cu:100,126,129) */
+#define QDAS_INTERP_NEAREST  0
+#define QDAS_INTERP_LINEAR   1
+#define QDAS_INTERP_CUBIC    2 /* Catmull-Rom = MATLAB interp1 'cubic' (the CPU path)   */
+#define QDAS_INTERP_LANCZOS3 3 /* window a = 2, 4 taps (src/interpd.cu:116-150)          */
+#define QDAS_INTERP_LINEAR4  4 /* alias of linear (src/interpd.cu:163)                   */
+#define QDAS_INTERP_CUBIC_DEV 5 /* extension: the Horner lines the CUDA/OpenCL code executes
+                                   (src/interpd.cu:103-106) -- NOT Catmull-Rom; see DESIGN.md */
+#define QDAS_FLAG_INTERP_MASK 7
+#define QDAS_FLAG_KEEP_RX 8   /* 'SYN' | 'BF' : keep the receive dimension   */
+#define QDAS_FLAG_KEEP_TX 16  /* 'MUL' | 'BF' : keep the transmit dimension  */
+#define QDAS_FLAG_TPOSE   32  /* data is T x M x N instead of T x N x M      */
+
+/* ---- where caller pointers live */
+#define QDAS_MEM_HOST   0
+#define QDAS_MEM_DEVICE 1
+
+/* ---- kernel selection (QDAS_KERNEL_AUTO picks the tiled kernel when eligible) */
+#define QDAS_KERNEL_AUTO    0
+#define QDAS_KERNEL_GENERIC 1 /* one pixel per lane, any mode / broadcast shape        */
+#define QDAS_KERNEL_TILED   2 /* LDS-staged pixel tiles; error if the case is ineligible */
+
+/* ---- error codes */
+#define QDAS_OK            0
+#define QDAS_EINVAL        1 /* bad argument / inconsistent sizes (message says which)  */
+#define QDAS_EUNSUPPORTED  2 /* valid request the build cannot serve                    */
+#define QDAS_EHIP          3 /* HIP runtime error (message carries hipGetErrorString)   */
+#define QDAS_ENOMEM        4
+
+/* Size/flag constants: the reference's constant-memory symbols QUPS_{T,N,M,I,I1,I2,I3,S},
+ * QUPS_{VS,DV}, QUPS_BF_FLAG (reference src/sizes.cu:17-52, src/bf.cu:45-47;
+ * uploaded at kern/das_spec.m:294-298). */
+typedef struct qdas_sizes {
+    uint64_t T;          /* fast-time samples per trace                                  */
+    uint64_t N, M;       /* receivers, transmits                                         */
+    uint64_t I1, I2, I3; /* image size; I = I1*I2*I3, I1 fastest                         */
+    uint64_t S;          /* number of apodization arrays (0 = none; reference passes {1}) */
+    int32_t  flag;       /* QUPS_BF_FLAG                                                  */
+    int32_t  VS;         /* 1: virtual-source model, 0: plane-wave model                  */
+    int32_t  DV;         /* 1: diverging wave (distance always positive)                  */
+    int32_t  dtype;      /* QDAS_F64 | QDAS_F32 | QDAS_F16                                */
+} qdas_sizes;
+
+/* Full description of one beamforming problem (everything except the data). */
+typedef struct qdas_desc {
+    qdas_sizes sz;
+    double fs, fmod;      /* [fs, fmod] == tvars (src/bf.cu:57-58)                        */
+    /* geometry, real(prec) -- float for QDAS_F16 (kern/das_spec.m:356) */
+    const void *Pi;       /* 3 x I    pixel positions                                      */
+    const void *Pr;       /* 3 x N    receiver positions                                   */
+    const void *Pv;       /* 4 x M    (virtual) source positions, row 4 = t0 (das_spec.m:361) */
+    const void *Nv;       /* 3 x M    transmit normals                                     */
+    const void *apod;     /* concatenated apodization arrays (das_spec.m:344-345); complex(prec)
+                             unless apod_real != 0; may be NULL iff S == 0                 */
+    const void *cinv;     /* 1/c, real(prec), broadcastable I1 x I2 x I3 x N x M           */
+    const uint64_t *acstride; /* HOST pointer, 6*(1+S) entries: [cstride(6), astride(6 x S)]
+                             element strides for dims (I1,I2,I3,N,M) -- 0 where singleton -- and
+                             the array's base offset in entry 6 (reference das_spec.m:257-260) */
+    int32_t mem;          /* QDAS_MEM_*: where Pi..cinv AND x / y of execute() live        */
+    int32_t apod_real;    /* extension: apod buffer holds real(prec) weights               */
+    int32_t kernel;       /* QDAS_KERNEL_*                                                 */
+    int32_t device;       /* HIP device ordinal, -1 = current device                       */
+    /* pixel shard (multi-GPU: every rank builds the same desc with its own slab;
+       single GPU: i_begin = 0, i_count = 0 meaning "all I") */
+    uint64_t i_begin;     /* first linear pixel index of this plan                         */
+    uint64_t i_count;     /* number of pixels (0 = I - i_begin)                            */
+    uint64_t y_ld;        /* pixels between consecutive [n|m] planes of y (0 = i_count): lets a
+                             shard write straight into a full-size I x [N] x [M] buffer    */
+    uint64_t reserved[4];
+} qdas_desc;
+
+typedef struct qdas_plan qdas_plan; /* opaque: device copies of geometry + strides + kernel choice */
+
+/* ---- plan API: the reusable [k, PRE_ARGS, POST_ARGS] handle of the reference
+ *      (kern/das_spec.m:72-81,387-390) */
+int  qdas_plan_create(qdas_plan **plan, const qdas_desc *desc);
+/* Beamform ONE frame: x is T x N x M (or T x M x N with QDAS_FLAG_TPOSE) complex(prec);
+ * y is i_count x [1|N] x [1|M] complex(prec) with plane stride y_ld; y is fully
+ * overwritten.  Asynchronous on `stream` when desc.mem == QDAS_MEM_DEVICE. */
+int  qdas_plan_execute(qdas_plan *plan, const void *x, void *y, void *stream);
+/* F frames in one call (kern/das_spec.m:371-373 host loop): frame f uses
+ * x + f*x_stride and y + f*y_stride (strides in complex elements). */
+int  qdas_plan_execute_frames(qdas_plan *plan, const void *x, void *y, uint64_t F,
+                              uint64_t x_stride, uint64_t y_stride, void *stream);
+/* 'delays' (src/bf.cu:209-298, kern/das_spec.m:377): tau is i_count x N x M real(prec),
+ * tau = cinv(1) * (dv + dr); no t0, like the reference. */
+int  qdas_plan_delays(qdas_plan *plan, void *tau, void *stream);
+void qdas_plan_destroy(qdas_plan *plan);
+/* which kernel a plan resolved to (QDAS_KERNEL_GENERIC | QDAS_KERNEL_TILED) and, after an
+ * execute, how many pixel tiles fell back to the generic kernel (oversize delay window) */
+int  qdas_plan_kernel(const qdas_plan *plan);
+int  qdas_plan_fallback_tiles(const qdas_plan *plan, uint64_t *ntiles);
+/* time of the last execute()'s kernels in ms measured with hipEvents on its stream
+ * (enabled by qdas_plan_set_timing(plan, 1); synchronises the stream) */
+int  qdas_plan_set_timing(qdas_plan *plan, int enable);
+int  qdas_plan_last_kernel_ms(const qdas_plan *plan, float *ms);
+
+/* ---- one-shot entries shaped like the reference kernels' argument lists
+ *      (device pointers; sizes struct replaces the constant-memory symbols).
+ *      DAS  <-> src/bf.cu:144-151, DASf <-> :153-161, DASh <-> :164-171 */
+int qdas_DAS (const qdas_sizes *sz, void *y, const double *Pi, const double *Pr, const double *Pv,
+              const double *Nv, const void *a, const double *cinv, const uint64_t *acstride_host,
+              const void *x, const double tvars[2], void *stream);
+int qdas_DASf(const qdas_sizes *sz, void *y, const float *Pi, const float *Pr, const float *Pv,
+              const float *Nv, const void *a, const float *cinv, const uint64_t *acstride_host,
+              const void *x, const float tvars[2], void *stream);
+int qdas_DASh(const qdas_sizes *sz, void *y, const float *Pi, const float *Pr, const float *Pv,
+              const float *Nv, const void *a, const float *cinv, const uint64_t *acstride_host,
+              const void *x, const float tvars[2], void *stream);
+/* delays <-> src/bf.cu:255-298, delaysf <-> :209-252 (tau is I x N x M) */
+int qdas_delays (const qdas_sizes *sz, double *tau, const double *Pi, const double *Pr,
+                 const double *Pv, const double *Nv, double cinv, void *stream);
+int qdas_delaysf(const qdas_sizes *sz, float *tau, const float *Pi, const float *Pr,
+                 const float *Pv, const float *Nv, float cinv, void *stream);
+
+/* ---- split-delay flavour ("next" row): what bfDASLUT ->
+ *      ChannelData.sample2sep -> wsinterpd2 computes (reference src/UltrasoundSystem.m:4641-4660,
+ *      src/ChannelData.m:1431-1445, kern/wsinterpd2.m:236, src/interpd.cu:344-396) with owned
+ *      outputs instead of float atomics:
+ *        y[i,(n),(m)] = sum w[i,n,m] * exp(j*omega*s) * sample(x[:,n,m], s),
+ *        s = tau_rx[i,n] + tau_tx[i,m]        (sample units, already (tau - t0)*fs)
+ *      non-finite s are skipped (src/interpd.cu:390). */
+typedef struct qdas_lut_desc {
+    uint64_t T, N, M, I;      /* I pixels (any shape, flattened)                            */
+    int32_t  flag;            /* interp bits + QDAS_FLAG_KEEP_RX/TX (+ TPOSE for the data)   */
+    int32_t  dtype;           /* QDAS_F64 | QDAS_F32 | QDAS_F16 (delays: double|float|float) */
+    double   omega;           /* imag(omega) = 2*pi*fmod/fs (src/ChannelData.m:1439)         */
+    const void *tau_rx;       /* I x N real, device                                          */
+    const void *tau_tx;       /* I x M real, device                                          */
+    const void *w;            /* complex(prec) weights or NULL; strides below               */
+    uint64_t wstride[3];      /* element strides of w for (i, n, m); 0 where singleton       */
+    int32_t  w_real;          /* weights are real(prec)                                      */
+    int32_t  reserved;
+} qdas_lut_desc;
+int qdas_das_lut(const qdas_lut_desc *d, const void *x, void *y, void *stream);
+
+/* ---- misc */
+const char *qdas_last_error(void);
+int  qdas_version(void);
+/* device properties the host side reports next to measurements */
+int  qdas_device_info(int device, char *name, size_t name_len, int *cu_count, int *clock_khz,
+                      uint64_t *hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QDAS_H */

@@ -1,0 +1,10 @@
+"""qups_amd -- MI355X-native delay-and-sum beamforming engine.
+
+A from-scratch drop-in for ONE hot path of thorstone25/qups: ``UltrasoundSystem.DAS`` /
+``bfDAS`` -> ``das_spec`` -> the ``DAS*`` device kernels.
+The compute lives in ``libqdas.so`` (hand-written HIP for gfx950, C ABI in ``include/qdas.h``);
+this package is the host-side mirror of the reference's interface for that path.
+"""
+from .das_spec import DasError, DasPlan, DasProblem, build_problem, das_spec, parse_options  # noqa: F401
+
+__all__ = ["das_spec", "DasPlan", "DasProblem", "DasError", "build_problem", "parse_options"]

@@ -1,0 +1,486 @@
+// qdas_api.hip -- C ABI of libqdas.so (see include/qdas.h for the contract and the reference
+// call sites each entry replaces).  Host-side only: validation, plan construction (device
+// copies of geometry, folded apodization table, stride tables), kernel selection and launch.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/qdas.h"
+#include "qdas_kernels.h"
+
+using namespace qdas;
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) return fail(QDAS_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char *qdas_last_error(void) { return g_err.c_str(); }
+extern "C" int qdas_version(void) { return QDAS_VERSION; }
+
+extern "C" int qdas_device_info(int device, char *name, size_t name_len, int *cu_count, int *clock_khz,
+                                uint64_t *hbm_bytes) {
+    if (device < 0) HIPCHK(hipGetDevice(&device));
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, device));
+    if (name && name_len) { snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName); }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (clock_khz) *clock_khz = p.clockRate;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)p.totalGlobalMem;
+    return QDAS_OK;
+}
+
+// ------------------------------------------------------------------------------------ plan
+static size_t real_size(int dtype) { return dtype == QDAS_F64 ? 8 : 4; }            // geometry / time type
+static size_t data_size(int dtype) { return dtype == QDAS_F64 ? 16 : (dtype == QDAS_F32 ? 8 : 4); }  // complex sample
+static size_t apod_real_size(int dtype) { return dtype == QDAS_F64 ? 8 : (dtype == QDAS_F32 ? 4 : 2); }
+
+struct qdas_plan {
+    qdas_desc d{};
+    uint64_t I = 0, i_count = 0, y_ld = 0, oN = 1, oM = 1;
+    int device = 0;
+    int kernel = QDAS_KERNEL_GENERIC;
+    std::vector<void *> owned;                // device allocations made by the plan
+    GenericParams gp{};
+    TileParams tp{};
+    TileConfig tc{};
+    unsigned ntiles = 0;
+    uint32_t *fallback = nullptr;             // device: [0] = count, [1..ntiles]
+    bool timing = false;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float last_ms = 0.f;
+    // host staging (mem == HOST)
+    void *dx = nullptr, *dy = nullptr;
+    size_t x_bytes = 0, y_bytes = 0;
+
+    ~qdas_plan() {
+        for (void *p : owned) (void)hipFree(p);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+
+static int dev_alloc(qdas_plan *pl, void **out, size_t bytes) {
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(QDAS_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    pl->owned.push_back(p);
+    *out = p;
+    return QDAS_OK;
+}
+
+// device copy of a caller array (host -> new device buffer; device -> used in place)
+static int import_array(qdas_plan *pl, const void *src, size_t bytes, int mem, const void **out) {
+    if (mem == QDAS_MEM_DEVICE || bytes == 0) { *out = src; return QDAS_OK; }
+    void *p;
+    int rc = dev_alloc(pl, &p, bytes);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    *out = p;
+    return QDAS_OK;
+}
+
+// host copy of (part of) a caller array
+static int fetch_host(const void *src, size_t bytes, int mem, void *dst) {
+    if (mem == QDAS_MEM_DEVICE) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    else memcpy(dst, src, bytes);
+    return QDAS_OK;
+}
+
+static float half_to_float(uint16_t h) {
+    const uint32_t s = (h >> 15) & 1, e = (h >> 10) & 31, m = h & 1023;
+    float v;
+    if (e == 0) v = std::ldexp((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = std::ldexp((float)(m + 1024), (int)e - 25);
+    return s ? -v : v;
+}
+
+static int validate(const qdas_desc *d) {
+    const qdas_sizes &z = d->sz;
+    if (z.dtype < QDAS_F64 || z.dtype > QDAS_F16) return fail(QDAS_EINVAL, "Unrecognized input precision %d", z.dtype);
+    const int interp = z.flag & QDAS_FLAG_INTERP_MASK;
+    if (interp > 5) return fail(QDAS_EINVAL, "QUPS:das_spec:UnrecognizedInput: Unrecognized interpolation flag %d: must be one of "
+                                "{'nearest', 'linear', 'cubic', 'lanczos3'}.", interp);
+    if (z.flag & ~63) return fail(QDAS_EINVAL, "Invalid beamformer flag 0x%x.", z.flag);
+    if (z.S > QDAS_MAX_APOD) return fail(QDAS_EUNSUPPORTED, "at most %d apodization arrays are supported (got %llu)", QDAS_MAX_APOD,
+                                         (unsigned long long)z.S);
+    if (!(d->fs > 0.0) || !std::isfinite(d->fs)) return fail(QDAS_EINVAL, "Undefined sampling rate.");
+    if (!std::isfinite(d->fmod)) return fail(QDAS_EINVAL, "modulation frequency must be finite");
+    const uint64_t I = z.I1 * z.I2 * z.I3;
+    if (d->i_begin > I || (d->i_count && d->i_begin + d->i_count > I))
+        return fail(QDAS_EINVAL, "pixel shard [%llu, +%llu) exceeds the image (%llu pixels)", (unsigned long long)d->i_begin,
+                    (unsigned long long)d->i_count, (unsigned long long)I);
+    if (I && z.N && z.M) {
+        if (!d->Pi || !d->Pr || !d->Pv || !d->Nv || !d->cinv || !d->acstride) return fail(QDAS_EINVAL, "null geometry / stride pointer");
+        if (z.S && !d->apod) return fail(QDAS_EINVAL, "S > 0 but apod is null");
+    }
+    if (d->mem != QDAS_MEM_HOST && d->mem != QDAS_MEM_DEVICE) return fail(QDAS_EINVAL, "bad mem kind %d", d->mem);
+    if (z.T > 0x7fffffffull) return fail(QDAS_EUNSUPPORTED, "T must be < 2^31");
+    return QDAS_OK;
+}
+
+// size (elements) of a broadcastable I1xI2xI3xNxM array from its stride row
+static uint64_t bcast_numel(const uint64_t *st, const qdas_sizes &z) {
+    const uint64_t dims[5] = {z.I1, z.I2, z.I3, z.N, z.M};
+    uint64_t n = 1;
+    for (int k = 0; k < 5; ++k) if (st[k]) n += (dims[k] - 1) * st[k];
+    return n;
+}
+
+extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
+    if (!out || !desc) return fail(QDAS_EINVAL, "null argument");
+    *out = nullptr;
+    int rc = validate(desc);
+    if (rc) return rc;
+    qdas_plan *pl = new qdas_plan();
+    pl->d = *desc;
+    const qdas_sizes &z = pl->d.sz;
+    const int dt = z.dtype;
+    pl->I = z.I1 * z.I2 * z.I3;
+    pl->i_count = desc->i_count ? desc->i_count : pl->I - desc->i_begin;
+    pl->y_ld = desc->y_ld ? desc->y_ld : pl->i_count;
+    pl->oN = (z.flag & QDAS_FLAG_KEEP_RX) ? z.N : 1;
+    pl->oM = (z.flag & QDAS_FLAG_KEEP_TX) ? z.M : 1;
+    if (pl->y_ld < pl->i_count) { delete pl; return fail(QDAS_EINVAL, "y_ld smaller than the pixel count"); }
+
+    auto bail = [&](int code) { delete pl; return code; };
+    if (desc->device >= 0) { hipError_t e = hipSetDevice(desc->device); if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipSetDevice(%d): %s", desc->device, hipGetErrorString(e))); }
+    { hipError_t e = hipGetDevice(&pl->device); if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipGetDevice: %s", hipGetErrorString(e))); }
+
+    if (pl->I == 0 || z.N == 0 || z.M == 0) { *out = pl; return QDAS_OK; }   // empty problem: execute() just zero-fills
+
+    // ---- stride tables (host pointer, reference kern/das_spec.m:257-260)
+    GenericParams &g = pl->gp;
+    memcpy(g.cst, desc->acstride, sizeof g.cst);
+    memset(g.ast, 0, sizeof g.ast);
+    memcpy(g.ast, desc->acstride + 6, sizeof(uint64_t) * 6 * z.S);
+
+    // ---- device copies of the constant inputs
+    const size_t rs = real_size(dt);
+    uint64_t apod_elems = 0;
+    for (uint64_t s = 0; s < z.S; ++s) {
+        const uint64_t end = g.ast[6 * s + 5] + bcast_numel(&g.ast[6 * s], z);
+        if (end > apod_elems) apod_elems = end;
+    }
+    const size_t ael = desc->apod_real ? apod_real_size(dt) : data_size(dt);
+    const uint64_t cinv_elems = bcast_numel(g.cst, z);
+    if ((rc = import_array(pl, desc->Pi, 3 * pl->I * rs, desc->mem, &g.Pi))) return bail(rc);
+    if ((rc = import_array(pl, desc->Pr, 3 * z.N * rs, desc->mem, &g.Pr))) return bail(rc);
+    if ((rc = import_array(pl, desc->Pv, 4 * z.M * rs, desc->mem, &g.Pv))) return bail(rc);
+    if ((rc = import_array(pl, desc->Nv, 3 * z.M * rs, desc->mem, &g.Nv))) return bail(rc);
+    if ((rc = import_array(pl, desc->cinv, cinv_elems * rs, desc->mem, &g.cinv))) return bail(rc);
+    if ((rc = import_array(pl, desc->apod, apod_elems * ael, desc->mem, &g.apod))) return bail(rc);
+    g.T = z.T; g.N = z.N; g.M = z.M; g.I1 = z.I1; g.I2 = z.I2; g.I3 = z.I3;
+    g.i_begin = desc->i_begin; g.i_count = pl->i_count; g.y_ld = pl->y_ld;
+    // the reference passes [fs, fmod] in the kernel's real type (src/bf.cu:57-58)
+    g.fs = dt == QDAS_F64 ? desc->fs : (double)(float)desc->fs;
+    g.fmod = dt == QDAS_F64 ? desc->fmod : (double)(float)desc->fmod;
+    g.S = (int32_t)z.S; g.flag = z.flag; g.VS = z.VS; g.DV = z.DV; g.apod_real = desc->apod_real;
+    g.tile_list = nullptr; g.blocks_per_tile = 0; g.tile_cols = 0; g.tiles_z = 0;
+
+    // ---- kernel selection
+    bool eligible = (dt == QDAS_F32 || dt == QDAS_F16) && !(z.flag & (QDAS_FLAG_KEEP_RX | QDAS_FLAG_KEEP_TX));
+    const char *why = "tiled kernel needs fp32/fp16 data and the 'DAS' (sum both apertures) mode";
+    for (int k = 0; k < 5 && eligible; ++k) if (g.cst[k]) { eligible = false; why = "tiled kernel needs a scalar sound speed"; }
+    for (uint64_t s = 0; s < z.S && eligible; ++s)
+        for (int k = 0; k < 3; ++k) if (g.ast[6 * s + k]) { eligible = false; why = "tiled kernel needs pixel-independent apodization"; }
+    pl->tc = tile_config(dt, z.flag & 7);
+    const size_t MX = z.M > z.N ? z.M : z.N;
+    if (eligible && ((z.M + z.N) * 8 + 16 + (pl->tc.lds_bytes > 32 * MX ? pl->tc.lds_bytes : 32 * MX) > 160 * 1024)) {
+        eligible = false; why = "tiled kernel: N + M too large for the LDS header";
+    }
+    if (eligible && (z.T < 8)) { eligible = false; why = "tiled kernel needs T >= 8"; }
+    if (desc->kernel == QDAS_KERNEL_TILED && !eligible) return bail(fail(QDAS_EUNSUPPORTED, "%s", why));
+    pl->kernel = (eligible && desc->kernel != QDAS_KERNEL_GENERIC) ? QDAS_KERNEL_TILED : QDAS_KERNEL_GENERIC;
+
+    if (pl->kernel == QDAS_KERNEL_TILED) {
+        TileParams &t = pl->tp;
+        t.Pi = (const float *)g.Pi; t.Pr = (const float *)g.Pr; t.Pv = (const float *)g.Pv; t.Nv = (const float *)g.Nv;
+        t.T = z.T; t.N = z.N; t.M = z.M; t.I1 = z.I1; t.I2 = z.I2; t.I3 = z.I3;
+        t.i_begin = desc->i_begin; t.i_count = pl->i_count;
+        const bool tp = z.flag & QDAS_FLAG_TPOSE;
+        t.strN = tp ? z.T * z.M : z.T;                  // reference src/bf.cu:100
+        t.strM = tp ? z.T : z.T * z.N;
+        float cinv0;
+        if ((rc = fetch_host(desc->cinv, sizeof(float), desc->mem, &cinv0))) return bail(rc);
+        t.fs = g.fs; t.fmod = g.fmod;
+        t.cinv_fs = (double)cinv0 * g.fs;
+        t.flag = z.flag; t.VS = z.VS; t.DV = z.DV;
+        // tile grid: 64 pixels of I1 x tile_cols columns (columns = I2*I3 flattened)
+        const uint64_t ncols = z.I2 * z.I3;
+        const uint64_t col0 = desc->i_begin / z.I1, col1 = (desc->i_begin + pl->i_count - 1) / z.I1;
+        t.tiles_z = (uint32_t)((z.I1 + 63) / 64);
+        t.tile_x0 = (uint32_t)(col0 / pl->tc.tile_cols);
+        t.tiles_x = (uint32_t)(col1 / pl->tc.tile_cols) - t.tile_x0 + 1;
+        (void)ncols;
+        pl->ntiles = t.tiles_z * t.tiles_x;
+        void *fb;
+        if ((rc = dev_alloc(pl, &fb, sizeof(uint32_t) * (pl->ntiles + 1)))) return bail(rc);
+        pl->fallback = (uint32_t *)fb;
+        t.fallback_list = pl->fallback; t.fallback_cap = pl->ntiles;
+        // fold the (pixel-independent) apodization stack into one N x M complex64 table
+        t.wtab = nullptr;
+        if (z.S) {
+            std::vector<float> tab(2 * z.N * z.M);
+            for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.f; tab[2 * k + 1] = 0.f; }
+            for (uint64_t s = 0; s < z.S; ++s) {
+                const uint64_t *st = &g.ast[6 * s];
+                const uint64_t nel = bcast_numel(st, z);
+                std::vector<unsigned char> raw(nel * ael);
+                if ((rc = fetch_host((const unsigned char *)desc->apod + st[5] * ael, nel * ael, desc->mem, raw.data()))) return bail(rc);
+                for (uint64_t m = 0; m < z.M; ++m)
+                    for (uint64_t n = 0; n < z.N; ++n) {
+                        const uint64_t k = n * st[3] + m * st[4];
+                        float ar, ai = 0.f;
+                        if (desc->apod_real) ar = dt == QDAS_F32 ? ((const float *)raw.data())[k] : half_to_float(((const uint16_t *)raw.data())[k]);
+                        else if (dt == QDAS_F32) { ar = ((const float *)raw.data())[2 * k]; ai = ((const float *)raw.data())[2 * k + 1]; }
+                        else { ar = half_to_float(((const uint16_t *)raw.data())[2 * k]); ai = half_to_float(((const uint16_t *)raw.data())[2 * k + 1]); }
+                        float &tr = tab[2 * (n + z.N * m)], &ti = tab[2 * (n + z.N * m) + 1];
+                        const float nr = tr * ar - ti * ai, ni = tr * ai + ti * ar;
+                        tr = nr; ti = ni;
+                    }
+            }
+            void *dtab;
+            if ((rc = dev_alloc(pl, &dtab, tab.size() * sizeof(float)))) return bail(rc);
+            hipError_t e = hipMemcpy(dtab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e)));
+            t.wtab = dtab;
+        }
+    }
+
+    if (desc->mem == QDAS_MEM_HOST) {                   // staging buffers for x / y
+        pl->x_bytes = (size_t)z.T * z.N * z.M * data_size(dt);
+        pl->y_bytes = (size_t)pl->y_ld * pl->oN * pl->oM * data_size(dt);
+        if ((rc = dev_alloc(pl, &pl->dx, pl->x_bytes))) return bail(rc);
+        if ((rc = dev_alloc(pl, &pl->dy, pl->y_bytes))) return bail(rc);
+    }
+    *out = pl;
+    return QDAS_OK;
+}
+
+extern "C" void qdas_plan_destroy(qdas_plan *pl) {
+    if (!pl) return;
+    (void)hipSetDevice(pl->device);
+    delete pl;
+}
+
+extern "C" int qdas_plan_kernel(const qdas_plan *pl) { return pl ? pl->kernel : 0; }
+
+extern "C" int qdas_plan_fallback_tiles(const qdas_plan *pl, uint64_t *n) {
+    if (!pl || !n) return fail(QDAS_EINVAL, "null argument");
+    *n = 0;
+    if (pl->kernel != QDAS_KERNEL_TILED || !pl->fallback) return QDAS_OK;
+    uint32_t c = 0;
+    HIPCHK(hipMemcpy(&c, pl->fallback, sizeof c, hipMemcpyDeviceToHost));
+    *n = c;
+    return QDAS_OK;
+}
+
+extern "C" int qdas_plan_set_timing(qdas_plan *pl, int enable) {
+    if (!pl) return fail(QDAS_EINVAL, "null plan");
+    pl->timing = enable != 0;
+    if (pl->timing && !pl->e0) { HIPCHK(hipEventCreate(&pl->e0)); HIPCHK(hipEventCreate(&pl->e1)); }
+    return QDAS_OK;
+}
+
+extern "C" int qdas_plan_last_kernel_ms(const qdas_plan *pl, float *ms) {
+    if (!pl || !ms) return fail(QDAS_EINVAL, "null argument");
+    *ms = pl->last_ms;
+    return QDAS_OK;
+}
+
+static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s) {
+    const qdas_sizes &z = pl->d.sz;
+    if (pl->kernel == QDAS_KERNEL_TILED) {
+        TileParams t = pl->tp;
+        t.x = x; t.y = y;
+        HIPCHK(hipMemsetAsync(pl->fallback, 0, sizeof(uint32_t), s));
+        HIPCHK(launch_tile(t, z.dtype, pl->ntiles, s));
+        // tiles whose delay window overflowed LDS are redone by the generic kernel; the launch is
+        // sized for the worst case and exits immediately for ids >= the device-side count
+        GenericParams g = pl->gp;
+        g.x = x; g.y = y; g.y_ld = pl->y_ld;
+        g.tile_list = pl->fallback;
+        g.tile_cols = pl->tc.tile_cols;
+        g.blocks_per_tile = (64 * pl->tc.tile_cols + 255) / 256;
+        g.tiles_z = pl->tp.tiles_z;
+        HIPCHK(launch_generic(g, z.dtype, pl->ntiles * g.blocks_per_tile, s));
+    } else {
+        GenericParams g = pl->gp;
+        g.x = x; g.y = y;
+        HIPCHK(launch_generic(g, z.dtype, (unsigned)((pl->i_count + 255) / 256), s));
+    }
+    return QDAS_OK;
+}
+
+extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, uint64_t F, uint64_t x_stride,
+                                        uint64_t y_stride, void *stream) {
+    if (!pl) return fail(QDAS_EINVAL, "null plan");
+    if (F == 0) return QDAS_OK;
+    if (!y) return fail(QDAS_EINVAL, "null output");
+    const qdas_sizes &z = pl->d.sz;
+    const size_t ds = data_size(z.dtype);
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(pl->device));
+    const size_t ybytes = (size_t)pl->y_ld * pl->oN * pl->oM * ds;
+    if (pl->I == 0 || z.N == 0 || z.M == 0 || pl->i_count == 0 || z.T == 0) {      // empty sum: zeros
+        for (uint64_t f = 0; f < F && ybytes; ++f) {
+            char *yf = (char *)y + f * y_stride * ds;
+            if (pl->d.mem == QDAS_MEM_HOST) memset(yf, 0, ybytes);
+            else HIPCHK(hipMemsetAsync(yf, 0, ybytes, s));
+        }
+        return QDAS_OK;
+    }
+    if (!x) return fail(QDAS_EINVAL, "null data");
+    if (pl->timing) HIPCHK(hipEventRecord(pl->e0, s));
+    for (uint64_t f = 0; f < F; ++f) {
+        const char *xf = (const char *)x + f * x_stride * ds;
+        char *yf = (char *)y + f * y_stride * ds;
+        if (pl->d.mem == QDAS_MEM_HOST) {
+            HIPCHK(hipMemcpyAsync(pl->dx, xf, pl->x_bytes, hipMemcpyHostToDevice, s));
+            int rc = run_frame(pl, pl->dx, pl->dy, s);
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(yf, pl->dy, pl->y_bytes, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        } else {
+            int rc = run_frame(pl, xf, yf, s);
+            if (rc) return rc;
+        }
+    }
+    if (pl->timing) {
+        HIPCHK(hipEventRecord(pl->e1, s));
+        HIPCHK(hipEventSynchronize(pl->e1));
+        HIPCHK(hipEventElapsedTime(&pl->last_ms, pl->e0, pl->e1));
+    }
+    return QDAS_OK;
+}
+
+extern "C" int qdas_plan_execute(qdas_plan *pl, const void *x, void *y, void *stream) {
+    return qdas_plan_execute_frames(pl, x, y, 1, 0, 0, stream);
+}
+
+extern "C" int qdas_plan_delays(qdas_plan *pl, void *tau, void *stream) {
+    if (!pl || !tau) return fail(QDAS_EINVAL, "null argument");
+    const qdas_sizes &z = pl->d.sz;
+    if (pl->I == 0 || z.N == 0 || z.M == 0 || pl->i_count == 0) return QDAS_OK;
+    HIPCHK(hipSetDevice(pl->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rs = real_size(z.dtype);
+    double cinv;
+    if (z.dtype == QDAS_F64) { int rc = fetch_host(pl->d.cinv, 8, pl->d.mem, &cinv); if (rc) return rc; }
+    else { float c; int rc = fetch_host(pl->d.cinv, 4, pl->d.mem, &c); if (rc) return rc; cinv = c; }
+    GenericParams g = pl->gp;
+    g.y_ld = pl->i_count;
+    const size_t bytes = (size_t)pl->i_count * z.N * z.M * rs;
+    if (pl->d.mem == QDAS_MEM_HOST) {
+        void *dt;
+        HIPCHK(hipMalloc(&dt, bytes));
+        hipError_t e = launch_delays(g, z.dtype == QDAS_F64 ? 0 : 1, dt, cinv, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(tau, dt, bytes, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(dt);
+        if (e != hipSuccess) return fail(QDAS_EHIP, "delays: %s", hipGetErrorString(e));
+    } else {
+        HIPCHK(launch_delays(g, z.dtype == QDAS_F64 ? 0 : 1, tau, cinv, s));
+    }
+    return QDAS_OK;
+}
+
+// ------------------------------------------------------------------------------------ one-shot entries
+static int one_shot(const qdas_sizes *sz, int dtype, void *y, const void *Pi, const void *Pr, const void *Pv, const void *Nv,
+                    const void *a, const void *cinv, const uint64_t *acs, const void *x, double fs, double fmod, void *stream) {
+    if (!sz) return fail(QDAS_EINVAL, "null sizes");
+    qdas_desc d{};
+    d.sz = *sz;
+    d.sz.dtype = dtype;
+    d.fs = fs; d.fmod = fmod;
+    d.Pi = Pi; d.Pr = Pr; d.Pv = Pv; d.Nv = Nv; d.apod = a; d.cinv = cinv; d.acstride = acs;
+    d.mem = QDAS_MEM_DEVICE; d.device = -1; d.kernel = QDAS_KERNEL_AUTO;
+    qdas_plan *pl = nullptr;
+    int rc = qdas_plan_create(&pl, &d);
+    if (rc) return rc;
+    rc = qdas_plan_execute(pl, x, y, stream);
+    if (!rc) { hipError_t e = hipStreamSynchronize((hipStream_t)stream); if (e != hipSuccess) rc = fail(QDAS_EHIP, "sync: %s", hipGetErrorString(e)); }
+    qdas_plan_destroy(pl);
+    return rc;
+}
+
+extern "C" int qdas_DAS(const qdas_sizes *sz, void *y, const double *Pi, const double *Pr, const double *Pv, const double *Nv,
+                        const void *a, const double *cinv, const uint64_t *acs, const void *x, const double tv[2], void *stream) {
+    if (!tv) return fail(QDAS_EINVAL, "null tvars");
+    return one_shot(sz, QDAS_F64, y, Pi, Pr, Pv, Nv, a, cinv, acs, x, tv[0], tv[1], stream);
+}
+extern "C" int qdas_DASf(const qdas_sizes *sz, void *y, const float *Pi, const float *Pr, const float *Pv, const float *Nv,
+                         const void *a, const float *cinv, const uint64_t *acs, const void *x, const float tv[2], void *stream) {
+    if (!tv) return fail(QDAS_EINVAL, "null tvars");
+    return one_shot(sz, QDAS_F32, y, Pi, Pr, Pv, Nv, a, cinv, acs, x, tv[0], tv[1], stream);
+}
+extern "C" int qdas_DASh(const qdas_sizes *sz, void *y, const float *Pi, const float *Pr, const float *Pv, const float *Nv,
+                         const void *a, const float *cinv, const uint64_t *acs, const void *x, const float tv[2], void *stream) {
+    if (!tv) return fail(QDAS_EINVAL, "null tvars");
+    return one_shot(sz, QDAS_F16, y, Pi, Pr, Pv, Nv, a, cinv, acs, x, tv[0], tv[1], stream);
+}
+
+static int delays_one_shot(const qdas_sizes *sz, int dtype, void *tau, const void *Pi, const void *Pr, const void *Pv,
+                           const void *Nv, double cinv, void *stream) {
+    if (!sz || !tau) return fail(QDAS_EINVAL, "null argument");
+    GenericParams g{};
+    g.Pi = Pi; g.Pr = Pr; g.Pv = Pv; g.Nv = Nv;
+    g.N = sz->N; g.M = sz->M; g.I1 = sz->I1; g.I2 = sz->I2; g.I3 = sz->I3;
+    g.i_begin = 0; g.i_count = sz->I1 * sz->I2 * sz->I3; g.y_ld = g.i_count;
+    g.VS = sz->VS; g.DV = sz->DV;
+    if (g.i_count == 0 || g.N == 0 || g.M == 0) return QDAS_OK;
+    if (!Pi || !Pr || !Pv || !Nv) return fail(QDAS_EINVAL, "null geometry pointer");
+    HIPCHK(launch_delays(g, dtype, tau, cinv, (hipStream_t)stream));
+    return QDAS_OK;
+}
+extern "C" int qdas_delays(const qdas_sizes *sz, double *tau, const double *Pi, const double *Pr, const double *Pv,
+                           const double *Nv, double cinv, void *stream) {
+    return delays_one_shot(sz, 0, tau, Pi, Pr, Pv, Nv, cinv, stream);
+}
+extern "C" int qdas_delaysf(const qdas_sizes *sz, float *tau, const float *Pi, const float *Pr, const float *Pv,
+                            const float *Nv, float cinv, void *stream) {
+    return delays_one_shot(sz, 1, tau, Pi, Pr, Pv, Nv, cinv, stream);
+}
+
+// ------------------------------------------------------------------------------------ split-delay flavour
+extern "C" int qdas_das_lut(const qdas_lut_desc *d, const void *x, void *y, void *stream) {
+    if (!d || !y) return fail(QDAS_EINVAL, "null argument");
+    if (d->dtype < QDAS_F64 || d->dtype > QDAS_F16) return fail(QDAS_EINVAL, "Unrecognized input precision %d", d->dtype);
+    if ((d->flag & 7) > 5) return fail(QDAS_EINVAL, "Interp option not recognized: %d", d->flag & 7);
+    const uint64_t oN = (d->flag & QDAS_FLAG_KEEP_RX) ? d->N : 1, oM = (d->flag & QDAS_FLAG_KEEP_TX) ? d->M : 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->I == 0) return QDAS_OK;
+    if (d->N == 0 || d->M == 0 || d->T == 0) {
+        HIPCHK(hipMemsetAsync(y, 0, d->I * oN * oM * data_size(d->dtype), s));
+        return QDAS_OK;
+    }
+    if (!x || !d->tau_rx || !d->tau_tx) return fail(QDAS_EINVAL, "null data / delay table");
+    LutParams p{};
+    p.tau_rx = d->tau_rx; p.tau_tx = d->tau_tx; p.w = d->w; p.x = x; p.y = y;
+    p.T = d->T; p.N = d->N; p.M = d->M; p.I = d->I;
+    p.wst[0] = d->wstride[0]; p.wst[1] = d->wstride[1]; p.wst[2] = d->wstride[2];
+    p.omega = d->omega; p.flag = d->flag; p.w_real = d->w_real;
+    HIPCHK(launch_lut(p, d->dtype, s));
+    return QDAS_OK;
+}

@@ -1,0 +1,63 @@
+// qdas_kernels.h -- host<->kernel parameter blocks and launchers (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define QDAS_MAX_APOD 6
+
+namespace qdas {
+
+// Parameter block of the generic kernel == the reference kernel's argument list
+// (reference src/bf.cu:50-54) plus the size constants (src/sizes.cu) and the shard window.
+struct GenericParams {
+    const void *Pi, *Pr, *Pv, *Nv, *apod, *cinv, *x;
+    void *y;
+    uint64_t T, N, M, I1, I2, I3;
+    uint64_t i_begin, i_count, y_ld;
+    uint64_t cst[6];                    // cstride  (reference kern/das_spec.m:259)
+    uint64_t ast[6 * QDAS_MAX_APOD];    // astride  (reference kern/das_spec.m:260)
+    double fs, fmod;
+    int32_t S, flag, VS, DV, apod_real;
+    // fallback-tile mode (tile_list != nullptr): process only the listed 64 x tile_cols tiles;
+    // tile_list[0] = count, tile_list[1..] = tile ids (written by the tiled kernel)
+    const uint32_t *tile_list;
+    uint32_t blocks_per_tile, tile_cols;
+    uint64_t tiles_z;
+};
+
+hipError_t launch_generic(const GenericParams &P, int dtype, unsigned grid, hipStream_t s);
+hipError_t launch_delays(const GenericParams &P, int dtype, void *tau, double cinv, hipStream_t s);
+
+// ---- tiled kernel (das_tile.hip)
+struct TileParams {
+    const float *Pi, *Pr, *Pv, *Nv;     // fp32 geometry (QDAS_F32 / QDAS_F16 only)
+    const void *x;
+    void *y;
+    const void *wtab;                   // optional N x M table of folded apodization weights (float2), may be null
+    uint64_t T, N, M, I1, I2, I3;
+    uint64_t i_begin, i_count;
+    uint64_t strN, strM;                // trace strides of x in samples: (T, T*N) or (T*M, T) when transposed
+    double cinv_fs;                     // cinv * fs
+    double fs, fmod;
+    int32_t flag, VS, DV;
+    uint32_t tiles_z, tiles_x, tile_x0; // tile grid over (I1/64) x (columns/TX); first column tile of the shard
+    uint32_t *fallback_list;            // [0] = count, [1..] = tile ids that did not fit the LDS window
+    uint32_t fallback_cap;
+};
+
+struct TileConfig { int tile_cols; int mb; int window; size_t lds_bytes; int threads; };
+TileConfig tile_config(int dtype, int interp);
+hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s);
+
+// ---- split-delay kernel (das_lut.hip)
+struct LutParams {
+    const void *tau_rx, *tau_tx, *w, *x;
+    void *y;
+    uint64_t T, N, M, I;
+    uint64_t wst[3];
+    double omega;
+    int32_t flag, w_real;
+};
+hipError_t launch_lut(const LutParams &P, int dtype, hipStream_t s);
+
+}  // namespace qdas

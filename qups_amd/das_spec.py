@@ -1,0 +1,479 @@
+"""Host side of the delay-and-sum path: the Python mirror of the reference's ``das_spec``.
+
+``das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs, c, *options)`` has the reference's signature, option
+strings, argument meaning and error behaviour (reference ``kern/das_spec.m:1-148,563-670``); what
+differs is only what sits below it: instead of ``parallel.gpu.CUDAKernel('bf.ptx', ...)`` +
+``k.feval`` (``kern/das_spec.m:279-306,372``) the arguments are marshalled into the C-ABI of
+``libqdas.so`` (``include/qdas.h``) whose kernels are hand-written for MI355X.
+
+Array convention: arrays keep MATLAB's dimension ORDER (``x`` is ``T x N x M x F...``, ``Pi`` is
+``3 x I1 x I2 x I3``, outputs are ``I1 x I2 x I3 x [1|N] x [1|M] x F...``).  They may be numpy
+arrays or torch tensors with any strides; the column-major buffers the kernel ABI needs are
+produced here (zero-copy when the tensor already is column-major, e.g. a ``(M, N, T)`` C-contiguous
+tensor viewed as ``.permute(2, 1, 0)``).
+
+Everything up to :class:`DasProblem` is pure host logic (numpy only) and is unit-tested without
+a GPU; :class:`DasPlan` needs ``libqdas.so`` and a HIP device and fails loudly otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Any, Sequence
+
+import numpy as np
+
+from . import _lib
+
+_FUNS = ("DAS", "SYN", "MUL", "BF", "delays")
+_PREC = {"double": _lib.QDAS_F64, "single": _lib.QDAS_F32, "halfT": _lib.QDAS_F16}
+_REAL_NP = {"double": np.float64, "single": np.float32, "halfT": np.float32}
+
+
+class DasError(ValueError):
+    """Host-side argument error; ``identifier`` mirrors the MATLAB error ID where the reference has one."""
+
+    def __init__(self, msg, identifier=None):
+        super().__init__(msg)
+        self.identifier = identifier
+
+
+# ------------------------------------------------------------------------------------------
+# option parsing (reference kern/das_spec.m:90-148)
+# ------------------------------------------------------------------------------------------
+def _is_torch(a) -> bool:
+    return type(a).__module__.startswith("torch")
+
+
+def _default_prec(x) -> str:
+    """reference kern/das_spec.m:96-104: precision follows the data type, default double."""
+    dt = str(getattr(x, "dtype", "")).replace("torch.", "")
+    if dt in ("float32", "complex64"):
+        return "single"
+    if dt in ("float16", "complex32"):
+        return "halfT"
+    return "double"
+
+
+def parse_options(x, varargin: Sequence[Any]) -> dict:
+    o = dict(VS=True, DV=False, interp="linear", apod=[], prec=_default_prec(x), device=-1,
+             fmod=0.0, tpose=False)
+    n = 0
+    nargs = len(varargin)
+
+    def val():
+        nonlocal n
+        n += 1
+        if n >= nargs:
+            raise DasError("Unrecognized option")
+        return varargin[n]
+
+    while n < nargs:
+        key = varargin[n]
+        if not isinstance(key, str):
+            raise DasError("Unrecognized option")
+        if key == "plane-waves":
+            o["VS"] = False
+        elif key == "virtual-source":
+            o["VS"] = True
+        elif key == "diverging-waves":
+            o["DV"] = True
+        elif key == "focused-waves":
+            o["DV"] = False
+        elif key == "input-precision":
+            o["prec"] = str(val())
+        elif key == "device":
+            o["device"] = int(val())
+        elif key == "interp":
+            o["interp"] = str(val())
+        elif key == "apod":
+            o["apod"].append(val())
+        elif key == "modulation":
+            o["fmod"] = float(val())
+        elif key == "transpose":
+            o["tpose"] = bool(val())
+        else:
+            raise DasError("Unrecognized option")
+        n += 1
+    if o["prec"] not in _PREC:
+        raise DasError(f"Unrecognized input precision {o['prec']!r}: must be one of {sorted(_PREC)}")
+    return o
+
+
+# ------------------------------------------------------------------------------------------
+# geometry normalisation (reference kern/das_spec.m:563-670)
+# ------------------------------------------------------------------------------------------
+def _to_numpy(a, dtype=None) -> np.ndarray:
+    if _is_torch(a):
+        a = a.detach().cpu().numpy()
+    a = np.asarray(a)
+    return a.astype(dtype) if dtype is not None else a
+
+
+def _mod_size(P: np.ndarray) -> np.ndarray:
+    """coordinates into the first dimension (reference kern/das_spec.m:591-599)"""
+    if P.ndim < 2:
+        P = P.reshape(-1, 1)
+    if P.shape[0] <= 4:
+        return P
+    if P.shape[1] <= 4 and P.ndim == 2:
+        return P.T
+    import warnings
+    warnings.warn("Input data size is ambiguous.")
+    return P
+
+
+def _mod_dim(P: np.ndarray) -> np.ndarray:
+    """1D -> x, 2D -> (x,z), 4D -> xyz/w (reference kern/das_spec.m:656-669)"""
+    d = P.shape[0]
+    if d == 3:
+        return P
+    z = np.zeros((1,) + P.shape[1:], dtype=P.dtype)
+    if d == 1:
+        return np.concatenate([P, z, z], 0)
+    if d == 2:
+        return np.concatenate([P[:1], z, P[1:2]], 0)
+    if d == 4:
+        return P[:3] / P[3:4]
+    raise DasError("Improper coordinate dimension.")
+
+
+def _size5(a: np.ndarray):
+    if a.ndim > 5:
+        raise DasError("Apodization / sound speed arrays must have at most 5 dimensions (I1 x I2 x I3 x N x M).")
+    return tuple(a.shape) + (1,) * (5 - a.ndim)
+
+
+def _stride_row(shape5) -> list:
+    """element strides with 0 on singleton dims (reference kern/das_spec.m:259-260)"""
+    st, acc = [], 1
+    for s in shape5:
+        st.append(0 if s == 1 else acc)
+        acc *= s
+    return st
+
+
+@dataclass
+class DasProblem:
+    """Everything of one ``das_spec`` call except the data: the kernel ABI arguments on the host."""
+    fun: str
+    prec: str
+    flag: int
+    VS: bool
+    DV: bool
+    Isz: tuple
+    T: int
+    N: int
+    M: int
+    fsz: tuple                      # frame dims of x (dims 4+)
+    fs: float
+    fmod: float
+    Pi: np.ndarray                  # 3 x I   (column-major flat, real(prec))
+    Pr: np.ndarray                  # 3 x N
+    Pv: np.ndarray                  # 4 x M, row 4 = t0 (reference kern/das_spec.m:361)
+    Nv: np.ndarray                  # 3 x M
+    cinv: np.ndarray                # flat, real(prec)
+    apod: np.ndarray | None         # flat concatenation (reference kern/das_spec.m:344-345)
+    apod_real: bool
+    acstride: np.ndarray            # uint64, 6*(1+S)  (reference kern/das_spec.m:257-260)
+    S: int
+    tpose: bool
+    interp: str
+    osize: tuple = field(default=(1, 1))
+
+    @property
+    def I(self) -> int:
+        return int(np.prod(self.Isz))
+
+
+def build_problem(fun, Pi, Pr, Pv, Nv, xshape, t0, fs, c, opts: dict) -> DasProblem:
+    """Host marshalling of one call: reference ``kern/das_spec.m:150-170,198-213,246-269,344-361``."""
+    if fun not in _FUNS:
+        raise DasError("Invalid beamformer.")
+    prec = opts["prec"]
+    rt = _REAL_NP[prec]
+    ct = {"double": np.complex128, "single": np.complex64, "halfT": np.complex64}[prec]
+    interp = opts["interp"]
+    if interp not in _lib.INTERP_FLAGS:
+        raise DasError("Unrecognized interpolation of type " + str(interp)
+                       + ": must be one of {'nearest', 'linear', 'cubic', 'lanczos3'}.",
+                       "QUPS:das_spec:UnrecognizedInput")
+    if c is None:
+        c = 1540.0
+    if fs is None:
+        t0v = _to_numpy(t0).reshape(-1)
+        if fun == "delays":
+            fs = 1.0
+        elif t0v.size > 1:  # "find the sampling frequency" from a time axis (reference kern/das_spec.m:153-155)
+            fs = 1.0 / float(np.mean(np.diff(t0v)))
+            t0 = float(t0v.min())
+        else:
+            raise DasError("Undefined sampling rate.")
+    fs = float(_to_numpy(fs).reshape(-1)[0])
+
+    Pi = _mod_dim(_mod_size(_to_numpy(Pi, np.float64)))
+    Pr = _mod_dim(_mod_size(_to_numpy(Pr, np.float64)))
+    Pv = _mod_dim(_mod_size(_to_numpy(Pv, np.float64)))
+    Nv = _mod_dim(_mod_size(_to_numpy(Nv, np.float64)))
+    if Pi.ndim > 4:
+        raise DasError("Pixel positions must be 3 x I1 x I2 x I3.")
+    Pi = Pi.reshape(Pi.shape + (1,) * (4 - Pi.ndim))
+    Isz = tuple(int(s) for s in Pi.shape[1:4])
+    Pr, Pv, Nv = (p.reshape(3, -1) for p in (Pr, Pv, Nv))
+
+    tpose = bool(opts["tpose"])
+    if fun == "delays":
+        T = 0
+        M = max(Pv.shape[1], Nv.shape[1])
+        N = Pr.shape[1]
+        fsz = ()
+    else:
+        xs = tuple(int(s) for s in xshape) + (1,) * max(0, 3 - len(xshape))
+        T, N, M = xs[0], xs[1], xs[2]
+        if tpose:
+            M, N = N, M                                       # reference kern/das_spec.m:251
+        fsz = xs[3:]
+    Mv, Mnv, Nr = Pv.shape[1], Nv.shape[1], Pr.shape[1]
+    if Mv == 1:
+        Pv, Mv = np.repeat(Pv, M, 1), M                      # reference kern/das_spec.m:631-633
+    if Mnv == 1:
+        Nv, Mnv = np.repeat(Nv, M, 1), M
+    if Nr == 1 and fun != "delays":
+        Pr, Nr = np.repeat(Pr, N, 1), N
+    if not (Mv == Mnv and M == Mv):
+        raise DasError("Inconsistent transmitter data size.")
+    if N != Nr:
+        raise DasError("Inconsistent receiver data size.")
+
+    # sound speed and apodization: broadcastable I1 x I2 x I3 x N x M (reference kern/das_spec.m:636-641)
+    cinv = 1.0 / _to_numpy(c, np.float64)
+    cinv = cinv.reshape(_size5(cinv))
+    full = Isz + (N, M)
+    if any(s not in (1, f) for s, f in zip(cinv.shape[:3], full[:3])):
+        raise DasError("Sound speed data size inconsistent with pixel data size")
+    if cinv.shape[3] not in (1, N):
+        raise DasError("Sound speed data size inconsistent with receiver data size")
+    if cinv.shape[4] not in (1, M):
+        raise DasError("Sound speed data size inconsistent with transmit data size")
+    apods = []
+    for a in opts["apod"]:
+        a = _to_numpy(a)
+        a = a.reshape(_size5(a))
+        if any(s not in (1, f) for s, f in zip(a.shape[:3], full[:3])):
+            raise DasError("Apodization data size inconsistent with pixel data size")
+        if a.shape[3] not in (1, N):
+            raise DasError("Apodization data size inconsistent with receiver data size")
+        if a.shape[4] not in (1, M):
+            raise DasError("Apodization data size inconsistent with transmit data size")
+        if a.size == 1 and a.reshape(-1)[0] == 1:
+            continue                                          # the reference's default {1}: a no-op
+        apods.append(a)
+    if len(apods) > _lib.MAX_APOD:
+        raise DasError(f"At most {_lib.MAX_APOD} apodization arrays are supported.")
+    apod_real = all(not np.iscomplexobj(a) for a in apods)
+    table = _stride_row(cinv.shape) + [0]
+    base = 0
+    for a in apods:
+        table += _stride_row(a.shape) + [base]
+        base += a.size
+    if apods:
+        adt = rt if apod_real else ct
+        if prec == "halfT":
+            adt = np.float16 if apod_real else None
+        if adt is None:   # complex half: interleaved (re, im) float16 pairs
+            flat = np.concatenate([np.stack([a.real, a.imag], 0).reshape(2, -1, order="F").T.reshape(-1)
+                                   for a in apods]).astype(np.float16)
+        else:
+            flat = np.concatenate([a.reshape(-1, order="F") for a in apods]).astype(adt)
+    else:
+        flat = None
+
+    t0v = _to_numpy(t0, np.float64).reshape(-1) if fun != "delays" else np.zeros(1)
+    if t0v.size not in (1, M):
+        raise DasError("t0 must be a scalar or have one value per transmit.")
+    Pv4 = np.concatenate([Pv, np.broadcast_to(t0v.reshape(1, -1), (1, M))], 0)   # reference kern/das_spec.m:361
+
+    keep_rx, keep_tx = fun in ("SYN", "BF"), fun in ("MUL", "BF")
+    flag = _lib.INTERP_FLAGS[interp] + 8 * keep_rx + 16 * keep_tx + 32 * tpose     # reference kern/das_spec.m:210-213
+    osize = {"DAS": (1, 1), "SYN": (N, 1), "MUL": (1, M), "BF": (N, M), "delays": (N, M)}[fun]
+    col = lambda A: np.ascontiguousarray(A.reshape(-1, order="F").astype(rt))
+    return DasProblem(fun=fun, prec=prec, flag=int(flag), VS=bool(opts["VS"]), DV=bool(opts["DV"]), Isz=Isz,
+                      T=T, N=N, M=M, fsz=tuple(fsz), fs=fs, fmod=float(opts["fmod"]),
+                      Pi=col(Pi), Pr=col(Pr), Pv=col(Pv4), Nv=col(Nv), cinv=col(cinv),
+                      apod=flat, apod_real=apod_real, acstride=np.asarray(table, dtype=np.uint64),
+                      S=len(apods), tpose=tpose, interp=interp, osize=osize)
+
+
+# ------------------------------------------------------------------------------------------
+# device side
+# ------------------------------------------------------------------------------------------
+def _torch():
+    import torch
+    return torch
+
+
+def _colmajor(t):
+    """Tensor whose memory is the column-major image of ``t`` (zero-copy if it already is)."""
+    return t.permute(*reversed(range(t.ndim))).contiguous()
+
+
+def _data_dtype(prec):
+    torch = _torch()
+    return {"double": torch.complex128, "single": torch.complex64, "halfT": torch.complex32}[prec]
+
+
+def _cast_data(x, prec, device):
+    """channel data -> complex(prec) on the device (reference kern/das_spec.m:243: dtypefun = complex(prec(x)))"""
+    torch = _torch()
+    if not _is_torch(x):
+        x = torch.from_numpy(np.asarray(x))
+    x = x.to(device)
+    want = _data_dtype(prec)
+    if x.dtype == want:
+        return x
+    if not x.is_complex():
+        x = torch.complex(x.to(torch.float32 if prec != "double" else torch.float64),
+                          torch.zeros((), device=device, dtype=torch.float32 if prec != "double" else torch.float64).expand_as(x))
+    if prec == "halfT":
+        return torch.view_as_complex(torch.view_as_real(x.to(torch.complex64)).to(torch.float16).contiguous())
+    return x.to(want)
+
+
+class DasPlan:
+    """Reusable beamforming plan: the ``[k, PRE_ARGS, POST_ARGS]`` handle of the reference
+    (``kern/das_spec.m:72-81,387-390``).  ``plan.feval(x)`` beamforms one ``T x N x M`` frame."""
+
+    def __init__(self, prob: DasProblem, device=None, kernel: int = _lib.KERNEL_AUTO,
+                 i_begin: int = 0, i_count: int = 0):
+        torch = _torch()
+        self.lib = _lib.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("qups_amd: no HIP device visible -- the DAS path has no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.prob = prob
+        self.i_begin = int(i_begin)
+        self.i_count = int(i_count) if i_count else prob.I - int(i_begin)
+        dev = self.device
+        up = lambda a: torch.from_numpy(a).to(dev) if a is not None else None
+        self._bufs = [up(prob.Pi), up(prob.Pr), up(prob.Pv), up(prob.Nv), up(prob.cinv),
+                      up(prob.apod.view(np.uint16) if (prob.apod is not None and prob.apod.dtype == np.float16) else prob.apod)]
+        self._acs = (C.c_uint64 * len(prob.acstride))(*[int(v) for v in prob.acstride])
+        d = _lib.Desc()
+        d.sz = _lib.Sizes(prob.T, prob.N, prob.M, prob.Isz[0], prob.Isz[1], prob.Isz[2], prob.S, prob.flag,
+                          int(prob.VS), int(prob.DV), _PREC[prob.prec])
+        d.fs, d.fmod = prob.fs, prob.fmod
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        d.Pi, d.Pr, d.Pv, d.Nv, d.cinv, d.apod = (ptr(self._bufs[0]), ptr(self._bufs[1]), ptr(self._bufs[2]),
+                                                   ptr(self._bufs[3]), ptr(self._bufs[4]), ptr(self._bufs[5]))
+        d.acstride = self._acs
+        d.mem, d.apod_real, d.kernel = _lib.MEM_DEVICE, int(prob.apod_real), int(kernel)
+        d.device = dev.index if dev.index is not None else torch.cuda.current_device()
+        d.i_begin, d.i_count, d.y_ld = self.i_begin, self.i_count, 0
+        self._desc = d
+        self._h = C.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.qdas_plan_create(C.byref(self._h), C.byref(d)))
+
+    # -- introspection
+    @property
+    def kernel(self) -> str:
+        return _lib.KERNEL_NAMES.get(self.lib.qdas_plan_kernel(self._h), "?")
+
+    def fallback_tiles(self) -> int:
+        n = C.c_uint64()
+        _lib.check(self.lib.qdas_plan_fallback_tiles(self._h, C.byref(n)))
+        return int(n.value)
+
+    def set_timing(self, on: bool = True):
+        _lib.check(self.lib.qdas_plan_set_timing(self._h, int(on)))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _lib.check(self.lib.qdas_plan_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    # -- execution
+    def _stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def execute_colmajor(self, xc, F: int = 1):
+        """``xc``: column-major channel data, i.e. a contiguous tensor shaped ``(F.., M, N, T)`` (or
+        ``(F.., N, M, T)`` when transposed) of complex(prec).  Returns ``(F, oM, oN, i_count)``."""
+        torch = _torch()
+        p = self.prob
+        oN, oM = p.osize
+        y = torch.empty((F, oM, oN, self.i_count), dtype=_data_dtype(p.prec), device=self.device)
+        per = p.T * p.N * p.M
+        if xc.numel() != F * per or not xc.is_contiguous():
+            raise DasError("channel data size does not match the plan")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.qdas_plan_execute_frames(self._h, C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                         F, per, oM * oN * self.i_count, self._stream()))
+        return y
+
+    def feval(self, x):
+        """One frame ``x`` (``T x N x M``, MATLAB order) -> ``I x [1|N] x [1|M]`` like ``k.feval`` at
+        reference ``kern/das_spec.m:372``."""
+        xc = _colmajor(_cast_data(x, self.prob.prec, self.device))
+        y = self.execute_colmajor(xc.reshape(1, *xc.shape[-3:]) if xc.ndim >= 3 else xc, 1)
+        return y[0].permute(2, 1, 0)
+
+    def delays(self):
+        torch = _torch()
+        p = self.prob
+        rt = torch.float64 if p.prec == "double" else torch.float32
+        tau = torch.empty((p.M, p.N, self.i_count), dtype=rt, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.qdas_plan_delays(self._h, C.c_void_p(tau.data_ptr()), self._stream()))
+        return tau.permute(2, 1, 0)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.qdas_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs=None, c=None, *varargin, return_plan=False,
+             kernel: int = _lib.KERNEL_AUTO):
+    """``y = das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs, c, ...)`` -- see reference ``kern/das_spec.m:1-87``.
+
+    ``fun`` in ``{'DAS','SYN','MUL','BF','delays'}``; options (strings, as in the reference):
+    ``'plane-waves' | 'virtual-source' | 'diverging-waves' | 'focused-waves'``,
+    ``'input-precision', {'double','single','halfT'}``, ``'device', id``, ``'interp', method``,
+    ``'apod', A`` (repeatable), ``'modulation', fmod``, ``'transpose', tf``.
+
+    Returns ``y`` (``I1 x I2 x I3 x [1|N] x [1|M] x F...``, torch tensor on the device); with
+    ``return_plan=True`` also the reusable :class:`DasPlan` (the reference's 2nd-4th outputs).
+    ``'device', 0`` asks the reference for its native-MATLAB CPU branch; this package IS the
+    device path and raises instead of silently computing on the host.
+    """
+    opts = parse_options(x, varargin)
+    if opts["device"] == 0:
+        raise NotImplementedError("das_spec(..., 'device', 0): qups_amd implements the device path only "
+                                  "(no CPU fallback by design)")
+    torch = _torch()
+    xshape = tuple(x.shape) if fun != "delays" else ()
+    prob = build_problem(fun, Pi, Pr, Pv, Nv, xshape, t0, fs, c, opts)
+    device = None if opts["device"] in (-1, None) else f"cuda:{opts['device'] - 1}"   # MATLAB device ids are 1-based
+    plan = DasPlan(prob, device=device, kernel=kernel)
+    Isz = prob.Isz
+    rev = lambda t: t.permute(*reversed(range(t.ndim)))
+    if fun == "delays":
+        tau = rev(plan.delays()).contiguous()           # (M, N, I) column-major parent
+        y = rev(tau.reshape(prob.M, prob.N, Isz[2], Isz[1], Isz[0]))
+        return (y, plan) if return_plan else y
+    xd = _cast_data(x, prob.prec, plan.device)
+    while xd.ndim < 3:
+        xd = xd.unsqueeze(-1)
+    F = int(np.prod(prob.fsz)) if prob.fsz else 1
+    xc = _colmajor(xd)                                  # (F.., M, N, T): MATLAB memory order
+    yc = plan.execute_colmajor(xc, F)                   # (F, oM, oN, I)
+    oN, oM = prob.osize
+    y = rev(yc.reshape(tuple(reversed(prob.fsz)) + (oM, oN, Isz[2], Isz[1], Isz[0])))
+    return (y, plan) if return_plan else y              # I1 x I2 x I3 x [1|N] x [1|M] x F...

@@ -1,0 +1,308 @@
+"""GPU parity tests: the HIP path (through the C ABI of libqdas.so) against the float64 oracle on
+identical float32 inputs.  Stated tolerances:
+
+    fp32 data:  max|b - b_ref| / max|b_ref| <= 1e-4      (generic kernel: the reference's own fp32 time
+                                                          arithmetic; tiled kernel is ~10x tighter)
+    fp16 data:  <= 2e-3 against the oracle fed with the SAME half-rounded data (fp32 accumulation)
+    fp64 data:  <= 1e-10
+"""
+import numpy as np
+import pytest
+
+from tests.cases import cinv_f32, make_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-4
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def run_das(case, fun="DAS", kernel=0, prec="single", apod=(), fmod=0.0, tpose=False, c=None, x=None, t0=None):
+    torch = _torch()
+    from qups_amd import das_spec
+    x = case["x"] if x is None else x
+    xs = np.swapaxes(x, 1, 2) if tpose else x
+    opts = list(case["opt"]) + ["interp", case["interp"], "input-precision", prec, "modulation", fmod, "transpose", tpose]
+    for a in apod:
+        opts += ["apod", a]
+    y, plan = das_spec(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], torch.from_numpy(np.ascontiguousarray(xs)),
+                       case["t0"] if t0 is None else t0, case["fs"], case["c"] if c is None else c, *opts,
+                       return_plan=True, kernel=kernel)
+    torch.cuda.synchronize()
+    out = y.to(torch.complex128 if prec == "double" else torch.complex64).cpu().numpy()
+    return out, plan
+
+
+def run_oracle(case, fun="DAS", apod=(), fmod=0.0, c=None, x=None, t0=None, interp=None):
+    from oracle import das_oracle as O
+    c = case["c"] if c is None else c
+    return O.das_spec(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"] if x is None else x,
+                      case["t0"] if t0 is None else t0, case["fs"], cinv_f32(c) if np.isscalar(c) else c,
+                      VS=case["VS"], DV=case["DV"], interp=interp or case["interp"], apod=apod, fmod=fmod)
+
+
+def test_extension_loaded_and_device():
+    from qups_amd import _lib
+    info = _lib.device_info()
+    assert "gfx950" in info["name"], info
+    assert info["cu_count"] >= 200
+
+
+@pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3", "cubic_dev"])
+@pytest.mark.parametrize("seq", ["FSA", "PW", "FC", "DV"])
+def test_das_generic_matches_oracle(seq, interp):
+    case = make_case(seq=seq, interp=interp, seed=1)
+    ref = run_oracle(case)
+    out, plan = run_das(case, kernel=1)
+    assert plan.kernel == "generic"
+    assert np.abs(ref).max() > 0
+    assert rel_err(out, ref) <= TOL32
+
+
+@pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3", "cubic_dev"])
+@pytest.mark.parametrize("seq", ["FSA", "PW", "FC", "DV"])
+def test_das_tiled_matches_oracle(seq, interp):
+    case = make_case(seq=seq, interp=interp, seed=2, I1=150, I2=19)   # ragged tile edges in both axes
+    ref = run_oracle(case)
+    out, plan = run_das(case, kernel=2)
+    assert plan.kernel == "tiled"
+    assert plan.fallback_tiles() == 0
+    assert rel_err(out, ref) <= 2e-5
+
+
+def test_tiled_and_generic_agree_on_noise():
+    """white-noise data (what the reference's own benchmark feeds, test/ParTest.m:254-257)"""
+    case = make_case(seq="FSA", interp="lanczos3", seed=3, data="noise", I1=130, I2=9)
+    ref = run_oracle(case)
+    out_t, _ = run_das(case, kernel=2)
+    out_g, _ = run_das(case, kernel=1)
+    assert rel_err(out_t, ref) <= 2e-5
+    assert rel_err(out_g, ref) <= 3e-4        # fp32 time arithmetic on white noise
+
+
+@pytest.mark.parametrize("fun", ["SYN", "MUL", "BF"])
+def test_keep_modes(fun):
+    case = make_case(seq="PW", interp="linear", seed=4, N=8, M=5, I1=40, I2=6)
+    ref = run_oracle(case, fun=fun)
+    out, plan = run_das(case, fun=fun)
+    assert plan.kernel == "generic"
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) <= TOL32
+    # identity: summing the kept dimensions reproduces 'DAS' (kern/das_spec.m:263-269)
+    das, _ = run_das(case, fun="DAS", kernel=1)
+    assert rel_err(out.sum(axis=(3, 4), keepdims=True), das) <= 1e-5
+
+
+def test_bf_transposed_output_order():
+    case = make_case(seq="PW", interp="linear", seed=5, N=6, M=4, I1=33, I2=3)
+    ref = run_oracle(case, fun="BF")                 # I x N x M
+    out, _ = run_das(case, fun="BF", tpose=True)     # reference stores plane nm = m + n*M  (src/bf.cu:100,135)
+    assert out.shape[3:5] == (case["M"], case["N"])
+    assert rel_err(np.swapaxes(out, 3, 4), ref) <= TOL32
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_transpose_and_per_tx_t0(kernel):
+    case = make_case(seq="FSA", interp="cubic", seed=6, N=12)
+    t0 = (case["t0"] + np.linspace(0, 3, case["M"]) / case["fs"]).astype(np.float32).astype(np.float64)
+    x = np.stack([np.roll(case["x"][:, :, m], 0, axis=0) for m in range(case["M"])], axis=2)
+    ref = run_oracle(case, x=x, t0=t0)
+    out, plan = run_das(case, x=x, t0=t0, tpose=True, kernel=kernel)
+    assert rel_err(out, ref) <= (TOL32 if kernel == 1 else 2e-5)
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_fmod_device_semantics(kernel):
+    case = make_case(seq="PW", interp="cubic", seed=7)
+    fm = float(np.float32(case["fc"]))
+    ref = run_oracle(case, fmod=fm)
+    out, _ = run_das(case, fmod=fm, kernel=kernel)
+    assert rel_err(out, ref) <= 2e-4     # phase 2*pi*fmod*tau with tau ~ 1e-5 s in fp32
+
+
+def test_apod_broadcast_shapes_generic():
+    """every singleton pattern of I1 x I2 x I3 x N x M (reference test/USTest.m:333-337)"""
+    case = make_case(seq="PW", interp="linear", seed=8, N=5, M=3, I1=20, I2=4)
+    rng = np.random.default_rng(0)
+    full = (20, 4, 1, 5, 3)
+    for mask in range(32):
+        shp = tuple(full[k] if (mask >> k) & 1 else 1 for k in range(5))
+        a = f32r(rng.uniform(0.2, 1.0, shp))
+        ref = run_oracle(case, apod=(a,))
+        out, _ = run_das(case, apod=(a,))
+        assert rel_err(out, ref) <= TOL32, shp
+
+
+def f32r(a):
+    return np.asarray(a, np.float32).astype(np.float64)
+
+
+def test_apod_stack_complex_and_zero_skip():
+    case = make_case(seq="FSA", interp="cubic", seed=9, N=8, I1=64, I2=8)
+    rng = np.random.default_rng(1)
+    a1 = f32r(rng.uniform(0, 1, (64, 8, 1, 8, 1)) > 0.4).astype(np.float64)          # sparse mask (zeros short-circuit)
+    a2 = (f32r(rng.uniform(0, 1, (1, 1, 1, 1, 8))) + 1j * f32r(rng.uniform(0, 1, (1, 1, 1, 1, 8))))
+    ref = run_oracle(case, apod=(a1, a2))
+    out, plan = run_das(case, apod=(a1, a2))
+    assert plan.kernel == "generic"
+    assert rel_err(out, ref) <= TOL32
+
+
+def test_tiled_with_trace_weights():
+    case = make_case(seq="FSA", interp="lanczos3", seed=10, N=10, I1=100, I2=8)
+    rng = np.random.default_rng(2)
+    an = f32r(np.hanning(12)[1:-1]).reshape(1, 1, 1, 10, 1)
+    am = (f32r(rng.uniform(0, 1, (1, 1, 1, 1, 10))) > 0.3) * (1 + 0.5j)
+    ref = run_oracle(case, apod=(an, am))
+    out, plan = run_das(case, apod=(an, am), kernel=2)
+    assert plan.kernel == "tiled"
+    assert rel_err(out, ref) <= 2e-5
+
+
+def test_nd_sound_speed():
+    case = make_case(seq="PW", interp="linear", seed=11, N=6, M=4, I1=30, I2=5)
+    rng = np.random.default_rng(3)
+    cmap = f32r(1.0 / f32r(1.0 / rng.uniform(1480, 1600, (30, 5, 1))))
+    from oracle import das_oracle as O
+    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"],
+                     1.0 / f32r(1.0 / cmap), VS=case["VS"], DV=case["DV"], interp="linear")
+    out, plan = run_das(case, c=cmap)
+    assert plan.kernel == "generic"
+    assert rel_err(out, ref) <= TOL32
+
+
+def test_double_precision():
+    case = make_case(seq="FC", interp="cubic", seed=12)
+    from oracle import das_oracle as O
+    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"], case["c"],
+                     VS=case["VS"], DV=case["DV"], interp="cubic")
+    out, plan = run_das(case, prec="double")
+    assert rel_err(out, ref) <= 1e-10
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_half_precision(kernel):
+    case = make_case(seq="FSA", interp="cubic", seed=13, I1=96, I2=8)
+    xh = case["x"]
+    xh = (xh.real.astype(np.float16).astype(np.float64) + 1j * xh.imag.astype(np.float16).astype(np.float64))
+    ref = run_oracle(case, x=xh)
+    out, plan = run_das(case, prec="halfT", kernel=kernel)
+    assert rel_err(out, ref) <= 2e-3
+
+
+def test_edges_and_out_of_record():
+    """record shorter than the path: samples before 0 / after T-1 are exactly zero"""
+    for interp in ("nearest", "linear", "cubic", "lanczos3"):
+        case = make_case(seq="FSA", interp=interp, seed=14, T=300, data="noise", zlim=(1e-3, 30e-3), I1=128, I2=8)
+        ref = run_oracle(case)
+        for kernel in (1, 2):
+            out, plan = run_das(case, kernel=kernel)
+            # pixels whose every contribution is out of the record must be exactly zero
+            dead = np.abs(ref) == 0
+            assert dead.any()
+            assert np.all(out[dead] == 0), (interp, kernel)
+            assert rel_err(out, ref) <= (3e-4 if kernel == 1 else 3e-5), (interp, kernel)
+
+
+def test_oversize_window_falls_back():
+    """pixel spacing so coarse that a 64-pixel tile spans far more than the LDS window"""
+    case = make_case(seq="FSA", interp="linear", seed=15, I1=256, I2=4, zlim=(2e-3, 60e-3), data="noise", N=8)
+    ref = run_oracle(case)
+    out, plan = run_das(case, kernel=0)
+    assert plan.kernel == "tiled"
+    assert plan.fallback_tiles() > 0
+    assert rel_err(out, ref) <= 3e-4
+
+
+def test_delays():
+    from qups_amd import das_spec
+    from oracle import das_oracle as O
+    case = make_case(seq="FC", seed=16, N=5, M=3, I1=17, I2=4)
+    tau = das_spec("delays", case["Pi"], case["Pr"], case["Pv"], case["Nv"], None, 0.0, None, case["c"],
+                   "input-precision", "single").cpu().numpy()
+    ref = O.das_spec("delays", case["Pi"], case["Pr"], case["Pv"], case["Nv"], None, 0, 1, cinv_f32(case["c"]), VS=True, DV=False)
+    assert tau.shape == ref.shape
+    assert np.abs(tau - ref).max() <= 1e-6 * np.abs(ref).max()
+
+
+def test_frames_and_plan_reuse():
+    torch = _torch()
+    from qups_amd import das_spec
+    case = make_case(seq="PW", interp="cubic", seed=17, N=8, M=4, I1=70, I2=8)
+    rng = np.random.default_rng(5)
+    xf = np.stack([case["x"] * (k + 1) * np.exp(1j * k) for k in range(3)], axis=3).astype(np.complex64)
+    y, plan = das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], torch.from_numpy(xf), case["t0"], case["fs"],
+                       case["c"], *case["opt"], "interp", "cubic", return_plan=True)
+    y = y.cpu().numpy()
+    assert y.shape == (70, 8, 1, 1, 1, 3)
+    ref = run_oracle(case)
+    for k in range(3):
+        assert rel_err(y[..., k], ref * (k + 1) * np.exp(1j * k)) <= 5e-5
+    y1 = plan.feval(torch.from_numpy(xf[..., 1])).cpu().numpy()     # k.feval(PRE_ARGS{:}, x{f}, POST_ARGS{:})
+    assert rel_err(y1.reshape(70, 8), y[:, :, 0, 0, 0, 1]) == 0.0
+
+
+def test_pixel_shards_concatenate():
+    """multi-GPU layout on one device: contiguous slabs of the linear pixel index"""
+    torch = _torch()
+    from qups_amd import build_problem, parse_options, DasPlan
+    case = make_case(seq="FSA", interp="cubic", seed=18, I1=100, I2=10)
+    x = torch.from_numpy(case["x"]).cuda()
+    opts = parse_options(x, list(case["opt"]) + ["interp", "cubic"])
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], x.shape, case["t0"], case["fs"], case["c"], opts)
+    full = DasPlan(prob).feval(x).cpu().numpy().reshape(-1)
+    I = prob.I
+    for G in (2, 3, 7):
+        parts = []
+        for g in range(G):
+            b, e = I * g // G, I * (g + 1) // G
+            parts.append(DasPlan(prob, i_begin=b, i_count=e - b).feval(x).cpu().numpy().reshape(-1))
+        assert np.array_equal(np.concatenate(parts), full), G
+
+
+def test_c_abi_one_shot_matches_plan():
+    """qdas_DASf: the reference kernel's own argument list (src/bf.cu:153-158)"""
+    import ctypes as C
+    torch = _torch()
+    from qups_amd import _lib, build_problem, parse_options, DasPlan
+    case = make_case(seq="PW", interp="linear", seed=19, N=6, M=3, I1=40, I2=4)
+    x = torch.from_numpy(case["x"]).cuda()
+    opts = parse_options(x, list(case["opt"]) + ["interp", "linear"])
+    p = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], x.shape, case["t0"], case["fs"], case["c"], opts)
+    ref = DasPlan(p, kernel=1).feval(x).reshape(-1)
+    L = _lib.lib()
+    dev = lambda a: torch.from_numpy(a).cuda()
+    Pi, Pr, Pv, Nv, cinv = dev(p.Pi), dev(p.Pr), dev(p.Pv), dev(p.Nv), dev(p.cinv)
+    xc = x.permute(2, 1, 0).contiguous()
+    y = torch.zeros(p.I, dtype=torch.complex64, device="cuda")
+    sz = _lib.Sizes(p.T, p.N, p.M, p.Isz[0], p.Isz[1], p.Isz[2], 0, p.flag, int(p.VS), int(p.DV), 1)
+    acs = (C.c_uint64 * 6)(*[0] * 6)
+    tv = (C.c_float * 2)(p.fs, 0.0)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(L.qdas_DASf(C.byref(sz), ptr(y), ptr(Pi), ptr(Pr), ptr(Pv), ptr(Nv), None, ptr(cinv), acs, ptr(xc),
+                           C.cast(tv, C.c_void_p), None))
+    torch.cuda.synchronize()
+    assert rel_err(y.cpu().numpy(), ref.cpu().numpy()) <= 2e-5
+
+
+def test_error_paths():
+    from qups_amd import das_spec, DasError, _lib
+    case = make_case(seq="PW", seed=20, N=4, M=3, I1=8, I2=2)
+    torch = _torch()
+    x = torch.from_numpy(case["x"])
+    args = (case["Pi"], case["Pr"], case["Pv"], case["Nv"], x, case["t0"], case["fs"], case["c"])
+    with pytest.raises(DasError, match="Unrecognized option"):
+        das_spec("DAS", *args, "bogus")
+    with pytest.raises(DasError, match="Invalid beamformer"):
+        das_spec("XYZ", *args)
+    with pytest.raises(DasError) as ei:
+        das_spec("DAS", *args, "interp", "spline")
+    assert ei.value.identifier == "QUPS:das_spec:UnrecognizedInput"
+    with pytest.raises(DasError, match="Apodization data size inconsistent with receiver"):
+        das_spec("DAS", *args, "apod", np.ones((1, 1, 1, 5, 1)))
+    with pytest.raises(_lib.QdasError, match="tiled kernel"):
+        das_spec("SYN", *args, kernel=2)
