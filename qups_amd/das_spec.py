@@ -295,7 +295,10 @@ def build_problem(fun, Pi, Pr, Pv, Nv, xshape, t0, fs, c, opts: dict) -> DasProb
 
     keep_rx, keep_tx = fun in ("SYN", "BF"), fun in ("MUL", "BF")
     flag = _lib.INTERP_FLAGS[interp] + 8 * keep_rx + 16 * keep_tx + 32 * tpose     # reference kern/das_spec.m:210-213
-    osize = {"DAS": (1, 1), "SYN": (N, 1), "MUL": (1, M), "BF": (N, M), "delays": (N, M)}[fun]
+    # 'BF' stores plane nm, i.e. the DATA's aperture order (reference src/bf.cu:100,135): I x M x N when the
+    # data is transposed.  (The reference then labels that buffer [Isz N M], kern/das_spec.m:381 -- "perm(N x M)",
+    # src/UltrasoundSystem.m:3357; here the array is returned with the shape it actually has.)
+    osize = {"DAS": (1, 1), "SYN": (N, 1), "MUL": (1, M), "BF": (M, N) if tpose else (N, M), "delays": (N, M)}[fun]
     col = lambda A: np.ascontiguousarray(A.reshape(-1, order="F").astype(rt))
     return DasProblem(fun=fun, prec=prec, flag=int(flag), VS=bool(opts["VS"]), DV=bool(opts["DV"]), Isz=Isz,
                       T=T, N=N, M=M, fsz=tuple(fsz), fs=fs, fmod=float(opts["fmod"]),
