@@ -8,35 +8,42 @@
 // Design (MI355X-first, not a re-tiling of the reference's one-thread-per-pixel loop):
 //
 //  * A workgroup owns a TILE of 64 (fast image axis I1 = depth) x TX (columns) pixels.  A wave's
-//    64 lanes are 64 consecutive depth pixels, so for any trace (n, m) the lanes read
-//    neighbouring fast-time samples.
+//    64 lanes are 64 consecutive depth pixels of one column, so for any trace (n, m) the lanes
+//    read neighbouring fast-time samples.  Two consecutive transmits (m, m+1) of the same pixel
+//    ride in the two halves of packed-fp32 (v_pk_*_f32) instructions (measured on MI355X: 5.2
+//    cycles per packed FMA vs 2 x 3.3 for two scalar FMAs -- profiles/microbench_r01.txt).
 //  * Time of flight is separable: tau*fs + off = a(i,m) + b(i,n).  The prologue computes, in
-//    fp64, the tile-wide integer window bases A[m] <= a, B[n] <= b and extents; afterwards each
-//    lane only carries the small fp32 residuals ra = a - A[m], rb = b - B[n] (exact to ~1e-5
-//    sample; the reference's fp32 tau carries ~1e-4 sample at tau*fs ~ 2000).  The per-pair
-//    address is then ONE add:  tr = ra[m] + rb,  tap index = (uint)tr inside the staged window.
+//    fp64, tile-wide integer window bases A[m] <= a, B[n] <= b and extents; afterwards each lane
+//    only carries the small fp32 residuals ra = a - A[m] - 1/2, rb = b - B[n] (exact to ~1e-5
+//    sample; the reference's fp32 tau carries ~1e-4 sample at tau*fs ~ 2000).  Per pair:
+//        t = ra[m] + rb;  k = rint(t) (magic-number add);  s = t - k  in [-1/2, 1/2];
+//        first tap = window[k], weights = even/odd polynomials in s.
 //  * For every (receiver n, block of MB transmits) the workgroup stages MB fast-time WINDOWS
 //    (W samples starting at A[m]+B[n]) of the channel data into LDS, coalesced along fast time
 //    and double-buffered against the compute of the previous stage; taps are then gathered from
-//    LDS with ds_read_b64 (fp32) / ds_read_b32 (fp16), not from global memory.
+//    LDS with four ds_read_b64 (issued from inline asm: hipcc would merge them into ds_read2_b64,
+//    which measures 2x slower for this gather -- profiles/microbench_r01.txt).
 //  * All resident workgroups walk the traces in the same order, so the channel data streams
 //    from HBM about once per "round" of tiles and is otherwise served by L2 / Infinity Cache.
-//  * A stage whose windows lie completely inside [0, T) takes a branch-free path; stages that
-//    touch the ends of the record take the checked path (edge rule of SURVEY.md section 8 a5).
+//  * Tiles whose windows all lie inside [0, T) run a branch-free loop; tiles that touch the ends
+//    of the record run the checked loop (edge rule of SURVEY.md section 8 a5).
 //  * A tile whose delay spread does not fit W appends itself to a fallback list and is
 //    processed by the generic kernel afterwards -- results never depend on the geometry being
 //    "image like".
-//  * Lanczos weights: even/plain polynomials (lanczos_poly.h), no transcendentals; fp16 data is
-//    accumulated in fp32 (the reference accumulates in half2, src/bf.cu:170).
+//  * Lanczos weights: even/odd-split polynomials (lanczos_poly.h), no transcendentals; fp16 data
+//    is accumulated in fp32 (the reference accumulates in half2, src/bf.cu:170).
 #include "qdas_device.h"
 #include "qdas_kernels.h"
 #include "lanczos_poly.h"
+#include <type_traits>
 
 namespace qdas {
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 constexpr int TZ = 64;            // pixels along I1 per tile == wave width
-constexpr int WAVES = 4;          // waves per workgroup
-constexpr int THREADS = WAVES * 64;
+constexpr float MAGIC = 12582912.0f;          // 1.5 * 2^23: (t + MAGIC) has rint(t) in its low mantissa bits
+constexpr uint32_t MAGIC_BITS = 0x4B400000u;
 
 template <int INTERP> struct tapinfo {
     static constexpr int K = interp_taps(INTERP);
@@ -47,24 +54,34 @@ template <int INTERP> struct tapinfo {
     static constexpr float LO = (INTERP == 0) ? 0.5f : 0.0f;
 };
 
-template <int D> __device__ __forceinline__ float horner(const float (&c)[D + 1], float t) {
-    float r = c[D];
+template <int D> __device__ __forceinline__ v2f horner2(const float (&c)[D + 1], v2f q) {
+    v2f r = {c[D], c[D]};
 #pragma unroll
-    for (int k = D - 1; k >= 0; --k) r = fmaf(r, t, c[k]);
+    for (int k = D - 1; k >= 0; --k) r = r * q + (v2f){c[k], c[k]};
     return r;
 }
 
-template <int INTERP> __device__ __forceinline__ void tile_weights(float u, float w[4]) {
-    if constexpr (INTERP == 3) {
-        constexpr float ein[QDAS_LANCZOS_DIN + 1] = QDAS_LANCZOS_EIN;
-        constexpr float pout[QDAS_LANCZOS_DOUT + 1] = QDAS_LANCZOS_POUT;
-        const float v = 1.0f - u;
-        w[0] = horner<QDAS_LANCZOS_DOUT>(pout, u);
-        w[1] = horner<QDAS_LANCZOS_DIN>(ein, u * u);
-        w[2] = horner<QDAS_LANCZOS_DIN>(ein, v * v);
-        w[3] = horner<QDAS_LANCZOS_DOUT>(pout, v);
-    } else {
-        interp_weights<INTERP, float>(u, w);
+// Tap weights for s = u - 1/2 (two columns packed).  w[k] multiplies tap (first + k).
+template <int INTERP> __device__ __forceinline__ void weights2(v2f s, v2f w[4]) {
+    if constexpr (INTERP == 1 || INTERP == 4) {            // lerp (reference src/interpd.cu:84)
+        w[0] = 0.5f - s; w[1] = 0.5f + s;
+    } else if constexpr (INTERP == 2) {                    // Catmull-Rom, exact even/odd split about u = 1/2
+        const v2f q = s * s;
+        const v2f ei = 0.5625f - 0.25f * q, oi = -1.375f + 1.5f * q;
+        const v2f eo = -0.0625f + 0.25f * q, oo = 0.125f - 0.5f * q;
+        w[1] = ei + s * oi; w[2] = ei - s * oi; w[0] = eo + s * oo; w[3] = eo - s * oo;
+    } else if constexpr (INTERP == 3) {                    // Lanczos (a = 2), lanczos_poly.h
+        constexpr float EI[] = QDAS_LANCZOS_EI, OI[] = QDAS_LANCZOS_OI, EO[] = QDAS_LANCZOS_EO, OO[] = QDAS_LANCZOS_OO;
+        const v2f q = s * s;
+        const v2f ei = horner2<sizeof(EI) / 4 - 1>(EI, q), oi = horner2<sizeof(OI) / 4 - 1>(OI, q);
+        const v2f eo = horner2<sizeof(EO) / 4 - 1>(EO, q), oo = horner2<sizeof(OO) / 4 - 1>(OO, q);
+        w[1] = ei + s * oi; w[2] = ei - s * oi; w[0] = eo + s * oo; w[3] = eo - s * oo;
+    } else if constexpr (INTERP == 5) {                    // the Horner lines the device code executes (src/interpd.cu:103-106)
+        const v2f u = s + 0.5f;
+        w[0] = 0.5f * (u * (-1.0f + u * (2.0f * u - 1.0f)));
+        w[1] = 0.5f * (2.0f + u * (u * (-5.0f * u + 3.0f)));
+        w[2] = 0.5f * (u * (1.0f + u * (4.0f * u - 3.0f)));
+        w[3] = 0.5f * (u * (u * (1.0f - u)));
     }
 }
 
@@ -79,29 +96,57 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// LDS sample -> fp32 complex
-__device__ __forceinline__ cplx<float> lds_ld(const float2 *p) { const float2 v = *p; return {v.x, v.y}; }
-__device__ __forceinline__ cplx<float> lds_ld(const uint32_t *p) {
-    const uint32_t v = *p;
-    return {__half2float(__ushort_as_half((unsigned short)(v & 0xffffu))),
-            __half2float(__ushort_as_half((unsigned short)(v >> 16)))};
+// ---- LDS tap gathers.  fp32 data: 4 x ds_read_b64 from inline asm; the results are only usable
+//      after lds_fence(), which ties the registers through the s_waitcnt so the compiler cannot
+//      hoist a consumer above it (cdna_hip_programming.md section 5.4 rule 18 / 5.7).
+struct taps_f32 { v2f s[4]; };
+__device__ __forceinline__ void lds_issue(taps_f32 &t, uint32_t addr) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24"
+                 : "=&v"(t.s[0]), "=&v"(t.s[1]), "=&v"(t.s[2]), "=&v"(t.s[3]) : "v"(addr));
 }
+__device__ __forceinline__ void lds_issue1(taps_f32 &t, uint32_t addr) {
+    asm volatile("ds_read_b64 %0, %1" : "=&v"(t.s[0]) : "v"(addr));
+}
+__device__ __forceinline__ void lds_issue2(taps_f32 &t, uint32_t addr) {
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=&v"(t.s[0]), "=&v"(t.s[1]) : "v"(addr));
+}
+// The weights are tied through the wait as well, so that their evaluation is scheduled BEFORE it
+// (between the issue of the loads and the wait: that is what hides the LDS latency).
+__device__ __forceinline__ void lds_fence(taps_f32 &a, taps_f32 &b, v2f (&w)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a.s[0]), "+v"(a.s[1]), "+v"(a.s[2]), "+v"(a.s[3]), "+v"(b.s[0]), "+v"(b.s[1]), "+v"(b.s[2]), "+v"(b.s[3]),
+                   "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+}
+// fp16 data: 4-byte samples; plain loads (ds_read_b32 pairs merge without penalty), widened to fp32
+struct taps_f16 { v2f s[4]; };
+template <int K> __device__ __forceinline__ void lds_load_f16(taps_f16 &t, uint32_t addr) {
+    const __attribute__((address_space(3))) uint32_t *p = (const __attribute__((address_space(3))) uint32_t *)(uintptr_t)addr;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t v = p[k];
+        t.s[k] = (v2f){__half2float(__ushort_as_half((unsigned short)(v & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(v >> 16)))};
+    }
+}
+
 __device__ __forceinline__ float2   zero_of(const float2 *)   { return make_float2(0.f, 0.f); }
 __device__ __forceinline__ uint32_t zero_of(const uint32_t *) { return 0u; }
 
-template <int INTERP, typename ST, bool FMOD, bool WTAB, int CPW, int MB, int W>
-__global__ void __launch_bounds__(THREADS)
+template <int INTERP, typename ST, bool FMOD, bool WTAB, int WAVES, int MB, int W>
+__global__ void __launch_bounds__(WAVES * 64, WAVES / 2)   // 2 workgroups per CU -> WAVES/2 waves per SIMD
 das_tile_kernel(const TileParams P) {
     constexpr int K = tapinfo<INTERP>::K;
-    constexpr int TX = WAVES * CPW;
+    constexpr int THREADS = WAVES * 64;
+    constexpr int TX = WAVES;                 // one image column per wave
     constexpr int WPW = MB / WAVES;           // windows staged per wave
     constexpr int CH = W / 64;                // 64-sample chunks per window
-    static_assert(MB % WAVES == 0 && W % 64 == 0, "staging split");
+    constexpr int SB = (int)sizeof(ST);       // bytes per complex sample
+    constexpr bool F32 = (SB == 8);
+    static_assert(MB % WAVES == 0 && W % 64 == 0 && MB % 2 == 0, "staging split");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t M = (uint32_t)P.M, N = (uint32_t)P.N;
-    const long T = (long)P.T;
+    const int T = (int)P.T;
     int   *Abase = (int *)smem;                       // [M]
     float *Aext  = (float *)(Abase + M);              // [M]
     int   *Bbase = (int *)(Aext + M);                 // [N]
@@ -109,8 +154,9 @@ das_tile_kernel(const TileParams P) {
     const uint32_t hdr = ((M + N) * 8 + 15) & ~15u;
     ST *win = (ST *)(smem + hdr);                     // [2][MB][W]
     float *part = (float *)(smem + hdr);              // prologue scratch, aliases the windows
+    const uint32_t win_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem) + hdr;
 
-    // ---- which tile (XCD-aware: consecutive tile ids -> same XCD, dispatch is round-robin mod 8)
+    // ---- which tile (XCD-aware: consecutive tile ids -> same XCD; dispatch is round-robin mod 8)
     const uint32_t nb = gridDim.x;
     uint32_t bid = blockIdx.x;
     {
@@ -120,106 +166,107 @@ das_tile_kernel(const TileParams P) {
     const uint32_t tz = bid % P.tiles_z, txi = P.tile_x0 + bid / P.tiles_z;
     const uint32_t tile_id = tz + P.tiles_z * txi;
 
-    // ---- my pixels: lane -> depth, (wave, c) -> column.  Out-of-image lanes are clamped onto a
-    //      real pixel (keeps them inside the tile's delay window) and masked at the store.
+    // ---- my pixel: lane -> depth, wave -> column.  Out-of-image lanes are clamped onto a real
+    //      pixel (keeps them inside the tile's delay window) and masked at the store.
     const uint64_t ncols = P.I2 * P.I3, i_end = P.i_begin + P.i_count;
     const uint64_t i1 = (uint64_t)tz * TZ + lane;
-    const uint64_t i1c = i1 < P.I1 ? i1 : P.I1 - 1;
-    double px[CPW], py[CPW], pz[CPW];
-    bool ok[CPW];
-    uint64_t ipix[CPW];
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) {
-        const uint64_t col = (uint64_t)txi * TX + wave * CPW + c;
-        const uint64_t colc = col < ncols ? col : ncols - 1;
-        const uint64_t i = i1c + P.I1 * colc;
-        const uint64_t ig = i1 + P.I1 * col;
-        ok[c] = (i1 < P.I1) && (col < ncols) && (ig >= P.i_begin) && (ig < i_end);
-        ipix[c] = ig;
-        px[c] = P.Pi[3 * i]; py[c] = P.Pi[3 * i + 1]; pz[c] = P.Pi[3 * i + 2];
+    const uint64_t col = (uint64_t)txi * TX + wave;
+    float px, py, pz;                                 // widened to fp64 where they are used
+    {
+        const uint64_t i = (i1 < P.I1 ? i1 : P.I1 - 1) + P.I1 * (col < ncols ? col : ncols - 1);
+        px = P.Pi[3 * i]; py = P.Pi[3 * i + 1]; pz = P.Pi[3 * i + 2];
     }
     const double cf = P.cinv_fs, fs = P.fs;
     const bool VS = P.VS, DV = P.DV;
 
-    auto a_of = [&](int c, uint32_t m) -> double {       // (tau_tx*fs - t0*fs + OFF), reference src/bf.cu:104-108,114
-        const double rx = px[c] - (double)P.Pv[4 * m], ry = py[c] - (double)P.Pv[4 * m + 1], rz = pz[c] - (double)P.Pv[4 * m + 2];
+    // sqrt in fp64 from an fp32 seed + one Newton step (rel. error ~1e-14; v_sqrt_f32 is 1 ulp)
+    auto dsqrt = [](double d2) -> double {
+        const float s0 = __builtin_sqrtf((float)d2);
+        const double sd = (double)s0;
+        const double r = __builtin_fma(-sd, sd, d2);
+        return s0 > 0.f ? __builtin_fma(r, (double)(0.5f / s0), sd) : 0.0;
+    };
+    auto a_of = [&](uint32_t m) -> double {              // tau_tx*fs - t0*fs + OFF, reference src/bf.cu:104-108,114
+        const double rx = (double)px - (double)P.Pv[4 * m], ry = (double)py - (double)P.Pv[4 * m + 1], rz = (double)pz - (double)P.Pv[4 * m + 2];
         const double dot = rx * (double)P.Nv[3 * m] + ry * (double)P.Nv[3 * m + 1] + rz * (double)P.Nv[3 * m + 2];
         double dv = dot;
-        if (VS) { const double len = sqrt(rx * rx + ry * ry + rz * rz); dv = DV ? len : copysign(len, dot); }
+        if (VS) { const double len = dsqrt(rx * rx + ry * ry + rz * rz); dv = DV ? len : copysign(len, dot); }
         return dv * cf - (double)P.Pv[4 * m + 3] * fs + tapinfo<INTERP>::OFF;
     };
-    auto b_of = [&](int c, uint32_t n) -> double {       // tau_rx*fs, reference src/bf.cu:110
-        const double rx = px[c] - (double)P.Pr[3 * n], ry = py[c] - (double)P.Pr[3 * n + 1], rz = pz[c] - (double)P.Pr[3 * n + 2];
-        return sqrt(rx * rx + ry * ry + rz * rz) * cf;
+    auto b_of = [&](uint32_t n) -> double {              // tau_rx*fs, reference src/bf.cu:110
+        const double rx = (double)px - (double)P.Pr[3 * n], ry = (double)py - (double)P.Pr[3 * n + 1], rz = (double)pz - (double)P.Pr[3 * n + 2];
+        return dsqrt(rx * rx + ry * ry + rz * rz) * cf;
     };
 
     // ---- prologue: tile-wide window bases / extents per transmit and per receiver
     const uint32_t MX = M > N ? M : N;
     for (uint32_t m = 0; m < M; ++m) {
-        float mn = INFINITY, mx = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) { const float a = (float)a_of(c, m); mn = fminf(mn, a); mx = fmaxf(mx, a); if (!(a == a)) mx = INFINITY; }
-        mn = wave_min(mn); mx = wave_max(mx);
-        if (lane == 0) { part[wave * MX + m] = mn; part[(WAVES + wave) * MX + m] = mx; }
+        const float a = (float)a_of(m);
+        const float mn = wave_min(a), mx = (a == a) ? wave_max(a) : INFINITY;
+        const float mxx = wave_max(mx);
+        if (lane == 0) { part[wave * MX + m] = mn; part[(WAVES + wave) * MX + m] = mxx; }
     }
     __syncthreads();
+    float a_lo = INFINITY, a_hi = -INFINITY, a_ext = 0.f;            // per-thread partials of tile-wide stats
     for (uint32_t m = tid; m < M; m += THREADS) {
         float mn = part[m], mx = part[WAVES * MX + m];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + m]); mx = fmaxf(mx, part[(WAVES + w) * MX + m]); }
         const float fl = floorf(mn) - 1.0f;              // margin: (float)a may have rounded up
-        Abase[m] = (fabsf(fl) < 1.0e9f) ? (int)fl : 0;
-        Aext[m] = (fabsf(fl) < 1.0e9f) ? (mx - fl) + 0.01f : INFINITY;
+        const bool fin = fabsf(fl) < 1.0e9f;
+        const float e = fin ? (mx - fl) + 0.01f : INFINITY;
+        Abase[m] = fin ? (int)fl : 0;
+        Aext[m] = e;
+        a_lo = fminf(a_lo, fl); a_hi = fmaxf(a_hi, fl + e); a_ext = fmaxf(a_ext, e);
     }
     __syncthreads();
     for (uint32_t n = 0; n < N; ++n) {
-        float mn = INFINITY, mx = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) { const float b = (float)b_of(c, n); mn = fminf(mn, b); mx = fmaxf(mx, b); if (!(b == b)) mx = INFINITY; }
-        mn = wave_min(mn); mx = wave_max(mx);
-        if (lane == 0) { part[wave * MX + n] = mn; part[(WAVES + wave) * MX + n] = mx; }
+        const float b = (float)b_of(n);
+        const float mn = wave_min(b), mx = (b == b) ? wave_max(b) : INFINITY;
+        const float mxx = wave_max(mx);
+        if (lane == 0) { part[wave * MX + n] = mn; part[(WAVES + wave) * MX + n] = mxx; }
     }
     __syncthreads();
-    float emax = 0.f;
+    float b_lo = INFINITY, b_hi = -INFINITY, b_ext = 0.f;
     for (uint32_t n = tid; n < N; n += THREADS) {
         float mn = part[n], mx = part[WAVES * MX + n];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + n]); mx = fmaxf(mx, part[(WAVES + w) * MX + n]); }
         const float fl = floorf(mn) - 1.0f;
         const bool fin = fabsf(fl) < 1.0e9f;
-        Bbase[n] = fin ? (int)fl : 0;
         const float e = fin ? (mx - fl) + 0.01f : INFINITY;
+        Bbase[n] = fin ? (int)fl : 0;
         Bext[n] = e;
-        emax = fmaxf(emax, e);
+        b_lo = fminf(b_lo, fl); b_hi = fmaxf(b_hi, fl + e); b_ext = fmaxf(b_ext, e);
     }
-    float amax = 0.f;
-    for (uint32_t m = tid; m < M; m += THREADS) amax = fmaxf(amax, Aext[m]);
     __syncthreads();                                   // part[] is free again
-    emax = wave_max(emax); amax = wave_max(amax);
-    if (lane == 0) { part[wave] = emax; part[WAVES + wave] = amax; }
+    a_lo = wave_min(a_lo); b_lo = wave_min(b_lo);
+    a_hi = wave_max(a_hi); b_hi = wave_max(b_hi); a_ext = wave_max(a_ext); b_ext = wave_max(b_ext);
+    if (lane == 0) { float *q = part + wave * 8; q[0] = a_lo; q[1] = b_lo; q[2] = a_hi; q[3] = b_hi; q[4] = a_ext; q[5] = b_ext; }
     __syncthreads();
-    {
-        float e = part[0], a = part[WAVES];
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) { e = fmaxf(e, part[w]); a = fmaxf(a, part[WAVES + w]); }
-        // every lane's last tap must be inside the staged window: floor(tr) + K - 1 <= W - 1
-        if (!(a + e + (float)K <= (float)W)) {
-            if (tid == 0) {
-                const uint32_t slot = atomicAdd(&P.fallback_list[0], 1u);
-                if (slot < P.fallback_cap) P.fallback_list[1 + slot] = tile_id;
-            }
-            return;                                    // uniform exit: generic kernel takes this tile
-        }
+    for (int w = 0; w < WAVES; ++w) {
+        const float *q = part + w * 8;
+        a_lo = fminf(a_lo, q[0]); b_lo = fminf(b_lo, q[1]); a_hi = fmaxf(a_hi, q[2]); b_hi = fmaxf(b_hi, q[3]);
+        a_ext = fmaxf(a_ext, q[4]); b_ext = fmaxf(b_ext, q[5]);
     }
+    // every lane's last tap (+1 for the rint/floor ambiguity at exact integers) must be inside the staged window
+    if (!(a_ext + b_ext + (float)(K + 1) <= (float)W)) {
+        if (tid == 0) {
+            const uint32_t slot = atomicAdd(&P.fallback_list[0], 1u);
+            if (slot < P.fallback_cap) P.fallback_list[1 + slot] = tile_id;
+        }
+        return;                                        // uniform exit: generic kernel takes this tile
+    }
+    // every window of every stage strictly inside the record?  (uniform) -> branch-free loop
+    const bool tile_interior = (a_lo + b_lo >= 1.0f) && (a_hi + b_hi + (float)(K + 1) < (float)T);
     __syncthreads();
 
     // ---- main loop over stages (mb = transmit block, n = receiver; n is the inner index)
     const uint32_t nmb = (M + MB - 1) / MB;
     const uint32_t nstage = nmb * N;
-    float accx[CPW], accy[CPW];
-#pragma unroll
-    for (int c = 0; c < CPW; ++c) { accx[c] = 0.f; accy[c] = 0.f; }
-    float ra[CPW][MB];
+    v2f acc = {0.f, 0.f};                              // (re, im) of this lane's pixel
+    v2f ra[MB / 2];                                    // tx residuals a - A[m] - 1/2 of transmits (2p, 2p+1), packed
     const ST *__restrict__ xg = (const ST *)P.x;
     ST stg[WPW][CH];                                   // staging registers (global -> LDS)
 
@@ -230,12 +277,12 @@ das_tile_kernel(const TileParams P) {
         for (int r = 0; r < WPW; ++r) {
             const uint32_t j = wave + WAVES * r, m = m0 + j;
             const bool mok = m < M;
-            const long ws = (long)(mok ? Abase[m] : 0) + bn;
-            const long base = (long)n * (long)P.strN + (long)(mok ? m : 0) * (long)P.strM;
+            const int ws = (mok ? Abase[m] : 0) + bn;
+            const ST *tp = xg + ((long)n * (long)P.strN + (long)(mok ? m : 0) * (long)P.strM + (long)ws);
 #pragma unroll
             for (int q = 0; q < CH; ++q) {
-                const long s = ws + q * 64 + lane;
-                stg[r][q] = (mok && s >= 0 && s < T) ? xg[base + s] : zero_of(xg);
+                const int s = ws + q * 64 + lane;
+                stg[r][q] = (mok && s >= 0 && s < T) ? tp[q * 64 + lane] : zero_of(xg);
             }
         }
     };
@@ -248,109 +295,121 @@ das_tile_kernel(const TileParams P) {
         }
     };
 
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
+    auto run = [&](auto check_tag) {
+        constexpr bool CHECK = decltype(check_tag)::value;
+        stage_load(0);
+        stage_store(0);
+        __syncthreads();
+        for (uint32_t st = 0; st < nstage; ++st) {
+            const uint32_t n = st % N, m0 = (st / N) * MB;
+            const int buf = st & 1;
+            if (st + 1 < nstage) stage_load(st + 1);   // in flight during the compute below
 
-    for (uint32_t st = 0; st < nstage; ++st) {
-        const uint32_t n = st % N, m0 = (st / N) * MB;
-        const int buf = st & 1;
-        if (st + 1 < nstage) stage_load(st + 1);       // in flight during the compute below
-
-        if (n == 0) {                                  // new transmit block: refresh the tx residuals
+            if (n == 0) {                              // new transmit block: refresh the tx residuals
 #pragma unroll
-            for (int j = 0; j < MB; ++j) {
-                const uint32_t m = m0 + j < M ? m0 + j : M - 1;
-                const double A = (double)Abase[m];
-#pragma unroll
-                for (int c = 0; c < CPW; ++c) ra[c][j] = (float)(a_of(c, m) - A);
-            }
-        }
-        const int bn = Bbase[n];
-        const float en = Bext[n];
-        float rb[CPW];
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) rb[c] = (float)(b_of(c, n) - (double)bn);
-
-        // is every window of this stage strictly inside the record?  (uniform)
-        bool interior = true;
-#pragma unroll
-        for (int j = 0; j < MB; ++j) {
-            const uint32_t m = m0 + j;
-            if (m < M) {
-                const long ws = (long)Abase[m] + bn;
-                interior = interior && (ws >= 1) && ((float)ws + Aext[m] + en + (float)K < (float)T);
-            }
-        }
-        const ST *wb = win + (size_t)buf * MB * W;
-
-#pragma unroll
-        for (int j = 0; j < MB; ++j) {
-            const uint32_t m = m0 + j;
-            if (m >= M) break;
-            float wr = 1.f, wi = 0.f;
-            if constexpr (WTAB) {
-                const float2 wt = ((const float2 *)P.wtab)[n + (size_t)N * m];
-                wr = wt.x; wi = wt.y;
-                if (wr == 0.f && wi == 0.f) continue;   // zero weight: skip (reference src/bf.cu:122,126)
-            }
-            const long ws = (long)Abase[m] + bn;
-            const float lo = tapinfo<INTERP>::LO - (float)ws;     // validity bounds in window-relative units
-            const float hi = (float)(T - K + 1 - ws);
-            float phc = 0.f, fcyc = 0.f;
-            if constexpr (FMOD) {                       // phase (cycles) = fmod*tau, tau = (tr + ws - OFF)/fs
-                fcyc = (float)(P.fmod / fs);
-                const double p0 = ((double)ws - tapinfo<INTERP>::OFF) * (P.fmod / fs);
-                phc = (float)(p0 - floor(p0));
-            }
-#pragma unroll
-            for (int c = 0; c < CPW; ++c) {
-                const float tr = ra[c][j] + rb[c];
-                const uint32_t idx = (uint32_t)tr;       // tr >= ~2 by construction
-                const ST *tp = wb + j * W + idx;
-                float vx, vy;
-                if constexpr (K == 1) {
-                    const cplx<float> s0 = lds_ld(tp);
-                    vx = s0.x; vy = s0.y;
-                } else {
-                    float w[4];
-                    tile_weights<INTERP>(tr - (float)idx, w);
-                    vx = 0.f; vy = 0.f;
-#pragma unroll
-                    for (int k = 0; k < K; ++k) { const cplx<float> s = lds_ld(tp + k); vx = fmaf(w[k], s.x, vx); vy = fmaf(w[k], s.y, vy); }
+                for (int p = 0; p < MB / 2; ++p) {
+                    const uint32_t ma = m0 + 2 * p < M ? m0 + 2 * p : M - 1, mb = m0 + 2 * p + 1 < M ? m0 + 2 * p + 1 : M - 1;
+                    ra[p] = (v2f){(float)(a_of(ma) - ((double)Abase[ma] + 0.5)), (float)(a_of(mb) - ((double)Abase[mb] + 0.5))};
                 }
-                if (!interior) { const bool v = (tr >= lo) && (tr < hi); vx = v ? vx : 0.f; vy = v ? vy : 0.f; }
-                if constexpr (FMOD) {                   // reference src/bf.cu:117
-                    const float ph = fmaf(tr, fcyc, phc);
-                    const float cs = __builtin_amdgcn_cosf(ph), sn = __builtin_amdgcn_sinf(ph);
-                    const float tx = vx * cs - vy * sn; vy = vx * sn + vy * cs; vx = tx;
+            }
+            const int bn = Bbase[n];
+            const float rb = (float)(b_of(n) - (double)bn);
+            // byte address of sample 0 of window j: cbase + j*W*SB; the magic bits are folded in
+            const uint32_t cbase = win_off + (uint32_t)buf * (MB * W * SB) - (MAGIC_BITS * (uint32_t)SB);
+
+#pragma unroll
+            for (int p = 0; p < MB / 2; ++p) {
+                const uint32_t m = m0 + 2 * p;            // transmits m, m+1 ride in the two halves
+                if (m >= M) break;
+                float wr0 = 1.f, wi0 = 0.f, wr1 = 1.f, wi1 = 0.f;
+                if constexpr (WTAB) {
+                    const float2 wa = ((const float2 *)P.wtab)[n + (size_t)N * m];
+                    const float2 wb = (m + 1 < M) ? ((const float2 *)P.wtab)[n + (size_t)N * (m + 1)] : make_float2(0.f, 0.f);
+                    wr0 = wa.x; wi0 = wa.y; wr1 = wb.x; wi1 = wb.y;
+                    if (wr0 == 0.f && wi0 == 0.f && wr1 == 0.f && wi1 == 0.f) continue;   // zero weights: skip (src/bf.cu:122,126)
+                }
+                const v2f t = ra[p] + rb;                 // = tau*fs + OFF - (A+B) - 1/2
+                const v2f tm = t + MAGIC;
+                const v2f s = t - (tm - MAGIC);           // in [-1/2, 1/2]
+                const uint32_t ad0 = __float_as_uint(tm.x) * (uint32_t)SB + (cbase + (uint32_t)(2 * p) * (W * SB));
+                const uint32_t ad1 = __float_as_uint(tm.y) * (uint32_t)SB + (cbase + (uint32_t)(2 * p + 1) * (W * SB));
+                constexpr bool SPLIT = CHECK || FMOD || WTAB;       // the two halves need separate post-processing
+                v2f v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
+                if constexpr (F32) {
+                    taps_f32 g0, g1;
+                    if constexpr (K == 4) { lds_issue(g0, ad0); lds_issue(g1, ad1); }
+                    else if constexpr (K == 2) { lds_issue2(g0, ad0); lds_issue2(g1, ad1); g0.s[2] = g0.s[3] = g1.s[2] = g1.s[3] = (v2f){0.f, 0.f}; }
+                    else { lds_issue1(g0, ad0); lds_issue1(g1, ad1); g0.s[1] = g0.s[2] = g0.s[3] = g1.s[1] = g1.s[2] = g1.s[3] = (v2f){0.f, 0.f}; }
+                    v2f w[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+                    if constexpr (K > 1) weights2<INTERP>(s, w);       // overlaps the LDS latency
+                    lds_fence(g0, g1, w);
+                    if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; }
+                    else if constexpr (SPLIT) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { v0 = w[k].x * g0.s[k] + v0; v1 = w[k].y * g1.s[k] + v1; }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { acc = w[k].x * g0.s[k] + acc; acc = w[k].y * g1.s[k] + acc; }
+                    }
+                } else {
+                    taps_f16 g0, g1;
+                    lds_load_f16<K>(g0, ad0); lds_load_f16<K>(g1, ad1);
+                    if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; }
+                    else {
+                        v2f w[4];
+                        weights2<INTERP>(s, w);
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { v0 = w[k].x * g0.s[k] + v0; v1 = w[k].y * g1.s[k] + v1; }
+                    }
+                }
+                if constexpr (CHECK) {                    // edge rule: all taps in [0,T) and tau >= 0
+                    const uint32_t mb = m + 1 < M ? m + 1 : m;
+                    const int ws0 = Abase[m] + bn, ws1 = Abase[mb] + bn;
+                    const float lo0 = tapinfo<INTERP>::LO - 0.5f - (float)ws0, hi0 = (float)(T - K + 1 - ws0) - 0.5f;
+                    const float lo1 = tapinfo<INTERP>::LO - 0.5f - (float)ws1, hi1 = (float)(T - K + 1 - ws1) - 0.5f;
+                    const bool k0 = (t.x >= lo0) && (t.x < hi0), k1 = (t.y >= lo1) && (t.y < hi1) && (m + 1 < M);
+                    v0 = k0 ? v0 : (v2f){0.f, 0.f}; v1 = k1 ? v1 : (v2f){0.f, 0.f};
+                }
+                if constexpr (FMOD) {                     // reference src/bf.cu:117: w = exp(2j pi fmod tau)
+                    const uint32_t mb = m + 1 < M ? m + 1 : m;
+                    const double f = P.fmod / fs;         // tau*fs = t + 1/2 + ws - OFF
+                    const double p0 = ((double)(Abase[m] + bn) + 0.5 - tapinfo<INTERP>::OFF) * f;
+                    const double p1 = ((double)(Abase[mb] + bn) + 0.5 - tapinfo<INTERP>::OFF) * f;
+                    const v2f ph = t * (float)f + (v2f){(float)(p0 - floor(p0)), (float)(p1 - floor(p1))};   // cycles
+                    const float c0 = __builtin_amdgcn_cosf(ph.x), s0 = __builtin_amdgcn_sinf(ph.x);
+                    const float c1 = __builtin_amdgcn_cosf(ph.y), s1 = __builtin_amdgcn_sinf(ph.y);
+                    v0 = (v2f){v0.x * c0 - v0.y * s0, v0.x * s0 + v0.y * c0};
+                    v1 = (v2f){v1.x * c1 - v1.y * s1, v1.x * s1 + v1.y * c1};
                 }
                 if constexpr (WTAB) {
-                    accx[c] = fmaf(wr, vx, fmaf(-wi, vy, accx[c]));
-                    accy[c] = fmaf(wr, vy, fmaf(wi, vx, accy[c]));
-                } else { accx[c] += vx; accy[c] += vy; }
+                    acc += (v2f){wr0 * v0.x - wi0 * v0.y, wr0 * v0.y + wi0 * v0.x};
+                    acc += (v2f){wr1 * v1.x - wi1 * v1.y, wr1 * v1.y + wi1 * v1.x};
+                } else if constexpr (SPLIT || !F32 || K == 1) { acc += v0; acc += v1; }
             }
-        }
 
-        if (st + 1 < nstage) stage_store(buf ^ 1);
-        __syncthreads();
-    }
+            if (st + 1 < nstage) stage_store(buf ^ 1);
+            __syncthreads();
+        }
+    };
+    if (tile_interior) run(std::false_type{}); else run(std::true_type{});
 
     // ---- epilogue: y[i] = pix  (reference src/bf.cu:140); lanes = consecutive i -> coalesced
-#pragma unroll
-    for (int c = 0; c < CPW; ++c)
-        if (ok[c]) st((ST *)P.y, (size_t)(ipix[c] - P.i_begin), cplx<float>{accx[c], accy[c]});
+    {
+        const uint64_t ig = i1 + P.I1 * col;
+        if ((i1 < P.I1) && (col < ncols) && (ig >= P.i_begin) && (ig < i_end))
+            st((ST *)P.y, (size_t)(ig - P.i_begin), cplx<float>{acc.x, acc.y});
+    }
 }
 
 // ------------------------------------------------------------------------------------------
-constexpr int CFG_CPW = 2, CFG_MB = 16, CFG_W = 192;
+constexpr int CFG_WAVES = 8, CFG_MB = 16, CFG_W = 192;
 
 TileConfig tile_config(int dtype, int /*interp*/) {
     TileConfig c;
-    c.tile_cols = WAVES * CFG_CPW;
+    c.tile_cols = CFG_WAVES;
     c.mb = CFG_MB;
     c.window = CFG_W;
-    c.threads = THREADS;
+    c.threads = CFG_WAVES * 64;
     c.lds_bytes = (size_t)2 * CFG_MB * CFG_W * (dtype == 2 ? 4 : 8);
     return c;
 }
@@ -358,10 +417,10 @@ TileConfig tile_config(int dtype, int /*interp*/) {
 template <int INTERP, typename ST>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
-    const dim3 g(ntiles), b(THREADS);
+    const dim3 g(ntiles), b(CFG_WAVES * 64);
 #define QDAS_LAUNCH(FM, WT)                                                                              \
     do {                                                                                                 \
-        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, CFG_CPW, CFG_MB, CFG_W>;                          \
+        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, CFG_WAVES, CFG_MB, CFG_W>;                        \
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                   \
         kfn<<<g, b, lds, s>>>(P);                                                                        \
@@ -374,14 +433,19 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
     return hipGetLastError();
 }
 
+size_t tile_lds_bytes(int dtype, uint64_t N, uint64_t M) {
+    const TileConfig c = tile_config(dtype, 0);
+    const size_t MX = M > N ? M : N;
+    const size_t hdr = (((M + N) * 8) + 15) & ~(size_t)15;
+    size_t body = c.lds_bytes;
+    const size_t scratch = 2 * CFG_WAVES * MX * 4 + 1024;       // prologue scratch aliases the windows
+    if (body < scratch) body = scratch;
+    return hdr + body;
+}
+
 hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s) {
     if (ntiles == 0) return hipSuccess;
-    const TileConfig c = tile_config(dtype, P.flag & 7);
-    const size_t MX = P.M > P.N ? P.M : P.N;
-    const size_t hdr = (((P.M + P.N) * 8) + 15) & ~(size_t)15;
-    size_t body = c.lds_bytes;
-    if (body < 2 * WAVES * MX * 4) body = 2 * WAVES * MX * 4;   // prologue scratch aliases the windows
-    const size_t lds = hdr + body;
+    const size_t lds = tile_lds_bytes(dtype, P.N, P.M);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int interp = P.flag & 7;
 #define QDAS_DT(I)                                                                       \

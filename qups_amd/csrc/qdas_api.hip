@@ -205,8 +205,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     for (uint64_t s = 0; s < z.S && eligible; ++s)
         for (int k = 0; k < 3; ++k) if (g.ast[6 * s + k]) { eligible = false; why = "tiled kernel needs pixel-independent apodization"; }
     pl->tc = tile_config(dt, z.flag & 7);
-    const size_t MX = z.M > z.N ? z.M : z.N;
-    if (eligible && ((z.M + z.N) * 8 + 16 + (pl->tc.lds_bytes > 32 * MX ? pl->tc.lds_bytes : 32 * MX) > 160 * 1024)) {
+    if (eligible && tile_lds_bytes(dt, z.N, z.M) > 80 * 1024) {     // two workgroups per CU
         eligible = false; why = "tiled kernel: N + M too large for the LDS header";
     }
     if (eligible && (z.T < 8)) { eligible = false; why = "tiled kernel needs T >= 8"; }
