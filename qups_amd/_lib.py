@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqdas.so")
+LIB_PATH = os.environ.get("QDAS_LIB") or os.path.join(_HERE, "libqdas.so")   # QDAS_LIB: A/B builds for profiling
 
 # ---- constants (include/qdas.h)
 QDAS_F64, QDAS_F32, QDAS_F16 = 0, 1, 2

@@ -19,8 +19,10 @@
 //        t = ra[m] + rb;  k = rint(t) (magic-number add);  s = t - k  in [-1/2, 1/2];
 //        first tap = window[k], weights = even/odd polynomials in s.
 //  * For every (receiver n, block of MB transmits) the workgroup stages MB fast-time WINDOWS
-//    (W samples starting at A[m]+B[n]) of the channel data into LDS, coalesced along fast time
-//    and double-buffered against the compute of the previous stage; taps are then gathered from
+//    (W samples starting at A[m]+B[n]) of the channel data into LDS with LDS-DMA
+//    (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write; out-of-buffer lanes deliver 0),
+//    coalesced along fast time and double-buffered against the compute of the previous stage
+//    (ablation: register staging cost 17 of 66 ms -- profiles/ablation_r01.txt); taps are then gathered from
 //    LDS with four ds_read_b64 (issued from inline asm: hipcc would merge them into ds_read2_b64,
 //    which measures 2x slower for this gather -- profiles/microbench_r01.txt).
 //  * All resident workgroups walk the traces in the same order, so the channel data streams
@@ -36,6 +38,10 @@
 #include "qdas_kernels.h"
 #include "lanczos_poly.h"
 #include <type_traits>
+
+#ifndef QDAS_ABL
+#define QDAS_ABL 0   // ablation bits for profiling builds only (tools/ablate.sh); 0 in the product
+#endif
 
 namespace qdas {
 
@@ -138,10 +144,9 @@ das_tile_kernel(const TileParams P) {
     constexpr int THREADS = WAVES * 64;
     constexpr int TX = WAVES;                 // one image column per wave
     constexpr int WPW = MB / WAVES;           // windows staged per wave
-    constexpr int CH = W / 64;                // 64-sample chunks per window
     constexpr int SB = (int)sizeof(ST);       // bytes per complex sample
     constexpr bool F32 = (SB == 8);
-    static_assert(MB % WAVES == 0 && W % 64 == 0 && MB % 2 == 0, "staging split");
+    static_assert(MB % WAVES == 0 && MB % 2 == 0, "staging split");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -151,7 +156,10 @@ das_tile_kernel(const TileParams P) {
     float *Aext  = (float *)(Abase + M);              // [M]
     int   *Bbase = (int *)(Aext + M);                 // [N]
     float *Bext  = (float *)(Bbase + N);              // [N]
-    const uint32_t hdr = ((M + N) * 8 + 15) & ~15u;
+    float *PrL   = Bext + N;                          // [3N] receiver positions
+    float *PvL   = PrL + 3 * N;                       // [4M] (virtual) sources + t0
+    float *NvL   = PvL + 4 * M;                       // [3M] transmit normals
+    const uint32_t hdr = ((M + N) * 8 + (3 * N + 7 * M) * 4 + 15) & ~15u;
     ST *win = (ST *)(smem + hdr);                     // [2][MB][W]
     float *part = (float *)(smem + hdr);              // prologue scratch, aliases the windows
     const uint32_t win_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem) + hdr;
@@ -163,7 +171,9 @@ das_tile_kernel(const TileParams P) {
         const uint32_t q = nb / 8, r = nb % 8, xcd = bid % 8, k = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;   // bijective remap
     }
-    const uint32_t tz = bid % P.tiles_z, txi = P.tile_x0 + bid / P.tiles_z;
+    // columns fastest: the tiles an XCD runs concurrently sit at the SAME depth band, so they stage (nearly)
+    // the same window of every trace and the XCD's L2 serves all but the first of them
+    const uint32_t tz = bid / P.tiles_x, txi = P.tile_x0 + bid % P.tiles_x;
     const uint32_t tile_id = tz + P.tiles_z * txi;
 
     // ---- my pixel: lane -> depth, wave -> column.  Out-of-image lanes are clamped onto a real
@@ -186,15 +196,19 @@ das_tile_kernel(const TileParams P) {
         const double r = __builtin_fma(-sd, sd, d2);
         return s0 > 0.f ? __builtin_fma(r, (double)(0.5f / s0), sd) : 0.0;
     };
+    // The geometry tables are read from global memory in the prologue and from their LDS copies in the
+    // main loop: a vector-memory load there would sit behind the stage's LDS-DMA in the in-order vmcnt
+    // queue and expose the DMA latency every stage (measured: 15 of 64 ms).
+    const float *gPv = P.Pv, *gNv = P.Nv, *gPr = P.Pr;
     auto a_of = [&](uint32_t m) -> double {              // tau_tx*fs - t0*fs + OFF, reference src/bf.cu:104-108,114
-        const double rx = (double)px - (double)P.Pv[4 * m], ry = (double)py - (double)P.Pv[4 * m + 1], rz = (double)pz - (double)P.Pv[4 * m + 2];
-        const double dot = rx * (double)P.Nv[3 * m] + ry * (double)P.Nv[3 * m + 1] + rz * (double)P.Nv[3 * m + 2];
+        const double rx = (double)px - (double)gPv[4 * m], ry = (double)py - (double)gPv[4 * m + 1], rz = (double)pz - (double)gPv[4 * m + 2];
+        const double dot = rx * (double)gNv[3 * m] + ry * (double)gNv[3 * m + 1] + rz * (double)gNv[3 * m + 2];
         double dv = dot;
         if (VS) { const double len = dsqrt(rx * rx + ry * ry + rz * rz); dv = DV ? len : copysign(len, dot); }
-        return dv * cf - (double)P.Pv[4 * m + 3] * fs + tapinfo<INTERP>::OFF;
+        return dv * cf - (double)gPv[4 * m + 3] * fs + tapinfo<INTERP>::OFF;
     };
     auto b_of = [&](uint32_t n) -> double {              // tau_rx*fs, reference src/bf.cu:110
-        const double rx = (double)px - (double)P.Pr[3 * n], ry = (double)py - (double)P.Pr[3 * n + 1], rz = (double)pz - (double)P.Pr[3 * n + 2];
+        const double rx = (double)px - (double)gPr[3 * n], ry = (double)py - (double)gPr[3 * n + 1], rz = (double)pz - (double)gPr[3 * n + 2];
         return dsqrt(rx * rx + ry * ry + rz * rz) * cf;
     };
 
@@ -260,6 +274,10 @@ das_tile_kernel(const TileParams P) {
     }
     // every window of every stage strictly inside the record?  (uniform) -> branch-free loop
     const bool tile_interior = (a_lo + b_lo >= 1.0f) && (a_hi + b_hi + (float)(K + 1) < (float)T);
+    for (uint32_t k = tid; k < 3 * N; k += THREADS) PrL[k] = P.Pr[k];
+    for (uint32_t k = tid; k < 4 * M; k += THREADS) PvL[k] = P.Pv[k];
+    for (uint32_t k = tid; k < 3 * M; k += THREADS) NvL[k] = P.Nv[k];
+    gPv = PvL; gNv = NvL; gPr = PrL;
     __syncthreads();
 
     // ---- main loop over stages (mb = transmit block, n = receiver; n is the inner index)
@@ -268,42 +286,44 @@ das_tile_kernel(const TileParams P) {
     v2f acc = {0.f, 0.f};                              // (re, im) of this lane's pixel
     v2f ra[MB / 2];                                    // tx residuals a - A[m] - 1/2 of transmits (2p, 2p+1), packed
     const ST *__restrict__ xg = (const ST *)P.x;
-    ST stg[WPW][CH];                                   // staging registers (global -> LDS)
-
-    auto stage_load = [&](uint32_t st) {               // issue the global loads of stage st
+    // ---- LDS-DMA staging.  One buffer descriptor per stage, based at trace (n, m0): window j starts
+    //      (j*strM + A[m0+j] + B[n]) samples after it.  A lane moves 16 bytes; a wave-instruction 1 KiB.
+    //      Offsets before the base wrap to >= num_records and, like offsets past the end of x, deliver 0.
+    //      Samples outside [0, T) of a trace but inside x read the neighbouring trace: they are only ever
+    //      touched by lanes that the checked loop masks out (select, not multiply).
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr int WB = W * SB;                         // bytes per window
+    constexpr int PCS = WB / 1024;                     // 1 KiB pieces per window
+    static_assert(WB % 1024 == 0, "window must be a whole number of 1 KiB DMA pieces");
+    const uint64_t xbytes = (uint64_t)P.N * P.M * P.T * SB;
+    auto stage_dma = [&](uint32_t st, int buf) {
         const uint32_t n = st % N, m0 = (st / N) * MB;
         const int bn = Bbase[n];
+        const uint64_t off = ((uint64_t)n * P.strN + (uint64_t)m0 * P.strM) * SB;
+        const uint64_t rem = xbytes - off;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + off), 0,
+                                                                    rem > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem, 0x00020000);
 #pragma unroll
         for (int r = 0; r < WPW; ++r) {
-            const uint32_t j = wave + WAVES * r, m = m0 + j;
-            const bool mok = m < M;
-            const int ws = (mok ? Abase[m] : 0) + bn;
-            const ST *tp = xg + ((long)n * (long)P.strN + (long)(mok ? m : 0) * (long)P.strM + (long)ws);
+            const uint32_t j = __builtin_amdgcn_readfirstlane(wave + WAVES * r);
+            const uint32_t m = m0 + j < M ? m0 + j : M - 1;
+            const int ws = __builtin_amdgcn_readfirstlane(Abase[m]) + bn;
+            const int so = (QDAS_ABL & 32) ? (int)(j & 1) * 4096 : (int)(((long)j * (long)P.strM + (long)ws) * SB);      // < 2^31 by plan-time check
 #pragma unroll
-            for (int q = 0; q < CH; ++q) {
-                const int s = ws + q * 64 + lane;
-                stg[r][q] = (mok && s >= 0 && s < T) ? tp[q * 64 + lane] : zero_of(xg);
-            }
-        }
-    };
-    auto stage_store = [&](int buf) {                  // registers -> LDS window buffer
-#pragma unroll
-        for (int r = 0; r < WPW; ++r) {
-            const uint32_t j = wave + WAVES * r;
-#pragma unroll
-            for (int q = 0; q < CH; ++q) win[(buf * MB + j) * W + q * 64 + lane] = stg[r][q];
+            for (int q = 0; q < ((QDAS_ABL & 64) ? 1 : PCS); ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)((unsigned char *)win + ((buf * MB + j) * WB + q * 1024)), 16,
+                                                         lane * 16, so + q * 1024, 0, 0);
         }
     };
 
     auto run = [&](auto check_tag) {
         constexpr bool CHECK = decltype(check_tag)::value;
-        stage_load(0);
-        stage_store(0);
+        stage_dma(0, 0);
         __syncthreads();
         for (uint32_t st = 0; st < nstage; ++st) {
             const uint32_t n = st % N, m0 = (st / N) * MB;
             const int buf = st & 1;
-            if (st + 1 < nstage) stage_load(st + 1);   // in flight during the compute below
+            if (!(QDAS_ABL & 1) && st + 1 < nstage) stage_dma(st + 1, buf ^ 1);   // lands during the compute below
 
             if (n == 0) {                              // new transmit block: refresh the tx residuals
 #pragma unroll
@@ -313,7 +333,7 @@ das_tile_kernel(const TileParams P) {
                 }
             }
             const int bn = Bbase[n];
-            const float rb = (float)(b_of(n) - (double)bn);
+            const float rb = (QDAS_ABL & 2) ? (float)(lane * 2 + 3) + 0.37f * (float)(n & 7) : (float)(b_of(n) - (double)bn);
             // byte address of sample 0 of window j: cbase + j*W*SB; the magic bits are folded in
             const uint32_t cbase = win_off + (uint32_t)buf * (MB * W * SB) - (MAGIC_BITS * (uint32_t)SB);
 
@@ -337,12 +357,18 @@ das_tile_kernel(const TileParams P) {
                 v2f v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
                 if constexpr (F32) {
                     taps_f32 g0, g1;
-                    if constexpr (K == 4) { lds_issue(g0, ad0); lds_issue(g1, ad1); }
+                    if constexpr ((QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { g0.s[k] = (v2f){s.x, t.x}; g1.s[k] = (v2f){t.y, s.y}; } }
+                    else if constexpr (K == 4) { lds_issue(g0, ad0); lds_issue(g1, ad1); }
                     else if constexpr (K == 2) { lds_issue2(g0, ad0); lds_issue2(g1, ad1); g0.s[2] = g0.s[3] = g1.s[2] = g1.s[3] = (v2f){0.f, 0.f}; }
                     else { lds_issue1(g0, ad0); lds_issue1(g1, ad1); g0.s[1] = g0.s[2] = g0.s[3] = g1.s[1] = g1.s[2] = g1.s[3] = (v2f){0.f, 0.f}; }
                     v2f w[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-                    if constexpr (K > 1) weights2<INTERP>(s, w);       // overlaps the LDS latency
+                    if constexpr ((QDAS_ABL & 8) != 0) { w[0] = s; w[1] = t; w[2] = tm; w[3] = s + t; }
+                    else if constexpr (K > 1) weights2<INTERP>(s, w);       // overlaps the LDS latency
                     lds_fence(g0, g1, w);
+                    if (m + 1 >= M) {                      // odd M: the upper half has no transmit (uniform, rare)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) g1.s[k] = (v2f){0.f, 0.f};
+                    }
                     if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; }
                     else if constexpr (SPLIT) {
 #pragma unroll
@@ -354,6 +380,10 @@ das_tile_kernel(const TileParams P) {
                 } else {
                     taps_f16 g0, g1;
                     lds_load_f16<K>(g0, ad0); lds_load_f16<K>(g1, ad1);
+                    if (m + 1 >= M) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) g1.s[k] = (v2f){0.f, 0.f};
+                    }
                     if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; }
                     else {
                         v2f w[4];
@@ -387,8 +417,7 @@ das_tile_kernel(const TileParams P) {
                 } else if constexpr (SPLIT || !F32 || K == 1) { acc += v0; acc += v1; }
             }
 
-            if (st + 1 < nstage) stage_store(buf ^ 1);
-            __syncthreads();
+            if (!(QDAS_ABL & 16)) __syncthreads();     // also drains this wave's DMA (vmcnt) before the buffers swap
         }
     };
     if (tile_interior) run(std::false_type{}); else run(std::true_type{});
@@ -402,7 +431,7 @@ das_tile_kernel(const TileParams P) {
 }
 
 // ------------------------------------------------------------------------------------------
-constexpr int CFG_WAVES = 8, CFG_MB = 16, CFG_W = 192;
+constexpr int CFG_WAVES = 8, CFG_MB = 16, CFG_W = 256;
 
 TileConfig tile_config(int dtype, int /*interp*/) {
     TileConfig c;
@@ -436,7 +465,7 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
 size_t tile_lds_bytes(int dtype, uint64_t N, uint64_t M) {
     const TileConfig c = tile_config(dtype, 0);
     const size_t MX = M > N ? M : N;
-    const size_t hdr = (((M + N) * 8) + 15) & ~(size_t)15;
+    const size_t hdr = (((M + N) * 8 + (3 * N + 7 * M) * 4) + 15) & ~(size_t)15;
     size_t body = c.lds_bytes;
     const size_t scratch = 2 * CFG_WAVES * MX * 4 + 1024;       // prologue scratch aliases the windows
     if (body < scratch) body = scratch;

@@ -209,6 +209,12 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         eligible = false; why = "tiled kernel: N + M too large for the LDS header";
     }
     if (eligible && (z.T < 8)) { eligible = false; why = "tiled kernel needs T >= 8"; }
+    {   // LDS-DMA offsets inside one stage are 32-bit: (mb-1)*strM + window must stay below 2^31 bytes
+        const uint64_t strM = (z.flag & QDAS_FLAG_TPOSE) ? z.T : z.T * z.N;
+        if (eligible && ((uint64_t)pl->tc.mb * strM + 4096) * data_size(dt) >= (1ull << 31)) {
+            eligible = false; why = "tiled kernel: transmit stride too large for 32-bit DMA offsets";
+        }
+    }
     if (desc->kernel == QDAS_KERNEL_TILED && !eligible) return bail(fail(QDAS_EUNSUPPORTED, "%s", why));
     pl->kernel = (eligible && desc->kernel != QDAS_KERNEL_GENERIC) ? QDAS_KERNEL_TILED : QDAS_KERNEL_GENERIC;
 
