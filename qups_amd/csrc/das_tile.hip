@@ -38,6 +38,7 @@
 #include "qdas_kernels.h"
 #include "lanczos_poly.h"
 #include <type_traits>
+#include <cstdlib>
 
 #ifndef QDAS_ABL
 #define QDAS_ABL 0   // ablation bits for profiling builds only (tools/ablate.sh); 0 in the product
@@ -137,8 +138,11 @@ template <int K> __device__ __forceinline__ void lds_load_f16(taps_f16 &t, uint3
 __device__ __forceinline__ float2   zero_of(const float2 *)   { return make_float2(0.f, 0.f); }
 __device__ __forceinline__ uint32_t zero_of(const uint32_t *) { return 0u; }
 
-template <int INTERP, typename ST, bool FMOD, bool WTAB, int WAVES, int MB, int W>
-__global__ void __launch_bounds__(WAVES * 64, WAVES / 2)   // 2 workgroups per CU -> WAVES/2 waves per SIMD
+// CFG: WAVES waves (= image columns) per workgroup, MB transmits per stage, W samples per window,
+//      NBUF window buffers (NBUF-1 stages of LDS-DMA in flight), PSZ bytes per lane and DMA piece (12|16),
+//      BPC workgroups per CU the register budget is sized for.
+template <int INTERP, typename ST, bool FMOD, bool WTAB, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC>
+__global__ void __launch_bounds__(WAVES * 64, WAVES * BPC / 4)
 das_tile_kernel(const TileParams P) {
     constexpr int K = tapinfo<INTERP>::K;
     constexpr int THREADS = WAVES * 64;
@@ -160,7 +164,7 @@ das_tile_kernel(const TileParams P) {
     float *PvL   = PrL + 3 * N;                       // [4M] (virtual) sources + t0
     float *NvL   = PvL + 4 * M;                       // [3M] transmit normals
     const uint32_t hdr = ((M + N) * 8 + (3 * N + 7 * M) * 4 + 15) & ~15u;
-    ST *win = (ST *)(smem + hdr);                     // [2][MB][W]
+    ST *win = (ST *)(smem + hdr);                     // [NBUF][MB][W]
     float *part = (float *)(smem + hdr);              // prologue scratch, aliases the windows
     const uint32_t win_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem) + hdr;
 
@@ -285,7 +289,6 @@ das_tile_kernel(const TileParams P) {
     const uint32_t nstage = nmb * N;
     v2f acc = {0.f, 0.f};                              // (re, im) of this lane's pixel
     v2f ra[MB / 2];                                    // tx residuals a - A[m] - 1/2 of transmits (2p, 2p+1), packed
-    const ST *__restrict__ xg = (const ST *)P.x;
     // ---- LDS-DMA staging.  One buffer descriptor per stage, based at trace (n, m0): window j starts
     //      (j*strM + A[m0+j] + B[n]) samples after it.  A lane moves 16 bytes; a wave-instruction 1 KiB.
     //      Offsets before the base wrap to >= num_records and, like offsets past the end of x, deliver 0.
@@ -293,8 +296,12 @@ das_tile_kernel(const TileParams P) {
     //      touched by lanes that the checked loop masks out (select, not multiply).
     typedef __attribute__((address_space(3))) void lds_void;
     constexpr int WB = W * SB;                         // bytes per window
-    constexpr int PCS = WB / 1024;                     // 1 KiB pieces per window
-    static_assert(WB % 1024 == 0, "window must be a whole number of 1 KiB DMA pieces");
+    // (only 16-byte pieces give a contiguous LDS image: a 12-byte piece still advances 16 bytes per lane --
+    //  measured with tools/scratch/dma12.hip)
+    constexpr int PB = 1024;                           // bytes per full DMA piece (one wave-instruction x 16 B)
+    constexpr int PCS = (WB + PB - 1) / PB;            // pieces per window; the last one may use fewer lanes
+    constexpr int NDMA = WPW * PCS;                    // DMA instructions per wave and stage
+    static_assert(WB % 16 == 0 && PSZ == 16, "window must be a whole number of 16-byte lanes");
     const uint64_t xbytes = (uint64_t)P.N * P.M * P.T * SB;
     auto stage_dma = [&](uint32_t st, int buf) {
         const uint32_t n = st % N, m0 = (st / N) * MB;
@@ -310,20 +317,26 @@ das_tile_kernel(const TileParams P) {
             const int ws = __builtin_amdgcn_readfirstlane(Abase[m]) + bn;
             const int so = (QDAS_ABL & 32) ? (int)(j & 1) * 4096 : (int)(((long)j * (long)P.strM + (long)ws) * SB);      // < 2^31 by plan-time check
 #pragma unroll
-            for (int q = 0; q < ((QDAS_ABL & 64) ? 1 : PCS); ++q)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void *)((unsigned char *)win + ((buf * MB + j) * WB + q * 1024)), 16,
-                                                         lane * 16, so + q * 1024, 0, 0);
+            for (int q = 0; q < ((QDAS_ABL & 64) ? 1 : PCS); ++q) {
+                lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * MB + j) * WB + q * PB));
+                if (lane * 16 < WB - q * PB)             // trailing partial piece: upper lanes masked off
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, lane * 16, so + q * PB, 0, 0);
+            }
         }
     };
 
     auto run = [&](auto check_tag) {
         constexpr bool CHECK = decltype(check_tag)::value;
-        stage_dma(0, 0);
-        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < NBUF - 1; ++b) if ((uint32_t)b < nstage) stage_dma(b, b);
+        // counted wait: everything but the newest (NBUF-2) stages has landed; then publish to the workgroup
+        if (nstage >= (uint32_t)(NBUF - 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        int buf = 0;
         for (uint32_t st = 0; st < nstage; ++st) {
             const uint32_t n = st % N, m0 = (st / N) * MB;
-            const int buf = st & 1;
-            if (!(QDAS_ABL & 1) && st + 1 < nstage) stage_dma(st + 1, buf ^ 1);   // lands during the compute below
+            const bool more = st + (NBUF - 1) < nstage;
+            if (!(QDAS_ABL & 1) && more) stage_dma(st + (NBUF - 1), (buf + NBUF - 1) % NBUF);   // lands during the next NBUF-1 stages
 
             if (n == 0) {                              // new transmit block: refresh the tx residuals
 #pragma unroll
@@ -417,7 +430,12 @@ das_tile_kernel(const TileParams P) {
                 } else if constexpr (SPLIT || !F32 || K == 1) { acc += v0; acc += v1; }
             }
 
-            if (!(QDAS_ABL & 16)) __syncthreads();     // also drains this wave's DMA (vmcnt) before the buffers swap
+            // stage st+1 must have landed (all but the NBUF-2 newest DMA groups), all my LDS reads are done
+            if (!(QDAS_ABL & 16)) {
+                if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NBUF - 2) * NDMA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            buf = (buf + 1 == NBUF) ? 0 : buf + 1;
         }
     };
     if (tile_interior) run(std::false_type{}); else run(std::true_type{});
@@ -431,25 +449,49 @@ das_tile_kernel(const TileParams P) {
 }
 
 // ------------------------------------------------------------------------------------------
-constexpr int CFG_WAVES = 8, CFG_MB = 16, CFG_W = 256;
+// Launch configurations.  cfg 0: 16-wave workgroup = 64 x 16 pixel tile, 3 window buffers, one workgroup per CU;
+//                         cfg 1: 8-wave workgroup  = 64 x 8 pixel tile, 2 buffers, two workgroups per CU.
+struct Cfg { int waves, mb, w, nbuf, psz, bpc; };
+static constexpr Cfg CFGS[2] = {{16, 16, 192, 3, 16, 1}, {8, 16, 192, 2, 16, 2}};
 
-TileConfig tile_config(int dtype, int /*interp*/) {
-    TileConfig c;
-    c.tile_cols = CFG_WAVES;
-    c.mb = CFG_MB;
-    c.window = CFG_W;
-    c.threads = CFG_WAVES * 64;
-    c.lds_bytes = (size_t)2 * CFG_MB * CFG_W * (dtype == 2 ? 4 : 8);
+static int active_cfg() {
+    static int c = -1;
+    if (c < 0) { const char *e = getenv("QDAS_TILE_CFG"); c = (e && e[0] == '1') ? 1 : 0; }
     return c;
 }
 
-template <int INTERP, typename ST>
+TileConfig tile_config(int dtype, int /*interp*/) {
+    const Cfg &g = CFGS[active_cfg()];
+    TileConfig c;
+    c.tile_cols = g.waves;
+    c.mb = g.mb;
+    c.window = g.w;
+    c.threads = g.waves * 64;
+    c.lds_bytes = (size_t)g.nbuf * g.mb * g.w * (dtype == 2 ? 4 : 8);
+    return c;
+}
+
+size_t tile_lds_bytes(int dtype, uint64_t N, uint64_t M) {
+    const Cfg &g = CFGS[active_cfg()];
+    const TileConfig c = tile_config(dtype, 0);
+    const size_t MX = M > N ? M : N;
+    const size_t hdr = (((M + N) * 8 + (3 * N + 7 * M) * 4) + 15) & ~(size_t)15;
+    size_t body = c.lds_bytes;
+    const size_t scratch = 2 * (size_t)g.waves * MX * 4 + 1024;   // prologue scratch aliases the windows
+    if (body < scratch) body = scratch;
+    return hdr + body;
+}
+size_t tile_lds_limit() { return (size_t)(160 * 1024) / CFGS[active_cfg()].bpc; }
+
+template <int INTERP, typename ST, int CI>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
+    constexpr Cfg G = CFGS[CI];
+    constexpr int W = (sizeof(ST) == 4 && G.psz == 12) ? G.w : G.w;     // fp16: W*4 bytes must still be whole pieces
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
-    const dim3 g(ntiles), b(CFG_WAVES * 64);
+    const dim3 g(ntiles), b(G.waves * 64);
 #define QDAS_LAUNCH(FM, WT)                                                                              \
     do {                                                                                                 \
-        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, CFG_WAVES, CFG_MB, CFG_W>;                        \
+        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, G.waves, G.mb, W, G.nbuf, G.psz, G.bpc>;          \
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                   \
         kfn<<<g, b, lds, s>>>(P);                                                                        \
@@ -462,23 +504,14 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
     return hipGetLastError();
 }
 
-size_t tile_lds_bytes(int dtype, uint64_t N, uint64_t M) {
-    const TileConfig c = tile_config(dtype, 0);
-    const size_t MX = M > N ? M : N;
-    const size_t hdr = (((M + N) * 8 + (3 * N + 7 * M) * 4) + 15) & ~(size_t)15;
-    size_t body = c.lds_bytes;
-    const size_t scratch = 2 * CFG_WAVES * MX * 4 + 1024;       // prologue scratch aliases the windows
-    if (body < scratch) body = scratch;
-    return hdr + body;
-}
-
 hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s) {
     if (ntiles == 0) return hipSuccess;
     const size_t lds = tile_lds_bytes(dtype, P.N, P.M);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const int interp = P.flag & 7;
-#define QDAS_DT(I)                                                                       \
-    (dtype == 2 ? launch_tile_i<I, uint32_t>(P, ntiles, lds, s) : launch_tile_i<I, float2>(P, ntiles, lds, s))
+    if (lds > tile_lds_limit()) return hipErrorInvalidValue;
+    const int interp = P.flag & 7, ci = active_cfg();
+#define QDAS_DT(I)                                                                                         \
+    (ci == 0 ? (dtype == 2 ? launch_tile_i<I, uint32_t, 0>(P, ntiles, lds, s) : launch_tile_i<I, float2, 0>(P, ntiles, lds, s)) \
+             : (dtype == 2 ? launch_tile_i<I, uint32_t, 1>(P, ntiles, lds, s) : launch_tile_i<I, float2, 1>(P, ntiles, lds, s)))
     switch (interp) {
         case 0: return QDAS_DT(0);
         case 1: case 4: return QDAS_DT(1);

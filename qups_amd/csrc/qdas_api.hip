@@ -205,7 +205,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     for (uint64_t s = 0; s < z.S && eligible; ++s)
         for (int k = 0; k < 3; ++k) if (g.ast[6 * s + k]) { eligible = false; why = "tiled kernel needs pixel-independent apodization"; }
     pl->tc = tile_config(dt, z.flag & 7);
-    if (eligible && tile_lds_bytes(dt, z.N, z.M) > 80 * 1024) {     // two workgroups per CU
+    if (eligible && tile_lds_bytes(dt, z.N, z.M) > tile_lds_limit()) {
         eligible = false; why = "tiled kernel: N + M too large for the LDS header";
     }
     if (eligible && (z.T < 8)) { eligible = false; why = "tiled kernel needs T >= 8"; }

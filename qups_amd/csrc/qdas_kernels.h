@@ -48,6 +48,7 @@ struct TileParams {
 struct TileConfig { int tile_cols; int mb; int window; size_t lds_bytes; int threads; };
 TileConfig tile_config(int dtype, int interp);
 size_t tile_lds_bytes(int dtype, uint64_t N, uint64_t M);   // dynamic LDS of one workgroup
+size_t tile_lds_limit();                                      // LDS budget of one workgroup in the active configuration
 hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s);
 
 // ---- split-delay kernel (das_lut.hip)

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile.sh output directory: per-kernel average duration (kernel trace) and PMC
+counters averaged per dispatch of the dominant kernel."""
+import csv, glob, os, sys, collections
+
+out = sys.argv[1]
+def find(pat):
+    r = glob.glob(os.path.join(out, pat), recursive=True)
+    return r[0] if r else None
+
+kt = find("trace/**/*kernel_trace.csv")
+dom = None
+if kt:
+    dur = collections.defaultdict(list)
+    for row in csv.DictReader(open(kt)):
+        dur[row["Kernel_Name"]].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6)
+    print("== kernel trace (ms): name, calls, avg, min, max, total")
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:8]:
+        print(f"{k[:100]:100s} {len(v):4d} {sum(v)/len(v):10.3f} {min(v):10.3f} {max(v):10.3f} {sum(v):10.3f}")
+    dom = max(dur.items(), key=lambda kv: sum(kv[1]))[0]
+    print("dominant kernel:", dom[:120])
+    avg_ms = sum(dur[dom]) / len(dur[dom])
+st = find("trace/**/*kernel_stats.csv")
+if st:
+    print("== rocprofv3 --stats (kernel_stats.csv)")
+    for i, l in enumerate(open(st)):
+        if i < 6: print(l.rstrip()[:220])
+print("== PMC (average per dispatch of the dominant kernel)")
+vals = {}
+for f in sorted(glob.glob(os.path.join(out, "pmc_*/**/*counter_collection.csv"), recursive=True)):
+    acc = collections.defaultdict(list)
+    for row in csv.DictReader(open(f)):
+        if dom is None or row["Kernel_Name"] == dom:
+            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k, v in acc.items():
+        vals[k] = sum(v) / len(v)
+        print(f"{k:28s} {vals[k]:18.1f}   (n={len(v)})")
+if kt and "GRBM_GUI_ACTIVE" in vals:
+    print(f"effective clock = GRBM_GUI_ACTIVE / kernel time = {vals['GRBM_GUI_ACTIVE'] / (avg_ms * 1e-3) / 1e9:.3f} GHz  (kernel {avg_ms:.3f} ms)")
+if "FETCH_SIZE" in vals:
+    print(f"FETCH_SIZE raw (KiB units -> bytes x1024): {vals['FETCH_SIZE'] * 1024 / 1e9:.3f} GB; x2 gfx950 correction for wide loads: {vals['FETCH_SIZE'] * 2048 / 1e9:.3f} GB")
+if "WRITE_SIZE" in vals:
+    print(f"WRITE_SIZE raw: {vals['WRITE_SIZE'] * 1024 / 1e9:.4f} GB")
+if "TCC_HIT_sum" in vals:
+    h, m = vals["TCC_HIT_sum"], vals["TCC_MISS_sum"]
+    print(f"L2 hit rate = {h / (h + m):.4f}")
