@@ -38,6 +38,7 @@
 #include "qdas_kernels.h"
 #include "lanczos_poly.h"
 #include <type_traits>
+#include <utility>
 #include <cstdlib>
 
 #ifndef QDAS_ABL
@@ -107,15 +108,14 @@ __device__ __forceinline__ float wave_max(float v) {
 //      after lds_fence(), which ties the registers through the s_waitcnt so the compiler cannot
 //      hoist a consumer above it (cdna_hip_programming.md section 5.4 rule 18 / 5.7).
 struct taps_f32 { v2f s[4]; };
-__device__ __forceinline__ void lds_issue(taps_f32 &t, uint32_t addr) {
-    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24"
-                 : "=&v"(t.s[0]), "=&v"(t.s[1]), "=&v"(t.s[2]), "=&v"(t.s[3]) : "v"(addr));
-}
-__device__ __forceinline__ void lds_issue1(taps_f32 &t, uint32_t addr) {
-    asm volatile("ds_read_b64 %0, %1" : "=&v"(t.s[0]) : "v"(addr));
-}
-__device__ __forceinline__ void lds_issue2(taps_f32 &t, uint32_t addr) {
-    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8" : "=&v"(t.s[0]), "=&v"(t.s[1]) : "v"(addr));
+template <int K, int OFF> __device__ __forceinline__ void lds_issue(taps_f32 &t, uint32_t addr) {
+    if constexpr (K == 4)
+        asm volatile("ds_read_b64 %0, %4 offset:%5\n\tds_read_b64 %1, %4 offset:%6\n\tds_read_b64 %2, %4 offset:%7\n\tds_read_b64 %3, %4 offset:%8"
+                     : "=&v"(t.s[0]), "=&v"(t.s[1]), "=&v"(t.s[2]), "=&v"(t.s[3]) : "v"(addr), "n"(OFF), "n"(OFF + 8), "n"(OFF + 16), "n"(OFF + 24));
+    else if constexpr (K == 2)
+        asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4" : "=&v"(t.s[0]), "=&v"(t.s[1]) : "v"(addr), "n"(OFF), "n"(OFF + 8));
+    else
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=&v"(t.s[0]) : "v"(addr), "n"(OFF));
 }
 // The weights are tied through the wait as well, so that their evaluation is scheduled BEFORE it
 // (between the issue of the loads and the wait: that is what hides the LDS latency).
@@ -124,6 +124,11 @@ __device__ __forceinline__ void lds_fence(taps_f32 &a, taps_f32 &b, v2f (&w)[4])
                  : "+v"(a.s[0]), "+v"(a.s[1]), "+v"(a.s[2]), "+v"(a.s[3]), "+v"(b.s[0]), "+v"(b.s[1]), "+v"(b.s[2]), "+v"(b.s[3]),
                    "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
 }
+template <int... Is, typename F> __device__ __forceinline__ void unroll_impl(std::integer_sequence<int, Is...>, F &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void unroll(F &&f) { unroll_impl(std::make_integer_sequence<int, N>{}, f); }
+
 // fp16 data: 4-byte samples; plain loads (ds_read_b32 pairs merge without penalty), widened to fp32
 struct taps_f16 { v2f s[4]; };
 template <int K> __device__ __forceinline__ void lds_load_f16(taps_f16 &t, uint32_t addr) {
@@ -198,7 +203,8 @@ das_tile_kernel(const TileParams P) {
         const float s0 = __builtin_sqrtf((float)d2);
         const double sd = (double)s0;
         const double r = __builtin_fma(-sd, sd, d2);
-        return s0 > 0.f ? __builtin_fma(r, (double)(0.5f / s0), sd) : 0.0;
+        // (v_rcp_f32 is plenty for the correction term; s0 == 0 gives r == 0 and inf*0 -> guard with a max)
+        return __builtin_fma(r, (double)(0.5f * __builtin_amdgcn_rcpf(fmaxf(s0, 1.0e-30f))), sd);
     };
     // The geometry tables are read from global memory in the prologue and from their LDS copies in the
     // main loop: a vector-memory load there would sit behind the stage's LDS-DMA in the in-order vmcnt
@@ -303,8 +309,7 @@ das_tile_kernel(const TileParams P) {
     constexpr int NDMA = WPW * PCS;                    // DMA instructions per wave and stage
     static_assert(WB % 16 == 0 && PSZ == 16, "window must be a whole number of 16-byte lanes");
     const uint64_t xbytes = (uint64_t)P.N * P.M * P.T * SB;
-    auto stage_dma = [&](uint32_t st, int buf) {
-        const uint32_t n = st % N, m0 = (st / N) * MB;
+    auto stage_dma = [&](uint32_t n, uint32_t m0, int buf) {     // stage (receiver n, transmit block at m0)
         const int bn = Bbase[n];
         const uint64_t off = ((uint64_t)n * P.strN + (uint64_t)m0 * P.strM) * SB;
         const uint64_t rem = xbytes - off;
@@ -327,16 +332,21 @@ das_tile_kernel(const TileParams P) {
 
     auto run = [&](auto check_tag) {
         constexpr bool CHECK = decltype(check_tag)::value;
+        uint32_t pn = 0, pm0 = 0;                          // stage the DMA front is at (NBUF-1 stages ahead)
 #pragma unroll
-        for (int b = 0; b < NBUF - 1; ++b) if ((uint32_t)b < nstage) stage_dma(b, b);
+        for (int b = 0; b < NBUF - 1; ++b)
+            if ((uint32_t)b < nstage) { stage_dma(pn, pm0, b); if (++pn == N) { pn = 0; pm0 += MB; } }
         // counted wait: everything but the newest (NBUF-2) stages has landed; then publish to the workgroup
         if (nstage >= (uint32_t)(NBUF - 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         int buf = 0;
-        for (uint32_t st = 0; st < nstage; ++st) {
-            const uint32_t n = st % N, m0 = (st / N) * MB;
+        uint32_t n = 0, m0 = 0;
+        for (uint32_t st = 0; st < nstage; ++st, n = (n + 1 == N ? 0 : n + 1), m0 += (n == 0 ? MB : 0)) {
             const bool more = st + (NBUF - 1) < nstage;
-            if (!(QDAS_ABL & 1) && more) stage_dma(st + (NBUF - 1), (buf + NBUF - 1) % NBUF);   // lands during the next NBUF-1 stages
+            if (!(QDAS_ABL & 1) && more) {               // lands during the next NBUF-1 stages
+                stage_dma(pn, pm0, (buf + NBUF - 1) % NBUF);
+                if (++pn == N) { pn = 0; pm0 += MB; }
+            }
 
             if (n == 0) {                              // new transmit block: refresh the tx residuals
 #pragma unroll
@@ -347,40 +357,46 @@ das_tile_kernel(const TileParams P) {
             }
             const int bn = Bbase[n];
             const float rb = (QDAS_ABL & 2) ? (float)(lane * 2 + 3) + 0.37f * (float)(n & 7) : (float)(b_of(n) - (double)bn);
-            // byte address of sample 0 of window j: cbase + j*W*SB; the magic bits are folded in
-            const uint32_t cbase = win_off + (uint32_t)buf * (MB * W * SB) - (MAGIC_BITS * (uint32_t)SB);
+            // LDS byte address of a tap = bits(t + MAGIC)*SB + cbase + (window, tap) immediate
+            const uint32_t cbase = win_off + (uint32_t)buf * (MB * WB) - (MAGIC_BITS * (uint32_t)SB);
 
-#pragma unroll
-            for (int p = 0; p < MB / 2; ++p) {
-                const uint32_t m = m0 + 2 * p;            // transmits m, m+1 ride in the two halves
-                if (m >= M) break;
+            auto pairs = [&](auto pc, auto tailc) {       // transmits (m0+2p, m0+2p+1) ride in the two halves
+                constexpr int p = decltype(pc)::value;
+                constexpr bool TAIL = decltype(tailc)::value;   // last, partial transmit block: bounds checks
+                const uint32_t m = m0 + 2 * p;
+                if constexpr (TAIL) { if (m >= M) return; }
+                const bool upper = !TAIL || (m + 1 < M);  // the upper half carries a real transmit
                 float wr0 = 1.f, wi0 = 0.f, wr1 = 1.f, wi1 = 0.f;
                 if constexpr (WTAB) {
                     const float2 wa = ((const float2 *)P.wtab)[n + (size_t)N * m];
-                    const float2 wb = (m + 1 < M) ? ((const float2 *)P.wtab)[n + (size_t)N * (m + 1)] : make_float2(0.f, 0.f);
+                    const float2 wb = upper ? ((const float2 *)P.wtab)[n + (size_t)N * (m + 1)] : make_float2(0.f, 0.f);
                     wr0 = wa.x; wi0 = wa.y; wr1 = wb.x; wi1 = wb.y;
-                    if (wr0 == 0.f && wi0 == 0.f && wr1 == 0.f && wi1 == 0.f) continue;   // zero weights: skip (src/bf.cu:122,126)
+                    if (wr0 == 0.f && wi0 == 0.f && wr1 == 0.f && wi1 == 0.f) return;   // zero weights: skip (src/bf.cu:122,126)
                 }
                 const v2f t = ra[p] + rb;                 // = tau*fs + OFF - (A+B) - 1/2
                 const v2f tm = t + MAGIC;
                 const v2f s = t - (tm - MAGIC);           // in [-1/2, 1/2]
-                const uint32_t ad0 = __float_as_uint(tm.x) * (uint32_t)SB + (cbase + (uint32_t)(2 * p) * (W * SB));
-                const uint32_t ad1 = __float_as_uint(tm.y) * (uint32_t)SB + (cbase + (uint32_t)(2 * p + 1) * (W * SB));
+                const uint32_t ad0 = __float_as_uint(tm.x) * (uint32_t)SB + cbase;
+                const uint32_t ad1 = __float_as_uint(tm.y) * (uint32_t)SB + cbase;
                 constexpr bool SPLIT = CHECK || FMOD || WTAB;       // the two halves need separate post-processing
                 v2f v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
                 if constexpr (F32) {
                     taps_f32 g0, g1;
                     if constexpr ((QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { g0.s[k] = (v2f){s.x, t.x}; g1.s[k] = (v2f){t.y, s.y}; } }
-                    else if constexpr (K == 4) { lds_issue(g0, ad0); lds_issue(g1, ad1); }
-                    else if constexpr (K == 2) { lds_issue2(g0, ad0); lds_issue2(g1, ad1); g0.s[2] = g0.s[3] = g1.s[2] = g1.s[3] = (v2f){0.f, 0.f}; }
-                    else { lds_issue1(g0, ad0); lds_issue1(g1, ad1); g0.s[1] = g0.s[2] = g0.s[3] = g1.s[1] = g1.s[2] = g1.s[3] = (v2f){0.f, 0.f}; }
+                    else {
+                        lds_issue<K, (2 * p) * WB>(g0, ad0); lds_issue<K, (2 * p + 1) * WB>(g1, ad1);
+                        if constexpr (K < 4) { g0.s[2] = g0.s[3] = g1.s[2] = g1.s[3] = (v2f){0.f, 0.f}; }
+                        if constexpr (K < 2) { g0.s[1] = g1.s[1] = (v2f){0.f, 0.f}; }
+                    }
                     v2f w[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
                     if constexpr ((QDAS_ABL & 8) != 0) { w[0] = s; w[1] = t; w[2] = tm; w[3] = s + t; }
                     else if constexpr (K > 1) weights2<INTERP>(s, w);       // overlaps the LDS latency
                     lds_fence(g0, g1, w);
-                    if (m + 1 >= M) {                      // odd M: the upper half has no transmit (uniform, rare)
+                    if constexpr (TAIL) {
+                        if (!upper) {                       // odd M: no transmit in the upper half (uniform, rare)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) g1.s[k] = (v2f){0.f, 0.f};
+                            for (int k = 0; k < 4; ++k) g1.s[k] = (v2f){0.f, 0.f};
+                        }
                     }
                     if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; }
                     else if constexpr (SPLIT) {
@@ -392,10 +408,12 @@ das_tile_kernel(const TileParams P) {
                     }
                 } else {
                     taps_f16 g0, g1;
-                    lds_load_f16<K>(g0, ad0); lds_load_f16<K>(g1, ad1);
-                    if (m + 1 >= M) {
+                    lds_load_f16<K>(g0, ad0 + (2 * p) * WB); lds_load_f16<K>(g1, ad1 + (2 * p + 1) * WB);
+                    if constexpr (TAIL) {
+                        if (!upper) {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) g1.s[k] = (v2f){0.f, 0.f};
+                            for (int k = 0; k < K; ++k) g1.s[k] = (v2f){0.f, 0.f};
+                        }
                     }
                     if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; }
                     else {
@@ -406,15 +424,15 @@ das_tile_kernel(const TileParams P) {
                     }
                 }
                 if constexpr (CHECK) {                    // edge rule: all taps in [0,T) and tau >= 0
-                    const uint32_t mb = m + 1 < M ? m + 1 : m;
+                    const uint32_t mb = upper ? m + 1 : m;
                     const int ws0 = Abase[m] + bn, ws1 = Abase[mb] + bn;
                     const float lo0 = tapinfo<INTERP>::LO - 0.5f - (float)ws0, hi0 = (float)(T - K + 1 - ws0) - 0.5f;
                     const float lo1 = tapinfo<INTERP>::LO - 0.5f - (float)ws1, hi1 = (float)(T - K + 1 - ws1) - 0.5f;
-                    const bool k0 = (t.x >= lo0) && (t.x < hi0), k1 = (t.y >= lo1) && (t.y < hi1) && (m + 1 < M);
+                    const bool k0 = (t.x >= lo0) && (t.x < hi0), k1 = (t.y >= lo1) && (t.y < hi1) && upper;
                     v0 = k0 ? v0 : (v2f){0.f, 0.f}; v1 = k1 ? v1 : (v2f){0.f, 0.f};
                 }
                 if constexpr (FMOD) {                     // reference src/bf.cu:117: w = exp(2j pi fmod tau)
-                    const uint32_t mb = m + 1 < M ? m + 1 : m;
+                    const uint32_t mb = upper ? m + 1 : m;
                     const double f = P.fmod / fs;         // tau*fs = t + 1/2 + ws - OFF
                     const double p0 = ((double)(Abase[m] + bn) + 0.5 - tapinfo<INTERP>::OFF) * f;
                     const double p1 = ((double)(Abase[mb] + bn) + 0.5 - tapinfo<INTERP>::OFF) * f;
@@ -428,7 +446,9 @@ das_tile_kernel(const TileParams P) {
                     acc += (v2f){wr0 * v0.x - wi0 * v0.y, wr0 * v0.y + wi0 * v0.x};
                     acc += (v2f){wr1 * v1.x - wi1 * v1.y, wr1 * v1.y + wi1 * v1.x};
                 } else if constexpr (SPLIT || !F32 || K == 1) { acc += v0; acc += v1; }
-            }
+            };
+            if (m0 + MB <= M) unroll<MB / 2>([&](auto pc) { pairs(pc, std::false_type{}); });   // full block: check-free
+            else              unroll<MB / 2>([&](auto pc) { pairs(pc, std::true_type{}); });
 
             // stage st+1 must have landed (all but the NBUF-2 newest DMA groups), all my LDS reads are done
             if (!(QDAS_ABL & 16)) {
