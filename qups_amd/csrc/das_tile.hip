@@ -472,11 +472,15 @@ das_tile_kernel(const TileParams P) {
 // Launch configurations.  cfg 0: 16-wave workgroup = 64 x 16 pixel tile, 3 window buffers, one workgroup per CU;
 //                         cfg 1: 8-wave workgroup  = 64 x 8 pixel tile, 2 buffers, two workgroups per CU.
 struct Cfg { int waves, mb, w, nbuf, psz, bpc; };
-static constexpr Cfg CFGS[2] = {{16, 16, 192, 3, 16, 1}, {8, 16, 192, 2, 16, 2}};
+static constexpr Cfg CFGS[4] = {{16, 16, 192, 3, 16, 1}, {8, 16, 192, 2, 16, 2}, {16, 32, 192, 3, 16, 1}, {16, 32, 192, 2, 16, 1}};
 
+#define QDAS_DEFAULT_CFG 3
 static int active_cfg() {
+#ifndef QDAS_ALL_CFGS
+    return QDAS_DEFAULT_CFG;
+#endif
     static int c = -1;
-    if (c < 0) { const char *e = getenv("QDAS_TILE_CFG"); c = (e && e[0] == '1') ? 1 : 0; }
+    if (c < 0) { const char *e = getenv("QDAS_TILE_CFG"); c = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : QDAS_DEFAULT_CFG; }
     return c;
 }
 
@@ -529,9 +533,12 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     const size_t lds = tile_lds_bytes(dtype, P.N, P.M);
     if (lds > tile_lds_limit()) return hipErrorInvalidValue;
     const int interp = P.flag & 7, ci = active_cfg();
-#define QDAS_DT(I)                                                                                         \
-    (ci == 0 ? (dtype == 2 ? launch_tile_i<I, uint32_t, 0>(P, ntiles, lds, s) : launch_tile_i<I, float2, 0>(P, ntiles, lds, s)) \
-             : (dtype == 2 ? launch_tile_i<I, uint32_t, 1>(P, ntiles, lds, s) : launch_tile_i<I, float2, 1>(P, ntiles, lds, s)))
+#define QDAS_CI(I, C) (dtype == 2 ? launch_tile_i<I, uint32_t, C>(P, ntiles, lds, s) : launch_tile_i<I, float2, C>(P, ntiles, lds, s))
+#ifdef QDAS_ALL_CFGS
+#define QDAS_DT(I) (ci == 0 ? QDAS_CI(I, 0) : ci == 1 ? QDAS_CI(I, 1) : ci == 2 ? QDAS_CI(I, 2) : QDAS_CI(I, 3))
+#else
+#define QDAS_DT(I) QDAS_CI(I, QDAS_DEFAULT_CFG)
+#endif
     switch (interp) {
         case 0: return QDAS_DT(0);
         case 1: case 4: return QDAS_DT(1);
@@ -540,6 +547,7 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
         case 5: return QDAS_DT(5);
     }
 #undef QDAS_DT
+#undef QDAS_CI
     return hipErrorInvalidValue;
 }
 
