@@ -7,4 +7,8 @@ this package is the host-side mirror of the reference's interface for that path.
 """
 from .das_spec import DasError, DasPlan, DasProblem, build_problem, das_spec, parse_options  # noqa: F401
 
-__all__ = ["das_spec", "DasPlan", "DasProblem", "DasError", "build_problem", "parse_options"]
+from .interpd import das_lut, sample2sep, wsinterpd2  # noqa: F401,E402
+from .ultrasound import ChannelData, Scan, Sequence, Transducer, UltrasoundSystem  # noqa: F401,E402
+
+__all__ = ["das_spec", "DasPlan", "DasProblem", "DasError", "build_problem", "parse_options", "das_lut", "sample2sep",
+           "wsinterpd2", "UltrasoundSystem", "Transducer", "Sequence", "Scan", "ChannelData"]

@@ -1,0 +1,175 @@
+"""Split-delay ("look-up table") sampling: the Python mirror of the reference's
+``ChannelData.sample2sep`` -> ``wsinterpd2`` path that ``bfDAS`` / ``bfDASLUT`` / ``bfEikonal`` / ``focusTx``
+use (reference ``src/ChannelData.m:1338-1447``, ``kern/wsinterpd2.m:1-320``; device kernel
+``src/interpd.cu:344-396``).  The compute is ``qdas_das_lut`` of ``libqdas.so`` (``include/qdas.h``).
+
+    y[i,(n),(m),f] = sum  w[i,n,m] * exp(omega * s) * sample(x[:,n,m,f], s),     s = t_rx[i,n] + t_tx[i,m]
+
+Differences from the reference by design: outputs are owned by one lane and summed in a fixed order
+(deterministic; the reference uses float atomics, ``src/interpd.cu:339,393``), and out-of-support samples
+are exactly 0 (the device's ``no_v``; the ``extrapval`` argument of the MATLAB branch is accepted only as 0/NaN).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .das_spec import DasError, _cast_data, _colmajor, _is_torch, _PREC
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _real_dtype(prec):
+    torch = _torch()
+    return torch.float64 if prec == "double" else torch.float32
+
+
+def das_lut(x, tau_rx, tau_tx, *, interp="linear", w=None, keep_rx=False, keep_tx=False, omega=0.0, prec=None,
+            tpose=False, device=None):
+    """Weighted, phase-rotated sampling with separable delays (sample units, 0-based: ``x(1)`` in MATLAB
+    is ``t == 0``, reference ``kern/wsinterpd2.m:20``).
+
+    ``x``: ``T x N x M x F...`` (``T x M x N`` with ``tpose``); ``tau_rx``: ``I... x N``; ``tau_tx``: ``I... x M``
+    (same leading pixel dims); ``w``: broadcastable to ``I... x N x M`` (real or complex) or ``None``;
+    ``omega``: the IMAGINARY part of the reference's ``omega = 2i*pi*fmod/fs`` (``src/ChannelData.m:1439``).
+    Returns ``I... x [1|N] x [1|M] x F...``.
+    """
+    torch = _torch()
+    L = _lib.lib()
+    if not torch.cuda.is_available():
+        raise RuntimeError("qups_amd: no HIP device visible -- the sampling path has no CPU fallback")
+    if interp not in _lib.INTERP_FLAGS:
+        raise DasError("Interp option not recognized: " + str(interp))
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    if prec is None:
+        from .das_spec import _default_prec
+        prec = _default_prec(x)
+    xd = _cast_data(x, prec, dev)
+    while xd.ndim < 3:
+        xd = xd.unsqueeze(-1)
+    T = xd.shape[0]
+    N, M = (xd.shape[2], xd.shape[1]) if tpose else (xd.shape[1], xd.shape[2])
+    fsz = tuple(xd.shape[3:])
+    F = int(np.prod(fsz)) if fsz else 1
+    rt = _real_dtype(prec)
+    as_t = lambda a: (a if _is_torch(a) else torch.from_numpy(np.asarray(a))).to(dev)
+    trx, ttx = as_t(tau_rx).to(rt), as_t(tau_tx).to(rt)
+    if trx.shape[-1] != N or ttx.shape[-1] != M or trx.shape[:-1] != ttx.shape[:-1]:
+        raise DasError("Delay tables must be I... x N and I... x M with identical pixel dimensions.",
+                       "QUPS:UltrasoundSystem:bfDASLUT:incompatibleReceiveDelayTable")
+    Isz = tuple(trx.shape[:-1])
+    I = int(np.prod(Isz)) if Isz else 1
+    trx_c = _colmajor(trx.reshape(I, N)) if len(Isz) <= 1 else _colmajor(trx).reshape(N, I)
+    ttx_c = _colmajor(ttx.reshape(I, M)) if len(Isz) <= 1 else _colmajor(ttx).reshape(M, I)
+    d = _lib.LutDesc()
+    d.T, d.N, d.M, d.I = T, N, M, I
+    d.flag = _lib.INTERP_FLAGS[interp] + 8 * bool(keep_rx) + 16 * bool(keep_tx) + 32 * bool(tpose)
+    d.dtype = _PREC[prec]
+    d.omega = float(omega)
+    d.tau_rx, d.tau_tx = trx_c.data_ptr(), ttx_c.data_ptr()
+    wc = None
+    if w is not None:
+        wt = as_t(w)
+        shp = tuple(wt.shape) + (1,) * (len(Isz) + 2 - wt.ndim)
+        wt = wt.reshape(shp)
+        full = Isz + (N, M)
+        if len(shp) != len(full) or any(s not in (1, f) for s, f in zip(shp, full)):
+            raise DasError("The weighting vector w must have dimensions compatible with the data.")
+        # pixel dims must be all-singleton or all-full so that one stride describes them
+        pix = shp[:len(Isz)]
+        if not (all(s == 1 for s in pix) or tuple(pix) == Isz):
+            wt = wt.expand(Isz + shp[len(Isz):])
+            shp = tuple(wt.shape)
+            pix = Isz
+        wI = int(np.prod(pix)) if pix else 1
+        real = not wt.is_complex()
+        if prec == "halfT":
+            wt = wt.to(torch.float16) if real else torch.view_as_complex(torch.view_as_real(wt.to(torch.complex64)).to(torch.float16).contiguous())
+        else:
+            wt = wt.to(rt if real else (torch.complex128 if prec == "double" else torch.complex64))
+        wc = _colmajor(wt).contiguous()
+        st, acc = [], 1
+        for s in (wI, shp[-2], shp[-1]):
+            st.append(0 if s == 1 else acc)
+            acc *= s
+        d.wstride = (C.c_uint64 * 3)(*st)
+        d.w, d.w_real = wc.data_ptr(), int(real)
+    oN, oM = (N if keep_rx else 1), (M if keep_tx else 1)
+    xc = _colmajor(xd)                                   # (F.., M, N, T)
+    from .das_spec import _data_dtype
+    y = torch.empty((F, oM, oN, I), dtype=_data_dtype(prec), device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    es = xc.element_size()
+    with torch.cuda.device(dev):
+        for f in range(F):
+            _lib.check(L.qdas_das_lut(C.byref(d), C.c_void_p(xc.data_ptr() + f * T * N * M * es),
+                                      C.c_void_p(y.data_ptr() + f * oM * oN * I * es), stream))
+    rev = lambda t: t.permute(*reversed(range(t.ndim)))
+    return rev(y.reshape(tuple(reversed(fsz)) + (oM, oN) + tuple(reversed(Isz))))
+
+
+def sample2sep(x, t0, fs, tau1, tau2, interp="linear", w=None, sdim=(), fmod=0.0, **kw):
+    """``ChannelData.sample2sep`` for data ordered ``T x N x M x F...`` (reference ``src/ChannelData.m:1338-1447``):
+    ``tau1`` (``I... x N``, receive) and ``tau2`` (``I... x M``, transmit) are TIMES; the sample delays are
+    ``(tau - t0) * fs`` (``:1431-1435``) and the phasor is ``exp(2i*pi*fmod/fs * ntau)`` (``:1439``).
+    ``sdim`` lists the aperture dims to sum, counted like the reference's default ``apdim``: ``'rx'`` / ``'tx'``."""
+    t0a = np.asarray(t0, dtype=np.float64).reshape(-1)
+    torch = _torch()
+    as_t = lambda a: a if _is_torch(a) else torch.from_numpy(np.asarray(a))
+    t1, t2 = as_t(tau1).to(torch.float64), as_t(tau2).to(torch.float64)
+    M = t2.shape[-1]
+    if t0a.size not in (1, M):
+        raise DasError("t0 must be a scalar or have one value per transmit.")
+    t0t = torch.from_numpy(np.broadcast_to(t0a, (M,)).copy()).to(t2.device)
+    n1, n2 = t1 * fs, (t2 - t0t) * fs
+    sdim = set(sdim)
+    return das_lut(x, n1, n2, interp=interp, w=w, keep_rx="rx" not in sdim, keep_tx="tx" not in sdim,
+                   omega=2 * np.pi * fmod / fs, **kw)
+
+
+def wsinterpd2(x, t1, t2, dim=1, w=1, sdim=None, interp="linear", extrapval=0, omega=0, **kw):
+    """``y = wsinterpd2(x, t1, t2, dim, w, sdim, interp, extrapval, omega)`` (reference ``kern/wsinterpd2.m:1-47``) for
+    the separable layouts the beamformers use: after moving ``dim`` first, ``x`` is ``T x N x M x F...`` (``N``/``M``
+    may be 1), and each of ``t1``, ``t2`` (``I x [1|N] x [1|M]``) depends on the pixel and on AT MOST ONE of the two
+    aperture dims.  ``sdim`` (1-based, as in MATLAB) may contain 2 and/or 3.  ``omega`` is complex as in the reference
+    (only its imaginary part rotates the phase; a real part is not supported on the device either,
+    ``kern/wsinterpd2.m:102``)."""
+    torch = _torch()
+    if not (extrapval == 0 or (isinstance(extrapval, float) and np.isnan(extrapval))):
+        raise DasError("Only extrapval 0 (the device semantics) is supported.")
+    if np.real(omega) != 0:
+        raise DasError("omega must be purely imaginary on the device path.")
+    as_t = lambda a: a if _is_torch(a) else torch.from_numpy(np.asarray(a))
+    mv = lambda a: as_t(a).movedim(dim - 1, 0) if as_t(a).ndim >= dim else as_t(a)
+    x, t1, t2 = mv(x), mv(t1), mv(t2)
+    pad3 = lambda a: a.reshape(tuple(a.shape) + (1,) * max(0, 3 - a.ndim))
+    x, t1, t2 = pad3(x), pad3(t1), pad3(t2)
+    if not (torch.is_floating_point(t1) and torch.is_floating_point(t2)):
+        raise DasError("Sample indices must be real.")
+    N = max(x.shape[1], t1.shape[1], t2.shape[1])
+    M = max(x.shape[2], t1.shape[2], t2.shape[2])
+    I = max(t1.shape[0], t2.shape[0])
+    rx = torch.zeros((I, N), dtype=torch.float64)
+    tx = torch.zeros((I, M), dtype=torch.float64)
+    for t in (t1, t2):
+        if t.ndim > 3 and any(s != 1 for s in t.shape[3:]):
+            raise DasError("Delays may only vary over the pixel and aperture dimensions.")
+        t = t.reshape(t.shape[:3]).to(torch.float64).cpu()
+        if t.shape[1] > 1 and t.shape[2] > 1:
+            raise DasError("Delays must be separable: each of t1, t2 may depend on at most one aperture dimension.")
+        if t.shape[2] > 1:
+            tx = tx + t[:, 0, :].expand(I, M)
+        else:
+            rx = rx + t[:, :, 0].expand(I, N)
+    xb = x.expand((x.shape[0], N, M) + tuple(x.shape[3:]))
+    sd = set(np.atleast_1d(sdim).astype(int).tolist()) if sdim is not None and np.size(sdim) else set()
+    if not sd <= {2, 3}:
+        raise DasError("Only the aperture dimensions (2, 3) can be summed on the device path.")
+    wt = None if (np.isscalar(w) and w == 1) else pad3(mv(w))
+    y = das_lut(xb, rx, tx, interp=interp, w=wt, keep_rx=2 not in sd, keep_tx=3 not in sd, omega=float(np.imag(omega)), **kw)
+    return y.movedim(0, dim - 1) if dim != 1 else y

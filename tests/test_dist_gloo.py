@@ -1,0 +1,82 @@
+"""world_size-2/3 gloo tests of the multi-GPU layout (pixel slabs + one all_gather) on CPU: the local
+compute is the oracle restricted to the rank's slab, so what is exercised is exactly the N > 1 host logic
+of qups_amd.dist (shard ranges, ragged slabs, plane layouts of the keep_rx/keep_tx modes, the collective)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.cases import cinv_f32, make_case
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, cases, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import das_oracle as O
+        from qups_amd import build_problem, parse_options
+        from qups_amd.dist import ShardedDasPlan
+        for fun, I1, I2 in cases:
+            case = make_case(seq="PW", interp="linear", seed=3, N=4, M=3, I1=I1, I2=I2)
+            x = torch.from_numpy(case["x"])
+            opts = parse_options(x, list(case["opt"]) + ["interp", "linear"])
+            prob = build_problem(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], x.shape, case["t0"], case["fs"], case["c"], opts)
+            full = O.das_spec(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"],
+                              cinv_f32(case["c"]), VS=case["VS"], DV=case["DV"], interp="linear")       # I1 x I2 x 1 x oN x oM
+            oN, oM = prob.osize
+            full_cm = torch.from_numpy(np.ascontiguousarray(full.reshape(prob.I, oN, oM, order="F").transpose(2, 1, 0)).astype(np.complex64))[None]
+
+            def compute(xc, F, b, c, full_cm=full_cm):   # the slab a GPU rank would produce: (1, oM, oN, count)
+                return full_cm[..., b:b + c].contiguous()
+
+            plan = ShardedDasPlan(prob, rank, world, compute=compute)
+            y = plan.execute_colmajor(x.permute(2, 1, 0).contiguous(), 1)
+            ok = bool(torch.equal(y, full_cm)) and tuple(y.shape) == (1, oM, oN, prob.I)
+            q.put((rank, fun, I1 * I2, ok, plan.i_begin, plan.i_count))
+    finally:
+        dist.destroy_process_group()
+
+
+CASES = [("DAS", 16, 4), ("DAS", 9, 3), ("SYN", 7, 3), ("BF", 6, 2), ("DAS", 1, 1)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_gather_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, CASES, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world * len(CASES))]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[3] for r in res), res
+    for fun, I1, I2 in CASES:
+        spans = sorted((b, c) for _, f, I, _, b, c in res if f == fun and I == I1 * I2)
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == I1 * I2
+        for (b0, c0), (b1, _) in zip(spans, spans[1:]):
+            assert b0 + c0 == b1
+
+
+def test_shard_range_properties():
+    from qups_amd.dist import shard_range
+    for I in (0, 1, 7, 64, 1000, 1 << 20):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(I, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == I
+            assert all(b0 + c0 == b1 for (b0, c0), (b1, _) in zip(spans, spans[1:]))
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)

@@ -1,0 +1,139 @@
+"""GPU tests against the committed golden fixtures (tests/golden/*.npz) and of the caller-level mirrors
+(UltrasoundSystem.DAS / bfDAS, sample2sep / wsinterpd2) -- everything goes through the C ABI of libqdas.so."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.cases import cinv_f32, make_case, rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def _np(t):
+    import torch
+    return t.to(torch.complex128).cpu().numpy() if t.is_complex() else t.cpu().numpy()
+
+
+@pytest.mark.parametrize("terp", ["nearest", "linear", "cubic", "lanczos3", "cubic_dev"])
+@pytest.mark.parametrize("prec", ["single", "double"])
+def test_f1_interptest_fixture_wsinterpd2(terp, prec):
+    """the reference's own kernel test (test/interpTest.m:97-143) on its closed-form fixture"""
+    import torch
+    from qups_amd import wsinterpd2
+    g = gold("f1_interptest.npz")
+    tau, x0 = g["tau"], g["x0"]                               # I x N x M ; T x N x F
+    I, N, M = tau.shape
+    F = x0.shape[2]
+    i = np.arange(I)[:, None, None]
+    n = np.arange(N)[None, :, None]
+    m = np.arange(M)[None, None, :]
+    T = x0.shape[0]
+    t1 = 4 + (T - 8) * ((1 + i) / I * 1 / N * (1 + m) / M)    # I x 1 x M   (interpTest.m:38)
+    t2 = 4 + (T - 8) * 1 / I * (1 + n) / N                    # 1 x N x 1   (interpTest.m:39)
+    x = torch.from_numpy(x0[:, :, None, :].astype(np.complex64 if prec == "single" else np.complex128))   # T x N x 1 x F
+    tol = (1e4 * np.finfo(np.float32 if prec == "single" else np.float64).eps) * 50     # interpTest.m:126 (x50: tau*fs in fp32)
+    y = _np(wsinterpd2(x, t1, t2, 1, 1, None, terp, 0, prec=prec))                       # I x N x M x F
+    ref = g["y_" + terp]
+    assert y.shape == ref.shape
+    if terp != "nearest":
+        assert np.abs(y - ref).max() <= tol * np.abs(ref).max() * (40 if prec == "single" else 1)
+    else:
+        assert np.mean(np.abs(y - ref) > 1e-5) < 0.01
+    w = np.random.default_rng(3).uniform(size=(1, 1, M)).astype(np.float32)              # weights over dim 3, summed over [2 3]
+    ys = _np(wsinterpd2(x, t1, t2, 1, w, [2, 3], terp, 0, prec=prec))
+    if terp != "nearest":
+        assert rel_err(ys[:, 0, 0, :], (w[..., None] * ref).sum((1, 2))) <= (2e-5 if prec == "single" else 1e-12)
+
+
+@pytest.mark.parametrize("seq", ["FSA", "PW", "FC"])
+def test_f2_psf_DAS_and_bfDAS(seq):
+    """UltrasoundSystem.DAS and bfDAS reproduce the frozen PSF image and the BFTest criterion (test/BFTest.m:306-316)"""
+    import torch
+    from qups_amd import ChannelData, Scan, Sequence, Transducer, UltrasoundSystem
+    g = gold("f2_psf.npz")
+    k = lambda s: g[seq + "_" + s]
+    xdc = Transducer(k("Pr"), np.stack([0 * k("Pr")[0], 0 * k("Pr")[0], 1 + 0 * k("Pr")[0]]))
+    focus = k("Nv") if seq == "PW" else k("Pv")
+    us = UltrasoundSystem(xdc, Sequence(seq, focus=focus, c0=float(k("c"))), Scan(k("Pi")))
+    chd = ChannelData(torch.from_numpy(k("x")), float(k("t0")), float(k("fs")))
+    ref = k("y")
+    b = _np(us.DAS(chd, interp="cubic"))[..., 0, 0] if False else _np(us.DAS(chd, interp="cubic")).reshape(ref.shape)
+    assert rel_err(b, ref) <= (1e-4 if seq == "FC" else 2e-5)
+    iz, ix, _ = np.unravel_index(np.argmax(np.abs(b)), b.shape)
+    assert np.count_nonzero(b) and abs(k("dx")[ix]) <= 1.1e-3 and abs(k("dz")[iz]) <= 1.1e-3
+    b2 = _np(us.bfDAS(chd, interp="cubic")).reshape(ref.shape)                # split-delay flavour, fp32 tables
+    assert rel_err(b2, ref) <= 5e-4
+    iz, ix, _ = np.unravel_index(np.argmax(np.abs(b2)), b2.shape)
+    assert abs(k("dx")[ix]) <= 1.1e-3 and abs(k("dz")[iz]) <= 1.1e-3
+
+
+def test_f3_modes_golden():
+    import torch
+    from qups_amd import das_spec
+    g = gold("f3_modes.npz")
+    args = (g["Pi"], g["Pr"], g["Pv"], g["Nv"], torch.from_numpy(g["x"]), float(g["t0"]), float(g["fs"]), float(g["c"]))
+    for fun in ("DAS", "SYN", "MUL", "BF"):
+        y = _np(das_spec(fun, *args, "plane-waves", "interp", "linear", "apod", g["a1"], "apod", g["a2"]))
+        assert y.shape == g["y_" + fun].shape
+        assert rel_err(y, g["y_" + fun]) <= 1e-4
+    y = _np(das_spec("DAS", *args, "plane-waves", "interp", "linear", "modulation", float(np.float32(3e6))))
+    assert rel_err(y, g["y_DAS_fmod"]) <= 2e-4
+
+
+def test_f4_edges_golden_lut_kernel():
+    import torch
+    from qups_amd import das_lut
+    g = gold("f4_edges.npz")
+    x, s = g["x"], g["s"]
+    for terp in ("nearest", "linear", "cubic", "lanczos3"):
+        y = _np(das_lut(torch.from_numpy(x.reshape(-1, 1, 1)), s.reshape(-1, 1), np.zeros((len(s), 1)), interp=terp, prec="double"))
+        ref = g["y_" + terp]
+        assert np.array_equal(y.reshape(-1) == 0, np.nan_to_num(ref) == 0), terp     # exactly zero out of support
+        assert np.abs(y.reshape(-1) - np.nan_to_num(ref)).max() <= 1e-12
+
+
+@pytest.mark.parametrize("keep", [(False, False), (True, False), (False, True), (True, True)])
+def test_das_lut_matches_oracle(keep):
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import sample2sep
+    case = make_case(seq="FSA", interp="cubic", seed=21, N=6, I1=40, I2=5)
+    dv, dr = O.tx_rx_distances(case["Pi"], case["Pr"], case["Pv"], case["Nv"], True, True)
+    c = cinv_f32(case["c"])
+    tau_tx = (dv[:, :, :, 0, :] / c)
+    tau_rx = (dr[:, :, :, :, 0] / c)
+    rng = np.random.default_rng(0)
+    w = rng.uniform(0.2, 1, (40, 5, 1, 6, 1)).astype(np.float32).astype(np.float64)
+    keep_rx, keep_tx = keep
+    fm = float(np.float32(2e6))
+    ref = O.das_lut(case["x"], tau_rx, tau_tx, case["t0"], case["fs"], interp="cubic", apod=(w,), fmod=fm, keep_rx=keep_rx, keep_tx=keep_tx)
+    sd = set() if keep_rx else {"rx"}
+    sd |= set() if keep_tx else {"tx"}
+    y = _np(sample2sep(torch.from_numpy(case["x"]), case["t0"], case["fs"], tau_rx, tau_tx, "cubic", w, sd, fm, prec="double"))
+    assert y.shape == ref.shape and rel_err(y, ref) <= 1e-9
+    y32 = _np(sample2sep(torch.from_numpy(case["x"]), case["t0"], case["fs"], tau_rx, tau_tx, "cubic", w, sd, fm, prec="single"))
+    assert rel_err(y32, ref) <= 5e-4
+
+
+def test_us_DAS_keep_dims_and_frames_layout():
+    import torch
+    from qups_amd import ChannelData, Scan, Sequence, Transducer, UltrasoundSystem
+    case = make_case(seq="PW", interp="linear", seed=22, N=6, M=4, I1=30, I2=5)
+    xdc = Transducer(case["Pr"], np.stack([0 * case["Pr"][0], 0 * case["Pr"][0], 1 + 0 * case["Pr"][0]]))
+    us = UltrasoundSystem(xdc, Sequence("PW", focus=case["Nv"], c0=case["c"]), Scan(case["Pi"]))
+    xf = np.stack([case["x"], 2 * case["x"]], axis=3)
+    chd = ChannelData(torch.from_numpy(xf), case["t0"], case["fs"])
+    b = us.DAS(chd, interp="linear", keep_rx=True, keep_tx=True)
+    assert tuple(b.shape) == (30, 5, 1, 2, 6, 4)              # I1 x I2 x I3 x F x N x M (src/UltrasoundSystem.m:3361)
+    b0 = us.DAS(chd, interp="linear")
+    assert tuple(b0.shape) == (30, 5, 1, 2, 1, 1)
+    assert rel_err(_np(b.sum((4, 5), keepdim=True)), _np(b0)) <= 1e-5
+    assert rel_err(_np(b0[..., 1, :, :]), 2 * _np(b0[..., 0, :, :])) <= 1e-6
+    chd_t = ChannelData(torch.from_numpy(np.swapaxes(xf, 1, 2)), case["t0"], case["fs"], order="TMN")
+    assert rel_err(_np(us.DAS(chd_t, interp="linear")), _np(b0)) <= 1e-6

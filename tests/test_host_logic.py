@@ -1,0 +1,175 @@
+"""CPU tests of the host side (no GPU, no compute calls): option parsing, geometry normalisation, stride
+tables, error behaviour mirroring reference kern/das_spec.m, the geometry producers, and the C-ABI library
+(loads, exports every symbol include/qdas.h declares, struct layouts)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from qups_amd import DasError, build_problem, parse_options, _lib
+from qups_amd import geometry as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _prob(fun="DAS", Isz=(6, 4, 1), N=5, M=3, T=64, opts=(), x=None, **kw):
+    Pi = np.random.default_rng(0).uniform(size=(3,) + Isz)
+    Pr = np.zeros((3, N)); Pr[0] = np.linspace(-1, 1, N)
+    Pv = np.zeros((3, M)); Nv = np.zeros((3, M)); Nv[2] = 1
+    x = np.zeros((T, N, M), np.complex64) if x is None else x
+    o = parse_options(x, list(opts))
+    return build_problem(fun, kw.get("Pi", Pi), kw.get("Pr", Pr), kw.get("Pv", Pv), kw.get("Nv", Nv), x.shape,
+                         kw.get("t0", 0.0), kw.get("fs", 20e6), kw.get("c", 1540.0), o)
+
+
+def test_option_parsing_matches_reference_strings():
+    x = np.zeros((8, 2, 2), np.complex64)
+    o = parse_options(x, ["plane-waves", "diverging-waves", "interp", "cubic", "apod", 2.0, "apod", np.ones((1, 1, 1, 2)),
+                          "modulation", 1e6, "transpose", True, "device", -1, "input-precision", "double"])
+    assert (o["VS"], o["DV"], o["interp"], o["fmod"], o["tpose"], o["prec"], len(o["apod"])) == (False, True, "cubic", 1e6, True, "double", 2)
+    assert parse_options(x, [])["prec"] == "single" and parse_options(np.zeros(3), [])["prec"] == "double"    # das_spec.m:96-104
+    assert parse_options(x, [])["interp"] == "linear"                                                          # das_spec.m:93
+    for bad in (["bogus"], ["interp"], [3]):
+        with pytest.raises(DasError, match="Unrecognized option"):
+            parse_options(x, bad)
+
+
+def test_flag_bits_and_output_sizes():
+    for fun, bits, osz in (("DAS", 0, (1, 1)), ("SYN", 8, (5, 1)), ("MUL", 16, (1, 3)), ("BF", 24, (5, 3))):
+        p = _prob(fun, opts=["interp", "lanczos3"])
+        assert p.flag == 3 + bits and p.osize == osz                    # das_spec.m:198-213,263-269
+    p = _prob("BF", opts=["transpose", True], x=np.zeros((64, 3, 5), np.complex64))
+    assert p.flag & 32 and (p.N, p.M) == (5, 3) and p.osize == (3, 5)   # das_spec.m:251; planes follow the data order
+    with pytest.raises(DasError, match="Invalid beamformer"):
+        _prob("FOO")
+    with pytest.raises(DasError) as e:
+        _prob(opts=["interp", "pchip"])
+    assert e.value.identifier == "QUPS:das_spec:UnrecognizedInput"
+
+
+def test_stride_tables_like_reference():
+    """cstride / astride of reference kern/das_spec.m:257-260 for every singleton pattern"""
+    Isz, N, M = (6, 4, 2), 5, 3
+    full = Isz + (N, M)
+    rng = np.random.default_rng(1)
+    for mask in range(32):
+        shp = tuple(full[k] if (mask >> k) & 1 else 1 for k in range(5))
+        a = rng.uniform(0.5, 1, shp)
+        b = rng.uniform(0.5, 1, (1, 1, 1, N, 1))
+        p = _prob(Isz=Isz, N=N, M=M, opts=["apod", a, "apod", b], c=rng.uniform(1500, 1600, Isz))
+        t = p.acstride.reshape(-1, 6)
+        exp = [0 if s == 1 else int(np.prod(shp[:k])) for k, s in enumerate(shp)]
+        assert list(t[1][:5]) == exp and t[1][5] == 0
+        assert list(t[2][:5]) == [0, 0, 0, 1, 0] and t[2][5] == a.size            # base offset = numel of the arrays before
+        assert list(t[0]) == [1, 6, 24, 0, 0, 0]                                  # cinv: I1 x I2 x I3
+        assert p.S == 2 and p.apod_real and p.apod.size == a.size + b.size
+        # the flat buffer is the column-major concatenation (das_spec.m:344-345)
+        i = tuple(min(1, s - 1) for s in shp)
+        lin = sum(ix * st for ix, st in zip(i, exp))
+        assert np.isclose(p.apod[lin], a[i])
+    # a complex apodization switches the whole stack to complex storage; the default {1} is dropped
+    p = _prob(opts=["apod", 1, "apod", np.ones((1, 1, 1, 5)) * (1 + 1j)])
+    assert p.S == 1 and not p.apod_real and p.apod.dtype == np.complex64
+
+
+def test_expand_inputs_and_errors():
+    p = _prob(Pv=np.zeros((3, 1)), Nv=np.array([[0.0], [0.0], [1.0]]))             # singleton Pv/Nv replicate (das_spec.m:631-633)
+    assert p.Pv.size == 4 * 3 and p.Nv.size == 3 * 3
+    assert np.allclose(p.Pv.reshape(3, 4)[:, 3], 0.0)                              # row 4 = t0 (das_spec.m:361)
+    p = _prob(t0=np.array([1e-6, 2e-6, 3e-6]))
+    assert np.allclose(p.Pv.reshape(3, 4)[:, 3], [1e-6, 2e-6, 3e-6])
+    p = _prob(Pr=np.stack([np.linspace(-1, 1, 5), np.zeros(5)]))                   # 2-D coordinates are (x, z) (das_spec.m:661-662)
+    assert np.allclose(p.Pr.reshape(5, 3)[:, 1], 0) and np.allclose(p.Pr.reshape(5, 3)[:, 0], np.linspace(-1, 1, 5))
+    p = _prob(Pr=np.linspace(-1, 1, 5)[None, :] * np.array([[1.0], [0], [0], [0]]) + np.array([[0], [0], [0], [2.0]]))   # projective
+    assert np.allclose(p.Pr.reshape(5, 3)[:, 0], np.linspace(-1, 1, 5) / 2)
+    with pytest.raises(DasError, match="Inconsistent receiver data size"):
+        _prob(Pr=np.zeros((3, 4)))
+    with pytest.raises(DasError, match="Inconsistent transmitter data size"):
+        _prob(Pv=np.zeros((3, 2)))
+    with pytest.raises(DasError, match="Improper coordinate dimension"):
+        _prob(Pr=np.zeros((5, 7)).T.reshape(7, 5)[:5].T if False else np.zeros((6, 7)))
+    for shape, what in (((5, 1, 1, 1, 1), "pixel"), ((1, 1, 1, 4, 1), "receiver"), ((1, 1, 1, 1, 2), "transmit")):
+        with pytest.raises(DasError, match=f"Apodization data size inconsistent with {what}"):
+            _prob(opts=["apod", np.ones(shape)])
+        with pytest.raises(DasError, match=f"Sound speed data size inconsistent with {what}"):
+            _prob(c=np.full(shape, 1540.0))
+    with pytest.raises(DasError, match="Undefined sampling rate"):
+        _prob(fs=None)
+    assert _prob("delays", fs=None, x=np.zeros((0, 5, 3))).osize == (5, 3)
+
+
+def test_precision_casting():
+    p = _prob(opts=["input-precision", "double"])
+    assert p.Pi.dtype == np.float64 and p.cinv.dtype == np.float64
+    p = _prob(opts=["input-precision", "halfT", "apod", np.full((1, 1, 1, 5), 0.5)])
+    assert p.Pi.dtype == np.float32 and p.apod.dtype == np.float16                 # half weights, single geometry (das_spec.m:356)
+    assert np.isclose(_prob().cinv[0], np.float32(1 / 1540.0))
+
+
+def test_geometry_producers():
+    p, n = G.linear_array(5, 0.3e-3)
+    assert np.allclose(p[0], [-0.6e-3, -0.3e-3, 0, 0.3e-3, 0.6e-3]) and np.allclose(n[2], 1)      # TransducerArray.m:95-99
+    p, n = G.convex_array(3, 50e-3, 10.0)
+    assert np.allclose(p[:, 1], 0) and np.allclose(np.linalg.norm(p + np.array([[0], [0], [50e-3]]), axis=0), 50e-3)   # TransducerConvex.m:85-92
+    assert np.allclose(n[:, 2], [np.sin(np.deg2rad(10)), 0, np.cos(np.deg2rad(10))])
+    Pi = G.scan_cartesian([1, 2, 3], [10, 20])
+    assert Pi.shape == (3, 2, 3, 1) and Pi[2, 1, 0, 0] == 20 and Pi[0, 0, 2, 0] == 3             # 'ZXY': z fastest (ScanCartesian.m:11)
+    Pp = G.scan_polar([1.0, 2.0], [0.0, 90.0], origin=(0, 0, -1))
+    assert np.allclose(Pp[:, 1, 1, 0], [2, 0, -1]) and np.allclose(Pp[:, 0, 0, 0], [0, 0, 0])    # ScanPolar.m:99-115
+    Pv, Nv, opt = G.sequence_args("PW", focus=np.array([[0.0], [0], [1]]))
+    assert opt == ["plane-waves"] and Pv.shape == (3, 1)
+    assert G.sequence_args("FSA", tx_pos=p, tx_normals=n)[2] == ["diverging-waves"]
+    Pv, Nv, opt = G.sequence_args("DV", focus=np.array([[0.0, 1e-3], [0, 0], [-5e-3, -5e-3]]))
+    assert opt == ["diverging-waves"] and np.allclose(np.linalg.norm(Nv, axis=0), 1)
+
+
+# ---------------------------------------------------------------- the C ABI (no device needed)
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "qdas.h")).read()
+    declared = set(re.findall(r"\b(qdas_[a-zA-Z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes found in include/qdas.h"
+    assert declared == set(_lib.SYMBOLS)
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.qdas_version() == 100
+    assert C.sizeof(_lib.Sizes) == 7 * 8 + 4 * 4
+    assert C.sizeof(_lib.Desc) == C.sizeof(_lib.Sizes) + 2 * 8 + 7 * 8 + 4 * 4 + 3 * 8 + 4 * 8
+
+
+def test_abi_validation_needs_no_device():
+    """argument validation happens before any HIP call and reports through qdas_last_error()"""
+    L = _lib.lib()
+    d = _lib.Desc()
+    d.sz = _lib.Sizes(64, 4, 3, 8, 2, 1, 0, 7, 1, 0, 1)     # interp code 7 is invalid
+    d.fs = 20e6
+    h = C.c_void_p()
+    rc = L.qdas_plan_create(C.byref(h), C.byref(d))
+    assert rc == 1 and b"Unrecognized interpolation" in L.qdas_last_error()
+    d.sz.flag = 1
+    d.fs = 0.0
+    assert L.qdas_plan_create(C.byref(h), C.byref(d)) == 1 and b"Undefined sampling rate" in L.qdas_last_error()
+    d.fs = 1.0
+    d.sz.S = 99
+    assert L.qdas_plan_create(C.byref(h), C.byref(d)) == 2
+    with pytest.raises(_lib.QdasError):
+        _lib.check(2)
+
+
+def test_no_cpu_fallback_in_product_path():
+    """the product package must not import the oracle, and das_spec must refuse to run without a HIP device"""
+    from qups_amd import das_spec as das_spec_fn
+    for f in os.listdir(os.path.join(ROOT, "qups_amd")):
+        if f.endswith(".py"):
+            src = open(os.path.join(ROOT, "qups_amd", f)).read()
+            assert "import oracle" not in src and "from oracle" not in src, f
+    import torch
+    if not torch.cuda.is_available():
+        x = np.zeros((16, 2, 2), np.complex64)
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            das_spec_fn("DAS", np.zeros((3, 4)), np.zeros((3, 2)), np.zeros((3, 1)), np.array([[0.0], [0], [1]]), x, 0.0, 1e6, 1540.0)
+    with pytest.raises(NotImplementedError):
+        das_spec_fn("DAS", np.zeros((3, 4)), np.zeros((3, 2)), np.zeros((3, 1)), np.array([[0.0], [0], [1]]),
+                    np.zeros((16, 2, 2), np.complex64), 0.0, 1e6, 1540.0, "device", 0)
