@@ -41,6 +41,16 @@ if "FETCH_SIZE" in vals:
     print(f"FETCH_SIZE raw (KiB units -> bytes x1024): {vals['FETCH_SIZE'] * 1024 / 1e9:.3f} GB; x2 gfx950 correction for wide loads: {vals['FETCH_SIZE'] * 2048 / 1e9:.3f} GB")
 if "WRITE_SIZE" in vals:
     print(f"WRITE_SIZE raw: {vals['WRITE_SIZE'] * 1024 / 1e9:.4f} GB")
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    import json
+    tr = {"hbm_bytes_per_launch": int(vals["FETCH_SIZE"] * 2048 + vals["WRITE_SIZE"] * 1024),
+          "fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib_raw": vals["WRITE_SIZE"],
+          "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, averaged per dispatch of the dominant "
+                    "kernel; FETCH_SIZE x2 (gfx950 reports half the bytes of 16 B/lane streaming reads, MI355X_MICROARCH.md HBM "
+                    "section), KiB -> bytes; WRITE_SIZE uncorrected",
+          "kernel": dom}
+    json.dump(tr, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    print("traffic.json:", tr["hbm_bytes_per_launch"] / 1e9, "GB per launch")
 if "TCC_HIT_sum" in vals:
     h, m = vals["TCC_HIT_sum"], vals["TCC_MISS_sum"]
     print(f"L2 hit rate = {h / (h + m):.4f}")
