@@ -35,41 +35,7 @@ FP32_PEAK_TFLOPS = 157.3       # fp32 vector peak (same guide)
 FLOP_PER_PAIR = {"nearest": 17, "linear": 24, "cubic": 42, "lanczos3": 54}   # SURVEY.md section 8d flop model
 
 
-def workload(name: str):
-    """Geometry of the BASELINE configs."""
-    from qups_amd import geometry as G
-    c0 = 1540.0
-    if name == "c3":      # 256 el FSA, 1024^2, lanczos3
-        fc, N, pitch, nx, nz, T, interp = 5e6, 256, 0.2e-3, 1024, 1024, 2816, "lanczos3"
-        lam = c0 / fc
-        Pr, nrm = G.linear_array(N, pitch)
-        Pv, Nv, opt = G.sequence_args("FSA", tx_pos=Pr, tx_normals=nrm)
-        x = (np.arange(nx) - (nx - 1) / 2) * lam / 4
-        z = 2e-3 + np.arange(nz) * lam / 4
-        label = "C3: 256-el FSA (256 Tx x 256 Rx), 1024x1024 ScanCartesian lambda/4, T=2816, complex64, lanczos3"
-    elif name == "c2":    # 128 el, 128 PW, 512^2, cubic
-        fc, N, pitch, nx, nz, T, interp = 5e6, 128, 0.3e-3, 512, 512, 2048, "cubic"
-        lam = c0 / fc
-        Pr, nrm = G.linear_array(N, pitch)
-        th = np.deg2rad(np.linspace(-25, 25, 128))
-        Pv, Nv, opt = G.sequence_args("PW", focus=np.stack([np.sin(th), 0 * th, np.cos(th)]))
-        x = (np.arange(nx) - (nx - 1) / 2) * lam / 4
-        z = 2e-3 + np.arange(nz) * lam / 4
-        label = "C2: 128-el, 128 plane waves, 512x512 ScanCartesian lambda/4, T=2048, complex64, cubic"
-    elif name == "small":  # quick plumbing check
-        fc, N, pitch, nx, nz, T, interp = 5e6, 32, 0.3e-3, 128, 256, 1024, "lanczos3"
-        lam = c0 / fc
-        Pr, nrm = G.linear_array(N, pitch)
-        Pv, Nv, opt = G.sequence_args("FSA", tx_pos=Pr, tx_normals=nrm)
-        x = (np.arange(nx) - (nx - 1) / 2) * lam / 4
-        z = 2e-3 + np.arange(nz) * lam / 4
-        label = "small: 32-el FSA, 256x128, T=1024, complex64, lanczos3"
-    else:
-        raise SystemExit(f"unknown workload {name}")
-    Pi = G.scan_cartesian(x, z)
-    M = Nv.shape[1] if Nv.shape[1] > 1 else Pv.shape[1]
-    return dict(name=name, label=label, Pi=Pi, Pr=Pr, Pv=Pv, Nv=Nv, opt=opt, T=T, N=N, M=M, fs=4 * fc, c0=c0,
-                interp=interp, I1=nz, I2=nx)
+from qups_amd.configs import workload  # noqa: E402  (geometry of the BASELINE configs)
 
 
 def cpu_baseline(w, x_host, budget_s=15.0):
@@ -80,7 +46,7 @@ def cpu_baseline(w, x_host, budget_s=15.0):
     def run(step):
         Pi = w["Pi"][:, ::step, ::step, :]
         t = time.perf_counter()
-        das_ref.das_spec("DAS", Pi, w["Pr"], w["Pv"], w["Nv"], x_host, 0.0, w["fs"], w["c0"],
+        das_ref.das_spec("DAS", Pi, w["Pr"], w["Pv"], w["Nv"], x_host, w["t0"], w["fs"], w["c0"],
                          VS="plane-waves" not in w["opt"], DV="diverging-waves" in w["opt"], interp=w["interp"],
                          prec="single", timing=True)
         return das_ref.LAST_SECONDS, Pi.shape[1] * Pi.shape[2]
@@ -128,20 +94,15 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234)     # same data on every rank (replicated input)
     xc = torch.view_as_complex(torch.randn((M, N, T, 2), generator=g, device=dev, dtype=torch.float32))
     opts = parse_options(xc, list(w["opt"]) + ["interp", w["interp"]])
-    prob = build_problem("DAS", w["Pi"], w["Pr"], w["Pv"], w["Nv"], (T, N, M), 0.0, w["fs"], w["c0"], opts)
+    prob = build_problem("DAS", w["Pi"], w["Pr"], w["Pv"], w["Nv"], (T, N, M), w["t0"], w["fs"], w["c0"], opts)
     b, e = I * rank // world, I * (rank + 1) // world       # contiguous slab of the linear pixel index
     plan = DasPlan(prob, device=dev, kernel=args.kernel, i_begin=b, i_count=e - b)
-    equal = (I % world == 0)
-    out = torch.empty(I, dtype=torch.complex64, device=dev) if world > 1 else None
+    from qups_amd.dist import gather_pixels
 
     def step():
-        y = plan.execute_colmajor(xc, 1).reshape(-1)
+        y = plan.execute_colmajor(xc, 1)                       # (1, 1, 1, slab)
         if world > 1:
-            if equal:
-                dist.all_gather_into_tensor(out, y)
-            else:
-                parts = [torch.empty(I * (r + 1) // world - I * r // world, dtype=y.dtype, device=dev) for r in range(world)]
-                dist.all_gather(parts, y)
+            y = gather_pixels(y, I, world)                     # one RCCL all_gather of the slabs -> (1, 1, 1, I) on every rank
         return y
 
     for _ in range(args.warmup):

@@ -36,8 +36,8 @@ def gather_pixels(y_local, I: int, world: int, group=None):
     ax = len(lead)                                                        # the pixel axis
     counts = [shard_range(I, r, world)[1] for r in range(world)]
     cmax = max(counts)
-    complex32 = y_local.dtype == torch.complex32
-    src = torch.view_as_real(y_local) if complex32 else y_local          # gloo/nccl know no ComplexHalf
+    cplx = y_local.is_complex()
+    src = torch.view_as_real(y_local) if cplx else y_local               # collectives move (re, im) pairs of the real type
     if all(c == cmax for c in counts) and not lead_has_planes(lead):
         out = torch.empty((I,) + tuple(src.shape[ax + 1:]), dtype=src.dtype, device=src.device)
         dist.all_gather_into_tensor(out, src.reshape((cmax,) + tuple(src.shape[ax + 1:])).contiguous(), group=group)
@@ -49,7 +49,7 @@ def gather_pixels(y_local, I: int, world: int, group=None):
         out = torch.empty((world,) + tuple(pad.shape), dtype=src.dtype, device=src.device)
         dist.all_gather_into_tensor(out, flat, group=group)
         full = torch.cat([out[r].narrow(ax, 0, counts[r]) for r in range(world)], dim=ax)
-    return torch.view_as_complex(full.contiguous()) if complex32 else full
+    return torch.view_as_complex(full.contiguous()) if cplx else full
 
 
 def lead_has_planes(lead) -> bool:

@@ -1,0 +1,84 @@
+"""Full-size parity of the five BASELINE.json configurations on the GPU.
+
+The float64 numpy oracle is too slow at these sizes, so each full-size image is checked (a) on a regular
+sub-lattice of pixels against the C oracle (oracle/das_ref.c, double precision, all host cores) fed with the
+same data, and (b) through size-independent properties: linearity in the data, and slab concatenation
+(the multi-GPU layout) being bit-identical to the single-plan image."""
+import numpy as np
+import pytest
+
+from tests.cases import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(name, seed=1234):
+    import torch
+    from qups_amd import build_problem, parse_options
+    from qups_amd.configs import workload
+    w = workload(name)
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(seed)
+    xc = torch.view_as_complex(torch.randn((w["M"], w["N"], w["T"], 2), generator=g, device=dev, dtype=torch.float32))
+    if w["prec"] == "halfT":       # data that is exactly representable in half
+        xc = torch.view_as_complex(torch.view_as_real(xc).to(torch.float16).to(torch.float32).contiguous())
+    extra = ["interp", w["interp"], "input-precision", w["prec"]]
+    if w["apod"] is not None:
+        extra += ["apod", w["apod"]]
+    opts = parse_options(xc, list(w["opt"]) + extra)
+    prob = build_problem("DAS", w["Pi"], w["Pr"], w["Pv"], w["Nv"], (w["T"], w["N"], w["M"]), w["t0"], w["fs"], w["c0"], opts)
+    return w, xc, prob
+
+
+def _run(prob, xc, **kw):
+    import torch
+    from qups_amd import DasPlan
+    from qups_amd.das_spec import _cast_data
+    plan = DasPlan(prob, **kw)
+    xd = xc if prob.prec == "single" else _cast_data(xc, prob.prec, xc.device)
+    y = plan.execute_colmajor(xd.contiguous(), 1).reshape(-1)
+    torch.cuda.synchronize()
+    return y, plan
+
+
+def _oracle_lattice(w, xc, step):
+    from oracle import das_ref
+    xh = xc.cpu().numpy().transpose(2, 1, 0)               # T x N x M view of the (M, N, T) buffer
+    Pi = w["Pi"][:, ::step, ::step, :]
+    ap = () if w["apod"] is None else (w["apod"][::step, ::step].astype(np.float64),)
+    c_eff = 1.0 / np.float64(np.float32(1.0 / w["c0"]))
+    return das_ref.das_spec("DAS", Pi, w["Pr"], w["Pv"], w["Nv"], xh, w["t0"], w["fs"], c_eff,
+                            VS="plane-waves" not in w["opt"], DV="diverging-waves" in w["opt"], interp=w["interp"],
+                            apod=ap, prec="double")[..., 0, 0]
+
+
+@pytest.mark.parametrize("name,step,tol", [("c1", 1, 1e-4), ("c2", 8, 5e-5), ("c3", 32, 5e-5), ("c5", 16, 2e-3)])
+def test_config_lattice_parity(name, step, tol):
+    w, xc, prob = _setup(name)
+    y, plan = _run(prob, xc)
+    img = y.to(__import__("torch").complex64).cpu().numpy().reshape(w["I1"], w["I2"], order="F")
+    ref = _oracle_lattice(w, xc, step)
+    assert np.abs(ref).max() > 0
+    assert rel_err(img[::step, ::step, None], ref) <= tol, (name, plan.kernel, plan.fallback_tiles())
+    if name in ("c2", "c3"):
+        assert plan.kernel == "tiled" and plan.fallback_tiles() == 0
+    if name == "c5":
+        assert plan.kernel == "generic"        # pixel-dependent apodization
+
+
+@pytest.mark.parametrize("name", ["c2", "c3"])
+def test_config_linearity_and_slabs(name):
+    import torch
+    w, xa, prob = _setup(name, seed=1)
+    _, xb, _ = _setup(name, seed=2)
+    ya, _ = _run(prob, xa)
+    yb, _ = _run(prob, xb)
+    al, be = 0.75 - 0.5j, -1.25 + 2.0j
+    yc, _ = _run(prob, al * xa + be * xb)
+    den = float(yc.abs().max())
+    assert float((yc - (al * ya + be * yb)).abs().max()) / den <= 1e-4             # linear in the data (fp32 accumulation of up to 65536 terms)
+    I = prob.I
+    parts = [_run(prob, xa, i_begin=I * g // 3, i_count=I * (g + 1) // 3 - I * g // 3)[0] for g in range(3)]
+    assert torch.equal(torch.cat(parts), ya)                                          # slabs concatenate bit-exactly
+    z, _ = _run(prob, torch.zeros_like(xa))
+    assert float(z.abs().max()) == 0.0
