@@ -93,7 +93,11 @@ def main():
     I = w["I1"] * w["I2"]
     g = torch.Generator(device=dev).manual_seed(1234)     # same data on every rank (replicated input)
     xc = torch.view_as_complex(torch.randn((M, N, T, 2), generator=g, device=dev, dtype=torch.float32))
-    opts = parse_options(xc, list(w["opt"]) + ["interp", w["interp"]])
+    extra = ["interp", w["interp"], "input-precision", w["prec"]] + (["apod", w["apod"]] if w["apod"] is not None else [])
+    opts = parse_options(xc, list(w["opt"]) + extra)
+    if w["prec"] == "halfT":
+        from qups_amd.das_spec import _cast_data
+        xc = _cast_data(xc, "halfT", dev).contiguous()
     prob = build_problem("DAS", w["Pi"], w["Pr"], w["Pv"], w["Nv"], (T, N, M), w["t0"], w["fs"], w["c0"], opts)
     b, e = I * rank // world, I * (rank + 1) // world       # contiguous slab of the linear pixel index
     plan = DasPlan(prob, device=dev, kernel=args.kernel, i_begin=b, i_count=e - b)
@@ -135,7 +139,9 @@ def main():
     if rank == 0:
         ms = el / args.steps * 1e3
         pairs = I * N * M
-        alg_bytes = (T * N * M * 8 + 12 * I + 8 * I) / world      # per launch (per rank): x + Pi + y  (SURVEY 8d "B")
+        sb = 4 if w["prec"] == "halfT" else 8
+        apb = 0 if w["apod"] is None else w["apod"].size * (2 if w["prec"] == "halfT" else 4)
+        alg_bytes = (T * N * M * sb + 12 * I + sb * I + apb) / world      # per launch (per rank): x + Pi + y (+ apod)  (SURVEY 8d "B")
         traffic = None
         tfile = os.path.join(ROOT, "profiles", f"traffic_{w['name']}.json")
         if os.path.exists(tfile):
@@ -148,7 +154,7 @@ def main():
             "metric": "beamformed Mpixels/sec (1024^2 px, 256x256 Tx/Rx)" if w["name"] == "c3" else "beamformed Mpixels/sec",
             "value": round(I / (el / args.steps) / 1e6, 4), "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16" if w["prec"] == "halfT" else "f32", "data": "synthetic",
             "config": {"workload": w["label"], "pixels": I, "pairs_per_frame": pairs, "kernel": plan.kernel,
                        "fallback_tiles": fallback, "parallelism": f"pixel-slab x{world} + RCCL all_gather" if world > 1 else "1 GPU",
                        "device": info["name"], "cu": info["cu_count"]},
@@ -158,8 +164,8 @@ def main():
                          "note": "compulsory-traffic accounting: this path is FP32-VALU / LDS-gather bound "
                                  "(~2.5e3 flop/byte), see also valu_frac",
                          "gpairs_per_s": round(pairs / world / (kernel_ms * 1e-3) / 1e9, 3),
-                         "valu_tflops_model": round(pairs / world * FLOP_PER_PAIR[w["interp"]] / (kernel_ms * 1e-3) / 1e12, 3),
-                         "valu_frac": round(pairs / world * FLOP_PER_PAIR[w["interp"]] / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)},
+                         "valu_tflops_model": round(pairs / world * FLOP_PER_PAIR.get(w["interp"], 42) / (kernel_ms * 1e-3) / 1e12, 3),
+                         "valu_frac": round(pairs / world * FLOP_PER_PAIR.get(w["interp"], 42) / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)},
         }
         if world == 1 and not args.no_cpu:
             try:

@@ -158,17 +158,17 @@ das_tile_kernel(const TileParams P) {
     static_assert(MB % WAVES == 0 && MB % 2 == 0, "staging split");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keeps everything derived from it in SGPRs
     const uint32_t M = (uint32_t)P.M, N = (uint32_t)P.N;
     const int T = (int)P.T;
     int   *Abase = (int *)smem;                       // [M]
     float *Aext  = (float *)(Abase + M);              // [M]
-    int   *Bbase = (int *)(Aext + M);                 // [N]
-    float *Bext  = (float *)(Bbase + N);              // [N]
-    float *PrL   = Bext + N;                          // [3N] receiver positions
-    float *PvL   = PrL + 3 * N;                       // [4M] (virtual) sources + t0
+    float *Bext  = Aext + M;                          // [N]
+    float4 *nrec = (float4 *)(smem + (((2 * M + N) * 4 + 15) & ~15u));   // [N] per receiver {window base B (int bits), x, y, z}: ONE broadcast read per stage
+    float *PvL   = (float *)(nrec + N);               // [4M] (virtual) sources + t0
     float *NvL   = PvL + 4 * M;                       // [3M] transmit normals
-    const uint32_t hdr = ((M + N) * 8 + (3 * N + 7 * M) * 4 + 15) & ~15u;
+    const uint32_t hdr = ((((2 * M + N) * 4 + 15) & ~15u) + 16 * N + 7 * M * 4 + 15) & ~15u;
     ST *win = (ST *)(smem + hdr);                     // [NBUF][MB][W]
     float *part = (float *)(smem + hdr);              // prologue scratch, aliases the windows
     const uint32_t win_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem) + hdr;
@@ -209,7 +209,7 @@ das_tile_kernel(const TileParams P) {
     // The geometry tables are read from global memory in the prologue and from their LDS copies in the
     // main loop: a vector-memory load there would sit behind the stage's LDS-DMA in the in-order vmcnt
     // queue and expose the DMA latency every stage (measured: 15 of 64 ms).
-    const float *gPv = P.Pv, *gNv = P.Nv, *gPr = P.Pr;
+    const float *gPv = P.Pv, *gNv = P.Nv;
     auto a_of = [&](uint32_t m) -> double {              // tau_tx*fs - t0*fs + OFF, reference src/bf.cu:104-108,114
         const double rx = (double)px - (double)gPv[4 * m], ry = (double)py - (double)gPv[4 * m + 1], rz = (double)pz - (double)gPv[4 * m + 2];
         const double dot = rx * (double)gNv[3 * m] + ry * (double)gNv[3 * m + 1] + rz * (double)gNv[3 * m + 2];
@@ -217,10 +217,11 @@ das_tile_kernel(const TileParams P) {
         if (VS) { const double len = dsqrt(rx * rx + ry * ry + rz * rz); dv = DV ? len : copysign(len, dot); }
         return dv * cf - (double)gPv[4 * m + 3] * fs + tapinfo<INTERP>::OFF;
     };
-    auto b_of = [&](uint32_t n) -> double {              // tau_rx*fs, reference src/bf.cu:110
-        const double rx = (double)px - (double)gPr[3 * n], ry = (double)py - (double)gPr[3 * n + 1], rz = (double)pz - (double)gPr[3 * n + 2];
+    auto b_at = [&](float ex, float ey, float ez) -> double {      // tau_rx*fs for a receiver at (ex,ey,ez), reference src/bf.cu:110
+        const double rx = (double)px - (double)ex, ry = (double)py - (double)ey, rz = (double)pz - (double)ez;
         return dsqrt(rx * rx + ry * ry + rz * rz) * cf;
     };
+    auto b_of = [&](uint32_t n) -> double { return b_at(P.Pr[3 * n], P.Pr[3 * n + 1], P.Pr[3 * n + 2]); };
 
     // ---- prologue: tile-wide window bases / extents per transmit and per receiver
     const uint32_t MX = M > N ? M : N;
@@ -259,7 +260,7 @@ das_tile_kernel(const TileParams P) {
         const float fl = floorf(mn) - 1.0f;
         const bool fin = fabsf(fl) < 1.0e9f;
         const float e = fin ? (mx - fl) + 0.01f : INFINITY;
-        Bbase[n] = fin ? (int)fl : 0;
+        nrec[n] = make_float4(__int_as_float(fin ? (int)fl : 0), P.Pr[3 * n], P.Pr[3 * n + 1], P.Pr[3 * n + 2]);
         Bext[n] = e;
         b_lo = fminf(b_lo, fl); b_hi = fmaxf(b_hi, fl + e); b_ext = fmaxf(b_ext, e);
     }
@@ -284,10 +285,9 @@ das_tile_kernel(const TileParams P) {
     }
     // every window of every stage strictly inside the record?  (uniform) -> branch-free loop
     const bool tile_interior = (a_lo + b_lo >= 1.0f) && (a_hi + b_hi + (float)(K + 1) < (float)T);
-    for (uint32_t k = tid; k < 3 * N; k += THREADS) PrL[k] = P.Pr[k];
     for (uint32_t k = tid; k < 4 * M; k += THREADS) PvL[k] = P.Pv[k];
     for (uint32_t k = tid; k < 3 * M; k += THREADS) NvL[k] = P.Nv[k];
-    gPv = PvL; gNv = NvL; gPr = PrL;
+    gPv = PvL; gNv = NvL;
     __syncthreads();
 
     // ---- main loop over stages (mb = transmit block, n = receiver; n is the inner index)
@@ -309,18 +309,26 @@ das_tile_kernel(const TileParams P) {
     constexpr int NDMA = WPW * PCS;                    // DMA instructions per wave and stage
     static_assert(WB % 16 == 0 && PSZ == 16, "window must be a whole number of 16-byte lanes");
     const uint64_t xbytes = (uint64_t)P.N * P.M * P.T * SB;
-    auto stage_dma = [&](uint32_t n, uint32_t m0, int buf) {     // stage (receiver n, transmit block at m0)
-        const int bn = Bbase[n];
-        const uint64_t off = ((uint64_t)n * P.strN + (uint64_t)m0 * P.strM) * SB;
-        const uint64_t rem = xbytes - off;
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + off), 0,
+    // Per-wave DMA state: this wave stages windows j_r = wave + WAVES*r.  Everything that does not depend on the receiver is
+    // refreshed once per transmit block (dma_block); a stage then costs one LDS read (B[n]) and a few scalar ops per window.
+    int djo[WPW];                                      // j_r * strM * SB   (< 2^31 by the plan-time check)
+    uint64_t doff = 0;                                 // byte offset of trace (n, m0)
+#pragma unroll
+    for (int r = 0; r < WPW; ++r) djo[r] = (int)((long)(wave + WAVES * r) * (long)P.strM * SB);
+    uint32_t dm0 = 0;                                  // transmit block the DMA front is in
+    auto dma_block = [&](uint32_t m0) { dm0 = m0; doff = (uint64_t)m0 * P.strM * SB; };
+    auto stage_dma = [&](uint32_t n, int buf) {       // stage (receiver n, current DMA transmit block)
+        const int bn = __builtin_amdgcn_readfirstlane(__float_as_int(nrec[n].x));
+        const uint64_t rem = xbytes - doff;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + doff), 0,
                                                                     rem > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem, 0x00020000);
 #pragma unroll
         for (int r = 0; r < WPW; ++r) {
-            const uint32_t j = __builtin_amdgcn_readfirstlane(wave + WAVES * r);
-            const uint32_t m = m0 + j < M ? m0 + j : M - 1;
-            const int ws = __builtin_amdgcn_readfirstlane(Abase[m]) + bn;
-            const int so = (QDAS_ABL & 32) ? (int)(j & 1) * 4096 : (int)(((long)j * (long)P.strM + (long)ws) * SB);      // < 2^31 by plan-time check
+            const int j = __builtin_amdgcn_readfirstlane(wave + WAVES * r);
+            const uint32_t m = dm0 + j;
+            // (A[m] is re-read from LDS: keeping it in a register across stages costs a scratch spill at this occupancy)
+            const int am = __builtin_amdgcn_readfirstlane(Abase[m < M ? m : M - 1]);
+            const int so = (QDAS_ABL & 32) ? (j & 1) * 4096 : (am + bn) * SB + djo[r];
 #pragma unroll
             for (int q = 0; q < ((QDAS_ABL & 64) ? 1 : PCS); ++q) {
                 lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * MB + j) * WB + q * PB));
@@ -328,14 +336,16 @@ das_tile_kernel(const TileParams P) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, lane * 16, so + q * PB, 0, 0);
             }
         }
+        doff += (uint64_t)P.strN * SB;                 // next receiver, same transmit block
     };
 
     auto run = [&](auto check_tag) {
         constexpr bool CHECK = decltype(check_tag)::value;
         uint32_t pn = 0, pm0 = 0;                          // stage the DMA front is at (NBUF-1 stages ahead)
+        dma_block(0);
 #pragma unroll
         for (int b = 0; b < NBUF - 1; ++b)
-            if ((uint32_t)b < nstage) { stage_dma(pn, pm0, b); if (++pn == N) { pn = 0; pm0 += MB; } }
+            if ((uint32_t)b < nstage) { stage_dma(pn, b); if (++pn == N) { pn = 0; pm0 += MB; dma_block(pm0); } }
         // counted wait: everything but the newest (NBUF-2) stages has landed; then publish to the workgroup
         if (nstage >= (uint32_t)(NBUF - 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -344,8 +354,8 @@ das_tile_kernel(const TileParams P) {
         for (uint32_t st = 0; st < nstage; ++st, n = (n + 1 == N ? 0 : n + 1), m0 += (n == 0 ? MB : 0)) {
             const bool more = st + (NBUF - 1) < nstage;
             if (!(QDAS_ABL & 1) && more) {               // lands during the next NBUF-1 stages
-                stage_dma(pn, pm0, (buf + NBUF - 1) % NBUF);
-                if (++pn == N) { pn = 0; pm0 += MB; }
+                stage_dma(pn, (buf + NBUF - 1) % NBUF);
+                if (++pn == N) { pn = 0; pm0 += MB; dma_block(pm0); }
             }
 
             if (n == 0) {                              // new transmit block: refresh the tx residuals
@@ -353,10 +363,12 @@ das_tile_kernel(const TileParams P) {
                 for (int p = 0; p < MB / 2; ++p) {
                     const uint32_t ma = m0 + 2 * p < M ? m0 + 2 * p : M - 1, mb = m0 + 2 * p + 1 < M ? m0 + 2 * p + 1 : M - 1;
                     ra[p] = (v2f){(float)(a_of(ma) - ((double)Abase[ma] + 0.5)), (float)(a_of(mb) - ((double)Abase[mb] + 0.5))};
+                    __builtin_amdgcn_sched_barrier(0);      // one pair at a time: keeps this cold block from inflating the register budget
                 }
             }
-            const int bn = Bbase[n];
-            const float rb = (QDAS_ABL & 2) ? (float)(lane * 2 + 3) + 0.37f * (float)(n & 7) : (float)(b_of(n) - (double)bn);
+            const float4 rec = nrec[n];                // {B[n], receiver position}: one broadcast LDS read
+            const int bn = __float_as_int(rec.x);
+            const float rb = (QDAS_ABL & 2) ? (float)(lane * 2 + 3) + 0.37f * (float)(n & 7) : (float)(b_at(rec.y, rec.z, rec.w) - (double)bn);
             // LDS byte address of a tap = bits(t + MAGIC)*SB + cbase + (window, tap) immediate
             const uint32_t cbase = win_off + (uint32_t)buf * (MB * WB) - (MAGIC_BITS * (uint32_t)SB);
 
@@ -499,7 +511,7 @@ size_t tile_lds_bytes(int dtype, uint64_t N, uint64_t M) {
     const Cfg &g = CFGS[active_cfg()];
     const TileConfig c = tile_config(dtype, 0);
     const size_t MX = M > N ? M : N;
-    const size_t hdr = (((M + N) * 8 + (3 * N + 7 * M) * 4) + 15) & ~(size_t)15;
+    const size_t hdr = (((((2 * M + N) * 4 + 15) & ~(size_t)15) + 16 * N + 7 * M * 4) + 15) & ~(size_t)15;
     size_t body = c.lds_bytes;
     const size_t scratch = 2 * (size_t)g.waves * MX * 4 + 1024;   // prologue scratch aliases the windows
     if (body < scratch) body = scratch;
