@@ -34,6 +34,11 @@
 //    "image like".
 //  * Lanczos weights: even/odd-split polynomials (lanczos_poly.h), no transcendentals; fp16 data
 //    is accumulated in fp32 (the reference accumulates in half2, src/bf.cu:170).
+//  * Reciprocal mode (SYM): for a full-synthetic-aperture acquisition whose transmit elements ARE the
+//    receive elements (Pv == Pr, one t0), tau(n,m) == tau(m,n): tap index and weights are computed once
+//    per unordered pair {n,m} and applied to both traces x[:,n,m] and x[:,m,n] (direct + mirror window),
+//    which removes a third of the VALU work of the headline configuration without changing a single
+//    product (bit-identical weights for both traces).
 #include "qdas_device.h"
 #include "qdas_kernels.h"
 #include "lanczos_poly.h"
@@ -124,6 +129,12 @@ __device__ __forceinline__ void lds_fence(taps_f32 &a, taps_f32 &b, v2f (&w)[4])
                  : "+v"(a.s[0]), "+v"(a.s[1]), "+v"(a.s[2]), "+v"(a.s[3]), "+v"(b.s[0]), "+v"(b.s[1]), "+v"(b.s[2]), "+v"(b.s[3]),
                    "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
 }
+__device__ __forceinline__ void lds_fence2(taps_f32 &a, taps_f32 &b, taps_f32 &c, taps_f32 &d, v2f (&w)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a.s[0]), "+v"(a.s[1]), "+v"(a.s[2]), "+v"(a.s[3]), "+v"(b.s[0]), "+v"(b.s[1]), "+v"(b.s[2]), "+v"(b.s[3]),
+                   "+v"(c.s[0]), "+v"(c.s[1]), "+v"(c.s[2]), "+v"(c.s[3]), "+v"(d.s[0]), "+v"(d.s[1]), "+v"(d.s[2]), "+v"(d.s[3]),
+                   "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+}
 template <int... Is, typename F> __device__ __forceinline__ void unroll_impl(std::integer_sequence<int, Is...>, F &&f) {
     (f(std::integral_constant<int, Is>{}), ...);
 }
@@ -146,9 +157,11 @@ __device__ __forceinline__ uint32_t zero_of(const uint32_t *) { return 0u; }
 // CFG: WAVES waves (= image columns) per workgroup, MB transmits per stage, W samples per window,
 //      NBUF window buffers (NBUF-1 stages of LDS-DMA in flight), PSZ bytes per lane and DMA piece (12|16),
 //      BPC workgroups per CU the register budget is sized for.
-template <int INTERP, typename ST, bool FMOD, bool WTAB, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC>
+template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC>
 __global__ void __launch_bounds__(WAVES * 64, WAVES * BPC / 4)
 das_tile_kernel(const TileParams P) {
+    constexpr int NW = SYM ? 2 * MB : MB;     // windows per LDS buffer: direct (+ mirror) traces of a stage
+    static_assert(!SYM || (sizeof(ST) == 8 && !WTAB), "reciprocal mode: fp32 data, no weight table");
     constexpr int K = tapinfo<INTERP>::K;
     constexpr int THREADS = WAVES * 64;
     constexpr int TX = WAVES;                 // one image column per wave
@@ -169,7 +182,7 @@ das_tile_kernel(const TileParams P) {
     float *PvL   = (float *)(nrec + N);               // [4M] (virtual) sources + t0
     float *NvL   = PvL + 4 * M;                       // [3M] transmit normals
     const uint32_t hdr = ((((2 * M + N) * 4 + 15) & ~15u) + 16 * N + 7 * M * 4 + 15) & ~15u;
-    ST *win = (ST *)(smem + hdr);                     // [NBUF][MB][W]
+    ST *win = (ST *)(smem + hdr);                     // [NBUF][NW][W]
     float *part = (float *)(smem + hdr);              // prologue scratch, aliases the windows
     const uint32_t win_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem) + hdr;
 
@@ -225,26 +238,31 @@ das_tile_kernel(const TileParams P) {
 
     // ---- prologue: tile-wide window bases / extents per transmit and per receiver
     const uint32_t MX = M > N ? M : N;
-    for (uint32_t m = 0; m < M; ++m) {
-        const float a = (float)a_of(m);
-        const float mn = wave_min(a), mx = (a == a) ? wave_max(a) : INFINITY;
-        const float mxx = wave_max(mx);
-        if (lane == 0) { part[wave * MX + m] = mn; part[(WAVES + wave) * MX + m] = mxx; }
-    }
-    __syncthreads();
     float a_lo = INFINITY, a_hi = -INFINITY, a_ext = 0.f;            // per-thread partials of tile-wide stats
-    for (uint32_t m = tid; m < M; m += THREADS) {
-        float mn = part[m], mx = part[WAVES * MX + m];
+    // reciprocal mode: a(i,m) = b(i,m) + C with C = OFF - t0*fs, so A[m] := B[m] + floor(C) (filled below)
+    const double symC = tapinfo<INTERP>::OFF - (double)P.Pv[3] * fs;
+    const int symCi = (int)floor(symC);
+    if constexpr (!SYM) {
+        for (uint32_t m = 0; m < M; ++m) {
+            const float a = (float)a_of(m);
+            const float mn = wave_min(a), mx = (a == a) ? wave_max(a) : INFINITY;
+            const float mxx = wave_max(mx);
+            if (lane == 0) { part[wave * MX + m] = mn; part[(WAVES + wave) * MX + m] = mxx; }
+        }
+        __syncthreads();
+        for (uint32_t m = tid; m < M; m += THREADS) {
+            float mn = part[m], mx = part[WAVES * MX + m];
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + m]); mx = fmaxf(mx, part[(WAVES + w) * MX + m]); }
-        const float fl = floorf(mn) - 1.0f;              // margin: (float)a may have rounded up
-        const bool fin = fabsf(fl) < 1.0e9f;
-        const float e = fin ? (mx - fl) + 0.01f : INFINITY;
-        Abase[m] = fin ? (int)fl : 0;
-        Aext[m] = e;
-        a_lo = fminf(a_lo, fl); a_hi = fmaxf(a_hi, fl + e); a_ext = fmaxf(a_ext, e);
+            for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + m]); mx = fmaxf(mx, part[(WAVES + w) * MX + m]); }
+            const float fl = floorf(mn) - 1.0f;              // margin: (float)a may have rounded up
+            const bool fin = fabsf(fl) < 1.0e9f;
+            const float e = fin ? (mx - fl) + 0.01f : INFINITY;
+            Abase[m] = fin ? (int)fl : 0;
+            Aext[m] = e;
+            a_lo = fminf(a_lo, fl); a_hi = fmaxf(a_hi, fl + e); a_ext = fmaxf(a_ext, e);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (uint32_t n = 0; n < N; ++n) {
         const float b = (float)b_of(n);
         const float mn = wave_min(b), mx = (b == b) ? wave_max(b) : INFINITY;
@@ -263,6 +281,11 @@ das_tile_kernel(const TileParams P) {
         nrec[n] = make_float4(__int_as_float(fin ? (int)fl : 0), P.Pr[3 * n], P.Pr[3 * n + 1], P.Pr[3 * n + 2]);
         Bext[n] = e;
         b_lo = fminf(b_lo, fl); b_hi = fmaxf(b_hi, fl + e); b_ext = fmaxf(b_ext, e);
+        if constexpr (SYM) {                             // a - A = (b - B) + frac(C) in [1, Bext + 1)
+            Abase[n] = (fin ? (int)fl : 0) + symCi;
+            Aext[n] = e + 1.0f;
+            a_lo = fminf(a_lo, fl + (float)symCi); a_hi = fmaxf(a_hi, fl + (float)symCi + e + 1.0f); a_ext = fmaxf(a_ext, e + 1.0f);
+        }
     }
     __syncthreads();                                   // part[] is free again
     a_lo = wave_min(a_lo); b_lo = wave_min(b_lo);
@@ -292,7 +315,10 @@ das_tile_kernel(const TileParams P) {
 
     // ---- main loop over stages (mb = transmit block, n = receiver; n is the inner index)
     const uint32_t nmb = (M + MB - 1) / MB;
-    const uint32_t nstage = nmb * N;
+    // receivers paired with transmit block m0: all of them, or -- reciprocal mode -- only n <= the block's last transmit
+    auto nlim = [&](uint32_t m0) -> uint32_t { return SYM ? (m0 + MB < N ? m0 + MB : N) : N; };
+    uint32_t nstage = 0;
+    for (uint32_t kb = 0; kb < nmb; ++kb) nstage += nlim(kb * MB);
     v2f acc = {0.f, 0.f};                              // (re, im) of this lane's pixel
     v2f ra[MB / 2];                                    // tx residuals a - A[m] - 1/2 of transmits (2p, 2p+1), packed
     // ---- LDS-DMA staging.  One buffer descriptor per stage, based at trace (n, m0): window j starts
@@ -306,17 +332,20 @@ das_tile_kernel(const TileParams P) {
     //  measured with tools/scratch/dma12.hip)
     constexpr int PB = 1024;                           // bytes per full DMA piece (one wave-instruction x 16 B)
     constexpr int PCS = (WB + PB - 1) / PB;            // pieces per window; the last one may use fewer lanes
-    constexpr int NDMA = WPW * PCS;                    // DMA instructions per wave and stage
+    constexpr int NDMA = WPW * PCS * (SYM ? 2 : 1);    // DMA instructions per wave and stage
     static_assert(WB % 16 == 0 && PSZ == 16, "window must be a whole number of 16-byte lanes");
     const uint64_t xbytes = (uint64_t)P.N * P.M * P.T * SB;
     // Per-wave DMA state: this wave stages windows j_r = wave + WAVES*r.  Everything that does not depend on the receiver is
     // refreshed once per transmit block (dma_block); a stage then costs one LDS read (B[n]) and a few scalar ops per window.
-    int djo[WPW];                                      // j_r * strM * SB   (< 2^31 by the plan-time check)
-    uint64_t doff = 0;                                 // byte offset of trace (n, m0)
+    int djo[WPW], djo2[WPW];                           // j_r * strM * SB, j_r * strN * SB  (< 2^31 by the plan-time check)
+    uint64_t doff = 0, doff2 = 0;                      // byte offsets of trace (rx n, tx m0) and of the mirror trace (rx m0, tx n)
 #pragma unroll
-    for (int r = 0; r < WPW; ++r) djo[r] = (int)((long)(wave + WAVES * r) * (long)P.strM * SB);
+    for (int r = 0; r < WPW; ++r) {
+        djo[r] = (int)((long)(wave + WAVES * r) * (long)P.strM * SB);
+        djo2[r] = (int)((long)(wave + WAVES * r) * (long)P.strN * SB);
+    }
     uint32_t dm0 = 0;                                  // transmit block the DMA front is in
-    auto dma_block = [&](uint32_t m0) { dm0 = m0; doff = (uint64_t)m0 * P.strM * SB; };
+    auto dma_block = [&](uint32_t m0) { dm0 = m0; doff = (uint64_t)m0 * P.strM * SB; doff2 = (uint64_t)m0 * P.strN * SB; };
     auto stage_dma = [&](uint32_t n, int buf) {       // stage (receiver n, current DMA transmit block)
         const int bn = __builtin_amdgcn_readfirstlane(__float_as_int(nrec[n].x));
         const uint64_t rem = xbytes - doff;
@@ -331,12 +360,31 @@ das_tile_kernel(const TileParams P) {
             const int so = (QDAS_ABL & 32) ? (j & 1) * 4096 : (am + bn) * SB + djo[r];
 #pragma unroll
             for (int q = 0; q < ((QDAS_ABL & 64) ? 1 : PCS); ++q) {
-                lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * MB + j) * WB + q * PB));
+                lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + j) * WB + q * PB));
                 if (lane * 16 < WB - q * PB)             // trailing partial piece: upper lanes masked off
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, lane * 16, so + q * PB, 0, 0);
             }
         }
         doff += (uint64_t)P.strN * SB;                 // next receiver, same transmit block
+        if constexpr (SYM) {                           // mirror traces x[:, rx = m0 + j, tx = n]: same window start A[m] + B[n]
+            const uint64_t rem2 = xbytes - doff2;
+            __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + doff2), 0,
+                                                                         rem2 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem2, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < WPW; ++r) {
+                const int j = __builtin_amdgcn_readfirstlane(wave + WAVES * r);
+                const uint32_t m = dm0 + j;
+                const int am = __builtin_amdgcn_readfirstlane(Abase[m < M ? m : M - 1]);
+                const int so = (am + bn) * SB + djo2[r];
+#pragma unroll
+                for (int q = 0; q < PCS; ++q) {
+                    lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + MB + j) * WB + q * PB));
+                    if (lane * 16 < WB - q * PB)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, dst, 16, lane * 16, so + q * PB, 0, 0);
+                }
+            }
+            doff2 += (uint64_t)P.strM * SB;            // next "transmit" n of the mirror traces
+        }
     };
 
     auto run = [&](auto check_tag) {
@@ -345,23 +393,29 @@ das_tile_kernel(const TileParams P) {
         dma_block(0);
 #pragma unroll
         for (int b = 0; b < NBUF - 1; ++b)
-            if ((uint32_t)b < nstage) { stage_dma(pn, b); if (++pn == N) { pn = 0; pm0 += MB; dma_block(pm0); } }
+            if ((uint32_t)b < nstage) { stage_dma(pn, b); if (++pn == nlim(pm0)) { pn = 0; pm0 += MB; dma_block(pm0); } }
         // counted wait: everything but the newest (NBUF-2) stages has landed; then publish to the workgroup
         if (nstage >= (uint32_t)(NBUF - 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         int buf = 0;
         uint32_t n = 0, m0 = 0;
-        for (uint32_t st = 0; st < nstage; ++st, n = (n + 1 == N ? 0 : n + 1), m0 += (n == 0 ? MB : 0)) {
+        for (uint32_t st = 0; st < nstage; ++st, n = (n + 1 == nlim(m0) ? 0 : n + 1), m0 += (n == 0 ? MB : 0)) {
             const bool more = st + (NBUF - 1) < nstage;
             if (!(QDAS_ABL & 1) && more) {               // lands during the next NBUF-1 stages
                 stage_dma(pn, (buf + NBUF - 1) % NBUF);
-                if (++pn == N) { pn = 0; pm0 += MB; dma_block(pm0); }
+                if (++pn == nlim(pm0)) { pn = 0; pm0 += MB; dma_block(pm0); }
             }
 
             if (n == 0) {                              // new transmit block: refresh the tx residuals
 #pragma unroll
                 for (int p = 0; p < MB / 2; ++p) {
                     const uint32_t ma = m0 + 2 * p < M ? m0 + 2 * p : M - 1, mb = m0 + 2 * p + 1 < M ? m0 + 2 * p + 1 : M - 1;
+                    if constexpr (SYM) {               // a - A - 1/2 = (b - B) + frac(C) - 1/2, from the receiver records
+                        const float4 ea = nrec[ma], eb = nrec[mb];
+                        const double fc = symC - (double)symCi - 0.5;
+                        ra[p] = (v2f){(float)(b_at(ea.y, ea.z, ea.w) - (double)__float_as_int(ea.x) + fc),
+                                      (float)(b_at(eb.y, eb.z, eb.w) - (double)__float_as_int(eb.x) + fc)};
+                    } else
                     ra[p] = (v2f){(float)(a_of(ma) - ((double)Abase[ma] + 0.5)), (float)(a_of(mb) - ((double)Abase[mb] + 0.5))};
                     __builtin_amdgcn_sched_barrier(0);      // one pair at a time: keeps this cold block from inflating the register budget
                 }
@@ -370,13 +424,15 @@ das_tile_kernel(const TileParams P) {
             const int bn = __float_as_int(rec.x);
             const float rb = (QDAS_ABL & 2) ? (float)(lane * 2 + 3) + 0.37f * (float)(n & 7) : (float)(b_at(rec.y, rec.z, rec.w) - (double)bn);
             // LDS byte address of a tap = bits(t + MAGIC)*SB + cbase + (window, tap) immediate
-            const uint32_t cbase = win_off + (uint32_t)buf * (MB * WB) - (MAGIC_BITS * (uint32_t)SB);
+            const uint32_t cbase = win_off + (uint32_t)buf * (NW * WB) - (MAGIC_BITS * (uint32_t)SB);
 
             auto pairs = [&](auto pc, auto tailc) {       // transmits (m0+2p, m0+2p+1) ride in the two halves
                 constexpr int p = decltype(pc)::value;
-                constexpr bool TAIL = decltype(tailc)::value;   // last, partial transmit block: bounds checks
+                constexpr bool TAIL = !SYM && decltype(tailc)::value;  // last, partial transmit block: bounds checks
+                constexpr bool DIAG = SYM && decltype(tailc)::value;   // reciprocal mode, block that contains m == n
                 const uint32_t m = m0 + 2 * p;
                 if constexpr (TAIL) { if (m >= M) return; }
+                if constexpr (DIAG) { if (m + 1 < n) return; }          // both transmits below the diagonal: their pairs were done as mirrors
                 const bool upper = !TAIL || (m + 1 < M);  // the upper half carries a real transmit
                 float wr0 = 1.f, wi0 = 0.f, wr1 = 1.f, wi1 = 0.f;
                 if constexpr (WTAB) {
@@ -393,17 +449,24 @@ das_tile_kernel(const TileParams P) {
                 constexpr bool SPLIT = CHECK || FMOD || WTAB;       // the two halves need separate post-processing
                 v2f v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
                 if constexpr (F32) {
-                    taps_f32 g0, g1;
-                    if constexpr ((QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { g0.s[k] = (v2f){s.x, t.x}; g1.s[k] = (v2f){t.y, s.y}; } }
+                    taps_f32 g0, g1, h0, h1;              // direct taps x[:, n, m | m+1]; mirror taps x[:, m | m+1, n]
+                    if constexpr ((QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { g0.s[k] = h0.s[k] = (v2f){s.x, t.x}; g1.s[k] = h1.s[k] = (v2f){t.y, s.y}; } }
                     else {
                         lds_issue<K, (2 * p) * WB>(g0, ad0); lds_issue<K, (2 * p + 1) * WB>(g1, ad1);
-                        if constexpr (K < 4) { g0.s[2] = g0.s[3] = g1.s[2] = g1.s[3] = (v2f){0.f, 0.f}; }
-                        if constexpr (K < 2) { g0.s[1] = g1.s[1] = (v2f){0.f, 0.f}; }
+                        if constexpr (SYM) { lds_issue<K, (MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (MB + 2 * p + 1) * WB>(h1, ad1); }
+                        if constexpr (K < 4) { g0.s[2] = g0.s[3] = g1.s[2] = g1.s[3] = h0.s[2] = h0.s[3] = h1.s[2] = h1.s[3] = (v2f){0.f, 0.f}; }
+                        if constexpr (K < 2) { g0.s[1] = g1.s[1] = h0.s[1] = h1.s[1] = (v2f){0.f, 0.f}; }
                     }
                     v2f w[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
                     if constexpr ((QDAS_ABL & 8) != 0) { w[0] = s; w[1] = t; w[2] = tm; w[3] = s + t; }
                     else if constexpr (K > 1) weights2<INTERP>(s, w);       // overlaps the LDS latency
-                    lds_fence(g0, g1, w);
+                    if constexpr (SYM) lds_fence2(g0, g1, h0, h1, w); else lds_fence(g0, g1, w);
+                    if constexpr (DIAG) {                 // uniform, only in the block that holds the diagonal
+                        const v2f z = {0.f, 0.f};
+                        if (m < n)      { for (int k = 0; k < 4; ++k) g0.s[k] = z; }     // pair (n, m<n): done as the mirror of (m, n)
+                        if (m <= n)     { for (int k = 0; k < 4; ++k) h0.s[k] = z; }     // m == n: the trace is its own mirror
+                        if (m + 1 <= n) { for (int k = 0; k < 4; ++k) h1.s[k] = z; }
+                    }
                     if constexpr (TAIL) {
                         if (!upper) {                       // odd M: no transmit in the upper half (uniform, rare)
 #pragma unroll
@@ -414,10 +477,19 @@ das_tile_kernel(const TileParams P) {
                     else if constexpr (SPLIT) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { v0 = w[k].x * g0.s[k] + v0; v1 = w[k].y * g1.s[k] + v1; }
+                        if constexpr (SYM) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) { v0 = w[k].x * h0.s[k] + v0; v1 = w[k].y * h1.s[k] + v1; }
+                        }
                     } else {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { acc = w[k].x * g0.s[k] + acc; acc = w[k].y * g1.s[k] + acc; }
+                        if constexpr (SYM) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) { acc = w[k].x * h0.s[k] + acc; acc = w[k].y * h1.s[k] + acc; }
+                        }
                     }
+                    if constexpr (SYM && K == 1) { v0 += h0.s[0]; v1 += h1.s[0]; }
                 } else {
                     taps_f16 g0, g1;
                     lds_load_f16<K>(g0, ad0 + (2 * p) * WB); lds_load_f16<K>(g1, ad1 + (2 * p + 1) * WB);
@@ -459,8 +531,9 @@ das_tile_kernel(const TileParams P) {
                     acc += (v2f){wr1 * v1.x - wi1 * v1.y, wr1 * v1.y + wi1 * v1.x};
                 } else if constexpr (SPLIT || !F32 || K == 1) { acc += v0; acc += v1; }
             };
-            if (m0 + MB <= M) unroll<MB / 2>([&](auto pc) { pairs(pc, std::false_type{}); });   // full block: check-free
-            else              unroll<MB / 2>([&](auto pc) { pairs(pc, std::true_type{}); });
+            // full block (reciprocal mode: block entirely above the diagonal): check-free; else the tail / diagonal variant
+            if (SYM ? (n < m0) : (m0 + MB <= M)) unroll<MB / 2>([&](auto pc) { pairs(pc, std::false_type{}); });
+            else                                 unroll<MB / 2>([&](auto pc) { pairs(pc, std::true_type{}); });
 
             // stage st+1 must have landed (all but the NBUF-2 newest DMA groups), all my LDS reads are done
             if (!(QDAS_ABL & 16)) {
@@ -481,35 +554,26 @@ das_tile_kernel(const TileParams P) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Launch configurations.  cfg 0: 16-wave workgroup = 64 x 16 pixel tile, 3 window buffers, one workgroup per CU;
-//                         cfg 1: 8-wave workgroup  = 64 x 8 pixel tile, 2 buffers, two workgroups per CU.
+// Launch configurations.  cfg 0: 16-wave workgroup = 64 x 16 pixel tile, 32 transmits per stage, 2 window buffers, one
+// workgroup per CU (general case);  cfg 1: the same tile with 16 transmits per stage and direct + mirror windows
+// (reciprocal mode).
 struct Cfg { int waves, mb, w, nbuf, psz, bpc; };
-static constexpr Cfg CFGS[4] = {{16, 16, 192, 3, 16, 1}, {8, 16, 192, 2, 16, 2}, {16, 32, 192, 3, 16, 1}, {16, 32, 192, 2, 16, 1}};
+static constexpr Cfg CFGS[2] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}};
 
-#define QDAS_DEFAULT_CFG 3
-static int active_cfg() {
-#ifndef QDAS_ALL_CFGS
-    return QDAS_DEFAULT_CFG;
-#endif
-    static int c = -1;
-    if (c < 0) { const char *e = getenv("QDAS_TILE_CFG"); c = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : QDAS_DEFAULT_CFG; }
-    return c;
-}
-
-TileConfig tile_config(int dtype, int /*interp*/) {
-    const Cfg &g = CFGS[active_cfg()];
+TileConfig tile_config(int dtype, int sym) {
+    const Cfg &g = CFGS[sym ? 1 : 0];
     TileConfig c;
     c.tile_cols = g.waves;
     c.mb = g.mb;
     c.window = g.w;
     c.threads = g.waves * 64;
-    c.lds_bytes = (size_t)g.nbuf * g.mb * g.w * (dtype == 2 ? 4 : 8);
+    c.lds_bytes = (size_t)g.nbuf * g.mb * (sym ? 2 : 1) * g.w * (dtype == 2 ? 4 : 8);
     return c;
 }
 
-size_t tile_lds_bytes(int dtype, uint64_t N, uint64_t M) {
-    const Cfg &g = CFGS[active_cfg()];
-    const TileConfig c = tile_config(dtype, 0);
+size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M) {
+    const Cfg &g = CFGS[sym ? 1 : 0];
+    const TileConfig c = tile_config(dtype, sym);
     const size_t MX = M > N ? M : N;
     const size_t hdr = (((((2 * M + N) * 4 + 15) & ~(size_t)15) + 16 * N + 7 * M * 4) + 15) & ~(size_t)15;
     size_t body = c.lds_bytes;
@@ -517,40 +581,43 @@ size_t tile_lds_bytes(int dtype, uint64_t N, uint64_t M) {
     if (body < scratch) body = scratch;
     return hdr + body;
 }
-size_t tile_lds_limit() { return (size_t)(160 * 1024) / CFGS[active_cfg()].bpc; }
+size_t tile_lds_limit(int sym) { return (size_t)(160 * 1024) / CFGS[sym ? 1 : 0].bpc; }
 
 template <int INTERP, typename ST, int CI>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
     constexpr Cfg G = CFGS[CI];
-    constexpr int W = (sizeof(ST) == 4 && G.psz == 12) ? G.w : G.w;     // fp16: W*4 bytes must still be whole pieces
+    constexpr bool SYM = (CI == 1);
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
     const dim3 g(ntiles), b(G.waves * 64);
 #define QDAS_LAUNCH(FM, WT)                                                                              \
     do {                                                                                                 \
-        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, G.waves, G.mb, W, G.nbuf, G.psz, G.bpc>;          \
+        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc>;   \
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                   \
         kfn<<<g, b, lds, s>>>(P);                                                                        \
     } while (0)
-    if (fm && wt) QDAS_LAUNCH(true, true);
-    else if (fm)  QDAS_LAUNCH(true, false);
-    else if (wt)  QDAS_LAUNCH(false, true);
-    else          QDAS_LAUNCH(false, false);
+    if constexpr (SYM) {
+        if (wt) return hipErrorInvalidValue;
+        if (fm) QDAS_LAUNCH(true, false); else QDAS_LAUNCH(false, false);
+    } else {
+        if (fm && wt) QDAS_LAUNCH(true, true);
+        else if (fm)  QDAS_LAUNCH(true, false);
+        else if (wt)  QDAS_LAUNCH(false, true);
+        else          QDAS_LAUNCH(false, false);
+    }
 #undef QDAS_LAUNCH
     return hipGetLastError();
 }
 
 hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s) {
     if (ntiles == 0) return hipSuccess;
-    const size_t lds = tile_lds_bytes(dtype, P.N, P.M);
-    if (lds > tile_lds_limit()) return hipErrorInvalidValue;
-    const int interp = P.flag & 7, ci = active_cfg();
-#define QDAS_CI(I, C) (dtype == 2 ? launch_tile_i<I, uint32_t, C>(P, ntiles, lds, s) : launch_tile_i<I, float2, C>(P, ntiles, lds, s))
-#ifdef QDAS_ALL_CFGS
-#define QDAS_DT(I) (ci == 0 ? QDAS_CI(I, 0) : ci == 1 ? QDAS_CI(I, 1) : ci == 2 ? QDAS_CI(I, 2) : QDAS_CI(I, 3))
-#else
-#define QDAS_DT(I) QDAS_CI(I, QDAS_DEFAULT_CFG)
-#endif
+    const int sym = P.sym ? 1 : 0;
+    if (sym && dtype != 1) return hipErrorInvalidValue;
+    const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M);
+    if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
+    const int interp = P.flag & 7;
+#define QDAS_DT(I) (sym ? launch_tile_i<I, float2, 1>(P, ntiles, lds, s)                                 \
+                        : (dtype == 2 ? launch_tile_i<I, uint32_t, 0>(P, ntiles, lds, s) : launch_tile_i<I, float2, 0>(P, ntiles, lds, s)))
     switch (interp) {
         case 0: return QDAS_DT(0);
         case 1: case 4: return QDAS_DT(1);
@@ -559,7 +626,6 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
         case 5: return QDAS_DT(5);
     }
 #undef QDAS_DT
-#undef QDAS_CI
     return hipErrorInvalidValue;
 }
 

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -204,15 +205,29 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     for (int k = 0; k < 5 && eligible; ++k) if (g.cst[k]) { eligible = false; why = "tiled kernel needs a scalar sound speed"; }
     for (uint64_t s = 0; s < z.S && eligible; ++s)
         for (int k = 0; k < 3; ++k) if (g.ast[6 * s + k]) { eligible = false; why = "tiled kernel needs pixel-independent apodization"; }
-    pl->tc = tile_config(dt, z.flag & 7);
-    if (eligible && tile_lds_bytes(dt, z.N, z.M) > tile_lds_limit()) {
+    // reciprocal mode (das_tile.hip "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
+    // elements and share one t0 has tau(n,m) == tau(m,n); detected from the geometry itself, bit-exactly.
+    int sym = 0;
+    if (eligible && dt == QDAS_F32 && z.VS && z.DV && z.N == z.M && z.S == 0 && !getenv("QDAS_NO_SYM")) {
+        std::vector<float> hr(3 * z.N), hv(4 * z.M);
+        if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
+        if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);
+        sym = 1;
+        for (uint64_t m = 0; m < z.M && sym; ++m)
+            if (memcmp(&hv[4 * m], &hr[3 * m], 12) != 0 || memcmp(&hv[4 * m + 3], &hv[3], 4) != 0) sym = 0;
+        if (sym && (z.M % tile_config(dt, 1).mb != 0 || tile_lds_bytes(dt, 1, z.N, z.M) > tile_lds_limit(1))) sym = 0;
+    }
+    pl->tc = tile_config(dt, sym);
+    if (eligible && tile_lds_bytes(dt, sym, z.N, z.M) > tile_lds_limit(sym)) {
         eligible = false; why = "tiled kernel: N + M too large for the LDS header";
     }
     if (eligible && (z.T < 8)) { eligible = false; why = "tiled kernel needs T >= 8"; }
-    {   // LDS-DMA offsets inside one stage are 32-bit: (mb-1)*strM + window must stay below 2^31 bytes
+    {   // LDS-DMA offsets inside one stage are 32-bit: (mb-1)*stride + window must stay below 2^31 bytes
         const uint64_t strM = (z.flag & QDAS_FLAG_TPOSE) ? z.T : z.T * z.N;
-        if (eligible && ((uint64_t)pl->tc.mb * strM + 4096) * data_size(dt) >= (1ull << 31)) {
-            eligible = false; why = "tiled kernel: transmit stride too large for 32-bit DMA offsets";
+        const uint64_t strN = (z.flag & QDAS_FLAG_TPOSE) ? z.T * z.M : z.T;
+        const uint64_t smax = sym ? (strM > strN ? strM : strN) : strM;
+        if (eligible && ((uint64_t)pl->tc.mb * smax + 4096) * data_size(dt) >= (1ull << 31)) {
+            eligible = false; why = "tiled kernel: trace stride too large for 32-bit DMA offsets";
         }
     }
     if (desc->kernel == QDAS_KERNEL_TILED && !eligible) return bail(fail(QDAS_EUNSUPPORTED, "%s", why));
@@ -230,7 +245,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if ((rc = fetch_host(desc->cinv, sizeof(float), desc->mem, &cinv0))) return bail(rc);
         t.fs = g.fs; t.fmod = g.fmod;
         t.cinv_fs = (double)cinv0 * g.fs;
-        t.flag = z.flag; t.VS = z.VS; t.DV = z.DV;
+        t.flag = z.flag; t.VS = z.VS; t.DV = z.DV; t.sym = sym;
         // tile grid: 64 pixels of I1 x tile_cols columns (columns = I2*I3 flattened)
         const uint64_t ncols = z.I2 * z.I3;
         const uint64_t col0 = desc->i_begin / z.I1, col1 = (desc->i_begin + pl->i_count - 1) / z.I1;

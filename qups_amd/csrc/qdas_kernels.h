@@ -40,15 +40,16 @@ struct TileParams {
     double cinv_fs;                     // cinv * fs
     double fs, fmod;
     int32_t flag, VS, DV;
+    int32_t sym;                        // reciprocal mode: Pv == Pr, one t0 (checked by the host) -> tau(n,m) == tau(m,n)
     uint32_t tiles_z, tiles_x, tile_x0; // tile grid over (I1/64) x (columns/TX); first column tile of the shard
     uint32_t *fallback_list;            // [0] = count, [1..] = tile ids that did not fit the LDS window
     uint32_t fallback_cap;
 };
 
 struct TileConfig { int tile_cols; int mb; int window; size_t lds_bytes; int threads; };
-TileConfig tile_config(int dtype, int interp);
-size_t tile_lds_bytes(int dtype, uint64_t N, uint64_t M);   // dynamic LDS of one workgroup
-size_t tile_lds_limit();                                      // LDS budget of one workgroup in the active configuration
+TileConfig tile_config(int dtype, int sym);
+size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M);   // dynamic LDS of one workgroup
+size_t tile_lds_limit(int sym);                               // LDS budget of one workgroup in that configuration
 hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s);
 
 // ---- split-delay kernel (das_lut.hip)
