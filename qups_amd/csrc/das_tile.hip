@@ -135,6 +135,14 @@ __device__ __forceinline__ void lds_fence2(taps_f32 &a, taps_f32 &b, taps_f32 &c
                    "+v"(c.s[0]), "+v"(c.s[1]), "+v"(c.s[2]), "+v"(c.s[3]), "+v"(d.s[0]), "+v"(d.s[1]), "+v"(d.s[2]), "+v"(d.s[3]),
                    "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
 }
+// counted variant for the software-pipelined loop: the NEWEST `KEEP` LDS reads (the next iteration's direct taps) stay in flight
+template <int KEEP> __device__ __forceinline__ void lds_fence2_keep(taps_f32 &a, taps_f32 &b, taps_f32 &c, taps_f32 &d, v2f (&w)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%20)"
+                 : "+v"(a.s[0]), "+v"(a.s[1]), "+v"(a.s[2]), "+v"(a.s[3]), "+v"(b.s[0]), "+v"(b.s[1]), "+v"(b.s[2]), "+v"(b.s[3]),
+                   "+v"(c.s[0]), "+v"(c.s[1]), "+v"(c.s[2]), "+v"(c.s[3]), "+v"(d.s[0]), "+v"(d.s[1]), "+v"(d.s[2]), "+v"(d.s[3]),
+                   "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])
+                 : "n"(KEEP));
+}
 template <int... Is, typename F> __device__ __forceinline__ void unroll_impl(std::integer_sequence<int, Is...>, F &&f) {
     (f(std::integral_constant<int, Is>{}), ...);
 }
@@ -320,6 +328,7 @@ das_tile_kernel(const TileParams P) {
     uint32_t nstage = 0;
     for (uint32_t kb = 0; kb < nmb; ++kb) nstage += nlim(kb * MB);
     v2f acc = {0.f, 0.f};                              // (re, im) of this lane's pixel
+    v2f acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f}, acc3 = {0.f, 0.f};   // independent partial sums: no back-to-back dependent packed FMAs
     v2f ra[MB / 2];                                    // tx residuals a - A[m] - 1/2 of transmits (2p, 2p+1), packed
     // ---- LDS-DMA staging.  One buffer descriptor per stage, based at trace (n, m0): window j starts
     //      (j*strM + A[m0+j] + B[n]) samples after it.  A lane moves 16 bytes; a wave-instruction 1 KiB.
@@ -444,8 +453,8 @@ das_tile_kernel(const TileParams P) {
                 const v2f t = ra[p] + rb;                 // = tau*fs + OFF - (A+B) - 1/2
                 const v2f tm = t + MAGIC;
                 const v2f s = t - (tm - MAGIC);           // in [-1/2, 1/2]
-                const uint32_t ad0 = __float_as_uint(tm.x) * (uint32_t)SB + cbase;
-                const uint32_t ad1 = __float_as_uint(tm.y) * (uint32_t)SB + cbase;
+                const uint32_t ad0 = ((QDAS_ABL & 128) ? (MAGIC_BITS + (uint32_t)lane + (__float_as_uint(tm.x) & 1u)) : __float_as_uint(tm.x)) * (uint32_t)SB + cbase;
+                const uint32_t ad1 = ((QDAS_ABL & 128) ? (MAGIC_BITS + (uint32_t)lane + (__float_as_uint(tm.y) & 1u)) : __float_as_uint(tm.y)) * (uint32_t)SB + cbase;
                 constexpr bool SPLIT = CHECK || FMOD || WTAB;       // the two halves need separate post-processing
                 v2f v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
                 if constexpr (F32) {
@@ -483,10 +492,10 @@ das_tile_kernel(const TileParams P) {
                         }
                     } else {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) { acc = w[k].x * g0.s[k] + acc; acc = w[k].y * g1.s[k] + acc; }
+                        for (int k = 0; k < K; ++k) { acc = w[k].x * g0.s[k] + acc; acc1 = w[k].y * g1.s[k] + acc1; }
                         if constexpr (SYM) {
 #pragma unroll
-                            for (int k = 0; k < K; ++k) { acc = w[k].x * h0.s[k] + acc; acc = w[k].y * h1.s[k] + acc; }
+                            for (int k = 0; k < K; ++k) { acc2 = w[k].x * h0.s[k] + acc2; acc3 = w[k].y * h1.s[k] + acc3; }
                         }
                     }
                     if constexpr (SYM && K == 1) { v0 += h0.s[0]; v1 += h1.s[0]; }
@@ -532,8 +541,45 @@ das_tile_kernel(const TileParams P) {
                 } else if constexpr (SPLIT || !F32 || K == 1) { acc += v0; acc += v1; }
             };
             // full block (reciprocal mode: block entirely above the diagonal): check-free; else the tail / diagonal variant
-            if (SYM ? (n < m0) : (m0 + MB <= M)) unroll<MB / 2>([&](auto pc) { pairs(pc, std::false_type{}); });
-            else                                 unroll<MB / 2>([&](auto pc) { pairs(pc, std::true_type{}); });
+            if (SYM ? (n < m0) : (m0 + MB <= M)) {
+                if constexpr (SYM && F32 && K == 4 && !(CHECK || FMOD || WTAB) && !(QDAS_ABL & 256)) {
+                    // Software-pipelined: the direct taps of iteration p+1 are requested before the MACs of iteration p, so the
+                    // LDS pipe always has work queued and the counted wait (newest 8 reads stay in flight) rarely stalls.
+                    constexpr int NP = MB / 2;
+                    taps_f32 gd0[2], gd1[2];               // direct taps of the two halves, double-buffered over iterations
+                    v2f sv[2];
+                    uint32_t a0v[2], a1v[2];
+                    auto index = [&](auto pc) {            // index math + direct reads of iteration p
+                        constexpr int p = decltype(pc)::value;
+                        const v2f t = ra[p] + rb;
+                        const v2f tm = t + MAGIC;
+                        sv[p & 1] = t - (tm - MAGIC);
+                        a0v[p & 1] = __float_as_uint(tm.x) * (uint32_t)SB + cbase;
+                        a1v[p & 1] = __float_as_uint(tm.y) * (uint32_t)SB + cbase;
+                        lds_issue<K, (2 * p) * WB>(gd0[p & 1], a0v[p & 1]); lds_issue<K, (2 * p + 1) * WB>(gd1[p & 1], a1v[p & 1]);
+                    };
+                    index(std::integral_constant<int, 0>{});
+                    unroll<NP>([&](auto pc) {
+                        constexpr int p = decltype(pc)::value;
+                        taps_f32 h0, h1;
+                        lds_issue<K, (MB + 2 * p) * WB>(h0, a0v[p & 1]); lds_issue<K, (MB + 2 * p + 1) * WB>(h1, a1v[p & 1]);
+                        if constexpr (p + 1 < NP) index(std::integral_constant<int, p + 1>{});
+                        v2f w[4];
+                        weights2<INTERP>(sv[p & 1], w);
+                        if constexpr (p + 1 < NP) lds_fence2_keep<8>(gd0[p & 1], gd1[p & 1], h0, h1, w);
+                        else                      lds_fence2_keep<0>(gd0[p & 1], gd1[p & 1], h0, h1, w);
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            acc = w[k].x * gd0[p & 1].s[k] + acc; acc1 = w[k].y * gd1[p & 1].s[k] + acc1;
+                            acc2 = w[k].x * h0.s[k] + acc2;        acc3 = w[k].y * h1.s[k] + acc3;
+                        }
+                    });
+                } else {
+                    unroll<MB / 2>([&](auto pc) { pairs(pc, std::false_type{}); });
+                }
+            } else {
+                unroll<MB / 2>([&](auto pc) { pairs(pc, std::true_type{}); });
+            }
 
             // stage st+1 must have landed (all but the NBUF-2 newest DMA groups), all my LDS reads are done
             if (!(QDAS_ABL & 16)) {
@@ -545,6 +591,7 @@ das_tile_kernel(const TileParams P) {
     };
     if (tile_interior) run(std::false_type{}); else run(std::true_type{});
 
+    acc = (acc + acc1) + (acc2 + acc3);
     // ---- epilogue: y[i] = pix  (reference src/bf.cu:140); lanes = consecutive i -> coalesced
     {
         const uint64_t ig = i1 + P.I1 * col;

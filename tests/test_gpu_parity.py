@@ -321,3 +321,37 @@ def test_error_paths():
         das_spec("DAS", *args, "apod", np.ones((1, 1, 1, 5, 1)))
     with pytest.raises(_lib.QdasError, match="tiled kernel"):
         das_spec("SYN", *args, kernel=2)
+
+
+def test_reciprocal_mode_matches_general_mode(monkeypatch):
+    """FSA with Pv == Pr runs the reciprocal (SYM) tiled kernel: tau(n,m) == tau(m,n), weights shared by the direct and the
+    mirror trace.  It must agree with the general tiled kernel (QDAS_NO_SYM=1) and with the oracle, also for transposed data,
+    and must NOT engage when the geometry is not reciprocal (per-transmit t0, N not a multiple of the transmit block)."""
+    for tpose in (False, True):
+        case = make_case(seq="FSA", interp="lanczos3", seed=31, N=32, I1=140, I2=20, data="noise")
+        ref = run_oracle(case)
+        monkeypatch.delenv("QDAS_NO_SYM", raising=False)
+        a, pa = run_das(case, kernel=2, tpose=tpose)
+        monkeypatch.setenv("QDAS_NO_SYM", "1")
+        b, pb = run_das(case, kernel=2, tpose=tpose)
+        monkeypatch.delenv("QDAS_NO_SYM", raising=False)
+        assert pa.fallback_tiles() == 0 and pb.fallback_tiles() == 0
+        assert rel_err(a, ref) <= 2e-5 and rel_err(b, ref) <= 2e-5
+        assert rel_err(a, b) <= 5e-6
+    # edge of the record + reciprocal mode (checked loop)
+    case = make_case(seq="FSA", interp="cubic", seed=32, N=16, T=300, data="noise", zlim=(1e-3, 30e-3), I1=128, I2=16)
+    ref = run_oracle(case)
+    out, _ = run_das(case, kernel=2)
+    assert np.all(out[np.abs(ref) == 0] == 0) and rel_err(out, ref) <= 3e-5
+    # fmod in reciprocal mode
+    case = make_case(seq="FSA", interp="cubic", seed=33, N=16, I1=100, I2=16)
+    fm = float(np.float32(case["fc"]))
+    assert rel_err(run_das(case, kernel=2, fmod=fm)[0], run_oracle(case, fmod=fm)) <= 2e-4
+    # not reciprocal: per-transmit t0 -> general kernel path, still correct
+    case = make_case(seq="FSA", interp="linear", seed=34, N=16, I1=70, I2=16)
+    t0 = (case["t0"] + np.arange(16) / case["fs"]).astype(np.float32).astype(np.float64)
+    # (this grid is coarse enough that its first tile overflows the LDS window and is redone by the generic kernel:
+    #  generic-kernel tolerance applies)
+    assert rel_err(run_das(case, kernel=2, t0=t0)[0], run_oracle(case, t0=t0)) <= TOL32
+    case = make_case(seq="FSA", interp="linear", seed=35, N=20, I1=70, I2=16)      # 20 % 16 != 0
+    assert rel_err(run_das(case, kernel=2)[0], run_oracle(case)) <= TOL32
