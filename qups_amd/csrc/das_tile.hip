@@ -34,6 +34,10 @@
 //    "image like".
 //  * Lanczos weights: even/odd-split polynomials (lanczos_poly.h), no transcendentals; fp16 data
 //    is accumulated in fp32 (the reference accumulates in half2, src/bf.cu:170).
+//  * One apodization array may depend on the pixel AND the receiver (I1 x I2 x I3 x N, e.g. an acceptance-angle
+//    mask, reference src/UltrasoundSystem.m:5303-5374): it does not depend on the transmit, so it multiplies the
+//    stage's partial sum once per (pixel, receiver) -- prefetched one stage ahead, coalesced along I1 -- and a wave
+//    whose 64 weights are all zero skips the stage's gathers altogether.
 //  * Reciprocal mode (SYM): for a full-synthetic-aperture acquisition whose transmit elements ARE the
 //    receive elements (Pv == Pr, one t0), tau(n,m) == tau(m,n): tap index and weights are computed once
 //    per unordered pair {n,m} and applied to both traces x[:,n,m] and x[:,m,n] (direct + mirror window),
@@ -396,8 +400,27 @@ das_tile_kernel(const TileParams P) {
         }
     };
 
+    // ---- per-(pixel, receiver) apodization (optional; uniform runtime switch, nothing of it in the pair loop)
+    const bool wpix = P.apix != nullptr;
+    const uint64_t Itot = P.I1 * P.I2 * P.I3;
+    const uint64_t ipc = (i1 < P.I1 ? i1 : P.I1 - 1) + P.I1 * (col < ncols ? col : ncols - 1);   // my (clamped) pixel
+    auto wload = [&](uint32_t n) -> v2f {
+        const uint64_t k = ipc + Itot * n;
+        if (P.apix_real) {
+            if constexpr (F32) return (v2f){((const float *)P.apix)[k], 0.f};
+            else return (v2f){__half2float(__ushort_as_half(((const unsigned short *)P.apix)[k])), 0.f};
+        } else {
+            if constexpr (F32) { const float2 v = ((const float2 *)P.apix)[k]; return (v2f){v.x, v.y}; }
+            else { const uint32_t v = ((const uint32_t *)P.apix)[k];
+                   return (v2f){__half2float(__ushort_as_half((unsigned short)(v & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(v >> 16)))}; }
+        }
+    };
+    v2f tot = {0.f, 0.f};                              // weighted total when wpix (acc.. then hold one stage's partial sum)
+
     auto run = [&](auto check_tag) {
         constexpr bool CHECK = decltype(check_tag)::value;
+        v2f wcur = {1.f, 0.f}, wnext = {1.f, 0.f};
+        if (wpix) wcur = wload(0);
         uint32_t pn = 0, pm0 = 0;                          // stage the DMA front is at (NBUF-1 stages ahead)
         dma_block(0);
 #pragma unroll
@@ -410,6 +433,9 @@ das_tile_kernel(const TileParams P) {
         uint32_t n = 0, m0 = 0;
         for (uint32_t st = 0; st < nstage; ++st, n = (n + 1 == nlim(m0) ? 0 : n + 1), m0 += (n == 0 ? MB : 0)) {
             const bool more = st + (NBUF - 1) < nstage;
+            // next stage's pixel weight: requested BEFORE this stage's DMA, so the end-of-stage wait covers it
+            if (wpix && st + 1 < nstage) wnext = wload(n + 1 == nlim(m0) ? 0 : n + 1);
+            const bool skip = wpix && (__ballot(wcur.x != 0.f || wcur.y != 0.f) == 0ull);   // whole wave weightless: no gathers
             if (!(QDAS_ABL & 1) && more) {               // lands during the next NBUF-1 stages
                 stage_dma(pn, (buf + NBUF - 1) % NBUF);
                 if (++pn == nlim(pm0)) { pn = 0; pm0 += MB; dma_block(pm0); }
@@ -429,6 +455,7 @@ das_tile_kernel(const TileParams P) {
                     __builtin_amdgcn_sched_barrier(0);      // one pair at a time: keeps this cold block from inflating the register budget
                 }
             }
+            if (!skip) {
             const float4 rec = nrec[n];                // {B[n], receiver position}: one broadcast LDS read
             const int bn = __float_as_int(rec.x);
             const float rb = (QDAS_ABL & 2) ? (float)(lane * 2 + 3) + 0.37f * (float)(n & 7) : (float)(b_at(rec.y, rec.z, rec.w) - (double)bn);
@@ -581,17 +608,25 @@ das_tile_kernel(const TileParams P) {
                 unroll<MB / 2>([&](auto pc) { pairs(pc, std::true_type{}); });
             }
 
+            }   // !skip
+
             // stage st+1 must have landed (all but the NBUF-2 newest DMA groups), all my LDS reads are done
             if (!(QDAS_ABL & 16)) {
                 if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NBUF - 2) * NDMA) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             buf = (buf + 1 == NBUF) ? 0 : buf + 1;
+            if (wpix) {                                // weight the stage's partial sum (the weight does not depend on m)
+                const v2f S = (acc + acc1) + (acc2 + acc3);
+                tot += (v2f){wcur.x * S.x - wcur.y * S.y, wcur.x * S.y + wcur.y * S.x};
+                acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
+                wcur = wnext;
+            }
         }
     };
     if (tile_interior) run(std::false_type{}); else run(std::true_type{});
 
-    acc = (acc + acc1) + (acc2 + acc3);
+    acc = wpix ? tot : (acc + acc1) + (acc2 + acc3);
     // ---- epilogue: y[i] = pix  (reference src/bf.cu:140); lanes = consecutive i -> coalesced
     {
         const uint64_t ig = i1 + P.I1 * col;

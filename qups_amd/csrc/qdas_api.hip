@@ -203,8 +203,19 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     bool eligible = (dt == QDAS_F32 || dt == QDAS_F16) && !(z.flag & (QDAS_FLAG_KEEP_RX | QDAS_FLAG_KEEP_TX));
     const char *why = "tiled kernel needs fp32/fp16 data and the 'DAS' (sum both apertures) mode";
     for (int k = 0; k < 5 && eligible; ++k) if (g.cst[k]) { eligible = false; why = "tiled kernel needs a scalar sound speed"; }
-    for (uint64_t s = 0; s < z.S && eligible; ++s)
-        for (int k = 0; k < 3; ++k) if (g.ast[6 * s + k]) { eligible = false; why = "tiled kernel needs pixel-independent apodization"; }
+    // apodization arrays: pixel-independent ones fold into an N x M table; ONE array may be a full I1 x I2 x I3 x [N] array
+    // (contiguous pixel strides, no transmit dependence) -- it is applied per (pixel, receiver) by the tiled kernel
+    int pix_arr = -1;
+    for (uint64_t s = 0; s < z.S && eligible; ++s) {
+        const uint64_t *a = &g.ast[6 * s];
+        if (!a[0] && !a[1] && !a[2]) continue;
+        const uint64_t I = z.I1 * z.I2 * z.I3;
+        const bool full = (a[0] == 1 || z.I1 == 1) && (a[1] == z.I1 || z.I2 == 1) && (a[2] == z.I1 * z.I2 || z.I3 == 1)
+                          && (a[3] == I || a[3] == 0) && a[4] == 0 && (a[3] == I || z.N == 1 || a[3] == 0);
+        if (a[3] == 0 && z.N > 1) { eligible = false; why = "tiled kernel: a pixel-only apodization array needs the generic kernel"; }
+        else if (!full || pix_arr >= 0) { eligible = false; why = "tiled kernel: at most one apodization array may depend on the pixel (I x [N], no transmit dependence)"; }
+        else pix_arr = (int)s;
+    }
     // reciprocal mode (das_tile.hip "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
     // elements and share one t0 has tau(n,m) == tau(m,n); detected from the geometry itself, bit-exactly.
     int sym = 0;
@@ -259,11 +270,19 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         pl->fallback = (uint32_t *)fb;
         t.fallback_list = pl->fallback; t.fallback_cap = pl->ntiles;
         // fold the (pixel-independent) apodization stack into one N x M complex64 table
-        t.wtab = nullptr;
-        if (z.S) {
+        t.wtab = nullptr; t.apix = nullptr; t.apix_real = desc->apod_real;
+        if (pix_arr >= 0) {
+            const uint64_t *a = &g.ast[6 * pix_arr];
+            if (a[3] == 0 && z.N > 1) {                 // I-only array: no receiver dependence -> cannot index by n; use the generic kernel
+                return bail(fail(QDAS_EUNSUPPORTED, "internal: pixel-only apodization reached the tiled path"));
+            }
+            t.apix = (const unsigned char *)g.apod + a[5] * ael;
+        }
+        if (z.S > (pix_arr >= 0 ? 1u : 0u)) {
             std::vector<float> tab(2 * z.N * z.M);
             for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.f; tab[2 * k + 1] = 0.f; }
             for (uint64_t s = 0; s < z.S; ++s) {
+                if ((int)s == pix_arr) continue;
                 const uint64_t *st = &g.ast[6 * s];
                 const uint64_t nel = bcast_numel(st, z);
                 std::vector<unsigned char> raw(nel * ael);

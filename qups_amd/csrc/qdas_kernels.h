@@ -34,6 +34,8 @@ struct TileParams {
     const void *x;
     void *y;
     const void *wtab;                   // optional N x M table of folded apodization weights (float2), may be null
+    const void *apix;                   // optional I x N apodization (data precision; real if apix_real), may be null
+    int32_t apix_real;
     uint64_t T, N, M, I1, I2, I3;
     uint64_t i_begin, i_count;
     uint64_t strN, strM;                // trace strides of x in samples: (T, T*N) or (T*M, T) when transposed

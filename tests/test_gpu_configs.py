@@ -63,7 +63,7 @@ def test_config_lattice_parity(name, step, tol):
     if name in ("c2", "c3"):
         assert plan.kernel == "tiled" and plan.fallback_tiles() == 0
     if name == "c5":
-        assert plan.kernel == "generic"        # pixel-dependent apodization
+        assert plan.kernel == "tiled"          # I1 x I2 x 1 x N apodization is applied per (pixel, receiver) by the tiled kernel
 
 
 @pytest.mark.parametrize("name", ["c2", "c3"])

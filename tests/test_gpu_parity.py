@@ -155,14 +155,15 @@ def f32r(a):
     return np.asarray(a, np.float32).astype(np.float64)
 
 
-def test_apod_stack_complex_and_zero_skip():
+@pytest.mark.parametrize("kernel,name", [(1, "generic"), (0, "tiled")])
+def test_apod_stack_complex_and_zero_skip(kernel, name):
     case = make_case(seq="FSA", interp="cubic", seed=9, N=8, I1=64, I2=8)
     rng = np.random.default_rng(1)
     a1 = f32r(rng.uniform(0, 1, (64, 8, 1, 8, 1)) > 0.4).astype(np.float64)          # sparse mask (zeros short-circuit)
     a2 = (f32r(rng.uniform(0, 1, (1, 1, 1, 1, 8))) + 1j * f32r(rng.uniform(0, 1, (1, 1, 1, 1, 8))))
     ref = run_oracle(case, apod=(a1, a2))
-    out, plan = run_das(case, apod=(a1, a2))
-    assert plan.kernel == "generic"
+    out, plan = run_das(case, apod=(a1, a2), kernel=kernel)
+    assert plan.kernel == name          # pixel x receiver mask -> in-kernel weights, transmit vector -> folded table
     assert rel_err(out, ref) <= TOL32
 
 
@@ -355,3 +356,39 @@ def test_reciprocal_mode_matches_general_mode(monkeypatch):
     assert rel_err(run_das(case, kernel=2, t0=t0)[0], run_oracle(case, t0=t0)) <= TOL32
     case = make_case(seq="FSA", interp="linear", seed=35, N=20, I1=70, I2=16)      # 20 % 16 != 0
     assert rel_err(run_das(case, kernel=2)[0], run_oracle(case)) <= TOL32
+
+
+@pytest.mark.parametrize("prec", ["single", "halfT"])
+def test_tiled_pixel_receiver_apodization(prec):
+    """one I1 x I2 x I3 x N array (acceptance-angle style mask with whole waves of zeros) + pixel-independent arrays"""
+    case = make_case(seq="PW", interp="cubic", seed=41, N=12, M=7, I1=150, I2=20)
+    rng = np.random.default_rng(4)
+    tol = 2e-5 if prec == "single" else 2e-3
+    x = case["x"]
+    if prec == "halfT":
+        x = x.real.astype(np.float16).astype(np.float64) + 1j * x.imag.astype(np.float16).astype(np.float64)
+    zz = np.linspace(0, 1, 150)[:, None, None, None, None]
+    nn = np.linspace(0, 1, 12)[None, None, None, :, None]
+    mask = (np.abs(zz - nn) < 0.35).astype(np.float64) * f32r(rng.uniform(0.5, 1.0, (150, 20, 1, 12, 1)))      # zero for whole depth ranges
+    mask = mask.astype(np.float16).astype(np.float64) if prec == "halfT" else mask
+    am = f32r(np.hanning(9)[1:-1]).reshape(1, 1, 1, 1, 7)
+    am = am.astype(np.float16).astype(np.float64) if prec == "halfT" else am
+    ref = run_oracle(case, apod=(mask, am), x=x)
+    out, plan = run_das(case, apod=(mask, am), kernel=2, prec=prec)
+    assert plan.kernel == "tiled" and plan.fallback_tiles() == 0
+    assert rel_err(out, ref) <= tol
+    if prec == "single":     # complex pixel weights
+        cm = mask * np.exp(1j * f32r(rng.uniform(0, 1, (150, 20, 1, 12, 1))))
+        cm = cm.real.astype(np.float32) + 1j * cm.imag.astype(np.float32)
+        ref = run_oracle(case, apod=(cm,))
+        out, plan = run_das(case, apod=(cm,), kernel=2)
+        assert plan.kernel == "tiled" and rel_err(out, ref) <= tol
+    # two pixel-dependent arrays, or one that also depends on the transmit, go to the generic kernel
+    from qups_amd import _lib
+    with pytest.raises(_lib.QdasError, match="at most one apodization"):
+        run_das(case, apod=(mask, mask), kernel=2, prec=prec)
+    full = np.broadcast_to(mask, (150, 20, 1, 12, 7)).copy()
+    with pytest.raises(_lib.QdasError, match="at most one apodization"):
+        run_das(case, apod=(full,), kernel=2, prec=prec)
+    out, plan = run_das(case, apod=(full,), kernel=0, prec=prec)
+    assert plan.kernel == "generic" and rel_err(out, run_oracle(case, apod=(full,), x=x)) <= max(tol, TOL32)
