@@ -44,8 +44,9 @@ das_generic_kernel(const GenericParams P) {
         const uint32_t t = P.tile_list[1 + blockIdx.x / P.blocks_per_tile];
         const uint32_t within = (blockIdx.x % P.blocks_per_tile) * blockDim.x + threadIdx.x; // 0..64*TX
         const uint64_t tz = t % P.tiles_z, tx = t / P.tiles_z;
-        const uint64_t i1 = tz * 64 + (within & 63), col = tx * P.tile_cols + (within >> 6);
-        if (i1 >= P.I1 || (within >> 6) >= P.tile_cols || col >= P.I2 * P.I3) return;
+        const uint32_t wz = within & ((1u << P.tile_zl) - 1u), wc = within >> P.tile_zl;
+        const uint64_t i1 = (tz << P.tile_zl) + wz, col = tx * P.tile_cols + wc;
+        if (i1 >= P.I1 || wc >= P.tile_cols || col >= P.I2 * P.I3) return;
         const uint64_t i = i1 + P.I1 * col;
         if (i < P.i_begin || i >= P.i_begin + P.i_count) return;
         il = i - P.i_begin;

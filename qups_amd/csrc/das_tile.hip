@@ -58,7 +58,6 @@ namespace qdas {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr int TZ = 64;            // pixels along I1 per tile == wave width
 constexpr float MAGIC = 12582912.0f;          // 1.5 * 2^23: (t + MAGIC) has rint(t) in its low mantissa bits
 constexpr uint32_t MAGIC_BITS = 0x4B400000u;
 
@@ -176,7 +175,7 @@ das_tile_kernel(const TileParams P) {
     static_assert(!SYM || (sizeof(ST) == 8 && !WTAB), "reciprocal mode: fp32 data, no weight table");
     constexpr int K = tapinfo<INTERP>::K;
     constexpr int THREADS = WAVES * 64;
-    constexpr int TX = WAVES;                 // one image column per wave
+    constexpr int TX = WAVES;                 // waves per workgroup; a wave holds 1, 2 or 4 image columns (tz_log2)
     constexpr int WPW = MB / WAVES;           // windows staged per wave
     constexpr int SB = (int)sizeof(ST);       // bytes per complex sample
     constexpr bool F32 = (SB == 8);
@@ -213,8 +212,12 @@ das_tile_kernel(const TileParams P) {
     // ---- my pixel: lane -> depth, wave -> column.  Out-of-image lanes are clamped onto a real
     //      pixel (keeps them inside the tile's delay window) and masked at the store.
     const uint64_t ncols = P.I2 * P.I3, i_end = P.i_begin + P.i_count;
-    const uint64_t i1 = (uint64_t)tz * TZ + lane;
-    const uint64_t col = (uint64_t)txi * TX + wave;
+    // Tile shape (uniform, chosen by the plan from the scan's delay gradient): a wave covers (1 << tzl) pixels of I1 in
+    // (64 >> tzl) adjacent columns -- 64 x 1 for fine axial sampling, down to 16 x 4 for coarse (e.g. polar) scans, so that
+    // the tile's delay spread still fits the LDS window.
+    const int tzl = P.tz_log2;
+    const uint64_t i1 = ((uint64_t)tz << tzl) + (uint32_t)(lane & ((1 << tzl) - 1));
+    const uint64_t col = (((uint64_t)txi * TX + wave) << (6 - tzl)) + (uint32_t)(lane >> tzl);
     float px, py, pz;                                 // widened to fp64 where they are used
     {
         const uint64_t i = (i1 < P.I1 ? i1 : P.I1 - 1) + P.I1 * (col < ncols ? col : ncols - 1);
@@ -640,12 +643,13 @@ das_tile_kernel(const TileParams P) {
 // workgroup per CU (general case);  cfg 1: the same tile with 16 transmits per stage and direct + mirror windows
 // (reciprocal mode).
 struct Cfg { int waves, mb, w, nbuf, psz, bpc; };
-static constexpr Cfg CFGS[2] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}};
+static constexpr Cfg CFGS[3] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1}};
+static inline int cfg_index(int dtype, int sym) { return sym ? 1 : (dtype == 2 ? 2 : 0); }
 
 TileConfig tile_config(int dtype, int sym) {
-    const Cfg &g = CFGS[sym ? 1 : 0];
+    const Cfg &g = CFGS[cfg_index(dtype, sym)];
     TileConfig c;
-    c.tile_cols = g.waves;
+    c.waves = g.waves;
     c.mb = g.mb;
     c.window = g.w;
     c.threads = g.waves * 64;
@@ -654,7 +658,7 @@ TileConfig tile_config(int dtype, int sym) {
 }
 
 size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M) {
-    const Cfg &g = CFGS[sym ? 1 : 0];
+    const Cfg &g = CFGS[cfg_index(dtype, sym)];
     const TileConfig c = tile_config(dtype, sym);
     const size_t MX = M > N ? M : N;
     const size_t hdr = (((((2 * M + N) * 4 + 15) & ~(size_t)15) + 16 * N + 7 * M * 4) + 15) & ~(size_t)15;
@@ -699,7 +703,7 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
     const int interp = P.flag & 7;
 #define QDAS_DT(I) (sym ? launch_tile_i<I, float2, 1>(P, ntiles, lds, s)                                 \
-                        : (dtype == 2 ? launch_tile_i<I, uint32_t, 0>(P, ntiles, lds, s) : launch_tile_i<I, float2, 0>(P, ntiles, lds, s)))
+                        : (dtype == 2 ? launch_tile_i<I, uint32_t, 2>(P, ntiles, lds, s) : launch_tile_i<I, float2, 0>(P, ntiles, lds, s)))
     switch (interp) {
         case 0: return QDAS_DT(0);
         case 1: case 4: return QDAS_DT(1);

