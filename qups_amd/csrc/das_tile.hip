@@ -212,12 +212,14 @@ das_tile_kernel(const TileParams P) {
     // ---- my pixel: lane -> depth, wave -> column.  Out-of-image lanes are clamped onto a real
     //      pixel (keeps them inside the tile's delay window) and masked at the store.
     const uint64_t ncols = P.I2 * P.I3, i_end = P.i_begin + P.i_count;
-    // Tile shape (uniform, chosen by the plan from the scan's delay gradient): a wave covers (1 << tzl) pixels of I1 in
-    // (64 >> tzl) adjacent columns -- 64 x 1 for fine axial sampling, down to 16 x 4 for coarse (e.g. polar) scans, so that
-    // the tile's delay spread still fits the LDS window.
-    const int tzl = P.tz_log2;
-    const uint64_t i1 = ((uint64_t)tz << tzl) + (uint32_t)(lane & ((1 << tzl) - 1));
-    const uint64_t col = (((uint64_t)txi * TX + wave) << (6 - tzl)) + (uint32_t)(lane >> tzl);
+    // Tile and wave footprints (uniform, chosen by the plan from the scan's delay gradient; qdas_api.hip choose_tile_shape):
+    // the tile is (1 << tzl) pixels of I1 x (1024 >> tzl) columns -- as deep as the LDS window allows; inside it a wave covers
+    // (1 << wzl) x (64 >> wzl) pixels -- as shallow as needed for the 32 lanes of an LDS access group to read <= 32
+    // consecutive samples (conflict-free), e.g. 8 x 8 when the delay advances 2 samples per pixel of depth.
+    const int tzl = P.tz_log2, wzl = P.wz_log2;
+    const uint32_t wave_z = (uint32_t)wave & ((1u << (tzl - wzl)) - 1u), wave_c = (uint32_t)wave >> (tzl - wzl);
+    const uint64_t i1 = ((uint64_t)tz << tzl) + (wave_z << wzl) + (uint32_t)(lane & ((1 << wzl) - 1));
+    const uint64_t col = (uint64_t)txi * ((uint32_t)(TX * 64) >> tzl) + (wave_c << (6 - wzl)) + (uint32_t)(lane >> wzl);
     float px, py, pz;                                 // widened to fp64 where they are used
     {
         const uint64_t i = (i1 < P.I1 ? i1 : P.I1 - 1) + P.I1 * (col < ncols ? col : ncols - 1);
@@ -321,6 +323,7 @@ das_tile_kernel(const TileParams P) {
         }
         return;                                        // uniform exit: generic kernel takes this tile
     }
+    if (P.probe) return;                               // plan-time shape selection only wants the fit verdict
     // every window of every stage strictly inside the record?  (uniform) -> branch-free loop
     const bool tile_interior = (a_lo + b_lo >= 1.0f) && (a_hi + b_hi + (float)(K + 1) < (float)T);
     for (uint32_t k = tid; k < 4 * M; k += THREADS) PvL[k] = P.Pv[k];

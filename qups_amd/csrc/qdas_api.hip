@@ -107,17 +107,10 @@ static int fetch_host(const void *src, size_t bytes, int mem, void *dst) {
     return QDAS_OK;
 }
 
-// Tile shape of the tiled kernel: the largest depth extent (64, 32 or 16 pixels of I1 per wave) whose estimated delay spread
-// fits the LDS window.  The estimate uses the largest pixel pitch along I1 (3 sampled columns) and across columns (3 sampled
-// rows): both delay terms change by at most cinv*fs*pitch per pixel; the lateral term is weighted by 1/2 (obliquity).  A wrong
-// guess costs speed, never correctness: tiles that do not fit are redone by the generic kernel.
-static int choose_tile_shape(const qdas_desc *desc, double cinv_fs, const TileConfig &tc, int taps, int *tzl) {
+// Largest pixel pitch [m] along I1 (3 sampled columns) and across columns (3 sampled rows) of the scan: the inputs of the
+// tiled kernel's shape model (choose_tile_shape below).
+static int scan_pitch(const qdas_desc *desc, double *gz_out, double *gc_out) {
     const qdas_sizes &z = desc->sz;
-    *tzl = 6;
-    if (const char *e = getenv("QDAS_TILE_Z")) {
-        const int v = atoi(e);
-        if (v == 16 || v == 32 || v == 64) { *tzl = v == 16 ? 4 : (v == 32 ? 5 : 6); return QDAS_OK; }
-    }
     const uint64_t ncols = z.I2 * z.I3;
     const float *Pi = (const float *)desc->Pi;
     double gz = 0.0, gc = 0.0;
@@ -150,13 +143,8 @@ static int choose_tile_shape(const qdas_desc *desc, double cinv_fs, const TileCo
             }
         }
     }
-    if (!(gz == gz) || !(gc == gc)) return QDAS_OK;     // NaN pixels: keep the default
-    const double per = 2.0 * std::fabs(cinv_fs);
-    for (int l = 6; l >= 4; --l) {
-        const double est = per * ((double)(1 << l) * gz + 0.5 * (double)(tc.waves << (6 - l)) * gc) + taps + 4;
-        *tzl = l;
-        if (est <= (double)tc.window) break;
-    }
+    *gz_out = (gz == gz) ? gz : 0.0;                     // NaN pixels: no information
+    *gc_out = (gc == gc) ? gc : 0.0;
     return QDAS_OK;
 }
 
@@ -199,6 +187,61 @@ static uint64_t bcast_numel(const uint64_t *st, const qdas_sizes &z) {
     uint64_t n = 1;
     for (int k = 0; k < 5; ++k) if (st[k]) n += (dims[k] - 1) * st[k];
     return n;
+}
+
+// Shape of the tiled kernel's tiles and waves (das_tile.hip).
+//  * tile footprint (64x16, 32x32, 16x64 or 8x128 pixels of I1 x columns): every candidate is PROBED -- the kernel's own
+//    prologue runs for all tiles and counts those whose delay spread does not fit the LDS window; only footprints with the
+//    fewest misfits are considered (a misfit tile is redone by the generic kernel at >10x the cost).
+//  * wave footprint inside the tile (2^w x 2^(6-w) pixels): an LDS access group is 32 lanes; it is conflict-free when the
+//    lanes read <= 32 consecutive samples, i.e. (group depth) x (delay samples per pixel of depth) + (group columns) x
+//    (lateral gradient) <= 32.  The shallowest-needed wave wins; ties go to the deeper wave (longer store runs).
+// QDAS_TILE_Z / QDAS_WAVE_Z override the choice (profiling, tests).
+template <typename F>
+static int choose_tile_shape(qdas_plan *pl, const qdas_desc *desc, F &&set_grid) {
+    TileParams &t = pl->tp;
+    const qdas_sizes &z = desc->sz;
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    int env_tz = 0, env_wz = 0;
+    if (const char *e = getenv("QDAS_TILE_Z")) { const int v = atoi(e); if (v == 8 || v == 16 || v == 32 || v == 64) env_tz = v; }
+    if (const char *e = getenv("QDAS_WAVE_Z")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) env_wz = v; }
+    double gz = 0.0, gc = 0.0;
+    int rc = scan_pitch(desc, &gz, &gc);
+    if (rc) return rc;
+    const double per = 2.0 * std::fabs(t.cinv_fs);      // delay samples per metre of pixel pitch (both legs)
+    const double spz = per * gz, spc = 0.35 * per * gc;  // per pixel of depth / per column (obliquity-weighted)
+    // misfit count of each footprint
+    double fbn[7] = {0, 0, 0, 0, 0, 0, 0}, best_fb = 2.0;   // misfit FRACTION of the footprint's tiles
+    for (int l = 6; l >= 3; --l) {
+        if (env_tz && (1 << l) != env_tz) continue;
+        set_grid(l);
+        TileParams p = t;
+        p.probe = 1; p.wz_log2 = l; p.x = nullptr; p.y = nullptr; p.wtab = nullptr; p.apix = nullptr;
+        HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));
+        HIPCHK(launch_tile(p, z.dtype, pl->ntiles, nullptr));
+        uint32_t cnt = 0;
+        HIPCHK(hipMemcpy(&cnt, pl->fallback, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        fbn[l] = (double)cnt / (double)(pl->ntiles ? pl->ntiles : 1);
+        if (fbn[l] < best_fb) best_fb = fbn[l];
+    }
+    int best_t = -1, best_w = -1;
+    double best_c = 1e300;
+    for (int l = 6; l >= 3; --l) {
+        if (env_tz && (1 << l) != env_tz) continue;
+        if (fbn[l] > best_fb + 1e-9) continue;
+        for (int w = l; w >= 2 && w >= l - 4; --w) {
+            if (env_wz && (1 << w) != env_wz && !(env_wz > (1 << l) && w == l)) continue;
+            const int gd = w >= 5 ? 32 : (1 << w), gcn = 32 / gd;     // depth x columns of one 32-lane access group
+            const double span = gd * spz + gcn * spc;
+            const double c = span <= 32.0 ? 1.0 : span / 32.0;
+            if (c < best_c - 1e-9) { best_c = c; best_t = l; best_w = w; }
+        }
+    }
+    if (best_t < 0) { best_t = env_tz ? lg(env_tz) : 6; best_w = best_t; }
+    set_grid(best_t);
+    t.wz_log2 = best_w;
+    t.probe = 0;
+    return QDAS_OK;
 }
 
 extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
@@ -310,21 +353,23 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         t.fs = g.fs; t.fmod = g.fmod;
         t.cinv_fs = (double)cinv0 * g.fs;
         t.flag = z.flag; t.VS = z.VS; t.DV = z.DV; t.sym = sym;
-        // tile grid: (1 << tz_log2) pixels of I1 x tile_cols columns (columns = I2*I3 flattened)
-        static const int ktaps[6] = {1, 2, 4, 4, 2, 4};
-        int tzl = 6;
-        if ((rc = choose_tile_shape(desc, t.cinv_fs, pl->tc, ktaps[z.flag & QDAS_FLAG_INTERP_MASK], &tzl))) return bail(rc);
-        t.tz_log2 = tzl;
-        pl->tile_cols = (unsigned)pl->tc.waves << (6 - tzl);
-        const uint64_t col0 = desc->i_begin / z.I1, col1 = (desc->i_begin + pl->i_count - 1) / z.I1;
-        t.tiles_z = (uint32_t)((z.I1 + (1u << tzl) - 1) >> tzl);
-        t.tile_x0 = (uint32_t)(col0 / pl->tile_cols);
-        t.tiles_x = (uint32_t)(col1 / pl->tile_cols) - t.tile_x0 + 1;
-        pl->ntiles = t.tiles_z * t.tiles_x;
+        // tile grid: (1 << tz_log2) pixels of I1 x tile_cols columns (columns = I2*I3 flattened); the footprint is chosen below
+        auto set_grid = [&](int tzl) {
+            t.tz_log2 = tzl;
+            pl->tile_cols = ((unsigned)pl->tc.waves * 64u) >> tzl;
+            const uint64_t col0 = desc->i_begin / z.I1, col1 = (desc->i_begin + pl->i_count - 1) / z.I1;
+            t.tiles_z = (uint32_t)((z.I1 + (1u << tzl) - 1) >> tzl);
+            t.tile_x0 = (uint32_t)(col0 / pl->tile_cols);
+            t.tiles_x = (uint32_t)(col1 / pl->tile_cols) - t.tile_x0 + 1;
+            pl->ntiles = t.tiles_z * t.tiles_x;
+        };
+        unsigned max_tiles = 0;
+        for (int l = 3; l <= 6; ++l) { set_grid(l); if (pl->ntiles > max_tiles) max_tiles = pl->ntiles; }
         void *fb;
-        if ((rc = dev_alloc(pl, &fb, sizeof(uint32_t) * (pl->ntiles + 1)))) return bail(rc);
+        if ((rc = dev_alloc(pl, &fb, sizeof(uint32_t) * (max_tiles + 1)))) return bail(rc);
         pl->fallback = (uint32_t *)fb;
-        t.fallback_list = pl->fallback; t.fallback_cap = pl->ntiles;
+        t.fallback_list = pl->fallback; t.fallback_cap = max_tiles;
+        t.probe = 0; t.wz_log2 = 6;
         // fold the (pixel-independent) apodization stack into one N x M complex64 table
         t.wtab = nullptr; t.apix = nullptr; t.apix_real = desc->apod_real;
         if (pix_arr >= 0) {
@@ -361,6 +406,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e)));
             t.wtab = dtab;
         }
+        if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
     }
 
     if (desc->mem == QDAS_MEM_HOST) {                   // staging buffers for x / y
@@ -391,11 +437,12 @@ extern "C" int qdas_plan_fallback_tiles(const qdas_plan *pl, uint64_t *n) {
     return QDAS_OK;
 }
 
-extern "C" int qdas_plan_tile_shape(const qdas_plan *pl, int *tile_z, int *tile_cols) {
+extern "C" int qdas_plan_tile_shape(const qdas_plan *pl, int *tile_z, int *tile_cols, int *wave_z) {
     if (!pl || !tile_z || !tile_cols) return fail(QDAS_EINVAL, "null argument");
     const bool tiled = pl->kernel == QDAS_KERNEL_TILED;
     *tile_z = tiled ? (1 << pl->tp.tz_log2) : 0;
     *tile_cols = tiled ? (int)pl->tile_cols : 0;
+    if (wave_z) *wave_z = tiled ? (1 << pl->tp.wz_log2) : 0;
     return QDAS_OK;
 }
 

@@ -43,7 +43,9 @@ struct TileParams {
     double fs, fmod;
     int32_t flag, VS, DV;
     int32_t sym;                        // reciprocal mode: Pv == Pr, one t0 (checked by the host) -> tau(n,m) == tau(m,n)
-    int32_t tz_log2;                    // tile shape: (1 << tz_log2) pixels of I1 x (waves * (64 >> tz_log2)) columns; 4 | 5 | 6
+    int32_t tz_log2;                    // tile footprint: (1 << tz_log2) pixels of I1 x (waves * 64 >> tz_log2) columns; 3..6
+    int32_t wz_log2;                    // wave footprint inside the tile: (1 << wz_log2) pixels of I1 x (64 >> wz_log2) columns; <= tz_log2
+    int32_t probe;                      // 1: stop after the window-fit test (plan-time shape selection; only fallback_list is written)
     uint32_t tiles_z, tiles_x, tile_x0; // tile grid over (I1 >> tz_log2) x (columns / tile columns); first column tile of the shard
     uint32_t *fallback_list;            // [0] = count, [1..] = tile ids that did not fit the LDS window
     uint32_t fallback_cap;

@@ -385,8 +385,14 @@ class DasPlan:
     def tile_shape(self) -> tuple:
         """(pixels of I1, columns) of one workgroup tile of the tiled kernel; (0, 0) for the generic kernel."""
         tz, tc = C.c_int(0), C.c_int(0)
-        _lib.check(self.lib.qdas_plan_tile_shape(self._h, C.byref(tz), C.byref(tc)))
+        _lib.check(self.lib.qdas_plan_tile_shape(self._h, C.byref(tz), C.byref(tc), None))
         return int(tz.value), int(tc.value)
+
+    def wave_shape(self) -> tuple:
+        """(pixels of I1, columns) one wave covers inside a tile; (0, 0) for the generic kernel."""
+        tz, tc, wz = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check(self.lib.qdas_plan_tile_shape(self._h, C.byref(tz), C.byref(tc), C.byref(wz)))
+        return (int(wz.value), 64 // int(wz.value)) if wz.value else (0, 0)
 
     def fallback_tiles(self) -> int:
         n = C.c_uint64()

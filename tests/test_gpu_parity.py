@@ -229,7 +229,7 @@ def test_oversize_window_falls_back():
     case = make_case(seq="FSA", interp="linear", seed=15, I1=64, I2=4, zlim=(2e-3, 60e-3), data="noise", N=8)
     ref = run_oracle(case)
     out, plan = run_das(case, kernel=0)
-    assert plan.kernel == "tiled" and plan.tile_shape() == (16, 64)
+    assert plan.kernel == "tiled" and plan.tile_shape()[0] < 64             # the footprint with the smallest misfit fraction
     assert plan.fallback_tiles() > 0
     assert rel_err(out, ref) <= 3e-4
 
@@ -394,18 +394,19 @@ def test_tiled_pixel_receiver_apodization(prec):
     assert plan.kernel == "generic" and rel_err(out, run_oracle(case, apod=(full,), x=x)) <= max(tol, TOL32)
 
 
-@pytest.mark.parametrize("tz", [16, 32, 64])
+@pytest.mark.parametrize("tz,wz", [(64, 64), (64, 8), (64, 4), (32, 32), (32, 4), (16, 16), (16, 8), (8, 8), (8, 4)])
 @pytest.mark.parametrize("seq,prec", [("FSA", "single"), ("PW", "single"), ("DV", "halfT")])
-def test_tile_shapes_forced(tz, seq, prec, monkeypatch):
-    """every tile shape (64x16, 32x32, 16x64 pixels) gives the same image, ragged edges included"""
+def test_tile_shapes_forced(tz, wz, seq, prec, monkeypatch):
+    """every tile footprint (64x16 ... 8x128 pixels) and wave footprint (64x1 ... 4x16) gives the same image, ragged edges included"""
     monkeypatch.setenv("QDAS_TILE_Z", str(tz))
+    monkeypatch.setenv("QDAS_WAVE_Z", str(wz))
     case = make_case(seq=seq, interp="lanczos3", seed=21, N=16, I1=150, I2=37, zlim=(4e-3, 14e-3), xspan=3e-3)
     xq = case["x"]
     if prec == "halfT":
         xq = xq.real.astype(np.float16).astype(np.float64) + 1j * xq.imag.astype(np.float16).astype(np.float64)
     ref = run_oracle(case, x=xq)
     out, plan = run_das(case, kernel=2, prec=prec)
-    assert plan.kernel == "tiled" and plan.tile_shape() == (tz, 16 * 64 // tz)
+    assert plan.kernel == "tiled" and plan.tile_shape() == (tz, 16 * 64 // tz) and plan.wave_shape() == (wz, 64 // wz)
     assert plan.fallback_tiles() == 0
     assert rel_err(out, ref) <= (2e-3 if prec == "halfT" else TOL32)
 
@@ -416,7 +417,7 @@ def test_tile_shape_follows_the_axial_pitch():
     coarse = make_case(seq="FSA", interp="cubic", seed=22, N=16, I1=48, I2=40, zlim=(4e-3, 14e-3), xspan=2e-3)
     out_f, plan_f = run_das(fine, kernel=2)
     out_c, plan_c = run_das(coarse, kernel=2)
-    assert plan_f.tile_shape() == (64, 16)
+    assert plan_f.tile_shape() == (64, 16) and plan_f.wave_shape()[0] <= 16     # 2.6 samples/pixel: shallow waves (LDS banks)
     assert plan_c.tile_shape()[0] < 64
     assert plan_f.fallback_tiles() == 0 and plan_c.fallback_tiles() == 0
     assert rel_err(out_f, run_oracle(fine)) <= TOL32
