@@ -168,7 +168,9 @@ __device__ __forceinline__ uint32_t zero_of(const uint32_t *) { return 0u; }
 // CFG: WAVES waves (= image columns) per workgroup, MB transmits per stage, W samples per window,
 //      NBUF window buffers (NBUF-1 stages of LDS-DMA in flight), PSZ bytes per lane and DMA piece (12|16),
 //      BPC workgroups per CU the register budget is sized for.
-template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC>
+//      PROBE: plan-time variant that stops after the window-fit test (a kernel of its own name, so that profiles of
+//      das_tile_kernel<..., false> hold full frames only).
+template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE>
 __global__ void __launch_bounds__(WAVES * 64, WAVES * BPC / 4)
 das_tile_kernel(const TileParams P) {
     constexpr int NW = SYM ? 2 * MB : MB;     // windows per LDS buffer: direct (+ mirror) traces of a stage
@@ -323,7 +325,7 @@ das_tile_kernel(const TileParams P) {
         }
         return;                                        // uniform exit: generic kernel takes this tile
     }
-    if (P.probe) return;                               // plan-time shape selection only wants the fit verdict
+    if constexpr (PROBE) return;                       // plan-time shape selection only wants the fit verdict
     // every window of every stage strictly inside the record?  (uniform) -> branch-free loop
     const bool tile_interior = (a_lo + b_lo >= 1.0f) && (a_hi + b_hi + (float)(K + 1) < (float)T);
     for (uint32_t k = tid; k < 4 * M; k += THREADS) PvL[k] = P.Pv[k];
@@ -589,16 +591,19 @@ das_tile_kernel(const TileParams P) {
                         sv[p & 1] = t - (tm - MAGIC);
                         a0v[p & 1] = __float_as_uint(tm.x) * (uint32_t)SB + cbase;
                         a1v[p & 1] = __float_as_uint(tm.y) * (uint32_t)SB + cbase;
-                        lds_issue<K, (2 * p) * WB>(gd0[p & 1], a0v[p & 1]); lds_issue<K, (2 * p + 1) * WB>(gd1[p & 1], a1v[p & 1]);
+                        if constexpr ((QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { gd0[p & 1].s[k] = (v2f){t.x, tm.y}; gd1[p & 1].s[k] = (v2f){tm.x, t.y}; } }
+                        else { lds_issue<K, (2 * p) * WB>(gd0[p & 1], a0v[p & 1]); lds_issue<K, (2 * p + 1) * WB>(gd1[p & 1], a1v[p & 1]); }
                     };
                     index(std::integral_constant<int, 0>{});
                     unroll<NP>([&](auto pc) {
                         constexpr int p = decltype(pc)::value;
                         taps_f32 h0, h1;
-                        lds_issue<K, (MB + 2 * p) * WB>(h0, a0v[p & 1]); lds_issue<K, (MB + 2 * p + 1) * WB>(h1, a1v[p & 1]);
+                        if constexpr ((QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { h0.s[k] = sv[p & 1]; h1.s[k] = (v2f){sv[p & 1].y, sv[p & 1].x}; } }
+                        else { lds_issue<K, (MB + 2 * p) * WB>(h0, a0v[p & 1]); lds_issue<K, (MB + 2 * p + 1) * WB>(h1, a1v[p & 1]); }
                         if constexpr (p + 1 < NP) index(std::integral_constant<int, p + 1>{});
                         v2f w[4];
-                        weights2<INTERP>(sv[p & 1], w);
+                        if constexpr ((QDAS_ABL & 8) != 0) { w[0] = sv[p & 1]; w[1] = sv[p & 1] + 1.f; w[2] = sv[p & 1] * 2.f; w[3] = 1.f - sv[p & 1]; }
+                        else weights2<INTERP>(sv[p & 1], w);
                         if constexpr (p + 1 < NP) lds_fence2_keep<8>(gd0[p & 1], gd1[p & 1], h0, h1, w);
                         else                      lds_fence2_keep<0>(gd0[p & 1], gd1[p & 1], h0, h1, w);
 #pragma unroll
@@ -678,13 +683,15 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
     constexpr bool SYM = (CI == 1);
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
     const dim3 g(ntiles), b(G.waves * 64);
-#define QDAS_LAUNCH(FM, WT)                                                                              \
+#define QDAS_LAUNCH(FM, WT) QDAS_LAUNCH_P(FM, WT, false)
+#define QDAS_LAUNCH_P(FM, WT, PR)                                                                        \
     do {                                                                                                 \
-        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc>;   \
+        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR>; \
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                   \
         kfn<<<g, b, lds, s>>>(P);                                                                        \
     } while (0)
+    if (P.probe) { QDAS_LAUNCH_P(false, false, true); return hipGetLastError(); }
     if constexpr (SYM) {
         if (wt) return hipErrorInvalidValue;
         if (fm) QDAS_LAUNCH(true, false); else QDAS_LAUNCH(false, false);
@@ -695,6 +702,7 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
         else          QDAS_LAUNCH(false, false);
     }
 #undef QDAS_LAUNCH
+#undef QDAS_LAUNCH_P
     return hipGetLastError();
 }
 

@@ -19,18 +19,24 @@ if kt:
         print(f"{k[:100]:100s} {len(v):4d} {sum(v)/len(v):10.3f} {min(v):10.3f} {max(v):10.3f} {sum(v):10.3f}")
     dom = max(dur.items(), key=lambda kv: sum(kv[1]))[0]
     print("dominant kernel:", dom[:120])
-    avg_ms = sum(dur[dom]) / len(dur[dom])
+    # plan creation launches the same kernel in probe mode (prologue only, ~1 ms): keep the full-frame dispatches
+    full = [d for d in dur[dom] if d >= 0.5 * max(dur[dom])]
+    avg_ms = sum(full) / len(full)
+    print(f"full-frame dispatches of it: {len(full)} of {len(dur[dom])}, avg {avg_ms:.3f} ms, min {min(full):.3f}, max {max(full):.3f}"
+          f"  (the others are plan-time probe launches: prologue only)")
 st = find("trace/**/*kernel_stats.csv")
 if st:
     print("== rocprofv3 --stats (kernel_stats.csv)")
     for i, l in enumerate(open(st)):
         if i < 6: print(l.rstrip()[:220])
-print("== PMC (average per dispatch of the dominant kernel)")
+print("== PMC (average per full-frame dispatch of the dominant kernel)")
 vals = {}
 for f in sorted(glob.glob(os.path.join(out, "pmc_*/**/*counter_collection.csv"), recursive=True)):
     acc = collections.defaultdict(list)
-    for row in csv.DictReader(open(f)):
-        if dom is None or row["Kernel_Name"] == dom:
+    rows = [r for r in csv.DictReader(open(f)) if dom is None or r["Kernel_Name"] == dom]
+    dmax = max([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows] or [0])
+    for row in rows:
+        if int(row["End_Timestamp"]) - int(row["Start_Timestamp"]) >= 0.5 * dmax:      # full-frame dispatches only
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k, v in acc.items():
         vals[k] = sum(v) / len(v)
