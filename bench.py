@@ -156,7 +156,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16" if w["prec"] == "halfT" else "f32", "data": "synthetic",
             "config": {"workload": w["label"], "pixels": I, "pairs_per_frame": pairs, "kernel": plan.kernel,
-                       "fallback_tiles": fallback, "tile": list(plan.tile_shape()), "wave": list(plan.wave_shape()), "parallelism": f"pixel-slab x{world} + RCCL all_gather" if world > 1 else "1 GPU",
+                       "fallback_tiles": fallback, "tile": list(plan.tile_shape()), "wave": list(plan.wave_shape()), "aperture_split": plan.aperture_split(), "parallelism": f"pixel-slab x{world} + RCCL all_gather" if world > 1 else "1 GPU",
                        "device": info["name"], "cu": info["cu_count"]},
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),

@@ -129,10 +129,12 @@ void qdas_plan_destroy(qdas_plan *plan);
  * execute, how many pixel tiles fell back to the generic kernel (oversize delay window) */
 int  qdas_plan_kernel(const qdas_plan *plan);
 int  qdas_plan_fallback_tiles(const qdas_plan *plan, uint64_t *ntiles);
-/* shapes a QDAS_KERNEL_TILED plan chose from the scan's delay gradient: a workgroup tile of tile_z pixels
- * of I1 (64 | 32 | 16 | 8) x tile_cols columns of I2*I3, made of waves of wave_z x (64 / wave_z) pixels
- * (wave_z may be NULL); all 0 for a generic-kernel plan */
-int  qdas_plan_tile_shape(const qdas_plan *plan, int *tile_z, int *tile_cols, int *wave_z);
+/* shapes a QDAS_KERNEL_TILED plan chose from the scan's delay gradient and size: a workgroup tile of
+ * tile_z pixels of I1 (64 | 32 | 16 | 8) x tile_cols columns of I2*I3, made of waves of wave_z x
+ * (64 / wave_z) pixels, and ksplit workgroups per tile that each sum a slice of the aperture (> 1 when the
+ * image or pixel slab has too few tiles to fill the GPU); wave_z / ksplit may be NULL; all 0 for a
+ * generic-kernel plan */
+int  qdas_plan_tile_shape(const qdas_plan *plan, int *tile_z, int *tile_cols, int *wave_z, int *ksplit);
 /* time of the last execute()'s kernels in ms measured with hipEvents on its stream
  * (enabled by qdas_plan_set_timing(plan, 1); synchronises the stream) */
 int  qdas_plan_set_timing(qdas_plan *plan, int enable);

@@ -88,7 +88,7 @@ def lib():
     L.qdas_plan_destroy.restype = None
     L.qdas_plan_kernel.argtypes = [C.c_void_p]
     L.qdas_plan_fallback_tiles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-    L.qdas_plan_tile_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.qdas_plan_tile_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.qdas_plan_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.qdas_plan_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.qdas_das_lut.argtypes = [C.POINTER(LutDesc), C.c_void_p, C.c_void_p, C.c_void_p]

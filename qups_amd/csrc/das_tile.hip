@@ -208,6 +208,10 @@ das_tile_kernel(const TileParams P) {
     }
     // columns fastest: the tiles an XCD runs concurrently sit at the SAME depth band, so they stage (nearly)
     // the same window of every trace and the XCD's L2 serves all but the first of them
+    // split = slowest index: the workgroups an XCD runs concurrently work on the SAME slice of the aperture of neighbouring tiles
+    const uint32_t ntile = P.tiles_x * P.tiles_z;
+    const uint32_t split = bid / ntile, S = P.ksplit;
+    bid -= split * ntile;
     const uint32_t tz = bid / P.tiles_x, txi = P.tile_x0 + bid % P.tiles_x;
     const uint32_t tile_id = tz + P.tiles_z * txi;
 
@@ -261,12 +265,27 @@ das_tile_kernel(const TileParams P) {
     // reciprocal mode: a(i,m) = b(i,m) + C with C = OFF - t0*fs, so A[m] := B[m] + floor(C) (filled below)
     const double symC = tapinfo<INTERP>::OFF - (double)P.Pv[3] * fs;
     const int symCi = (int)floor(symC);
+    // (four elements per pass: the 6-step cross-lane reductions are latency chains, independent chains overlap)
+    auto minmax4 = [&](float (&v)[4], uint32_t e0, uint32_t cnt) {
+        float lo[4], hi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lo[q] = hi[q] = (v[q] == v[q]) ? v[q] : INFINITY; }   // a NaN delay poisons the tile's extent
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { lo[q] = fminf(lo[q], __shfl_xor(lo[q], o)); hi[q] = fmaxf(hi[q], __shfl_xor(hi[q], o)); }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (e0 + q < cnt) { part[wave * MX + e0 + q] = lo[q]; part[(WAVES + wave) * MX + e0 + q] = hi[q]; }
+        }
+    };
     if constexpr (!SYM) {
-        for (uint32_t m = 0; m < M; ++m) {
-            const float a = (float)a_of(m);
-            const float mn = wave_min(a), mx = (a == a) ? wave_max(a) : INFINITY;
-            const float mxx = wave_max(mx);
-            if (lane == 0) { part[wave * MX + m] = mn; part[(WAVES + wave) * MX + m] = mxx; }
+        for (uint32_t m = 0; m < M; m += 4) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (float)a_of(m + q < M ? m + q : M - 1);
+            minmax4(v, m, M);
         }
         __syncthreads();
         for (uint32_t m = tid; m < M; m += THREADS) {
@@ -282,11 +301,11 @@ das_tile_kernel(const TileParams P) {
         }
         __syncthreads();
     }
-    for (uint32_t n = 0; n < N; ++n) {
-        const float b = (float)b_of(n);
-        const float mn = wave_min(b), mx = (b == b) ? wave_max(b) : INFINITY;
-        const float mxx = wave_max(mx);
-        if (lane == 0) { part[wave * MX + n] = mn; part[(WAVES + wave) * MX + n] = mxx; }
+    for (uint32_t n = 0; n < N; n += 4) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (float)b_of(n + q < N ? n + q : N - 1);
+        minmax4(v, n, N);
     }
     __syncthreads();
     float b_lo = INFINITY, b_hi = -INFINITY, b_ext = 0.f;
@@ -319,7 +338,7 @@ das_tile_kernel(const TileParams P) {
     }
     // every lane's last tap (+1 for the rint/floor ambiguity at exact integers) must be inside the staged window
     if (!(a_ext + b_ext + (float)(K + 1) <= (float)W)) {
-        if (tid == 0) {
+        if (tid == 0 && split == 0) {
             const uint32_t slot = atomicAdd(&P.fallback_list[0], 1u);
             if (slot < P.fallback_cap) P.fallback_list[1 + slot] = tile_id;
         }
@@ -334,11 +353,20 @@ das_tile_kernel(const TileParams P) {
     __syncthreads();
 
     // ---- main loop over stages (mb = transmit block, n = receiver; n is the inner index)
-    const uint32_t nmb = (M + MB - 1) / MB;
-    // receivers paired with transmit block m0: all of them, or -- reciprocal mode -- only n <= the block's last transmit
-    auto nlim = [&](uint32_t m0) -> uint32_t { return SYM ? (m0 + MB < N ? m0 + MB : N) : N; };
+    // This workgroup's share of the aperture (ksplit workgroups per tile when the image has too few tiles to fill the GPU;
+    // their partial sums are added in a fixed order by tile_reduce_kernel):
+    //   reciprocal mode: every S-th transmit block, dealt out boustrophedon (0..S-1, S-1..0, ...) because block kb pairs with
+    //   16(kb+1) receivers -- the triangular work is balanced;   otherwise: a contiguous range of receivers, all transmit blocks.
+    auto blk = [&](uint32_t r) -> uint32_t {             // first transmit of my r-th block (>= M: exhausted)
+        if constexpr (SYM) return (r * S + ((r & 1u) ? S - 1u - split : split)) * MB;
+        else return r * MB;
+    };
+    const uint32_t n_lo = SYM ? 0u : (uint32_t)((uint64_t)N * split / S);
+    const uint32_t n_hi = (uint32_t)((uint64_t)N * (split + 1) / S);
+    // receivers paired with transmit block m0: my range, or -- reciprocal mode -- all n <= the block's last transmit
+    auto nlim = [&](uint32_t m0) -> uint32_t { return SYM ? (m0 + MB < N ? m0 + MB : N) : n_hi; };
     uint32_t nstage = 0;
-    for (uint32_t kb = 0; kb < nmb; ++kb) nstage += nlim(kb * MB);
+    for (uint32_t r = 0; blk(r) < M; ++r) nstage += nlim(blk(r)) - n_lo;
     v2f acc = {0.f, 0.f};                              // (re, im) of this lane's pixel
     v2f acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f}, acc3 = {0.f, 0.f};   // independent partial sums: no back-to-back dependent packed FMAs
     v2f ra[MB / 2];                                    // tx residuals a - A[m] - 1/2 of transmits (2p, 2p+1), packed
@@ -366,7 +394,11 @@ das_tile_kernel(const TileParams P) {
         djo2[r] = (int)((long)(wave + WAVES * r) * (long)P.strN * SB);
     }
     uint32_t dm0 = 0;                                  // transmit block the DMA front is in
-    auto dma_block = [&](uint32_t m0) { dm0 = m0; doff = (uint64_t)m0 * P.strM * SB; doff2 = (uint64_t)m0 * P.strN * SB; };
+    auto dma_block = [&](uint32_t m0) {
+        dm0 = m0;
+        doff = ((uint64_t)m0 * P.strM + (uint64_t)n_lo * P.strN) * SB;
+        doff2 = (uint64_t)m0 * P.strN * SB;              // (reciprocal mode starts every block at receiver 0)
+    };
     auto stage_dma = [&](uint32_t n, int buf) {       // stage (receiver n, current DMA transmit block)
         const int bn = __builtin_amdgcn_readfirstlane(__float_as_int(nrec[n].x));
         const uint64_t rem = xbytes - doff;
@@ -428,28 +460,28 @@ das_tile_kernel(const TileParams P) {
     auto run = [&](auto check_tag) {
         constexpr bool CHECK = decltype(check_tag)::value;
         v2f wcur = {1.f, 0.f}, wnext = {1.f, 0.f};
-        if (wpix) wcur = wload(0);
-        uint32_t pn = 0, pm0 = 0;                          // stage the DMA front is at (NBUF-1 stages ahead)
-        dma_block(0);
+        if (wpix) wcur = wload(n_lo);
+        uint32_t pr = 0, pn = n_lo, pm0 = blk(0);          // stage the DMA front is at (NBUF-1 stages ahead)
+        dma_block(pm0);
 #pragma unroll
         for (int b = 0; b < NBUF - 1; ++b)
-            if ((uint32_t)b < nstage) { stage_dma(pn, b); if (++pn == nlim(pm0)) { pn = 0; pm0 += MB; dma_block(pm0); } }
+            if ((uint32_t)b < nstage) { stage_dma(pn, b); if (++pn == nlim(pm0)) { pn = n_lo; pm0 = blk(++pr); dma_block(pm0); } }
         // counted wait: everything but the newest (NBUF-2) stages has landed; then publish to the workgroup
         if (nstage >= (uint32_t)(NBUF - 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         int buf = 0;
-        uint32_t n = 0, m0 = 0;
-        for (uint32_t st = 0; st < nstage; ++st, n = (n + 1 == nlim(m0) ? 0 : n + 1), m0 += (n == 0 ? MB : 0)) {
+        uint32_t cr = 0, n = n_lo, m0 = blk(0);
+        for (uint32_t st = 0; st < nstage; ++st) {
             const bool more = st + (NBUF - 1) < nstage;
             // next stage's pixel weight: requested BEFORE this stage's DMA, so the end-of-stage wait covers it
-            if (wpix && st + 1 < nstage) wnext = wload(n + 1 == nlim(m0) ? 0 : n + 1);
+            if (wpix && st + 1 < nstage) wnext = wload(n + 1 == nlim(m0) ? n_lo : n + 1);
             const bool skip = wpix && (__ballot(wcur.x != 0.f || wcur.y != 0.f) == 0ull);   // whole wave weightless: no gathers
             if (!(QDAS_ABL & 1) && more) {               // lands during the next NBUF-1 stages
                 stage_dma(pn, (buf + NBUF - 1) % NBUF);
-                if (++pn == nlim(pm0)) { pn = 0; pm0 += MB; dma_block(pm0); }
+                if (++pn == nlim(pm0)) { pn = n_lo; pm0 = blk(++pr); dma_block(pm0); }
             }
 
-            if (n == 0) {                              // new transmit block: refresh the tx residuals
+            if (n == n_lo) {                           // new transmit block: refresh the tx residuals
 #pragma unroll
                 for (int p = 0; p < MB / 2; ++p) {
                     const uint32_t ma = m0 + 2 * p < M ? m0 + 2 * p : M - 1, mb = m0 + 2 * p + 1 < M ? m0 + 2 * p + 1 : M - 1;
@@ -633,6 +665,7 @@ das_tile_kernel(const TileParams P) {
                 acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
                 wcur = wnext;
             }
+            if (++n == nlim(m0)) { n = n_lo; m0 = blk(++cr); }
         }
     };
     if (tile_interior) run(std::false_type{}); else run(std::true_type{});
@@ -641,9 +674,21 @@ das_tile_kernel(const TileParams P) {
     // ---- epilogue: y[i] = pix  (reference src/bf.cu:140); lanes = consecutive i -> coalesced
     {
         const uint64_t ig = i1 + P.I1 * col;
-        if ((i1 < P.I1) && (col < ncols) && (ig >= P.i_begin) && (ig < i_end))
-            st((ST *)P.y, (size_t)(ig - P.i_begin), cplx<float>{acc.x, acc.y});
+        if ((i1 < P.I1) && (col < ncols) && (ig >= P.i_begin) && (ig < i_end)) {
+            if (S > 1) P.part[(size_t)split * P.i_count + (size_t)(ig - P.i_begin)] = make_float2(acc.x, acc.y);
+            else st((ST *)P.y, (size_t)(ig - P.i_begin), cplx<float>{acc.x, acc.y});
+        }
     }
+}
+
+// y[i] = sum over the ksplit partial images, in split order (deterministic)
+template <typename ST>
+__global__ void __launch_bounds__(256) tile_reduce_kernel(const float2 *part, ST *y, uint64_t count, uint32_t ksplit) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    float2 a = part[i];
+    for (uint32_t j = 1; j < ksplit; ++j) { const float2 b = part[(size_t)j * count + i]; a.x += b.x; a.y += b.y; }
+    st(y, (size_t)i, cplx<float>{a.x, a.y});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -682,7 +727,7 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
     constexpr Cfg G = CFGS[CI];
     constexpr bool SYM = (CI == 1);
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
-    const dim3 g(ntiles), b(G.waves * 64);
+    const dim3 g(ntiles * (P.probe ? 1u : P.ksplit)), b(G.waves * 64);
 #define QDAS_LAUNCH(FM, WT) QDAS_LAUNCH_P(FM, WT, false)
 #define QDAS_LAUNCH_P(FM, WT, PR)                                                                        \
     do {                                                                                                 \
@@ -713,17 +758,23 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M);
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
     const int interp = P.flag & 7;
+    if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part))) return hipErrorInvalidValue;
 #define QDAS_DT(I) (sym ? launch_tile_i<I, float2, 1>(P, ntiles, lds, s)                                 \
                         : (dtype == 2 ? launch_tile_i<I, uint32_t, 2>(P, ntiles, lds, s) : launch_tile_i<I, float2, 0>(P, ntiles, lds, s)))
+    hipError_t e = hipErrorInvalidValue;
     switch (interp) {
-        case 0: return QDAS_DT(0);
-        case 1: case 4: return QDAS_DT(1);
-        case 2: return QDAS_DT(2);
-        case 3: return QDAS_DT(3);
-        case 5: return QDAS_DT(5);
+        case 0: e = QDAS_DT(0); break;
+        case 1: case 4: e = QDAS_DT(1); break;
+        case 2: e = QDAS_DT(2); break;
+        case 3: e = QDAS_DT(3); break;
+        case 5: e = QDAS_DT(5); break;
     }
 #undef QDAS_DT
-    return hipErrorInvalidValue;
+    if (e != hipSuccess || P.probe || P.ksplit <= 1) return e;
+    const unsigned rb = (unsigned)((P.i_count + 255) / 256);
+    if (dtype == 2) tile_reduce_kernel<uint32_t><<<rb, 256, 0, s>>>(P.part, (uint32_t *)P.y, P.i_count, P.ksplit);
+    else            tile_reduce_kernel<float2><<<rb, 256, 0, s>>>(P.part, (float2 *)P.y, P.i_count, P.ksplit);
+    return hipGetLastError();
 }
 
 }  // namespace qdas

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -369,7 +370,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if ((rc = dev_alloc(pl, &fb, sizeof(uint32_t) * (max_tiles + 1)))) return bail(rc);
         pl->fallback = (uint32_t *)fb;
         t.fallback_list = pl->fallback; t.fallback_cap = max_tiles;
-        t.probe = 0; t.wz_log2 = 6;
+        t.probe = 0; t.wz_log2 = 6; t.ksplit = 1; t.part = nullptr;
         // fold the (pixel-independent) apodization stack into one N x M complex64 table
         t.wtab = nullptr; t.apix = nullptr; t.apix_real = desc->apod_real;
         if (pix_arr >= 0) {
@@ -407,6 +408,24 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             t.wtab = dtab;
         }
         if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
+        // Too few tiles for the GPU (a pixel slab of a multi-GPU job, a small image): several workgroups per tile, each summing a
+        // slice of the aperture (das_tile.hip) until every CU has a workgroup.  QDAS_KSPLIT overrides.
+        {
+            int ncu = 0;
+            HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device));
+            const unsigned cus = ncu > 0 ? (unsigned)ncu : 256u;
+            const uint64_t nmb = (z.M + pl->tc.mb - 1) / pl->tc.mb;
+            const unsigned cap = (unsigned)std::min<uint64_t>(8, sym ? nmb : z.N);
+            unsigned ks = 1;
+            while (ks * 2 <= cap && (uint64_t)pl->ntiles * ks < (uint64_t)cus) ks *= 2;   // (a split costs one more prologue per tile)
+            if (const char *e = getenv("QDAS_KSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8 && (unsigned)v <= cap) ks = (unsigned)v; }
+            t.ksplit = ks;
+            if (ks > 1) {
+                void *pb;
+                if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)ks * pl->i_count))) return bail(rc);
+                t.part = (float2 *)pb;
+            }
+        }
     }
 
     if (desc->mem == QDAS_MEM_HOST) {                   // staging buffers for x / y
@@ -437,12 +456,13 @@ extern "C" int qdas_plan_fallback_tiles(const qdas_plan *pl, uint64_t *n) {
     return QDAS_OK;
 }
 
-extern "C" int qdas_plan_tile_shape(const qdas_plan *pl, int *tile_z, int *tile_cols, int *wave_z) {
+extern "C" int qdas_plan_tile_shape(const qdas_plan *pl, int *tile_z, int *tile_cols, int *wave_z, int *ksplit) {
     if (!pl || !tile_z || !tile_cols) return fail(QDAS_EINVAL, "null argument");
     const bool tiled = pl->kernel == QDAS_KERNEL_TILED;
     *tile_z = tiled ? (1 << pl->tp.tz_log2) : 0;
     *tile_cols = tiled ? (int)pl->tile_cols : 0;
     if (wave_z) *wave_z = tiled ? (1 << pl->tp.wz_log2) : 0;
+    if (ksplit) *ksplit = tiled ? (int)pl->tp.ksplit : 0;
     return QDAS_OK;
 }
 

@@ -385,14 +385,20 @@ class DasPlan:
     def tile_shape(self) -> tuple:
         """(pixels of I1, columns) of one workgroup tile of the tiled kernel; (0, 0) for the generic kernel."""
         tz, tc = C.c_int(0), C.c_int(0)
-        _lib.check(self.lib.qdas_plan_tile_shape(self._h, C.byref(tz), C.byref(tc), None))
+        _lib.check(self.lib.qdas_plan_tile_shape(self._h, C.byref(tz), C.byref(tc), None, None))
         return int(tz.value), int(tc.value)
 
     def wave_shape(self) -> tuple:
         """(pixels of I1, columns) one wave covers inside a tile; (0, 0) for the generic kernel."""
         tz, tc, wz = C.c_int(0), C.c_int(0), C.c_int(0)
-        _lib.check(self.lib.qdas_plan_tile_shape(self._h, C.byref(tz), C.byref(tc), C.byref(wz)))
+        _lib.check(self.lib.qdas_plan_tile_shape(self._h, C.byref(tz), C.byref(tc), C.byref(wz), None))
         return (int(wz.value), 64 // int(wz.value)) if wz.value else (0, 0)
+
+    def aperture_split(self) -> int:
+        """workgroups per tile (each sums a slice of the aperture; > 1 when the image / slab has too few tiles for the GPU)."""
+        tz, tc, ks = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check(self.lib.qdas_plan_tile_shape(self._h, C.byref(tz), C.byref(tc), None, C.byref(ks)))
+        return int(ks.value)
 
     def fallback_tiles(self) -> int:
         n = C.c_uint64()

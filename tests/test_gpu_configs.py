@@ -67,8 +67,9 @@ def test_config_lattice_parity(name, step, tol):
 
 
 @pytest.mark.parametrize("name", ["c2", "c3"])
-def test_config_linearity_and_slabs(name):
+def test_config_linearity_and_slabs(name, monkeypatch):
     import torch
+    monkeypatch.setenv("QDAS_KSPLIT", "1")      # same summation order for every slab size (a small slab would split the aperture)
     w, xa, prob = _setup(name, seed=1)
     _, xb, _ = _setup(name, seed=2)
     ya, _ = _run(prob, xa)
@@ -82,3 +83,9 @@ def test_config_linearity_and_slabs(name):
     assert torch.equal(torch.cat(parts), ya)                                          # slabs concatenate bit-exactly
     z, _ = _run(prob, torch.zeros_like(xa))
     assert float(z.abs().max()) == 0.0
+    # an eighth of the image (one rank of an 8-GPU job): the plan splits the aperture over several workgroups per tile;
+    # another summation order, same image to fp32 accumulation accuracy
+    monkeypatch.delenv("QDAS_KSPLIT")
+    sl, plan8 = _run(prob, xa, i_begin=I * 3 // 8, i_count=I // 8)
+    assert plan8.aperture_split() >= 2
+    assert float((sl - ya.reshape(-1)[I * 3 // 8: I * 3 // 8 + I // 8].reshape(sl.shape)).abs().max()) / float(ya.abs().max()) <= 2e-5
