@@ -54,6 +54,17 @@
 #define QDAS_ABL 0   // ablation bits for profiling builds only (tools/ablate.sh); 0 in the product
 #endif
 
+#ifndef QDAS_PROF
+#define QDAS_PROF 0  // 1: in-kernel phase timers (s_memtime) of waves 0 and 15 of every workgroup -> tools/phase_timers.py; 0 in the product
+#endif
+#if QDAS_PROF
+__device__ unsigned long long qdas_prof_buf[2 * 8 * 8192];
+extern "C" int qdas_debug_read_prof(unsigned long long *dst, size_t n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(qdas_prof_buf), n * sizeof(unsigned long long));
+}
+#define QDAS_TICK() ({ asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); unsigned long long t_ = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_; })
+#endif
+
 namespace qdas {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -184,6 +195,10 @@ das_tile_kernel(const TileParams P) {
     static_assert(MB % WAVES == 0 && MB % 2 == 0, "staging split");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#if QDAS_PROF
+    unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long pstart_ = QDAS_TICK();
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keeps everything derived from it in SGPRs
     const uint32_t M = (uint32_t)P.M, N = (uint32_t)P.N;
@@ -352,6 +367,9 @@ das_tile_kernel(const TileParams P) {
     gPv = PvL; gNv = NvL;
     __syncthreads();
 
+#if QDAS_PROF
+    pt_[0] = QDAS_TICK() - pstart_;                    // prologue
+#endif
     // ---- main loop over stages (mb = transmit block, n = receiver; n is the inner index)
     // This workgroup's share of the aperture (ksplit workgroups per tile when the image has too few tiles to fill the GPU;
     // their partial sums are added in a fixed order by tile_reduce_kernel):
@@ -384,59 +402,62 @@ das_tile_kernel(const TileParams P) {
     constexpr int NDMA = WPW * PCS * (SYM ? 2 : 1);    // DMA instructions per wave and stage
     static_assert(WB % 16 == 0 && PSZ == 16, "window must be a whole number of 16-byte lanes");
     const uint64_t xbytes = (uint64_t)P.N * P.M * P.T * SB;
-    // Per-wave DMA state: this wave stages windows j_r = wave + WAVES*r.  Everything that does not depend on the receiver is
-    // refreshed once per transmit block (dma_block); a stage then costs one LDS read (B[n]) and a few scalar ops per window.
-    int djo[WPW], djo2[WPW];                           // j_r * strM * SB, j_r * strN * SB  (< 2^31 by the plan-time check)
-    uint64_t doff = 0, doff2 = 0;                      // byte offsets of trace (rx n, tx m0) and of the mirror trace (rx m0, tx n)
-#pragma unroll
-    for (int r = 0; r < WPW; ++r) {
-        djo[r] = (int)((long)(wave + WAVES * r) * (long)P.strM * SB);
-        djo2[r] = (int)((long)(wave + WAVES * r) * (long)P.strN * SB);
-    }
+    // Per-wave DMA state: this wave stages windows j_r = wave + WAVES*r.  One buffer descriptor per TRANSMIT BLOCK, based at
+    // trace (rx n_lo, tx m0) (mirror: (rx m0, tx 0)); everything that does not depend on the receiver -- A[m], the window's
+    // trace offset -- is folded into one scalar per window when the block starts (dma_block).  A stage then costs two scalar
+    // adds per window: offset = soff (running receiver offset, 32-bit by the plan-time check) + wb[r] + B[n]*SB.
+    int wb[WPW], wb2[WPW];                             // A[m_r]*SB + j_r*strM*SB   (mirror: + j_r*strN*SB)
+    uint32_t soff = 0, soff2 = 0;
     uint32_t dm0 = 0;                                  // transmit block the DMA front is in
+    __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)P.x, 0, 0, 0x00020000), rsM = rsD;
     auto dma_block = [&](uint32_t m0) {
         dm0 = m0;
-        doff = ((uint64_t)m0 * P.strM + (uint64_t)n_lo * P.strN) * SB;
-        doff2 = (uint64_t)m0 * P.strN * SB;              // (reciprocal mode starts every block at receiver 0)
-    };
-    auto stage_dma = [&](uint32_t n, int buf) {       // stage (receiver n, current DMA transmit block)
-        const int bn = __builtin_amdgcn_readfirstlane(__float_as_int(nrec[n].x));
-        const uint64_t rem = xbytes - doff;
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + doff), 0,
-                                                                    rem > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem, 0x00020000);
+        const uint64_t o = ((uint64_t)m0 * P.strM + (uint64_t)n_lo * P.strN) * SB;
+        const uint64_t rem = xbytes > o ? xbytes - o : 0;   // (m0 >= M when the split is exhausted: nothing more is issued)
+        rsD = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + (rem ? o : 0)), 0, rem > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem, 0x00020000);
+        soff = 0;
 #pragma unroll
         for (int r = 0; r < WPW; ++r) {
             const int j = __builtin_amdgcn_readfirstlane(wave + WAVES * r);
-            const uint32_t m = dm0 + j;
-            // (A[m] is re-read from LDS: keeping it in a register across stages costs a scratch spill at this occupancy)
+            const uint32_t m = m0 + j;
             const int am = __builtin_amdgcn_readfirstlane(Abase[m < M ? m : M - 1]);
-            const int so = (QDAS_ABL & 32) ? (j & 1) * 4096 : (am + bn) * SB + djo[r];
+            wb[r] = am * SB + (int)((long)j * (long)P.strM * SB);
+            if constexpr (SYM) wb2[r] = am * SB + (int)((long)j * (long)P.strN * SB);
+        }
+        if constexpr (SYM) {                           // mirror traces x[:, rx = m0 + j, tx = n] (reciprocal mode starts every block at n = 0)
+            const uint64_t o2 = (uint64_t)m0 * P.strN * SB;
+            const uint64_t rem2 = xbytes > o2 ? xbytes - o2 : 0;
+            rsM = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + (rem2 ? o2 : 0)), 0, rem2 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem2, 0x00020000);
+            soff2 = 0;
+        }
+    };
+    auto stage_dma = [&](int bn, int buf) {           // stage (receiver with window base bn = B[n], current DMA transmit block)
+        const int bs = bn * SB;
+#pragma unroll
+        for (int r = 0; r < WPW; ++r) {
+            const int j = __builtin_amdgcn_readfirstlane(wave + WAVES * r);
+            const int so = (int)soff + wb[r] + bs;
 #pragma unroll
             for (int q = 0; q < ((QDAS_ABL & 64) ? 1 : PCS); ++q) {
                 lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + j) * WB + q * PB));
                 if (lane * 16 < WB - q * PB)             // trailing partial piece: upper lanes masked off
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, lane * 16, so + q * PB, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, dst, 16, lane * 16, so + q * PB, 0, 0);
             }
         }
-        doff += (uint64_t)P.strN * SB;                 // next receiver, same transmit block
-        if constexpr (SYM) {                           // mirror traces x[:, rx = m0 + j, tx = n]: same window start A[m] + B[n]
-            const uint64_t rem2 = xbytes - doff2;
-            __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + doff2), 0,
-                                                                         rem2 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem2, 0x00020000);
+        soff += (uint32_t)P.strN * SB;                 // next receiver, same transmit block
+        if constexpr (SYM) {                           // same window start A[m] + B[n] in the mirror trace
 #pragma unroll
             for (int r = 0; r < WPW; ++r) {
                 const int j = __builtin_amdgcn_readfirstlane(wave + WAVES * r);
-                const uint32_t m = dm0 + j;
-                const int am = __builtin_amdgcn_readfirstlane(Abase[m < M ? m : M - 1]);
-                const int so = (am + bn) * SB + djo2[r];
+                const int so = (int)soff2 + wb2[r] + bs;
 #pragma unroll
                 for (int q = 0; q < PCS; ++q) {
                     lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + MB + j) * WB + q * PB));
                     if (lane * 16 < WB - q * PB)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, dst, 16, lane * 16, so + q * PB, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, dst, 16, lane * 16, so + q * PB, 0, 0);
                 }
             }
-            doff2 += (uint64_t)P.strM * SB;            // next "transmit" n of the mirror traces
+            soff2 += (uint32_t)P.strM * SB;            // next "transmit" n of the mirror traces
         }
     };
 
@@ -463,24 +484,38 @@ das_tile_kernel(const TileParams P) {
         if (wpix) wcur = wload(n_lo);
         uint32_t pr = 0, pn = n_lo, pm0 = blk(0);          // stage the DMA front is at (NBUF-1 stages ahead)
         dma_block(pm0);
+        // B[n] of the stage at the DMA front travels in a VGPR, loaded one stage before it is needed: every LDS read of a stage
+        // is issued BEFORE the stage's LDS-DMA in program order (the compiler orders a later LDS read behind the DMA's vmcnt).
+        float vbn = nrec[pn < N ? pn : N - 1].x;
+        auto dma_next = [&](int buf) {
+            const int bn = __builtin_amdgcn_readfirstlane(__float_as_int(vbn));
+            const uint32_t qn = (pn + 1 == nlim(pm0)) ? n_lo : pn + 1;     // receiver of the stage after this one
+            vbn = nrec[qn < N ? qn : N - 1].x;
+            stage_dma(bn, buf);
+            if (++pn == nlim(pm0)) { pn = n_lo; pm0 = blk(++pr); dma_block(pm0); }
+        };
 #pragma unroll
         for (int b = 0; b < NBUF - 1; ++b)
-            if ((uint32_t)b < nstage) { stage_dma(pn, b); if (++pn == nlim(pm0)) { pn = n_lo; pm0 = blk(++pr); dma_block(pm0); } }
+            if ((uint32_t)b < nstage) dma_next(b);
         // counted wait: everything but the newest (NBUF-2) stages has landed; then publish to the workgroup
         if (nstage >= (uint32_t)(NBUF - 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         int buf = 0;
         uint32_t cr = 0, n = n_lo, m0 = blk(0);
         for (uint32_t st = 0; st < nstage; ++st) {
+#if QDAS_PROF
+            const unsigned long long ts0_ = QDAS_TICK();
+#endif
             const bool more = st + (NBUF - 1) < nstage;
             // next stage's pixel weight: requested BEFORE this stage's DMA, so the end-of-stage wait covers it
             if (wpix && st + 1 < nstage) wnext = wload(n + 1 == nlim(m0) ? n_lo : n + 1);
             const bool skip = wpix && (__ballot(wcur.x != 0.f || wcur.y != 0.f) == 0ull);   // whole wave weightless: no gathers
-            if (!(QDAS_ABL & 1) && more) {               // lands during the next NBUF-1 stages
-                stage_dma(pn, (buf + NBUF - 1) % NBUF);
-                if (++pn == nlim(pm0)) { pn = n_lo; pm0 = blk(++pr); dma_block(pm0); }
-            }
+            const float4 rec = nrec[n];                // {B[n], receiver position}: one broadcast LDS read, issued ahead of the DMA
+            if (!(QDAS_ABL & 1) && more) dma_next((buf + NBUF - 1) % NBUF);   // lands during the next NBUF-1 stages
 
+#if QDAS_PROF
+            const unsigned long long ts1_ = QDAS_TICK();
+#endif
             if (n == n_lo) {                           // new transmit block: refresh the tx residuals
 #pragma unroll
                 for (int p = 0; p < MB / 2; ++p) {
@@ -495,8 +530,10 @@ das_tile_kernel(const TileParams P) {
                     __builtin_amdgcn_sched_barrier(0);      // one pair at a time: keeps this cold block from inflating the register budget
                 }
             }
+#if QDAS_PROF
+            const unsigned long long ts2_ = QDAS_TICK();
+#endif
             if (!skip) {
-            const float4 rec = nrec[n];                // {B[n], receiver position}: one broadcast LDS read
             const int bn = __float_as_int(rec.x);
             const float rb = (QDAS_ABL & 2) ? (float)(lane * 2 + 3) + 0.37f * (float)(n & 7) : (float)(b_at(rec.y, rec.z, rec.w) - (double)bn);
             // LDS byte address of a tap = bits(t + MAGIC)*SB + cbase + (window, tap) immediate
@@ -652,12 +689,19 @@ das_tile_kernel(const TileParams P) {
             }
 
             }   // !skip
+#if QDAS_PROF
+            const unsigned long long ts3_ = QDAS_TICK();
+#endif
 
             // stage st+1 must have landed (all but the NBUF-2 newest DMA groups), all my LDS reads are done
             if (!(QDAS_ABL & 16)) {
                 if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((NBUF - 2) * NDMA) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
+#if QDAS_PROF
+            { const unsigned long long ts4_ = QDAS_TICK();
+              pt_[1] += ts1_ - ts0_; pt_[2] += ts2_ - ts1_; pt_[3] += ts3_ - ts2_; pt_[4] += ts4_ - ts3_; pt_[6] += 1; }
+#endif
             buf = (buf + 1 == NBUF) ? 0 : buf + 1;
             if (wpix) {                                // weight the stage's partial sum (the weight does not depend on m)
                 const v2f S = (acc + acc1) + (acc2 + acc3);
@@ -670,6 +714,13 @@ das_tile_kernel(const TileParams P) {
     };
     if (tile_interior) run(std::false_type{}); else run(std::true_type{});
 
+#if QDAS_PROF
+    pt_[5] = QDAS_TICK() - pstart_;                    // whole workgroup
+    if (lane == 0 && (wave == 0 || wave == WAVES - 1) && blockIdx.x < 8192) {
+        unsigned long long *o = qdas_prof_buf + ((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+        for (int k = 0; k < 8; ++k) o[k] = pt_[k];
+    }
+#endif
     acc = wpix ? tot : (acc + acc1) + (acc2 + acc3);
     // ---- epilogue: y[i] = pix  (reference src/bf.cu:140); lanes = consecutive i -> coalesced
     {

@@ -330,12 +330,18 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         eligible = false; why = "tiled kernel: N + M too large for the LDS header";
     }
     if (eligible && (z.T < 8)) { eligible = false; why = "tiled kernel needs T >= 8"; }
-    {   // LDS-DMA offsets inside one stage are 32-bit: (mb-1)*stride + window must stay below 2^31 bytes
+    {   // LDS-DMA offsets inside one transmit block are 32-bit: N receivers + mb transmits + a window must stay below 2^31 bytes
         const uint64_t strM = (z.flag & QDAS_FLAG_TPOSE) ? z.T : z.T * z.N;
         const uint64_t strN = (z.flag & QDAS_FLAG_TPOSE) ? z.T * z.M : z.T;
-        const uint64_t smax = sym ? (strM > strN ? strM : strN) : strM;
-        if (eligible && ((uint64_t)pl->tc.mb * smax + 4096) * data_size(dt) >= (1ull << 31)) {
-            eligible = false; why = "tiled kernel: trace stride too large for 32-bit DMA offsets";
+        const uint64_t lim = 1ull << 31, slack = 65536;
+        // mirror traces of the reciprocal mode walk the other way (N "transmits" apart): drop the mode for >2 GiB frames
+        if (sym && (z.N * strM + (uint64_t)tile_config(dt, 1).mb * strN) * data_size(dt) + slack >= lim) {
+            sym = 0;
+            pl->tc = tile_config(dt, 0);
+            if (eligible && tile_lds_bytes(dt, 0, z.N, z.M) > tile_lds_limit(0)) { eligible = false; why = "tiled kernel: N + M too large for the LDS header"; }
+        }
+        if (eligible && (z.N * strN + (uint64_t)pl->tc.mb * strM) * data_size(dt) + slack >= lim) {
+            eligible = false; why = "tiled kernel: trace strides too large for 32-bit DMA offsets (transposed data of more than 2 GiB)";
         }
     }
     if (desc->kernel == QDAS_KERNEL_TILED && !eligible) return bail(fail(QDAS_EUNSUPPORTED, "%s", why));
