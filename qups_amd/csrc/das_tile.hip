@@ -162,15 +162,32 @@ template <int... Is, typename F> __device__ __forceinline__ void unroll_impl(std
 }
 template <int N, typename F> __device__ __forceinline__ void unroll(F &&f) { unroll_impl(std::make_integer_sequence<int, N>{}, f); }
 
-// fp16 data: 4-byte samples; plain loads (ds_read_b32 pairs merge without penalty), widened to fp32
-struct taps_f16 { v2f s[4]; };
-template <int K> __device__ __forceinline__ void lds_load_f16(taps_f16 &t, uint32_t addr) {
-    const __attribute__((address_space(3))) uint32_t *p = (const __attribute__((address_space(3))) uint32_t *)(uintptr_t)addr;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const uint32_t v = p[k];
-        t.s[k] = (v2f){__half2float(__ushort_as_half((unsigned short)(v & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(v >> 16)))};
-    }
+// fp16 data: 4-byte samples {re, im}.  K x ds_read_b32 with immediate offsets from inline asm (the same issue / weights / fence
+// pattern as fp32); the MAC is v_fma_mix_f32 -- fp16 tap x fp32 weight + fp32 accumulator in ONE instruction per component, so the
+// taps are never converted (hipcc's own choice is 2 v_cvt_f32_f16 + 1 v_pk_fma_f32 per tap: 1.8x the issue cycles).
+struct taps_f16 { uint32_t r[4]; };
+template <int K, int OFF> __device__ __forceinline__ void lds_issue(taps_f16 &t, uint32_t addr) {
+    if constexpr (K == 4)
+        asm volatile("ds_read_b32 %0, %4 offset:%5\n\tds_read_b32 %1, %4 offset:%6\n\tds_read_b32 %2, %4 offset:%7\n\tds_read_b32 %3, %4 offset:%8"
+                     : "=&v"(t.r[0]), "=&v"(t.r[1]), "=&v"(t.r[2]), "=&v"(t.r[3]) : "v"(addr), "n"(OFF), "n"(OFF + 4), "n"(OFF + 8), "n"(OFF + 12));
+    else if constexpr (K == 2)
+        asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4" : "=&v"(t.r[0]), "=&v"(t.r[1]) : "v"(addr), "n"(OFF), "n"(OFF + 4));
+    else
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(t.r[0]) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void lds_fence(taps_f16 &a, taps_f16 &b, v2f (&w)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a.r[0]), "+v"(a.r[1]), "+v"(a.r[2]), "+v"(a.r[3]), "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]),
+                   "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+}
+__device__ __forceinline__ void mix_mac(v2f &acc, uint32_t tap, float w) {       // acc += w * (float2)tap
+    float ar = acc.x, ai = acc.y;
+    asm("v_fma_mix_f32 %0, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "+v"(ar), "+v"(ai) : "v"(tap), "v"(w));
+    acc = (v2f){ar, ai};
+}
+__device__ __forceinline__ v2f half2_to_v2f(uint32_t v) {
+    return (v2f){__half2float(__ushort_as_half((unsigned short)(v & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(v >> 16)))};
 }
 
 __device__ __forceinline__ float2   zero_of(const float2 *)   { return make_float2(0.f, 0.f); }
@@ -605,19 +622,25 @@ das_tile_kernel(const TileParams P) {
                     if constexpr (SYM && K == 1) { v0 += h0.s[0]; v1 += h1.s[0]; }
                 } else {
                     taps_f16 g0, g1;
-                    lds_load_f16<K>(g0, ad0 + (2 * p) * WB); lds_load_f16<K>(g1, ad1 + (2 * p + 1) * WB);
+                    lds_issue<K, (2 * p) * WB>(g0, ad0); lds_issue<K, (2 * p + 1) * WB>(g1, ad1);
+                    if constexpr (K < 4) { g0.r[2] = g0.r[3] = g1.r[2] = g1.r[3] = 0u; }
+                    if constexpr (K < 2) { g0.r[1] = g1.r[1] = 0u; }
+                    v2f w[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+                    if constexpr (K > 1) weights2<INTERP>(s, w);            // overlaps the LDS latency
+                    lds_fence(g0, g1, w);
                     if constexpr (TAIL) {
                         if (!upper) {
 #pragma unroll
-                            for (int k = 0; k < K; ++k) g1.s[k] = (v2f){0.f, 0.f};
+                            for (int k = 0; k < 4; ++k) g1.r[k] = 0u;
                         }
                     }
-                    if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; }
-                    else {
-                        v2f w[4];
-                        weights2<INTERP>(s, w);
+                    if constexpr (K == 1) { v0 = half2_to_v2f(g0.r[0]); v1 = half2_to_v2f(g1.r[0]); }
+                    else if constexpr (SPLIT) {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) { v0 = w[k].x * g0.s[k] + v0; v1 = w[k].y * g1.s[k] + v1; }
+                        for (int k = 0; k < K; ++k) { mix_mac(v0, g0.r[k], w[k].x); mix_mac(v1, g1.r[k], w[k].y); }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { mix_mac(acc, g0.r[k], w[k].x); mix_mac(acc1, g1.r[k], w[k].y); }
                     }
                 }
                 if constexpr (CHECK) {                    // edge rule: all taps in [0,T) and tau >= 0
@@ -642,7 +665,7 @@ das_tile_kernel(const TileParams P) {
                 if constexpr (WTAB) {
                     acc += (v2f){wr0 * v0.x - wi0 * v0.y, wr0 * v0.y + wi0 * v0.x};
                     acc += (v2f){wr1 * v1.x - wi1 * v1.y, wr1 * v1.y + wi1 * v1.x};
-                } else if constexpr (SPLIT || !F32 || K == 1) { acc += v0; acc += v1; }
+                } else if constexpr (SPLIT || K == 1) { acc += v0; acc += v1; }
             };
             // full block (reciprocal mode: block entirely above the diagonal): check-free; else the tail / diagonal variant
             if (SYM ? (n < m0) : (m0 + MB <= M)) {
