@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 tiled")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--gen-apod", action="store_true", help="generate the workload's receive apodization inside the kernel "
+                    "(qdas_desc.rx_apod_*) instead of streaming the materialised I x N array")
     args = ap.parse_args()
 
     import torch
@@ -93,7 +95,13 @@ def main():
     I = w["I1"] * w["I2"]
     g = torch.Generator(device=dev).manual_seed(1234)     # same data on every rank (replicated input)
     xc = torch.view_as_complex(torch.randn((M, N, T, 2), generator=g, device=dev, dtype=torch.float32))
-    extra = ["interp", w["interp"], "input-precision", w["prec"]] + (["apod", w["apod"]] if w["apod"] is not None else [])
+    extra = ["interp", w["interp"], "input-precision", w["prec"]]
+    if args.gen_apod and w["rx_apod"] is not None:
+        from qups_amd.apodization import rx_apod_spec
+        extra += ["rx-apod", rx_apod_spec(w["rx_apod"][0], normals=w["nrm"], **w["rx_apod"][1])]
+        w["apod"] = None
+    elif w["apod"] is not None:
+        extra += ["apod", w["apod"]]
     opts = parse_options(xc, list(w["opt"]) + extra)
     if w["prec"] == "halfT":
         from qups_amd.das_spec import _cast_data

@@ -59,6 +59,17 @@ extern "C" {
 #define QDAS_KERNEL_GENERIC 1 /* one pixel per lane, any mode / broadcast shape        */
 #define QDAS_KERNEL_TILED   2 /* LDS-staged pixel tiles; error if the case is ineligible */
 
+/* ---- generated receive apodization w(pixel, receiver), r = Pi - Pr(n), nhat = element normal:
+ *  ACCEPTANCE     (reference src/UltrasoundSystem.m:5355-5373 apAcceptanceAngle): w = [ r.nhat/|r| >= p[0] ],  p[0] = cosd(theta)
+ *  COSINE         (:5414-5428 apCosineAngle): w = cos(min(pi/2, p[0]*acos(clip(r.nhat/|r|, -1, 1)))),        p[0] = 90/theta
+ *  FNUMBER_PLANAR (:5251-5256 apApertureGrowth, planar array): d = x_n - x_i, z = z_i: w = [z > p[0]*|2d|]*[|2d| < p[1]],  p = {f, Dmax}
+ *  FNUMBER_ORIENTED (:5244-5250,5255-5256, non-planar array, elements rotated about y): d = r_x*n_z - r_z*n_x, z = |r_x*n_x + r_z*n_z| */
+#define QDAS_RXAPOD_NONE             0
+#define QDAS_RXAPOD_ACCEPTANCE       1
+#define QDAS_RXAPOD_COSINE           2
+#define QDAS_RXAPOD_FNUMBER_PLANAR   3
+#define QDAS_RXAPOD_FNUMBER_ORIENTED 4
+
 /* ---- error codes */
 #define QDAS_OK            0
 #define QDAS_EINVAL        1 /* bad argument / inconsistent sizes (message says which)  */
@@ -105,7 +116,13 @@ typedef struct qdas_desc {
     uint64_t i_count;     /* number of pixels (0 = I - i_begin)                            */
     uint64_t y_ld;        /* pixels between consecutive [n|m] planes of y (0 = i_count): lets a
                              shard write straight into a full-size I x [N] x [M] buffer    */
-    uint64_t reserved[4];
+    /* extension: receive apodization GENERATED in the kernel from the geometry instead of a
+       materialised I1 x I2 x I3 x N array; multiplies the apodization arrays.  rx_normals: 3 x N element
+       normals, real(prec) like Pr (float for QDAS_F16); same memory kind as Pr.                            */
+    int32_t  rx_apod_kind;   /* QDAS_RXAPOD_*                                                             */
+    int32_t  reserved0;
+    double   rx_apod_p[2];   /* parameters, see QDAS_RXAPOD_*                                             */
+    const void *rx_normals;  /* may be NULL for QDAS_RXAPOD_NONE / QDAS_RXAPOD_FNUMBER_PLANAR             */
 } qdas_desc;
 
 typedef struct qdas_plan qdas_plan; /* opaque: device copies of geometry + strides + kernel choice */

@@ -384,3 +384,69 @@ def convolve_sample(x, s, kernel, support):
             continue
         out[j] = sum(x[k] * kernel(sj - k) for k in ks)
     return out
+
+
+# --------------------------------------------------------------------------
+# Receive-apodization generators -- restated line by line from the reference, in the
+# reference's own formulation (degrees, atan2d / sind / cosd), float64.  Pi: 3 x I1 x I2 x I3, Pr: 3 x N,
+# nrm: 3 x N element normals, ang: N element azimuth angles in degrees.  Output I1 x I2 x I3 x N x 1.
+# --------------------------------------------------------------------------
+def _cosd(d):
+    d = np.asarray(d, dtype=np.float64)
+    r = np.cos(np.deg2rad(d))
+    m = np.mod(d, 360.0)
+    for a, v in ((0.0, 1.0), (60.0, 0.5), (90.0, 0.0), (120.0, -0.5), (180.0, -1.0), (240.0, -0.5), (270.0, 0.0), (300.0, 0.5)):
+        r = np.where(m == a, v, r)                                 # MATLAB cosd is exact at these angles
+    return r
+
+
+def _sind(d):
+    return _cosd(np.asarray(d, dtype=np.float64) - 90.0)
+
+
+def ap_acceptance_angle(Pi, Pr, nrm, theta=45.0):
+    """reference src/UltrasoundSystem.m:5355-5373"""
+    Pi = np.asarray(Pi, np.float64)
+    Pi = Pi.reshape(3, *Pi.shape[1:], *([1] * (4 - Pi.ndim)))
+    Pn = np.asarray(Pr, np.float64).reshape(3, 1, 1, 1, -1)        # :5356
+    n = np.asarray(nrm, np.float64).reshape(3, 1, 1, 1, -1)        # :5357-5358
+    r = Pi[..., None] - Pn                                         # :5364
+    with np.errstate(invalid="ignore", divide="ignore"):
+        r = r / np.sqrt((r * r).sum(0, keepdims=True))             # :5369
+        c = (n * r).sum(0)                                         # :5370
+        return (c >= float(_cosd(theta))).astype(np.float64)[..., None]   # :5373
+
+
+def ap_cosine_angle(Pi, Pr, nrm, theta=45.0):
+    """reference src/UltrasoundSystem.m:5414-5428"""
+    Pi = np.asarray(Pi, np.float64)
+    Pi = Pi.reshape(3, *Pi.shape[1:], *([1] * (4 - Pi.ndim)))
+    pn = np.asarray(Pr, np.float64).reshape(3, 1, 1, 1, -1)
+    nn = np.asarray(nrm, np.float64).reshape(3, 1, 1, 1, -1)
+    r = Pi[..., None] - pn                                         # :5421
+    with np.errstate(invalid="ignore", divide="ignore"):
+        r = r / np.sqrt((r * r).sum(0, keepdims=True))             # :5422
+    r = (nn * r).sum(0)                                            # :5423
+    r = np.fmax(-1.0, np.fmin(1.0, r))                             # :5424  (MATLAB max/min ignore NaN: NaN -> 1)
+    return _cosd(np.minimum(90.0, (90.0 / theta) * np.rad2deg(np.arccos(r))))[..., None]   # :5425
+
+
+def ap_aperture_growth(Pi, Pr, ang=None, f=1.5, Dmax=np.inf):
+    """reference src/UltrasoundSystem.m:5227-5262 (generic-scan branch :5236-5239)"""
+    Pi = np.asarray(Pi, np.float64)
+    Pi = Pi.reshape(3, *Pi.shape[1:], *([1] * (4 - Pi.ndim)))
+    Pr = np.asarray(Pr, np.float64)
+    Xn, Zn = Pr[0].reshape(1, 1, 1, -1), Pr[2].reshape(1, 1, 1, -1)            # :5228-5229
+    Xi, Zi = Pi[0][..., None], Pi[2][..., None]                                # :5237-5238
+    if ang is not None and np.any(np.asarray(ang) != 0):                       # :5243
+        ae = np.asarray(ang, np.float64).reshape(1, 1, 1, -1)                  # :5244
+        rp = np.hypot(Xi - Xn, Zi - Zn)                                        # :5245
+        ap = np.rad2deg(np.arctan2(Xi - Xn, Zi - Zn))                          # :5246
+        d = rp * _sind(ap - ae)                                                # :5247
+        z = np.abs(rp * _cosd(ap - ae))                                        # :5248
+    else:
+        d = Xn - Xi                                                            # :5251
+        z = Zi - 0.0 + 0.0 * d                                                 # :5252
+    apod = (z > f * np.abs(2 * d)).astype(np.float64)                          # :5255
+    apod = apod * (np.abs(2 * d) < Dmax)                                       # :5256
+    return apod[..., None]

@@ -8,6 +8,7 @@ this package is the host-side mirror of the reference's interface for that path.
 from .das_spec import DasError, DasPlan, DasProblem, build_problem, das_spec, parse_options  # noqa: F401
 
 from .interpd import das_lut, sample2sep, wsinterpd2  # noqa: F401,E402
+from . import apodization  # noqa: F401,E402
 from .ultrasound import ChannelData, Scan, Sequence, Transducer, UltrasoundSystem  # noqa: F401,E402
 
 __all__ = ["das_spec", "DasPlan", "DasProblem", "DasError", "build_problem", "parse_options", "das_lut", "sample2sep",

@@ -20,6 +20,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED = 0, 1, 2
 KERNEL_NAMES = {KERNEL_GENERIC: "generic", KERNEL_TILED: "tiled"}
 MAX_APOD = 6
+RXAPOD_NONE, RXAPOD_ACCEPTANCE, RXAPOD_COSINE, RXAPOD_FNUMBER_PLANAR, RXAPOD_FNUMBER_ORIENTED = 0, 1, 2, 3, 4
 
 # every symbol include/qdas.h declares (tests check the library exports all of them)
 SYMBOLS = (
@@ -42,7 +43,8 @@ class Desc(C.Structure):
                 ("apod", C.c_void_p), ("cinv", C.c_void_p), ("acstride", C.POINTER(C.c_uint64)),
                 ("mem", C.c_int32), ("apod_real", C.c_int32), ("kernel", C.c_int32), ("device", C.c_int32),
                 ("i_begin", C.c_uint64), ("i_count", C.c_uint64), ("y_ld", C.c_uint64),
-                ("reserved", C.c_uint64 * 4)]
+                ("rx_apod_kind", C.c_int32), ("reserved0", C.c_int32), ("rx_apod_p", C.c_double * 2),
+                ("rx_normals", C.c_void_p)]
 
 
 class LutDesc(C.Structure):

@@ -18,6 +18,7 @@ def _f32(a):
 def workload(name: str) -> dict:
     c0 = 1540.0
     apod = None
+    rx_apod = None
     prec = "single"
     if name == "c1":      # 64-el linear array (L7-4-like), 32 focused transmits, 256 x 256, linear interp
         fc, N, pitch, nx, nz, T, interp = 5.208e6, 64, 0.298e-3, 256, 256, 2048, "linear"
@@ -65,6 +66,7 @@ def workload(name: str) -> dict:
         d = Pi[:, :, :, 0, None] - Pr[:, None, None, :]
         cosang = (d * nrm[:, None, None, :]).sum(0) / np.maximum(np.linalg.norm(d, axis=0), 1e-12)
         apod = (cosang >= np.cos(np.deg2rad(30.0))).astype(np.float32)[:, :, None, :, None]
+        rx_apod = ("acceptance", dict(theta=30.0))                      # the same rule, for generation inside the kernel
         nx, nz = na, nr
         t0 = -rv / c0 * 0                                               # DV: distance measured from the virtual source
         prec = "halfT"
@@ -84,4 +86,5 @@ def workload(name: str) -> dict:
     M = max(Nv.shape[1], Pv.shape[1])
     fs = float(np.float32(4 * fc))
     return dict(name=name, label=label, Pi=_f32(Pi), Pr=_f32(Pr), Pv=_f32(Pv), Nv=_f32(Nv), opt=list(opt), T=T, N=N, M=M, fs=fs,
-                c0=c0, interp=interp, I1=nz, I2=nx, t0=float(np.float32(t0)), apod=apod, prec=prec)
+                c0=c0, interp=interp, I1=nz, I2=nx, t0=float(np.float32(t0)), apod=apod, prec=prec,
+                nrm=_f32(nrm), rx_apod=rx_apod)

@@ -92,6 +92,14 @@ das_generic_kernel(const GenericParams P) {
                 else a = cmul(a, ld((const ST *)P.apod, k));
             }
         }
+        if (P.gen_kind && (a.x != (R)0 || a.y != (R)0)) {                      // generated receive apodization (qdas.h QDAS_RXAPOD_*)
+            const R *rn = (const R *)P.rxn;
+            const double ex = (double)Pr[3 * n], ey = (double)Pr[3 * n + 1], ez = (double)Pr[3 * n + 2];
+            const double nx = rn ? (double)rn[3 * n] : 0.0, ny = rn ? (double)rn[3 * n + 1] : 0.0, nz = rn ? (double)rn[3 * n + 2] : 1.0;
+            const R w = (R)rx_apod_weight(P.gen_kind, P.gen_p0, P.gen_p1, (double)px - ex, (double)py - ey, (double)pz - ez,
+                                          nx, ny, nz, (double)px, (double)pz, ex);
+            a.x *= w; a.y *= w;
+        }
         if (a.x == (R)0 && a.y == (R)0) return {(R)0, (R)0};                  // zero weight: skip the gather
         cplx<R> v = sample_global<INTERP, R, ST>(x + nm * T, (long)T, tau * fs);
         if (fc != (R)0) {                                                    // src/bf.cu:117

@@ -176,6 +176,11 @@ static int validate(const qdas_desc *d) {
     if (I && z.N && z.M) {
         if (!d->Pi || !d->Pr || !d->Pv || !d->Nv || !d->cinv || !d->acstride) return fail(QDAS_EINVAL, "null geometry / stride pointer");
         if (z.S && !d->apod) return fail(QDAS_EINVAL, "S > 0 but apod is null");
+        if (d->rx_apod_kind < QDAS_RXAPOD_NONE || d->rx_apod_kind > QDAS_RXAPOD_FNUMBER_ORIENTED)
+            return fail(QDAS_EINVAL, "Unrecognized generated receive apodization %d", d->rx_apod_kind);
+        if ((d->rx_apod_kind == QDAS_RXAPOD_ACCEPTANCE || d->rx_apod_kind == QDAS_RXAPOD_COSINE || d->rx_apod_kind == QDAS_RXAPOD_FNUMBER_ORIENTED)
+            && !d->rx_normals) return fail(QDAS_EINVAL, "generated receive apodization needs the element normals (rx_normals)");
+        if (d->rx_apod_kind && !(d->rx_apod_p[0] == d->rx_apod_p[0])) return fail(QDAS_EINVAL, "generated receive apodization: NaN parameter");
     }
     if (d->mem != QDAS_MEM_HOST && d->mem != QDAS_MEM_DEVICE) return fail(QDAS_EINVAL, "bad mem kind %d", d->mem);
     if (z.T > 0x7fffffffull) return fail(QDAS_EUNSUPPORTED, "T must be < 2^31");
@@ -294,6 +299,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     g.fs = dt == QDAS_F64 ? desc->fs : (double)(float)desc->fs;
     g.fmod = dt == QDAS_F64 ? desc->fmod : (double)(float)desc->fmod;
     g.S = (int32_t)z.S; g.flag = z.flag; g.VS = z.VS; g.DV = z.DV; g.apod_real = desc->apod_real;
+    g.gen_kind = desc->rx_apod_kind; g.gen_p0 = desc->rx_apod_p[0]; g.gen_p1 = desc->rx_apod_p[1]; g.rxn = nullptr;
+    if (g.gen_kind && desc->rx_normals && (rc = import_array(pl, desc->rx_normals, 3 * z.N * rs, desc->mem, &g.rxn))) return bail(rc);
     g.tile_list = nullptr; g.blocks_per_tile = 0; g.tile_cols = 0; g.tiles_z = 0;
 
     // ---- kernel selection
@@ -313,10 +320,13 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         else if (!full || pix_arr >= 0) { eligible = false; why = "tiled kernel: at most one apodization array may depend on the pixel (I x [N], no transmit dependence)"; }
         else pix_arr = (int)s;
     }
+    if (eligible && g.gen_kind && pix_arr >= 0) {
+        eligible = false; why = "tiled kernel: a generated receive apodization and a pixel-dependent array need the generic kernel";
+    }
     // reciprocal mode (das_tile.hip "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
     // elements and share one t0 has tau(n,m) == tau(m,n); detected from the geometry itself, bit-exactly.
     int sym = 0;
-    if (eligible && dt == QDAS_F32 && z.VS && z.DV && z.N == z.M && z.S == 0 && !getenv("QDAS_NO_SYM")) {
+    if (eligible && dt == QDAS_F32 && z.VS && z.DV && z.N == z.M && z.S == 0 && !g.gen_kind && !getenv("QDAS_NO_SYM")) {
         std::vector<float> hr(3 * z.N), hv(4 * z.M);
         if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
         if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);
@@ -379,6 +389,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         t.probe = 0; t.wz_log2 = 6; t.ksplit = 1; t.part = nullptr;
         // fold the (pixel-independent) apodization stack into one N x M complex64 table
         t.wtab = nullptr; t.apix = nullptr; t.apix_real = desc->apod_real;
+        t.gen_kind = g.gen_kind; t.gen_p0 = g.gen_p0; t.gen_p1 = g.gen_p1; t.rxn = (const float *)g.rxn;
         if (pix_arr >= 0) {
             const uint64_t *a = &g.ast[6 * pix_arr];
             if (a[3] == 0 && z.N > 1) {                 // I-only array: no receiver dependence -> cannot index by n; use the generic kernel

@@ -39,6 +39,29 @@ __device__ __forceinline__ void st(uint32_t *p, size_t i, cplx<float> v) {
     p[i] = (uint32_t)__half_as_ushort(__float2half_rn(v.x)) | ((uint32_t)__half_as_ushort(__float2half_rn(v.y)) << 16);
 }
 
+// ---------------------------------------------------------------- generated receive apodization (qdas.h QDAS_RXAPOD_*)
+// Evaluated in fp64 from the fp32/fp64 inputs: the masks are step functions of the geometry, and a float64 host evaluation
+// (reference src/UltrasoundSystem.m:5165-5430 runs in double) must give the same side of the step.
+// r = pixel - element, n = element normal, (pix_x, pix_z) the pixel and el_x the element's x coordinate.
+__device__ __forceinline__ double rx_apod_weight(int kind, double p0, double p1, double rx, double ry, double rz,
+                                                 double nx, double ny, double nz, double pix_x, double pix_z, double el_x) {
+    if (kind == 1 || kind == 2) {
+        const double c = (rx * nx + ry * ny + rz * nz) / sqrt(rx * rx + ry * ry + rz * rz);   // NaN at the element itself
+        if (kind == 1) return (c >= p0) ? 1.0 : 0.0;                                            // NaN -> 0, like MATLAB's >=
+        const double cc = (c == c) ? fmin(1.0, fmax(-1.0, c)) : 1.0;    // MATLAB's max(-1, min(1, NaN)) == 1
+        return cos(fmin(1.5707963267948966, p0 * acos(cc)));
+    }
+    if (kind == 3) {
+        const double d2 = fabs(2.0 * (el_x - pix_x));
+        return (pix_z > p0 * d2 && d2 < p1) ? 1.0 : 0.0;
+    }
+    if (kind == 4) {
+        const double d2 = fabs(2.0 * (rx * nz - rz * nx)), z = fabs(rx * nx + rz * nz);
+        return (z > p0 * d2 && d2 < p1) ? 1.0 : 0.0;
+    }
+    return 1.0;
+}
+
 // ---------------------------------------------------------------- interpolation weights
 __device__ __forceinline__ float  qfloor(float v)  { return floorf(v); }
 __device__ __forceinline__ double qfloor(double v) { return floor(v); }

@@ -18,6 +18,10 @@ struct GenericParams {
     uint64_t ast[6 * QDAS_MAX_APOD];    // astride  (reference kern/das_spec.m:260)
     double fs, fmod;
     int32_t S, flag, VS, DV, apod_real;
+    // generated receive apodization (qdas.h QDAS_RXAPOD_*): kind, parameters, element normals (3 x N, same type as Pr)
+    int32_t gen_kind;
+    double gen_p0, gen_p1;
+    const void *rxn;
     // fallback-tile mode (tile_list != nullptr): process only the listed (1 << tile_zl) x tile_cols tiles;
     // tile_list[0] = count, tile_list[1..] = tile ids (written by the tiled kernel)
     const uint32_t *tile_list;
@@ -36,6 +40,9 @@ struct TileParams {
     const void *wtab;                   // optional N x M table of folded apodization weights (float2), may be null
     const void *apix;                   // optional I x N apodization (data precision; real if apix_real), may be null
     int32_t apix_real;
+    int32_t gen_kind;                   // generated pixel x receiver apodization (QDAS_RXAPOD_*), exclusive with apix
+    double gen_p0, gen_p1;
+    const float *rxn;                   // 3 x N element normals (device)
     uint64_t T, N, M, I1, I2, I3;
     uint64_t i_begin, i_count;
     uint64_t strN, strM;                // trace strides of x in samples: (T, T*N) or (T*M, T) when transposed

@@ -57,7 +57,7 @@ def _default_prec(x) -> str:
 
 def parse_options(x, varargin: Sequence[Any]) -> dict:
     o = dict(VS=True, DV=False, interp="linear", apod=[], prec=_default_prec(x), device=-1,
-             fmod=0.0, tpose=False)
+             fmod=0.0, tpose=False, rx_apod=None)
     n = 0
     nargs = len(varargin)
 
@@ -92,6 +92,8 @@ def parse_options(x, varargin: Sequence[Any]) -> dict:
             o["fmod"] = float(val())
         elif key == "transpose":
             o["tpose"] = bool(val())
+        elif key == "rx-apod":                      # extension: generated in the kernel (qups_amd.apodization.rx_apod_spec)
+            o["rx_apod"] = val()
         else:
             raise DasError("Unrecognized option")
         n += 1
@@ -180,6 +182,7 @@ class DasProblem:
     tpose: bool
     interp: str
     osize: tuple = field(default=(1, 1))
+    rx_apod: dict | None = None     # generated receive apodization: {'kind', 'p', 'normals' (3 x N, real(prec)) | None}
 
     @property
     def I(self) -> int:
@@ -300,11 +303,22 @@ def build_problem(fun, Pi, Pr, Pv, Nv, xshape, t0, fs, c, opts: dict) -> DasProb
     # src/UltrasoundSystem.m:3357; here the array is returned with the shape it actually has.)
     osize = {"DAS": (1, 1), "SYN": (N, 1), "MUL": (1, M), "BF": (M, N) if tpose else (N, M), "delays": (N, M)}[fun]
     col = lambda A: np.ascontiguousarray(A.reshape(-1, order="F").astype(rt))
+    rxa = opts.get("rx_apod")
+    if rxa is not None:
+        if not isinstance(rxa, dict) or "kind" not in rxa:
+            raise DasError("'rx-apod' expects the dict returned by qups_amd.apodization.rx_apod_spec")
+        nrm = rxa.get("normals")
+        if nrm is not None:
+            nrm = np.asarray(nrm, dtype=np.float64).reshape(3, -1)
+            if nrm.shape[1] != N:
+                raise DasError(f"'rx-apod': expected 3 x {N} element normals, got {nrm.shape}")
+            nrm = col(nrm)
+        rxa = dict(kind=int(rxa["kind"]), p=tuple(float(v) for v in rxa.get("p", (0.0, 0.0))), normals=nrm)
     return DasProblem(fun=fun, prec=prec, flag=int(flag), VS=bool(opts["VS"]), DV=bool(opts["DV"]), Isz=Isz,
                       T=T, N=N, M=M, fsz=tuple(fsz), fs=fs, fmod=float(opts["fmod"]),
                       Pi=col(Pi), Pr=col(Pr), Pv=col(Pv4), Nv=col(Nv), cinv=col(cinv),
                       apod=flat, apod_real=apod_real, acstride=np.asarray(table, dtype=np.uint64),
-                      S=len(apods), tpose=tpose, interp=interp, osize=osize)
+                      S=len(apods), tpose=tpose, interp=interp, osize=osize, rx_apod=rxa)
 
 
 # ------------------------------------------------------------------------------------------
@@ -372,6 +386,11 @@ class DasPlan:
         d.mem, d.apod_real, d.kernel = _lib.MEM_DEVICE, int(prob.apod_real), int(kernel)
         d.device = dev.index if dev.index is not None else torch.cuda.current_device()
         d.i_begin, d.i_count, d.y_ld = self.i_begin, self.i_count, 0
+        if prob.rx_apod is not None:                       # generated receive apodization (qdas.h QDAS_RXAPOD_*)
+            d.rx_apod_kind = prob.rx_apod["kind"]
+            d.rx_apod_p[0], d.rx_apod_p[1] = prob.rx_apod["p"]
+            self._bufs.append(up(prob.rx_apod["normals"]))
+            d.rx_normals = ptr(self._bufs[-1])
         self._desc = d
         self._h = C.c_void_p()
         with torch.cuda.device(dev):

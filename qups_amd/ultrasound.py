@@ -101,8 +101,29 @@ class UltrasoundSystem:
             return G.sequence_args(t, focus=self.seq.focus, tx_offset=self.tx.offset)
         raise DasError(f"Unknown sequence type {t!r}.")
 
+    # ---- receive-apodization generators (reference src/UltrasoundSystem.m:5165-5267, 5303-5429)
+    def apAcceptanceAngle(self, theta=45.0):
+        """materialised ``I1 x I2 x I3 x N x 1`` mask, reference ``:5303-5374``"""
+        from . import apodization as A
+        return A.ap_acceptance_angle(self.scan.positions(), self.rx.positions(), self.rx.normals, theta)
+
+    def apCosineAngle(self, theta=45.0):
+        """reference ``:5377-5429``"""
+        from . import apodization as A
+        return A.ap_cosine_angle(self.scan.positions(), self.rx.positions(), self.rx.normals, theta)
+
+    def apApertureGrowth(self, f=1.5, Dmax=np.inf):
+        """reference ``:5165-5267``"""
+        from . import apodization as A
+        return A.ap_aperture_growth(self.scan.positions(), self.rx.positions(), self.rx.normals, f, Dmax)
+
+    def rx_apod(self, kind, **kw):
+        """the same rules, GENERATED inside the beamforming kernel: ``us.DAS(chd, rx_apod=us.rx_apod('acceptance', theta=30))``"""
+        from . import apodization as A
+        return A.rx_apod_spec(kind, normals=self.rx.normals, **kw)
+
     def DAS(self, chd: ChannelData, *apods, c0=None, fmod=0.0, prec="single", device=-1, apod=1, interp="cubic",
-            keep_tx=False, keep_rx=False, return_plan=False, kernel=0):
+            keep_tx=False, keep_rx=False, return_plan=False, kernel=0, rx_apod=None):
         """``b = DAS(us, chd, A1, ..., 'c0', c0, 'fmod', fc, 'interp', method, 'prec', type, 'keep_tx', tf, 'keep_rx', tf)``
 
         reference ``src/UltrasoundSystem.m:3172-3372``.  Output ``I1 x I2 x I3 x F... x [N] x [M]`` (``:3361``).
@@ -118,6 +139,8 @@ class UltrasoundSystem:
         ext = ["device", device, "input-precision", prec, "transpose", chd.order == "TMN", "interp", interp, "modulation", fmod]   # :3336-3338
         for a in apods:
             ext += ["apod", a]
+        if rx_apod is not None:
+            ext += ["rx-apod", rx_apod]
         out = das_spec(fun, self.scan.positions(), self.rx.positions(), Pv, Nv, chd.data, chd.t0, chd.fs, c0, *ext, *opt,
                        return_plan=return_plan, kernel=kernel)
         b, plan = out if return_plan else (out, None)
