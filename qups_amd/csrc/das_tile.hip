@@ -479,11 +479,11 @@ das_tile_kernel(const TileParams P) {
     };
 
     // ---- per-(pixel, receiver) apodization (optional; uniform runtime switch, nothing of it in the pair loop)
-    const bool wpix = P.apix != nullptr || P.gen_kind != 0;   // weights from an I x N array, or generated from the geometry
+    const bool wpix = !SYM && (P.apix != nullptr || P.gen_kind != 0);   // weights from an I x N array, or generated from the geometry
     const uint64_t Itot = P.I1 * P.I2 * P.I3;
     const uint64_t ipc = (i1 < P.I1 ? i1 : P.I1 - 1) + P.I1 * (col < ncols ? col : ncols - 1);   // my (clamped) pixel
     auto wload = [&](uint32_t n) -> v2f {
-        if (P.gen_kind) {                                 // qdas.h QDAS_RXAPOD_*: element from the LDS record, normal by scalar loads
+        if (!SYM && P.gen_kind) {                         // qdas.h QDAS_RXAPOD_*: element from the LDS record, normal by scalar loads (never in reciprocal mode)
             const float4 e = nrec[n];
             const float nx = P.rxn ? P.rxn[3 * n] : 0.f, ny = P.rxn ? P.rxn[3 * n + 1] : 0.f, nz = P.rxn ? P.rxn[3 * n + 2] : 1.f;
             return (v2f){(float)rx_apod_weight(P.gen_kind, P.gen_p0, P.gen_p1, (double)px - (double)e.y, (double)py - (double)e.z,
