@@ -197,6 +197,36 @@ typedef struct qdas_lut_desc {
 int qdas_das_lut(const qdas_lut_desc *d, const void *x, void *y, void *stream);
 
 /* ---- misc */
+/* ---- Point-scatterer channel-data simulator: replaces the kernels greens / greensf
+ * (reference src/greens.cu:88-121, body :8-86) launched by UltrasoundSystem.greens
+ * (src/UltrasoundSystem.m:681-718: k.feval(x, ps, as, pn, pv, kn, sb, blocks, [t0k t0x fso fsr cinv R0], [E E], flagnum)).
+ *   y[s,n,m] = 1/fsr * sum_i sum_ne sum_me a_i * sample(x, fsr*(s - (cinv*(r1+r2) + t0 - s0)*fs)) / (max(r1,R0)*max(r2,R0))
+ * All pointers are DEVICE pointers; real = double (QDAS_F64) or float (QDAS_F32), complex = interleaved pairs.
+ * The reference's `sb` / `blocks` arguments (per-scatterer sample windows for culling) are not needed: the kernel
+ * derives the windows itself.  R0 == 0: no propagation loss (the reference's CPU branch, :797-803). */
+typedef struct qdas_greens_desc {
+    uint64_t S;            /* output samples per trace                          (QUPS_S) */
+    uint64_t T;            /* samples of the waveform x                          (QUPS_T) */
+    uint64_t N, M, I;      /* receivers, transmitters, scatterers                         */
+    int32_t  En, Em;       /* sub-apertures per receive / transmit element       (E)      */
+    int32_t  interp;       /* QDAS_INTERP_*                                      (iflag)  */
+    int32_t  dtype;        /* QDAS_F64 | QDAS_F32                                         */
+    double   s0;           /* time of output sample 0 [s]                        (t0k)    */
+    double   t0;           /* time of waveform sample 0 [s]                      (t0x)    */
+    double   fs;           /* output sampling frequency [Hz]                     (fso)    */
+    double   fsr;          /* waveform sampling frequency / fs                            */
+    double   cinv;         /* 1 / sound speed                                             */
+    double   R0;           /* minimum distance of the 1/(r1 r2) loss; 0 = no loss         */
+    const void *Ps;        /* 3 x I   scatterer positions, real                           */
+    const void *a;         /* I       scatterer amplitudes, complex                       */
+    const void *Pr;        /* 3 x N x En receive (sub-)element positions, real            */
+    const void *Pv;        /* 3 x M x Em transmit (sub-)element positions, real           */
+    const void *x;         /* T       waveform samples, complex                           */
+    int32_t  device;       /* HIP device ordinal, -1 = current                            */
+    int32_t  reserved;
+} qdas_greens_desc;
+int qdas_greens(const qdas_greens_desc *desc, void *y /* S x N x M complex */, void *stream);
+
 const char *qdas_last_error(void);
 int  qdas_version(void);
 /* device properties the host side reports next to measurements */

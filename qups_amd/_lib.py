@@ -27,7 +27,7 @@ SYMBOLS = (
     "qdas_plan_create", "qdas_plan_execute", "qdas_plan_execute_frames", "qdas_plan_delays",
     "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_set_timing",
     "qdas_plan_last_kernel_ms", "qdas_DAS", "qdas_DASf", "qdas_DASh", "qdas_delays", "qdas_delaysf",
-    "qdas_das_lut", "qdas_last_error", "qdas_version", "qdas_device_info",
+    "qdas_das_lut", "qdas_greens", "qdas_last_error", "qdas_version", "qdas_device_info",
 )
 
 
@@ -52,6 +52,14 @@ class LutDesc(C.Structure):
                 ("flag", C.c_int32), ("dtype", C.c_int32), ("omega", C.c_double),
                 ("tau_rx", C.c_void_p), ("tau_tx", C.c_void_p), ("w", C.c_void_p),
                 ("wstride", C.c_uint64 * 3), ("w_real", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GreensDesc(C.Structure):
+    _fields_ = [("S", C.c_uint64), ("T", C.c_uint64), ("N", C.c_uint64), ("M", C.c_uint64), ("I", C.c_uint64),
+                ("En", C.c_int32), ("Em", C.c_int32), ("interp", C.c_int32), ("dtype", C.c_int32),
+                ("s0", C.c_double), ("t0", C.c_double), ("fs", C.c_double), ("fsr", C.c_double), ("cinv", C.c_double),
+                ("R0", C.c_double), ("Ps", C.c_void_p), ("a", C.c_void_p), ("Pr", C.c_void_p), ("Pv", C.c_void_p),
+                ("x", C.c_void_p), ("device", C.c_int32), ("reserved", C.c_int32)]
 
 
 class QdasError(RuntimeError):
@@ -94,6 +102,7 @@ def lib():
     L.qdas_plan_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.qdas_plan_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.qdas_das_lut.argtypes = [C.POINTER(LutDesc), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.qdas_greens.argtypes = [C.POINTER(GreensDesc), C.c_void_p, C.c_void_p]
     L.qdas_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_uint64)]
     vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)

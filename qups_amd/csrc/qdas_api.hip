@@ -672,3 +672,27 @@ extern "C" int qdas_das_lut(const qdas_lut_desc *d, const void *x, void *y, void
     HIPCHK(launch_lut(p, d->dtype, s));
     return QDAS_OK;
 }
+
+extern "C" int qdas_greens(const qdas_greens_desc *d, void *y, void *stream) {
+    if (!d || !y) return fail(QDAS_EINVAL, "null argument");
+    if (d->dtype != QDAS_F64 && d->dtype != QDAS_F32) return fail(QDAS_EINVAL, "greens: datatype must be double or single");
+    if (d->interp < 0 || d->interp > 5) return fail(QDAS_EINVAL, "Interp option not recognized: %d", d->interp);
+    if (d->En < 1 || d->Em < 1) return fail(QDAS_EINVAL, "greens: element subdivisions must be >= 1");
+    if (!(d->fs > 0) || !(d->fsr > 0) || !(d->R0 >= 0)) return fail(QDAS_EINVAL, "greens: fs, fsr must be positive and R0 non-negative");
+    if (d->N > 65535 || d->M > 65535) return fail(QDAS_EUNSUPPORTED, "greens: at most 65535 receivers / transmitters");
+    hipStream_t s = (hipStream_t)stream;
+    if (d->device >= 0) HIPCHK(hipSetDevice(d->device));
+    if (d->S == 0 || d->N == 0 || d->M == 0) return QDAS_OK;
+    if (d->I == 0 || d->T == 0) {
+        HIPCHK(hipMemsetAsync(y, 0, d->S * d->N * d->M * data_size(d->dtype), s));
+        return QDAS_OK;
+    }
+    if (!d->Ps || !d->a || !d->Pr || !d->Pv || !d->x) return fail(QDAS_EINVAL, "null scatterer / element / waveform pointer");
+    GreensParams p{};
+    p.Ps = d->Ps; p.a = d->a; p.Pr = d->Pr; p.Pv = d->Pv; p.x = d->x; p.y = y;
+    p.S = d->S; p.T = d->T; p.N = d->N; p.M = d->M; p.I = d->I;
+    p.En = d->En; p.Em = d->Em; p.interp = d->interp;
+    p.s0 = d->s0; p.t0 = d->t0; p.fs = d->fs; p.fsr = d->fsr; p.cinv = d->cinv; p.R0 = d->R0;
+    HIPCHK(launch_greens(p, d->dtype, s));
+    return QDAS_OK;
+}

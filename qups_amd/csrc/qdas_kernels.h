@@ -77,4 +77,14 @@ struct LutParams {
 };
 hipError_t launch_lut(const LutParams &P, int dtype, hipStream_t s);
 
+// ---- point-scatterer simulator (greens.hip)
+struct GreensParams {
+    const void *Ps, *a, *Pr, *Pv, *x;
+    void *y;
+    uint64_t S, T, N, M, I;
+    int32_t En, Em, interp, x_in_lds;
+    double s0, t0, fs, fsr, cinv, R0;
+};
+hipError_t launch_greens(const GreensParams &P, int dtype, hipStream_t s);
+
 }  // namespace qdas

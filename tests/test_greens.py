@@ -1,0 +1,98 @@
+"""Point-scatterer simulator: oracle properties on the CPU; HIP kernel vs oracle and the reference's own
+integration criterion (test/BFTest.m:306-316: the beamformed image of greens() data peaks within 1.1 mm of the scatterer) on the GPU."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from qups_amd import geometry as G
+
+
+def _pulse(fc, fsk, ncyc=2.5):
+    t = np.arange(-ncyc / fc, ncyc / fc + 0.5 / fsk, 1.0 / fsk)
+    return (np.exp(-(t * fc * 1.2) ** 2) * np.exp(2j * np.pi * fc * t)).astype(np.complex64), float(t[0])
+
+
+def _setup(seed=0, N=8, M=6, I=5, En=1, Em=1, fsr=2.0):
+    r = np.random.default_rng(seed)
+    fc, c0 = 5e6, 1540.0
+    fs = 4 * fc
+    Pr = G.linear_array(N, 0.3e-3)[0]
+    Pv = G.linear_array(M, 0.4e-3)[0]
+    if En > 1:
+        Pr = np.stack([Pr + np.array([[dx], [0], [0]]) for dx in np.linspace(-0.1e-3, 0.1e-3, En)], axis=2)
+    if Em > 1:
+        Pv = np.stack([Pv + np.array([[dx], [0], [0]]) for dx in np.linspace(-0.12e-3, 0.12e-3, Em)], axis=2)
+    Ps = np.stack([r.uniform(-3e-3, 3e-3, I), np.zeros(I), r.uniform(5e-3, 12e-3, I)])
+    a = (r.uniform(0.5, 1.5, I) * np.exp(2j * np.pi * r.uniform(0, 1, I))).astype(np.complex64)
+    x, t0x = _pulse(fc, fsr * fs)
+    f32 = lambda v: np.asarray(v, np.float32).astype(np.float64)
+    return dict(Ps=f32(Ps), a=a, Pr=f32(Pr), Pv=f32(Pv), x=x, S=700, s0=float(np.float32(4e-6)), t0=float(np.float32(t0x)),
+                fs=float(np.float32(fs)), fsr=fsr, cinv=float(np.float32(1 / c0)), R0=float(np.float32(0.3e-3)), c0=c0, fc=fc)
+
+
+def test_oracle_single_scatterer_arrives_on_time_and_is_linear():
+    from oracle import greens_oracle as GO
+    g = _setup(I=1)
+    y = GO.greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], g["x"], g["S"], g["s0"], g["t0"], g["fs"], g["fsr"], g["cinv"], g["R0"], "cubic")
+    assert y.shape == (700, 8, 6)
+    for n, m in ((0, 0), (3, 5), (7, 2)):
+        tof = (np.linalg.norm(g["Ps"][:, 0] - g["Pr"][:, n]) + np.linalg.norm(g["Ps"][:, 0] - g["Pv"][:, m])) * g["cinv"]
+        peak = np.argmax(np.abs(y[:, n, m])) / g["fs"] + g["s0"]
+        assert abs(peak - tof) <= 1.0 / g["fs"]                       # the envelope peaks at the two-way time of flight
+    g2 = _setup(I=4, seed=3)
+    ya = GO.greens_kernel(g2["Ps"], g2["a"], g2["Pr"], g2["Pv"], g2["x"], g2["S"], g2["s0"], g2["t0"], g2["fs"], g2["fsr"], g2["cinv"], g2["R0"], "linear")
+    yb = sum(GO.greens_kernel(g2["Ps"][:, [i]], g2["a"][[i]], g2["Pr"], g2["Pv"], g2["x"], g2["S"], g2["s0"], g2["t0"], g2["fs"], g2["fsr"],
+                              g2["cinv"], g2["R0"], "linear") for i in range(4))
+    assert np.abs(ya - yb).max() <= 1e-12 * np.abs(ya).max()
+    # R0 = 0: no propagation loss (the reference's CPU branch)
+    y0 = GO.greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], g["x"], g["S"], g["s0"], g["t0"], g["fs"], g["fsr"], g["cinv"], 0.0, "cubic")
+    assert abs(np.abs(y0).max() - abs(g["a"][0]) / g["fsr"]) <= 0.02 * abs(g["a"][0]) / g["fsr"]     # unit-peak pulse, no 1/(r1 r2)
+    assert np.abs(y).max() > 100 * np.abs(y0).max()                    # with loss: / (r1 r2), r ~ 1e-2 m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3"])
+@pytest.mark.parametrize("prec,En,Em,fsr,R0", [("single", 1, 1, 2.0, None), ("single", 2, 3, 1.0, None), ("double", 1, 2, 4.0, None),
+                                                ("single", 1, 1, 2.0, 0.0)])
+def test_greens_kernel_matches_oracle(interp, prec, En, Em, fsr, R0):
+    import torch
+    from oracle import greens_oracle as GO
+    from qups_amd.greens import greens_kernel
+    g = _setup(seed=5, N=9, M=7, I=300 if En == 1 else 40, En=En, Em=Em, fsr=fsr)     # > one 256-entry pass
+    R0 = g["R0"] if R0 is None else R0
+    ref = GO.greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], g["x"], g["S"], g["s0"], g["t0"], g["fs"], fsr, g["cinv"], R0, interp)
+    y = greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], g["x"], g["S"], g["s0"], g["t0"], g["fs"], fsr, g["cinv"], R0, interp, prec)
+    torch.cuda.synchronize()
+    out = y.cpu().numpy()
+    assert out.shape == ref.shape
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    if interp == "nearest" and prec == "single":
+        bad = np.abs(out - ref) / np.abs(ref).max() > 1e-4
+        assert bad.mean() < 0.02                                        # an fp32 delay on a rounding boundary picks the neighbour
+    else:
+        assert err <= (1e-10 if prec == "double" else 3e-4), err
+
+
+@pytest.mark.gpu
+def test_greens_then_das_peaks_at_the_scatterer():
+    """the reference's integration criterion (test/BFTest.m:306-316)"""
+    import torch
+    from qups_amd import das_spec
+    from qups_amd.greens import greens
+    fc, c0 = 5e6, 1500.0
+    fs = 4 * fc
+    Pr, nrm = G.linear_array(32, 0.3e-3)
+    scat = np.array([[2e-3], [0.0], [15e-3]])                          # test/BFTest.m:28
+    wv, t0w = _pulse(fc, 4 * fs)
+    y, t0 = greens(Pr, Pr, scat, [1.0], c0, wv, t0w, 4 * fs, fs, R0=c0 / fc, interp="cubic")
+    x = np.linspace(-4e-3, 8e-3, 97)
+    z = np.linspace(9e-3, 21e-3, 97)
+    Pi = G.scan_cartesian(x, z)
+    Pv, Nv, opt = G.sequence_args("FSA", tx_pos=Pr, tx_normals=nrm)
+    b = das_spec("DAS", Pi, Pr, Pv, Nv, y.contiguous(), t0, fs, c0, *opt, "interp", "cubic")
+    torch.cuda.synchronize()
+    img = np.abs(b.cpu().numpy())[:, :, 0, 0, 0]
+    assert img.max() > 0
+    iz, ix = np.unravel_index(np.argmax(img), img.shape)
+    assert abs(x[ix] - 2e-3) <= 1.1e-3 and abs(z[iz] - 15e-3) <= 1.1e-3
