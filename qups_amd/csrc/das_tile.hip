@@ -259,11 +259,13 @@ das_tile_kernel(const TileParams P) {
     const uint64_t i1 = ((uint64_t)tz << tzl) + (wave_z << wzl) + (uint32_t)(lane & ((1 << wzl) - 1));
     const uint64_t col = (uint64_t)txi * ((uint32_t)(TX * 64) >> tzl) + (wave_c << (6 - wzl)) + (uint32_t)(lane >> wzl);
     float px, py, pz;                                 // widened to fp64 where they are used
+    const double fs = P.fs;
+    double cf = P.cinv_fs;                            // samples per metre: scalar sound speed, or this pixel's entry of a sound-speed map
     {
         const uint64_t i = (i1 < P.I1 ? i1 : P.I1 - 1) + P.I1 * (col < ncols ? col : ncols - 1);
         px = P.Pi[3 * i]; py = P.Pi[3 * i + 1]; pz = P.Pi[3 * i + 2];
+        if (P.cinv_pix) cf = (double)P.cinv_pix[i] * fs;
     }
-    const double cf = P.cinv_fs, fs = P.fs;
     const bool VS = P.VS, DV = P.DV;
 
     // sqrt in fp64 from an fp32 seed + one Newton step (rel. error ~1e-14; v_sqrt_f32 is 1 ulp)

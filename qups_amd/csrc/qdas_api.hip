@@ -306,7 +306,12 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // ---- kernel selection
     bool eligible = (dt == QDAS_F32 || dt == QDAS_F16) && !(z.flag & (QDAS_FLAG_KEEP_RX | QDAS_FLAG_KEEP_TX));
     const char *why = "tiled kernel needs fp32/fp16 data and the 'DAS' (sum both apertures) mode";
-    for (int k = 0; k < 5 && eligible; ++k) if (g.cst[k]) { eligible = false; why = "tiled kernel needs a scalar sound speed"; }
+    // sound speed: a scalar, or a full per-pixel map (contiguous I1 x I2 x I3, no aperture dependence): the delay stays separable
+    bool cmap = false;
+    if (eligible && (g.cst[0] || g.cst[1] || g.cst[2] || g.cst[3] || g.cst[4])) {
+        cmap = !g.cst[3] && !g.cst[4] && (g.cst[0] == 1 || z.I1 == 1) && (g.cst[1] == z.I1 || z.I2 == 1) && (g.cst[2] == z.I1 * z.I2 || z.I3 == 1);
+        if (!cmap) { eligible = false; why = "tiled kernel needs a scalar sound speed or a full per-pixel map without aperture dependence"; }
+    }
     // apodization arrays: pixel-independent ones fold into an N x M table; ONE array may be a full I1 x I2 x I3 x [N] array
     // (contiguous pixel strides, no transmit dependence) -- it is applied per (pixel, receiver) by the tiled kernel
     int pix_arr = -1;
@@ -369,6 +374,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if ((rc = fetch_host(desc->cinv, sizeof(float), desc->mem, &cinv0))) return bail(rc);
         t.fs = g.fs; t.fmod = g.fmod;
         t.cinv_fs = (double)cinv0 * g.fs;
+        t.cinv_pix = cmap ? (const float *)g.cinv + g.cst[5] : nullptr;
         t.flag = z.flag; t.VS = z.VS; t.DV = z.DV; t.sym = sym;
         // tile grid: (1 << tz_log2) pixels of I1 x tile_cols columns (columns = I2*I3 flattened); the footprint is chosen below
         auto set_grid = [&](int tzl) {

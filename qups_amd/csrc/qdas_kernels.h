@@ -46,7 +46,8 @@ struct TileParams {
     uint64_t T, N, M, I1, I2, I3;
     uint64_t i_begin, i_count;
     uint64_t strN, strM;                // trace strides of x in samples: (T, T*N) or (T*M, T) when transposed
-    double cinv_fs;                     // cinv * fs
+    double cinv_fs;                     // cinv * fs (scalar sound speed; first pixel's value when cinv_pix is set)
+    const float *cinv_pix;              // optional per-pixel 1/c (I1 x I2 x I3, contiguous): sound-speed map; the delay stays separable
     double fs, fmod;
     int32_t flag, VS, DV;
     int32_t sym;                        // reciprocal mode: Pv == Pr, one t0 (checked by the host) -> tau(n,m) == tau(m,n)

@@ -185,9 +185,33 @@ def test_nd_sound_speed():
     from oracle import das_oracle as O
     ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"],
                      1.0 / f32r(1.0 / cmap), VS=case["VS"], DV=case["DV"], interp="linear")
-    out, plan = run_das(case, c=cmap)
+    out, plan = run_das(case, c=cmap, kernel=1)
     assert plan.kernel == "generic"
     assert rel_err(out, ref) <= TOL32
+    # the tiled kernel takes per-pixel maps too (the delay stays separable); white-noise speeds give tiles whose delay spread
+    # exceeds the LDS window: those are redone by the generic kernel -- same image
+    out, plan = run_das(case, c=cmap)
+    assert plan.kernel == "tiled"
+    assert rel_err(out, ref) <= TOL32
+
+
+@pytest.mark.parametrize("seq,prec", [("FSA", "single"), ("PW", "single"), ("DV", "halfT")])
+def test_sound_speed_map_in_the_tiled_kernel(seq, prec):
+    """a smooth I1 x I2 sound-speed map (aberration correction): fused kernel, no fallback, reciprocal mode included"""
+    case = make_case(seq=seq, interp="cubic", seed=17, N=16, I1=140, I2=24, zlim=(4e-3, 18e-3), xspan=4e-3)
+    zz, xx = np.meshgrid(np.linspace(0, 1, 140), np.linspace(0, 1, 24), indexing="ij")
+    cmap = f32r(1.0 / f32r(1.0 / (1540.0 + 25.0 * np.sin(2.1 * zz + 0.4) * np.cos(1.7 * xx))))[:, :, None]
+    xq = case["x"]
+    if prec == "halfT":
+        xq = xq.real.astype(np.float16).astype(np.float64) + 1j * xq.imag.astype(np.float16).astype(np.float64)
+    from oracle import das_oracle as O
+    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xq, case["t0"], case["fs"],
+                     1.0 / f32r(1.0 / cmap), VS=case["VS"], DV=case["DV"], interp="cubic")
+    out, plan = run_das(case, c=cmap, prec=prec, kernel=2)
+    assert plan.kernel == "tiled" and plan.fallback_tiles() == 0
+    assert rel_err(out, ref) <= (2e-3 if prec == "halfT" else 2e-5)
+    gen, _ = run_das(case, c=cmap, prec=prec, kernel=1)
+    assert rel_err(gen, ref) <= (2e-3 if prec == "halfT" else TOL32)
 
 
 def test_double_precision():
