@@ -1,0 +1,116 @@
+"""Edge cases of the DAS path on the GPU: empty problems, 3-D scans over a matrix array, non-finite geometry, very short
+records, apertures too large for the LDS header, frames = 0 -- through the C ABI (ctypes) like every GPU test."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.cases import cinv_f32, make_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(case, **kw):
+    from oracle import das_oracle as O
+    return O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"], cinv_f32(case["c"]),
+                      VS=case["VS"], DV=case["DV"], interp=case["interp"], **kw)
+
+
+def _run(case, kernel=0, **kw):
+    import torch
+    from qups_amd import das_spec
+    y, plan = das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], torch.from_numpy(case["x"]), case["t0"], case["fs"],
+                       case["c"], *case["opt"], "interp", case["interp"], return_plan=True, kernel=kernel, **kw)
+    torch.cuda.synchronize()
+    return y.cpu().numpy(), plan
+
+
+def test_empty_problems_through_the_c_abi():
+    """I = 0 writes nothing; N = 0 or M = 0 or T = 0 (an empty sum) zero-fills; F = 0 is a no-op"""
+    import torch
+    from qups_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+    Pi, Pr, Pv, Nv, cinv = z(3, 6), z(3, 4), z(4, 3), z(3, 3), torch.full((1,), 1 / 1540, dtype=torch.float32, device=dev)
+    acs = (C.c_uint64 * 6)(0, 0, 0, 0, 0, 0)
+    for (T, N, M, I1) in ((16, 4, 3, 0), (16, 0, 3, 6), (16, 4, 0, 6), (0, 4, 3, 6)):
+        d = _lib.Desc()
+        d.sz = _lib.Sizes(T, N, M, I1, 1, 1, 0, 1, 1, 1, _lib.QDAS_F32)
+        d.fs = 20e6
+        d.Pi, d.Pr, d.Pv, d.Nv, d.cinv = (C.c_void_p(t.data_ptr()) for t in (Pi, Pr, Pv, Nv, cinv))
+        d.acstride, d.mem, d.device = acs, _lib.MEM_DEVICE, 0
+        h = C.c_void_p()
+        _lib.check(L.qdas_plan_create(C.byref(h), C.byref(d)))
+        x = torch.ones((max(T * N * M, 1), 2), dtype=torch.float32, device=dev)
+        y = torch.full((max(I1, 1), 2), 7.0, dtype=torch.float32, device=dev)
+        _lib.check(L.qdas_plan_execute(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), None))
+        _lib.check(L.qdas_plan_execute_frames(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), 0, 0, 0, None))
+        torch.cuda.synchronize()
+        assert float(y.abs().max()) == (7.0 if I1 == 0 else 0.0), (T, N, M, I1)
+        L.qdas_plan_destroy(h)
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_volume_scan_over_a_matrix_array(kernel):
+    """I3 > 1 and elements / pixels with y != 0 (matrix probe, 3-D scan)"""
+    import torch
+    from qups_amd import das_spec
+    from oracle import das_oracle as O
+    r = np.random.default_rng(7)
+    fc, c0 = 5e6, 1540.0
+    fs = 4 * fc
+    ex, ey = np.meshgrid((np.arange(4) - 1.5) * 0.3e-3, (np.arange(4) - 1.5) * 0.3e-3, indexing="ij")
+    Pr = np.stack([ex.ravel(), ey.ravel(), 0 * ex.ravel()])
+    z = 5e-3 + np.arange(70) * 0.08e-3
+    xs = np.linspace(-1e-3, 1e-3, 9)
+    ys = np.linspace(-0.8e-3, 0.8e-3, 3)
+    Z, X, Y = np.meshgrid(z, xs, ys, indexing="ij")
+    Pi = np.stack([X, Y, Z])                                            # 3 x I1 x I2 x I3
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    Pi, Pr = f32(Pi), f32(Pr)
+    T = 420
+    x = (r.standard_normal((T, 16, 16)) + 1j * r.standard_normal((T, 16, 16))).astype(np.complex64)
+    Nv = np.tile(np.array([[0.0], [0.0], [1.0]]), (1, 16))
+    ref = O.das_spec("DAS", Pi, Pr, Pr, Nv, x, 0.0, float(np.float32(fs)), cinv_f32(float(np.float32(c0))), VS=True, DV=True, interp="cubic")
+    y, plan = das_spec("DAS", Pi, Pr, Pr, Nv, torch.from_numpy(x), 0.0, float(np.float32(fs)), float(np.float32(c0)),
+                       "virtual-source", "diverging-waves", "interp", "cubic", return_plan=True, kernel=kernel)
+    torch.cuda.synchronize()
+    assert tuple(y.shape)[:3] == (70, 9, 3) and np.abs(ref).max() > 0
+    assert rel_err(y.cpu().numpy(), ref) <= (1e-4 if kernel == 1 else 3e-5)
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_non_finite_pixels_give_exact_zeros(kernel):
+    """NaN / Inf pixel coordinates: that pixel is exactly 0 (non-finite delay -> out of support), its neighbours are untouched"""
+    case = make_case(seq="FSA", interp="linear", seed=51, N=16, I1=130, I2=18, zlim=(4e-3, 17e-3), xspan=3e-3)
+    ref = _oracle(case)
+    bad = [(5, 2), (64, 0), (129, 17), (77, 9)]
+    case["Pi"] = case["Pi"].copy()
+    for k, (a, b) in enumerate(bad):
+        case["Pi"][k % 3, a, b, 0] = np.nan if k % 2 == 0 else np.inf
+    out, plan = _run(case, kernel=kernel)
+    assert np.all(np.isfinite(out))
+    mask = np.zeros(out.shape[:2], bool)
+    for a, b in bad:
+        assert out[a, b].ravel()[0] == 0
+        mask[a, b] = True
+    assert rel_err(out[~mask], ref[~mask]) <= 1e-4
+
+
+def test_very_short_record_and_huge_aperture_route_to_the_generic_kernel():
+    from qups_amd import _lib
+    case = make_case(seq="PW", interp="cubic", seed=52, N=5, M=3, I1=20, I2=4, T=6, data="noise", zlim=(0.1e-3, 0.4e-3), t0=0.0)
+    out, plan = _run(case)
+    assert plan.kernel == "generic"                                     # T < 8: nothing to stage
+    assert rel_err(out, _oracle(case)) <= 1e-4 or np.abs(_oracle(case)).max() == 0
+    with pytest.raises(_lib.QdasError, match="T >= 8"):
+        _run(case, kernel=2)
+    big = make_case(seq="PW", interp="linear", seed=53, N=4000, M=2, I1=8, I2=2, data="noise", pitch=0.01e-3)
+    out, plan = _run(big)
+    assert plan.kernel == "generic"                                     # N + M receivers / transmits do not fit the LDS header
+    assert rel_err(out, _oracle(big)) <= 1e-4
+    with pytest.raises(_lib.QdasError, match="LDS header"):
+        _run(big, kernel=2)
