@@ -66,6 +66,7 @@ struct qdas_plan {
     TileParams tp{};
     TileConfig tc{};
     unsigned ntiles = 0, tile_cols = 0;
+    bool no_fallback = false;                 // the probe found no tile whose delay spread exceeds the LDS window
     uint32_t *fallback = nullptr;             // device: [0] = count, [1..ntiles]
     bool timing = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -244,6 +245,9 @@ static int choose_tile_shape(qdas_plan *pl, const qdas_desc *desc, F &&set_grid)
         }
     }
     if (best_t < 0) { best_t = env_tz ? lg(env_tz) : 6; best_w = best_t; }
+    // the window fit depends on the geometry only: a footprint without misfits never needs the per-frame fallback pass
+    pl->no_fallback = fbn[best_t] == 0.0;
+    HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));
     set_grid(best_t);
     t.wz_log2 = best_w;
     t.probe = 0;
@@ -502,11 +506,14 @@ extern "C" int qdas_plan_last_kernel_ms(const qdas_plan *pl, float *ms) {
     return QDAS_OK;
 }
 
+static int hip_rc(hipError_t e) { HIPCHK(e); return QDAS_OK; }
+
 static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s) {
     const qdas_sizes &z = pl->d.sz;
     if (pl->kernel == QDAS_KERNEL_TILED) {
         TileParams t = pl->tp;
         t.x = x; t.y = y;
+        if (pl->no_fallback) return hip_rc(launch_tile(t, z.dtype, pl->ntiles, s));     // one launch per frame (+ the reduce of a split aperture)
         HIPCHK(hipMemsetAsync(pl->fallback, 0, sizeof(uint32_t), s));
         HIPCHK(launch_tile(t, z.dtype, pl->ntiles, s));
         // tiles whose delay window overflowed LDS are redone by the generic kernel; the launch is
