@@ -112,6 +112,22 @@ template <int INTERP> __device__ __forceinline__ void weights2(v2f s, v2f w[4]) 
     }
 }
 
+// DPP wave reductions (VALU speed; the result is valid in lane 63 only): quad swaps, half-row / row mirrors, then the row
+// broadcasts of GFX9 (lane 15 -> next row, lane 31 -> rows 2-3).  __shfl_xor compiles to ds_bpermute_b32: six dependent
+// LDS-pipe round trips per reduction.
+template <int CTRL, int ROWMASK = 0xf> __device__ __forceinline__ float dppf(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWMASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_min63(float v) {
+    v = fminf(v, dppf<0xB1>(v)); v = fminf(v, dppf<0x4E>(v)); v = fminf(v, dppf<0x141>(v)); v = fminf(v, dppf<0x140>(v));
+    v = fminf(v, dppf<0x142, 0xa>(v)); v = fminf(v, dppf<0x143, 0xc>(v));
+    return v;
+}
+__device__ __forceinline__ float wave_max63(float v) {
+    v = fmaxf(v, dppf<0xB1>(v)); v = fmaxf(v, dppf<0x4E>(v)); v = fmaxf(v, dppf<0x141>(v)); v = fmaxf(v, dppf<0x140>(v));
+    v = fmaxf(v, dppf<0x142, 0xa>(v)); v = fmaxf(v, dppf<0x143, 0xc>(v));
+    return v;
+}
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
@@ -299,17 +315,31 @@ das_tile_kernel(const TileParams P) {
     // reciprocal mode: a(i,m) = b(i,m) + C with C = OFF - t0*fs, so A[m] := B[m] + floor(C) (filled below)
     const double symC = tapinfo<INTERP>::OFF - (double)P.Pv[3] * fs;
     const int symCi = (int)floor(symC);
-    // (four elements per pass: the 6-step cross-lane reductions are latency chains, independent chains overlap)
+    // The window bases / extents only need the delays to a small fraction of a sample: fp32 estimates with an explicit error
+    // margin (DLT, below) -- a quarter of the fp64 cost.  Focused transmits keep fp64: their delay flips sign with
+    // (Pi - Pv).Nv (copysign, src/bf.cu:107) and the two precisions must agree on the sign of a dot product that may be ~0.
+    const bool pro32 = !(VS && !DV);
+    const float cf32 = (float)cf, fs32 = (float)fs;
+    auto a_est = [&](uint32_t m) -> float {
+        if (!pro32) return (float)a_of(m);
+        const float rx = px - gPv[4 * m], ry = py - gPv[4 * m + 1], rz = pz - gPv[4 * m + 2];
+        const float d = VS ? __builtin_sqrtf(rx * rx + ry * ry + rz * rz) : rx * gNv[3 * m] + ry * gNv[3 * m + 1] + rz * gNv[3 * m + 2];
+        return d * cf32 - gPv[4 * m + 3] * fs32 + (float)tapinfo<INTERP>::OFF;
+    };
+    auto b_est = [&](uint32_t n) -> float {
+        const float rx = px - P.Pr[3 * n], ry = py - P.Pr[3 * n + 1], rz = pz - P.Pr[3 * n + 2];
+        return __builtin_sqrtf(rx * rx + ry * ry + rz * rz) * cf32;
+    };
+    // |fp32 estimate - fp64 delay| <= ~4e-7 * (|distance*cf| + |t0*fs|), and |distance*cf| <= |a| + |t0*fs| + 1: 1e-6 is generous
+    auto margin = [](float mn, float mx, float t0fs) -> float { return 1.0e-6f * (fmaxf(fabsf(mn), fabsf(mx)) + 2.0f * fabsf(t0fs) + 2.0f); };
+    // (four elements per pass: independent reduction chains overlap)
     auto minmax4 = [&](float (&v)[4], uint32_t e0, uint32_t cnt) {
         float lo[4], hi[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { lo[q] = hi[q] = (v[q] == v[q]) ? v[q] : INFINITY; }   // a NaN delay poisons the tile's extent
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { lo[q] = fminf(lo[q], __shfl_xor(lo[q], o)); hi[q] = fmaxf(hi[q], __shfl_xor(hi[q], o)); }
-        }
-        if (lane == 0) {
+        for (int q = 0; q < 4; ++q) { lo[q] = wave_min63(lo[q]); hi[q] = wave_max63(hi[q]); }
+        if (lane == 63) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (e0 + q < cnt) { part[wave * MX + e0 + q] = lo[q]; part[(WAVES + wave) * MX + e0 + q] = hi[q]; }
         }
@@ -318,7 +348,7 @@ das_tile_kernel(const TileParams P) {
         for (uint32_t m = 0; m < M; m += 4) {
             float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = (float)a_of(m + q < M ? m + q : M - 1);
+            for (int q = 0; q < 4; ++q) v[q] = a_est(m + q < M ? m + q : M - 1);
             minmax4(v, m, M);
         }
         __syncthreads();
@@ -326,9 +356,10 @@ das_tile_kernel(const TileParams P) {
             float mn = part[m], mx = part[WAVES * MX + m];
 #pragma unroll
             for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + m]); mx = fmaxf(mx, part[(WAVES + w) * MX + m]); }
-            const float fl = floorf(mn) - 1.0f;              // margin: (float)a may have rounded up
+            const float dlt = margin(mn, mx, P.Pv[4 * m + 3] * fs32);
+            const float fl = floorf(mn - dlt) - 1.0f;        // margin: the estimate may lie above the true minimum
             const bool fin = fabsf(fl) < 1.0e9f;
-            const float e = fin ? (mx - fl) + 0.01f : INFINITY;
+            const float e = fin ? ((mx + dlt) - fl) + 0.01f : INFINITY;
             Abase[m] = fin ? (int)fl : 0;
             Aext[m] = e;
             a_lo = fminf(a_lo, fl); a_hi = fmaxf(a_hi, fl + e); a_ext = fmaxf(a_ext, e);
@@ -338,7 +369,7 @@ das_tile_kernel(const TileParams P) {
     for (uint32_t n = 0; n < N; n += 4) {
         float v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = (float)b_of(n + q < N ? n + q : N - 1);
+        for (int q = 0; q < 4; ++q) v[q] = b_est(n + q < N ? n + q : N - 1);
         minmax4(v, n, N);
     }
     __syncthreads();
@@ -347,9 +378,10 @@ das_tile_kernel(const TileParams P) {
         float mn = part[n], mx = part[WAVES * MX + n];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + n]); mx = fmaxf(mx, part[(WAVES + w) * MX + n]); }
-        const float fl = floorf(mn) - 1.0f;
+        const float dlt = margin(mn, mx, SYM ? P.Pv[3] * fs32 : 0.f);
+        const float fl = floorf(mn - dlt) - 1.0f;
         const bool fin = fabsf(fl) < 1.0e9f;
-        const float e = fin ? (mx - fl) + 0.01f : INFINITY;
+        const float e = fin ? ((mx + dlt) - fl) + 0.01f : INFINITY;
         nrec[n] = make_float4(__int_as_float(fin ? (int)fl : 0), P.Pr[3 * n], P.Pr[3 * n + 1], P.Pr[3 * n + 2]);
         Bext[n] = e;
         b_lo = fminf(b_lo, fl); b_hi = fmaxf(b_hi, fl + e); b_ext = fmaxf(b_ext, e);
