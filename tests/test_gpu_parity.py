@@ -474,3 +474,18 @@ def test_aperture_split(ks, seq, N, prec, mask, monkeypatch):
     # deterministic: a second run is bit-identical
     out2, _ = run_das(case, kernel=2, prec=prec, apod=apod)
     assert np.array_equal(out, out2)
+
+
+@pytest.mark.parametrize("seq", ["FSA", "PW", "FC"])
+def test_large_time_offset(seq):
+    """t0 = -100 us (2000 samples at 20 MHz): the fp32 window-base estimates of the tiled kernel's prologue cancel two large
+    numbers; their error margin must still cover the fp64 delays (no fallback, same image)"""
+    case = make_case(seq=seq, interp="lanczos3", seed=61, N=16, I1=150, I2=20, zlim=(4e-3, 16e-3), xspan=3e-3, t0=float(np.float32(-1.0e-4)))
+    assert case["T"] > 2000
+    ref = run_oracle(case)
+    out, plan = run_das(case, kernel=2)
+    assert plan.kernel == "tiled"
+    if seq == "FC":
+        assert plan.fallback_tiles() <= 4 and rel_err(out, ref) <= TOL32
+    else:
+        assert plan.fallback_tiles() == 0 and rel_err(out, ref) <= 3e-5
