@@ -1,6 +1,6 @@
 // das_generic.hip -- the "any shape" DAS kernel: one pixel per lane.
 //
-// Serves every case the tiled kernel (das_tile.hip) does not: fp64, the keep_rx/keep_tx
+// Serves every case the tiled kernel (das_tile_impl.h) does not: fp64, the keep_rx/keep_tx
 // modes, N-D sound speed, arbitrary broadcast apodization stacks, and pixel tiles whose
 // delay window does not fit in LDS.  It computes exactly what reference src/bf.cu:49-142
 // (`DAS_temp`) defines, but is organised differently:

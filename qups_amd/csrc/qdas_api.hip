@@ -196,7 +196,7 @@ static uint64_t bcast_numel(const uint64_t *st, const qdas_sizes &z) {
     return n;
 }
 
-// Shape of the tiled kernel's tiles and waves (das_tile.hip).
+// Shape of the tiled kernel's tiles and waves (das_tile_impl.h).
 //  * tile footprint (64x16, 32x32, 16x64 or 8x128 pixels of I1 x columns): every candidate is PROBED -- the kernel's own
 //    prologue runs for all tiles and counts those whose delay spread does not fit the LDS window; only footprints with the
 //    fewest misfits are considered (a misfit tile is redone by the generic kernel at >10x the cost).
@@ -332,7 +332,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     if (eligible && g.gen_kind && pix_arr >= 0) {
         eligible = false; why = "tiled kernel: a generated receive apodization and a pixel-dependent array need the generic kernel";
     }
-    // reciprocal mode (das_tile.hip "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
+    // reciprocal mode (das_tile_impl.h "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
     // elements and share one t0 has tau(n,m) == tau(m,n); detected from the geometry itself, bit-exactly.
     int sym = 0;
     if (eligible && dt == QDAS_F32 && z.VS && z.DV && z.N == z.M && z.S == 0 && !g.gen_kind && !getenv("QDAS_NO_SYM")) {
@@ -436,7 +436,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         }
         if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
         // Too few tiles for the GPU (a pixel slab of a multi-GPU job, a small image): several workgroups per tile, each summing a
-        // slice of the aperture (das_tile.hip) until every CU has a workgroup.  QDAS_KSPLIT overrides.
+        // slice of the aperture (das_tile_impl.h) until every CU has a workgroup.  QDAS_KSPLIT overrides.
         {
             int ncu = 0;
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device));

@@ -32,7 +32,7 @@ struct GenericParams {
 hipError_t launch_generic(const GenericParams &P, int dtype, unsigned grid, hipStream_t s);
 hipError_t launch_delays(const GenericParams &P, int dtype, void *tau, double cinv, hipStream_t s);
 
-// ---- tiled kernel (das_tile.hip)
+// ---- tiled kernel (das_tile_impl.h)
 struct TileParams {
     const float *Pi, *Pr, *Pv, *Nv;     // fp32 geometry (QDAS_F32 / QDAS_F16 only)
     const void *x;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Register / spill table of every das_tile_kernel instantiation: tools/kernel_regs.py <device code object>
-(hipcc --cuda-device-only -c das_tile.hip -o tile.co; reads the AMDGPU metadata notes)."""
+(hipcc -DQDAS_UNITY --cuda-device-only -c das_tile.hip -o tile.co, then clang-offload-bundler --unbundle; reads the AMDGPU metadata notes)."""
 import re, subprocess, sys
 t = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", sys.argv[1]], capture_output=True, text=True).stdout
 for b in t.split("- .agpr_count")[1:]:
