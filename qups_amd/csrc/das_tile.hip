@@ -6,6 +6,8 @@
 #include "das_tile_f32.hip"
 #include "das_tile_sym.hip"
 #include "das_tile_f16.hip"
+#include "das_tile_f32x2.hip"
+#include "das_tile_f16x2.hip"
 #else
 #include "qdas_device.h"
 #include "qdas_kernels.h"
@@ -17,14 +19,16 @@ namespace qdas {
 hipError_t launch_tile_f32(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_sym(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f16(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
+hipError_t launch_tile_f32x2(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
+hipError_t launch_tile_f16x2(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 
 // y[i] = sum over the ksplit partial images, in split order (deterministic)
 template <typename ST>
-__global__ void __launch_bounds__(256) tile_reduce_kernel(const float2 *part, ST *y, uint64_t count, uint32_t ksplit) {
+__global__ void __launch_bounds__(256) tile_reduce_kernel(const float2 *part, ST *y, uint64_t count, uint32_t ksplit, uint64_t stride) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
     float2 a = part[i];
-    for (uint32_t j = 1; j < ksplit; ++j) { const float2 b = part[(size_t)j * count + i]; a.x += b.x; a.y += b.y; }
+    for (uint32_t j = 1; j < ksplit; ++j) { const float2 b = part[(size_t)j * stride + i]; a.x += b.x; a.y += b.y; }
     st(y, (size_t)i, cplx<float>{a.x, a.y});
 }
 
@@ -57,14 +61,22 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     if (ntiles == 0) return hipSuccess;
     const int sym = P.sym ? 1 : 0;
     if (sym && dtype != 1) return hipErrorInvalidValue;
-    const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M);
+    const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M);    // (the two-frame configurations have the same LDS image)
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
     if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part))) return hipErrorInvalidValue;
-hipError_t e = sym ? launch_tile_sym(P, ntiles, lds, s) : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));
+if (P.fb2 && (sym || P.probe)) return hipErrorInvalidValue;
+    hipError_t e = sym ? launch_tile_sym(P, ntiles, lds, s)
+                 : P.fb2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))
+                         : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));
     if (e != hipSuccess || P.probe || P.ksplit <= 1) return e;
     const unsigned rb = (unsigned)((P.i_count + 255) / 256);
-    if (dtype == 2) tile_reduce_kernel<uint32_t><<<rb, 256, 0, s>>>(P.part, (uint32_t *)P.y, P.i_count, P.ksplit);
-    else            tile_reduce_kernel<float2><<<rb, 256, 0, s>>>(P.part, (float2 *)P.y, P.i_count, P.ksplit);
+    const int nf = P.fb2 ? 2 : 1;                        // partial images: [split][frame][pixel]
+    for (int f = 0; f < nf; ++f) {
+        const float2 *src = P.part + (size_t)f * P.i_count;
+        const uint64_t stride = (uint64_t)nf * P.i_count;
+        if (dtype == 2) tile_reduce_kernel<uint32_t><<<rb, 256, 0, s>>>(src, (uint32_t *)P.y + (size_t)f * P.y_fstride, P.i_count, P.ksplit, stride);
+        else            tile_reduce_kernel<float2><<<rb, 256, 0, s>>>(src, (float2 *)P.y + (size_t)f * P.y_fstride, P.i_count, P.ksplit, stride);
+    }
     return hipGetLastError();
 }
 

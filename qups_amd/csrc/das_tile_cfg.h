@@ -6,6 +6,8 @@ namespace qdas {
 // workgroup per CU (general case);  cfg 1: the same tile with 16 transmits per stage and direct + mirror windows
 // (reciprocal mode).
 struct Cfg { int waves, mb, w, nbuf, psz, bpc; };
-static constexpr Cfg CFGS[3] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1}};
-static inline int cfg_index(int dtype, int sym) { return sym ? 1 : (dtype == 2 ? 2 : 0); }
+// cfg 3 / 4: two frames per launch (fp32 / fp16 data): 16 transmits x 2 frames per stage -- the reciprocal mode's window layout
+static constexpr Cfg CFGS[5] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1},
+                                {16, 16, 192, 2, 16, 1}, {16, 16, 384, 2, 16, 1}};
+static inline int cfg_index(int dtype, int sym, int fb2 = 0) { return sym ? 1 : (fb2 ? (dtype == 2 ? 4 : 3) : (dtype == 2 ? 2 : 0)); }
 }  // namespace qdas

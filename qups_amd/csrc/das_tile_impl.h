@@ -198,6 +198,12 @@ __device__ __forceinline__ void lds_fence(taps_f16 &a, taps_f16 &b, v2f (&w)[4])
                  : "+v"(a.r[0]), "+v"(a.r[1]), "+v"(a.r[2]), "+v"(a.r[3]), "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]),
                    "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
 }
+__device__ __forceinline__ void lds_fence2(taps_f16 &a, taps_f16 &b, taps_f16 &c, taps_f16 &d, v2f (&w)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a.r[0]), "+v"(a.r[1]), "+v"(a.r[2]), "+v"(a.r[3]), "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]),
+                   "+v"(c.r[0]), "+v"(c.r[1]), "+v"(c.r[2]), "+v"(c.r[3]), "+v"(d.r[0]), "+v"(d.r[1]), "+v"(d.r[2]), "+v"(d.r[3]),
+                   "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+}
 __device__ __forceinline__ void mix_mac(v2f &acc, uint32_t tap, float w) {       // acc += w * (float2)tap
     float ar = acc.x, ai = acc.y;
     asm("v_fma_mix_f32 %0, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
@@ -216,11 +222,17 @@ __device__ __forceinline__ uint32_t zero_of(const uint32_t *) { return 0u; }
 //      BPC workgroups per CU the register budget is sized for.
 //      PROBE: plan-time variant that stops after the window-fit test (a kernel of its own name, so that profiles of
 //      das_tile_kernel<..., false> hold full frames only).
-template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE>
+//      FB2: two FRAMES per launch (x, x + x_fstride -> y, y + y_fstride): the second window set of a stage holds the same
+//      traces of the next frame, so tap index and weights -- which depend on the geometry only -- are computed once for
+//      both frames (the reference launches one kernel per frame, kern/das_spec.m:371).  Structurally the reciprocal mode's
+//      "mirror" set with another source and a separate sum.
+template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, bool FB2, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE>
 __global__ void __launch_bounds__(WAVES * 64, WAVES * BPC / 4)
 das_tile_kernel(const TileParams P) {
-    constexpr int NW = SYM ? 2 * MB : MB;     // windows per LDS buffer: direct (+ mirror) traces of a stage
+    constexpr bool TWO = SYM || FB2;          // two window sets per stage: direct + (mirror | next frame)
+    constexpr int NW = TWO ? 2 * MB : MB;     // windows per LDS buffer
     static_assert(!SYM || (sizeof(ST) == 8 && !WTAB), "reciprocal mode: fp32 data, no weight table");
+    static_assert(!(SYM && FB2), "reciprocal mode runs one frame per launch");
     constexpr int K = tapinfo<INTERP>::K;
     constexpr int THREADS = WAVES * 64;
     constexpr int TX = WAVES;                 // waves per workgroup; a wave holds 1, 2 or 4 image columns (tz_log2)
@@ -451,7 +463,7 @@ das_tile_kernel(const TileParams P) {
     //  measured with tools/scratch/dma12.hip)
     constexpr int PB = 1024;                           // bytes per full DMA piece (one wave-instruction x 16 B)
     constexpr int PCS = (WB + PB - 1) / PB;            // pieces per window; the last one may use fewer lanes
-    constexpr int NDMA = WPW * PCS * (SYM ? 2 : 1);    // DMA instructions per wave and stage
+    constexpr int NDMA = WPW * PCS * (TWO ? 2 : 1);    // DMA instructions per wave and stage
     static_assert(WB % 16 == 0 && PSZ == 16, "window must be a whole number of 16-byte lanes");
     const uint64_t xbytes = (uint64_t)P.N * P.M * P.T * SB;
     // Per-wave DMA state: this wave stages windows j_r = wave + WAVES*r.  One buffer descriptor per TRANSMIT BLOCK, based at
@@ -474,6 +486,10 @@ das_tile_kernel(const TileParams P) {
             wb[r] = am * SB + (int)((long)j * (long)P.strM * SB);
             if constexpr (SYM) wb2[r] = am * SB + (int)((long)j * (long)P.strN * SB);
         }
+        if constexpr (FB2) {                           // the same traces of the next frame
+            const uint64_t o2 = o + P.x_fstride;
+            rsM = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + (rem ? o2 : 0)), 0, rem > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem, 0x00020000);
+        }
         if constexpr (SYM) {                           // mirror traces x[:, rx = m0 + j, tx = n] (reciprocal mode starts every block at n = 0)
             const uint64_t o2 = (uint64_t)m0 * P.strN * SB;
             const uint64_t rem2 = xbytes > o2 ? xbytes - o2 : 0;
@@ -492,6 +508,19 @@ das_tile_kernel(const TileParams P) {
                 lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + j) * WB + q * PB));
                 if (lane * 16 < WB - q * PB)             // trailing partial piece: upper lanes masked off
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, dst, 16, lane * 16, so + q * PB, 0, 0);
+            }
+        }
+        if constexpr (FB2) {                           // next frame: same offsets, other descriptor, second window set
+#pragma unroll
+            for (int r = 0; r < WPW; ++r) {
+                const int j = __builtin_amdgcn_readfirstlane(wave + WAVES * r);
+                const int so = (int)soff + wb[r] + bs;
+#pragma unroll
+                for (int q = 0; q < PCS; ++q) {
+                    lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + MB + j) * WB + q * PB));
+                    if (lane * 16 < WB - q * PB)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, dst, 16, lane * 16, so + q * PB, 0, 0);
+                }
             }
         }
         soff += (uint32_t)P.strN * SB;                 // next receiver, same transmit block
@@ -533,6 +562,7 @@ das_tile_kernel(const TileParams P) {
         }
     };
     v2f tot = {0.f, 0.f};                              // weighted total when wpix (acc.. then hold one stage's partial sum)
+    v2f tot2 = {0.f, 0.f};                             // ... of the second frame (FB2)
 
     auto run = [&](auto check_tag) {
         constexpr bool CHECK = decltype(check_tag)::value;
@@ -617,19 +647,20 @@ das_tile_kernel(const TileParams P) {
                 const uint32_t ad1 = ((QDAS_ABL & 128) ? (MAGIC_BITS + (uint32_t)lane + (__float_as_uint(tm.y) & 1u)) : __float_as_uint(tm.y)) * (uint32_t)SB + cbase;
                 constexpr bool SPLIT = CHECK || FMOD || WTAB;       // the two halves need separate post-processing
                 v2f v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
+                v2f u0 = {0.f, 0.f}, u1 = {0.f, 0.f};     // the same two pairs of the second frame (FB2)
                 if constexpr (F32) {
                     taps_f32 g0, g1, h0, h1;              // direct taps x[:, n, m | m+1]; mirror taps x[:, m | m+1, n]
                     if constexpr ((QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { g0.s[k] = h0.s[k] = (v2f){s.x, t.x}; g1.s[k] = h1.s[k] = (v2f){t.y, s.y}; } }
                     else {
                         lds_issue<K, (2 * p) * WB>(g0, ad0); lds_issue<K, (2 * p + 1) * WB>(g1, ad1);
-                        if constexpr (SYM) { lds_issue<K, (MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (MB + 2 * p + 1) * WB>(h1, ad1); }
+                        if constexpr (TWO) { lds_issue<K, (MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (MB + 2 * p + 1) * WB>(h1, ad1); }
                         if constexpr (K < 4) { g0.s[2] = g0.s[3] = g1.s[2] = g1.s[3] = h0.s[2] = h0.s[3] = h1.s[2] = h1.s[3] = (v2f){0.f, 0.f}; }
                         if constexpr (K < 2) { g0.s[1] = g1.s[1] = h0.s[1] = h1.s[1] = (v2f){0.f, 0.f}; }
                     }
                     v2f w[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
                     if constexpr ((QDAS_ABL & 8) != 0) { w[0] = s; w[1] = t; w[2] = tm; w[3] = s + t; }
                     else if constexpr (K > 1) weights2<INTERP>(s, w);       // overlaps the LDS latency
-                    if constexpr (SYM) lds_fence2(g0, g1, h0, h1, w); else lds_fence(g0, g1, w);
+                    if constexpr (TWO) lds_fence2(g0, g1, h0, h1, w); else lds_fence(g0, g1, w);
                     if constexpr (DIAG) {                 // uniform, only in the block that holds the diagonal
                         const v2f z = {0.f, 0.f};
                         if (m < n)      { for (int k = 0; k < 4; ++k) g0.s[k] = z; }     // pair (n, m<n): done as the mirror of (m, n)
@@ -639,10 +670,10 @@ das_tile_kernel(const TileParams P) {
                     if constexpr (TAIL) {
                         if (!upper) {                       // odd M: no transmit in the upper half (uniform, rare)
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) g1.s[k] = (v2f){0.f, 0.f};
+                            for (int k = 0; k < 4; ++k) { g1.s[k] = (v2f){0.f, 0.f}; if constexpr (FB2) h1.s[k] = (v2f){0.f, 0.f}; }
                         }
                     }
-                    if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; }
+                    if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; if constexpr (FB2) { u0 = h0.s[0]; u1 = h1.s[0]; } }
                     else if constexpr (SPLIT) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { v0 = w[k].x * g0.s[k] + v0; v1 = w[k].y * g1.s[k] + v1; }
@@ -650,36 +681,51 @@ das_tile_kernel(const TileParams P) {
 #pragma unroll
                             for (int k = 0; k < K; ++k) { v0 = w[k].x * h0.s[k] + v0; v1 = w[k].y * h1.s[k] + v1; }
                         }
+                        if constexpr (FB2) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) { u0 = w[k].x * h0.s[k] + u0; u1 = w[k].y * h1.s[k] + u1; }
+                        }
                     } else {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { acc = w[k].x * g0.s[k] + acc; acc1 = w[k].y * g1.s[k] + acc1; }
-                        if constexpr (SYM) {
+                        if constexpr (TWO) {
 #pragma unroll
                             for (int k = 0; k < K; ++k) { acc2 = w[k].x * h0.s[k] + acc2; acc3 = w[k].y * h1.s[k] + acc3; }
                         }
                     }
                     if constexpr (SYM && K == 1) { v0 += h0.s[0]; v1 += h1.s[0]; }
                 } else {
-                    taps_f16 g0, g1;
+                    taps_f16 g0, g1, h0, h1;
                     lds_issue<K, (2 * p) * WB>(g0, ad0); lds_issue<K, (2 * p + 1) * WB>(g1, ad1);
-                    if constexpr (K < 4) { g0.r[2] = g0.r[3] = g1.r[2] = g1.r[3] = 0u; }
-                    if constexpr (K < 2) { g0.r[1] = g1.r[1] = 0u; }
+                    if constexpr (FB2) { lds_issue<K, (MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (MB + 2 * p + 1) * WB>(h1, ad1); }
+                    if constexpr (K < 4) { g0.r[2] = g0.r[3] = g1.r[2] = g1.r[3] = h0.r[2] = h0.r[3] = h1.r[2] = h1.r[3] = 0u; }
+                    if constexpr (K < 2) { g0.r[1] = g1.r[1] = h0.r[1] = h1.r[1] = 0u; }
                     v2f w[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
                     if constexpr (K > 1) weights2<INTERP>(s, w);            // overlaps the LDS latency
-                    lds_fence(g0, g1, w);
+                    if constexpr (FB2) lds_fence2(g0, g1, h0, h1, w); else lds_fence(g0, g1, w);
                     if constexpr (TAIL) {
                         if (!upper) {
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) g1.r[k] = 0u;
+                            for (int k = 0; k < 4; ++k) { g1.r[k] = 0u; if constexpr (FB2) h1.r[k] = 0u; }
                         }
                     }
-                    if constexpr (K == 1) { v0 = half2_to_v2f(g0.r[0]); v1 = half2_to_v2f(g1.r[0]); }
-                    else if constexpr (SPLIT) {
+                    if constexpr (K == 1) {
+                        v0 = half2_to_v2f(g0.r[0]); v1 = half2_to_v2f(g1.r[0]);
+                        if constexpr (FB2) { u0 = half2_to_v2f(h0.r[0]); u1 = half2_to_v2f(h1.r[0]); }
+                    } else if constexpr (SPLIT) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { mix_mac(v0, g0.r[k], w[k].x); mix_mac(v1, g1.r[k], w[k].y); }
+                        if constexpr (FB2) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) { mix_mac(u0, h0.r[k], w[k].x); mix_mac(u1, h1.r[k], w[k].y); }
+                        }
                     } else {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { mix_mac(acc, g0.r[k], w[k].x); mix_mac(acc1, g1.r[k], w[k].y); }
+                        if constexpr (FB2) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) { mix_mac(acc2, h0.r[k], w[k].x); mix_mac(acc3, h1.r[k], w[k].y); }
+                        }
                     }
                 }
                 if constexpr (CHECK) {                    // edge rule: all taps in [0,T) and tau >= 0
@@ -689,6 +735,7 @@ das_tile_kernel(const TileParams P) {
                     const float lo1 = tapinfo<INTERP>::LO - 0.5f - (float)ws1, hi1 = (float)(T - K + 1 - ws1) - 0.5f;
                     const bool k0 = (t.x >= lo0) && (t.x < hi0), k1 = (t.y >= lo1) && (t.y < hi1) && upper;
                     v0 = k0 ? v0 : (v2f){0.f, 0.f}; v1 = k1 ? v1 : (v2f){0.f, 0.f};
+                    if constexpr (FB2) { u0 = k0 ? u0 : (v2f){0.f, 0.f}; u1 = k1 ? u1 : (v2f){0.f, 0.f}; }
                 }
                 if constexpr (FMOD) {                     // reference src/bf.cu:117: w = exp(2j pi fmod tau)
                     const uint32_t mb = upper ? m + 1 : m;
@@ -700,15 +747,23 @@ das_tile_kernel(const TileParams P) {
                     const float c1 = __builtin_amdgcn_cosf(ph.y), s1 = __builtin_amdgcn_sinf(ph.y);
                     v0 = (v2f){v0.x * c0 - v0.y * s0, v0.x * s0 + v0.y * c0};
                     v1 = (v2f){v1.x * c1 - v1.y * s1, v1.x * s1 + v1.y * c1};
+                    if constexpr (FB2) {
+                        u0 = (v2f){u0.x * c0 - u0.y * s0, u0.x * s0 + u0.y * c0};
+                        u1 = (v2f){u1.x * c1 - u1.y * s1, u1.x * s1 + u1.y * c1};
+                    }
                 }
                 if constexpr (WTAB) {
                     acc += (v2f){wr0 * v0.x - wi0 * v0.y, wr0 * v0.y + wi0 * v0.x};
                     acc += (v2f){wr1 * v1.x - wi1 * v1.y, wr1 * v1.y + wi1 * v1.x};
-                } else if constexpr (SPLIT || K == 1) { acc += v0; acc += v1; }
+                    if constexpr (FB2) {
+                        acc2 += (v2f){wr0 * u0.x - wi0 * u0.y, wr0 * u0.y + wi0 * u0.x};
+                        acc2 += (v2f){wr1 * u1.x - wi1 * u1.y, wr1 * u1.y + wi1 * u1.x};
+                    }
+                } else if constexpr (SPLIT || K == 1) { acc += v0; acc += v1; if constexpr (FB2) { acc2 += u0; acc2 += u1; } }
             };
             // full block (reciprocal mode: block entirely above the diagonal): check-free; else the tail / diagonal variant
             if (SYM ? (n < m0) : (m0 + MB <= M)) {
-                if constexpr (SYM && F32 && K == 4 && !(CHECK || FMOD || WTAB) && !(QDAS_ABL & 256)) {
+                if constexpr (TWO && F32 && K == 4 && !(CHECK || FMOD || WTAB) && !(QDAS_ABL & 256)) {
                     // Software-pipelined: the direct taps of iteration p+1 are requested before the MACs of iteration p, so the
                     // LDS pipe always has work queued and the counted wait (newest 8 reads stay in flight) rarely stalls.
                     constexpr int NP = MB / 2;
@@ -766,8 +821,9 @@ das_tile_kernel(const TileParams P) {
 #endif
             buf = (buf + 1 == NBUF) ? 0 : buf + 1;
             if (wpix) {                                // weight the stage's partial sum (the weight does not depend on m)
-                const v2f S = (acc + acc1) + (acc2 + acc3);
+                const v2f S = FB2 ? (acc + acc1) : (acc + acc1) + (acc2 + acc3);
                 tot += (v2f){wcur.x * S.x - wcur.y * S.y, wcur.x * S.y + wcur.y * S.x};
+                if constexpr (FB2) { const v2f S2 = acc2 + acc3; tot2 += (v2f){wcur.x * S2.x - wcur.y * S2.y, wcur.x * S2.y + wcur.y * S2.x}; }
                 acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
                 wcur = wnext;
             }
@@ -783,13 +839,19 @@ das_tile_kernel(const TileParams P) {
         for (int k = 0; k < 8; ++k) o[k] = pt_[k];
     }
 #endif
-    acc = wpix ? tot : (acc + acc1) + (acc2 + acc3);
+    const v2f res2 = wpix ? tot2 : (acc2 + acc3);       // second frame (FB2)
+    acc = wpix ? tot : (FB2 ? (acc + acc1) : (acc + acc1) + (acc2 + acc3));
     // ---- epilogue: y[i] = pix  (reference src/bf.cu:140); lanes = consecutive i -> coalesced
     {
         const uint64_t ig = i1 + P.I1 * col;
         if ((i1 < P.I1) && (col < ncols) && (ig >= P.i_begin) && (ig < i_end)) {
-            if (S > 1) P.part[(size_t)split * P.i_count + (size_t)(ig - P.i_begin)] = make_float2(acc.x, acc.y);
+            constexpr size_t NF = FB2 ? 2 : 1;              // partial images are laid out [split][frame][pixel]
+            if (S > 1) P.part[((size_t)split * NF) * P.i_count + (size_t)(ig - P.i_begin)] = make_float2(acc.x, acc.y);
             else st((ST *)P.y, (size_t)(ig - P.i_begin), cplx<float>{acc.x, acc.y});
+            if constexpr (FB2) {
+                if (S > 1) P.part[((size_t)split * NF + 1) * P.i_count + (size_t)(ig - P.i_begin)] = make_float2(res2.x, res2.y);
+                else st((ST *)P.y + P.y_fstride, (size_t)(ig - P.i_begin), cplx<float>{res2.x, res2.y});
+            }
         }
     }
 }
@@ -797,18 +859,21 @@ das_tile_kernel(const TileParams P) {
 template <int INTERP, typename ST, int CI>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
     constexpr Cfg G = CFGS[CI];
-    constexpr bool SYM = (CI == 1);
+    constexpr bool SYM = (CI == 1), FB2 = (CI >= 3);
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
     const dim3 g(ntiles * (P.probe ? 1u : P.ksplit)), b(G.waves * 64);
 #define QDAS_LAUNCH(FM, WT) QDAS_LAUNCH_P(FM, WT, false)
 #define QDAS_LAUNCH_P(FM, WT, PR)                                                                        \
     do {                                                                                                 \
-        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR>; \
+        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR>; \
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                   \
         kfn<<<g, b, lds, s>>>(P);                                                                        \
     } while (0)
-    if (P.probe) { QDAS_LAUNCH_P(false, false, true); return hipGetLastError(); }
+    if (P.probe) {
+        if constexpr (FB2) return hipErrorInvalidValue;    // the window fit does not depend on the frame count: probes use FB = 1
+        else { QDAS_LAUNCH_P(false, false, true); return hipGetLastError(); }
+    }
     if constexpr (SYM) {
         if (wt) return hipErrorInvalidValue;
         if (fm) QDAS_LAUNCH(true, false); else QDAS_LAUNCH(false, false);

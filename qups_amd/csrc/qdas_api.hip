@@ -396,7 +396,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if ((rc = dev_alloc(pl, &fb, sizeof(uint32_t) * (max_tiles + 1)))) return bail(rc);
         pl->fallback = (uint32_t *)fb;
         t.fallback_list = pl->fallback; t.fallback_cap = max_tiles;
-        t.probe = 0; t.wz_log2 = 6; t.ksplit = 1; t.part = nullptr;
+        t.probe = 0; t.wz_log2 = 6; t.ksplit = 1; t.part = nullptr; t.fb2 = 0; t.x_fstride = 0; t.y_fstride = 0;
         // fold the (pixel-independent) apodization stack into one N x M complex64 table
         t.wtab = nullptr; t.apix = nullptr; t.apix_real = desc->apod_real;
         t.gen_kind = g.gen_kind; t.gen_p0 = g.gen_p0; t.gen_p1 = g.gen_p1; t.rxn = (const float *)g.rxn;
@@ -449,7 +449,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             t.ksplit = ks;
             if (ks > 1) {
                 void *pb;
-                if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)ks * pl->i_count))) return bail(rc);
+                if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)ks * 2 * pl->i_count))) return bail(rc);   // x2: frame pairs
                 t.part = (float2 *)pb;
             }
         }
@@ -508,11 +508,14 @@ extern "C" int qdas_plan_last_kernel_ms(const qdas_plan *pl, float *ms) {
 
 static int hip_rc(hipError_t e) { HIPCHK(e); return QDAS_OK; }
 
-static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s) {
+// One frame -- or, for the tiled kernel outside the reciprocal mode, TWO frames in one launch (nf == 2): frame 1 lives at
+// x + x_fstride bytes / y + y_fstride elements and shares tap indices and weights with frame 0 (das_tile_impl.h "FB2").
+static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s, int nf = 1, uint64_t x_fstride = 0, uint64_t y_fstride = 0) {
     const qdas_sizes &z = pl->d.sz;
     if (pl->kernel == QDAS_KERNEL_TILED) {
         TileParams t = pl->tp;
         t.x = x; t.y = y;
+        t.fb2 = nf == 2; t.x_fstride = x_fstride; t.y_fstride = y_fstride;
         if (pl->no_fallback) return hip_rc(launch_tile(t, z.dtype, pl->ntiles, s));     // one launch per frame (+ the reduce of a split aperture)
         HIPCHK(hipMemsetAsync(pl->fallback, 0, sizeof(uint32_t), s));
         HIPCHK(launch_tile(t, z.dtype, pl->ntiles, s));
@@ -526,6 +529,10 @@ static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s) {
         g.blocks_per_tile = (64 * pl->tc.waves + 255) / 256;
         g.tiles_z = pl->tp.tiles_z;
         HIPCHK(launch_generic(g, z.dtype, pl->ntiles * g.blocks_per_tile, s));
+        if (nf == 2) {                                  // the same misfit tiles of the second frame
+            g.x = (const char *)x + x_fstride; g.y = (char *)y + y_fstride * data_size(z.dtype);
+            HIPCHK(launch_generic(g, z.dtype, pl->ntiles * g.blocks_per_tile, s));
+        }
     } else {
         GenericParams g = pl->gp;
         g.x = x; g.y = y;
@@ -554,9 +561,18 @@ extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, u
     }
     if (!x) return fail(QDAS_EINVAL, "null data");
     if (pl->timing) HIPCHK(hipEventRecord(pl->e0, s));
+    // frame pairs share one launch (device-resident data, tiled kernel, not the reciprocal mode; QDAS_NO_FB2 disables)
+    const bool pairs_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->tp.sym && pl->d.mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2")
+                          && x_stride * ds < (1ull << 40);
     for (uint64_t f = 0; f < F; ++f) {
         const char *xf = (const char *)x + f * x_stride * ds;
         char *yf = (char *)y + f * y_stride * ds;
+        if (pairs_ok && f + 1 < F) {
+            int rc = run_frame(pl, xf, yf, s, 2, x_stride * ds, y_stride);
+            if (rc) return rc;
+            ++f;
+            continue;
+        }
         if (pl->d.mem == QDAS_MEM_HOST) {
             HIPCHK(hipMemcpyAsync(pl->dx, xf, pl->x_bytes, hipMemcpyHostToDevice, s));
             int rc = run_frame(pl, pl->dx, pl->dy, s);

@@ -55,8 +55,10 @@ struct TileParams {
     int32_t wz_log2;                    // wave footprint inside the tile: (1 << wz_log2) pixels of I1 x (64 >> wz_log2) columns; <= tz_log2
     int32_t probe;                      // 1: stop after the window-fit test (plan-time shape selection; only fallback_list is written)
     uint32_t tiles_z, tiles_x, tile_x0; // tile grid over (I1 >> tz_log2) x (columns / tile columns); first column tile of the shard
+    int32_t fb2;                        // 1: two frames per launch (x, x + x_fstride -> y, y + y_fstride); never with sym
+    uint64_t x_fstride, y_fstride;      // frame strides: BYTES of x, ELEMENTS of y
     uint32_t ksplit;                    // workgroups per tile (>= 1): each sums a slice of the aperture into part[], then reduced into y
-    float2 *part;                       // [ksplit][i_count] partial images (ksplit > 1 only)
+    float2 *part;                       // [ksplit][frames per launch][i_count] partial images (ksplit > 1 only)
     uint32_t *fallback_list;            // [0] = count, [1..] = tile ids that did not fit the LDS window
     uint32_t fallback_cap;
 };

@@ -489,3 +489,70 @@ def test_large_time_offset(seq):
         assert plan.fallback_tiles() <= 4 and rel_err(out, ref) <= TOL32
     else:
         assert plan.fallback_tiles() == 0 and rel_err(out, ref) <= 3e-5
+
+
+@pytest.mark.parametrize("seq,interp,prec,extra", [("PW", "cubic", "single", {}), ("FSA", "lanczos3", "single", {"N": 24}), ("DV", "linear", "halfT", {}),
+                                                   ("PW", "nearest", "single", {}), ("FC", "cubic", "single", {"fmod": 2.0e6}),
+                                                   ("PW", "cubic", "single", {"wtab": True}), ("DV", "cubic", "halfT", {"wpix": True}),
+                                                   ("PW", "lanczos3", "single", {"ks": 4})])
+@pytest.mark.parametrize("F", [2, 3])
+def test_frame_pairs_share_one_launch(seq, interp, prec, extra, F, monkeypatch):
+    """F frames through one plan: the tiled kernel beamforms them two at a time with shared tap indices / weights; every frame must
+    equal what a frame-by-frame run (QDAS_NO_FB2=1) and the oracle give"""
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd.das_spec import _cast_data, _colmajor
+    from oracle import das_oracle as O
+    N = extra.get("N", 16)
+    case = make_case(seq=seq, interp=interp, seed=71, N=N, I1=150, I2=21, zlim=(4e-3, 15e-3), xspan=3e-3, data="noise")
+    M = case["M"]
+    rng = np.random.default_rng(72)
+    xs = np.stack([case["x"]] + [(rng.standard_normal(case["x"].shape) + 1j * rng.standard_normal(case["x"].shape)).astype(np.complex64)
+                                 for _ in range(F - 1)], axis=3)                     # T x N x M x F
+    if prec == "halfT":
+        xs = (xs.real.astype(np.float16).astype(np.float32) + 1j * xs.imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
+    apod = []
+    q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else (lambda a: a.astype(np.float32).astype(np.float64))
+    if extra.get("wtab"):
+        a = q(rng.uniform(0, 1, (1, 1, 1, 1, M)))
+        a[..., 1] = 0.0
+        apod.append(a * (1 + 0.5j))
+    if extra.get("wpix"):
+        a = q(rng.uniform(0, 1, (150, 21, 1, N, 1)) > 0.4)
+        a[:40] = 0.0
+        apod.append(a)
+    fmod = float(np.float32(extra.get("fmod", 0.0)))
+    if "ks" in extra:
+        monkeypatch.setenv("QDAS_KSPLIT", str(extra["ks"]))
+    opts = list(case["opt"]) + ["interp", interp, "input-precision", prec, "modulation", fmod]
+    for a in apod:
+        opts += ["apod", a]
+    xt = torch.from_numpy(np.ascontiguousarray(xs))
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"],
+                         parse_options(xt, opts))
+    xc = _colmajor(_cast_data(xt, prob.prec, torch.device("cuda:0")))
+
+    def run():
+        plan = DasPlan(prob, kernel=2)
+        y = plan.execute_colmajor(xc, F)
+        torch.cuda.synchronize()
+        return y.to(torch.complex64).cpu().numpy().reshape(F, -1), plan
+
+    ya, plan = run()
+    monkeypatch.setenv("QDAS_NO_FB2", "1")
+    yb, _ = run()
+    monkeypatch.delenv("QDAS_NO_FB2")
+    assert plan.kernel == "tiled"
+    tol = 3e-3 if prec == "halfT" else 3e-5
+    for f in range(F):
+        ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs[..., f], case["t0"], case["fs"], cinv_f32(case["c"]),
+                         VS=case["VS"], DV=case["DV"], interp=interp, apod=tuple(apod), fmod=fmod).reshape(-1, order="F")
+        den = np.abs(ref).max()
+        if interp == "nearest":
+            assert np.mean(np.abs(ya[f] - ref) / den > 1e-4) < 0.05
+            assert np.mean(np.abs(ya[f] - yb[f]) / den > 1e-4) < 0.05
+        elif seq == "FC":
+            assert np.abs(ya[f] - ref).max() / den <= 1e-4 and np.abs(ya[f] - yb[f]).max() / den <= 1e-4      # focal-depth tiles: generic kernel
+        else:
+            assert np.abs(ya[f] - ref).max() / den <= tol, (f, np.abs(ya[f] - ref).max() / den)
+            assert np.abs(ya[f] - yb[f]).max() / den <= tol
