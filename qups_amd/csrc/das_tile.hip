@@ -68,7 +68,7 @@ if (P.fb2 && (sym || P.probe)) return hipErrorInvalidValue;
     hipError_t e = sym ? launch_tile_sym(P, ntiles, lds, s)
                  : P.fb2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))
                          : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));
-    if (e != hipSuccess || P.probe || P.ksplit <= 1) return e;
+    if (e != hipSuccess || P.probe || P.ksplit <= 1 || P.syn) return e;   // ('SYN' planes are accumulated in place)
     const unsigned rb = (unsigned)((P.i_count + 255) / 256);
     const int nf = P.fb2 ? 2 : 1;                        // partial images: [split][frame][pixel]
     for (int f = 0; f < nf; ++f) {

@@ -563,6 +563,8 @@ das_tile_kernel(const TileParams P) {
     };
     v2f tot = {0.f, 0.f};                              // weighted total when wpix (acc.. then hold one stage's partial sum)
     v2f tot2 = {0.f, 0.f};                             // ... of the second frame (FB2)
+    const bool syn = !SYM && F32 && P.syn;             // keep the receive dimension: one output plane per receiver
+    const bool in_shard = (i1 < P.I1) && (col < ncols) && (i1 + P.I1 * col >= P.i_begin) && (i1 + P.I1 * col < i_end);
 
     auto run = [&](auto check_tag) {
         constexpr bool CHECK = decltype(check_tag)::value;
@@ -820,7 +822,22 @@ das_tile_kernel(const TileParams P) {
               pt_[1] += ts1_ - ts0_; pt_[2] += ts2_ - ts1_; pt_[3] += ts3_ - ts2_; pt_[4] += ts4_ - ts3_; pt_[6] += 1; }
 #endif
             buf = (buf + 1 == NBUF) ? 0 : buf + 1;
-            if (wpix) {                                // weight the stage's partial sum (the weight does not depend on m)
+            if (syn) {                                 // 'SYN' (src/bf.cu:131-133): the stage's sum over its transmits joins plane n of y.
+                // Non-returning fp32 atomics: the planes are zero-filled by the host, the transmit blocks of one (pixel, n) are
+                // visited in order by this lane only (and receiver ranges of a split aperture are disjoint) -> deterministic.
+                v2f S0 = FB2 ? (acc + acc1) : (acc + acc1) + (acc2 + acc3), S1 = acc2 + acc3;
+                if (wpix) {
+                    S0 = (v2f){wcur.x * S0.x - wcur.y * S0.y, wcur.x * S0.y + wcur.y * S0.x};
+                    S1 = (v2f){wcur.x * S1.x - wcur.y * S1.y, wcur.x * S1.y + wcur.y * S1.x};
+                    wcur = wnext;
+                }
+                if (in_shard) {
+                    float *q = (float *)((float2 *)P.y + (size_t)(i1 + P.I1 * col - P.i_begin) + (size_t)n * P.y_ld);
+                    unsafeAtomicAdd(q, S0.x); unsafeAtomicAdd(q + 1, S0.y);
+                    if constexpr (FB2) { q += 2 * P.y_fstride; unsafeAtomicAdd(q, S1.x); unsafeAtomicAdd(q + 1, S1.y); }
+                }
+                acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
+            } else if (wpix) {                         // weight the stage's partial sum (the weight does not depend on m)
                 const v2f S = FB2 ? (acc + acc1) : (acc + acc1) + (acc2 + acc3);
                 tot += (v2f){wcur.x * S.x - wcur.y * S.y, wcur.x * S.y + wcur.y * S.x};
                 if constexpr (FB2) { const v2f S2 = acc2 + acc3; tot2 += (v2f){wcur.x * S2.x - wcur.y * S2.y, wcur.x * S2.y + wcur.y * S2.x}; }
@@ -839,6 +856,7 @@ das_tile_kernel(const TileParams P) {
         for (int k = 0; k < 8; ++k) o[k] = pt_[k];
     }
 #endif
+    if (syn) return;                                   // every stage already added its share to its plane
     const v2f res2 = wpix ? tot2 : (acc2 + acc3);       // second frame (FB2)
     acc = wpix ? tot : (FB2 ? (acc + acc1) : (acc + acc1) + (acc2 + acc3));
     // ---- epilogue: y[i] = pix  (reference src/bf.cu:140); lanes = consecutive i -> coalesced

@@ -308,8 +308,10 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     g.tile_list = nullptr; g.blocks_per_tile = 0; g.tile_cols = 0; g.tiles_z = 0;
 
     // ---- kernel selection
-    bool eligible = (dt == QDAS_F32 || dt == QDAS_F16) && !(z.flag & (QDAS_FLAG_KEEP_RX | QDAS_FLAG_KEEP_TX));
-    const char *why = "tiled kernel needs fp32/fp16 data and the 'DAS' (sum both apertures) mode";
+    // modes: 'DAS' (sum both apertures), and with fp32 data 'SYN' (keep the receive dimension: a plane per receiver)
+    const bool syn = (z.flag & QDAS_FLAG_KEEP_RX) && !(z.flag & QDAS_FLAG_KEEP_TX);
+    bool eligible = (dt == QDAS_F32 || dt == QDAS_F16) && !(z.flag & QDAS_FLAG_KEEP_TX) && (!syn || dt == QDAS_F32);
+    const char *why = "tiled kernel needs fp32/fp16 data and the 'DAS' mode (or fp32 data and 'SYN')";
     // sound speed: a scalar, or a full per-pixel map (contiguous I1 x I2 x I3, no aperture dependence): the delay stays separable
     bool cmap = false;
     if (eligible && (g.cst[0] || g.cst[1] || g.cst[2] || g.cst[3] || g.cst[4])) {
@@ -335,7 +337,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // reciprocal mode (das_tile_impl.h "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
     // elements and share one t0 has tau(n,m) == tau(m,n); detected from the geometry itself, bit-exactly.
     int sym = 0;
-    if (eligible && dt == QDAS_F32 && z.VS && z.DV && z.N == z.M && z.S == 0 && !g.gen_kind && !getenv("QDAS_NO_SYM")) {
+    if (eligible && !syn && dt == QDAS_F32 && z.VS && z.DV && z.N == z.M && z.S == 0 && !g.gen_kind && !getenv("QDAS_NO_SYM")) {
         std::vector<float> hr(3 * z.N), hv(4 * z.M);
         if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
         if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);
@@ -397,6 +399,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         pl->fallback = (uint32_t *)fb;
         t.fallback_list = pl->fallback; t.fallback_cap = max_tiles;
         t.probe = 0; t.wz_log2 = 6; t.ksplit = 1; t.part = nullptr; t.fb2 = 0; t.x_fstride = 0; t.y_fstride = 0;
+        t.syn = syn ? 1 : 0; t.y_ld = pl->y_ld;
         // fold the (pixel-independent) apodization stack into one N x M complex64 table
         t.wtab = nullptr; t.apix = nullptr; t.apix_real = desc->apod_real;
         t.gen_kind = g.gen_kind; t.gen_p0 = g.gen_p0; t.gen_p1 = g.gen_p1; t.rxn = (const float *)g.rxn;
@@ -516,6 +519,11 @@ static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s, int n
         TileParams t = pl->tp;
         t.x = x; t.y = y;
         t.fb2 = nf == 2; t.x_fstride = x_fstride; t.y_fstride = y_fstride;
+        if (t.syn) {                                    // planes are accumulated with atomics: start from zero
+            const size_t ds = data_size(z.dtype);        // (only this plan's pixels of every plane: y_ld may span a full-size buffer)
+            for (int f = 0; f < nf; ++f)
+                HIPCHK(hipMemset2DAsync((char *)y + (size_t)f * y_fstride * ds, (size_t)pl->y_ld * ds, 0, (size_t)pl->i_count * ds, pl->oN, s));
+        }
         if (pl->no_fallback) return hip_rc(launch_tile(t, z.dtype, pl->ntiles, s));     // one launch per frame (+ the reduce of a split aperture)
         HIPCHK(hipMemsetAsync(pl->fallback, 0, sizeof(uint32_t), s));
         HIPCHK(launch_tile(t, z.dtype, pl->ntiles, s));

@@ -55,6 +55,8 @@ struct TileParams {
     int32_t wz_log2;                    // wave footprint inside the tile: (1 << wz_log2) pixels of I1 x (64 >> wz_log2) columns; <= tz_log2
     int32_t probe;                      // 1: stop after the window-fit test (plan-time shape selection; only fallback_list is written)
     uint32_t tiles_z, tiles_x, tile_x0; // tile grid over (I1 >> tz_log2) x (columns / tile columns); first column tile of the shard
+    int32_t syn;                        // 1: 'SYN' -- keep the receive dimension: y is I x N planes (leading dimension y_ld), zero-filled by the host
+    uint64_t y_ld;
     int32_t fb2;                        // 1: two frames per launch (x, x + x_fstride -> y, y + y_fstride); never with sym
     uint64_t x_fstride, y_fstride;      // frame strides: BYTES of x, ELEMENTS of y
     uint32_t ksplit;                    // workgroups per tile (>= 1): each sums a slice of the aperture into part[], then reduced into y

@@ -103,12 +103,15 @@ def test_keep_modes(fun):
     case = make_case(seq="PW", interp="linear", seed=4, N=8, M=5, I1=40, I2=6)
     ref = run_oracle(case, fun=fun)
     out, plan = run_das(case, fun=fun)
-    assert plan.kernel == "generic"
+    assert plan.kernel == ("tiled" if fun == "SYN" else "generic")       # 'SYN' with fp32 data: planes accumulated by the tiled kernel
     assert out.shape == ref.shape
     assert rel_err(out, ref) <= TOL32
+    gen, _ = run_das(case, fun=fun, kernel=1)
+    assert rel_err(gen, ref) <= TOL32
     # identity: summing the kept dimensions reproduces 'DAS' (kern/das_spec.m:263-269)
     das, _ = run_das(case, fun="DAS", kernel=1)
-    assert rel_err(out.sum(axis=(3, 4), keepdims=True), das) <= 1e-5
+    assert rel_err(gen.sum(axis=(3, 4), keepdims=True), das) <= 1e-5        # same kernel: summation order only
+    assert rel_err(out.sum(axis=(3, 4), keepdims=True), das) <= TOL32
 
 
 def test_bf_transposed_output_order():
@@ -345,7 +348,7 @@ def test_error_paths():
     with pytest.raises(DasError, match="Apodization data size inconsistent with receiver"):
         das_spec("DAS", *args, "apod", np.ones((1, 1, 1, 5, 1)))
     with pytest.raises(_lib.QdasError, match="tiled kernel"):
-        das_spec("SYN", *args, kernel=2)
+        das_spec("MUL", *args, kernel=2)
 
 
 def test_reciprocal_mode_matches_general_mode(monkeypatch):
@@ -556,3 +559,57 @@ def test_frame_pairs_share_one_launch(seq, interp, prec, extra, F, monkeypatch):
         else:
             assert np.abs(ya[f] - ref).max() / den <= tol, (f, np.abs(ya[f] - ref).max() / den)
             assert np.abs(ya[f] - yb[f]).max() / den <= tol
+
+
+@pytest.mark.parametrize("seq,interp,extra", [("PW", "cubic", {}), ("FSA", "lanczos3", {}), ("DV", "linear", {"wtab": True}),
+                                              ("PW", "cubic", {"wpix": True}), ("PW", "lanczos3", {"ks": 4}), ("FC", "cubic", {"fmod": 2.0e6}),
+                                              ("PW", "cubic", {"F": 3}), ("PW", "linear", {"shard": True})])
+def test_syn_mode_in_the_tiled_kernel(seq, interp, extra, monkeypatch):
+    """'SYN' (keep the receive dimension, kern/das_spec.m:263-269): I x N planes accumulated by the tiled kernel, with weight tables,
+    pixel x receiver masks, a split aperture, frames, shards writing into a full-size buffer"""
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd.das_spec import _cast_data, _colmajor
+    from oracle import das_oracle as O
+    N = 16
+    F = extra.get("F", 1)
+    case = make_case(seq=seq, interp=interp, seed=81, N=N, I1=150, I2=21, zlim=(4e-3, 15e-3), xspan=3e-3, data="noise")
+    M = case["M"]
+    rng = np.random.default_rng(82)
+    xs = np.stack([case["x"]] + [(rng.standard_normal(case["x"].shape) + 1j * rng.standard_normal(case["x"].shape)).astype(np.complex64)
+                                 for _ in range(F - 1)], axis=3)
+    apod = []
+    if extra.get("wtab"):
+        a = f32r(rng.uniform(0, 1, (1, 1, 1, 1, M)))
+        a[..., 1] = 0.0
+        apod.append(a * (1 + 0.5j))
+        apod.append(f32r(rng.uniform(0.5, 1, (1, 1, 1, N, 1))))
+    if extra.get("wpix"):
+        a = f32r(rng.uniform(0, 1, (150, 21, 1, N, 1)) > 0.4)
+        a[:40] = 0.0
+        apod.append(a)
+    fmod = float(np.float32(extra.get("fmod", 0.0)))
+    if "ks" in extra:
+        monkeypatch.setenv("QDAS_KSPLIT", str(extra["ks"]))
+    opts = list(case["opt"]) + ["interp", interp, "modulation", fmod]
+    for a in apod:
+        opts += ["apod", a]
+    xt = torch.from_numpy(np.ascontiguousarray(xs))
+    prob = build_problem("SYN", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"],
+                         parse_options(xt, opts))
+    xc = _colmajor(_cast_data(xt, prob.prec, torch.device("cuda:0")))
+    I = 150 * 21
+    kw = dict(i_begin=I // 3, i_count=I // 2) if extra.get("shard") else {}
+    plan = DasPlan(prob, kernel=2, **kw)
+    y = plan.execute_colmajor(xc, F)                               # (F, 1, N, count)
+    torch.cuda.synchronize()
+    assert plan.kernel == "tiled" and tuple(y.shape)[:3] == (F, 1, N)
+    out = y.cpu().numpy()
+    for f in range(F):
+        ref = O.das_spec("SYN", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs[..., f], case["t0"], case["fs"], cinv_f32(case["c"]),
+                         VS=case["VS"], DV=case["DV"], interp=interp, apod=tuple(apod), fmod=fmod)          # I1 x I2 x 1 x N x 1
+        ref = ref.reshape(I, N, order="F")
+        if kw:
+            ref = ref[kw["i_begin"]: kw["i_begin"] + kw["i_count"]]
+        got = out[f, 0].T                                          # count x N
+        assert np.abs(got - ref).max() / np.abs(ref).max() <= (1e-4 if seq == "FC" else 3e-5)
