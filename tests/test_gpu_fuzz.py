@@ -26,11 +26,13 @@ def _draw(seed):
                prec=str(r.choice(["single", "single", "halfT"])), data=str(r.choice(["targets", "noise"])),
                t0vec=bool(r.integers(0, 3) == 0), wn=bool(r.integers(0, 3) == 0), wm=bool(r.integers(0, 3) == 0),
                wpix=bool(r.integers(0, 3) == 0), shard=bool(r.integers(0, 3) == 0),
-               tz=int(r.choice([0, 0, 64, 32, 16, 8])), ks=int(r.choice([0, 0, 1, 2, 3, 4])))
+               tz=int(r.choice([0, 0, 64, 32, 16, 8])), ks=int(r.choice([0, 0, 1, 2, 3, 4])),
+               fun=str(r.choice(["DAS", "DAS", "SYN"])), F=int(r.choice([1, 1, 2, 3])), cmap=bool(r.integers(0, 4) == 0),
+               gen=str(r.choice(["", "", "", "acceptance", "cosine", "fnumber"])))
     return r, cfg
 
 
-@pytest.mark.parametrize("seed", range(96))
+@pytest.mark.parametrize("seed", range(128))
 def test_tiled_kernel_random_configuration(seed, monkeypatch):
     import torch
     from qups_amd import DasPlan, build_problem, parse_options
@@ -59,45 +61,69 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
         a = q(r.uniform(0, 1, (c["I1"], c["I2"], 1, N, 1)) > 0.4)
         a[: c["I1"] // 3] = 0.0
         apod.append(a)
+    fun = c["fun"] if c["prec"] == "single" else "DAS"                # 'SYN' is fused for fp32 data only
+    F = c["F"]
+    xs_all = [x] + [(r.standard_normal(x.shape) + 1j * r.standard_normal(x.shape)).astype(np.complex64) for _ in range(F - 1)]
+    if c["prec"] == "halfT":
+        xs_all = [(v.real.astype(np.float16).astype(np.float32) + 1j * v.imag.astype(np.float16).astype(np.float32)).astype(np.complex64) for v in xs_all]
+    cval = case["c"]
+    c_or = cinv_f32(case["c"])
+    if c["cmap"]:                                                        # smooth per-pixel sound-speed map
+        zz, xx = np.meshgrid(np.linspace(0, 1, c["I1"]), np.linspace(0, 1, c["I2"]), indexing="ij")
+        f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+        cval = f32(1.0 / f32(1.0 / (1540.0 + 20.0 * np.sin(1.9 * zz + 0.3) * np.cos(1.3 * xx))))[:, :, None]
+        c_or = 1.0 / f32(1.0 / cval)
+    gen_spec = None
+    if c["gen"] and not (c["wpix"] and N > 1):
+        from qups_amd import apodization as A
+        from qups_amd import geometry as G
+        nrm = np.asarray(G.linear_array(N, 0.3e-3)[1], np.float32).astype(np.float64)
+        kw = dict(theta=35.0) if c["gen"] != "fnumber" else dict(f=1.0, Dmax=5e-3)
+        gen_spec = A.rx_apod_spec(c["gen"], normals=nrm, **kw)
+        gen_arr = {"acceptance": lambda: A.ap_acceptance_angle(case["Pi"], case["Pr"], nrm, 35.0),
+                   "cosine": lambda: A.ap_cosine_angle(case["Pi"], case["Pr"], nrm, 35.0),
+                   "fnumber": lambda: A.ap_aperture_growth(case["Pi"], case["Pr"], nrm, 1.0, 5e-3)}[c["gen"]]()
     if c["tz"]:
         monkeypatch.setenv("QDAS_TILE_Z", str(c["tz"]))
     if c["ks"]:
         monkeypatch.setenv("QDAS_KSPLIT", str(c["ks"]))
-    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], x, t0, case["fs"], cinv_f32(case["c"]),
-                     VS=case["VS"], DV=case["DV"], interp=c["interp"], apod=tuple(apod), fmod=c["fmod"])
-    xs = np.swapaxes(x, 1, 2) if c["tpose"] else x
+    xs = np.stack([np.swapaxes(v, 1, 2) if c["tpose"] else v for v in xs_all], axis=3)
     opts = list(case["opt"]) + ["interp", c["interp"], "input-precision", c["prec"], "modulation", c["fmod"], "transpose", c["tpose"]]
     for a in apod:
         opts += ["apod", a]
+    if gen_spec is not None:
+        opts += ["rx-apod", gen_spec]
     I = c["I1"] * c["I2"]
     kw = {}
     if c["shard"] and I >= 3:
         kw = dict(i_begin=I // 3, i_count=I - I // 3 - I // 4)
     xt = torch.from_numpy(np.ascontiguousarray(xs))
     po = parse_options(xt, opts)
-    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), t0, case["fs"], case["c"], po)
+    prob = build_problem(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), t0, case["fs"], cval, po)
     plan = DasPlan(prob, kernel=2, **kw)
     xc = _colmajor(_cast_data(xt, prob.prec, plan.device))
-    y = plan.execute_colmajor(xc, 1)
+    y = plan.execute_colmajor(xc, F)                                    # (F, oM, oN, count)
     torch.cuda.synchronize()
-    out = y.to(torch.complex64).cpu().numpy().reshape(-1)
+    outs = y.to(torch.complex64).cpu().numpy()
     assert plan.kernel == "tiled", c
-    refv = ref.reshape(-1, order="F")
-    if kw:
-        refv = refv[kw["i_begin"]: kw["i_begin"] + kw["i_count"]]
-    den = np.abs(ref).max()
-    if den == 0:
-        assert np.abs(out).max() == 0, c
-        return
-    err = np.abs(out - refv).max() / den
-    if c["interp"] == "nearest":
-        # discontinuous in tau: an fp32 rounding of tau*fs across a half-integer swaps ONE of the N*M samples of a pixel; such
-        # pixels are rare, the others agree to rounding
-        bad = np.abs(out - refv) / den > (3e-3 if c["prec"] == "halfT" else 1e-4)
-        assert bad.mean() <= 0.05, (seed, c, float(bad.mean()))
-        return
-    if c["prec"] == "halfT":
-        tol = 3e-3
-    else:
-        tol = 1e-4                      # covers tiles that fell back to the generic kernel (fp32 delays)
-    assert err <= tol, (seed, c, plan.tile_shape(), plan.wave_shape(), plan.aperture_split(), plan.fallback_tiles(), err)
+    oapod = tuple(apod) + ((gen_arr,) if gen_spec is not None else ())
+    for f in range(F):
+        ref = O.das_spec(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs_all[f], t0, case["fs"], c_or,
+                         VS=case["VS"], DV=case["DV"], interp=c["interp"], apod=oapod, fmod=c["fmod"])
+        refv = ref.reshape(I, -1, order="F")                              # pixels x planes
+        if kw:
+            refv = refv[kw["i_begin"]: kw["i_begin"] + kw["i_count"]]
+        out = outs[f].reshape(refv.shape[1], -1).T                        # (planes, count) -> count x planes
+        den = np.abs(ref).max()
+        if den == 0:
+            assert np.abs(out).max() == 0, c
+            continue
+        err = np.abs(out - refv).max() / den
+        if c["interp"] == "nearest" or (gen_spec is not None and c["gen"] != "cosine"):
+            # discontinuous in tau (nearest) or in the geometry (binary masks): a rounding at the step swaps ONE of the N*M
+            # samples of a pixel / one receiver; such pixels are rare, the others agree to rounding
+            bad = np.abs(out - refv) / den > (3e-3 if c["prec"] == "halfT" else 1e-4)
+            assert bad.mean() <= 0.05, (seed, c, float(bad.mean()))
+            continue
+        tol = 3e-3 if c["prec"] == "halfT" else 1e-4                      # covers tiles that fell back to the generic kernel (fp32 delays)
+        assert err <= tol, (seed, c, f, plan.tile_shape(), plan.wave_shape(), plan.aperture_split(), plan.fallback_tiles(), err)
