@@ -296,7 +296,11 @@ das_tile_kernel(const TileParams P) {
         px = P.Pi[3 * i]; py = P.Pi[3 * i + 1]; pz = P.Pi[3 * i + 2];
         if (P.cinv_pix) cf = (double)P.cinv_pix[i] * fs;
     }
-    const bool VS = P.VS, DV = P.DV;
+    // Delay model of the BLOCK elements (the MB "transmits" of a stage) and of the STAGE elements (its "receiver"):
+    // 0 = distance, 1 = signed distance (focused wave: copysign by the normal, src/bf.cu:106-108), 2 = plane wave (dot product).
+    // 'DAS' / 'SYN': block = transmits (kind from VS / DV), stage = receivers (distance).  'MUL' (keep the transmit dimension) runs
+    // the same kernel with the roles swapped by the host: block = receivers, stage = transmits -- tables, strides and kinds swap.
+    const int kindB = P.kindB, kindS = P.kindS;
 
     // sqrt in fp64 from an fp32 seed + one Newton step (rel. error ~1e-14; v_sqrt_f32 is 1 ulp)
     auto dsqrt = [](double d2) -> double {
@@ -312,14 +316,23 @@ das_tile_kernel(const TileParams P) {
     const float *gPv = P.Pv, *gNv = P.Nv;
     auto a_of = [&](uint32_t m) -> double {              // tau_tx*fs - t0*fs + OFF, reference src/bf.cu:104-108,114
         const double rx = (double)px - (double)gPv[4 * m], ry = (double)py - (double)gPv[4 * m + 1], rz = (double)pz - (double)gPv[4 * m + 2];
-        const double dot = rx * (double)gNv[3 * m] + ry * (double)gNv[3 * m + 1] + rz * (double)gNv[3 * m + 2];
+        const double dot = kindB ? rx * (double)gNv[3 * m] + ry * (double)gNv[3 * m + 1] + rz * (double)gNv[3 * m + 2] : 0.0;
         double dv = dot;
-        if (VS) { const double len = dsqrt(rx * rx + ry * ry + rz * rz); dv = DV ? len : copysign(len, dot); }
+        if (kindB != 2) { const double len = dsqrt(rx * rx + ry * ry + rz * rz); dv = kindB == 0 ? len : copysign(len, dot); }
         return dv * cf - (double)gPv[4 * m + 3] * fs + tapinfo<INTERP>::OFF;
     };
     auto b_at = [&](float ex, float ey, float ez) -> double {      // tau_rx*fs for a receiver at (ex,ey,ez), reference src/bf.cu:110
         const double rx = (double)px - (double)ex, ry = (double)py - (double)ey, rz = (double)pz - (double)ez;
         return dsqrt(rx * rx + ry * ry + rz * rz) * cf;
+    };
+    // delay of STAGE element n at (ex,ey,ez): a receiver (kind 0), or -- roles swapped -- a transmit with {t0, normal} in P.St (scalar loads)
+    auto s_at = [&](uint32_t n, float ex, float ey, float ez) -> double {
+        if (!P.St) return b_at(ex, ey, ez);
+        const double rx = (double)px - (double)ex, ry = (double)py - (double)ey, rz = (double)pz - (double)ez;
+        const double dot = kindS ? rx * (double)P.St[4 * n + 1] + ry * (double)P.St[4 * n + 2] + rz * (double)P.St[4 * n + 3] : 0.0;
+        double dv = dot;
+        if (kindS != 2) { const double len = dsqrt(rx * rx + ry * ry + rz * rz); dv = kindS == 0 ? len : copysign(len, dot); }
+        return dv * cf - (double)P.St[4 * n] * fs;
     };
 
     // ---- prologue: tile-wide window bases / extents per transmit and per receiver
@@ -331,17 +344,20 @@ das_tile_kernel(const TileParams P) {
     // The window bases / extents only need the delays to a small fraction of a sample: fp32 estimates with an explicit error
     // margin (DLT, below) -- a quarter of the fp64 cost.  Focused transmits keep fp64: their delay flips sign with
     // (Pi - Pv).Nv (copysign, src/bf.cu:107) and the two precisions must agree on the sign of a dot product that may be ~0.
-    const bool pro32 = !(VS && !DV);
+    const bool pro32 = kindB != 1 && kindS != 1;
     const float cf32 = (float)cf, fs32 = (float)fs;
     auto a_est = [&](uint32_t m) -> float {
         if (!pro32) return (float)a_of(m);
         const float rx = px - gPv[4 * m], ry = py - gPv[4 * m + 1], rz = pz - gPv[4 * m + 2];
-        const float d = VS ? __builtin_sqrtf(rx * rx + ry * ry + rz * rz) : rx * gNv[3 * m] + ry * gNv[3 * m + 1] + rz * gNv[3 * m + 2];
+        const float d = kindB != 2 ? __builtin_sqrtf(rx * rx + ry * ry + rz * rz) : rx * gNv[3 * m] + ry * gNv[3 * m + 1] + rz * gNv[3 * m + 2];
         return d * cf32 - gPv[4 * m + 3] * fs32 + (float)tapinfo<INTERP>::OFF;
     };
     auto b_est = [&](uint32_t n) -> float {
+        if (kindS == 1) return (float)s_at(n, P.Pr[3 * n], P.Pr[3 * n + 1], P.Pr[3 * n + 2]);
         const float rx = px - P.Pr[3 * n], ry = py - P.Pr[3 * n + 1], rz = pz - P.Pr[3 * n + 2];
-        return __builtin_sqrtf(rx * rx + ry * ry + rz * rz) * cf32;
+        if (!P.St) return __builtin_sqrtf(rx * rx + ry * ry + rz * rz) * cf32;
+        if (kindS == 0) return __builtin_sqrtf(rx * rx + ry * ry + rz * rz) * cf32 - P.St[4 * n] * fs32;
+        return (rx * P.St[4 * n + 1] + ry * P.St[4 * n + 2] + rz * P.St[4 * n + 3]) * cf32 - P.St[4 * n] * fs32;
     };
     // |fp32 estimate - fp64 delay| <= ~4e-7 * (|distance*cf| + |t0*fs|), and |distance*cf| <= |a| + |t0*fs| + 1: 1e-6 is generous
     auto margin = [](float mn, float mx, float t0fs) -> float { return 1.0e-6f * (fmaxf(fabsf(mn), fabsf(mx)) + 2.0f * fabsf(t0fs) + 2.0f); };
@@ -391,7 +407,7 @@ das_tile_kernel(const TileParams P) {
         float mn = part[n], mx = part[WAVES * MX + n];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + n]); mx = fmaxf(mx, part[(WAVES + w) * MX + n]); }
-        const float dlt = margin(mn, mx, SYM ? P.Pv[3] * fs32 : 0.f);
+        const float dlt = margin(mn, mx, SYM ? P.Pv[3] * fs32 : (P.St ? P.St[4 * n] * fs32 : 0.f));
         const float fl = floorf(mn - dlt) - 1.0f;
         const bool fin = fabsf(fl) < 1.0e9f;
         const float e = fin ? ((mx + dlt) - fl) + 0.01f : INFINITY;
@@ -623,7 +639,7 @@ das_tile_kernel(const TileParams P) {
 #endif
             if (!skip) {
             const int bn = __float_as_int(rec.x);
-            const float rb = (QDAS_ABL & 2) ? (float)(lane * 2 + 3) + 0.37f * (float)(n & 7) : (float)(b_at(rec.y, rec.z, rec.w) - (double)bn);
+            const float rb = (QDAS_ABL & 2) ? (float)(lane * 2 + 3) + 0.37f * (float)(n & 7) : (float)(s_at(n, rec.y, rec.z, rec.w) - (double)bn);
             // LDS byte address of a tap = bits(t + MAGIC)*SB + cbase + (window, tap) immediate
             const uint32_t cbase = win_off + (uint32_t)buf * (NW * WB) - (MAGIC_BITS * (uint32_t)SB);
 

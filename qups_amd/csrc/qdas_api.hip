@@ -309,9 +309,13 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
 
     // ---- kernel selection
     // modes: 'DAS' (sum both apertures), and with fp32 data 'SYN' (keep the receive dimension: a plane per receiver)
-    const bool syn = (z.flag & QDAS_FLAG_KEEP_RX) && !(z.flag & QDAS_FLAG_KEEP_TX);
-    bool eligible = (dt == QDAS_F32 || dt == QDAS_F16) && !(z.flag & QDAS_FLAG_KEEP_TX) && (!syn || dt == QDAS_F32);
-    const char *why = "tiled kernel needs fp32/fp16 data and the 'DAS' mode (or fp32 data and 'SYN')";
+    // and 'MUL' (keep the transmit dimension: the same kernel with the roles of the two apertures swapped)
+    const bool mul = (z.flag & QDAS_FLAG_KEEP_TX) && !(z.flag & QDAS_FLAG_KEEP_RX);
+    const bool syn = ((z.flag & QDAS_FLAG_KEEP_RX) && !(z.flag & QDAS_FLAG_KEEP_TX)) || mul;      // one output plane per STAGE element
+    bool eligible = (dt == QDAS_F32 || dt == QDAS_F16) && !((z.flag & QDAS_FLAG_KEEP_TX) && (z.flag & QDAS_FLAG_KEEP_RX)) && (!syn || dt == QDAS_F32);
+    const char *why = "tiled kernel needs fp32/fp16 data and the 'DAS' mode (or fp32 data and 'SYN' / 'MUL')";
+    // stage / block element counts of the kernel (das_tile_impl.h): receivers / transmits, swapped for 'MUL'
+    const uint64_t kN = mul ? z.M : z.N, kM = mul ? z.N : z.M;
     // sound speed: a scalar, or a full per-pixel map (contiguous I1 x I2 x I3, no aperture dependence): the delay stays separable
     bool cmap = false;
     if (eligible && (g.cst[0] || g.cst[1] || g.cst[2] || g.cst[3] || g.cst[4])) {
@@ -334,6 +338,9 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     if (eligible && g.gen_kind && pix_arr >= 0) {
         eligible = false; why = "tiled kernel: a generated receive apodization and a pixel-dependent array need the generic kernel";
     }
+    if (eligible && mul && (pix_arr >= 0 || g.gen_kind)) {
+        eligible = false; why = "tiled kernel: 'MUL' with a pixel x receiver apodization needs the generic kernel";
+    }
     // reciprocal mode (das_tile_impl.h "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
     // elements and share one t0 has tau(n,m) == tau(m,n); detected from the geometry itself, bit-exactly.
     int sym = 0;
@@ -347,13 +354,14 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (sym && (z.M % tile_config(dt, 1).mb != 0 || tile_lds_bytes(dt, 1, z.N, z.M) > tile_lds_limit(1))) sym = 0;
     }
     pl->tc = tile_config(dt, sym);
-    if (eligible && tile_lds_bytes(dt, sym, z.N, z.M) > tile_lds_limit(sym)) {
+    if (eligible && tile_lds_bytes(dt, sym, kN, kM) > tile_lds_limit(sym)) {
         eligible = false; why = "tiled kernel: N + M too large for the LDS header";
     }
     if (eligible && (z.T < 8)) { eligible = false; why = "tiled kernel needs T >= 8"; }
     {   // LDS-DMA offsets inside one transmit block are 32-bit: N receivers + mb transmits + a window must stay below 2^31 bytes
-        const uint64_t strM = (z.flag & QDAS_FLAG_TPOSE) ? z.T : z.T * z.N;
-        const uint64_t strN = (z.flag & QDAS_FLAG_TPOSE) ? z.T * z.M : z.T;
+        uint64_t strM = (z.flag & QDAS_FLAG_TPOSE) ? z.T : z.T * z.N;
+        uint64_t strN = (z.flag & QDAS_FLAG_TPOSE) ? z.T * z.M : z.T;
+        if (mul) std::swap(strM, strN);
         const uint64_t lim = 1ull << 31, slack = 65536;
         // mirror traces of the reciprocal mode walk the other way (N "transmits" apart): drop the mode for >2 GiB frames
         if (sym && (z.N * strM + (uint64_t)tile_config(dt, 1).mb * strN) * data_size(dt) + slack >= lim) {
@@ -361,7 +369,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             pl->tc = tile_config(dt, 0);
             if (eligible && tile_lds_bytes(dt, 0, z.N, z.M) > tile_lds_limit(0)) { eligible = false; why = "tiled kernel: N + M too large for the LDS header"; }
         }
-        if (eligible && (z.N * strN + (uint64_t)pl->tc.mb * strM) * data_size(dt) + slack >= lim) {
+        if (eligible && (kN * strN + (uint64_t)pl->tc.mb * strM) * data_size(dt) + slack >= lim) {
             eligible = false; why = "tiled kernel: trace strides too large for 32-bit DMA offsets (transposed data of more than 2 GiB)";
         }
     }
@@ -370,12 +378,35 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
 
     if (pl->kernel == QDAS_KERNEL_TILED) {
         TileParams &t = pl->tp;
-        t.Pi = (const float *)g.Pi; t.Pr = (const float *)g.Pr; t.Pv = (const float *)g.Pv; t.Nv = (const float *)g.Nv;
+        t.Pi = (const float *)g.Pi; t.Pr = (const float *)g.Pr; t.Pv = (const float *)g.Pv; t.Nv = (const float *)g.Nv; t.St = nullptr;
         t.T = z.T; t.N = z.N; t.M = z.M; t.I1 = z.I1; t.I2 = z.I2; t.I3 = z.I3;
         t.i_begin = desc->i_begin; t.i_count = pl->i_count;
         const bool tp = z.flag & QDAS_FLAG_TPOSE;
         t.strN = tp ? z.T * z.M : z.T;                  // reference src/bf.cu:100
         t.strM = tp ? z.T : z.T * z.N;
+        const int txkind = z.VS ? (z.DV ? 0 : 1) : 2;   // distance | signed distance | plane wave
+        t.kindB = txkind; t.kindS = 0;
+        if (mul) {                                      // roles swapped: stage elements = transmits, block elements = receivers
+            std::vector<float> hr(3 * z.N), hv(4 * z.M), hn(3 * z.M);
+            if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
+            if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);
+            if ((rc = fetch_host(desc->Nv, hn.size() * 4, desc->mem, hn.data()))) return bail(rc);
+            std::vector<float> spos(3 * z.M), sst(4 * z.M), bpos(4 * z.N), bnrm(3 * z.N, 0.f);
+            for (uint64_t m = 0; m < z.M; ++m) {
+                for (int k = 0; k < 3; ++k) { spos[3 * m + k] = hv[4 * m + k]; sst[4 * m + 1 + k] = hn[3 * m + k]; }
+                sst[4 * m] = hv[4 * m + 3];
+            }
+            for (uint64_t n = 0; n < z.N; ++n) { for (int k = 0; k < 3; ++k) bpos[4 * n + k] = hr[3 * n + k]; bpos[4 * n + 3] = 0.f; }
+            const void *d0, *d1, *d2, *d3;
+            if ((rc = import_array(pl, spos.data(), spos.size() * 4, QDAS_MEM_HOST, &d0))) return bail(rc);
+            if ((rc = import_array(pl, sst.data(), sst.size() * 4, QDAS_MEM_HOST, &d1))) return bail(rc);
+            if ((rc = import_array(pl, bpos.data(), bpos.size() * 4, QDAS_MEM_HOST, &d2))) return bail(rc);
+            if ((rc = import_array(pl, bnrm.data(), bnrm.size() * 4, QDAS_MEM_HOST, &d3))) return bail(rc);
+            t.Pr = (const float *)d0; t.St = (const float *)d1; t.Pv = (const float *)d2; t.Nv = (const float *)d3;
+            t.N = z.M; t.M = z.N;
+            std::swap(t.strN, t.strM);
+            t.kindB = 0; t.kindS = txkind;
+        }
         float cinv0;
         if ((rc = fetch_host(desc->cinv, sizeof(float), desc->mem, &cinv0))) return bail(rc);
         t.fs = g.fs; t.fmod = g.fmod;
@@ -426,7 +457,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
                         if (desc->apod_real) ar = dt == QDAS_F32 ? ((const float *)raw.data())[k] : half_to_float(((const uint16_t *)raw.data())[k]);
                         else if (dt == QDAS_F32) { ar = ((const float *)raw.data())[2 * k]; ai = ((const float *)raw.data())[2 * k + 1]; }
                         else { ar = half_to_float(((const uint16_t *)raw.data())[2 * k]); ai = half_to_float(((const uint16_t *)raw.data())[2 * k + 1]); }
-                        float &tr = tab[2 * (n + z.N * m)], &ti = tab[2 * (n + z.N * m) + 1];
+                        const size_t q = mul ? (m + z.M * n) : (n + z.N * m);        // [stage element + stages * block element]
+                        float &tr = tab[2 * q], &ti = tab[2 * q + 1];
                         const float nr = tr * ar - ti * ai, ni = tr * ai + ti * ar;
                         tr = nr; ti = ni;
                     }
@@ -445,7 +477,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device));
             const unsigned cus = ncu > 0 ? (unsigned)ncu : 256u;
             const uint64_t nmb = (z.M + pl->tc.mb - 1) / pl->tc.mb;
-            const unsigned cap = (unsigned)std::min<uint64_t>(8, sym ? nmb : z.N);
+            const unsigned cap = (unsigned)std::min<uint64_t>(8, sym ? nmb : kN);
             unsigned ks = 1;
             while (ks * 2 <= cap && (uint64_t)pl->ntiles * ks < (uint64_t)cus) ks *= 2;   // (a split costs one more prologue per tile)
             if (const char *e = getenv("QDAS_KSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8 && (unsigned)v <= cap) ks = (unsigned)v; }
@@ -522,7 +554,7 @@ static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s, int n
         if (t.syn) {                                    // planes are accumulated with atomics: start from zero
             const size_t ds = data_size(z.dtype);        // (only this plan's pixels of every plane: y_ld may span a full-size buffer)
             for (int f = 0; f < nf; ++f)
-                HIPCHK(hipMemset2DAsync((char *)y + (size_t)f * y_fstride * ds, (size_t)pl->y_ld * ds, 0, (size_t)pl->i_count * ds, pl->oN, s));
+                HIPCHK(hipMemset2DAsync((char *)y + (size_t)f * y_fstride * ds, (size_t)pl->y_ld * ds, 0, (size_t)pl->i_count * ds, pl->oN * pl->oM, s));
         }
         if (pl->no_fallback) return hip_rc(launch_tile(t, z.dtype, pl->ntiles, s));     // one launch per frame (+ the reduce of a split aperture)
         HIPCHK(hipMemsetAsync(pl->fallback, 0, sizeof(uint32_t), s));

@@ -34,7 +34,11 @@ hipError_t launch_delays(const GenericParams &P, int dtype, void *tau, double ci
 
 // ---- tiled kernel (das_tile_impl.h)
 struct TileParams {
-    const float *Pi, *Pr, *Pv, *Nv;     // fp32 geometry (QDAS_F32 / QDAS_F16 only)
+    // fp32 geometry (QDAS_F32 / QDAS_F16 only).  Pv (4 x M: position, t0) and Nv (3 x M) describe the BLOCK elements of a stage,
+    // Pr (3 x N) and -- when kindS != 0 -- St (4 x N: t0, normal) the STAGE elements; kindB / kindS: 0 distance, 1 signed distance,
+    // 2 plane wave.  'DAS' / 'SYN': block = transmits, stage = receivers; 'MUL': roles (and N, M, strN, strM, wtab) swapped by the host.
+    const float *Pi, *Pr, *Pv, *Nv, *St;
+    int32_t kindB, kindS;
     const void *x;
     void *y;
     const void *wtab;                   // optional N x M table of folded apodization weights (float2), may be null

@@ -27,7 +27,7 @@ def _draw(seed):
                t0vec=bool(r.integers(0, 3) == 0), wn=bool(r.integers(0, 3) == 0), wm=bool(r.integers(0, 3) == 0),
                wpix=bool(r.integers(0, 3) == 0), shard=bool(r.integers(0, 3) == 0),
                tz=int(r.choice([0, 0, 64, 32, 16, 8])), ks=int(r.choice([0, 0, 1, 2, 3, 4])),
-               fun=str(r.choice(["DAS", "DAS", "SYN"])), F=int(r.choice([1, 1, 2, 3])), cmap=bool(r.integers(0, 4) == 0),
+               fun=str(r.choice(["DAS", "DAS", "SYN", "MUL"])), F=int(r.choice([1, 1, 2, 3])), cmap=bool(r.integers(0, 4) == 0),
                gen=str(r.choice(["", "", "", "acceptance", "cosine", "fnumber"])))
     return r, cfg
 
@@ -61,7 +61,9 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
         a = q(r.uniform(0, 1, (c["I1"], c["I2"], 1, N, 1)) > 0.4)
         a[: c["I1"] // 3] = 0.0
         apod.append(a)
-    fun = c["fun"] if c["prec"] == "single" else "DAS"                # 'SYN' is fused for fp32 data only
+    fun = c["fun"] if c["prec"] == "single" else "DAS"                # 'SYN' / 'MUL' are fused for fp32 data only
+    if fun == "MUL" and ((c["wpix"] and N > 1) or c["gen"]):
+        fun = "SYN"                                                   # 'MUL' with pixel x receiver weights: generic kernel
     F = c["F"]
     xs_all = [x] + [(r.standard_normal(x.shape) + 1j * r.standard_normal(x.shape)).astype(np.complex64) for _ in range(F - 1)]
     if c["prec"] == "halfT":

@@ -103,7 +103,7 @@ def test_keep_modes(fun):
     case = make_case(seq="PW", interp="linear", seed=4, N=8, M=5, I1=40, I2=6)
     ref = run_oracle(case, fun=fun)
     out, plan = run_das(case, fun=fun)
-    assert plan.kernel == ("tiled" if fun == "SYN" else "generic")       # 'SYN' with fp32 data: planes accumulated by the tiled kernel
+    assert plan.kernel == ("generic" if fun == "BF" else "tiled")        # 'SYN' / 'MUL' with fp32 data: planes accumulated by the tiled kernel
     assert out.shape == ref.shape
     assert rel_err(out, ref) <= TOL32
     gen, _ = run_das(case, fun=fun, kernel=1)
@@ -348,7 +348,7 @@ def test_error_paths():
     with pytest.raises(DasError, match="Apodization data size inconsistent with receiver"):
         das_spec("DAS", *args, "apod", np.ones((1, 1, 1, 5, 1)))
     with pytest.raises(_lib.QdasError, match="tiled kernel"):
-        das_spec("MUL", *args, kernel=2)
+        das_spec("BF", *args, kernel=2)
 
 
 def test_reciprocal_mode_matches_general_mode(monkeypatch):
@@ -564,13 +564,16 @@ def test_frame_pairs_share_one_launch(seq, interp, prec, extra, F, monkeypatch):
 @pytest.mark.parametrize("seq,interp,extra", [("PW", "cubic", {}), ("FSA", "lanczos3", {}), ("DV", "linear", {"wtab": True}),
                                               ("PW", "cubic", {"wpix": True}), ("PW", "lanczos3", {"ks": 4}), ("FC", "cubic", {"fmod": 2.0e6}),
                                               ("PW", "cubic", {"F": 3}), ("PW", "linear", {"shard": True})])
-def test_syn_mode_in_the_tiled_kernel(seq, interp, extra, monkeypatch):
+@pytest.mark.parametrize("fun", ["SYN", "MUL"])
+def test_syn_mode_in_the_tiled_kernel(fun, seq, interp, extra, monkeypatch):
     """'SYN' (keep the receive dimension, kern/das_spec.m:263-269): I x N planes accumulated by the tiled kernel, with weight tables,
     pixel x receiver masks, a split aperture, frames, shards writing into a full-size buffer"""
     import torch
     from qups_amd import DasPlan, build_problem, parse_options
     from qups_amd.das_spec import _cast_data, _colmajor
     from oracle import das_oracle as O
+    if fun == "MUL" and extra.get("wpix"):
+        pytest.skip("'MUL' with a pixel x receiver array runs the generic kernel")
     N = 16
     F = extra.get("F", 1)
     case = make_case(seq=seq, interp=interp, seed=81, N=N, I1=150, I2=21, zlim=(4e-3, 15e-3), xspan=3e-3, data="noise")
@@ -595,21 +598,22 @@ def test_syn_mode_in_the_tiled_kernel(seq, interp, extra, monkeypatch):
     for a in apod:
         opts += ["apod", a]
     xt = torch.from_numpy(np.ascontiguousarray(xs))
-    prob = build_problem("SYN", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"],
+    prob = build_problem(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"],
                          parse_options(xt, opts))
     xc = _colmajor(_cast_data(xt, prob.prec, torch.device("cuda:0")))
     I = 150 * 21
     kw = dict(i_begin=I // 3, i_count=I // 2) if extra.get("shard") else {}
     plan = DasPlan(prob, kernel=2, **kw)
-    y = plan.execute_colmajor(xc, F)                               # (F, 1, N, count)
+    y = plan.execute_colmajor(xc, F)                               # (F, [M], [N], count)
     torch.cuda.synchronize()
-    assert plan.kernel == "tiled" and tuple(y.shape)[:3] == (F, 1, N)
-    out = y.cpu().numpy()
+    P = N if fun == "SYN" else M                                   # planes: one per receiver / per transmit
+    assert plan.kernel == "tiled" and tuple(y.shape)[:3] == ((F, 1, N) if fun == "SYN" else (F, M, 1))
+    out = y.cpu().numpy().reshape(F, P, -1)
     for f in range(F):
-        ref = O.das_spec("SYN", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs[..., f], case["t0"], case["fs"], cinv_f32(case["c"]),
+        ref = O.das_spec(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs[..., f], case["t0"], case["fs"], cinv_f32(case["c"]),
                          VS=case["VS"], DV=case["DV"], interp=interp, apod=tuple(apod), fmod=fmod)          # I1 x I2 x 1 x N x 1
-        ref = ref.reshape(I, N, order="F")
+        ref = ref.reshape(I, P, order="F")
         if kw:
             ref = ref[kw["i_begin"]: kw["i_begin"] + kw["i_count"]]
-        got = out[f, 0].T                                          # count x N
+        got = out[f].T                                             # count x planes
         assert np.abs(got - ref).max() / np.abs(ref).max() <= (1e-4 if seq == "FC" else 3e-5)
