@@ -74,11 +74,17 @@ struct qdas_plan {
     // host staging (mem == HOST)
     void *dx = nullptr, *dy = nullptr;
     size_t x_bytes = 0, y_bytes = 0;
+    // second staging set + copy stream: frame f+1 is uploaded while frame f is beamformed (host-resident frame sequences)
+    void *dx2 = nullptr, *dy2 = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ex[2] = {nullptr, nullptr}, ek[2] = {nullptr, nullptr};
 
     ~qdas_plan() {
         for (void *p : owned) (void)hipFree(p);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
+        for (int k = 0; k < 2; ++k) { if (ex[k]) (void)hipEventDestroy(ex[k]); if (ek[k]) (void)hipEventDestroy(ek[k]); }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
     }
 };
 
@@ -604,6 +610,38 @@ extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, u
     // frame pairs share one launch (device-resident data, tiled kernel, not the reciprocal mode; QDAS_NO_FB2 disables)
     const bool pairs_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->tp.sym && pl->d.mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2")
                           && x_stride * ds < (1ull << 40);
+    if (pl->d.mem == QDAS_MEM_HOST && F >= 2) {         // host frames: upload f+1 on the copy stream while f is beamformed
+        if (!pl->copy_stream) {
+            int rc;
+            if ((rc = dev_alloc(pl, &pl->dx2, pl->x_bytes)) || (rc = dev_alloc(pl, &pl->dy2, pl->y_bytes))) return rc;
+            HIPCHK(hipStreamCreateWithFlags(&pl->copy_stream, hipStreamNonBlocking));
+            for (int k = 0; k < 2; ++k) {
+                HIPCHK(hipEventCreateWithFlags(&pl->ex[k], hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&pl->ek[k], hipEventDisableTiming));
+            }
+        }
+        void *dxs[2] = {pl->dx, pl->dx2}, *dys[2] = {pl->dy, pl->dy2};
+        hipStream_t sc = pl->copy_stream;
+        HIPCHK(hipMemcpyAsync(dxs[0], x, pl->x_bytes, hipMemcpyHostToDevice, sc));
+        HIPCHK(hipEventRecord(pl->ex[0], sc));
+        for (uint64_t f = 0; f < F; ++f) {
+            const int b = (int)(f & 1), nb = b ^ 1;
+            HIPCHK(hipStreamWaitEvent(s, pl->ex[b], 0));
+            int rc = run_frame(pl, dxs[b], dys[b], s);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(pl->ek[b], s));
+            if (f + 1 < F) {                            // the other buffer's last reader was frame f-1
+                if (f >= 1) HIPCHK(hipStreamWaitEvent(sc, pl->ek[nb], 0));
+                HIPCHK(hipMemcpyAsync(dxs[nb], (const char *)x + (f + 1) * x_stride * ds, pl->x_bytes, hipMemcpyHostToDevice, sc));
+                HIPCHK(hipEventRecord(pl->ex[nb], sc));
+            }
+            HIPCHK(hipMemcpyAsync((char *)y + f * y_stride * ds, dys[b], pl->y_bytes, hipMemcpyDeviceToHost, s));
+        }
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipStreamSynchronize(sc));
+        if (pl->timing) { HIPCHK(hipEventRecord(pl->e1, s)); HIPCHK(hipEventSynchronize(pl->e1)); HIPCHK(hipEventElapsedTime(&pl->last_ms, pl->e0, pl->e1)); }
+        return QDAS_OK;
+    }
     for (uint64_t f = 0; f < F; ++f) {
         const char *xf = (const char *)x + f * x_stride * ds;
         char *yf = (char *)y + f * y_stride * ds;

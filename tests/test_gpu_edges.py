@@ -114,3 +114,42 @@ def test_very_short_record_and_huge_aperture_route_to_the_generic_kernel():
     assert rel_err(out, _oracle(big)) <= 1e-4
     with pytest.raises(_lib.QdasError, match="LDS header"):
         _run(big, kernel=2)
+
+
+@pytest.mark.parametrize("F", [1, 4])
+@pytest.mark.parametrize("seq", ["FSA", "PW"])
+def test_host_resident_inputs_through_the_c_abi(F, seq):
+    """QDAS_MEM_HOST (what the MEX shim passes): geometry, data and output are HOST arrays; the plan stages them -- frame
+    sequences double-buffered on a copy stream -- and must give what the device-resident path gives"""
+    import torch
+    from qups_amd import DasPlan, _lib, build_problem, parse_options
+    from qups_amd.das_spec import _cast_data, _colmajor
+    case = make_case(seq=seq, interp="cubic", seed=91, N=16, I1=140, I2=18, zlim=(4e-3, 15e-3), xspan=3e-3, data="noise")
+    r = np.random.default_rng(92)
+    xs = np.stack([case["x"]] + [(r.standard_normal(case["x"].shape) + 1j * r.standard_normal(case["x"].shape)).astype(np.complex64)
+                                 for _ in range(F - 1)], axis=3)
+    xt = torch.from_numpy(np.ascontiguousarray(xs))
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"],
+                         parse_options(xt, list(case["opt"]) + ["interp", "cubic"]))
+    # device-resident reference run
+    plan = DasPlan(prob, kernel=2)
+    yd = plan.execute_colmajor(_colmajor(_cast_data(xt, prob.prec, plan.device)), F)
+    torch.cuda.synchronize()
+    yd = yd.cpu().numpy().reshape(F, -1)
+    # host-resident run through ctypes
+    L = _lib.lib()
+    acs = (C.c_uint64 * len(prob.acstride))(*[int(v) for v in prob.acstride])
+    d = _lib.Desc()
+    d.sz = _lib.Sizes(prob.T, prob.N, prob.M, prob.Isz[0], prob.Isz[1], prob.Isz[2], prob.S, prob.flag, int(prob.VS), int(prob.DV), _lib.QDAS_F32)
+    d.fs, d.fmod = prob.fs, prob.fmod
+    keep = [np.ascontiguousarray(a) for a in (prob.Pi, prob.Pr, prob.Pv, prob.Nv, prob.cinv)]
+    d.Pi, d.Pr, d.Pv, d.Nv, d.cinv = (C.c_void_p(a.ctypes.data) for a in keep)
+    d.acstride, d.mem, d.device, d.kernel = acs, _lib.MEM_HOST, 0, _lib.KERNEL_TILED
+    h = C.c_void_p()
+    _lib.check(L.qdas_plan_create(C.byref(h), C.byref(d)))
+    xh = np.ascontiguousarray(xs.transpose(3, 2, 1, 0))               # (F, M, N, T): MATLAB memory order of T x N x M x F
+    I = prob.I
+    yh = np.full((F, I), 7 + 7j, np.complex64)
+    _lib.check(L.qdas_plan_execute_frames(h, C.c_void_p(xh.ctypes.data), C.c_void_p(yh.ctypes.data), F, prob.T * prob.N * prob.M, I, None))
+    L.qdas_plan_destroy(h)
+    assert np.abs(yh - yd).max() / np.abs(yd).max() <= 3e-5          # (frame pairs on the device path: another summation order)
