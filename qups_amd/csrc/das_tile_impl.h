@@ -1,49 +1,48 @@
 #pragma once
 // das_tile_impl.h -- the fused, LDS-staged delay-and-sum kernel for gfx950 (MI355X).
 //
-// Replaces the reference launch of `DASf` / `DASh` (reference src/bf.cu:153-171, body
-// src/bf.cu:49-142) for the bulk case: sum over both apertures ('DAS'), scalar sound speed,
-// apodization that does not depend on the pixel (folded by the host into one N x M table).
-// Everything else is served by das_generic.hip.
+// Replaces the reference launch of `DASf` / `DASh` (reference src/bf.cu:153-171, body src/bf.cu:49-142) for the bulk of the
+// work: 'DAS' (sum over both apertures) with fp32 / fp16 data, 'SYN' / 'MUL' (keep one aperture) with fp32 data; scalar sound
+// speed or a per-pixel map; pixel-independent apodization (folded by the host into one N x M table) plus one pixel x receiver
+// array or generated rule.  Everything else is served by das_generic.hip.  (Instantiated per launch configuration in
+// das_tile_{f32,sym,f16,f32x2,f16x2}.hip; dispatch in das_tile.hip.)
 //
 // Design (MI355X-first, not a re-tiling of the reference's one-thread-per-pixel loop):
 //
-//  * A workgroup owns a TILE of 64 (fast image axis I1 = depth) x TX (columns) pixels.  A wave's
-//    64 lanes are 64 consecutive depth pixels of one column, so for any trace (n, m) the lanes
-//    read neighbouring fast-time samples.  Two consecutive transmits (m, m+1) of the same pixel
-//    ride in the two halves of packed-fp32 (v_pk_*_f32) instructions (measured on MI355X: 5.2
-//    cycles per packed FMA vs 2 x 3.3 for two scalar FMAs -- profiles/microbench_r01.txt).
-//  * Time of flight is separable: tau*fs + off = a(i,m) + b(i,n).  The prologue computes, in
-//    fp64, tile-wide integer window bases A[m] <= a, B[n] <= b and extents; afterwards each lane
-//    only carries the small fp32 residuals ra = a - A[m] - 1/2, rb = b - B[n] (exact to ~1e-5
-//    sample; the reference's fp32 tau carries ~1e-4 sample at tau*fs ~ 2000).  Per pair:
+//  * A workgroup (16 waves) owns a TILE of 1024 pixels, 2^t (fast image axis I1 = depth) x 1024/2^t columns; a wave covers
+//    2^w x 64/2^w of them.  The plan probes the tile footprint (largest that fits the LDS window) and picks the wave footprint
+//    from an LDS bank model (8 x 8 pixels on a lambda/4 grid: the 32 lanes of an access group read <= 32 consecutive samples).
+//    Two consecutive transmits (m, m+1) of the same pixel ride in the two halves of packed-fp32 (v_pk_*_f32) instructions.
+//  * Time of flight is separable: tau*fs + off = a(i,m) + b(i,n).  The prologue computes tile-wide integer window bases
+//    A[m] <= a, B[n] <= b and extents (fp32 estimates with explicit error margins); afterwards each lane only carries the
+//    small fp32 residuals of the fp64 delays, ra = a - A[m] - 1/2, rb = b - B[n] (exact to ~1e-5 sample; the reference's fp32
+//    tau carries ~1e-4 sample at tau*fs ~ 2000).  Per pair:
 //        t = ra[m] + rb;  k = rint(t) (magic-number add);  s = t - k  in [-1/2, 1/2];
 //        first tap = window[k], weights = even/odd polynomials in s.
-//  * For every (receiver n, block of MB transmits) the workgroup stages MB fast-time WINDOWS
-//    (W samples starting at A[m]+B[n]) of the channel data into LDS with LDS-DMA
-//    (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write; out-of-buffer lanes deliver 0),
-//    coalesced along fast time and double-buffered against the compute of the previous stage
-//    (ablation: register staging cost 17 of 66 ms -- profiles/ablation_r01.txt); taps are then gathered from
-//    LDS with four ds_read_b64 (issued from inline asm: hipcc would merge them into ds_read2_b64,
-//    which measures 2x slower for this gather -- profiles/microbench_r01.txt).
-//  * All resident workgroups walk the traces in the same order, so the channel data streams
-//    from HBM about once per "round" of tiles and is otherwise served by L2 / Infinity Cache.
-//  * Tiles whose windows all lie inside [0, T) run a branch-free loop; tiles that touch the ends
-//    of the record run the checked loop (edge rule of SURVEY.md section 8 a5).
-//  * A tile whose delay spread does not fit W appends itself to a fallback list and is
-//    processed by the generic kernel afterwards -- results never depend on the geometry being
-//    "image like".
-//  * Lanczos weights: even/odd-split polynomials (lanczos_poly.h), no transcendentals; fp16 data
-//    is accumulated in fp32 (the reference accumulates in half2, src/bf.cu:170).
-//  * One apodization array may depend on the pixel AND the receiver (I1 x I2 x I3 x N, e.g. an acceptance-angle
-//    mask, reference src/UltrasoundSystem.m:5303-5374): it does not depend on the transmit, so it multiplies the
-//    stage's partial sum once per (pixel, receiver) -- prefetched one stage ahead, coalesced along I1 -- and a wave
+//    "Block" elements (the MB transmits of a stage) and the "stage" element (its receiver) each have a delay kind {distance,
+//    signed distance, plane wave}; for 'MUL' the host swaps the two apertures' roles.
+//  * For every STAGE (receiver n, block of MB transmits) the workgroup stages MB fast-time WINDOWS (W samples starting at
+//    A[m]+B[n]) of the channel data into LDS with LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write;
+//    out-of-buffer lanes deliver 0), coalesced along fast time and double-buffered against the compute of the previous stage;
+//    one buffer descriptor per transmit block, B[n] prefetched a stage ahead, every LDS read of a stage issued before its DMA
+//    (hipcc orders a later LDS read behind the DMA's vmcnt).  Taps are gathered with ds_read_b64 / ds_read_b32 from inline asm
+//    with immediate (window, tap) offsets (hipcc would merge them into ds_read2_b64: 2x slower for this gather).
+//  * A stage's SECOND window set holds, depending on the mode: the mirror traces x[:,m,n] (reciprocal mode, SYM: Pv == Pr, so
+//    tau(n,m) == tau(m,n) and index + weights serve both traces of an unordered pair), or the same traces of the NEXT FRAME
+//    (FB2: index + weights serve two frames).
+//  * All resident workgroups walk the traces in the same order (columns-fastest tile order, XCD-aware remap), so the channel
+//    data is served by L2 to all but the first of the tiles of a depth band.
+//  * Tiles whose windows all lie inside [0, T) run a branch-free loop; tiles that touch the ends of the record run the checked
+//    loop (edge rule of SURVEY.md section 8 a5).  A tile whose delay spread does not fit W appends itself to a fallback list
+//    and is processed by the generic kernel afterwards -- results never depend on the geometry being "image like".
+//  * Lanczos weights: even/odd-split polynomials (lanczos_poly.h), no transcendentals; fp16 taps are consumed by
+//    v_fma_mix_f32 (fp16 x fp32 + fp32) and accumulated in fp32 (the reference accumulates in half2, src/bf.cu:170).
+//  * A pixel x receiver weight (an I1 x I2 x I3 x N array, or a rule evaluated from the geometry: qdas.h QDAS_RXAPOD_*) does
+//    not depend on the transmit: it multiplies the stage's partial sum once per (pixel, receiver), one stage ahead, and a wave
 //    whose 64 weights are all zero skips the stage's gathers altogether.
-//  * Reciprocal mode (SYM): for a full-synthetic-aperture acquisition whose transmit elements ARE the
-//    receive elements (Pv == Pr, one t0), tau(n,m) == tau(m,n): tap index and weights are computed once
-//    per unordered pair {n,m} and applied to both traces x[:,n,m] and x[:,m,n] (direct + mirror window),
-//    which removes a third of the VALU work of the headline configuration without changing a single
-//    product (bit-identical weights for both traces).
+//  * 'SYN' / 'MUL': a stage belongs to one plane of the output; its sum is added with non-returning fp32 atomics.
+//  * Few tiles (pixel slab of a multi-GPU job, small image): ksplit workgroups per tile, each a slice of the aperture,
+//    partial images reduced in a fixed order.
 #include "qdas_device.h"
 #include "qdas_kernels.h"
 #include "lanczos_poly.h"
