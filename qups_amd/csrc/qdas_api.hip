@@ -67,6 +67,7 @@ struct qdas_plan {
     TileConfig tc{};
     unsigned ntiles = 0, tile_cols = 0;
     bool no_fallback = false;                 // the probe found no tile whose delay spread exceeds the LDS window
+    bool fb2_ok = false;                      // frames of a sequence may share launches pairwise (decided at plan creation)
     uint32_t *fallback = nullptr;             // device: [0] = count, [1..ntiles]
     bool timing = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -496,6 +497,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         }
     }
 
+    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->tp.sym && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
     if (desc->mem == QDAS_MEM_HOST) {                   // staging buffers for x / y
         pl->x_bytes = (size_t)z.T * z.N * z.M * data_size(dt);
         pl->y_bytes = (size_t)pl->y_ld * pl->oN * pl->oM * data_size(dt);
@@ -608,8 +610,7 @@ extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, u
     if (!x) return fail(QDAS_EINVAL, "null data");
     if (pl->timing) HIPCHK(hipEventRecord(pl->e0, s));
     // frame pairs share one launch (device-resident data, tiled kernel, not the reciprocal mode; QDAS_NO_FB2 disables)
-    const bool pairs_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->tp.sym && pl->d.mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2")
-                          && x_stride * ds < (1ull << 40);
+    const bool pairs_ok = pl->fb2_ok && x_stride * ds < (1ull << 40);
     if (pl->d.mem == QDAS_MEM_HOST && F >= 2) {         // host frames: upload f+1 on the copy stream while f is beamformed
         if (!pl->copy_stream) {
             int rc;
