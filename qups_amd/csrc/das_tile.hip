@@ -8,6 +8,8 @@
 #include "das_tile_f16.hip"
 #include "das_tile_f32x2.hip"
 #include "das_tile_f16x2.hip"
+#include "das_tile_f32x4.hip"
+#include "das_tile_f16x4.hip"
 #else
 #include "qdas_device.h"
 #include "qdas_kernels.h"
@@ -21,6 +23,8 @@ hipError_t launch_tile_sym(const TileParams &P, unsigned ntiles, size_t lds, hip
 hipError_t launch_tile_f16(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f32x2(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f16x2(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
+hipError_t launch_tile_f32x4(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
+hipError_t launch_tile_f16x4(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 
 // y[i] = sum over the ksplit partial images, in split order (deterministic)
 template <typename ST>
@@ -64,14 +68,15 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M);    // (the two-frame configurations have the same LDS image)
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
     if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part))) return hipErrorInvalidValue;
-if (P.fb2 && (sym || P.probe)) return hipErrorInvalidValue;
+const int nf = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
+    if ((nf != 1 && nf != 2 && nf != 4) || (nf > 1 && sym)) return hipErrorInvalidValue;
     hipError_t e = sym ? launch_tile_sym(P, ntiles, lds, s)
-                 : P.fb2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))
-                         : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));
+                 : nf == 4 ? (dtype == 2 ? launch_tile_f16x4(P, ntiles, lds, s) : launch_tile_f32x4(P, ntiles, lds, s))
+                 : nf == 2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))
+                           : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));
     if (e != hipSuccess || P.probe || P.ksplit <= 1 || P.syn) return e;   // ('SYN' planes are accumulated in place)
     const unsigned rb = (unsigned)((P.i_count + 255) / 256);
-    const int nf = P.fb2 ? 2 : 1;                        // partial images: [split][frame][pixel]
-    for (int f = 0; f < nf; ++f) {
+    for (int f = 0; f < nf; ++f) {                       // partial images: [split][frame][pixel]
         const float2 *src = P.part + (size_t)f * P.i_count;
         const uint64_t stride = (uint64_t)nf * P.i_count;
         if (dtype == 2) tile_reduce_kernel<uint32_t><<<rb, 256, 0, s>>>(src, (uint32_t *)P.y + (size_t)f * P.y_fstride, P.i_count, P.ksplit, stride);

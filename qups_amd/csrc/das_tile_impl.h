@@ -225,20 +225,24 @@ __device__ __forceinline__ uint32_t zero_of(const uint32_t *) { return 0u; }
 //      traces of the next frame, so tap index and weights -- which depend on the geometry only -- are computed once for
 //      both frames (the reference launches one kernel per frame, kern/das_spec.m:371).  Structurally the reciprocal mode's
 //      "mirror" set with another source and a separate sum.
-template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, bool FB2, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE>
+//      FB4: four frames per launch: four window sets of MB = 8 transmits; the pair loop makes two passes (frames 0-1, 2-3).
+template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, bool FB2, bool FB4, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE>
 __global__ void __launch_bounds__(WAVES * 64, WAVES * BPC / 4)
 das_tile_kernel(const TileParams P) {
-    constexpr bool TWO = SYM || FB2;          // two window sets per stage: direct + (mirror | next frame)
-    constexpr int NW = TWO ? 2 * MB : MB;     // windows per LDS buffer
+    constexpr bool FBX = FB2 || FB4;          // more than one frame per launch
+    constexpr bool TWO = SYM || FBX;          // (at least) two window sets per stage: direct + (mirror | next frame)
+    constexpr int NHP = FB4 ? 2 : 1;          // passes of the pair loop: one per frame pair
+    constexpr int NFR = FB4 ? 4 : (FB2 ? 2 : 1);   // frames per launch
+    constexpr int NW = FB4 ? 4 * MB : (TWO ? 2 * MB : MB);     // windows per LDS buffer
     static_assert(!SYM || (sizeof(ST) == 8 && !WTAB), "reciprocal mode: fp32 data, no weight table");
-    static_assert(!(SYM && FB2), "reciprocal mode runs one frame per launch");
+    static_assert(!(SYM && FBX) && !(FB2 && FB4), "reciprocal mode runs one frame per launch");
     constexpr int K = tapinfo<INTERP>::K;
     constexpr int THREADS = WAVES * 64;
     constexpr int TX = WAVES;                 // waves per workgroup; a wave holds 1, 2 or 4 image columns (tz_log2)
-    constexpr int WPW = MB / WAVES;           // windows staged per wave
+    constexpr int WPW = FB4 ? 1 : MB / WAVES; // windows staged per wave and window set
     constexpr int SB = (int)sizeof(ST);       // bytes per complex sample
     constexpr bool F32 = (SB == 8);
-    static_assert(MB % WAVES == 0 && MB % 2 == 0, "staging split");
+    static_assert(FB4 ? (2 * MB == WAVES) : (MB % WAVES == 0 && MB % 2 == 0), "staging split");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #if QDAS_PROF
@@ -466,6 +470,12 @@ das_tile_kernel(const TileParams P) {
     for (uint32_t r = 0; blk(r) < M; ++r) nstage += nlim(blk(r)) - n_lo;
     v2f acc = {0.f, 0.f};                              // (re, im) of this lane's pixel
     v2f acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f}, acc3 = {0.f, 0.f};   // independent partial sums: no back-to-back dependent packed FMAs
+    // accumulator -> frame: one frame: all four; two frames: (acc, acc1 | acc2, acc3); four frames: one each
+    auto frame_sums = [&](v2f (&Sf)[4]) {
+        if constexpr (FB4) { Sf[0] = acc; Sf[1] = acc1; Sf[2] = acc2; Sf[3] = acc3; }
+        else if constexpr (FB2) { Sf[0] = acc + acc1; Sf[1] = acc2 + acc3; }
+        else Sf[0] = (acc + acc1) + (acc2 + acc3);
+    };
     v2f ra[MB / 2];                                    // tx residuals a - A[m] - 1/2 of transmits (2p, 2p+1), packed
     // ---- LDS-DMA staging.  One buffer descriptor per stage, based at trace (n, m0): window j starts
     //      (j*strM + A[m0+j] + B[n]) samples after it.  A lane moves 16 bytes; a wave-instruction 1 KiB.
@@ -478,7 +488,10 @@ das_tile_kernel(const TileParams P) {
     //  measured with tools/scratch/dma12.hip)
     constexpr int PB = 1024;                           // bytes per full DMA piece (one wave-instruction x 16 B)
     constexpr int PCS = (WB + PB - 1) / PB;            // pieces per window; the last one may use fewer lanes
-    constexpr int NDMA = WPW * PCS * (TWO ? 2 : 1);    // DMA instructions per wave and stage
+    constexpr int NDMA = WPW * PCS * (TWO ? 2 : 1);    // DMA instructions per wave and stage (four frames: two of the four sets per wave)
+    // window sets this wave stages: (0, 1) in general; with four frames the lower / upper half of the waves take frames (0, 2) / (1, 3)
+    const int fa = FB4 ? __builtin_amdgcn_readfirstlane(wave / MB) : 0, fb = FB4 ? fa + 2 : 1;
+    auto wjr = [&](int r) -> int { return FB4 ? __builtin_amdgcn_readfirstlane(wave % MB) : __builtin_amdgcn_readfirstlane(wave + WAVES * r); };
     static_assert(WB % 16 == 0 && PSZ == 16, "window must be a whole number of 16-byte lanes");
     const uint64_t xbytes = (uint64_t)P.N * P.M * P.T * SB;
     // Per-wave DMA state: this wave stages windows j_r = wave + WAVES*r.  One buffer descriptor per TRANSMIT BLOCK, based at
@@ -491,18 +504,18 @@ das_tile_kernel(const TileParams P) {
     auto dma_block = [&](uint32_t m0) {
         const uint64_t o = ((uint64_t)m0 * P.strM + (uint64_t)n_lo * P.strN) * SB;
         const uint64_t rem = xbytes > o ? xbytes - o : 0;   // (m0 >= M when the split is exhausted: nothing more is issued)
-        rsD = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + (rem ? o : 0)), 0, rem > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem, 0x00020000);
+        rsD = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + (rem ? o + (uint64_t)fa * P.x_fstride : 0)), 0, rem > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem, 0x00020000);
         soff = 0;
 #pragma unroll
         for (int r = 0; r < WPW; ++r) {
-            const int j = __builtin_amdgcn_readfirstlane(wave + WAVES * r);
+            const int j = wjr(r);
             const uint32_t m = m0 + j;
             const int am = __builtin_amdgcn_readfirstlane(Abase[m < M ? m : M - 1]);
             wb[r] = am * SB + (int)((long)j * (long)P.strM * SB);
             if constexpr (SYM) wb2[r] = am * SB + (int)((long)j * (long)P.strN * SB);
         }
-        if constexpr (FB2) {                           // the same traces of the next frame
-            const uint64_t o2 = o + P.x_fstride;
+        if constexpr (FBX) {                           // the same traces of the next frame (four frames: of frame fb)
+            const uint64_t o2 = o + (uint64_t)fb * P.x_fstride;
             rsM = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + (rem ? o2 : 0)), 0, rem > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem, 0x00020000);
         }
         if constexpr (SYM) {                           // mirror traces x[:, rx = m0 + j, tx = n] (reciprocal mode starts every block at n = 0)
@@ -516,23 +529,23 @@ das_tile_kernel(const TileParams P) {
         const int bs = bn * SB;
 #pragma unroll
         for (int r = 0; r < WPW; ++r) {
-            const int j = __builtin_amdgcn_readfirstlane(wave + WAVES * r);
+            const int j = wjr(r);
             const int so = (int)soff + wb[r] + bs;
 #pragma unroll
             for (int q = 0; q < ((QDAS_ABL & 64) ? 1 : PCS); ++q) {
-                lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + j) * WB + q * PB));
+                lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + fa * MB + j) * WB + q * PB));
                 if (lane * 16 < WB - q * PB)             // trailing partial piece: upper lanes masked off
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, dst, 16, lane * 16, so + q * PB, 0, 0);
             }
         }
-        if constexpr (FB2) {                           // next frame: same offsets, other descriptor, second window set
+        if constexpr (FBX) {                           // next frame: same offsets, other descriptor, another window set
 #pragma unroll
             for (int r = 0; r < WPW; ++r) {
-                const int j = __builtin_amdgcn_readfirstlane(wave + WAVES * r);
+                const int j = wjr(r);
                 const int so = (int)soff + wb[r] + bs;
 #pragma unroll
                 for (int q = 0; q < PCS; ++q) {
-                    lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + MB + j) * WB + q * PB));
+                    lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + fb * MB + j) * WB + q * PB));
                     if (lane * 16 < WB - q * PB)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, dst, 16, lane * 16, so + q * PB, 0, 0);
                 }
@@ -576,8 +589,9 @@ das_tile_kernel(const TileParams P) {
                    return (v2f){__half2float(__ushort_as_half((unsigned short)(v & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(v >> 16)))}; }
         }
     };
-    v2f tot = {0.f, 0.f};                              // weighted total when wpix (acc.. then hold one stage's partial sum)
-    v2f tot2 = {0.f, 0.f};                             // ... of the second frame (FB2)
+    v2f tot[NFR];                                      // weighted totals per frame when wpix (acc.. then hold one stage's partial sums)
+#pragma unroll
+    for (int f = 0; f < NFR; ++f) tot[f] = (v2f){0.f, 0.f};
     const bool syn = !SYM && F32 && P.syn;             // keep the receive dimension: one output plane per receiver
     const bool in_shard = (i1 < P.I1) && (col < ncols) && (i1 + P.I1 * col >= P.i_begin) && (i1 + P.I1 * col < i_end);
 
@@ -663,20 +677,29 @@ das_tile_kernel(const TileParams P) {
                 const uint32_t ad0 = ((QDAS_ABL & 128) ? (MAGIC_BITS + (uint32_t)lane + (__float_as_uint(tm.x) & 1u)) : __float_as_uint(tm.x)) * (uint32_t)SB + cbase;
                 const uint32_t ad1 = ((QDAS_ABL & 128) ? (MAGIC_BITS + (uint32_t)lane + (__float_as_uint(tm.y) & 1u)) : __float_as_uint(tm.y)) * (uint32_t)SB + cbase;
                 constexpr bool SPLIT = CHECK || FMOD || WTAB;       // the two halves need separate post-processing
+                v2f w[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+                // one pass per FRAME PAIR (two passes when four frames share the launch): same tap index and weights
+                unroll<NHP>([&](auto hpc) {
+                constexpr int hp = decltype(hpc)::value;
+                constexpr int GSET = FB4 ? 2 * hp : 0, HSET = FB4 ? 2 * hp + 1 : 1;       // window sets of the pass
+                // accumulators: one per (frame, transmit half) with up to two frames, one per frame with four
+                v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : &acc1);
+                v2f &B0 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc3);
                 v2f v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
                 v2f u0 = {0.f, 0.f}, u1 = {0.f, 0.f};     // the same two pairs of the second frame (FB2)
                 if constexpr (F32) {
                     taps_f32 g0, g1, h0, h1;              // direct taps x[:, n, m | m+1]; mirror taps x[:, m | m+1, n]
                     if constexpr ((QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { g0.s[k] = h0.s[k] = (v2f){s.x, t.x}; g1.s[k] = h1.s[k] = (v2f){t.y, s.y}; } }
                     else {
-                        lds_issue<K, (2 * p) * WB>(g0, ad0); lds_issue<K, (2 * p + 1) * WB>(g1, ad1);
-                        if constexpr (TWO) { lds_issue<K, (MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (MB + 2 * p + 1) * WB>(h1, ad1); }
+                        lds_issue<K, (GSET * MB + 2 * p) * WB>(g0, ad0); lds_issue<K, (GSET * MB + 2 * p + 1) * WB>(g1, ad1);
+                        if constexpr (TWO) { lds_issue<K, (HSET * MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (HSET * MB + 2 * p + 1) * WB>(h1, ad1); }
                         if constexpr (K < 4) { g0.s[2] = g0.s[3] = g1.s[2] = g1.s[3] = h0.s[2] = h0.s[3] = h1.s[2] = h1.s[3] = (v2f){0.f, 0.f}; }
                         if constexpr (K < 2) { g0.s[1] = g1.s[1] = h0.s[1] = h1.s[1] = (v2f){0.f, 0.f}; }
                     }
-                    v2f w[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-                    if constexpr ((QDAS_ABL & 8) != 0) { w[0] = s; w[1] = t; w[2] = tm; w[3] = s + t; }
-                    else if constexpr (K > 1) weights2<INTERP>(s, w);       // overlaps the LDS latency
+                    if constexpr (hp == 0) {              // (the next frame pair reuses them)
+                        if constexpr ((QDAS_ABL & 8) != 0) { w[0] = s; w[1] = t; w[2] = tm; w[3] = s + t; }
+                        else if constexpr (K > 1) weights2<INTERP>(s, w);   // overlaps the LDS latency
+                    }
                     if constexpr (TWO) lds_fence2(g0, g1, h0, h1, w); else lds_fence(g0, g1, w);
                     if constexpr (DIAG) {                 // uniform, only in the block that holds the diagonal
                         const v2f z = {0.f, 0.f};
@@ -687,10 +710,10 @@ das_tile_kernel(const TileParams P) {
                     if constexpr (TAIL) {
                         if (!upper) {                       // odd M: no transmit in the upper half (uniform, rare)
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) { g1.s[k] = (v2f){0.f, 0.f}; if constexpr (FB2) h1.s[k] = (v2f){0.f, 0.f}; }
+                            for (int k = 0; k < 4; ++k) { g1.s[k] = (v2f){0.f, 0.f}; if constexpr (FBX) h1.s[k] = (v2f){0.f, 0.f}; }
                         }
                     }
-                    if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; if constexpr (FB2) { u0 = h0.s[0]; u1 = h1.s[0]; } }
+                    if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; if constexpr (FBX) { u0 = h0.s[0]; u1 = h1.s[0]; } }
                     else if constexpr (SPLIT) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { v0 = w[k].x * g0.s[k] + v0; v1 = w[k].y * g1.s[k] + v1; }
@@ -698,50 +721,49 @@ das_tile_kernel(const TileParams P) {
 #pragma unroll
                             for (int k = 0; k < K; ++k) { v0 = w[k].x * h0.s[k] + v0; v1 = w[k].y * h1.s[k] + v1; }
                         }
-                        if constexpr (FB2) {
+                        if constexpr (FBX) {
 #pragma unroll
                             for (int k = 0; k < K; ++k) { u0 = w[k].x * h0.s[k] + u0; u1 = w[k].y * h1.s[k] + u1; }
                         }
                     } else {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) { acc = w[k].x * g0.s[k] + acc; acc1 = w[k].y * g1.s[k] + acc1; }
+                        for (int k = 0; k < K; ++k) { A0 = w[k].x * g0.s[k] + A0; A1 = w[k].y * g1.s[k] + A1; }
                         if constexpr (TWO) {
 #pragma unroll
-                            for (int k = 0; k < K; ++k) { acc2 = w[k].x * h0.s[k] + acc2; acc3 = w[k].y * h1.s[k] + acc3; }
+                            for (int k = 0; k < K; ++k) { B0 = w[k].x * h0.s[k] + B0; B1 = w[k].y * h1.s[k] + B1; }
                         }
                     }
                     if constexpr (SYM && K == 1) { v0 += h0.s[0]; v1 += h1.s[0]; }
                 } else {
                     taps_f16 g0, g1, h0, h1;
-                    lds_issue<K, (2 * p) * WB>(g0, ad0); lds_issue<K, (2 * p + 1) * WB>(g1, ad1);
-                    if constexpr (FB2) { lds_issue<K, (MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (MB + 2 * p + 1) * WB>(h1, ad1); }
+                    lds_issue<K, (GSET * MB + 2 * p) * WB>(g0, ad0); lds_issue<K, (GSET * MB + 2 * p + 1) * WB>(g1, ad1);
+                    if constexpr (FBX) { lds_issue<K, (HSET * MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (HSET * MB + 2 * p + 1) * WB>(h1, ad1); }
                     if constexpr (K < 4) { g0.r[2] = g0.r[3] = g1.r[2] = g1.r[3] = h0.r[2] = h0.r[3] = h1.r[2] = h1.r[3] = 0u; }
                     if constexpr (K < 2) { g0.r[1] = g1.r[1] = h0.r[1] = h1.r[1] = 0u; }
-                    v2f w[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-                    if constexpr (K > 1) weights2<INTERP>(s, w);            // overlaps the LDS latency
-                    if constexpr (FB2) lds_fence2(g0, g1, h0, h1, w); else lds_fence(g0, g1, w);
+                    if constexpr (hp == 0 && K > 1) weights2<INTERP>(s, w);  // overlaps the LDS latency
+                    if constexpr (FBX) lds_fence2(g0, g1, h0, h1, w); else lds_fence(g0, g1, w);
                     if constexpr (TAIL) {
                         if (!upper) {
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) { g1.r[k] = 0u; if constexpr (FB2) h1.r[k] = 0u; }
+                            for (int k = 0; k < 4; ++k) { g1.r[k] = 0u; if constexpr (FBX) h1.r[k] = 0u; }
                         }
                     }
                     if constexpr (K == 1) {
                         v0 = half2_to_v2f(g0.r[0]); v1 = half2_to_v2f(g1.r[0]);
-                        if constexpr (FB2) { u0 = half2_to_v2f(h0.r[0]); u1 = half2_to_v2f(h1.r[0]); }
+                        if constexpr (FBX) { u0 = half2_to_v2f(h0.r[0]); u1 = half2_to_v2f(h1.r[0]); }
                     } else if constexpr (SPLIT) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { mix_mac(v0, g0.r[k], w[k].x); mix_mac(v1, g1.r[k], w[k].y); }
-                        if constexpr (FB2) {
+                        if constexpr (FBX) {
 #pragma unroll
                             for (int k = 0; k < K; ++k) { mix_mac(u0, h0.r[k], w[k].x); mix_mac(u1, h1.r[k], w[k].y); }
                         }
                     } else {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) { mix_mac(acc, g0.r[k], w[k].x); mix_mac(acc1, g1.r[k], w[k].y); }
-                        if constexpr (FB2) {
+                        for (int k = 0; k < K; ++k) { mix_mac(A0, g0.r[k], w[k].x); mix_mac(A1, g1.r[k], w[k].y); }
+                        if constexpr (FBX) {
 #pragma unroll
-                            for (int k = 0; k < K; ++k) { mix_mac(acc2, h0.r[k], w[k].x); mix_mac(acc3, h1.r[k], w[k].y); }
+                            for (int k = 0; k < K; ++k) { mix_mac(B0, h0.r[k], w[k].x); mix_mac(B1, h1.r[k], w[k].y); }
                         }
                     }
                 }
@@ -752,7 +774,7 @@ das_tile_kernel(const TileParams P) {
                     const float lo1 = tapinfo<INTERP>::LO - 0.5f - (float)ws1, hi1 = (float)(T - K + 1 - ws1) - 0.5f;
                     const bool k0 = (t.x >= lo0) && (t.x < hi0), k1 = (t.y >= lo1) && (t.y < hi1) && upper;
                     v0 = k0 ? v0 : (v2f){0.f, 0.f}; v1 = k1 ? v1 : (v2f){0.f, 0.f};
-                    if constexpr (FB2) { u0 = k0 ? u0 : (v2f){0.f, 0.f}; u1 = k1 ? u1 : (v2f){0.f, 0.f}; }
+                    if constexpr (FBX) { u0 = k0 ? u0 : (v2f){0.f, 0.f}; u1 = k1 ? u1 : (v2f){0.f, 0.f}; }
                 }
                 if constexpr (FMOD) {                     // reference src/bf.cu:117: w = exp(2j pi fmod tau)
                     const uint32_t mb = upper ? m + 1 : m;
@@ -764,55 +786,63 @@ das_tile_kernel(const TileParams P) {
                     const float c1 = __builtin_amdgcn_cosf(ph.y), s1 = __builtin_amdgcn_sinf(ph.y);
                     v0 = (v2f){v0.x * c0 - v0.y * s0, v0.x * s0 + v0.y * c0};
                     v1 = (v2f){v1.x * c1 - v1.y * s1, v1.x * s1 + v1.y * c1};
-                    if constexpr (FB2) {
+                    if constexpr (FBX) {
                         u0 = (v2f){u0.x * c0 - u0.y * s0, u0.x * s0 + u0.y * c0};
                         u1 = (v2f){u1.x * c1 - u1.y * s1, u1.x * s1 + u1.y * c1};
                     }
                 }
                 if constexpr (WTAB) {
-                    acc += (v2f){wr0 * v0.x - wi0 * v0.y, wr0 * v0.y + wi0 * v0.x};
-                    acc += (v2f){wr1 * v1.x - wi1 * v1.y, wr1 * v1.y + wi1 * v1.x};
-                    if constexpr (FB2) {
-                        acc2 += (v2f){wr0 * u0.x - wi0 * u0.y, wr0 * u0.y + wi0 * u0.x};
-                        acc2 += (v2f){wr1 * u1.x - wi1 * u1.y, wr1 * u1.y + wi1 * u1.x};
+                    A0 += (v2f){wr0 * v0.x - wi0 * v0.y, wr0 * v0.y + wi0 * v0.x};
+                    A0 += (v2f){wr1 * v1.x - wi1 * v1.y, wr1 * v1.y + wi1 * v1.x};
+                    if constexpr (FBX) {
+                        B0 += (v2f){wr0 * u0.x - wi0 * u0.y, wr0 * u0.y + wi0 * u0.x};
+                        B0 += (v2f){wr1 * u1.x - wi1 * u1.y, wr1 * u1.y + wi1 * u1.x};
                     }
-                } else if constexpr (SPLIT || K == 1) { acc += v0; acc += v1; if constexpr (FB2) { acc2 += u0; acc2 += u1; } }
+                } else if constexpr (SPLIT || K == 1) { A0 += v0; A0 += v1; if constexpr (FBX) { B0 += u0; B0 += u1; } }
+                            });
             };
             // full block (reciprocal mode: block entirely above the diagonal): check-free; else the tail / diagonal variant
             if (SYM ? (n < m0) : (m0 + MB <= M)) {
                 if constexpr (TWO && F32 && K == 4 && !(CHECK || FMOD || WTAB) && !(QDAS_ABL & 256)) {
                     // Software-pipelined: the direct taps of iteration p+1 are requested before the MACs of iteration p, so the
                     // LDS pipe always has work queued and the counted wait (newest 8 reads stay in flight) rarely stalls.
-                    constexpr int NP = MB / 2;
-                    taps_f32 gd0[2], gd1[2];               // direct taps of the two halves, double-buffered over iterations
+                    // A unit = (transmit pair p, frame pair hp); hp only with four frames per launch: same index and weights.
+                    constexpr int NP = MB / 2, NU = NP * NHP;
+                    taps_f32 gd0[2], gd1[2];               // first-set taps of the two halves, double-buffered over units
                     v2f sv[2];
                     uint32_t a0v[2], a1v[2];
-                    auto index = [&](auto pc) {            // index math + direct reads of iteration p
-                        constexpr int p = decltype(pc)::value;
-                        const v2f t = ra[p] + rb;
-                        const v2f tm = t + MAGIC;
-                        sv[p & 1] = t - (tm - MAGIC);
-                        a0v[p & 1] = __float_as_uint(tm.x) * (uint32_t)SB + cbase;
-                        a1v[p & 1] = __float_as_uint(tm.y) * (uint32_t)SB + cbase;
-                        if constexpr ((QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { gd0[p & 1].s[k] = (v2f){t.x, tm.y}; gd1[p & 1].s[k] = (v2f){tm.x, t.y}; } }
-                        else { lds_issue<K, (2 * p) * WB>(gd0[p & 1], a0v[p & 1]); lds_issue<K, (2 * p + 1) * WB>(gd1[p & 1], a1v[p & 1]); }
+                    v2f w[4];
+                    auto index = [&](auto uc) {            // index math (first unit of a pair) + first-set reads of unit u
+                        constexpr int u = decltype(uc)::value, p = u / NHP, hp = u % NHP, GSET = FB4 ? 2 * hp : 0;
+                        if constexpr (hp == 0) {
+                            const v2f t = ra[p] + rb;
+                            const v2f tm = t + MAGIC;
+                            sv[p & 1] = t - (tm - MAGIC);
+                            a0v[p & 1] = __float_as_uint(tm.x) * (uint32_t)SB + cbase;
+                            a1v[p & 1] = __float_as_uint(tm.y) * (uint32_t)SB + cbase;
+                        }
+                        if constexpr ((QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { gd0[u & 1].s[k] = (v2f){sv[p & 1].x, rb}; gd1[u & 1].s[k] = (v2f){rb, sv[p & 1].y}; } }
+                        else { lds_issue<K, (GSET * MB + 2 * p) * WB>(gd0[u & 1], a0v[p & 1]); lds_issue<K, (GSET * MB + 2 * p + 1) * WB>(gd1[u & 1], a1v[p & 1]); }
                     };
                     index(std::integral_constant<int, 0>{});
-                    unroll<NP>([&](auto pc) {
-                        constexpr int p = decltype(pc)::value;
+                    unroll<NU>([&](auto uc) {
+                        constexpr int u = decltype(uc)::value, p = u / NHP, hp = u % NHP, HSET = FB4 ? 2 * hp + 1 : 1;
                         taps_f32 h0, h1;
                         if constexpr ((QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { h0.s[k] = sv[p & 1]; h1.s[k] = (v2f){sv[p & 1].y, sv[p & 1].x}; } }
-                        else { lds_issue<K, (MB + 2 * p) * WB>(h0, a0v[p & 1]); lds_issue<K, (MB + 2 * p + 1) * WB>(h1, a1v[p & 1]); }
-                        if constexpr (p + 1 < NP) index(std::integral_constant<int, p + 1>{});
-                        v2f w[4];
-                        if constexpr ((QDAS_ABL & 8) != 0) { w[0] = sv[p & 1]; w[1] = sv[p & 1] + 1.f; w[2] = sv[p & 1] * 2.f; w[3] = 1.f - sv[p & 1]; }
-                        else weights2<INTERP>(sv[p & 1], w);
-                        if constexpr (p + 1 < NP) lds_fence2_keep<8>(gd0[p & 1], gd1[p & 1], h0, h1, w);
-                        else                      lds_fence2_keep<0>(gd0[p & 1], gd1[p & 1], h0, h1, w);
+                        else { lds_issue<K, (HSET * MB + 2 * p) * WB>(h0, a0v[p & 1]); lds_issue<K, (HSET * MB + 2 * p + 1) * WB>(h1, a1v[p & 1]); }
+                        if constexpr (u + 1 < NU) index(std::integral_constant<int, u + 1>{});
+                        if constexpr (hp == 0) {
+                            if constexpr ((QDAS_ABL & 8) != 0) { w[0] = sv[p & 1]; w[1] = sv[p & 1] + 1.f; w[2] = sv[p & 1] * 2.f; w[3] = 1.f - sv[p & 1]; }
+                            else weights2<INTERP>(sv[p & 1], w);
+                        }
+                        if constexpr (u + 1 < NU) lds_fence2_keep<8>(gd0[u & 1], gd1[u & 1], h0, h1, w);
+                        else                      lds_fence2_keep<0>(gd0[u & 1], gd1[u & 1], h0, h1, w);
+                        v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : &acc1);
+                        v2f &B0 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc3);
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
-                            acc = w[k].x * gd0[p & 1].s[k] + acc; acc1 = w[k].y * gd1[p & 1].s[k] + acc1;
-                            acc2 = w[k].x * h0.s[k] + acc2;        acc3 = w[k].y * h1.s[k] + acc3;
+                            A0 = w[k].x * gd0[u & 1].s[k] + A0; A1 = w[k].y * gd1[u & 1].s[k] + A1;
+                            B0 = w[k].x * h0.s[k] + B0;         B1 = w[k].y * h1.s[k] + B1;
                         }
                     });
                 } else {
@@ -840,22 +870,23 @@ das_tile_kernel(const TileParams P) {
             if (syn) {                                 // 'SYN' (src/bf.cu:131-133): the stage's sum over its transmits joins plane n of y.
                 // Non-returning fp32 atomics: the planes are zero-filled by the host, the transmit blocks of one (pixel, n) are
                 // visited in order by this lane only (and receiver ranges of a split aperture are disjoint) -> deterministic.
-                v2f S0 = FB2 ? (acc + acc1) : (acc + acc1) + (acc2 + acc3), S1 = acc2 + acc3;
-                if (wpix) {
-                    S0 = (v2f){wcur.x * S0.x - wcur.y * S0.y, wcur.x * S0.y + wcur.y * S0.x};
-                    S1 = (v2f){wcur.x * S1.x - wcur.y * S1.y, wcur.x * S1.y + wcur.y * S1.x};
-                    wcur = wnext;
+                v2f Sf[4];                             // the stage's sum per frame
+                frame_sums(Sf);
+#pragma unroll
+                for (int f = 0; f < NFR; ++f) {
+                    if (wpix) Sf[f] = (v2f){wcur.x * Sf[f].x - wcur.y * Sf[f].y, wcur.x * Sf[f].y + wcur.y * Sf[f].x};
+                    if (in_shard) {
+                        float *q = (float *)((float2 *)P.y + (size_t)f * P.y_fstride + (size_t)(i1 + P.I1 * col - P.i_begin) + (size_t)n * P.y_ld);
+                        unsafeAtomicAdd(q, Sf[f].x); unsafeAtomicAdd(q + 1, Sf[f].y);
+                    }
                 }
-                if (in_shard) {
-                    float *q = (float *)((float2 *)P.y + (size_t)(i1 + P.I1 * col - P.i_begin) + (size_t)n * P.y_ld);
-                    unsafeAtomicAdd(q, S0.x); unsafeAtomicAdd(q + 1, S0.y);
-                    if constexpr (FB2) { q += 2 * P.y_fstride; unsafeAtomicAdd(q, S1.x); unsafeAtomicAdd(q + 1, S1.y); }
-                }
+                if (wpix) wcur = wnext;
                 acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
             } else if (wpix) {                         // weight the stage's partial sum (the weight does not depend on m)
-                const v2f S = FB2 ? (acc + acc1) : (acc + acc1) + (acc2 + acc3);
-                tot += (v2f){wcur.x * S.x - wcur.y * S.y, wcur.x * S.y + wcur.y * S.x};
-                if constexpr (FB2) { const v2f S2 = acc2 + acc3; tot2 += (v2f){wcur.x * S2.x - wcur.y * S2.y, wcur.x * S2.y + wcur.y * S2.x}; }
+                v2f Sf[4];
+                frame_sums(Sf);
+#pragma unroll
+                for (int f = 0; f < NFR; ++f) tot[f] += (v2f){wcur.x * Sf[f].x - wcur.y * Sf[f].y, wcur.x * Sf[f].y + wcur.y * Sf[f].x};
                 acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
                 wcur = wnext;
             }
@@ -872,18 +903,18 @@ das_tile_kernel(const TileParams P) {
     }
 #endif
     if (syn) return;                                   // every stage already added its share to its plane
-    const v2f res2 = wpix ? tot2 : (acc2 + acc3);       // second frame (FB2)
-    acc = wpix ? tot : (FB2 ? (acc + acc1) : (acc + acc1) + (acc2 + acc3));
-    // ---- epilogue: y[i] = pix  (reference src/bf.cu:140); lanes = consecutive i -> coalesced
+    v2f res[4];
+    frame_sums(res);
+    // ---- epilogue: y[i] = pix  (reference src/bf.cu:140); one image per frame of the launch
     {
         const uint64_t ig = i1 + P.I1 * col;
         if ((i1 < P.I1) && (col < ncols) && (ig >= P.i_begin) && (ig < i_end)) {
-            constexpr size_t NF = FB2 ? 2 : 1;              // partial images are laid out [split][frame][pixel]
-            if (S > 1) P.part[((size_t)split * NF) * P.i_count + (size_t)(ig - P.i_begin)] = make_float2(acc.x, acc.y);
-            else st((ST *)P.y, (size_t)(ig - P.i_begin), cplx<float>{acc.x, acc.y});
-            if constexpr (FB2) {
-                if (S > 1) P.part[((size_t)split * NF + 1) * P.i_count + (size_t)(ig - P.i_begin)] = make_float2(res2.x, res2.y);
-                else st((ST *)P.y + P.y_fstride, (size_t)(ig - P.i_begin), cplx<float>{res2.x, res2.y});
+#pragma unroll
+            for (int f = 0; f < NFR; ++f) {
+                const v2f r = wpix ? tot[f] : res[f];
+                // partial images of a split aperture are laid out [split][frame][pixel]
+                if (S > 1) P.part[((size_t)split * NFR + f) * P.i_count + (size_t)(ig - P.i_begin)] = make_float2(r.x, r.y);
+                else st((ST *)P.y + (size_t)f * P.y_fstride, (size_t)(ig - P.i_begin), cplx<float>{r.x, r.y});
             }
         }
     }
@@ -892,19 +923,19 @@ das_tile_kernel(const TileParams P) {
 template <int INTERP, typename ST, int CI>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
     constexpr Cfg G = CFGS[CI];
-    constexpr bool SYM = (CI == 1), FB2 = (CI >= 3);
+    constexpr bool SYM = (CI == 1), FB2 = (CI == 3 || CI == 4), FB4 = (CI >= 5);
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
     const dim3 g(ntiles * (P.probe ? 1u : P.ksplit)), b(G.waves * 64);
 #define QDAS_LAUNCH(FM, WT) QDAS_LAUNCH_P(FM, WT, false)
 #define QDAS_LAUNCH_P(FM, WT, PR)                                                                        \
     do {                                                                                                 \
-        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR>; \
+        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, FB4, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR>; \
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                   \
         kfn<<<g, b, lds, s>>>(P);                                                                        \
     } while (0)
     if (P.probe) {
-        if constexpr (FB2) return hipErrorInvalidValue;    // the window fit does not depend on the frame count: probes use FB = 1
+        if constexpr (FB2 || FB4) return hipErrorInvalidValue;    // the window fit does not depend on the frame count: probes use one frame
         else { QDAS_LAUNCH_P(false, false, true); return hipGetLastError(); }
     }
     if constexpr (SYM) {

@@ -67,7 +67,8 @@ struct qdas_plan {
     TileConfig tc{};
     unsigned ntiles = 0, tile_cols = 0;
     bool no_fallback = false;                 // the probe found no tile whose delay spread exceeds the LDS window
-    bool fb2_ok = false;                      // frames of a sequence may share launches pairwise (decided at plan creation)
+    bool fb2_ok = false;                      // frames of a sequence may share launches, 4 or 2 at a time (decided at plan creation)
+    bool fb4_off = false;                     // ... but at most pairwise (QDAS_NO_FB4)
     uint32_t *fallback = nullptr;             // device: [0] = count, [1..ntiles]
     bool timing = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -436,7 +437,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if ((rc = dev_alloc(pl, &fb, sizeof(uint32_t) * (max_tiles + 1)))) return bail(rc);
         pl->fallback = (uint32_t *)fb;
         t.fallback_list = pl->fallback; t.fallback_cap = max_tiles;
-        t.probe = 0; t.wz_log2 = 6; t.ksplit = 1; t.part = nullptr; t.fb2 = 0; t.x_fstride = 0; t.y_fstride = 0;
+        t.probe = 0; t.wz_log2 = 6; t.ksplit = 1; t.part = nullptr; t.nfr = 1; t.x_fstride = 0; t.y_fstride = 0;
         t.syn = syn ? 1 : 0; t.y_ld = pl->y_ld;
         // fold the (pixel-independent) apodization stack into one N x M complex64 table
         t.wtab = nullptr; t.apix = nullptr; t.apix_real = desc->apod_real;
@@ -491,13 +492,14 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             t.ksplit = ks;
             if (ks > 1) {
                 void *pb;
-                if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)ks * 2 * pl->i_count))) return bail(rc);   // x2: frame pairs
+                if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)ks * 4 * pl->i_count))) return bail(rc);   // x4: up to four frames per launch
                 t.part = (float2 *)pb;
             }
         }
     }
 
     pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->tp.sym && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
+    pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr;
     if (desc->mem == QDAS_MEM_HOST) {                   // staging buffers for x / y
         pl->x_bytes = (size_t)z.T * z.N * z.M * data_size(dt);
         pl->y_bytes = (size_t)pl->y_ld * pl->oN * pl->oM * data_size(dt);
@@ -558,7 +560,7 @@ static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s, int n
     if (pl->kernel == QDAS_KERNEL_TILED) {
         TileParams t = pl->tp;
         t.x = x; t.y = y;
-        t.fb2 = nf == 2; t.x_fstride = x_fstride; t.y_fstride = y_fstride;
+        t.nfr = nf; t.x_fstride = x_fstride; t.y_fstride = y_fstride;
         if (t.syn) {                                    // planes are accumulated with atomics: start from zero
             const size_t ds = data_size(z.dtype);        // (only this plan's pixels of every plane: y_ld may span a full-size buffer)
             for (int f = 0; f < nf; ++f)
@@ -577,8 +579,8 @@ static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s, int n
         g.blocks_per_tile = (64 * pl->tc.waves + 255) / 256;
         g.tiles_z = pl->tp.tiles_z;
         HIPCHK(launch_generic(g, z.dtype, pl->ntiles * g.blocks_per_tile, s));
-        if (nf == 2) {                                  // the same misfit tiles of the second frame
-            g.x = (const char *)x + x_fstride; g.y = (char *)y + y_fstride * data_size(z.dtype);
+        for (int f = 1; f < nf; ++f) {                  // the same misfit tiles of the other frames of the launch
+            g.x = (const char *)x + (size_t)f * x_fstride; g.y = (char *)y + (size_t)f * y_fstride * data_size(z.dtype);
             HIPCHK(launch_generic(g, z.dtype, pl->ntiles * g.blocks_per_tile, s));
         }
     } else {
@@ -646,10 +648,11 @@ extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, u
     for (uint64_t f = 0; f < F; ++f) {
         const char *xf = (const char *)x + f * x_stride * ds;
         char *yf = (char *)y + f * y_stride * ds;
-        if (pairs_ok && f + 1 < F) {
-            int rc = run_frame(pl, xf, yf, s, 2, x_stride * ds, y_stride);
+        if (pairs_ok && f + 1 < F) {                    // four (else two) frames share a launch
+            const int nf = (f + 3 < F && !pl->fb4_off) ? 4 : 2;
+            int rc = run_frame(pl, xf, yf, s, nf, x_stride * ds, y_stride);
             if (rc) return rc;
-            ++f;
+            f += nf - 1;
             continue;
         }
         if (pl->d.mem == QDAS_MEM_HOST) {

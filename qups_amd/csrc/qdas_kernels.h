@@ -61,10 +61,10 @@ struct TileParams {
     uint32_t tiles_z, tiles_x, tile_x0; // tile grid over (I1 >> tz_log2) x (columns / tile columns); first column tile of the shard
     int32_t syn;                        // 1: 'SYN' -- keep the receive dimension: y is I x N planes (leading dimension y_ld), zero-filled by the host
     uint64_t y_ld;
-    int32_t fb2;                        // 1: two frames per launch (x, x + x_fstride -> y, y + y_fstride); never with sym
+    int32_t nfr;                        // frames per launch: 1, or 2 / 4 (frame f at x + f*x_fstride -> y + f*y_fstride); 1 with sym
     uint64_t x_fstride, y_fstride;      // frame strides: BYTES of x, ELEMENTS of y
     uint32_t ksplit;                    // workgroups per tile (>= 1): each sums a slice of the aperture into part[], then reduced into y
-    float2 *part;                       // [ksplit][frames per launch][i_count] partial images (ksplit > 1 only)
+    float2 *part;                       // [ksplit][nfr][i_count] partial images (ksplit > 1 only)
     uint32_t *fallback_list;            // [0] = count, [1..] = tile ids that did not fit the LDS window
     uint32_t fallback_cap;
 };

@@ -27,7 +27,7 @@ def _draw(seed):
                t0vec=bool(r.integers(0, 3) == 0), wn=bool(r.integers(0, 3) == 0), wm=bool(r.integers(0, 3) == 0),
                wpix=bool(r.integers(0, 3) == 0), shard=bool(r.integers(0, 3) == 0),
                tz=int(r.choice([0, 0, 64, 32, 16, 8])), ks=int(r.choice([0, 0, 1, 2, 3, 4])),
-               fun=str(r.choice(["DAS", "DAS", "SYN", "MUL"])), F=int(r.choice([1, 1, 2, 3])), cmap=bool(r.integers(0, 4) == 0),
+               fun=str(r.choice(["DAS", "DAS", "SYN", "MUL"])), F=int(r.choice([1, 1, 2, 3, 4, 6])), cmap=bool(r.integers(0, 4) == 0),
                gen=str(r.choice(["", "", "", "acceptance", "cosine", "fnumber"])))
     return r, cfg
 

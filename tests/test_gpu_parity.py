@@ -498,7 +498,7 @@ def test_large_time_offset(seq):
                                                    ("PW", "nearest", "single", {}), ("FC", "cubic", "single", {"fmod": 2.0e6}),
                                                    ("PW", "cubic", "single", {"wtab": True}), ("DV", "cubic", "halfT", {"wpix": True}),
                                                    ("PW", "lanczos3", "single", {"ks": 4})])
-@pytest.mark.parametrize("F", [2, 3])
+@pytest.mark.parametrize("F", [2, 3, 4, 7])
 def test_frame_pairs_share_one_launch(seq, interp, prec, extra, F, monkeypatch):
     """F frames through one plan: the tiled kernel beamforms them two at a time with shared tap indices / weights; every frame must
     equal what a frame-by-frame run (QDAS_NO_FB2=1) and the oracle give"""
