@@ -11,16 +11,17 @@ from qups_amd import DasPlan, build_problem, parse_options, _lib
 from qups_amd.configs import workload
 
 w = workload(sys.argv[1] if len(sys.argv) > 1 else "c3")
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 1            # frames per call (2 / 4: shared launches)
 dev = torch.device("cuda:0")
 T, N, M = w["T"], w["N"], w["M"]
 g = torch.Generator(device=dev).manual_seed(1234)
-xc = torch.view_as_complex(torch.randn((M, N, T, 2), generator=g, device=dev, dtype=torch.float32))
+xc = torch.view_as_complex(torch.randn((F, M, N, T, 2), generator=g, device=dev, dtype=torch.float32))
 opts = parse_options(xc, list(w["opt"]) + ["interp", w["interp"], "input-precision", "single"])
-prob = build_problem("DAS", w["Pi"], w["Pr"], w["Pv"], w["Nv"], (T, N, M), w["t0"], w["fs"], w["c0"], opts)
+prob = build_problem("DAS", w["Pi"], w["Pr"], w["Pv"], w["Nv"], (T, N, M, F), w["t0"], w["fs"], w["c0"], opts)
 plan = DasPlan(prob, device=dev)
 plan.set_timing(True)
 for _ in range(2):
-    plan.execute_colmajor(xc, 1)
+    plan.execute_colmajor(xc, F)
 ms = plan.last_kernel_ms()
 torch.cuda.synchronize()
 L = _lib.lib()
