@@ -38,7 +38,7 @@ FLOP_PER_PAIR = {"nearest": 17, "linear": 24, "cubic": 42, "lanczos3": 54}   # S
 from qups_amd.configs import workload  # noqa: E402  (geometry of the BASELINE configs)
 
 
-def cpu_baseline(w, x_host, budget_s=20.0):
+def cpu_baseline(w, x_host, budget_s=30.0):
     """Time the C oracle (port of the reference CPU branch) on a pixel-subsampled image."""
     from oracle import das_ref
     nthreads = das_ref.lib().das_ref_max_threads()
