@@ -227,6 +227,27 @@ typedef struct qdas_greens_desc {
 } qdas_greens_desc;
 int qdas_greens(const qdas_greens_desc *desc, void *y /* S x N x M complex */, void *stream);
 
+/* ---- Pre-processing in front of the DAS path: real RF traces -> analytic channel data, optionally downmixed.
+ * Replaces ChannelData.hilbert (reference src/ChannelData.m:935-966: fft to N points along time, weights
+ * [1; 2...; 1 + mod(N,2); 0...], ifft) and ChannelData.downmix (src/ChannelData.m:757-766: data .* exp(-2i*pi*fc*time))
+ * applied after it.  x: T x K real traces (K = N*M*F, device pointer) as fp32 or int16; y: Nfft x K complex64 (device).
+ * Real input is half (fp32) / a quarter (int16) of the bytes of complex64 channel data on the PCIe link. */
+#define QDAS_PRE_F32 0
+#define QDAS_PRE_I16 1
+typedef struct qdas_pre_desc {
+    uint64_t T;        /* samples per input trace                                   */
+    uint64_t K;        /* number of traces                                          */
+    uint64_t Nfft;     /* transform length = output samples per trace (0 = T)       */
+    int32_t  in_type;  /* QDAS_PRE_F32 | QDAS_PRE_I16                               */
+    int32_t  device;   /* HIP device ordinal, -1 = current                          */
+    double   fs, t0;   /* sampling frequency, time of sample 0 (downmix only)       */
+    double   fdown;    /* downmix frequency [Hz]; 0 = no downmix                    */
+} qdas_pre_desc;
+typedef struct qdas_pre_plan qdas_pre_plan;
+int  qdas_pre_plan_create(qdas_pre_plan **plan, const qdas_pre_desc *desc);
+int  qdas_pre_execute(qdas_pre_plan *plan, const void *x, void *y, void *stream);
+void qdas_pre_plan_destroy(qdas_pre_plan *plan);
+
 const char *qdas_last_error(void);
 int  qdas_version(void);
 /* device properties the host side reports next to measurements */

@@ -9,6 +9,7 @@ from .das_spec import DasError, DasPlan, DasProblem, build_problem, das_spec, pa
 
 from .interpd import das_lut, sample2sep, wsinterpd2  # noqa: F401,E402
 from . import apodization  # noqa: F401,E402
+from . import preproc  # noqa: F401,E402
 from .ultrasound import ChannelData, Scan, Sequence, Transducer, UltrasoundSystem  # noqa: F401,E402
 
 __all__ = ["das_spec", "DasPlan", "DasProblem", "DasError", "build_problem", "parse_options", "das_lut", "sample2sep",

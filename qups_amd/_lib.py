@@ -20,6 +20,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED = 0, 1, 2
 KERNEL_NAMES = {KERNEL_GENERIC: "generic", KERNEL_TILED: "tiled"}
 MAX_APOD = 6
+QDAS_PRE_F32, QDAS_PRE_I16 = 0, 1
 RXAPOD_NONE, RXAPOD_ACCEPTANCE, RXAPOD_COSINE, RXAPOD_FNUMBER_PLANAR, RXAPOD_FNUMBER_ORIENTED = 0, 1, 2, 3, 4
 
 # every symbol include/qdas.h declares (tests check the library exports all of them)
@@ -27,7 +28,7 @@ SYMBOLS = (
     "qdas_plan_create", "qdas_plan_execute", "qdas_plan_execute_frames", "qdas_plan_delays",
     "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_set_timing",
     "qdas_plan_last_kernel_ms", "qdas_DAS", "qdas_DASf", "qdas_DASh", "qdas_delays", "qdas_delaysf",
-    "qdas_das_lut", "qdas_greens", "qdas_last_error", "qdas_version", "qdas_device_info",
+    "qdas_das_lut", "qdas_greens", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_last_error", "qdas_version", "qdas_device_info",
 )
 
 
@@ -60,6 +61,11 @@ class GreensDesc(C.Structure):
                 ("s0", C.c_double), ("t0", C.c_double), ("fs", C.c_double), ("fsr", C.c_double), ("cinv", C.c_double),
                 ("R0", C.c_double), ("Ps", C.c_void_p), ("a", C.c_void_p), ("Pr", C.c_void_p), ("Pv", C.c_void_p),
                 ("x", C.c_void_p), ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PreDesc(C.Structure):
+    _fields_ = [("T", C.c_uint64), ("K", C.c_uint64), ("Nfft", C.c_uint64), ("in_type", C.c_int32), ("device", C.c_int32),
+                ("fs", C.c_double), ("t0", C.c_double), ("fdown", C.c_double)]
 
 
 class QdasError(RuntimeError):
@@ -103,6 +109,10 @@ def lib():
     L.qdas_plan_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.qdas_das_lut.argtypes = [C.POINTER(LutDesc), C.c_void_p, C.c_void_p, C.c_void_p]
     L.qdas_greens.argtypes = [C.POINTER(GreensDesc), C.c_void_p, C.c_void_p]
+    L.qdas_pre_plan_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(PreDesc)]
+    L.qdas_pre_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.qdas_pre_plan_destroy.argtypes = [C.c_void_p]
+    L.qdas_pre_plan_destroy.restype = None
     L.qdas_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_uint64)]
     vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)

@@ -807,3 +807,43 @@ extern "C" int qdas_greens(const qdas_greens_desc *d, void *y, void *stream) {
     HIPCHK(launch_greens(p, d->dtype, s));
     return QDAS_OK;
 }
+
+// ---- pre-processing (pre.hip)
+namespace qdas {
+struct PrePlan;
+int pre_create(PrePlan **out, uint64_t T, uint64_t K, uint64_t N, int in_type, double fs, double t0, double fd);
+void pre_destroy(PrePlan *p);
+int pre_execute(PrePlan *p, const void *x, void *y, hipStream_t s);
+}
+struct qdas_pre_plan { qdas::PrePlan *p; int device; };
+
+extern "C" int qdas_pre_plan_create(qdas_pre_plan **out, const qdas_pre_desc *d) {
+    if (!out || !d) return fail(QDAS_EINVAL, "null argument");
+    *out = nullptr;
+    if (d->in_type != QDAS_PRE_F32 && d->in_type != QDAS_PRE_I16) return fail(QDAS_EINVAL, "pre: input type must be fp32 or int16");
+    const uint64_t N = d->Nfft ? d->Nfft : d->T;
+    if (N >= (1ull << 31) || d->K >= (1ull << 31)) return fail(QDAS_EUNSUPPORTED, "pre: transform length / trace count too large");
+    if (d->fdown != 0.0 && !(d->fs > 0)) return fail(QDAS_EINVAL, "Undefined sampling rate.");
+    if (d->device >= 0) HIPCHK(hipSetDevice(d->device));
+    qdas_pre_plan *pl = new qdas_pre_plan();
+    { hipError_t e = hipGetDevice(&pl->device); if (e != hipSuccess) { delete pl; return fail(QDAS_EHIP, "hipGetDevice: %s", hipGetErrorString(e)); } }
+    const int rc = qdas::pre_create(&pl->p, d->T, d->K, d->Nfft, d->in_type, d->fs, d->t0, d->fdown);
+    if (rc) { delete pl; return fail(rc == 2 ? QDAS_ENOMEM : QDAS_EHIP, "pre: hipFFT plan / workspace creation failed"); }
+    *out = pl;
+    return QDAS_OK;
+}
+
+extern "C" int qdas_pre_execute(qdas_pre_plan *pl, const void *x, void *y, void *stream) {
+    if (!pl || !y) return fail(QDAS_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(pl->device));
+    const int rc = qdas::pre_execute(pl->p, x, y, (hipStream_t)stream);
+    if (rc) return fail(QDAS_EHIP, "pre: hipFFT execution failed (%d)", rc);
+    return QDAS_OK;
+}
+
+extern "C" void qdas_pre_plan_destroy(qdas_pre_plan *pl) {
+    if (!pl) return;
+    (void)hipSetDevice(pl->device);
+    qdas::pre_destroy(pl->p);
+    delete pl;
+}
