@@ -10,6 +10,7 @@
 #include "das_tile_f16x2.hip"
 #include "das_tile_f32x4.hip"
 #include "das_tile_f16x4.hip"
+#include "das_tile_symw.hip"
 #else
 #include "qdas_device.h"
 #include "qdas_kernels.h"
@@ -25,6 +26,7 @@ hipError_t launch_tile_f32x2(const TileParams &P, unsigned ntiles, size_t lds, h
 hipError_t launch_tile_f16x2(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f32x4(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f16x4(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
+hipError_t launch_tile_symw(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 
 // y[i] = sum over the ksplit partial images, in split order (deterministic)
 template <typename ST>
@@ -38,8 +40,8 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const float2 *part, ST
 
 
 
-TileConfig tile_config(int dtype, int sym) {
-    const Cfg &g = CFGS[cfg_index(dtype, sym)];
+TileConfig tile_config(int dtype, int sym, int narrow) {
+    const Cfg &g = CFGS[cfg_index(dtype, sym, 1, narrow)];
     TileConfig c;
     c.waves = g.waves;
     c.mb = g.mb;
@@ -49,9 +51,9 @@ TileConfig tile_config(int dtype, int sym) {
     return c;
 }
 
-size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M) {
-    const Cfg &g = CFGS[cfg_index(dtype, sym)];
-    const TileConfig c = tile_config(dtype, sym);
+size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow) {
+    const Cfg &g = CFGS[cfg_index(dtype, sym, 1, narrow)];
+    const TileConfig c = tile_config(dtype, sym, narrow);
     const size_t MX = M > N ? M : N;
     const size_t hdr = (((((2 * M + N) * 4 + 15) & ~(size_t)15) + 16 * N + 7 * M * 4) + 15) & ~(size_t)15;
     size_t body = c.lds_bytes;
@@ -65,12 +67,13 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     if (ntiles == 0) return hipSuccess;
     const int sym = P.sym ? 1 : 0;
     if (sym && dtype != 1) return hipErrorInvalidValue;
-    const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M);    // (the two-frame configurations have the same LDS image)
+    const int narrow = (sym && P.narrow) ? 1 : 0;
+    const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M, narrow);    // (the two-frame configurations have the same LDS image)
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
     if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part))) return hipErrorInvalidValue;
 const int nf = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
     if ((nf != 1 && nf != 2 && nf != 4) || (nf > 1 && sym)) return hipErrorInvalidValue;
-    hipError_t e = sym ? launch_tile_sym(P, ntiles, lds, s)
+    hipError_t e = sym ? (narrow ? launch_tile_symw(P, ntiles, lds, s) : launch_tile_sym(P, ntiles, lds, s))
                  : nf == 4 ? (dtype == 2 ? launch_tile_f16x4(P, ntiles, lds, s) : launch_tile_f32x4(P, ntiles, lds, s))
                  : nf == 2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))
                            : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));

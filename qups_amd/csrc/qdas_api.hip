@@ -477,7 +477,16 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e)));
             t.wtab = dtab;
         }
+        // reciprocal mode: first the 128-sample-window configuration (less staging traffic); it is kept only if some footprint
+        // has no misfit tile at all -- otherwise the 192-sample configuration
+        t.narrow = (sym && !getenv("QDAS_NO_NARROW")) ? 1 : 0;
+        if (t.narrow) pl->tc = tile_config(dt, 1, 1);
         if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
+        if (t.narrow && !pl->no_fallback) {
+            t.narrow = 0;
+            pl->tc = tile_config(dt, 1, 0);
+            if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
+        }
         // Too few tiles for the GPU (a pixel slab of a multi-GPU job, a small image): several workgroups per tile, each summing a
         // slice of the aperture (das_tile_impl.h) until every CU has a workgroup.  QDAS_KSPLIT overrides.
         {

@@ -54,6 +54,7 @@ struct TileParams {
     const float *cinv_pix;              // optional per-pixel 1/c (I1 x I2 x I3, contiguous): sound-speed map; the delay stays separable
     double fs, fmod;
     int32_t flag, VS, DV;
+    int32_t narrow;                     // reciprocal mode: the 128-sample-window configuration (chosen by the plan when every tile fits)
     int32_t sym;                        // reciprocal mode: Pv == Pr, one t0 (checked by the host) -> tau(n,m) == tau(m,n)
     int32_t tz_log2;                    // tile footprint: (1 << tz_log2) pixels of I1 x (waves * 64 >> tz_log2) columns; 3..6
     int32_t wz_log2;                    // wave footprint inside the tile: (1 << wz_log2) pixels of I1 x (64 >> wz_log2) columns; <= tz_log2
@@ -70,8 +71,8 @@ struct TileParams {
 };
 
 struct TileConfig { int waves; int mb; int window; size_t lds_bytes; int threads; };
-TileConfig tile_config(int dtype, int sym);
-size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M);   // dynamic LDS of one workgroup
+TileConfig tile_config(int dtype, int sym, int narrow = 0);
+size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow = 0);   // dynamic LDS of one workgroup
 size_t tile_lds_limit(int sym);                               // LDS budget of one workgroup in that configuration
 hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s);
 
