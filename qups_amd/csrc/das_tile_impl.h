@@ -628,7 +628,11 @@ das_tile_kernel(const TileParams P) {
             if (wpix && st + 1 < nstage) wnext = wload(n + 1 == nlim(m0) ? n_lo : n + 1);
             const bool skip = wpix && (__ballot(wcur.x != 0.f || wcur.y != 0.f) == 0ull);   // whole wave weightless: no gathers
             const float4 rec = nrec[n];                // {B[n], receiver position}: one broadcast LDS read, issued ahead of the DMA
-            if (!(QDAS_ABL & 1) && more) dma_next((buf + NBUF - 1) % NBUF);   // lands during the next NBUF-1 stages
+            // The next stage's staging is issued at the start of this stage by the younger half of the waves and AFTER the pair
+            // loop by the older half: the hardware favours older waves, they finish their pair loop early and would only wait at
+            // the barrier -- their (scalar-heavy) issue phase then overlaps the younger waves' arithmetic instead of everybody's.
+            const bool dma_late = SYM && !(QDAS_ABL & 1024) && wave < WAVES / 2;
+            if (!(QDAS_ABL & 1) && more && !dma_late) dma_next((buf + NBUF - 1) % NBUF);   // lands during the next NBUF-1 stages
 
 #if QDAS_PROF
             const unsigned long long ts1_ = QDAS_TICK();
@@ -853,6 +857,7 @@ das_tile_kernel(const TileParams P) {
             }
 
             }   // !skip
+            if (!(QDAS_ABL & 1) && more && dma_late) dma_next((buf + NBUF - 1) % NBUF);
 #if QDAS_PROF
             const unsigned long long ts3_ = QDAS_TICK();
 #endif
