@@ -96,3 +96,15 @@ def test_greens_then_das_peaks_at_the_scatterer():
     assert img.max() > 0
     iz, ix = np.unravel_index(np.argmax(img), img.shape)
     assert abs(x[ix] - 2e-3) <= 1.1e-3 and abs(z[iz] - 15e-3) <= 1.1e-3
+
+
+@pytest.mark.gpu
+def test_examples_psf_demo_finds_both_targets():
+    """examples/psf_demo.py: greens -> real RF -> hilbert -> DAS with a generated acceptance-angle apodization"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("psf_demo", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "psf_demo.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    peaks = mod.main()
+    (x0, z0, _), (x1, z1, _) = peaks
+    assert abs(x0 + 3.0) <= 1.1 and abs(z0 - 22.0) <= 1.1 and abs(x1 - 2.0) <= 1.1 and abs(z1 - 15.0) <= 1.1
