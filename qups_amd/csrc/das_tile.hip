@@ -1,5 +1,5 @@
 // das_tile.hip -- host side of the tiled kernel: launch configurations, LDS budget, dispatch to the per-configuration
-// translation units (das_tile_f32.hip / das_tile_sym.hip / das_tile_f16.hip, kernel in das_tile_impl.h) and the fixed-order
+// translation units (das_tile_{f32,sym,symw,f16,f32x2,f16x2,f32x4,f16x4}.hip, kernel in das_tile_impl.h) and the fixed-order
 // reduce of a split aperture.  -DQDAS_UNITY compiles everything as ONE translation unit (profiling / ablation builds that
 // pass -DQDAS_ABL / -DQDAS_PROF: tools/ablate.sh).
 #ifdef QDAS_UNITY

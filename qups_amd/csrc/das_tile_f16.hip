@@ -1,5 +1,5 @@
 // das_tile_f16.hip -- instantiations of the tiled kernel for launch configuration 2 (fp16 data); one translation unit per
-// configuration so that the three compile in parallel (make -j).
+// configuration so that they compile in parallel (make -j).
 #include "das_tile_impl.h"
 
 namespace qdas {

@@ -1,5 +1,5 @@
 // das_tile_f32x2.hip -- instantiations of the tiled kernel for launch configuration 3 (two frames per launch); one translation unit per
-// configuration so that the three compile in parallel (make -j).
+// configuration so that they compile in parallel (make -j).
 #include "das_tile_impl.h"
 
 namespace qdas {

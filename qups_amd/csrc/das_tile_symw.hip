@@ -1,5 +1,5 @@
 // das_tile_symw.hip -- instantiations of the tiled kernel for launch configuration 7 (reciprocal mode, 128-sample windows); one translation unit per
-// configuration so that the three compile in parallel (make -j).
+// configuration so that they compile in parallel (make -j).
 #include "das_tile_impl.h"
 
 namespace qdas {
