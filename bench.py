@@ -84,8 +84,15 @@ def main():
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # QDAS_BENCH_SHARE_GPU=1 (plumbing check of the N > 1 path on a one-GPU box): every rank on cuda:0, gloo instead of RCCL
+        share = os.environ.get("QDAS_BENCH_SHARE_GPU", "0") == "1"
+        if share:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     else:
         torch.cuda.set_device(0)
     dev = torch.device(f"cuda:{local}")

@@ -86,3 +86,69 @@ class ShardedDasPlan:
             oN, oM = self.prob.osize
             y = torch.zeros((F, oM, oN, 0), dtype=xc.dtype, device=xc.device)
         return gather_pixels(y, self.prob.I, self.world, self.group)
+
+
+# ------------------------------------------------------------------------------------------
+# Alternative layout (SURVEY.md section 8e "alternative"): shard the TRANSMITS.  Every rank holds only its own slice
+# x[:, :, m-slab] of the channel data (1/G of it: for acquisitions that do not fit -- or should not be replicated --
+# on every GPU), beamforms ALL pixels over that sub-aperture and the partial images are summed with one all_reduce
+# (8 MiB at C3).  Works for the modes that sum over transmits ('DAS', 'SYN').  A sub-aperture of a full-synthetic-
+# aperture acquisition is no longer reciprocal, so the tiled kernel's reciprocal mode does not engage here.
+# ------------------------------------------------------------------------------------------
+def slice_transmits(Pv, Nv, t0, apods, M: int, rank: int, world: int):
+    """The rank's transmit slab ``[M*rank/world, M*(rank+1)/world)`` of every argument that has a transmit dimension:
+    ``Pv`` / ``Nv`` (3 x M; single-column arrays broadcast and are kept), ``t0`` (scalar or ``1 x 1 x M``), apodization arrays
+    (dimension 5 of ``I1 x I2 x I3 x N x M`` when it has size M).  Returns ``(Pv, Nv, t0, apods, m_begin, m_count)``."""
+    import numpy as np
+    b, c = shard_range(M, rank, world)
+    sl = slice(b, b + c)
+    cut = lambda P: P if np.asarray(P).reshape(np.asarray(P).shape[0], -1).shape[1] == 1 else np.asarray(P).reshape(np.asarray(P).shape[0], -1)[:, sl]
+    t0a = np.asarray(t0)
+    t0s = t0 if t0a.size == 1 else t0a.reshape(-1)[sl].reshape(1, 1, -1)
+    out = []
+    for a in apods:
+        a = np.asarray(a)
+        a5 = a.reshape(a.shape + (1,) * (5 - a.ndim))
+        out.append(a5[..., sl] if a5.shape[4] == M and M > 1 else a5)
+    return cut(Pv), cut(Nv), t0s, out, b, c
+
+
+def allreduce_image(y, group=None):
+    """Sum the ranks' partial images (complex tensors travel as (re, im) pairs of the real type)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return y
+    buf = torch.view_as_real(y.contiguous()) if y.is_complex() else y.contiguous()
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return torch.view_as_complex(buf) if y.is_complex() else buf
+
+
+def das_spec_tx_sharded(fun, Pi, Pr, Pv, Nv, x_local, t0, fs, c, *varargin, rank: int, world: int, M: int, group=None, compute: Callable | None = None):
+    """``das_spec`` over a transmit-sharded acquisition: ``x_local`` is THIS rank's ``T x N x M_r`` slice; the result (the full
+    image, summed over all transmits) is returned on every rank.  ``compute(fun, Pi, Pr, Pv_r, Nv_r, x_local, t0_r, fs, c, *opts)``
+    replaces the device path in the CPU tests."""
+    if fun not in ("DAS", "SYN"):
+        raise ValueError("transmit sharding needs a mode that sums over transmits ('DAS' | 'SYN')")
+    opts, apods, k = [], [], 0
+    va = list(varargin)
+    while k < len(va):
+        if not isinstance(va[k], str):
+            opts.append(va[k]); k += 1
+        elif va[k] == "apod":
+            apods.append(va[k + 1]); k += 2
+        elif va[k] in ("input-precision", "device", "interp", "modulation", "transpose", "rx-apod"):
+            opts += va[k:k + 2]; k += 2
+        else:
+            opts.append(va[k]); k += 1
+    Pv_r, Nv_r, t0_r, ap_r, _, cnt = slice_transmits(Pv, Nv, t0, apods, M, rank, world)
+    for a in ap_r:
+        opts += ["apod", a]
+    if cnt == 0:
+        raise ValueError("transmit sharding needs at least one transmit per rank")
+    if compute is not None:
+        y = compute(fun, Pi, Pr, Pv_r, Nv_r, x_local, t0_r, fs, c, *opts)
+    else:
+        from .das_spec import das_spec
+        y = das_spec(fun, Pi, Pr, Pv_r, Nv_r, x_local, t0_r, fs, c, *opts)
+    return allreduce_image(y, group)

@@ -80,3 +80,47 @@ def test_shard_range_properties():
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+
+
+def _tx_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import das_oracle as O
+        from qups_amd.dist import das_spec_tx_sharded, shard_range
+        for seq, fun, tvec in (("PW", "DAS", False), ("FSA", "DAS", True), ("DV", "SYN", False)):
+            case = make_case(seq=seq, interp="cubic", seed=5, N=6, M=7, I1=20, I2=5)
+            M = case["M"]
+            rng = np.random.default_rng(9)
+            t0 = case["t0"]
+            if tvec:
+                t0 = (case["t0"] + 1.0 / case["fs"] * rng.integers(-2, 3, (1, 1, M))).astype(np.float64)
+            am = rng.uniform(0.2, 1, (1, 1, 1, 1, M))
+            an = rng.uniform(0.2, 1, (1, 1, 1, case["N"], 1))
+            ora = lambda f, Pi, Pr, Pv, Nv, x, t0_, fs, c, *opts: torch.from_numpy(np.ascontiguousarray(O.das_spec(
+                f, Pi, Pr, Pv, Nv, x, t0_, fs, cinv_f32(c), VS=case["VS"], DV=case["DV"], interp="cubic",
+                apod=tuple(opts[k + 1] for k in range(len(opts)) if isinstance(opts[k], str) and opts[k] == "apod"))))
+            full = ora(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], t0, case["fs"], case["c"], "apod", am, "apod", an)
+            b, c = shard_range(M, rank, world)
+            y = das_spec_tx_sharded(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"][:, :, b:b + c], t0, case["fs"], case["c"],
+                                    *case["opt"], "interp", "cubic", "apod", am, "apod", an, rank=rank, world=world, M=M, compute=ora)
+            err = float((y - full).abs().max() / full.abs().max())
+            q.put((rank, seq, fun, err, tuple(y.shape) == tuple(full.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_transmit_sharded_allreduce_gloo(world):
+    """the alternative multi-GPU layout: every rank beamforms all pixels over ITS transmits, one all_reduce sums the partial images"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tx_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world * 3)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[4] and r[3] <= 1e-12 for r in res), res

@@ -307,6 +307,26 @@ def test_pixel_shards_concatenate():
         assert np.array_equal(np.concatenate(parts), full), G
 
 
+@pytest.mark.parametrize("seq,fun", [("FSA", "DAS"), ("PW", "DAS"), ("DV", "SYN")])
+def test_transmit_slabs_sum_to_the_image(seq, fun):
+    """the alternative multi-GPU layout on one device: partial images over transmit slabs add up to the image"""
+    torch = _torch()
+    from qups_amd import das_spec
+    from qups_amd.dist import slice_transmits
+    case = make_case(seq=seq, interp="cubic", seed=21, N=16, M=None if seq == "FSA" else 9, I1=96, I2=16)
+    M = case["M"]
+    am = np.random.default_rng(3).uniform(0.3, 1, (1, 1, 1, 1, M))
+    x = torch.from_numpy(case["x"]).cuda()
+    opts = list(case["opt"]) + ["interp", "cubic"]
+    full = das_spec(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], x, case["t0"], case["fs"], case["c"], *opts, "apod", am)
+    for G in (2, 3):
+        acc = torch.zeros_like(full)
+        for g in range(G):
+            Pv, Nv, t0, ap, b, c = slice_transmits(case["Pv"], case["Nv"], case["t0"], [am], M, g, G)
+            acc += das_spec(fun, case["Pi"], case["Pr"], Pv, Nv, x[:, :, b:b + c].contiguous(), t0, case["fs"], case["c"], *opts, "apod", ap[0])
+        assert rel_err(acc.cpu().numpy(), full.cpu().numpy()) <= 2e-5, G
+
+
 def test_c_abi_one_shot_matches_plan():
     """qdas_DASf: the reference kernel's own argument list (src/bf.cu:153-158)"""
     import ctypes as C
