@@ -227,6 +227,33 @@ typedef struct qdas_greens_desc {
 } qdas_greens_desc;
 int qdas_greens(const qdas_greens_desc *desc, void *y /* S x N x M complex */, void *stream);
 
+/* ---- Batched 1-D convolution along one dimension (band-pass / matched filtering of the traces in front of DAS).
+ * Replaces the kernels conv / convf / convc / convcf (reference src/convd.cu:95-127,130-146) launched by kern/convd.m:150-199
+ * (kern.feval(x, y, z, sizes) with the constant L0).  x: C x M x S, y: C x N x S, z: C x L x S, column-major, all DEVICE pointers,
+ * real or interleaved complex of `dtype`; C = product of the dimensions in front of the convolved one, S = of those behind it:
+ *   z[c,l,s] = sum_i x[c,i,s] * y[c, l + off - i, s]
+ * 'full': L = M+N-1, off = 0; 'same': L = M, off = N-1 - floor((N-1)/2); 'valid': L = max(M-N+1, 0), off = N-1
+ * (kern/convd.m:103-114).  A singleton column / slice dimension of x or y is broadcast (bits of `bcast`) instead of being
+ * replicated as the reference does (kern/convd.m:75-84).  The half-precision twins (convh / convch) are not provided. */
+#define QDAS_CONV_FULL  0
+#define QDAS_CONV_SAME  1
+#define QDAS_CONV_VALID 2
+#define QDAS_CONV_X_ONE_COLUMN 1   /* x is 1 x M x (S | 1) */
+#define QDAS_CONV_X_ONE_SLICE  2   /* x is (C | 1) x M x 1 */
+#define QDAS_CONV_Y_ONE_COLUMN 4
+#define QDAS_CONV_Y_ONE_SLICE  8
+typedef struct qdas_convd_desc {
+    uint64_t C, M, N, S;
+    int32_t  dtype;    /* QDAS_F64 | QDAS_F32                    */
+    int32_t  cplx;     /* 0: real data, 1: interleaved complex   */
+    int32_t  shape;    /* QDAS_CONV_*                            */
+    int32_t  bcast;    /* QDAS_CONV_{X,Y}_ONE_{COLUMN,SLICE}     */
+    int32_t  device;   /* HIP device ordinal, -1 = current       */
+    int32_t  reserved;
+} qdas_convd_desc;
+uint64_t qdas_convd_len(uint64_t M, uint64_t N, int shape);    /* L */
+int qdas_convd(const qdas_convd_desc *desc, const void *x, const void *y, void *z, void *stream);
+
 /* ---- Pre-processing in front of the DAS path: real RF traces -> analytic channel data, optionally downmixed.
  * Replaces ChannelData.hilbert (reference src/ChannelData.m:935-966: fft to N points along time, weights
  * [1; 2...; 1 + mod(N,2); 0...], ifft) and ChannelData.downmix (src/ChannelData.m:757-766: data .* exp(-2i*pi*fc*time))

@@ -10,7 +10,8 @@ from .das_spec import DasError, DasPlan, DasProblem, build_problem, das_spec, pa
 from .interpd import das_lut, sample2sep, wsinterpd2  # noqa: F401,E402
 from . import apodization  # noqa: F401,E402
 from . import preproc  # noqa: F401,E402
+from .convd import convd  # noqa: F401,E402
 from .ultrasound import ChannelData, Scan, Sequence, Transducer, UltrasoundSystem  # noqa: F401,E402
 
 __all__ = ["das_spec", "DasPlan", "DasProblem", "DasError", "build_problem", "parse_options", "das_lut", "sample2sep",
-           "wsinterpd2", "UltrasoundSystem", "Transducer", "Sequence", "Scan", "ChannelData"]
+           "wsinterpd2", "convd", "UltrasoundSystem", "Transducer", "Sequence", "Scan", "ChannelData"]

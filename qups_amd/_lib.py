@@ -21,6 +21,8 @@ KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED = 0, 1, 2
 KERNEL_NAMES = {KERNEL_GENERIC: "generic", KERNEL_TILED: "tiled"}
 MAX_APOD = 6
 QDAS_PRE_F32, QDAS_PRE_I16 = 0, 1
+QDAS_CONV_FULL, QDAS_CONV_SAME, QDAS_CONV_VALID = 0, 1, 2
+QDAS_CONV_X_ONE_COLUMN, QDAS_CONV_X_ONE_SLICE, QDAS_CONV_Y_ONE_COLUMN, QDAS_CONV_Y_ONE_SLICE = 1, 2, 4, 8
 RXAPOD_NONE, RXAPOD_ACCEPTANCE, RXAPOD_COSINE, RXAPOD_FNUMBER_PLANAR, RXAPOD_FNUMBER_ORIENTED = 0, 1, 2, 3, 4
 
 # every symbol include/qdas.h declares (tests check the library exports all of them)
@@ -28,7 +30,7 @@ SYMBOLS = (
     "qdas_plan_create", "qdas_plan_execute", "qdas_plan_execute_frames", "qdas_plan_delays",
     "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_set_timing",
     "qdas_plan_last_kernel_ms", "qdas_DAS", "qdas_DASf", "qdas_DASh", "qdas_delays", "qdas_delaysf",
-    "qdas_das_lut", "qdas_greens", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_last_error", "qdas_version", "qdas_device_info",
+    "qdas_das_lut", "qdas_greens", "qdas_convd", "qdas_convd_len", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_last_error", "qdas_version", "qdas_device_info",
 )
 
 
@@ -66,6 +68,11 @@ class GreensDesc(C.Structure):
 class PreDesc(C.Structure):
     _fields_ = [("T", C.c_uint64), ("K", C.c_uint64), ("Nfft", C.c_uint64), ("in_type", C.c_int32), ("device", C.c_int32),
                 ("fs", C.c_double), ("t0", C.c_double), ("fdown", C.c_double)]
+
+
+class ConvdDesc(C.Structure):
+    _fields_ = [("C", C.c_uint64), ("M", C.c_uint64), ("N", C.c_uint64), ("S", C.c_uint64), ("dtype", C.c_int32), ("cplx", C.c_int32),
+                ("shape", C.c_int32), ("bcast", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
 
 
 class QdasError(RuntimeError):
@@ -109,6 +116,9 @@ def lib():
     L.qdas_plan_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.qdas_das_lut.argtypes = [C.POINTER(LutDesc), C.c_void_p, C.c_void_p, C.c_void_p]
     L.qdas_greens.argtypes = [C.POINTER(GreensDesc), C.c_void_p, C.c_void_p]
+    L.qdas_convd.argtypes = [C.POINTER(ConvdDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.qdas_convd_len.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
+    L.qdas_convd_len.restype = C.c_uint64
     L.qdas_pre_plan_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(PreDesc)]
     L.qdas_pre_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.qdas_pre_plan_destroy.argtypes = [C.c_void_p]

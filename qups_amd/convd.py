@@ -1,0 +1,104 @@
+"""``convd`` -- batched convolution along one dimension on the device (reference kern/convd.m, kernels src/convd.cu:95-146).
+
+Mirrors the reference's call ``[C, lags] = convd(x, y, dim, shape)``: ``x`` and ``y`` are N-D arrays with compatible sizes
+(singleton dimensions broadcast) that are convolved along ``dim`` (1-based, as in the reference; default: the first
+non-singleton dimension); ``shape`` is ``'full'`` (default), ``'same'`` or ``'valid'``; ``convd(x)`` is the auto-correlation
+(``y = conj(flip(x))``, kern/convd.m:55).  The work is done by ``qdas_convd`` in ``libqdas.so`` (qups_amd/csrc/conv.hip); there is
+no CPU fallback.  Torch tensors are row-major, so the dimensions BEHIND ``dim`` are the fast "columns" of the C ABI and the
+ones in front of it the "slices": no transposition or replication of the data takes place."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_SHAPES = {"full": _lib.QDAS_CONV_FULL, "same": _lib.QDAS_CONV_SAME, "valid": _lib.QDAS_CONV_VALID}
+
+
+def conv_lags(M: int, N: int, shape: str):
+    """lags of the outputs (reference kern/convd.m:103-110)"""
+    if shape == "full":
+        return np.arange(-(N - 1), M)
+    if shape == "same":
+        return np.arange(0, M) - (N - 1) // 2
+    if shape == "valid":
+        return np.arange(0, M - N + 1)
+    raise ValueError("shape must be one of {'full', 'same', 'valid'}")
+
+
+def _first_nonsingleton(*arrs):
+    ds = [next((k for k, v in enumerate(a.shape) if v != 1), None) for a in arrs]
+    ds = [d for d in ds if d is not None]
+    return (min(ds) if ds else 0) + 1
+
+
+def convd(x, y=None, dim: int | None = None, shape: str = "full", device=None, return_lags: bool = False):
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("qups_amd: no HIP device visible -- convd has no CPU fallback")
+    if shape not in _SHAPES:
+        raise ValueError("shape must be one of {'full', 'same', 'valid'}")
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    xt = as_t(x)
+    if dim is None:
+        dim = _first_nonsingleton(xt, as_t(y)) if y is not None else _first_nonsingleton(xt)
+    if dim < 1:
+        raise ValueError("dim must be a positive integer")
+    d = dim - 1
+    yt = as_t(y) if y is not None else None
+    D = max(xt.ndim, yt.ndim if yt is not None else 0, dim)
+    xt = xt.reshape(tuple(xt.shape) + (1,) * (D - xt.ndim))
+    if yt is None:
+        yt = torch.conj(torch.flip(xt, (d,))).resolve_conj()
+    yt = yt.reshape(tuple(yt.shape) + (1,) * (D - yt.ndim))
+    for t in (xt, yt):
+        if not (t.is_floating_point() or t.is_complex()):
+            raise TypeError("convd expects floating-point data")
+    # computation type (kern/convd.m:259-268): single if either operand is single, else double; complex if either is complex
+    single = any(t.dtype in (torch.float32, torch.complex64, torch.float16) for t in (xt, yt))
+    cplx = xt.is_complex() or yt.is_complex()
+    dt = {(True, True): torch.complex64, (True, False): torch.float32, (False, True): torch.complex128, (False, False): torch.float64}[(single, cplx)]
+    sx, sy = list(xt.shape), list(yt.shape)
+    other = [k for k in range(D) if k != d]
+    if not all(sx[k] == sy[k] or sx[k] == 1 or sy[k] == 1 for k in other):
+        raise ValueError(f"Incompatible sizes {sx}, and {sy}.")
+    full = [max(sx[k], sy[k]) if k != d else 0 for k in range(D)]
+    M, N = sx[d], sy[d]
+    S = int(np.prod(full[:d])) if d else 1                      # slow dimensions (in front of dim in row-major order)
+    Cc = int(np.prod(full[d + 1:])) if d + 1 < D else 1         # fast dimensions
+    bits = 0
+
+    def prep(t, sz, one_col, one_slice):
+        nonlocal bits
+        lead, trail = sz[:d], sz[d + 1:]
+        lead_ok = lead == full[:d] or all(v == 1 for v in lead)
+        trail_ok = trail == full[d + 1:] or all(v == 1 for v in trail)
+        if not (lead_ok and trail_ok):                          # partial broadcast: replicate (the reference always does)
+            tgt = list(full); tgt[d] = sz[d]
+            t = t.expand(tgt)
+            lead, trail = full[:d], full[d + 1:]
+        if Cc > 1 and all(v == 1 for v in trail):
+            bits |= one_col
+        if S > 1 and all(v == 1 for v in lead):
+            bits |= one_slice
+        return t.to(device=dev, dtype=dt).contiguous()
+
+    xd = prep(xt, sx, _lib.QDAS_CONV_X_ONE_COLUMN, _lib.QDAS_CONV_X_ONE_SLICE)
+    yd = prep(yt, sy, _lib.QDAS_CONV_Y_ONE_COLUMN, _lib.QDAS_CONV_Y_ONE_SLICE)
+    lags = conv_lags(M, N, shape)
+    L = len(lags)
+    osz = list(full); osz[d] = L
+    z = torch.empty(osz, dtype=dt, device=dev)
+    if z.numel():
+        desc = _lib.ConvdDesc(Cc, M, N, S, _lib.QDAS_F32 if single else _lib.QDAS_F64, int(cplx), _SHAPES[shape], bits,
+                              dev.index if dev.index is not None else torch.cuda.current_device(), 0)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().qdas_convd(C.byref(desc), C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), C.c_void_p(z.data_ptr()),
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    if return_lags:
+        lsz = [1] * D; lsz[d] = L
+        return z, lags.reshape(lsz)
+    return z

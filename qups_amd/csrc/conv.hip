@@ -1,0 +1,161 @@
+// conv.hip -- batched 1-D convolution along one dimension (the band-pass / matched-filter step in front of DAS).
+//
+// Computes what the reference kernels conv / convf / convc / convcf compute (reference src/convd.cu:95-127, launched from
+// kern/convd.m:150-199) for x: C x M x S and y: C x N x S (C = product of the dimensions in front of the convolved one):
+//
+//   z[c, l, s] = sum_i x[c, i, s] * y[c, (l + off) - i, s],   l = 0 .. L-1,
+//
+// `off` = index of output 0 in the full convolution: 0 ('full', L = M+N-1), N-1 - floor((N-1)/2) ('same', L = M),
+// N-1 ('valid', L = M-N+1) (kern/convd.m:103-114: l0 = -lags(1); the kernel reads y[N-1 - (l0 - l + i)]).
+//
+// MI355X mapping.  The reference runs one thread per output that walks ALL of x (M iterations, most of them masked off) with two
+// dependent global loads per product.  Here
+//   * time-contiguous data (C == 1): a workgroup owns 1024 consecutive outputs of one slice; taps are processed in chunks of 256:
+//     the x span a chunk needs (1024 + 256 samples, zero-filled outside the record) and the taps are staged in LDS, the span
+//     de-interleaved by (index mod 4) so that a wave's reads are consecutive words.  Each lane produces 4 consecutive outputs and
+//     slides an 8-sample register window over the span: 4 LDS reads feed 16 multiply-accumulates (64 FMAs for complex data).
+//   * strided time (C > 1): lanes run along the contiguous column index c, every lane slides the same register window over its
+//     own column straight from global memory (the loads of a wave are coalesced, taps of a broadcast y come from one address).
+// A singleton column / slice dimension of either operand is broadcast by a zero stride instead of being replicated
+// (the reference repmat's, kern/convd.m:75-84).
+#include "qdas_device.h"
+#include "qdas_kernels.h"
+#include "../../include/qdas.h"
+
+namespace qdas {
+
+constexpr int CV_TL = 1024;   // outputs per workgroup (time-contiguous kernel)
+constexpr int CV_KC = 256;    // taps per LDS chunk
+constexpr int CV_Q  = (CV_TL + CV_KC) / 4;   // quads in the staged span
+
+template <typename T> struct cv_zero;
+template <> struct cv_zero<float>   { static __device__ __forceinline__ float   v() { return 0.f; } };
+template <> struct cv_zero<double>  { static __device__ __forceinline__ double  v() { return 0.0; } };
+template <> struct cv_zero<float2>  { static __device__ __forceinline__ float2  v() { return make_float2(0.f, 0.f); } };
+template <> struct cv_zero<double2> { static __device__ __forceinline__ double2 v() { return make_double2(0.0, 0.0); } };
+
+__device__ __forceinline__ void cv_mac(float &a, float x, float y)    { a = fmaf(x, y, a); }
+__device__ __forceinline__ void cv_mac(double &a, double x, double y) { a = fma(x, y, a); }
+__device__ __forceinline__ void cv_mac(float2 &a, float2 x, float2 y) {
+    a.x = fmaf(x.x, y.x, a.x); a.x = fmaf(-x.y, y.y, a.x);
+    a.y = fmaf(x.x, y.y, a.y); a.y = fmaf(x.y, y.x, a.y);
+}
+__device__ __forceinline__ void cv_mac(double2 &a, double2 x, double2 y) {
+    a.x = fma(x.x, y.x, a.x); a.x = fma(-x.y, y.y, a.x);
+    a.y = fma(x.x, y.y, a.y); a.y = fma(x.y, y.x, a.y);
+}
+
+// 4 outputs x 4 taps: output r, tap u uses window element w = r - u (hi[w] if w >= 0, lo[4 + w] otherwise)
+template <typename T>
+__device__ __forceinline__ void cv_step(T (&acc)[4], const T (&hi)[4], const T (&lo)[4], const T (&tap)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int w = r - u;
+            cv_mac(acc[r], w >= 0 ? hi[w] : lo[4 + w], tap[u]);
+        }
+}
+
+// ---- time-contiguous: x (M x S), y (N x S), z (L x S)
+template <typename T>
+__global__ void __launch_bounds__(256) conv_time_kernel(const ConvParams P) {
+    __shared__ T X[4][CV_Q];                     // X[w][k] = span element 4k + w
+    __shared__ T Y[CV_KC];
+    const T *__restrict__ x = (const T *)P.x + (uint64_t)blockIdx.x * P.xss;     // slices along grid.x (may exceed 65535)
+    const T *__restrict__ y = (const T *)P.y + (uint64_t)blockIdx.x * P.yss;
+    T *__restrict__ z = (T *)P.z + (uint64_t)blockIdx.x * P.L;
+    const int t = threadIdx.x;
+    const int64_t M = (int64_t)P.M, N = (int64_t)P.N, L = (int64_t)P.L;
+    const int64_t lfb = (int64_t)blockIdx.y * CV_TL + P.off;          // full-convolution index of this tile's first output
+    // taps that meet the record for some output of the tile: j in [lfb - (M-1), lfb + TL - 1]
+    int64_t jlo = lfb - (M - 1); if (jlo < 0) jlo = 0;
+    int64_t jhi = lfb + CV_TL; if (jhi > N) jhi = N;                  // exclusive
+    T acc[4] = {cv_zero<T>::v(), cv_zero<T>::v(), cv_zero<T>::v(), cv_zero<T>::v()};
+    for (int64_t j0 = jlo & ~(int64_t)3; j0 < jhi; j0 += CV_KC) {
+        const int64_t o = lfb - j0 - CV_KC;                           // record index of span element 0
+        __syncthreads();
+        for (int e = t; e < CV_TL + CV_KC; e += 256) {
+            const int64_t i = o + e;
+            X[e & 3][e >> 2] = (i >= 0 && i < M) ? x[i] : cv_zero<T>::v();
+        }
+        { const int64_t j = j0 + t; Y[t] = (j < N) ? y[j] : cv_zero<T>::v(); }
+        __syncthreads();
+        const int nt = (int)((jhi - j0 < CV_KC) ? (jhi - j0) : CV_KC);
+        const int nq = (nt + 3) >> 2;
+        int k = CV_KC / 4 + t;
+        T hi[4], lo[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) hi[w] = X[w][k];
+        for (int q = 0; q < nq; ++q) {
+            --k;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) lo[w] = X[w][k];
+            T tap[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tap[u] = Y[4 * q + u];
+            cv_step(acc, hi, lo, tap);
+#pragma unroll
+            for (int w = 0; w < 4; ++w) hi[w] = lo[w];
+        }
+    }
+    const int64_t l = (int64_t)blockIdx.y * CV_TL + 4 * t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (l + r < L) z[l + r] = acc[r];
+}
+
+// ---- strided time: x (C x M x S), y (C x N x S), z (C x L x S); lanes along c, 4 consecutive outputs per lane
+template <typename T>
+__global__ void __launch_bounds__(256) conv_col_kernel(const ConvParams P) {
+    const uint32_t ncb = (uint32_t)((P.C + 63) / 64);
+    const uint64_t sl = blockIdx.x / ncb;                                // slice; column block = blockIdx.x % ncb
+    const uint64_t c = (uint64_t)(blockIdx.x % ncb) * 64 + threadIdx.x;
+    const int64_t l = ((int64_t)blockIdx.y * 4 + threadIdx.y) * 4;
+    const int64_t M = (int64_t)P.M, N = (int64_t)P.N, L = (int64_t)P.L;
+    if (c >= P.C || l >= L) return;
+    const T *__restrict__ x = (const T *)P.x + sl * P.xss + c * P.xcs;
+    const T *__restrict__ y = (const T *)P.y + sl * P.yss + c * P.ycs;
+    T *__restrict__ z = (T *)P.z + (sl * P.L) * P.C + c;
+    const int64_t lf = l + P.off;
+    int64_t jlo = lf - (M - 1); if (jlo < 0) jlo = 0;
+    int64_t jhi = lf + 4; if (jhi > N) jhi = N;
+    auto ldx = [&](int64_t i) -> T { return (i >= 0 && i < M) ? x[(uint64_t)i * P.xts] : cv_zero<T>::v(); };
+    auto ldy = [&](int64_t j) -> T { return (j < N) ? y[(uint64_t)j * P.yts] : cv_zero<T>::v(); };
+    T acc[4] = {cv_zero<T>::v(), cv_zero<T>::v(), cv_zero<T>::v(), cv_zero<T>::v()};
+    T hi[4], lo[4], tap[4];
+    int64_t j = jlo;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) hi[w] = ldx(lf - j + w);
+    for (; j < jhi; j += 4) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) lo[w] = ldx(lf - j - 4 + w);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tap[u] = ldy(j + u);
+        cv_step(acc, hi, lo, tap);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) hi[w] = lo[w];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (l + r < L) z[(uint64_t)(l + r) * P.C] = acc[r];
+}
+
+template <typename T>
+static hipError_t launch_conv_t(const ConvParams &P, hipStream_t s) {
+    if (P.C == 1) {
+        dim3 grid((unsigned)P.S, (unsigned)((P.L + CV_TL - 1) / CV_TL));
+        hipLaunchKernelGGL(conv_time_kernel<T>, grid, dim3(256), 0, s, P);
+    } else {
+        dim3 grid((unsigned)(((P.C + 63) / 64) * P.S), (unsigned)((P.L + 15) / 16));
+        hipLaunchKernelGGL(conv_col_kernel<T>, grid, dim3(64, 4), 0, s, P);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(const ConvParams &P, int dtype, int cplx, hipStream_t s) {
+    if (dtype == QDAS_F32) return cplx ? launch_conv_t<float2>(P, s) : launch_conv_t<float>(P, s);
+    return cplx ? launch_conv_t<double2>(P, s) : launch_conv_t<double>(P, s);
+}
+
+}  // namespace qdas

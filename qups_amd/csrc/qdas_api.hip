@@ -856,3 +856,39 @@ extern "C" void qdas_pre_plan_destroy(qdas_pre_plan *pl) {
     qdas::pre_destroy(pl->p);
     delete pl;
 }
+
+// ---- batched 1-D convolution (conv.hip)
+extern "C" uint64_t qdas_convd_len(uint64_t M, uint64_t N, int shape) {
+    if (M == 0 || N == 0) return 0;
+    switch (shape) {
+        case QDAS_CONV_FULL:  return M + N - 1;
+        case QDAS_CONV_SAME:  return M;
+        case QDAS_CONV_VALID: return M >= N ? M - N + 1 : 0;
+        default: return 0;
+    }
+}
+
+extern "C" int qdas_convd(const qdas_convd_desc *d, const void *x, const void *y, void *z, void *stream) {
+    if (!d) return fail(QDAS_EINVAL, "null argument");
+    if (d->dtype != QDAS_F64 && d->dtype != QDAS_F32) return fail(QDAS_EINVAL, "convd: datatype must be double or single");
+    if (d->shape != QDAS_CONV_FULL && d->shape != QDAS_CONV_SAME && d->shape != QDAS_CONV_VALID)
+        return fail(QDAS_EINVAL, "convd: shape must be one of {'full', 'same', 'valid'}");
+    if (d->bcast & ~15) return fail(QDAS_EINVAL, "convd: unknown broadcast bits");
+    if (d->M >= (1ull << 31) || d->N >= (1ull << 31)) return fail(QDAS_EUNSUPPORTED, "convd: at most 2^31 - 1 samples along the convolved dimension");
+    const uint64_t L = qdas_convd_len(d->M, d->N, d->shape);
+    if (L == 0 || d->C == 0 || d->S == 0) return QDAS_OK;
+    if (!x || !y || !z) return fail(QDAS_EINVAL, "null data pointer");
+    const uint64_t ncb = (d->C + 63) / 64;
+    if (d->S * (d->C == 1 ? 1 : ncb) >= (1ull << 31) || (L + 15) / 16 > 65535ull * (d->C == 1 ? 64 : 1))
+        return fail(QDAS_EUNSUPPORTED, "convd: too many slices / outputs for one launch");
+    if (d->device >= 0) HIPCHK(hipSetDevice(d->device));
+    ConvParams p{};
+    p.x = x; p.y = y; p.z = z;
+    p.C = d->C; p.M = d->M; p.N = d->N; p.L = L; p.S = d->S;
+    p.off = d->shape == QDAS_CONV_FULL ? 0 : d->shape == QDAS_CONV_VALID ? (int64_t)d->N - 1 : (int64_t)(d->N - 1 - (d->N - 1) / 2);
+    const uint64_t Cx = (d->bcast & QDAS_CONV_X_ONE_COLUMN) ? 1 : d->C, Cy = (d->bcast & QDAS_CONV_Y_ONE_COLUMN) ? 1 : d->C;
+    p.xcs = Cx == 1 && d->C > 1 ? 0 : 1; p.xts = Cx; p.xss = (d->bcast & QDAS_CONV_X_ONE_SLICE) ? 0 : Cx * d->M;
+    p.ycs = Cy == 1 && d->C > 1 ? 0 : 1; p.yts = Cy; p.yss = (d->bcast & QDAS_CONV_Y_ONE_SLICE) ? 0 : Cy * d->N;
+    HIPCHK(launch_conv(p, d->dtype, d->cplx ? 1 : 0, (hipStream_t)stream));
+    return QDAS_OK;
+}

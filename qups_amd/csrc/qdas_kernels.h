@@ -97,4 +97,15 @@ struct GreensParams {
 };
 hipError_t launch_greens(const GreensParams &P, int dtype, hipStream_t s);
 
+// ---- batched 1-D convolution (conv.hip)
+struct ConvParams {
+    const void *x, *y;
+    void *z;
+    uint64_t C, M, N, L, S;          // x: C x M x S, y: C x N x S, z: C x L x S
+    int64_t off;                     // index of output 0 in the full convolution
+    uint64_t xcs, xts, xss;          // element strides of x: column, time, slice (0 = broadcast)
+    uint64_t ycs, yts, yss;
+};
+hipError_t launch_conv(const ConvParams &P, int dtype, int cplx, hipStream_t s);
+
 }  // namespace qdas

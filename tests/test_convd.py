@@ -1,0 +1,143 @@
+"""``convd``: oracle pins on CPU, device parity on the GPU (reference test: test/KernTest.m:115-163)."""
+import numpy as np
+import pytest
+
+from oracle import convd_oracle as O
+
+
+def rel(a, b):
+    den = np.abs(b).max() if b.size else 1.0
+    return float(np.abs(a - b).max() / (den if den > 0 else 1.0)) if b.size else 0.0
+
+
+# ---------------------------------------------------------------- CPU: the oracle against the reference's documented answers
+def test_oracle_doc_example_autocorrelation():
+    a = np.array([1, -2, 3, -4, 5.0])
+    z, lags = O.convd(a, a[::-1])                                       # kern/convd.m:33-35
+    assert np.array_equal(z, np.correlate(a, a, "full")) and np.array_equal(z, [5, -14, 26, -40, 55, -40, 26, -14, 5])
+    assert np.array_equal(lags, np.arange(-4, 5))
+    z2, _ = O.convd(a)                                                  # default y = conj(flip(x))
+    assert np.array_equal(z2, z)
+    c = a + 1j * a[::-1]
+    assert np.allclose(O.convd(c)[0], np.correlate(c, c, "full"))       # xcorr of a complex sequence
+
+
+@pytest.mark.parametrize("M,N", [(4, 2), (5, 3), (7, 4), (3, 5), (6, 1), (1, 1)])
+def test_oracle_shapes_follow_matlab_conv(M, N):
+    """MATLAB conv(u, v, 'same') = central part, size of u, starting at full index ceil((N-1)/2); 'valid' = full[N-1 : M]"""
+    rng = np.random.default_rng(M * 10 + N)
+    u, v = rng.standard_normal(M), rng.standard_normal(N)
+    f = np.convolve(u, v, "full")
+    assert np.allclose(O.convd(u, v, 1, "full")[0], f)
+    s0 = -(-(N - 1) // 2)
+    assert np.allclose(O.convd(u, v, 1, "same")[0], f[s0:s0 + M])
+    assert np.allclose(O.convd(u, v, 1, "valid")[0], f[N - 1:M] if M >= N else [])
+    for shp in ("full", "same", "valid"):
+        assert np.allclose(O.convd(u, v, 1, shp)[0], O.convd_direct(u, v, shp))
+    assert np.array_equal(O.convd([1, 2, 3, 4.0], [1, 1.0], 1, "same")[0], [3, 5, 7, 4])      # MATLAB, not numpy, centring
+
+
+def test_oracle_exponential_rows_example():
+    """kern/convd.m:37-50: row-wise conv(xa(i,:), xb(i,:), 'same') == convd(xa, xb, 2, 'same')"""
+    n, m = np.arange(16)[None, :], np.arange(4)[:, None]
+    xa, xb = 0.84 ** (n + m), 0.92 ** (n + m)
+    z, _ = O.convd(xa, xb, 2, "same")
+    for i in range(4):
+        f = np.convolve(xa[i], xb[i], "full")
+        assert np.allclose(z[i], f[8:24])
+    zb, _ = O.convd(np.stack([xa, xa], -1), xb, 2, "same")              # broadcasting over a trailing dimension
+    assert np.allclose(zb[..., 0], z) and np.allclose(zb[..., 1], z)
+
+
+def test_oracle_incompatible_sizes():
+    with pytest.raises(ValueError, match="Incompatible sizes"):
+        O.convd(np.zeros((4, 3)), np.zeros((2, 2)), 1)
+
+
+# ---------------------------------------------------------------- GPU parity
+def _dev(a, prec, cplx):
+    a = np.asarray(a)
+    if not cplx:
+        a = a.real
+    return a.astype({("single", True): np.complex64, ("single", False): np.float32, ("double", True): np.complex128,
+                     ("double", False): np.float64}[(prec, cplx)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["single", "double"])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_convd_reference_test_case(prec, cplx):
+    """the reference's own case (test/KernTest.m:51-55,152-160): 1024 random samples, every shape, every dimension"""
+    import torch
+    from qups_amd import convd
+    rng = np.random.default_rng(0)
+    A = _dev(rng.standard_normal(1024) + 1j * rng.standard_normal(1024), prec, cplx)
+    B = _dev(rng.standard_normal(1024) + 1j * rng.standard_normal(1024), prec, cplx)
+    tol = 1e4 * np.finfo(np.float32).eps if prec == "single" else 1e4 * np.finfo(np.float64).eps     # KernTest.m:131-135 (x eps(max))
+    for shape in ("full", "same", "valid"):
+        ref, lags = O.convd(A, B, 1, shape)
+        for dim in (1, 2, 3):
+            sz = [1] * 3
+            sz[dim - 1] = 1024
+            z, lg = convd(torch.from_numpy(A.reshape(sz)), torch.from_numpy(B.reshape(sz)), dim, shape, return_lags=True)
+            assert z.dtype == torch.from_numpy(A).dtype and tuple(z.shape) == tuple(1 if k != dim - 1 else len(ref) for k in range(3))
+            assert rel(z.cpu().numpy().reshape(-1), ref) <= tol, (shape, dim)
+            assert np.array_equal(lg.reshape(-1), lags.reshape(-1))
+    z = convd(torch.from_numpy(A)).cpu().numpy()                                          # auto-correlation default
+    assert rel(z, np.correlate(A.astype(np.complex128), A.astype(np.complex128), "full")) <= tol
+    zb = convd(torch.from_numpy(np.stack([A, A], -1).reshape(1024, 1, 1, 2)), torch.from_numpy(B))   # cat(4, A, A) broadcast
+    z1 = convd(torch.from_numpy(A), torch.from_numpy(B))
+    assert torch.equal(zb[:, 0, 0, 0], z1) and torch.equal(zb[:, 0, 0, 1], z1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["full", "same", "valid"])
+@pytest.mark.parametrize("sz_x,sz_y,dim", [
+    ((1500, 3, 2), (37, 3, 2), 1), ((1500, 3, 2), (37, 1, 1), 1), ((2, 3, 1100), (2, 3, 300), 3), ((2, 3, 1100), (1, 1, 300), 3),
+    ((5, 260, 70), (5, 9, 70), 2), ((5, 260, 70), (1, 9, 1), 2), ((5, 260, 70), (5, 9, 1), 2), ((5, 260, 1), (1, 9, 70), 2),
+    ((3, 40), (3, 90), 2), ((7, 1), (1, 1), 1), ((2049, 2), (1025, 1), 1), ((4, 3, 5), (4, 1, 5), 2), ((2, 1, 64), (2, 3, 5), 3),
+])
+def test_convd_shapes_dims_and_broadcast(sz_x, sz_y, dim, shape):
+    import torch
+    from qups_amd import convd
+    rng = np.random.default_rng(hash((sz_x, sz_y, dim)) & 0xffff)
+    x = (rng.standard_normal(sz_x) + 1j * rng.standard_normal(sz_x)).astype(np.complex64)
+    y = (rng.standard_normal(sz_y) + 1j * rng.standard_normal(sz_y)).astype(np.complex64)
+    ref, lags = O.convd(x, y, dim, shape)
+    z, lg = convd(torch.from_numpy(x), torch.from_numpy(y), dim, shape, return_lags=True)
+    assert tuple(z.shape) == ref.shape and lg.shape == lags.shape and np.array_equal(lg, lags)
+    assert rel(z.cpu().numpy(), ref) <= 2e-5
+    xr, yr = x.real.copy(), y.real.copy()                                                  # real data, mixed precision -> single
+    zr = convd(torch.from_numpy(xr.astype(np.float64)), torch.from_numpy(yr), dim, shape)
+    assert zr.dtype == torch.float32 and rel(zr.cpu().numpy(), O.convd(xr, yr, dim, shape)[0]) <= 2e-5
+
+
+@pytest.mark.gpu
+def test_convd_band_pass_of_channel_data():
+    """the use in front of DAS: FIR band-pass of every trace (T x N x M, time first) == per-trace numpy convolution"""
+    import torch
+    from qups_amd import convd
+    rng = np.random.default_rng(3)
+    T, N, M, K = 700, 8, 5, 63
+    x = rng.standard_normal((T, N, M)).astype(np.float32)
+    n = np.arange(K) - (K - 1) / 2
+    h = (np.sinc(0.5 * n) - 0.5 * np.sinc(0.25 * n) * 0.5) * np.hamming(K)
+    z = convd(torch.from_numpy(x).cuda(), torch.from_numpy(h.astype(np.float32)).cuda(), 1, "same").cpu().numpy()
+    ref = np.stack([[np.convolve(x[:, a, b].astype(np.float64), h, "full")[(K - 1) - (K - 1) // 2:][:T] for b in range(M)] for a in range(N)], 0).transpose(2, 0, 1)
+    assert z.shape == x.shape and rel(z, ref) <= 1e-5
+    zt = convd(torch.from_numpy(np.ascontiguousarray(x.transpose(2, 1, 0))).cuda(), torch.from_numpy(h.astype(np.float32)).cuda().reshape(1, 1, K), 3, "same")
+    assert rel(zt.cpu().numpy().transpose(2, 1, 0), ref) <= 1e-5                         # time-contiguous layout: the LDS kernel
+
+
+@pytest.mark.gpu
+def test_convd_errors_and_empty():
+    import torch
+    from qups_amd import convd
+    with pytest.raises(ValueError, match="Incompatible sizes"):
+        convd(torch.zeros(4, 3), torch.zeros(2, 2), 1)
+    with pytest.raises(ValueError, match="shape must be one of"):
+        convd(torch.zeros(4), torch.zeros(2), 1, "circular")
+    z = convd(torch.ones(3), torch.ones(5), 1, "valid")
+    assert tuple(z.shape) == (0,)
+    with pytest.raises(TypeError):
+        convd(torch.ones(3, dtype=torch.int32), torch.ones(2))
