@@ -29,10 +29,16 @@ def _draw(seed):
                tz=int(r.choice([0, 0, 64, 32, 16, 8])), ks=int(r.choice([0, 0, 1, 2, 3, 4])),
                fun=str(r.choice(["DAS", "DAS", "SYN", "MUL"])), F=int(r.choice([1, 1, 2, 3, 4, 6])), cmap=bool(r.integers(0, 4) == 0),
                gen=str(r.choice(["", "", "", "acceptance", "cosine", "fnumber"])))
+    if os.environ.get("QDAS_FUZZ_OVERRIDE"):                            # debugging aid: JSON dict of fields to force
+        import json
+        cfg.update(json.loads(os.environ["QDAS_FUZZ_OVERRIDE"]))
     return r, cfg
 
 
-@pytest.mark.parametrize("seed", range(128))
+_SEED0 = int(os.environ.get("QDAS_FUZZ_OFFSET", "0"))          # soak runs: QDAS_FUZZ_OFFSET=2000 QDAS_FUZZ_SEEDS=2000 pytest -n 8 ...
+
+
+@pytest.mark.parametrize("seed", range(_SEED0, _SEED0 + int(os.environ.get("QDAS_FUZZ_SEEDS", "128"))))
 def test_tiled_kernel_random_configuration(seed, monkeypatch):
     import torch
     from qups_amd import DasPlan, build_problem, parse_options
@@ -128,4 +134,26 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
             assert bad.mean() <= 0.05, (seed, c, float(bad.mean()))
             continue
         tol = 3e-3 if c["prec"] == "halfT" else 1e-4                      # covers tiles that fell back to the generic kernel (fp32 delays)
-        assert err <= tol, (seed, c, f, plan.tile_shape(), plan.wave_shape(), plan.aperture_split(), plan.fallback_tiles(), err)
+        if err > tol and os.environ.get("QDAS_FUZZ_DEBUG"):                 # debugging aid: where, and what the generic kernel says
+            yg = DasPlan(prob, kernel=1, **kw).execute_colmajor(xc, F).to(torch.complex64).cpu().numpy()[f].reshape(refv.shape[1], -1).T
+            e = np.abs(out - refv).max(axis=1) / den
+            worst = np.argsort(e)[::-1][:12]
+            i0 = kw.get("i_begin", 0)
+            print("bad pixels:", int((e > tol).sum()), "of", e.size)
+            for w in worst:
+                print("  i1", int((w + i0) % c["I1"]), "col", int((w + i0) // c["I1"]), "err", float(e[w]), "tiled", out[w, 0], "generic", yg[w, 0], "oracle", refv[w, 0])
+        if err > tol:
+            # The edge rule (all taps inside the record, else exactly 0) is a step in tau: a pair whose first / last tap sits within
+            # rounding of the end of the record is counted by one precision and not by the other.  Such pixels must be rare and
+            # must be explained by the float64 oracle with its time origin moved by 2e-4 samples either way.
+            e = np.abs(out - refv).max(axis=1) / den
+            bad = np.nonzero(e > tol)[0]
+            assert bad.size <= max(2, e.size // 500), (seed, c, f, plan.tile_shape(), plan.wave_shape(), plan.aperture_split(), plan.fallback_tiles(), err, bad.size)
+            best = e[bad]
+            for sh in (-2e-4, 2e-4):
+                r2 = O.das_spec(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs_all[f], np.asarray(t0, np.float64) + sh / case["fs"], case["fs"], c_or,
+                                VS=case["VS"], DV=case["DV"], interp=c["interp"], apod=oapod, fmod=c["fmod"]).reshape(I, -1, order="F")
+                if kw:
+                    r2 = r2[kw["i_begin"]: kw["i_begin"] + kw["i_count"]]
+                best = np.minimum(best, np.abs(out[bad] - r2[bad]).max(axis=1) / den)
+            assert best.max() <= 10 * tol, (seed, c, f, plan.tile_shape(), plan.wave_shape(), plan.aperture_split(), plan.fallback_tiles(), err, float(best.max()))
