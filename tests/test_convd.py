@@ -141,3 +141,39 @@ def test_convd_errors_and_empty():
     assert tuple(z.shape) == (0,)
     with pytest.raises(TypeError):
         convd(torch.ones(3, dtype=torch.int32), torch.ones(2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("QDAS_CONVD_FUZZ", "48"))))
+def test_convd_random_configuration(seed):
+    """random ranks, dimensions, broadcast patterns, lengths (around the 1024-output tile / 256-tap chunk), types"""
+    import torch
+    from qups_amd import convd
+    r = np.random.default_rng(7000 + seed)
+    D = int(r.integers(1, 5))
+    d = int(r.integers(0, D))
+    full = [int(r.choice([1, 2, 3, 5, 70])) for _ in range(D)]
+    M = int(r.choice([1, 2, 7, 255, 256, 257, 1023, 1024, 1025, 1300, 2400]))
+    N = int(r.choice([1, 2, 3, 4, 5, 31, 64, 255, 256, 257, 300, 700]))
+    sx, sy = list(full), list(full)
+    sx[d], sy[d] = M, N
+    for k in range(D):
+        if k != d and r.integers(0, 3) == 0:
+            (sx if r.integers(0, 2) else sy)[k] = 1
+    while int(np.prod(sx)) * N > 3e8 or int(np.prod(sy)) * M > 3e8:       # keep the oracle fast
+        k = int(np.argmax([v if i != d else 0 for i, v in enumerate(full)]))
+        full[k] = sx[k] = sy[k] = 1
+    shape = str(r.choice(["full", "same", "valid"]))
+    cx, cy, dbl = bool(r.integers(0, 2)), bool(r.integers(0, 2)), bool(r.integers(0, 4) == 0)
+    rt = np.float64 if dbl else np.float32
+    mk = lambda sz, cp: ((r.standard_normal(sz) + 1j * r.standard_normal(sz)).astype(np.complex128 if dbl else np.complex64) if cp
+                         else r.standard_normal(sz).astype(rt))
+    x, y = mk(sx, cx), mk(sy, cy)
+    if M * max(1, int(np.prod(full)) // max(full[d], 1)) > 2e6 and N > 300:
+        pytest.skip("oracle too slow")
+    ref, lags = O.convd(x, y, d + 1, shape)
+    z, lg = convd(torch.from_numpy(x), torch.from_numpy(y), d + 1, shape, return_lags=True)
+    assert tuple(z.shape) == ref.shape, (sx, sy, d, shape)
+    assert z.is_complex() == (cx or cy) and (z.dtype in (torch.float64, torch.complex128)) == dbl
+    assert np.array_equal(lg, lags)
+    assert rel(z.cpu().numpy(), ref) <= (1e-12 if dbl else 3e-5), (seed, sx, sy, d, shape, cx, cy, dbl)
