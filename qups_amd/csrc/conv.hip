@@ -11,9 +11,10 @@
 // MI355X mapping.  The reference runs one thread per output that walks ALL of x (M iterations, most of them masked off) with two
 // dependent global loads per product.  Here
 //   * time-contiguous data (C == 1): a workgroup owns 1024 consecutive outputs of one slice; taps are processed in chunks of 256:
-//     the x span a chunk needs (1024 + 256 samples, zero-filled outside the record) and the taps are staged in LDS, the span
-//     de-interleaved by (index mod 4) so that a wave's reads are consecutive words.  Each lane produces 4 consecutive outputs and
-//     slides an 8-sample register window over the span: 4 LDS reads feed 16 multiply-accumulates (64 FMAs for complex data).
+//     the x span a chunk needs (1024 + 256 samples, zero-filled outside the record) is staged in LDS, de-interleaved by
+//     (index mod 8) so that a wave's reads are consecutive words.  Each lane produces 8 consecutive outputs and slides a
+//     16-sample register window over the span; the taps are uniform and arrive through the scalar cache: 8 LDS reads feed 64
+//     multiply-accumulates (256 FMAs for complex data).
 //   * strided time (C > 1): lanes run along the contiguous column index c, every lane slides the same register window over its
 //     own column straight from global memory (the loads of a wave are coalesced, taps of a broadcast y come from one address).
 // A singleton column / slice dimension of either operand is broadcast by a zero stride instead of being replicated
@@ -26,7 +27,6 @@ namespace qdas {
 
 constexpr int CV_TL = 1024;   // outputs per workgroup (time-contiguous kernel)
 constexpr int CV_KC = 256;    // taps per LDS chunk
-constexpr int CV_Q  = (CV_TL + CV_KC) / 4;   // quads in the staged span
 
 template <typename T> struct cv_zero;
 template <> struct cv_zero<float>   { static __device__ __forceinline__ float   v() { return 0.f; } };
@@ -57,11 +57,20 @@ __device__ __forceinline__ void cv_step(T (&acc)[4], const T (&hi)[4], const T (
         }
 }
 
-// ---- time-contiguous: x (M x S), y (N x S), z (L x S)
+// ---- time-contiguous: x (M x S), y (N x S), z (L x S).  128 lanes x 8 consecutive outputs; the span is de-interleaved by
+// (index mod 8) with rows padded so that both the staging writes and the window reads are bank-conflict free; taps are uniform
+// per workgroup and come through the scalar cache (no LDS traffic): per 8 taps a lane issues 8 LDS reads for 64 MACs.
+template <typename T> struct cv_row {      // padded row length: row stride = 8 words x (words per element)  (mod 64 banks)
+    static constexpr int WPE = sizeof(T) / 4 > 4 ? 4 : sizeof(T) / 4;
+    static constexpr int Q = (CV_TL + CV_KC) / 8;
+    static constexpr int MOD = 64 / WPE;
+    static constexpr int LEN = Q + ((8 - Q % MOD) % MOD + MOD) % MOD;
+};
+
 template <typename T>
-__global__ void __launch_bounds__(256) conv_time_kernel(const ConvParams P) {
-    __shared__ T X[4][CV_Q];                     // X[w][k] = span element 4k + w
-    __shared__ T Y[CV_KC];
+__global__ void __launch_bounds__(128) conv_time_kernel(const ConvParams P) {
+    constexpr int QP = cv_row<T>::LEN;
+    __shared__ T X[8][QP];                       // X[w][k] = span element 8k + w
     const T *__restrict__ x = (const T *)P.x + (uint64_t)blockIdx.x * P.xss;     // slices along grid.x (may exceed 65535)
     const T *__restrict__ y = (const T *)P.y + (uint64_t)blockIdx.x * P.yss;
     T *__restrict__ z = (T *)P.z + (uint64_t)blockIdx.x * P.L;
@@ -71,38 +80,62 @@ __global__ void __launch_bounds__(256) conv_time_kernel(const ConvParams P) {
     // taps that meet the record for some output of the tile: j in [lfb - (M-1), lfb + TL - 1]
     int64_t jlo = lfb - (M - 1); if (jlo < 0) jlo = 0;
     int64_t jhi = lfb + CV_TL; if (jhi > N) jhi = N;                  // exclusive
-    T acc[4] = {cv_zero<T>::v(), cv_zero<T>::v(), cv_zero<T>::v(), cv_zero<T>::v()};
-    for (int64_t j0 = jlo & ~(int64_t)3; j0 < jhi; j0 += CV_KC) {
-        const int64_t o = lfb - j0 - CV_KC;                           // record index of span element 0
-        __syncthreads();
-        for (int e = t; e < CV_TL + CV_KC; e += 256) {
-            const int64_t i = o + e;
-            X[e & 3][e >> 2] = (i >= 0 && i < M) ? x[i] : cv_zero<T>::v();
-        }
-        { const int64_t j = j0 + t; Y[t] = (j < N) ? y[j] : cv_zero<T>::v(); }
-        __syncthreads();
-        const int nt = (int)((jhi - j0 < CV_KC) ? (jhi - j0) : CV_KC);
-        const int nq = (nt + 3) >> 2;
-        int k = CV_KC / 4 + t;
-        T hi[4], lo[4];
+    T acc[8];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) hi[w] = X[w][k];
-        for (int q = 0; q < nq; ++q) {
+    for (int r = 0; r < 8; ++r) acc[r] = cv_zero<T>::v();
+    for (int64_t j0 = jlo & ~(int64_t)7; j0 < jhi; j0 += CV_KC) {
+        const int64_t o = lfb - j0 - CV_KC;                           // record index of span element 0
+        const int nt = (int)((jhi - j0 < CV_KC) ? (jhi - j0) : CV_KC);
+        const int no = (nt + 7) >> 3;                                 // groups of 8 taps
+        {   // stage span elements [KC - 8 no, TL + KC): all loads in flight before the first LDS write
+            constexpr int NLD = (CV_TL + CV_KC) / 128;
+            const int e0 = CV_KC - 8 * no + t;
+            T v[NLD];
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) {
+                const int e = e0 + 128 * q;
+                const int64_t i = o + e;
+                v[q] = (e < CV_TL + CV_KC && i >= 0 && i < M) ? x[i] : cv_zero<T>::v();
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NLD; ++q) {
+                const int e = e0 + 128 * q;
+                if (e < CV_TL + CV_KC) X[e & 7][e >> 3] = v[q];
+            }
+            __syncthreads();
+        }
+        // window: win[w + 8] = span element (KC + 8t - 8g) + w, w = -8 .. 7  (output r, tap u of the group uses w = r - u)
+        T win[16];
+        int k = CV_KC / 8 + t;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) win[8 + w] = X[w][k];
+        for (int g = 0; g < no; ++g) {
             --k;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) lo[w] = X[w][k];
-            T tap[4];
+            for (int w = 0; w < 8; ++w) win[w] = X[w][k];
+            const int64_t jb = j0 + 8 * g;                            // uniform: scalar loads
 #pragma unroll
-            for (int u = 0; u < 4; ++u) tap[u] = Y[4 * q + u];
-            cv_step(acc, hi, lo, tap);
+            for (int u = 0; u < 8; ++u) {
+                const T tap = (jb + u < N) ? y[jb + u] : cv_zero<T>::v();
 #pragma unroll
-            for (int w = 0; w < 4; ++w) hi[w] = lo[w];
+                for (int r = 0; r < 8; ++r) cv_mac(acc[r], win[8 + r - u], tap);
+            }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) win[8 + w] = win[w];
         }
     }
-    const int64_t l = (int64_t)blockIdx.y * CV_TL + 4 * t;
+    // outputs 8t .. 8t+7 of a lane go through LDS (same de-interleaved mapping as the span) so that the stores are coalesced
+    __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (l + r < L) z[l + r] = acc[r];
+    for (int r = 0; r < 8; ++r) X[r][t] = acc[r];
+    __syncthreads();
+    const int64_t l0 = (int64_t)blockIdx.y * CV_TL;
+#pragma unroll
+    for (int q = 0; q < CV_TL / 128; ++q) {
+        const int e = t + 128 * q;
+        if (l0 + e < L) z[l0 + e] = X[e & 7][e >> 3];
+    }
 }
 
 // ---- strided time: x (C x M x S), y (C x N x S), z (C x L x S); lanes along c, 4 consecutive outputs per lane
@@ -145,7 +178,7 @@ template <typename T>
 static hipError_t launch_conv_t(const ConvParams &P, hipStream_t s) {
     if (P.C == 1) {
         dim3 grid((unsigned)P.S, (unsigned)((P.L + CV_TL - 1) / CV_TL));
-        hipLaunchKernelGGL(conv_time_kernel<T>, grid, dim3(256), 0, s, P);
+        hipLaunchKernelGGL(conv_time_kernel<T>, grid, dim3(128), 0, s, P);
     } else {
         dim3 grid((unsigned)(((P.C + 63) / 64) * P.S), (unsigned)((P.L + 15) / 16));
         hipLaunchKernelGGL(conv_col_kernel<T>, grid, dim3(64, 4), 0, s, P);
