@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""End-to-end demo on one MI355X: simulate point targets (greens) -> take the real RF -> hilbert on the device -> delay-and-sum
+"""End-to-end demo on one MI355X: simulate point targets (greens) -> take the real RF -> FIR band-pass (convd) -> hilbert on the device -> delay-and-sum
 with an acceptance-angle apodization generated inside the kernel -> report where the image peaks.
 
     python examples/psf_demo.py
@@ -14,6 +14,7 @@ from qups_amd import geometry as G, das_spec
 from qups_amd.apodization import rx_apod_spec
 from qups_amd.greens import greens
 from qups_amd.preproc import hilbert
+from qups_amd import convd
 
 
 def main():
@@ -25,6 +26,9 @@ def main():
     pulse = (np.exp(-(t * fc * 1.2) ** 2) * np.exp(2j * np.pi * fc * t)).astype(np.complex64)
     y, t0 = greens(Pr, Pr, scat, [1.0, 0.8], c0, pulse, float(t[0]), 4 * fs, fs, R0=c0 / fc, interp="cubic")   # S x N x M on the device
     rf = y.real.contiguous()                                                  # what a scanner delivers: real traces
+    k = np.arange(63) - 31                                                    # zero-phase band-pass 0.5 fc .. 1.5 fc (windowed sinc)
+    h = (2 * 1.5 * fc / fs * np.sinc(2 * 1.5 * fc / fs * k) - 2 * 0.5 * fc / fs * np.sinc(2 * 0.5 * fc / fs * k)) * np.hamming(63)
+    rf = convd(rf, torch.from_numpy(h.astype(np.float32)).cuda(), 1, "same")    # along time (dim 1), every trace, on the device
     x = hilbert(rf)                                                           # analytic channel data, on the device
     xs = np.linspace(-8e-3, 8e-3, 257)
     zs = np.linspace(8e-3, 28e-3, 321)

@@ -16,7 +16,8 @@
 //     16-sample register window over the span; the taps are uniform and arrive through the scalar cache: 8 LDS reads feed 64
 //     multiply-accumulates (256 FMAs for complex data).
 //   * strided time (C > 1): lanes run along the contiguous column index c, every lane slides the same register window over its
-//     own column straight from global memory (the loads of a wave are coalesced, taps of a broadcast y come from one address).
+//     own column straight from global memory (the loads of a wave are coalesced; the taps of a filter shared by all columns are
+//     uniform and come through the scalar cache).
 // A singleton column / slice dimension of either operand is broadcast by a zero stride instead of being replicated
 // (the reference repmat's, kern/convd.m:75-84).
 #include "qdas_device.h"
@@ -43,18 +44,6 @@ __device__ __forceinline__ void cv_mac(float2 &a, float2 x, float2 y) {
 __device__ __forceinline__ void cv_mac(double2 &a, double2 x, double2 y) {
     a.x = fma(x.x, y.x, a.x); a.x = fma(-x.y, y.y, a.x);
     a.y = fma(x.x, y.y, a.y); a.y = fma(x.y, y.x, a.y);
-}
-
-// 4 outputs x 4 taps: output r, tap u uses window element w = r - u (hi[w] if w >= 0, lo[4 + w] otherwise)
-template <typename T>
-__device__ __forceinline__ void cv_step(T (&acc)[4], const T (&hi)[4], const T (&lo)[4], const T (&tap)[4]) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int w = r - u;
-            cv_mac(acc[r], w >= 0 ? hi[w] : lo[4 + w], tap[u]);
-        }
 }
 
 // ---- time-contiguous: x (M x S), y (N x S), z (L x S).  128 lanes x 8 consecutive outputs; the span is de-interleaved by
@@ -138,39 +127,44 @@ __global__ void __launch_bounds__(128) conv_time_kernel(const ConvParams P) {
     }
 }
 
-// ---- strided time: x (C x M x S), y (C x N x S), z (C x L x S); lanes along c, 4 consecutive outputs per lane
-template <typename T>
+// ---- strided time: x (C x M x S), y (C x N x S), z (C x L x S); lanes along c, 8 consecutive outputs per lane, the same
+// 16-sample register window fed straight from global memory (a wave's loads are coalesced along c).  YB: y has one column
+// (a filter shared by all traces): its taps are uniform and come through the scalar cache.
+template <typename T, bool YB>
 __global__ void __launch_bounds__(256) conv_col_kernel(const ConvParams P) {
     const uint32_t ncb = (uint32_t)((P.C + 63) / 64);
     const uint64_t sl = blockIdx.x / ncb;                                // slice; column block = blockIdx.x % ncb
     const uint64_t c = (uint64_t)(blockIdx.x % ncb) * 64 + threadIdx.x;
-    const int64_t l = ((int64_t)blockIdx.y * 4 + threadIdx.y) * 4;
+    const int64_t l = ((int64_t)blockIdx.y * 4 + threadIdx.y) * 8;
     const int64_t M = (int64_t)P.M, N = (int64_t)P.N, L = (int64_t)P.L;
     if (c >= P.C || l >= L) return;
     const T *__restrict__ x = (const T *)P.x + sl * P.xss + c * P.xcs;
-    const T *__restrict__ y = (const T *)P.y + sl * P.yss + c * P.ycs;
+    const T *__restrict__ y = (const T *)P.y + sl * P.yss + (YB ? 0 : c * P.ycs);
     T *__restrict__ z = (T *)P.z + (sl * P.L) * P.C + c;
     const int64_t lf = l + P.off;
     int64_t jlo = lf - (M - 1); if (jlo < 0) jlo = 0;
-    int64_t jhi = lf + 4; if (jhi > N) jhi = N;
+    int64_t jhi = lf + 8; if (jhi > N) jhi = N;
     auto ldx = [&](int64_t i) -> T { return (i >= 0 && i < M) ? x[(uint64_t)i * P.xts] : cv_zero<T>::v(); };
-    auto ldy = [&](int64_t j) -> T { return (j < N) ? y[(uint64_t)j * P.yts] : cv_zero<T>::v(); };
-    T acc[4] = {cv_zero<T>::v(), cv_zero<T>::v(), cv_zero<T>::v(), cv_zero<T>::v()};
-    T hi[4], lo[4], tap[4];
+    T acc[8], win[16];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = cv_zero<T>::v();
     int64_t j = jlo;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) hi[w] = ldx(lf - j + w);
-    for (; j < jhi; j += 4) {
+    for (int w = 0; w < 8; ++w) win[8 + w] = ldx(lf - j + w);
+    for (; j < jhi; j += 8) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) lo[w] = ldx(lf - j - 4 + w);
+        for (int w = 0; w < 8; ++w) win[w] = ldx(lf - j - 8 + w);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) tap[u] = ldy(j + u);
-        cv_step(acc, hi, lo, tap);
+        for (int u = 0; u < 8; ++u) {
+            const T tap = (j + u < N) ? y[(uint64_t)(j + u) * (YB ? 1 : P.yts)] : cv_zero<T>::v();
 #pragma unroll
-        for (int w = 0; w < 4; ++w) hi[w] = lo[w];
+            for (int r = 0; r < 8; ++r) cv_mac(acc[r], win[8 + r - u], tap);
+        }
+#pragma unroll
+        for (int w = 0; w < 8; ++w) win[8 + w] = win[w];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 8; ++r)
         if (l + r < L) z[(uint64_t)(l + r) * P.C] = acc[r];
 }
 
@@ -180,8 +174,9 @@ static hipError_t launch_conv_t(const ConvParams &P, hipStream_t s) {
         dim3 grid((unsigned)P.S, (unsigned)((P.L + CV_TL - 1) / CV_TL));
         hipLaunchKernelGGL(conv_time_kernel<T>, grid, dim3(128), 0, s, P);
     } else {
-        dim3 grid((unsigned)(((P.C + 63) / 64) * P.S), (unsigned)((P.L + 15) / 16));
-        hipLaunchKernelGGL(conv_col_kernel<T>, grid, dim3(64, 4), 0, s, P);
+        dim3 grid((unsigned)(((P.C + 63) / 64) * P.S), (unsigned)((P.L + 31) / 32));
+        if (P.ycs == 0 && P.yts == 1) hipLaunchKernelGGL((conv_col_kernel<T, true>), grid, dim3(64, 4), 0, s, P);
+        else hipLaunchKernelGGL((conv_col_kernel<T, false>), grid, dim3(64, 4), 0, s, P);
     }
     return hipGetLastError();
 }
