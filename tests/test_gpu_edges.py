@@ -153,3 +153,38 @@ def test_host_resident_inputs_through_the_c_abi(F, seq):
     _lib.check(L.qdas_plan_execute_frames(h, C.c_void_p(xh.ctypes.data), C.c_void_p(yh.ctypes.data), F, prob.T * prob.N * prob.M, I, None))
     L.qdas_plan_destroy(h)
     assert np.abs(yh - yd).max() / np.abs(yd).max() <= 3e-5          # (frame pairs on the device path: another summation order)
+
+
+@pytest.mark.parametrize("kernel,tpose", [(2, False), (1, False), (0, True)])
+def test_channel_data_larger_than_4_GiB(kernel, tpose):
+    """64-bit addressing: a 4.4 GB acquisition whose only non-zero traces lie behind the 4 GiB mark must beamform exactly like
+    the small acquisition made of those transmits alone (both kernels; the tiled kernel's DMA descriptors are per transmit block).
+    Transposed data of more than 2 GiB has receiver strides beyond the 32-bit DMA offsets: the plan routes it to the generic kernel."""
+    import torch
+    from qups_amd import das_spec
+    from qups_amd import geometry as G
+    T, N, M, Ml = 4096, 256, 520, 8                                       # 4096 * 256 * 520 * 8 B = 4.36 GB
+    fc, c0 = 5e6, 1540.0
+    fs = 4 * fc
+    Pr, nrm = G.linear_array(N, 0.2e-3)
+    th = np.deg2rad(np.linspace(-20, 20, M))
+    Pv, Nv, opt = G.sequence_args("PW", focus=np.stack([np.sin(th), 0 * th, np.cos(th)]))
+    Pi = G.scan_cartesian(np.linspace(-5e-3, 5e-3, 48), np.linspace(5e-3, 30e-3, 160))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    tail = torch.view_as_complex(torch.randn((T, N, Ml, 2), generator=g, device="cuda", dtype=torch.float32))
+    x = torch.zeros((T, N, M), dtype=torch.complex64, device="cuda")
+    x[:, :, M - Ml:] = tail
+    f32 = lambda a: np.asarray(a, np.float32)
+    xa, ta = (x.permute(0, 2, 1).contiguous(), tail.permute(0, 2, 1).contiguous()) if tpose else (x, tail)
+    big, plan = das_spec("DAS", f32(Pi), f32(Pr), f32(Pv), f32(Nv), xa, -2e-6, fs, c0, *opt, "interp", "cubic", "transpose", tpose,
+                         return_plan=True, kernel=kernel)
+    last = lambda P: f32(P) if np.asarray(P).shape[1] == 1 else f32(P)[:, M - Ml:]
+    small = das_spec("DAS", f32(Pi), f32(Pr), last(Pv), last(Nv), ta, -2e-6, fs, c0, *opt, "interp", "cubic",
+                     "transpose", tpose, kernel=kernel or 1)          # (the same kernel on both sides: same fp32 delay rounding)
+    torch.cuda.synchronize()
+    assert plan.kernel == ("tiled" if kernel == 2 else "generic")
+    if kernel == 0:
+        with pytest.raises(Exception, match="trace strides too large"):
+            das_spec("DAS", f32(Pi), f32(Pr), f32(Pv), f32(Nv), xa, -2e-6, fs, c0, *opt, "interp", "cubic", "transpose", tpose, kernel=2)
+    b, s = big.cpu().numpy(), small.cpu().numpy()
+    assert np.abs(s).max() > 0 and rel_err(b, s) <= 2e-6
