@@ -152,6 +152,9 @@ int  qdas_plan_fallback_tiles(const qdas_plan *plan, uint64_t *ntiles);
  * image or pixel slab has too few tiles to fill the GPU); wave_z / ksplit may be NULL; all 0 for a
  * generic-kernel plan */
 int  qdas_plan_tile_shape(const qdas_plan *plan, int *tile_z, int *tile_cols, int *wave_z, int *ksplit);
+/* 1 when a QDAS_KERNEL_TILED plan runs in reciprocal mode (transmit elements == receive elements, one t0: every unordered
+ * transmit/receive pair is indexed and weighted once), else 0 */
+int  qdas_plan_reciprocal(const qdas_plan *plan);
 /* time of the last execute()'s kernels in ms measured with hipEvents on its stream
  * (enabled by qdas_plan_set_timing(plan, 1); synchronises the stream) */
 int  qdas_plan_set_timing(qdas_plan *plan, int enable);

@@ -28,7 +28,7 @@ RXAPOD_NONE, RXAPOD_ACCEPTANCE, RXAPOD_COSINE, RXAPOD_FNUMBER_PLANAR, RXAPOD_FNU
 # every symbol include/qdas.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "qdas_plan_create", "qdas_plan_execute", "qdas_plan_execute_frames", "qdas_plan_delays",
-    "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_set_timing",
+    "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_reciprocal", "qdas_plan_set_timing",
     "qdas_plan_last_kernel_ms", "qdas_DAS", "qdas_DASf", "qdas_DASh", "qdas_delays", "qdas_delaysf",
     "qdas_das_lut", "qdas_greens", "qdas_convd", "qdas_convd_len", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_last_error", "qdas_version", "qdas_device_info",
 )
@@ -112,6 +112,7 @@ def lib():
     L.qdas_plan_kernel.argtypes = [C.c_void_p]
     L.qdas_plan_fallback_tiles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.qdas_plan_tile_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.qdas_plan_reciprocal.argtypes = [C.c_void_p]
     L.qdas_plan_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.qdas_plan_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.qdas_das_lut.argtypes = [C.POINTER(LutDesc), C.c_void_p, C.c_void_p, C.c_void_p]

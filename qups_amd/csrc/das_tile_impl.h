@@ -501,10 +501,20 @@ das_tile_kernel(const TileParams P) {
     int wb[WPW], wb2[WPW];                             // A[m_r]*SB + j_r*strM*SB   (mirror: + j_r*strN*SB)
     uint32_t soff = 0, soff2 = 0;
     __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)P.x, 0, 0, 0x00020000), rsM = rsD;
+    // descriptor based `o` bytes into the frame (+ `extra`: the frame itself); records beyond the frame read as zeros
+    auto make_rs = [&](uint64_t o, uint64_t extra) -> __amdgpu_buffer_rsrc_t {
+        const uint64_t rem = xbytes > o ? xbytes - o : 0;   // (m0 >= M when the split is exhausted: nothing more is issued)
+        return __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + (rem ? o + extra : 0)), 0, rem > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem, 0x00020000);
+    };
+    // Reciprocal mode walks the whole frame inside one transmit block (the mirror "transmits", or the receivers of transposed
+    // data): its running offsets are kept below 2^30 by re-basing the descriptor when they get there (uniform, rare).  The
+    // general kernels keep one descriptor per block (plan-time check: the walk stays below 2^31 bytes).
+    constexpr uint32_t REBASE = 1u << 30;
+    uint64_t offD = 0, offM = 0;
     auto dma_block = [&](uint32_t m0) {
         const uint64_t o = ((uint64_t)m0 * P.strM + (uint64_t)n_lo * P.strN) * SB;
-        const uint64_t rem = xbytes > o ? xbytes - o : 0;   // (m0 >= M when the split is exhausted: nothing more is issued)
-        rsD = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + (rem ? o + (uint64_t)fa * P.x_fstride : 0)), 0, rem > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem, 0x00020000);
+        if constexpr (SYM) offD = o;
+        rsD = make_rs(o, (uint64_t)fa * P.x_fstride);
         soff = 0;
 #pragma unroll
         for (int r = 0; r < WPW; ++r) {
@@ -514,14 +524,10 @@ das_tile_kernel(const TileParams P) {
             wb[r] = am * SB + (int)((long)j * (long)P.strM * SB);
             if constexpr (SYM) wb2[r] = am * SB + (int)((long)j * (long)P.strN * SB);
         }
-        if constexpr (FBX) {                           // the same traces of the next frame (four frames: of frame fb)
-            const uint64_t o2 = o + (uint64_t)fb * P.x_fstride;
-            rsM = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + (rem ? o2 : 0)), 0, rem > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem, 0x00020000);
-        }
+        if constexpr (FBX) rsM = make_rs(o, (uint64_t)fb * P.x_fstride);   // the same traces of the next frame (four frames: of frame fb)
         if constexpr (SYM) {                           // mirror traces x[:, rx = m0 + j, tx = n] (reciprocal mode starts every block at n = 0)
-            const uint64_t o2 = (uint64_t)m0 * P.strN * SB;
-            const uint64_t rem2 = xbytes > o2 ? xbytes - o2 : 0;
-            rsM = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + (rem2 ? o2 : 0)), 0, rem2 > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem2, 0x00020000);
+            offM = (uint64_t)m0 * P.strN * SB;
+            rsM = make_rs(offM, 0);
             soff2 = 0;
         }
     };
@@ -552,6 +558,9 @@ das_tile_kernel(const TileParams P) {
             }
         }
         soff += (uint32_t)P.strN * SB;                 // next receiver, same transmit block
+        if constexpr (SYM) {
+            if (soff >= REBASE) { offD += soff; soff = 0; rsD = make_rs(offD, 0); }
+        }
         if constexpr (SYM) {                           // same window start A[m] + B[n] in the mirror trace
 #pragma unroll
             for (int r = 0; r < WPW; ++r) {
@@ -565,6 +574,7 @@ das_tile_kernel(const TileParams P) {
                 }
             }
             soff2 += (uint32_t)P.strM * SB;            // next "transmit" n of the mirror traces
+            if (soff2 >= REBASE) { offM += soff2; soff2 = 0; rsM = make_rs(offM, 0); }
         }
     };
 

@@ -366,18 +366,20 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         eligible = false; why = "tiled kernel: N + M too large for the LDS header";
     }
     if (eligible && (z.T < 8)) { eligible = false; why = "tiled kernel needs T >= 8"; }
-    {   // LDS-DMA offsets inside one transmit block are 32-bit: N receivers + mb transmits + a window must stay below 2^31 bytes
+    {   // LDS-DMA offsets are 32-bit and signed: inside one transmit block, N receivers + mb transmits + a window must stay below
+        // 2^31 bytes.  The reciprocal kernel re-bases its descriptors whenever a running offset reaches 2^30 (its mirror traces
+        // walk the whole frame), so there only one trace stride and the span of a block have to stay below 2^30.
         uint64_t strM = (z.flag & QDAS_FLAG_TPOSE) ? z.T : z.T * z.N;
         uint64_t strN = (z.flag & QDAS_FLAG_TPOSE) ? z.T * z.M : z.T;
         if (mul) std::swap(strM, strN);
-        const uint64_t lim = 1ull << 31, slack = 65536;
-        // mirror traces of the reciprocal mode walk the other way (N "transmits" apart): drop the mode for >2 GiB frames
-        if (sym && (z.N * strM + (uint64_t)tile_config(dt, 1).mb * strN) * data_size(dt) + slack >= lim) {
+        const uint64_t slack = 65536;
+        const uint64_t smax = strM > strN ? strM : strN;
+        if (sym && (uint64_t)(tile_config(dt, 1).mb + 1) * smax * data_size(dt) + slack >= (1ull << 30)) {
             sym = 0;
             pl->tc = tile_config(dt, 0);
             if (eligible && tile_lds_bytes(dt, 0, z.N, z.M) > tile_lds_limit(0)) { eligible = false; why = "tiled kernel: N + M too large for the LDS header"; }
         }
-        if (eligible && (kN * strN + (uint64_t)pl->tc.mb * strM) * data_size(dt) + slack >= lim) {
+        if (eligible && !sym && (kN * strN + (uint64_t)pl->tc.mb * strM) * data_size(dt) + slack >= (1ull << 31)) {
             eligible = false; why = "tiled kernel: trace strides too large for 32-bit DMA offsets (transposed data of more than 2 GiB)";
         }
     }
@@ -546,6 +548,8 @@ extern "C" int qdas_plan_tile_shape(const qdas_plan *pl, int *tile_z, int *tile_
     if (ksplit) *ksplit = tiled ? (int)pl->tp.ksplit : 0;
     return QDAS_OK;
 }
+
+extern "C" int qdas_plan_reciprocal(const qdas_plan *pl) { return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.sym ? 1 : 0; }
 
 extern "C" int qdas_plan_set_timing(qdas_plan *pl, int enable) {
     if (!pl) return fail(QDAS_EINVAL, "null plan");

@@ -419,6 +419,11 @@ class DasPlan:
         _lib.check(self.lib.qdas_plan_tile_shape(self._h, C.byref(tz), C.byref(tc), None, C.byref(ks)))
         return int(ks.value)
 
+    @property
+    def reciprocal(self) -> bool:
+        """True when the tiled kernel runs in reciprocal mode (FSA with transmit elements == receive elements, one t0)."""
+        return bool(self.lib.qdas_plan_reciprocal(self._h))
+
     def fallback_tiles(self) -> int:
         n = C.c_uint64()
         _lib.check(self.lib.qdas_plan_fallback_tiles(self._h, C.byref(n)))

@@ -159,7 +159,8 @@ def test_host_resident_inputs_through_the_c_abi(F, seq):
 def test_channel_data_larger_than_4_GiB(kernel, tpose):
     """64-bit addressing: a 4.4 GB acquisition whose only non-zero traces lie behind the 4 GiB mark must beamform exactly like
     the small acquisition made of those transmits alone (both kernels; the tiled kernel's DMA descriptors are per transmit block).
-    Transposed data of more than 2 GiB has receiver strides beyond the 32-bit DMA offsets: the plan routes it to the generic kernel."""
+    Transposed data of more than 2 GiB has receiver strides beyond the 32-bit DMA offsets of the general tiled kernel: the plan
+    routes it to the generic kernel."""
     import torch
     from qups_amd import das_spec
     from qups_amd import geometry as G
@@ -188,3 +189,29 @@ def test_channel_data_larger_than_4_GiB(kernel, tpose):
             das_spec("DAS", f32(Pi), f32(Pr), f32(Pv), f32(Nv), xa, -2e-6, fs, c0, *opt, "interp", "cubic", "transpose", tpose, kernel=2)
     b, s = big.cpu().numpy(), small.cpu().numpy()
     assert np.abs(s).max() > 0 and rel_err(b, s) <= 2e-6
+
+
+@pytest.mark.parametrize("tpose", [False, True])
+def test_reciprocal_mode_beyond_2_GiB(tpose, monkeypatch):
+    """a 2.6 GB full-synthetic-aperture acquisition: the mirror traces of the reciprocal mode walk the whole frame (descriptor
+    re-basing); the result must equal the general tiled kernel's"""
+    import torch
+    from qups_amd import das_spec
+    from qups_amd import geometry as G
+    T, N = 3072, 320                                                      # 3072 * 320 * 320 * 8 B = 2.5 GB
+    fc, c0 = 5e6, 1540.0
+    fs = 4 * fc
+    Pr, nrm = G.linear_array(N, 0.2e-3)
+    Pv, Nv, opt = G.sequence_args("FSA", tx_pos=Pr, tx_normals=nrm)
+    Pi = G.scan_cartesian(np.linspace(-6e-3, 6e-3, 64), np.linspace(5e-3, 5e-3 + 127 * 77e-6, 128))
+    g = torch.Generator(device="cuda").manual_seed(6)
+    x = torch.view_as_complex(torch.randn((T, N, N, 2), generator=g, device="cuda", dtype=torch.float32))
+    f32 = lambda a: np.asarray(a, np.float32)
+    ys, plan = das_spec("DAS", f32(Pi), f32(Pr), f32(Pv), f32(Nv), x, 0.0, fs, c0, *opt, "interp", "lanczos3", "transpose", tpose, return_plan=True, kernel=2)
+    monkeypatch.setenv("QDAS_NO_SYM", "1")
+    if tpose:                                                             # general tiled kernel: not for transposed data of this size
+        x = x.permute(0, 2, 1).contiguous()
+    yg = das_spec("DAS", f32(Pi), f32(Pr), f32(Pv), f32(Nv), x, 0.0, fs, c0, *opt, "interp", "lanczos3", kernel=2)
+    torch.cuda.synchronize()
+    assert plan.kernel == "tiled" and plan.reciprocal
+    assert rel_err(ys.cpu().numpy(), yg.cpu().numpy()) <= 1e-5
