@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 tiled")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--prec", default=None, help="override the workload's data precision (single | halfT); not the headline")
     ap.add_argument("--gen-apod", action="store_true", help="generate the workload's receive apodization inside the kernel "
                     "(qdas_desc.rx_apod_*) instead of streaming the materialised I x N array")
     args = ap.parse_args()
@@ -98,6 +99,9 @@ def main():
     dev = torch.device(f"cuda:{local}")
 
     w = workload(args.workload)
+    if args.prec:
+        w["prec"] = args.prec
+        w["label"] += f" [data precision {args.prec}]"
     T, N, M = w["T"], w["N"], w["M"]
     I = w["I1"] * w["I2"]
     g = torch.Generator(device=dev).manual_seed(1234)     # same data on every rank (replicated input)

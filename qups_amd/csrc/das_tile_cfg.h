@@ -9,9 +9,10 @@ struct Cfg { int waves, mb, w, nbuf, psz, bpc; };
 // cfg 3 / 4: two frames per launch (fp32 / fp16 data): 16 transmits x 2 frames per stage -- the reciprocal mode's window layout;
 // cfg 5 / 6: four frames per launch: 8 transmits x 4 frames per stage
 // cfg 7: reciprocal mode with 128-sample windows (a third less staging traffic; used when every tile of some footprint fits them)
-static constexpr Cfg CFGS[8] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1},
+// cfg 8: reciprocal mode for fp16 data (256-sample windows = one 1024-byte DMA piece, like cfg 7)
+static constexpr Cfg CFGS[9] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1},
                                 {16, 16, 192, 2, 16, 1}, {16, 16, 384, 2, 16, 1}, {16, 8, 192, 2, 16, 1}, {16, 8, 384, 2, 16, 1},
-                                {16, 16, 128, 2, 16, 1}};
+                                {16, 16, 128, 2, 16, 1}, {16, 16, 256, 2, 16, 1}};
 // fb: frames per launch (1 | 2 | 4)
-static inline int cfg_index(int dtype, int sym, int fb = 1, int narrow = 0) { return sym ? (narrow ? 7 : 1) : (fb == 4 ? (dtype == 2 ? 6 : 5) : (fb == 2 ? (dtype == 2 ? 4 : 3) : (dtype == 2 ? 2 : 0))); }
+static inline int cfg_index(int dtype, int sym, int fb = 1, int narrow = 0) { return sym ? (dtype == 2 ? 8 : (narrow ? 7 : 1)) : (fb == 4 ? (dtype == 2 ? 6 : 5) : (fb == 2 ? (dtype == 2 ? 4 : 3) : (dtype == 2 ? 2 : 0))); }
 }  // namespace qdas

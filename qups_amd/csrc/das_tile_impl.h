@@ -234,7 +234,7 @@ das_tile_kernel(const TileParams P) {
     constexpr int NHP = FB4 ? 2 : 1;          // passes of the pair loop: one per frame pair
     constexpr int NFR = FB4 ? 4 : (FB2 ? 2 : 1);   // frames per launch
     constexpr int NW = FB4 ? 4 * MB : (TWO ? 2 * MB : MB);     // windows per LDS buffer
-    static_assert(!SYM || (sizeof(ST) == 8 && !WTAB), "reciprocal mode: fp32 data, no weight table");
+    static_assert(!SYM || !WTAB, "reciprocal mode: no weight table");
     static_assert(!(SYM && FBX) && !(FB2 && FB4), "reciprocal mode runs one frame per launch");
     constexpr int K = tapinfo<INTERP>::K;
     constexpr int THREADS = WAVES * 64;
@@ -751,11 +751,16 @@ das_tile_kernel(const TileParams P) {
                 } else {
                     taps_f16 g0, g1, h0, h1;
                     lds_issue<K, (GSET * MB + 2 * p) * WB>(g0, ad0); lds_issue<K, (GSET * MB + 2 * p + 1) * WB>(g1, ad1);
-                    if constexpr (FBX) { lds_issue<K, (HSET * MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (HSET * MB + 2 * p + 1) * WB>(h1, ad1); }
+                    if constexpr (TWO) { lds_issue<K, (HSET * MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (HSET * MB + 2 * p + 1) * WB>(h1, ad1); }
                     if constexpr (K < 4) { g0.r[2] = g0.r[3] = g1.r[2] = g1.r[3] = h0.r[2] = h0.r[3] = h1.r[2] = h1.r[3] = 0u; }
                     if constexpr (K < 2) { g0.r[1] = g1.r[1] = h0.r[1] = h1.r[1] = 0u; }
                     if constexpr (hp == 0 && K > 1) weights2<INTERP>(s, w);  // overlaps the LDS latency
-                    if constexpr (FBX) lds_fence2(g0, g1, h0, h1, w); else lds_fence(g0, g1, w);
+                    if constexpr (TWO) lds_fence2(g0, g1, h0, h1, w); else lds_fence(g0, g1, w);
+                    if constexpr (DIAG) {                 // (as for fp32 data above)
+                        if (m < n)      { for (int k = 0; k < 4; ++k) g0.r[k] = 0u; }
+                        if (m <= n)     { for (int k = 0; k < 4; ++k) h0.r[k] = 0u; }
+                        if (m + 1 <= n) { for (int k = 0; k < 4; ++k) h1.r[k] = 0u; }
+                    }
                     if constexpr (TAIL) {
                         if (!upper) {
 #pragma unroll
@@ -765,9 +770,14 @@ das_tile_kernel(const TileParams P) {
                     if constexpr (K == 1) {
                         v0 = half2_to_v2f(g0.r[0]); v1 = half2_to_v2f(g1.r[0]);
                         if constexpr (FBX) { u0 = half2_to_v2f(h0.r[0]); u1 = half2_to_v2f(h1.r[0]); }
+                        if constexpr (SYM) { v0 += half2_to_v2f(h0.r[0]); v1 += half2_to_v2f(h1.r[0]); }
                     } else if constexpr (SPLIT) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { mix_mac(v0, g0.r[k], w[k].x); mix_mac(v1, g1.r[k], w[k].y); }
+                        if constexpr (SYM) {
+#pragma unroll
+                            for (int k = 0; k < K; ++k) { mix_mac(v0, h0.r[k], w[k].x); mix_mac(v1, h1.r[k], w[k].y); }
+                        }
                         if constexpr (FBX) {
 #pragma unroll
                             for (int k = 0; k < K; ++k) { mix_mac(u0, h0.r[k], w[k].x); mix_mac(u1, h1.r[k], w[k].y); }
@@ -775,7 +785,7 @@ das_tile_kernel(const TileParams P) {
                     } else {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { mix_mac(A0, g0.r[k], w[k].x); mix_mac(A1, g1.r[k], w[k].y); }
-                        if constexpr (FBX) {
+                        if constexpr (TWO) {
 #pragma unroll
                             for (int k = 0; k < K; ++k) { mix_mac(B0, h0.r[k], w[k].x); mix_mac(B1, h1.r[k], w[k].y); }
                         }
@@ -938,7 +948,7 @@ das_tile_kernel(const TileParams P) {
 template <int INTERP, typename ST, int CI>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
     constexpr Cfg G = CFGS[CI];
-    constexpr bool SYM = (CI == 1 || CI == 7), FB2 = (CI == 3 || CI == 4), FB4 = (CI == 5 || CI == 6);
+    constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8), FB2 = (CI == 3 || CI == 4), FB4 = (CI == 5 || CI == 6);
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
     const dim3 g(ntiles * (P.probe ? 1u : P.ksplit)), b(G.waves * 64);
 #define QDAS_LAUNCH(FM, WT) QDAS_LAUNCH_P(FM, WT, false)

@@ -352,7 +352,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // reciprocal mode (das_tile_impl.h "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
     // elements and share one t0 has tau(n,m) == tau(m,n); detected from the geometry itself, bit-exactly.
     int sym = 0;
-    if (eligible && !syn && dt == QDAS_F32 && z.VS && z.DV && z.N == z.M && z.S == 0 && !g.gen_kind && !getenv("QDAS_NO_SYM")) {
+    if (eligible && !syn && (dt == QDAS_F32 || dt == QDAS_F16) && z.VS && z.DV && z.N == z.M && z.S == 0 && !g.gen_kind && !getenv("QDAS_NO_SYM")) {
         std::vector<float> hr(3 * z.N), hv(4 * z.M);
         if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
         if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);
@@ -481,7 +481,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         }
         // reciprocal mode: first the 128-sample-window configuration (less staging traffic); it is kept only if some footprint
         // has no misfit tile at all -- otherwise the 192-sample configuration
-        t.narrow = (sym && !getenv("QDAS_NO_NARROW")) ? 1 : 0;
+        t.narrow = (sym && dt == QDAS_F32 && !getenv("QDAS_NO_NARROW")) ? 1 : 0;
         if (t.narrow) pl->tc = tile_config(dt, 1, 1);
         if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
         if (t.narrow && !pl->no_fallback) {

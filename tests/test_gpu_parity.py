@@ -405,6 +405,30 @@ def test_reciprocal_mode_matches_general_mode(monkeypatch):
     assert rel_err(run_das(case, kernel=2)[0], run_oracle(case)) <= TOL32
 
 
+@pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3"])
+def test_reciprocal_mode_with_half_precision_data(interp, monkeypatch):
+    """fp16 channel data in reciprocal mode (launch configuration 8): equals the general fp16 kernel and the oracle on the
+    fp16-rounded data; transposed data, the record edge (checked loop) and fmod included"""
+    from tests.test_gpu_parity import run_das as rd
+    for tpose, fmod in ((False, 0.0), (True, 0.0), (False, 2.5e6)):
+        case = make_case(seq="FSA", interp=interp, seed=41, N=32, I1=140, I2=20, data="noise", T=420 if tpose else None)
+        xh = (case["x"].real.astype(np.float16).astype(np.float32) + 1j * case["x"].imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
+        ref = run_oracle(case, x=xh, fmod=fmod)
+        monkeypatch.delenv("QDAS_NO_SYM", raising=False)
+        a, pa = rd(case, kernel=2, prec="halfT", tpose=tpose, fmod=fmod, x=xh)
+        assert pa.reciprocal and pa.kernel == "tiled"
+        monkeypatch.setenv("QDAS_NO_SYM", "1")
+        b, pb = rd(case, kernel=2, prec="halfT", tpose=tpose, fmod=fmod, x=xh)
+        monkeypatch.delenv("QDAS_NO_SYM", raising=False)
+        assert not pb.reciprocal
+        if interp == "nearest":
+            bad = np.abs(a - ref) / np.abs(ref).max() > 3e-3
+            assert bad.mean() <= 0.05
+        else:
+            assert rel_err(a, ref) <= 3e-3 and rel_err(a, b) <= 3e-3      # fp16 output rounding
+        assert np.all(a[np.abs(ref) == 0] == 0)
+
+
 @pytest.mark.parametrize("prec", ["single", "halfT"])
 def test_tiled_pixel_receiver_apodization(prec):
     """one I1 x I2 x I3 x N array (acceptance-angle style mask with whole waves of zeros) + pixel-independent arrays"""
