@@ -20,8 +20,8 @@ __global__ void __launch_bounds__(256) pre_pad_kernel(const TI *x, float *xr, ui
     xr[i] = t < T ? (float)x[t + T * k] : 0.f;
 }
 
-// half spectrum (N/2+1 bins per trace) -> analytic full spectrum (N bins): src/ChannelData.m:961-963
-__global__ void __launch_bounds__(256) pre_spectrum_kernel(const float2 *half, float2 *full, uint64_t N, uint64_t K) {
+// half spectrum (N/2+1 bins per trace) -> analytic full spectrum (N bins), scaled by 1/N: src/ChannelData.m:961-963
+__global__ void __launch_bounds__(256) pre_spectrum_kernel(const float2 *half, float2 *full, uint64_t N, uint64_t K, float scale) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N * K) return;
     const uint64_t f = i % N, k = i / N, Nd2 = N / 2, H = N / 2 + 1;
@@ -30,11 +30,12 @@ __global__ void __launch_bounds__(256) pre_spectrum_kernel(const float2 *half, f
     else if (f < Nd2) w = 2.f;
     else if (f == Nd2) w = 1.f + (float)(N & 1);
     float2 v = make_float2(0.f, 0.f);
+    w *= scale;                                  // the 1/N of the inverse transform rides on the weights
     if (w != 0.f) { const float2 h = half[f + H * k]; v = make_float2(w * h.x, w * h.y); }
     full[i] = v;
 }
 
-// 1/N of the inverse transform and the downmix phasor exp(-2j pi fd (t0 + t/fs)) (fd == 0: none)
+// the downmix phasor exp(-2j pi fd (t0 + t/fs)) (only launched when fd != 0)
 __global__ void __launch_bounds__(256) pre_finish_kernel(float2 *y, uint64_t N, uint64_t K, float scale, double fd, double t0, double fs) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N * K) return;
@@ -88,9 +89,9 @@ int pre_execute(PrePlan *p, const void *x, void *y, hipStream_t s) {
     else pre_pad_kernel<float><<<g, 256, 0, s>>>((const float *)x, p->xr, p->T, p->N, p->K);
     if (hipfftSetStream(p->r2c, s) != HIPFFT_SUCCESS || hipfftSetStream(p->c2c, s) != HIPFFT_SUCCESS) return 1;
     if (hipfftExecR2C(p->r2c, p->xr, (hipfftComplex *)p->half) != HIPFFT_SUCCESS) return 1;
-    pre_spectrum_kernel<<<g, 256, 0, s>>>(p->half, (float2 *)y, p->N, p->K);
+    pre_spectrum_kernel<<<g, 256, 0, s>>>(p->half, (float2 *)y, p->N, p->K, 1.0f / (float)p->N);
     if (hipfftExecC2C(p->c2c, (hipfftComplex *)y, (hipfftComplex *)y, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) return 1;
-    pre_finish_kernel<<<g, 256, 0, s>>>((float2 *)y, p->N, p->K, 1.0f / (float)p->N, p->fd, p->t0, p->fs);
+    if (p->fd != 0.0) pre_finish_kernel<<<g, 256, 0, s>>>((float2 *)y, p->N, p->K, 1.0f, p->fd, p->t0, p->fs);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
