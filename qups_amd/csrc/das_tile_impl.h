@@ -203,12 +203,22 @@ __device__ __forceinline__ void lds_fence2(taps_f16 &a, taps_f16 &b, taps_f16 &c
                    "+v"(c.r[0]), "+v"(c.r[1]), "+v"(c.r[2]), "+v"(c.r[3]), "+v"(d.r[0]), "+v"(d.r[1]), "+v"(d.r[2]), "+v"(d.r[3]),
                    "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
 }
+template <int KEEP> __device__ __forceinline__ void lds_fence2_keep(taps_f16 &a, taps_f16 &b, taps_f16 &c, taps_f16 &d, v2f (&w)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%20)"
+                 : "+v"(a.r[0]), "+v"(a.r[1]), "+v"(a.r[2]), "+v"(a.r[3]), "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]),
+                   "+v"(c.r[0]), "+v"(c.r[1]), "+v"(c.r[2]), "+v"(c.r[3]), "+v"(d.r[0]), "+v"(d.r[1]), "+v"(d.r[2]), "+v"(d.r[3]),
+                   "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])
+                 : "n"(KEEP));
+}
 __device__ __forceinline__ void mix_mac(v2f &acc, uint32_t tap, float w) {       // acc += w * (float2)tap
     float ar = acc.x, ai = acc.y;
     asm("v_fma_mix_f32 %0, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
         : "+v"(ar), "+v"(ai) : "v"(tap), "v"(w));
     acc = (v2f){ar, ai};
 }
+// acc += w * tap k, either data type (software-pipelined loop)
+__device__ __forceinline__ void tap_mac(v2f &acc, const taps_f32 &t, int k, float w) { acc = w * t.s[k] + acc; }
+__device__ __forceinline__ void tap_mac(v2f &acc, const taps_f16 &t, int k, float w) { mix_mac(acc, t.r[k], w); }
 __device__ __forceinline__ v2f half2_to_v2f(uint32_t v) {
     return (v2f){__half2float(__ushort_as_half((unsigned short)(v & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(v >> 16)))};
 }
@@ -827,12 +837,13 @@ das_tile_kernel(const TileParams P) {
             };
             // full block (reciprocal mode: block entirely above the diagonal): check-free; else the tail / diagonal variant
             if (SYM ? (n < m0) : (m0 + MB <= M)) {
-                if constexpr (TWO && F32 && K == 4 && !(CHECK || FMOD || WTAB) && !(QDAS_ABL & 256)) {
+                if constexpr (TWO && (F32 || SYM) && K == 4 && !(CHECK || FMOD || WTAB) && !(QDAS_ABL & 256)) {
                     // Software-pipelined: the direct taps of iteration p+1 are requested before the MACs of iteration p, so the
                     // LDS pipe always has work queued and the counted wait (newest 8 reads stay in flight) rarely stalls.
                     // A unit = (transmit pair p, frame pair hp); hp only with four frames per launch: same index and weights.
                     constexpr int NP = MB / 2, NU = NP * NHP;
-                    taps_f32 gd0[2], gd1[2];               // first-set taps of the two halves, double-buffered over units
+                    using taps_t = std::conditional_t<F32, taps_f32, taps_f16>;
+                    taps_t gd0[2], gd1[2];                 // first-set taps of the two halves, double-buffered over units
                     v2f sv[2];
                     uint32_t a0v[2], a1v[2];
                     v2f w[4];
@@ -845,14 +856,14 @@ das_tile_kernel(const TileParams P) {
                             a0v[p & 1] = __float_as_uint(tm.x) * (uint32_t)SB + cbase;
                             a1v[p & 1] = __float_as_uint(tm.y) * (uint32_t)SB + cbase;
                         }
-                        if constexpr ((QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { gd0[u & 1].s[k] = (v2f){sv[p & 1].x, rb}; gd1[u & 1].s[k] = (v2f){rb, sv[p & 1].y}; } }
+                        if constexpr (F32 && (QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { gd0[u & 1].s[k] = (v2f){sv[p & 1].x, rb}; gd1[u & 1].s[k] = (v2f){rb, sv[p & 1].y}; } }
                         else { lds_issue<K, (GSET * MB + 2 * p) * WB>(gd0[u & 1], a0v[p & 1]); lds_issue<K, (GSET * MB + 2 * p + 1) * WB>(gd1[u & 1], a1v[p & 1]); }
                     };
                     index(std::integral_constant<int, 0>{});
                     unroll<NU>([&](auto uc) {
                         constexpr int u = decltype(uc)::value, p = u / NHP, hp = u % NHP, HSET = FB4 ? 2 * hp + 1 : 1;
-                        taps_f32 h0, h1;
-                        if constexpr ((QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { h0.s[k] = sv[p & 1]; h1.s[k] = (v2f){sv[p & 1].y, sv[p & 1].x}; } }
+                        taps_t h0, h1;
+                        if constexpr (F32 && (QDAS_ABL & 4) != 0) { for (int k = 0; k < 4; ++k) { h0.s[k] = sv[p & 1]; h1.s[k] = (v2f){sv[p & 1].y, sv[p & 1].x}; } }
                         else { lds_issue<K, (HSET * MB + 2 * p) * WB>(h0, a0v[p & 1]); lds_issue<K, (HSET * MB + 2 * p + 1) * WB>(h1, a1v[p & 1]); }
                         if constexpr (u + 1 < NU) index(std::integral_constant<int, u + 1>{});
                         if constexpr (hp == 0) {
@@ -865,8 +876,8 @@ das_tile_kernel(const TileParams P) {
                         v2f &B0 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc3);
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
-                            A0 = w[k].x * gd0[u & 1].s[k] + A0; A1 = w[k].y * gd1[u & 1].s[k] + A1;
-                            B0 = w[k].x * h0.s[k] + B0;         B1 = w[k].y * h1.s[k] + B1;
+                            tap_mac(A0, gd0[u & 1], k, w[k].x); tap_mac(A1, gd1[u & 1], k, w[k].y);
+                            tap_mac(B0, h0, k, w[k].x);         tap_mac(B1, h1, k, w[k].y);
                         }
                     });
                 } else {
