@@ -236,7 +236,7 @@ __device__ __forceinline__ uint32_t zero_of(const uint32_t *) { return 0u; }
 //      both frames (the reference launches one kernel per frame, kern/das_spec.m:371).  Structurally the reciprocal mode's
 //      "mirror" set with another source and a separate sum.
 //      FB4: four frames per launch: four window sets of MB = 8 transmits; the pair loop makes two passes (frames 0-1, 2-3).
-template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, bool FB2, bool FB4, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE>
+template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, bool FB2, bool FB4, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE, bool BIG = false>
 __global__ void __launch_bounds__(WAVES * 64, WAVES * BPC / 4)
 das_tile_kernel(const TileParams P) {
     constexpr bool FBX = FB2 || FB4;          // more than one frame per launch
@@ -246,6 +246,7 @@ das_tile_kernel(const TileParams P) {
     constexpr int NW = FB4 ? 4 * MB : (TWO ? 2 * MB : MB);     // windows per LDS buffer
     static_assert(!SYM || !WTAB, "reciprocal mode: no weight table");
     static_assert(!(SYM && FBX) && !(FB2 && FB4), "reciprocal mode runs one frame per launch");
+    static_assert(!BIG || (!SYM && !FBX), "the re-basing general kernel runs one frame per launch");
     constexpr int K = tapinfo<INTERP>::K;
     constexpr int THREADS = WAVES * 64;
     constexpr int TX = WAVES;                 // waves per workgroup; a wave holds 1, 2 or 4 image columns (tz_log2)
@@ -518,12 +519,13 @@ das_tile_kernel(const TileParams P) {
     };
     // Reciprocal mode walks the whole frame inside one transmit block (the mirror "transmits", or the receivers of transposed
     // data): its running offsets are kept below 2^30 by re-basing the descriptor when they get there (uniform, rare).  The
-    // general kernels keep one descriptor per block (plan-time check: the walk stays below 2^31 bytes).
+    // general kernels keep one descriptor per block (plan-time check: the walk stays below 2^31 bytes); transposed fp32 frames
+    // beyond that run the BIG instantiation (launch configuration 9), which re-bases as well.
     constexpr uint32_t REBASE = 1u << 30;
     uint64_t offD = 0, offM = 0;
     auto dma_block = [&](uint32_t m0) {
         const uint64_t o = ((uint64_t)m0 * P.strM + (uint64_t)n_lo * P.strN) * SB;
-        if constexpr (SYM) offD = o;
+        if constexpr (SYM || BIG) offD = o;
         rsD = make_rs(o, (uint64_t)fa * P.x_fstride);
         soff = 0;
 #pragma unroll
@@ -568,7 +570,7 @@ das_tile_kernel(const TileParams P) {
             }
         }
         soff += (uint32_t)P.strN * SB;                 // next receiver, same transmit block
-        if constexpr (SYM) {
+        if constexpr (SYM || BIG) {
             if (soff >= REBASE) { offD += soff; soff = 0; rsD = make_rs(offD, 0); }
         }
         if constexpr (SYM) {                           // same window start A[m] + B[n] in the mirror trace
@@ -959,13 +961,13 @@ das_tile_kernel(const TileParams P) {
 template <int INTERP, typename ST, int CI>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
     constexpr Cfg G = CFGS[CI];
-    constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8), FB2 = (CI == 3 || CI == 4), FB4 = (CI == 5 || CI == 6);
+    constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8), FB2 = (CI == 3 || CI == 4), FB4 = (CI == 5 || CI == 6), BIG = (CI == 9);
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
     const dim3 g(ntiles * (P.probe ? 1u : P.ksplit)), b(G.waves * 64);
 #define QDAS_LAUNCH(FM, WT) QDAS_LAUNCH_P(FM, WT, false)
 #define QDAS_LAUNCH_P(FM, WT, PR)                                                                        \
     do {                                                                                                 \
-        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, FB4, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR>; \
+        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, FB4, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR, BIG && !PR>; \
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                   \
         kfn<<<g, b, lds, s>>>(P);                                                                        \

@@ -351,7 +351,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     }
     // reciprocal mode (das_tile_impl.h "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
     // elements and share one t0 has tau(n,m) == tau(m,n); detected from the geometry itself, bit-exactly.
-    int sym = 0;
+    int sym = 0, big = 0;
     if (eligible && !syn && (dt == QDAS_F32 || dt == QDAS_F16) && z.VS && z.DV && z.N == z.M && z.S == 0 && !g.gen_kind && !getenv("QDAS_NO_SYM")) {
         std::vector<float> hr(3 * z.N), hv(4 * z.M);
         if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
@@ -380,7 +380,9 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             if (eligible && tile_lds_bytes(dt, 0, z.N, z.M) > tile_lds_limit(0)) { eligible = false; why = "tiled kernel: N + M too large for the LDS header"; }
         }
         if (eligible && !sym && (kN * strN + (uint64_t)pl->tc.mb * strM) * data_size(dt) + slack >= (1ull << 31)) {
-            eligible = false; why = "tiled kernel: trace strides too large for 32-bit DMA offsets (transposed data of more than 2 GiB)";
+            // fp32, one frame per launch: the re-basing instantiation of the general kernel (launch configuration 9)
+            if (dt == QDAS_F32 && ((uint64_t)pl->tc.mb * strM + strN) * data_size(dt) + slack < (1ull << 30)) big = 1;
+            else { eligible = false; why = "tiled kernel: trace strides too large for 32-bit DMA offsets (transposed data of more than 2 GiB)"; }
         }
     }
     if (desc->kernel == QDAS_KERNEL_TILED && !eligible) return bail(fail(QDAS_EUNSUPPORTED, "%s", why));
@@ -422,7 +424,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         t.fs = g.fs; t.fmod = g.fmod;
         t.cinv_fs = (double)cinv0 * g.fs;
         t.cinv_pix = cmap ? (const float *)g.cinv + g.cst[5] : nullptr;
-        t.flag = z.flag; t.VS = z.VS; t.DV = z.DV; t.sym = sym;
+        t.flag = z.flag; t.VS = z.VS; t.DV = z.DV; t.sym = sym; t.big = big;
         // tile grid: (1 << tz_log2) pixels of I1 x tile_cols columns (columns = I2*I3 flattened); the footprint is chosen below
         auto set_grid = [&](int tzl) {
             t.tz_log2 = tzl;
@@ -509,7 +511,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         }
     }
 
-    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->tp.sym && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
+    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
     pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr;
     if (desc->mem == QDAS_MEM_HOST) {                   // staging buffers for x / y
         pl->x_bytes = (size_t)z.T * z.N * z.M * data_size(dt);

@@ -55,6 +55,7 @@ struct TileParams {
     double fs, fmod;
     int32_t flag, VS, DV;
     int32_t narrow;                     // reciprocal mode: the 128-sample-window configuration (chosen by the plan when every tile fits)
+    int32_t big;                        // general mode, fp32: re-base the DMA descriptors along the receiver walk (transposed frames > 2 GiB)
     int32_t sym;                        // reciprocal mode: Pv == Pr, one t0 (checked by the host) -> tau(n,m) == tau(m,n)
     int32_t tz_log2;                    // tile footprint: (1 << tz_log2) pixels of I1 x (waves * 64 >> tz_log2) columns; 3..6
     int32_t wz_log2;                    // wave footprint inside the tile: (1 << wz_log2) pixels of I1 x (64 >> wz_log2) columns; <= tz_log2
