@@ -5,6 +5,11 @@
 // data .* exp(-2i*pi*fc*time)), so that real (fp32 or int16) traces can be uploaded -- half / a quarter of the bytes of
 // complex64 channel data over PCIe -- and turned into the beamformer's input on the device.  The FFTs are hipFFT plans
 // (a library FFT, like the reference's MATLAB fft); the packing, weighting and downmix kernels are HIP.
+//
+// For real input, ifft(w .* fft(x)) = x + i*H(x): the real part IS the (padded / truncated) input, only the imaginary part
+// needs an inverse transform, and it is real: H(x) = C2R of (-i sgn(f) X(f)) over the half spectrum.  So the pass is
+// pad -> R2C -> half-spectrum weights -> C2R -> interleave (x, H(x)) [* phasor]: two half-size real transforms instead of a real
+// forward + a full complex inverse one (whose length-2816 decomposition costs hipFFT two extra transposes).
 #include <hip/hip_runtime.h>
 #include <hipfft/hipfft.h>
 #include <stdint.h>
@@ -20,27 +25,24 @@ __global__ void __launch_bounds__(256) pre_pad_kernel(const TI *x, float *xr, ui
     xr[i] = t < T ? (float)x[t + T * k] : 0.f;
 }
 
-// half spectrum (N/2+1 bins per trace) -> analytic full spectrum (N bins), scaled by 1/N: src/ChannelData.m:961-963
-__global__ void __launch_bounds__(256) pre_spectrum_kernel(const float2 *half, float2 *full, uint64_t N, uint64_t K, float scale) {
+// half spectrum X (N/2+1 bins per trace) -> spectrum of the Hilbert transform, scaled by the 1/N of the inverse transform:
+// -i*sgn(f)*X(f)/N for 0 < f < N/2, 0 at DC and (even N) at Nyquist -- the imaginary part of what the reference's weights
+// [1; 2...; 1 + mod(N,2); 0...] produce (src/ChannelData.m:961-963)
+__global__ void __launch_bounds__(256) pre_spectrum_kernel(float2 *half, uint64_t N, uint64_t K, float scale) {
+    const uint64_t H = N / 2 + 1;
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= N * K) return;
-    const uint64_t f = i % N, k = i / N, Nd2 = N / 2, H = N / 2 + 1;
-    float w = 0.f;
-    if (f == 0) w = 1.f;
-    else if (f < Nd2) w = 2.f;
-    else if (f == Nd2) w = 1.f + (float)(N & 1);
-    float2 v = make_float2(0.f, 0.f);
-    w *= scale;                                  // the 1/N of the inverse transform rides on the weights
-    if (w != 0.f) { const float2 h = half[f + H * k]; v = make_float2(w * h.x, w * h.y); }
-    full[i] = v;
+    if (i >= H * K) return;
+    const uint64_t f = i % H;
+    const bool zero = (f == 0) || ((N & 1) == 0 && f == N / 2);
+    const float2 v = half[i];
+    half[i] = zero ? make_float2(0.f, 0.f) : make_float2(v.y * scale, -v.x * scale);
 }
 
-// the downmix phasor exp(-2j pi fd (t0 + t/fs)) (only launched when fd != 0)
-__global__ void __launch_bounds__(256) pre_finish_kernel(float2 *y, uint64_t N, uint64_t K, float scale, double fd, double t0, double fs) {
+// y = (x, H(x)) times the downmix phasor exp(-2j pi fd (t0 + t/fs)) (fd == 0: none)
+__global__ void __launch_bounds__(256) pre_finish_kernel(const float *xr, const float *hr, float2 *y, uint64_t N, uint64_t K, double fd, double t0, double fs) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N * K) return;
-    float2 v = y[i];
-    v.x *= scale; v.y *= scale;
+    float2 v = make_float2(xr[i], hr[i]);
     if (fd != 0.0) {
         const double cyc = fd * (t0 + (double)(i % N) / fs);           // cycles; reduced in fp64 before the fp32 sincos
         const float ph = (float)(cyc - floor(cyc));
@@ -54,8 +56,9 @@ struct PrePlan {
     uint64_t T, K, N;
     int in_type;          // 0: fp32, 1: int16
     double fs, t0, fd;
-    hipfftHandle r2c = 0, c2c = 0;
+    hipfftHandle r2c = 0, c2r = 0;
     float *xr = nullptr;  // N x K real (padded input)
+    float *hr = nullptr;  // N x K real (its Hilbert transform)
     float2 *half = nullptr;
     bool have = false;
 };
@@ -66,9 +69,10 @@ int pre_create(PrePlan **out, uint64_t T, uint64_t K, uint64_t N, int in_type, d
     if (p->N == 0 || K == 0) { *out = p; return 0; }
     int n[1] = {(int)p->N};
     if (hipfftPlanMany(&p->r2c, 1, n, nullptr, 1, (int)p->N, nullptr, 1, (int)(p->N / 2 + 1), HIPFFT_R2C, (int)K) != HIPFFT_SUCCESS) { delete p; return 1; }
-    if (hipfftPlanMany(&p->c2c, 1, n, nullptr, 1, (int)p->N, nullptr, 1, (int)p->N, HIPFFT_C2C, (int)K) != HIPFFT_SUCCESS) { hipfftDestroy(p->r2c); delete p; return 1; }
-    if (hipMalloc(&p->xr, sizeof(float) * p->N * K) != hipSuccess || hipMalloc(&p->half, sizeof(float2) * (p->N / 2 + 1) * K) != hipSuccess) {
-        hipfftDestroy(p->r2c); hipfftDestroy(p->c2c); if (p->xr) (void)hipFree(p->xr); delete p; return 2;
+    if (hipfftPlanMany(&p->c2r, 1, n, nullptr, 1, (int)(p->N / 2 + 1), nullptr, 1, (int)p->N, HIPFFT_C2R, (int)K) != HIPFFT_SUCCESS) { hipfftDestroy(p->r2c); delete p; return 1; }
+    if (hipMalloc(&p->xr, sizeof(float) * p->N * K) != hipSuccess || hipMalloc(&p->hr, sizeof(float) * p->N * K) != hipSuccess ||
+        hipMalloc(&p->half, sizeof(float2) * (p->N / 2 + 1) * K) != hipSuccess) {
+        hipfftDestroy(p->r2c); hipfftDestroy(p->c2r); if (p->xr) (void)hipFree(p->xr); if (p->hr) (void)hipFree(p->hr); delete p; return 2;
     }
     p->have = true;
     *out = p;
@@ -77,7 +81,7 @@ int pre_create(PrePlan **out, uint64_t T, uint64_t K, uint64_t N, int in_type, d
 
 void pre_destroy(PrePlan *p) {
     if (!p) return;
-    if (p->have) { hipfftDestroy(p->r2c); hipfftDestroy(p->c2c); (void)hipFree(p->xr); (void)hipFree(p->half); }
+    if (p->have) { hipfftDestroy(p->r2c); hipfftDestroy(p->c2r); (void)hipFree(p->xr); (void)hipFree(p->hr); (void)hipFree(p->half); }
     delete p;
 }
 
@@ -87,11 +91,12 @@ int pre_execute(PrePlan *p, const void *x, void *y, hipStream_t s) {
     const unsigned g = (unsigned)((NK + 255) / 256);
     if (p->in_type == 1) pre_pad_kernel<int16_t><<<g, 256, 0, s>>>((const int16_t *)x, p->xr, p->T, p->N, p->K);
     else pre_pad_kernel<float><<<g, 256, 0, s>>>((const float *)x, p->xr, p->T, p->N, p->K);
-    if (hipfftSetStream(p->r2c, s) != HIPFFT_SUCCESS || hipfftSetStream(p->c2c, s) != HIPFFT_SUCCESS) return 1;
+    if (hipfftSetStream(p->r2c, s) != HIPFFT_SUCCESS || hipfftSetStream(p->c2r, s) != HIPFFT_SUCCESS) return 1;
     if (hipfftExecR2C(p->r2c, p->xr, (hipfftComplex *)p->half) != HIPFFT_SUCCESS) return 1;
-    pre_spectrum_kernel<<<g, 256, 0, s>>>(p->half, (float2 *)y, p->N, p->K, 1.0f / (float)p->N);
-    if (hipfftExecC2C(p->c2c, (hipfftComplex *)y, (hipfftComplex *)y, HIPFFT_BACKWARD) != HIPFFT_SUCCESS) return 1;
-    if (p->fd != 0.0) pre_finish_kernel<<<g, 256, 0, s>>>((float2 *)y, p->N, p->K, 1.0f, p->fd, p->t0, p->fs);
+    const uint64_t HK = (p->N / 2 + 1) * p->K;
+    pre_spectrum_kernel<<<(unsigned)((HK + 255) / 256), 256, 0, s>>>(p->half, p->N, p->K, 1.0f / (float)p->N);
+    if (hipfftExecC2R(p->c2r, (hipfftComplex *)p->half, p->hr) != HIPFFT_SUCCESS) return 1;
+    pre_finish_kernel<<<g, 256, 0, s>>>(p->xr, p->hr, (float2 *)y, p->N, p->K, p->fd, p->t0, p->fs);
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 

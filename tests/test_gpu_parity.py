@@ -409,16 +409,15 @@ def test_reciprocal_mode_matches_general_mode(monkeypatch):
 def test_reciprocal_mode_with_half_precision_data(interp, monkeypatch):
     """fp16 channel data in reciprocal mode (launch configuration 8): equals the general fp16 kernel and the oracle on the
     fp16-rounded data; transposed data, the record edge (checked loop) and fmod included"""
-    from tests.test_gpu_parity import run_das as rd
     for tpose, fmod in ((False, 0.0), (True, 0.0), (False, 2.5e6)):
         case = make_case(seq="FSA", interp=interp, seed=41, N=32, I1=140, I2=20, data="noise", T=420 if tpose else None)
         xh = (case["x"].real.astype(np.float16).astype(np.float32) + 1j * case["x"].imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
         ref = run_oracle(case, x=xh, fmod=fmod)
         monkeypatch.delenv("QDAS_NO_SYM", raising=False)
-        a, pa = rd(case, kernel=2, prec="halfT", tpose=tpose, fmod=fmod, x=xh)
+        a, pa = run_das(case, kernel=2, prec="halfT", tpose=tpose, fmod=fmod, x=xh)
         assert pa.reciprocal and pa.kernel == "tiled"
         monkeypatch.setenv("QDAS_NO_SYM", "1")
-        b, pb = rd(case, kernel=2, prec="halfT", tpose=tpose, fmod=fmod, x=xh)
+        b, pb = run_das(case, kernel=2, prec="halfT", tpose=tpose, fmod=fmod, x=xh)
         monkeypatch.delenv("QDAS_NO_SYM", raising=False)
         assert not pb.reciprocal
         if interp == "nearest":
