@@ -196,6 +196,8 @@ typedef struct qdas_lut_desc {
     uint64_t wstride[3];      /* element strides of w for (i, n, m); 0 where singleton       */
     int32_t  w_real;          /* weights are real(prec)                                      */
     int32_t  reserved;
+    uint64_t I1;              /* size of the fastest pixel dimension (the image is I1 x I/I1; 0: unknown) -- lets fp32 full-sum
+                                 calls run on the fused tiled kernel, whose tiles must be compact in depth */
 } qdas_lut_desc;
 int qdas_das_lut(const qdas_lut_desc *d, const void *x, void *y, void *stream);
 

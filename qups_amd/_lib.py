@@ -54,7 +54,7 @@ class LutDesc(C.Structure):
     _fields_ = [("T", C.c_uint64), ("N", C.c_uint64), ("M", C.c_uint64), ("I", C.c_uint64),
                 ("flag", C.c_int32), ("dtype", C.c_int32), ("omega", C.c_double),
                 ("tau_rx", C.c_void_p), ("tau_tx", C.c_void_p), ("w", C.c_void_p),
-                ("wstride", C.c_uint64 * 3), ("w_real", C.c_int32), ("reserved", C.c_int32)]
+                ("wstride", C.c_uint64 * 3), ("w_real", C.c_int32), ("reserved", C.c_int32), ("I1", C.c_uint64)]
 
 
 class GreensDesc(C.Structure):

@@ -236,7 +236,7 @@ __device__ __forceinline__ uint32_t zero_of(const uint32_t *) { return 0u; }
 //      both frames (the reference launches one kernel per frame, kern/das_spec.m:371).  Structurally the reciprocal mode's
 //      "mirror" set with another source and a separate sum.
 //      FB4: four frames per launch: four window sets of MB = 8 transmits; the pair loop makes two passes (frames 0-1, 2-3).
-template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, bool FB2, bool FB4, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE, bool BIG = false>
+template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, bool FB2, bool FB4, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE, bool BIG = false, bool LUT = false>
 __global__ void __launch_bounds__(WAVES * 64, WAVES * BPC / 4)
 das_tile_kernel(const TileParams P) {
     constexpr bool FBX = FB2 || FB4;          // more than one frame per launch
@@ -247,6 +247,7 @@ das_tile_kernel(const TileParams P) {
     static_assert(!SYM || !WTAB, "reciprocal mode: no weight table");
     static_assert(!(SYM && FBX) && !(FB2 && FB4), "reciprocal mode runs one frame per launch");
     static_assert(!BIG || (!SYM && !FBX), "the re-basing general kernel runs one frame per launch");
+    static_assert(!LUT || (!SYM && !FBX && !BIG), "table-driven delays: general mode, one frame per launch");
     constexpr int K = tapinfo<INTERP>::K;
     constexpr int THREADS = WAVES * 64;
     constexpr int TX = WAVES;                 // waves per workgroup; a wave holds 1, 2 or 4 image columns (tz_log2)
@@ -305,11 +306,19 @@ das_tile_kernel(const TileParams P) {
     float px, py, pz;                                 // widened to fp64 where they are used
     const double fs = P.fs;
     double cf = P.cinv_fs;                            // samples per metre: scalar sound speed, or this pixel's entry of a sound-speed map
-    {
+    // LUT: the delays come from host-supplied tables (tau_tx: I x M, tau_rx: I x N, in samples; the split-delay flavour
+    // bfDASLUT / sample2sep / wsinterpd2 of the reference) instead of the geometry; everything downstream is the same kernel.
+    uint64_t ipl = 0;                                 // my (clamped) pixel's row of the tables
+    if constexpr (LUT) {
+        px = py = pz = 0.f;
+        const uint64_t i = (i1 < P.I1 ? i1 : P.I1 - 1) + P.I1 * (col < ncols ? col : ncols - 1);
+        ipl = i < i_end ? i : i_end - 1;
+    } else {
         const uint64_t i = (i1 < P.I1 ? i1 : P.I1 - 1) + P.I1 * (col < ncols ? col : ncols - 1);
         px = P.Pi[3 * i]; py = P.Pi[3 * i + 1]; pz = P.Pi[3 * i + 2];
         if (P.cinv_pix) cf = (double)P.cinv_pix[i] * fs;
     }
+    const uint64_t Ilut = i_end;                      // (table-driven plans cover [0, I))
     // Delay model of the BLOCK elements (the MB "transmits" of a stage) and of the STAGE elements (its "receiver"):
     // 0 = distance, 1 = signed distance (focused wave: copysign by the normal, src/bf.cu:106-108), 2 = plane wave (dot product).
     // 'DAS' / 'SYN': block = transmits (kind from VS / DV), stage = receivers (distance).  'MUL' (keep the transmit dimension) runs
@@ -329,6 +338,7 @@ das_tile_kernel(const TileParams P) {
     // queue and expose the DMA latency every stage (measured: 15 of 64 ms).
     const float *gPv = P.Pv, *gNv = P.Nv;
     auto a_of = [&](uint32_t m) -> double {              // tau_tx*fs - t0*fs + OFF, reference src/bf.cu:104-108,114
+        if constexpr (LUT) return (double)P.lut_tx[ipl + Ilut * m] + tapinfo<INTERP>::OFF;
         const double rx = (double)px - (double)gPv[4 * m], ry = (double)py - (double)gPv[4 * m + 1], rz = (double)pz - (double)gPv[4 * m + 2];
         const double dot = kindB ? rx * (double)gNv[3 * m] + ry * (double)gNv[3 * m + 1] + rz * (double)gNv[3 * m + 2] : 0.0;
         double dv = dot;
@@ -341,6 +351,7 @@ das_tile_kernel(const TileParams P) {
     };
     // delay of STAGE element n at (ex,ey,ez): a receiver (kind 0), or -- roles swapped -- a transmit with {t0, normal} in P.St (scalar loads)
     auto s_at = [&](uint32_t n, float ex, float ey, float ez) -> double {
+        if constexpr (LUT) return (double)P.lut_rx[ipl + Ilut * n];
         if (!P.St) return b_at(ex, ey, ez);
         const double rx = (double)px - (double)ex, ry = (double)py - (double)ey, rz = (double)pz - (double)ez;
         const double dot = kindS ? rx * (double)P.St[4 * n + 1] + ry * (double)P.St[4 * n + 2] + rz * (double)P.St[4 * n + 3] : 0.0;
@@ -358,7 +369,7 @@ das_tile_kernel(const TileParams P) {
     // The window bases / extents only need the delays to a small fraction of a sample: fp32 estimates with an explicit error
     // margin (DLT, below) -- a quarter of the fp64 cost.  Focused transmits keep fp64: their delay flips sign with
     // (Pi - Pv).Nv (copysign, src/bf.cu:107) and the two precisions must agree on the sign of a dot product that may be ~0.
-    const bool pro32 = kindB != 1 && kindS != 1;
+    const bool pro32 = !LUT && kindB != 1 && kindS != 1;
     const float cf32 = (float)cf, fs32 = (float)fs;
     auto a_est = [&](uint32_t m) -> float {
         if (!pro32) return (float)a_of(m);
@@ -367,6 +378,7 @@ das_tile_kernel(const TileParams P) {
         return d * cf32 - gPv[4 * m + 3] * fs32 + (float)tapinfo<INTERP>::OFF;
     };
     auto b_est = [&](uint32_t n) -> float {
+        if constexpr (LUT) return P.lut_rx[ipl + Ilut * n];
         if (kindS == 1) return (float)s_at(n, P.Pr[3 * n], P.Pr[3 * n + 1], P.Pr[3 * n + 2]);
         const float rx = px - P.Pr[3 * n], ry = py - P.Pr[3 * n + 1], rz = pz - P.Pr[3 * n + 2];
         if (!P.St) return __builtin_sqrtf(rx * rx + ry * ry + rz * rz) * cf32;
@@ -399,7 +411,7 @@ das_tile_kernel(const TileParams P) {
             float mn = part[m], mx = part[WAVES * MX + m];
 #pragma unroll
             for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + m]); mx = fmaxf(mx, part[(WAVES + w) * MX + m]); }
-            const float dlt = margin(mn, mx, P.Pv[4 * m + 3] * fs32);
+            const float dlt = margin(mn, mx, LUT ? 0.f : P.Pv[4 * m + 3] * fs32);
             const float fl = floorf(mn - dlt) - 1.0f;        // margin: the estimate may lie above the true minimum
             const bool fin = fabsf(fl) < 1.0e9f;
             const float e = fin ? ((mx + dlt) - fl) + 0.01f : INFINITY;
@@ -421,11 +433,12 @@ das_tile_kernel(const TileParams P) {
         float mn = part[n], mx = part[WAVES * MX + n];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + n]); mx = fmaxf(mx, part[(WAVES + w) * MX + n]); }
-        const float dlt = margin(mn, mx, SYM ? P.Pv[3] * fs32 : (P.St ? P.St[4 * n] * fs32 : 0.f));
+        const float dlt = margin(mn, mx, LUT ? 0.f : SYM ? P.Pv[3] * fs32 : (P.St ? P.St[4 * n] * fs32 : 0.f));
         const float fl = floorf(mn - dlt) - 1.0f;
         const bool fin = fabsf(fl) < 1.0e9f;
         const float e = fin ? ((mx + dlt) - fl) + 0.01f : INFINITY;
-        nrec[n] = make_float4(__int_as_float(fin ? (int)fl : 0), P.Pr[3 * n], P.Pr[3 * n + 1], P.Pr[3 * n + 2]);
+        if constexpr (LUT) nrec[n] = make_float4(__int_as_float(fin ? (int)fl : 0), 0.f, 0.f, 0.f);
+        else nrec[n] = make_float4(__int_as_float(fin ? (int)fl : 0), P.Pr[3 * n], P.Pr[3 * n + 1], P.Pr[3 * n + 2]);
         Bext[n] = e;
         b_lo = fminf(b_lo, fl); b_hi = fmaxf(b_hi, fl + e); b_ext = fmaxf(b_ext, e);
         if constexpr (SYM) {                             // a - A = (b - B) + frac(C) in [1, Bext + 1)
@@ -456,9 +469,11 @@ das_tile_kernel(const TileParams P) {
     if constexpr (PROBE) return;                       // plan-time shape selection only wants the fit verdict
     // every window of every stage strictly inside the record?  (uniform) -> branch-free loop
     const bool tile_interior = (a_lo + b_lo >= 1.0f) && (a_hi + b_hi + (float)(K + 1) < (float)T);
-    for (uint32_t k = tid; k < 4 * M; k += THREADS) PvL[k] = P.Pv[k];
-    for (uint32_t k = tid; k < 3 * M; k += THREADS) NvL[k] = P.Nv[k];
-    gPv = PvL; gNv = NvL;
+    if constexpr (!LUT) {
+        for (uint32_t k = tid; k < 4 * M; k += THREADS) PvL[k] = P.Pv[k];
+        for (uint32_t k = tid; k < 3 * M; k += THREADS) NvL[k] = P.Nv[k];
+        gPv = PvL; gNv = NvL;
+    }
     __syncthreads();
 
 #if QDAS_PROF
@@ -621,6 +636,8 @@ das_tile_kernel(const TileParams P) {
         constexpr bool CHECK = decltype(check_tag)::value;
         v2f wcur = {1.f, 0.f}, wnext = {1.f, 0.f};
         if (wpix) wcur = wload(n_lo);
+        float tbc = 0.f, tbn = 0.f;                        // LUT: this / the next stage's receive delay of my pixel
+        if constexpr (LUT) tbc = P.lut_rx[ipl + Ilut * n_lo];
         uint32_t pr = 0, pn = n_lo, pm0 = blk(0);          // stage the DMA front is at (NBUF-1 stages ahead)
         dma_block(pm0);
         // B[n] of the stage at the DMA front travels in a VGPR, loaded one stage before it is needed: every LDS read of a stage
@@ -648,6 +665,7 @@ das_tile_kernel(const TileParams P) {
             const bool more = st + (NBUF - 1) < nstage;
             // next stage's pixel weight: requested BEFORE this stage's DMA, so the end-of-stage wait covers it
             if (wpix && st + 1 < nstage) wnext = wload(n + 1 == nlim(m0) ? n_lo : n + 1);
+            if constexpr (LUT) { if (st + 1 < nstage) tbn = P.lut_rx[ipl + Ilut * (n + 1 == nlim(m0) ? n_lo : n + 1)]; }
             const bool skip = wpix && (__ballot(wcur.x != 0.f || wcur.y != 0.f) == 0ull);   // whole wave weightless: no gathers
             const float4 rec = nrec[n];                // {B[n], receiver position}: one broadcast LDS read, issued ahead of the DMA
             // The next stage's staging is issued at the start of this stage by the younger half of the waves and AFTER the pair
@@ -678,7 +696,7 @@ das_tile_kernel(const TileParams P) {
 #endif
             if (!skip) {
             const int bn = __float_as_int(rec.x);
-            const float rb = (QDAS_ABL & 2) ? (float)(lane * 2 + 3) + 0.37f * (float)(n & 7) : (float)(s_at(n, rec.y, rec.z, rec.w) - (double)bn);
+            const float rb = LUT ? tbc - (float)bn : (QDAS_ABL & 2) ? (float)(lane * 2 + 3) + 0.37f * (float)(n & 7) : (float)(s_at(n, rec.y, rec.z, rec.w) - (double)bn);
             // LDS byte address of a tap = bits(t + MAGIC)*SB + cbase + (window, tap) immediate
             const uint32_t cbase = win_off + (uint32_t)buf * (NW * WB) - (MAGIC_BITS * (uint32_t)SB);
 
@@ -928,6 +946,7 @@ das_tile_kernel(const TileParams P) {
                 acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
                 wcur = wnext;
             }
+            if constexpr (LUT) tbc = tbn;
             if (++n == nlim(m0)) { n = n_lo; m0 = blk(++cr); }
         }
     };
@@ -961,13 +980,13 @@ das_tile_kernel(const TileParams P) {
 template <int INTERP, typename ST, int CI>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
     constexpr Cfg G = CFGS[CI];
-    constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8), FB2 = (CI == 3 || CI == 4), FB4 = (CI == 5 || CI == 6), BIG = (CI == 9);
+    constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8), FB2 = (CI == 3 || CI == 4), FB4 = (CI == 5 || CI == 6), BIG = (CI == 9), LUT = (CI == 10);
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
     const dim3 g(ntiles * (P.probe ? 1u : P.ksplit)), b(G.waves * 64);
 #define QDAS_LAUNCH(FM, WT) QDAS_LAUNCH_P(FM, WT, false)
 #define QDAS_LAUNCH_P(FM, WT, PR)                                                                        \
     do {                                                                                                 \
-        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, FB4, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR, BIG && !PR>; \
+        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, FB4, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR, BIG && !PR, LUT>; \
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                   \
         kfn<<<g, b, lds, s>>>(P);                                                                        \

@@ -778,6 +778,65 @@ extern "C" int qdas_delaysf(const qdas_sizes *sz, float *tau, const float *Pi, c
 }
 
 // ------------------------------------------------------------------------------------ split-delay flavour
+// The split-delay flavour through the tiled kernel.  Returns -1 when the launch was made, +1 when the problem has to run on
+// das_lut_kernel (other precision / kept dimensions / pixel-dependent weights / a tile whose delay spread does not fit the
+// LDS window for any footprint / QDAS_LUT_GENERIC=1), 0 on a HIP error.
+static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t s) {
+    if (d->dtype != QDAS_F32 || (d->flag & (QDAS_FLAG_KEEP_RX | QDAS_FLAG_KEEP_TX)) || getenv("QDAS_LUT_GENERIC")) return 1;
+    if (d->w && (d->wstride[0] != 0 || d->w_real)) return 1;         // weights: none, or one complex N x M table
+    if (d->T < 8 || d->N >= (1ull << 20) || d->M >= (1ull << 20)) return 1;
+    if (tile_lds_bytes(QDAS_F32, 0, d->N, d->M) > tile_lds_limit(0)) return 1;
+    const bool tp = d->flag & QDAS_FLAG_TPOSE;
+    const uint64_t strN = tp ? d->T * d->M : d->T, strM = tp ? d->T : d->T * d->N;
+    const TileConfig tc = tile_config(QDAS_F32, 0);
+    if ((d->N * strN + (uint64_t)tc.mb * strM) * 8 + 65536 >= (1ull << 31)) return 1;
+    static uint32_t *counter[64] = {nullptr};                         // per device, kept for the life of the process
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    if (!counter[dev] && hipMalloc(&counter[dev], 64) != hipSuccess) return 1;
+    const void *wtab = nullptr;
+    void *wtmp = nullptr;
+    if (d->w) {                                                       // w[n*st1 + m*st2] -> table [n + N*m]
+        if (d->wstride[1] == 1 && d->wstride[2] == d->N) wtab = d->w;
+        else return 1;
+    }
+    TileParams t{};
+    t.x = x; t.y = y; t.wtab = wtab;
+    t.T = d->T; t.N = d->N; t.M = d->M;
+    const uint64_t I1 = (d->I1 && d->I1 < d->I && d->I % d->I1 == 0) ? d->I1 : (d->I1 >= d->I ? d->I : 64);
+    t.I1 = I1; t.I2 = (d->I + I1 - 1) / I1; t.I3 = 1;
+    t.i_begin = 0; t.i_count = d->I; t.y_ld = d->I;
+    t.strN = strN; t.strM = strM;
+    t.fs = 1.0; t.cinv_fs = 0.0; t.fmod = d->omega / 6.283185307179586476925;
+    t.flag = d->flag & (7 | QDAS_FLAG_TPOSE);
+    t.nfr = 1; t.ksplit = 1;
+    t.lut_tx = (const float *)d->tau_tx; t.lut_rx = (const float *)d->tau_rx;
+    t.fallback_list = counter[dev]; t.fallback_cap = 0;
+    // footprint: the deepest tile (of 64, 32, 16, 8 pixels of I1) whose delay spreads all fit the window; the tables are data
+    // of this call, so the fit is probed per call (prologue-only launches)
+    int best = -1;
+    unsigned ntiles = 0;
+    for (int l = 6; l >= 3 && best < 0; --l) {
+        t.tz_log2 = l; t.wz_log2 = l < 3 ? l : 3;
+        const unsigned cols = ((unsigned)tc.waves * 64u) >> l;
+        t.tiles_z = (uint32_t)((t.I1 + (1u << l) - 1) >> l);
+        t.tile_x0 = 0;
+        t.tiles_x = (uint32_t)((t.I2 + cols - 1) / cols);
+        ntiles = t.tiles_z * t.tiles_x;
+        t.probe = 1;
+        if (hipMemsetAsync(counter[dev], 0, sizeof(uint32_t), s) != hipSuccess) return 0;
+        if (launch_tile(t, QDAS_F32, ntiles, s) != hipSuccess) return 0;
+        uint32_t cnt = 1;
+        if (hipMemcpyAsync(&cnt, counter[dev], sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 0;
+        if (cnt == 0) best = l;
+    }
+    (void)wtmp;
+    if (best < 0) return 1;
+    t.probe = 0;
+    if (hipMemsetAsync(counter[dev], 0, sizeof(uint32_t), s) != hipSuccess) return 0;
+    return launch_tile(t, QDAS_F32, ntiles, s) == hipSuccess ? -1 : 0;
+}
+
 extern "C" int qdas_das_lut(const qdas_lut_desc *d, const void *x, void *y, void *stream) {
     if (!d || !y) return fail(QDAS_EINVAL, "null argument");
     if (d->dtype < QDAS_F64 || d->dtype > QDAS_F16) return fail(QDAS_EINVAL, "Unrecognized input precision %d", d->dtype);
@@ -790,6 +849,10 @@ extern "C" int qdas_das_lut(const qdas_lut_desc *d, const void *x, void *y, void
         return QDAS_OK;
     }
     if (!x || !d->tau_rx || !d->tau_tx) return fail(QDAS_EINVAL, "null data / delay table");
+    {   // fp32, full sum, no pixel-dependent weights: the fused tiled kernel with table-driven delays (das_tile_impl.h "LUT")
+        const int rc = lut_tiled(d, x, y, s);
+        if (rc <= 0) return rc < 0 ? QDAS_OK : fail(QDAS_EHIP, "das_lut: tiled launch failed");
+    }
     LutParams p{};
     p.tau_rx = d->tau_rx; p.tau_tx = d->tau_tx; p.w = d->w; p.x = x; p.y = y;
     p.T = d->T; p.N = d->N; p.M = d->M; p.I = d->I;

@@ -69,6 +69,8 @@ struct TileParams {
     float2 *part;                       // [ksplit][nfr][i_count] partial images (ksplit > 1 only)
     uint32_t *fallback_list;            // [0] = count, [1..] = tile ids that did not fit the LDS window
     uint32_t fallback_cap;
+    // table-driven delays (launch configuration 10, qdas_das_lut): tau_tx (I x M) and tau_rx (I x N) in samples, fp32
+    const float *lut_tx, *lut_rx;
 };
 
 struct TileConfig { int waves; int mb; int window; size_t lds_bytes; int threads; };

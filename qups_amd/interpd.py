@@ -68,6 +68,7 @@ def das_lut(x, tau_rx, tau_tx, *, interp="linear", w=None, keep_rx=False, keep_t
     ttx_c = _colmajor(ttx.reshape(I, M)) if len(Isz) <= 1 else _colmajor(ttx).reshape(M, I)
     d = _lib.LutDesc()
     d.T, d.N, d.M, d.I = T, N, M, I
+    d.I1 = int(Isz[0]) if len(Isz) >= 2 else 0                      # fastest pixel dimension: lets the fused tiled kernel take the call
     d.flag = _lib.INTERP_FLAGS[interp] + 8 * bool(keep_rx) + 16 * bool(keep_tx) + 32 * bool(tpose)
     d.dtype = _PREC[prec]
     d.omega = float(omega)

@@ -121,6 +121,46 @@ def test_das_lut_matches_oracle(keep):
     assert rel_err(y32, ref) <= 5e-4
 
 
+@pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3"])
+@pytest.mark.parametrize("seq,tpose,wtab,fm", [("FSA", False, False, 0.0), ("PW", True, True, 2e6), ("DV", False, True, 0.0), ("FC", False, False, 2e6)])
+def test_das_lut_full_sum_runs_the_fused_kernel(interp, seq, tpose, wtab, fm, monkeypatch):
+    """fp32 full-sum calls with the image shape known go through the tiled kernel with table-driven delays (launch configuration
+    10): must agree with the oracle and with the one-thread-per-pixel kernel (QDAS_LUT_GENERIC=1), also with an N x M weight
+    table, remodulation, transposed data, a ragged last tile and delays that leave the record"""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import das_lut
+    case = make_case(seq=seq, interp=interp, seed=23, N=16, M=None if seq == "FSA" else 9, I1=150, I2=21, data="noise")
+    N, M = case["N"], case["M"]
+    dv, dr = O.tx_rx_distances(case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["VS"], case["DV"])
+    c = cinv_f32(case["c"])
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    tau_tx = f32((dv[:, :, :, 0, :] / c - case["t0"]) * case["fs"])[:, :, 0]           # I1 x I2 x M, in samples, fp32-representable
+    tau_rx = f32(dr[:, :, :, :, 0] / c * case["fs"])[:, :, 0]                           # I1 x I2 x N
+    rng = np.random.default_rng(1)
+    w = None
+    if wtab:
+        w = (rng.uniform(0.2, 1, (1, 1, N, M)) + 1j * rng.uniform(-0.3, 0.3, (1, 1, N, M))).astype(np.complex64)
+    omega = 2 * np.pi * fm / case["fs"]
+    x = case["x"]
+    xs = np.ascontiguousarray(np.swapaxes(x, 1, 2)) if tpose else x
+    ref = O.das_lut(x, tau_rx[:, :, None] / case["fs"], tau_tx[:, :, None] / case["fs"], 0.0, case["fs"], interp=interp,
+                    apod=(() if w is None else (w.reshape(1, 1, 1, N, M).astype(np.complex128),)), fmod=fm)
+    ref = np.asarray(ref).reshape(150, 21)
+    run = lambda: _np(das_lut(torch.from_numpy(xs), tau_rx, tau_tx, interp=interp, w=w, omega=omega, prec="single", tpose=tpose)).reshape(150, 21)
+    monkeypatch.delenv("QDAS_LUT_GENERIC", raising=False)
+    a = run()
+    monkeypatch.setenv("QDAS_LUT_GENERIC", "1")
+    b = run()
+    den = np.abs(ref).max()
+    if interp == "nearest":                                   # a rounding at the step swaps one sample of a pixel: rare
+        assert (np.abs(a - ref) / den > 1e-4).mean() <= 0.05 and (np.abs(a - b) / den > 1e-4).mean() <= 0.05
+    else:
+        assert rel_err(a, ref) <= 1e-4 and rel_err(a, b) <= 1e-4
+    assert not np.array_equal(a, b)                           # two different kernels did run
+    assert np.all(a[np.abs(ref) == 0] == 0)
+
+
 def test_us_DAS_keep_dims_and_frames_layout():
     import torch
     from qups_amd import ChannelData, Scan, Sequence, Transducer, UltrasoundSystem
