@@ -833,8 +833,21 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     (void)wtmp;
     if (best < 0) return 1;
     t.probe = 0;
+    // too few tiles for the GPU: several workgroups per tile, each summing a range of receivers (as plans do)
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    unsigned ks = 1;
+    const unsigned cap = (unsigned)std::min<uint64_t>(8, d->N);
+    while (ks * 2 <= cap && (uint64_t)ntiles * ks < (uint64_t)ncu) ks *= 2;
+    void *part = nullptr;
+    if (ks > 1) {
+        if (hipMallocAsync(&part, sizeof(float) * 2 * (size_t)ks * d->I, s) != hipSuccess) { part = nullptr; ks = 1; }
+    }
+    t.ksplit = ks; t.part = (float2 *)part;
     if (hipMemsetAsync(counter[dev], 0, sizeof(uint32_t), s) != hipSuccess) return 0;
-    return launch_tile(t, QDAS_F32, ntiles, s) == hipSuccess ? -1 : 0;
+    const hipError_t e = launch_tile(t, QDAS_F32, ntiles, s);
+    if (part) (void)hipFreeAsync(part, s);
+    return e == hipSuccess ? -1 : 0;
 }
 
 extern "C" int qdas_das_lut(const qdas_lut_desc *d, const void *x, void *y, void *stream) {

@@ -21,7 +21,10 @@ trx = (torch.linalg.norm(Pi[:, :, None] - Pr[:, None, :], dim=0) * cinv * fs).co
 if "plane-waves" in w["opt"]:
     ttx = ((Pi[:, :, None] * Nv[:, None, :]).sum(0) * cinv - t0) * fs
 else:
-    ttx = (torch.linalg.norm(Pi[:, :, None] - Pv[:, None, :], dim=0) * cinv - t0) * fs
+    dv = torch.linalg.norm(Pi[:, :, None] - Pv[:, None, :], dim=0)
+    if "diverging-waves" not in w["opt"]:                 # focused: the distance is signed by the side of the focus (src/bf.cu:106-108)
+        dv = torch.copysign(dv, ((Pi[:, :, None] - Pv[:, None, :]) * Nv[:, None, :]).sum(0))
+    ttx = (dv * cinv - t0) * fs
 ttx = ttx.contiguous()                                                                                   # I x M
 # the image shape rides on the tables' leading dimensions (I1 x I2 x N, MATLAB order): the fused kernel needs depth-compact tiles
 trx, ttx = trx.reshape(w["I1"], w["I2"], N), ttx.reshape(w["I1"], w["I2"], M)
