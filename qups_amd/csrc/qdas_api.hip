@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/qdas.h"
@@ -791,6 +792,8 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     const TileConfig tc = tile_config(QDAS_F32, 0);
     if ((d->N * strN + (uint64_t)tc.mb * strM) * 8 + 65536 >= (1ull << 31)) return 1;
     static uint32_t *counter[64] = {nullptr};                         // per device, kept for the life of the process
+    static std::mutex lut_mutex;                                      // the misfit counter is shared: one probing call at a time
+    std::lock_guard<std::mutex> lock(lut_mutex);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
     if (!counter[dev] && hipMalloc(&counter[dev], 64) != hipSuccess) return 1;
