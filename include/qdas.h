@@ -259,6 +259,12 @@ typedef struct qdas_convd_desc {
 uint64_t qdas_convd_len(uint64_t M, uint64_t N, int shape);    /* L */
 int qdas_convd(const qdas_convd_desc *desc, const void *x, const void *y, void *z, void *stream);
 
+/* ---- Layout conversion for row-major hosts (numpy / torch; no reference counterpart: MATLAB arrays are column-major already and
+ * the ABI follows the reference's memory order, e.g. kern/das_spec.m:367-372 passes x(:,:,:,f) as it lies in memory).
+ * out[c][b][a] = in[a][b][c] for a row-major A x B x C array of elem_bytes-sized elements (2 | 4 | 8 | 16): the column-major
+ * image of T x N x M channel data or I1 x I2 x N delay tables.  Device pointers, in != out. */
+int qdas_permute3(const void *in, void *out, uint64_t A, uint64_t B, uint64_t C, int elem_bytes, void *stream);
+
 /* ---- Pre-processing in front of the DAS path: real RF traces -> analytic channel data, optionally downmixed.
  * Replaces ChannelData.hilbert (reference src/ChannelData.m:935-966: fft to N points along time, weights
  * [1; 2...; 1 + mod(N,2); 0...], ifft) and ChannelData.downmix (src/ChannelData.m:757-766: data .* exp(-2i*pi*fc*time))

@@ -30,7 +30,7 @@ SYMBOLS = (
     "qdas_plan_create", "qdas_plan_execute", "qdas_plan_execute_frames", "qdas_plan_delays",
     "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_reciprocal", "qdas_plan_set_timing",
     "qdas_plan_last_kernel_ms", "qdas_DAS", "qdas_DASf", "qdas_DASh", "qdas_delays", "qdas_delaysf",
-    "qdas_das_lut", "qdas_greens", "qdas_convd", "qdas_convd_len", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_last_error", "qdas_version", "qdas_device_info",
+    "qdas_das_lut", "qdas_greens", "qdas_convd", "qdas_convd_len", "qdas_permute3", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_last_error", "qdas_version", "qdas_device_info",
 )
 
 
@@ -118,6 +118,7 @@ def lib():
     L.qdas_das_lut.argtypes = [C.POINTER(LutDesc), C.c_void_p, C.c_void_p, C.c_void_p]
     L.qdas_greens.argtypes = [C.POINTER(GreensDesc), C.c_void_p, C.c_void_p]
     L.qdas_convd.argtypes = [C.POINTER(ConvdDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.qdas_permute3.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
     L.qdas_convd_len.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
     L.qdas_convd_len.restype = C.c_uint64
     L.qdas_pre_plan_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(PreDesc)]

@@ -977,3 +977,13 @@ extern "C" int qdas_convd(const qdas_convd_desc *d, const void *x, const void *y
     HIPCHK(launch_conv(p, d->dtype, d->cplx ? 1 : 0, (hipStream_t)stream));
     return QDAS_OK;
 }
+
+// ---- layout conversion for row-major hosts (layout.hip)
+extern "C" int qdas_permute3(const void *in, void *out, uint64_t A, uint64_t B, uint64_t C, int elem_bytes, void *stream) {
+    if (A == 0 || B == 0 || C == 0) return QDAS_OK;
+    if (!in || !out) return fail(QDAS_EINVAL, "null argument");
+    if (elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16) return fail(QDAS_EINVAL, "permute3: element size must be 2, 4, 8 or 16 bytes");
+    if (B > 65535 || (A + 63) / 64 > 65535) return fail(QDAS_EUNSUPPORTED, "permute3: too many slices for one launch");
+    HIPCHK(launch_permute3(in, out, A, B, C, elem_bytes, (hipStream_t)stream));
+    return QDAS_OK;
+}

@@ -111,4 +111,7 @@ struct ConvParams {
 };
 hipError_t launch_conv(const ConvParams &P, int dtype, int cplx, hipStream_t s);
 
+// ---- layout.hip: out[c][b][a] = in[a][b][c]
+hipError_t launch_permute3(const void *in, void *out, uint64_t A, uint64_t B, uint64_t C, int elem_bytes, hipStream_t s);
+
 }  // namespace qdas

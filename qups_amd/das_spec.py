@@ -330,7 +330,19 @@ def _torch():
 
 
 def _colmajor(t):
-    """Tensor whose memory is the column-major image of ``t`` (zero-copy if it already is)."""
+    """Tensor whose memory is the column-major image of ``t`` (zero-copy if it already is).  Device tensors of up to three
+    dimensions go through ``qdas_permute3`` (LDS-tiled, coalesced both ways); the rest through torch's strided copy."""
+    if t.ndim <= 1:
+        return t.contiguous()
+    if t.is_cuda and 2 <= t.ndim <= 3 and t.is_contiguous() and t.element_size() in (2, 4, 8, 16) and t.numel():
+        sh = tuple(t.shape) if t.ndim == 3 else (t.shape[0], 1, t.shape[1])
+        if sh[1] <= 65535 and (sh[0] + 63) // 64 <= 65535:
+            torch = _torch()
+            out = torch.empty(tuple(reversed(t.shape)), dtype=t.dtype, device=t.device)
+            with torch.cuda.device(t.device):
+                _lib.check(_lib.lib().qdas_permute3(C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), sh[0], sh[1], sh[2],
+                                                    t.element_size(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            return out
     return t.permute(*reversed(range(t.ndim))).contiguous()
 
 

@@ -212,3 +212,20 @@ def test_reciprocal_mode_beyond_2_GiB(tpose, monkeypatch):
     torch.cuda.synchronize()
     assert plan.kernel == "tiled" and plan.reciprocal
     assert rel_err(ys.cpu().numpy(), yg.cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize("shape", [(70, 3, 130), (1, 5, 64), (257, 1, 33), (64, 2, 1), (5, 7)])
+@pytest.mark.parametrize("dtype", ["float16", "float32", "complex64", "complex128"])
+def test_colmajor_layout_kernel(shape, dtype):
+    """qdas_permute3 (row-major host arrays -> the column-major order of the ABI): equals torch's permute, ragged tiles, 2-16 byte elements"""
+    import torch
+    from qups_amd.das_spec import _colmajor
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    t = torch.randn(shape + ((2,) if dtype.startswith("complex") else ()), generator=g, device="cuda",
+                    dtype=torch.float64 if dtype == "complex128" else torch.float32)
+    t = torch.view_as_complex(t) if dtype.startswith("complex") else t.to(getattr(torch, dtype))
+    t = t.contiguous()
+    out = _colmajor(t)
+    ref = t.permute(*reversed(range(t.ndim))).contiguous()
+    assert out.shape == ref.shape and out.is_contiguous() and torch.equal(torch.view_as_real(out) if out.is_complex() else out,
+                                                                            torch.view_as_real(ref) if ref.is_complex() else ref)
