@@ -31,7 +31,8 @@ def hilbert(x, N: int | None = None, fdown: float = 0.0, t0: float = 0.0, fs: fl
     N = T if N is None else int(N)
     if fdown and not fs:
         raise ValueError("Undefined sampling rate.")
-    xc = xt.to(dev).reshape(T, K).t().contiguous()                # K x T: time fastest (MATLAB memory order of T x K)
+    from .das_spec import _colmajor
+    xc = _colmajor(xt.to(dev).reshape(T, K).contiguous())         # K x T: time fastest (MATLAB memory order of T x K)
     y = torch.empty((K, N), dtype=torch.complex64, device=dev)
     d = _lib.PreDesc(T, K, N, _lib.QDAS_PRE_I16 if xt.dtype == torch.int16 else _lib.QDAS_PRE_F32,
                      dev.index if dev.index is not None else torch.cuda.current_device(), float(fs or 0.0), float(t0), float(fdown))
