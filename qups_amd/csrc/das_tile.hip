@@ -1,5 +1,5 @@
 // das_tile.hip -- host side of the tiled kernel: launch configurations, LDS budget, dispatch to the per-configuration
-// translation units (das_tile_{f32,f32big,lut,sym,symw,symh,f16,f32x2,f16x2,f32x4,f16x4}.hip, kernel in das_tile_impl.h) and the fixed-order
+// translation units (das_tile_{f32,f32big,lut,luth,sym,symw,symh,f16,f32x2,f16x2,f32x4,f16x4}.hip, kernel in das_tile_impl.h) and the fixed-order
 // reduce of a split aperture.  -DQDAS_UNITY compiles everything as ONE translation unit (profiling / ablation builds that
 // pass -DQDAS_ABL / -DQDAS_PROF: tools/ablate.sh).
 #ifdef QDAS_UNITY
@@ -14,6 +14,7 @@
 #include "das_tile_symh.hip"
 #include "das_tile_f32big.hip"
 #include "das_tile_lut.hip"
+#include "das_tile_luth.hip"
 #else
 #include "qdas_device.h"
 #include "qdas_kernels.h"
@@ -33,6 +34,7 @@ hipError_t launch_tile_symw(const TileParams &P, unsigned ntiles, size_t lds, hi
 hipError_t launch_tile_symh(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f32big(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_lut(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
+hipError_t launch_tile_luth(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 
 // y[i] = sum over the ksplit partial images, in split order (deterministic)
 template <typename ST>
@@ -79,8 +81,8 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part))) return hipErrorInvalidValue;
 const int nf = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
     if ((nf != 1 && nf != 2 && nf != 4) || (nf > 1 && (sym || P.big))) return hipErrorInvalidValue;
-    if (P.lut_tx && (sym || nf != 1 || dtype != 1 || P.syn)) return hipErrorInvalidValue;
-    hipError_t e = P.lut_tx ? launch_tile_lut(P, ntiles, lds, s) : sym ? (dtype == 2 ? launch_tile_symh(P, ntiles, lds, s) : narrow ? launch_tile_symw(P, ntiles, lds, s) : launch_tile_sym(P, ntiles, lds, s))
+    if (P.lut_tx && (sym || nf != 1 || (dtype != 1 && dtype != 2) || P.syn)) return hipErrorInvalidValue;
+    hipError_t e = P.lut_tx ? (dtype == 2 ? launch_tile_luth(P, ntiles, lds, s) : launch_tile_lut(P, ntiles, lds, s)) : sym ? (dtype == 2 ? launch_tile_symh(P, ntiles, lds, s) : narrow ? launch_tile_symw(P, ntiles, lds, s) : launch_tile_sym(P, ntiles, lds, s))
                  : nf == 4 ? (dtype == 2 ? launch_tile_f16x4(P, ntiles, lds, s) : launch_tile_f32x4(P, ntiles, lds, s))
                  : nf == 2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))
                            : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : (P.big && !P.probe) ? launch_tile_f32big(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));

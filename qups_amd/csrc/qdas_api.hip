@@ -779,18 +779,19 @@ extern "C" int qdas_delaysf(const qdas_sizes *sz, float *tau, const float *Pi, c
 }
 
 // ------------------------------------------------------------------------------------ split-delay flavour
-// The split-delay flavour through the tiled kernel.  Returns -1 when the launch was made, +1 when the problem has to run on
-// das_lut_kernel (other precision / kept dimensions / pixel-dependent weights / a tile whose delay spread does not fit the
+// The split-delay flavour through the tiled kernel (fp32 / fp16 data).  Returns -1 when the launch was made, +1 when the problem has to run on
+// das_lut_kernel (double precision / kept dimensions / pixel-dependent weights / a tile whose delay spread does not fit the
 // LDS window for any footprint / QDAS_LUT_GENERIC=1), 0 on a HIP error.
 static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t s) {
-    if (d->dtype != QDAS_F32 || (d->flag & (QDAS_FLAG_KEEP_RX | QDAS_FLAG_KEEP_TX)) || getenv("QDAS_LUT_GENERIC")) return 1;
-    if (d->w && (d->wstride[0] != 0 || d->w_real)) return 1;         // weights: none, or one complex N x M table
+    const int dt = d->dtype;
+    if ((dt != QDAS_F32 && dt != QDAS_F16) || (d->flag & (QDAS_FLAG_KEEP_RX | QDAS_FLAG_KEEP_TX)) || getenv("QDAS_LUT_GENERIC")) return 1;
+    if (d->w && (d->wstride[0] != 0 || d->w_real || dt != QDAS_F32)) return 1;   // weights: none, or one complex fp32 N x M table
     if (d->T < 8 || d->N >= (1ull << 20) || d->M >= (1ull << 20)) return 1;
-    if (tile_lds_bytes(QDAS_F32, 0, d->N, d->M) > tile_lds_limit(0)) return 1;
+    if (tile_lds_bytes(dt, 0, d->N, d->M) > tile_lds_limit(0)) return 1;
     const bool tp = d->flag & QDAS_FLAG_TPOSE;
     const uint64_t strN = tp ? d->T * d->M : d->T, strM = tp ? d->T : d->T * d->N;
-    const TileConfig tc = tile_config(QDAS_F32, 0);
-    if ((d->N * strN + (uint64_t)tc.mb * strM) * 8 + 65536 >= (1ull << 31)) return 1;
+    const TileConfig tc = tile_config(dt, 0);
+    if ((d->N * strN + (uint64_t)tc.mb * strM) * data_size(dt) + 65536 >= (1ull << 31)) return 1;
     static uint32_t *counter[64] = {nullptr};                         // per device, kept for the life of the process
     static std::mutex lut_mutex;                                      // the misfit counter is shared: one probing call at a time
     std::lock_guard<std::mutex> lock(lut_mutex);
@@ -828,7 +829,7 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
         ntiles = t.tiles_z * t.tiles_x;
         t.probe = 1;
         if (hipMemsetAsync(counter[dev], 0, sizeof(uint32_t), s) != hipSuccess) return 0;
-        if (launch_tile(t, QDAS_F32, ntiles, s) != hipSuccess) return 0;
+        if (launch_tile(t, dt, ntiles, s) != hipSuccess) return 0;
         uint32_t cnt = 1;
         if (hipMemcpyAsync(&cnt, counter[dev], sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 0;
         if (cnt == 0) best = l;
@@ -848,7 +849,7 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     }
     t.ksplit = ks; t.part = (float2 *)part;
     if (hipMemsetAsync(counter[dev], 0, sizeof(uint32_t), s) != hipSuccess) return 0;
-    const hipError_t e = launch_tile(t, QDAS_F32, ntiles, s);
+    const hipError_t e = launch_tile(t, dt, ntiles, s);
     if (part) (void)hipFreeAsync(part, s);
     return e == hipSuccess ? -1 : 0;
 }

@@ -161,6 +161,35 @@ def test_das_lut_full_sum_runs_the_fused_kernel(interp, seq, tpose, wtab, fm, mo
     assert np.all(a[np.abs(ref) == 0] == 0)
 
 
+@pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3"])
+def test_das_lut_half_precision_data_on_the_fused_kernel(interp, monkeypatch):
+    """fp16 channel data + fp32 delay tables (launch configuration 11) against the oracle on the fp16-rounded data and against the
+    one-thread-per-output kernel"""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import das_lut
+    case = make_case(seq="DV", interp=interp, seed=29, N=16, M=9, I1=150, I2=21, data="noise")
+    N, M = case["N"], case["M"]
+    dv, dr = O.tx_rx_distances(case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["VS"], case["DV"])
+    c = cinv_f32(case["c"])
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    tau_tx = f32((dv[:, :, :, 0, :] / c - case["t0"]) * case["fs"])[:, :, 0]
+    tau_rx = f32(dr[:, :, :, :, 0] / c * case["fs"])[:, :, 0]
+    xh = (case["x"].real.astype(np.float16).astype(np.float32) + 1j * case["x"].imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
+    ref = np.asarray(O.das_lut(xh, tau_rx[:, :, None] / case["fs"], tau_tx[:, :, None] / case["fs"], 0.0, case["fs"], interp=interp)).reshape(150, 21)
+    run = lambda: _np(das_lut(torch.from_numpy(xh), tau_rx, tau_tx, interp=interp, prec="halfT").to(torch.complex64)).reshape(150, 21)
+    monkeypatch.delenv("QDAS_LUT_GENERIC", raising=False)
+    a = run()
+    monkeypatch.setenv("QDAS_LUT_GENERIC", "1")
+    b = run()
+    den = np.abs(ref).max()
+    if interp == "nearest":
+        assert (np.abs(a - ref) / den > 3e-3).mean() <= 0.05
+    else:
+        assert rel_err(a, ref) <= 3e-3 and rel_err(a, b) <= 3e-3      # fp16 output rounding
+    assert not np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("QDAS_LUT_FUZZ", "32"))))
 def test_das_lut_random_configuration(seed):
     """random image shapes (ragged tiles, small images -> aperture split), apertures, interpolators, sequences, weight tables,
