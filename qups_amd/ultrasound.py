@@ -149,15 +149,34 @@ class UltrasoundSystem:
         return (b, plan) if return_plan else b
 
     # ------------------------------------------------------------------------------------
-    def delay_tables(self, c0=None):
+    def delay_tables(self, c0=None, device=None):
         """``tau_rx (I1 x I2 x I3 x N)``, ``tau_tx (I1 x I2 x I3 x M)`` as ``bfDAS`` computes them
-        (reference ``src/UltrasoundSystem.m:4429-4463``): ``dr/c0`` and ``dv/c0`` with the per-type sign rule."""
+        (reference ``src/UltrasoundSystem.m:4429-4463``): ``dr/c0`` and ``dv/c0`` with the per-type sign rule.  numpy arrays, or --
+        with ``device`` -- float64 torch tensors computed there (the tables of a 1024 x 1024 image over 256 elements are 2 x 2 GB)."""
         c0 = self.seq.c0 if c0 is None else c0
         Pi, Pr = self.scan.positions(), self.rx.positions()
         Pv, Nv, _ = self._tx_geometry()
         M = max(Pv.shape[1], Nv.shape[1])
         Pv = np.broadcast_to(Pv, (3, M)) if Pv.shape[1] == 1 else Pv
         Nv = np.broadcast_to(Nv, (3, M)) if Nv.shape[1] == 1 else Nv
+        if device is not None:
+            import torch
+            tt = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=device)
+            Pi_t, Pr_t, Pv_t, Nv_t = tt(Pi), tt(Pr), tt(Pv), tt(Nv)
+            e = lambda P: P[:, None, None, None, :]
+            ct = tt(np.asarray(c0, float))
+            ct = ct.reshape(tuple(ct.shape) + (1,) * (4 - ct.ndim)) if ct.ndim else ct
+            tau_rx = torch.stack([torch.linalg.norm(Pi_t - Pr_t[:, n, None, None, None], dim=0) for n in range(Pr_t.shape[1])], -1) / ct
+            cols = []
+            for m in range(M):                                     # one transmit at a time: no 3 x I x M temporary
+                rv = Pi_t - Pv_t[:, m, None, None, None]
+                if self.seq.type in ("DV", "FSA"):
+                    cols.append(torch.linalg.norm(rv, dim=0))
+                elif self.seq.type in ("VS", "FC"):
+                    cols.append(torch.linalg.norm(rv, dim=0) * torch.sign((rv * Nv_t[:, m, None, None, None]).sum(0)))
+                else:
+                    cols.append((rv * Nv_t[:, m, None, None, None]).sum(0))
+            return tau_rx, torch.stack(cols, -1) / ct
         dr = np.linalg.norm(Pi[..., None] - Pr[:, None, None, None, :], axis=0)
         rv = Pi[..., None] - Pv[:, None, None, None, :]
         t = self.seq.type
@@ -174,7 +193,9 @@ class UltrasoundSystem:
     def bfDAS(self, chd: ChannelData, *apods, c0=None, apod=1, fmod=0.0, interp="cubic", keep_tx=False, keep_rx=False,
               prec=None):
         """``b = bfDAS(us, chd, ...)`` (reference ``src/UltrasoundSystem.m:4334-4474``): delay tables + ``bfDASLUT``."""
-        tau_rx, tau_tx = self.delay_tables(c0)
+        import torch
+        dev = (chd.data.device if hasattr(chd.data, "is_cuda") and chd.data.is_cuda else "cuda") if torch.cuda.is_available() else None
+        tau_rx, tau_tx = self.delay_tables(c0, device=dev)
         return self.bfDASLUT(chd, tau_rx, tau_tx, *apods, apod=apod, fmod=fmod, interp=interp, keep_tx=keep_tx, keep_rx=keep_rx, prec=prec)
 
     def bfDASLUT(self, chd: ChannelData, tau_rx, tau_tx, *apods, apod=1, fmod=0.0, interp="cubic", keep_tx=False,
