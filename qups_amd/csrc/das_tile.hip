@@ -81,7 +81,7 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part))) return hipErrorInvalidValue;
 const int nf = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
     if ((nf != 1 && nf != 2 && nf != 4) || (nf > 1 && (sym || P.big))) return hipErrorInvalidValue;
-    if (P.lut_tx && (sym || nf != 1 || (dtype != 1 && dtype != 2) || P.syn)) return hipErrorInvalidValue;
+    if (P.lut_tx && (sym || nf != 1 || (dtype != 1 && dtype != 2) || (P.syn && dtype != 1))) return hipErrorInvalidValue;
     hipError_t e = P.lut_tx ? (dtype == 2 ? launch_tile_luth(P, ntiles, lds, s) : launch_tile_lut(P, ntiles, lds, s)) : sym ? (dtype == 2 ? launch_tile_symh(P, ntiles, lds, s) : narrow ? launch_tile_symw(P, ntiles, lds, s) : launch_tile_sym(P, ntiles, lds, s))
                  : nf == 4 ? (dtype == 2 ? launch_tile_f16x4(P, ntiles, lds, s) : launch_tile_f32x4(P, ntiles, lds, s))
                  : nf == 2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))

@@ -784,14 +784,22 @@ extern "C" int qdas_delaysf(const qdas_sizes *sz, float *tau, const float *Pi, c
 // LDS window for any footprint / QDAS_LUT_GENERIC=1), 0 on a HIP error.
 static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t s) {
     const int dt = d->dtype;
-    if ((dt != QDAS_F32 && dt != QDAS_F16) || (d->flag & (QDAS_FLAG_KEEP_RX | QDAS_FLAG_KEEP_TX)) || getenv("QDAS_LUT_GENERIC")) return 1;
+    const bool keep_rx = d->flag & QDAS_FLAG_KEEP_RX, keep_tx = d->flag & QDAS_FLAG_KEEP_TX;
+    if ((dt != QDAS_F32 && dt != QDAS_F16) || (keep_rx && keep_tx) || getenv("QDAS_LUT_GENERIC")) return 1;
+    // one kept dimension (fp32, no weights): the kernel's 'SYN' mode -- one output plane per STAGE element; keeping the transmit
+    // dimension swaps the roles of the two tables (as 'MUL' does for geometry-driven plans)
+    const bool keep = keep_rx || keep_tx;
+    if (keep && (dt != QDAS_F32 || d->w)) return 1;
     if (d->w && (d->wstride[0] != 0 || d->w_real || dt != QDAS_F32)) return 1;   // weights: none, or one complex fp32 N x M table
     if (d->T < 8 || d->N >= (1ull << 20) || d->M >= (1ull << 20)) return 1;
-    if (tile_lds_bytes(dt, 0, d->N, d->M) > tile_lds_limit(0)) return 1;
+    if (tile_lds_bytes(dt, 0, d->N > d->M ? d->N : d->M, d->N > d->M ? d->N : d->M) > tile_lds_limit(0)) return 1;
     const bool tp = d->flag & QDAS_FLAG_TPOSE;
-    const uint64_t strN = tp ? d->T * d->M : d->T, strM = tp ? d->T : d->T * d->N;
+    uint64_t strN = tp ? d->T * d->M : d->T, strM = tp ? d->T : d->T * d->N;
+    uint64_t kN = d->N, kM = d->M;
+    const void *tab_s = d->tau_rx, *tab_b = d->tau_tx;                // stage / block tables
+    if (keep_tx) { std::swap(strN, strM); std::swap(kN, kM); std::swap(tab_s, tab_b); }
     const TileConfig tc = tile_config(dt, 0);
-    if ((d->N * strN + (uint64_t)tc.mb * strM) * data_size(dt) + 65536 >= (1ull << 31)) return 1;
+    if ((kN * strN + (uint64_t)tc.mb * strM) * data_size(dt) + 65536 >= (1ull << 31)) return 1;
     static uint32_t *counter[64] = {nullptr};                         // per device, kept for the life of the process
     static std::mutex lut_mutex;                                      // the misfit counter is shared: one probing call at a time
     std::lock_guard<std::mutex> lock(lut_mutex);
@@ -806,7 +814,8 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     }
     TileParams t{};
     t.x = x; t.y = y; t.wtab = wtab;
-    t.T = d->T; t.N = d->N; t.M = d->M;
+    t.T = d->T; t.N = kN; t.M = kM;
+    t.syn = keep ? 1 : 0;
     const uint64_t I1 = (d->I1 && d->I1 < d->I && d->I % d->I1 == 0) ? d->I1 : (d->I1 >= d->I ? d->I : 64);
     t.I1 = I1; t.I2 = (d->I + I1 - 1) / I1; t.I3 = 1;
     t.i_begin = 0; t.i_count = d->I; t.y_ld = d->I;
@@ -814,7 +823,7 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     t.fs = 1.0; t.cinv_fs = 0.0; t.fmod = d->omega / 6.283185307179586476925;
     t.flag = d->flag & (7 | QDAS_FLAG_TPOSE);
     t.nfr = 1; t.ksplit = 1;
-    t.lut_tx = (const float *)d->tau_tx; t.lut_rx = (const float *)d->tau_rx;
+    t.lut_tx = (const float *)tab_b; t.lut_rx = (const float *)tab_s;
     t.fallback_list = counter[dev]; t.fallback_cap = 0;
     // footprint: the deepest tile (of 64, 32, 16, 8 pixels of I1) whose delay spreads all fit the window; the tables are data
     // of this call, so the fit is probed per call (prologue-only launches)
@@ -841,13 +850,14 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
     unsigned ks = 1;
-    const unsigned cap = (unsigned)std::min<uint64_t>(8, d->N);
+    const unsigned cap = (unsigned)std::min<uint64_t>(8, kN);
     while (ks * 2 <= cap && (uint64_t)ntiles * ks < (uint64_t)ncu) ks *= 2;
     void *part = nullptr;
     if (ks > 1) {
         if (hipMallocAsync(&part, sizeof(float) * 2 * (size_t)ks * d->I, s) != hipSuccess) { part = nullptr; ks = 1; }
     }
     t.ksplit = ks; t.part = (float2 *)part;
+    if (keep && hipMemsetAsync(y, 0, d->I * kN * sizeof(float2), s) != hipSuccess) return 0;   // planes are accumulated with atomics
     if (hipMemsetAsync(counter[dev], 0, sizeof(uint32_t), s) != hipSuccess) return 0;
     const hipError_t e = launch_tile(t, dt, ntiles, s);
     if (part) (void)hipFreeAsync(part, s);

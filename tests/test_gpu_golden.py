@@ -161,6 +161,36 @@ def test_das_lut_full_sum_runs_the_fused_kernel(interp, seq, tpose, wtab, fm, mo
     assert np.all(a[np.abs(ref) == 0] == 0)
 
 
+@pytest.mark.parametrize("keep", ["rx", "tx"])
+@pytest.mark.parametrize("seq,interp,tpose,fm", [("FSA", "cubic", False, 0.0), ("PW", "lanczos3", True, 2e6), ("FC", "linear", False, 0.0)])
+def test_das_lut_one_kept_dimension_on_the_fused_kernel(keep, seq, interp, tpose, fm, monkeypatch):
+    """keep the receive or the transmit dimension (sum over the other one): the fused kernel's plane-per-stage mode, with the two
+    tables trading places for the transmit dimension; oracle + one-thread-per-output kernel"""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import das_lut
+    case = make_case(seq=seq, interp=interp, seed=27, N=16, M=None if seq == "FSA" else 9, I1=130, I2=19, data="noise")
+    N, M = case["N"], case["M"]
+    dv, dr = O.tx_rx_distances(case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["VS"], case["DV"])
+    c = cinv_f32(case["c"])
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    tau_tx = f32((dv[:, :, :, 0, :] / c - case["t0"]) * case["fs"])[:, :, 0]
+    tau_rx = f32(dr[:, :, :, :, 0] / c * case["fs"])[:, :, 0]
+    x = case["x"]
+    xs = np.ascontiguousarray(np.swapaxes(x, 1, 2)) if tpose else x
+    kr, kt = keep == "rx", keep == "tx"
+    ref = np.asarray(O.das_lut(x, tau_rx[:, :, None] / case["fs"], tau_tx[:, :, None] / case["fs"], 0.0, case["fs"], interp=interp, fmod=fm,
+                               keep_rx=kr, keep_tx=kt)).reshape(130, 19, N if kr else M)
+    run = lambda: _np(das_lut(torch.from_numpy(xs), tau_rx, tau_tx, interp=interp, omega=2 * np.pi * fm / case["fs"], prec="single", tpose=tpose,
+                              keep_rx=kr, keep_tx=kt)).reshape(130, 19, -1)
+    monkeypatch.delenv("QDAS_LUT_GENERIC", raising=False)
+    a = run()
+    monkeypatch.setenv("QDAS_LUT_GENERIC", "1")
+    b = run()
+    assert a.shape == ref.shape and rel_err(a, ref) <= 1e-4 and rel_err(a, b) <= 1e-4
+    assert not np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3"])
 def test_das_lut_half_precision_data_on_the_fused_kernel(interp, monkeypatch):
     """fp16 channel data + fp32 delay tables (launch configuration 11) against the oracle on the fp16-rounded data and against the
