@@ -786,11 +786,15 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     const int dt = d->dtype;
     const bool keep_rx = d->flag & QDAS_FLAG_KEEP_RX, keep_tx = d->flag & QDAS_FLAG_KEEP_TX;
     if ((dt != QDAS_F32 && dt != QDAS_F16) || (keep_rx && keep_tx) || getenv("QDAS_LUT_GENERIC")) return 1;
-    // one kept dimension (fp32, no weights): the kernel's 'SYN' mode -- one output plane per STAGE element; keeping the transmit
+    // one kept dimension (fp32; weights: none, or a pixel x receiver array with the receive dimension kept): the kernel's 'SYN' mode -- one output plane per STAGE element; keeping the transmit
     // dimension swaps the roles of the two tables (as 'MUL' does for geometry-driven plans)
     const bool keep = keep_rx || keep_tx;
-    if (keep && (dt != QDAS_F32 || d->w)) return 1;
-    if (d->w && (d->wstride[0] != 0 || d->w_real || dt != QDAS_F32)) return 1;   // weights: none, or one complex fp32 N x M table
+    // weights: none; one complex fp32 N x M table (wstride {0, 1, N}); or -- the usual receive apodization -- an I x N array in the
+    // data precision, real or complex (wstride {1, I, 0}), which the kernel applies per stage like the plans' pixel x receiver arrays
+    const bool w_tab = d->w && d->wstride[0] == 0 && !d->w_real && dt == QDAS_F32 && d->wstride[1] == 1 && d->wstride[2] == d->N;
+    const bool w_pix = d->w && !w_tab && d->wstride[0] == 1 && d->wstride[1] == d->I && d->wstride[2] == 0 && d->N > 1;
+    if (d->w && !w_tab && !w_pix) return 1;
+    if (keep && (dt != QDAS_F32 || w_tab || (w_pix && keep_tx))) return 1;
     if (d->T < 8 || d->N >= (1ull << 20) || d->M >= (1ull << 20)) return 1;
     if (tile_lds_bytes(dt, 0, d->N > d->M ? d->N : d->M, d->N > d->M ? d->N : d->M) > tile_lds_limit(0)) return 1;
     const bool tp = d->flag & QDAS_FLAG_TPOSE;
@@ -806,17 +810,14 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
     if (!counter[dev] && hipMalloc(&counter[dev], 64) != hipSuccess) return 1;
-    const void *wtab = nullptr;
-    void *wtmp = nullptr;
-    if (d->w) {                                                       // w[n*st1 + m*st2] -> table [n + N*m]
-        if (d->wstride[1] == 1 && d->wstride[2] == d->N) wtab = d->w;
-        else return 1;
-    }
+    const bool shaped = d->I1 && d->I1 < d->I && d->I % d->I1 == 0;    // (a per-pixel array needs the true image shape: no ragged rows)
+    if (w_pix && !shaped && d->I1 != d->I) return 1;
     TileParams t{};
-    t.x = x; t.y = y; t.wtab = wtab;
+    t.x = x; t.y = y; t.wtab = w_tab ? d->w : nullptr;
+    if (w_pix) { t.apix = d->w; t.apix_real = d->w_real; }
     t.T = d->T; t.N = kN; t.M = kM;
     t.syn = keep ? 1 : 0;
-    const uint64_t I1 = (d->I1 && d->I1 < d->I && d->I % d->I1 == 0) ? d->I1 : (d->I1 >= d->I ? d->I : 64);
+    const uint64_t I1 = shaped ? d->I1 : (d->I1 >= d->I ? d->I : 64);
     t.I1 = I1; t.I2 = (d->I + I1 - 1) / I1; t.I3 = 1;
     t.i_begin = 0; t.i_count = d->I; t.y_ld = d->I;
     t.strN = strN; t.strM = strM;
@@ -843,7 +844,6 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
         if (hipMemcpyAsync(&cnt, counter[dev], sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 0;
         if (cnt == 0) best = l;
     }
-    (void)wtmp;
     if (best < 0) return 1;
     t.probe = 0;
     // too few tiles for the GPU: several workgroups per tile, each summing a range of receivers (as plans do)

@@ -161,6 +161,41 @@ def test_das_lut_full_sum_runs_the_fused_kernel(interp, seq, tpose, wtab, fm, mo
     assert np.all(a[np.abs(ref) == 0] == 0)
 
 
+@pytest.mark.parametrize("prec,real,keep_rx", [("single", True, False), ("single", False, False), ("single", True, True), ("halfT", True, False), ("halfT", False, False)])
+def test_das_lut_receive_apodization_array_on_the_fused_kernel(prec, real, keep_rx, monkeypatch):
+    """the usual bfDASLUT call: a pixel x receiver apodization (I1 x I2 x N, real or complex, data precision) -- applied per stage by
+    the fused kernel like the plans' arrays; also with the receive dimension kept"""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import das_lut
+    case = make_case(seq="DV", interp="cubic", seed=31, N=16, M=9, I1=130, I2=19, data="noise")
+    N, M = case["N"], case["M"]
+    dv, dr = O.tx_rx_distances(case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["VS"], case["DV"])
+    c = cinv_f32(case["c"])
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    tau_tx = f32((dv[:, :, :, 0, :] / c - case["t0"]) * case["fs"])[:, :, 0]
+    tau_rx = f32(dr[:, :, :, :, 0] / c * case["fs"])[:, :, 0]
+    rng = np.random.default_rng(2)
+    q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else (lambda a: a.astype(np.float32).astype(np.float64))
+    w = q(rng.uniform(0, 1, (130, 19, N, 1)) * (rng.uniform(0, 1, (130, 19, N, 1)) > 0.3))
+    if not real:
+        w = w + 1j * q(rng.uniform(-0.3, 0.3, (130, 19, N, 1)))
+    x = case["x"]
+    if prec == "halfT":
+        x = (x.real.astype(np.float16).astype(np.float32) + 1j * x.imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
+    ref = np.asarray(O.das_lut(x, tau_rx[:, :, None] / case["fs"], tau_tx[:, :, None] / case["fs"], 0.0, case["fs"], interp="cubic",
+                               apod=(w.reshape(130, 19, 1, N, 1).astype(np.complex128),), keep_rx=keep_rx)).reshape(130, 19, -1)
+    wt = torch.from_numpy(w.astype(np.float32) if real else w.astype(np.complex64))
+    run = lambda: _np(das_lut(torch.from_numpy(x), tau_rx, tau_tx, interp="cubic", w=wt, prec=prec, keep_rx=keep_rx).to(torch.complex64)).reshape(130, 19, -1)
+    monkeypatch.delenv("QDAS_LUT_GENERIC", raising=False)
+    a = run()
+    monkeypatch.setenv("QDAS_LUT_GENERIC", "1")
+    b = run()
+    tol = 3e-3 if prec == "halfT" else 1e-4
+    assert a.shape == ref.shape and rel_err(a, ref) <= tol and rel_err(a, b) <= tol
+    assert not np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("keep", ["rx", "tx"])
 @pytest.mark.parametrize("seq,interp,tpose,fm", [("FSA", "cubic", False, 0.0), ("PW", "lanczos3", True, 2e6), ("FC", "linear", False, 0.0)])
 def test_das_lut_one_kept_dimension_on_the_fused_kernel(keep, seq, interp, tpose, fm, monkeypatch):
