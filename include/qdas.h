@@ -10,7 +10,10 @@
  * of `DAS` / `DASf` / `DASh`, reference src/bf.cu:144-172), plus the `delays`
  * variant (kern/das_spec.m:377, src/bf.cu:209-298) and -- as the "next" row --
  * the split-delay launch of `wsinterpd2[f|h]` (kern/wsinterpd2.m:236,
- * src/interpd.cu:449-476) used by bfDAS/bfDASLUT.
+ * src/interpd.cu:449-476) used by bfDAS/bfDASLUT.  The steps either side of
+ * the path have their own entry points further down: `qdas_greens`
+ * (src/greens.cu), `qdas_pre_*` (ChannelData.hilbert / downmix), `qdas_convd`
+ * (src/convd.cu), and `qdas_permute3` for row-major hosts.
  *
  * Everything is plain C: pointers, sizes, no torch / HIP types in signatures
  * (`stream` is a `hipStream_t` passed as `void*`; NULL = the default stream).
