@@ -226,6 +226,36 @@ __device__ __forceinline__ v2f half2_to_v2f(uint32_t v) {
 __device__ __forceinline__ float2   zero_of(const float2 *)   { return make_float2(0.f, 0.f); }
 __device__ __forceinline__ uint32_t zero_of(const uint32_t *) { return 0u; }
 
+// ---- cold fp64 code, kept OUT of line on purpose.  Inlined into the stage loop (16 unrolled copies of the transmit-block refresh,
+//      the fp64 acos / cos of the generated receive apodization) it inflated the live ranges around the pair loop until the
+//      register allocator parked the lane's transmit residuals ra[] in scratch and re-loaded them every stage (round 1: 170-230
+//      spilled VGPRs, 340-416 B of scratch per lane in every general instantiation).  As calls they cost a few scalar
+//      instructions once per transmit block / stage and the kernels have no scratch at all (tools/kernel_regs.py).
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+// a(i,m) - A[m] - 1/2 of one (pixel, block element): geometry tables in LDS, fp64 (reference src/bf.cu:104-108,114)
+static __device__ __noinline__ float block_residual(float px, float py, float pz, double cf, double fs, int kindB, lds_cfloat *Pv, lds_cfloat *Nv,
+                                                    uint32_t m, int Abase_m, double off) {
+    const double rx = (double)px - (double)Pv[4 * m], ry = (double)py - (double)Pv[4 * m + 1], rz = (double)pz - (double)Pv[4 * m + 2];
+    const double dot = kindB ? rx * (double)Nv[3 * m] + ry * (double)Nv[3 * m + 1] + rz * (double)Nv[3 * m + 2] : 0.0;
+    double dv = dot;
+    if (kindB != 2) {
+        const double d2 = rx * rx + ry * ry + rz * rz;
+        const float s0 = __builtin_sqrtf((float)d2);                  // fp32 seed + one Newton step (as dsqrt in the kernel)
+        const double sd = (double)s0;
+        const double r = __builtin_fma(-sd, sd, d2);
+        const double len = __builtin_fma(r, (double)(0.5f * __builtin_amdgcn_rcpf(fmaxf(s0, 1.0e-30f))), sd);
+        dv = kindB == 0 ? len : copysign(len, dot);
+    }
+    return (float)((dv * cf - (double)Pv[4 * m + 3] * fs + off) - ((double)Abase_m + 0.5));
+}
+// generated pixel x receiver weight (qdas.h QDAS_RXAPOD_*): element position from the LDS record, normal by scalar loads
+static __device__ __noinline__ float rx_apod_generated(int kind, double p0, double p1, float px, float py, float pz, float ex, float ey, float ez,
+                                                       const float *rxn, uint32_t n) {
+    const float nx = rxn ? rxn[3 * n] : 0.f, ny = rxn ? rxn[3 * n + 1] : 0.f, nz = rxn ? rxn[3 * n + 2] : 1.f;
+    return (float)rx_apod_weight(kind, p0, p1, (double)px - (double)ex, (double)py - (double)ey, (double)pz - (double)ez,
+                                 (double)nx, (double)ny, (double)nz, (double)px, (double)pz, (double)ex);
+}
+
 // CFG: WAVES waves (= image columns) per workgroup, MB transmits per stage, W samples per window,
 //      NBUF window buffers (NBUF-1 stages of LDS-DMA in flight), PSZ bytes per lane and DMA piece (12|16),
 //      BPC workgroups per CU the register budget is sized for.
@@ -612,9 +642,7 @@ das_tile_kernel(const TileParams P) {
     auto wload = [&](uint32_t n) -> v2f {
         if (!SYM && P.gen_kind) {                         // qdas.h QDAS_RXAPOD_*: element from the LDS record, normal by scalar loads (never in reciprocal mode)
             const float4 e = nrec[n];
-            const float nx = P.rxn ? P.rxn[3 * n] : 0.f, ny = P.rxn ? P.rxn[3 * n + 1] : 0.f, nz = P.rxn ? P.rxn[3 * n + 2] : 1.f;
-            return (v2f){(float)rx_apod_weight(P.gen_kind, P.gen_p0, P.gen_p1, (double)px - (double)e.y, (double)py - (double)e.z,
-                                               (double)pz - (double)e.w, (double)nx, (double)ny, (double)nz, (double)px, (double)pz, (double)e.y), 0.f};
+            return (v2f){rx_apod_generated(P.gen_kind, P.gen_p0, P.gen_p1, px, py, pz, e.y, e.z, e.w, P.rxn, n), 0.f};
         }
         const uint64_t k = ipc + Itot * n;
         if (P.apix_real) {
@@ -686,8 +714,11 @@ das_tile_kernel(const TileParams P) {
                         const double fc = symC - (double)symCi - 0.5;
                         ra[p] = (v2f){(float)(b_at(ea.y, ea.z, ea.w) - (double)__float_as_int(ea.x) + fc),
                                       (float)(b_at(eb.y, eb.z, eb.w) - (double)__float_as_int(eb.x) + fc)};
-                    } else
-                    ra[p] = (v2f){(float)(a_of(ma) - ((double)Abase[ma] + 0.5)), (float)(a_of(mb) - ((double)Abase[mb] + 0.5))};
+                    } else if constexpr (LUT)
+                        ra[p] = (v2f){(float)(a_of(ma) - ((double)Abase[ma] + 0.5)), (float)(a_of(mb) - ((double)Abase[mb] + 0.5))};
+                    else
+                        ra[p] = (v2f){block_residual(px, py, pz, cf, fs, kindB, (lds_cfloat *)PvL, (lds_cfloat *)NvL, ma, Abase[ma], tapinfo<INTERP>::OFF),
+                                      block_residual(px, py, pz, cf, fs, kindB, (lds_cfloat *)PvL, (lds_cfloat *)NvL, mb, Abase[mb], tapinfo<INTERP>::OFF)};
                     __builtin_amdgcn_sched_barrier(0);      // one pair at a time: keeps this cold block from inflating the register budget
                 }
             }
