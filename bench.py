@@ -1,27 +1,40 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the DAS hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|small]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c5|c1|small]
 
 One "step" = one full-frame delay-and-sum of the workload (default: BASELINE config C3 -- 256-element
 array, 256-transmit full-synthetic-aperture, 1024 x 1024 Cartesian scan, T = 2816, complex64 channel
 data, lanczos3, no apodization, scalar sound speed) with the channel data
-already resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per GPU) the SAME
-image is split into N contiguous slabs of the linear pixel index, every rank beamforms its slab from
-its own replica of the data, and the slabs are gathered with one RCCL all_gather -- inside the timed
-region (strong scaling of one frame).
+already resident in HBM.
+
+N > 1: one rank per GPU over RCCL.  Either launched by `python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or -- when those are absent --
+bench.py re-executes ITSELF under torch.distributed.run, so a bare `python bench.py --gpus 8` works too.
+The SAME image is split into N contiguous slabs of the linear pixel index, every rank beamforms its slab
+from its own replica of the data, and the slabs are gathered with one RCCL all_gather -- inside the timed
+region (strong scaling of one frame).  Outside the timed region rank 0 also reports the per-rank kernel
+times, the gather alone, and the cost of replicating the channel data from rank 0 (RCCL broadcast).
 
 Rank 0 prints ONE JSON line: metric/value/unit per BASELINE.json plus
-  "roofline":     algorithmic HBM bytes per launch / measured kernel time (hipEvents on the launch stream)
-  "cpu_baseline": the C restatement of the reference's CPU branch (oracle/, kind "port") timed on this
-                  host's cores on a pixel-subsampled image (N=1 only).
+  "roofline":     algorithmic HBM bytes per launch / measured kernel time (hipEvents on the launch stream),
+                  HBM traffic from rocprofv3 counter passes of this very command (N = 1; --traffic file|none to skip),
+                  the fp32-VALU fraction on the model AND on the executed flop count of the kernel
+  "general_ms_per_step": the same frame with the reciprocal mode disabled by a plan flag (what an apodized FSA costs)
+  "cpu_baseline": the C restatement of the reference's CPU branch (oracle/) timed on this host's cores on a
+                  pixel-subsampled image (N = 1 only): as written ("port") and rebuilt for this host ("port-tuned").
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -33,33 +46,110 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP32_PEAK_TFLOPS = 157.3       # fp32 vector peak (same guide)
 FLOP_PER_PAIR = {"nearest": 17, "linear": 24, "cubic": 42, "lanczos3": 54}   # SURVEY.md section 8d flop model
+# Flops the tiled kernel's pair loop EXECUTES per (pixel, rx, tx) pair, counted from its instruction mix (DESIGN.md section 4.1:
+# v_pk_add/mul = 2 flop, v_pk_fma = 4 flop per lane; index math 4 packed adds per transmit pair, weights, 4-tap complex MACs);
+# reciprocal mode shares index + weights between the two traces of an unordered pair.  Cross-checked once against
+# SQ_INSTS_VALU_{FMA,ADD,MUL}_F32 (profiles/r02/).  Per-stage code (receive delay in fp64, DMA issue) is not counted.
+EXEC_FLOP_PER_PAIR = {("nearest", False): 6.0, ("linear", False): 14.0, ("cubic", False): 37.0, ("lanczos3", False): 53.0,
+                      ("nearest", True): 5.0, ("linear", True): 11.0, ("cubic", True): 26.5, ("lanczos3", True): 34.5}
 
 
 from qups_amd.configs import workload  # noqa: E402  (geometry of the BASELINE configs)
 
 
-def cpu_baseline(w, x_host, budget_s=30.0):
-    """Time the C oracle (port of the reference CPU branch) on a pixel-subsampled image."""
+def host_info():
+    model, phys = "?", None
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":", 1)[0].strip(): l.split(":", 1)[1].strip() for l in out.splitlines() if ":" in l}
+        model = kv.get("Model name", "?")
+        phys = int(kv.get("Core(s) per socket", "0")) * int(kv.get("Socket(s)", "1")) or None
+    except Exception:
+        pass
+    return model, phys
+
+
+def cpu_baseline(w, x_host, budget_s=12.0):
+    """Time the C oracle (port of the reference CPU branch) on a pixel-subsampled image: the straight port and the
+    host-tuned rebuild (-march=native, float weight math; oracle/Makefile)."""
     from oracle import das_ref
-    nthreads = das_ref.lib().das_ref_max_threads()
+    model, phys = host_info()
+    out = []
+    for kind in ("port", "port-tuned"):
+        try:
+            L = das_ref.lib(tuned=(kind == "port-tuned"))
+        except Exception as ex:
+            out.append({"value": None, "unit": "Mpixel/s", "kind": kind, "sample": f"unavailable: {ex!r}"})
+            continue
+        nthreads = L.das_ref_max_threads()
 
-    def run(step):
-        Pi = w["Pi"][:, ::step, ::step, :]
-        t = time.perf_counter()
-        das_ref.das_spec("DAS", Pi, w["Pr"], w["Pv"], w["Nv"], x_host, w["t0"], w["fs"], w["c0"],
-                         VS="plane-waves" not in w["opt"], DV="diverging-waves" in w["opt"], interp=w["interp"],
-                         prec="single", timing=True)
-        return das_ref.LAST_SECONDS, Pi.shape[1] * Pi.shape[2]
+        def run(step):
+            Pi = w["Pi"][:, ::step, ::step, :]
+            das_ref.das_spec("DAS", Pi, w["Pr"], w["Pv"], w["Nv"], x_host, w["t0"], w["fs"], w["c0"],
+                             VS="plane-waves" not in w["opt"], DV="diverging-waves" in w["opt"], interp=w["interp"],
+                             prec="single", timing=True, tuned=(kind == "port-tuned"))
+            return das_ref.LAST_SECONDS, Pi.shape[1] * Pi.shape[2]
 
-    t, npx = run(32)                                   # calibration
-    rate = npx / max(t, 1e-6)
-    want = rate * budget_s
-    step = int(np.clip(np.ceil(np.sqrt(w["I1"] * w["I2"] / max(want, 1.0))), 1, 32))
-    t, npx = run(step)
-    return {"value": round(npx / t / 1e6, 6), "unit": "Mpixel/s", "cores": int(nthreads), "kind": "port",
-            "seconds": round(t, 3),
-            "sample": f"every {step}th pixel per axis of the same image ({npx} px), full {w['N']}x{w['M']} aperture, "
-                      f"float32, OpenMP x{nthreads}; full-frame time extrapolated: {w['I1'] * w['I2'] / (npx / t):.1f} s"}
+        t, npx = run(32)                                   # calibration
+        rate = npx / max(t, 1e-6)
+        want = rate * budget_s
+        step = int(np.clip(np.ceil(np.sqrt(w["I1"] * w["I2"] / max(want, 1.0))), 1, 32))
+        t, npx = run(step)
+        out.append({"value": round(npx / t / 1e6, 6), "unit": "Mpixel/s", "cores": int(nthreads), "kind": kind,
+                    "seconds": round(t, 3), "cpu_model": model, "physical_cores": phys,
+                    "gpairs_per_s": round(npx * w["N"] * w["M"] / t / 1e9, 4),
+                    "sample": f"every {step}th pixel per axis of the same image ({npx} px), full {w['N']}x{w['M']} aperture, "
+                              f"float32, OpenMP x{nthreads}; full-frame time extrapolated: {w['I1'] * w['I2'] / (npx / t):.1f} s"})
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def measure_traffic(argv, kernel_hint="das_tile_kernel"):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 counter passes of THIS command (one pass per counter: FETCH_SIZE
+    and WRITE_SIZE do not fit together), corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KiB) x 2 for 16 B/lane
+    streaming reads, WRITE_SIZE (KiB) as is.  Returns (bytes | None, source string)."""
+    import csv
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="qdas_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", QDAS_BENCH_CHILD="1")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__)] + argv + ["--steps", "2", "--warmup", "1", "--no-cpu", "--traffic", "none",
+                                                                       "--no-general"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
+            rows = [x for x in csv.DictReader(open(files[0])) if x["Counter_Name"] == ctr and kernel_hint in x["Kernel_Name"]
+                    and "generic" not in x["Kernel_Name"]]
+            if not rows:
+                rows = [x for x in csv.DictReader(open(files[0])) if x["Counter_Name"] == ctr]
+            dur = [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in rows]
+            full = [float(x["Counter_Value"]) for x, t in zip(rows, dur) if t >= 0.5 * max(dur)]   # (plan-time probe launches are short)
+            vals[ctr] = sum(full) / len(full)
+    except Exception as ex:
+        return None, f"rocprofv3 counter pass failed: {ex!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return int(vals["FETCH_SIZE"] * 2048 + vals["WRITE_SIZE"] * 1024), \
+        "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command (FETCH_SIZE KiB x2 gfx950 correction + WRITE_SIZE KiB)"
 
 
 def main():
@@ -70,10 +160,18 @@ def main():
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 tiled")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-general", action="store_true", help="skip the reciprocal-mode-off measurement")
+    ap.add_argument("--no-reciprocal", action="store_true", help="disable the reciprocal mode for the headline measurement itself (plan flag)")
+    ap.add_argument("--jit", action="store_true", help="plan flag QDAS_PLAN_JIT: hiprtc-specialised tiled kernel")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "none"],
+                    help="roofline.traffic: rocprofv3 counter passes of this command (live; auto = live at N=1) or profiles/traffic_<w>.json")
     ap.add_argument("--prec", default=None, help="override the workload's data precision (single | halfT); not the headline")
     ap.add_argument("--gen-apod", action="store_true", help="generate the workload's receive apodization inside the kernel "
                     "(qdas_desc.rx_apod_*) instead of streaming the materialised I x N array")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -82,14 +180,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
     if args.gpus > 1 or world > 1:
-        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # QDAS_BENCH_SHARE_GPU=1 (plumbing check of the N > 1 path on a one-GPU box): every rank on cuda:0, gloo instead of RCCL
         share = os.environ.get("QDAS_BENCH_SHARE_GPU", "0") == "1"
+        if not share and torch.cuda.device_count() < world:
+            raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} HIP device(s) visible")
         if share:
             local = 0
         torch.cuda.set_device(local)
+        backend = "gloo" if share else "nccl"
         if share:
             dist.init_process_group("gloo")
         else:
@@ -119,7 +221,7 @@ def main():
         xc = _cast_data(xc, "halfT", dev).contiguous()
     prob = build_problem("DAS", w["Pi"], w["Pr"], w["Pv"], w["Nv"], (T, N, M), w["t0"], w["fs"], w["c0"], opts)
     b, e = I * rank // world, I * (rank + 1) // world       # contiguous slab of the linear pixel index
-    plan = DasPlan(prob, device=dev, kernel=args.kernel, i_begin=b, i_count=e - b)
+    plan = DasPlan(prob, device=dev, kernel=args.kernel, i_begin=b, i_count=e - b, reciprocal=not args.no_reciprocal, jit=args.jit)
     from qups_amd.dist import gather_pixels
 
     def step():
@@ -145,15 +247,75 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
 
-    # kernel-only time (hipEvents on the launch stream), outside the timed region
-    plan.set_timing(True)
-    kms = []
-    for _ in range(max(2, min(args.steps, 5))):
-        plan.execute_colmajor(xc, 1)
-        kms.append(plan.last_kernel_ms())
-    plan.set_timing(False)
-    kernel_ms = float(np.mean(kms))
+    # ---- outside the timed region
+    def kernel_time(p, reps):
+        p.set_timing(True)
+        ks = []
+        for _ in range(reps):
+            p.execute_colmajor(xc, 1)
+            ks.append(p.last_kernel_ms())
+        p.set_timing(False)
+        return float(np.mean(ks))
+
+    kernel_ms = kernel_time(plan, max(2, min(args.steps, 5)))     # hipEvents on the launch stream
     fallback = plan.fallback_tiles()
+    multi = {}
+    if world > 1:
+        km = torch.tensor([kernel_ms], device=dev, dtype=torch.float64)
+        allk = [torch.zeros_like(km) for _ in range(world)]
+        dist.all_gather(allk, km)
+        y = plan.execute_colmajor(xc, 1)
+        torch.cuda.synchronize(); dist.barrier()
+        tg = time.perf_counter()
+        for _ in range(5):
+            gather_pixels(y, I, world)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) / 5 * 1e3
+        # replicating the channel data from rank 0 (what a single acquisition host has to do once per frame): one RCCL broadcast
+        xr = torch.view_as_real(xc) if xc.is_complex() else xc
+        dist.broadcast(xr, 0)                                   # warm-up (connection setup)
+        torch.cuda.synchronize(); dist.barrier()
+        tb = time.perf_counter()
+        for _ in range(3):
+            dist.broadcast(xr, 0)
+        torch.cuda.synchronize(); dist.barrier()
+        bcast_ms = (time.perf_counter() - tb) / 3 * 1e3
+        multi = {"backend": backend, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
+                 "per_rank_kernel_ms": [round(float(k.item()), 3) for k in allk], "gather_ms": round(gather_ms, 3),
+                 "broadcast_x_ms": round(bcast_ms, 3), "x_bytes": int(xc.numel() * xc.element_size()),
+                 "ms_per_step_incl_replication": round(el / args.steps * 1e3 + bcast_ms, 3),
+                 "value_incl_replication": round(I / (el / args.steps + bcast_ms * 1e-3) / 1e6, 4)}
+    reciprocal = bool(plan.reciprocal)
+    general_ms = None
+    if world == 1 and reciprocal and not args.no_general:      # the same frame without the reciprocal special case (plan flag)
+        gplan = DasPlan(prob, device=dev, kernel=args.kernel, i_begin=b, i_count=e - b, reciprocal=False, jit=args.jit)
+        gplan.execute_colmajor(xc, 1)
+        general_ms = kernel_time(gplan, 3)
+        gplan.close()
+
+    traffic, tsrc = None, "not measured"
+    if rank == 0 and not os.environ.get("QDAS_BENCH_CHILD"):
+        mode = args.traffic
+        if mode == "auto":
+            mode = "live" if world == 1 else "file"
+        if mode == "live":
+            argv = ["--workload", args.workload] + (["--kernel", str(args.kernel)] if args.kernel else []) + \
+                   (["--prec", args.prec] if args.prec else []) + (["--gen-apod"] if args.gen_apod else []) + \
+                   (["--no-reciprocal"] if args.no_reciprocal else []) + (["--jit"] if args.jit else [])
+            traffic, tsrc = measure_traffic(argv)
+            if traffic is None:
+                mode = "file"
+                tsrc += "; "
+            else:
+                tsrc = tsrc
+        if mode == "file":
+            tfile = os.path.join(ROOT, "profiles", f"traffic_{w['name']}.json")
+            if os.path.exists(tfile):
+                try:
+                    traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                    tsrc = (tsrc if tsrc.endswith("; ") else "") + f"profiles/traffic_{w['name']}.json (committed rocprofv3 pass, not this run)"
+                except Exception:
+                    traffic = None
 
     if rank == 0:
         ms = el / args.steps * 1e3
@@ -161,35 +323,42 @@ def main():
         sb = 4 if w["prec"] == "halfT" else 8
         apb = 0 if w["apod"] is None else w["apod"].size * (2 if w["prec"] == "halfT" else 4)
         alg_bytes = (T * N * M * sb + 12 * I + sb * I + apb) / world      # per launch (per rank): x + Pi + y (+ apod)  (SURVEY 8d "B")
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", f"traffic_{w['name']}.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         info = _lib.device_info(local)
+        ksec = kernel_ms * 1e-3
+        exec_fpp = EXEC_FLOP_PER_PAIR.get((w["interp"], reciprocal))
         rec = {
             "metric": "beamformed Mpixels/sec (1024^2 px, 256x256 Tx/Rx)" if w["name"] == "c3" else "beamformed Mpixels/sec",
             "value": round(I / (el / args.steps) / 1e6, 4), "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16" if w["prec"] == "halfT" else "f32", "data": "synthetic",
-            "config": {"workload": w["label"], "pixels": I, "pairs_per_frame": pairs, "kernel": plan.kernel,
+            "config": {"workload": w["label"], "pixels": I, "pairs_per_frame": pairs, "kernel": plan.kernel, "reciprocal_mode": reciprocal,
+                       "kernel_name": plan.kernel_name(), "jit": bool(args.jit),
                        "fallback_tiles": fallback, "tile": list(plan.tile_shape()), "wave": list(plan.wave_shape()), "aperture_split": plan.aperture_split(), "parallelism": f"pixel-slab x{world} + RCCL all_gather" if world > 1 else "1 GPU",
                        "device": info["name"], "cu": info["cu_count"]},
-            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                         "traffic": traffic, "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes": int(alg_bytes),
+            "roofline": {"bound": "hbm", "achieved": round(alg_bytes / ksec / 1e9, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(alg_bytes / ksec / 1e9 / HBM_PEAK_GBS, 6),
+                         "traffic": traffic, "traffic_source": tsrc, "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes": int(alg_bytes),
                          "note": "compulsory-traffic accounting: this path is FP32-VALU / LDS-gather bound "
                                  "(~2.5e3 flop/byte), see also valu_frac",
-                         "gpairs_per_s": round(pairs / world / (kernel_ms * 1e-3) / 1e9, 3),
-                         "valu_tflops_model": round(pairs / world * FLOP_PER_PAIR.get(w["interp"], 42) / (kernel_ms * 1e-3) / 1e12, 3),
-                         "valu_frac": round(pairs / world * FLOP_PER_PAIR.get(w["interp"], 42) / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4)},
+                         "gpairs_per_s": round(pairs / world / ksec / 1e9, 3),
+                         "valu_tflops_model": round(pairs / world * FLOP_PER_PAIR.get(w["interp"], 42) / ksec / 1e12, 3),
+                         "valu_frac": round(pairs / world * FLOP_PER_PAIR.get(w["interp"], 42) / ksec / 1e12 / FP32_PEAK_TFLOPS, 4),
+                         "valu_flop_per_pair_executed": exec_fpp,
+                         "valu_frac_executed": None if exec_fpp is None or plan.kernel != "tiled" else
+                                               round(pairs / world * exec_fpp / ksec / 1e12 / FP32_PEAK_TFLOPS, 4)},
         }
+        if general_ms is not None:
+            rec["general_ms_per_step"] = round(general_ms, 3)
+            rec["general_value"] = round(I / (general_ms * 1e-3) / 1e6, 4)
+        if multi:
+            rec["multi_gpu"] = multi
         if world == 1 and not args.no_cpu:
             try:
                 xh = torch.view_as_real(xc).cpu().numpy().view(np.complex64).reshape(M, N, T).transpose(2, 1, 0)
-                rec["cpu_baseline"] = cpu_baseline(w, xh)
+                cb = cpu_baseline(w, xh)
+                rec["cpu_baseline"] = cb[0]
+                if len(cb) > 1:
+                    rec["cpu_baseline_tuned"] = cb[1]
             except Exception as ex:  # report, never hide
                 rec["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"FAILED: {ex!r}"}

@@ -73,6 +73,15 @@ extern "C" {
 #define QDAS_RXAPOD_FNUMBER_PLANAR   3
 #define QDAS_RXAPOD_FNUMBER_ORIENTED 4
 
+/* ---- plan flags (qdas_desc.plan_flags) */
+#define QDAS_PLAN_NO_RECIPROCAL 1 /* never use the reciprocal mode of the tiled kernel (transmit elements == receive elements):
+                                     the general kernel that every apodized / non-FSA acquisition runs                        */
+#define QDAS_PLAN_JIT           2 /* compile the tiled kernel for THIS plan's sizes with hiprtc: N, M, T, strides, delay kinds,
+                                     tile shape and modes become constants, the reference's const-compile specialisation
+                                     (src/UltrasoundSystem.m:5626-5748 getDASConstCudaDef, src/sizes.cu:17-52).  Cached on disk
+                                     (QDAS_CACHE_DIR, default ~/.cache/qdas); falls back to the prebuilt kernel with a message
+                                     in qdas_last_error() if hiprtc is unavailable                                            */
+
 /* ---- error codes */
 #define QDAS_OK            0
 #define QDAS_EINVAL        1 /* bad argument / inconsistent sizes (message says which)  */
@@ -123,7 +132,7 @@ typedef struct qdas_desc {
        materialised I1 x I2 x I3 x N array; multiplies the apodization arrays.  rx_normals: 3 x N element
        normals, real(prec) like Pr (float for QDAS_F16); same memory kind as Pr.                            */
     int32_t  rx_apod_kind;   /* QDAS_RXAPOD_*                                                             */
-    int32_t  reserved0;
+    int32_t  plan_flags;     /* QDAS_PLAN_* bits (0 = defaults)                                           */
     double   rx_apod_p[2];   /* parameters, see QDAS_RXAPOD_*                                             */
     const void *rx_normals;  /* may be NULL for QDAS_RXAPOD_NONE / QDAS_RXAPOD_FNUMBER_PLANAR             */
 } qdas_desc;
@@ -158,6 +167,11 @@ int  qdas_plan_tile_shape(const qdas_plan *plan, int *tile_z, int *tile_cols, in
 /* 1 when a QDAS_KERNEL_TILED plan runs in reciprocal mode (transmit elements == receive elements, one t0: every unordered
  * transmit/receive pair is indexed and weighted once), else 0 */
 int  qdas_plan_reciprocal(const qdas_plan *plan);
+/* human-readable name of the kernel a plan launches for one frame, e.g.
+ *   "das_tile_kernel<interp=3,f32,sym,mb=16,W=128> [prebuilt]"   |   "... [jit 5f0c...]"  (QDAS_PLAN_JIT, hiprtc build)   |
+ *   "das_generic_kernel<interp=2,f64>"
+ * Written NUL-terminated into buf (truncated to len). */
+int  qdas_plan_kernel_name(const qdas_plan *plan, char *buf, size_t len);
 /* time of the last execute()'s kernels in ms measured with hipEvents on its stream
  * (enabled by qdas_plan_set_timing(plan, 1); synchronises the stream) */
 int  qdas_plan_set_timing(qdas_plan *plan, int enable);

@@ -31,8 +31,44 @@ def build(force: bool = False) -> str:
     return so
 
 
-def lib():
-    global _LIB
+def _host_tag() -> str:
+    """identifies the host's instruction set: the tuned build is -march=native and must never run on another CPU model"""
+    import hashlib
+    try:
+        txt = open("/proc/cpuinfo").read()
+        flags = next((l for l in txt.splitlines() if l.startswith("flags")), "")
+        model = next((l for l in txt.splitlines() if l.startswith("model name")), "")
+    except OSError:
+        flags = model = ""
+    return hashlib.sha1((model + flags).encode()).hexdigest()[:12]
+
+
+def build_tuned() -> str:
+    """``das_ref_tuned.c`` compiled FOR THIS HOST (gcc -O3 -march=native -fopenmp, no -ffast-math) at first use; cached per CPU
+    model under ``oracle/_tuned/`` (git- and gpurun-ignored: a build made elsewhere may use instructions this host lacks)."""
+    d = os.path.join(_HERE, "_tuned")
+    so = os.path.join(d, f"libdas_ref_tuned.{_host_tag()}.so")
+    src = os.path.join(_HERE, "das_ref_tuned.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        os.makedirs(d, exist_ok=True)
+        tmp = so + f".{os.getpid()}.tmp"
+        subprocess.check_call([os.environ.get("CC", "gcc"), "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-Wall",
+                               "-Wno-unknown-pragmas", "-o", tmp, src, "-lm"])
+        os.replace(tmp, so)
+    return so
+
+
+_LIB_TUNED = None
+
+
+def lib(tuned: bool = False):
+    global _LIB, _LIB_TUNED
+    if tuned:
+        if _LIB_TUNED is None:
+            _LIB_TUNED = C.CDLL(build_tuned())
+            _LIB_TUNED.das_ref_tuned_f32.restype = C.c_int
+            _LIB_TUNED.das_ref_max_threads.restype = C.c_int
+        return _LIB_TUNED
     if _LIB is None:
         _LIB = C.CDLL(build())
         for name in ("das_ref_f32", "das_ref_f64"):
@@ -63,7 +99,7 @@ def _pad5(a):
 
 
 def das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs, c=1540.0, *, VS=True, DV=False, interp="linear",
-             apod=(), fmod=0.0, tpose=False, prec="single", nthreads=0, timing=False):
+             apod=(), fmod=0.0, tpose=False, prec="single", nthreads=0, timing=False, tuned=False):
     """Same signature/result as :func:`oracle.das_oracle.das_spec` (single frame,
     device ``fmod`` semantics), computed by the C oracle in ``prec``."""
     rt = np.float32 if prec == "single" else np.float64
@@ -101,10 +137,21 @@ def das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs, c=1540.0, *, VS=True, DV=False, int
     fn = lib().das_ref_f32 if prec == "single" else lib().das_ref_f64
     import time
     global LAST_SECONDS
-    t_start = time.perf_counter()
-    rc = fn(C.byref(sz), y.ctypes.data_as(C.c_void_p), *[b.ctypes.data_as(C.c_void_p) for b in bufs],
-            C.c_int(nthreads))
-    LAST_SECONDS = time.perf_counter() - t_start
+    rc = 3
+    if tuned:                                       # host-tuned build of the same loop nest (das_ref_tuned.c); rc 3 = outside its subset
+        if prec != "single":
+            raise ValueError("the tuned baseline is fp32 only")
+        t_start = time.perf_counter()
+        rc = lib(True).das_ref_tuned_f32(C.byref(sz), y.ctypes.data_as(C.c_void_p), *[b.ctypes.data_as(C.c_void_p) for b in bufs],
+                                         C.c_int(nthreads))
+        LAST_SECONDS = time.perf_counter() - t_start
+        if rc == 3:
+            raise ValueError("das_ref_tuned covers 'DAS', fp32, scalar sound speed, no apodization, fmod = 0 only")
+    else:
+        t_start = time.perf_counter()
+        rc = fn(C.byref(sz), y.ctypes.data_as(C.c_void_p), *[b.ctypes.data_as(C.c_void_p) for b in bufs],
+                C.c_int(nthreads))
+        LAST_SECONDS = time.perf_counter() - t_start
     if rc:
         raise RuntimeError(f"das_ref failed rc={rc}")
     if keep_rx and keep_tx and tpose:   # 'BF' keeps the data's aperture order: I x M x N (src/bf.cu:100,135)

@@ -23,12 +23,13 @@ MAX_APOD = 6
 QDAS_PRE_F32, QDAS_PRE_I16 = 0, 1
 QDAS_CONV_FULL, QDAS_CONV_SAME, QDAS_CONV_VALID = 0, 1, 2
 QDAS_CONV_X_ONE_COLUMN, QDAS_CONV_X_ONE_SLICE, QDAS_CONV_Y_ONE_COLUMN, QDAS_CONV_Y_ONE_SLICE = 1, 2, 4, 8
+PLAN_NO_RECIPROCAL, PLAN_JIT = 1, 2
 RXAPOD_NONE, RXAPOD_ACCEPTANCE, RXAPOD_COSINE, RXAPOD_FNUMBER_PLANAR, RXAPOD_FNUMBER_ORIENTED = 0, 1, 2, 3, 4
 
 # every symbol include/qdas.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "qdas_plan_create", "qdas_plan_execute", "qdas_plan_execute_frames", "qdas_plan_delays",
-    "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_reciprocal", "qdas_plan_set_timing",
+    "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_reciprocal", "qdas_plan_kernel_name", "qdas_plan_set_timing",
     "qdas_plan_last_kernel_ms", "qdas_DAS", "qdas_DASf", "qdas_DASh", "qdas_delays", "qdas_delaysf",
     "qdas_das_lut", "qdas_greens", "qdas_convd", "qdas_convd_len", "qdas_permute3", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_last_error", "qdas_version", "qdas_device_info",
 )
@@ -46,7 +47,7 @@ class Desc(C.Structure):
                 ("apod", C.c_void_p), ("cinv", C.c_void_p), ("acstride", C.POINTER(C.c_uint64)),
                 ("mem", C.c_int32), ("apod_real", C.c_int32), ("kernel", C.c_int32), ("device", C.c_int32),
                 ("i_begin", C.c_uint64), ("i_count", C.c_uint64), ("y_ld", C.c_uint64),
-                ("rx_apod_kind", C.c_int32), ("reserved0", C.c_int32), ("rx_apod_p", C.c_double * 2),
+                ("rx_apod_kind", C.c_int32), ("plan_flags", C.c_int32), ("rx_apod_p", C.c_double * 2),
                 ("rx_normals", C.c_void_p)]
 
 
@@ -113,6 +114,7 @@ def lib():
     L.qdas_plan_fallback_tiles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.qdas_plan_tile_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.qdas_plan_reciprocal.argtypes = [C.c_void_p]
+    L.qdas_plan_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.qdas_plan_set_timing.argtypes = [C.c_void_p, C.c_int]
     L.qdas_plan_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.qdas_das_lut.argtypes = [C.POINTER(LutDesc), C.c_void_p, C.c_void_p, C.c_void_p]

@@ -71,6 +71,7 @@ struct qdas_plan {
     bool fb2_ok = false;                      // frames of a sequence may share launches, 4 or 2 at a time (decided at plan creation)
     bool fb4_off = false;                     // ... but at most pairwise (QDAS_NO_FB4)
     uint32_t *fallback = nullptr;             // device: [0] = count, [1..ntiles]
+    std::string jit_tag;                      // "jit <hash>" when the plan runs a hiprtc-specialised kernel (QDAS_PLAN_JIT)
     bool timing = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     float last_ms = 0.f;
@@ -353,7 +354,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // reciprocal mode (das_tile_impl.h "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
     // elements and share one t0 has tau(n,m) == tau(m,n); detected from the geometry itself, bit-exactly.
     int sym = 0, big = 0;
-    if (eligible && !syn && (dt == QDAS_F32 || dt == QDAS_F16) && z.VS && z.DV && z.N == z.M && z.S == 0 && !g.gen_kind && !getenv("QDAS_NO_SYM")) {
+    if (eligible && !syn && (dt == QDAS_F32 || dt == QDAS_F16) && z.VS && z.DV && z.N == z.M && z.S == 0 && !g.gen_kind && !(desc->plan_flags & QDAS_PLAN_NO_RECIPROCAL) && !getenv("QDAS_NO_SYM")) {
         std::vector<float> hr(3 * z.N), hv(4 * z.M);
         if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
         if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);
@@ -513,7 +514,9 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     }
 
     pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
-    pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr;
+    // four frames per launch: not for fp32 plans with remodulation, a weight table or a pixel x receiver weight (das_tile_impl.h launch_tile_i)
+    pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr
+                  || (dt == QDAS_F32 && pl->kernel == QDAS_KERNEL_TILED && (pl->tp.fmod != 0.0 || pl->tp.wtab || pl->tp.apix || pl->tp.gen_kind));
     if (desc->mem == QDAS_MEM_HOST) {                   // staging buffers for x / y
         pl->x_bytes = (size_t)z.T * z.N * z.M * data_size(dt);
         pl->y_bytes = (size_t)pl->y_ld * pl->oN * pl->oM * data_size(dt);
@@ -553,6 +556,18 @@ extern "C" int qdas_plan_tile_shape(const qdas_plan *pl, int *tile_z, int *tile_
 }
 
 extern "C" int qdas_plan_reciprocal(const qdas_plan *pl) { return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.sym ? 1 : 0; }
+
+extern "C" int qdas_plan_kernel_name(const qdas_plan *pl, char *buf, size_t len) {
+    if (!pl || !buf || !len) return fail(QDAS_EINVAL, "null argument");
+    const qdas_sizes &z = pl->d.sz;
+    const char *dts = z.dtype == QDAS_F64 ? "f64" : (z.dtype == QDAS_F32 ? "f32" : "f16");
+    if (pl->kernel == QDAS_KERNEL_TILED) {
+        const TileParams &t = pl->tp;
+        snprintf(buf, len, "das_tile_kernel<interp=%d,%s%s%s%s%s,mb=%d,W=%d> [%s]", z.flag & 7, dts, t.sym ? ",sym" : "", t.fmod != 0.0 ? ",fmod" : "",
+                 t.wtab ? ",wtab" : "", t.big ? ",big" : "", pl->tc.mb, pl->tc.window, pl->jit_tag.empty() ? "prebuilt" : pl->jit_tag.c_str());
+    } else snprintf(buf, len, "das_generic_kernel<interp=%d,%s>", z.flag & 7, dts);
+    return QDAS_OK;
+}
 
 extern "C" int qdas_plan_set_timing(qdas_plan *pl, int enable) {
     if (!pl) return fail(QDAS_EINVAL, "null plan");
@@ -804,12 +819,13 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     if (keep_tx) { std::swap(strN, strM); std::swap(kN, kM); std::swap(tab_s, tab_b); }
     const TileConfig tc = tile_config(dt, 0);
     if ((kN * strN + (uint64_t)tc.mb * strM) * data_size(dt) + 65536 >= (1ull << 31)) return 1;
-    static uint32_t *counter[64] = {nullptr};                         // per device, kept for the life of the process
-    static std::mutex lut_mutex;                                      // the misfit counter is shared: one probing call at a time
-    std::lock_guard<std::mutex> lock(lut_mutex);
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
-    if (!counter[dev] && hipMalloc(&counter[dev], 64) != hipSuccess) return 1;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    // misfit counter of THIS call, allocated and released in stream order on the caller's stream: concurrent calls (other host
+    // threads, other streams of the device) never share it, so no probe result can be cleared or read by another call
+    uint32_t *counter = nullptr;
+    if (hipMallocAsync((void **)&counter, 64, s) != hipSuccess || !counter) return 1;
+    struct CounterGuard { uint32_t *p; hipStream_t s; ~CounterGuard() { (void)hipFreeAsync(p, s); } } guard{counter, s};
     const bool shaped = d->I1 && d->I1 < d->I && d->I % d->I1 == 0;    // (a per-pixel array needs the true image shape: no ragged rows)
     if (w_pix && !shaped && d->I1 != d->I) return 1;
     TileParams t{};
@@ -825,7 +841,7 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     t.flag = d->flag & (7 | QDAS_FLAG_TPOSE);
     t.nfr = 1; t.ksplit = 1;
     t.lut_tx = (const float *)tab_b; t.lut_rx = (const float *)tab_s;
-    t.fallback_list = counter[dev]; t.fallback_cap = 0;
+    t.fallback_list = counter; t.fallback_cap = 0;
     // footprint: the deepest tile (of 64, 32, 16, 8 pixels of I1) whose delay spreads all fit the window; the tables are data
     // of this call, so the fit is probed per call (prologue-only launches)
     int best = -1;
@@ -838,10 +854,10 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
         t.tiles_x = (uint32_t)((t.I2 + cols - 1) / cols);
         ntiles = t.tiles_z * t.tiles_x;
         t.probe = 1;
-        if (hipMemsetAsync(counter[dev], 0, sizeof(uint32_t), s) != hipSuccess) return 0;
+        if (hipMemsetAsync(counter, 0, sizeof(uint32_t), s) != hipSuccess) return 0;
         if (launch_tile(t, dt, ntiles, s) != hipSuccess) return 0;
         uint32_t cnt = 1;
-        if (hipMemcpyAsync(&cnt, counter[dev], sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 0;
+        if (hipMemcpyAsync(&cnt, counter, sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 0;
         if (cnt == 0) best = l;
     }
     if (best < 0) return 1;
@@ -858,10 +874,10 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     }
     t.ksplit = ks; t.part = (float2 *)part;
     if (keep && hipMemsetAsync(y, 0, d->I * kN * sizeof(float2), s) != hipSuccess) return 0;   // planes are accumulated with atomics
-    if (hipMemsetAsync(counter[dev], 0, sizeof(uint32_t), s) != hipSuccess) return 0;
+    if (hipMemsetAsync(counter, 0, sizeof(uint32_t), s) != hipSuccess) return 0;
     const hipError_t e = launch_tile(t, dt, ntiles, s);
     if (part) (void)hipFreeAsync(part, s);
-    return e == hipSuccess ? -1 : 0;
+    return e == hipSuccess ? -1 : 0;     // (the probe of this footprint found no misfit on these very tables: every tile is written)
 }
 
 extern "C" int qdas_das_lut(const qdas_lut_desc *d, const void *x, void *y, void *stream) {

@@ -5,9 +5,7 @@
 // with the edge rule of SURVEY.md section 8 a5: a sample is in support iff all taps lie in
 // [0, T) and tau >= 0; everything else is exactly 0.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <hip/hip_fp16.h>
-#include <stdint.h>
+#include "tile_rtc.h"
 
 namespace qdas {
 

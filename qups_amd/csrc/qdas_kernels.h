@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "tile_params.h"
 
 #define QDAS_MAX_APOD 6
 
@@ -32,47 +33,7 @@ struct GenericParams {
 hipError_t launch_generic(const GenericParams &P, int dtype, unsigned grid, hipStream_t s);
 hipError_t launch_delays(const GenericParams &P, int dtype, void *tau, double cinv, hipStream_t s);
 
-// ---- tiled kernel (das_tile_impl.h)
-struct TileParams {
-    // fp32 geometry (QDAS_F32 / QDAS_F16 only).  Pv (4 x M: position, t0) and Nv (3 x M) describe the BLOCK elements of a stage,
-    // Pr (3 x N) and -- when kindS != 0 -- St (4 x N: t0, normal) the STAGE elements; kindB / kindS: 0 distance, 1 signed distance,
-    // 2 plane wave.  'DAS' / 'SYN': block = transmits, stage = receivers; 'MUL': roles (and N, M, strN, strM, wtab) swapped by the host.
-    const float *Pi, *Pr, *Pv, *Nv, *St;
-    int32_t kindB, kindS;
-    const void *x;
-    void *y;
-    const void *wtab;                   // optional N x M table of folded apodization weights (float2), may be null
-    const void *apix;                   // optional I x N apodization (data precision; real if apix_real), may be null
-    int32_t apix_real;
-    int32_t gen_kind;                   // generated pixel x receiver apodization (QDAS_RXAPOD_*), exclusive with apix
-    double gen_p0, gen_p1;
-    const float *rxn;                   // 3 x N element normals (device)
-    uint64_t T, N, M, I1, I2, I3;
-    uint64_t i_begin, i_count;
-    uint64_t strN, strM;                // trace strides of x in samples: (T, T*N) or (T*M, T) when transposed
-    double cinv_fs;                     // cinv * fs (scalar sound speed; first pixel's value when cinv_pix is set)
-    const float *cinv_pix;              // optional per-pixel 1/c (I1 x I2 x I3, contiguous): sound-speed map; the delay stays separable
-    double fs, fmod;
-    int32_t flag, VS, DV;
-    int32_t narrow;                     // reciprocal mode: the 128-sample-window configuration (chosen by the plan when every tile fits)
-    int32_t big;                        // general mode, fp32: re-base the DMA descriptors along the receiver walk (transposed frames > 2 GiB)
-    int32_t sym;                        // reciprocal mode: Pv == Pr, one t0 (checked by the host) -> tau(n,m) == tau(m,n)
-    int32_t tz_log2;                    // tile footprint: (1 << tz_log2) pixels of I1 x (waves * 64 >> tz_log2) columns; 3..6
-    int32_t wz_log2;                    // wave footprint inside the tile: (1 << wz_log2) pixels of I1 x (64 >> wz_log2) columns; <= tz_log2
-    int32_t probe;                      // 1: stop after the window-fit test (plan-time shape selection; only fallback_list is written)
-    uint32_t tiles_z, tiles_x, tile_x0; // tile grid over (I1 >> tz_log2) x (columns / tile columns); first column tile of the shard
-    int32_t syn;                        // 1: 'SYN' -- keep the receive dimension: y is I x N planes (leading dimension y_ld), zero-filled by the host
-    uint64_t y_ld;
-    int32_t nfr;                        // frames per launch: 1, or 2 / 4 (frame f at x + f*x_fstride -> y + f*y_fstride); 1 with sym
-    uint64_t x_fstride, y_fstride;      // frame strides: BYTES of x, ELEMENTS of y
-    uint32_t ksplit;                    // workgroups per tile (>= 1): each sums a slice of the aperture into part[], then reduced into y
-    float2 *part;                       // [ksplit][nfr][i_count] partial images (ksplit > 1 only)
-    uint32_t *fallback_list;            // [0] = count, [1..] = tile ids that did not fit the LDS window
-    uint32_t fallback_cap;
-    // table-driven delays (launch configuration 10, qdas_das_lut): tau_tx (I x M) and tau_rx (I x N) in samples, fp32
-    const float *lut_tx, *lut_rx;
-};
-
+// ---- tiled kernel (das_tile_impl.h); parameter block in tile_params.h
 struct TileConfig { int waves; int mb; int window; size_t lds_bytes; int threads; };
 TileConfig tile_config(int dtype, int sym, int narrow = 0);
 size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow = 0);   // dynamic LDS of one workgroup

@@ -1,0 +1,223 @@
+// tile_pairs.h -- the pair loops of the tiled kernel (internal; included by das_tile_impl.h): for one stage (receiver n, block of
+// MB transmits), every lane forms its pixel's MB interpolated samples and adds them to its accumulators.
+//
+// Transmits (m0+2p, m0+2p+1) ride in the two halves of packed fp32.  Per packed pair:
+//     t  = ra[p] + rb                    = tau*fs + OFF - (A+B) - 1/2
+//     tm = t + MAGIC;  s = t - (tm - MAGIC)  in [-1/2, 1/2];   LDS byte address of the first tap = bits(tm)*SB + cbase + immediate
+//     weights2<INTERP>(s)  (scheduled between the issue of the LDS reads and their wait: that hides the LDS latency)
+//     acc += w[k] * tap[k]
+// Accumulators: one per (frame, transmit half) with up to two frames per launch, one per frame with four.
+#pragma once
+
+namespace qdas {
+
+// Plain loop.  TAILV = false: full block (reciprocal mode: block entirely above the diagonal), no bounds tests on m.
+// TAILV = true: last, partial transmit block (bounds checks) or -- reciprocal mode -- the block that contains m == n.
+// CHECK: the tile touches the ends of the record: edge rule per sample (all taps in [0,T) and tau >= 0; select, not multiply).
+template <class C> template <bool CHECK, bool TAILV>
+__device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, int bn, float rb, uint32_t cbase, float phB) {
+    constexpr int K = C::K, MB = C::MB, WB = C::WB, INTERP = C::INTERP, NHP = C::NHP;
+    constexpr bool SYM = C::SYM, FB4 = C::FB4, FBX = C::FBX, TWO = C::TWO, F32 = C::F32, FMOD = C::FMOD, WTAB = C::WTAB;
+    constexpr bool TAIL = !SYM && TAILV, DIAG = SYM && TAILV;
+    unroll<MB / 2>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        const uint32_t m = m0 + 2 * p;
+        if constexpr (TAIL) { if (m >= M) return; }
+        if constexpr (DIAG) { if (m + 1 < n) return; }          // both transmits below the diagonal: their pairs were done as mirrors
+        const bool upper = !TAIL || (m + 1 < M);  // the upper half carries a real transmit
+        float wr0 = 1.f, wi0 = 0.f, wr1 = 1.f, wi1 = 0.f;
+        if constexpr (WTAB) {
+            const float2 wa = ((const float2 *)P.wtab)[n + (size_t)N * m];
+            const float2 wb_ = upper ? ((const float2 *)P.wtab)[n + (size_t)N * (m + 1)] : make_float2(0.f, 0.f);
+            wr0 = wa.x; wi0 = wa.y; wr1 = wb_.x; wi1 = wb_.y;
+            if (wr0 == 0.f && wi0 == 0.f && wr1 == 0.f && wi1 == 0.f) return;   // zero weights: skip (src/bf.cu:122,126)
+        }
+        const v2f t = ra[p] + rb;
+        const v2f tm = t + MAGIC;
+        const v2f s = t - (tm - MAGIC);
+        const uint32_t ad0 = (hooks::linear_taps ? (MAGIC_BITS + (uint32_t)lane + (__float_as_uint(tm.x) & 1u)) : __float_as_uint(tm.x)) * (uint32_t)C::SB + cbase;
+        const uint32_t ad1 = (hooks::linear_taps ? (MAGIC_BITS + (uint32_t)lane + (__float_as_uint(tm.y) & 1u)) : __float_as_uint(tm.y)) * (uint32_t)C::SB + cbase;
+        constexpr bool SPLIT = CHECK || FMOD || WTAB;       // the two halves need separate post-processing
+        v2f w[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+        // one pass per FRAME PAIR (two passes when four frames share the launch): same tap index and weights
+        unroll<NHP>([&](auto hpc) {
+            constexpr int hp = decltype(hpc)::value;
+            constexpr int GSET = FB4 ? 2 * hp : 0, HSET = FB4 ? 2 * hp + 1 : 1;       // window sets of the pass
+            v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : &acc1);
+            v2f &B0 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc3);
+            v2f v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
+            v2f u0 = {0.f, 0.f}, u1 = {0.f, 0.f};     // the same two pairs of the second frame (FB2)
+            if constexpr (F32) {
+                taps_f32 g0, g1, h0, h1;              // direct taps x[:, n, m | m+1]; mirror taps x[:, m | m+1, n]
+                if constexpr (hooks::no_tap_reads) { for (int k = 0; k < 4; ++k) { g0.s[k] = h0.s[k] = (v2f){s.x, t.x}; g1.s[k] = h1.s[k] = (v2f){t.y, s.y}; } }
+                else {
+                    lds_issue<K, (GSET * MB + 2 * p) * WB>(g0, ad0); lds_issue<K, (GSET * MB + 2 * p + 1) * WB>(g1, ad1);
+                    if constexpr (TWO) { lds_issue<K, (HSET * MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (HSET * MB + 2 * p + 1) * WB>(h1, ad1); }
+                    if constexpr (K < 4) { g0.s[2] = g0.s[3] = g1.s[2] = g1.s[3] = h0.s[2] = h0.s[3] = h1.s[2] = h1.s[3] = (v2f){0.f, 0.f}; }
+                    if constexpr (K < 2) { g0.s[1] = g1.s[1] = h0.s[1] = h1.s[1] = (v2f){0.f, 0.f}; }
+                }
+                if constexpr (hp == 0) {              // (the next frame pair reuses them)
+                    if constexpr (hooks::trivial_weights) { w[0] = s; w[1] = t; w[2] = tm; w[3] = s + t; }
+                    else if constexpr (K > 1) weights2<INTERP>(s, w);   // overlaps the LDS latency
+                }
+                if constexpr (TWO) lds_fence2(g0, g1, h0, h1, w); else lds_fence(g0, g1, w);
+                if constexpr (DIAG) {                 // uniform, only in the block that holds the diagonal
+                    const v2f z = {0.f, 0.f};
+                    if (m < n)      { for (int k = 0; k < 4; ++k) g0.s[k] = z; }     // pair (n, m<n): done as the mirror of (m, n)
+                    if (m <= n)     { for (int k = 0; k < 4; ++k) h0.s[k] = z; }     // m == n: the trace is its own mirror
+                    if (m + 1 <= n) { for (int k = 0; k < 4; ++k) h1.s[k] = z; }
+                }
+                if constexpr (TAIL) {
+                    if (!upper) {                       // odd M: no transmit in the upper half (uniform, rare)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { g1.s[k] = (v2f){0.f, 0.f}; if constexpr (FBX) h1.s[k] = (v2f){0.f, 0.f}; }
+                    }
+                }
+                if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; if constexpr (FBX) { u0 = h0.s[0]; u1 = h1.s[0]; } }
+                else if constexpr (SPLIT) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { v0 = w[k].x * g0.s[k] + v0; v1 = w[k].y * g1.s[k] + v1; }
+                    if constexpr (SYM) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { v0 = w[k].x * h0.s[k] + v0; v1 = w[k].y * h1.s[k] + v1; }
+                    }
+                    if constexpr (FBX) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { u0 = w[k].x * h0.s[k] + u0; u1 = w[k].y * h1.s[k] + u1; }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { A0 = w[k].x * g0.s[k] + A0; A1 = w[k].y * g1.s[k] + A1; }
+                    if constexpr (TWO) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { B0 = w[k].x * h0.s[k] + B0; B1 = w[k].y * h1.s[k] + B1; }
+                    }
+                }
+                if constexpr (SYM && K == 1) { v0 += h0.s[0]; v1 += h1.s[0]; }
+            } else {
+                taps_f16 g0, g1, h0, h1;
+                lds_issue<K, (GSET * MB + 2 * p) * WB>(g0, ad0); lds_issue<K, (GSET * MB + 2 * p + 1) * WB>(g1, ad1);
+                if constexpr (TWO) { lds_issue<K, (HSET * MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (HSET * MB + 2 * p + 1) * WB>(h1, ad1); }
+                if constexpr (K < 4) { g0.r[2] = g0.r[3] = g1.r[2] = g1.r[3] = h0.r[2] = h0.r[3] = h1.r[2] = h1.r[3] = 0u; }
+                if constexpr (K < 2) { g0.r[1] = g1.r[1] = h0.r[1] = h1.r[1] = 0u; }
+                if constexpr (hp == 0 && K > 1) weights2<INTERP>(s, w);  // overlaps the LDS latency
+                if constexpr (TWO) lds_fence2(g0, g1, h0, h1, w); else lds_fence(g0, g1, w);
+                if constexpr (DIAG) {                 // (as for fp32 data above)
+                    if (m < n)      { for (int k = 0; k < 4; ++k) g0.r[k] = 0u; }
+                    if (m <= n)     { for (int k = 0; k < 4; ++k) h0.r[k] = 0u; }
+                    if (m + 1 <= n) { for (int k = 0; k < 4; ++k) h1.r[k] = 0u; }
+                }
+                if constexpr (TAIL) {
+                    if (!upper) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { g1.r[k] = 0u; if constexpr (FBX) h1.r[k] = 0u; }
+                    }
+                }
+                if constexpr (K == 1) {
+                    v0 = half2_to_v2f(g0.r[0]); v1 = half2_to_v2f(g1.r[0]);
+                    if constexpr (FBX) { u0 = half2_to_v2f(h0.r[0]); u1 = half2_to_v2f(h1.r[0]); }
+                    if constexpr (SYM) { v0 += half2_to_v2f(h0.r[0]); v1 += half2_to_v2f(h1.r[0]); }
+                } else if constexpr (SPLIT) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { mix_mac(v0, g0.r[k], w[k].x); mix_mac(v1, g1.r[k], w[k].y); }
+                    if constexpr (SYM) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { mix_mac(v0, h0.r[k], w[k].x); mix_mac(v1, h1.r[k], w[k].y); }
+                    }
+                    if constexpr (FBX) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { mix_mac(u0, h0.r[k], w[k].x); mix_mac(u1, h1.r[k], w[k].y); }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) { mix_mac(A0, g0.r[k], w[k].x); mix_mac(A1, g1.r[k], w[k].y); }
+                    if constexpr (TWO) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) { mix_mac(B0, h0.r[k], w[k].x); mix_mac(B1, h1.r[k], w[k].y); }
+                    }
+                }
+            }
+            if constexpr (CHECK) {                    // edge rule: all taps in [0,T) and tau >= 0
+                const uint32_t mb = upper ? m + 1 : m;
+                const int ws0 = Abase[m] + bn, ws1 = Abase[mb] + bn;
+                const float lo0 = tapinfo<INTERP>::LO - 0.5f - (float)ws0, hi0 = (float)(T - K + 1 - ws0) - 0.5f;
+                const float lo1 = tapinfo<INTERP>::LO - 0.5f - (float)ws1, hi1 = (float)(T - K + 1 - ws1) - 0.5f;
+                const bool k0 = (t.x >= lo0) && (t.x < hi0), k1 = (t.y >= lo1) && (t.y < hi1) && upper;
+                v0 = k0 ? v0 : (v2f){0.f, 0.f}; v1 = k1 ? v1 : (v2f){0.f, 0.f};
+                if constexpr (FBX) { u0 = k0 ? u0 : (v2f){0.f, 0.f}; u1 = k1 ? u1 : (v2f){0.f, 0.f}; }
+            }
+            if constexpr (FMOD) {                     // reference src/bf.cu:117: w = exp(2j pi fmod tau), tau*fs = t + 1/2 + (A[m] + B[n]) - OFF
+                // phase in cycles = t*f + frac((A[m] + 1/2 - OFF)*f) + frac(B[n]*f), f = fmod/fs: the two constants were tabulated in
+                // fp64 by the prologue (Aext / Bext are free by now); v_sin / v_cos take revolutions and reduce the argument themselves
+                const uint32_t mb = upper ? m + 1 : m;
+                const float f = (float)(P.fmod / fs);
+                const v2f ph = t * f + ((v2f){Aext[m], Aext[mb]} + phB);
+                const float c0 = __builtin_amdgcn_cosf(ph.x), s0 = __builtin_amdgcn_sinf(ph.x);
+                const float c1 = __builtin_amdgcn_cosf(ph.y), s1 = __builtin_amdgcn_sinf(ph.y);
+                v0 = (v2f){v0.x * c0 - v0.y * s0, v0.x * s0 + v0.y * c0};
+                v1 = (v2f){v1.x * c1 - v1.y * s1, v1.x * s1 + v1.y * c1};
+                if constexpr (FBX) {
+                    u0 = (v2f){u0.x * c0 - u0.y * s0, u0.x * s0 + u0.y * c0};
+                    u1 = (v2f){u1.x * c1 - u1.y * s1, u1.x * s1 + u1.y * c1};
+                }
+            }
+            if constexpr (WTAB) {
+                A0 += (v2f){wr0 * v0.x - wi0 * v0.y, wr0 * v0.y + wi0 * v0.x};
+                A0 += (v2f){wr1 * v1.x - wi1 * v1.y, wr1 * v1.y + wi1 * v1.x};
+                if constexpr (FBX) {
+                    B0 += (v2f){wr0 * u0.x - wi0 * u0.y, wr0 * u0.y + wi0 * u0.x};
+                    B0 += (v2f){wr1 * u1.x - wi1 * u1.y, wr1 * u1.y + wi1 * u1.x};
+                }
+            } else if constexpr (SPLIT || K == 1) { A0 += v0; A0 += v1; if constexpr (FBX) { B0 += u0; B0 += u1; } }
+        });
+    });
+}
+
+// Software-pipelined loop (two window sets, 4 taps, full interior block, no per-sample post-processing): the first-set taps of
+// iteration p+1 are requested before the MACs of iteration p, so the LDS pipe always has work queued and the counted wait (newest
+// 8 reads stay in flight) rarely stalls.  A unit = (transmit pair p, frame pair hp); hp only with four frames per launch.
+template <class C> __device__ __forceinline__ void Tile<C>::pairs_pipelined(float rb, uint32_t cbase) {
+    constexpr int K = C::K, MB = C::MB, WB = C::WB, INTERP = C::INTERP, NHP = C::NHP;
+    constexpr bool FB4 = C::FB4, F32 = C::F32;
+    constexpr int NP = MB / 2, NU = NP * NHP;
+    using taps_t = std::conditional_t<F32, taps_f32, taps_f16>;
+    taps_t gd0[2], gd1[2];                 // first-set taps of the two halves, double-buffered over units
+    v2f sv[2];
+    uint32_t a0v[2], a1v[2];
+    v2f w[4];
+    auto index = [&](auto uc) {            // index math (first unit of a pair) + first-set reads of unit u
+        constexpr int u = decltype(uc)::value, p = u / NHP, hp = u % NHP, GSET = FB4 ? 2 * hp : 0;
+        if constexpr (hp == 0) {
+            const v2f t = ra[p] + rb;
+            const v2f tm = t + MAGIC;
+            sv[p & 1] = t - (tm - MAGIC);
+            a0v[p & 1] = __float_as_uint(tm.x) * (uint32_t)C::SB + cbase;
+            a1v[p & 1] = __float_as_uint(tm.y) * (uint32_t)C::SB + cbase;
+        }
+        if constexpr (F32 && hooks::no_tap_reads) { for (int k = 0; k < 4; ++k) { gd0[u & 1].s[k] = (v2f){sv[p & 1].x, rb}; gd1[u & 1].s[k] = (v2f){rb, sv[p & 1].y}; } }
+        else { lds_issue<K, (GSET * MB + 2 * p) * WB>(gd0[u & 1], a0v[p & 1]); lds_issue<K, (GSET * MB + 2 * p + 1) * WB>(gd1[u & 1], a1v[p & 1]); }
+    };
+    index(std::integral_constant<int, 0>{});
+    unroll<NU>([&](auto uc) {
+        constexpr int u = decltype(uc)::value, p = u / NHP, hp = u % NHP, HSET = FB4 ? 2 * hp + 1 : 1;
+        taps_t h0, h1;
+        if constexpr (F32 && hooks::no_tap_reads) { for (int k = 0; k < 4; ++k) { h0.s[k] = sv[p & 1]; h1.s[k] = (v2f){sv[p & 1].y, sv[p & 1].x}; } }
+        else { lds_issue<K, (HSET * MB + 2 * p) * WB>(h0, a0v[p & 1]); lds_issue<K, (HSET * MB + 2 * p + 1) * WB>(h1, a1v[p & 1]); }
+        if constexpr (u + 1 < NU) index(std::integral_constant<int, u + 1>{});
+        if constexpr (hp == 0) {
+            if constexpr (hooks::trivial_weights) { w[0] = sv[p & 1]; w[1] = sv[p & 1] + 1.f; w[2] = sv[p & 1] * 2.f; w[3] = 1.f - sv[p & 1]; }
+            else weights2<INTERP>(sv[p & 1], w);
+        }
+        if constexpr (u + 1 < NU) lds_fence2_keep<8>(gd0[u & 1], gd1[u & 1], h0, h1, w);
+        else                      lds_fence2_keep<0>(gd0[u & 1], gd1[u & 1], h0, h1, w);
+        v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : &acc1);
+        v2f &B0 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc3);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            tap_mac(A0, gd0[u & 1], k, w[k].x); tap_mac(A1, gd1[u & 1], k, w[k].y);
+            tap_mac(B0, h0, k, w[k].x);         tap_mac(B1, h1, k, w[k].y);
+        }
+    });
+}
+
+}  // namespace qdas

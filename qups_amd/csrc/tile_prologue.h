@@ -1,0 +1,138 @@
+// tile_prologue.h -- prologue of the tiled kernel (internal; included by das_tile_impl.h): tile-wide integer window bases A[m], B[n]
+// and extents of the separable delay tau*fs + off = a(i,m) + b(i,n), the window-fit verdict, and the LDS copies of the geometry.
+#pragma once
+
+namespace qdas {
+
+// Returns false when the workgroup is done: the tile's delay spread does not fit the LDS window (it has appended itself to the
+// fallback list; the generic kernel takes it), or PROBE (plan-time footprint selection only wants the verdict).
+template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>::prologue() {
+    constexpr int WAVES = C::WAVES, THREADS = C::THREADS, K = C::K, INTERP = C::INTERP;
+    constexpr bool SYM = C::SYM, LUT = C::LUT;
+    // the geometry tables are read from global memory here and from their LDS copies in the main loop: a vector-memory load there
+    // would sit behind the stage's LDS-DMA in the in-order vmcnt queue and expose the DMA latency every stage (measured: 15 of 64 ms)
+    const float *gPv = P.Pv, *gNv = P.Nv;
+    const uint32_t MX = M > N ? M : N;
+    const uint64_t Ilut = P.i_begin + P.i_count;
+    const bool has_st = QSPEC(HAS_ST, P.St != nullptr);
+    float a_lo = INFINITY, a_hi = -INFINITY, a_ext = 0.f;            // per-thread partials of tile-wide stats
+    // The window bases / extents only need the delays to a small fraction of a sample: fp32 estimates with an explicit error
+    // margin (DLT, below) -- a quarter of the fp64 cost.  Focused transmits keep fp64: their delay flips sign with
+    // (Pi - Pv).Nv (copysign, src/bf.cu:107) and the two precisions must agree on the sign of a dot product that may be ~0.
+    const bool pro32 = !LUT && kindB != 1 && kindS != 1;
+    const float cf32 = (float)cf, fs32 = (float)fs;
+    auto a_est = [&](uint32_t m) -> float {
+        if (!pro32) return (float)a_of(m, gPv, gNv);
+        const float rx = px - gPv[4 * m], ry = py - gPv[4 * m + 1], rz = pz - gPv[4 * m + 2];
+        const float d = kindB != 2 ? __builtin_sqrtf(rx * rx + ry * ry + rz * rz) : rx * gNv[3 * m] + ry * gNv[3 * m + 1] + rz * gNv[3 * m + 2];
+        return d * cf32 - gPv[4 * m + 3] * fs32 + (float)tapinfo<INTERP>::OFF;
+    };
+    auto b_est = [&](uint32_t n) -> float {
+        if constexpr (LUT) return P.lut_rx[ipx + Ilut * n];
+        if (kindS == 1) return (float)s_at(n, P.Pr[3 * n], P.Pr[3 * n + 1], P.Pr[3 * n + 2]);
+        const float rx = px - P.Pr[3 * n], ry = py - P.Pr[3 * n + 1], rz = pz - P.Pr[3 * n + 2];
+        if (!has_st) return __builtin_sqrtf(rx * rx + ry * ry + rz * rz) * cf32;
+        if (kindS == 0) return __builtin_sqrtf(rx * rx + ry * ry + rz * rz) * cf32 - P.St[4 * n] * fs32;
+        return (rx * P.St[4 * n + 1] + ry * P.St[4 * n + 2] + rz * P.St[4 * n + 3]) * cf32 - P.St[4 * n] * fs32;
+    };
+    // |fp32 estimate - fp64 delay| <= ~4e-7 * (|distance*cf| + |t0*fs|), and |distance*cf| <= |a| + |t0*fs| + 1: 1e-6 is generous
+    auto margin = [](float mn, float mx, float t0fs) -> float { return 1.0e-6f * (fmaxf(fabsf(mn), fabsf(mx)) + 2.0f * fabsf(t0fs) + 2.0f); };
+    // (four elements per pass: independent reduction chains overlap)
+    auto minmax4 = [&](float (&v)[4], uint32_t e0, uint32_t cnt) {
+        float lo[4], hi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lo[q] = hi[q] = (v[q] == v[q]) ? v[q] : INFINITY; }   // a NaN delay poisons the tile's extent
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lo[q] = wave_min63(lo[q]); hi[q] = wave_max63(hi[q]); }
+        if (lane == 63) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (e0 + q < cnt) { part[wave * MX + e0 + q] = lo[q]; part[(WAVES + wave) * MX + e0 + q] = hi[q]; }
+        }
+    };
+    if constexpr (!SYM) {
+        for (uint32_t m = 0; m < M; m += 4) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = a_est(m + q < M ? m + q : M - 1);
+            minmax4(v, m, M);
+        }
+        __syncthreads();
+        for (uint32_t m = tid; m < M; m += THREADS) {
+            float mn = part[m], mx = part[WAVES * MX + m];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + m]); mx = fmaxf(mx, part[(WAVES + w) * MX + m]); }
+            const float dlt = margin(mn, mx, LUT ? 0.f : P.Pv[4 * m + 3] * fs32);
+            const float fl = floorf(mn - dlt) - 1.0f;        // margin: the estimate may lie above the true minimum
+            const bool fin = fabsf(fl) < 1.0e9f;
+            const float e = fin ? ((mx + dlt) - fl) + 0.01f : INFINITY;
+            Abase[m] = fin ? (int)fl : 0;
+            Aext[m] = e;
+            a_lo = fminf(a_lo, fl); a_hi = fmaxf(a_hi, fl + e); a_ext = fmaxf(a_ext, e);
+        }
+        __syncthreads();
+    }
+    for (uint32_t n = 0; n < N; n += 4) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = b_est(n + q < N ? n + q : N - 1);
+        minmax4(v, n, N);
+    }
+    __syncthreads();
+    float b_lo = INFINITY, b_hi = -INFINITY, b_ext = 0.f;
+    for (uint32_t n = tid; n < N; n += THREADS) {
+        float mn = part[n], mx = part[WAVES * MX + n];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + n]); mx = fmaxf(mx, part[(WAVES + w) * MX + n]); }
+        float t0fs = 0.f;
+        if constexpr (SYM) t0fs = P.Pv[3] * fs32;
+        else if constexpr (!LUT) t0fs = has_st ? P.St[4 * n] * fs32 : 0.f;
+        const float dlt = margin(mn, mx, t0fs);
+        const float fl = floorf(mn - dlt) - 1.0f;
+        const bool fin = fabsf(fl) < 1.0e9f;
+        const float e = fin ? ((mx + dlt) - fl) + 0.01f : INFINITY;
+        if constexpr (LUT) nrec[n] = make_float4(__int_as_float(fin ? (int)fl : 0), 0.f, 0.f, 0.f);
+        else nrec[n] = make_float4(__int_as_float(fin ? (int)fl : 0), P.Pr[3 * n], P.Pr[3 * n + 1], P.Pr[3 * n + 2]);
+        Bext[n] = e;
+        b_lo = fminf(b_lo, fl); b_hi = fmaxf(b_hi, fl + e); b_ext = fmaxf(b_ext, e);
+        if constexpr (SYM) {                             // a - A = (b - B) + frac(C) in [1, Bext + 1)
+            Abase[n] = (fin ? (int)fl : 0) + symCi;
+            Aext[n] = e + 1.0f;
+            a_lo = fminf(a_lo, fl + (float)symCi); a_hi = fmaxf(a_hi, fl + (float)symCi + e + 1.0f); a_ext = fmaxf(a_ext, e + 1.0f);
+        }
+    }
+    __syncthreads();                                   // part[] is free again
+    a_lo = wave_min(a_lo); b_lo = wave_min(b_lo);
+    a_hi = wave_max(a_hi); b_hi = wave_max(b_hi); a_ext = wave_max(a_ext); b_ext = wave_max(b_ext);
+    if (lane == 0) { float *q = part + wave * 8; q[0] = a_lo; q[1] = b_lo; q[2] = a_hi; q[3] = b_hi; q[4] = a_ext; q[5] = b_ext; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        const float *q = part + w * 8;
+        a_lo = fminf(a_lo, q[0]); b_lo = fminf(b_lo, q[1]); a_hi = fmaxf(a_hi, q[2]); b_hi = fmaxf(b_hi, q[3]);
+        a_ext = fmaxf(a_ext, q[4]); b_ext = fmaxf(b_ext, q[5]);
+    }
+    // every lane's last tap (+1 for the rint/floor ambiguity at exact integers) must be inside the staged window
+    if (!(a_ext + b_ext + (float)(K + 1) <= (float)C::W)) {
+        if (tid == 0 && split == 0) {
+            const uint32_t slot = atomicAdd(&P.fallback_list[0], 1u);
+            if (slot < P.fallback_cap) P.fallback_list[1 + slot] = tile_id;
+        }
+        return false;
+    }
+    if constexpr (PROBE) return false;
+    // every window of every stage strictly inside the record?  (uniform) -> branch-free loop
+    tile_interior = (a_lo + b_lo >= 1.0f) && (a_hi + b_hi + (float)(K + 1) < (float)T);
+    if constexpr (C::FMOD) {                           // remodulation phase constants (cycles) of the window bases, tile_pairs.h
+        const double f = P.fmod / fs;
+        for (uint32_t m = tid; m < M; m += THREADS) { const double c = ((double)Abase[m] + 0.5 - tapinfo<INTERP>::OFF) * f; Aext[m] = (float)(c - floor(c)); }
+        for (uint32_t n = tid; n < N; n += THREADS) { const double c = (double)__float_as_int(nrec[n].x) * f; Bext[n] = (float)(c - floor(c)); }
+    }
+    if constexpr (!LUT) {
+        for (uint32_t k = tid; k < 4 * M; k += THREADS) PvL[k] = P.Pv[k];
+        for (uint32_t k = tid; k < 3 * M; k += THREADS) NvL[k] = P.Nv[k];
+    }
+    __syncthreads();
+    return true;
+}
+
+}  // namespace qdas

@@ -1,0 +1,104 @@
+// tile_staging.h -- LDS-DMA staging of the tiled kernel (internal; included by das_tile_impl.h).
+//
+// One buffer descriptor per TRANSMIT BLOCK, based at trace (rx n_lo, tx m0) (mirror: (rx m0, tx 0)): window j starts
+// (j*strM + A[m0+j] + B[n]) samples after it.  A lane moves 16 bytes; a wave-instruction 1 KiB (only 16-byte pieces give a
+// contiguous LDS image: a 12-byte piece still advances 16 bytes per lane -- measured with tools/scratch/dma12.hip).  Offsets before
+// the base wrap to >= num_records and, like offsets past the end of x, deliver 0.  Samples outside [0, T) of a trace but inside x
+// read the neighbouring trace: they are only ever touched by lanes that the checked loop masks out (select, not multiply).
+// Everything that does not depend on the receiver -- A[m], the window's trace offset -- is folded into one scalar per window when
+// the block starts (dma_block).  A stage then costs two scalar adds per window: offset = soff (running receiver offset, 32-bit by
+// the plan-time check) + wb[r] + B[n]*SB.
+// Reciprocal mode walks the whole frame inside one transmit block (the mirror "transmits", or the receivers of transposed data):
+// its running offsets are kept below 2^30 by re-basing the descriptor when they get there (uniform, rare).  The general kernels
+// keep one descriptor per block (plan-time check: the walk stays below 2^31 bytes); transposed fp32 frames beyond that run the BIG
+// instantiation (launch configuration 9), which re-bases as well.
+#pragma once
+
+namespace qdas {
+
+constexpr uint32_t DMA_REBASE = 1u << 30;
+
+// descriptor based `o` bytes into the frame (+ `extra`: the frame itself); records beyond the frame read as zeros
+template <class C> __device__ __forceinline__ __amdgpu_buffer_rsrc_t Tile<C>::make_rs(uint64_t o, uint64_t extra) const {
+    const uint64_t rem = xbytes > o ? xbytes - o : 0;   // (m0 >= M when the split is exhausted: nothing more is issued)
+    return __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)P.x + (rem ? o + extra : 0)), 0, rem > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)rem, 0x00020000);
+}
+
+// window index (within its set) this wave stages in round r: windows wave + WAVES*r; with four frames the lower / upper half of
+// the waves take frames (0, 2) / (1, 3) of window wave % MB
+template <class C> __device__ __forceinline__ int Tile<C>::wjr(int r) const {
+    return C::FB4 ? __builtin_amdgcn_readfirstlane(wave % C::MB) : __builtin_amdgcn_readfirstlane(wave + C::WAVES * r);
+}
+
+template <class C> __device__ __forceinline__ void Tile<C>::dma_block(uint32_t m0) {
+    constexpr int SB = C::SB;
+    const uint64_t o = ((uint64_t)m0 * strM + (uint64_t)n_lo * strN) * SB;
+    if constexpr (C::SYM || C::BIG) offD = o;
+    rsD = make_rs(o, (uint64_t)fa * P.x_fstride);
+    soff = 0;
+#pragma unroll
+    for (int r = 0; r < C::WPW; ++r) {
+        const int j = wjr(r);
+        const uint32_t m = m0 + j;
+        const int am = __builtin_amdgcn_readfirstlane(Abase[m < M ? m : M - 1]);
+        wb[r] = am * SB + (int)((long)j * (long)strM * SB);
+        if constexpr (C::SYM) wb2[r] = am * SB + (int)((long)j * (long)strN * SB);
+    }
+    if constexpr (C::FBX) rsM = make_rs(o, (uint64_t)fb * P.x_fstride);   // the same traces of the next frame (four frames: of frame fb)
+    if constexpr (C::SYM) {                           // mirror traces x[:, rx = m0 + j, tx = n] (reciprocal mode starts every block at n = 0)
+        offM = (uint64_t)m0 * strN * SB;
+        rsM = make_rs(offM, 0);
+        soff2 = 0;
+    }
+}
+
+// stage (receiver with window base bn = B[n], current DMA transmit block) into window buffer `buf`
+template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, int buf) {
+    constexpr int SB = C::SB, WB = C::WB, PB = C::PB, PCS = C::PCS, NW = C::NW, MB = C::MB;
+    const int bs = bn * SB;
+#pragma unroll
+    for (int r = 0; r < C::WPW; ++r) {
+        const int j = wjr(r);
+        const int so = (int)soff + wb[r] + bs;
+#pragma unroll
+        for (int q = 0; q < (hooks::one_dma_piece ? 1 : PCS); ++q) {
+            lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + fa * MB + j) * WB + q * PB));
+            if (lane * 16 < WB - q * PB)             // trailing partial piece: upper lanes masked off
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, dst, 16, lane * 16, so + q * PB, 0, 0);
+        }
+    }
+    if constexpr (C::FBX) {                           // next frame: same offsets, other descriptor, another window set
+#pragma unroll
+        for (int r = 0; r < C::WPW; ++r) {
+            const int j = wjr(r);
+            const int so = (int)soff + wb[r] + bs;
+#pragma unroll
+            for (int q = 0; q < PCS; ++q) {
+                lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + fb * MB + j) * WB + q * PB));
+                if (lane * 16 < WB - q * PB)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, dst, 16, lane * 16, so + q * PB, 0, 0);
+            }
+        }
+    }
+    soff += (uint32_t)strN * SB;                      // next receiver, same transmit block
+    if constexpr (C::SYM || C::BIG) {
+        if (soff >= DMA_REBASE) { offD += soff; soff = 0; rsD = make_rs(offD, 0); }
+    }
+    if constexpr (C::SYM) {                           // same window start A[m] + B[n] in the mirror trace
+#pragma unroll
+        for (int r = 0; r < C::WPW; ++r) {
+            const int j = __builtin_amdgcn_readfirstlane(wave + C::WAVES * r);
+            const int so = (int)soff2 + wb2[r] + bs;
+#pragma unroll
+            for (int q = 0; q < PCS; ++q) {
+                lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + MB + j) * WB + q * PB));
+                if (lane * 16 < WB - q * PB)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, dst, 16, lane * 16, so + q * PB, 0, 0);
+            }
+        }
+        soff2 += (uint32_t)strM * SB;                 // next "transmit" n of the mirror traces
+        if (soff2 >= DMA_REBASE) { offM += soff2; soff2 = 0; rsM = make_rs(offM, 0); }
+    }
+}
+
+}  // namespace qdas

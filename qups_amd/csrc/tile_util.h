@@ -1,0 +1,125 @@
+// tile_util.h -- small device-side building blocks of the tiled kernel (internal): packed-fp32 tap weights, DPP wave reductions,
+// compile-time unrolling, and the cold fp64 helpers that are deliberately kept out of line.
+#pragma once
+#include "qdas_device.h"
+#include "lanczos_poly.h"
+#include <type_traits>
+#include <utility>
+
+namespace qdas {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr float MAGIC = 12582912.0f;          // 1.5 * 2^23: (t + MAGIC) has rint(t) in its low mantissa bits
+constexpr uint32_t MAGIC_BITS = 0x4B400000u;
+
+template <int INTERP> struct tapinfo {
+    static constexpr int K = interp_taps(INTERP);
+    // offset folded into a(i,m) so that floor(a + b) is the FIRST tap:
+    //   nearest: round(tau) = floor(tau + 1/2); linear: floor(tau); 4-tap: floor(tau) - 1
+    static constexpr double OFF = (INTERP == 0) ? 0.5 : (K == 2 ? 0.0 : -1.0);
+    // lowest admissible value of (tau*fs + OFF): tau >= 0 AND first tap >= 0
+    static constexpr float LO = (INTERP == 0) ? 0.5f : 0.0f;
+};
+
+template <int D> __device__ __forceinline__ v2f horner2(const float (&c)[D + 1], v2f q) {
+    v2f r = {c[D], c[D]};
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) r = r * q + (v2f){c[k], c[k]};
+    return r;
+}
+
+// Tap weights for s = u - 1/2 (two columns packed).  w[k] multiplies tap (first + k).
+template <int INTERP> __device__ __forceinline__ void weights2(v2f s, v2f w[4]) {
+    if constexpr (INTERP == 1 || INTERP == 4) {            // lerp (reference src/interpd.cu:84)
+        w[0] = 0.5f - s; w[1] = 0.5f + s;
+    } else if constexpr (INTERP == 2) {                    // Catmull-Rom, exact even/odd split about u = 1/2
+        const v2f q = s * s;
+        const v2f ei = 0.5625f - 0.25f * q, oi = -1.375f + 1.5f * q;
+        const v2f eo = -0.0625f + 0.25f * q, oo = 0.125f - 0.5f * q;
+        w[1] = ei + s * oi; w[2] = ei - s * oi; w[0] = eo + s * oo; w[3] = eo - s * oo;
+    } else if constexpr (INTERP == 3) {                    // Lanczos (a = 2), lanczos_poly.h
+        constexpr float EI[] = QDAS_LANCZOS_EI, OI[] = QDAS_LANCZOS_OI, EO[] = QDAS_LANCZOS_EO, OO[] = QDAS_LANCZOS_OO;
+        const v2f q = s * s;
+        const v2f ei = horner2<sizeof(EI) / 4 - 1>(EI, q), oi = horner2<sizeof(OI) / 4 - 1>(OI, q);
+        const v2f eo = horner2<sizeof(EO) / 4 - 1>(EO, q), oo = horner2<sizeof(OO) / 4 - 1>(OO, q);
+        w[1] = ei + s * oi; w[2] = ei - s * oi; w[0] = eo + s * oo; w[3] = eo - s * oo;
+    } else if constexpr (INTERP == 5) {                    // the Horner lines the device code executes (src/interpd.cu:103-106)
+        const v2f u = s + 0.5f;
+        w[0] = 0.5f * (u * (-1.0f + u * (2.0f * u - 1.0f)));
+        w[1] = 0.5f * (2.0f + u * (u * (-5.0f * u + 3.0f)));
+        w[2] = 0.5f * (u * (1.0f + u * (4.0f * u - 3.0f)));
+        w[3] = 0.5f * (u * (u * (1.0f - u)));
+    }
+}
+
+// DPP wave reductions (VALU speed; the result is valid in lane 63 only): quad swaps, half-row / row mirrors, then the row
+// broadcasts of GFX9 (lane 15 -> next row, lane 31 -> rows 2-3).  __shfl_xor compiles to ds_bpermute_b32: six dependent
+// LDS-pipe round trips per reduction.
+template <int CTRL, int ROWMASK = 0xf> __device__ __forceinline__ float dppf(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROWMASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_min63(float v) {
+    v = fminf(v, dppf<0xB1>(v)); v = fminf(v, dppf<0x4E>(v)); v = fminf(v, dppf<0x141>(v)); v = fminf(v, dppf<0x140>(v));
+    v = fminf(v, dppf<0x142, 0xa>(v)); v = fminf(v, dppf<0x143, 0xc>(v));
+    return v;
+}
+__device__ __forceinline__ float wave_max63(float v) {
+    v = fmaxf(v, dppf<0xB1>(v)); v = fmaxf(v, dppf<0x4E>(v)); v = fmaxf(v, dppf<0x141>(v)); v = fmaxf(v, dppf<0x140>(v));
+    v = fmaxf(v, dppf<0x142, 0xa>(v)); v = fmaxf(v, dppf<0x143, 0xc>(v));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+template <int... Is, typename F> __device__ __forceinline__ void unroll_impl(std::integer_sequence<int, Is...>, F &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void unroll(F &&f) { unroll_impl(std::make_integer_sequence<int, N>{}, f); }
+
+__device__ __forceinline__ v2f half2_to_v2f(uint32_t v) {
+    return (v2f){__half2float(__ushort_as_half((unsigned short)(v & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(v >> 16)))};
+}
+
+__device__ __forceinline__ float2   zero_of(const float2 *)   { return make_float2(0.f, 0.f); }
+__device__ __forceinline__ uint32_t zero_of(const uint32_t *) { return 0u; }
+
+// ---- cold fp64 code, kept OUT of line on purpose.  Inlined into the stage loop (16 unrolled copies of the transmit-block refresh,
+//      the fp64 acos / cos of the generated receive apodization) it inflated the live ranges around the pair loop until the
+//      register allocator parked the lane's transmit residuals ra[] in scratch and re-loaded them every stage (round 1: 170-230
+//      spilled VGPRs, 340-416 B of scratch per lane in every general instantiation).  As calls they cost a few scalar
+//      instructions once per transmit block / stage and the kernels have no scratch at all (tools/kernel_regs.py).
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+// a(i,m) - A[m] - 1/2 of one (pixel, block element): geometry tables in LDS, fp64 (reference src/bf.cu:104-108,114)
+static __device__ __noinline__ float block_residual(float px, float py, float pz, double cf, double fs, int kindB, lds_cfloat *Pv, lds_cfloat *Nv,
+                                                    uint32_t m, int Abase_m, double off) {
+    const double rx = (double)px - (double)Pv[4 * m], ry = (double)py - (double)Pv[4 * m + 1], rz = (double)pz - (double)Pv[4 * m + 2];
+    const double dot = kindB ? rx * (double)Nv[3 * m] + ry * (double)Nv[3 * m + 1] + rz * (double)Nv[3 * m + 2] : 0.0;
+    double dv = dot;
+    if (kindB != 2) {
+        const double d2 = rx * rx + ry * ry + rz * rz;
+        const float s0 = __builtin_sqrtf((float)d2);                  // fp32 seed + one Newton step (as dsqrt in the kernel)
+        const double sd = (double)s0;
+        const double r = __builtin_fma(-sd, sd, d2);
+        const double len = __builtin_fma(r, (double)(0.5f * __builtin_amdgcn_rcpf(fmaxf(s0, 1.0e-30f))), sd);
+        dv = kindB == 0 ? len : copysign(len, dot);
+    }
+    return (float)((dv * cf - (double)Pv[4 * m + 3] * fs + off) - ((double)Abase_m + 0.5));
+}
+// generated pixel x receiver weight (qdas.h QDAS_RXAPOD_*): element position from the LDS record, normal by scalar loads
+static __device__ __noinline__ float rx_apod_generated(int kind, double p0, double p1, float px, float py, float pz, float ex, float ey, float ez,
+                                                       const float *rxn, uint32_t n) {
+    const float nx = rxn ? rxn[3 * n] : 0.f, ny = rxn ? rxn[3 * n + 1] : 0.f, nz = rxn ? rxn[3 * n + 2] : 1.f;
+    return (float)rx_apod_weight(kind, p0, p1, (double)px - (double)ex, (double)py - (double)ey, (double)pz - (double)ez,
+                                 (double)nx, (double)ny, (double)nz, (double)px, (double)pz, (double)ex);
+}
+
+}  // namespace qdas

@@ -202,7 +202,8 @@ class UltrasoundSystem:
                  keep_rx=False, prec=None):
         """``b = bfDASLUT(us, chd, tau_rx, tau_tx, ...)`` (reference ``src/UltrasoundSystem.m:4476-4673``):
         ``tau_rx`` is ``I1 x I2 x I3 x N``, ``tau_tx`` is ``I1 x I2 x I3 x M`` (times).  Output
-        ``I1 x I2 x I3 x [N] x [M] x F...``."""
+        ``I1 x I2 x I3 x F... x [N] x [M]``: the aperture dimensions are moved behind the frame dimensions exactly as the
+        reference does (``:4663-4664``) -- the same layout as ``DAS`` (``:3361``)."""
         if chd.order != "TNM":
             raise DasError("bfDASLUT needs data ordered T x N x M (use rectifyDims).")
         Isz = self.scan.size
@@ -222,5 +223,6 @@ class UltrasoundSystem:
             w = a if w is None else w * a
         sdim = set() if keep_rx else {"rx"}
         sdim |= set() if keep_tx else {"tx"}
-        return sample2sep(chd.data, chd.t0, chd.fs, tr, tt, interp=interp, w=w, sdim=sdim, fmod=fmod,
-                          **({"prec": prec} if prec else {}))
+        b = sample2sep(chd.data, chd.t0, chd.fs, tr, tt, interp=interp, w=w, sdim=sdim, fmod=fmod,
+                       **({"prec": prec} if prec else {}))           # I1 x I2 x I3 x [N] x [M] x F...
+        return b.permute(0, 1, 2, *range(5, b.ndim), 3, 4)           # move the aperture dimensions to the end (:4663-4664)

@@ -1,0 +1,34 @@
+"""Build check (CPU only): register metadata of the kernels `make` produced, read from the code objects embedded in
+qups_amd/libqdas.so (tools/kernel_regs.py).  The tiled kernel is sized for 4 waves per SIMD (128 VGPRs); a spilled register there
+means scratch traffic in the stage loop (round 1: 170-230 spilled VGPRs in every general instantiation) -- never again silently."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def table():
+    import kernel_regs
+    so = os.path.join(ROOT, "qups_amd", "libqdas.so")
+    if not os.path.exists(so) or not os.path.exists(kernel_regs.READELF):
+        pytest.skip("libqdas.so / llvm-readelf not available")
+    rows = kernel_regs.kernel_table(so)
+    assert rows, "no gfx950 code objects found in libqdas.so"
+    return rows
+
+
+def test_tiled_kernels_do_not_spill(table):
+    tiled = [r for r in table if "das_tile_kernel" in r["name"]]
+    assert len(tiled) >= 150, len(tiled)                  # every launch configuration x interpolator x {fmod, wtab} variant
+    bad = [(r["name"][:90], r["vgpr_spill"], r["scratch"]) for r in tiled if r["vgpr_spill"] or r["scratch"]]
+    assert not bad, bad
+    assert max(r["vgpr"] + r["agpr"] for r in tiled) <= 128      # 16 waves per CU = 4 per SIMD
+
+
+def test_no_kernel_spills_vector_registers(table):
+    bad = [(r["name"][:90], r["vgpr_spill"]) for r in table if r["vgpr_spill"]]
+    assert not bad, bad

@@ -318,3 +318,30 @@ def test_us_DAS_keep_dims_and_frames_layout():
     assert rel_err(_np(b0[..., 1, :, :]), 2 * _np(b0[..., 0, :, :])) <= 1e-6
     chd_t = ChannelData(torch.from_numpy(np.swapaxes(xf, 1, 2)), case["t0"], case["fs"], order="TMN")
     assert rel_err(_np(us.DAS(chd_t, interp="linear")), _np(b0)) <= 1e-6
+
+
+@pytest.mark.parametrize("keep", [(True, False), (False, True), (True, True), (False, False)])
+def test_us_bfDAS_frames_layout_matches_DAS_and_oracle(keep):
+    """bfDAS / bfDASLUT put the aperture dimensions BEHIND the frame dimensions like the reference
+    (src/UltrasoundSystem.m:4663-4664) and like DAS (:3361): compared without any reshape, multi-frame, kept dimensions."""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import ChannelData, Scan, Sequence, Transducer, UltrasoundSystem
+    keep_rx, keep_tx = keep
+    case = make_case(seq="FSA", interp="linear", seed=23, N=5, I1=24, I2=4)
+    N = M = 5
+    xdc = Transducer(case["Pr"], np.stack([0 * case["Pr"][0], 0 * case["Pr"][0], 1 + 0 * case["Pr"][0]]))
+    us = UltrasoundSystem(xdc, Sequence("FSA", c0=case["c"]), Scan(case["Pi"]))
+    xf = np.stack([case["x"], 2j * case["x"], -0.5 * case["x"]], axis=3)      # T x N x M x F, F = 3
+    chd = ChannelData(torch.from_numpy(xf), case["t0"], case["fs"])
+    b_lut = us.bfDAS(chd, interp="linear", keep_rx=keep_rx, keep_tx=keep_tx)
+    b_das = us.DAS(chd, interp="linear", keep_rx=keep_rx, keep_tx=keep_tx)
+    want = (24, 4, 1, 3, N if keep_rx else 1, M if keep_tx else 1)
+    assert tuple(b_lut.shape) == want and tuple(b_das.shape) == want
+    fun = {(False, False): "DAS", (True, False): "SYN", (False, True): "MUL", (True, True): "BF"}[keep]
+    ref1 = O.das_spec(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"], cinv_f32(case["c"]),
+                      VS=case["VS"], DV=case["DV"], interp="linear")          # I1 x I2 x I3 x [N] x [M]
+    ref = np.stack([ref1, 2j * ref1, -0.5 * ref1], axis=3)                    # I1 x I2 x I3 x F x [N] x [M]
+    assert ref.shape == want
+    assert rel_err(_np(b_das), ref) <= 1e-4
+    assert rel_err(_np(b_lut), ref) <= 5e-4                                   # fp32 delay tables
