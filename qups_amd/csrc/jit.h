@@ -1,0 +1,28 @@
+// jit.h -- plan-specialised builds of the tiled kernel with hiprtc (internal; implementation and rationale in jit.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "tile_params.h"
+#include "das_tile_cfg.h"
+
+namespace qdas {
+
+// Everything that becomes a constant of the compiled kernel: the template parameters of the instantiation and the plan's sizes.
+struct JitSpec {
+    int interp, dtype, fmod, wtab, sym, big;            // instantiation (one frame per launch, geometry-driven delays)
+    int waves, mb, w, nbuf;                             // launch configuration (das_tile_cfg.h)
+    uint64_t N, M, T, I1, strN, strM;                   // stage / block elements, record length, fastest image dimension, trace strides
+    int kindB, kindS, tzl, wzl;                         // delay kinds, tile / wave footprint
+    unsigned ksplit;
+    int gen_kind, has_apix, apix_real, syn, has_st, has_cinv_pix;
+};
+
+std::string jit_source(const JitSpec &k);
+// "" on success, else the reason (hiprtc missing, compile log, ...)
+std::string jit_compile(const JitSpec &k, std::vector<char> *code, std::string *key_out);
+std::string jit_get_kernel(const JitSpec &k, int device, hipFunction_t *fn, std::string *key_out);
+hipError_t jit_launch(hipFunction_t fn, const TileParams &P, unsigned grid, unsigned block, size_t lds, hipStream_t s);
+
+}  // namespace qdas

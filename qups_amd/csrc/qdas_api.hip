@@ -16,6 +16,7 @@
 
 #include "../../include/qdas.h"
 #include "qdas_kernels.h"
+#include "jit.h"
 
 using namespace qdas;
 
@@ -71,6 +72,7 @@ struct qdas_plan {
     bool fb2_ok = false;                      // frames of a sequence may share launches, 4 or 2 at a time (decided at plan creation)
     bool fb4_off = false;                     // ... but at most pairwise (QDAS_NO_FB4)
     uint32_t *fallback = nullptr;             // device: [0] = count, [1..ntiles]
+    hipFunction_t jit_fn = nullptr;           // plan-specialised kernel (QDAS_PLAN_JIT, jit.hip); null: prebuilt instantiation
     std::string jit_tag;                      // "jit <hash>" when the plan runs a hiprtc-specialised kernel (QDAS_PLAN_JIT)
     bool timing = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -513,7 +515,26 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         }
     }
 
-    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
+    // ---- QDAS_PLAN_JIT: the tiled kernel compiled for this plan's sizes (jit.hip).  A failure is not an error: the plan keeps its
+    //      prebuilt kernel and qdas_last_error() says why.
+    g_err.clear();
+    if ((desc->plan_flags & QDAS_PLAN_JIT) && pl->kernel == QDAS_KERNEL_TILED && !getenv("QDAS_NO_JIT")) {
+        const TileParams &t = pl->tp;
+        JitSpec k{};
+        k.interp = (z.flag & 7) == 4 ? 1 : (z.flag & 7); k.dtype = dt; k.fmod = t.fmod != 0.0; k.wtab = t.wtab != nullptr; k.sym = t.sym; k.big = t.big;
+        const int narrow = (t.sym && dt == QDAS_F32 && t.narrow) ? 1 : 0;
+        const Cfg &cg = CFGS[cfg_index(dt, t.sym, 1, narrow)];
+        k.waves = cg.waves; k.mb = cg.mb; k.w = cg.w; k.nbuf = cg.nbuf;
+        k.N = t.N; k.M = t.M; k.T = t.T; k.I1 = t.I1; k.strN = t.strN; k.strM = t.strM;
+        k.kindB = t.kindB; k.kindS = t.kindS; k.tzl = t.tz_log2; k.wzl = t.wz_log2; k.ksplit = t.ksplit;
+        k.gen_kind = t.gen_kind; k.has_apix = t.apix != nullptr; k.apix_real = t.apix_real; k.syn = t.syn;
+        k.has_st = t.St != nullptr; k.has_cinv_pix = t.cinv_pix != nullptr;
+        std::string key;
+        const std::string err = jit_get_kernel(k, pl->device, &pl->jit_fn, &key);
+        if (err.empty()) pl->jit_tag = "jit " + key;
+        else { pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel"; }
+    }
+    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->jit_fn && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
     // four frames per launch: not for fp32 plans with remodulation, a weight table or a pixel x receiver weight (das_tile_impl.h launch_tile_i)
     pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr
                   || (dt == QDAS_F32 && pl->kernel == QDAS_KERNEL_TILED && (pl->tp.fmod != 0.0 || pl->tp.wtab || pl->tp.apix || pl->tp.gen_kind));
@@ -597,9 +618,9 @@ static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s, int n
             for (int f = 0; f < nf; ++f)
                 HIPCHK(hipMemset2DAsync((char *)y + (size_t)f * y_fstride * ds, (size_t)pl->y_ld * ds, 0, (size_t)pl->i_count * ds, pl->oN * pl->oM, s));
         }
-        if (pl->no_fallback) return hip_rc(launch_tile(t, z.dtype, pl->ntiles, s));     // one launch per frame (+ the reduce of a split aperture)
+        if (pl->no_fallback) return hip_rc(launch_tile(t, z.dtype, pl->ntiles, s, pl->jit_fn));     // one launch per frame (+ the reduce of a split aperture)
         HIPCHK(hipMemsetAsync(pl->fallback, 0, sizeof(uint32_t), s));
-        HIPCHK(launch_tile(t, z.dtype, pl->ntiles, s));
+        HIPCHK(launch_tile(t, z.dtype, pl->ntiles, s, pl->jit_fn));
         // tiles whose delay window overflowed LDS are redone by the generic kernel; the launch is
         // sized for the worst case and exits immediately for ids >= the device-side count
         GenericParams g = pl->gp;

@@ -504,7 +504,7 @@ class DasPlan:
 
 
 def das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs=None, c=None, *varargin, return_plan=False,
-             kernel: int = _lib.KERNEL_AUTO):
+             kernel: int = _lib.KERNEL_AUTO, jit: bool = False):
     """``y = das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs, c, ...)`` -- see reference ``kern/das_spec.m:1-87``.
 
     ``fun`` in ``{'DAS','SYN','MUL','BF','delays'}``; options (strings, as in the reference):
@@ -525,7 +525,7 @@ def das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs=None, c=None, *varargin, return_plan
     xshape = tuple(x.shape) if fun != "delays" else ()
     prob = build_problem(fun, Pi, Pr, Pv, Nv, xshape, t0, fs, c, opts)
     device = None if opts["device"] in (-1, None) else f"cuda:{opts['device'] - 1}"   # MATLAB device ids are 1-based
-    plan = DasPlan(prob, device=device, kernel=kernel)
+    plan = DasPlan(prob, device=device, kernel=kernel, jit=jit)     # jit: hiprtc build for these sizes (qdas.h QDAS_PLAN_JIT)
     Isz = prob.Isz
     rev = lambda t: t.permute(*reversed(range(t.ndim)))
     if fun == "delays":
