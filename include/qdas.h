@@ -177,6 +177,21 @@ int  qdas_plan_kernel_name(const qdas_plan *plan, char *buf, size_t len);
 int  qdas_plan_set_timing(qdas_plan *plan, int enable);
 int  qdas_plan_last_kernel_ms(const qdas_plan *plan, float *ms);
 
+/* ---- one host thread, several devices: the image is split into ndev contiguous slabs of the linear pixel
+ *      index, one per entry of devices[] (NULL: 0 .. ndev-1; an ordinal may repeat: several streams on one device); geometry and
+ *      channel data are replicated, every device beamforms its slab with an ordinary plan, the slabs are concatenated into y.
+ *      desc->mem == QDAS_MEM_DEVICE: the constant inputs and x / y live on devices[0]; x is replicated with peer copies down a binary
+ *      tree (xGMI), slabs come back with peer copies; asynchronous on `stream` (a stream of devices[0]).
+ *      desc->mem == QDAS_MEM_HOST: x is uploaded once to devices[0] and replicated from there; y is downloaded; synchronous.
+ *      desc->i_begin / i_count / y_ld must be 0; y is I x [1|N] x [1|M].  The reference has no multi-device path (one gpuDevice
+ *      per MATLAB process, README.md:232): this is what lets its single-process host reach a whole node. */
+typedef struct qdas_sharded_plan qdas_sharded_plan;
+int  qdas_plan_create_sharded(qdas_sharded_plan **plan, const qdas_desc *desc, int ndev, const int *devices);
+int  qdas_plan_execute_sharded(qdas_sharded_plan *plan, const void *x, void *y, void *stream);
+/* shard < 0: the number of shards in *device.  Else the shard's device, pixel slab and kernel (QDAS_KERNEL_*; 0: empty slab). */
+int  qdas_plan_sharded_info(const qdas_sharded_plan *plan, int shard, int *device, uint64_t *i_begin, uint64_t *i_count, int *kernel);
+void qdas_plan_destroy_sharded(qdas_sharded_plan *plan);
+
 /* ---- one-shot entries shaped like the reference kernels' argument lists
  *      (device pointers; sizes struct replaces the constant-memory symbols).
  *      DAS  <-> src/bf.cu:144-151, DASf <-> :153-161, DASh <-> :164-171 */

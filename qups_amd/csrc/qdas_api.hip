@@ -39,6 +39,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *qdas_last_error(void) { return g_err.c_str(); }
+void qdas_internal_set_error(const char *msg) { g_err = msg ? msg : ""; }      // for the library's other translation units (sharded.hip)
 extern "C" int qdas_version(void) { return QDAS_VERSION; }
 
 extern "C" int qdas_device_info(int device, char *name, size_t name_len, int *cu_count, int *clock_khz,

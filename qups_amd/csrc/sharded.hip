@@ -1,0 +1,289 @@
+// sharded.hip -- ONE host thread, several HIP devices: the multi-device entry of the C ABI (include/qdas.h qdas_plan_*_sharded).
+//
+// The reference drives one gpuDevice per MATLAB process (reference README.md:232) and has no multi-device path; SURVEY.md
+// section 8b/8e ask for `qdas_plan_create_sharded(..., ndev)` + gather so that a single-process caller (MATLAB through the MEX
+// gateway, any C program) reaches all GPUs of a node.  Layout, exactly as the per-process layout of qups_amd/dist.py: pixels are
+// split into ndev contiguous slabs of the linear pixel index; geometry and channel data are REPLICATED; every device beamforms
+// its slab with an ordinary plan (qdas_plan_create with i_begin / i_count); the slabs are concatenated into the caller's y.
+// No collective library is needed for that: the data path is
+//     x: caller -> devices[0] (H2D if the caller's memory is host memory) -> peer copies down a binary tree (xGMI; every device
+//        forwards to at most log2(ndev) others, so no link carries the frame more than once per round)
+//     y: slab g -> peer copy into its place in y on devices[0] (-> one D2H for host callers)
+// issued on one stream per device and ordered with events only -- the host thread never blocks before the final wait.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/qdas.h"
+
+void qdas_internal_set_error(const char *msg);         // qdas_api.hip: the thread-local message behind qdas_last_error()
+
+namespace {
+
+struct Shard {
+    int device = 0;
+    qdas_plan *plan = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t x_ready = nullptr, done = nullptr;
+    uint64_t i_begin = 0, i_count = 0;
+    void *x = nullptr;                                  // this device's replica of the frame (null: shares the root's)
+    void *y = nullptr;                                  // slab output, i_count x [N] x [M]
+    std::vector<void *> owned;                          // device copies of geometry made for this shard
+};
+
+int failf(int code, const char *fmt, const char *a = "", const char *b = "") {
+    char buf[512];
+    snprintf(buf, sizeof buf, fmt, a, b);
+    qdas_internal_set_error(buf);
+    return code;
+}
+#define SHIP(call)                                                                                   \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return failf(QDAS_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+size_t real_size(int dtype) { return dtype == QDAS_F64 ? 8 : 4; }
+size_t data_size(int dtype) { return dtype == QDAS_F64 ? 16 : (dtype == QDAS_F32 ? 8 : 4); }
+size_t apod_real_size(int dtype) { return dtype == QDAS_F64 ? 8 : (dtype == QDAS_F32 ? 4 : 2); }
+
+uint64_t bcast_numel(const uint64_t *st, const qdas_sizes &z) {
+    const uint64_t dims[5] = {z.I1, z.I2, z.I3, z.N, z.M};
+    uint64_t n = 1;
+    for (int k = 0; k < 5; ++k) if (st[k]) n += (dims[k] - 1) * st[k];
+    return n;
+}
+
+}  // namespace
+
+struct qdas_sharded_plan {
+    qdas_desc d{};
+    std::vector<Shard> sh;
+    std::vector<uint64_t> acs;
+    uint64_t I = 0, oN = 1, oM = 1;
+    size_t x_bytes = 0, ds = 0;
+    void *y_root = nullptr;                             // host callers: the gathered image on devices[0]
+    void *x_root = nullptr;                             // host callers: the uploaded frame on devices[0]
+    ~qdas_sharded_plan() {
+        for (Shard &s : sh) {
+            (void)hipSetDevice(s.device);
+            if (s.plan) qdas_plan_destroy(s.plan);
+            for (void *p : s.owned) (void)hipFree(p);
+            if (s.x) (void)hipFree(s.x);
+            if (s.y) (void)hipFree(s.y);
+            if (s.x_ready) (void)hipEventDestroy(s.x_ready);
+            if (s.done) (void)hipEventDestroy(s.done);
+            if (s.stream) (void)hipStreamDestroy(s.stream);
+        }
+        if (!sh.empty()) (void)hipSetDevice(sh[0].device);
+        if (y_root) (void)hipFree(y_root);
+        if (x_root) (void)hipFree(x_root);
+    }
+};
+
+extern "C" int qdas_plan_create_sharded(qdas_sharded_plan **out, const qdas_desc *desc, int ndev, const int *devices) {
+    if (!out || !desc) return failf(QDAS_EINVAL, "null argument");
+    *out = nullptr;
+    if (ndev < 1 || ndev > 64) return failf(QDAS_EINVAL, "qdas_plan_create_sharded: ndev must be in 1..64");
+    if (desc->i_begin || desc->i_count || desc->y_ld) return failf(QDAS_EINVAL, "qdas_plan_create_sharded: the library chooses the pixel slabs (i_begin, i_count, y_ld must be 0)");
+    int have = 0;
+    SHIP(hipGetDeviceCount(&have));
+    qdas_sharded_plan *sp = new qdas_sharded_plan();
+    auto bail = [&](int code) { delete sp; return code; };
+    sp->d = *desc;
+    const qdas_sizes &z = desc->sz;
+    sp->I = z.I1 * z.I2 * z.I3;
+    sp->oN = (z.flag & QDAS_FLAG_KEEP_RX) ? z.N : 1;
+    sp->oM = (z.flag & QDAS_FLAG_KEEP_TX) ? z.M : 1;
+    sp->ds = data_size(z.dtype);
+    sp->x_bytes = (size_t)z.T * z.N * z.M * sp->ds;
+    sp->acs.assign(desc->acstride ? desc->acstride : nullptr, desc->acstride ? desc->acstride + 6 * (1 + z.S) : nullptr);
+    int root_dev = devices ? devices[0] : 0;
+    if (desc->mem == QDAS_MEM_DEVICE && desc->device >= 0 && devices && desc->device != devices[0])
+        return bail(failf(QDAS_EINVAL, "qdas_plan_create_sharded: device-resident inputs must live on devices[0]"));
+    sp->sh.resize(ndev);
+    // sizes of the constant inputs (as qdas_plan_create computes them)
+    const size_t rs = real_size(z.dtype);
+    uint64_t apod_elems = 0;
+    for (uint64_t s = 0; s < z.S && desc->acstride; ++s) {
+        const uint64_t *a = desc->acstride + 6 * (1 + s);
+        const uint64_t end = a[5] + bcast_numel(a, z);
+        if (end > apod_elems) apod_elems = end;
+    }
+    const size_t ael = desc->apod_real ? apod_real_size(z.dtype) : sp->ds;
+    const uint64_t cinv_elems = desc->acstride ? bcast_numel(desc->acstride, z) : 1;
+    for (int g = 0; g < ndev; ++g) {
+        Shard &s = sp->sh[g];
+        s.device = devices ? devices[g] : g;
+        if (s.device < 0 || s.device >= have) return bail(failf(QDAS_EINVAL, "qdas_plan_create_sharded: device ordinal out of range"));
+        s.i_begin = sp->I * (uint64_t)g / (uint64_t)ndev;
+        s.i_count = sp->I * (uint64_t)(g + 1) / (uint64_t)ndev - s.i_begin;
+        hipError_t e = hipSetDevice(s.device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.x_ready, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+        if (e != hipSuccess) return bail(failf(QDAS_EHIP, "qdas_plan_create_sharded: stream / event creation: %s", hipGetErrorString(e)));
+        if (s.device != root_dev) {                      // peer access makes the copies direct (xGMI); without it HIP stages them
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, s.device, root_dev) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(root_dev, 0);
+            (void)hipGetLastError();                     // (already enabled is fine)
+        }
+        qdas_desc d = *desc;
+        d.device = s.device;
+        d.i_begin = s.i_begin; d.i_count = s.i_count; d.y_ld = 0;
+        d.acstride = sp->acs.empty() ? nullptr : sp->acs.data();
+        d.mem = QDAS_MEM_DEVICE;                         // shards always run on device-resident frames (the sharded plan moves the data)
+        // constant inputs: host arrays are uploaded per device; device arrays (on devices[0]) are replicated with peer copies
+        auto bring = [&](const void *src, size_t bytes, const void **dst) -> int {
+            *dst = src;
+            if (!src || !bytes) return QDAS_OK;
+            if (desc->mem == QDAS_MEM_DEVICE && s.device == root_dev) return QDAS_OK;
+            void *p = nullptr;
+            hipError_t e2 = hipMalloc(&p, bytes);
+            if (e2 != hipSuccess) return failf(QDAS_ENOMEM, "qdas_plan_create_sharded: hipMalloc: %s", hipGetErrorString(e2));
+            s.owned.push_back(p);
+            e2 = desc->mem == QDAS_MEM_HOST ? hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) : hipMemcpyPeer(p, s.device, src, root_dev, bytes);
+            if (e2 != hipSuccess) return failf(QDAS_EHIP, "qdas_plan_create_sharded: replicating inputs: %s", hipGetErrorString(e2));
+            *dst = p;
+            return QDAS_OK;
+        };
+        int rc = 0;
+        if (sp->I && z.N && z.M) {
+            if ((rc = bring(desc->Pi, 3 * sp->I * rs, &d.Pi)) || (rc = bring(desc->Pr, 3 * z.N * rs, &d.Pr)) || (rc = bring(desc->Pv, 4 * z.M * rs, &d.Pv)) ||
+                (rc = bring(desc->Nv, 3 * z.M * rs, &d.Nv)) || (rc = bring(desc->cinv, cinv_elems * rs, &d.cinv)) ||
+                (rc = bring(desc->apod, apod_elems * ael, &d.apod)) || (rc = bring(desc->rx_normals, desc->rx_apod_kind ? 3 * z.N * rs : 0, &d.rx_normals)))
+                return bail(rc);
+        }
+        if (s.i_count) {
+            rc = qdas_plan_create(&s.plan, &d);
+            if (rc) return bail(rc);
+            e = hipSetDevice(s.device);
+            if (e == hipSuccess) e = hipMalloc(&s.y, (size_t)s.i_count * sp->oN * sp->oM * sp->ds + 16);
+            if (e != hipSuccess) return bail(failf(QDAS_ENOMEM, "qdas_plan_create_sharded: slab buffer: %s", hipGetErrorString(e)));
+        }
+        // replica of the frame: one per distinct device (a device listed twice shares it); the root needs one only for host callers
+        int first = g;
+        for (int q = 0; q < g; ++q) if (sp->sh[q].device == s.device) { first = q; break; }
+        if (first == g && !(s.device == root_dev && desc->mem == QDAS_MEM_DEVICE) && sp->x_bytes) {
+            e = hipSetDevice(s.device);
+            if (e == hipSuccess) e = hipMalloc(&s.x, sp->x_bytes);
+            if (e != hipSuccess) return bail(failf(QDAS_ENOMEM, "qdas_plan_create_sharded: frame replica: %s", hipGetErrorString(e)));
+        }
+    }
+    if (desc->mem == QDAS_MEM_HOST) {
+        hipError_t e = hipSetDevice(root_dev);
+        if (e == hipSuccess) e = hipMalloc(&sp->y_root, (size_t)sp->I * sp->oN * sp->oM * sp->ds + 16);
+        if (e != hipSuccess) return bail(failf(QDAS_ENOMEM, "qdas_plan_create_sharded: gather buffer: %s", hipGetErrorString(e)));
+    }
+    *out = sp;
+    return QDAS_OK;
+}
+
+extern "C" int qdas_plan_execute_sharded(qdas_sharded_plan *sp, const void *x, void *y, void *stream) {
+    if (!sp || !y) return failf(QDAS_EINVAL, "null argument");
+    const qdas_sizes &z = sp->d.sz;
+    const int G = (int)sp->sh.size();
+    const int root_dev = sp->sh[0].device;
+    const bool host = sp->d.mem == QDAS_MEM_HOST;
+    const size_t ybytes = (size_t)sp->I * sp->oN * sp->oM * sp->ds;
+    if (sp->I == 0 || z.N == 0 || z.M == 0 || z.T == 0) {                // empty sum: zeros
+        if (!ybytes) return QDAS_OK;
+        if (host) { memset(y, 0, ybytes); return QDAS_OK; }
+        SHIP(hipSetDevice(root_dev));
+        SHIP(hipMemsetAsync(y, 0, ybytes, (hipStream_t)stream));
+        return QDAS_OK;
+    }
+    if (!x) return failf(QDAS_EINVAL, "null data");
+    // ---- the frame on the root device
+    Shard &r0 = sp->sh[0];
+    const void *x0 = x;
+    SHIP(hipSetDevice(root_dev));
+    if (host) {
+        void *dst = r0.x;                                // (the root owns a replica for host callers)
+        if (!dst) return failf(QDAS_EINVAL, "qdas_plan_execute_sharded: internal: no root replica");
+        SHIP(hipMemcpyAsync(dst, x, sp->x_bytes, hipMemcpyHostToDevice, r0.stream));
+        x0 = dst;
+    } else if (stream != (void *)r0.stream) {            // order behind the caller's stream on the root device
+        SHIP(hipEventRecord(r0.done, (hipStream_t)stream));
+        SHIP(hipStreamWaitEvent(r0.stream, r0.done, 0));
+    }
+    SHIP(hipEventRecord(r0.x_ready, r0.stream));
+    // ---- replicate down a binary tree over the DISTINCT devices (a device listed twice holds one replica): in round k, holder
+    //      u < 2^k feeds holder u + 2^k.  Each holder's copy runs on the stream of the first shard on that device.
+    std::vector<int> holder;                             // shard index of the first shard on each distinct device (holder[0] = 0)
+    std::vector<int> uidx(G, 0);                         // shard -> index into holder
+    for (int g = 0; g < G; ++g) {
+        int u = -1;
+        for (size_t k = 0; k < holder.size(); ++k) if (sp->sh[holder[k]].device == sp->sh[g].device) { u = (int)k; break; }
+        if (u < 0) { u = (int)holder.size(); holder.push_back(g); }
+        uidx[g] = u;
+    }
+    const int U = (int)holder.size();
+    std::vector<const void *> xr(U, nullptr);
+    xr[0] = x0;
+    for (int step = 1; step < U; step <<= 1) {
+        for (int q = 0; q < step && q + step < U; ++q) {
+            Shard &src = sp->sh[holder[q]], &dst = sp->sh[holder[q + step]];
+            if (!dst.x) return failf(QDAS_EINVAL, "qdas_plan_execute_sharded: internal: missing replica buffer");
+            SHIP(hipSetDevice(dst.device));
+            SHIP(hipStreamWaitEvent(dst.stream, src.x_ready, 0));
+            SHIP(hipMemcpyPeerAsync(dst.x, dst.device, xr[q], src.device, sp->x_bytes, dst.stream));
+            SHIP(hipEventRecord(dst.x_ready, dst.stream));
+            xr[q + step] = dst.x;
+        }
+    }
+    std::vector<const void *> xs(G, nullptr);
+    for (int g = 0; g < G; ++g) {
+        xs[g] = xr[uidx[g]];
+        if (g != holder[uidx[g]]) {                      // a later shard on the same device: its stream waits for the device's replica
+            SHIP(hipSetDevice(sp->sh[g].device));
+            SHIP(hipStreamWaitEvent(sp->sh[g].stream, sp->sh[holder[uidx[g]]].x_ready, 0));
+        }
+    }
+    // ---- beamform the slabs and gather them into y (on the root device)
+    void *ydst = host ? sp->y_root : y;
+    for (int g = 0; g < G; ++g) {
+        Shard &s = sp->sh[g];
+        if (!s.plan) continue;
+        SHIP(hipSetDevice(s.device));
+        int rc = qdas_plan_execute(s.plan, xs[g], s.y, (void *)s.stream);
+        if (rc) return rc;
+        // slab planes (i_count x [N] x [M]) -> their rows of the I x [N] x [M] image
+        const size_t planes = (size_t)sp->oN * sp->oM;
+        if (s.device == root_dev)
+            SHIP(hipMemcpy2DAsync((char *)ydst + s.i_begin * sp->ds, (size_t)sp->I * sp->ds, s.y, (size_t)s.i_count * sp->ds,
+                                  (size_t)s.i_count * sp->ds, planes, hipMemcpyDeviceToDevice, s.stream));
+        else
+            for (size_t p = 0; p < planes; ++p)
+                SHIP(hipMemcpyPeerAsync((char *)ydst + ((size_t)p * sp->I + s.i_begin) * sp->ds, root_dev,
+                                        (const char *)s.y + p * (size_t)s.i_count * sp->ds, s.device, (size_t)s.i_count * sp->ds, s.stream));
+        SHIP(hipEventRecord(s.done, s.stream));
+    }
+    // ---- join: the caller's stream (device callers) or the host (host callers) waits for every slab
+    SHIP(hipSetDevice(root_dev));
+    if (host) {
+        for (int g = 1; g < G; ++g) if (sp->sh[g].plan) SHIP(hipStreamWaitEvent(r0.stream, sp->sh[g].done, 0));
+        SHIP(hipMemcpyAsync(y, sp->y_root, ybytes, hipMemcpyDeviceToHost, r0.stream));
+        SHIP(hipStreamSynchronize(r0.stream));
+    } else {
+        for (int g = 0; g < G; ++g) if (sp->sh[g].plan) SHIP(hipStreamWaitEvent((hipStream_t)stream, sp->sh[g].done, 0));
+    }
+    return QDAS_OK;
+}
+
+extern "C" int qdas_plan_sharded_info(const qdas_sharded_plan *sp, int shard, int *device, uint64_t *i_begin, uint64_t *i_count, int *kernel) {
+    if (!sp) return failf(QDAS_EINVAL, "null plan");
+    if (shard < 0) { if (device) *device = (int)sp->sh.size(); return QDAS_OK; }      // shard = -1: number of shards in *device
+    if (shard >= (int)sp->sh.size()) return failf(QDAS_EINVAL, "shard index out of range");
+    const Shard &s = sp->sh[shard];
+    if (device) *device = s.device;
+    if (i_begin) *i_begin = s.i_begin;
+    if (i_count) *i_count = s.i_count;
+    if (kernel) *kernel = s.plan ? qdas_plan_kernel(s.plan) : 0;
+    return QDAS_OK;
+}
+
+extern "C" void qdas_plan_destroy_sharded(qdas_sharded_plan *sp) { delete sp; }

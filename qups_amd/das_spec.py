@@ -496,6 +496,87 @@ class DasPlan:
             self.lib.qdas_plan_destroy(self._h)
             self._h = C.c_void_p()
 
+
+class MultiDevicePlan:
+    """One process, several GPUs: ``qdas_plan_create_sharded`` (``include/qdas.h``).  The image is split into ``len(devices)``
+    contiguous slabs of the linear pixel index, one per entry of ``devices`` (an ordinal may repeat); the channel data handed to
+    :meth:`feval` lives on ``devices[0]`` and is replicated by the library with peer copies; the result is the full image on
+    ``devices[0]``.  The per-process layout (``torch.distributed``, one rank per GPU) is :mod:`qups_amd.dist`."""
+
+    def __init__(self, prob: DasProblem, devices, kernel: int = _lib.KERNEL_AUTO, reciprocal: bool = True, jit: bool = False):
+        torch = _torch()
+        self.lib = _lib.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("qups_amd: no HIP device visible -- the DAS path has no CPU fallback")
+        self.devices = [int(d) for d in devices]
+        self.device = torch.device(f"cuda:{self.devices[0]}")
+        self.prob = prob
+        # (the same marshalling as DasPlan: device copies of the constant inputs on devices[0])
+        dev = self.device
+        up = lambda a: torch.from_numpy(a).to(dev) if a is not None else None
+        self._bufs = [up(prob.Pi), up(prob.Pr), up(prob.Pv), up(prob.Nv), up(prob.cinv),
+                      up(prob.apod.view(np.uint16) if (prob.apod is not None and prob.apod.dtype == np.float16) else prob.apod)]
+        self._acs = (C.c_uint64 * len(prob.acstride))(*[int(v) for v in prob.acstride])
+        d = _lib.Desc()
+        d.sz = _lib.Sizes(prob.T, prob.N, prob.M, prob.Isz[0], prob.Isz[1], prob.Isz[2], prob.S, prob.flag,
+                          int(prob.VS), int(prob.DV), _PREC[prob.prec])
+        d.fs, d.fmod = prob.fs, prob.fmod
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        d.Pi, d.Pr, d.Pv, d.Nv, d.cinv, d.apod = (ptr(b) for b in self._bufs[:6])
+        d.acstride = self._acs
+        d.mem, d.apod_real, d.kernel, d.device = _lib.MEM_DEVICE, int(prob.apod_real), int(kernel), self.devices[0]
+        d.plan_flags = (0 if reciprocal else _lib.PLAN_NO_RECIPROCAL) | (_lib.PLAN_JIT if jit else 0)
+        if prob.rx_apod is not None:
+            d.rx_apod_kind = prob.rx_apod["kind"]
+            d.rx_apod_p[0], d.rx_apod_p[1] = prob.rx_apod["p"]
+            self._bufs.append(up(prob.rx_apod["normals"]))
+            d.rx_normals = ptr(self._bufs[-1])
+        self._desc = d
+        self._h = C.c_void_p()
+        devs = (C.c_int * len(self.devices))(*self.devices)
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.qdas_plan_create_sharded(C.byref(self._h), C.byref(d), len(self.devices), devs))
+
+    def shards(self):
+        """[(device, i_begin, i_count, kernel name)] per slab"""
+        n = C.c_int()
+        _lib.check(self.lib.qdas_plan_sharded_info(self._h, -1, C.byref(n), None, None, None))
+        out = []
+        for g in range(n.value):
+            dv, b, c, k = C.c_int(), C.c_uint64(), C.c_uint64(), C.c_int()
+            _lib.check(self.lib.qdas_plan_sharded_info(self._h, g, C.byref(dv), C.byref(b), C.byref(c), C.byref(k)))
+            out.append((dv.value, int(b.value), int(c.value), _lib.KERNEL_NAMES.get(k.value, "-")))
+        return out
+
+    def execute_colmajor(self, xc):
+        """one frame: ``xc`` column-major channel data ``(M, N, T)`` on ``devices[0]`` -> ``(oM, oN, I)`` there"""
+        torch = _torch()
+        p = self.prob
+        oN, oM = p.osize
+        if xc.numel() != p.T * p.N * p.M or not xc.is_contiguous() or xc.device != self.device:
+            raise DasError("channel data size / device does not match the plan")
+        y = torch.empty((oM, oN, p.I), dtype=_data_dtype(p.prec), device=self.device)
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(self.lib.qdas_plan_execute_sharded(self._h, C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()), stream))
+        return y
+
+    def feval(self, x):
+        """``x`` (``T x N x M``, MATLAB order) -> ``I x [1|N] x [1|M]`` like ``k.feval`` at reference ``kern/das_spec.m:372``"""
+        xc = _colmajor(_cast_data(x, self.prob.prec, self.device))
+        return self.execute_colmajor(xc.reshape(*xc.shape[-3:])).permute(2, 1, 0)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.qdas_plan_destroy_sharded(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def __del__(self):  # pragma: no cover
         try:
             self.close()

@@ -660,3 +660,48 @@ def test_syn_mode_in_the_tiled_kernel(fun, seq, interp, extra, monkeypatch):
             ref = ref[kw["i_begin"]: kw["i_begin"] + kw["i_count"]]
         got = out[f].T                                             # count x planes
         assert np.abs(got - ref).max() / np.abs(ref).max() <= (1e-4 if seq == "FC" else 3e-5)
+
+
+@pytest.mark.parametrize("fun,ndev,mem", [("DAS", 2, "device"), ("DAS", 3, "device"), ("SYN", 2, "device"), ("BF", 2, "device"),
+                                          ("DAS", 2, "host"), ("MUL", 3, "host")])
+def test_sharded_c_abi_entry_on_one_device(fun, ndev, mem):
+    """qdas_plan_create_sharded / _execute_sharded (one host thread, N streams): with every shard on device 0 the slabs, the
+    replication bookkeeping and the plane-wise gather are exercised and the image must equal the single-plan image bit for bit"""
+    import ctypes as C
+    import torch
+    from qups_amd import DasPlan, MultiDevicePlan, _lib, build_problem, parse_options
+    case = make_case(seq="PW", interp="cubic", seed=41, N=10, M=6, I1=203, I2=11)      # I = 2233: ragged slabs
+    x = torch.from_numpy(case["x"])
+    opts = parse_options(x, list(case["opt"]) + ["interp", "cubic"])
+    T, N, M = case["x"].shape
+    prob = build_problem(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], (T, N, M), case["t0"], case["fs"], case["c"], opts)
+    one = DasPlan(prob)
+    y1 = one.feval(x)
+    if mem == "device":
+        mp = MultiDevicePlan(prob, devices=[0] * ndev)
+        sh = mp.shards()
+        assert len(sh) == ndev and sum(c for _, _, c, _ in sh) == prob.I and [b for _, b, _, _ in sh] == [prob.I * g // ndev for g in range(ndev)]
+        y2 = mp.feval(x)
+        y3 = mp.feval(x)                                  # plan reuse
+        torch.cuda.synchronize()
+        assert torch.equal(y2, y1) and torch.equal(y3, y1)
+        mp.close()
+    else:                                                 # host-resident inputs through the same entry (what the MEX gateway passes)
+        L = _lib.lib()
+        d = _lib.Desc()
+        keep = [np.ascontiguousarray(a) for a in (prob.Pi, prob.Pr, prob.Pv, prob.Nv, prob.cinv)]
+        acs = (C.c_uint64 * len(prob.acstride))(*[int(v) for v in prob.acstride])
+        d.sz = _lib.Sizes(prob.T, prob.N, prob.M, *prob.Isz, prob.S, prob.flag, int(prob.VS), int(prob.DV), 1)
+        d.fs, d.fmod = prob.fs, prob.fmod
+        d.Pi, d.Pr, d.Pv, d.Nv, d.cinv = (a.ctypes.data for a in keep)
+        d.acstride, d.mem, d.kernel, d.device = acs, _lib.MEM_HOST, 0, 0
+        h = C.c_void_p()
+        devs = (C.c_int * ndev)(*([0] * ndev))
+        _lib.check(L.qdas_plan_create_sharded(C.byref(h), C.byref(d), ndev, devs))
+        xh = np.ascontiguousarray(case["x"].astype(np.complex64).transpose(2, 1, 0))        # column-major T x N x M
+        oN, oM = prob.osize
+        yh = np.empty((oM, oN, prob.I), np.complex64)
+        _lib.check(L.qdas_plan_execute_sharded(h, xh.ctypes.data, yh.ctypes.data, None))
+        L.qdas_plan_destroy_sharded(h)
+        assert np.array_equal(yh.transpose(2, 1, 0), y1.cpu().numpy())
+    one.close()
