@@ -233,6 +233,31 @@ typedef struct qdas_lut_desc {
 } qdas_lut_desc;
 int qdas_das_lut(const qdas_lut_desc *d, const void *x, void *y, void *stream);
 
+/* ---- General single-delay flavour: weighted, phase-rotated sampling over an N-D broadcast index space.  Replaces the launches of
+ *      wsinterpd[f|h] (reference kern/wsinterpd.m:221-236, kernel src/interpd.cu:295-342) and interpd[f|h] (kern/interpd.m,
+ *      src/interpd.cu:169-192) -- what ChannelData.sample (src/ChannelData.m:1230-1336) and focusTx run on:
+ *        y[kept] = sum over summed dims of  w[j] * exp(i*omega*t[j]) * sample(x[:, j], t[j])        (t in samples, 0-based)
+ *      The index space has ndim <= 8 dimensions of sizes size[]; dimension 0 is the sampling dimension (size[0] samples of t
+ *      against T samples of x).  t, w and the trace bases of x address it through element strides (0 = broadcast): the reference's
+ *      matching / outer dimension classification (kern/wsinterpd.m:70-93) reduces to these.  y is dense, column-major over the kept
+ *      dimensions (summed ones have size 1).  Infinite t are skipped; samples outside the record give `extrap` (NaN allowed; sums
+ *      omit NaN like the reference's sum(..., 'omitnan')).  All pointers are device pointers of `dtype` (t: double | float | float). */
+typedef struct qdas_wsinterpd_desc {
+    uint64_t T;               /* samples per trace of x                                             */
+    uint64_t x_tstride;       /* element stride between consecutive samples of a trace (1: contiguous) */
+    int32_t  ndim;            /* 1..8                                                               */
+    int32_t  flag;            /* QDAS_INTERP_*                                                      */
+    int32_t  dtype;           /* QDAS_F64 | QDAS_F32 | QDAS_F16                                     */
+    int32_t  w_real;          /* weights are real(prec)                                             */
+    uint64_t size[8];
+    int64_t  tstride[8], xstride[8], wstride[8];   /* xstride[0] must be 0 (the sampling dimension indexes t, not x) */
+    uint8_t  sum[8];          /* 1: summed dimension                                                */
+    double   omega;           /* imag(omega)                                                        */
+    double   extrap;          /* value of out-of-record samples                                     */
+    const void *t, *w, *x;    /* w may be NULL                                                      */
+} qdas_wsinterpd_desc;
+int qdas_wsinterpd(const qdas_wsinterpd_desc *d, void *y, void *stream);
+
 /* ---- misc */
 /* ---- Point-scatterer channel-data simulator: replaces the kernels greens / greensf
  * (reference src/greens.cu:88-121, body :8-86) launched by UltrasoundSystem.greens

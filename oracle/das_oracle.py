@@ -450,3 +450,136 @@ def ap_aperture_growth(Pi, Pr, ang=None, f=1.5, Dmax=np.inf):
     apod = (z > f * np.abs(2 * d)).astype(np.float64)                          # :5255
     apod = apod * (np.abs(2 * d) < Dmax)                                       # :5256
     return apod[..., None]
+
+
+# --------------------------------------------------------------------------
+# general single-delay flavour: kern/wsinterpd.m (CPU branch :240-274), kern/interpd.m
+# --------------------------------------------------------------------------
+def wsinterpd(x, t, dim=1, w=1, sdim=None, interp="linear", extrapval=np.nan, omega=0):
+    """``y = wsinterpd(x, t, dim, w, sdim, interp, extrapval, omega)`` restated with numpy broadcasting.
+
+    After swapping ``dim`` with dimension 1 (``kern/wsinterpd.m:54-60``): ``x`` is ``T x ...``, ``t`` is ``I x ...``; every data
+    dimension matches or is singleton in one of them (``:63-69``).  ``y = sum_sdim( exp(omega*t) .* w .* interp1(x, 1+t, interp,
+    extrapval), 'omitnan')`` (``:262``) with the interpolators of ``src/interpd.cu:68-150`` (edge rule of this repository:
+    a sample is in the record iff all taps are in ``[0, T)`` and ``t >= 0``).  Infinite ``t`` contribute nothing
+    (``src/interpd.cu:333``)."""
+    x, t = np.asarray(x), np.asarray(t, dtype=np.float64)
+    wa = np.asarray(w)
+    nd = max(x.ndim, t.ndim, wa.ndim, dim)
+    pad = lambda a: a.reshape(a.shape + (1,) * (nd - a.ndim))
+    sw = lambda a: np.swapaxes(a, 0, dim - 1)
+    x, t, wa = sw(pad(x)), sw(pad(t)), sw(pad(wa))
+    sd = [] if sdim is None else [int(v) for v in np.atleast_1d(sdim)]
+    sd = [dim if v == 1 else (1 if v == dim else v) for v in sd]
+    sd = [v for v in sd if v <= nd and not (x.shape[v - 1] == 1 and t.shape[v - 1] == 1)]      # kern/wsinterpd.m:73
+    val = sample(x, t, interp)                                   # I x broadcast(data dims): out of record -> 0
+    # in-record mask (for extrapval): recompute support like sample()
+    T = x.shape[0]
+    tb = np.broadcast_to(t, val.shape)
+    fin = np.isfinite(tb)
+    s0 = np.where(fin, tb, -1.0)
+    if interp == "nearest":
+        inrec = fin & (s0 >= 0) & (np.floor(s0 + 0.5) < T)
+    else:
+        off, wk = interp_weights(s0 - np.floor(s0), interp)
+        first = np.floor(s0).astype(np.int64) + off
+        inrec = fin & (s0 >= 0) & (first >= 0) & (first + wk.shape[0] - 1 < T)
+    val = np.where(inrec, val, extrapval).astype(np.complex128)
+    val = np.where(np.isinf(tb), 0.0, val)                      # infinite delays are skipped
+    if omega != 0:
+        val = val * np.exp(omega * np.where(fin, tb, 0.0))
+    val = val * wa
+    if sd:
+        val = np.where(np.isnan(val), 0.0, val)                  # 'omitnan'
+        val = val.sum(axis=tuple(v - 1 for v in sd), keepdims=True)
+    return sw(val)
+
+
+def interpd(x, t, dim=1, interp="linear", extrapval=np.nan):
+    """``kern/interpd.m``: ``wsinterpd`` without weights / sums"""
+    return wsinterpd(x, t, dim, 1, None, interp, extrapval, 0)
+
+
+# --------------------------------------------------------------------------
+# Sequence.delays / apodization (src/Sequence.m:888-1006), ChannelData.zeropad / rectifyt0 (src/ChannelData.m:1153-1228),
+# UltrasoundSystem.focusTx (src/UltrasoundSystem.m:3374-3503)
+# --------------------------------------------------------------------------
+def sequence_delays(seq_type, tx_pos, focus=None, c0=1540.0):
+    """``tau = seq.delays(tx)`` (N x S), ``src/Sequence.m:888-931``"""
+    p = np.asarray(tx_pos, float)                                # 3 x N
+    N = p.shape[1]
+    if seq_type == "FSA":
+        return np.zeros((N, N))
+    f = np.asarray(focus, float)                                 # 3 x S
+    if seq_type == "PW":
+        return -(f[:, None, :] * p[:, :, None]).sum(0) / c0      # :914
+    v = f[:, None, :] - p[:, :, None]                            # element -> focus, 3 x N x S
+    tau = np.sqrt((v ** 2).sum(0)) / c0
+    if seq_type == "FC":
+        s = 1.0
+    elif seq_type == "DV":
+        s = -1.0
+    elif seq_type == "VS":                                       # :908: behind the transducer -> negative
+        s = np.where(np.all(f[2][None, :] > p[2][:, None], axis=0), 1.0, -1.0)[None, :]
+    else:
+        raise ValueError(seq_type)
+    return tau * s
+
+
+def sequence_apodization(seq_type, N, S):
+    """``src/Sequence.m:953-975``"""
+    return np.eye(N) if seq_type == "FSA" else np.ones((N, S))
+
+
+def zeropad(x, t0, fs, B=0, A=0):
+    """``src/ChannelData.m:1153-1183``: B zeros in front (t0 moves back), A behind; time is axis 0"""
+    x = np.asarray(x)
+    z = lambda n: np.zeros((n,) + x.shape[1:], x.dtype)
+    return np.concatenate([z(B), x, z(A)], 0), np.asarray(t0, float) - B / fs
+
+
+def rectifyt0(x, t0, fs, interp="cubic", index_dtype=np.float64):
+    """``src/ChannelData.m:1205-1228`` for data ``T x N x M`` and ``t0`` of shape ``1 x 1 x M``: one start time for all transmits.
+    (Mirrors the reference including its length: the time axis is extended by npad twice, ``:1220-1222``.)  ``index_dtype``:
+    precision the sample indices are rounded to before sampling -- ``float32`` for single-precision data, as ``wsinterpd`` casts
+    them (``kern/wsinterpd.m:128-130``); at whole-sample offsets the record edge depends on it."""
+    t0 = np.asarray(t0, float)
+    if t0.size == 1:
+        return np.asarray(x), float(t0.reshape(-1)[0])
+    t0_ = float(t0.min())
+    npad = int(np.ceil((t0 - t0_).max() * fs))
+    xp, _ = zeropad(x, t0, fs, 0, npad)
+    T2 = xp.shape[0]
+    tau = t0_ + np.arange(T2 + npad).reshape(-1, 1, 1) / fs
+    ntau = ((tau - t0.reshape(1, 1, -1)) * fs).astype(index_dtype)      # the device kernels take the indices in the data precision
+    y = wsinterpd(xp, ntau, 1, 1, None, interp, 0.0, 0)
+    return y, t0_
+
+
+def focus_tx(x, t0, fs, tau_seq, apd, interp="cubic", buffer=0):
+    """``chd = focusTx(us, chd, seq)``: synthesise a sequence's transmits from full-synthetic-aperture data ``x`` (``T x N x M``).
+
+    ``tau_seq = seq.delays(tx)`` (M x M'), ``apd = seq.apodization(tx)`` ([1|M] x [1|M']).  Reference
+    ``src/UltrasoundSystem.m:3457-3502``: ``tau = -delays``; the time axis is shifted / extended to hold every delayed trace
+    (``:3463-3470``); ``z[t', n, m'] = sum_m apd[m, m'] * x(time[t'] - tau[m, m'], n, m)`` via ``sample2sep`` (``:3498``)."""
+    x = np.asarray(x)
+    T, N, M = x.shape
+    tau = -np.asarray(tau_seq, float)
+    apd = np.broadcast_to(np.asarray(apd, float), tau.shape)
+    i = apd != 0
+    nmin = int(np.floor(np.nanmin(tau[i]) * fs))
+    nmax = int(np.ceil(np.nanmax(tau[i]) * fs))
+    t0n = float(np.asarray(t0).reshape(-1)[0]) + nmin / fs
+    tau = tau - nmin / fs
+    xp, _ = zeropad(x, t0n, fs, 0, (nmax - nmin) + int(buffer))
+    T2 = xp.shape[0]
+    Mp = tau.shape[1]
+    z = np.zeros((T2, N, Mp), np.complex128)
+    tt = np.arange(T2, dtype=np.float64)
+    for mp in range(Mp):
+        for m in range(M):
+            if apd[m, mp] == 0:
+                continue
+            s = tt - tau[m, mp] * fs                              # (time - tau - t0) * fs
+            z[:, :, mp] += apd[m, mp] * sample(xp[:, :, m], s[:, None], interp)
+    return z, t0n

@@ -32,7 +32,7 @@ SYMBOLS = (
     "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_reciprocal", "qdas_plan_kernel_name", "qdas_plan_set_timing",
     "qdas_plan_last_kernel_ms", "qdas_plan_create_sharded", "qdas_plan_execute_sharded", "qdas_plan_sharded_info",
     "qdas_plan_destroy_sharded", "qdas_DAS", "qdas_DASf", "qdas_DASh", "qdas_delays", "qdas_delaysf",
-    "qdas_das_lut", "qdas_greens", "qdas_convd", "qdas_convd_len", "qdas_permute3", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_last_error", "qdas_version", "qdas_device_info",
+    "qdas_das_lut", "qdas_wsinterpd", "qdas_greens", "qdas_convd", "qdas_convd_len", "qdas_permute3", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_last_error", "qdas_version", "qdas_device_info",
 )
 
 
@@ -57,6 +57,13 @@ class LutDesc(C.Structure):
                 ("flag", C.c_int32), ("dtype", C.c_int32), ("omega", C.c_double),
                 ("tau_rx", C.c_void_p), ("tau_tx", C.c_void_p), ("w", C.c_void_p),
                 ("wstride", C.c_uint64 * 3), ("w_real", C.c_int32), ("reserved", C.c_int32), ("I1", C.c_uint64)]
+
+
+class WsDesc(C.Structure):
+    _fields_ = [("T", C.c_uint64), ("x_tstride", C.c_uint64), ("ndim", C.c_int32), ("flag", C.c_int32), ("dtype", C.c_int32),
+                ("w_real", C.c_int32), ("size", C.c_uint64 * 8), ("tstride", C.c_int64 * 8), ("xstride", C.c_int64 * 8),
+                ("wstride", C.c_int64 * 8), ("sum", C.c_uint8 * 8), ("omega", C.c_double), ("extrap", C.c_double),
+                ("t", C.c_void_p), ("w", C.c_void_p), ("x", C.c_void_p)]
 
 
 class GreensDesc(C.Structure):
@@ -124,6 +131,7 @@ def lib():
     L.qdas_plan_destroy_sharded.argtypes = [C.c_void_p]
     L.qdas_plan_destroy_sharded.restype = None
     L.qdas_das_lut.argtypes = [C.POINTER(LutDesc), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.qdas_wsinterpd.argtypes = [C.POINTER(WsDesc), C.c_void_p, C.c_void_p]
     L.qdas_greens.argtypes = [C.POINTER(GreensDesc), C.c_void_p, C.c_void_p]
     L.qdas_convd.argtypes = [C.POINTER(ConvdDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.qdas_permute3.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]

@@ -927,6 +927,32 @@ extern "C" int qdas_das_lut(const qdas_lut_desc *d, const void *x, void *y, void
     return QDAS_OK;
 }
 
+extern "C" int qdas_wsinterpd(const qdas_wsinterpd_desc *d, void *y, void *stream) {
+    if (!d || !y) return fail(QDAS_EINVAL, "null argument");
+    if (d->dtype < QDAS_F64 || d->dtype > QDAS_F16) return fail(QDAS_EINVAL, "Unrecognized input precision %d", d->dtype);
+    if ((d->flag & 7) > 5 || (d->flag & ~7)) return fail(QDAS_EINVAL, "Interp option not recognized: %d", d->flag);
+    if (d->ndim < 1 || d->ndim > 8) return fail(QDAS_EINVAL, "wsinterpd: 1..8 dimensions");
+    if (d->xstride[0] != 0) return fail(QDAS_EINVAL, "wsinterpd: xstride[0] must be 0 (dimension 0 is the sampling dimension)");
+    WsParams p{};
+    p.t = d->t; p.w = d->w; p.x = d->x; p.y = y;
+    p.T = d->T; p.x_tstride = d->x_tstride ? d->x_tstride : 1; p.nd = d->ndim;
+    p.n_out = 1; p.n_sum = 1;
+    for (int k = 0; k < d->ndim; ++k) {
+        p.size[k] = d->size[k]; p.tst[k] = d->tstride[k]; p.xst[k] = d->xstride[k]; p.wst[k] = d->wstride[k]; p.sum[k] = d->sum[k] ? 1 : 0;
+        if (p.sum[k]) { p.n_sum *= d->size[k]; p.any_sum = 1; } else p.n_out *= d->size[k];
+    }
+    p.omega = d->omega; p.extrap = d->extrap; p.flag = d->flag; p.w_real = d->w_real;
+    if (p.n_out == 0) return QDAS_OK;
+    if (p.n_out >= (1ull << 39)) return fail(QDAS_EUNSUPPORTED, "wsinterpd: too many outputs for one launch");
+    hipStream_t s = (hipStream_t)stream;
+    if (p.n_sum == 0 || d->T == 0) {                     // empty sums / empty record
+        if (p.n_sum == 0 || p.any_sum || d->extrap == 0.0) { HIPCHK(hipMemsetAsync(y, 0, p.n_out * data_size(d->dtype), s)); return QDAS_OK; }
+    }
+    if (!d->t || (!d->x && d->T)) return fail(QDAS_EINVAL, "null data / delay pointer");
+    HIPCHK(launch_wsinterpd(p, d->dtype, s));
+    return QDAS_OK;
+}
+
 extern "C" int qdas_greens(const qdas_greens_desc *d, void *y, void *stream) {
     if (!d || !y) return fail(QDAS_EINVAL, "null argument");
     if (d->dtype != QDAS_F64 && d->dtype != QDAS_F32) return fail(QDAS_EINVAL, "greens: datatype must be double or single");

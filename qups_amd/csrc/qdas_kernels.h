@@ -52,6 +52,21 @@ struct LutParams {
 };
 hipError_t launch_lut(const LutParams &P, int dtype, hipStream_t s);
 
+// ---- general single-delay flavour over an N-D broadcast index space (wsinterpd.hip)
+struct WsParams {
+    const void *t, *w, *x;
+    void *y;
+    uint64_t T, x_tstride;           // samples per trace of x, element stride between consecutive samples
+    int32_t nd;                      // dimensions of the index space (<= 8); dimension 0 is the sampling dimension
+    uint64_t size[8];
+    int64_t tst[8], xst[8], wst[8];  // element strides of t / x (trace base) / w per dimension; 0 = broadcast
+    uint8_t sum[8];                  // 1: the dimension is summed
+    uint64_t n_out, n_sum;           // product of the kept / summed sizes
+    double omega, extrap;
+    int32_t flag, w_real, any_sum;
+};
+hipError_t launch_wsinterpd(const WsParams &P, int dtype, hipStream_t s);
+
 // ---- point-scatterer simulator (greens.hip)
 struct GreensParams {
     const void *Ps, *a, *Pr, *Pv, *x;

@@ -1,0 +1,123 @@
+// wsinterpd.hip -- the general single-delay flavour: weighted, phase-rotated sampling over an N-D broadcast index space.
+//
+// Computes what reference kern/wsinterpd.m (and kern/interpd.m: no weights, no sums) computes on the device
+// (kernel bodies reference src/interpd.cu:295-342 wsinterpd_temp, :169-192 interpd_temp; launches kern/wsinterpd.m:221-236,
+// kern/interpd.m) -- the entry behind ChannelData.sample (src/ChannelData.m:1230-1336) and everything built on it:
+//
+//     y[j_kept] = sum over the summed dimensions of   w[j] * exp(i*omega*t[j]) * sample(x[:, j], t[j])
+//
+// where j runs over an index space of up to 8 dimensions; dimension 0 is the sampling dimension (I samples of t against T samples
+// of x), and each of t, w, x addresses it through its own element strides (0 = broadcast) -- the reference's matching / outer
+// dimension classification (kern/wsinterpd.m:70-93) boils down to exactly these strides.  Differences by design: every output is
+// OWNED by one lane and summed in a fixed order (the reference adds with float atomics, src/interpd.cu:339); the summed dimensions
+// are the inner loop.  Infinite t are skipped (src/interpd.cu:333); out-of-record samples yield `extrap` (the kernels' no_v), which
+// sums treat like MATLAB's sum(..., 'omitnan') when it is NaN (kern/wsinterpd.m:262).
+#include "qdas_device.h"
+#include "qdas_kernels.h"
+
+namespace qdas {
+
+template <int INTERP, typename R, typename ST>
+__device__ __forceinline__ bool sample_strided(const ST *__restrict__ tr, long tstride, long T, R s, cplx<R> &out) {
+    out = {(R)0, (R)0};
+    if (!(s >= (R)0)) return false;                      // tau >= 0; rejects NaN
+    if constexpr (INTERP == 0) {                         // nearest (src/interpd.cu:70-72)
+        const R r = qfloor(s + (R)0.5);
+        if (!(r < (R)T)) return false;
+        out = ld(tr, (size_t)((long)r * tstride));
+        return true;
+    } else {
+        const R fl = qfloor(s);
+        constexpr int K = interp_taps(INTERP);
+        constexpr int OFF = (K == 2) ? 0 : -1;
+        if (!(fl + (R)(K - 1 + OFF) < (R)T) || fl + (R)OFF < (R)0) return false;   // all taps in [0,T); rejects +inf
+        const long first = (long)fl + OFF;
+        R w[4];
+        interp_weights<INTERP>(s - fl, w);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const cplx<R> v = ld(tr, (size_t)((first + k) * tstride));
+            out.x += w[k] * v.x; out.y += w[k] * v.y;
+        }
+        return true;
+    }
+}
+
+template <int INTERP, typename TY>
+__global__ void __launch_bounds__(256) wsinterpd_kernel(const WsParams P) {
+    using R  = typename TY::real;
+    using ST = typename TY::store;
+    using AR = typename TY::apod_real_t;
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= P.n_out) return;
+    const R *__restrict__ t = (const R *)P.t;
+    const ST *__restrict__ x = (const ST *)P.x;
+    // kept dimensions: decode the output index (dense, column-major over the kept dimensions)
+    int64_t tb = 0, xb = 0, wb = 0;
+    {
+        uint64_t q = o;
+        for (int d = 0; d < P.nd; ++d) {
+            if (P.sum[d]) continue;
+            const uint64_t k = q % P.size[d];
+            q /= P.size[d];
+            tb += (int64_t)k * P.tst[d]; xb += (int64_t)k * P.xst[d]; wb += (int64_t)k * P.wst[d];
+        }
+    }
+    const R omega = (R)P.omega;
+    const bool skip_nan = P.any_sum && !(P.extrap == P.extrap);      // sums omit NaN (kern/wsinterpd.m:262)
+    cplx<R> acc = {(R)0, (R)0};
+    for (uint64_t r = 0; r < P.n_sum; ++r) {
+        int64_t to = tb, xo = xb, wo = wb;
+        uint64_t q = r;
+        for (int d = 0; d < P.nd; ++d) {
+            if (!P.sum[d]) continue;
+            const uint64_t k = q % P.size[d];
+            q /= P.size[d];
+            to += (int64_t)k * P.tst[d]; xo += (int64_t)k * P.xst[d]; wo += (int64_t)k * P.wst[d];
+        }
+        const R tau = t[to];
+        if (!(fabs((double)tau) <= 1.0e300) && tau == tau) continue;              // +-inf: excluded (src/interpd.cu:333)
+        cplx<R> v;
+        if (!sample_strided<INTERP, R, ST>(x + xo, (long)P.x_tstride, (long)P.T, tau, v)) {
+            if (skip_nan) continue;
+            v = {(R)P.extrap, (R)0};
+        }
+        if (omega != (R)0) {                                                       // src/interpd.cu:334
+            R sn, cs;
+            if constexpr (sizeof(R) == 8) sincos((double)(omega * tau), (double *)&sn, (double *)&cs);
+            else sincosf((float)(omega * tau), (float *)&sn, (float *)&cs);
+            v = cmul(v, cplx<R>{cs, sn});
+        }
+        if (P.w) {
+            if (P.w_real) { const R w = (R)ldr((const AR *)P.w, (size_t)wo); v.x *= w; v.y *= w; }
+            else v = cmul(v, ld((const ST *)P.w, (size_t)wo));
+        }
+        acc.x += v.x; acc.y += v.y;
+    }
+    st((ST *)P.y, (size_t)o, acc);
+}
+
+template <typename TY> static hipError_t launch_ws_t(const WsParams &P, hipStream_t s) {
+    const dim3 g((unsigned)((P.n_out + 255) / 256)), b(256);
+    switch (P.flag & 7) {
+        case 0: wsinterpd_kernel<0, TY><<<g, b, 0, s>>>(P); break;
+        case 1: case 4: wsinterpd_kernel<1, TY><<<g, b, 0, s>>>(P); break;
+        case 2: wsinterpd_kernel<2, TY><<<g, b, 0, s>>>(P); break;
+        case 3: wsinterpd_kernel<3, TY><<<g, b, 0, s>>>(P); break;
+        case 5: wsinterpd_kernel<5, TY><<<g, b, 0, s>>>(P); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_wsinterpd(const WsParams &P, int dtype, hipStream_t s) {
+    if (P.n_out == 0) return hipSuccess;
+    switch (dtype) {
+        case 0: return launch_ws_t<st_f64>(P, s);
+        case 1: return launch_ws_t<st_f32>(P, s);
+        case 2: return launch_ws_t<st_f16>(P, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace qdas

@@ -174,3 +174,112 @@ def wsinterpd2(x, t1, t2, dim=1, w=1, sdim=None, interp="linear", extrapval=0, o
     wt = None if (np.isscalar(w) and w == 1) else pad3(mv(w))
     y = das_lut(xb, rx, tx, interp=interp, w=wt, keep_rx=2 not in sd, keep_tx=3 not in sd, omega=float(np.imag(omega)), **kw)
     return y.movedim(0, dim - 1) if dim != 1 else y
+
+
+# ------------------------------------------------------------------------------------------
+# General single-delay flavour (reference kern/wsinterpd.m, kern/interpd.m): one delay array t that may depend on every
+# dimension; matching / outer dimensions of x and t broadcast against each other.  Runs on qdas_wsinterpd (csrc/wsinterpd.hip).
+# ------------------------------------------------------------------------------------------
+def _pad_shape(shape, nd):
+    return tuple(shape) + (1,) * (nd - len(shape))
+
+
+def _col_strides(shape):
+    """element strides of a column-major array, 0 on singleton dimensions (kern/wsinterpd.m:106-116)"""
+    st, acc = [], 1
+    for s in shape:
+        st.append(0 if s == 1 else acc)
+        acc *= s
+    return st
+
+
+def wsinterpd(x, t, dim=1, w=1, sdim=None, interp="linear", extrapval=float("nan"), omega=0, prec=None, device=None):
+    """``y = wsinterpd(x, t, dim, w, sdim, interp, extrapval, omega)`` -- reference ``kern/wsinterpd.m:1-43``.
+
+    ``x`` is ``T x N' x F'``, ``t`` is ``I x N' x M'`` (sample indices, 0-based: ``x(1)`` in MATLAB is ``t == 0``) after swapping
+    ``dim`` (1-based) with dimension 1; matching dimensions are sampled element-wise, dimensions that are singleton in one of the
+    two broadcast (``:70-93``); ``w`` (sizes 1 or full, ``:84-88``) multiplies the samples, ``exp(omega .* t)`` rotates them
+    (``omega`` purely imaginary on the device, ``:102``), dimensions ``sdim`` are summed.  Result ``I x N' x M' x F'`` with the
+    summed dimensions singleton, ``dim`` swapped back.  ``extrapval`` is the value of samples outside the record (``NaN`` by
+    default as in the reference; sums omit NaN, ``:262``)."""
+    torch = _torch()
+    L = _lib.lib()
+    if not torch.cuda.is_available():
+        raise RuntimeError("qups_amd: no HIP device visible -- the sampling path has no CPU fallback")
+    if interp not in _lib.INTERP_FLAGS:
+        raise DasError("Interp option not recognized: " + str(interp))
+    if np.real(omega) != 0:
+        raise DasError("omega must be purely imaginary on the device path.")
+    if np.ndim(extrapval) != 0 or np.iscomplexobj(extrapval):
+        raise DasError("Only a scalar value accepted for extrapolation.")
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    as_t = lambda a: a if _is_torch(a) else torch.from_numpy(np.asarray(a))
+    xt, tt = as_t(x), as_t(t)
+    if tt.is_complex():
+        raise DasError("Sample indices must be real.")
+    if prec is None:
+        from .das_spec import _default_prec
+        prec = _default_prec(xt)
+    wscalar = not _is_torch(w) and np.ndim(w) == 0
+    wt = None if (wscalar and w == 1) else as_t(np.asarray(w) if not _is_torch(w) else w)
+    nd = max(xt.ndim, tt.ndim, wt.ndim if wt is not None else 0, dim)
+    if nd > 8:
+        raise DasError("At most 8 dimensions are supported.")
+    pad = lambda a: a.reshape(_pad_shape(a.shape, nd))
+    sw = lambda a: a.transpose(0, dim - 1) if dim != 1 else a          # swapdim(a, dim, 1)
+    xt, tt = sw(pad(xt)), sw(pad(tt))
+    if wt is not None:
+        wt = sw(pad(wt))
+    sd = [] if sdim is None else [int(v) for v in np.atleast_1d(sdim)]
+    sd = [dim if v == 1 else (1 if v == dim else v) for v in sd]        # the same swap for the summed dimensions
+    if any(v < 1 for v in sd):
+        raise DasError("Summation dimensions must be positive.")
+    # summation over dimensions that are singleton in x and t is a no-op (kern/wsinterpd.m:73)
+    sd = [v for v in sd if v <= nd and not (xt.shape[v - 1] == 1 and tt.shape[v - 1] == 1)]
+    T, I = xt.shape[0], tt.shape[0]
+    size = [I]
+    for d in range(1, nd):
+        xs, ts = xt.shape[d], tt.shape[d]
+        if xs != ts and xs != 1 and ts != 1:
+            raise DasError(f"Delay size must match the data size ({xs}) or be singleton in dimension {d + 1}.")
+        size.append(max(xs, ts))
+    if wt is not None and (wt.shape[0] not in (1, I) or any(ws not in (1, fs_) for ws, fs_ in zip(wt.shape[1:], size[1:]))):
+        raise DasError("The weighting vector w must have dimensions compatible with the data and may not broadcast.")
+    xd = _cast_data(xt, prec, dev)
+    rt = _real_dtype(prec)
+    td = tt.to(dev).to(rt)
+    xc, tc = _colmajor(xd), _colmajor(td)
+    d = _lib.WsDesc()
+    d.T, d.x_tstride, d.ndim, d.flag, d.dtype = T, 1, nd, _lib.INTERP_FLAGS[interp], _PREC[prec]
+    xs_ = _col_strides(xt.shape)
+    xs_[0] = 0
+    ts_ = _col_strides(tt.shape)
+    for k in range(nd):
+        d.size[k], d.tstride[k], d.xstride[k] = size[k], ts_[k], xs_[k]
+        d.sum[k] = 1 if (k + 1) in sd else 0
+    wc = None
+    if wt is not None:
+        real = not wt.is_complex()
+        wt = wt.to(dev)
+        if prec == "halfT":
+            wt = wt.to(torch.float16) if real else torch.view_as_complex(torch.view_as_real(wt.to(torch.complex64)).to(torch.float16).contiguous())
+        else:
+            wt = wt.to(rt if real else (torch.complex128 if prec == "double" else torch.complex64))
+        wc = _colmajor(wt).contiguous()
+        for k, v in enumerate(_col_strides(wt.shape)):
+            d.wstride[k] = v
+        d.w, d.w_real = wc.data_ptr(), int(real)
+    d.omega, d.extrap = float(np.imag(omega)), float(extrapval)
+    d.t, d.x = tc.data_ptr(), xc.data_ptr()
+    osz = [1 if (k + 1) in sd else size[k] for k in range(nd)]
+    from .das_spec import _data_dtype
+    y = torch.empty(tuple(reversed(osz)), dtype=_data_dtype(prec), device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.qdas_wsinterpd(C.byref(d), C.c_void_p(y.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    y = y.permute(*reversed(range(nd)))
+    return sw(y)
+
+
+def interpd(x, t, dim=1, interp="linear", extrapval=float("nan"), **kw):
+    """``y = interpd(x, t, dim, interp, extrapval)`` -- reference ``kern/interpd.m:1-47``: ``wsinterpd`` without weights or sums."""
+    return wsinterpd(x, t, dim, 1, None, interp, extrapval, 0, **kw)

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import geometry as G
 from .das_spec import DasError, das_spec
-from .interpd import sample2sep
+from .interpd import sample2sep, wsinterpd
 
 
 @dataclass
@@ -52,6 +52,34 @@ class Sequence:
     c0: float = 1540.0
     numPulse: int | None = None
 
+    def delays(self, tx: "Transducer"):
+        """``tau = delays(seq, tx)``: ``N x S`` transmit delays (reference ``src/Sequence.m:888-931``): FC ``+|focus - p|/c0``,
+        DV the negative, VS signed by whether every element lies in front of the focus, PW ``-(n . p)/c0``, FSA zeros."""
+        p = np.asarray(tx.positions(), float)
+        N = p.shape[1]
+        if self.type == "FSA":
+            return np.zeros((N, N))
+        f = np.asarray(self.focus, float)
+        if self.type == "PW":
+            return -(f[:, None, :] * p[:, :, None]).sum(0) / self.c0
+        v = f[:, None, :] - p[:, :, None]
+        tau = np.sqrt((v ** 2).sum(0)) / self.c0
+        if self.type == "FC":
+            return tau
+        if self.type == "DV":
+            return -tau
+        if self.type == "VS":
+            return tau * np.where(np.all(f[2][None, :] > p[2][:, None], axis=0), 1.0, -1.0)[None, :]
+        raise DasError(f"Unknown sequence type {self.type!r}.")
+
+    def apodization(self, tx: "Transducer"):
+        """``N x S`` transmit apodization (reference ``src/Sequence.m:953-975``): identity for FSA, ones otherwise"""
+        N = tx.numel
+        if self.type == "FSA":
+            return np.eye(N)
+        S = self.numPulse or (np.asarray(self.focus).shape[1] if self.focus is not None else N)
+        return np.ones((N, S))
+
 
 @dataclass
 class Scan:
@@ -76,12 +104,76 @@ class Scan:
 
 @dataclass
 class ChannelData:
-    """``data`` is ``T x N x M x F...`` in ``order='TNM'`` (or ``T x M x N`` for ``'TMN'``); ``t0`` scalar or one value per
-    transmit; ``fs`` scalar (reference ``src/ChannelData.m``; ``rectifyDims`` / ``rectifyt0`` are the caller's job here)."""
+    """``data`` is ``T x N x M x F...`` in ``order='TNM'`` (any permutation of the three letters is accepted and put in order by
+    :meth:`rectifyDims`); ``t0`` scalar or one value per transmit (``1 x 1 x M``); ``fs`` scalar (reference ``src/ChannelData.m``)."""
     data: object
     t0: object = 0.0
     fs: float = 1.0
     order: str = "TNM"
+
+    # -- the pieces of ChannelData the DAS path calls
+    def _torch_data(self):
+        import torch
+        return self.data if hasattr(self.data, "is_cuda") else torch.from_numpy(np.asarray(self.data))
+
+    @property
+    def T(self):
+        return int(self.data.shape[self.order.index("T")])
+
+    def rectifyDims(self):
+        """``T x N x M x ...`` order (reference ``src/ChannelData.m:1895-1913``): permutes ``data`` (and a non-scalar ``t0``)"""
+        if self.order[:3] == "TNM":
+            return self
+        d = self._torch_data()
+        lead = [self.order.index(c) for c in "TNM"]
+        perm = lead + [k for k in range(max(d.ndim, 3)) if k not in lead]
+        d = d.reshape(tuple(d.shape) + (1,) * (len(perm) - d.ndim)).permute(*perm)
+        t0 = self.t0
+        if np.ndim(t0) > 0 and np.size(t0) > 1:
+            t0a = np.asarray(t0)
+            t0a = t0a.reshape(t0a.shape + (1,) * (len(perm) - t0a.ndim)).transpose(perm)
+            t0 = t0a
+        return ChannelData(d, t0, self.fs, "TNM")
+
+    def zeropad(self, B=0, A=0):
+        """``B`` zeros in front (``t0`` moves back by ``B/fs``), ``A`` behind, along time (reference ``src/ChannelData.m:1153-1183``)"""
+        import torch
+        if A < 0 or B < 0:
+            raise DasError("Data append or prepend size must be positive.")
+        if A == 0 and B == 0:
+            return self
+        d = self._torch_data()
+        ax = self.order.index("T")
+        z = lambda n: torch.zeros(tuple(d.shape[:ax]) + (n,) + tuple(d.shape[ax + 1:]), dtype=d.dtype, device=d.device)
+        return ChannelData(torch.cat([z(B), d, z(A)], ax), np.asarray(self.t0, float) - B / self.fs if np.ndim(self.t0) else float(self.t0) - B / self.fs,
+                           self.fs, self.order)
+
+    def sample(self, tau, interp="linear", w=1, sdim=None, fmod=0.0, **kw):
+        """``y = sample(chd, tau, interp, w, sdim, fmod)`` (reference ``src/ChannelData.m:1230-1336``): ``tau`` holds TIMES and
+        broadcasts against ``T x N x M x F...`` in every dimension but the first; sample indices ``(tau - t0) * fs`` (``:1317``),
+        upmix ``exp(2i pi fmod/fs * ntau)`` (``:1320``), then ``wsinterpd(data, ntau, 1, w, sdim, interp, 0, omega)`` (``:1327``)."""
+        import torch
+        chd = self.rectifyDims()
+        as_t = lambda a: a if hasattr(a, "is_cuda") else torch.from_numpy(np.asarray(a, dtype=np.float64))
+        tt = as_t(tau).to(torch.float64)
+        t0 = as_t(np.asarray(chd.t0, dtype=np.float64)).to(tt.device)
+        ntau = (tt - t0) * chd.fs
+        return wsinterpd(chd.data, ntau, 1, w, sdim, interp, 0.0, 2j * np.pi * fmod / chd.fs, **kw)
+
+    def rectifyt0(self, interp="cubic"):
+        """one start time for all transmits (reference ``src/ChannelData.m:1205-1228``): traces are resampled onto the earliest
+        ``t0``; the time axis grows by ``ceil(max(t0 - min t0) * fs)`` samples at zeropad and again in the sampling grid, as in
+        the reference (``:1220-1222``)."""
+        if np.size(self.t0) == 1:
+            return self
+        chd = self.rectifyDims()
+        t0 = np.asarray(chd.t0, float)
+        t0_ = float(t0.min())
+        npad = int(np.ceil((t0 - t0_).max() * chd.fs))
+        chd = chd.zeropad(0, npad)
+        nd = max(chd._torch_data().ndim, t0.ndim)
+        tau = t0_ + np.arange(chd.T + npad).reshape((-1,) + (1,) * (nd - 1)) / chd.fs
+        return ChannelData(chd.sample(tau, interp), t0_, chd.fs, "TNM")
 
 
 class UltrasoundSystem:
@@ -133,8 +225,10 @@ class UltrasoundSystem:
         c0 = self.seq.c0 if c0 is None else c0
         apods = list(apods) + ([] if (np.isscalar(apod) and apod == 1) else [apod])
         fun = {(True, True): "DAS", (True, False): "SYN", (False, True): "MUL", (False, False): "BF"}[(not keep_tx, not keep_rx)]   # :3318-3322
-        if chd.order not in ("TNM", "TMN"):
-            raise DasError("ChannelData must be ordered T x perm(N x M) x ... (use rectifyDims).")
+        if np.size(chd.t0) > 1 and np.asarray(chd.t0).reshape(-1).size != self._num_tx(chd):
+            chd = chd.rectifyt0()                              # t0 varies outside the transmit dimension   (:3330)
+        if chd.order[0] != "T" or chd.order[:3] not in ("TNM", "TMN"):
+            chd = chd.rectifyDims()                            # time is not the first dimension             (:3333)
         Pv, Nv, opt = self._tx_geometry()
         ext = ["device", device, "input-precision", prec, "transpose", chd.order == "TMN", "interp", interp, "modulation", fmod]   # :3336-3338
         for a in apods:
@@ -147,6 +241,40 @@ class UltrasoundSystem:
         nd = b.ndim
         b = b.permute(0, 1, 2, *range(5, nd), 3, 4)          # I1 x I2 x I3 x F... x [N] x [M]   (:3361)
         return (b, plan) if return_plan else b
+
+    def _num_tx(self, chd):
+        return int(chd.data.shape[chd.order.index("M")])
+
+    def focusTx(self, chd: ChannelData, seq: Sequence | None = None, interp="cubic", buffer=0):
+        """``chd = focusTx(us, chd, seq)`` (reference ``src/UltrasoundSystem.m:3374-3503``): synthesise the transmits of ``seq`` from
+        full-synthetic-aperture data by delaying and summing over the transmit elements,
+        ``z[t', n, m'] = sum_m apd[m, m'] * x(time[t'] - tau[m, m'], n, m)`` with ``tau = -seq.delays(tx)`` shifted so that all delays
+        are non-negative (``:3457-3470``).  One split-delay launch per synthesised transmit (``sample2sep`` at ``:3498``): the
+        "pixels" are the output time samples, the receive delay is the sample index, the transmit delay ``-tau*fs``."""
+        import torch
+        from .interpd import das_lut
+        seq = seq or self.seq
+        chd = chd.rectifyDims()
+        tau = -np.asarray(seq.delays(self.tx), float)            # M x M'
+        apd = np.broadcast_to(np.asarray(seq.apodization(self.tx), float), tau.shape)
+        if seq.type == "FSA" and not np.count_nonzero(tau) and np.array_equal(apd, np.eye(self.tx.numel)):
+            return chd                                             # already FSA (:3461)
+        i = apd != 0
+        nmin = int(np.floor(np.nanmin(tau[i]) * chd.fs))
+        nmax = int(np.ceil(np.nanmax(tau[i]) * chd.fs))
+        t0 = float(np.asarray(chd.t0).reshape(-1)[0]) + nmin / chd.fs
+        tau = tau - nmin / chd.fs
+        chd = ChannelData(chd.data, t0, chd.fs, "TNM").zeropad(0, (nmax - nmin) + int(buffer))
+        d = chd._torch_data()
+        T2, N, M = d.shape[:3]
+        dev = d.device if d.is_cuda else torch.device("cuda")
+        trx = torch.arange(T2, dtype=torch.float64, device=dev).reshape(T2, 1).expand(T2, N)
+        out = []
+        for mp in range(tau.shape[1]):
+            ttx = torch.from_numpy(-tau[:, mp] * chd.fs).to(dev).reshape(1, M).expand(T2, M)
+            out.append(das_lut(d, trx, ttx, interp=interp, w=apd[:, mp].reshape(1, 1, M), keep_rx=True, keep_tx=False))   # T' x N x 1 x F...
+        z = torch.cat(out, 2)
+        return ChannelData(z, t0, chd.fs, "TNM")
 
     # ------------------------------------------------------------------------------------
     def delay_tables(self, c0=None, device=None):
@@ -204,8 +332,8 @@ class UltrasoundSystem:
         ``tau_rx`` is ``I1 x I2 x I3 x N``, ``tau_tx`` is ``I1 x I2 x I3 x M`` (times).  Output
         ``I1 x I2 x I3 x F... x [N] x [M]``: the aperture dimensions are moved behind the frame dimensions exactly as the
         reference does (``:4663-4664``) -- the same layout as ``DAS`` (``:3361``)."""
-        if chd.order != "TNM":
-            raise DasError("bfDASLUT needs data ordered T x N x M (use rectifyDims).")
+        if chd.order[:3] != "TNM":
+            chd = chd.rectifyDims()
         Isz = self.scan.size
         tr, tt = np.asarray(tau_rx) if not hasattr(tau_rx, "shape") else tau_rx, tau_tx
         N, M = self.rx.numel, (self.seq.numPulse or tt.shape[-1])
