@@ -242,6 +242,18 @@ class UltrasoundSystem:
         b = b.permute(0, 1, 2, *range(5, nd), 3, 4)          # I1 x I2 x I3 x F... x [N] x [M]   (:3361)
         return (b, plan) if return_plan else b
 
+    def greens(self, scat_pos, scat_amp, waveform, wv_t0, wv_fs, fs=None, R0=None, interp="cubic", focus=True):
+        """``chd = greens(us, scat)`` (reference ``src/UltrasoundSystem.m:463-882``): full-synthetic-aperture channel data of point
+        scatterers from the simulator kernel, then -- like the reference's last step (``:877``) -- ``focusTx`` synthesises this
+        system's transmit sequence from it.  The transmit-receive waveform is an input (samples, start time, sampling frequency)."""
+        import torch
+        from .greens import greens as _greens
+        fs = fs or self.fs
+        y, t0 = _greens(self.rx.positions(), self.tx.positions(), scat_pos, scat_amp, self.seq.c0, waveform, wv_t0, wv_fs, fs,
+                        R0=R0, interp=interp)
+        chd = ChannelData(y.contiguous(), t0, fs, "TNM")
+        return self.focusTx(chd, self.seq, interp=interp) if focus else chd
+
     def _num_tx(self, chd):
         return int(chd.data.shape[chd.order.index("M")])
 

@@ -7,7 +7,7 @@ same data, and (b) through size-independent properties: linearity in the data, a
 import numpy as np
 import pytest
 
-from tests.cases import rel_err
+from tests.cases import cinv_f32, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -89,3 +89,48 @@ def test_config_linearity_and_slabs(name, monkeypatch):
     sl, plan8 = _run(prob, xa, i_begin=I * 3 // 8, i_count=I // 8)
     assert plan8.aperture_split() >= 2
     assert float((sl - ya.reshape(-1)[I * 3 // 8: I * 3 // 8 + I // 8].reshape(sl.shape)).abs().max()) / float(ya.abs().max()) <= 2e-5
+
+
+def test_c1_exactly_as_named_greens_focusTx_bfDAS():
+    """BASELINE config C1 end to end, as BASELINE.json names it: 64-element linear array (L7-4-like), 32-transmit focused
+    sequence, 256 x 256 ScanCartesian, synthetic point scatterers via greens() -> focusTx -> bfDAS with linear interpolation.
+    Checks: (1) the reference's integration criterion (test/BFTest.m:306-316: non-zero image, peak within 1.1 mm of a scatterer),
+    (2) bfDAS (split-delay flavour) == DAS (fused kernel) on the same synthesised data, (3) both == the float64 oracle fed with
+    the same channel data, (4) focusTx == its oracle restatement."""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import ChannelData, Scan, Sequence, Transducer, UltrasoundSystem
+    from qups_amd.configs import workload
+    w = workload("c1")
+    fc, c0, fs = 5.208e6, w["c0"], w["fs"]
+    N = w["N"]
+    xdc = Transducer(w["Pr"], w["nrm"], fc)
+    focus = w["Pv"][:3]                                            # 32 foci at z = 30 mm (walking aperture)
+    seq = Sequence("FC", focus=focus, c0=c0, numPulse=focus.shape[1])
+    scan = Scan(w["Pi"])
+    us = UltrasoundSystem(xdc, seq, scan, fs=fs)
+    # three point targets inside the image
+    xs, zs = w["Pi"][0, 0, :, 0], w["Pi"][2, :, 0, 0]
+    scat = np.array([[xs[60], 0.0, zs[70]], [xs[128], 0.0, zs[128]], [xs[200], 0.0, zs[190]]]).T
+    t = np.arange(-2.0 / fc, 2.0 / fc, 1 / (4 * fs))
+    wv = np.exp(-(t * fc * 1.2) ** 2) * np.exp(2j * np.pi * fc * t)
+    fsa = us.greens(scat, [1.0, 1.0, 1.0], wv, t[0], 4 * fs, R0=c0 / fc, interp="linear", focus=False)       # T x 64 x 64
+    chd = us.focusTx(fsa, seq, interp="linear")                                                               # T' x 64 x 32
+    assert tuple(chd.data.shape[1:3]) == (N, 32)
+    xh = fsa.data.cpu().numpy()
+    zref, t0z = O.focus_tx(xh, fsa.t0, fs, O.sequence_delays("FC", xdc.positions(), focus, c0), O.sequence_apodization("FC", N, 32), "linear")
+    assert abs(chd.t0 - t0z) < 1e-12 and rel_err(chd.data.cpu().numpy(), zref) <= 1e-4       # fp32 delay tables (sample index ~1500)
+    b_lut = us.bfDAS(chd, interp="linear")
+    b_das = us.DAS(chd, interp="linear")
+    torch.cuda.synchronize()
+    img = np.abs(b_lut.cpu().numpy()).reshape(w["I1"], w["I2"])
+    assert np.count_nonzero(img) and np.isfinite(img).all()
+    iz, ix = np.unravel_index(np.argmax(img), img.shape)
+    assert min(np.hypot(xs[ix] - sx, zs[iz] - sz) for sx, sz in zip(scat[0], scat[2])) <= 1.1e-3
+    # oracle on every 4th pixel per axis (the full 256^2 x 64 x 32 float64 loop takes minutes)
+    Pi_s = w["Pi"][:, ::4, ::4, :]
+    Pv, Nv, opt = w["Pv"][:3], w["Nv"], w["opt"]
+    ref = O.das_spec("DAS", Pi_s, w["Pr"], Pv, Nv, chd.data.cpu().numpy(), chd.t0, fs, cinv_f32(c0), VS=True, DV=False, interp="linear")
+    sub = lambda b: b.cpu().numpy().reshape(w["I1"], w["I2"])[::4, ::4]
+    assert rel_err(sub(b_das), ref[:, :, 0, 0, 0]) <= 1e-4
+    assert rel_err(sub(b_lut), ref[:, :, 0, 0, 0]) <= 5e-4            # fp32 delay tables
