@@ -345,3 +345,47 @@ def test_us_bfDAS_frames_layout_matches_DAS_and_oracle(keep):
     assert ref.shape == want
     assert rel_err(_np(b_das), ref) <= 1e-4
     assert rel_err(_np(b_lut), ref) <= 5e-4                                   # fp32 delay tables
+
+
+def test_all_32_apodization_shapes_through_DAS_and_bfDAS():
+    """reference test/USTest.m:333-337 (bfordgeneric): every broadcastable apodization shape -- each of I1, I2, I3, N, M full or
+    singleton -- through UltrasoundSystem.DAS and bfDAS.  The reference asserts the output size (:296); here also the values."""
+    import itertools
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import ChannelData, Scan, Sequence, Transducer, UltrasoundSystem
+    case = make_case(seq="PW", interp="linear", seed=27, N=5, M=3, I1=12, I2=4)
+    xdc = Transducer(case["Pr"], np.stack([0 * case["Pr"][0], 0 * case["Pr"][0], 1 + 0 * case["Pr"][0]]))
+    us = UltrasoundSystem(xdc, Sequence("PW", focus=case["Nv"], c0=case["c"]), Scan(case["Pi"]))
+    chd = ChannelData(torch.from_numpy(case["x"]), case["t0"], case["fs"])
+    full = (12, 4, 1, 5, 3)
+    rng = np.random.default_rng(8)
+    shapes = sorted({tuple(1 if m else f for m, f in zip(mask, full)) for mask in itertools.product((0, 1), repeat=5)})
+    assert len(shapes) == 16                                          # I3 == 1: 2^4 distinct shapes of the 32 masks
+    for shp in shapes:
+        a = (0.5 + rng.random(shp)).astype(np.float32)
+        ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"], cinv_f32(case["c"]),
+                         VS=case["VS"], DV=case["DV"], interp="linear", apod=[a])
+        b1, b2 = us.DAS(chd, a, interp="linear"), us.bfDAS(chd, a, interp="linear")
+        assert tuple(b1.shape[:3]) == (12, 4, 1) and tuple(b2.shape[:3]) == (12, 4, 1)       # test/USTest.m:296
+        assert rel_err(_np(b1).reshape(ref.shape), ref) <= 1e-4, shp
+        assert rel_err(_np(b2).reshape(ref.shape), ref) <= 5e-4, shp
+
+
+@pytest.mark.parametrize("prec", ["single", "double", "halfT"])
+def test_greens_then_DAS_has_no_nan_and_is_not_all_zero(prec):
+    """reference test/ParTest.m:185-209 (greens_das_dev -> logTestCheck): simulate, beamform; no NaN, not all zero"""
+    import torch
+    from qups_amd import Scan, Sequence, Transducer, UltrasoundSystem
+    fc, c0 = 5e6, 1500.0
+    fs = 4 * fc
+    xdc = Transducer.linear(16, 0.3e-3, fc)
+    us = UltrasoundSystem(xdc, Sequence("FSA", c0=c0), Scan.cartesian(np.linspace(-2e-3, 2e-3, 21), np.linspace(8e-3, 12e-3, 33)), fs=fs)
+    t = np.arange(-2.0 / fc, 2.0 / fc, 1 / (4 * fs))
+    wv = np.exp(-(t * fc * 1.2) ** 2) * np.exp(2j * np.pi * fc * t)
+    chd = us.greens(np.array([[0.5e-3], [0.0], [10e-3]]), [1.0], wv, t[0], 4 * fs, R0=c0 / fc)
+    d = _np(chd.data)
+    assert not np.isnan(d).any() and np.count_nonzero(d)
+    b = us.DAS(chd, prec=prec)
+    bn = torch.view_as_real(b).float().cpu().numpy() if prec == "halfT" else _np(b)
+    assert not np.isnan(bn).any() and np.count_nonzero(bn)
