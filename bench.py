@@ -162,13 +162,17 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-general", action="store_true", help="skip the reciprocal-mode-off measurement")
     ap.add_argument("--no-reciprocal", action="store_true", help="disable the reciprocal mode for the headline measurement itself (plan flag)")
-    ap.add_argument("--jit", action="store_true", help="plan flag QDAS_PLAN_JIT: hiprtc-specialised tiled kernel")
+    ap.add_argument("--no-jit", action="store_true", help="do not set the plan flag QDAS_PLAN_JIT: run the prebuilt instantiation instead of "
+                    "the kernel hiprtc compiles for this plan's sizes (the reference's benchmark runs const-compiled kernels too: "
+                    "src/UltrasoundSystem.m:5626-5748, test/ParTest.m:322-327)")
+    ap.add_argument("--jit", action="store_true", help="(default; kept for compatibility)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "none"],
                     help="roofline.traffic: rocprofv3 counter passes of this command (live; auto = live at N=1) or profiles/traffic_<w>.json")
     ap.add_argument("--prec", default=None, help="override the workload's data precision (single | halfT); not the headline")
     ap.add_argument("--gen-apod", action="store_true", help="generate the workload's receive apodization inside the kernel "
                     "(qdas_desc.rx_apod_*) instead of streaming the materialised I x N array")
     args = ap.parse_args()
+    args.jit = not args.no_jit
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -293,6 +297,13 @@ def main():
         general_ms = kernel_time(gplan, 3)
         gplan.close()
 
+    prebuilt_ms = None
+    if world == 1 and args.jit and not os.environ.get("QDAS_BENCH_CHILD"):      # the same frame on the prebuilt instantiation
+        pplan = DasPlan(prob, device=dev, kernel=args.kernel, i_begin=b, i_count=e - b, reciprocal=not args.no_reciprocal, jit=False)
+        pplan.execute_colmajor(xc, 1)
+        prebuilt_ms = kernel_time(pplan, 3)
+        pplan.close()
+
     traffic, tsrc = None, "not measured"
     if rank == 0 and not os.environ.get("QDAS_BENCH_CHILD"):
         mode = args.traffic
@@ -301,7 +312,7 @@ def main():
         if mode == "live":
             argv = ["--workload", args.workload] + (["--kernel", str(args.kernel)] if args.kernel else []) + \
                    (["--prec", args.prec] if args.prec else []) + (["--gen-apod"] if args.gen_apod else []) + \
-                   (["--no-reciprocal"] if args.no_reciprocal else []) + (["--jit"] if args.jit else [])
+                   (["--no-reciprocal"] if args.no_reciprocal else []) + (["--no-jit"] if args.no_jit else [])
             traffic, tsrc = measure_traffic(argv)
             if traffic is None:
                 mode = "file"
@@ -347,6 +358,8 @@ def main():
                          "valu_frac_executed": None if exec_fpp is None or plan.kernel != "tiled" else
                                                round(pairs / world * exec_fpp / ksec / 1e12 / FP32_PEAK_TFLOPS, 4)},
         }
+        if prebuilt_ms is not None:
+            rec["prebuilt_kernel_ms"] = round(prebuilt_ms, 3)
         if general_ms is not None:
             rec["general_ms_per_step"] = round(general_ms, 3)
             rec["general_value"] = round(I / (general_ms * 1e-3) / 1e6, 4)

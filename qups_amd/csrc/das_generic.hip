@@ -26,6 +26,12 @@ template <typename R> __device__ __forceinline__ R qcopysign(R a, R b);
 template <> __device__ __forceinline__ float  qcopysign(float a, float b)   { return copysignf(a, b); }
 template <> __device__ __forceinline__ double qcopysign(double a, double b) { return copysign(a, b); }
 
+// out of line: four inlined copies of the fp64 acos / cos code (one per accumulation mode) cost ~200 spilled scalars
+static __device__ __noinline__ double rx_apod_weight_call(int kind, double p0, double p1, double rx, double ry, double rz, double nx, double ny,
+                                                         double nz, double pix_x, double pix_z, double el_x) {
+    return rx_apod_weight(kind, p0, p1, rx, ry, rz, nx, ny, nz, pix_x, pix_z, el_x);
+}
+
 template <int INTERP, typename TY>
 __global__ void __launch_bounds__(256)
 das_generic_kernel(const GenericParams P) {
@@ -96,7 +102,7 @@ das_generic_kernel(const GenericParams P) {
             const R *rn = (const R *)P.rxn;
             const double ex = (double)Pr[3 * n], ey = (double)Pr[3 * n + 1], ez = (double)Pr[3 * n + 2];
             const double nx = rn ? (double)rn[3 * n] : 0.0, ny = rn ? (double)rn[3 * n + 1] : 0.0, nz = rn ? (double)rn[3 * n + 2] : 1.0;
-            const R w = (R)rx_apod_weight(P.gen_kind, P.gen_p0, P.gen_p1, (double)px - ex, (double)py - ey, (double)pz - ez,
+            const R w = (R)rx_apod_weight_call(P.gen_kind, P.gen_p0, P.gen_p1, (double)px - ex, (double)py - ey, (double)pz - ez,
                                           nx, ny, nz, (double)px, (double)pz, ex);
             a.x *= w; a.y *= w;
         }

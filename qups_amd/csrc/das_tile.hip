@@ -72,7 +72,7 @@ size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow) {
 }
 size_t tile_lds_limit(int sym) { return (size_t)(160 * 1024) / CFGS[sym ? 1 : 0].bpc; }
 
-hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s, hipFunction_t jit) {
+hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s, hipFunction_t jit, size_t jit_lds) {
     if (ntiles == 0) return hipSuccess;
     const int sym = P.sym ? 1 : 0;
     if (sym && dtype != 1 && dtype != 2) return hipErrorInvalidValue;
@@ -84,7 +84,7 @@ const int nf = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
     if ((nf != 1 && nf != 2 && nf != 4) || (nf > 1 && (sym || P.big))) return hipErrorInvalidValue;
     if (P.lut_tx && (sym || nf != 1 || (dtype != 1 && dtype != 2) || (P.syn && dtype != 1))) return hipErrorInvalidValue;
     if (jit && (P.probe || nf != 1 || P.lut_tx)) return hipErrorInvalidValue;
-    hipError_t e = jit ? jit_launch(jit, P, ntiles * P.ksplit, (unsigned)CFGS[cfg_index(dtype, sym, 1, narrow)].waves * 64u, lds, s) : P.lut_tx ? (dtype == 2 ? launch_tile_luth(P, ntiles, lds, s) : launch_tile_lut(P, ntiles, lds, s)) : sym ? (dtype == 2 ? launch_tile_symh(P, ntiles, lds, s) : narrow ? launch_tile_symw(P, ntiles, lds, s) : launch_tile_sym(P, ntiles, lds, s))
+    hipError_t e = jit ? jit_launch(jit, P, ntiles * P.ksplit, (unsigned)CFGS[cfg_index(dtype, sym, 1, narrow)].waves * 64u, jit_lds ? jit_lds : lds, s) : P.lut_tx ? (dtype == 2 ? launch_tile_luth(P, ntiles, lds, s) : launch_tile_lut(P, ntiles, lds, s)) : sym ? (dtype == 2 ? launch_tile_symh(P, ntiles, lds, s) : narrow ? launch_tile_symw(P, ntiles, lds, s) : launch_tile_sym(P, ntiles, lds, s))
                  : nf == 4 ? (dtype == 2 ? launch_tile_f16x4(P, ntiles, lds, s) : launch_tile_f32x4(P, ntiles, lds, s))
                  : nf == 2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))
                            : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : (P.big && !P.probe) ? launch_tile_f32big(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));

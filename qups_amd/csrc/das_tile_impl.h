@@ -223,6 +223,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
     const uint64_t ig = (uint64_t)i1 + I1 * (uint64_t)col;
     in_shard = ((uint64_t)i1 < I1) && ((uint64_t)col < ncols) && (ig >= P.i_begin) && (ig < i_end);
     pofs = (uint32_t)(ig - P.i_begin);
+    asm volatile("" : "+v"(pofs));                    // opaque: carried through the stage loop as ONE register (not re-derived from the 64-bit (row, column) pair at the end)
     ipx = ((uint64_t)i1 < I1 ? (uint64_t)i1 : I1 - 1) + I1 * ((uint64_t)col < ncols ? (uint64_t)col : ncols - 1);
     cf = P.cinv_fs;
     if constexpr (C::LUT) {                            // delays from host tables (tau_tx: I x M, tau_rx: I x N, in samples; table-driven plans cover [0, I))
@@ -253,14 +254,18 @@ template <class C> __device__ __forceinline__ double Tile<C>::a_of(uint32_t m, c
     return dv * cf - (double)gPv[4 * m + 3] * fs + tapinfo<C::INTERP>::OFF;
 }
 template <class C> __device__ __forceinline__ double Tile<C>::b_at(float ex, float ey, float ez) const {      // tau_rx*fs, reference src/bf.cu:110
-    const double rx = (double)px - (double)ex, ry = (double)py - (double)ey, rz = (double)pz - (double)ez;
+    float qx = px, qy = py, qz = pz;
+    asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));      // opaque: the fp64 images of the pixel are re-made per call (3 conversions) instead of living in 6 registers through the stage loop
+    const double rx = (double)qx - (double)ex, ry = (double)qy - (double)ey, rz = (double)qz - (double)ez;
     return dsqrt(rx * rx + ry * ry + rz * rz) * cf;
 }
 // delay of STAGE element n at (ex,ey,ez): a receiver (kind 0), or -- roles swapped -- a transmit with {t0, normal} in P.St (scalar loads)
 template <class C> __device__ __forceinline__ double Tile<C>::s_at(uint32_t n, float ex, float ey, float ez) const {
     if constexpr (C::LUT) return (double)P.lut_rx[ipx + (P.i_begin + P.i_count) * n];
     if (!QSPEC(HAS_ST, P.St != nullptr)) return b_at(ex, ey, ez);
-    const double rx = (double)px - (double)ex, ry = (double)py - (double)ey, rz = (double)pz - (double)ez;
+    float qx = px, qy = py, qz = pz;
+    asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
+    const double rx = (double)qx - (double)ex, ry = (double)qy - (double)ey, rz = (double)qz - (double)ez;
     const double dot = kindS ? rx * (double)P.St[4 * n + 1] + ry * (double)P.St[4 * n + 2] + rz * (double)P.St[4 * n + 3] : 0.0;
     double dv = dot;
     if (kindS != 2) { const double len = dsqrt(rx * rx + ry * ry + rz * rz); dv = kindS == 0 ? len : copysign(len, dot); }
@@ -383,6 +388,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
                 pairs_plain<CHECK, true>(n, m0, bn, rb, cbase, phB);
             }
         }
+        if constexpr (!hooks::no_fair_prio) __builtin_amdgcn_s_setprio(3);     // stage epilogue / next preamble at full priority (tile_pairs.h)
         if (!hooks::no_stage_dma && more && dma_late) dma_next((buf + NBUF - 1) % NBUF);
         timer.mark(3);
         // stage st+1 must have landed (all but the NBUF-2 newest DMA groups), all my LDS reads are done

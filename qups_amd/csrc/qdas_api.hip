@@ -73,6 +73,8 @@ struct qdas_plan {
     bool fb2_ok = false;                      // frames of a sequence may share launches, 4 or 2 at a time (decided at plan creation)
     bool fb4_off = false;                     // ... but at most pairwise (QDAS_NO_FB4)
     uint32_t *fallback = nullptr;             // device: [0] = count, [1..ntiles]
+    size_t jit_lds = 0;                       // dynamic LDS of the specialised kernel
+    int jit_mb = 0;                           // its transmits per stage
     hipFunction_t jit_fn = nullptr;           // plan-specialised kernel (QDAS_PLAN_JIT, jit.hip); null: prebuilt instantiation
     std::string jit_tag;                      // "jit <hash>" when the plan runs a hiprtc-specialised kernel (QDAS_PLAN_JIT)
     bool timing = false;
@@ -530,9 +532,29 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         k.kindB = t.kindB; k.kindS = t.kindS; k.tzl = t.tz_log2; k.wzl = t.wz_log2; k.ksplit = t.ksplit;
         k.gen_kind = t.gen_kind; k.has_apix = t.apix != nullptr; k.apix_real = t.apix_real; k.syn = t.syn;
         k.has_st = t.St != nullptr; k.has_cinv_pix = t.cinv_pix != nullptr;
+        // tuning: a specialised build may use another number of transmits per stage than the prebuilt configuration (its register
+        // budget is smaller); the LDS image grows with it
+        // reciprocal mode: the specialised kernel has the registers for 32-transmit stages (half the stages, barriers and per-stage
+        // delay evaluations of the prebuilt 16-transmit configuration) whenever the 64 windows of a buffer stay within the 16-bit
+        // immediate offsets of the LDS reads (C3: 30.9 -> 29.2 ms)
+        if (t.sym && z.M % 32 == 0 && 2 * 32 * k.w * (dt == QDAS_F16 ? 4 : 8) <= 65536 && !getenv("QDAS_JIT_NO_MB32")) k.mb = 32;
+        if (const char *e = getenv("QDAS_JIT_MB")) {
+            const int mb = atoi(e);
+            if (mb >= 2 && mb % k.waves == 0 && (!t.sym || z.M % (uint64_t)mb == 0)) k.mb = mb;
+        }
+        if (const char *e = getenv("QDAS_JIT_NBUF")) { const int nb = atoi(e); if (nb >= 2 && nb <= 4) k.nbuf = nb; }
+        {
+            const size_t MX = t.M > t.N ? t.M : t.N;
+            const size_t hdr = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + 15) & ~(size_t)15;
+            size_t body = (size_t)k.nbuf * k.mb * (t.sym ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
+            const size_t scratch = 2 * (size_t)k.waves * MX * 4 + 1024;
+            if (body < scratch) body = scratch;
+            pl->jit_lds = hdr + body;
+        }
         std::string key;
-        const std::string err = jit_get_kernel(k, pl->device, &pl->jit_fn, &key);
-        if (err.empty()) pl->jit_tag = "jit " + key;
+        const std::string err = pl->jit_lds > (size_t)160 * 1024 ? std::string("LDS image too large for the requested configuration")
+                                                                 : jit_get_kernel(k, pl->device, &pl->jit_fn, &key);
+        if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; }
         else { pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel"; }
     }
     pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->jit_fn && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
@@ -586,7 +608,7 @@ extern "C" int qdas_plan_kernel_name(const qdas_plan *pl, char *buf, size_t len)
     if (pl->kernel == QDAS_KERNEL_TILED) {
         const TileParams &t = pl->tp;
         snprintf(buf, len, "das_tile_kernel<interp=%d,%s%s%s%s%s,mb=%d,W=%d> [%s]", z.flag & 7, dts, t.sym ? ",sym" : "", t.fmod != 0.0 ? ",fmod" : "",
-                 t.wtab ? ",wtab" : "", t.big ? ",big" : "", pl->tc.mb, pl->tc.window, pl->jit_tag.empty() ? "prebuilt" : pl->jit_tag.c_str());
+                 t.wtab ? ",wtab" : "", t.big ? ",big" : "", pl->jit_fn ? pl->jit_mb : pl->tc.mb, pl->tc.window, pl->jit_tag.empty() ? "prebuilt" : pl->jit_tag.c_str());
     } else snprintf(buf, len, "das_generic_kernel<interp=%d,%s>", z.flag & 7, dts);
     return QDAS_OK;
 }
@@ -619,9 +641,9 @@ static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s, int n
             for (int f = 0; f < nf; ++f)
                 HIPCHK(hipMemset2DAsync((char *)y + (size_t)f * y_fstride * ds, (size_t)pl->y_ld * ds, 0, (size_t)pl->i_count * ds, pl->oN * pl->oM, s));
         }
-        if (pl->no_fallback) return hip_rc(launch_tile(t, z.dtype, pl->ntiles, s, pl->jit_fn));     // one launch per frame (+ the reduce of a split aperture)
+        if (pl->no_fallback) return hip_rc(launch_tile(t, z.dtype, pl->ntiles, s, pl->jit_fn, pl->jit_lds));     // one launch per frame (+ the reduce of a split aperture)
         HIPCHK(hipMemsetAsync(pl->fallback, 0, sizeof(uint32_t), s));
-        HIPCHK(launch_tile(t, z.dtype, pl->ntiles, s, pl->jit_fn));
+        HIPCHK(launch_tile(t, z.dtype, pl->ntiles, s, pl->jit_fn, pl->jit_lds));
         // tiles whose delay window overflowed LDS are redone by the generic kernel; the launch is
         // sized for the worst case and exits immediately for ids >= the device-side count
         GenericParams g = pl->gp;

@@ -39,7 +39,7 @@ TileConfig tile_config(int dtype, int sym, int narrow = 0);
 size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow = 0);   // dynamic LDS of one workgroup
 size_t tile_lds_limit(int sym);                               // LDS budget of one workgroup in that configuration
 // jit: plan-specialised kernel (jit.hip) to launch instead of the prebuilt instantiation; one frame per launch only
-hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s, hipFunction_t jit = nullptr);
+hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s, hipFunction_t jit = nullptr, size_t jit_lds = 0);
 
 // ---- split-delay kernel (das_lut.hip)
 struct LutParams {

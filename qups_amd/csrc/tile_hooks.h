@@ -34,6 +34,7 @@ struct hooks {
     static constexpr bool linear_taps      = (abl & 128) != 0;   // conflict-free synthetic tap addresses
     static constexpr bool no_pipeline      = (abl & 256) != 0;   // plain pair loop where the software-pipelined one would run
     static constexpr bool no_late_dma      = (abl & 1024) != 0;  // every wave issues the next stage's DMA before its pair loop
+    static constexpr bool no_fair_prio     = (abl & 2048) != 0;  // no s_setprio staircase in the pair loops
     static constexpr bool product = abl == 0 && QDAS_PROF == 0;
 
     // phase timers of waves 0 and 15 of every workgroup (tools/phase_timers.py)

@@ -21,6 +21,11 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
     constexpr bool TAIL = !SYM && TAILV, DIAG = SYM && TAILV;
     unroll<MB / 2>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
+        // Fair progress inside a stage: the hardware issues oldest-wave-first, so without help the four waves of a SIMD finish their
+        // pair loops one after the other and the last one runs alone -- at a fraction of the issue rate -- until the stage barrier.
+        // Lowering the priority as a wave advances (3 .. 0 over the block) lets the waves that are BEHIND go first: they finish
+        // together.  Measured (profiles/r02/exp_prio.txt): general kernels -5 ... -7 %, reciprocal mode with 32-transmit stages -6 %.
+        if constexpr (!hooks::no_fair_prio && (p * 4) % (MB / 2) == 0) __builtin_amdgcn_s_setprio(3 - (p * 4) / (MB / 2));
         const uint32_t m = m0 + 2 * p;
         if constexpr (TAIL) { if (m >= M) return; }
         if constexpr (DIAG) { if (m + 1 < n) return; }          // both transmits below the diagonal: their pairs were done as mirrors
@@ -53,24 +58,22 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                 else {
                     lds_issue<K, (GSET * MB + 2 * p) * WB>(g0, ad0); lds_issue<K, (GSET * MB + 2 * p + 1) * WB>(g1, ad1);
                     if constexpr (TWO) { lds_issue<K, (HSET * MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (HSET * MB + 2 * p + 1) * WB>(h1, ad1); }
-                    if constexpr (K < 4) { g0.s[2] = g0.s[3] = g1.s[2] = g1.s[3] = h0.s[2] = h0.s[3] = h1.s[2] = h1.s[3] = (v2f){0.f, 0.f}; }
-                    if constexpr (K < 2) { g0.s[1] = g1.s[1] = h0.s[1] = h1.s[1] = (v2f){0.f, 0.f}; }
                 }
                 if constexpr (hp == 0) {              // (the next frame pair reuses them)
                     if constexpr (hooks::trivial_weights) { w[0] = s; w[1] = t; w[2] = tm; w[3] = s + t; }
                     else if constexpr (K > 1) weights2<INTERP>(s, w);   // overlaps the LDS latency
                 }
-                if constexpr (TWO) lds_fence2(g0, g1, h0, h1, w); else lds_fence(g0, g1, w);
+                if constexpr (TWO) lds_fence2<K>(g0, g1, h0, h1, w); else lds_fence<K>(g0, g1, w);
                 if constexpr (DIAG) {                 // uniform, only in the block that holds the diagonal
                     const v2f z = {0.f, 0.f};
-                    if (m < n)      { for (int k = 0; k < 4; ++k) g0.s[k] = z; }     // pair (n, m<n): done as the mirror of (m, n)
-                    if (m <= n)     { for (int k = 0; k < 4; ++k) h0.s[k] = z; }     // m == n: the trace is its own mirror
-                    if (m + 1 <= n) { for (int k = 0; k < 4; ++k) h1.s[k] = z; }
+                    if (m < n)      { for (int k = 0; k < K; ++k) g0.s[k] = z; }     // pair (n, m<n): done as the mirror of (m, n)
+                    if (m <= n)     { for (int k = 0; k < K; ++k) h0.s[k] = z; }     // m == n: the trace is its own mirror
+                    if (m + 1 <= n) { for (int k = 0; k < K; ++k) h1.s[k] = z; }
                 }
                 if constexpr (TAIL) {
                     if (!upper) {                       // odd M: no transmit in the upper half (uniform, rare)
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { g1.s[k] = (v2f){0.f, 0.f}; if constexpr (FBX) h1.s[k] = (v2f){0.f, 0.f}; }
+                        for (int k = 0; k < K; ++k) { g1.s[k] = (v2f){0.f, 0.f}; if constexpr (FBX) h1.s[k] = (v2f){0.f, 0.f}; }
                     }
                 }
                 if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; if constexpr (FBX) { u0 = h0.s[0]; u1 = h1.s[0]; } }
@@ -98,19 +101,17 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                 taps_f16 g0, g1, h0, h1;
                 lds_issue<K, (GSET * MB + 2 * p) * WB>(g0, ad0); lds_issue<K, (GSET * MB + 2 * p + 1) * WB>(g1, ad1);
                 if constexpr (TWO) { lds_issue<K, (HSET * MB + 2 * p) * WB>(h0, ad0); lds_issue<K, (HSET * MB + 2 * p + 1) * WB>(h1, ad1); }
-                if constexpr (K < 4) { g0.r[2] = g0.r[3] = g1.r[2] = g1.r[3] = h0.r[2] = h0.r[3] = h1.r[2] = h1.r[3] = 0u; }
-                if constexpr (K < 2) { g0.r[1] = g1.r[1] = h0.r[1] = h1.r[1] = 0u; }
                 if constexpr (hp == 0 && K > 1) weights2<INTERP>(s, w);  // overlaps the LDS latency
-                if constexpr (TWO) lds_fence2(g0, g1, h0, h1, w); else lds_fence(g0, g1, w);
+                if constexpr (TWO) lds_fence2<K>(g0, g1, h0, h1, w); else lds_fence<K>(g0, g1, w);
                 if constexpr (DIAG) {                 // (as for fp32 data above)
-                    if (m < n)      { for (int k = 0; k < 4; ++k) g0.r[k] = 0u; }
-                    if (m <= n)     { for (int k = 0; k < 4; ++k) h0.r[k] = 0u; }
-                    if (m + 1 <= n) { for (int k = 0; k < 4; ++k) h1.r[k] = 0u; }
+                    if (m < n)      { for (int k = 0; k < K; ++k) g0.r[k] = 0u; }
+                    if (m <= n)     { for (int k = 0; k < K; ++k) h0.r[k] = 0u; }
+                    if (m + 1 <= n) { for (int k = 0; k < K; ++k) h1.r[k] = 0u; }
                 }
                 if constexpr (TAIL) {
                     if (!upper) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { g1.r[k] = 0u; if constexpr (FBX) h1.r[k] = 0u; }
+                        for (int k = 0; k < K; ++k) { g1.r[k] = 0u; if constexpr (FBX) h1.r[k] = 0u; }
                     }
                 }
                 if constexpr (K == 1) {
@@ -200,6 +201,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::pairs_pipelined(floa
     index(std::integral_constant<int, 0>{});
     unroll<NU>([&](auto uc) {
         constexpr int u = decltype(uc)::value, p = u / NHP, hp = u % NHP, HSET = FB4 ? 2 * hp + 1 : 1;
+        if constexpr (!hooks::no_fair_prio && (u * 4) % NU == 0) __builtin_amdgcn_s_setprio(3 - (u * 4) / NU);     // fair progress, see pairs_plain
         taps_t h0, h1;
         if constexpr (F32 && hooks::no_tap_reads) { for (int k = 0; k < 4; ++k) { h0.s[k] = sv[p & 1]; h1.s[k] = (v2f){sv[p & 1].y, sv[p & 1].x}; } }
         else { lds_issue<K, (HSET * MB + 2 * p) * WB>(h0, a0v[p & 1]); lds_issue<K, (HSET * MB + 2 * p + 1) * WB>(h1, a1v[p & 1]); }

@@ -20,16 +20,29 @@ template <int K, int OFF> __device__ __forceinline__ void lds_issue(taps_f32 &t,
 }
 // The weights are tied through the wait as well, so that their evaluation is scheduled BEFORE it
 // (between the issue of the loads and the wait: that is what hides the LDS latency).
-__device__ __forceinline__ void lds_fence(taps_f32 &a, taps_f32 &b, v2f (&w)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a.s[0]), "+v"(a.s[1]), "+v"(a.s[2]), "+v"(a.s[3]), "+v"(b.s[0]), "+v"(b.s[1]), "+v"(b.s[2]), "+v"(b.s[3]),
-                   "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+// (K: taps per sample -- only the registers that were actually loaded are tied, so that 1- and 2-tap interpolators do not pin
+//  registers for taps they never read)
+template <int K> __device__ __forceinline__ void lds_fence(taps_f32 &a, taps_f32 &b, v2f (&w)[4]) {
+    if constexpr (K == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a.s[0]), "+v"(a.s[1]), "+v"(a.s[2]), "+v"(a.s[3]), "+v"(b.s[0]), "+v"(b.s[1]), "+v"(b.s[2]), "+v"(b.s[3]),
+                       "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+    else if constexpr (K == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.s[0]), "+v"(a.s[1]), "+v"(b.s[0]), "+v"(b.s[1]), "+v"(w[0]), "+v"(w[1]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.s[0]), "+v"(b.s[0]));
 }
-__device__ __forceinline__ void lds_fence2(taps_f32 &a, taps_f32 &b, taps_f32 &c, taps_f32 &d, v2f (&w)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a.s[0]), "+v"(a.s[1]), "+v"(a.s[2]), "+v"(a.s[3]), "+v"(b.s[0]), "+v"(b.s[1]), "+v"(b.s[2]), "+v"(b.s[3]),
-                   "+v"(c.s[0]), "+v"(c.s[1]), "+v"(c.s[2]), "+v"(c.s[3]), "+v"(d.s[0]), "+v"(d.s[1]), "+v"(d.s[2]), "+v"(d.s[3]),
-                   "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+template <int K> __device__ __forceinline__ void lds_fence2(taps_f32 &a, taps_f32 &b, taps_f32 &c, taps_f32 &d, v2f (&w)[4]) {
+    if constexpr (K == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a.s[0]), "+v"(a.s[1]), "+v"(a.s[2]), "+v"(a.s[3]), "+v"(b.s[0]), "+v"(b.s[1]), "+v"(b.s[2]), "+v"(b.s[3]),
+                       "+v"(c.s[0]), "+v"(c.s[1]), "+v"(c.s[2]), "+v"(c.s[3]), "+v"(d.s[0]), "+v"(d.s[1]), "+v"(d.s[2]), "+v"(d.s[3]),
+                       "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+    else if constexpr (K == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a.s[0]), "+v"(a.s[1]), "+v"(b.s[0]), "+v"(b.s[1]), "+v"(c.s[0]), "+v"(c.s[1]), "+v"(d.s[0]), "+v"(d.s[1]), "+v"(w[0]), "+v"(w[1]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.s[0]), "+v"(b.s[0]), "+v"(c.s[0]), "+v"(d.s[0]));
 }
 // counted variant for the software-pipelined loop: the NEWEST `KEEP` LDS reads (the next iteration's direct taps) stay in flight
 template <int KEEP> __device__ __forceinline__ void lds_fence2_keep(taps_f32 &a, taps_f32 &b, taps_f32 &c, taps_f32 &d, v2f (&w)[4]) {
@@ -52,16 +65,27 @@ template <int K, int OFF> __device__ __forceinline__ void lds_issue(taps_f16 &t,
     else
         asm volatile("ds_read_b32 %0, %1 offset:%2" : "=&v"(t.r[0]) : "v"(addr), "n"(OFF));
 }
-__device__ __forceinline__ void lds_fence(taps_f16 &a, taps_f16 &b, v2f (&w)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a.r[0]), "+v"(a.r[1]), "+v"(a.r[2]), "+v"(a.r[3]), "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]),
-                   "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+template <int K> __device__ __forceinline__ void lds_fence(taps_f16 &a, taps_f16 &b, v2f (&w)[4]) {
+    if constexpr (K == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a.r[0]), "+v"(a.r[1]), "+v"(a.r[2]), "+v"(a.r[3]), "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]),
+                       "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+    else if constexpr (K == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.r[0]), "+v"(a.r[1]), "+v"(b.r[0]), "+v"(b.r[1]), "+v"(w[0]), "+v"(w[1]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.r[0]), "+v"(b.r[0]));
 }
-__device__ __forceinline__ void lds_fence2(taps_f16 &a, taps_f16 &b, taps_f16 &c, taps_f16 &d, v2f (&w)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a.r[0]), "+v"(a.r[1]), "+v"(a.r[2]), "+v"(a.r[3]), "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]),
-                   "+v"(c.r[0]), "+v"(c.r[1]), "+v"(c.r[2]), "+v"(c.r[3]), "+v"(d.r[0]), "+v"(d.r[1]), "+v"(d.r[2]), "+v"(d.r[3]),
-                   "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+template <int K> __device__ __forceinline__ void lds_fence2(taps_f16 &a, taps_f16 &b, taps_f16 &c, taps_f16 &d, v2f (&w)[4]) {
+    if constexpr (K == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a.r[0]), "+v"(a.r[1]), "+v"(a.r[2]), "+v"(a.r[3]), "+v"(b.r[0]), "+v"(b.r[1]), "+v"(b.r[2]), "+v"(b.r[3]),
+                       "+v"(c.r[0]), "+v"(c.r[1]), "+v"(c.r[2]), "+v"(c.r[3]), "+v"(d.r[0]), "+v"(d.r[1]), "+v"(d.r[2]), "+v"(d.r[3]),
+                       "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+    else if constexpr (K == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a.r[0]), "+v"(a.r[1]), "+v"(b.r[0]), "+v"(b.r[1]), "+v"(c.r[0]), "+v"(c.r[1]), "+v"(d.r[0]), "+v"(d.r[1]), "+v"(w[0]), "+v"(w[1]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.r[0]), "+v"(b.r[0]), "+v"(c.r[0]), "+v"(d.r[0]));
 }
 template <int KEEP> __device__ __forceinline__ void lds_fence2_keep(taps_f16 &a, taps_f16 &b, taps_f16 &c, taps_f16 &d, v2f (&w)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%20)"

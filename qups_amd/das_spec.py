@@ -207,7 +207,15 @@ def build_problem(fun, Pi, Pr, Pv, Nv, xshape, t0, fs, c, opts: dict) -> DasProb
         t0v = _to_numpy(t0).reshape(-1)
         if fun == "delays":
             fs = 1.0
-        elif t0v.size > 1:  # "find the sampling frequency" from a time axis (reference kern/das_spec.m:153-155)
+        elif t0v.size > 1:
+            # "find the sampling frequency" from a time axis.  DEVIATION: the reference takes fs = mean(diff(t0,1,1))
+            # (kern/das_spec.m:153-155), i.e. the sampling PERIOD -- its own comment says "frequency"; this mirror uses 1 / mean(diff).
+            # A per-transmit t0 vector (one start time per transmit) passed WITHOUT fs would be read as a time axis here, exactly as
+            # the reference does: say so instead of silently collapsing it to min(t0).
+            if xshape is not None and len(xshape) >= 3 and t0v.size == xshape[1 if opts["tpose"] else 2] and t0v.size != xshape[0]:
+                import warnings
+                warnings.warn("das_spec: fs is omitted and t0 has one entry per transmit: it is interpreted as a TIME AXIS "
+                              "(kern/das_spec.m:153-155), not as per-transmit start times -- pass fs to use it as the latter.")
             fs = 1.0 / float(np.mean(np.diff(t0v)))
             t0 = float(t0v.min())
         else:
@@ -605,7 +613,8 @@ def das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs=None, c=None, *varargin, return_plan
     torch = _torch()
     xshape = tuple(x.shape) if fun != "delays" else ()
     prob = build_problem(fun, Pi, Pr, Pv, Nv, xshape, t0, fs, c, opts)
-    device = None if opts["device"] in (-1, None) else f"cuda:{opts['device'] - 1}"   # MATLAB device ids are 1-based
+    # MATLAB device ids are 1-based; any negative id means "the current device" (the reference passes -1, kern/das_spec.m:131)
+    device = None if (opts["device"] is None or opts["device"] < 0) else f"cuda:{opts['device'] - 1}"
     plan = DasPlan(prob, device=device, kernel=kernel, jit=jit)     # jit: hiprtc build for these sizes (qdas.h QDAS_PLAN_JIT)
     Isz = prob.Isz
     rev = lambda t: t.permute(*reversed(range(t.ndim)))
