@@ -15,6 +15,7 @@
 #include "das_tile_f32big.hip"
 #include "das_tile_lut.hip"
 #include "das_tile_luth.hip"
+#include "das_tile_bf.hip"
 #else
 #include "qdas_device.h"
 #include "qdas_kernels.h"
@@ -36,6 +37,7 @@ hipError_t launch_tile_symh(const TileParams &P, unsigned ntiles, size_t lds, hi
 hipError_t launch_tile_f32big(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_lut(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_luth(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
+hipError_t launch_tile_bf(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 
 // y[i] = sum over the ksplit partial images, in split order (deterministic)
 template <typename ST>
@@ -79,16 +81,17 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     const int narrow = (sym && dtype == 1 && P.narrow) ? 1 : 0;
     const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M, narrow);    // (the two-frame configurations have the same LDS image)
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
-    if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part))) return hipErrorInvalidValue;
+    if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part && !P.bf))) return hipErrorInvalidValue;
 const int nf = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
     if ((nf != 1 && nf != 2 && nf != 4) || (nf > 1 && (sym || P.big))) return hipErrorInvalidValue;
     if (P.lut_tx && (sym || nf != 1 || (dtype != 1 && dtype != 2) || (P.syn && dtype != 1))) return hipErrorInvalidValue;
-    if (jit && (P.probe || nf != 1 || P.lut_tx)) return hipErrorInvalidValue;
+    if (jit && (P.probe || nf != 1 || P.lut_tx || P.bf)) return hipErrorInvalidValue;
+    if (P.bf && (sym || nf != 1 || dtype != 1 || P.lut_tx || P.big || P.apix || P.gen_kind)) return hipErrorInvalidValue;
     hipError_t e = jit ? jit_launch(jit, P, ntiles * P.ksplit, (unsigned)CFGS[cfg_index(dtype, sym, 1, narrow)].waves * 64u, jit_lds ? jit_lds : lds, s) : P.lut_tx ? (dtype == 2 ? launch_tile_luth(P, ntiles, lds, s) : launch_tile_lut(P, ntiles, lds, s)) : sym ? (dtype == 2 ? launch_tile_symh(P, ntiles, lds, s) : narrow ? launch_tile_symw(P, ntiles, lds, s) : launch_tile_sym(P, ntiles, lds, s))
                  : nf == 4 ? (dtype == 2 ? launch_tile_f16x4(P, ntiles, lds, s) : launch_tile_f32x4(P, ntiles, lds, s))
                  : nf == 2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))
-                           : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : (P.big && !P.probe) ? launch_tile_f32big(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));
-    if (e != hipSuccess || P.probe || P.ksplit <= 1 || P.syn) return e;   // ('SYN' planes are accumulated in place)
+                           : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : (P.bf && !P.probe) ? launch_tile_bf(P, ntiles, lds, s) : (P.big && !P.probe) ? launch_tile_f32big(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));
+    if (e != hipSuccess || P.probe || P.ksplit <= 1 || P.syn || P.bf) return e;   // ('SYN' planes are accumulated in place, 'BF' planes stored by their owners)
     const unsigned rb = (unsigned)((P.i_count + 255) / 256);
     for (int f = 0; f < nf; ++f) {                       // partial images: [split][frame][pixel]
         const float2 *src = P.part + (size_t)f * P.i_count;

@@ -57,11 +57,12 @@ typedef __attribute__((address_space(3))) void lds_void;
 //   the same traces of the next frames, so tap index and weights -- which depend on the geometry only -- are computed once for all
 //   of them (the reference launches one kernel per frame, kern/das_spec.m:371).  BIG: re-base the DMA descriptors along the
 //   receiver walk (transposed fp32 frames beyond 2 GiB).  LUT: the delays come from host-supplied tables (qdas_das_lut).
-template <int INTERP_, typename ST_, bool FMOD_, bool WTAB_, bool SYM_, bool FB2_, bool FB4_, int WAVES_, int MB_, int W_, int NBUF_, bool BIG_, bool LUT_>
+template <int INTERP_, typename ST_, bool FMOD_, bool WTAB_, bool SYM_, bool FB2_, bool FB4_, int WAVES_, int MB_, int W_, int NBUF_, bool BIG_, bool LUT_, bool BF_ = false>
 struct TileCfg {
     static constexpr int INTERP = INTERP_, WAVES = WAVES_, MB = MB_, W = W_, NBUF = NBUF_;
     using ST = ST_;
     static constexpr bool FMOD = FMOD_, WTAB = WTAB_, SYM = SYM_, FB2 = FB2_, FB4 = FB4_, BIG = BIG_, LUT = LUT_;
+    static constexpr bool BF = BF_;                  // keep both aperture dimensions: every pair's sample goes to its own output plane
     static constexpr bool FBX = FB2 || FB4;          // more than one frame per launch
     static constexpr bool TWO = SYM || FBX;          // (at least) two window sets per stage: direct + (mirror | next frame)
     static constexpr int NHP = FB4 ? 2 : 1;          // passes of the pair loop: one per frame pair
@@ -80,6 +81,7 @@ struct TileCfg {
     static_assert(!(SYM && FBX) && !(FB2 && FB4), "reciprocal mode runs one frame per launch");
     static_assert(!BIG || (!SYM && !FBX), "the re-basing general kernel runs one frame per launch");
     static_assert(!LUT || (!SYM && !FBX && !BIG), "table-driven delays: general mode, one frame per launch");
+    static_assert(!BF || (!SYM && !FBX && !BIG && !LUT && sizeof(ST_) == 8), "'BF': general mode, fp32 data, one frame per launch");
     static_assert(FB4 ? (2 * MB == WAVES) : (MB % WAVES == 0 && MB % 2 == 0), "staging split");
     static_assert(WB % 16 == 0, "window must be a whole number of 16-byte lanes");
 };
@@ -301,8 +303,8 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
     acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
 #pragma unroll
     for (int f = 0; f < C::NFR; ++f) tot[f] = (v2f){0.f, 0.f};
-    wpix = !C::SYM && !(C::FB4 && C::F32) && (QSPEC(HAS_APIX, P.apix != nullptr) || QSPEC(GEN_KIND, P.gen_kind) != 0);   // weights from an I x N array, or generated from the geometry
-    syn = !C::SYM && C::F32 && QSPEC(SYN, P.syn);          // keep the stage dimension: one output plane per stage element
+    wpix = !C::SYM && !C::BF && !(C::FB4 && C::F32) && (QSPEC(HAS_APIX, P.apix != nullptr) || QSPEC(GEN_KIND, P.gen_kind) != 0);   // weights from an I x N array, or generated from the geometry
+    syn = !C::SYM && !C::BF && C::F32 && QSPEC(SYN, P.syn);          // keep the stage dimension: one output plane per stage element
     fa = C::FB4 ? __builtin_amdgcn_readfirstlane(wave / C::MB) : 0;   // window sets this wave stages: (0, 1) in general; four frames: (0, 2) / (1, 3)
     fb = C::FB4 ? fa + 2 : 1;
     soff = soff2 = 0; offD = offM = 0;
@@ -433,7 +435,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
 
 // ---- epilogue: y[i] = pix  (reference src/bf.cu:140); one image per frame of the launch
 template <class C> __device__ __forceinline__ void Tile<C>::epilogue() {
-    if (syn) return;                                   // every stage already added its share to its plane
+    if (syn || C::BF) return;                          // every stage already added its share to its plane / stored its pairs
     v2f res[4];
     frame_sums(res);
     if (in_shard) {
@@ -468,25 +470,25 @@ template <class C, bool PROBE> __device__ __forceinline__ void das_tile_body(con
 // PSZ / BPC: bytes per lane and DMA piece (16) and workgroups per CU the register budget is sized for -- kept in the kernel's
 // name so that profiles of different rounds list the same kernels.  PROBE is a kernel of its own name: profiles of
 // das_tile_kernel<..., false> hold full frames only.
-template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, bool FB2, bool FB4, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE, bool BIG = false, bool LUT = false>
+template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, bool FB2, bool FB4, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE, bool BIG = false, bool LUT = false, bool BFM = false>
 __global__ void __launch_bounds__(WAVES * 64, WAVES * BPC / 4)
 das_tile_kernel(const TileParams P) {
     static_assert(PSZ == 16, "16-byte DMA pieces");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    das_tile_body<TileCfg<INTERP, ST, FMOD, WTAB, SYM, FB2, FB4, WAVES, MB, W, NBUF, BIG, LUT>, PROBE>(P, smem);
+    das_tile_body<TileCfg<INTERP, ST, FMOD, WTAB, SYM, FB2, FB4, WAVES, MB, W, NBUF, BIG, LUT, BFM>, PROBE>(P, smem);
 }
 
 #ifndef __HIPCC_RTC__
 template <int INTERP, typename ST, int CI>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
     constexpr Cfg G = CFGS[CI];
-    constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8), FB2 = (CI == 3 || CI == 4), FB4 = (CI == 5 || CI == 6), BIG = (CI == 9), LUT = (CI == 10 || CI == 11);
+    constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8), FB2 = (CI == 3 || CI == 4), FB4 = (CI == 5 || CI == 6), BIG = (CI == 9), LUT = (CI == 10 || CI == 11), BFM = (CI == 12);
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
     const dim3 g(ntiles * (P.probe ? 1u : P.ksplit)), b(G.waves * 64);
 #define QDAS_LAUNCH(FM, WT) QDAS_LAUNCH_P(FM, WT, false)
 #define QDAS_LAUNCH_P(FM, WT, PR)                                                                        \
     do {                                                                                                 \
-        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, FB4, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR, BIG && !PR, LUT>; \
+        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, FB4, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR, BIG && !PR, LUT, BFM && !PR>; \
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                   \
         kfn<<<g, b, lds, s>>>(P);                                                                        \

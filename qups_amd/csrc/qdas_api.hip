@@ -327,8 +327,10 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // and 'MUL' (keep the transmit dimension: the same kernel with the roles of the two apertures swapped)
     const bool mul = (z.flag & QDAS_FLAG_KEEP_TX) && !(z.flag & QDAS_FLAG_KEEP_RX);
     const bool syn = ((z.flag & QDAS_FLAG_KEEP_RX) && !(z.flag & QDAS_FLAG_KEEP_TX)) || mul;      // one output plane per STAGE element
-    bool eligible = (dt == QDAS_F32 || dt == QDAS_F16) && !((z.flag & QDAS_FLAG_KEEP_TX) && (z.flag & QDAS_FLAG_KEEP_RX)) && (!syn || dt == QDAS_F32);
-    const char *why = "tiled kernel needs fp32/fp16 data and the 'DAS' mode (or fp32 data and 'SYN' / 'MUL')";
+    // 'BF' (both dimensions kept, fp32 data): the same stage loop, every pair's weighted sample stored to its own plane
+    const bool bfm = (z.flag & QDAS_FLAG_KEEP_TX) && (z.flag & QDAS_FLAG_KEEP_RX);
+    bool eligible = (dt == QDAS_F32 || dt == QDAS_F16) && ((!syn && !bfm) || dt == QDAS_F32);
+    const char *why = "tiled kernel needs fp32/fp16 data and the 'DAS' mode (or fp32 data and 'SYN' / 'MUL' / 'BF')";
     // stage / block element counts of the kernel (das_tile_impl.h): receivers / transmits, swapped for 'MUL'
     const uint64_t kN = mul ? z.M : z.N, kM = mul ? z.N : z.M;
     // sound speed: a scalar, or a full per-pixel map (contiguous I1 x I2 x I3, no aperture dependence): the delay stays separable
@@ -353,13 +355,16 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     if (eligible && g.gen_kind && pix_arr >= 0) {
         eligible = false; why = "tiled kernel: a generated receive apodization and a pixel-dependent array need the generic kernel";
     }
+    if (eligible && bfm && (pix_arr >= 0 || g.gen_kind)) {
+        eligible = false; why = "tiled kernel: 'BF' with a pixel x receiver apodization needs the generic kernel";
+    }
     if (eligible && mul && (pix_arr >= 0 || g.gen_kind)) {
         eligible = false; why = "tiled kernel: 'MUL' with a pixel x receiver apodization needs the generic kernel";
     }
     // reciprocal mode (das_tile_impl.h "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
     // elements and share one t0 has tau(n,m) == tau(m,n); detected from the geometry itself, bit-exactly.
     int sym = 0, big = 0;
-    if (eligible && !syn && (dt == QDAS_F32 || dt == QDAS_F16) && z.VS && z.DV && z.N == z.M && z.S == 0 && !g.gen_kind && !(desc->plan_flags & QDAS_PLAN_NO_RECIPROCAL) && !getenv("QDAS_NO_SYM")) {
+    if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && z.VS && z.DV && z.N == z.M && z.S == 0 && !g.gen_kind && !(desc->plan_flags & QDAS_PLAN_NO_RECIPROCAL) && !getenv("QDAS_NO_SYM")) {
         std::vector<float> hr(3 * z.N), hv(4 * z.M);
         if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
         if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);
@@ -388,7 +393,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         }
         if (eligible && !sym && (kN * strN + (uint64_t)pl->tc.mb * strM) * data_size(dt) + slack >= (1ull << 31)) {
             // fp32, one frame per launch: the re-basing instantiation of the general kernel (launch configuration 9)
-            if (dt == QDAS_F32 && ((uint64_t)pl->tc.mb * strM + strN) * data_size(dt) + slack < (1ull << 30)) big = 1;
+            if (dt == QDAS_F32 && !bfm && ((uint64_t)pl->tc.mb * strM + strN) * data_size(dt) + slack < (1ull << 30)) big = 1;
             else { eligible = false; why = "tiled kernel: trace strides too large for 32-bit DMA offsets (transposed data of more than 2 GiB)"; }
         }
     }
@@ -450,6 +455,9 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         t.fallback_list = pl->fallback; t.fallback_cap = max_tiles;
         t.probe = 0; t.wz_log2 = 6; t.ksplit = 1; t.part = nullptr; t.nfr = 1; t.x_fstride = 0; t.y_fstride = 0;
         t.syn = syn ? 1 : 0; t.y_ld = pl->y_ld;
+        t.bf = bfm ? 1 : 0;
+        t.bf_pn = (z.flag & QDAS_FLAG_TPOSE) ? z.M : 1;      // plane nm = the data's aperture order (src/bf.cu:100,135)
+        t.bf_pm = (z.flag & QDAS_FLAG_TPOSE) ? 1 : z.N;
         // fold the (pixel-independent) apodization stack into one N x M complex64 table
         t.wtab = nullptr; t.apix = nullptr; t.apix_real = desc->apod_real;
         t.gen_kind = g.gen_kind; t.gen_p0 = g.gen_p0; t.gen_p1 = g.gen_p1; t.rxn = (const float *)g.rxn;
@@ -510,7 +518,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             while (ks * 2 <= cap && (uint64_t)pl->ntiles * ks < (uint64_t)cus) ks *= 2;   // (a split costs one more prologue per tile)
             if (const char *e = getenv("QDAS_KSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8 && (unsigned)v <= cap) ks = (unsigned)v; }
             t.ksplit = ks;
-            if (ks > 1) {
+            if (ks > 1 && !bfm) {
                 void *pb;
                 if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)ks * 4 * pl->i_count))) return bail(rc);   // x4: up to four frames per launch
                 t.part = (float2 *)pb;
@@ -521,7 +529,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // ---- QDAS_PLAN_JIT: the tiled kernel compiled for this plan's sizes (jit.hip).  A failure is not an error: the plan keeps its
     //      prebuilt kernel and qdas_last_error() says why.
     g_err.clear();
-    if ((desc->plan_flags & QDAS_PLAN_JIT) && pl->kernel == QDAS_KERNEL_TILED && !getenv("QDAS_NO_JIT")) {
+    if ((desc->plan_flags & QDAS_PLAN_JIT) && pl->kernel == QDAS_KERNEL_TILED && !pl->tp.bf && !getenv("QDAS_NO_JIT")) {
         const TileParams &t = pl->tp;
         JitSpec k{};
         k.interp = (z.flag & 7) == 4 ? 1 : (z.flag & 7); k.dtype = dt; k.fmod = t.fmod != 0.0; k.wtab = t.wtab != nullptr; k.sym = t.sym; k.big = t.big;
@@ -557,7 +565,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; }
         else { pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel"; }
     }
-    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->jit_fn && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
+    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->jit_fn && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
     // four frames per launch: not for fp32 plans with remodulation, a weight table or a pixel x receiver weight (das_tile_impl.h launch_tile_i)
     pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr
                   || (dt == QDAS_F32 && pl->kernel == QDAS_KERNEL_TILED && (pl->tp.fmod != 0.0 || pl->tp.wtab || pl->tp.apix || pl->tp.gen_kind));

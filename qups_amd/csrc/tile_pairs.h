@@ -17,7 +17,7 @@ namespace qdas {
 template <class C> template <bool CHECK, bool TAILV>
 __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, int bn, float rb, uint32_t cbase, float phB) {
     constexpr int K = C::K, MB = C::MB, WB = C::WB, INTERP = C::INTERP, NHP = C::NHP;
-    constexpr bool SYM = C::SYM, FB4 = C::FB4, FBX = C::FBX, TWO = C::TWO, F32 = C::F32, FMOD = C::FMOD, WTAB = C::WTAB;
+    constexpr bool SYM = C::SYM, FB4 = C::FB4, FBX = C::FBX, TWO = C::TWO, F32 = C::F32, FMOD = C::FMOD, WTAB = C::WTAB, BF = C::BF;
     constexpr bool TAIL = !SYM && TAILV, DIAG = SYM && TAILV;
     unroll<MB / 2>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
@@ -35,14 +35,14 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
             const float2 wa = ((const float2 *)P.wtab)[n + (size_t)N * m];
             const float2 wb_ = upper ? ((const float2 *)P.wtab)[n + (size_t)N * (m + 1)] : make_float2(0.f, 0.f);
             wr0 = wa.x; wi0 = wa.y; wr1 = wb_.x; wi1 = wb_.y;
-            if (wr0 == 0.f && wi0 == 0.f && wr1 == 0.f && wi1 == 0.f) return;   // zero weights: skip (src/bf.cu:122,126)
+            if constexpr (!BF) { if (wr0 == 0.f && wi0 == 0.f && wr1 == 0.f && wi1 == 0.f) return; }   // zero weights: skip (src/bf.cu:122,126); 'BF' stores the zeros
         }
         const v2f t = ra[p] + rb;
         const v2f tm = t + MAGIC;
         const v2f s = t - (tm - MAGIC);
         const uint32_t ad0 = (hooks::linear_taps ? (MAGIC_BITS + (uint32_t)lane + (__float_as_uint(tm.x) & 1u)) : __float_as_uint(tm.x)) * (uint32_t)C::SB + cbase;
         const uint32_t ad1 = (hooks::linear_taps ? (MAGIC_BITS + (uint32_t)lane + (__float_as_uint(tm.y) & 1u)) : __float_as_uint(tm.y)) * (uint32_t)C::SB + cbase;
-        constexpr bool SPLIT = CHECK || FMOD || WTAB;       // the two halves need separate post-processing
+        constexpr bool SPLIT = CHECK || FMOD || WTAB || BF; // the two halves need separate post-processing
         v2f w[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         // one pass per FRAME PAIR (two passes when four frames share the launch): same tap index and weights
         unroll<NHP>([&](auto hpc) {
@@ -162,7 +162,20 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                     u1 = (v2f){u1.x * c1 - u1.y * s1, u1.x * s1 + u1.y * c1};
                 }
             }
-            if constexpr (WTAB) {
+            if constexpr (BF) {                       // 'BF' (src/bf.cu:134-135): the pair's weighted sample IS the output, plane nm of y
+                if constexpr (WTAB) {
+                    v0 = (v2f){wr0 * v0.x - wi0 * v0.y, wr0 * v0.y + wi0 * v0.x};
+                    v1 = (v2f){wr1 * v1.x - wi1 * v1.y, wr1 * v1.y + wi1 * v1.x};
+                }
+                if (in_shard) {
+                    float2 *pl0 = (float2 *)P.y + ((size_t)n * P.bf_pn + (size_t)m * P.bf_pm) * P.y_ld;      // uniform
+                    asm volatile("" : "+s"(pl0));
+                    uint32_t po = pofs;
+                    asm volatile("" : "+v"(po));
+                    pl0[po] = make_float2(v0.x, v0.y);
+                    if (upper) { float2 *pl1 = pl0 + P.bf_pm * P.y_ld; asm volatile("" : "+s"(pl1)); pl1[po] = make_float2(v1.x, v1.y); }
+                }
+            } else if constexpr (WTAB) {
                 A0 += (v2f){wr0 * v0.x - wi0 * v0.y, wr0 * v0.y + wi0 * v0.x};
                 A0 += (v2f){wr1 * v1.x - wi1 * v1.y, wr1 * v1.y + wi1 * v1.x};
                 if constexpr (FBX) {

@@ -35,6 +35,8 @@ struct TileParams {
     uint32_t tiles_z, tiles_x, tile_x0; // tile grid over (I1 >> tz_log2) x (columns / tile columns); first column tile of the shard
     int32_t syn;                        // 1: 'SYN' -- keep the receive dimension: y is I x N planes (leading dimension y_ld), zero-filled by the host
     uint64_t y_ld;
+    int32_t bf;                         // 1: 'BF' -- keep both aperture dimensions: plane (n*bf_pn + m*bf_pm) of y per pair (launch configuration 12)
+    uint64_t bf_pn, bf_pm;              // plane strides of the stage / block element: (1, N) or -- transposed data -- (M, 1): the DATA's aperture order (src/bf.cu:100,135)
     int32_t nfr;                        // frames per launch: 1, or 2 / 4 (frame f at x + f*x_fstride -> y + f*y_fstride); 1 with sym
     uint64_t x_fstride, y_fstride;      // frame strides: BYTES of x, ELEMENTS of y
     uint32_t ksplit;                    // workgroups per tile (>= 1): each sums a slice of the aperture into part[], then reduced into y

@@ -103,7 +103,7 @@ def test_keep_modes(fun):
     case = make_case(seq="PW", interp="linear", seed=4, N=8, M=5, I1=40, I2=6)
     ref = run_oracle(case, fun=fun)
     out, plan = run_das(case, fun=fun)
-    assert plan.kernel == ("generic" if fun == "BF" else "tiled")        # 'SYN' / 'MUL' with fp32 data: planes accumulated by the tiled kernel
+    assert plan.kernel == "tiled"        # fp32 data: 'SYN' / 'MUL' planes are accumulated, 'BF' planes stored, by the fused kernel
     assert out.shape == ref.shape
     assert rel_err(out, ref) <= TOL32
     gen, _ = run_das(case, fun=fun, kernel=1)
@@ -367,8 +367,8 @@ def test_error_paths():
     assert ei.value.identifier == "QUPS:das_spec:UnrecognizedInput"
     with pytest.raises(DasError, match="Apodization data size inconsistent with receiver"):
         das_spec("DAS", *args, "apod", np.ones((1, 1, 1, 5, 1)))
-    with pytest.raises(_lib.QdasError, match="tiled kernel"):
-        das_spec("BF", *args, kernel=2)
+    with pytest.raises(_lib.QdasError, match="tiled kernel"):           # forcing the fused kernel on a case it cannot serve says why
+        das_spec("BF", *args, "input-precision", "double", kernel=2)
 
 
 def test_reciprocal_mode_matches_general_mode(monkeypatch):
@@ -705,3 +705,43 @@ def test_sharded_c_abi_entry_on_one_device(fun, ndev, mem):
         L.qdas_plan_destroy_sharded(h)
         assert np.array_equal(yh.transpose(2, 1, 0), y1.cpu().numpy())
     one.close()
+
+
+@pytest.mark.parametrize("seq,interp,extra", [("PW", "cubic", {}), ("FSA", "lanczos3", {}), ("FC", "linear", {"fmod": 3e6}), ("DV", "nearest", {}),
+                                              ("PW", "linear", {"apod": True}), ("FSA", "cubic", {"tpose": True})])
+def test_bf_mode_on_the_tiled_kernel(seq, interp, extra):
+    """'BF' (keep both aperture dimensions, src/bf.cu:134-135) runs on the fused kernel for fp32 data: every pair's weighted sample
+    goes to plane nm of y.  Against the float64 oracle and against the one-pixel-per-lane kernel; ragged tiles, odd M, record edges."""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import das_spec
+    case = make_case(seq=seq, interp=interp, seed=17, N=9, M=7 if seq != "FSA" else None, I1=70, I2=19)
+    x = case["x"]
+    N, M = x.shape[1], x.shape[2]
+    fmod = float(np.float32(extra.get("fmod", 0.0)))
+    opts = list(case["opt"]) + ["interp", interp, "modulation", fmod]
+    apod = []
+    if extra.get("apod"):
+        rng = np.random.default_rng(2)
+        a = (rng.random((1, 1, 1, N, M)) + 1j * rng.random((1, 1, 1, N, M))).astype(np.complex64)
+        a[0, 0, 0, 2, :] = 0                                     # a dead receiver: its planes must hold exact zeros
+        apod = [a]
+        opts += ["apod", a]
+    xin = x
+    if extra.get("tpose"):
+        xin = np.ascontiguousarray(np.swapaxes(x, 1, 2))
+        opts += ["transpose", True]
+    args = (case["Pi"], case["Pr"], case["Pv"], case["Nv"], torch.from_numpy(xin), case["t0"], case["fs"], case["c"])
+    y2, p2 = das_spec("BF", *args, *opts, return_plan=True, kernel=2)
+    y1, p1 = das_spec("BF", *args, *opts, return_plan=True, kernel=1)
+    assert p2.kernel == "tiled" and p1.kernel == "generic"
+    ref = O.das_spec("BF", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xin, case["t0"], case["fs"], cinv_f32(case["c"]),
+                     VS=case["VS"], DV=case["DV"], interp=interp, apod=apod, fmod=fmod, tpose=bool(extra.get("tpose")))
+    y2n, y1n = y2.cpu().numpy().reshape(ref.shape), y1.cpu().numpy().reshape(ref.shape)
+    tol = 1e-2 if interp == "nearest" else (2e-4 if fmod else 2e-5)
+    assert rel_err(y2n, ref) <= tol
+    assert rel_err(y2n, y1n) <= max(tol, 1e-4)
+    if extra.get("apod"):
+        assert not np.any(y2n[:, :, :, 2, :])
+    auto, pa = das_spec("BF", *args, *opts, return_plan=True)
+    assert pa.kernel == "tiled"                                   # the fused kernel is the default for fp32 'BF'
