@@ -138,8 +138,9 @@ template <class C> struct Tile {
     __device__ __forceinline__ uint32_t nlim(uint32_t m0) const { return C::SYM ? (m0 + C::MB < N ? m0 + C::MB : N) : n_hi; }
 
     // delays (fp64)
-    static __device__ __forceinline__ double dsqrt(double d2) {          // fp32 seed + one Newton step (rel. error ~1e-14)
-        const float s0 = __builtin_sqrtf((float)d2);
+    // fp32 seed (the raw v_sqrt_f32, 1 ulp: the IEEE-exact sqrtf expands to ~20 instructions) + one Newton step in fp64 (rel. error ~1e-14)
+    static __device__ __forceinline__ double dsqrt(double d2) {
+        const float s0 = __builtin_amdgcn_sqrtf((float)d2);
         const double sd = (double)s0;
         const double r = __builtin_fma(-sd, sd, d2);
         return __builtin_fma(r, (double)(0.5f * __builtin_amdgcn_rcpf(fmaxf(s0, 1.0e-30f))), sd);

@@ -24,15 +24,15 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
     auto a_est = [&](uint32_t m) -> float {
         if (!pro32) return (float)a_of(m, gPv, gNv);
         const float rx = px - gPv[4 * m], ry = py - gPv[4 * m + 1], rz = pz - gPv[4 * m + 2];
-        const float d = kindB != 2 ? __builtin_sqrtf(rx * rx + ry * ry + rz * rz) : rx * gNv[3 * m] + ry * gNv[3 * m + 1] + rz * gNv[3 * m + 2];
+        const float d = kindB != 2 ? __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz) : rx * gNv[3 * m] + ry * gNv[3 * m + 1] + rz * gNv[3 * m + 2];
         return d * cf32 - gPv[4 * m + 3] * fs32 + (float)tapinfo<INTERP>::OFF;
     };
     auto b_est = [&](uint32_t n) -> float {
         if constexpr (LUT) return P.lut_rx[ipx + Ilut * n];
         if (kindS == 1) return (float)s_at(n, P.Pr[3 * n], P.Pr[3 * n + 1], P.Pr[3 * n + 2]);
         const float rx = px - P.Pr[3 * n], ry = py - P.Pr[3 * n + 1], rz = pz - P.Pr[3 * n + 2];
-        if (!has_st) return __builtin_sqrtf(rx * rx + ry * ry + rz * rz) * cf32;
-        if (kindS == 0) return __builtin_sqrtf(rx * rx + ry * ry + rz * rz) * cf32 - P.St[4 * n] * fs32;
+        if (!has_st) return __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz) * cf32;
+        if (kindS == 0) return __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz) * cf32 - P.St[4 * n] * fs32;
         return (rx * P.St[4 * n + 1] + ry * P.St[4 * n + 2] + rz * P.St[4 * n + 3]) * cf32 - P.St[4 * n] * fs32;
     };
     // |fp32 estimate - fp64 delay| <= ~4e-7 * (|distance*cf| + |t0*fs|), and |distance*cf| <= |a| + |t0*fs| + 1: 1e-6 is generous

@@ -106,7 +106,7 @@ static __device__ __noinline__ float block_residual(float px, float py, float pz
     double dv = dot;
     if (kindB != 2) {
         const double d2 = rx * rx + ry * ry + rz * rz;
-        const float s0 = __builtin_sqrtf((float)d2);                  // fp32 seed + one Newton step (as dsqrt in the kernel)
+        const float s0 = __builtin_amdgcn_sqrtf((float)d2);                  // fp32 seed + one Newton step (as dsqrt in the kernel)
         const double sd = (double)s0;
         const double r = __builtin_fma(-sd, sd, d2);
         const double len = __builtin_fma(r, (double)(0.5f * __builtin_amdgcn_rcpf(fmaxf(s0, 1.0e-30f))), sd);
