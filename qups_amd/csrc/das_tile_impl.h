@@ -104,11 +104,12 @@ template <class C> struct Tile {
     double fs, symC; int symCi;
     bool tile_interior;
     // ---- this lane's pixel
-    uint32_t pofs;                                   // my pixel's offset in this plan's slab (valid if in_shard; the host keeps slabs below 2^32 pixels)
+    static constexpr uint32_t NOT_MINE = 0xffffffffu;
+    uint32_t pofs;                                   // my pixel's offset in this plan's slab, or NOT_MINE (lane outside the image / the slab; slabs stay below 2^32 - 1 pixels)
+    __device__ __forceinline__ bool in_shard() const { return pofs != NOT_MINE; }
     uint64_t ipx;                                    // (clamped) linear pixel index: row of per-pixel arrays / delay tables
     float px, py, pz;
     double cf;                                       // samples per metre (scalar sound speed or this pixel's entry of the map)
-    bool in_shard;
     // ---- stage loop
     uint32_t n_lo, n_hi, nstage;
     v2f acc, acc1, acc2, acc3;                       // independent partial sums: no back-to-back dependent packed FMAs
@@ -125,6 +126,7 @@ template <class C> struct Tile {
     __device__ __forceinline__ Tile(const TileParams &p) : P(p) {}
 
     __device__ __forceinline__ void setup(unsigned char *smem);          // LDS carve-up, tile / pixel of this lane
+    __device__ __forceinline__ uint32_t locate(uint32_t &i1, uint32_t &col, bool first);
     template <bool PROBE> __device__ __forceinline__ bool prologue();    // window bases + fit verdict           (tile_prologue.h)
     __device__ __forceinline__ void plan_stages();                       // this workgroup's share of the aperture
     template <bool CHECK> __device__ __forceinline__ void run();         // the stage loop
@@ -175,6 +177,44 @@ template <class C> struct Tile {
 namespace qdas {
 
 // ------------------------------------------------------------------------------------------------- which tile, which pixel
+// (row, column) of this lane's pixel and its offset in the plan's slab.  Called by setup() and -- in the register-tight reciprocal
+// kernels -- AGAIN by the epilogue: ~25 mostly scalar instructions once per tile, instead of a register held through the stage loop.
+template <class C> __device__ __forceinline__ uint32_t Tile<C>::locate(uint32_t &i1, uint32_t &col, bool first) {
+    // ---- which tile (XCD-aware: consecutive tile ids -> same XCD; dispatch is round-robin mod 8)
+    const uint32_t nb = gridDim.x;
+    uint32_t bid = blockIdx.x;
+    {
+        const uint32_t q = nb / 8, r = nb % 8, xcd = bid % 8, k = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;   // bijective remap
+    }
+    // columns fastest: the tiles an XCD runs concurrently sit at the SAME depth band, so they stage (nearly) the same window of
+    // every trace and the XCD's L2 serves all but the first of them.  split = slowest index: the workgroups an XCD runs
+    // concurrently work on the SAME slice of the aperture of neighbouring tiles
+    const uint32_t ntile = P.tiles_x * P.tiles_z;
+    const uint32_t sp = bid / ntile;
+    bid -= sp * ntile;
+    const uint32_t tz = bid / P.tiles_x, txi = P.tile_x0 + bid % P.tiles_x;
+    if (first) { S = QSPEC(KSPLIT, P.ksplit); split = sp; tile_id = tz + P.tiles_z * txi; }
+
+    // ---- my pixel.  Tile and wave footprints (uniform, chosen by the plan from the scan's delay gradient; qdas_api.hip
+    //      choose_tile_shape): the tile is (1 << tzl) pixels of I1 x (1024 >> tzl) columns -- as deep as the LDS window allows;
+    //      inside it a wave covers (1 << wzl) x (64 >> wzl) pixels -- as shallow as needed for the 32 lanes of an LDS access group
+    //      to read <= 32 consecutive samples (conflict-free), e.g. 8 x 8 when the delay advances 2 samples per pixel of depth.
+    //      Out-of-image lanes are clamped onto a real pixel (keeps them inside the tile's delay window) and masked at the store.
+    const uint64_t I1 = QSPEC(I1, P.I1);
+    const uint64_t ncols = P.I2 * P.I3, i_end = P.i_begin + P.i_count;
+    const int tzl = QSPEC(TZL, P.tz_log2), wzl = QSPEC(WZL, P.wz_log2);
+    const uint32_t wave_z = (uint32_t)wave & ((1u << (tzl - wzl)) - 1u), wave_c = (uint32_t)wave >> (tzl - wzl);
+    // (depth index, column: may lie outside the image -- clamped for the delays, masked at the store)
+    i1 = (tz << tzl) + (wave_z << wzl) + (uint32_t)(lane & ((1 << wzl) - 1));
+    col = txi * ((uint32_t)(C::WAVES * 64) >> tzl) + (wave_c << (6 - wzl)) + (uint32_t)(lane >> wzl);
+    const uint64_t ig = (uint64_t)i1 + I1 * (uint64_t)col;
+    const bool inside = ((uint64_t)i1 < I1) && ((uint64_t)col < ncols) && (ig >= P.i_begin) && (ig < i_end);
+    uint32_t po = inside ? (uint32_t)(ig - P.i_begin) : NOT_MINE;
+    asm volatile("" : "+v"(po));                      // opaque: ONE register carries "mine?" and "where" (never re-derived from the 64-bit (row, column) pair)
+    return po;
+}
+
 template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char *smem) {
     tid = threadIdx.x; lane = tid & 63;
     wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keeps everything derived from it in SGPRs
@@ -194,43 +234,14 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
     part = (float *)(smem + hdr);                     // prologue scratch, aliases the windows
     win_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem) + hdr;
 
-    // ---- which tile (XCD-aware: consecutive tile ids -> same XCD; dispatch is round-robin mod 8)
-    const uint32_t nb = gridDim.x;
-    uint32_t bid = blockIdx.x;
-    {
-        const uint32_t q = nb / 8, r = nb % 8, xcd = bid % 8, k = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;   // bijective remap
-    }
-    // columns fastest: the tiles an XCD runs concurrently sit at the SAME depth band, so they stage (nearly) the same window of
-    // every trace and the XCD's L2 serves all but the first of them.  split = slowest index: the workgroups an XCD runs
-    // concurrently work on the SAME slice of the aperture of neighbouring tiles
-    const uint32_t ntile = P.tiles_x * P.tiles_z;
-    S = QSPEC(KSPLIT, P.ksplit);
-    split = bid / ntile;
-    bid -= split * ntile;
-    const uint32_t tz = bid / P.tiles_x, txi = P.tile_x0 + bid % P.tiles_x;
-    tile_id = tz + P.tiles_z * txi;
-
-    // ---- my pixel.  Tile and wave footprints (uniform, chosen by the plan from the scan's delay gradient; qdas_api.hip
-    //      choose_tile_shape): the tile is (1 << tzl) pixels of I1 x (1024 >> tzl) columns -- as deep as the LDS window allows;
-    //      inside it a wave covers (1 << wzl) x (64 >> wzl) pixels -- as shallow as needed for the 32 lanes of an LDS access group
-    //      to read <= 32 consecutive samples (conflict-free), e.g. 8 x 8 when the delay advances 2 samples per pixel of depth.
-    //      Out-of-image lanes are clamped onto a real pixel (keeps them inside the tile's delay window) and masked at the store.
-    const uint64_t I1 = QSPEC(I1, P.I1);
-    const uint64_t ncols = P.I2 * P.I3, i_end = P.i_begin + P.i_count;
-    const int tzl = QSPEC(TZL, P.tz_log2), wzl = QSPEC(WZL, P.wz_log2);
-    const uint32_t wave_z = (uint32_t)wave & ((1u << (tzl - wzl)) - 1u), wave_c = (uint32_t)wave >> (tzl - wzl);
-    // (depth index, column: may lie outside the image -- clamped for the delays, masked at the store)
-    const uint32_t i1 = (tz << tzl) + (wave_z << wzl) + (uint32_t)(lane & ((1 << wzl) - 1));
-    const uint32_t col = txi * ((uint32_t)(C::WAVES * 64) >> tzl) + (wave_c << (6 - wzl)) + (uint32_t)(lane >> wzl);
-    const uint64_t ig = (uint64_t)i1 + I1 * (uint64_t)col;
-    in_shard = ((uint64_t)i1 < I1) && ((uint64_t)col < ncols) && (ig >= P.i_begin) && (ig < i_end);
-    pofs = (uint32_t)(ig - P.i_begin);
-    asm volatile("" : "+v"(pofs));                    // opaque: carried through the stage loop as ONE register (not re-derived from the 64-bit (row, column) pair at the end)
+    uint32_t i1, col;
+    pofs = locate(i1, col, true);
+    const uint64_t I1 = QSPEC(I1, P.I1), ncols = P.I2 * P.I3;
     ipx = ((uint64_t)i1 < I1 ? (uint64_t)i1 : I1 - 1) + I1 * ((uint64_t)col < ncols ? (uint64_t)col : ncols - 1);
     cf = P.cinv_fs;
     if constexpr (C::LUT) {                            // delays from host tables (tau_tx: I x M, tau_rx: I x N, in samples; table-driven plans cover [0, I))
         px = py = pz = 0.f;
+        const uint64_t i_end = P.i_begin + P.i_count;
         ipx = ipx < i_end ? ipx : i_end - 1;
     } else {
         px = P.Pi[3 * ipx]; py = P.Pi[3 * ipx + 1]; pz = P.Pi[3 * ipx + 2];
@@ -410,7 +421,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
 #pragma unroll
             for (int f = 0; f < C::NFR; ++f) {
                 if (wpix) Sf[f] = (v2f){wcur.x * Sf[f].x - wcur.y * Sf[f].y, wcur.x * Sf[f].y + wcur.y * Sf[f].x};
-                if (in_shard) {
+                if (in_shard()) {
                     float2 *plane = (float2 *)P.y + (size_t)f * P.y_fstride + (size_t)n * P.y_ld;     // uniform: stays in SGPRs;
                     asm volatile("" : "+s"(plane));                // opaque, so that no per-frame 64-bit lane address is hoisted out of the stage loop
                     uint32_t po = pofs;
@@ -439,8 +450,9 @@ template <class C> __device__ __forceinline__ void Tile<C>::epilogue() {
     if (syn || C::BF) return;                          // every stage already added its share to its plane / stored its pairs
     v2f res[4];
     frame_sums(res);
-    if (in_shard) {
-        uint32_t po = pofs;
+    uint32_t po = pofs;
+    if constexpr (C::SYM) { uint32_t i1, col; po = locate(i1, col, false); }      // (nothing in the reciprocal stage loop needs it: not kept alive)
+    if (po != NOT_MINE) {
         asm volatile("" : "+v"(po));
 #pragma unroll
         for (int f = 0; f < C::NFR; ++f) {

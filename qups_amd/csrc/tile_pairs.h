@@ -49,7 +49,7 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
             constexpr int hp = decltype(hpc)::value;
             constexpr int GSET = FB4 ? 2 * hp : 0, HSET = FB4 ? 2 * hp + 1 : 1;       // window sets of the pass
             v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : &acc1);
-            v2f &B0 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc3);
+            v2f &B0 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(SYM ? &acc2 : (FB4 ? (hp ? &acc3 : &acc1) : &acc3));
             v2f v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
             v2f u0 = {0.f, 0.f}, u1 = {0.f, 0.f};     // the same two pairs of the second frame (FB2)
             if constexpr (F32) {
@@ -167,7 +167,7 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                     v0 = (v2f){wr0 * v0.x - wi0 * v0.y, wr0 * v0.y + wi0 * v0.x};
                     v1 = (v2f){wr1 * v1.x - wi1 * v1.y, wr1 * v1.y + wi1 * v1.x};
                 }
-                if (in_shard) {
+                if (in_shard()) {
                     float2 *pl0 = (float2 *)P.y + ((size_t)n * P.bf_pn + (size_t)m * P.bf_pm) * P.y_ld;      // uniform
                     asm volatile("" : "+s"(pl0));
                     uint32_t po = pofs;
@@ -226,7 +226,9 @@ template <class C> __device__ __forceinline__ void Tile<C>::pairs_pipelined(floa
         if constexpr (u + 1 < NU) lds_fence2_keep<8>(gd0[u & 1], gd1[u & 1], h0, h1, w);
         else                      lds_fence2_keep<0>(gd0[u & 1], gd1[u & 1], h0, h1, w);
         v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : &acc1);
-        v2f &B0 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc3);
+        // (reciprocal mode: both mirror halves share ONE accumulator -- three in all; with 32-transmit stages the fourth costs the two
+        //  registers that would otherwise spill, and measures the same: profiles/r02/exp_prio.txt)
+        v2f &B0 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(C::SYM ? &acc2 : (FB4 ? (hp ? &acc3 : &acc1) : &acc3));
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             tap_mac(A0, gd0[u & 1], k, w[k].x); tap_mac(A1, gd1[u & 1], k, w[k].y);
