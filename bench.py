@@ -116,7 +116,7 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def measure_traffic(argv, kernel_hint="das_tile_kernel"):
+def measure_traffic(argv):
     """HBM bytes per launch of the dominant kernel from rocprofv3 counter passes of THIS command (one pass per counter: FETCH_SIZE
     and WRITE_SIZE do not fit together), corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KiB) x 2 for 16 B/lane
     streaming reads, WRITE_SIZE (KiB) as is.  Returns (bytes | None, source string)."""
@@ -137,10 +137,12 @@ def measure_traffic(argv, kernel_hint="das_tile_kernel"):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
-            rows = [x for x in csv.DictReader(open(files[0])) if x["Counter_Name"] == ctr and kernel_hint in x["Kernel_Name"]
-                    and "generic" not in x["Kernel_Name"]]
-            if not rows:
-                rows = [x for x in csv.DictReader(open(files[0])) if x["Counter_Name"] == ctr]
+            rows = [x for x in csv.DictReader(open(files[0])) if x["Counter_Name"] == ctr]
+            tot = {}
+            for x in rows:                                   # the dominant kernel = largest total duration (the frame kernel: prebuilt
+                tot[x["Kernel_Name"]] = tot.get(x["Kernel_Name"], 0) + int(x["End_Timestamp"]) - int(x["Start_Timestamp"])   # das_tile_kernel<...> or hiprtc-built qdas_jit_tile)
+            dom = max(tot, key=tot.get)
+            rows = [x for x in rows if x["Kernel_Name"] == dom]
             dur = [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in rows]
             full = [float(x["Counter_Value"]) for x, t in zip(rows, dur) if t >= 0.5 * max(dur)]   # (plan-time probe launches are short)
             vals[ctr] = sum(full) / len(full)

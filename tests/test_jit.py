@@ -17,6 +17,8 @@ def test_hiprtc_builds_the_specialised_kernel_without_a_device(tmp_path, monkeyp
     L = _lib.lib()
     f = L.qdas_debug_jit_compile
     f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.c_char_p, C.c_size_t, C.POINTER(C.c_ulonglong)]
+    monkeypatch.setenv("QDAS_JIT_NARROW", "1")            # the reciprocal build plans use: 128-sample windows, 32 transmits per stage
+    monkeypatch.setenv("QDAS_JIT_MB", "32")
     for interp, dtype, sym, fmod in ((3, 1, 1, 0), (2, 2, 0, 1)):
         msg, n = C.create_string_buffer(4000), C.c_ulonglong()
         rc = f(interp, dtype, sym, fmod, 64, 64, 1024, msg, 4000, C.byref(n))
