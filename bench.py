@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--jit", action="store_true", help="(default; kept for compatibility)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "none"],
                     help="roofline.traffic: rocprofv3 counter passes of this command (live; auto = live at N=1) or profiles/traffic_<w>.json")
+    ap.add_argument("--fmod", type=float, default=0.0, help="remodulation frequency [Hz] ('modulation' option): baseband data; not the headline")
     ap.add_argument("--prec", default=None, help="override the workload's data precision (single | halfT); not the headline")
     ap.add_argument("--gen-apod", action="store_true", help="generate the workload's receive apodization inside the kernel "
                     "(qdas_desc.rx_apod_*) instead of streaming the materialised I x N array")
@@ -214,7 +215,9 @@ def main():
     I = w["I1"] * w["I2"]
     g = torch.Generator(device=dev).manual_seed(1234)     # same data on every rank (replicated input)
     xc = torch.view_as_complex(torch.randn((M, N, T, 2), generator=g, device=dev, dtype=torch.float32))
-    extra = ["interp", w["interp"], "input-precision", w["prec"]]
+    extra = ["interp", w["interp"], "input-precision", w["prec"]] + (["modulation", args.fmod] if args.fmod else [])
+    if args.fmod:
+        w["label"] += f" [fmod {args.fmod:g} Hz]"
     if args.gen_apod and w["rx_apod"] is not None:
         from qups_amd.apodization import rx_apod_spec
         extra += ["rx-apod", rx_apod_spec(w["rx_apod"][0], normals=w["nrm"], **w["rx_apod"][1])]
@@ -313,7 +316,7 @@ def main():
             mode = "live" if world == 1 else "file"
         if mode == "live":
             argv = ["--workload", args.workload] + (["--kernel", str(args.kernel)] if args.kernel else []) + \
-                   (["--prec", args.prec] if args.prec else []) + (["--gen-apod"] if args.gen_apod else []) + \
+                   (["--prec", args.prec] if args.prec else []) + (["--fmod", str(args.fmod)] if args.fmod else []) + (["--gen-apod"] if args.gen_apod else []) + \
                    (["--no-reciprocal"] if args.no_reciprocal else []) + (["--no-jit"] if args.no_jit else [])
             traffic, tsrc = measure_traffic(argv)
             if traffic is None:

@@ -155,11 +155,16 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                 const v2f ph = t * f + ((v2f){Aext[m], Aext[mb]} + phB);
                 const float c0 = __builtin_amdgcn_cosf(ph.x), s0 = __builtin_amdgcn_sinf(ph.x);
                 const float c1 = __builtin_amdgcn_cosf(ph.y), s1 = __builtin_amdgcn_sinf(ph.y);
-                v0 = (v2f){v0.x * c0 - v0.y * s0, v0.x * s0 + v0.y * c0};
-                v1 = (v2f){v1.x * c1 - v1.y * s1, v1.x * s1 + v1.y * c1};
-                if constexpr (FBX) {
-                    u0 = (v2f){u0.x * c0 - u0.y * s0, u0.x * s0 + u0.y * c0};
-                    u1 = (v2f){u1.x * c1 - u1.y * s1, u1.x * s1 + u1.y * c1};
+                if constexpr (!BF && !WTAB) {       // rotate and accumulate in one go: two packed FMAs per sample (acc += v*c; acc += (v.y, v.x)*(-s, s))
+                    rot_acc(A0, v0, c0, s0); rot_acc(A1, v1, c1, s1);
+                    if constexpr (FBX) { rot_acc(B0, u0, c0, s0); rot_acc(B1, u1, c1, s1); }
+                } else {
+                    v0 = (v2f){v0.x * c0 - v0.y * s0, v0.x * s0 + v0.y * c0};
+                    v1 = (v2f){v1.x * c1 - v1.y * s1, v1.x * s1 + v1.y * c1};
+                    if constexpr (FBX) {
+                        u0 = (v2f){u0.x * c0 - u0.y * s0, u0.x * s0 + u0.y * c0};
+                        u1 = (v2f){u1.x * c1 - u1.y * s1, u1.x * s1 + u1.y * c1};
+                    }
                 }
             }
             if constexpr (BF) {                       // 'BF' (src/bf.cu:134-135): the pair's weighted sample IS the output, plane nm of y
@@ -176,12 +181,9 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                     if (upper) { float2 *pl1 = pl0 + P.bf_pm * P.y_ld; asm volatile("" : "+s"(pl1)); pl1[po] = make_float2(v1.x, v1.y); }
                 }
             } else if constexpr (WTAB) {
-                A0 += (v2f){wr0 * v0.x - wi0 * v0.y, wr0 * v0.y + wi0 * v0.x};
-                A0 += (v2f){wr1 * v1.x - wi1 * v1.y, wr1 * v1.y + wi1 * v1.x};
-                if constexpr (FBX) {
-                    B0 += (v2f){wr0 * u0.x - wi0 * u0.y, wr0 * u0.y + wi0 * u0.x};
-                    B0 += (v2f){wr1 * u1.x - wi1 * u1.y, wr1 * u1.y + wi1 * u1.x};
-                }
+                rot_acc(A0, v0, wr0, wi0); rot_acc(A1, v1, wr1, wi1);             // complex weight folded into the accumulation
+                if constexpr (FBX) { rot_acc(B0, u0, wr0, wi0); rot_acc(B1, u1, wr1, wi1); }
+            } else if constexpr (FMOD) {              // (accumulated by the rotation above)
             } else if constexpr (SPLIT || K == 1) { A0 += v0; A0 += v1; if constexpr (FBX) { B0 += u0; B0 += u1; } }
         });
     });

@@ -100,6 +100,11 @@ __device__ __forceinline__ void mix_mac(v2f &acc, uint32_t tap, float w) {      
         : "+v"(ar), "+v"(ai) : "v"(tap), "v"(w));
     acc = (v2f){ar, ai};
 }
+// acc += v * (c + i s): complex rotation folded into the accumulation ('modulation': two packed FMAs per sample)
+__device__ __forceinline__ void rot_acc(v2f &acc, v2f v, float c, float s) {
+    acc = v * c + acc;
+    acc = (v2f){v.y, v.x} * (v2f){-s, s} + acc;
+}
 // acc += w * tap k, either data type (software-pipelined loop)
 __device__ __forceinline__ void tap_mac(v2f &acc, const taps_f32 &t, int k, float w) { acc = w * t.s[k] + acc; }
 __device__ __forceinline__ void tap_mac(v2f &acc, const taps_f16 &t, int k, float w) { mix_mac(acc, t.r[k], w); }
