@@ -29,6 +29,13 @@ def _draw(seed):
                tz=int(r.choice([0, 0, 64, 32, 16, 8])), ks=int(r.choice([0, 0, 1, 2, 3, 4])),
                fun=str(r.choice(["DAS", "DAS", "SYN", "MUL"])), F=int(r.choice([1, 1, 2, 3, 4, 6])), cmap=bool(r.integers(0, 4) == 0),
                gen=str(r.choice(["", "", "", "acceptance", "cosine", "fnumber"])))
+    # (round 2; drawn last so that the fields above keep their round-1 values per seed)
+    extra = dict(sym=bool(r.integers(0, 6) == 0), bf=bool(r.integers(0, 8) == 0), jit=bool(r.integers(0, 10) == 0))
+    if extra["sym"]:                # a reciprocal-mode candidate: full synthetic aperture, M == N, no weights, plain 'DAS'
+        cfg.update(seq="FSA", M=N, wn=False, wm=False, wpix=False, gen="", fun="DAS")
+    elif extra["bf"] and cfg["prec"] == "single":
+        cfg.update(fun="BF", F=min(cfg["F"], 2))
+    cfg.update(extra)
     if os.environ.get("QDAS_FUZZ_OVERRIDE"):                            # debugging aid: JSON dict of fields to force
         import json
         cfg.update(json.loads(os.environ["QDAS_FUZZ_OVERRIDE"]))
@@ -68,7 +75,7 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
         a[: c["I1"] // 3] = 0.0
         apod.append(a)
     fun = c["fun"] if c["prec"] == "single" else "DAS"                # 'SYN' / 'MUL' are fused for fp32 data only
-    if fun == "MUL" and ((c["wpix"] and N > 1) or c["gen"]):
+    if fun in ("MUL", "BF") and ((c["wpix"] and N > 1) or c["gen"]):
         fun = "SYN"                                                   # 'MUL' with pixel x receiver weights: generic kernel
     F = c["F"]
     xs_all = [x] + [(r.standard_normal(x.shape) + 1j * r.standard_normal(x.shape)).astype(np.complex64) for _ in range(F - 1)]
@@ -108,7 +115,9 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
     xt = torch.from_numpy(np.ascontiguousarray(xs))
     po = parse_options(xt, opts)
     prob = build_problem(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), t0, case["fs"], cval, po)
-    plan = DasPlan(prob, kernel=2, **kw)
+    plan = DasPlan(prob, kernel=2, jit=c["jit"], **kw)
+    if c["jit"] and fun != "BF":                                        # ('BF' runs the prebuilt kernel)
+        assert "[jit " in plan.kernel_name(), (c, plan.kernel_name())
     xc = _colmajor(_cast_data(xt, prob.prec, plan.device))
     y = plan.execute_colmajor(xc, F)                                    # (F, oM, oN, count)
     torch.cuda.synchronize()
@@ -118,6 +127,8 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
     for f in range(F):
         ref = O.das_spec(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs_all[f], t0, case["fs"], c_or,
                          VS=case["VS"], DV=case["DV"], interp=c["interp"], apod=oapod, fmod=c["fmod"])
+        if fun == "BF" and c["tpose"]:
+            ref = np.swapaxes(ref, -1, -2)                                # planes in the data's aperture order (src/bf.cu:99,135)
         refv = ref.reshape(I, -1, order="F")                              # pixels x planes
         if kw:
             refv = refv[kw["i_begin"]: kw["i_begin"] + kw["i_count"]]
