@@ -1,5 +1,5 @@
 // VGPR operand-bank experiment for v_pk_fma_f32 / v_fma_f32 on gfx950: same instruction count, different source-register placement.
-// hipcc -O3 --offload-arch=gfx950 tools/scratch/vgpr_bank.hip -o /tmp/vgpr_bank && /tmp/vgpr_bank
+// hipcc -O3 --offload-arch=gfx950 tools/microbench_src/vgpr_bank.hip -o /tmp/vgpr_bank && /tmp/vgpr_bank
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s\n", hipGetErrorString(e)); return 1; } } while (0)
