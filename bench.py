@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "none"],
                     help="roofline.traffic: rocprofv3 counter passes of this command (live; auto = live at N=1) or profiles/traffic_<w>.json")
     ap.add_argument("--fmod", type=float, default=0.0, help="remodulation frequency [Hz] ('modulation' option): baseband data; not the headline")
-    ap.add_argument("--prec", default=None, help="override the workload's data precision (single | halfT); not the headline")
+    ap.add_argument("--prec", default=None, help="override the workload's data precision (single | halfT | double); not the headline")
     ap.add_argument("--gen-apod", action="store_true", help="generate the workload's receive apodization inside the kernel "
                     "(qdas_desc.rx_apod_*) instead of streaming the materialised I x N array")
     args = ap.parse_args()
@@ -225,9 +225,9 @@ def main():
     elif w["apod"] is not None:
         extra += ["apod", w["apod"]]
     opts = parse_options(xc, list(w["opt"]) + extra)
-    if w["prec"] == "halfT":
+    if w["prec"] != "single":
         from qups_amd.das_spec import _cast_data
-        xc = _cast_data(xc, "halfT", dev).contiguous()
+        xc = _cast_data(xc, w["prec"], dev).contiguous()
     prob = build_problem("DAS", w["Pi"], w["Pr"], w["Pv"], w["Nv"], (T, N, M), w["t0"], w["fs"], w["c0"], opts)
     b, e = I * rank // world, I * (rank + 1) // world       # contiguous slab of the linear pixel index
     plan = DasPlan(prob, device=dev, kernel=args.kernel, i_begin=b, i_count=e - b, reciprocal=not args.no_reciprocal, jit=args.jit)
@@ -336,8 +336,8 @@ def main():
     if rank == 0:
         ms = el / args.steps * 1e3
         pairs = I * N * M
-        sb = 4 if w["prec"] == "halfT" else 8
-        apb = 0 if w["apod"] is None else w["apod"].size * (2 if w["prec"] == "halfT" else 4)
+        sb = {"halfT": 4, "single": 8, "double": 16}[w["prec"]]
+        apb = 0 if w["apod"] is None else w["apod"].size * sb // 2
         alg_bytes = (T * N * M * sb + 12 * I + sb * I + apb) / world      # per launch (per rank): x + Pi + y (+ apod)  (SURVEY 8d "B")
         info = _lib.device_info(local)
         ksec = kernel_ms * 1e-3
@@ -346,7 +346,7 @@ def main():
             "metric": "beamformed Mpixels/sec (1024^2 px, 256x256 Tx/Rx)" if w["name"] == "c3" else "beamformed Mpixels/sec",
             "value": round(I / (el / args.steps) / 1e6, 4), "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16" if w["prec"] == "halfT" else "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"halfT": "f16", "single": "f32", "double": "f64"}[w["prec"]], "data": "synthetic",
             "config": {"workload": w["label"], "pixels": I, "pairs_per_frame": pairs, "kernel": plan.kernel, "reciprocal_mode": reciprocal,
                        "kernel_name": plan.kernel_name(), "jit": bool(args.jit),
                        "fallback_tiles": fallback, "tile": list(plan.tile_shape()), "wave": list(plan.wave_shape()), "aperture_split": plan.aperture_split(), "parallelism": f"pixel-slab x{world} + RCCL all_gather" if world > 1 else "1 GPU",

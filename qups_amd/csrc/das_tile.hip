@@ -1,5 +1,5 @@
 // das_tile.hip -- host side of the tiled kernel: launch configurations, LDS budget, dispatch to the per-configuration
-// translation units (das_tile_{f32,f32big,lut,luth,sym,symw,symh,f16,f32x2,f16x2,f32x4,f16x4}.hip, kernel in das_tile_impl.h) and the fixed-order
+// translation units (das_tile_{f32,f32big,lut,luth,bf,sym,symw,symh,f16,f32x2,f16x2,f32x4,f16x4,f64}.hip, kernel in das_tile_impl.h) and the fixed-order
 // reduce of a split aperture.  -DQDAS_UNITY compiles everything as ONE translation unit (profiling / ablation builds that
 // pass -DQDAS_ABL / -DQDAS_PROF: tools/ablate.sh).
 #ifdef QDAS_UNITY
@@ -16,6 +16,7 @@
 #include "das_tile_lut.hip"
 #include "das_tile_luth.hip"
 #include "das_tile_bf.hip"
+#include "das_tile_f64.hip"
 #else
 #include "qdas_device.h"
 #include "qdas_kernels.h"
@@ -38,6 +39,7 @@ hipError_t launch_tile_f32big(const TileParams &P, unsigned ntiles, size_t lds, 
 hipError_t launch_tile_lut(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_luth(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_bf(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
+hipError_t launch_tile_f64(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 
 // y[i] = sum over the ksplit partial images, in split order (deterministic)
 template <typename ST>
@@ -58,7 +60,7 @@ TileConfig tile_config(int dtype, int sym, int narrow) {
     c.mb = g.mb;
     c.window = g.w;
     c.threads = g.waves * 64;
-    c.lds_bytes = (size_t)g.nbuf * g.mb * (sym ? 2 : 1) * g.w * (dtype == 2 ? 4 : 8);
+    c.lds_bytes = (size_t)g.nbuf * g.mb * (sym ? 2 : 1) * g.w * (dtype == 2 ? 4 : dtype == 0 ? 16 : 8);
     return c;
 }
 
@@ -66,7 +68,8 @@ size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow) {
     const Cfg &g = CFGS[cfg_index(dtype, sym, 1, narrow)];
     const TileConfig c = tile_config(dtype, sym, narrow);
     const size_t MX = M > N ? M : N;
-    const size_t hdr = (((((2 * M + N) * 4 + 15) & ~(size_t)15) + 16 * N + 7 * M * 4) + 15) & ~(size_t)15;
+    // (geometry tables in the plan's real type: 32-byte receiver records and 8-byte table entries for fp64 data -- Tile::setup)
+    const size_t hdr = (((((2 * M + N) * 4 + 15) & ~(size_t)15) + (dtype == 0 ? 32 : 16) * N + 7 * M * (dtype == 0 ? 8 : 4)) + 15) & ~(size_t)15;
     size_t body = c.lds_bytes;
     const size_t scratch = 2 * (size_t)g.waves * MX * 4 + 1024;   // prologue scratch aliases the windows
     if (body < scratch) body = scratch;
@@ -78,6 +81,12 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     if (ntiles == 0) return hipSuccess;
     const int sym = P.sym ? 1 : 0;
     if (sym && dtype != 1 && dtype != 2) return hipErrorInvalidValue;
+    if (dtype == 0) {                                    // fp64 data: one frame, one workgroup per tile, plain 'DAS' sum, prebuilt kernels
+        if (jit || P.lut_tx || P.bf || P.syn || P.big || P.nfr > 1 || (!P.probe && P.ksplit != 1)) return hipErrorInvalidValue;
+        const size_t lds64 = tile_lds_bytes(0, 0, P.N, P.M, 0);
+        if (lds64 > tile_lds_limit(0)) return hipErrorInvalidValue;
+        return launch_tile_f64(P, ntiles, lds64, s);
+    }
     const int narrow = (sym && dtype == 1 && P.narrow) ? 1 : 0;
     const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M, narrow);    // (the two-frame configurations have the same LDS image)
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;

@@ -14,9 +14,11 @@ struct Cfg { int waves, mb, w, nbuf, psz, bpc; };
 // cfg 10: cfg 0 with table-driven delays (the split-delay flavour: qdas_das_lut)
 // cfg 11: cfg 2 (fp16 data) with table-driven delays
 // cfg 12: cfg 0 keeping BOTH aperture dimensions ('BF': one output plane per (receiver, transmit) pair, nothing is summed)
-static constexpr Cfg CFGS[13] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1},
+// cfg 13: fp64 data (16-byte samples): 16 transmits per stage, 192-sample windows -- the LDS image of cfg 0
+static constexpr Cfg CFGS[14] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1},
                                 {16, 16, 192, 2, 16, 1}, {16, 16, 384, 2, 16, 1}, {16, 8, 192, 2, 16, 1}, {16, 8, 384, 2, 16, 1},
-                                {16, 16, 128, 2, 16, 1}, {16, 16, 256, 2, 16, 1}, {16, 32, 192, 2, 16, 1}, {16, 32, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1}, {16, 32, 192, 2, 16, 1}};
+                                {16, 16, 128, 2, 16, 1}, {16, 16, 256, 2, 16, 1}, {16, 32, 192, 2, 16, 1}, {16, 32, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1}, {16, 32, 192, 2, 16, 1},
+                                {16, 16, 192, 2, 16, 1}};
 // fb: frames per launch (1 | 2 | 4)
-static inline int cfg_index(int dtype, int sym, int fb = 1, int narrow = 0) { return sym ? (dtype == 2 ? 8 : (narrow ? 7 : 1)) : (fb == 4 ? (dtype == 2 ? 6 : 5) : (fb == 2 ? (dtype == 2 ? 4 : 3) : (dtype == 2 ? 2 : 0))); }
+static inline int cfg_index(int dtype, int sym, int fb = 1, int narrow = 0) { return dtype == 0 ? 13 : sym ? (dtype == 2 ? 8 : (narrow ? 7 : 1)) : (fb == 4 ? (dtype == 2 ? 6 : 5) : (fb == 2 ? (dtype == 2 ? 4 : 3) : (dtype == 2 ? 2 : 0))); }
 }  // namespace qdas

@@ -73,6 +73,8 @@ struct TileCfg {
     static constexpr int WPW = FB4 ? 1 : MB / WAVES; // windows staged per wave and window set
     static constexpr int SB = (int)sizeof(ST);       // bytes per complex sample
     static constexpr bool F32 = (SB == 8);
+    static constexpr bool F64 = (SB == 16);          // double data: geometry, delays, weights and sums in fp64 (tile_pairs.h pairs_f64)
+    using GT = std::conditional_t<F64, double, float>;   // type of the geometry tables (the reference casts them to the data precision, kern/das_spec.m:244)
     static constexpr int WB = W * SB;                // bytes per window
     static constexpr int PB = 1024;                  // bytes per full DMA piece (one wave-instruction x 16 B)
     static constexpr int PCS = (WB + PB - 1) / PB;   // pieces per window; the last one may use fewer lanes
@@ -82,6 +84,7 @@ struct TileCfg {
     static_assert(!BIG || (!SYM && !FBX), "the re-basing general kernel runs one frame per launch");
     static_assert(!LUT || (!SYM && !FBX && !BIG), "table-driven delays: general mode, one frame per launch");
     static_assert(!BF || (!SYM && !FBX && !BIG && !LUT && sizeof(ST_) == 8), "'BF': general mode, fp32 data, one frame per launch");
+    static_assert(!F64 || (!FMOD && !SYM && !FBX && !BIG && !LUT && !BF), "fp64 data: the plain 'DAS' sum (optionally with a weight table), one frame per launch");
     static_assert(FB4 ? (2 * MB == WAVES) : (MB % WAVES == 0 && MB % 2 == 0), "staging split");
     static_assert(WB % 16 == 0, "window must be a whole number of 16-byte lanes");
 };
@@ -99,7 +102,9 @@ template <class C> struct Tile {
     int T;
     uint64_t strN, strM;                             // trace strides in samples
     int kindB, kindS;
-    int *Abase; float *Aext, *Bext; float4 *nrec; float *PvL, *NvL; ST *win; float *part; uint32_t win_off;
+    using GT = typename C::GT;
+    struct rec64 { double x, y, z; int b, pad; };     // fp64 twin of the receiver record {window base B, position}
+    int *Abase; float *Aext, *Bext; float4 *nrec; rec64 *nrec64; GT *PvL, *NvL; ST *win; float *part; uint32_t win_off;
     uint32_t split, S, tile_id;
     double fs, symC; int symCi;
     bool tile_interior;
@@ -108,12 +113,14 @@ template <class C> struct Tile {
     uint32_t pofs;                                   // my pixel's offset in this plan's slab, or NOT_MINE (lane outside the image / the slab; slabs stay below 2^32 - 1 pixels)
     __device__ __forceinline__ bool in_shard() const { return pofs != NOT_MINE; }
     uint64_t ipx;                                    // (clamped) linear pixel index: row of per-pixel arrays / delay tables
-    float px, py, pz;
+    GT px, py, pz;
     double cf;                                       // samples per metre (scalar sound speed or this pixel's entry of the map)
     // ---- stage loop
     uint32_t n_lo, n_hi, nstage;
     v2f acc, acc1, acc2, acc3;                       // independent partial sums: no back-to-back dependent packed FMAs
     v2f ra[C::MB / 2];                               // block residuals a - A[m] - 1/2 of transmits (2p, 2p+1), packed
+    double rad[C::F64 ? C::MB : 1];                  // fp64 data: the same residuals, one double per transmit
+    double dacc[4];                                  // fp64 data: two independent complex partial sums {re, im, re, im}
     v2f tot[C::NFR];                                 // weighted totals per frame when a pixel x receiver weight is applied
     bool wpix, syn;
     // ---- LDS-DMA staging (tile_staging.h)
@@ -147,9 +154,14 @@ template <class C> struct Tile {
         const double r = __builtin_fma(-sd, sd, d2);
         return __builtin_fma(r, (double)(0.5f * __builtin_amdgcn_rcpf(fmaxf(s0, 1.0e-30f))), sd);
     }
-    __device__ __forceinline__ double a_of(uint32_t m, const float *gPv, const float *gNv) const;
-    __device__ __forceinline__ double b_at(float ex, float ey, float ez) const;
-    __device__ __forceinline__ double s_at(uint32_t n, float ex, float ey, float ez) const;
+    __device__ __forceinline__ double a_of(uint32_t m, const GT *gPv, const GT *gNv) const;
+    __device__ __forceinline__ double b_at(GT ex, GT ey, GT ez) const;
+    __device__ __forceinline__ double s_at(uint32_t n, GT ex, GT ey, GT ez) const;
+    // geometry tables in the plan's real type (TileParams carries them as float pointers)
+    __device__ __forceinline__ const GT *geo_Pi() const { return (const GT *)P.Pi; }
+    __device__ __forceinline__ const GT *geo_Pr() const { return (const GT *)P.Pr; }
+    __device__ __forceinline__ const GT *geo_Pv() const { return (const GT *)P.Pv; }
+    __device__ __forceinline__ const GT *geo_Nv() const { return (const GT *)P.Nv; }
     __device__ __forceinline__ v2f wload(uint32_t n) const;              // pixel x receiver weight of stage element n
 
     // staging (tile_staging.h)
@@ -161,6 +173,7 @@ template <class C> struct Tile {
     // pair loops (tile_pairs.h)
     template <bool CHECK, bool TAILV> __device__ __forceinline__ void pairs_plain(uint32_t n, uint32_t m0, int bn, float rb, uint32_t cbase, float phB);
     __device__ __forceinline__ void pairs_pipelined(float rb, uint32_t cbase);
+    template <bool CHECK, bool TAILV> __device__ __forceinline__ void pairs_f64(uint32_t n, uint32_t m0, int bn, double rb, uint32_t cbase);
     __device__ __forceinline__ void frame_sums(v2f (&Sf)[4]) const {
         if constexpr (C::FB4) { Sf[0] = acc; Sf[1] = acc1; Sf[2] = acc2; Sf[3] = acc3; }
         else if constexpr (C::FB2) { Sf[0] = acc + acc1; Sf[1] = acc2 + acc3; }
@@ -227,9 +240,11 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
     Aext  = (float *)(Abase + M);                     // [M]
     Bext  = Aext + M;                                 // [N]
     nrec = (float4 *)(smem + (((2 * M + N) * 4 + 15) & ~15u));   // [N] per receiver {window base B (int bits), x, y, z}: ONE broadcast read per stage
-    PvL   = (float *)(nrec + N);                      // [4M] (virtual) sources + t0
+    nrec64 = (rec64 *)nrec;                           // (fp64 data: 32-byte records)
+    constexpr uint32_t RECB = C::F64 ? 32u : 16u, GB = (uint32_t)sizeof(GT);
+    PvL   = (GT *)((unsigned char *)nrec + RECB * N);   // [4M] (virtual) sources + t0
     NvL   = PvL + 4 * M;                              // [3M] transmit normals
-    const uint32_t hdr = ((((2 * M + N) * 4 + 15) & ~15u) + 16 * N + 7 * M * 4 + 15) & ~15u;
+    const uint32_t hdr = ((((2 * M + N) * 4 + 15) & ~15u) + RECB * N + 7 * M * GB + 15) & ~15u;
     win = (ST *)(smem + hdr);                         // [NBUF][NW][W]
     part = (float *)(smem + hdr);                     // prologue scratch, aliases the windows
     win_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem) + hdr;
@@ -244,12 +259,12 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
         const uint64_t i_end = P.i_begin + P.i_count;
         ipx = ipx < i_end ? ipx : i_end - 1;
     } else {
-        px = P.Pi[3 * ipx]; py = P.Pi[3 * ipx + 1]; pz = P.Pi[3 * ipx + 2];
+        px = geo_Pi()[3 * ipx]; py = geo_Pi()[3 * ipx + 1]; pz = geo_Pi()[3 * ipx + 2];
         if (QSPEC(HAS_CINV_PIX, P.cinv_pix != nullptr)) cf = (double)P.cinv_pix[ipx] * fs;
     }
     // reciprocal mode: a(i,m) = b(i,m) + C with C = OFF - t0*fs, so A[m] := B[m] + floor(C)
     symC = 0.0; symCi = 0;
-    if constexpr (C::SYM) { symC = tapinfo<C::INTERP>::OFF - (double)P.Pv[3] * fs; symCi = (int)floor(symC); }
+    if constexpr (C::SYM) { symC = tapinfo<C::INTERP>::OFF - (double)geo_Pv()[3] * fs; symCi = (int)floor(symC); }
     xbytes = (uint64_t)N * M * (uint64_t)T * C::SB;
 }
 
@@ -258,7 +273,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
 // 0 = distance, 1 = signed distance (focused wave: copysign by the normal, src/bf.cu:106-108), 2 = plane wave (dot product).
 // 'DAS' / 'SYN': block = transmits (kind from VS / DV), stage = receivers (distance).  'MUL' (keep the transmit dimension) runs
 // the same kernel with the roles swapped by the host: block = receivers, stage = transmits -- tables, strides and kinds swap.
-template <class C> __device__ __forceinline__ double Tile<C>::a_of(uint32_t m, const float *gPv, const float *gNv) const {
+template <class C> __device__ __forceinline__ double Tile<C>::a_of(uint32_t m, const GT *gPv, const GT *gNv) const {
     // tau_tx*fs - t0*fs + OFF, reference src/bf.cu:104-108,114
     if constexpr (C::LUT) return (double)P.lut_tx[ipx + (P.i_begin + P.i_count) * m] + tapinfo<C::INTERP>::OFF;
     const double rx = (double)px - (double)gPv[4 * m], ry = (double)py - (double)gPv[4 * m + 1], rz = (double)pz - (double)gPv[4 * m + 2];
@@ -267,17 +282,17 @@ template <class C> __device__ __forceinline__ double Tile<C>::a_of(uint32_t m, c
     if (kindB != 2) { const double len = dsqrt(rx * rx + ry * ry + rz * rz); dv = kindB == 0 ? len : copysign(len, dot); }
     return dv * cf - (double)gPv[4 * m + 3] * fs + tapinfo<C::INTERP>::OFF;
 }
-template <class C> __device__ __forceinline__ double Tile<C>::b_at(float ex, float ey, float ez) const {      // tau_rx*fs, reference src/bf.cu:110
-    float qx = px, qy = py, qz = pz;
+template <class C> __device__ __forceinline__ double Tile<C>::b_at(GT ex, GT ey, GT ez) const {      // tau_rx*fs, reference src/bf.cu:110
+    GT qx = px, qy = py, qz = pz;
     asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));      // opaque: the fp64 images of the pixel are re-made per call (3 conversions) instead of living in 6 registers through the stage loop
     const double rx = (double)qx - (double)ex, ry = (double)qy - (double)ey, rz = (double)qz - (double)ez;
     return dsqrt(rx * rx + ry * ry + rz * rz) * cf;
 }
 // delay of STAGE element n at (ex,ey,ez): a receiver (kind 0), or -- roles swapped -- a transmit with {t0, normal} in P.St (scalar loads)
-template <class C> __device__ __forceinline__ double Tile<C>::s_at(uint32_t n, float ex, float ey, float ez) const {
+template <class C> __device__ __forceinline__ double Tile<C>::s_at(uint32_t n, GT ex, GT ey, GT ez) const {
     if constexpr (C::LUT) return (double)P.lut_rx[ipx + (P.i_begin + P.i_count) * n];
-    if (!QSPEC(HAS_ST, P.St != nullptr)) return b_at(ex, ey, ez);
-    float qx = px, qy = py, qz = pz;
+    if (C::F64 || !QSPEC(HAS_ST, P.St != nullptr)) return b_at(ex, ey, ez);
+    GT qx = px, qy = py, qz = pz;
     asm volatile("" : "+v"(qx), "+v"(qy), "+v"(qz));
     const double rx = (double)qx - (double)ex, ry = (double)qy - (double)ey, rz = (double)qz - (double)ez;
     const double dot = kindS ? rx * (double)P.St[4 * n + 1] + ry * (double)P.St[4 * n + 2] + rz * (double)P.St[4 * n + 3] : 0.0;
@@ -313,9 +328,10 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
     nstage = 0;
     for (uint32_t r = 0; blk(r) < M; ++r) nstage += nlim(blk(r)) - n_lo;
     acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
+    dacc[0] = dacc[1] = dacc[2] = dacc[3] = 0.0;
 #pragma unroll
     for (int f = 0; f < C::NFR; ++f) tot[f] = (v2f){0.f, 0.f};
-    wpix = !C::SYM && !C::BF && !(C::FB4 && C::F32) && (QSPEC(HAS_APIX, P.apix != nullptr) || QSPEC(GEN_KIND, P.gen_kind) != 0);   // weights from an I x N array, or generated from the geometry
+    wpix = !C::F64 && !C::SYM && !C::BF && !(C::FB4 && C::F32) && (QSPEC(HAS_APIX, P.apix != nullptr) || QSPEC(GEN_KIND, P.gen_kind) != 0);   // weights from an I x N array, or generated from the geometry
     syn = !C::SYM && !C::BF && C::F32 && QSPEC(SYN, P.syn);          // keep the stage dimension: one output plane per stage element
     fa = C::FB4 ? __builtin_amdgcn_readfirstlane(wave / C::MB) : 0;   // window sets this wave stages: (0, 1) in general; four frames: (0, 2) / (1, 3)
     fb = C::FB4 ? fa + 2 : 1;
@@ -336,11 +352,12 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
     dma_block(pm0);
     // B[n] of the stage at the DMA front travels in a VGPR, loaded one stage before it is needed: every LDS read of a stage
     // is issued BEFORE the stage's LDS-DMA in program order (the compiler orders a later LDS read behind the DMA's vmcnt).
-    float vbn = nrec[pn < N ? pn : N - 1].x;
+    auto rec_base = [&](uint32_t k) -> float { if constexpr (C::F64) return __int_as_float(nrec64[k].b); else return nrec[k].x; };
+    float vbn = rec_base(pn < N ? pn : N - 1);
     auto dma_next = [&](int buf) {
         const int bn = __builtin_amdgcn_readfirstlane(__float_as_int(vbn));
         const uint32_t qn = (pn + 1 == nlim(pm0)) ? n_lo : pn + 1;     // receiver of the stage after this one
-        vbn = nrec[qn < N ? qn : N - 1].x;
+        vbn = rec_base(qn < N ? qn : N - 1);
         stage_dma(bn, buf);
         if (++pn == nlim(pm0)) { pn = n_lo; pm0 = blk(++pr); dma_block(pm0); }
     };
@@ -359,7 +376,10 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         if (wpix && st + 1 < nstage) wnext = wload(n + 1 == nlim(m0) ? n_lo : n + 1);
         if constexpr (C::LUT) { if (st + 1 < nstage) tbn = P.lut_rx[ipx + Ilut * (n + 1 == nlim(m0) ? n_lo : n + 1)]; }
         const bool skip = wpix && (__ballot(wcur.x != 0.f || wcur.y != 0.f) == 0ull);   // whole wave weightless: no gathers
-        const float4 rec = nrec[n];                    // {B[n], receiver position}: one broadcast LDS read, issued ahead of the DMA
+        // {B[n], receiver position}: one broadcast LDS read (fp64 data: two), issued ahead of the DMA
+        int rec_b; GT rec_x, rec_y, rec_z;
+        if constexpr (C::F64) { const rec64 r = nrec64[n]; rec_b = r.b; rec_x = r.x; rec_y = r.y; rec_z = r.z; }
+        else { const float4 r = nrec[n]; rec_b = __float_as_int(r.x); rec_x = r.y; rec_y = r.z; rec_z = r.w; }
         float phB = 0.f;                               // remodulation: frac(B[n]*fmod/fs) (tile_prologue.h)
         if constexpr (C::FMOD) phB = Bext[n];
         // The next stage's staging is issued at the start of this stage by the younger half of the waves and AFTER the pair
@@ -368,7 +388,16 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         const bool dma_late = C::SYM && !hooks::no_late_dma && wave < C::WAVES / 2;
         if (!hooks::no_stage_dma && more && !dma_late) dma_next((buf + NBUF - 1) % NBUF);   // lands during the next NBUF-1 stages
         timer.mark(1);
-        if (n == n_lo) {                               // new transmit block: refresh the block residuals (cold: once per N stages)
+        if constexpr (C::F64) {
+            if (n == n_lo) {                           // new transmit block: refresh the block residuals (cold: once per N stages)
+#pragma unroll
+                for (int p = 0; p < C::MB; ++p) {
+                    const uint32_t ma = m0 + p < M ? m0 + p : M - 1;
+                    rad[p] = block_residual64(px, py, pz, cf, fs, kindB, (lds_cdouble *)PvL, (lds_cdouble *)NvL, ma, Abase[ma], tapinfo<C::INTERP>::OFF);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else if (n == n_lo) {                        // new transmit block: refresh the block residuals (cold: once per N stages)
 #pragma unroll
             for (int p = 0; p < C::MB / 2; ++p) {
                 const uint32_t ma = m0 + 2 * p < M ? m0 + 2 * p : M - 1, mb = m0 + 2 * p + 1 < M ? m0 + 2 * p + 1 : M - 1;
@@ -386,10 +415,16 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
             }
         }
         timer.mark(2);
-        if (!skip) {
-            const int bn = __float_as_int(rec.x);
+        if constexpr (C::F64) {                        // everything in fp64; the low word of (t + 1.5*2^52) IS rint(t)
+            const int bn = rec_b;
+            const double rbd = s_at(n, rec_x, rec_y, rec_z) - (double)bn;
+            const uint32_t cbase = win_off + (uint32_t)buf * (C::NW * C::WB);
+            if (m0 + C::MB <= M) pairs_f64<CHECK, false>(n, m0, bn, rbd, cbase);
+            else                 pairs_f64<CHECK, true>(n, m0, bn, rbd, cbase);
+        } else if (!skip) {
+            const int bn = rec_b;
             const float rb = C::LUT ? tbc - (float)bn : hooks::fake_rx_delay ? (float)(lane * 2 + 3) + 0.37f * (float)(n & 7)
-                                                                            : (float)(s_at(n, rec.y, rec.z, rec.w) - (double)bn);
+                                                                            : (float)(s_at(n, rec_x, rec_y, rec_z) - (double)bn);
             // LDS byte address of a tap = bits(t + MAGIC)*SB + cbase + (window, tap) immediate
             const uint32_t cbase = win_off + (uint32_t)buf * (C::NW * C::WB) - (MAGIC_BITS * (uint32_t)C::SB);
             // full block (reciprocal mode: block entirely above the diagonal): check-free; else the tail / diagonal variant
@@ -448,19 +483,29 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
 // ---- epilogue: y[i] = pix  (reference src/bf.cu:140); one image per frame of the launch
 template <class C> __device__ __forceinline__ void Tile<C>::epilogue() {
     if (syn || C::BF) return;                          // every stage already added its share to its plane / stored its pairs
-    v2f res[4];
-    frame_sums(res);
-    uint32_t po = pofs;
-    if constexpr (C::SYM) { uint32_t i1, col; po = locate(i1, col, false); }      // (nothing in the reciprocal stage loop needs it: not kept alive)
-    if (po != NOT_MINE) {
-        asm volatile("" : "+v"(po));
+    if constexpr (C::F64) {                            // (fp64 plans run one workgroup per tile: no partial images)
+        if (pofs != NOT_MINE) {
+            uint32_t po = pofs;
+            asm volatile("" : "+v"(po));
+            ST *base = (ST *)P.y;
+            asm volatile("" : "+s"(base));
+            st(base, (size_t)po, cplx<double>{dacc[0] + dacc[2], dacc[1] + dacc[3]});
+        }
+    } else {
+        v2f res[4];
+        frame_sums(res);
+        uint32_t po = pofs;
+        if constexpr (C::SYM) { uint32_t i1, col; po = locate(i1, col, false); }      // (nothing in the reciprocal stage loop needs it: not kept alive)
+        if (po != NOT_MINE) {
+            asm volatile("" : "+v"(po));
 #pragma unroll
-        for (int f = 0; f < C::NFR; ++f) {
-            const v2f r = wpix ? tot[f] : res[f];
-            // partial images of a split aperture are laid out [split][frame][pixel]
-            // (uniform bases made opaque: no 64-bit lane address is formed before the stage loop and carried through it)
-            if (S > 1) { float2 *base = P.part + ((size_t)split * C::NFR + f) * P.i_count; asm volatile("" : "+s"(base)); base[po] = make_float2(r.x, r.y); }
-            else { ST *base = (ST *)P.y + (size_t)f * P.y_fstride; asm volatile("" : "+s"(base)); st(base, (size_t)po, cplx<float>{r.x, r.y}); }
+            for (int f = 0; f < C::NFR; ++f) {
+                const v2f r = wpix ? tot[f] : res[f];
+                // partial images of a split aperture are laid out [split][frame][pixel]
+                // (uniform bases made opaque: no 64-bit lane address is formed before the stage loop and carried through it)
+                if (S > 1) { float2 *base = P.part + ((size_t)split * C::NFR + f) * P.i_count; asm volatile("" : "+s"(base)); base[po] = make_float2(r.x, r.y); }
+                else { ST *base = (ST *)P.y + (size_t)f * P.y_fstride; asm volatile("" : "+s"(base)); st(base, (size_t)po, cplx<float>{r.x, r.y}); }
+            }
         }
     }
 }
@@ -510,7 +555,10 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
         if constexpr (FB2 || FB4) return hipErrorInvalidValue;    // the window fit does not depend on the frame count: probes use one frame
         else { QDAS_LAUNCH_P(false, false, true); return hipGetLastError(); }
     }
-    if constexpr (SYM) {
+    if constexpr (sizeof(ST) == 16) {                  // fp64 data: no remodulation, no pixel x receiver weight (qdas_api.hip)
+        if (fm || P.apix || P.gen_kind || P.syn) return hipErrorInvalidValue;
+        if (wt) QDAS_LAUNCH(false, true); else QDAS_LAUNCH(false, false);
+    } else if constexpr (SYM) {
         if (wt) return hipErrorInvalidValue;
         if (fm) QDAS_LAUNCH(true, false); else QDAS_LAUNCH(false, false);
     } else if constexpr (FB4 && sizeof(ST) == 8) {

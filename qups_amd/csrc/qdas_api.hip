@@ -129,33 +129,37 @@ static int fetch_host(const void *src, size_t bytes, int mem, void *dst) {
 static int scan_pitch(const qdas_desc *desc, double *gz_out, double *gc_out) {
     const qdas_sizes &z = desc->sz;
     const uint64_t ncols = z.I2 * z.I3;
-    const float *Pi = (const float *)desc->Pi;
+    const size_t rs = z.dtype == QDAS_F64 ? 8 : 4, ps = 3 * rs;          // bytes per coordinate / per pixel position (real(prec))
+    const unsigned char *Pi = (const unsigned char *)desc->Pi;
     double gz = 0.0, gc = 0.0;
-    auto dist = [](const float *a, const float *b) {
-        const double dx = (double)a[0] - b[0], dy = (double)a[1] - b[1], dz = (double)a[2] - b[2];
-        return std::sqrt(dx * dx + dy * dy + dz * dz);
+    std::vector<unsigned char> buf;
+    auto dist = [&](uint64_t i, uint64_t j) {                             // distance between pixels i and j of buf
+        double d[3];
+        for (int k = 0; k < 3; ++k)
+            d[k] = rs == 8 ? ((const double *)buf.data())[3 * i + k] - ((const double *)buf.data())[3 * j + k]
+                           : (double)((const float *)buf.data())[3 * i + k] - (double)((const float *)buf.data())[3 * j + k];
+        return std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
     };
-    std::vector<float> buf;
     if (z.I1 > 1) {
-        buf.resize(3 * z.I1);
+        buf.resize(ps * z.I1);
         const uint64_t cs[3] = {0, ncols / 2, ncols - 1};
         for (int k = 0; k < 3; ++k) {
-            int rc = fetch_host(Pi + 3 * z.I1 * cs[k], 12 * z.I1, desc->mem, buf.data());
+            int rc = fetch_host(Pi + ps * z.I1 * cs[k], ps * z.I1, desc->mem, buf.data());
             if (rc) return rc;
-            for (uint64_t i = 0; i + 1 < z.I1; ++i) { const double d = dist(&buf[3 * i], &buf[3 * i + 3]); if (d > gz) gz = d; }
+            for (uint64_t i = 0; i + 1 < z.I1; ++i) { const double d = dist(i, i + 1); if (d > gz) gz = d; }
         }
     }
     if (z.I2 > 1) {
-        buf.resize(3 * ncols);
-        const uint64_t rs[3] = {0, z.I1 / 2, z.I1 - 1};
+        buf.resize(ps * ncols);
+        const uint64_t rws[3] = {0, z.I1 / 2, z.I1 - 1};
         for (int k = 0; k < 3; ++k) {
             if (desc->mem == QDAS_MEM_DEVICE)
-                HIPCHK(hipMemcpy2D(buf.data(), 12, Pi + 3 * rs[k], 12 * z.I1, 12, ncols, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy2D(buf.data(), ps, Pi + ps * rws[k], ps * z.I1, ps, ncols, hipMemcpyDeviceToHost));
             else
-                for (uint64_t c = 0; c < ncols; ++c) memcpy(&buf[3 * c], Pi + 3 * (rs[k] + z.I1 * c), 12);
+                for (uint64_t c = 0; c < ncols; ++c) memcpy(&buf[ps * c], Pi + ps * (rws[k] + z.I1 * c), ps);
             for (uint64_t c = 0; c + 1 < ncols; ++c) {
                 if ((c + 1) % z.I2 == 0) continue;         // slice boundary of a 3-D scan
-                const double d = dist(&buf[3 * c], &buf[3 * c + 3]);
+                const double d = dist(c, c + 1);
                 if (d > gc) gc = d;
             }
         }
@@ -329,8 +333,11 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     const bool syn = ((z.flag & QDAS_FLAG_KEEP_RX) && !(z.flag & QDAS_FLAG_KEEP_TX)) || mul;      // one output plane per STAGE element
     // 'BF' (both dimensions kept, fp32 data): the same stage loop, every pair's weighted sample stored to its own plane
     const bool bfm = (z.flag & QDAS_FLAG_KEEP_TX) && (z.flag & QDAS_FLAG_KEEP_RX);
-    bool eligible = (dt == QDAS_F32 || dt == QDAS_F16) && ((!syn && !bfm) || dt == QDAS_F32);
-    const char *why = "tiled kernel needs fp32/fp16 data and the 'DAS' mode (or fp32 data and 'SYN' / 'MUL' / 'BF')";
+    bool eligible = (!syn && !bfm) || dt == QDAS_F32;
+    const char *why = "tiled kernel needs the 'DAS' mode (or fp32 data and 'SYN' / 'MUL' / 'BF')";
+    // fp64 data (das_tile_impl.h "F64"): the plain sum with pixel-independent weights, scalar sound speed, no remodulation
+    if (eligible && dt == QDAS_F64 && desc->fmod != 0.0) { eligible = false; why = "tiled kernel, fp64 data: remodulation needs the generic kernel"; }
+    if (eligible && dt == QDAS_F64 && desc->rx_apod_kind) { eligible = false; why = "tiled kernel, fp64 data: a generated receive apodization needs the generic kernel"; }
     // stage / block element counts of the kernel (das_tile_impl.h): receivers / transmits, swapped for 'MUL'
     const uint64_t kN = mul ? z.M : z.N, kM = mul ? z.N : z.M;
     // sound speed: a scalar, or a full per-pixel map (contiguous I1 x I2 x I3, no aperture dependence): the delay stays separable
@@ -338,6 +345,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     if (eligible && (g.cst[0] || g.cst[1] || g.cst[2] || g.cst[3] || g.cst[4])) {
         cmap = !g.cst[3] && !g.cst[4] && (g.cst[0] == 1 || z.I1 == 1) && (g.cst[1] == z.I1 || z.I2 == 1) && (g.cst[2] == z.I1 * z.I2 || z.I3 == 1);
         if (!cmap) { eligible = false; why = "tiled kernel needs a scalar sound speed or a full per-pixel map without aperture dependence"; }
+        else if (dt == QDAS_F64) { eligible = false; why = "tiled kernel, fp64 data: a sound-speed map needs the generic kernel"; }
     }
     // apodization arrays: pixel-independent ones fold into an N x M table; ONE array may be a full I1 x I2 x I3 x [N] array
     // (contiguous pixel strides, no transmit dependence) -- it is applied per (pixel, receiver) by the tiled kernel
@@ -350,6 +358,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
                           && (a[3] == I || a[3] == 0) && a[4] == 0 && (a[3] == I || z.N == 1 || a[3] == 0);
         if (a[3] == 0 && z.N > 1) { eligible = false; why = "tiled kernel: a pixel-only apodization array needs the generic kernel"; }
         else if (!full || pix_arr >= 0) { eligible = false; why = "tiled kernel: at most one apodization array may depend on the pixel (I x [N], no transmit dependence)"; }
+        else if (dt == QDAS_F64) { eligible = false; why = "tiled kernel, fp64 data: a pixel-dependent apodization array needs the generic kernel"; }
         else pix_arr = (int)s;
     }
     if (eligible && g.gen_kind && pix_arr >= 0) {
@@ -431,10 +440,11 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             std::swap(t.strN, t.strM);
             t.kindB = 0; t.kindS = txkind;
         }
-        float cinv0;
-        if ((rc = fetch_host(desc->cinv, sizeof(float), desc->mem, &cinv0))) return bail(rc);
+        double cinv0;
+        if (dt == QDAS_F64) { if ((rc = fetch_host(desc->cinv, sizeof(double), desc->mem, &cinv0))) return bail(rc); }
+        else { float c32; if ((rc = fetch_host(desc->cinv, sizeof(float), desc->mem, &c32))) return bail(rc); cinv0 = (double)c32; }
         t.fs = g.fs; t.fmod = g.fmod;
-        t.cinv_fs = (double)cinv0 * g.fs;
+        t.cinv_fs = cinv0 * g.fs;
         t.cinv_pix = cmap ? (const float *)g.cinv + g.cst[5] : nullptr;
         t.flag = z.flag; t.VS = z.VS; t.DV = z.DV; t.sym = sym; t.big = big;
         // tile grid: (1 << tz_log2) pixels of I1 x tile_cols columns (columns = I2*I3 flattened); the footprint is chosen below
@@ -468,7 +478,29 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             }
             t.apix = (const unsigned char *)g.apod + a[5] * ael;
         }
-        if (z.S > (pix_arr >= 0 ? 1u : 0u)) {
+        if (z.S > 0 && dt == QDAS_F64) {                // fp64 data: the same table in double (complex128 entries)
+            std::vector<double> tab(2 * z.N * z.M);
+            for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.0; tab[2 * k + 1] = 0.0; }
+            for (uint64_t s = 0; s < z.S; ++s) {
+                const uint64_t *st = &g.ast[6 * s];
+                const uint64_t nel = bcast_numel(st, z);
+                std::vector<double> raw(nel * (desc->apod_real ? 1 : 2));
+                if ((rc = fetch_host((const unsigned char *)desc->apod + st[5] * ael, nel * ael, desc->mem, raw.data()))) return bail(rc);
+                for (uint64_t m = 0; m < z.M; ++m)
+                    for (uint64_t n = 0; n < z.N; ++n) {
+                        const uint64_t k = n * st[3] + m * st[4];
+                        const double ar = desc->apod_real ? raw[k] : raw[2 * k], ai = desc->apod_real ? 0.0 : raw[2 * k + 1];
+                        double &tr = tab[2 * (n + z.N * m)], &ti = tab[2 * (n + z.N * m) + 1];
+                        const double nr = tr * ar - ti * ai, ni = tr * ai + ti * ar;
+                        tr = nr; ti = ni;
+                    }
+            }
+            void *dtab;
+            if ((rc = dev_alloc(pl, &dtab, tab.size() * sizeof(double)))) return bail(rc);
+            hipError_t e = hipMemcpy(dtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+            if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e)));
+            t.wtab = dtab;
+        } else if (z.S > (pix_arr >= 0 ? 1u : 0u)) {
             std::vector<float> tab(2 * z.N * z.M);
             for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.f; tab[2 * k + 1] = 0.f; }
             for (uint64_t s = 0; s < z.S; ++s) {
@@ -517,6 +549,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             unsigned ks = 1;
             while (ks * 2 <= cap && (uint64_t)pl->ntiles * ks < (uint64_t)cus) ks *= 2;   // (a split costs one more prologue per tile)
             if (const char *e = getenv("QDAS_KSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8 && (unsigned)v <= cap) ks = (unsigned)v; }
+            if (dt == QDAS_F64) ks = 1;                 // (the partial images of a split aperture are fp32)
             t.ksplit = ks;
             if (ks > 1 && !bfm) {
                 void *pb;
@@ -529,7 +562,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // ---- QDAS_PLAN_JIT: the tiled kernel compiled for this plan's sizes (jit.hip).  A failure is not an error: the plan keeps its
     //      prebuilt kernel and qdas_last_error() says why.
     g_err.clear();
-    if ((desc->plan_flags & QDAS_PLAN_JIT) && pl->kernel == QDAS_KERNEL_TILED && !pl->tp.bf && !getenv("QDAS_NO_JIT")) {
+    if ((desc->plan_flags & QDAS_PLAN_JIT) && pl->kernel == QDAS_KERNEL_TILED && !pl->tp.bf && dt != QDAS_F64 && !getenv("QDAS_NO_JIT")) {
         const TileParams &t = pl->tp;
         JitSpec k{};
         k.interp = (z.flag & 7) == 4 ? 1 : (z.flag & 7); k.dtype = dt; k.fmod = t.fmod != 0.0; k.wtab = t.wtab != nullptr; k.sym = t.sym; k.big = t.big;
@@ -565,7 +598,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; }
         else { pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel"; }
     }
-    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && !pl->jit_fn && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
+    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->jit_fn && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
     // four frames per launch: not for fp32 plans with remodulation, a weight table or a pixel x receiver weight (das_tile_impl.h launch_tile_i)
     pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr
                   || (dt == QDAS_F32 && pl->kernel == QDAS_KERNEL_TILED && (pl->tp.fmod != 0.0 || pl->tp.wtab || pl->tp.apix || pl->tp.gen_kind));

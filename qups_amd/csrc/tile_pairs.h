@@ -189,6 +189,55 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
     });
 }
 
+// fp64 data: one transmit at a time, everything in double -- the reference's double kernel computes delays, weights and sums in
+// fp64 (src/bf.cu:144-151) and the parity bar of this precision is 1e-10 of the image maximum.  Same scheme as above: t = ra + rb,
+// k = rint(t) read off the low word of (t + 1.5*2^52), s = t - k, K x ds_read_b128, weights between issue and wait, 2K v_fma_f64.
+template <class C> template <bool CHECK, bool TAILV>
+__device__ __forceinline__ void Tile<C>::pairs_f64(uint32_t n, uint32_t m0, int bn, double rb, uint32_t cbase) {
+    constexpr int K = C::K, MB = C::MB, WB = C::WB, INTERP = C::INTERP;
+    unroll<MB>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (!hooks::no_fair_prio && (p * 4) % MB == 0) __builtin_amdgcn_s_setprio(3 - (p * 4) / MB);     // fair progress, see pairs_plain
+        const uint32_t m = m0 + p;
+        if constexpr (TAILV) { if (m >= M) return; }
+        double wr = 1.0, wi = 0.0;
+        if constexpr (C::WTAB) {
+            const double2 wv = ((const double2 *)P.wtab)[n + (size_t)N * m];
+            wr = wv.x; wi = wv.y;
+            if (wr == 0.0 && wi == 0.0) return;          // zero weight: skip (src/bf.cu:122,126)
+        }
+        const double t = rad[p] + rb;
+        const double tm = t + MAGIC64;
+        const double s = t - (tm - MAGIC64);
+        const uint32_t ad = (uint32_t)__double2loint(tm) * 16u + cbase;
+        taps_f64 g;
+        lds_issue<K, p * WB>(g, ad);
+        double w[4] = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (K > 1) weights1<INTERP>(s, w);  // overlaps the LDS latency
+        lds_fence<K>(g, w);
+        double &ar = dacc[2 * (p & 1)], &ai = dacc[2 * (p & 1) + 1];
+        if constexpr (K > 1 && !CHECK && !C::WTAB) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) { ar = __builtin_fma(w[k], g.s[k].x, ar); ai = __builtin_fma(w[k], g.s[k].y, ai); }
+        } else {
+            double vr = g.s[0].x, vi = g.s[0].y;
+            if constexpr (K > 1) {
+                vr *= w[0]; vi *= w[0];
+#pragma unroll
+                for (int k = 1; k < K; ++k) { vr = __builtin_fma(w[k], g.s[k].x, vr); vi = __builtin_fma(w[k], g.s[k].y, vi); }
+            }
+            if constexpr (CHECK) {                    // edge rule: all taps in [0,T) and tau >= 0
+                const int ws = Abase[m] + bn;
+                const double lo = (double)tapinfo<INTERP>::LO - 0.5 - (double)ws, hi = (double)(T - K + 1 - ws) - 0.5;
+                const bool keep = (t >= lo) && (t < hi);
+                vr = keep ? vr : 0.0; vi = keep ? vi : 0.0;
+            }
+            if constexpr (C::WTAB) { ar += wr * vr - wi * vi; ai += wr * vi + wi * vr; }
+            else { ar += vr; ai += vi; }
+        }
+    });
+}
+
 // Software-pipelined loop (two window sets, 4 taps, full interior block, no per-sample post-processing): the first-set taps of
 // iteration p+1 are requested before the MACs of iteration p, so the LDS pipe always has work queued and the counted wait (newest
 // 8 reads stay in flight) rarely stalls.  A unit = (transmit pair p, frame pair hp); hp only with four frames per launch.

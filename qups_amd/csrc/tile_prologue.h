@@ -11,7 +11,8 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
     constexpr bool SYM = C::SYM, LUT = C::LUT;
     // the geometry tables are read from global memory here and from their LDS copies in the main loop: a vector-memory load there
     // would sit behind the stage's LDS-DMA in the in-order vmcnt queue and expose the DMA latency every stage (measured: 15 of 64 ms)
-    const float *gPv = P.Pv, *gNv = P.Nv;
+    using GT = typename C::GT;
+    const GT *gPv = geo_Pv(), *gNv = geo_Nv(), *gPr = geo_Pr();
     const uint32_t MX = M > N ? M : N;
     const uint64_t Ilut = P.i_begin + P.i_count;
     const bool has_st = QSPEC(HAS_ST, P.St != nullptr);
@@ -23,14 +24,14 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
     const float cf32 = (float)cf, fs32 = (float)fs;
     auto a_est = [&](uint32_t m) -> float {
         if (!pro32) return (float)a_of(m, gPv, gNv);
-        const float rx = px - gPv[4 * m], ry = py - gPv[4 * m + 1], rz = pz - gPv[4 * m + 2];
-        const float d = kindB != 2 ? __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz) : rx * gNv[3 * m] + ry * gNv[3 * m + 1] + rz * gNv[3 * m + 2];
-        return d * cf32 - gPv[4 * m + 3] * fs32 + (float)tapinfo<INTERP>::OFF;
+        const float rx = (float)(px - gPv[4 * m]), ry = (float)(py - gPv[4 * m + 1]), rz = (float)(pz - gPv[4 * m + 2]);
+        const float d = kindB != 2 ? __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz) : rx * (float)gNv[3 * m] + ry * (float)gNv[3 * m + 1] + rz * (float)gNv[3 * m + 2];
+        return d * cf32 - (float)gPv[4 * m + 3] * fs32 + (float)tapinfo<INTERP>::OFF;
     };
     auto b_est = [&](uint32_t n) -> float {
         if constexpr (LUT) return P.lut_rx[ipx + Ilut * n];
-        if (kindS == 1) return (float)s_at(n, P.Pr[3 * n], P.Pr[3 * n + 1], P.Pr[3 * n + 2]);
-        const float rx = px - P.Pr[3 * n], ry = py - P.Pr[3 * n + 1], rz = pz - P.Pr[3 * n + 2];
+        if (kindS == 1) return (float)s_at(n, gPr[3 * n], gPr[3 * n + 1], gPr[3 * n + 2]);
+        const float rx = (float)(px - gPr[3 * n]), ry = (float)(py - gPr[3 * n + 1]), rz = (float)(pz - gPr[3 * n + 2]);
         if (!has_st) return __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz) * cf32;
         if (kindS == 0) return __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz) * cf32 - P.St[4 * n] * fs32;
         return (rx * P.St[4 * n + 1] + ry * P.St[4 * n + 2] + rz * P.St[4 * n + 3]) * cf32 - P.St[4 * n] * fs32;
@@ -61,7 +62,7 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
             float mn = part[m], mx = part[WAVES * MX + m];
 #pragma unroll
             for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + m]); mx = fmaxf(mx, part[(WAVES + w) * MX + m]); }
-            const float dlt = margin(mn, mx, LUT ? 0.f : P.Pv[4 * m + 3] * fs32);
+            const float dlt = margin(mn, mx, LUT ? 0.f : (float)gPv[4 * m + 3] * fs32);
             const float fl = floorf(mn - dlt) - 1.0f;        // margin: the estimate may lie above the true minimum
             const bool fin = fabsf(fl) < 1.0e9f;
             const float e = fin ? ((mx + dlt) - fl) + 0.01f : INFINITY;
@@ -84,14 +85,15 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + n]); mx = fmaxf(mx, part[(WAVES + w) * MX + n]); }
         float t0fs = 0.f;
-        if constexpr (SYM) t0fs = P.Pv[3] * fs32;
+        if constexpr (SYM) t0fs = (float)gPv[3] * fs32;
         else if constexpr (!LUT) t0fs = has_st ? P.St[4 * n] * fs32 : 0.f;
         const float dlt = margin(mn, mx, t0fs);
         const float fl = floorf(mn - dlt) - 1.0f;
         const bool fin = fabsf(fl) < 1.0e9f;
         const float e = fin ? ((mx + dlt) - fl) + 0.01f : INFINITY;
         if constexpr (LUT) nrec[n] = make_float4(__int_as_float(fin ? (int)fl : 0), 0.f, 0.f, 0.f);
-        else nrec[n] = make_float4(__int_as_float(fin ? (int)fl : 0), P.Pr[3 * n], P.Pr[3 * n + 1], P.Pr[3 * n + 2]);
+        else if constexpr (C::F64) nrec64[n] = rec64{gPr[3 * n], gPr[3 * n + 1], gPr[3 * n + 2], fin ? (int)fl : 0, 0};
+        else nrec[n] = make_float4(__int_as_float(fin ? (int)fl : 0), gPr[3 * n], gPr[3 * n + 1], gPr[3 * n + 2]);
         Bext[n] = e;
         b_lo = fminf(b_lo, fl); b_hi = fmaxf(b_hi, fl + e); b_ext = fmaxf(b_ext, e);
         if constexpr (SYM) {                             // a - A = (b - B) + frac(C) in [1, Bext + 1)
@@ -128,8 +130,8 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
         for (uint32_t n = tid; n < N; n += THREADS) { const double c = (double)__float_as_int(nrec[n].x) * f; Bext[n] = (float)(c - floor(c)); }
     }
     if constexpr (!LUT) {
-        for (uint32_t k = tid; k < 4 * M; k += THREADS) PvL[k] = P.Pv[k];
-        for (uint32_t k = tid; k < 3 * M; k += THREADS) NvL[k] = P.Nv[k];
+        for (uint32_t k = tid; k < 4 * M; k += THREADS) PvL[k] = gPv[k];
+        for (uint32_t k = tid; k < 3 * M; k += THREADS) NvL[k] = gNv[k];
     }
     __syncthreads();
     return true;

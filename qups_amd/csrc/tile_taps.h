@@ -94,6 +94,26 @@ template <int KEEP> __device__ __forceinline__ void lds_fence2_keep(taps_f16 &a,
                    "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])
                  : "n"(KEEP));
 }
+// fp64 data: 16-byte samples {re, im}: K x ds_read_b128 (windows are 16-byte aligned), one sample at a time
+typedef double v2d __attribute__((ext_vector_type(2)));
+struct taps_f64 { v2d s[4]; };
+template <int K, int OFF> __device__ __forceinline__ void lds_issue(taps_f64 &t, uint32_t addr) {
+    if constexpr (K == 4)
+        asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                     : "=&v"(t.s[0]), "=&v"(t.s[1]), "=&v"(t.s[2]), "=&v"(t.s[3]) : "v"(addr), "n"(OFF), "n"(OFF + 16), "n"(OFF + 32), "n"(OFF + 48));
+    else if constexpr (K == 2)
+        asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(t.s[0]), "=&v"(t.s[1]) : "v"(addr), "n"(OFF), "n"(OFF + 16));
+    else
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(t.s[0]) : "v"(addr), "n"(OFF));
+}
+template <int K> __device__ __forceinline__ void lds_fence(taps_f64 &a, double (&w)[4]) {
+    if constexpr (K == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.s[0]), "+v"(a.s[1]), "+v"(a.s[2]), "+v"(a.s[3]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+    else if constexpr (K == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.s[0]), "+v"(a.s[1]), "+v"(w[0]), "+v"(w[1]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.s[0]));
+}
 __device__ __forceinline__ void mix_mac(v2f &acc, uint32_t tap, float w) {       // acc += w * (float2)tap
     float ar = acc.x, ai = acc.y;
     asm("v_fma_mix_f32 %0, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %1, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]"

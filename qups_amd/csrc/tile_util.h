@@ -3,6 +3,7 @@
 #pragma once
 #include "qdas_device.h"
 #include "lanczos_poly.h"
+#include "lanczos_poly64.h"
 #include <type_traits>
 #include <utility>
 
@@ -12,6 +13,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr float MAGIC = 12582912.0f;          // 1.5 * 2^23: (t + MAGIC) has rint(t) in its low mantissa bits
 constexpr uint32_t MAGIC_BITS = 0x4B400000u;
+constexpr double MAGIC64 = 6755399441055744.0;   // 1.5 * 2^52: the LOW WORD of (t + MAGIC64) is rint(t) as a two's-complement int32
 
 template <int INTERP> struct tapinfo {
     static constexpr int K = interp_taps(INTERP);
@@ -50,6 +52,45 @@ template <int INTERP> __device__ __forceinline__ void weights2(v2f s, v2f w[4]) 
         w[1] = 0.5f * (2.0f + u * (u * (-5.0f * u + 3.0f)));
         w[2] = 0.5f * (u * (1.0f + u * (4.0f * u - 3.0f)));
         w[3] = 0.5f * (u * (u * (1.0f - u)));
+    }
+}
+
+// fp64 data: the same weights for ONE sample, in double (cubic exact; Lanczos: degree-9 polynomials in q, lanczos_poly64.h)
+// Four polynomials of the same degree in lock-step: four independent FMA chains (a dependent v_fma_f64 cannot issue back to back).
+// Every coefficient passes through an opaque scalar register right where it is used: left alone, the compiler keeps all 32 double
+// constants live across the 16 unrolled samples of a stage -- 64 SGPRs, which spill into VGPR lanes and from there into scratch;
+// one s_mov_b64 per use rides on the scalar unit, beside the other waves' vector work.
+template <int D> __device__ __forceinline__ void horner4(const double (&a)[D + 1], const double (&b)[D + 1], const double (&c)[D + 1], const double (&d)[D + 1],
+                                                         double q, double &ra, double &rb, double &rc, double &rd) {
+    auto k_ = [](double v) { asm volatile("" : "+s"(v)); return v; };
+    ra = k_(a[D]); rb = k_(b[D]); rc = k_(c[D]); rd = k_(d[D]);
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        ra = __builtin_fma(ra, q, k_(a[k])); rb = __builtin_fma(rb, q, k_(b[k]));
+        rc = __builtin_fma(rc, q, k_(c[k])); rd = __builtin_fma(rd, q, k_(d[k]));
+    }
+}
+template <int INTERP> __device__ __forceinline__ void weights1(double s, double (&w)[4]) {
+    if constexpr (INTERP == 1 || INTERP == 4) {
+        w[0] = 0.5 - s; w[1] = 0.5 + s;
+    } else if constexpr (INTERP == 2) {
+        const double q = s * s;
+        const double ei = 0.5625 - 0.25 * q, oi = -1.375 + 1.5 * q;
+        const double eo = -0.0625 + 0.25 * q, oo = 0.125 - 0.5 * q;
+        w[1] = ei + s * oi; w[2] = ei - s * oi; w[0] = eo + s * oo; w[3] = eo - s * oo;
+    } else if constexpr (INTERP == 3) {
+        constexpr double EI[] = QDAS_LANCZOS64_EI, OI[] = QDAS_LANCZOS64_OI, EO[] = QDAS_LANCZOS64_EO, OO[] = QDAS_LANCZOS64_OO;
+        const double q = s * s;
+        static_assert(sizeof(EI) == sizeof(OI) && sizeof(EI) == sizeof(EO) && sizeof(EI) == sizeof(OO), "one degree");
+        double ei, oi, eo, oo;
+        horner4<sizeof(EI) / 8 - 1>(EI, OI, EO, OO, q, ei, oi, eo, oo);
+        w[1] = ei + s * oi; w[2] = ei - s * oi; w[0] = eo + s * oo; w[3] = eo - s * oo;
+    } else if constexpr (INTERP == 5) {
+        const double u = s + 0.5;
+        w[0] = 0.5 * (u * (-1.0 + u * (2.0 * u - 1.0)));
+        w[1] = 0.5 * (2.0 + u * (u * (-5.0 * u + 3.0)));
+        w[2] = 0.5 * (u * (1.0 + u * (4.0 * u - 3.0)));
+        w[3] = 0.5 * (u * (u * (1.0 - u)));
     }
 }
 
@@ -113,6 +154,16 @@ static __device__ __noinline__ float block_residual(float px, float py, float pz
         dv = kindB == 0 ? len : copysign(len, dot);
     }
     return (float)((dv * cf - (double)Pv[4 * m + 3] * fs + off) - ((double)Abase_m + 0.5));
+}
+// fp64 data: the same from fp64 geometry tables, returned in double (IEEE sqrt: the residual is the whole delay precision here)
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+static __device__ __noinline__ double block_residual64(double px, double py, double pz, double cf, double fs, int kindB, lds_cdouble *Pv, lds_cdouble *Nv,
+                                                       uint32_t m, int Abase_m, double off) {
+    const double rx = px - Pv[4 * m], ry = py - Pv[4 * m + 1], rz = pz - Pv[4 * m + 2];
+    const double dot = kindB ? rx * Nv[3 * m] + ry * Nv[3 * m + 1] + rz * Nv[3 * m + 2] : 0.0;
+    double dv = dot;
+    if (kindB != 2) { const double len = sqrt(rx * rx + ry * ry + rz * rz); dv = kindB == 0 ? len : copysign(len, dot); }
+    return (dv * cf - Pv[4 * m + 3] * fs + off) - ((double)Abase_m + 0.5);
 }
 // generated pixel x receiver weight (qdas.h QDAS_RXAPOD_*): element position from the LDS record, normal by scalar loads
 static __device__ __noinline__ float rx_apod_generated(int kind, double p0, double p1, float px, float py, float pz, float ex, float ey, float ez,

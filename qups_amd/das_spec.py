@@ -478,6 +478,8 @@ class DasPlan:
         per = p.T * p.N * p.M
         if xc.numel() != F * per or not xc.is_contiguous():
             raise DasError("channel data size does not match the plan")
+        if xc.dtype != _data_dtype(p.prec) or xc.device != y.device:       # the library reads raw bytes: a wrong element size would run off the buffer
+            raise DasError(f"channel data must be {_data_dtype(p.prec)} on {y.device} for a '{p.prec}' plan, got {xc.dtype} on {xc.device}")
         with torch.cuda.device(self.device):
             _lib.check(self.lib.qdas_plan_execute_frames(self._h, C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()),
                                                          F, per, oM * oN * self.i_count, self._stream()))
@@ -561,8 +563,8 @@ class MultiDevicePlan:
         torch = _torch()
         p = self.prob
         oN, oM = p.osize
-        if xc.numel() != p.T * p.N * p.M or not xc.is_contiguous() or xc.device != self.device:
-            raise DasError("channel data size / device does not match the plan")
+        if xc.numel() != p.T * p.N * p.M or not xc.is_contiguous() or xc.device != self.device or xc.dtype != _data_dtype(p.prec):
+            raise DasError("channel data size / device / element type does not match the plan")
         y = torch.empty((oM, oN, p.I), dtype=_data_dtype(p.prec), device=self.device)
         with torch.cuda.device(self.device):
             stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -226,6 +226,76 @@ def test_double_precision():
     assert rel_err(out, ref) <= 1e-10
 
 
+def _oracle64(case, apod=(), x=None, t0=None):
+    from oracle import das_oracle as O
+    return O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"] if x is None else x, case["t0"] if t0 is None else t0,
+                      case["fs"], case["c"], VS=case["VS"], DV=case["DV"], interp=case["interp"], apod=apod)
+
+
+@pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3", "cubic_dev"])
+@pytest.mark.parametrize("seq", ["FSA", "PW", "FC", "DV"])
+def test_double_precision_in_the_tiled_kernel(seq, interp):
+    """fp64 data on the fused kernel (launch configuration 13): geometry, delays, weights and sums in double -- the bar of this
+    precision is 1e-10 of the image maximum, as for the generic kernel (reference twin: `DAS`, src/bf.cu:144-151)"""
+    case = make_case(seq=seq, interp=interp, seed=3, I1=150, I2=19)          # ragged tile edges in both axes
+    ref = _oracle64(case)
+    out, plan = run_das(case, kernel=2, prec="double")
+    assert plan.kernel == "tiled" and ",f64" in plan.kernel_name(), plan.kernel_name()
+    if seq != "FC":
+        assert plan.fallback_tiles() == 0
+    assert rel_err(out, ref) <= 1e-10
+    gen, _ = run_das(case, kernel=1, prec="double")
+    assert rel_err(out, gen) <= 1e-10
+
+
+def test_double_precision_tiled_variants():
+    """weights (pixel-independent: folded into one N x M complex128 table), transposed data with per-transmit t0, a pixel shard,
+    several frames, a record shorter than the path (checked loop: exact zeros) and an odd transmit count (tail block)"""
+    torch = _torch()
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd.das_spec import _cast_data, _colmajor
+    rng = np.random.default_rng(5)
+    case = make_case(seq="PW", interp="lanczos3", seed=21, I1=90, I2=23, N=24, M=19)
+    N, M = case["N"], case["M"]
+    wn = rng.uniform(0.2, 1, (1, 1, 1, N, 1))
+    wm = rng.uniform(0, 1, (1, 1, 1, 1, M)) * (1 + 0.5j)
+    wm[..., 3] = 0.0
+    ref = _oracle64(case, apod=(wn, wm))
+    out, plan = run_das(case, kernel=2, prec="double", apod=(wn, wm))
+    assert plan.kernel == "tiled" and ",wtab" in plan.kernel_name()
+    assert rel_err(out, ref) <= 1e-10
+    # transposed data + per-transmit t0
+    t0 = (case["t0"] + (1.0 / case["fs"]) * rng.integers(-3, 4, (1, 1, M))).astype(np.float64)
+    ref = _oracle64(case, t0=t0)
+    out, plan = run_das(case, kernel=2, prec="double", tpose=True, t0=t0)
+    assert plan.kernel == "tiled"
+    assert rel_err(out, ref) <= 1e-10
+    # a pixel shard and three frames through one plan
+    xs = [case["x"]] + [(rng.standard_normal(case["x"].shape) + 1j * rng.standard_normal(case["x"].shape)) for _ in range(2)]
+    xt = torch.from_numpy(np.stack(xs, axis=3))
+    po = parse_options(xt, list(case["opt"]) + ["interp", "lanczos3", "input-precision", "double"])
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], po)
+    I = 90 * 23
+    sh = DasPlan(prob, kernel=2, i_begin=I // 3, i_count=I // 2)
+    y = sh.execute_colmajor(_colmajor(_cast_data(xt, "double", sh.device)), 3).cpu().numpy()     # (F, 1, 1, count)
+    for f in range(3):
+        r = _oracle64(case, x=xs[f]).reshape(-1, order="F")[I // 3: I // 3 + I // 2]
+        assert np.abs(y[f].reshape(-1) - r).max() / np.abs(r).max() <= 1e-10, f
+    # record shorter than the path: zeros stay exact zeros
+    for interp in ("nearest", "linear", "cubic", "lanczos3"):
+        case = make_case(seq="FSA", interp=interp, seed=14, T=300, data="noise", zlim=(1e-3, 30e-3), I1=128, I2=8)
+        ref = _oracle64(case)
+        out, plan = run_das(case, kernel=2, prec="double")
+        dead = np.abs(ref) == 0
+        assert dead.any() and np.all(out[dead] == 0), interp
+        assert rel_err(out, ref) <= 1e-10, interp
+    # delay spread beyond the LDS window: those tiles are redone by the generic fp64 kernel
+    case = make_case(seq="FSA", interp="linear", seed=15, I1=64, I2=4, zlim=(2e-3, 60e-3), data="noise", N=8)
+    out, plan = run_das(case, kernel=0, prec="double")
+    assert plan.kernel == "tiled" and plan.fallback_tiles() > 0
+    assert rel_err(out, _oracle64(case)) <= 1e-10
+
+
 @pytest.mark.parametrize("kernel", [1, 2])
 def test_half_precision(kernel):
     case = make_case(seq="FSA", interp="cubic", seed=13, I1=96, I2=8)

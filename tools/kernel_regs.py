@@ -77,7 +77,7 @@ def short(dn: str) -> str:
     m = re.match(r"void qdas::das_tile_kernel<(.*)>\(qdas::TileParams\)", dn)
     if not m:
         return re.sub(r"^void ", "", dn)[:110]
-    a = [x.strip() for x in re.sub(r"HIP_vector_type<float, 2u>", "f32", m.group(1)).replace("unsigned int", "f16").split(",")]
+    a = [x.strip() for x in re.sub(r"HIP_vector_type<double, 2u>", "f64", re.sub(r"HIP_vector_type<float, 2u>", "f32", m.group(1))).replace("unsigned int", "f16").split(",")]
     keys = ["interp", "data", "fmod", "wtab", "sym", "fb2", "fb4", "waves", "mb", "W", "nbuf", "psz", "bpc", "probe", "big", "lut"]
     d = dict(zip(keys, a))
     flags = [k for k in ("fmod", "wtab", "sym", "fb2", "fb4", "probe", "big", "lut") if d.get(k) == "true"]
