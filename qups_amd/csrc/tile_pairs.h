@@ -195,6 +195,8 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
 template <class C> template <bool CHECK, bool TAILV>
 __device__ __forceinline__ void Tile<C>::pairs_f64(uint32_t n, uint32_t m0, int bn, double rb, uint32_t cbase) {
     constexpr int K = C::K, MB = C::MB, WB = C::WB, INTERP = C::INTERP;
+    double lead[4];
+    weights1_lead<INTERP>(lead);
     unroll<MB>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
         if constexpr (!hooks::no_fair_prio && (p * 4) % MB == 0) __builtin_amdgcn_s_setprio(3 - (p * 4) / MB);     // fair progress, see pairs_plain
@@ -213,7 +215,7 @@ __device__ __forceinline__ void Tile<C>::pairs_f64(uint32_t n, uint32_t m0, int 
         taps_f64 g;
         lds_issue<K, p * WB>(g, ad);
         double w[4] = {0.0, 0.0, 0.0, 0.0};
-        if constexpr (K > 1) weights1<INTERP>(s, w);  // overlaps the LDS latency
+        if constexpr (K > 1) weights1<INTERP>(s, w, lead);  // overlaps the LDS latency
         lds_fence<K>(g, w);
         double &ar = dacc[2 * (p & 1)], &ai = dacc[2 * (p & 1) + 1];
         if constexpr (K > 1 && !CHECK && !C::WTAB) {

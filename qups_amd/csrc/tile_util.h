@@ -55,22 +55,33 @@ template <int INTERP> __device__ __forceinline__ void weights2(v2f s, v2f w[4]) 
     }
 }
 
-// fp64 data: the same weights for ONE sample, in double (cubic exact; Lanczos: degree-9 polynomials in q, lanczos_poly64.h)
+// fp64 data: the same weights for ONE sample, in double (cubic exact; Lanczos: degree-6 polynomials in q, |error| < 2e-12: lanczos_poly64.h)
 // Four polynomials of the same degree in lock-step: four independent FMA chains (a dependent v_fma_f64 cannot issue back to back).
-// Every coefficient passes through an opaque scalar register right where it is used: left alone, the compiler keeps all 32 double
-// constants live across the 16 unrolled samples of a stage -- 64 SGPRs, which spill into VGPR lanes and from there into scratch;
-// one s_mov_b64 per use rides on the scalar unit, beside the other waves' vector work.
+// Every coefficient passes through an opaque scalar register right where it is used: left alone, the compiler keeps all the double
+// constants live across the 16 unrolled samples of a stage -- > 50 SGPRs, which spill into VGPR lanes and from there into scratch;
+// one s_mov_b64 per use rides on the scalar unit, beside the other waves' vector work.  The LEADING coefficients arrive in vector
+// registers (`lead`, made once per stage by the caller): an FMA reads one scalar operand only.
 template <int D> __device__ __forceinline__ void horner4(const double (&a)[D + 1], const double (&b)[D + 1], const double (&c)[D + 1], const double (&d)[D + 1],
-                                                         double q, double &ra, double &rb, double &rc, double &rd) {
+                                                         const double (&lead)[4], double q, double &ra, double &rb, double &rc, double &rd) {
     auto k_ = [](double v) { asm volatile("" : "+s"(v)); return v; };
-    ra = k_(a[D]); rb = k_(b[D]); rc = k_(c[D]); rd = k_(d[D]);
+    ra = __builtin_fma(lead[0], q, k_(a[D - 1])); rb = __builtin_fma(lead[1], q, k_(b[D - 1]));
+    rc = __builtin_fma(lead[2], q, k_(c[D - 1])); rd = __builtin_fma(lead[3], q, k_(d[D - 1]));
 #pragma unroll
-    for (int k = D - 1; k >= 0; --k) {
+    for (int k = D - 2; k >= 0; --k) {
         ra = __builtin_fma(ra, q, k_(a[k])); rb = __builtin_fma(rb, q, k_(b[k]));
         rc = __builtin_fma(rc, q, k_(c[k])); rd = __builtin_fma(rd, q, k_(d[k]));
     }
 }
-template <int INTERP> __device__ __forceinline__ void weights1(double s, double (&w)[4]) {
+// the four leading coefficients of the fp64 Lanczos polynomials, in vector registers (nothing for the other interpolators)
+template <int INTERP> __device__ __forceinline__ void weights1_lead(double (&lead)[4]) {
+    if constexpr (INTERP == 3) {
+        constexpr double EI[] = QDAS_LANCZOS64_EI, OI[] = QDAS_LANCZOS64_OI, EO[] = QDAS_LANCZOS64_EO, OO[] = QDAS_LANCZOS64_OO;
+        constexpr int D = sizeof(EI) / 8 - 1;
+        lead[0] = EI[D]; lead[1] = OI[D]; lead[2] = EO[D]; lead[3] = OO[D];
+        asm volatile("" : "+v"(lead[0]), "+v"(lead[1]), "+v"(lead[2]), "+v"(lead[3]));
+    } else { lead[0] = lead[1] = lead[2] = lead[3] = 0.0; }
+}
+template <int INTERP> __device__ __forceinline__ void weights1(double s, double (&w)[4], const double (&lead)[4]) {
     if constexpr (INTERP == 1 || INTERP == 4) {
         w[0] = 0.5 - s; w[1] = 0.5 + s;
     } else if constexpr (INTERP == 2) {
@@ -83,7 +94,7 @@ template <int INTERP> __device__ __forceinline__ void weights1(double s, double 
         const double q = s * s;
         static_assert(sizeof(EI) == sizeof(OI) && sizeof(EI) == sizeof(EO) && sizeof(EI) == sizeof(OO), "one degree");
         double ei, oi, eo, oo;
-        horner4<sizeof(EI) / 8 - 1>(EI, OI, EO, OO, q, ei, oi, eo, oo);
+        horner4<sizeof(EI) / 8 - 1>(EI, OI, EO, OO, lead, q, ei, oi, eo, oo);
         w[1] = ei + s * oi; w[2] = ei - s * oi; w[0] = eo + s * oo; w[3] = eo - s * oo;
     } else if constexpr (INTERP == 5) {
         const double u = s + 0.5;

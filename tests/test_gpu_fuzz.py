@@ -36,6 +36,8 @@ def _draw(seed):
     elif extra["bf"] and cfg["prec"] == "single":
         cfg.update(fun="BF", F=min(cfg["F"], 2))
     cfg.update(extra)
+    if r.integers(0, 8) == 0 and not extra["sym"] and cfg["fun"] != "BF":   # fp64 data on the fused kernel: plain 'DAS', pixel-independent weights
+        cfg.update(prec="double", fmod=0.0, wpix=False, gen="", fun="DAS", cmap=False, jit=False)
     if os.environ.get("QDAS_FUZZ_OVERRIDE"):                            # debugging aid: JSON dict of fields to force
         import json
         cfg.update(json.loads(os.environ["QDAS_FUZZ_OVERRIDE"]))
@@ -64,6 +66,8 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
         t0 = (case["t0"] + np.float32(1.0 / case["fs"]) * r.integers(-3, 4, (1, 1, M))).astype(np.float32).astype(np.float64)
     apod = []
     q = (lambda a: a.astype(np.float16).astype(np.float64)) if c["prec"] == "halfT" else (lambda a: a.astype(np.float32).astype(np.float64))
+    if c["prec"] == "double":
+        q = lambda a: a.astype(np.float64)
     if c["wn"]:
         apod.append(q(r.uniform(0.2, 1, (1, 1, 1, N, 1))))
     if c["wm"]:
@@ -82,7 +86,7 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
     if c["prec"] == "halfT":
         xs_all = [(v.real.astype(np.float16).astype(np.float32) + 1j * v.imag.astype(np.float16).astype(np.float32)).astype(np.complex64) for v in xs_all]
     cval = case["c"]
-    c_or = cinv_f32(case["c"])
+    c_or = cinv_f32(case["c"]) if c["prec"] != "double" else case["c"]
     if c["cmap"]:                                                        # smooth per-pixel sound-speed map
         zz, xx = np.meshgrid(np.linspace(0, 1, c["I1"]), np.linspace(0, 1, c["I2"]), indexing="ij")
         f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
@@ -121,7 +125,7 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
     xc = _colmajor(_cast_data(xt, prob.prec, plan.device))
     y = plan.execute_colmajor(xc, F)                                    # (F, oM, oN, count)
     torch.cuda.synchronize()
-    outs = y.to(torch.complex64).cpu().numpy()
+    outs = y.to(torch.complex128 if c["prec"] == "double" else torch.complex64).cpu().numpy()
     assert plan.kernel == "tiled", c
     oapod = tuple(apod) + ((gen_arr,) if gen_spec is not None else ())
     for f in range(F):
@@ -141,10 +145,12 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
         if c["interp"] == "nearest" or (gen_spec is not None and c["gen"] != "cosine"):
             # discontinuous in tau (nearest) or in the geometry (binary masks): a rounding at the step swaps ONE of the N*M
             # samples of a pixel / one receiver; such pixels are rare, the others agree to rounding
-            bad = np.abs(out - refv) / den > (3e-3 if c["prec"] == "halfT" else 1e-4)
+            bad = np.abs(out - refv) / den > {"halfT": 3e-3, "single": 1e-4, "double": 1e-9}[c["prec"]]
             assert bad.mean() <= 0.05, (seed, c, float(bad.mean()))
             continue
         tol = 3e-3 if c["prec"] == "halfT" else 1e-4                      # covers tiles that fell back to the generic kernel (fp32 delays)
+        if c["prec"] == "double":
+            tol = 1e-9
         if err > tol and os.environ.get("QDAS_FUZZ_DEBUG"):                 # debugging aid: where, and what the generic kernel says
             yg = DasPlan(prob, kernel=1, **kw).execute_colmajor(xc, F).to(torch.complex64).cpu().numpy()[f].reshape(refv.shape[1], -1).T
             e = np.abs(out - refv).max(axis=1) / den
