@@ -74,6 +74,12 @@ struct TileCfg {
     static constexpr int SB = (int)sizeof(ST);       // bytes per complex sample
     static constexpr bool F32 = (SB == 8);
     static constexpr bool F64 = (SB == 16);          // double data: geometry, delays, weights and sums in fp64 (tile_pairs.h pairs_f64)
+    // instantiations that may run a pixel x receiver weight: their stage list holds the ACTIVE receivers only
+#ifdef QDAS_NO_ACT
+    static constexpr bool ACT = false;               // (A/B builds)
+#else
+    static constexpr bool ACT = !F64 && !SYM && !BIG && !BF_ && !(FB4 && F32);
+#endif
     using GT = std::conditional_t<F64, double, float>;   // type of the geometry tables (the reference casts them to the data precision, kern/das_spec.m:244)
     static constexpr int WB = W * SB;                // bytes per window
     static constexpr int PB = 1024;                  // bytes per full DMA piece (one wave-instruction x 16 B)
@@ -105,6 +111,7 @@ template <class C> struct Tile {
     using GT = typename C::GT;
     struct rec64 { double x, y, z; int b, pad; };     // fp64 twin of the receiver record {window base B, position}
     int *Abase; float *Aext, *Bext; float4 *nrec; rec64 *nrec64; GT *PvL, *NvL; ST *win; float *part; uint32_t win_off;
+    unsigned short *act;                             // [N + 1] receivers with a non-zero weight somewhere in the tile, then their count (pixel x receiver weights)
     uint32_t split, S, tile_id;
     double fs, symC; int symCi;
     bool tile_interior;
@@ -117,6 +124,7 @@ template <class C> struct Tile {
     double cf;                                       // samples per metre (scalar sound speed or this pixel's entry of the map)
     // ---- stage loop
     uint32_t n_lo, n_hi, nstage;
+    uint32_t nact; bool use_act;                     // stages per transmit block / whether they come from act[] (else: receivers n_lo ... in order)
     v2f acc, acc1, acc2, acc3;                       // independent partial sums: no back-to-back dependent packed FMAs
     v2f ra[C::MB / 2];                               // block residuals a - A[m] - 1/2 of transmits (2p, 2p+1), packed
     double rad[C::F64 ? C::MB : 1];                  // fp64 data: the same residuals, one double per transmit
@@ -206,7 +214,13 @@ template <class C> __device__ __forceinline__ uint32_t Tile<C>::locate(uint32_t 
     const uint32_t ntile = P.tiles_x * P.tiles_z;
     const uint32_t sp = bid / ntile;
     bid -= sp * ntile;
+    // DEEPEST band first: with an acceptance-angle / f-number mask the deep tiles have the most active receivers -- the longest
+    // jobs start first and the shallow ones fill in behind them (a CU runs one workgroup at a time; images have 2-4 tiles per CU)
+#ifdef QDAS_SHALLOW_FIRST
     const uint32_t tz = bid / P.tiles_x, txi = P.tile_x0 + bid % P.tiles_x;
+#else
+    const uint32_t tz = P.tiles_z - 1u - bid / P.tiles_x, txi = P.tile_x0 + bid % P.tiles_x;
+#endif
     if (first) { S = QSPEC(KSPLIT, P.ksplit); split = sp; tile_id = tz + P.tiles_z * txi; }
 
     // ---- my pixel.  Tile and wave footprints (uniform, chosen by the plan from the scan's delay gradient; qdas_api.hip
@@ -244,7 +258,8 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
     constexpr uint32_t RECB = C::F64 ? 32u : 16u, GB = (uint32_t)sizeof(GT);
     PvL   = (GT *)((unsigned char *)nrec + RECB * N);   // [4M] (virtual) sources + t0
     NvL   = PvL + 4 * M;                              // [3M] transmit normals
-    const uint32_t hdr = ((((2 * M + N) * 4 + 15) & ~15u) + RECB * N + 7 * M * GB + 15) & ~15u;
+    act   = (unsigned short *)(NvL + 3 * M);          // [N + 1]
+    const uint32_t hdr = ((((2 * M + N) * 4 + 15) & ~15u) + RECB * N + 7 * M * GB + 2 * (N + 1) + 15) & ~15u;
     win = (ST *)(smem + hdr);                         // [NBUF][NW][W]
     part = (float *)(smem + hdr);                     // prologue scratch, aliases the windows
     win_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem) + hdr;
@@ -325,8 +340,6 @@ template <class C> __device__ __forceinline__ v2f Tile<C>::wload(uint32_t n) con
 template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
     n_lo = C::SYM ? 0u : (uint32_t)((uint64_t)N * split / S);
     n_hi = (uint32_t)((uint64_t)N * (split + 1) / S);
-    nstage = 0;
-    for (uint32_t r = 0; blk(r) < M; ++r) nstage += nlim(blk(r)) - n_lo;
     acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
     dacc[0] = dacc[1] = dacc[2] = dacc[3] = 0.0;
 #pragma unroll
@@ -337,18 +350,57 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
     fb = C::FB4 ? fa + 2 : 1;
     soff = soff2 = 0; offD = offM = 0;
     rsD = __builtin_amdgcn_make_buffer_rsrc((void *)P.x, 0, 0, 0x00020000); rsM = rsD;
+    // Pixel x receiver weights (an acceptance-angle or f-number mask, say): receivers whose weight is zero for EVERY pixel of the tile
+    // -- typically more than half of them -- are dropped from the tile's stage list: no staging, no barrier, no delay evaluation.
+    // (With one window buffer in flight a stage that every wave skips still costs a full LDS-DMA latency.)
+    nact = n_hi - n_lo; use_act = false;
+    if constexpr (C::ACT) {
+        if (wpix) {
+            use_act = true;
+            uint32_t *flg = (uint32_t *)part;          // prologue scratch (the windows are not in use yet)
+            for (uint32_t k = tid; k < (N + 31) / 32; k += C::THREADS) flg[k] = 0u;
+            __syncthreads();
+            for (uint32_t n0 = n_lo; n0 < n_hi; n0 += 4) {
+                v2f w4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w4[q] = wload(n0 + q < n_hi ? n0 + q : n_hi - 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool any = __ballot(!(w4[q].x == 0.f && w4[q].y == 0.f)) != 0ull;
+                    if (any && lane == 0 && n0 + q < n_hi) atomicOr(&flg[(n0 + q) >> 5], 1u << ((n0 + q) & 31u));
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t cnt = 0;
+                for (uint32_t n = n_lo; n < n_hi; ++n)
+                    if ((flg[n >> 5] >> (n & 31u)) & 1u) act[cnt++] = (unsigned short)n;
+                act[N] = (unsigned short)cnt;
+            }
+            __syncthreads();
+            nact = (uint32_t)__builtin_amdgcn_readfirstlane((int)act[N]);
+            __syncthreads();                           // (flg aliases the first window buffer)
+        }
+    }
+    nstage = 0;
+    if (use_act) { for (uint32_t r = 0; blk(r) < M; ++r) nstage += nact; }
+    else { for (uint32_t r = 0; blk(r) < M; ++r) nstage += nlim(blk(r)) - n_lo; }
 }
 
 // ------------------------------------------------------------------------------------------------- the stage loop
 // Stages: mb = transmit block, n = receiver; n is the inner index.  CHECK: the tile touches the ends of the record.
 template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>::run() {
     constexpr int NBUF = C::NBUF, NDMA = C::NDMA;
+    // the k-th stage of a transmit block works on receiver nsel(k); a block has klim(m0) stages
+    auto nsel = [&](uint32_t k) -> uint32_t { if constexpr (C::ACT) { if (use_act) return (uint32_t)__builtin_amdgcn_readfirstlane((int)act[k < N ? k : N - 1]); } return n_lo + k; };   // (uniform: scalar register)
+    auto klim = [&](uint32_t mm) -> uint32_t { if constexpr (C::ACT) { if (use_act) return nact; } return nlim(mm) - n_lo; };
     v2f wcur = {1.f, 0.f}, wnext = {1.f, 0.f};
-    if (wpix) wcur = wload(n_lo);
+    const uint32_t n_first = nstage ? nsel(0) : n_lo;
+    if (wpix) wcur = wload(n_first);
     float tbc = 0.f, tbn = 0.f;                        // LUT: this / the next stage's receive delay of my pixel
     const uint64_t Ilut = P.i_begin + P.i_count;
-    if constexpr (C::LUT) tbc = P.lut_rx[ipx + Ilut * n_lo];
-    uint32_t pr = 0, pn = n_lo, pm0 = blk(0);          // stage the DMA front is at (NBUF-1 stages ahead)
+    if constexpr (C::LUT) tbc = P.lut_rx[ipx + Ilut * n_first];
+    uint32_t pr = 0, pk = 0, pn = n_first, pm0 = blk(0);   // stage the DMA front is at (NBUF-1 stages ahead)
     dma_block(pm0);
     // B[n] of the stage at the DMA front travels in a VGPR, loaded one stage before it is needed: every LDS read of a stage
     // is issued BEFORE the stage's LDS-DMA in program order (the compiler orders a later LDS read behind the DMA's vmcnt).
@@ -356,10 +408,12 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
     float vbn = rec_base(pn < N ? pn : N - 1);
     auto dma_next = [&](int buf) {
         const int bn = __builtin_amdgcn_readfirstlane(__float_as_int(vbn));
-        const uint32_t qn = (pn + 1 == nlim(pm0)) ? n_lo : pn + 1;     // receiver of the stage after this one
+        const uint32_t qn = nsel(pk + 1 == klim(pm0) ? 0u : pk + 1);   // receiver of the stage after this one
         vbn = rec_base(qn < N ? qn : N - 1);
+        if constexpr (C::ACT) { if (use_act) soff = (pn - n_lo) * (uint32_t)strN * (uint32_t)C::SB; }   // (stage lists with gaps: no running offset)
         stage_dma(bn, buf);
-        if (++pn == nlim(pm0)) { pn = n_lo; pm0 = blk(++pr); dma_block(pm0); }
+        if (++pk == klim(pm0)) { pk = 0; pm0 = blk(++pr); dma_block(pm0); }
+        pn = qn;
     };
 #pragma unroll
     for (int b = 0; b < NBUF - 1; ++b)
@@ -368,13 +422,14 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
     if (nstage >= (uint32_t)(NBUF - 1)) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NBUF - 2) * NDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     int buf = 0;
-    uint32_t cr = 0, n = n_lo, m0 = blk(0);
+    uint32_t cr = 0, k = 0, n = n_first, m0 = blk(0);
     for (uint32_t st = 0; st < nstage; ++st) {
         timer.mark(0);
         const bool more = st + (NBUF - 1) < nstage;
+        const uint32_t n_next = nsel(k + 1 == klim(m0) ? 0u : k + 1);     // (an LDS read: like every LDS read of the stage, ahead of its DMA)
         // next stage's pixel weight: requested BEFORE this stage's DMA, so the end-of-stage wait covers it
-        if (wpix && st + 1 < nstage) wnext = wload(n + 1 == nlim(m0) ? n_lo : n + 1);
-        if constexpr (C::LUT) { if (st + 1 < nstage) tbn = P.lut_rx[ipx + Ilut * (n + 1 == nlim(m0) ? n_lo : n + 1)]; }
+        if (wpix && st + 1 < nstage) wnext = wload(n_next);
+        if constexpr (C::LUT) { if (st + 1 < nstage) tbn = P.lut_rx[ipx + Ilut * n_next]; }
         const bool skip = wpix && (__ballot(wcur.x != 0.f || wcur.y != 0.f) == 0ull);   // whole wave weightless: no gathers
         // {B[n], receiver position}: one broadcast LDS read (fp64 data: two), issued ahead of the DMA
         int rec_b; GT rec_x, rec_y, rec_z;
@@ -389,7 +444,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         if (!hooks::no_stage_dma && more && !dma_late) dma_next((buf + NBUF - 1) % NBUF);   // lands during the next NBUF-1 stages
         timer.mark(1);
         if constexpr (C::F64) {
-            if (n == n_lo) {                           // new transmit block: refresh the block residuals (cold: once per N stages)
+            if (k == 0) {                              // new transmit block: refresh the block residuals (cold: once per N stages)
 #pragma unroll
                 for (int p = 0; p < C::MB; ++p) {
                     const uint32_t ma = m0 + p < M ? m0 + p : M - 1;
@@ -397,7 +452,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        } else if (n == n_lo) {                        // new transmit block: refresh the block residuals (cold: once per N stages)
+        } else if (k == 0) {                           // new transmit block: refresh the block residuals (cold: once per N stages)
 #pragma unroll
             for (int p = 0; p < C::MB / 2; ++p) {
                 const uint32_t ma = m0 + 2 * p < M ? m0 + 2 * p : M - 1, mb = m0 + 2 * p + 1 < M ? m0 + 2 * p + 1 : M - 1;
@@ -476,7 +531,8 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
             wcur = wnext;
         }
         if constexpr (C::LUT) tbc = tbn;
-        if (++n == nlim(m0)) { n = n_lo; m0 = blk(++cr); }
+        if (++k == klim(m0)) { k = 0; m0 = blk(++cr); }
+        n = n_next;
     }
 }
 

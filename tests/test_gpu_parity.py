@@ -534,6 +534,28 @@ def test_tiled_pixel_receiver_apodization(prec):
     assert plan.kernel == "generic" and rel_err(out, run_oracle(case, apod=(full,), x=x)) <= max(tol, TOL32)
 
 
+@pytest.mark.parametrize("fun", ["DAS", "SYN"])
+@pytest.mark.parametrize("ks", [1, 3])
+def test_receivers_without_weight_in_a_tile_are_dropped_from_its_stage_list(fun, ks, monkeypatch):
+    """a pixel x receiver mask: receivers 0-4 weigh nothing anywhere, the shallow third of the image weighs nothing at all (tiles with an
+    EMPTY stage list), the rest follows a depth-dependent aperture -- the tile's stage list holds the active receivers only
+    (das_tile_impl.h plan_stages); 'SYN' planes of dropped receivers stay zero; with and without an aperture split"""
+    monkeypatch.setenv("QDAS_KSPLIT", str(ks))
+    case = make_case(seq="PW", interp="cubic", seed=31, N=24, M=9, I1=200, I2=21, zlim=(4e-3, 24e-3))
+    rng = np.random.default_rng(8)
+    zz = np.linspace(0, 1, 200)[:, None, None, None, None]
+    nn = np.arange(24)[None, None, None, :, None]
+    mask = ((np.abs(nn - 12) <= 2 + 14 * zz) & (nn >= 5) & (zz > 0.34)) * f32r(rng.uniform(0.5, 1.0, (200, 21, 1, 24, 1)))
+    assert (mask[:66] == 0).all() and (mask[..., :5, :] == 0).all() and (mask != 0).any()
+    ref = run_oracle(case, fun=fun, apod=(mask,))
+    out, plan = run_das(case, fun=fun, apod=(mask,), kernel=2)
+    assert plan.kernel == "tiled" and plan.fallback_tiles() == 0
+    assert rel_err(out, ref) <= 2e-5
+    assert np.all(out[:64] == 0)                                    # (whole tiles of the shallow third)
+    if fun == "SYN":
+        assert np.all(out[..., :5, :] == 0)
+
+
 @pytest.mark.parametrize("tz,wz", [(64, 64), (64, 8), (64, 4), (32, 32), (32, 4), (16, 16), (16, 8), (8, 8), (8, 4)])
 @pytest.mark.parametrize("seq,prec", [("FSA", "single"), ("PW", "single"), ("DV", "halfT")])
 def test_tile_shapes_forced(tz, wz, seq, prec, monkeypatch):

@@ -12,5 +12,5 @@ for a in "$@"; do
 done
 wait
 for a in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/abl/libqdas_abl$a.so qdas_api.o das_generic.o das_lut.o greens.o pre.o ../../tools/abl/das_tile_$a.o -L/opt/rocm/lib -lhipfft -Wl,-rpath,/opt/rocm/lib
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/abl/libqdas_abl$a.so qdas_api.o das_generic.o das_lut.o wsinterpd.o greens.o pre.o conv.o layout.o jit.o sharded.o ../../tools/abl/das_tile_$a.o -L/opt/rocm/lib -lhipfft -ldl -Wl,-rpath,/opt/rocm/lib
 done

@@ -16,9 +16,14 @@ dev = torch.device("cuda:0")
 T, N, M = w["T"], w["N"], w["M"]
 g = torch.Generator(device=dev).manual_seed(1234)
 xc = torch.view_as_complex(torch.randn((F, M, N, T, 2), generator=g, device=dev, dtype=torch.float32))
-opts = parse_options(xc, list(w["opt"]) + ["interp", w["interp"], "input-precision", "single"])
+prec = os.environ.get("QDAS_PT_PREC", w["prec"])                # the workload's data precision and pixel x receiver mask, as bench.py
+extra = ["apod", w["apod"]] if w["apod"] is not None and not os.environ.get("QDAS_PT_NO_APOD") else []
+opts = parse_options(xc, list(w["opt"]) + ["interp", w["interp"], "input-precision", prec] + extra)
+if prec != "single":
+    from qups_amd.das_spec import _cast_data
+    xc = _cast_data(xc, prec, dev).contiguous()
 prob = build_problem("DAS", w["Pi"], w["Pr"], w["Pv"], w["Nv"], (T, N, M, F), w["t0"], w["fs"], w["c0"], opts)
-plan = DasPlan(prob, device=dev)
+plan = DasPlan(prob, device=dev, reciprocal=not os.environ.get("QDAS_PT_NO_RECIPROCAL"))
 plan.set_timing(True)
 for _ in range(2):
     plan.execute_colmajor(xc, F)
