@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "none"],
                     help="roofline.traffic: rocprofv3 counter passes of this command (live; auto = live at N=1) or profiles/traffic_<w>.json")
     ap.add_argument("--fmod", type=float, default=0.0, help="remodulation frequency [Hz] ('modulation' option): baseband data; not the headline")
+    ap.add_argument("--rx-apod", default=None, help="generated receive apodization for ANY workload, e.g. fnumber:1.5 | acceptance:30 | cosine:45 "
+                    "(evaluated inside the kernel: what an apodized frame costs); not the headline")
     ap.add_argument("--prec", default=None, help="override the workload's data precision (single | halfT | double); not the headline")
     ap.add_argument("--gen-apod", action="store_true", help="generate the workload's receive apodization inside the kernel "
                     "(qdas_desc.rx_apod_*) instead of streaming the materialised I x N array")
@@ -218,7 +220,14 @@ def main():
     extra = ["interp", w["interp"], "input-precision", w["prec"]] + (["modulation", args.fmod] if args.fmod else [])
     if args.fmod:
         w["label"] += f" [fmod {args.fmod:g} Hz]"
-    if args.gen_apod and w["rx_apod"] is not None:
+    if args.rx_apod:
+        from qups_amd.apodization import rx_apod_spec
+        kind, _, par = args.rx_apod.partition(":")
+        kw = ({"f": float(par)} if kind == "fnumber" else {"theta": float(par)}) if par else {}
+        extra += ["rx-apod", rx_apod_spec(kind, normals=w.get("nrm"), **kw)]
+        w["apod"] = None
+        w["label"] += f" [generated receive apodization {args.rx_apod}]"
+    elif args.gen_apod and w["rx_apod"] is not None:
         from qups_amd.apodization import rx_apod_spec
         extra += ["rx-apod", rx_apod_spec(w["rx_apod"][0], normals=w["nrm"], **w["rx_apod"][1])]
         w["apod"] = None
@@ -316,7 +325,7 @@ def main():
             mode = "live" if world == 1 else "file"
         if mode == "live":
             argv = ["--workload", args.workload] + (["--kernel", str(args.kernel)] if args.kernel else []) + \
-                   (["--prec", args.prec] if args.prec else []) + (["--fmod", str(args.fmod)] if args.fmod else []) + (["--gen-apod"] if args.gen_apod else []) + \
+                   (["--prec", args.prec] if args.prec else []) + (["--fmod", str(args.fmod)] if args.fmod else []) + (["--rx-apod", args.rx_apod] if args.rx_apod else []) + (["--gen-apod"] if args.gen_apod else []) + \
                    (["--no-reciprocal"] if args.no_reciprocal else []) + (["--no-jit"] if args.no_jit else [])
             traffic, tsrc = measure_traffic(argv)
             if traffic is None:
