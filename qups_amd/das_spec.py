@@ -18,6 +18,7 @@ a GPU; :class:`DasPlan` needs ``libqdas.so`` and a HIP device and fails loudly o
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Any, Sequence
 
@@ -595,8 +596,12 @@ class MultiDevicePlan:
 
 
 def das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs=None, c=None, *varargin, return_plan=False,
-             kernel: int = _lib.KERNEL_AUTO, jit: bool = False):
+             kernel: int = _lib.KERNEL_AUTO, jit: bool | None = None):
     """``y = das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs, c, ...)`` -- see reference ``kern/das_spec.m:1-87``.
+
+    ``jit``: build the fused kernel for this call's sizes through hiprtc (``QDAS_PLAN_JIT``; the reference compiles its kernel per
+    call with the sizes as constants, ``src/UltrasoundSystem.m:5626-5748``): first use of a shape costs a few seconds, later ones
+    load from ``~/.cache/qdas``; 5-8 % faster than the prebuilt kernels.  Default: the environment variable ``QDAS_JIT`` (off).
 
     ``fun`` in ``{'DAS','SYN','MUL','BF','delays'}``; options (strings, as in the reference):
     ``'plane-waves' | 'virtual-source' | 'diverging-waves' | 'focused-waves'``,
@@ -617,6 +622,8 @@ def das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs=None, c=None, *varargin, return_plan
     prob = build_problem(fun, Pi, Pr, Pv, Nv, xshape, t0, fs, c, opts)
     # MATLAB device ids are 1-based; any negative id means "the current device" (the reference passes -1, kern/das_spec.m:131)
     device = None if (opts["device"] is None or opts["device"] < 0) else f"cuda:{opts['device'] - 1}"
+    if jit is None:
+        jit = os.environ.get("QDAS_JIT", "0") not in ("", "0")
     plan = DasPlan(prob, device=device, kernel=kernel, jit=jit)     # jit: hiprtc build for these sizes (qdas.h QDAS_PLAN_JIT)
     Isz = prob.Isz
     rev = lambda t: t.permute(*reversed(range(t.ndim)))
