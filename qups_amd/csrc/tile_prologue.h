@@ -43,8 +43,7 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
         float lo[4], hi[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { lo[q] = hi[q] = (v[q] == v[q]) ? v[q] : INFINITY; }   // a NaN delay poisons the tile's extent
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { lo[q] = wave_min63(lo[q]); hi[q] = wave_max63(hi[q]); }
+        wave_minmax63x4(lo, hi);
         if (lane == 63) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (e0 + q < cnt) { part[wave * MX + e0 + q] = lo[q]; part[(WAVES + wave) * MX + e0 + q] = hi[q]; }

@@ -121,6 +121,25 @@ __device__ __forceinline__ float wave_max63(float v) {
     v = fmaxf(v, dppf<0x142, 0xa>(v)); v = fmaxf(v, dppf<0x143, 0xc>(v));
     return v;
 }
+// Four minima and four maxima at once, one instruction per value and step (the result is valid in lane 63 only).  Written as
+// v_min/v_max_f32_dpp in ONE asm block: through the builtin each step compiles to a copy, a v_mov_dpp, a canonicalising v_max and
+// the v_min -- four instructions per value and step, 192 per call of the prologue's inner loop instead of 48.  The eight chains are
+// interleaved, so a DPP read follows the write of its register by seven instructions (the 2-wait-state hazard needs no s_nop);
+// the leading s_nop covers whatever wrote the inputs.  The inputs must not be NaN (the caller maps NaN to +-inf).
+__device__ __forceinline__ void wave_minmax63x4(float (&lo)[4], float (&hi)[4]) {
+#define QDAS_DPP_STEP(ctrl)                                                                                                       \
+    "v_min_f32_dpp %0, %0, %0 " ctrl "\n\tv_min_f32_dpp %1, %1, %1 " ctrl "\n\tv_min_f32_dpp %2, %2, %2 " ctrl "\n\tv_min_f32_dpp %3, %3, %3 " ctrl "\n\t" \
+    "v_max_f32_dpp %4, %4, %4 " ctrl "\n\tv_max_f32_dpp %5, %5, %5 " ctrl "\n\tv_max_f32_dpp %6, %6, %6 " ctrl "\n\tv_max_f32_dpp %7, %7, %7 " ctrl "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 QDAS_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 QDAS_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 QDAS_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 QDAS_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+                 QDAS_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 QDAS_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]));
+#undef QDAS_DPP_STEP
+}
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
