@@ -69,7 +69,7 @@ size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow) {
     const TileConfig c = tile_config(dtype, sym, narrow);
     const size_t MX = M > N ? M : N;
     // (geometry tables in the plan's real type: 32-byte receiver records and 8-byte table entries for fp64 data -- Tile::setup)
-    const size_t hdr = (((((2 * M + N) * 4 + 15) & ~(size_t)15) + (dtype == 0 ? 32 : 16) * N + 7 * M * (dtype == 0 ? 8 : 4)) + 2 * (N + 1) + 15) & ~(size_t)15;
+    const size_t hdr = (((((2 * M + N) * 4 + 15) & ~(size_t)15) + (dtype == 0 ? 32 : 16) * N + 7 * M * (dtype == 0 ? 8 : 4)) + 8 * (N + 1) + 15) & ~(size_t)15;
     size_t body = c.lds_bytes;
     const size_t scratch = 2 * (size_t)g.waves * MX * 4 + 1024;   // prologue scratch aliases the windows
     if (body < scratch) body = scratch;

@@ -78,7 +78,7 @@ struct TileCfg {
 #ifdef QDAS_NO_ACT
     static constexpr bool ACT = false;               // (A/B builds)
 #else
-    static constexpr bool ACT = !F64 && !SYM && !BIG && !BF_ && !(FB4 && F32);
+    static constexpr bool ACT = !F64 && !SYM && !BIG && !BF_ && !FB2 && !FB4;     // (frames sharing a launch keep the plain list: no register for it)
 #endif
     using GT = std::conditional_t<F64, double, float>;   // type of the geometry tables (the reference casts them to the data precision, kern/das_spec.m:244)
     static constexpr int WB = W * SB;                // bytes per window
@@ -111,7 +111,7 @@ template <class C> struct Tile {
     using GT = typename C::GT;
     struct rec64 { double x, y, z; int b, pad; };     // fp64 twin of the receiver record {window base B, position}
     int *Abase; float *Aext, *Bext; float4 *nrec; rec64 *nrec64; GT *PvL, *NvL; ST *win; float *part; uint32_t win_off;
-    unsigned short *act;                             // [N + 1] receivers with a non-zero weight somewhere in the tile, then their count (pixel x receiver weights)
+    uint2 *act;                                      // [N + 1] {receiver, its window base B} of the receivers with a non-zero weight somewhere in the tile, then {count, -} (pixel x receiver weights)
     uint32_t split, S, tile_id;
     double fs, symC; int symCi;
     bool tile_interior;
@@ -170,7 +170,10 @@ template <class C> struct Tile {
     __device__ __forceinline__ const GT *geo_Pr() const { return (const GT *)P.Pr; }
     __device__ __forceinline__ const GT *geo_Pv() const { return (const GT *)P.Pv; }
     __device__ __forceinline__ const GT *geo_Nv() const { return (const GT *)P.Nv; }
-    __device__ __forceinline__ v2f wload(uint32_t n) const;              // pixel x receiver weight of stage element n
+    struct wraw { uint32_t a, b; };                                      // pixel x receiver weight of a stage element as loaded (raw bits)
+    __device__ __forceinline__ wraw wload_raw(uint32_t n) const;
+    __device__ __forceinline__ v2f wconv(wraw r) const;
+    __device__ __forceinline__ v2f wload(uint32_t n) const { return wconv(wload_raw(n)); }
 
     // staging (tile_staging.h)
     __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rs(uint64_t o, uint64_t extra) const;
@@ -258,8 +261,8 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
     constexpr uint32_t RECB = C::F64 ? 32u : 16u, GB = (uint32_t)sizeof(GT);
     PvL   = (GT *)((unsigned char *)nrec + RECB * N);   // [4M] (virtual) sources + t0
     NvL   = PvL + 4 * M;                              // [3M] transmit normals
-    act   = (unsigned short *)(NvL + 3 * M);          // [N + 1]
-    const uint32_t hdr = ((((2 * M + N) * 4 + 15) & ~15u) + RECB * N + 7 * M * GB + 2 * (N + 1) + 15) & ~15u;
+    act   = (uint2 *)(NvL + 3 * M);                   // [N + 1]
+    const uint32_t hdr = ((((2 * M + N) * 4 + 15) & ~15u) + RECB * N + 7 * M * GB + 8 * (N + 1) + 15) & ~15u;
     win = (ST *)(smem + hdr);                         // [NBUF][NW][W]
     part = (float *)(smem + hdr);                     // prologue scratch, aliases the windows
     win_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem) + hdr;
@@ -317,20 +320,28 @@ template <class C> __device__ __forceinline__ double Tile<C>::s_at(uint32_t n, G
 }
 
 // ---- per-(pixel, receiver) apodization (optional; uniform runtime switch, nothing of it in the pair loop)
-template <class C> __device__ __forceinline__ v2f Tile<C>::wload(uint32_t n) const {
+// Two halves: the LOAD (raw bits, requested a stage ahead) and the CONVERSION to fp32 (done where the weight is used).  As one
+// expression the conversion was scheduled right behind the load: every stage then waited out a full global-memory latency.
+template <class C> __device__ __forceinline__ typename Tile<C>::wraw Tile<C>::wload_raw(uint32_t n) const {
     const int gen_kind = QSPEC(GEN_KIND, P.gen_kind);
     if (!C::SYM && gen_kind) {                        // qdas.h QDAS_RXAPOD_*: element from the LDS record (never in reciprocal mode)
         const float4 e = nrec[n];
-        return (v2f){rx_apod_generated(gen_kind, P.gen_p0, P.gen_p1, px, py, pz, e.y, e.z, e.w, P.rxn, n), 0.f};
+        return wraw{__float_as_uint(rx_apod_generated(gen_kind, P.gen_p0, P.gen_p1, px, py, pz, e.y, e.z, e.w, P.rxn, n)), 0u};
     }
     const uint64_t k = ipx + P.I1 * P.I2 * P.I3 * n;
     if (QSPEC(APIX_REAL, P.apix_real)) {
-        if constexpr (C::F32) return (v2f){((const float *)P.apix)[k], 0.f};
-        else return (v2f){__half2float(__ushort_as_half(((const unsigned short *)P.apix)[k])), 0.f};
+        if constexpr (C::F32) return wraw{((const uint32_t *)P.apix)[k], 0u};
+        else return wraw{(uint32_t)((const unsigned short *)P.apix)[k], 0u};
     } else {
-        if constexpr (C::F32) { const float2 v = ((const float2 *)P.apix)[k]; return (v2f){v.x, v.y}; }
-        else return half2_to_v2f(((const uint32_t *)P.apix)[k]);
+        if constexpr (C::F32) { const uint2 v = ((const uint2 *)P.apix)[k]; return wraw{v.x, v.y}; }
+        else return wraw{((const uint32_t *)P.apix)[k], 0u};
     }
+}
+template <class C> __device__ __forceinline__ v2f Tile<C>::wconv(wraw r) const {
+    if ((!C::SYM && QSPEC(GEN_KIND, P.gen_kind)) || (C::F32 && QSPEC(APIX_REAL, P.apix_real))) return (v2f){__uint_as_float(r.a), 0.f};
+    if (QSPEC(APIX_REAL, P.apix_real)) return (v2f){__half2float(__ushort_as_half((unsigned short)r.a)), 0.f};
+    if constexpr (C::F32) return (v2f){__uint_as_float(r.a), __uint_as_float(r.b)};
+    else return half2_to_v2f(r.a);
 }
 
 // ------------------------------------------------------------------------------------------------- aperture share
@@ -374,11 +385,11 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
             if (tid == 0) {
                 uint32_t cnt = 0;
                 for (uint32_t n = n_lo; n < n_hi; ++n)
-                    if ((flg[n >> 5] >> (n & 31u)) & 1u) act[cnt++] = (unsigned short)n;
-                act[N] = (unsigned short)cnt;
+                    if ((flg[n >> 5] >> (n & 31u)) & 1u) act[cnt++] = make_uint2(n, __float_as_uint(nrec[n].x));
+                act[N] = make_uint2(cnt, 0u);
             }
             __syncthreads();
-            nact = (uint32_t)__builtin_amdgcn_readfirstlane((int)act[N]);
+            nact = (uint32_t)__builtin_amdgcn_readfirstlane((int)act[N].x);
             __syncthreads();                           // (flg aliases the first window buffer)
         }
     }
@@ -392,28 +403,38 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
 template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>::run() {
     constexpr int NBUF = C::NBUF, NDMA = C::NDMA;
     // the k-th stage of a transmit block works on receiver nsel(k); a block has klim(m0) stages
-    auto nsel = [&](uint32_t k) -> uint32_t { if constexpr (C::ACT) { if (use_act) return (uint32_t)__builtin_amdgcn_readfirstlane((int)act[k < N ? k : N - 1]); } return n_lo + k; };   // (uniform: scalar register)
+    auto nsel = [&](uint32_t k) -> uint32_t { if constexpr (C::ACT) { if (use_act) return (uint32_t)__builtin_amdgcn_readfirstlane((int)act[k < N ? k : N - 1].x); } return n_lo + k; };   // (uniform: scalar register)
     auto klim = [&](uint32_t mm) -> uint32_t { if constexpr (C::ACT) { if (use_act) return nact; } return nlim(mm) - n_lo; };
-    v2f wcur = {1.f, 0.f}, wnext = {1.f, 0.f};
+    v2f wcur = {1.f, 0.f};
+    wraw wnext_r = {0x3f800000u, 0u};
     const uint32_t n_first = nstage ? nsel(0) : n_lo;
     if (wpix) wcur = wload(n_first);
     float tbc = 0.f, tbn = 0.f;                        // LUT: this / the next stage's receive delay of my pixel
     const uint64_t Ilut = P.i_begin + P.i_count;
     if constexpr (C::LUT) tbc = P.lut_rx[ipx + Ilut * n_first];
-    uint32_t pr = 0, pk = 0, pn = n_first, pm0 = blk(0);   // stage the DMA front is at (NBUF-1 stages ahead)
+    uint32_t pr = 0, pk = 0, pm0 = blk(0);             // stage the DMA front is at (NBUF-1 stages ahead)
     dma_block(pm0);
-    // B[n] of the stage at the DMA front travels in a VGPR, loaded one stage before it is needed: every LDS read of a stage
-    // is issued BEFORE the stage's LDS-DMA in program order (the compiler orders a later LDS read behind the DMA's vmcnt).
+    // The receiver of the stage at the DMA front and its window base B[n] travel in VGPRs, loaded one stage before they are needed:
+    // every LDS read of a stage is issued BEFORE the stage's LDS-DMA in program order (the compiler orders a later LDS read behind
+    // the DMA's vmcnt), and nothing waits for an LDS round trip just to form the next address (a stage list with gaps keeps
+    // {receiver, base} in one table entry).
     auto rec_base = [&](uint32_t k) -> float { if constexpr (C::F64) return __int_as_float(nrec64[k].b); else return nrec[k].x; };
-    float vbn = rec_base(pn < N ? pn : N - 1);
+    float vbn; uint32_t vpn;
+    auto front_entry = [&](uint32_t kk) {
+        if constexpr (C::ACT) {
+            if (use_act) { const uint2 e = act[kk < N ? kk : N - 1]; vpn = e.x; vbn = __uint_as_float(e.y); return; }
+        }
+        const uint32_t q = n_lo + kk;
+        vpn = q; vbn = rec_base(q < N ? q : N - 1);
+    };
+    front_entry(0);
     auto dma_next = [&](int buf) {
         const int bn = __builtin_amdgcn_readfirstlane(__float_as_int(vbn));
-        const uint32_t qn = nsel(pk + 1 == klim(pm0) ? 0u : pk + 1);   // receiver of the stage after this one
-        vbn = rec_base(qn < N ? qn : N - 1);
+        const uint32_t pn = (uint32_t)__builtin_amdgcn_readfirstlane((int)vpn);
+        front_entry(pk + 1 == klim(pm0) ? 0u : pk + 1);             // of the stage after this one
         if constexpr (C::ACT) { if (use_act) soff = (pn - n_lo) * (uint32_t)strN * (uint32_t)C::SB; }   // (stage lists with gaps: no running offset)
         stage_dma(bn, buf);
         if (++pk == klim(pm0)) { pk = 0; pm0 = blk(++pr); dma_block(pm0); }
-        pn = qn;
     };
 #pragma unroll
     for (int b = 0; b < NBUF - 1; ++b)
@@ -426,9 +447,10 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
     for (uint32_t st = 0; st < nstage; ++st) {
         timer.mark(0);
         const bool more = st + (NBUF - 1) < nstage;
-        const uint32_t n_next = nsel(k + 1 == klim(m0) ? 0u : k + 1);     // (an LDS read: like every LDS read of the stage, ahead of its DMA)
+        // receiver of the next stage: with one stage of staging in flight that is where the DMA front stands (no LDS round trip)
+        const uint32_t n_next = (NBUF == 2 && C::ACT) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)vpn) : nsel(k + 1 == klim(m0) ? 0u : k + 1);
         // next stage's pixel weight: requested BEFORE this stage's DMA, so the end-of-stage wait covers it
-        if (wpix && st + 1 < nstage) wnext = wload(n_next);
+        if (wpix && st + 1 < nstage) wnext_r = wload_raw(n_next);
         if constexpr (C::LUT) { if (st + 1 < nstage) tbn = P.lut_rx[ipx + Ilut * n_next]; }
         const bool skip = wpix && (__ballot(wcur.x != 0.f || wcur.y != 0.f) == 0ull);   // whole wave weightless: no gathers
         // {B[n], receiver position}: one broadcast LDS read (fp64 data: two), issued ahead of the DMA
@@ -520,7 +542,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
                     unsafeAtomicAdd(q, Sf[f].x); unsafeAtomicAdd(q + 1, Sf[f].y);
                 }
             }
-            if (wpix) wcur = wnext;
+            if (wpix) { if constexpr (!C::F32) asm volatile("" : "+v"(wnext_r.a)); wcur = wconv(wnext_r); }   // (fp16 weights: converted here, a stage after the load)
             acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
         } else if (wpix) {                             // weight the stage's partial sum (the weight does not depend on m)
             v2f Sf[4];
@@ -528,7 +550,8 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
 #pragma unroll
             for (int f = 0; f < C::NFR; ++f) tot[f] += (v2f){wcur.x * Sf[f].x - wcur.y * Sf[f].y, wcur.x * Sf[f].y + wcur.y * Sf[f].x};
             acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
-            wcur = wnext;
+            if constexpr (!C::F32) asm volatile("" : "+v"(wnext_r.a));      // (fp16 weights: converted here, a stage after the load)
+            wcur = wconv(wnext_r);
         }
         if constexpr (C::LUT) tbc = tbn;
         if (++k == klim(m0)) { k = 0; m0 = blk(++cr); }

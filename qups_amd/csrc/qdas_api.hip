@@ -586,7 +586,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (const char *e = getenv("QDAS_JIT_NBUF")) { const int nb = atoi(e); if (nb >= 2 && nb <= 4) k.nbuf = nb; }
         {
             const size_t MX = t.M > t.N ? t.M : t.N;
-            const size_t hdr = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + 2 * (t.N + 1) + 15) & ~(size_t)15;   // Tile::setup
+            const size_t hdr = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + 8 * (t.N + 1) + 15) & ~(size_t)15;   // Tile::setup
             size_t body = (size_t)k.nbuf * k.mb * (t.sym ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
             const size_t scratch = 2 * (size_t)k.waves * MX * 4 + 1024;
             if (body < scratch) body = scratch;
