@@ -428,14 +428,19 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         vpn = q; vbn = rec_base(q < N ? q : N - 1);
     };
     front_entry(0);
-    auto dma_next = [&](int buf) {
-        const int bn = __builtin_amdgcn_readfirstlane(__float_as_int(vbn));
-        const uint32_t pn = (uint32_t)__builtin_amdgcn_readfirstlane((int)vpn);
+    // staging of the stage at the front, in two steps: its LDS read, then the DMA itself (the stage loop puts its global loads between them)
+    int dbn = 0; uint32_t dpn = 0;
+    auto dma_prep = [&]() {
+        dbn = __builtin_amdgcn_readfirstlane(__float_as_int(vbn));
+        dpn = (uint32_t)__builtin_amdgcn_readfirstlane((int)vpn);
         front_entry(pk + 1 == klim(pm0) ? 0u : pk + 1);             // of the stage after this one
-        if constexpr (C::ACT) { if (use_act) soff = (pn - n_lo) * (uint32_t)strN * (uint32_t)C::SB; }   // (stage lists with gaps: no running offset)
-        stage_dma(bn, buf);
+    };
+    auto dma_go = [&](int buf) {
+        if constexpr (C::ACT) { if (use_act) soff = (dpn - n_lo) * (uint32_t)strN * (uint32_t)C::SB; }   // (stage lists with gaps: no running offset)
+        stage_dma(dbn, buf);
         if (++pk == klim(pm0)) { pk = 0; pm0 = blk(++pr); dma_block(pm0); }
     };
+    auto dma_next = [&](int buf) { dma_prep(); dma_go(buf); };
 #pragma unroll
     for (int b = 0; b < NBUF - 1; ++b)
         if ((uint32_t)b < nstage) dma_next(b);
@@ -449,9 +454,6 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         const bool more = st + (NBUF - 1) < nstage;
         // receiver of the next stage: with one stage of staging in flight that is where the DMA front stands (no LDS round trip)
         const uint32_t n_next = (NBUF == 2 && C::ACT) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)vpn) : nsel(k + 1 == klim(m0) ? 0u : k + 1);
-        // next stage's pixel weight: requested BEFORE this stage's DMA, so the end-of-stage wait covers it
-        if (wpix && st + 1 < nstage) wnext_r = wload_raw(n_next);
-        if constexpr (C::LUT) { if (st + 1 < nstage) tbn = P.lut_rx[ipx + Ilut * n_next]; }
         const bool skip = wpix && (__ballot(wcur.x != 0.f || wcur.y != 0.f) == 0ull);   // whole wave weightless: no gathers
         // {B[n], receiver position}: one broadcast LDS read (fp64 data: two), issued ahead of the DMA
         int rec_b; GT rec_x, rec_y, rec_z;
@@ -463,7 +465,15 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         // loop by the older half: the hardware favours older waves, they finish their pair loop early and would only wait at
         // the barrier -- their (scalar-heavy) issue phase then overlaps the younger waves' arithmetic instead of everybody's.
         const bool dma_late = C::SYM && !hooks::no_late_dma && wave < C::WAVES / 2;
-        if (!hooks::no_stage_dma && more && !dma_late) dma_next((buf + NBUF - 1) % NBUF);   // lands during the next NBUF-1 stages
+        const bool dma_now = !hooks::no_stage_dma && more && !dma_late;
+        if (dma_now) dma_prep();
+        // next stage's pixel weight / table delay: global loads, requested AFTER every LDS read of the stage's head (the compiler puts
+        // an s_waitcnt vmcnt(0) in front of an LDS read that follows them -- it cannot tell them from the LDS-DMA it has to order
+        // LDS reads behind: each stage then waited out a global-memory latency) and BEFORE this stage's DMA (so that the counted
+        // end-of-stage wait covers them)
+        if (wpix && st + 1 < nstage) wnext_r = wload_raw(n_next);
+        if constexpr (C::LUT) { if (st + 1 < nstage) tbn = P.lut_rx[ipx + Ilut * n_next]; }
+        if (dma_now) dma_go((buf + NBUF - 1) % NBUF);            // lands during the next NBUF-1 stages
         timer.mark(1);
         if constexpr (C::F64) {
             if (k == 0) {                              // new transmit block: refresh the block residuals (cold: once per N stages)
