@@ -387,6 +387,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         eligible = false; why = "tiled kernel: N + M too large for the LDS header";
     }
     if (eligible && (z.T < 8)) { eligible = false; why = "tiled kernel needs T >= 8"; }
+    // (a lane keeps its pixel's offset in the plan's slab in 32 bits, 0xffffffff = "not mine": das_tile_impl.h Tile::pofs)
+    if (eligible && pl->i_count >= 0xffffffffull) { eligible = false; why = "tiled kernel: more than 2^32 - 2 pixels in one plan (shard the image)"; }
     {   // LDS-DMA offsets are 32-bit and signed: inside one transmit block, N receivers + mb transmits + a window must stay below
         // 2^31 bytes.  The reciprocal kernel re-bases its descriptors whenever a running offset reaches 2^30 (its mirror traces
         // walk the whole frame), so there only one trace stride and the span of a block have to stay below 2^30.
