@@ -1,5 +1,7 @@
 // das_tile_cfg.h -- launch configurations of the tiled kernel, shared by its translation units (internal).
 #pragma once
+// elements per pass of the prologue's tile-wide reductions (LDS scratch = 2 * waves * min(max(N, M), chunk) floats, aliasing the windows)
+#define QDAS_PROLOGUE_CHUNK 512u
 namespace qdas {
 // ------------------------------------------------------------------------------------------
 // Launch configurations.  cfg 0: 16-wave workgroup = 64 x 16 pixel tile, 32 transmits per stage, 2 window buffers, one

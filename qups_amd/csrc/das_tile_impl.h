@@ -262,7 +262,8 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
     PvL   = (GT *)((unsigned char *)nrec + RECB * N);   // [4M] (virtual) sources + t0
     NvL   = PvL + 4 * M;                              // [3M] transmit normals
     act   = (uint2 *)(NvL + 3 * M);                   // [N + 1]
-    const uint32_t hdr = ((((2 * M + N) * 4 + 15) & ~15u) + RECB * N + 7 * M * GB + 8 * (N + 1) + 15) & ~15u;
+    const uint32_t actb = P.act_bytes;               // (only plans with a pixel x receiver weight pay for the stage list)
+    const uint32_t hdr = ((((2 * M + N) * 4 + 15) & ~15u) + RECB * N + 7 * M * GB + actb + 15) & ~15u;
     win = (ST *)(smem + hdr);                         // [NBUF][NW][W]
     part = (float *)(smem + hdr);                     // prologue scratch, aliases the windows
     win_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem) + hdr;
@@ -355,7 +356,9 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
     dacc[0] = dacc[1] = dacc[2] = dacc[3] = 0.0;
 #pragma unroll
     for (int f = 0; f < C::NFR; ++f) tot[f] = (v2f){0.f, 0.f};
-    wpix = !C::F64 && !C::SYM && !C::BF && !(C::FB4 && C::F32) && (QSPEC(HAS_APIX, P.apix != nullptr) || QSPEC(GEN_KIND, P.gen_kind) != 0);   // weights from an I x N array, or generated from the geometry
+    // weights from an I x N array, or generated from the geometry (fp32 frames with such a weight do not share launches: their single-frame
+    // kernel has the stage list of the active receivers instead, and the two-frame kernels have no registers for the weight bookkeeping)
+    wpix = !C::F64 && !C::SYM && !C::BF && !(C::FBX && C::F32) && (QSPEC(HAS_APIX, P.apix != nullptr) || QSPEC(GEN_KIND, P.gen_kind) != 0);
     syn = !C::SYM && !C::BF && C::F32 && QSPEC(SYN, P.syn);          // keep the stage dimension: one output plane per stage element
     fa = C::FB4 ? __builtin_amdgcn_readfirstlane(wave / C::MB) : 0;   // window sets this wave stages: (0, 1) in general; four frames: (0, 2) / (1, 3)
     fb = C::FB4 ? fa + 2 : 1;
@@ -371,14 +374,23 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
             uint32_t *flg = (uint32_t *)part;          // prologue scratch (the windows are not in use yet)
             for (uint32_t k = tid; k < (N + 31) / 32; k += C::THREADS) flg[k] = 0u;
             __syncthreads();
-            for (uint32_t n0 = n_lo; n0 < n_hi; n0 += 4) {
-                v2f w4[4];
+            if (QSPEC(GEN_KIND, P.gen_kind) != 0) {   // generated weights: arithmetic only (ONE call site of the out-of-line rule)
+                for (uint32_t n = n_lo; n < n_hi; ++n) {
+                    const v2f w = wload(n);
+                    const bool any = __ballot(!(w.x == 0.f && w.y == 0.f)) != 0ull;
+                    if (any && lane == 0) atomicOr(&flg[n >> 5], 1u << (n & 31u));
+                }
+            } else {                                   // array weights: four loads in flight
+                for (uint32_t n0 = n_lo; n0 < n_hi; n0 += 4) {
+                    wraw r4[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) w4[q] = wload(n0 + q < n_hi ? n0 + q : n_hi - 1);
+                    for (int q = 0; q < 4; ++q) r4[q] = wload_raw(n0 + q < n_hi ? n0 + q : n_hi - 1);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool any = __ballot(!(w4[q].x == 0.f && w4[q].y == 0.f)) != 0ull;
-                    if (any && lane == 0 && n0 + q < n_hi) atomicOr(&flg[(n0 + q) >> 5], 1u << ((n0 + q) & 31u));
+                    for (int q = 0; q < 4; ++q) {
+                        const v2f w = wconv(r4[q]);
+                        const bool any = __ballot(!(w.x == 0.f && w.y == 0.f)) != 0ull;
+                        if (any && lane == 0 && n0 + q < n_hi) atomicOr(&flg[(n0 + q) >> 5], 1u << ((n0 + q) & 31u));
+                    }
                 }
             }
             __syncthreads();
@@ -656,6 +668,12 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
         // pairwise (qdas_api.hip), so that no instantiation needs scratch memory
         if (fm || wt || P.apix || P.gen_kind) return hipErrorInvalidValue;
         QDAS_LAUNCH(false, false);
+    } else if constexpr (FB2 && sizeof(ST) == 8) {
+        if (P.apix || P.gen_kind) return hipErrorInvalidValue;     // (fp32 frames with a pixel x receiver weight run one per launch: qdas_api.hip)
+        if (fm && wt) QDAS_LAUNCH(true, true);
+        else if (fm)  QDAS_LAUNCH(true, false);
+        else if (wt)  QDAS_LAUNCH(false, true);
+        else          QDAS_LAUNCH(false, false);
     } else {
         if (fm && wt) QDAS_LAUNCH(true, true);
         else if (fm)  QDAS_LAUNCH(true, false);

@@ -383,7 +383,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (sym && (z.M % tile_config(dt, 1).mb != 0 || tile_lds_bytes(dt, 1, z.N, z.M) > tile_lds_limit(1))) sym = 0;
     }
     pl->tc = tile_config(dt, sym);
-    if (eligible && tile_lds_bytes(dt, sym, kN, kM) > tile_lds_limit(sym)) {
+    const int pixw = (pix_arr >= 0 || g.gen_kind) ? 1 : 0;      // a pixel x receiver weight: the tile keeps a stage list (das_tile_impl.h plan_stages)
+    if (eligible && tile_lds_bytes(dt, sym, kN, kM, 0, pixw) > tile_lds_limit(sym)) {
         eligible = false; why = "tiled kernel: N + M too large for the LDS header";
     }
     if (eligible && (z.T < 8)) { eligible = false; why = "tiled kernel needs T >= 8"; }
@@ -400,7 +401,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (sym && (uint64_t)(tile_config(dt, 1).mb + 1) * smax * data_size(dt) + slack >= (1ull << 30)) {
             sym = 0;
             pl->tc = tile_config(dt, 0);
-            if (eligible && tile_lds_bytes(dt, 0, z.N, z.M) > tile_lds_limit(0)) { eligible = false; why = "tiled kernel: N + M too large for the LDS header"; }
+            if (eligible && tile_lds_bytes(dt, 0, z.N, z.M, 0, pixw) > tile_lds_limit(0)) { eligible = false; why = "tiled kernel: N + M too large for the LDS header"; }
         }
         if (eligible && !sym && (kN * strN + (uint64_t)pl->tc.mb * strM) * data_size(dt) + slack >= (1ull << 31)) {
             // fp32, one frame per launch: the re-basing instantiation of the general kernel (launch configuration 9)
@@ -480,6 +481,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             }
             t.apix = (const unsigned char *)g.apod + a[5] * ael;
         }
+        t.act_bytes = (t.apix || t.gen_kind) ? (uint32_t)(8 * (t.N + 1)) : 0u;
         if (z.S > 0 && dt == QDAS_F64) {                // fp64 data: the same table in double (complex128 entries)
             std::vector<double> tab(2 * z.N * z.M);
             for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.0; tab[2 * k + 1] = 0.0; }
@@ -587,8 +589,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         }
         if (const char *e = getenv("QDAS_JIT_NBUF")) { const int nb = atoi(e); if (nb >= 2 && nb <= 4) k.nbuf = nb; }
         {
-            const size_t MX = t.M > t.N ? t.M : t.N;
-            const size_t hdr = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + 8 * (t.N + 1) + 15) & ~(size_t)15;   // Tile::setup
+            const size_t MX = std::min<size_t>(t.M > t.N ? t.M : t.N, QDAS_PROLOGUE_CHUNK);
+            const size_t hdr = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + t.act_bytes + 15) & ~(size_t)15;   // Tile::setup
             size_t body = (size_t)k.nbuf * k.mb * (t.sym ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
             const size_t scratch = 2 * (size_t)k.waves * MX * 4 + 1024;
             if (body < scratch) body = scratch;
@@ -600,7 +602,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; }
         else { pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel"; }
     }
-    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->jit_fn && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
+    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->jit_fn && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
     // four frames per launch: not for fp32 plans with remodulation, a weight table or a pixel x receiver weight (das_tile_impl.h launch_tile_i)
     pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr
                   || (dt == QDAS_F32 && pl->kernel == QDAS_KERNEL_TILED && (pl->tp.fmod != 0.0 || pl->tp.wtab || pl->tp.apix || pl->tp.gen_kind));
@@ -898,7 +900,7 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     if (d->w && !w_tab && !w_pix) return 1;
     if (keep && (dt != QDAS_F32 || w_tab || (w_pix && keep_tx))) return 1;
     if (d->T < 8 || d->N >= (1ull << 20) || d->M >= (1ull << 20)) return 1;
-    if (tile_lds_bytes(dt, 0, d->N > d->M ? d->N : d->M, d->N > d->M ? d->N : d->M) > tile_lds_limit(0)) return 1;
+    if (tile_lds_bytes(dt, 0, d->N > d->M ? d->N : d->M, d->N > d->M ? d->N : d->M, 0, w_pix ? 1 : 0) > tile_lds_limit(0)) return 1;
     const bool tp = d->flag & QDAS_FLAG_TPOSE;
     uint64_t strN = tp ? d->T * d->M : d->T, strM = tp ? d->T : d->T * d->N;
     uint64_t kN = d->N, kM = d->M;
@@ -919,6 +921,7 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     t.x = x; t.y = y; t.wtab = w_tab ? d->w : nullptr;
     if (w_pix) { t.apix = d->w; t.apix_real = d->w_real; }
     t.T = d->T; t.N = kN; t.M = kM;
+    t.act_bytes = t.apix ? (uint32_t)(8 * (t.N + 1)) : 0u;
     t.syn = keep ? 1 : 0;
     const uint64_t I1 = shaped ? d->I1 : (d->I1 >= d->I ? d->I : 64);
     t.I1 = I1; t.I2 = (d->I + I1 - 1) / I1; t.I3 = 1;

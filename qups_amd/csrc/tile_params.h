@@ -19,6 +19,7 @@ struct TileParams {
     int32_t gen_kind;                   // generated pixel x receiver apodization (QDAS_RXAPOD_*), exclusive with apix
     double gen_p0, gen_p1;
     const float *rxn;                   // 3 x N element normals (device)
+    uint32_t act_bytes;                 // LDS bytes of the tile's stage list: 8 * (N + 1) when a pixel x receiver weight (apix / gen_kind) is set, else 0
     uint64_t T, N, M, I1, I2, I3;
     uint64_t i_begin, i_count;
     uint64_t strN, strM;                // trace strides of x in samples: (T, T*N) or (T*M, T) when transposed

@@ -13,7 +13,10 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
     // would sit behind the stage's LDS-DMA in the in-order vmcnt queue and expose the DMA latency every stage (measured: 15 of 64 ms)
     using GT = typename C::GT;
     const GT *gPv = geo_Pv(), *gNv = geo_Nv(), *gPr = geo_Pr();
-    const uint32_t MX = M > N ? M : N;
+    // the per-wave partial extrema go through LDS scratch (aliasing the windows) in CHUNKS of PCH elements: 1000-element apertures
+    // (matrix arrays) would otherwise need more scratch than a CU has
+    constexpr uint32_t PCH = QDAS_PROLOGUE_CHUNK;
+    const uint32_t MX = (M > N ? M : N) < PCH ? (M > N ? M : N) : PCH;
     const uint64_t Ilut = P.i_begin + P.i_count;
     const bool has_st = QSPEC(HAS_ST, P.St != nullptr);
     float a_lo = INFINITY, a_hi = -INFINITY, a_ext = 0.f;            // per-thread partials of tile-wide stats
@@ -39,28 +42,30 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
     // |fp32 estimate - fp64 delay| <= ~4e-7 * (|distance*cf| + |t0*fs|), and |distance*cf| <= |a| + |t0*fs| + 1: 1e-6 is generous
     auto margin = [](float mn, float mx, float t0fs) -> float { return 1.0e-6f * (fmaxf(fabsf(mn), fabsf(mx)) + 2.0f * fabsf(t0fs) + 2.0f); };
     // (four elements per pass: independent reduction chains overlap)
-    auto minmax4 = [&](float (&v)[4], uint32_t e0, uint32_t cnt) {
+    auto minmax4 = [&](float (&v)[4], uint32_t e0, uint32_t cnt, uint32_t c0) {
         float lo[4], hi[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { lo[q] = hi[q] = (v[q] == v[q]) ? v[q] : INFINITY; }   // a NaN delay poisons the tile's extent
         wave_minmax63x4(lo, hi);
         if (lane == 63) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (e0 + q < cnt) { part[wave * MX + e0 + q] = lo[q]; part[(WAVES + wave) * MX + e0 + q] = hi[q]; }
+            for (int q = 0; q < 4; ++q) if (e0 + q < cnt) { part[wave * MX + (e0 - c0) + q] = lo[q]; part[(WAVES + wave) * MX + (e0 - c0) + q] = hi[q]; }
         }
     };
     if constexpr (!SYM) {
-        for (uint32_t m = 0; m < M; m += 4) {
+      for (uint32_t c0 = 0; c0 < M; c0 += PCH) {
+        const uint32_t c1 = c0 + PCH < M ? c0 + PCH : M;
+        for (uint32_t m = c0; m < c1; m += 4) {
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = a_est(m + q < M ? m + q : M - 1);
-            minmax4(v, m, M);
+            minmax4(v, m, c1, c0);
         }
         __syncthreads();
-        for (uint32_t m = tid; m < M; m += THREADS) {
-            float mn = part[m], mx = part[WAVES * MX + m];
+        for (uint32_t m = c0 + tid; m < c1; m += THREADS) {
+            float mn = part[m - c0], mx = part[WAVES * MX + m - c0];
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + m]); mx = fmaxf(mx, part[(WAVES + w) * MX + m]); }
+            for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + m - c0]); mx = fmaxf(mx, part[(WAVES + w) * MX + m - c0]); }
             const float dlt = margin(mn, mx, LUT ? 0.f : (float)gPv[4 * m + 3] * fs32);
             const float fl = floorf(mn - dlt) - 1.0f;        // margin: the estimate may lie above the true minimum
             const bool fin = fabsf(fl) < 1.0e9f;
@@ -70,19 +75,22 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
             a_lo = fminf(a_lo, fl); a_hi = fmaxf(a_hi, fl + e); a_ext = fmaxf(a_ext, e);
         }
         __syncthreads();
+      }
     }
-    for (uint32_t n = 0; n < N; n += 4) {
+    float b_lo = INFINITY, b_hi = -INFINITY, b_ext = 0.f;
+    for (uint32_t c0 = 0; c0 < N; c0 += PCH) {
+      const uint32_t c1 = c0 + PCH < N ? c0 + PCH : N;
+      for (uint32_t n = c0; n < c1; n += 4) {
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = b_est(n + q < N ? n + q : N - 1);
-        minmax4(v, n, N);
-    }
-    __syncthreads();
-    float b_lo = INFINITY, b_hi = -INFINITY, b_ext = 0.f;
-    for (uint32_t n = tid; n < N; n += THREADS) {
-        float mn = part[n], mx = part[WAVES * MX + n];
+        minmax4(v, n, c1, c0);
+      }
+      __syncthreads();
+      for (uint32_t n = c0 + tid; n < c1; n += THREADS) {
+        float mn = part[n - c0], mx = part[WAVES * MX + n - c0];
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + n]); mx = fmaxf(mx, part[(WAVES + w) * MX + n]); }
+        for (int w = 1; w < WAVES; ++w) { mn = fminf(mn, part[w * MX + n - c0]); mx = fmaxf(mx, part[(WAVES + w) * MX + n - c0]); }
         float t0fs = 0.f;
         if constexpr (SYM) t0fs = (float)gPv[3] * fs32;
         else if constexpr (!LUT) t0fs = has_st ? P.St[4 * n] * fs32 : 0.f;
@@ -100,8 +108,9 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
             Aext[n] = e + 1.0f;
             a_lo = fminf(a_lo, fl + (float)symCi); a_hi = fmaxf(a_hi, fl + (float)symCi + e + 1.0f); a_ext = fmaxf(a_ext, e + 1.0f);
         }
+      }
+      __syncthreads();                                 // part[] is free again
     }
-    __syncthreads();                                   // part[] is free again
     a_lo = wave_min(a_lo); b_lo = wave_min(b_lo);
     a_hi = wave_max(a_hi); b_hi = wave_max(b_hi); a_ext = wave_max(a_ext); b_ext = wave_max(b_ext);
     if (lane == 0) { float *q = part + wave * 8; q[0] = a_lo; q[1] = b_lo; q[2] = a_hi; q[3] = b_hi; q[4] = a_ext; q[5] = b_ext; }
