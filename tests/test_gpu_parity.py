@@ -534,20 +534,21 @@ def test_tiled_pixel_receiver_apodization(prec):
     assert plan.kernel == "generic" and rel_err(out, run_oracle(case, apod=(full,), x=x)) <= max(tol, TOL32)
 
 
-def test_thousand_element_apertures_stay_on_the_fused_kernel():
+@pytest.mark.parametrize("seq", ["PW", "FSA"])
+def test_thousand_element_apertures_stay_on_the_fused_kernel(seq):
     """a 32 x 32 matrix array's worth of elements on both sides (N = M = 1024, not reciprocal): the LDS header of the tile (window
     bases, receiver records, transmit tables) plus two window buffers still fit one CU; checked against the generic kernel"""
     torch = _torch()
     from qups_amd import DasPlan, build_problem, parse_options
     from qups_amd.das_spec import _colmajor
-    case = make_case(seq="PW", interp="linear", seed=41, N=1024, M=1024, I1=64, I2=16, pitch=0.05e-3, T=8, data="noise", zlim=(3e-3, 5e-3))
+    case = make_case(seq=seq, interp="linear", seed=41, N=1024, M=1024, I1=64, I2=16, pitch=0.05e-3, T=8, data="noise", zlim=(3e-3, 5e-3))
     g0 = torch.Generator(device="cuda").manual_seed(41)                    # (160 x 1024 x 1024 samples: drawn on the device)
     xt = torch.view_as_complex(torch.randn((160, 1024, 1024, 2), generator=g0, device="cuda", dtype=torch.float32))
     po = parse_options(xt, list(case["opt"]) + ["interp", "linear"])
     prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], po)
     xc = _colmajor(xt)
     tiled = DasPlan(prob, kernel=2)
-    assert tiled.kernel == "tiled"
+    assert tiled.kernel == "tiled" and tiled.reciprocal == (seq == "FSA")
     y = tiled.execute_colmajor(xc).cpu().numpy()
     g = DasPlan(prob, kernel=1).execute_colmajor(xc).cpu().numpy()
     # white noise and 10^6 pairs per pixel, a record that ends inside the image: the edge rule is a step in tau, so a pair within
