@@ -42,6 +42,18 @@ def workload(name: str) -> dict:
         Pi = G.scan_cartesian(x, z)
         t0 = -10e-3 / c0                                                 # steered waves reach the near corners before t = 0
         label = "C2: 128-el, 128 plane waves, 512x512 ScanCartesian lambda/4, T=2048, complex64, cubic"
+    elif name.startswith("pw"):   # "pw9": the C2 setup with a handful of plane waves (ultrafast compounding: what a kHz-rate scanner beamforms)
+        M = int(name[2:] or 9)
+        fc, N, pitch, nx, nz, T, interp = 5e6, 128, 0.3e-3, 512, 512, 2048, "cubic"
+        lam = c0 / fc
+        Pr, nrm = G.linear_array(N, pitch)
+        th = np.deg2rad(np.linspace(-12, 12, M))
+        Pv, Nv, opt = G.sequence_args("PW", focus=np.stack([np.sin(th), 0 * th, np.cos(th)]))
+        x = (np.arange(nx) - (nx - 1) / 2) * lam / 4
+        z = 2e-3 + np.arange(nz) * lam / 4
+        Pi = G.scan_cartesian(x, z)
+        t0 = -10e-3 / c0
+        label = f"PW{M}: 128-el, {M} plane waves, 512x512 ScanCartesian lambda/4, T=2048, complex64, cubic"
     elif name == "c3":    # 256 el FSA, 1024^2, lanczos3 (README headline)
         fc, N, pitch, nx, nz, T, interp = 5e6, 256, 0.2e-3, 1024, 1024, 2816, "lanczos3"
         lam = c0 / fc

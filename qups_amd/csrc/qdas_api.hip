@@ -338,8 +338,6 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // fp64 data (das_tile_impl.h "F64"): the plain sum with pixel-independent weights, scalar sound speed, no remodulation
     if (eligible && dt == QDAS_F64 && desc->fmod != 0.0) { eligible = false; why = "tiled kernel, fp64 data: remodulation needs the generic kernel"; }
     if (eligible && dt == QDAS_F64 && desc->rx_apod_kind) { eligible = false; why = "tiled kernel, fp64 data: a generated receive apodization needs the generic kernel"; }
-    // stage / block element counts of the kernel (das_tile_impl.h): receivers / transmits, swapped for 'MUL'
-    const uint64_t kN = mul ? z.M : z.N, kM = mul ? z.N : z.M;
     // sound speed: a scalar, or a full per-pixel map (contiguous I1 x I2 x I3, no aperture dependence): the delay stays separable
     bool cmap = false;
     if (eligible && (g.cst[0] || g.cst[1] || g.cst[2] || g.cst[3] || g.cst[4])) {
@@ -382,6 +380,16 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             if (memcmp(&hv[4 * m], &hr[3 * m], 12) != 0 || memcmp(&hv[4 * m + 3], &hv[3], 4) != 0) sym = 0;
         if (sym && (z.M % tile_config(dt, 1).mb != 0 || tile_lds_bytes(dt, 1, z.N, z.M) > tile_lds_limit(1))) sym = 0;
     }
+    // Roles of the two apertures (das_tile_impl.h): a stage = one STAGE element x a block of 32 BLOCK elements.  'DAS' / 'SYN': stage =
+    // receiver, block = transmits; 'MUL': swapped.  The full sum may run either way, and runs swapped when that gives fewer, fuller
+    // stages: plane-wave compounding with a handful of angles (N = 128, M = 9: 128 stages of 9 transmits -> 36 stages of 32 receivers).
+    bool swap = mul;
+    if (eligible && !syn && !bfm && !sym && dt != QDAS_F64 && pix_arr < 0 && !g.gen_kind && !getenv("QDAS_NO_ROLE_SWAP")) {
+        const uint64_t mb = (uint64_t)tile_config(dt, 0).mb;
+        if (4 * z.M * ((z.N + mb - 1) / mb) < 3 * z.N * ((z.M + mb - 1) / mb)) swap = true;     // (at least a quarter fewer stages: measured break-even, PW31 on 128 elements)
+    }
+    // stage / block element counts of the kernel: receivers / transmits, or swapped
+    const uint64_t kN = swap ? z.M : z.N, kM = swap ? z.N : z.M;
     pl->tc = tile_config(dt, sym);
     const int pixw = (pix_arr >= 0 || g.gen_kind) ? 1 : 0;      // a pixel x receiver weight: the tile keeps a stage list (das_tile_impl.h plan_stages)
     if (eligible && tile_lds_bytes(dt, sym, kN, kM, 0, pixw) > tile_lds_limit(sym)) {
@@ -395,7 +403,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // walk the whole frame), so there only one trace stride and the span of a block have to stay below 2^30.
         uint64_t strM = (z.flag & QDAS_FLAG_TPOSE) ? z.T : z.T * z.N;
         uint64_t strN = (z.flag & QDAS_FLAG_TPOSE) ? z.T * z.M : z.T;
-        if (mul) std::swap(strM, strN);
+        if (swap) std::swap(strM, strN);
         const uint64_t slack = 65536;
         const uint64_t smax = strM > strN ? strM : strN;
         if (sym && (uint64_t)(tile_config(dt, 1).mb + 1) * smax * data_size(dt) + slack >= (1ull << 30)) {
@@ -422,7 +430,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         t.strM = tp ? z.T : z.T * z.N;
         const int txkind = z.VS ? (z.DV ? 0 : 1) : 2;   // distance | signed distance | plane wave
         t.kindB = txkind; t.kindS = 0;
-        if (mul) {                                      // roles swapped: stage elements = transmits, block elements = receivers
+        if (swap) {                                     // roles swapped: stage elements = transmits, block elements = receivers
             std::vector<float> hr(3 * z.N), hv(4 * z.M), hn(3 * z.M);
             if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
             if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);
@@ -520,7 +528,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
                         if (desc->apod_real) ar = dt == QDAS_F32 ? ((const float *)raw.data())[k] : half_to_float(((const uint16_t *)raw.data())[k]);
                         else if (dt == QDAS_F32) { ar = ((const float *)raw.data())[2 * k]; ai = ((const float *)raw.data())[2 * k + 1]; }
                         else { ar = half_to_float(((const uint16_t *)raw.data())[2 * k]); ai = half_to_float(((const uint16_t *)raw.data())[2 * k + 1]); }
-                        const size_t q = mul ? (m + z.M * n) : (n + z.N * m);        // [stage element + stages * block element]
+                        const size_t q = swap ? (m + z.M * n) : (n + z.N * m);       // [stage element + stages * block element]
                         float &tr = tab[2 * q], &ti = tab[2 * q + 1];
                         const float nr = tr * ar - ti * ai, ni = tr * ai + ti * ar;
                         tr = nr; ti = ni;
@@ -652,8 +660,8 @@ extern "C" int qdas_plan_kernel_name(const qdas_plan *pl, char *buf, size_t len)
     const char *dts = z.dtype == QDAS_F64 ? "f64" : (z.dtype == QDAS_F32 ? "f32" : "f16");
     if (pl->kernel == QDAS_KERNEL_TILED) {
         const TileParams &t = pl->tp;
-        snprintf(buf, len, "das_tile_kernel<interp=%d,%s%s%s%s%s,mb=%d,W=%d> [%s]", z.flag & 7, dts, t.sym ? ",sym" : "", t.fmod != 0.0 ? ",fmod" : "",
-                 t.wtab ? ",wtab" : "", t.big ? ",big" : "", pl->jit_fn ? pl->jit_mb : pl->tc.mb, pl->tc.window, pl->jit_tag.empty() ? "prebuilt" : pl->jit_tag.c_str());
+        snprintf(buf, len, "das_tile_kernel<interp=%d,%s%s%s%s%s%s,mb=%d,W=%d> [%s]", z.flag & 7, dts, t.sym ? ",sym" : "", t.fmod != 0.0 ? ",fmod" : "",
+                 t.wtab ? ",wtab" : "", t.big ? ",big" : "", (t.St && !t.syn) ? ",roles swapped" : "", pl->jit_fn ? pl->jit_mb : pl->tc.mb, pl->tc.window, pl->jit_tag.empty() ? "prebuilt" : pl->jit_tag.c_str());
     } else snprintf(buf, len, "das_generic_kernel<interp=%d,%s>", z.flag & 7, dts);
     return QDAS_OK;
 }

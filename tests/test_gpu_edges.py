@@ -156,7 +156,7 @@ def test_host_resident_inputs_through_the_c_abi(F, seq):
 
 
 @pytest.mark.parametrize("kernel,tpose", [(2, False), (1, False), (2, True)])
-def test_channel_data_larger_than_4_GiB(kernel, tpose):
+def test_channel_data_larger_than_4_GiB(kernel, tpose, monkeypatch):
     """64-bit addressing: a 4.4 GB acquisition whose only non-zero traces lie behind the 4 GiB mark must beamform exactly like
     the small acquisition made of those transmits alone (both kernels; the tiled kernel's DMA descriptors are per transmit block).
     Transposed data of more than 2 GiB has receiver strides beyond the 32-bit DMA offsets of one descriptor: the plan picks the
@@ -164,6 +164,7 @@ def test_channel_data_larger_than_4_GiB(kernel, tpose):
     import torch
     from qups_amd import das_spec
     from qups_amd import geometry as G
+    monkeypatch.setenv("QDAS_NO_ROLE_SWAP", "1")                          # (the 8-transmit twin would otherwise run with the apertures' roles swapped: another summation order)
     T, N, M, Ml = 4096, 256, 520, 8                                       # 4096 * 256 * 520 * 8 B = 4.36 GB
     fc, c0 = 5e6, 1540.0
     fs = 4 * fc

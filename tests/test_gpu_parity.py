@@ -534,6 +534,29 @@ def test_tiled_pixel_receiver_apodization(prec):
     assert plan.kernel == "generic" and rel_err(out, run_oracle(case, apod=(full,), x=x)) <= max(tol, TOL32)
 
 
+@pytest.mark.parametrize("seq,prec", [("PW", "single"), ("DV", "halfT"), ("FC", "single")])
+def test_full_sum_with_few_transmits_swaps_the_roles_of_the_apertures(seq, prec, monkeypatch):
+    """plane-wave compounding with a handful of angles: the 'DAS' sum runs with stage = transmit, block = 32 receivers (fewer, fuller
+    stages) -- same image as with the usual roles, weights and per-transmit t0 included"""
+    rng = np.random.default_rng(3)
+    case = make_case(seq=seq, interp="cubic", seed=23, N=48, M=5, I1=130, I2=21)
+    x = case["x"]
+    q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else f32r
+    if prec == "halfT":
+        x = x.real.astype(np.float16).astype(np.float64) + 1j * x.imag.astype(np.float16).astype(np.float64)
+    wn = q(rng.uniform(0.3, 1, (1, 1, 1, 48, 1)))
+    wm = q(rng.uniform(0.3, 1, (1, 1, 1, 1, 5)))
+    t0 = (case["t0"] + np.float32(1.0 / case["fs"]) * rng.integers(-2, 3, (1, 1, 5))).astype(np.float32).astype(np.float64)
+    ref = run_oracle(case, apod=(wn, wm), x=x, t0=t0)
+    out, plan = run_das(case, kernel=2, prec=prec, apod=(wn, wm), t0=t0)
+    assert plan.kernel == "tiled" and "roles swapped" in plan.kernel_name(), plan.kernel_name()
+    tol = (2e-5 if prec == "single" else 2e-3) if seq != "FC" else 1e-4
+    assert rel_err(out, ref) <= tol
+    monkeypatch.setenv("QDAS_NO_ROLE_SWAP", "1")
+    out2, plan2 = run_das(case, kernel=2, prec=prec, apod=(wn, wm), t0=t0)
+    assert "roles swapped" not in plan2.kernel_name() and rel_err(out2, out) <= tol
+
+
 @pytest.mark.parametrize("seq", ["PW", "FSA"])
 def test_thousand_element_apertures_stay_on_the_fused_kernel(seq):
     """a 32 x 32 matrix array's worth of elements on both sides (N = M = 1024, not reciprocal): the LDS header of the tile (window
