@@ -347,14 +347,18 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     }
     // apodization arrays: pixel-independent ones fold into an N x M table; ONE array may be a full I1 x I2 x I3 x [N] array
     // (contiguous pixel strides, no transmit dependence) -- it is applied per (pixel, receiver) by the tiled kernel
+    // A full I1 x I2 x I3 x 1 x M array -- a weight per (pixel, TRANSMIT): scanline / multiline / parallelogram transmit apodization of
+    // focused sequences -- is the same thing with the roles of the apertures swapped (stage element = transmit): 'DAS' only.
     int pix_arr = -1;
+    bool pix_is_tx = false;
     for (uint64_t s = 0; s < z.S && eligible; ++s) {
         const uint64_t *a = &g.ast[6 * s];
         if (!a[0] && !a[1] && !a[2]) continue;
         const uint64_t I = z.I1 * z.I2 * z.I3;
-        const bool full = (a[0] == 1 || z.I1 == 1) && (a[1] == z.I1 || z.I2 == 1) && (a[2] == z.I1 * z.I2 || z.I3 == 1)
-                          && (a[3] == I || a[3] == 0) && a[4] == 0 && (a[3] == I || z.N == 1 || a[3] == 0);
-        if (a[3] == 0 && z.N > 1) { eligible = false; why = "tiled kernel: a pixel-only apodization array needs the generic kernel"; }
+        const bool pixstr = (a[0] == 1 || z.I1 == 1) && (a[1] == z.I1 || z.I2 == 1) && (a[2] == z.I1 * z.I2 || z.I3 == 1);
+        const bool full = pixstr && (a[3] == I || a[3] == 0) && a[4] == 0 && (a[3] == I || z.N == 1 || a[3] == 0);
+        if (pixstr && a[3] == 0 && a[4] == I && z.M > 1 && pix_arr < 0 && !syn && !bfm && dt != QDAS_F64) { pix_arr = (int)s; pix_is_tx = true; }
+        else if (a[3] == 0 && z.N > 1) { eligible = false; why = "tiled kernel: a pixel-only apodization array needs the generic kernel"; }
         else if (!full || pix_arr >= 0) { eligible = false; why = "tiled kernel: at most one apodization array may depend on the pixel (I x [N], no transmit dependence)"; }
         else if (dt == QDAS_F64) { eligible = false; why = "tiled kernel, fp64 data: a pixel-dependent apodization array needs the generic kernel"; }
         else pix_arr = (int)s;
@@ -383,7 +387,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // Roles of the two apertures (das_tile_impl.h): a stage = one STAGE element x a block of 32 BLOCK elements.  'DAS' / 'SYN': stage =
     // receiver, block = transmits; 'MUL': swapped.  The full sum may run either way, and runs swapped when that gives fewer, fuller
     // stages: plane-wave compounding with a handful of angles (N = 128, M = 9: 128 stages of 9 transmits -> 36 stages of 32 receivers).
-    bool swap = mul;
+    bool swap = mul || pix_is_tx;
     if (eligible && !syn && !bfm && !sym && dt != QDAS_F64 && pix_arr < 0 && !g.gen_kind && !getenv("QDAS_NO_ROLE_SWAP")) {
         const uint64_t mb = (uint64_t)tile_config(dt, 0).mb;
         if (4 * z.M * ((z.N + mb - 1) / mb) < 3 * z.N * ((z.M + mb - 1) / mb)) swap = true;     // (at least a quarter fewer stages: measured break-even, PW31 on 128 elements)
@@ -484,7 +488,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         t.gen_kind = g.gen_kind; t.gen_p0 = g.gen_p0; t.gen_p1 = g.gen_p1; t.rxn = (const float *)g.rxn;
         if (pix_arr >= 0) {
             const uint64_t *a = &g.ast[6 * pix_arr];
-            if (a[3] == 0 && z.N > 1) {                 // I-only array: no receiver dependence -> cannot index by n; use the generic kernel
+            if (a[3] == 0 && z.N > 1 && !pix_is_tx) {   // I-only array: no receiver dependence -> cannot index by n; use the generic kernel
                 return bail(fail(QDAS_EUNSUPPORTED, "internal: pixel-only apodization reached the tiled path"));
             }
             t.apix = (const unsigned char *)g.apod + a[5] * ael;

@@ -38,6 +38,8 @@ def _draw(seed):
     cfg.update(extra)
     if r.integers(0, 8) == 0 and not extra["sym"] and cfg["fun"] != "BF":   # fp64 data on the fused kernel: plain 'DAS', pixel-independent weights
         cfg.update(prec="double", fmod=0.0, wpix=False, gen="", fun="DAS", cmap=False, jit=False)
+    # a pixel x TRANSMIT weight (scanline-style transmit apodization): fused with the roles of the apertures swapped
+    cfg["wpm"] = bool(r.integers(0, 10) == 0) and cfg["fun"] == "DAS" and not cfg["wpix"] and not cfg["gen"] and not cfg["sym"] and cfg["prec"] != "double"
     if os.environ.get("QDAS_FUZZ_OVERRIDE"):                            # debugging aid: JSON dict of fields to force
         import json
         cfg.update(json.loads(os.environ["QDAS_FUZZ_OVERRIDE"]))
@@ -77,6 +79,10 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
     if c["wpix"] and N > 1:
         a = q(r.uniform(0, 1, (c["I1"], c["I2"], 1, N, 1)) > 0.4)
         a[: c["I1"] // 3] = 0.0
+        apod.append(a)
+    if c["wpm"] and M > 1:
+        a = q(r.uniform(0, 1, (c["I1"], c["I2"], 1, 1, M)) > 0.5)
+        a[c["I1"] // 2:, :, :, :, 0] = 0.0
         apod.append(a)
     fun = c["fun"] if c["prec"] == "single" else "DAS"                # 'SYN' / 'MUL' are fused for fp32 data only
     if fun in ("MUL", "BF") and ((c["wpix"] and N > 1) or c["gen"]):

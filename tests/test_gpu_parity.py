@@ -557,6 +557,29 @@ def test_full_sum_with_few_transmits_swaps_the_roles_of_the_apertures(seq, prec,
     assert "roles swapped" not in plan2.kernel_name() and rel_err(out2, out) <= tol
 
 
+@pytest.mark.parametrize("prec", ["single", "halfT"])
+def test_pixel_by_transmit_apodization_runs_fused_with_swapped_roles(prec):
+    """a weight per (pixel, transmit) -- the scanline / multiline / parallelogram transmit apodization of focused sequences, I1 x I2 x 1 x 1 x M
+    (reference src/UltrasoundSystem.m:4892-5074) -- is a pixel x stage-element weight once the transmit is the stage element: fused kernel,
+    stage list of the transmits that matter to the tile; plus a receive window (pixel-independent)"""
+    rng = np.random.default_rng(12)
+    case = make_case(seq="FC", interp="cubic", seed=29, N=32, M=12, I1=140, I2=36, xspan=5e-3)
+    x = case["x"]
+    q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else f32r
+    if prec == "halfT":
+        x = x.real.astype(np.float16).astype(np.float64) + 1j * x.imag.astype(np.float16).astype(np.float64)
+    col = np.arange(36)[None, :, None, None, None]
+    mm = np.arange(12)[None, None, None, None, :]
+    scan = (np.abs(col / 3.0 - mm) <= 1.0) * q(rng.uniform(0.5, 1.0, (140, 36, 1, 1, 12)))      # each image column listens to its 2-3 nearest transmits
+    wn = q(np.hanning(34)[1:-1]).reshape(1, 1, 1, 32, 1)
+    ref = run_oracle(case, apod=(scan, wn), x=x)
+    out, plan = run_das(case, kernel=2, prec=prec, apod=(scan, wn))
+    assert plan.kernel == "tiled" and "roles swapped" in plan.kernel_name(), plan.kernel_name()
+    assert rel_err(out, ref) <= (1e-4 if prec == "single" else 2e-3)
+    gen, gplan = run_das(case, kernel=1, prec=prec, apod=(scan, wn))
+    assert rel_err(out, gen) <= (2e-4 if prec == "single" else 3e-3)
+
+
 @pytest.mark.parametrize("seq", ["PW", "FSA"])
 def test_thousand_element_apertures_stay_on_the_fused_kernel(seq):
     """a 32 x 32 matrix array's worth of elements on both sides (N = M = 1024, not reciprocal): the LDS header of the tile (window
