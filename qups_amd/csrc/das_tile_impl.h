@@ -329,7 +329,7 @@ template <class C> __device__ __forceinline__ typename Tile<C>::wraw Tile<C>::wl
         const float4 e = nrec[n];
         return wraw{__float_as_uint(rx_apod_generated(gen_kind, P.gen_p0, P.gen_p1, px, py, pz, e.y, e.z, e.w, P.rxn, n)), 0u};
     }
-    const uint64_t k = ipx + P.I1 * P.I2 * P.I3 * n;
+    const uint64_t k = ipx + (P.apix_pixel_only ? 0ull : P.I1 * P.I2 * P.I3 * n);
     if (QSPEC(APIX_REAL, P.apix_real)) {
         if constexpr (C::F32) return wraw{((const uint32_t *)P.apix)[k], 0u};
         else return wraw{(uint32_t)((const unsigned short *)P.apix)[k], 0u};

@@ -350,7 +350,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // A full I1 x I2 x I3 x 1 x M array -- a weight per (pixel, TRANSMIT): scanline / multiline / parallelogram transmit apodization of
     // focused sequences -- is the same thing with the roles of the apertures swapped (stage element = transmit): 'DAS' only.
     int pix_arr = -1;
-    bool pix_is_tx = false;
+    bool pix_is_tx = false, pix_only = false;
     for (uint64_t s = 0; s < z.S && eligible; ++s) {
         const uint64_t *a = &g.ast[6 * s];
         if (!a[0] && !a[1] && !a[2]) continue;
@@ -358,6 +358,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         const bool pixstr = (a[0] == 1 || z.I1 == 1) && (a[1] == z.I1 || z.I2 == 1) && (a[2] == z.I1 * z.I2 || z.I3 == 1);
         const bool full = pixstr && (a[3] == I || a[3] == 0) && a[4] == 0 && (a[3] == I || z.N == 1 || a[3] == 0);
         if (pixstr && a[3] == 0 && a[4] == I && z.M > 1 && pix_arr < 0 && !syn && !bfm && dt != QDAS_F64) { pix_arr = (int)s; pix_is_tx = true; }
+        else if (pixstr && a[3] == 0 && a[4] == 0 && pix_arr < 0 && !bfm && !mul && dt != QDAS_F64) { pix_arr = (int)s; pix_only = true; }   // a spatial weight / ROI mask
         else if (a[3] == 0 && z.N > 1) { eligible = false; why = "tiled kernel: a pixel-only apodization array needs the generic kernel"; }
         else if (!full || pix_arr >= 0) { eligible = false; why = "tiled kernel: at most one apodization array may depend on the pixel (I x [N], no transmit dependence)"; }
         else if (dt == QDAS_F64) { eligible = false; why = "tiled kernel, fp64 data: a pixel-dependent apodization array needs the generic kernel"; }
@@ -488,11 +489,12 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         t.gen_kind = g.gen_kind; t.gen_p0 = g.gen_p0; t.gen_p1 = g.gen_p1; t.rxn = (const float *)g.rxn;
         if (pix_arr >= 0) {
             const uint64_t *a = &g.ast[6 * pix_arr];
-            if (a[3] == 0 && z.N > 1 && !pix_is_tx) {   // I-only array: no receiver dependence -> cannot index by n; use the generic kernel
+            if (a[3] == 0 && z.N > 1 && !pix_is_tx && !pix_only) {   // I-only array: no receiver dependence -> cannot index by n; use the generic kernel
                 return bail(fail(QDAS_EUNSUPPORTED, "internal: pixel-only apodization reached the tiled path"));
             }
             t.apix = (const unsigned char *)g.apod + a[5] * ael;
         }
+        t.apix_pixel_only = pix_only ? 1 : 0;
         t.act_bytes = (t.apix || t.gen_kind) ? (uint32_t)(8 * (t.N + 1)) : 0u;
         if (z.S > 0 && dt == QDAS_F64) {                // fp64 data: the same table in double (complex128 entries)
             std::vector<double> tab(2 * z.N * z.M);

@@ -16,6 +16,7 @@ struct TileParams {
     const void *wtab;                   // optional N x M table of folded apodization weights (float2), may be null
     const void *apix;                   // optional I x N apodization (data precision; real if apix_real), may be null
     int32_t apix_real;
+    int32_t apix_pixel_only;            // the array is I1 x I2 x I3 only (a spatial weight / region-of-interest mask): the same entry for every stage element
     int32_t gen_kind;                   // generated pixel x receiver apodization (QDAS_RXAPOD_*), exclusive with apix
     double gen_p0, gen_p1;
     const float *rxn;                   // 3 x N element normals (device)

@@ -557,6 +557,26 @@ def test_full_sum_with_few_transmits_swaps_the_roles_of_the_apertures(seq, prec,
     assert "roles swapped" not in plan2.kernel_name() and rel_err(out2, out) <= tol
 
 
+@pytest.mark.parametrize("fun,prec", [("DAS", "single"), ("DAS", "halfT"), ("SYN", "single")])
+def test_pixel_only_weights_run_fused(fun, prec):
+    """an I1 x I2 weight (a region-of-interest mask, a spatial gain): the same entry for every stage element; tiles outside the region of
+    interest have an empty stage list and cost a prologue"""
+    rng = np.random.default_rng(14)
+    case = make_case(seq="PW", interp="linear", seed=33, N=24, M=7, I1=150, I2=40, xspan=6e-3)
+    x = case["x"]
+    q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else f32r
+    if prec == "halfT":
+        x = x.real.astype(np.float16).astype(np.float64) + 1j * x.imag.astype(np.float16).astype(np.float64)
+    roi = q(rng.uniform(0.5, 2.0, (150, 40, 1, 1, 1)))
+    roi[:70, :] = 0.0                                                   # (whole tiles of the shallow half)
+    roi[:, 30:] = 0.0
+    ref = run_oracle(case, fun=fun, apod=(roi,), x=x)
+    out, plan = run_das(case, fun=fun, kernel=2, prec=prec, apod=(roi,))
+    assert plan.kernel == "tiled", plan.kernel_name()
+    assert rel_err(out, ref) <= (2e-5 if prec == "single" else 2e-3)
+    assert np.all(out[:70] == 0) and np.all(out[:, 30:] == 0)
+
+
 @pytest.mark.parametrize("prec", ["single", "halfT"])
 def test_pixel_by_transmit_apodization_runs_fused_with_swapped_roles(prec):
     """a weight per (pixel, transmit) -- the scanline / multiline / parallelogram transmit apodization of focused sequences, I1 x I2 x 1 x 1 x M
