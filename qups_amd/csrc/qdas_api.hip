@@ -911,16 +911,26 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     // data precision, real or complex (wstride {1, I, 0}), which the kernel applies per stage like the plans' pixel x receiver arrays
     const bool w_tab = d->w && d->wstride[0] == 0 && !d->w_real && dt == QDAS_F32 && d->wstride[1] == 1 && d->wstride[2] == d->N;
     const bool w_pix = d->w && !w_tab && d->wstride[0] == 1 && d->wstride[1] == d->I && d->wstride[2] == 0 && d->N > 1;
-    if (d->w && !w_tab && !w_pix) return 1;
+    // ... or an I x M array (a weight per pixel and TRANSMIT: scanline-style transmit apodization): the same with the roles of the two
+    // tables swapped (full sum only)
+    const bool w_pixm = d->w && !w_tab && !w_pix && !keep && d->wstride[0] == 1 && d->wstride[1] == 0 && d->wstride[2] == d->I && d->M > 1;
+    if (d->w && !w_tab && !w_pix && !w_pixm) return 1;
     if (keep && (dt != QDAS_F32 || w_tab || (w_pix && keep_tx))) return 1;
     if (d->T < 8 || d->N >= (1ull << 20) || d->M >= (1ull << 20)) return 1;
-    if (tile_lds_bytes(dt, 0, d->N > d->M ? d->N : d->M, d->N > d->M ? d->N : d->M, 0, w_pix ? 1 : 0) > tile_lds_limit(0)) return 1;
+    if (tile_lds_bytes(dt, 0, d->N > d->M ? d->N : d->M, d->N > d->M ? d->N : d->M, 0, (w_pix || w_pixm) ? 1 : 0) > tile_lds_limit(0)) return 1;
     const bool tp = d->flag & QDAS_FLAG_TPOSE;
     uint64_t strN = tp ? d->T * d->M : d->T, strM = tp ? d->T : d->T * d->N;
     uint64_t kN = d->N, kM = d->M;
     const void *tab_s = d->tau_rx, *tab_b = d->tau_tx;                // stage / block tables
-    if (keep_tx) { std::swap(strN, strM); std::swap(kN, kM); std::swap(tab_s, tab_b); }
     const TileConfig tc = tile_config(dt, 0);
+    // roles of the two tables: stage = receive table unless the transmit dimension is kept, the weights are per (pixel, transmit), or -- full
+    // sum without pixel weights -- swapping leaves at least a quarter fewer stages (few transmits: qdas_plan_create has the same rule)
+    bool swap = keep_tx || w_pixm;
+    if (!keep && !w_pix && !w_pixm && !w_tab && !getenv("QDAS_NO_ROLE_SWAP")) {      // (an N x M weight table is laid out for the usual roles)
+        const uint64_t mb = (uint64_t)tc.mb;
+        if (4 * d->M * ((d->N + mb - 1) / mb) < 3 * d->N * ((d->M + mb - 1) / mb)) swap = true;
+    }
+    if (swap) { std::swap(strN, strM); std::swap(kN, kM); std::swap(tab_s, tab_b); }
     if ((kN * strN + (uint64_t)tc.mb * strM) * data_size(dt) + 65536 >= (1ull << 31)) return 1;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1;
@@ -930,10 +940,10 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     if (hipMallocAsync((void **)&counter, 64, s) != hipSuccess || !counter) return 1;
     struct CounterGuard { uint32_t *p; hipStream_t s; ~CounterGuard() { (void)hipFreeAsync(p, s); } } guard{counter, s};
     const bool shaped = d->I1 && d->I1 < d->I && d->I % d->I1 == 0;    // (a per-pixel array needs the true image shape: no ragged rows)
-    if (w_pix && !shaped && d->I1 != d->I) return 1;
+    if ((w_pix || w_pixm) && !shaped && d->I1 != d->I) return 1;
     TileParams t{};
     t.x = x; t.y = y; t.wtab = w_tab ? d->w : nullptr;
-    if (w_pix) { t.apix = d->w; t.apix_real = d->w_real; }
+    if (w_pix || w_pixm) { t.apix = d->w; t.apix_real = d->w_real; }
     t.T = d->T; t.N = kN; t.M = kM;
     t.act_bytes = t.apix ? (uint32_t)(8 * (t.N + 1)) : 0u;
     t.syn = keep ? 1 : 0;

@@ -196,6 +196,42 @@ def test_das_lut_receive_apodization_array_on_the_fused_kernel(prec, real, keep_
     assert not np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("prec,wkind", [("single", "pixm"), ("halfT", "pixm"), ("single", "none")])
+def test_das_lut_with_swapped_tables(prec, wkind, monkeypatch):
+    """the split-delay flavour with the two tables trading places in a full sum: a weight per (pixel, TRANSMIT) -- I1 x I2 x 1 x M, scanline-style
+    transmit apodization -- applied per stage with the transmit as the stage element; and, without weights, few transmits against many
+    receivers (fewer, fuller stages).  Oracle + the one-thread-per-pixel kernel."""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import das_lut
+    case = make_case(seq="FC", interp="cubic", seed=37, N=40, M=6, I1=130, I2=24, data="noise")
+    N, M = case["N"], case["M"]
+    dv, dr = O.tx_rx_distances(case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["VS"], case["DV"])
+    c = cinv_f32(case["c"])
+    f32 = lambda a: np.asarray(a, np.float32).astype(np.float64)
+    tau_tx = f32((dv[:, :, :, 0, :] / c - case["t0"]) * case["fs"])[:, :, 0]
+    tau_rx = f32(dr[:, :, :, :, 0] / c * case["fs"])[:, :, 0]
+    rng = np.random.default_rng(6)
+    q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else (lambda a: a.astype(np.float32).astype(np.float64))
+    x = case["x"]
+    if prec == "halfT":
+        x = (x.real.astype(np.float16).astype(np.float32) + 1j * x.imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
+    w, apod = None, ()
+    if wkind == "pixm":
+        w = q(rng.uniform(0, 1, (130, 24, 1, M)) * (rng.uniform(0, 1, (130, 24, 1, M)) > 0.4))
+        apod = (w.reshape(130, 24, 1, 1, M).astype(np.complex128),)
+    ref = np.asarray(O.das_lut(x, tau_rx[:, :, None] / case["fs"], tau_tx[:, :, None] / case["fs"], 0.0, case["fs"], interp="cubic", apod=apod)).reshape(130, 24)
+    wt = None if w is None else torch.from_numpy(w.astype(np.float32))
+    run = lambda: _np(das_lut(torch.from_numpy(x), tau_rx, tau_tx, interp="cubic", w=wt, prec=prec).to(torch.complex64)).reshape(130, 24)
+    monkeypatch.delenv("QDAS_LUT_GENERIC", raising=False)
+    a = run()
+    monkeypatch.setenv("QDAS_LUT_GENERIC", "1")
+    b = run()
+    tol = 3e-3 if prec == "halfT" else 1e-4
+    assert rel_err(a, ref) <= tol and rel_err(a, b) <= tol
+    assert not np.array_equal(a, b)                              # two different kernels did run
+
+
 @pytest.mark.parametrize("keep", ["rx", "tx"])
 @pytest.mark.parametrize("seq,interp,tpose,fm", [("FSA", "cubic", False, 0.0), ("PW", "lanczos3", True, 2e6), ("FC", "linear", False, 0.0)])
 def test_das_lut_one_kept_dimension_on_the_fused_kernel(keep, seq, interp, tpose, fm, monkeypatch):
