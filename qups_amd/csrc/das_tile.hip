@@ -42,6 +42,14 @@ hipError_t launch_tile_bf(const TileParams &P, unsigned ntiles, size_t lds, hipS
 hipError_t launch_tile_f64(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 
 // y[i] = sum over the ksplit partial images, in split order (deterministic)
+// (fp64 data: complex128 partial images)
+__global__ void __launch_bounds__(256) tile_reduce_kernel_f64(const double2 *part, double2 *y, uint64_t count, uint32_t ksplit) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double2 a = part[i];
+    for (uint32_t j = 1; j < ksplit; ++j) { const double2 b = part[(size_t)j * count + i]; a.x += b.x; a.y += b.y; }
+    y[i] = a;
+}
 template <typename ST>
 __global__ void __launch_bounds__(256) tile_reduce_kernel(const float2 *part, ST *y, uint64_t count, uint32_t ksplit, uint64_t stride) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -82,10 +90,13 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     const int sym = P.sym ? 1 : 0;
     if (sym && dtype != 1 && dtype != 2) return hipErrorInvalidValue;
     if (dtype == 0) {                                    // fp64 data: one frame, one workgroup per tile, plain 'DAS' sum, prebuilt kernels
-        if (jit || P.lut_tx || P.bf || P.syn || P.big || P.nfr > 1 || (!P.probe && P.ksplit != 1)) return hipErrorInvalidValue;
+        if (jit || P.lut_tx || P.bf || P.syn || P.big || P.nfr > 1 || (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part)))) return hipErrorInvalidValue;
         const size_t lds64 = tile_lds_bytes(0, 0, P.N, P.M, 0);
         if (lds64 > tile_lds_limit(0)) return hipErrorInvalidValue;
-        return launch_tile_f64(P, ntiles, lds64, s);
+        hipError_t e64 = launch_tile_f64(P, ntiles, lds64, s);
+        if (e64 != hipSuccess || P.probe || P.ksplit <= 1) return e64;
+        tile_reduce_kernel_f64<<<(unsigned)((P.i_count + 255) / 256), 256, 0, s>>>((const double2 *)P.part, (double2 *)P.y, P.i_count, P.ksplit);
+        return hipGetLastError();
     }
     const int narrow = (sym && dtype == 1 && P.narrow) ? 1 : 0;
     if (P.act_bytes != 0 && P.act_bytes != 8 * (P.N + 1)) return hipErrorInvalidValue;

@@ -584,11 +584,11 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
 // ---- epilogue: y[i] = pix  (reference src/bf.cu:140); one image per frame of the launch
 template <class C> __device__ __forceinline__ void Tile<C>::epilogue() {
     if (syn || C::BF) return;                          // every stage already added its share to its plane / stored its pairs
-    if constexpr (C::F64) {                            // (fp64 plans run one workgroup per tile: no partial images)
+    if constexpr (C::F64) {                            // (one frame per launch; the partial images of a split aperture are complex128: [split][pixel])
         if (pofs != NOT_MINE) {
             uint32_t po = pofs;
             asm volatile("" : "+v"(po));
-            ST *base = (ST *)P.y;
+            ST *base = S > 1 ? (ST *)P.part + (size_t)split * P.i_count : (ST *)P.y;
             asm volatile("" : "+s"(base));
             st(base, (size_t)po, cplx<double>{dacc[0] + dacc[2], dacc[1] + dacc[3]});
         }
@@ -658,7 +658,7 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
     }
     if constexpr (sizeof(ST) == 16) {                  // fp64 data: no remodulation, no pixel x receiver weight (qdas_api.hip)
         if (fm || P.apix || P.gen_kind || P.syn) return hipErrorInvalidValue;
-        if (wt) QDAS_LAUNCH(false, true); else QDAS_LAUNCH(false, false);
+        if (wt) QDAS_LAUNCH(false, true); else QDAS_LAUNCH(false, false);    // (grid: ntiles * ksplit workgroups, as for the other data types)
     } else if constexpr (SYM) {
         if (wt) return hipErrorInvalidValue;
         if (fm) QDAS_LAUNCH(true, false); else QDAS_LAUNCH(false, false);

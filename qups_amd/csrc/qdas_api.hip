@@ -567,11 +567,10 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             unsigned ks = 1;
             while (ks * 2 <= cap && (uint64_t)pl->ntiles * ks < (uint64_t)cus) ks *= 2;   // (a split costs one more prologue per tile)
             if (const char *e = getenv("QDAS_KSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8 && (unsigned)v <= cap) ks = (unsigned)v; }
-            if (dt == QDAS_F64) ks = 1;                 // (the partial images of a split aperture are fp32)
             t.ksplit = ks;
             if (ks > 1 && !bfm) {
                 void *pb;
-                if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)ks * 4 * pl->i_count))) return bail(rc);   // x4: up to four frames per launch
+                if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)ks * 4 * pl->i_count))) return bail(rc);   // x4: up to four frames per launch (fp64 data: one complex128 frame -- fits as well)
                 t.part = (float2 *)pb;
             }
         }

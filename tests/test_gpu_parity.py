@@ -248,6 +248,16 @@ def test_double_precision_in_the_tiled_kernel(seq, interp):
     assert rel_err(out, gen) <= 1e-10
 
 
+@pytest.mark.parametrize("ks", [2, 3, 4])
+def test_double_precision_aperture_split(ks, monkeypatch):
+    """few tiles (a small image, a pixel slab of a multi-GPU job): several workgroups per tile, complex128 partial images, fixed-order sum"""
+    monkeypatch.setenv("QDAS_KSPLIT", str(ks))
+    case = make_case(seq="DV", interp="lanczos3", seed=8, N=24, I1=100, I2=21)
+    out, plan = run_das(case, kernel=2, prec="double")
+    assert plan.kernel == "tiled" and plan.aperture_split() == ks
+    assert rel_err(out, _oracle64(case)) <= 1e-10
+
+
 def test_double_precision_tiled_variants():
     """weights (pixel-independent: folded into one N x M complex128 table), transposed data with per-transmit t0, a pixel shard,
     several frames, a record shorter than the path (checked loop: exact zeros) and an odd transmit count (tail block)"""
