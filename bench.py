@@ -173,6 +173,8 @@ def main():
     ap.add_argument("--fmod", type=float, default=0.0, help="remodulation frequency [Hz] ('modulation' option): baseband data; not the headline")
     ap.add_argument("--rx-apod", default=None, help="generated receive apodization for ANY workload, e.g. fnumber:1.5 | acceptance:30 | cosine:45 "
                     "(evaluated inside the kernel: what an apodized frame costs); not the headline")
+    ap.add_argument("--window-apod", action="store_true", help="Hann receive window x Hann transmit window (pixel-independent apodization, folded "
+                    "into an N x M table): an apodized full-synthetic-aperture frame stays in the reciprocal mode; not the headline")
     ap.add_argument("--prec", default=None, help="override the workload's data precision (single | halfT | double); not the headline")
     ap.add_argument("--gen-apod", action="store_true", help="generate the workload's receive apodization inside the kernel "
                     "(qdas_desc.rx_apod_*) instead of streaming the materialised I x N array")
@@ -220,6 +222,9 @@ def main():
     extra = ["interp", w["interp"], "input-precision", w["prec"]] + (["modulation", args.fmod] if args.fmod else [])
     if args.fmod:
         w["label"] += f" [fmod {args.fmod:g} Hz]"
+    if args.window_apod:
+        extra += ["apod", np.hanning(N + 2)[1:-1].astype(np.float32).reshape(1, 1, 1, N, 1), "apod", np.hanning(M + 2)[1:-1].astype(np.float32).reshape(1, 1, 1, 1, M)]
+        w["label"] += " [Hann receive x transmit windows]"
     if args.rx_apod:
         from qups_amd.apodization import rx_apod_spec
         kind, _, par = args.rx_apod.partition(":")
@@ -325,7 +330,7 @@ def main():
             mode = "live" if world == 1 else "file"
         if mode == "live":
             argv = ["--workload", args.workload] + (["--kernel", str(args.kernel)] if args.kernel else []) + \
-                   (["--prec", args.prec] if args.prec else []) + (["--fmod", str(args.fmod)] if args.fmod else []) + (["--rx-apod", args.rx_apod] if args.rx_apod else []) + (["--gen-apod"] if args.gen_apod else []) + \
+                   (["--prec", args.prec] if args.prec else []) + (["--fmod", str(args.fmod)] if args.fmod else []) + (["--rx-apod", args.rx_apod] if args.rx_apod else []) + (["--window-apod"] if args.window_apod else []) + (["--gen-apod"] if args.gen_apod else []) + \
                    (["--no-reciprocal"] if args.no_reciprocal else []) + (["--no-jit"] if args.no_jit else [])
             traffic, tsrc = measure_traffic(argv)
             if traffic is None:

@@ -85,7 +85,6 @@ struct TileCfg {
     static constexpr int PB = 1024;                  // bytes per full DMA piece (one wave-instruction x 16 B)
     static constexpr int PCS = (WB + PB - 1) / PB;   // pieces per window; the last one may use fewer lanes
     static constexpr int NDMA = WPW * PCS * (TWO ? 2 : 1);    // DMA instructions per wave and stage
-    static_assert(!SYM || !WTAB, "reciprocal mode: no weight table");
     static_assert(!(SYM && FBX) && !(FB2 && FB4), "reciprocal mode runs one frame per launch");
     static_assert(!BIG || (!SYM && !FBX), "the re-basing general kernel runs one frame per launch");
     static_assert(!LUT || (!SYM && !FBX && !BIG), "table-driven delays: general mode, one frame per launch");
@@ -660,8 +659,10 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
         if (fm || P.apix || P.gen_kind || P.syn) return hipErrorInvalidValue;
         if (wt) QDAS_LAUNCH(false, true); else QDAS_LAUNCH(false, false);    // (grid: ntiles * ksplit workgroups, as for the other data types)
     } else if constexpr (SYM) {
-        if (wt) return hipErrorInvalidValue;
-        if (fm) QDAS_LAUNCH(true, false); else QDAS_LAUNCH(false, false);
+        if (fm && wt) QDAS_LAUNCH(true, true);
+        else if (fm)  QDAS_LAUNCH(true, false);
+        else if (wt)  QDAS_LAUNCH(false, true);
+        else          QDAS_LAUNCH(false, false);
     } else if constexpr (FB4 && sizeof(ST) == 8) {
         // four fp32 frames per launch: 4 x 8 tap registers per transmit pair leave no room for the per-sample post-processing of
         // remodulation / weight tables or for the per-frame totals of a pixel x receiver weight -- those plans share launches

@@ -376,7 +376,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // reciprocal mode (das_tile_impl.h "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
     // elements and share one t0 has tau(n,m) == tau(m,n); detected from the geometry itself, bit-exactly.
     int sym = 0, big = 0;
-    if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && z.VS && z.DV && z.N == z.M && z.S == 0 && !g.gen_kind && !(desc->plan_flags & QDAS_PLAN_NO_RECIPROCAL) && !getenv("QDAS_NO_SYM")) {
+    if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && z.VS && z.DV && z.N == z.M && pix_arr < 0 && !g.gen_kind && !(desc->plan_flags & QDAS_PLAN_NO_RECIPROCAL) && !getenv("QDAS_NO_SYM")) {
         std::vector<float> hr(3 * z.N), hv(4 * z.M);
         if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
         if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);

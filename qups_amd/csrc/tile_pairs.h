@@ -31,11 +31,17 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
         if constexpr (DIAG) { if (m + 1 < n) return; }          // both transmits below the diagonal: their pairs were done as mirrors
         const bool upper = !TAIL || (m + 1 < M);  // the upper half carries a real transmit
         float wr0 = 1.f, wi0 = 0.f, wr1 = 1.f, wi1 = 0.f;
+        float xr0 = 1.f, xi0 = 0.f, xr1 = 1.f, xi1 = 0.f;          // reciprocal mode: weights of the MIRROR pairs (receiver m | m+1, transmit n)
+        constexpr bool SW = SYM && WTAB;                          // the two traces of an unordered pair carry different weights: separate sums
         if constexpr (WTAB) {
             const float2 wa = ((const float2 *)P.wtab)[n + (size_t)N * m];
             const float2 wb_ = upper ? ((const float2 *)P.wtab)[n + (size_t)N * (m + 1)] : make_float2(0.f, 0.f);
             wr0 = wa.x; wi0 = wa.y; wr1 = wb_.x; wi1 = wb_.y;
-            if constexpr (!BF) { if (wr0 == 0.f && wi0 == 0.f && wr1 == 0.f && wi1 == 0.f) return; }   // zero weights: skip (src/bf.cu:122,126); 'BF' stores the zeros
+            if constexpr (SW) {
+                const float2 xa = ((const float2 *)P.wtab)[m + (size_t)N * n], xb = ((const float2 *)P.wtab)[m + 1 + (size_t)N * n];
+                xr0 = xa.x; xi0 = xa.y; xr1 = xb.x; xi1 = xb.y;
+                if (wr0 == 0.f && wi0 == 0.f && wr1 == 0.f && wi1 == 0.f && xr0 == 0.f && xi0 == 0.f && xr1 == 0.f && xi1 == 0.f) return;
+            } else if constexpr (!BF) { if (wr0 == 0.f && wi0 == 0.f && wr1 == 0.f && wi1 == 0.f) return; }   // zero weights: skip (src/bf.cu:122,126); 'BF' stores the zeros
         }
         const v2f t = ra[p] + rb;
         const v2f tm = t + MAGIC;
@@ -76,15 +82,15 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                         for (int k = 0; k < K; ++k) { g1.s[k] = (v2f){0.f, 0.f}; if constexpr (FBX) h1.s[k] = (v2f){0.f, 0.f}; }
                     }
                 }
-                if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; if constexpr (FBX) { u0 = h0.s[0]; u1 = h1.s[0]; } }
+                if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; if constexpr (FBX || SW) { u0 = h0.s[0]; u1 = h1.s[0]; } }
                 else if constexpr (SPLIT) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) { v0 = w[k].x * g0.s[k] + v0; v1 = w[k].y * g1.s[k] + v1; }
-                    if constexpr (SYM) {
+                    if constexpr (SYM && !SW) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { v0 = w[k].x * h0.s[k] + v0; v1 = w[k].y * h1.s[k] + v1; }
                     }
-                    if constexpr (FBX) {
+                    if constexpr (FBX || SW) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { u0 = w[k].x * h0.s[k] + u0; u1 = w[k].y * h1.s[k] + u1; }
                     }
@@ -96,7 +102,7 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                         for (int k = 0; k < K; ++k) { B0 = w[k].x * h0.s[k] + B0; B1 = w[k].y * h1.s[k] + B1; }
                     }
                 }
-                if constexpr (SYM && K == 1) { v0 += h0.s[0]; v1 += h1.s[0]; }
+                if constexpr (SYM && !SW && K == 1) { v0 += h0.s[0]; v1 += h1.s[0]; }
             } else {
                 taps_f16 g0, g1, h0, h1;
                 lds_issue<K, (GSET * MB + 2 * p) * WB>(g0, ad0); lds_issue<K, (GSET * MB + 2 * p + 1) * WB>(g1, ad1);
@@ -116,16 +122,16 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                 }
                 if constexpr (K == 1) {
                     v0 = half2_to_v2f(g0.r[0]); v1 = half2_to_v2f(g1.r[0]);
-                    if constexpr (FBX) { u0 = half2_to_v2f(h0.r[0]); u1 = half2_to_v2f(h1.r[0]); }
-                    if constexpr (SYM) { v0 += half2_to_v2f(h0.r[0]); v1 += half2_to_v2f(h1.r[0]); }
+                    if constexpr (FBX || SW) { u0 = half2_to_v2f(h0.r[0]); u1 = half2_to_v2f(h1.r[0]); }
+                    if constexpr (SYM && !SW) { v0 += half2_to_v2f(h0.r[0]); v1 += half2_to_v2f(h1.r[0]); }
                 } else if constexpr (SPLIT) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) { mix_mac(v0, g0.r[k], w[k].x); mix_mac(v1, g1.r[k], w[k].y); }
-                    if constexpr (SYM) {
+                    if constexpr (SYM && !SW) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { mix_mac(v0, h0.r[k], w[k].x); mix_mac(v1, h1.r[k], w[k].y); }
                     }
-                    if constexpr (FBX) {
+                    if constexpr (FBX || SW) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { mix_mac(u0, h0.r[k], w[k].x); mix_mac(u1, h1.r[k], w[k].y); }
                     }
@@ -145,7 +151,7 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                 const float lo1 = tapinfo<INTERP>::LO - 0.5f - (float)ws1, hi1 = (float)(T - K + 1 - ws1) - 0.5f;
                 const bool k0 = (t.x >= lo0) && (t.x < hi0), k1 = (t.y >= lo1) && (t.y < hi1) && upper;
                 v0 = k0 ? v0 : (v2f){0.f, 0.f}; v1 = k1 ? v1 : (v2f){0.f, 0.f};
-                if constexpr (FBX) { u0 = k0 ? u0 : (v2f){0.f, 0.f}; u1 = k1 ? u1 : (v2f){0.f, 0.f}; }
+                if constexpr (FBX || SW) { u0 = k0 ? u0 : (v2f){0.f, 0.f}; u1 = k1 ? u1 : (v2f){0.f, 0.f}; }
             }
             if constexpr (FMOD) {                     // reference src/bf.cu:117: w = exp(2j pi fmod tau), tau*fs = t + 1/2 + (A[m] + B[n]) - OFF
                 // phase in cycles = t*f + frac((A[m] + 1/2 - OFF)*f) + frac(B[n]*f), f = fmod/fs: the two constants were tabulated in
@@ -161,7 +167,7 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                 } else {
                     v0 = (v2f){v0.x * c0 - v0.y * s0, v0.x * s0 + v0.y * c0};
                     v1 = (v2f){v1.x * c1 - v1.y * s1, v1.x * s1 + v1.y * c1};
-                    if constexpr (FBX) {
+                    if constexpr (FBX || SW) {
                         u0 = (v2f){u0.x * c0 - u0.y * s0, u0.x * s0 + u0.y * c0};
                         u1 = (v2f){u1.x * c1 - u1.y * s1, u1.x * s1 + u1.y * c1};
                     }
@@ -183,6 +189,7 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
             } else if constexpr (WTAB) {
                 rot_acc(A0, v0, wr0, wi0); rot_acc(A1, v1, wr1, wi1);             // complex weight folded into the accumulation
                 if constexpr (FBX) { rot_acc(B0, u0, wr0, wi0); rot_acc(B1, u1, wr1, wi1); }
+                if constexpr (SW) { rot_acc(B0, u0, xr0, xi0); rot_acc(B1, u1, xr1, xi1); }      // mirror pairs, their own weights
             } else if constexpr (FMOD) {              // (accumulated by the rotation above)
             } else if constexpr (SPLIT || K == 1) { A0 += v0; A0 += v1; if constexpr (FBX) { B0 += u0; B0 += u1; } }
         });

@@ -31,8 +31,8 @@ def _draw(seed):
                gen=str(r.choice(["", "", "", "acceptance", "cosine", "fnumber"])))
     # (round 2; drawn last so that the fields above keep their round-1 values per seed)
     extra = dict(sym=bool(r.integers(0, 6) == 0), bf=bool(r.integers(0, 8) == 0), jit=bool(r.integers(0, 10) == 0))
-    if extra["sym"]:                # a reciprocal-mode candidate: full synthetic aperture, M == N, no weights, plain 'DAS'
-        cfg.update(seq="FSA", M=N, wn=False, wm=False, wpix=False, gen="", fun="DAS")
+    if extra["sym"]:                # a reciprocal-mode candidate: full synthetic aperture, M == N, no pixel-dependent weights, plain 'DAS'
+        cfg.update(seq="FSA", M=N, wpix=False, gen="", fun="DAS")       # (pixel-independent weights wn / wm stay: reciprocal mode with a weight table)
     elif extra["bf"] and cfg["prec"] == "single":
         cfg.update(fun="BF", F=min(cfg["F"], 2))
     cfg.update(extra)

@@ -485,6 +485,35 @@ def test_reciprocal_mode_matches_general_mode(monkeypatch):
     assert rel_err(run_das(case, kernel=2)[0], run_oracle(case)) <= TOL32
 
 
+@pytest.mark.parametrize("interp,prec,fm", [("lanczos3", "single", 0.0), ("cubic", "single", 2.5e6), ("linear", "halfT", 0.0), ("nearest", "single", 0.0), ("cubic", "halfT", 2.5e6)])
+def test_reciprocal_mode_with_aperture_weights(interp, prec, fm, monkeypatch):
+    """full synthetic aperture with pixel-independent apodization (receive window x transmit window x an N x M table, complex): the two
+    traces of an unordered pair share index and interpolation weights but carry DIFFERENT table entries -- w[n, m] and w[m, n]"""
+    rng = np.random.default_rng(17)
+    case = make_case(seq="FSA", interp=interp, seed=19, N=32, I1=150, I2=19)
+    x = case["x"]
+    q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else f32r
+    if prec == "halfT":
+        x = x.real.astype(np.float16).astype(np.float64) + 1j * x.imag.astype(np.float16).astype(np.float64)
+    wn = q(np.hanning(34)[1:-1]).reshape(1, 1, 1, 32, 1)
+    wm = q(rng.uniform(0, 1, (1, 1, 1, 1, 32)))
+    wm[..., 5] = 0.0
+    tab = q(rng.uniform(0.5, 1, (1, 1, 1, 32, 32)))
+    tab[..., 7, :] = 0.0
+    if prec == "single":
+        tab = tab * np.exp(1j * f32r(rng.uniform(0, 1, (1, 1, 1, 32, 32))))
+        tab = tab.real.astype(np.float32) + 1j * tab.imag.astype(np.float32)
+    fmod = float(np.float32(fm))
+    ref = run_oracle(case, apod=(wn, wm, tab), x=x, fmod=fmod)
+    out, plan = run_das(case, kernel=2, prec=prec, apod=(wn, wm, tab), fmod=fmod)
+    assert plan.kernel == "tiled" and plan.reciprocal and ",wtab" in plan.kernel_name(), plan.kernel_name()
+    tol = (2e-3 if interp == "nearest" else 3e-5) if prec == "single" else 3e-3
+    assert rel_err(out, ref) <= tol
+    monkeypatch.setenv("QDAS_NO_SYM", "1")
+    out2, plan2 = run_das(case, kernel=2, prec=prec, apod=(wn, wm, tab), fmod=fmod)
+    assert not plan2.reciprocal and rel_err(out2, out) <= tol
+
+
 @pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3"])
 def test_reciprocal_mode_with_half_precision_data(interp, monkeypatch):
     """fp16 channel data in reciprocal mode (launch configuration 8): equals the general fp16 kernel and the oracle on the
