@@ -72,12 +72,14 @@ TileConfig tile_config(int dtype, int sym, int narrow) {
     return c;
 }
 
-size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow, int pixw) {
+size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow, int pixw, int wtab) {
     const Cfg &g = CFGS[cfg_index(dtype, sym, 1, narrow)];
     const TileConfig c = tile_config(dtype, sym, narrow);
     const size_t MX = std::min<size_t>(M > N ? M : N, QDAS_PROLOGUE_CHUNK);
     // (geometry tables in the plan's real type: 32-byte receiver records and 8-byte table entries for fp64 data -- Tile::setup)
-    const size_t hdr = (((((2 * M + N) * 4 + 15) & ~(size_t)15) + (dtype == 0 ? 32 : 16) * N + 7 * M * (dtype == 0 ? 8 : 4)) + (pixw ? 8 * (N + 1) : 0) + 15) & ~(size_t)15;
+    const size_t off_act = (((((2 * M + N) * 4 + 15) & ~(size_t)15) + (dtype == 0 ? 32 : 16) * N + 7 * M * (dtype == 0 ? 8 : 4)) + 15) & ~(size_t)15;
+    const size_t off_wst = off_act + (((pixw ? 8 * (N + 1) : 0) + 15) & ~(size_t)15);
+    const size_t hdr = (off_wst + ((wtab && dtype != 0) ? (size_t)g.nbuf * (2 * (size_t)g.mb * 8 + 16) : 0) + 15) & ~(size_t)15;     // Tile::setup
     size_t body = c.lds_bytes;
     const size_t scratch = 2 * (size_t)g.waves * MX * 4 + 1024;   // prologue scratch aliases the windows
     if (body < scratch) body = scratch;
@@ -100,7 +102,7 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     }
     const int narrow = (sym && dtype == 1 && P.narrow) ? 1 : 0;
     if (P.act_bytes != 0 && P.act_bytes != 8 * (P.N + 1)) return hipErrorInvalidValue;
-    const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M, narrow, P.act_bytes ? 1 : 0);    // (the two-frame configurations have the same LDS image)
+    const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M, narrow, P.act_bytes ? 1 : 0, P.wtab ? 1 : 0);    // (the two-frame configurations have the same LDS image)
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
     if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part && !P.bf))) return hipErrorInvalidValue;
 const int nf = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);

@@ -80,6 +80,11 @@ struct TileCfg {
 #else
     static constexpr bool ACT = !F64 && !SYM && !BIG && !BF_ && !FB2 && !FB4;     // (frames sharing a launch keep the plain list: no register for it)
 #endif
+    // pixel-independent weights (N x M table) reach the pair loop through LDS: the 32 (reciprocal mode: 2 x 32) table entries of a stage are
+    // fetched one stage ahead by a single wave and read back with broadcast ds_reads -- as scalar loads inside the pair loop they cost a
+    // scalar-memory latency per transmit pair and drained the LDS queue with it (lgkmcnt counts both)
+    static constexpr bool WST = WTAB_ && !F64 && !BF_ && !FB4;      // (four frames per launch: no registers to spare -- scalar loads as before)
+    static constexpr int WSTB = WST ? NBUF_ * (2 * MB_ * 8 + 16) : 0;     // [NBUF][{direct, mirror}][MB] float2 + {non-zero masks} per buffer
     using GT = std::conditional_t<F64, double, float>;   // type of the geometry tables (the reference casts them to the data precision, kern/das_spec.m:244)
     static constexpr int WB = W * SB;                // bytes per window
     static constexpr int PB = 1024;                  // bytes per full DMA piece (one wave-instruction x 16 B)
@@ -110,6 +115,7 @@ template <class C> struct Tile {
     using GT = typename C::GT;
     struct rec64 { double x, y, z; int b, pad; };     // fp64 twin of the receiver record {window base B, position}
     int *Abase; float *Aext, *Bext; float4 *nrec; rec64 *nrec64; GT *PvL, *NvL; ST *win; float *part; uint32_t win_off;
+    unsigned char *wst; uint32_t wst_off;            // stage weights (TileCfg::WST), and their LDS byte address
     uint2 *act;                                      // [N + 1] {receiver, its window base B} of the receivers with a non-zero weight somewhere in the tile, then {count, -} (pixel x receiver weights)
     uint32_t split, S, tile_id;
     double fs, symC; int symCi;
@@ -181,7 +187,7 @@ template <class C> struct Tile {
     __device__ __forceinline__ void stage_dma(int bn, int buf);
 
     // pair loops (tile_pairs.h)
-    template <bool CHECK, bool TAILV> __device__ __forceinline__ void pairs_plain(uint32_t n, uint32_t m0, int bn, float rb, uint32_t cbase, float phB);
+    template <bool CHECK, bool TAILV, bool WZ = true> __device__ __forceinline__ void pairs_plain(uint32_t n, uint32_t m0, int bn, float rb, uint32_t cbase, float phB, uint32_t wbase, uint32_t wmask, uint32_t xmask);
     __device__ __forceinline__ void pairs_pipelined(float rb, uint32_t cbase);
     template <bool CHECK, bool TAILV> __device__ __forceinline__ void pairs_f64(uint32_t n, uint32_t m0, int bn, double rb, uint32_t cbase);
     __device__ __forceinline__ void frame_sums(v2f (&Sf)[4]) const {
@@ -260,9 +266,13 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
     constexpr uint32_t RECB = C::F64 ? 32u : 16u, GB = (uint32_t)sizeof(GT);
     PvL   = (GT *)((unsigned char *)nrec + RECB * N);   // [4M] (virtual) sources + t0
     NvL   = PvL + 4 * M;                              // [3M] transmit normals
-    act   = (uint2 *)(NvL + 3 * M);                   // [N + 1]
     const uint32_t actb = P.act_bytes;               // (only plans with a pixel x receiver weight pay for the stage list)
-    const uint32_t hdr = ((((2 * M + N) * 4 + 15) & ~15u) + RECB * N + 7 * M * GB + actb + 15) & ~15u;
+    const uint32_t off_act = ((((2 * M + N) * 4 + 15) & ~15u) + RECB * N + 7 * M * GB + 15) & ~15u;
+    const uint32_t off_wst = off_act + ((actb + 15) & ~15u);
+    act   = (uint2 *)(smem + off_act);                // [N + 1]
+    wst   = smem + off_wst;
+    wst_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem) + off_wst;
+    const uint32_t hdr = (off_wst + (uint32_t)C::WSTB + 15) & ~15u;
     win = (ST *)(smem + hdr);                         // [NBUF][NW][W]
     part = (float *)(smem + hdr);                     // prologue scratch, aliases the windows
     win_off = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char *)smem) + hdr;
@@ -452,6 +462,29 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         if (++pk == klim(pm0)) { pk = 0; pm0 = blk(++pr); dma_block(pm0); }
     };
     auto dma_next = [&](int buf) { dma_prep(); dma_go(buf); };
+    // stage weights (TileCfg::WST): wave 0 fetches the stage's MB table entries w[n, m0 .. m0+MB-1] (wave 1, reciprocal mode: the mirror
+    // entries w[m0 .., n]) one stage ahead -- requested with the stage head's global loads, written to LDS after the pair loop
+    constexpr uint32_t WBUF = 2u * C::MB * 8u + 16u;
+    float2 wnx = {0.f, 0.f};
+    auto wst_load = [&](uint32_t nn, uint32_t mm0) {
+        if constexpr (C::WST) {
+            const uint32_t mm = mm0 + (uint32_t)lane;
+            if (wave == 0 && lane < C::MB) wnx = mm < M ? ((const float2 *)P.wtab)[nn + (size_t)N * mm] : make_float2(0.f, 0.f);
+            if constexpr (C::SYM) { if (wave == 1 && lane < C::MB) wnx = ((const float2 *)P.wtab)[mm + (size_t)N * nn]; }
+        }
+    };
+    auto wst_store = [&](int b) {
+        if constexpr (C::WST) {
+            if (wave == 0 || (C::SYM && wave == 1)) {
+                const bool nz = lane < C::MB && !(wnx.x == 0.f && wnx.y == 0.f);
+                const uint32_t mask = (uint32_t)__ballot(nz);
+                unsigned char *q = wst + (uint32_t)b * WBUF + (wave ? C::MB * 8 : 0);
+                if (lane < C::MB) ((float2 *)q)[lane] = wnx;
+                if (lane == 0) ((uint32_t *)(wst + (uint32_t)b * WBUF + 2 * C::MB * 8))[wave ? 1 : 0] = mask;
+            }
+        }
+    };
+    if (nstage) { wst_load(n_first, blk(0)); wst_store(0); }
 #pragma unroll
     for (int b = 0; b < NBUF - 1; ++b)
         if ((uint32_t)b < nstage) dma_next(b);
@@ -472,6 +505,12 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         else { const float4 r = nrec[n]; rec_b = __float_as_int(r.x); rec_x = r.y; rec_y = r.z; rec_z = r.w; }
         float phB = 0.f;                               // remodulation: frac(B[n]*fmod/fs) (tile_prologue.h)
         if constexpr (C::FMOD) phB = Bext[n];
+        uint32_t wmask = 0xffffffffu, xmask = 0xffffffffu;       // which of this stage's table entries are non-zero (zero weights are skipped, src/bf.cu:122,126)
+        if constexpr (C::WST) {
+            const uint2 mk = *(const uint2 *)(wst + (uint32_t)buf * WBUF + 2 * C::MB * 8);
+            wmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)mk.x);
+            if constexpr (C::SYM) xmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)mk.y);
+        }
         // The next stage's staging is issued at the start of this stage by the younger half of the waves and AFTER the pair
         // loop by the older half: the hardware favours older waves, they finish their pair loop early and would only wait at
         // the barrier -- their (scalar-heavy) issue phase then overlaps the younger waves' arithmetic instead of everybody's.
@@ -484,6 +523,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         // end-of-stage wait covers them)
         if (wpix && st + 1 < nstage) wnext_r = wload_raw(n_next);
         if constexpr (C::LUT) { if (st + 1 < nstage) tbn = P.lut_rx[ipx + Ilut * n_next]; }
+        if (st + 1 < nstage) wst_load(n_next, k + 1 == klim(m0) ? blk(cr + 1) : m0);
         if (dma_now) dma_go((buf + NBUF - 1) % NBUF);            // lands during the next NBUF-1 stages
         timer.mark(1);
         if constexpr (C::F64) {
@@ -530,13 +570,24 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
                 if constexpr (C::TWO && (C::F32 || C::SYM) && C::K == 4 && !(CHECK || C::FMOD || C::WTAB) && !hooks::no_pipeline)
                     pairs_pipelined(rb, cbase);
                 else
-                    pairs_plain<CHECK, false>(n, m0, bn, rb, cbase, phB);
+                {
+                    constexpr uint32_t FULL = C::MB >= 32 ? 0xffffffffu : ((1u << (C::MB & 31)) - 1u);
+                    bool done = false;
+                    if constexpr (C::WST) {
+                        if (wmask == FULL && (!C::SYM || xmask == FULL)) {          // no zero weight in this stage: the loop without zero tests
+                            pairs_plain<CHECK, false, false>(n, m0, bn, rb, cbase, phB, wst_off + (uint32_t)buf * WBUF, wmask, xmask);
+                            done = true;
+                        }
+                    }
+                    if (!done) pairs_plain<CHECK, false>(n, m0, bn, rb, cbase, phB, wst_off + (uint32_t)buf * WBUF, wmask, xmask);
+                }
             } else {
-                pairs_plain<CHECK, true>(n, m0, bn, rb, cbase, phB);
+                pairs_plain<CHECK, true>(n, m0, bn, rb, cbase, phB, wst_off + (uint32_t)buf * WBUF, wmask, xmask);
             }
         }
         if constexpr (!hooks::no_fair_prio) __builtin_amdgcn_s_setprio(3);     // stage epilogue / next preamble at full priority (tile_pairs.h)
         if (!hooks::no_stage_dma && more && dma_late) dma_next((buf + NBUF - 1) % NBUF);
+        if (st + 1 < nstage) wst_store((buf + 1) % NBUF);          // (the barrier below publishes it)
         timer.mark(3);
         // stage st+1 must have landed (all but the NBUF-2 newest DMA groups), all my LDS reads are done
         if (!hooks::no_stage_barrier) {

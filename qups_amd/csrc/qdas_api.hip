@@ -397,7 +397,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     const uint64_t kN = swap ? z.M : z.N, kM = swap ? z.N : z.M;
     pl->tc = tile_config(dt, sym);
     const int pixw = (pix_arr >= 0 || g.gen_kind) ? 1 : 0;      // a pixel x receiver weight: the tile keeps a stage list (das_tile_impl.h plan_stages)
-    if (eligible && tile_lds_bytes(dt, sym, kN, kM, 0, pixw) > tile_lds_limit(sym)) {
+    const int wtb = z.S > (uint64_t)(pix_arr >= 0 ? 1 : 0) ? 1 : 0;      // pixel-independent arrays: folded into an N x M table, staged per stage in LDS
+    if (eligible && tile_lds_bytes(dt, sym, kN, kM, 0, pixw, wtb) > tile_lds_limit(sym)) {
         eligible = false; why = "tiled kernel: N + M too large for the LDS header";
     }
     if (eligible && (z.T < 8)) { eligible = false; why = "tiled kernel needs T >= 8"; }
@@ -414,7 +415,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (sym && (uint64_t)(tile_config(dt, 1).mb + 1) * smax * data_size(dt) + slack >= (1ull << 30)) {
             sym = 0;
             pl->tc = tile_config(dt, 0);
-            if (eligible && tile_lds_bytes(dt, 0, z.N, z.M, 0, pixw) > tile_lds_limit(0)) { eligible = false; why = "tiled kernel: N + M too large for the LDS header"; }
+            if (eligible && tile_lds_bytes(dt, 0, z.N, z.M, 0, pixw, wtb) > tile_lds_limit(0)) { eligible = false; why = "tiled kernel: N + M too large for the LDS header"; }
         }
         if (eligible && !sym && (kN * strN + (uint64_t)pl->tc.mb * strM) * data_size(dt) + slack >= (1ull << 31)) {
             // fp32, one frame per launch: the re-basing instantiation of the general kernel (launch configuration 9)
@@ -603,7 +604,9 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (const char *e = getenv("QDAS_JIT_NBUF")) { const int nb = atoi(e); if (nb >= 2 && nb <= 4) k.nbuf = nb; }
         {
             const size_t MX = std::min<size_t>(t.M > t.N ? t.M : t.N, QDAS_PROLOGUE_CHUNK);
-            const size_t hdr = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + t.act_bytes + 15) & ~(size_t)15;   // Tile::setup
+            const size_t off_act = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + 15) & ~(size_t)15;   // Tile::setup
+            const size_t off_wst = off_act + (((size_t)t.act_bytes + 15) & ~(size_t)15);
+            const size_t hdr = (off_wst + (t.wtab ? (size_t)k.nbuf * (2 * (size_t)k.mb * 8 + 16) : 0) + 15) & ~(size_t)15;
             size_t body = (size_t)k.nbuf * k.mb * (t.sym ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
             const size_t scratch = 2 * (size_t)k.waves * MX * 4 + 1024;
             if (body < scratch) body = scratch;
@@ -916,7 +919,7 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     if (d->w && !w_tab && !w_pix && !w_pixm) return 1;
     if (keep && (dt != QDAS_F32 || w_tab || (w_pix && keep_tx))) return 1;
     if (d->T < 8 || d->N >= (1ull << 20) || d->M >= (1ull << 20)) return 1;
-    if (tile_lds_bytes(dt, 0, d->N > d->M ? d->N : d->M, d->N > d->M ? d->N : d->M, 0, (w_pix || w_pixm) ? 1 : 0) > tile_lds_limit(0)) return 1;
+    if (tile_lds_bytes(dt, 0, d->N > d->M ? d->N : d->M, d->N > d->M ? d->N : d->M, 0, (w_pix || w_pixm) ? 1 : 0, w_tab ? 1 : 0) > tile_lds_limit(0)) return 1;
     const bool tp = d->flag & QDAS_FLAG_TPOSE;
     uint64_t strN = tp ? d->T * d->M : d->T, strM = tp ? d->T : d->T * d->N;
     uint64_t kN = d->N, kM = d->M;

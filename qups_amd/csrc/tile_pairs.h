@@ -14,11 +14,14 @@ namespace qdas {
 // Plain loop.  TAILV = false: full block (reciprocal mode: block entirely above the diagonal), no bounds tests on m.
 // TAILV = true: last, partial transmit block (bounds checks) or -- reciprocal mode -- the block that contains m == n.
 // CHECK: the tile touches the ends of the record: edge rule per sample (all taps in [0,T) and tau >= 0; select, not multiply).
-template <class C> template <bool CHECK, bool TAILV>
-__device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, int bn, float rb, uint32_t cbase, float phB) {
+// WZ: some table weight of the stage is zero (stage weights from LDS; else: no zero tests at all in the loop).
+template <class C> template <bool CHECK, bool TAILV, bool WZ>
+__device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, int bn, float rb, uint32_t cbase, float phB, uint32_t wbase, uint32_t wmask, uint32_t xmask) {
     constexpr int K = C::K, MB = C::MB, WB = C::WB, INTERP = C::INTERP, NHP = C::NHP;
     constexpr bool SYM = C::SYM, FB4 = C::FB4, FBX = C::FBX, TWO = C::TWO, F32 = C::F32, FMOD = C::FMOD, WTAB = C::WTAB, BF = C::BF;
     constexpr bool TAIL = !SYM && TAILV, DIAG = SYM && TAILV;
+    // (stage weights: does any transmit pair of this stage hold exactly one zero weight?)
+    const bool wmixed = C::WST && WZ && ((((wmask ^ (wmask >> 1)) & 0x55555555u) != 0u) || (SYM && C::WTAB && (((xmask ^ (xmask >> 1)) & 0x55555555u) != 0u)));
     unroll<MB / 2>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
         // Fair progress inside a stage: the hardware issues oldest-wave-first, so without help the four waves of a SIMD finish their
@@ -33,15 +36,17 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
         float wr0 = 1.f, wi0 = 0.f, wr1 = 1.f, wi1 = 0.f;
         float xr0 = 1.f, xi0 = 0.f, xr1 = 1.f, xi1 = 0.f;          // reciprocal mode: weights of the MIRROR pairs (receiver m | m+1, transmit n)
         constexpr bool SW = SYM && WTAB;                          // the two traces of an unordered pair carry different weights: separate sums
-        if constexpr (WTAB) {
+        v4f wv = {1.f, 0.f, 1.f, 0.f}, xv = {1.f, 0.f, 1.f, 0.f};    // stage weights from LDS: {w[n,m], w[n,m+1]} and, reciprocal mode, {w[m,n], w[m+1,n]}
+        if constexpr (C::WST) {
+            // zero weights: skipped (src/bf.cu:122,126) -- the stage's non-zero masks are uniform, the tests scalar
+            if constexpr (WZ) { if (((wmask >> (2 * p)) & 3u) == 0u && (!SW || ((xmask >> (2 * p)) & 3u) == 0u)) return; }
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(wv) : "v"(wbase), "n"(2 * p * 8));
+            if constexpr (SW) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(xv) : "v"(wbase), "n"(MB * 8 + 2 * p * 8));
+        } else if constexpr (WTAB) {
             const float2 wa = ((const float2 *)P.wtab)[n + (size_t)N * m];
             const float2 wb_ = upper ? ((const float2 *)P.wtab)[n + (size_t)N * (m + 1)] : make_float2(0.f, 0.f);
             wr0 = wa.x; wi0 = wa.y; wr1 = wb_.x; wi1 = wb_.y;
-            if constexpr (SW) {
-                const float2 xa = ((const float2 *)P.wtab)[m + (size_t)N * n], xb = ((const float2 *)P.wtab)[m + 1 + (size_t)N * n];
-                xr0 = xa.x; xi0 = xa.y; xr1 = xb.x; xi1 = xb.y;
-                if (wr0 == 0.f && wi0 == 0.f && wr1 == 0.f && wi1 == 0.f && xr0 == 0.f && xi0 == 0.f && xr1 == 0.f && xi1 == 0.f) return;
-            } else if constexpr (!BF) { if (wr0 == 0.f && wi0 == 0.f && wr1 == 0.f && wi1 == 0.f) return; }   // zero weights: skip (src/bf.cu:122,126); 'BF' stores the zeros
+            if constexpr (!BF) { if (wr0 == 0.f && wi0 == 0.f && wr1 == 0.f && wi1 == 0.f) return; }   // zero weights: skip (src/bf.cu:122,126); 'BF' stores the zeros
         }
         const v2f t = ra[p] + rb;
         const v2f tm = t + MAGIC;
@@ -144,6 +149,11 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                     }
                 }
             }
+            if constexpr (C::WST && hp == 0) {        // (the tap fence above waited for every LDS read of the iteration)
+                asm volatile("" : "+v"(wv), "+v"(xv));
+                wr0 = wv.x; wi0 = wv.y; wr1 = wv.z; wi1 = wv.w;
+                xr0 = xv.x; xi0 = xv.y; xr1 = xv.z; xi1 = xv.w;
+            }
             if constexpr (CHECK) {                    // edge rule: all taps in [0,T) and tau >= 0
                 const uint32_t mb = upper ? m + 1 : m;
                 const int ws0 = Abase[m] + bn, ws1 = Abase[mb] + bn;
@@ -187,6 +197,14 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                     if (upper) { float2 *pl1 = pl0 + P.bf_pm * P.y_ld; asm volatile("" : "+s"(pl1)); pl1[po] = make_float2(v1.x, v1.y); }
                 }
             } else if constexpr (WTAB) {
+                if constexpr (C::WST && WZ) {         // a zero weight never samples its trace (non-finite data stay out): uniform, scalar tests --
+                  if (wmixed) {                       // and only in stages where a zero shares a transmit pair with a non-zero weight
+                    const v2f z = {0.f, 0.f};
+                    if (!((wmask >> (2 * p)) & 1u)) { v0 = z; if constexpr (FBX) u0 = z; }
+                    if (!((wmask >> (2 * p + 1)) & 1u)) { v1 = z; if constexpr (FBX) u1 = z; }
+                    if constexpr (SW) { if (!((xmask >> (2 * p)) & 1u)) { u0 = z; } if (!((xmask >> (2 * p + 1)) & 1u)) { u1 = z; } }
+                  }
+                }
                 rot_acc(A0, v0, wr0, wi0); rot_acc(A1, v1, wr1, wi1);             // complex weight folded into the accumulation
                 if constexpr (FBX) { rot_acc(B0, u0, wr0, wi0); rot_acc(B1, u1, wr1, wi1); }
                 if constexpr (SW) { rot_acc(B0, u0, xr0, xi0); rot_acc(B1, u1, xr1, xi1); }      // mirror pairs, their own weights

@@ -10,6 +10,7 @@
 namespace qdas {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr float MAGIC = 12582912.0f;          // 1.5 * 2^23: (t + MAGIC) has rint(t) in its low mantissa bits
 constexpr uint32_t MAGIC_BITS = 0x4B400000u;

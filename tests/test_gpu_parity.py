@@ -170,6 +170,32 @@ def test_apod_stack_complex_and_zero_skip(kernel, name):
     assert rel_err(out, ref) <= TOL32
 
 
+@pytest.mark.parametrize("seq,kernel", [("PW", 2), ("FSA", 2), ("PW", 1)])
+def test_zero_weights_never_sample_their_trace(seq, kernel):
+    """device semantics (src/bf.cu:120-126): a pair whose weight is zero is skipped, so non-finite samples of a dead channel or an
+    unused transmit stay out of the image -- also when the zero shares a packed transmit pair with a non-zero weight, and in the
+    reciprocal mode (FSA: both w[n,m] and w[m,n])"""
+    rng = np.random.default_rng(21)
+    case = make_case(seq=seq, interp="cubic", seed=27, N=16, M=16, I1=100, I2=12)
+    x = case["x"].copy()
+    wn = f32r(rng.uniform(0.3, 1, (1, 1, 1, 16, 1)))
+    wm = f32r(rng.uniform(0.3, 1, (1, 1, 1, 1, 16)))
+    wn[..., 5, :] = 0.0                                   # dead receive channel 5, unused transmits 2 and 11 (isolated zeros)
+    wm[..., [2, 11]] = 0.0
+    xz = x.copy()
+    xz[:, 5, :] = 0
+    xz[:, :, [2, 11]] = 0
+    x[:, 5, :] = np.nan
+    x[:, :, 2] = np.inf
+    x[:, :, 11] = np.nan
+    ref = run_oracle(case, apod=(wn, wm), x=xz)
+    out, plan = run_das(case, kernel=kernel, apod=(wn, wm), x=x)
+    assert np.isfinite(out).all()
+    assert rel_err(out, ref) <= (3e-5 if kernel == 2 else TOL32)
+    if kernel == 2:
+        assert plan.kernel == "tiled" and plan.reciprocal == (seq == "FSA")
+
+
 def test_tiled_with_trace_weights():
     case = make_case(seq="FSA", interp="lanczos3", seed=10, N=10, I1=100, I2=8)
     rng = np.random.default_rng(2)
