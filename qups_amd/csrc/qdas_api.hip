@@ -357,7 +357,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         const uint64_t I = z.I1 * z.I2 * z.I3;
         const bool pixstr = (a[0] == 1 || z.I1 == 1) && (a[1] == z.I1 || z.I2 == 1) && (a[2] == z.I1 * z.I2 || z.I3 == 1);
         const bool full = pixstr && (a[3] == I || a[3] == 0) && a[4] == 0 && (a[3] == I || z.N == 1 || a[3] == 0);
-        if (pixstr && a[3] == 0 && a[4] == I && z.M > 1 && pix_arr < 0 && !syn && !bfm && dt != QDAS_F64) { pix_arr = (int)s; pix_is_tx = true; }
+        if (pixstr && a[3] == 0 && a[4] == I && z.M > 1 && pix_arr < 0 && (!syn || mul) && !bfm && dt != QDAS_F64) { pix_arr = (int)s; pix_is_tx = true; }   // ('MUL': the transmit is the stage element anyway)
         else if (pixstr && a[3] == 0 && a[4] == 0 && pix_arr < 0 && !bfm && !mul && dt != QDAS_F64) { pix_arr = (int)s; pix_only = true; }   // a spatial weight / ROI mask
         else if (a[3] == 0 && z.N > 1) { eligible = false; why = "tiled kernel: a pixel-only apodization array needs the generic kernel"; }
         else if (!full || pix_arr >= 0) { eligible = false; why = "tiled kernel: at most one apodization array may depend on the pixel (I x [N], no transmit dependence)"; }
@@ -370,7 +370,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     if (eligible && bfm && (pix_arr >= 0 || g.gen_kind)) {
         eligible = false; why = "tiled kernel: 'BF' with a pixel x receiver apodization needs the generic kernel";
     }
-    if (eligible && mul && (pix_arr >= 0 || g.gen_kind)) {
+    if (eligible && mul && ((pix_arr >= 0 && !pix_is_tx) || g.gen_kind)) {
         eligible = false; why = "tiled kernel: 'MUL' with a pixel x receiver apodization needs the generic kernel";
     }
     // reciprocal mode (das_tile_impl.h "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive

@@ -642,6 +642,18 @@ def test_pixel_only_weights_run_fused(fun, prec):
     assert np.all(out[:70] == 0) and np.all(out[:, 30:] == 0)
 
 
+def test_mul_mode_with_pixel_by_transmit_weights():
+    """'MUL' (keep the transmit dimension) with a weight per (pixel, transmit): the transmit is the stage element of that mode, the weight
+    scales its plane"""
+    rng = np.random.default_rng(13)
+    case = make_case(seq="DV", interp="linear", seed=43, N=20, M=6, I1=120, I2=18)
+    wt = f32r(rng.uniform(0, 1, (120, 18, 1, 1, 6)) * (rng.uniform(0, 1, (120, 18, 1, 1, 6)) > 0.3))
+    ref = run_oracle(case, fun="MUL", apod=(wt,))
+    out, plan = run_das(case, fun="MUL", kernel=2, apod=(wt,))
+    assert plan.kernel == "tiled"
+    assert out.shape == ref.shape and rel_err(out, ref) <= 2e-5
+
+
 @pytest.mark.parametrize("prec", ["single", "halfT"])
 def test_pixel_by_transmit_apodization_runs_fused_with_swapped_roles(prec):
     """a weight per (pixel, transmit) -- the scanline / multiline / parallelogram transmit apodization of focused sequences, I1 x I2 x 1 x 1 x M
