@@ -57,7 +57,13 @@ extern "C" {
 #define QDAS_MEM_HOST   0
 #define QDAS_MEM_DEVICE 1
 
-/* ---- kernel selection (QDAS_KERNEL_AUTO picks the tiled kernel when eligible) */
+/* ---- kernel selection (QDAS_KERNEL_AUTO picks the tiled kernel when eligible)
+ * Eligible: 'DAS' with any data precision -- fp64 data: pixel-independent apodization, scalar sound speed, no fmod --,
+ * 'SYN' / 'MUL' / 'BF' with fp32 data; scalar sound speed or a full per-pixel map; any number of pixel-independent apodization arrays
+ * (folded into an N x M table) plus at most ONE pixel-dependent array: I x N (pixel x receiver), I x 1 x M (pixel x transmit: 'DAS' / 'MUL';
+ * the roles of the two apertures are swapped), or I (a spatial weight / region-of-interest mask), or one generated receive rule (rx_apod_kind);
+ * N and M up to about 1000 each.  Everything else runs the generic kernel with identical semantics; qdas_last_error() after a
+ * QDAS_KERNEL_TILED request says why a plan is not eligible. */
 #define QDAS_KERNEL_AUTO    0
 #define QDAS_KERNEL_GENERIC 1 /* one pixel per lane, any mode / broadcast shape        */
 #define QDAS_KERNEL_TILED   2 /* LDS-staged pixel tiles; error if the case is ineligible */
