@@ -2,9 +2,10 @@
 // das_tile_impl.h -- the fused, LDS-staged delay-and-sum kernel for gfx950 (MI355X).
 //
 // Replaces the reference launch of `DASf` / `DASh` (reference src/bf.cu:153-171, body src/bf.cu:49-142) for the bulk of the
-// work: 'DAS' (sum over both apertures) with fp32 / fp16 data, 'SYN' / 'MUL' (keep one aperture) with fp32 data; scalar sound
-// speed or a per-pixel map; pixel-independent apodization (folded by the host into one N x M table) plus one pixel x receiver
-// array or generated rule.  Everything else is served by das_generic.hip.  Instantiated per launch configuration in
+// work: 'DAS' (sum over both apertures) with fp32 / fp16 / fp64 data, 'SYN' / 'MUL' / 'BF' (kept apertures) with fp32 data; scalar
+// sound speed or a per-pixel map; pixel-independent apodization (folded by the host into one N x M table) plus one pixel x
+// stage-element array (pixel x receiver; pixel x transmit with the roles swapped; pixel only) or generated rule.  Everything
+// else is served by das_generic.hip.  Instantiated per launch configuration in
 // das_tile_{f32,sym,f16,...}.hip (dispatch in das_tile.hip) and, with the plan's sizes as constants, by hiprtc (jit.hip).
 //
 // Design (MI355X-first, not a re-tiling of the reference's one-thread-per-pixel loop):
@@ -20,7 +21,8 @@
 //        t = ra[m] + rb;  k = rint(t) (magic-number add);  s = t - k  in [-1/2, 1/2];
 //        first tap = window[k], weights = even/odd polynomials in s.
 //    "Block" elements (the MB transmits of a stage) and the "stage" element (its receiver) each have a delay kind {distance,
-//    signed distance, plane wave}; for 'MUL' the host swaps the two apertures' roles.
+//    signed distance, plane wave}; for 'MUL' -- and for a full sum with few transmits, or with a pixel x transmit weight -- the
+//    host swaps the two apertures' roles (stage element = transmit, block = 32 receivers).
 //  * For every STAGE (receiver n, block of MB transmits) the workgroup stages MB fast-time WINDOWS (W samples starting at
 //    A[m]+B[n]) of the channel data into LDS with LDS-DMA (tile_staging.h: buffer_load_dwordx4 ... lds: no VGPR round trip, no
 //    ds_write; out-of-buffer lanes deliver 0), coalesced along fast time and double-buffered against the compute of the previous
@@ -34,8 +36,11 @@
 //    loop (edge rule of SURVEY.md section 8 a5).  A tile whose delay spread does not fit W appends itself to a fallback list
 //    and is processed by the generic kernel afterwards -- results never depend on the geometry being "image like".
 //  * A pixel x receiver weight (an I1 x I2 x I3 x N array, or a rule evaluated from the geometry: qdas.h QDAS_RXAPOD_*) does
-//    not depend on the transmit: it multiplies the stage's partial sum once per (pixel, receiver), one stage ahead, and a wave
-//    whose 64 weights are all zero skips the stage's gathers altogether.
+//    not depend on the transmit: it multiplies the stage's partial sum once per (pixel, receiver), loaded one stage ahead; the tile's
+//    STAGE LIST holds only the receivers that carry weight somewhere in the tile (plan_stages), and a wave whose 64 weights are all
+//    zero skips the stage's gathers altogether.
+//  * Pixel-independent weights: the stage's MB table entries go through LDS, fetched one stage ahead by one wave (TileCfg::WST).
+//  * fp64 data: geometry, delays, weights and sums in double, one transmit at a time (tile_pairs.h pairs_f64).
 //  * 'SYN' / 'MUL': a stage belongs to one plane of the output; its sum is added with non-returning fp32 atomics.
 //  * Few tiles (pixel slab of a multi-GPU job, small image): ksplit workgroups per tile, each a slice of the aperture,
 //    partial images reduced in a fixed order.
