@@ -82,3 +82,20 @@ def test_jit_modes_syn_mul_and_pixel_weights(tmp_path, monkeypatch):
         assert "[jit " in p1.kernel_name() and "[prebuilt]" in p0.kernel_name()
         assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) <= 1e-6, fun
         p0.close(); p1.close()
+
+
+@pytest.mark.gpu
+def test_environment_default_builds_the_specialised_kernel(tmp_path, monkeypatch):
+    """QDAS_JIT=1: every das_spec / UltrasoundSystem call asks for the plan-specialised kernel (as the reference compiles its kernel per call)"""
+    import torch
+    from qups_amd import das_spec
+    from tests.cases import make_case
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    case = make_case(seq="PW", interp="linear", seed=3, N=16, M=8, I1=64, I2=8)
+    args = (case["Pi"], case["Pr"], case["Pv"], case["Nv"], torch.from_numpy(case["x"]), case["t0"], case["fs"], case["c"])
+    y0, p0 = das_spec("DAS", *args, *case["opt"], "interp", "linear", return_plan=True)
+    monkeypatch.setenv("QDAS_JIT", "1")
+    y1, p1 = das_spec("DAS", *args, *case["opt"], "interp", "linear", return_plan=True)
+    assert "[prebuilt]" in p0.kernel_name() and "[jit " in p1.kernel_name()
+    a, b = y0.cpu().numpy(), y1.cpu().numpy()
+    assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
