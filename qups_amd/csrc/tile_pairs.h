@@ -9,6 +9,11 @@
 // Accumulators: one per (frame, transmit half) with up to two frames per launch, one per frame with four.
 #pragma once
 
+// priority of a pair-loop quarter (3, 2, 1, 0); tuning builds may shift the staircase below the stage head's priority 3
+#ifndef QDAS_PAIR_PRIO
+#define QDAS_PAIR_PRIO(q) (q)
+#endif
+
 namespace qdas {
 
 // Plain loop.  TAILV = false: full block (reciprocal mode: block entirely above the diagonal), no bounds tests on m.
@@ -28,7 +33,7 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
         // pair loops one after the other and the last one runs alone -- at a fraction of the issue rate -- until the stage barrier.
         // Lowering the priority as a wave advances (3 .. 0 over the block) lets the waves that are BEHIND go first: they finish
         // together.  Measured (profiles/r02/exp_prio.txt): general kernels -5 ... -7 %, reciprocal mode with 32-transmit stages -6 %.
-        if constexpr (!hooks::no_fair_prio && (p * 4) % (MB / 2) == 0) __builtin_amdgcn_s_setprio(3 - (p * 4) / (MB / 2));
+        if constexpr (!hooks::no_fair_prio && (p * 4) % (MB / 2) == 0) __builtin_amdgcn_s_setprio(QDAS_PAIR_PRIO(3 - (p * 4) / (MB / 2)));
         const uint32_t m = m0 + 2 * p;
         if constexpr (TAIL) { if (m >= M) return; }
         if constexpr (DIAG) { if (m + 1 < n) return; }          // both transmits below the diagonal: their pairs were done as mirrors
@@ -224,7 +229,7 @@ __device__ __forceinline__ void Tile<C>::pairs_f64(uint32_t n, uint32_t m0, int 
     weights1_lead<INTERP>(lead);
     unroll<MB>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
-        if constexpr (!hooks::no_fair_prio && (p * 4) % MB == 0) __builtin_amdgcn_s_setprio(3 - (p * 4) / MB);     // fair progress, see pairs_plain
+        if constexpr (!hooks::no_fair_prio && (p * 4) % MB == 0) __builtin_amdgcn_s_setprio(QDAS_PAIR_PRIO(3 - (p * 4) / MB));     // fair progress, see pairs_plain
         const uint32_t m = m0 + p;
         if constexpr (TAILV) { if (m >= M) return; }
         double wr = 1.0, wi = 0.0;
@@ -292,7 +297,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::pairs_pipelined(floa
     index(std::integral_constant<int, 0>{});
     unroll<NU>([&](auto uc) {
         constexpr int u = decltype(uc)::value, p = u / NHP, hp = u % NHP, HSET = FB4 ? 2 * hp + 1 : 1;
-        if constexpr (!hooks::no_fair_prio && (u * 4) % NU == 0) __builtin_amdgcn_s_setprio(3 - (u * 4) / NU);     // fair progress, see pairs_plain
+        if constexpr (!hooks::no_fair_prio && (u * 4) % NU == 0) __builtin_amdgcn_s_setprio(QDAS_PAIR_PRIO(3 - (u * 4) / NU));     // fair progress, see pairs_plain
         taps_t h0, h1;
         if constexpr (F32 && hooks::no_tap_reads) { for (int k = 0; k < 4; ++k) { h0.s[k] = sv[p & 1]; h1.s[k] = (v2f){sv[p & 1].y, sv[p & 1].x}; } }
         else { lds_issue<K, (HSET * MB + 2 * p) * WB>(h0, a0v[p & 1]); lds_issue<K, (HSET * MB + 2 * p + 1) * WB>(h1, a1v[p & 1]); }
