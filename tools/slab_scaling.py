@@ -20,7 +20,7 @@ for world in (1, 2, 4, 8):
     ts = []
     for rank in sorted({0, world // 2, world - 1}):
         b, e = I * rank // world, I * (rank + 1) // world
-        plan = DasPlan(prob, device=dev, i_begin=b, i_count=e - b)
+        plan = DasPlan(prob, device=dev, i_begin=b, i_count=e - b, jit=bool(os.environ.get("QDAS_JIT")))
         plan.set_timing(True)
         k = []
         for _ in range(4):
