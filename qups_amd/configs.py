@@ -20,17 +20,18 @@ def workload(name: str) -> dict:
     apod = None
     rx_apod = None
     prec = "single"
-    if name == "c1":      # 64-el linear array (L7-4-like), 32 focused transmits, 256 x 256, linear interp
+    if name in ("c1", "c1f"):   # 64-el linear array (L7-4-like), 32 focused transmits, 256 x 256, linear interp ("c1f": foci INSIDE the image)
         fc, N, pitch, nx, nz, T, interp = 5.208e6, 64, 0.298e-3, 256, 256, 2048, "linear"
         lam = c0 / fc
         Pr, nrm = G.linear_array(N, pitch)
+        zf = 30e-3 if name == "c1" else 12e-3
         xf = np.linspace(Pr[0, 8], Pr[0, -9], 32)                       # walking aperture, foci at z = 30 mm
-        Pv, Nv, opt = G.sequence_args("FC", focus=np.stack([xf, 0 * xf, 0 * xf + 30e-3]))
+        Pv, Nv, opt = G.sequence_args("FC", focus=np.stack([xf, 0 * xf, 0 * xf + zf]))
         x = (np.arange(nx) - (nx - 1) / 2) * lam / 4
         z = 2e-3 + np.arange(nz) * lam / 4
         Pi = G.scan_cartesian(x, z)
-        t0 = -30e-3 / c0 - 2e-6                                         # t = 0 when the wavefront passes the focus
-        label = "C1: 64-el linear array, 32 focused Tx (FC), 256x256 ScanCartesian lambda/4, T=2048, linear"
+        t0 = -zf / c0 - 2e-6                                            # t = 0 when the wavefront passes the focus
+        label = f"C1: 64-el linear array, 32 focused Tx (FC, foci at {zf * 1e3:g} mm), 256x256 ScanCartesian lambda/4, T=2048, linear"
     elif name == "c2":    # 128 el, 128 plane waves, 512^2, cubic
         fc, N, pitch, nx, nz, T, interp = 5e6, 128, 0.3e-3, 512, 512, 2048, "cubic"
         lam = c0 / fc
