@@ -175,6 +175,7 @@ template <class C> struct Tile {
     __device__ __forceinline__ double a_of(uint32_t m, const GT *gPv, const GT *gNv) const;
     __device__ __forceinline__ double b_at(GT ex, GT ey, GT ez) const;
     __device__ __forceinline__ double s_at(uint32_t n, GT ex, GT ey, GT ez) const;
+    __device__ __forceinline__ bool on_side(uint32_t n, GT ex, GT ey, GT ez) const;
     // geometry tables in the plan's real type (TileParams carries them as float pointers)
     __device__ __forceinline__ const GT *geo_Pi() const { return (const GT *)P.Pi; }
     __device__ __forceinline__ const GT *geo_Pr() const { return (const GT *)P.Pr; }
@@ -298,7 +299,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
     // reciprocal mode: a(i,m) = b(i,m) + C with C = OFF - t0*fs, so A[m] := B[m] + floor(C)
     symC = 0.0; symCi = 0;
     if constexpr (C::SYM) { symC = tapinfo<C::INTERP>::OFF - (double)geo_Pv()[3] * fs; symCi = (int)floor(symC); }
-    xbytes = (uint64_t)N * M * (uint64_t)T * C::SB;
+    xbytes = (uint64_t)(N >> (C::ACT ? P.stage_shift : 0)) * M * (uint64_t)T * C::SB;
 }
 
 // ------------------------------------------------------------------------------------------------- delays
@@ -330,15 +331,25 @@ template <class C> __device__ __forceinline__ double Tile<C>::s_at(uint32_t n, G
     const double rx = (double)qx - (double)ex, ry = (double)qy - (double)ey, rz = (double)qz - (double)ez;
     const double dot = kindS ? rx * (double)P.St[4 * n + 1] + ry * (double)P.St[4 * n + 2] + rz * (double)P.St[4 * n + 3] : 0.0;
     double dv = dot;
-    if (kindS != 2) { const double len = dsqrt(rx * rx + ry * ry + rz * rz); dv = kindS == 0 ? len : copysign(len, dot); }
+    if (kindS != 2) { const double len = dsqrt(rx * rx + ry * ry + rz * rz); dv = kindS == 0 ? len : ((C::ACT && kindS == 3) ? ((n & 1u) ? len : -len) : copysign(len, dot)); }
     return dv * cf - (double)P.St[4 * n] * fs;
 }
 
 // ---- per-(pixel, receiver) apodization (optional; uniform runtime switch, nothing of it in the pair loop)
 // Two halves: the LOAD (raw bits, requested a stage ahead) and the CONVERSION to fp32 (done where the weight is used).  As one
 // expression the conversion was scheduled right behind the load: every stage then waited out a full global-memory latency.
+// kindS == 3: is my pixel on the side of the focal plane that stage element n (transmit n >> 1, side n & 1) stands for?  The sign test of
+// src/bf.cu:107 (copysign: a zero dot product counts as behind the plane), evaluated in fp64 like the delay itself.
+template <class C> __device__ __forceinline__ bool Tile<C>::on_side(uint32_t n, GT ex, GT ey, GT ez) const {
+    const double rx = (double)px - (double)ex, ry = (double)py - (double)ey, rz = (double)pz - (double)ez;
+    const double dot = rx * (double)P.St[4 * n + 1] + ry * (double)P.St[4 * n + 2] + rz * (double)P.St[4 * n + 3];
+    return (__builtin_signbit(dot) != 0) == ((n & 1u) == 0u);
+}
 template <class C> __device__ __forceinline__ typename Tile<C>::wraw Tile<C>::wload_raw(uint32_t n) const {
     const int gen_kind = QSPEC(GEN_KIND, P.gen_kind);
+    if constexpr (C::ACT && !C::LUT) {
+        if (gen_kind == 5) { const float4 e = nrec[n]; return wraw{on_side(n, e.y, e.z, e.w) ? 0x3f800000u : 0u, 0u}; }
+    }
     if (!C::SYM && gen_kind) {                        // qdas.h QDAS_RXAPOD_*: element from the LDS record (never in reciprocal mode)
         const float4 e = nrec[n];
         return wraw{__float_as_uint(rx_apod_generated(gen_kind, P.gen_p0, P.gen_p1, px, py, pz, e.y, e.z, e.w, P.rxn, n)), 0u};
@@ -462,7 +473,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         front_entry(pk + 1 == klim(pm0) ? 0u : pk + 1);             // of the stage after this one
     };
     auto dma_go = [&](int buf) {
-        if constexpr (C::ACT) { if (use_act) soff = (dpn - n_lo) * (uint32_t)strN * (uint32_t)C::SB; }   // (stage lists with gaps: no running offset)
+        if constexpr (C::ACT) { if (use_act) soff = ((dpn >> P.stage_shift) - (n_lo >> P.stage_shift)) * (uint32_t)strN * (uint32_t)C::SB; }   // (stage lists with gaps: no running offset)
         stage_dma(dbn, buf);
         if (++pk == klim(pm0)) { pk = 0; pm0 = blk(++pr); dma_block(pm0); }
     };

@@ -70,6 +70,7 @@ struct qdas_plan {
     TileConfig tc{};
     unsigned ntiles = 0, tile_cols = 0;
     bool no_fallback = false;                 // the probe found no tile whose delay spread exceeds the LDS window
+    double misfit_frac = 0.0;                 // fraction of the chosen footprint's tiles that do not fit it
     bool fb2_ok = false;                      // frames of a sequence may share launches, 4 or 2 at a time (decided at plan creation)
     bool fb4_off = false;                     // ... but at most pairwise (QDAS_NO_FB4)
     uint32_t *fallback = nullptr;             // device: [0] = count, [1..ntiles]
@@ -266,6 +267,7 @@ static int choose_tile_shape(qdas_plan *pl, const qdas_desc *desc, F &&set_grid)
     if (best_t < 0) { best_t = env_tz ? lg(env_tz) : 6; best_w = best_t; }
     // the window fit depends on the geometry only: a footprint without misfits never needs the per-frame fallback pass
     pl->no_fallback = fbn[best_t] == 0.0;
+    pl->misfit_frac = fbn[best_t];
     HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));
     set_grid(best_t);
     t.wz_log2 = best_w;
@@ -497,6 +499,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         }
         t.apix_pixel_only = pix_only ? 1 : 0;
         t.act_bytes = (t.apix || t.gen_kind) ? (uint32_t)(8 * (t.N + 1)) : 0u;
+        std::vector<float> host_tab;                    // the folded N x M table as uploaded ([stage element + stages * block element])
         if (z.S > 0 && dt == QDAS_F64) {                // fp64 data: the same table in double (complex128 entries)
             std::vector<double> tab(2 * z.N * z.M);
             for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.0; tab[2 * k + 1] = 0.0; }
@@ -520,7 +523,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e)));
             t.wtab = dtab;
         } else if (z.S > (pix_arr >= 0 ? 1u : 0u)) {
-            std::vector<float> tab(2 * z.N * z.M);
+            std::vector<float> &tab = host_tab;
+            tab.assign(2 * z.N * z.M, 0.f);
             for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.f; tab[2 * k + 1] = 0.f; }
             for (uint64_t s = 0; s < z.S; ++s) {
                 if ((int)s == pix_arr) continue;
@@ -557,6 +561,60 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             pl->tc = tile_config(dt, 1, 0);
             if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
         }
+        // Focused transmits whose focal planes cut through the image: the delay flips sign there (src/bf.cu:106-108), so the tiles a plane
+        // crosses fit no window and would go to the generic kernel -- with a walking aperture that is half the image.  Second attempt:
+        // every transmit listed twice, once per side of its plane (tile_params.h kindS == 3); kept if fewer tiles misfit.
+        uint64_t kN_eff = kN;
+        if (!pl->no_fallback && txkind == 1 && !syn && !bfm && !sym && !big && pix_arr < 0 && !g.gen_kind && (dt == QDAS_F32 || dt == QDAS_F16)
+            && z.M < (1u << 15) && tile_lds_bytes(dt, 0, 2 * z.M, z.N, 0, 1, wtb) <= tile_lds_limit(0) && !getenv("QDAS_NO_SIDE_SPLIT")) {
+            const TileParams keep = t;
+            const double keep_frac = pl->misfit_frac;
+            const unsigned keep_ntiles = pl->ntiles, keep_cols = pl->tile_cols;
+            std::vector<float> hr(3 * z.N), hv(4 * z.M), hn(3 * z.M);
+            if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
+            if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);
+            if ((rc = fetch_host(desc->Nv, hn.size() * 4, desc->mem, hn.data()))) return bail(rc);
+            const uint64_t E = 2 * z.M;                  // stage elements: (transmit, side)
+            std::vector<float> spos(3 * E), sst(4 * E), bpos(4 * z.N), bnrm(3 * z.N, 0.f);
+            for (uint64_t e = 0; e < E; ++e) {
+                const uint64_t m = e >> 1;
+                for (int k = 0; k < 3; ++k) { spos[3 * e + k] = hv[4 * m + k]; sst[4 * e + 1 + k] = hn[3 * m + k]; }
+                sst[4 * e] = hv[4 * m + 3];
+            }
+            for (uint64_t n = 0; n < z.N; ++n) { for (int k = 0; k < 3; ++k) bpos[4 * n + k] = hr[3 * n + k]; bpos[4 * n + 3] = 0.f; }
+            const void *d0, *d1, *d2, *d3;
+            if ((rc = import_array(pl, spos.data(), spos.size() * 4, QDAS_MEM_HOST, &d0))) return bail(rc);
+            if ((rc = import_array(pl, sst.data(), sst.size() * 4, QDAS_MEM_HOST, &d1))) return bail(rc);
+            if ((rc = import_array(pl, bpos.data(), bpos.size() * 4, QDAS_MEM_HOST, &d2))) return bail(rc);
+            if ((rc = import_array(pl, bnrm.data(), bnrm.size() * 4, QDAS_MEM_HOST, &d3))) return bail(rc);
+            t.Pr = (const float *)d0; t.St = (const float *)d1; t.Pv = (const float *)d2; t.Nv = (const float *)d3;
+            t.N = E; t.M = z.N;
+            t.strN = tp ? z.T : z.T * z.N;               // stage element = transmit, block element = receiver
+            t.strM = tp ? z.T * z.M : z.T;
+            t.kindB = 0; t.kindS = 3; t.stage_shift = 1;
+            t.gen_kind = 5; t.gen_p0 = t.gen_p1 = 0.0; t.rxn = nullptr; t.apix = nullptr;
+            t.act_bytes = (uint32_t)(8 * (E + 1));
+            if (t.wtab) {                                // the table in the new element order: [(2m + side) + 2M * n]
+                std::vector<float> tab2(2 * E * z.N);
+                for (uint64_t n = 0; n < z.N; ++n)
+                    for (uint64_t e = 0; e < E; ++e) {
+                        const uint64_t m = e >> 1, q = swap ? (m + z.M * n) : (n + z.N * m);
+                        tab2[2 * (e + E * n)] = host_tab[2 * q]; tab2[2 * (e + E * n) + 1] = host_tab[2 * q + 1];
+                    }
+                void *dtab2;
+                if ((rc = dev_alloc(pl, &dtab2, tab2.size() * sizeof(float)))) return bail(rc);
+                hipError_t e2 = hipMemcpy(dtab2, tab2.data(), tab2.size() * sizeof(float), hipMemcpyHostToDevice);
+                if (e2 != hipSuccess) return bail(fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e2)));
+                t.wtab = dtab2;
+            }
+            if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
+            if (pl->misfit_frac < keep_frac) kN_eff = E;
+            else {                                       // no better: the plan as it was
+                t = keep;
+                pl->misfit_frac = keep_frac; pl->no_fallback = keep_frac == 0.0; pl->ntiles = keep_ntiles; pl->tile_cols = keep_cols;
+                HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));
+            }
+        }
         // Too few tiles for the GPU (a pixel slab of a multi-GPU job, a small image): several workgroups per tile, each summing a
         // slice of the aperture (das_tile_impl.h) until every CU has a workgroup.  QDAS_KSPLIT overrides.
         {
@@ -564,7 +622,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device));
             const unsigned cus = ncu > 0 ? (unsigned)ncu : 256u;
             const uint64_t nmb = (z.M + pl->tc.mb - 1) / pl->tc.mb;
-            const unsigned cap = (unsigned)std::min<uint64_t>(8, sym ? nmb : kN);
+            const unsigned cap = (unsigned)std::min<uint64_t>(8, sym ? nmb : kN_eff);
             unsigned ks = 1;
             while (ks * 2 <= cap && (uint64_t)pl->ntiles * ks < (uint64_t)cus) ks *= 2;   // (a split costs one more prologue per tile)
             if (const char *e = getenv("QDAS_KSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8 && (unsigned)v <= cap) ks = (unsigned)v; }
@@ -618,7 +676,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; }
         else { pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel"; }
     }
-    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->jit_fn && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
+    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->tp.stage_shift && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->jit_fn && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
     // four frames per launch: not for fp32 plans with remodulation, a weight table or a pixel x receiver weight (das_tile_impl.h launch_tile_i)
     pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr
                   || (dt == QDAS_F32 && pl->kernel == QDAS_KERNEL_TILED && (pl->tp.fmod != 0.0 || pl->tp.wtab || pl->tp.apix || pl->tp.gen_kind));

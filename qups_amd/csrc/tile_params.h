@@ -11,6 +11,12 @@ struct TileParams {
     // 2 plane wave.  'DAS' / 'SYN': block = transmits, stage = receivers; 'MUL': roles (and N, M, strN, strM, wtab) swapped by the host.
     const float *Pi, *Pr, *Pv, *Nv, *St;
     int32_t kindB, kindS;
+    // kindS == 3: ONE-SIDED signed distance.  A focused transmit's delay flips sign at the plane through its focus ((Pi - Pv).Nv = 0,
+    // src/bf.cu:106-108): discontinuous, so a tile that the plane crosses has no window that fits.  The host then lists every transmit twice
+    // -- stage element 2m: the pixels BEFORE the plane (delay -|r|), 2m + 1: those behind it (+|r|) -- with gen_kind 5 (1 on the element's
+    // side, else 0) as its pixel weight: each side is smooth, lanes of the other side stay out of the window bases, and the tile's stage
+    // list drops the side it does not have.  stage_shift = 1: stage element e reads the traces of transmit e >> 1.
+    int32_t stage_shift;
     const void *x;
     void *y;
     const void *wtab;                   // optional N x M table of folded apodization weights (float2), may be null

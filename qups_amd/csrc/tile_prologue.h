@@ -23,7 +23,9 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
     // The window bases / extents only need the delays to a small fraction of a sample: fp32 estimates with an explicit error
     // margin (DLT, below) -- a quarter of the fp64 cost.  Focused transmits keep fp64: their delay flips sign with
     // (Pi - Pv).Nv (copysign, src/bf.cu:107) and the two precisions must agree on the sign of a dot product that may be ~0.
-    const bool pro32 = !LUT && kindB != 1 && kindS != 1;
+    const bool pro32 = !LUT && kindB != 1 && kindS != 1 && kindS != 3;
+    const bool one_sided = C::ACT && !LUT && kindS == 3;     // stage elements that stand for ONE side of a focal plane (tile_params.h): the lanes
+                                                           // of the other side stay out of the element's window base (NaN = "not mine" below)
     const float cf32 = (float)cf, fs32 = (float)fs;
     auto a_est = [&](uint32_t m) -> float {
         if (!pro32) return (float)a_of(m, gPv, gNv);
@@ -34,6 +36,9 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
     auto b_est = [&](uint32_t n) -> float {
         if constexpr (LUT) return P.lut_rx[ipx + Ilut * n];
         if (kindS == 1) return (float)s_at(n, gPr[3 * n], gPr[3 * n + 1], gPr[3 * n + 2]);
+        if constexpr (C::ACT) {                          // (only the single-frame general kernels run such plans)
+            if (kindS == 3) return on_side(n, gPr[3 * n], gPr[3 * n + 1], gPr[3 * n + 2]) ? (float)s_at(n, gPr[3 * n], gPr[3 * n + 1], gPr[3 * n + 2]) : __builtin_nanf("");
+        }
         const float rx = (float)(px - gPr[3 * n]), ry = (float)(py - gPr[3 * n + 1]), rz = (float)(pz - gPr[3 * n + 2]);
         if (!has_st) return __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz) * cf32;
         if (kindS == 0) return __builtin_amdgcn_sqrtf(rx * rx + ry * ry + rz * rz) * cf32 - P.St[4 * n] * fs32;
@@ -42,10 +47,14 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
     // |fp32 estimate - fp64 delay| <= ~4e-7 * (|distance*cf| + |t0*fs|), and |distance*cf| <= |a| + |t0*fs| + 1: 1e-6 is generous
     auto margin = [](float mn, float mx, float t0fs) -> float { return 1.0e-6f * (fmaxf(fabsf(mn), fabsf(mx)) + 2.0f * fabsf(t0fs) + 2.0f); };
     // (four elements per pass: independent reduction chains overlap)
-    auto minmax4 = [&](float (&v)[4], uint32_t e0, uint32_t cnt, uint32_t c0) {
+    auto minmax4 = [&](float (&v)[4], uint32_t e0, uint32_t cnt, uint32_t c0, bool neutral) {
         float lo[4], hi[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { lo[q] = hi[q] = (v[q] == v[q]) ? v[q] : INFINITY; }   // a NaN delay poisons the tile's extent
+        for (int q = 0; q < 4; ++q) {                   // a NaN delay poisons the tile's extent -- unless it means "this lane is not the element's"
+            const bool ok = v[q] == v[q];
+            lo[q] = ok ? v[q] : INFINITY;
+            hi[q] = ok ? v[q] : (neutral ? -INFINITY : INFINITY);
+        }
         wave_minmax63x4(lo, hi);
         if (lane == 63) {
 #pragma unroll
@@ -59,7 +68,7 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = a_est(m + q < M ? m + q : M - 1);
-            minmax4(v, m, c1, c0);
+            minmax4(v, m, c1, c0, false);
         }
         __syncthreads();
         for (uint32_t m = c0 + tid; m < c1; m += THREADS) {
@@ -84,7 +93,7 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
         float v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = b_est(n + q < N ? n + q : N - 1);
-        minmax4(v, n, c1, c0);
+        minmax4(v, n, c1, c0, one_sided);
       }
       __syncthreads();
       for (uint32_t n = c0 + tid; n < c1; n += THREADS) {
@@ -94,15 +103,17 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
         float t0fs = 0.f;
         if constexpr (SYM) t0fs = (float)gPv[3] * fs32;
         else if constexpr (!LUT) t0fs = has_st ? P.St[4 * n] * fs32 : 0.f;
+        const bool nobody = one_sided && mx < mn;        // no pixel of the tile on this element's side: never staged (its weights are all zero)
+        if (nobody) { mn = 0.f; mx = 0.f; }
         const float dlt = margin(mn, mx, t0fs);
         const float fl = floorf(mn - dlt) - 1.0f;
         const bool fin = fabsf(fl) < 1.0e9f;
-        const float e = fin ? ((mx + dlt) - fl) + 0.01f : INFINITY;
+        const float e = nobody ? 0.0f : (fin ? ((mx + dlt) - fl) + 0.01f : INFINITY);
         if constexpr (LUT) nrec[n] = make_float4(__int_as_float(fin ? (int)fl : 0), 0.f, 0.f, 0.f);
         else if constexpr (C::F64) nrec64[n] = rec64{gPr[3 * n], gPr[3 * n + 1], gPr[3 * n + 2], fin ? (int)fl : 0, 0};
         else nrec[n] = make_float4(__int_as_float(fin ? (int)fl : 0), gPr[3 * n], gPr[3 * n + 1], gPr[3 * n + 2]);
         Bext[n] = e;
-        b_lo = fminf(b_lo, fl); b_hi = fmaxf(b_hi, fl + e); b_ext = fmaxf(b_ext, e);
+        if (!nobody) { b_lo = fminf(b_lo, fl); b_hi = fmaxf(b_hi, fl + e); b_ext = fmaxf(b_ext, e); }
         if constexpr (SYM) {                             // a - A = (b - B) + frac(C) in [1, Bext + 1)
             Abase[n] = (fin ? (int)fl : 0) + symCi;
             Aext[n] = e + 1.0f;

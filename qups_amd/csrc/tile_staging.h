@@ -32,7 +32,7 @@ template <class C> __device__ __forceinline__ int Tile<C>::wjr(int r) const {
 
 template <class C> __device__ __forceinline__ void Tile<C>::dma_block(uint32_t m0) {
     constexpr int SB = C::SB;
-    const uint64_t o = ((uint64_t)m0 * strM + (uint64_t)n_lo * strN) * SB;
+    const uint64_t o = ((uint64_t)m0 * strM + (uint64_t)(n_lo >> (C::ACT ? P.stage_shift : 0)) * strN) * SB;
     if constexpr (C::SYM || C::BIG) offD = o;
     rsD = make_rs(o, (uint64_t)fa * P.x_fstride);
     soff = 0;

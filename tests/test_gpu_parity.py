@@ -88,6 +88,35 @@ def test_das_tiled_matches_oracle(seq, interp):
         assert rel_err(out, ref) <= tol_for(interp, 2)
 
 
+@pytest.mark.parametrize("interp,prec", [("cubic", "single"), ("lanczos3", "single"), ("linear", "halfT"), ("nearest", "single")])
+def test_focused_transmits_with_the_foci_inside_the_image(interp, prec, monkeypatch):
+    """the delay of a focused transmit flips sign at the plane through its focus (src/bf.cu:106-108): a tile that the plane crosses has no
+    window that fits.  The plan lists every transmit twice -- once per side of its plane, the pixels of the other side weighted 0 -- and
+    the image runs fused without fallback tiles (das_tile_impl.h / tile_params.h kindS == 3); weights and per-transmit t0 included"""
+    rng = np.random.default_rng(31)
+    case = make_case(seq="FC", interp=interp, seed=35, N=24, M=10, I1=190, I2=40, zlim=(3e-3, 17e-3), xspan=8e-3)
+    x = case["x"]
+    q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else f32r
+    if prec == "halfT":
+        x = x.real.astype(np.float16).astype(np.float64) + 1j * x.imag.astype(np.float16).astype(np.float64)
+    wn = q(rng.uniform(0.3, 1, (1, 1, 1, 24, 1)))
+    wm = q(rng.uniform(0.3, 1, (1, 1, 1, 1, 10)))
+    t0 = (case["t0"] + np.float32(1.0 / case["fs"]) * rng.integers(-2, 3, (1, 1, 10))).astype(np.float32).astype(np.float64)
+    ref = run_oracle(case, apod=(wn, wm), x=x, t0=t0)
+    out, plan = run_das(case, kernel=2, prec=prec, apod=(wn, wm), t0=t0)
+    assert plan.kernel == "tiled" and "roles swapped" in plan.kernel_name() and plan.fallback_tiles() == 0, (plan.kernel_name(), plan.fallback_tiles())
+    # at the planes themselves the fp32 geometry of the kernel and the float64 oracle may disagree on the sign of a dot product that is ~0
+    e = np.abs(out - ref).reshape(-1) / np.abs(ref).max()
+    tol = {"single": 1e-2 if interp == "nearest" else 1e-4, "halfT": 3e-3}[prec]
+    assert np.median(e) <= tol / 10 and (e > tol).mean() <= 0.01, (np.median(e), (e > tol).mean(), e.max())
+    monkeypatch.setenv("QDAS_NO_SIDE_SPLIT", "1")
+    out2, plan2 = run_das(case, kernel=2, prec=prec, apod=(wn, wm), t0=t0)
+    if prec == "single":
+        assert plan2.fallback_tiles() > 0                             # (what the plan was before: those tiles on the generic kernel; fp16 windows are twice as long)
+    e2 = np.abs(out2 - out).reshape(-1) / np.abs(ref).max()
+    assert (e2 > tol).mean() <= 0.01
+
+
 def test_tiled_and_generic_agree_on_noise():
     """white-noise data (what the reference's own benchmark feeds, test/ParTest.m:254-257)"""
     case = make_case(seq="FSA", interp="lanczos3", seed=3, data="noise", I1=130, I2=9)
