@@ -17,6 +17,7 @@
 #include "das_tile_luth.hip"
 #include "das_tile_bf.hip"
 #include "das_tile_f64.hip"
+#include "das_tile_f32w.hip"
 #else
 #include "qdas_device.h"
 #include "das_tile_cfg.h"
@@ -40,6 +41,7 @@ hipError_t launch_tile_lut(const TileParams &P, unsigned ntiles, size_t lds, hip
 hipError_t launch_tile_luth(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_bf(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f64(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
+hipError_t launch_tile_f32w(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 
 // y[i] = sum over the ksplit partial images, in split order (deterministic)
 // (fp64 data: complex128 partial images)
@@ -100,7 +102,8 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
         tile_reduce_kernel_f64<<<(unsigned)((P.i_count + 255) / 256), 256, 0, s>>>((const double2 *)P.part, (double2 *)P.y, P.i_count, P.ksplit);
         return hipGetLastError();
     }
-    const int narrow = (sym && dtype == 1 && P.narrow) ? 1 : 0;
+    const int narrow = (sym && dtype == 1 && P.narrow) ? 1 : (!sym && dtype == 1 && P.narrow == 2) ? 2 : 0;     // window variant (das_tile_cfg.h)
+    if (narrow == 2 && (P.lut_tx || P.bf || P.big || (!P.probe && P.nfr > 1))) return hipErrorInvalidValue;
     if (P.act_bytes != 0 && P.act_bytes != 8 * (P.N + 1)) return hipErrorInvalidValue;
     const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M, narrow, P.act_bytes ? 1 : 0, P.wtab ? 1 : 0);    // (the two-frame configurations have the same LDS image)
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
@@ -113,7 +116,7 @@ const int nf = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
     hipError_t e = jit ? jit_launch(jit, P, ntiles * P.ksplit, (unsigned)CFGS[cfg_index(dtype, sym, 1, narrow)].waves * 64u, jit_lds ? jit_lds : lds, s) : P.lut_tx ? (dtype == 2 ? launch_tile_luth(P, ntiles, lds, s) : launch_tile_lut(P, ntiles, lds, s)) : sym ? (dtype == 2 ? launch_tile_symh(P, ntiles, lds, s) : narrow ? launch_tile_symw(P, ntiles, lds, s) : launch_tile_sym(P, ntiles, lds, s))
                  : nf == 4 ? (dtype == 2 ? launch_tile_f16x4(P, ntiles, lds, s) : launch_tile_f32x4(P, ntiles, lds, s))
                  : nf == 2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))
-                           : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : (P.bf && !P.probe) ? launch_tile_bf(P, ntiles, lds, s) : (P.big && !P.probe) ? launch_tile_f32big(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));
+                           : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : narrow == 2 ? launch_tile_f32w(P, ntiles, lds, s) : (P.bf && !P.probe) ? launch_tile_bf(P, ntiles, lds, s) : (P.big && !P.probe) ? launch_tile_f32big(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));
     if (e != hipSuccess || P.probe || P.ksplit <= 1 || P.syn || P.bf) return e;   // ('SYN' planes are accumulated in place, 'BF' planes stored by their owners)
     const unsigned rb = (unsigned)((P.i_count + 255) / 256);
     for (int f = 0; f < nf; ++f) {                       // partial images: [split][frame][pixel]

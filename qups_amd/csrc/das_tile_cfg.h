@@ -17,10 +17,13 @@ struct Cfg { int waves, mb, w, nbuf, psz, bpc; };
 // cfg 11: cfg 2 (fp16 data) with table-driven delays
 // cfg 12: cfg 0 keeping BOTH aperture dimensions ('BF': one output plane per (receiver, transmit) pair, nothing is summed)
 // cfg 13: fp64 data (16-byte samples): 16 transmits per stage, 192-sample windows -- the LDS image of cfg 0
-static constexpr Cfg CFGS[14] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1},
+// cfg 14: fp32 data with 384-sample windows and 16 transmits per stage (the LDS image of cfg 0): the second attempt of a plan whose
+//         tiles do not fit 192 samples -- pixel grids coarser than about lambda/2 (volumes, previews), steep delay gradients
+static constexpr Cfg CFGS[15] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1},
                                 {16, 16, 192, 2, 16, 1}, {16, 16, 384, 2, 16, 1}, {16, 8, 192, 2, 16, 1}, {16, 8, 384, 2, 16, 1},
                                 {16, 16, 128, 2, 16, 1}, {16, 16, 256, 2, 16, 1}, {16, 32, 192, 2, 16, 1}, {16, 32, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1}, {16, 32, 192, 2, 16, 1},
-                                {16, 16, 192, 2, 16, 1}};
+                                {16, 16, 192, 2, 16, 1}, {16, 16, 384, 2, 16, 1}};
 // fb: frames per launch (1 | 2 | 4)
-static inline int cfg_index(int dtype, int sym, int fb = 1, int narrow = 0) { return dtype == 0 ? 13 : sym ? (dtype == 2 ? 8 : (narrow ? 7 : 1)) : (fb == 4 ? (dtype == 2 ? 6 : 5) : (fb == 2 ? (dtype == 2 ? 4 : 3) : (dtype == 2 ? 2 : 0))); }
+// narrow: window variant -- 1: reciprocal mode with 128-sample windows (cfg 7); 2: general mode, fp32 data, 384-sample windows (cfg 14)
+static inline int cfg_index(int dtype, int sym, int fb = 1, int narrow = 0) { return dtype == 0 ? 13 : (!sym && narrow == 2 && dtype == 1 && fb == 1) ? 14 : sym ? (dtype == 2 ? 8 : (narrow ? 7 : 1)) : (fb == 4 ? (dtype == 2 ? 6 : 5) : (fb == 2 ? (dtype == 2 ? 4 : 3) : (dtype == 2 ? 2 : 0))); }
 }  // namespace qdas

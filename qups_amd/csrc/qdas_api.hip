@@ -615,6 +615,25 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
                 HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));
             }
         }
+        // Tiles that still do not fit (a pixel grid coarser than about lambda/2 -- volumes, previews --, steep delay gradients): fp32 plans
+        // try the 384-sample windows of launch configuration 14 (16 transmits per stage, same LDS image); kept if fewer tiles misfit.
+        // (a reciprocal plan gives up its mode for them: an image on the generic kernel costs ten times more than the shared index work saves)
+        if (!pl->no_fallback && dt == QDAS_F32 && !bfm && !big && !getenv("QDAS_NO_WIDE")
+            && tile_lds_bytes(dt, 0, t.N, t.M, 2, t.act_bytes ? 1 : 0, t.wtab ? 1 : 0) <= tile_lds_limit(0)
+            && ((uint64_t)t.N * t.strN + (uint64_t)tile_config(dt, 0, 2).mb * t.strM) * data_size(dt) + 65536 < (1ull << 31)) {
+            const TileParams keep = t;
+            const TileConfig keep_tc = pl->tc;
+            const double keep_frac = pl->misfit_frac;
+            const unsigned keep_ntiles = pl->ntiles, keep_cols = pl->tile_cols;
+            t.narrow = 2; t.sym = 0;
+            pl->tc = tile_config(dt, 0, 2);
+            if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
+            if (!(pl->misfit_frac < keep_frac)) {
+                t = keep; pl->tc = keep_tc;
+                pl->misfit_frac = keep_frac; pl->no_fallback = keep_frac == 0.0; pl->ntiles = keep_ntiles; pl->tile_cols = keep_cols;
+                HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));
+            }
+        }
         // Too few tiles for the GPU (a pixel slab of a multi-GPU job, a small image): several workgroups per tile, each summing a
         // slice of the aperture (das_tile_impl.h) until every CU has a workgroup.  QDAS_KSPLIT overrides.
         {
@@ -622,7 +641,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device));
             const unsigned cus = ncu > 0 ? (unsigned)ncu : 256u;
             const uint64_t nmb = (z.M + pl->tc.mb - 1) / pl->tc.mb;
-            const unsigned cap = (unsigned)std::min<uint64_t>(8, sym ? nmb : kN_eff);
+            const unsigned cap = (unsigned)std::min<uint64_t>(8, t.sym ? nmb : kN_eff);
             unsigned ks = 1;
             while (ks * 2 <= cap && (uint64_t)pl->ntiles * ks < (uint64_t)cus) ks *= 2;   // (a split costs one more prologue per tile)
             if (const char *e = getenv("QDAS_KSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8 && (unsigned)v <= cap) ks = (unsigned)v; }
@@ -642,7 +661,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         const TileParams &t = pl->tp;
         JitSpec k{};
         k.interp = (z.flag & 7) == 4 ? 1 : (z.flag & 7); k.dtype = dt; k.fmod = t.fmod != 0.0; k.wtab = t.wtab != nullptr; k.sym = t.sym; k.big = t.big;
-        const int narrow = (t.sym && dt == QDAS_F32 && t.narrow) ? 1 : 0;
+        const int narrow = (t.sym && dt == QDAS_F32 && t.narrow) ? 1 : (!t.sym && dt == QDAS_F32 && t.narrow == 2) ? 2 : 0;
         const Cfg &cg = CFGS[cfg_index(dt, t.sym, 1, narrow)];
         k.waves = cg.waves; k.mb = cg.mb; k.w = cg.w; k.nbuf = cg.nbuf;
         k.N = t.N; k.M = t.M; k.T = t.T; k.I1 = t.I1; k.strN = t.strN; k.strM = t.strM;
@@ -676,7 +695,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; }
         else { pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel"; }
     }
-    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->tp.stage_shift && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->jit_fn && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
+    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->tp.stage_shift && pl->tp.narrow != 2 && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->jit_fn && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
     // four frames per launch: not for fp32 plans with remodulation, a weight table or a pixel x receiver weight (das_tile_impl.h launch_tile_i)
     pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr
                   || (dt == QDAS_F32 && pl->kernel == QDAS_KERNEL_TILED && (pl->tp.fmod != 0.0 || pl->tp.wtab || pl->tp.apix || pl->tp.gen_kind));

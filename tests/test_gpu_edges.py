@@ -164,6 +164,7 @@ def test_channel_data_larger_than_4_GiB(kernel, tpose, monkeypatch):
     import torch
     from qups_amd import das_spec
     from qups_amd import geometry as G
+    monkeypatch.setenv("QDAS_NO_WIDE", "1")                              # (likewise: the twin alone would get the 384-sample windows the re-basing configuration has not)
     monkeypatch.setenv("QDAS_NO_ROLE_SWAP", "1")                          # (the 8-transmit twin would otherwise run with the apertures' roles swapped: another summation order)
     T, N, M, Ml = 4096, 256, 520, 8                                       # 4096 * 256 * 520 * 8 B = 4.36 GB
     fc, c0 = 5e6, 1540.0

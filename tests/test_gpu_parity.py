@@ -110,6 +110,7 @@ def test_focused_transmits_with_the_foci_inside_the_image(interp, prec, monkeypa
     tol = {"single": 1e-2 if interp == "nearest" else 1e-4, "halfT": 3e-3}[prec]
     assert np.median(e) <= tol / 10 and (e > tol).mean() <= 0.01, (np.median(e), (e > tol).mean(), e.max())
     monkeypatch.setenv("QDAS_NO_SIDE_SPLIT", "1")
+    monkeypatch.setenv("QDAS_NO_WIDE", "1")                               # (nor the 384-sample windows that would swallow this small case)
     out2, plan2 = run_das(case, kernel=2, prec=prec, apod=(wn, wm), t0=t0)
     if prec == "single":
         assert plan2.fallback_tiles() > 0                             # (what the plan was before: those tiles on the generic kernel; fp16 windows are twice as long)
@@ -386,14 +387,23 @@ def test_edges_and_out_of_record():
             assert rel_err(out, ref) <= tol, (interp, kernel)
 
 
-def test_oversize_window_falls_back():
-    """pixel spacing so coarse (24 samples of delay per pixel) that even the shortest tile spans more than the LDS window"""
+def test_oversize_window_falls_back(monkeypatch):
+    """pixel spacing so coarse (24 samples of delay per pixel) that even the shortest tile spans more than the 192-sample LDS window: those
+    tiles are redone by the generic kernel -- unless the plan's second attempt, 384-sample windows (launch configuration 14), fits them"""
     case = make_case(seq="FSA", interp="linear", seed=15, I1=64, I2=4, zlim=(2e-3, 60e-3), data="noise", N=8)
     ref = run_oracle(case)
+    out, plan = run_das(case, kernel=0)
+    assert plan.kernel == "tiled" and plan.fallback_tiles() == 0 and "W=384" in plan.kernel_name(), plan.kernel_name()
+    assert rel_err(out, ref) <= 3e-5
+    monkeypatch.setenv("QDAS_NO_WIDE", "1")
     out, plan = run_das(case, kernel=0)
     assert plan.kernel == "tiled" and plan.tile_shape()[0] < 64             # the footprint with the smallest misfit fraction
     assert plan.fallback_tiles() > 0
     assert rel_err(out, ref) <= 3e-4
+    case = make_case(seq="PW", interp="cubic", seed=16, I1=60, I2=6, zlim=(2e-3, 120e-3), data="noise", N=8, M=4)      # 49 samples per pixel: beyond both
+    monkeypatch.delenv("QDAS_NO_WIDE")
+    out, plan = run_das(case, kernel=0)
+    assert plan.fallback_tiles() > 0 and rel_err(out, run_oracle(case)) <= 3e-4
 
 
 def test_delays():
