@@ -40,6 +40,8 @@ def _draw(seed):
         cfg.update(prec="double", fmod=0.0, wpix=False, gen="", fun="DAS", cmap=False, jit=False)
     # a pixel x TRANSMIT weight (scanline-style transmit apodization): fused with the roles of the apertures swapped
     cfg["wpm"] = bool(r.integers(0, 10) == 0) and cfg["fun"] == "DAS" and not cfg["wpix"] and not cfg["gen"] and not cfg["sym"] and cfg["prec"] != "double"
+    # pixel pitch: ~lambda/3 (2.6 samples of delay per pixel), ~lambda (the 384-sample windows of the second attempt), ~1.6 lambda (tiles that fall back)
+    cfg["coarse"] = int(r.choice([1, 1, 1, 1, 3, 5]))
     if os.environ.get("QDAS_FUZZ_OVERRIDE"):                            # debugging aid: JSON dict of fields to force
         import json
         cfg.update(json.loads(os.environ["QDAS_FUZZ_OVERRIDE"]))
@@ -56,9 +58,9 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
     from qups_amd.das_spec import _cast_data, _colmajor
     from oracle import das_oracle as O
     r, c = _draw(seed)
-    zspan = (4e-3, 4e-3 + max(c["I1"], 2) * 0.1e-3)                      # ~2.6 samples of delay per pixel
+    zspan = (4e-3, 4e-3 + max(c["I1"], 2) * 0.1e-3 * c["coarse"])
     case = make_case(seq=c["seq"], interp=c["interp"], seed=seed, N=c["N"], M=c["M"], I1=c["I1"], I2=c["I2"], zlim=zspan,
-                     xspan=2e-3, data=c["data"])
+                     xspan=2e-3 * c["coarse"], data=c["data"])
     N, M = case["N"], case["M"]
     x = case["x"]
     if c["prec"] == "halfT":
@@ -152,11 +154,14 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
             # discontinuous in tau (nearest) or in the geometry (binary masks): a rounding at the step swaps ONE of the N*M
             # samples of a pixel / one receiver; such pixels are rare, the others agree to rounding
             bad = np.abs(out - refv) / den > {"halfT": 3e-3, "single": 1e-4, "double": 1e-9}[c["prec"]]
-            assert bad.mean() <= 0.05, (seed, c, float(bad.mean()))
+            assert bad.mean() <= 0.05 * c["coarse"], (seed, c, float(bad.mean()))     # (longer records: fp32 delays round more often across a step)
             continue
         tol = 3e-3 if c["prec"] == "halfT" else 1e-4                      # covers tiles that fell back to the generic kernel (fp32 delays)
         if c["prec"] == "double":
             tol = 1e-9
+        elif plan.fallback_tiles():
+            tol *= (1 if c["coarse"] == 1 else 2 * c["coarse"]) * (2.5 if c["fmod"] else 1.0)              # fp32 delays (and the modulation phase 2 pi fmod tau formed from them) round in
+                                                                          # proportion to the record length, which grows with the pitch
         if err > tol and os.environ.get("QDAS_FUZZ_DEBUG"):                 # debugging aid: where, and what the generic kernel says
             yg = DasPlan(prob, kernel=1, **kw).execute_colmajor(xc, F).to(torch.complex64).cpu().numpy()[f].reshape(refv.shape[1], -1).T
             e = np.abs(out - refv).max(axis=1) / den
