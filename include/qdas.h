@@ -60,8 +60,10 @@ extern "C" {
 /* ---- kernel selection (QDAS_KERNEL_AUTO picks the tiled kernel when eligible)
  * Eligible: 'DAS' with any data precision -- fp64 data: pixel-independent apodization, scalar sound speed, no fmod --,
  * 'SYN' / 'MUL' / 'BF' with fp32 data; scalar sound speed or a full per-pixel map; any number of pixel-independent apodization arrays
- * (folded into an N x M table) plus at most ONE pixel-dependent array: I x N (pixel x receiver), I x 1 x M (pixel x transmit: 'DAS' / 'MUL';
- * the roles of the two apertures are swapped), or I (a spatial weight / region-of-interest mask), or one generated receive rule (rx_apod_kind);
+ * (folded into an N x M table) plus pixel-dependent arrays of ONE side: I x N (pixel x receiver), or I x 1 x M (pixel x transmit: 'DAS' / 'MUL';
+ * the roles of the two apertures are swapped), with any I-only arrays (spatial weights / region-of-interest masks) -- several of them, or arrays
+ * that broadcast over a pixel dimension (I1 x 1 x 1 x N), are multiplied into one plan-owned array at plan creation --, or one generated receive
+ * rule (rx_apod_kind);
  * N and M up to about 1000 each.  Everything else runs the generic kernel with identical semantics; qdas_last_error() after a
  * QDAS_KERNEL_TILED request says why a plan is not eligible. */
 #define QDAS_KERNEL_AUTO    0

@@ -107,6 +107,34 @@ static int dev_alloc(qdas_plan *pl, void **out, size_t bytes) {
     return QDAS_OK;
 }
 
+// Product of the pixel-dependent apodization arrays of a plan, broadcast to one contiguous I1*I2*I3 x E array (E = N, M or 1) in the
+// arrays' own element type: what the fused kernel indexes as [pixel + I * stage element].  (The reference multiplies the S arrays per
+// pair in the data precision, src/bf.cu:118-120; here the pixel-dependent factors are multiplied once per plan, in fp32, rounded once.)
+struct ApodFold {
+    const void *base;
+    uint64_t st[QDAS_MAX_APOD][5];      // per array: strides over I1, I2, I3, the element; offset (in elements of the array type)
+    uint64_t I1, I2, I3, E;
+    int ns;
+};
+template <class T, bool CPLX> __global__ void apod_fold_kernel(ApodFold f, T *out, uint64_t nel) {
+    const uint64_t I = f.I1 * f.I2 * f.I3;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nel; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = q % I, e = q / I;
+        const uint64_t i1 = i % f.I1, i2 = (i / f.I1) % f.I2, i3 = i / (f.I1 * f.I2);
+        float wr = 1.f, wi = 0.f;
+        for (int s = 0; s < f.ns; ++s) {
+            const uint64_t k = f.st[s][4] + i1 * f.st[s][0] + i2 * f.st[s][1] + i3 * f.st[s][2] + e * f.st[s][3];
+            if constexpr (CPLX) {
+                const float ar = (float)((const T *)f.base)[2 * k], ai = (float)((const T *)f.base)[2 * k + 1];
+                const float nr = wr * ar - wi * ai, ni = wr * ai + wi * ar;
+                wr = nr; wi = ni;
+            } else wr *= (float)((const T *)f.base)[k];
+        }
+        if constexpr (CPLX) { out[2 * q] = (T)wr; out[2 * q + 1] = (T)wi; }
+        else out[q] = (T)wr;
+    }
+}
+
 // device copy of a caller array (host -> new device buffer; device -> used in place)
 static int import_array(qdas_plan *pl, const void *src, size_t bytes, int mem, const void **out) {
     if (mem == QDAS_MEM_DEVICE || bytes == 0) { *out = src; return QDAS_OK; }
@@ -351,20 +379,38 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // (contiguous pixel strides, no transmit dependence) -- it is applied per (pixel, receiver) by the tiled kernel
     // A full I1 x I2 x I3 x 1 x M array -- a weight per (pixel, TRANSMIT): scanline / multiline / parallelogram transmit apodization of
     // focused sequences -- is the same thing with the roles of the apertures swapped (stage element = transmit): 'DAS' only.
-    int pix_arr = -1;
-    bool pix_is_tx = false, pix_only = false;
-    for (uint64_t s = 0; s < z.S && eligible; ++s) {
-        const uint64_t *a = &g.ast[6 * s];
-        if (!a[0] && !a[1] && !a[2]) continue;
+    // Several pixel-dependent arrays of ONE family -- receive side (I x N, I), transmit side (I x M, I) -- and arrays that broadcast over some
+    // pixel dimension (a weight per depth and receiver: I1 x 1 x 1 x N) are multiplied into one plan-owned I x [N | M] array (apod_fold_kernel).
+    // A receive-side and a transmit-side pixel array together, or an I x N x M array: generic kernel.
+    int pix_arr = -1;                               // first pixel-dependent array (-1: none)
+    bool pix_is_tx = false, pix_only = false, pix_fold = false;
+    bool is_pix[QDAS_MAX_APOD] = {};
+    uint64_t npix = 0;
+    {
         const uint64_t I = z.I1 * z.I2 * z.I3;
-        const bool pixstr = (a[0] == 1 || z.I1 == 1) && (a[1] == z.I1 || z.I2 == 1) && (a[2] == z.I1 * z.I2 || z.I3 == 1);
-        const bool full = pixstr && (a[3] == I || a[3] == 0) && a[4] == 0 && (a[3] == I || z.N == 1 || a[3] == 0);
-        if (pixstr && a[3] == 0 && a[4] == I && z.M > 1 && pix_arr < 0 && (!syn || mul) && !bfm && dt != QDAS_F64) { pix_arr = (int)s; pix_is_tx = true; }   // ('MUL': the transmit is the stage element anyway)
-        else if (pixstr && a[3] == 0 && a[4] == 0 && pix_arr < 0 && !bfm && !mul && dt != QDAS_F64) { pix_arr = (int)s; pix_only = true; }   // a spatial weight / ROI mask
-        else if (a[3] == 0 && z.N > 1) { eligible = false; why = "tiled kernel: a pixel-only apodization array needs the generic kernel"; }
-        else if (!full || pix_arr >= 0) { eligible = false; why = "tiled kernel: at most one apodization array may depend on the pixel (I x [N], no transmit dependence)"; }
-        else if (dt == QDAS_F64) { eligible = false; why = "tiled kernel, fp64 data: a pixel-dependent apodization array needs the generic kernel"; }
-        else pix_arr = (int)s;
+        bool dep_rx = false, dep_tx = false, direct = true;
+        for (uint64_t s = 0; s < z.S && eligible; ++s) {
+            const uint64_t *a = &g.ast[6 * s];
+            if (!a[0] && !a[1] && !a[2]) continue;
+            const bool dn = a[3] && z.N > 1, dm = a[4] && z.M > 1;
+            if (dn && dm) { eligible = false; why = "tiled kernel: an apodization array over pixels x receivers x transmits needs the generic kernel"; break; }
+            const bool pixstr = (a[0] == 1 || z.I1 == 1) && (a[1] == z.I1 || z.I2 == 1) && (a[2] == z.I1 * z.I2 || z.I3 == 1);
+            if (!pixstr || (dn && a[3] != I) || (dm && a[4] != I)) direct = false;
+            is_pix[s] = true; ++npix; dep_rx |= dn; dep_tx |= dm;
+            if (pix_arr < 0) pix_arr = (int)s;
+        }
+        if (eligible && npix) {
+            if (dep_rx && dep_tx) { eligible = false; why = "tiled kernel: pixel x receiver and pixel x transmit apodization arrays together need the generic kernel"; }
+            else if (dt == QDAS_F64) { eligible = false; why = "tiled kernel, fp64 data: a pixel-dependent apodization array needs the generic kernel"; }
+            else if (dep_tx) {
+                if ((!syn || mul) && !bfm) pix_is_tx = true;           // ('MUL': the transmit is the stage element anyway)
+                else { eligible = false; why = "tiled kernel: a pixel x transmit apodization array with 'SYN' / 'BF' needs the generic kernel"; }
+            } else if (!dep_rx && z.N > 1) {
+                if (!bfm && !mul) pix_only = true;                     // a spatial weight / ROI mask
+                else { eligible = false; why = "tiled kernel: a pixel-only apodization array needs the generic kernel"; }
+            }
+            pix_fold = eligible && (npix > 1 || !direct);
+        }
     }
     if (eligible && g.gen_kind && pix_arr >= 0) {
         eligible = false; why = "tiled kernel: a generated receive apodization and a pixel-dependent array need the generic kernel";
@@ -399,7 +445,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     const uint64_t kN = swap ? z.M : z.N, kM = swap ? z.N : z.M;
     pl->tc = tile_config(dt, sym);
     const int pixw = (pix_arr >= 0 || g.gen_kind) ? 1 : 0;      // a pixel x receiver weight: the tile keeps a stage list (das_tile_impl.h plan_stages)
-    const int wtb = z.S > (uint64_t)(pix_arr >= 0 ? 1 : 0) ? 1 : 0;      // pixel-independent arrays: folded into an N x M table, staged per stage in LDS
+    const int wtb = z.S > npix ? 1 : 0;      // pixel-independent arrays: folded into an N x M table, staged per stage in LDS
     if (eligible && tile_lds_bytes(dt, sym, kN, kM, 0, pixw, wtb) > tile_lds_limit(sym)) {
         eligible = false; why = "tiled kernel: N + M too large for the LDS header";
     }
@@ -490,12 +536,33 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // fold the (pixel-independent) apodization stack into one N x M complex64 table
         t.wtab = nullptr; t.apix = nullptr; t.apix_real = desc->apod_real;
         t.gen_kind = g.gen_kind; t.gen_p0 = g.gen_p0; t.gen_p1 = g.gen_p1; t.rxn = (const float *)g.rxn;
-        if (pix_arr >= 0) {
-            const uint64_t *a = &g.ast[6 * pix_arr];
-            if (a[3] == 0 && z.N > 1 && !pix_is_tx && !pix_only) {   // I-only array: no receiver dependence -> cannot index by n; use the generic kernel
-                return bail(fail(QDAS_EUNSUPPORTED, "internal: pixel-only apodization reached the tiled path"));
+        if (pix_fold) {                                 // product of the pixel-dependent arrays, broadcast to I x [N | M | 1]
+            ApodFold f;
+            memset(&f, 0, sizeof f);
+            f.base = g.apod; f.I1 = z.I1; f.I2 = z.I2; f.I3 = z.I3;
+            f.E = pix_only ? 1 : pix_is_tx ? z.M : z.N;
+            for (uint64_t s = 0; s < z.S; ++s) {
+                if (!is_pix[s]) continue;
+                const uint64_t *a = &g.ast[6 * s];
+                uint64_t *q = f.st[f.ns++];
+                q[0] = a[0]; q[1] = a[1]; q[2] = a[2]; q[3] = pix_only ? 0 : pix_is_tx ? (z.M > 1 ? a[4] : 0) : (z.N > 1 ? a[3] : 0); q[4] = a[5];
             }
-            t.apix = (const unsigned char *)g.apod + a[5] * ael;
+            const uint64_t nel = z.I1 * z.I2 * z.I3 * f.E;
+            void *fb;
+            if ((rc = dev_alloc(pl, &fb, nel * ael))) return bail(rc);
+            const unsigned nb = (unsigned)std::min<uint64_t>((nel + 255) / 256, 1u << 20);
+            if (desc->apod_real) {
+                if (dt == QDAS_F32) apod_fold_kernel<float, false><<<nb, 256, 0, 0>>>(f, (float *)fb, nel);
+                else apod_fold_kernel<_Float16, false><<<nb, 256, 0, 0>>>(f, (_Float16 *)fb, nel);
+            } else {
+                if (dt == QDAS_F32) apod_fold_kernel<float, true><<<nb, 256, 0, 0>>>(f, (float *)fb, nel);
+                else apod_fold_kernel<_Float16, true><<<nb, 256, 0, 0>>>(f, (_Float16 *)fb, nel);
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(0));
+            t.apix = (const unsigned char *)fb;
+        } else if (pix_arr >= 0) {
+            t.apix = (const unsigned char *)g.apod + g.ast[6 * pix_arr + 5] * ael;
         }
         t.apix_pixel_only = pix_only ? 1 : 0;
         t.act_bytes = (t.apix || t.gen_kind) ? (uint32_t)(8 * (t.N + 1)) : 0u;
@@ -522,12 +589,12 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             hipError_t e = hipMemcpy(dtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
             if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e)));
             t.wtab = dtab;
-        } else if (z.S > (pix_arr >= 0 ? 1u : 0u)) {
+        } else if (z.S > npix) {
             std::vector<float> &tab = host_tab;
             tab.assign(2 * z.N * z.M, 0.f);
             for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.f; tab[2 * k + 1] = 0.f; }
             for (uint64_t s = 0; s < z.S; ++s) {
-                if ((int)s == pix_arr) continue;
+                if (is_pix[s]) continue;
                 const uint64_t *st = &g.ast[6 * s];
                 const uint64_t nel = bcast_numel(st, z);
                 std::vector<unsigned char> raw(nel * ael);

@@ -42,6 +42,7 @@ def _draw(seed):
     cfg["wpm"] = bool(r.integers(0, 10) == 0) and cfg["fun"] == "DAS" and not cfg["wpix"] and not cfg["gen"] and not cfg["sym"] and cfg["prec"] != "double"
     # pixel pitch: ~lambda/3 (2.6 samples of delay per pixel), ~lambda (the 384-sample windows of the second attempt), ~1.6 lambda (tiles that fall back)
     cfg["coarse"] = int(r.choice([1, 1, 1, 1, 3, 5]))
+    cfg["fold"] = bool(r.integers(0, 3) == 0)        # a second pixel-dependent array on the same side (per depth x element): folded per plan
     if os.environ.get("QDAS_FUZZ_OVERRIDE"):                            # debugging aid: JSON dict of fields to force
         import json
         cfg.update(json.loads(os.environ["QDAS_FUZZ_OVERRIDE"]))
@@ -86,6 +87,10 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
         a = q(r.uniform(0, 1, (c["I1"], c["I2"], 1, 1, M)) > 0.5)
         a[c["I1"] // 2:, :, :, :, 0] = 0.0
         apod.append(a)
+        if c["fold"]:
+            apod.append(q(r.uniform(0.5, 1, (c["I1"], 1, 1, 1, M))))
+    if c["wpix"] and N > 1 and c["fold"]:
+        apod.append(q(r.uniform(0.5, 1, (c["I1"], 1, 1, N, 1))))
     fun = c["fun"] if c["prec"] == "single" else "DAS"                # 'SYN' / 'MUL' are fused for fp32 data only
     if fun in ("MUL", "BF") and ((c["wpix"] and N > 1) or c["gen"]):
         fun = "SYN"                                                   # 'MUL' with pixel x receiver weights: generic kernel

@@ -627,12 +627,13 @@ def test_tiled_pixel_receiver_apodization(prec):
         ref = run_oracle(case, apod=(cm,))
         out, plan = run_das(case, apod=(cm,), kernel=2)
         assert plan.kernel == "tiled" and rel_err(out, ref) <= tol
-    # two pixel-dependent arrays, or one that also depends on the transmit, go to the generic kernel
+    # two receive-side arrays are folded into one (test_several_pixel_dependent_arrays_of_one_side_are_folded); an array that depends on the
+    # pixel and on both apertures goes to the generic kernel
     from qups_amd import _lib
-    with pytest.raises(_lib.QdasError, match="at most one apodization"):
-        run_das(case, apod=(mask, mask), kernel=2, prec=prec)
+    out, plan = run_das(case, apod=(mask, mask), kernel=2, prec=prec)
+    assert plan.kernel == "tiled" and rel_err(out, run_oracle(case, apod=(mask, mask), x=x)) <= tol
     full = np.broadcast_to(mask, (150, 20, 1, 12, 7)).copy()
-    with pytest.raises(_lib.QdasError, match="at most one apodization"):
+    with pytest.raises(_lib.QdasError, match="pixels x receivers x transmits"):
         run_das(case, apod=(full,), kernel=2, prec=prec)
     out, plan = run_das(case, apod=(full,), kernel=0, prec=prec)
     assert plan.kernel == "generic" and rel_err(out, run_oracle(case, apod=(full,), x=x)) <= max(tol, TOL32)
@@ -679,6 +680,51 @@ def test_pixel_only_weights_run_fused(fun, prec):
     assert plan.kernel == "tiled", plan.kernel_name()
     assert rel_err(out, ref) <= (2e-5 if prec == "single" else 2e-3)
     assert np.all(out[:70] == 0) and np.all(out[:, 30:] == 0)
+
+
+@pytest.mark.parametrize("prec", ["single", "halfT"])
+@pytest.mark.parametrize("kind", ["two-rx", "depth-by-rx", "roi-by-tx", "two-tx-complex"])
+def test_several_pixel_dependent_arrays_of_one_side_are_folded(kind, prec):
+    """several pixel-dependent apodization arrays on the receive side (or the transmit side), and arrays that broadcast over a pixel dimension
+    (a weight per depth and receiver, I1 x 1 x 1 x N), are multiplied into one plan-owned I x [N | M] array: fused kernel (round 1: generic)"""
+    rng = np.random.default_rng(15)
+    seq = "PW" if kind in ("two-rx", "depth-by-rx") else "FC"
+    case = make_case(seq=seq, interp="cubic", seed=51, N=24, M=10, I1=150, I2=36, xspan=5e-3)
+    N, M = case["N"], case["M"]
+    x = case["x"]
+    q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else f32r
+    if prec == "halfT":
+        x = x.real.astype(np.float16).astype(np.float64) + 1j * x.imag.astype(np.float16).astype(np.float64)
+    if kind == "two-rx":            # an acceptance mask x a smooth gain, both I1 x I2 x 1 x N
+        apod = (q(rng.uniform(0, 1, (150, 36, 1, N, 1)) > 0.35), q(rng.uniform(0.5, 1.5, (150, 36, 1, N, 1))), q(rng.uniform(0.5, 1, (1, 1, 1, N, 1))))
+    elif kind == "depth-by-rx":     # aperture growth per depth (no lateral dependence) x a lateral region of interest (pixel-only)
+        grow = q(np.abs(np.arange(N) - (N - 1) / 2)[None, None, None, :, None] <= (2 + np.arange(150) * 0.1)[:, None, None, None, None])
+        roi = q(np.ones((1, 36, 1, 1, 1))); roi[:, 30:] = 0.0
+        apod = (grow, roi)
+    elif kind == "roi-by-tx":       # scanline-style transmit weights x a spatial gain
+        col = np.arange(36)[None, :, None, None, None]
+        apod = (q((np.abs(col - 3 * np.arange(M)[None, None, None, None, :] - 1.5) <= 3.0).astype(np.float64) * np.ones((150, 1, 1, 1, 1))),
+                q(rng.uniform(0.5, 2.0, (150, 36, 1, 1, 1))))
+    else:                           # two transmit-side arrays, one complex (fp32 only: the half path takes real weights in this harness)
+        a2 = rng.uniform(0.5, 1.0, (150, 1, 1, 1, M))
+        apod = (q(rng.uniform(0, 1, (150, 36, 1, 1, M)) > 0.4), q(a2) * (1 + 0.5j) if prec == "single" else q(a2))
+    ref = run_oracle(case, apod=apod, x=x)
+    out, plan = run_das(case, kernel=2, prec=prec, apod=apod)
+    assert plan.kernel == "tiled", plan.kernel_name()
+    assert rel_err(out, ref) <= (2e-5 if prec == "single" else 3e-3)
+    gen, _ = run_das(case, kernel=1, prec=prec, apod=apod)
+    assert rel_err(gen, ref) <= (1e-4 if prec == "single" else 3e-3)
+
+
+def test_receive_and_transmit_pixel_arrays_together_use_the_generic_kernel():
+    """a pixel x receiver array AND a pixel x transmit array: no fused path (the second weight would have to be read per pair): generic kernel"""
+    rng = np.random.default_rng(16)
+    case = make_case(seq="FC", interp="linear", seed=52, N=16, M=6, I1=80, I2=20)
+    apod = (f32r(rng.uniform(0, 1, (80, 20, 1, 16, 1)) > 0.3), f32r(rng.uniform(0, 1, (80, 20, 1, 1, 6))))
+    ref = run_oracle(case, apod=apod)
+    out, plan = run_das(case, kernel=0, apod=apod)
+    assert plan.kernel == "generic"
+    assert rel_err(out, ref) <= 1e-4
 
 
 def test_mul_mode_with_pixel_by_transmit_weights():
