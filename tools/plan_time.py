@@ -5,7 +5,7 @@ sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(_
 import numpy as np, torch
 from qups_amd import DasPlan, build_problem, parse_options
 from qups_amd.configs import workload
-for name in ("c3", "c2", "c5"):
+for name in (sys.argv[1:] or ("c3", "c2", "c5", "c1", "c1f", "pw9")):
     w = workload(name)
     T, N, M = w["T"], w["N"], w["M"]
     xt = torch.zeros((2, 2, 2), dtype=torch.complex64)
@@ -17,4 +17,4 @@ for name in ("c3", "c2", "c5"):
         torch.cuda.synchronize(); t2 = time.perf_counter()
         plan = DasPlan(prob)
         torch.cuda.synchronize(); t3 = time.perf_counter()
-    print(f"{name}: host marshalling {1e3*(t1-t0):.1f} ms, plan creation (upload + reciprocity test + 4 probes) {1e3*(t3-t2):.1f} ms, kernel {plan.kernel}")
+    print(f"{name}: host marshalling {1e3*(t1-t0):.1f} ms, plan creation (upload + reciprocity test + probes; prebuilt kernels) {1e3*(t3-t2):.1f} ms, kernel {plan.kernel}")
