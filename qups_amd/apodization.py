@@ -10,6 +10,9 @@ Two forms of the same three pixel x receiver rules:
   ``qdas_desc.rx_apod_kind / rx_apod_p / rx_normals``): no I x N array is built, stored or streamed
   (C5: 268 MB; a C3-sized image: 2.1 GB).
 
+Plus the transmit-side rules of focused sequences (``ap_scanline``, ``ap_multiline``, ``ap_translating_aperture``, ``:4892-5163``) in the
+reference's broadcast shapes.
+
 All arithmetic here is float64 numpy on the host (this is input marshalling, not the hot path).
 """
 from __future__ import annotations
@@ -69,6 +72,65 @@ def ap_aperture_growth(Pi, Pr, normals=None, f: float = 1.5, Dmax: float = np.in
         d2 = np.abs(2.0 * (r[0] * n[2] - r[2] * n[0]))
         z = np.abs(r[0] * n[0] + r[2] * n[2])
     return ((z > f * d2) & (d2 < Dmax)).astype(np.float64)[..., None]
+
+
+# ------------------------------------------------------------------------------------------
+# transmit-side rules of focused sequences: weights per (lateral pixel coordinate, transmit).  The reference returns them in
+# broadcast form -- singleton over depth: ``1 x I2 x 1 x 1 x M`` for a Cartesian scan with the lateral axis second -- and so do these;
+# the plan multiplies such arrays out to ``I x M`` once (csrc/qdas_api.hip apod_fold_kernel) and runs the fused kernel with the transmit
+# as the stage element.
+# ------------------------------------------------------------------------------------------
+def _lateral(xi, xdim: int) -> np.ndarray:
+    shape = [1] * 5
+    xi = np.asarray(xi, dtype=np.float64).reshape(-1)
+    shape[xdim] = xi.size
+    return xi.reshape(shape)
+
+
+def ap_scanline(xi, xv, tol: float | None = None, xdim: int = 1) -> np.ndarray:
+    """Scanline mask (reference ``src/UltrasoundSystem.m:4892-4968``): pixel column ``xi`` (lateral position, or angle of a polar scan) takes
+    the transmits whose focus (or steering angle) ``xv`` lies within ``tol`` of it -- default: the mean spacing of ``xi`` (the reference's
+    ``scan.dx``).  ``xdim`` = axis (0-based) of the lateral pixel dimension.  Shape: singleton but for ``xdim`` and the transmit axis."""
+    xi = np.asarray(xi, dtype=np.float64).reshape(-1)
+    xv = np.asarray(xv, dtype=np.float64).reshape(1, 1, 1, 1, -1)
+    if tol is None:
+        tol = float(np.mean(np.diff(xi))) if xi.size > 1 else np.inf
+    return (np.abs(_lateral(xi, xdim) - xv) < tol).astype(np.float64)
+
+
+def ap_multiline(xi, xv, xdim: int = 1) -> np.ndarray:
+    """Multiline weights (reference ``:4970-5072``): every pixel column is interpolated linearly between the nearest transmit on its left
+    (the last ``xv <= xi``) and on its right (the first ``xv >= xi``) in transmit order; columns without a transmit on both sides get nothing;
+    where the two coincide the left one takes weight 1."""
+    xi = np.asarray(xi, dtype=np.float64).reshape(-1)
+    xv = np.asarray(xv, dtype=np.float64).reshape(-1)
+    out = np.zeros((xi.size, xv.size))
+    for k, x in enumerate(xi):                           # (host marshalling: a few hundred columns)
+        left = np.nonzero(x - xv >= 0)[0]
+        right = np.nonzero(x - xv <= 0)[0]
+        if left.size == 0 or right.size == 0:
+            continue
+        l, r = left[-1], right[0]
+        d = abs(xv[l] - xv[r])
+        if d == 0:
+            out[k, l] += 1.0
+        else:
+            out[k, l] += 1.0 - abs(xv[l] - x) / d
+            out[k, r] += 1.0 - abs(xv[r] - x) / d
+    shape = [1] * 5
+    shape[xdim] = xi.size
+    shape[4] = xv.size
+    return out.reshape(shape)
+
+
+def ap_translating_aperture(xi, xv, xn, tol, xdim: int = 1) -> np.ndarray:
+    """Translating-aperture mask (reference ``:5074-5163``): ``|xi - xv| <= tol[0]`` and ``|xi - xn| <= tol[-1]`` -- depends on the pixel column,
+    the receiver AND the transmit (``1 x I2 x 1 x N x M``): such plans run the generic kernel."""
+    tol = np.atleast_1d(np.asarray(tol, dtype=np.float64))
+    xn = np.asarray(xn, dtype=np.float64).reshape(1, 1, 1, -1, 1)
+    xv = np.asarray(xv, dtype=np.float64).reshape(1, 1, 1, 1, -1)
+    X = _lateral(xi, xdim)
+    return ((np.abs(X - xv) <= tol[0]) & (np.abs(X - xn) <= tol[-1])).astype(np.float64)
 
 
 def rx_apod_spec(kind: str, theta: float | None = None, f: float = 1.5, Dmax: float = np.inf, normals=None) -> dict:

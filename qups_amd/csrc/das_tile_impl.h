@@ -347,14 +347,24 @@ template <class C> __device__ __forceinline__ bool Tile<C>::on_side(uint32_t n, 
 }
 template <class C> __device__ __forceinline__ typename Tile<C>::wraw Tile<C>::wload_raw(uint32_t n) const {
     const int gen_kind = QSPEC(GEN_KIND, P.gen_kind);
+    uint32_t na = n;                                  // the stage element's entry of the weight array
     if constexpr (C::ACT && !C::LUT) {
-        if (gen_kind == 5) { const float4 e = nrec[n]; return wraw{on_side(n, e.y, e.z, e.w) ? 0x3f800000u : 0u, 0u}; }
+        if constexpr (C::FMOD && C::WTAB) {           // (at the register limit: the side rule alone; qdas_api.hip does not ask for 6 here)
+            if (gen_kind == 5) { const float4 e = nrec[n]; return wraw{on_side(n, e.y, e.z, e.w) ? 0x3f800000u : 0u, 0u}; }
+        } else if (gen_kind == 5 || gen_kind == 6) {  // 6: the side rule times a pixel x transmit (or pixel-only) array, transmit n >> 1
+            const float4 e = nrec[n];
+            const bool on = on_side(n, e.y, e.z, e.w);
+            if (gen_kind == 5 || !on) return wraw{on ? 0x3f800000u : 0u, 0u};
+            na = n >> 1;
+        }
     }
-    if (!C::SYM && gen_kind) {                        // qdas.h QDAS_RXAPOD_*: element from the LDS record (never in reciprocal mode)
+    bool generated = !C::SYM && gen_kind;
+    if constexpr (C::ACT && !C::LUT && !(C::FMOD && C::WTAB)) { if (gen_kind == 6) generated = false; }
+    if (generated) {                                  // qdas.h QDAS_RXAPOD_*: element from the LDS record (never in reciprocal mode)
         const float4 e = nrec[n];
         return wraw{__float_as_uint(rx_apod_generated(gen_kind, P.gen_p0, P.gen_p1, px, py, pz, e.y, e.z, e.w, P.rxn, n)), 0u};
     }
-    const uint64_t k = ipx + (P.apix_pixel_only ? 0ull : P.I1 * P.I2 * P.I3 * n);
+    const uint64_t k = ipx + (P.apix_pixel_only ? 0ull : P.I1 * P.I2 * P.I3 * na);
     if (QSPEC(APIX_REAL, P.apix_real)) {
         if constexpr (C::F32) return wraw{((const uint32_t *)P.apix)[k], 0u};
         else return wraw{(uint32_t)((const unsigned short *)P.apix)[k], 0u};
@@ -364,7 +374,9 @@ template <class C> __device__ __forceinline__ typename Tile<C>::wraw Tile<C>::wl
     }
 }
 template <class C> __device__ __forceinline__ v2f Tile<C>::wconv(wraw r) const {
-    if ((!C::SYM && QSPEC(GEN_KIND, P.gen_kind)) || (C::F32 && QSPEC(APIX_REAL, P.apix_real))) return (v2f){__uint_as_float(r.a), 0.f};
+    bool generated = !C::SYM && QSPEC(GEN_KIND, P.gen_kind);
+    if constexpr (C::ACT && !C::LUT && !(C::FMOD && C::WTAB)) { if (QSPEC(GEN_KIND, P.gen_kind) == 6) generated = false; }
+    if (generated || (C::F32 && QSPEC(APIX_REAL, P.apix_real))) return (v2f){__uint_as_float(r.a), 0.f};
     if (QSPEC(APIX_REAL, P.apix_real)) return (v2f){__half2float(__ushort_as_half((unsigned short)r.a)), 0.f};
     if constexpr (C::F32) return (v2f){__uint_as_float(r.a), __uint_as_float(r.b)};
     else return half2_to_v2f(r.a);

@@ -632,7 +632,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // crosses fit no window and would go to the generic kernel -- with a walking aperture that is half the image.  Second attempt:
         // every transmit listed twice, once per side of its plane (tile_params.h kindS == 3); kept if fewer tiles misfit.
         uint64_t kN_eff = kN;
-        if (!pl->no_fallback && txkind == 1 && !syn && !bfm && !sym && !big && pix_arr < 0 && !g.gen_kind && (dt == QDAS_F32 || dt == QDAS_F16)
+        if (!pl->no_fallback && txkind == 1 && !syn && !bfm && !sym && !big && (pix_arr < 0 || ((pix_is_tx || pix_only) && !(desc->fmod != 0.0 && wtb))) && !g.gen_kind && (dt == QDAS_F32 || dt == QDAS_F16)
             && z.M < (1u << 15) && tile_lds_bytes(dt, 0, 2 * z.M, z.N, 0, 1, wtb) <= tile_lds_limit(0) && !getenv("QDAS_NO_SIDE_SPLIT")) {
             const TileParams keep = t;
             const double keep_frac = pl->misfit_frac;
@@ -659,7 +659,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             t.strN = tp ? z.T : z.T * z.N;               // stage element = transmit, block element = receiver
             t.strM = tp ? z.T * z.M : z.T;
             t.kindB = 0; t.kindS = 3; t.stage_shift = 1;
-            t.gen_kind = 5; t.gen_p0 = t.gen_p1 = 0.0; t.rxn = nullptr; t.apix = nullptr;
+            t.gen_kind = t.apix ? 6 : 5; t.gen_p0 = t.gen_p1 = 0.0; t.rxn = nullptr;      // (6: the side rule times the plan's pixel x transmit / pixel-only array)
             t.act_bytes = (uint32_t)(8 * (E + 1));
             if (t.wtab) {                                // the table in the new element order: [(2m + side) + 2M * n]
                 std::vector<float> tab2(2 * E * z.N);

@@ -23,7 +23,8 @@ struct TileParams {
     const void *apix;                   // optional I x N apodization (data precision; real if apix_real), may be null
     int32_t apix_real;
     int32_t apix_pixel_only;            // the array is I1 x I2 x I3 only (a spatial weight / region-of-interest mask): the same entry for every stage element
-    int32_t gen_kind;                   // generated pixel x receiver apodization (QDAS_RXAPOD_*), exclusive with apix
+    int32_t gen_kind;                   // generated pixel x receiver apodization (QDAS_RXAPOD_*), exclusive with apix; 5: side of the focal plane (kindS == 3);
+                                        // 6: that side rule times apix[pixel + I * (n >> 1)] (pixel x transmit weights of a two-sided focused plan)
     double gen_p0, gen_p1;
     const float *rxn;                   // 3 x N element normals (device)
     uint32_t act_bytes;                 // LDS bytes of the tile's stage list: 8 * (N + 1) when a pixel x receiver weight (apix / gen_kind) is set, else 0

@@ -103,3 +103,56 @@ def test_generated_weights_equal_the_materialised_array(kernel, kind, kw, convex
         assert rel_err(g, a) <= 3e-3                       # the materialised fp16 array rounds the smooth weights
     else:
         assert rel_err(g, a) <= (2e-3 if prec == "halfT" else 2e-6)       # same weights, same kernel: rounding-level agreement
+
+
+def test_transmit_side_rules_shapes_and_values():
+    """``ap_scanline`` / ``ap_multiline`` / ``ap_translating_aperture`` (reference src/UltrasoundSystem.m:4892-5163): broadcast shapes
+    (singleton over depth), partition of unity between neighbouring transmits, known values on a hand-checked grid"""
+    from qups_amd import apodization as A
+    xi = np.linspace(-4e-3, 4e-3, 17)                      # pixel columns, 0.5 mm apart
+    xv = np.array([-3e-3, -1e-3, 1e-3, 3e-3])              # foci, 2 mm apart
+    s = A.ap_scanline(xi, xv)
+    assert s.shape == (1, 17, 1, 1, 4)
+    assert np.array_equal(np.nonzero(s[0, :, 0, 0, 1])[0], [6])        # |xi - (-1 mm)| < 0.5 mm: the column at -1 mm only
+    assert np.array_equal(np.nonzero(A.ap_scanline(xi, xv, 0.6e-3)[0, :, 0, 0, 1])[0], [5, 6, 7])
+    m = A.ap_multiline(xi, xv)
+    assert m.shape == (1, 17, 1, 1, 4)
+    w = m[0, :, 0, 0, :]                                   # columns x transmits
+    inside = (xi >= xv[0]) & (xi <= xv[-1])
+    assert np.allclose(w[inside].sum(1), 1.0) and np.all(w[~inside] == 0)    # linear interpolation between the neighbours; nothing outside
+    assert np.allclose(w[7], [0, 0.75, 0.25, 0])           # the column at -0.5 mm: 3/4 from the focus at -1 mm, 1/4 from +1 mm
+    assert np.allclose(w[6], [0, 1, 0, 0])                 # on a focus: all of it (left == right: the left one takes 1)
+    assert A.ap_multiline(xi, xv, xdim=0).shape == (17, 1, 1, 1, 4)
+    xn = np.linspace(-3e-3, 3e-3, 13)
+    t = A.ap_translating_aperture(xi, xv, xn, [1e-3, 1.5e-3])
+    assert t.shape == (1, 17, 1, 13, 4)
+    k = 7                                                  # column at -0.5 mm: transmits within 1 mm (the two central foci: no -- only -1 mm ... +0 mm)
+    assert np.array_equal(np.nonzero(t[0, k, 0, 6, :])[0], [1])
+    assert np.array_equal(np.nonzero(t[0, k, 0, :, 1])[0], np.nonzero(np.abs(xn - xi[k]) <= 1.5e-3)[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["single", "halfT"])
+@pytest.mark.parametrize("rule", ["multiline", "scanline"])
+def test_reference_shaped_transmit_rules_run_fused(rule, prec):
+    """the reference's transmit-side rules come singleton over depth (``1 x I2 x 1 x 1 x M``, src/UltrasoundSystem.m:5071): multiplied out per
+    plan, fused kernel with the transmit as the stage element; the translating aperture (pixel x receiver x transmit) runs the generic kernel"""
+    from qups_amd import apodization as A
+    from tests.test_gpu_parity import run_das, run_oracle
+    case = make_case(seq="FC", interp="cubic", seed=61, N=32, M=12, I1=140, I2=41, xspan=5e-3)
+    xi = np.linspace(-2.5e-3, 2.5e-3, 41)
+    xv = np.asarray(case["Pv"])[0]
+    x = case["x"]
+    q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else (lambda a: a.astype(np.float32).astype(np.float64))
+    if prec == "halfT":
+        x = x.real.astype(np.float16).astype(np.float64) + 1j * x.imag.astype(np.float16).astype(np.float64)
+    a = q(A.ap_multiline(xi, xv) if rule == "multiline" else A.ap_scanline(xi, xv, 0.3e-3))
+    assert a.shape == (1, 41, 1, 1, 12) and a.any()
+    ref = run_oracle(case, apod=(a,), x=x)
+    out, plan = run_das(case, kernel=2, prec=prec, apod=(a,))
+    assert plan.kernel == "tiled" and "roles swapped" in plan.kernel_name()
+    assert rel_err(out, ref) <= (2e-5 if prec == "single" else 3e-3)
+    if rule == "multiline" and prec == "single":
+        t = q(A.ap_translating_aperture(xi, xv, np.asarray(case["Pr"])[0], [0.5e-3, 3e-3]))
+        out, plan = run_das(case, kernel=0, apod=(t,))
+        assert plan.kernel == "generic" and rel_err(out, run_oracle(case, apod=(t,))) <= 1e-4

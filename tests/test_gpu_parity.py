@@ -118,6 +118,39 @@ def test_focused_transmits_with_the_foci_inside_the_image(interp, prec, monkeypa
     assert (e2 > tol).mean() <= 0.01
 
 
+@pytest.mark.parametrize("interp,prec", [("cubic", "single"), ("linear", "halfT")])
+@pytest.mark.parametrize("rule", ["multiline", "roi"])
+def test_focused_transmits_inside_the_image_with_pixel_weights(rule, interp, prec, monkeypatch):
+    """the same two-sided plan with a multiline transmit apodization in the reference's shape (1 x I2 x 1 x 1 x M, src/UltrasoundSystem.m:5071)
+    or a pixel-only gain: the stage weight is the side rule times the array (tile_params.h gen_kind 6); no fallback tiles"""
+    from qups_amd import apodization as A
+    rng = np.random.default_rng(32)
+    case = make_case(seq="FC", interp=interp, seed=36, N=24, M=10, I1=190, I2=40, zlim=(3e-3, 17e-3), xspan=8e-3)
+    x = case["x"]
+    q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else f32r
+    if prec == "halfT":
+        x = x.real.astype(np.float16).astype(np.float64) + 1j * x.imag.astype(np.float16).astype(np.float64)
+    if rule == "multiline":
+        a = q(A.ap_multiline(np.linspace(-4e-3, 4e-3, 40), np.asarray(case["Pv"])[0]))
+        assert a.shape == (1, 40, 1, 1, 10)
+    else:
+        a = q(rng.uniform(0.5, 2.0, (190, 40, 1, 1, 1)))
+        a[:, 33:] = 0.0
+    wn = q(rng.uniform(0.3, 1, (1, 1, 1, 24, 1)))
+    ref = run_oracle(case, apod=(a, wn), x=x)
+    out, plan = run_das(case, kernel=2, prec=prec, apod=(a, wn))
+    assert plan.kernel == "tiled" and plan.fallback_tiles() == 0, (plan.kernel_name(), plan.fallback_tiles())
+    e = np.abs(out - ref).reshape(-1) / np.abs(ref).max()
+    tol = {"single": 1e-4, "halfT": 3e-3}[prec]
+    assert np.median(e) <= tol / 10 and (e > tol).mean() <= 0.01, (np.median(e), (e > tol).mean(), e.max())
+    monkeypatch.setenv("QDAS_NO_SIDE_SPLIT", "1")
+    monkeypatch.setenv("QDAS_NO_WIDE", "1")
+    out2, plan2 = run_das(case, kernel=2, prec=prec, apod=(a, wn))
+    if prec == "single":
+        assert plan2.fallback_tiles() > 0
+    assert (np.abs(out2 - out).reshape(-1) / np.abs(ref).max() > tol).mean() <= 0.01
+
+
 def test_tiled_and_generic_agree_on_noise():
     """white-noise data (what the reference's own benchmark feeds, test/ParTest.m:254-257)"""
     case = make_case(seq="FSA", interp="lanczos3", seed=3, data="noise", I1=130, I2=9)
