@@ -175,6 +175,8 @@ def main():
                     "(evaluated inside the kernel: what an apodized frame costs); not the headline")
     ap.add_argument("--window-apod", action="store_true", help="Hann receive window x Hann transmit window (pixel-independent apodization, folded "
                     "into an N x M table): an apodized full-synthetic-aperture frame stays in the reciprocal mode; not the headline")
+    ap.add_argument("--tx-apod", default=None, choices=["multiline", "scanline"], help="transmit-side rule of a focused workload (c1, c1f) in the reference's "
+                    "shape 1 x I2 x 1 x 1 x M (UltrasoundSystem.apMultiline / apScanline); not the headline")
     ap.add_argument("--prec", default=None, help="override the workload's data precision (single | halfT | double); not the headline")
     ap.add_argument("--gen-apod", action="store_true", help="generate the workload's receive apodization inside the kernel "
                     "(qdas_desc.rx_apod_*) instead of streaming the materialised I x N array")
@@ -225,6 +227,13 @@ def main():
     if args.window_apod:
         extra += ["apod", np.hanning(N + 2)[1:-1].astype(np.float32).reshape(1, 1, 1, N, 1), "apod", np.hanning(M + 2)[1:-1].astype(np.float32).reshape(1, 1, 1, 1, M)]
         w["label"] += " [Hann receive x transmit windows]"
+    if args.tx_apod:
+        from qups_amd import apodization as A
+        Pi3 = np.asarray(w["Pi"]).reshape(3, w["I1"], w["I2"], -1)
+        xi, xv = Pi3[0, 0, :, 0], np.asarray(w["Pv"])[0]
+        a = A.ap_multiline(xi, xv) if args.tx_apod == "multiline" else A.ap_scanline(xi, xv)
+        extra += ["apod", a.astype(np.float32)]
+        w["label"] += f" [{args.tx_apod} transmit apodization]"
     if args.rx_apod:
         from qups_amd.apodization import rx_apod_spec
         kind, _, par = args.rx_apod.partition(":")
@@ -330,7 +339,7 @@ def main():
             mode = "live" if world == 1 else "file"
         if mode == "live":
             argv = ["--workload", args.workload] + (["--kernel", str(args.kernel)] if args.kernel else []) + \
-                   (["--prec", args.prec] if args.prec else []) + (["--fmod", str(args.fmod)] if args.fmod else []) + (["--rx-apod", args.rx_apod] if args.rx_apod else []) + (["--window-apod"] if args.window_apod else []) + (["--gen-apod"] if args.gen_apod else []) + \
+                   (["--prec", args.prec] if args.prec else []) + (["--fmod", str(args.fmod)] if args.fmod else []) + (["--rx-apod", args.rx_apod] if args.rx_apod else []) + (["--window-apod"] if args.window_apod else []) + (["--tx-apod", args.tx_apod] if args.tx_apod else []) + (["--gen-apod"] if args.gen_apod else []) + \
                    (["--no-reciprocal"] if args.no_reciprocal else []) + (["--no-jit"] if args.no_jit else [])
             traffic, tsrc = measure_traffic(argv)
             if traffic is None:
