@@ -63,7 +63,8 @@ extern "C" {
  * (folded into an N x M table) plus pixel-dependent arrays of ONE side: I x N (pixel x receiver), or I x 1 x M (pixel x transmit: 'DAS' / 'MUL';
  * the roles of the two apertures are swapped), with any I-only arrays (spatial weights / region-of-interest masks) -- several of them, or arrays
  * that broadcast over a pixel dimension (I1 x 1 x 1 x N), are multiplied into one plan-owned array at plan creation --, or one generated receive
- * rule (rx_apod_kind);
+ * rule (rx_apod_kind); fp32 data with real weights and no remodulation also takes a transmit-side AND a receive-side pixel array together
+ * (the receive-side product is applied per pair);
  * N and M up to about 1000 each.  Everything else runs the generic kernel with identical semantics; qdas_last_error() after a
  * QDAS_KERNEL_TILED request says why a plan is not eligible. */
 #define QDAS_KERNEL_AUTO    0

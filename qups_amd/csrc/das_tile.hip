@@ -104,6 +104,7 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     }
     const int narrow = (sym && dtype == 1 && P.narrow) ? 1 : (!sym && dtype == 1 && P.narrow == 2) ? 2 : 0;     // window variant (das_tile_cfg.h)
     if (narrow == 2 && (P.lut_tx || P.bf || P.big || (!P.probe && P.nfr > 1))) return hipErrorInvalidValue;
+    if (P.bpix && (narrow != 2 || P.wtab || P.fmod != 0.0 || P.syn || sym)) return hipErrorInvalidValue;      // (TileCfg::BPIX instantiations only)
     if (P.act_bytes != 0 && P.act_bytes != 8 * (P.N + 1)) return hipErrorInvalidValue;
     const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M, narrow, P.act_bytes ? 1 : 0, P.wtab ? 1 : 0);    // (the two-frame configurations have the same LDS image)
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;

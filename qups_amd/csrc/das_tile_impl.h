@@ -90,6 +90,8 @@ struct TileCfg {
     // scalar-memory latency per transmit pair and drained the LDS queue with it (lgkmcnt counts both)
     static constexpr bool WST = WTAB_ && !F64 && !BF_ && !FB4;      // (four frames per launch: no registers to spare -- scalar loads as before)
     static constexpr int WSTB = WST ? NBUF_ * (2 * MB_ * 8 + 16) : 0;     // [NBUF][{direct, mirror}][MB] float2 + {non-zero masks} per buffer
+    // a weight per (pixel, BLOCK element) on top of the stage weight: 16 more registers -- the 16-transmit wide-window configuration has them
+    static constexpr bool BPIX = F32 && !SYM_ && !FB2_ && !FB4_ && !BF_ && !LUT_ && !BIG_ && !WTAB_ && !FMOD_ && MB_ == 16 && W_ == 384;
     using GT = std::conditional_t<F64, double, float>;   // type of the geometry tables (the reference casts them to the data precision, kern/das_spec.m:244)
     static constexpr int WB = W * SB;                // bytes per window
     static constexpr int PB = 1024;                  // bytes per full DMA piece (one wave-instruction x 16 B)
@@ -137,6 +139,7 @@ template <class C> struct Tile {
     uint32_t nact; bool use_act;                     // stages per transmit block / whether they come from act[] (else: receivers n_lo ... in order)
     v2f acc, acc1, acc2, acc3;                       // independent partial sums: no back-to-back dependent packed FMAs
     v2f ra[C::MB / 2];                               // block residuals a - A[m] - 1/2 of transmits (2p, 2p+1), packed
+    v2f bw[C::BPIX ? C::MB / 2 : 1]; bool bp;        // pixel x block-element weights of the same transmits (TileParams::bpix), and whether the plan has them
     double rad[C::F64 ? C::MB : 1];                  // fp64 data: the same residuals, one double per transmit
     double dacc[4];                                  // fp64 data: two independent complex partial sums {re, im, re, im}
     v2f tot[C::NFR];                                 // weighted totals per frame when a pixel x receiver weight is applied
@@ -396,6 +399,8 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
     // weights from an I x N array, or generated from the geometry (fp32 frames with such a weight do not share launches: their single-frame
     // kernel has the stage list of the active receivers instead, and the two-frame kernels have no registers for the weight bookkeeping)
     wpix = !C::F64 && !C::SYM && !C::BF && !(C::FBX && C::F32) && (QSPEC(HAS_APIX, P.apix != nullptr) || QSPEC(GEN_KIND, P.gen_kind) != 0);
+    bp = false;
+    if constexpr (C::BPIX) bp = P.bpix != nullptr;
     syn = !C::SYM && !C::BF && C::F32 && QSPEC(SYN, P.syn);          // keep the stage dimension: one output plane per stage element
     fa = C::FB4 ? __builtin_amdgcn_readfirstlane(wave / C::MB) : 0;   // window sets this wave stages: (0, 1) in general; four frames: (0, 2) / (1, 3)
     fb = C::FB4 ? fa + 2 : 1;
@@ -578,6 +583,24 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
                     ra[p] = (v2f){block_residual(px, py, pz, cf, fs, kindB, (lds_cfloat *)PvL, (lds_cfloat *)NvL, ma, Abase[ma], tapinfo<C::INTERP>::OFF),
                                   block_residual(px, py, pz, cf, fs, kindB, (lds_cfloat *)PvL, (lds_cfloat *)NvL, mb, Abase[mb], tapinfo<C::INTERP>::OFF)};
                 __builtin_amdgcn_sched_barrier(0);      // one pair at a time: keeps this cold block from inflating the register budget
+            }
+            if constexpr (C::BPIX) {
+                if (!bp) {                             // (no such weight: ones -- the pair loop multiplies unconditionally: a uniform branch there
+#pragma unroll                                         //  makes the compiler clone the unrolled loop and spill 270 registers)
+                    for (int p = 0; p < C::MB / 2; ++p) bw[p] = (v2f){1.f, 1.f};
+                } else {                               // this block's pixel x block-element weights (cold: once per N stages)
+                    const uint64_t Itot = P.I1 * P.I2 * P.I3;
+                    uint32_t ip32 = (uint32_t)ipx;         // (uniform row pointer + 32-bit lane offset: the host keeps such plans below 2^30 pixels)
+                    asm volatile("" : "+v"(ip32));
+#pragma unroll
+                    for (int p = 0; p < C::MB / 2; ++p) {
+                        const uint32_t ma = m0 + 2 * p < M ? m0 + 2 * p : M - 1, mb = m0 + 2 * p + 1 < M ? m0 + 2 * p + 1 : M - 1;
+                        const float *rowa = P.bpix + Itot * ma, *rowb = P.bpix + Itot * mb;
+                        asm volatile("" : "+s"(rowa), "+s"(rowb));
+                        bw[p] = (v2f){rowa[ip32], rowb[ip32]};
+                        __builtin_amdgcn_sched_barrier(0);  // one pair at a time (as above)
+                    }
+                }
             }
         }
         timer.mark(2);

@@ -383,7 +383,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // pixel dimension (a weight per depth and receiver: I1 x 1 x 1 x N) are multiplied into one plan-owned I x [N | M] array (apod_fold_kernel).
     // A receive-side and a transmit-side pixel array together, or an I x N x M array: generic kernel.
     int pix_arr = -1;                               // first pixel-dependent array (-1: none)
-    bool pix_is_tx = false, pix_only = false, pix_fold = false;
+    bool pix_is_tx = false, pix_only = false, pix_fold = false, bpix_mode = false;
     bool is_pix[QDAS_MAX_APOD] = {};
     uint64_t npix = 0;
     {
@@ -400,7 +400,18 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             if (pix_arr < 0) pix_arr = (int)s;
         }
         if (eligible && npix) {
-            if (dep_rx && dep_tx) { eligible = false; why = "tiled kernel: pixel x receiver and pixel x transmit apodization arrays together need the generic kernel"; }
+            if (dep_rx && dep_tx) {
+                // a transmit-side rule AND a receive-side mask (multiline x acceptance angle): the transmit is the stage element with its weight, the
+                // receive-side product is a second weight per (pixel, block element) applied per pair -- launch configuration 14 (das_tile_impl.h BPIX):
+                // fp32 data, real weights, plain 'DAS', no remodulation; pixel-independent arrays must belong to one aperture (they join that side's product)
+                bool ok = dt == QDAS_F32 && desc->apod_real && !syn && !bfm && desc->fmod == 0.0 && I < (1ull << 30) && !getenv("QDAS_NO_BPIX");
+                for (uint64_t s = 0; s < z.S && ok; ++s) {
+                    const uint64_t *a = &g.ast[6 * s];
+                    if (!is_pix[s] && a[3] && z.N > 1 && a[4] && z.M > 1) ok = false;
+                }
+                if (ok) { bpix_mode = true; pix_is_tx = true; for (uint64_t s = 0; s < z.S; ++s) is_pix[s] = true; npix = z.S; }
+                else { eligible = false; why = "tiled kernel: pixel x receiver and pixel x transmit apodization arrays together run fused for fp32 data, real weights, 'DAS', no remodulation, no N x M array only"; }
+            }
             else if (dt == QDAS_F64) { eligible = false; why = "tiled kernel, fp64 data: a pixel-dependent apodization array needs the generic kernel"; }
             else if (dep_tx) {
                 if ((!syn || mul) && !bfm) pix_is_tx = true;           // ('MUL': the transmit is the stage element anyway)
@@ -409,7 +420,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
                 if (!bfm && !mul) pix_only = true;                     // a spatial weight / ROI mask
                 else { eligible = false; why = "tiled kernel: a pixel-only apodization array needs the generic kernel"; }
             }
-            pix_fold = eligible && (npix > 1 || !direct);
+            pix_fold = eligible && (npix > 1 || !direct || bpix_mode);
         }
     }
     if (eligible && g.gen_kind && pix_arr >= 0) {
@@ -536,20 +547,23 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // fold the (pixel-independent) apodization stack into one N x M complex64 table
         t.wtab = nullptr; t.apix = nullptr; t.apix_real = desc->apod_real;
         t.gen_kind = g.gen_kind; t.gen_p0 = g.gen_p0; t.gen_p1 = g.gen_p1; t.rxn = (const float *)g.rxn;
-        if (pix_fold) {                                 // product of the pixel-dependent arrays, broadcast to I x [N | M | 1]
+        t.bpix = nullptr;
+        // product of the arrays `take` selects, broadcast to I x E entries (E = M: indexed by the transmit; N: by the receiver; 1: pixel-only)
+        auto fold = [&](int side, auto take, void **out) -> int {
             ApodFold f;
             memset(&f, 0, sizeof f);
             f.base = g.apod; f.I1 = z.I1; f.I2 = z.I2; f.I3 = z.I3;
-            f.E = pix_only ? 1 : pix_is_tx ? z.M : z.N;
+            f.E = side == 2 ? 1 : side == 1 ? z.M : z.N;
             for (uint64_t s = 0; s < z.S; ++s) {
-                if (!is_pix[s]) continue;
+                if (!take(s)) continue;
                 const uint64_t *a = &g.ast[6 * s];
                 uint64_t *q = f.st[f.ns++];
-                q[0] = a[0]; q[1] = a[1]; q[2] = a[2]; q[3] = pix_only ? 0 : pix_is_tx ? (z.M > 1 ? a[4] : 0) : (z.N > 1 ? a[3] : 0); q[4] = a[5];
+                q[0] = a[0]; q[1] = a[1]; q[2] = a[2]; q[3] = side == 2 ? 0 : side == 1 ? (z.M > 1 ? a[4] : 0) : (z.N > 1 ? a[3] : 0); q[4] = a[5];
             }
             const uint64_t nel = z.I1 * z.I2 * z.I3 * f.E;
             void *fb;
-            if ((rc = dev_alloc(pl, &fb, nel * ael))) return bail(rc);
+            int frc = dev_alloc(pl, &fb, nel * ael);
+            if (frc) return frc;
             const unsigned nb = (unsigned)std::min<uint64_t>((nel + 255) / 256, 1u << 20);
             if (desc->apod_real) {
                 if (dt == QDAS_F32) apod_fold_kernel<float, false><<<nb, 256, 0, 0>>>(f, (float *)fb, nel);
@@ -560,6 +574,18 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(0));
+            *out = fb;
+            return QDAS_OK;
+        };
+        if (bpix_mode) {                                // transmit side (+ pixel-only arrays) -> stage weight; receive side -> per-pair weight (real fp32)
+            void *fa_ = nullptr, *fb_ = nullptr;
+            auto on_rx = [&](uint64_t s) { return g.ast[6 * s + 3] != 0 && z.N > 1; };
+            if ((rc = fold(1, [&](uint64_t s) { return !on_rx(s); }, &fa_))) return bail(rc);
+            if ((rc = fold(0, on_rx, &fb_))) return bail(rc);
+            t.apix = (const unsigned char *)fa_; t.bpix = (const float *)fb_;
+        } else if (pix_fold) {
+            void *fb = nullptr;
+            if ((rc = fold(pix_only ? 2 : pix_is_tx ? 1 : 0, [&](uint64_t s) { return is_pix[s]; }, &fb))) return bail(rc);
             t.apix = (const unsigned char *)fb;
         } else if (pix_arr >= 0) {
             t.apix = (const unsigned char *)g.apod + g.ast[6 * pix_arr + 5] * ael;
@@ -622,8 +648,9 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // has no misfit tile at all -- otherwise the 192-sample configuration
         t.narrow = (sym && dt == QDAS_F32 && !getenv("QDAS_NO_NARROW")) ? 1 : 0;
         if (t.narrow) pl->tc = tile_config(dt, 1, 1);
+        if (bpix_mode) { t.narrow = 2; pl->tc = tile_config(dt, 0, 2); }      // (the configuration that applies a per-pair pixel weight)
         if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
-        if (t.narrow && !pl->no_fallback) {
+        if (t.narrow == 1 && !pl->no_fallback) {
             t.narrow = 0;
             pl->tc = tile_config(dt, 1, 0);
             if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
@@ -685,7 +712,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // Tiles that still do not fit (a pixel grid coarser than about lambda/2 -- volumes, previews --, steep delay gradients): fp32 plans
         // try the 384-sample windows of launch configuration 14 (16 transmits per stage, same LDS image); kept if fewer tiles misfit.
         // (a reciprocal plan gives up its mode for them: an image on the generic kernel costs ten times more than the shared index work saves)
-        if (!pl->no_fallback && dt == QDAS_F32 && !bfm && !big && !getenv("QDAS_NO_WIDE")
+        if (!pl->no_fallback && dt == QDAS_F32 && !bfm && !big && t.narrow != 2 && !getenv("QDAS_NO_WIDE")
             && tile_lds_bytes(dt, 0, t.N, t.M, 2, t.act_bytes ? 1 : 0, t.wtab ? 1 : 0) <= tile_lds_limit(0)
             && ((uint64_t)t.N * t.strN + (uint64_t)tile_config(dt, 0, 2).mb * t.strM) * data_size(dt) + 65536 < (1ull << 31)) {
             const TileParams keep = t;
@@ -724,7 +751,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // ---- QDAS_PLAN_JIT: the tiled kernel compiled for this plan's sizes (jit.hip).  A failure is not an error: the plan keeps its
     //      prebuilt kernel and qdas_last_error() says why.
     g_err.clear();
-    if ((desc->plan_flags & QDAS_PLAN_JIT) && pl->kernel == QDAS_KERNEL_TILED && !pl->tp.bf && dt != QDAS_F64 && !getenv("QDAS_NO_JIT")) {
+    if ((desc->plan_flags & QDAS_PLAN_JIT) && pl->kernel == QDAS_KERNEL_TILED && !pl->tp.bf && !pl->tp.bpix && dt != QDAS_F64 && !getenv("QDAS_NO_JIT")) {
         const TileParams &t = pl->tp;
         JitSpec k{};
         k.interp = (z.flag & 7) == 4 ? 1 : (z.flag & 7); k.dtype = dt; k.fmod = t.fmod != 0.0; k.wtab = t.wtab != nullptr; k.sym = t.sym; k.big = t.big;

@@ -58,7 +58,7 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
         const v2f s = t - (tm - MAGIC);
         const uint32_t ad0 = (hooks::linear_taps ? (MAGIC_BITS + (uint32_t)lane + (__float_as_uint(tm.x) & 1u)) : __float_as_uint(tm.x)) * (uint32_t)C::SB + cbase;
         const uint32_t ad1 = (hooks::linear_taps ? (MAGIC_BITS + (uint32_t)lane + (__float_as_uint(tm.y) & 1u)) : __float_as_uint(tm.y)) * (uint32_t)C::SB + cbase;
-        constexpr bool SPLIT = CHECK || FMOD || WTAB || BF; // the two halves need separate post-processing
+        constexpr bool SPLIT = CHECK || FMOD || WTAB || BF || C::BPIX; // the two halves need separate post-processing
         v2f w[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
         // one pass per FRAME PAIR (two passes when four frames share the launch): same tap index and weights
         unroll<NHP>([&](auto hpc) {
@@ -167,6 +167,13 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                 const bool k0 = (t.x >= lo0) && (t.x < hi0), k1 = (t.y >= lo1) && (t.y < hi1) && upper;
                 v0 = k0 ? v0 : (v2f){0.f, 0.f}; v1 = k1 ? v1 : (v2f){0.f, 0.f};
                 if constexpr (FBX || SW) { u0 = k0 ? u0 : (v2f){0.f, 0.f}; u1 = k1 ? u1 : (v2f){0.f, 0.f}; }
+            }
+            if constexpr (C::BPIX) {                  // pixel x block-element weights; a zero weight never samples its trace (src/bf.cu:122,126)
+                {
+                    const v2f b2 = bw[p];
+                    v0 = b2.x != 0.f ? v0 * b2.x : (v2f){0.f, 0.f};
+                    v1 = b2.y != 0.f ? v1 * b2.y : (v2f){0.f, 0.f};
+                }
             }
             if constexpr (FMOD) {                     // reference src/bf.cu:117: w = exp(2j pi fmod tau), tau*fs = t + 1/2 + (A[m] + B[n]) - OFF
                 // phase in cycles = t*f + frac((A[m] + 1/2 - OFF)*f) + frac(B[n]*f), f = fmod/fs: the two constants were tabulated in

@@ -54,6 +54,9 @@ struct TileParams {
     uint32_t fallback_cap;
     // table-driven delays (launch configuration 10, qdas_das_lut): tau_tx (I x M) and tau_rx (I x N) in samples, fp32
     const float *lut_tx, *lut_rx;
+    // a SECOND pixel-dependent weight, per (pixel, BLOCK element): real fp32, [pixel + I * block element]; applied per pair (launch configuration 14
+    // without table / remodulation only: TileCfg::BPIX) -- the receive-side mask of a focused plan whose stage weight is the transmit-side rule
+    const float *bpix;
 };
 
 }  // namespace qdas

@@ -43,6 +43,9 @@ def _draw(seed):
     # pixel pitch: ~lambda/3 (2.6 samples of delay per pixel), ~lambda (the 384-sample windows of the second attempt), ~1.6 lambda (tiles that fall back)
     cfg["coarse"] = int(r.choice([1, 1, 1, 1, 3, 5]))
     cfg["fold"] = bool(r.integers(0, 3) == 0)        # a second pixel-dependent array on the same side (per depth x element): folded per plan
+    # a transmit-side AND a receive-side pixel array (real weights, fp32 data, plain 'DAS'): per-pair pixel weights on the wide-window configuration
+    if r.integers(0, 12) == 0 and cfg["prec"] == "single" and not cfg["sym"] and not cfg["bf"] and cfg["N"] > 1 and cfg["M"] > 1:
+        cfg.update(wpix=True, wpm=True, wm=False, gen="", fun="DAS", fmod=0.0, jit=False)
     if os.environ.get("QDAS_FUZZ_OVERRIDE"):                            # debugging aid: JSON dict of fields to force
         import json
         cfg.update(json.loads(os.environ["QDAS_FUZZ_OVERRIDE"]))

@@ -9,6 +9,7 @@ identical float32 inputs.  Stated tolerances:
 import numpy as np
 import pytest
 
+from qups_amd import geometry as G
 from tests.cases import cinv_f32, make_case, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -119,7 +120,7 @@ def test_focused_transmits_with_the_foci_inside_the_image(interp, prec, monkeypa
 
 
 @pytest.mark.parametrize("interp,prec", [("cubic", "single"), ("linear", "halfT")])
-@pytest.mark.parametrize("rule", ["multiline", "roi"])
+@pytest.mark.parametrize("rule", ["multiline", "roi", "multiline-x-acceptance"])
 def test_focused_transmits_inside_the_image_with_pixel_weights(rule, interp, prec, monkeypatch):
     """the same two-sided plan with a multiline transmit apodization in the reference's shape (1 x I2 x 1 x 1 x M, src/UltrasoundSystem.m:5071)
     or a pixel-only gain: the stage weight is the side rule times the array (tile_params.h gen_kind 6); no fallback tiles"""
@@ -130,23 +131,29 @@ def test_focused_transmits_inside_the_image_with_pixel_weights(rule, interp, pre
     q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else f32r
     if prec == "halfT":
         x = x.real.astype(np.float16).astype(np.float64) + 1j * x.imag.astype(np.float16).astype(np.float64)
-    if rule == "multiline":
+    extra = ()
+    if rule.startswith("multiline"):
         a = q(A.ap_multiline(np.linspace(-4e-3, 4e-3, 40), np.asarray(case["Pv"])[0]))
         assert a.shape == (1, 40, 1, 1, 10)
+        if rule == "multiline-x-acceptance":          # + a receive-side mask: per-pair pixel weights (fp32 data only: generic kernel otherwise)
+            if prec != "single":
+                pytest.skip("two-sided pixel weights run fused for fp32 data")
+            nrm = np.asarray(G.linear_array(24, 0.3e-3)[1], np.float32).astype(np.float64)
+            extra = (q(A.ap_acceptance_angle(case["Pi"], case["Pr"], nrm, 35.0)),)
     else:
         a = q(rng.uniform(0.5, 2.0, (190, 40, 1, 1, 1)))
         a[:, 33:] = 0.0
     wn = q(rng.uniform(0.3, 1, (1, 1, 1, 24, 1)))
-    ref = run_oracle(case, apod=(a, wn), x=x)
-    out, plan = run_das(case, kernel=2, prec=prec, apod=(a, wn))
+    ref = run_oracle(case, apod=(a, wn) + extra, x=x)
+    out, plan = run_das(case, kernel=2, prec=prec, apod=(a, wn) + extra)
     assert plan.kernel == "tiled" and plan.fallback_tiles() == 0, (plan.kernel_name(), plan.fallback_tiles())
     e = np.abs(out - ref).reshape(-1) / np.abs(ref).max()
     tol = {"single": 1e-4, "halfT": 3e-3}[prec]
     assert np.median(e) <= tol / 10 and (e > tol).mean() <= 0.01, (np.median(e), (e > tol).mean(), e.max())
     monkeypatch.setenv("QDAS_NO_SIDE_SPLIT", "1")
     monkeypatch.setenv("QDAS_NO_WIDE", "1")
-    out2, plan2 = run_das(case, kernel=2, prec=prec, apod=(a, wn))
-    if prec == "single":
+    out2, plan2 = run_das(case, kernel=2, prec=prec, apod=(a, wn) + extra)
+    if prec == "single" and not extra:
         assert plan2.fallback_tiles() > 0
     assert (np.abs(out2 - out).reshape(-1) / np.abs(ref).max() > tol).mean() <= 0.01
 
@@ -749,15 +756,61 @@ def test_several_pixel_dependent_arrays_of_one_side_are_folded(kind, prec):
     assert rel_err(gen, ref) <= (1e-4 if prec == "single" else 3e-3)
 
 
-def test_receive_and_transmit_pixel_arrays_together_use_the_generic_kernel():
-    """a pixel x receiver array AND a pixel x transmit array: no fused path (the second weight would have to be read per pair): generic kernel"""
+@pytest.mark.parametrize("seq,interp", [("FC", "cubic"), ("FC", "nearest"), ("PW", "lanczos3"), ("DV", "linear")])
+def test_receive_and_transmit_pixel_arrays_together_run_fused(seq, interp):
+    """a transmit-side rule (multiline weights in the reference's shape) AND a receive-side mask (acceptance angle) -- what a focused sequence
+    is beamformed with: the transmit is the stage element with its weight, the receive-side product is a second weight per (pixel, block
+    element) applied per pair (launch configuration 14, das_tile_impl.h BPIX); pixel-independent arrays join their aperture's product"""
+    from qups_amd import apodization as A
     rng = np.random.default_rng(16)
-    case = make_case(seq="FC", interp="linear", seed=52, N=16, M=6, I1=80, I2=20)
-    apod = (f32r(rng.uniform(0, 1, (80, 20, 1, 16, 1)) > 0.3), f32r(rng.uniform(0, 1, (80, 20, 1, 1, 6))))
+    case = make_case(seq=seq, interp=interp, seed=52, N=24, M=10, I1=150, I2=36, xspan=6e-3)
+    N, M = case["N"], case["M"]
+    Pv = np.asarray(case["Pv"])
+    xv = Pv[0] if seq != "PW" else np.linspace(-3e-3, 3e-3, M)
+    tx = f32r(A.ap_multiline(np.linspace(-3e-3, 3e-3, 36), xv))                       # 1 x 36 x 1 x 1 x M
+    nrm = np.asarray(G.linear_array(N, 0.3e-3)[1], np.float32).astype(np.float64)
+    rx = f32r(A.ap_acceptance_angle(case["Pi"], case["Pr"], nrm, 30.0))                # 150 x 36 x 1 x N x 1
+    gain = f32r(rng.uniform(0.5, 1.5, (150, 1, 1, N, 1)))                              # a second receive-side array (per depth)
+    wn = f32r(rng.uniform(0.3, 1, (1, 1, 1, N, 1)))
+    wm = f32r(rng.uniform(0.3, 1, (1, 1, 1, 1, M))); wm[..., 3] = 0.0
+    apod = (tx, rx, gain, wn, wm)
     ref = run_oracle(case, apod=apod)
-    out, plan = run_das(case, kernel=0, apod=apod)
-    assert plan.kernel == "generic"
-    assert rel_err(out, ref) <= 1e-4
+    out, plan = run_das(case, kernel=2, apod=apod)
+    assert plan.kernel == "tiled" and "W=384" in plan.kernel_name() and "roles swapped" in plan.kernel_name(), plan.kernel_name()
+    if interp == "nearest":
+        bad = np.abs(out - ref) / np.abs(ref).max() > 1e-4
+        assert bad.mean() <= 0.02
+    else:
+        assert rel_err(out, ref) <= 2e-5
+    assert np.all(out[np.abs(ref) == 0] == 0)
+    gen, _ = run_das(case, kernel=1, apod=apod)
+    assert rel_err(gen, ref) <= 1e-4 or interp == "nearest"
+    # a dead channel under a zero receive-side weight stays out (src/bf.cu:122,126): non-finite samples of receiver 5 wherever rx == 0
+    if interp == "cubic":
+        x2 = np.array(case["x"], dtype=np.complex128)
+        rx2 = rx.copy(); rx2[:, :, :, 5, :] = 0.0
+        x2[:, 5, :] = np.nan
+        out2, _ = run_das(case, kernel=2, apod=(tx, rx2, gain, wn, wm), x=x2)
+        x3 = np.array(case["x"], dtype=np.complex128); x3[:, 5, :] = 0.0
+        ref3 = run_oracle(case, apod=(tx, rx2, gain, wn, wm), x=x3)
+        assert np.isfinite(out2).all() and rel_err(out2, ref3) <= 2e-5
+
+
+def test_two_sided_pixel_weights_outside_the_fused_scope_use_the_generic_kernel():
+    """fp16 data, complex weights, remodulation or an N x M table next to two-sided pixel weights: generic kernel (same results)"""
+    rng = np.random.default_rng(17)
+    case = make_case(seq="FC", interp="linear", seed=53, N=16, M=6, I1=80, I2=20)
+    rx = f32r(rng.uniform(0, 1, (80, 20, 1, 16, 1)) > 0.3)
+    tx = f32r(rng.uniform(0, 1, (80, 20, 1, 1, 6)))
+    nm = f32r(rng.uniform(0.5, 1, (1, 1, 1, 16, 6)))
+    from qups_amd import _lib
+    with pytest.raises(_lib.QdasError, match="together run fused for"):
+        run_das(case, kernel=2, apod=(rx, tx, nm))
+    ref = run_oracle(case, apod=(rx, tx, nm))
+    out, plan = run_das(case, kernel=0, apod=(rx, tx, nm))
+    assert plan.kernel == "generic" and rel_err(out, ref) <= 1e-4
+    out, plan = run_das(case, kernel=0, apod=(rx, tx * (1 + 0.5j)))
+    assert plan.kernel == "generic" and rel_err(out, run_oracle(case, apod=(rx, tx * (1 + 0.5j)))) <= 1e-4
 
 
 def test_mul_mode_with_pixel_by_transmit_weights():
