@@ -124,6 +124,27 @@ def _flat_colmajor(a: np.ndarray, dtype) -> np.ndarray:
     return t.permute(*reversed(range(t.ndim))).contiguous().reshape(-1).numpy()
 
 
+def _split_separable(a: np.ndarray, N: int, M: int):
+    """``a`` (5-D, real, depends on the pixel, the receiver AND the transmit) as ``(tx, rx)`` with ``tx * rx == a`` exactly in float32 --
+    ``tx`` without receiver dependence, ``rx`` without transmit dependence --, or ``None``.  Per pixel the factors are the row and the
+    column through the entry of largest magnitude."""
+    if a.ndim != 5 or np.iscomplexobj(a) or N < 2 or M < 2 or a.shape[3] != N or a.shape[4] != M or all(d == 1 for d in a.shape[:3]) or a.size > (1 << 26):
+        return None
+    w = a.astype(np.float32)
+    pix = w.shape[:3]
+    flat = np.abs(w).reshape(pix + (N * M,))
+    piv = flat.argmax(axis=-1)                                   # pixel-shaped
+    n0, m0 = piv // M, piv % M
+    row = np.take_along_axis(w, n0[..., None, None], axis=3)     # pix x 1 x M: the transmit-side factor
+    col = np.take_along_axis(w, m0[..., None, None], axis=4)     # pix x N x 1
+    pv = np.take_along_axis(row, m0[..., None, None], axis=4)    # pix x 1 x 1
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rx = np.where(pv != 0, col / pv, np.float32(0)).astype(np.float32)
+    if not np.array_equal(row * rx, w):
+        return None
+    return row.astype(a.dtype if a.dtype.kind == "f" else np.float32), rx.astype(a.dtype if a.dtype.kind == "f" else np.float32)
+
+
 def _mod_size(P: np.ndarray) -> np.ndarray:
     """coordinates into the first dimension (reference kern/das_spec.m:591-599)"""
     if P.ndim < 2:
@@ -291,6 +312,15 @@ def build_problem(fun, Pi, Pr, Pv, Nv, xshape, t0, fs, c, opts: dict) -> DasProb
         if a.size == 1 and a.reshape(-1)[0] == 1:
             continue                                          # the reference's default {1}: a no-op
         apods.append(a)
+    # an array over pixels x receivers x transmits that is an exact product of a transmit-side and a receive-side factor (the reference's
+    # translating-aperture mask, src/UltrasoundSystem.m:5162: |xi - xv| <= tol & |xi - xn| <= tol) is passed as those two factors: both run
+    # on the fused kernel, the single array would not (csrc/qdas_api.hip)
+    if prec == "single" and len(apods) < _lib.MAX_APOD:
+        for k, a in enumerate(apods):
+            two = _split_separable(a, N, M)
+            if two is not None:
+                apods[k:k + 1] = list(two)
+                break
     if len(apods) > _lib.MAX_APOD:
         raise DasError(f"At most {_lib.MAX_APOD} apodization arrays are supported.")
     apod_real = all(not np.iscomplexobj(a) for a in apods)

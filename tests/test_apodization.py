@@ -136,7 +136,7 @@ def test_transmit_side_rules_shapes_and_values():
 @pytest.mark.parametrize("rule", ["multiline", "scanline"])
 def test_reference_shaped_transmit_rules_run_fused(rule, prec):
     """the reference's transmit-side rules come singleton over depth (``1 x I2 x 1 x 1 x M``, src/UltrasoundSystem.m:5071): multiplied out per
-    plan, fused kernel with the transmit as the stage element; the translating aperture (pixel x receiver x transmit) runs the generic kernel"""
+    plan, fused kernel with the transmit as the stage element; the translating aperture (pixel x receiver x transmit) is split into its two factors by the host"""
     from qups_amd import apodization as A
     from tests.test_gpu_parity import run_das, run_oracle
     case = make_case(seq="FC", interp="cubic", seed=61, N=32, M=12, I1=140, I2=41, xspan=5e-3)
@@ -154,5 +154,11 @@ def test_reference_shaped_transmit_rules_run_fused(rule, prec):
     assert rel_err(out, ref) <= (2e-5 if prec == "single" else 3e-3)
     if rule == "multiline" and prec == "single":
         t = q(A.ap_translating_aperture(xi, xv, np.asarray(case["Pr"])[0], [0.5e-3, 3e-3]))
+        assert t.shape == (1, 41, 1, 32, 12)
+        # pixel x receiver x transmit, but an exact product of a transmit-side and a receive-side mask: the host passes the two factors
+        # (qups_amd/das_spec.py _split_separable) and the plan runs them fused with per-pair pixel weights
         out, plan = run_das(case, kernel=0, apod=(t,))
-        assert plan.kernel == "generic" and rel_err(out, run_oracle(case, apod=(t,))) <= 1e-4
+        assert plan.kernel == "tiled" and "W=384" in plan.kernel_name() and rel_err(out, run_oracle(case, apod=(t,))) <= 2e-5
+        g = t * q(np.random.default_rng(3).uniform(0.5, 1.0, (1, 41, 1, 32, 12)))     # not separable: generic kernel
+        out, plan = run_das(case, kernel=0, apod=(g,))
+        assert plan.kernel == "generic" and rel_err(out, run_oracle(case, apod=(g,))) <= 1e-4

@@ -672,7 +672,8 @@ def test_tiled_pixel_receiver_apodization(prec):
     from qups_amd import _lib
     out, plan = run_das(case, apod=(mask, mask), kernel=2, prec=prec)
     assert plan.kernel == "tiled" and rel_err(out, run_oracle(case, apod=(mask, mask), x=x)) <= tol
-    full = np.broadcast_to(mask, (150, 20, 1, 12, 7)).copy()
+    full = np.broadcast_to(mask, (150, 20, 1, 12, 7)) * f32r(rng.uniform(0.5, 1.0, (1, 1, 1, 12, 7)))      # (not a product of a receive-side and a transmit-side factor)
+    full = full.astype(np.float16).astype(np.float64) if prec == "halfT" else f32r(full)
     with pytest.raises(_lib.QdasError, match="pixels x receivers x transmits"):
         run_das(case, apod=(full,), kernel=2, prec=prec)
     out, plan = run_das(case, apod=(full,), kernel=0, prec=prec)

@@ -173,3 +173,18 @@ def test_no_cpu_fallback_in_product_path():
     with pytest.raises(NotImplementedError):
         das_spec_fn("DAS", np.zeros((3, 4)), np.zeros((3, 2)), np.zeros((3, 1)), np.array([[0.0], [0], [1]]),
                     np.zeros((16, 2, 2), np.complex64), 0.0, 1e6, 1540.0, "device", 0)
+
+
+def test_separable_pixel_by_aperture_arrays_are_split():
+    """an array over pixels x receivers x transmits that is an exact product of a transmit-side and a receive-side factor (translating aperture,
+    reference src/UltrasoundSystem.m:5162) is handed to the library as the two factors; anything else is passed through untouched"""
+    from qups_amd import apodization as A
+    from qups_amd.das_spec import _split_separable
+    xi, xv, xn = np.linspace(-4e-3, 4e-3, 41), np.linspace(-3e-3, 3e-3, 12), np.linspace(-4.65e-3, 4.65e-3, 32)
+    t = A.ap_translating_aperture(xi, xv, xn, [0.5e-3, 3e-3])
+    tx, rx = _split_separable(t, 32, 12)
+    assert tx.shape == (1, 41, 1, 1, 12) and rx.shape == (1, 41, 1, 32, 1) and np.array_equal(tx * rx, t)
+    rng = np.random.default_rng(0)
+    assert _split_separable(rng.uniform(0, 1, (5, 4, 1, 32, 12)), 32, 12) is None            # full rank
+    assert _split_separable(t[..., :1], 32, 1) is None and _split_separable(t * 1j, 32, 12) is None
+    assert _split_separable(np.ones((1, 1, 1, 32, 12)), 32, 12) is None                      # no pixel dependence: the N x M table takes it
