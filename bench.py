@@ -177,6 +177,8 @@ def main():
                     "into an N x M table): an apodized full-synthetic-aperture frame stays in the reciprocal mode; not the headline")
     ap.add_argument("--tx-apod", default=None, choices=["multiline", "scanline"], help="transmit-side rule of a focused workload (c1, c1f) in the reference's "
                     "shape 1 x I2 x 1 x 1 x M (UltrasoundSystem.apMultiline / apScanline); not the headline")
+    ap.add_argument("--rx-apod-array", action="store_true", help="with --rx-apod: pass the MATERIALISED I x N array instead of the in-kernel rule "
+                    "(with --tx-apod: a transmit-side rule and a receive-side mask together -- per-pair pixel weights)")
     ap.add_argument("--prec", default=None, help="override the workload's data precision (single | halfT | double); not the headline")
     ap.add_argument("--gen-apod", action="store_true", help="generate the workload's receive apodization inside the kernel "
                     "(qdas_desc.rx_apod_*) instead of streaming the materialised I x N array")
@@ -238,9 +240,18 @@ def main():
         from qups_amd.apodization import rx_apod_spec
         kind, _, par = args.rx_apod.partition(":")
         kw = ({"f": float(par)} if kind == "fnumber" else {"theta": float(par)}) if par else {}
-        extra += ["rx-apod", rx_apod_spec(kind, normals=w.get("nrm"), **kw)]
+        if args.rx_apod_array:
+            from qups_amd import apodization as A
+            fn = {"acceptance": A.ap_acceptance_angle, "cosine": A.ap_cosine_angle, "fnumber": A.ap_aperture_growth}[kind]
+            nrm = w.get("nrm")
+            if nrm is None:
+                nrm = np.tile(np.array([[0.0], [0.0], [1.0]]), (1, N))
+            extra += ["apod", fn(w["Pi"], w["Pr"], nrm, *kw.values()).astype(np.float32)]
+            w["label"] += f" [receive apodization array {args.rx_apod}]"
+        else:
+            extra += ["rx-apod", rx_apod_spec(kind, normals=w.get("nrm"), **kw)]
+            w["label"] += f" [generated receive apodization {args.rx_apod}]"
         w["apod"] = None
-        w["label"] += f" [generated receive apodization {args.rx_apod}]"
     elif args.gen_apod and w["rx_apod"] is not None:
         from qups_amd.apodization import rx_apod_spec
         extra += ["rx-apod", rx_apod_spec(w["rx_apod"][0], normals=w["nrm"], **w["rx_apod"][1])]
@@ -339,7 +350,7 @@ def main():
             mode = "live" if world == 1 else "file"
         if mode == "live":
             argv = ["--workload", args.workload] + (["--kernel", str(args.kernel)] if args.kernel else []) + \
-                   (["--prec", args.prec] if args.prec else []) + (["--fmod", str(args.fmod)] if args.fmod else []) + (["--rx-apod", args.rx_apod] if args.rx_apod else []) + (["--window-apod"] if args.window_apod else []) + (["--tx-apod", args.tx_apod] if args.tx_apod else []) + (["--gen-apod"] if args.gen_apod else []) + \
+                   (["--prec", args.prec] if args.prec else []) + (["--fmod", str(args.fmod)] if args.fmod else []) + (["--rx-apod", args.rx_apod] if args.rx_apod else []) + (["--rx-apod-array"] if args.rx_apod_array else []) + (["--window-apod"] if args.window_apod else []) + (["--tx-apod", args.tx_apod] if args.tx_apod else []) + (["--gen-apod"] if args.gen_apod else []) + \
                    (["--no-reciprocal"] if args.no_reciprocal else []) + (["--no-jit"] if args.no_jit else [])
             traffic, tsrc = measure_traffic(argv)
             if traffic is None:
