@@ -45,7 +45,7 @@ def _draw(seed):
     cfg["fold"] = bool(r.integers(0, 3) == 0)        # a second pixel-dependent array on the same side (per depth x element): folded per plan
     # a transmit-side AND a receive-side pixel array (real weights, fp32 data, plain 'DAS'): per-pair pixel weights on the wide-window configuration
     if r.integers(0, 12) == 0 and cfg["prec"] == "single" and not cfg["sym"] and not cfg["bf"] and cfg["N"] > 1 and cfg["M"] > 1:
-        cfg.update(wpix=True, wpm=True, wm=False, gen="", fun="DAS", fmod=0.0, jit=False)
+        cfg.update(wpix=True, wpm=True, wm=False, gen="", fun="DAS", fmod=0.0)
     if os.environ.get("QDAS_FUZZ_OVERRIDE"):                            # debugging aid: JSON dict of fields to force
         import json
         cfg.update(json.loads(os.environ["QDAS_FUZZ_OVERRIDE"]))
