@@ -69,12 +69,14 @@ def host_info():
     return model, phys
 
 
-def cpu_baseline(w, x_host, budget_s=12.0):
+def cpu_baseline(w, x_host, budget_s=12.0, apod=None):
     """Time the C oracle (port of the reference CPU branch) on a pixel-subsampled image: the straight port and the
-    host-tuned rebuild (-march=native, float weight math; oracle/Makefile)."""
+    host-tuned rebuild (-march=native, float weight math; oracle/Makefile).  Returns (records, lattice step, lattice image of the
+    straight port) -- the image is what `parity_check` compares the GPU frame with."""
     from oracle import das_ref
     model, phys = host_info()
     out = []
+    lattice = (None, None)
     for kind in ("port", "port-tuned"):
         try:
             L = das_ref.lib(tuned=(kind == "port-tuned"))
@@ -85,22 +87,43 @@ def cpu_baseline(w, x_host, budget_s=12.0):
 
         def run(step):
             Pi = w["Pi"][:, ::step, ::step, :]
-            das_ref.das_spec("DAS", Pi, w["Pr"], w["Pv"], w["Nv"], x_host, w["t0"], w["fs"], w["c0"],
-                             VS="plane-waves" not in w["opt"], DV="diverging-waves" in w["opt"], interp=w["interp"],
-                             prec="single", timing=True, tuned=(kind == "port-tuned"))
-            return das_ref.LAST_SECONDS, Pi.shape[1] * Pi.shape[2]
+            ap = () if apod is None else (apod[::step, ::step],)       # (pixel x receiver weights of the workload: C5's acceptance mask)
+            img = das_ref.das_spec("DAS", Pi, w["Pr"], w["Pv"], w["Nv"], x_host, w["t0"], w["fs"], w["c0"],
+                                   VS="plane-waves" not in w["opt"], DV="diverging-waves" in w["opt"], interp=w["interp"],
+                                   apod=ap, prec="single", timing=True, tuned=(kind == "port-tuned"))
+            return das_ref.LAST_SECONDS, Pi.shape[1] * Pi.shape[2], img
 
-        t, npx = run(32)                                   # calibration
-        rate = npx / max(t, 1e-6)
-        want = rate * budget_s
-        step = int(np.clip(np.ceil(np.sqrt(w["I1"] * w["I2"] / max(want, 1.0))), 1, 32))
-        t, npx = run(step)
+        try:
+            t, npx, _ = run(32)                                # calibration
+            rate = npx / max(t, 1e-6)
+            want = rate * budget_s
+            step = int(np.clip(np.ceil(np.sqrt(w["I1"] * w["I2"] / max(want, 1.0))), 1, 32))
+            t, npx, img = run(step)
+        except ValueError as ex:                               # (the tuned rebuild covers the unweighted fp32 sum only)
+            out.append({"value": None, "unit": "Mpixel/s", "kind": kind, "sample": f"not applicable: {ex}"})
+            continue
+        if kind == "port":
+            lattice = (step, img[:, :, 0, 0, 0])
         out.append({"value": round(npx / t / 1e6, 6), "unit": "Mpixel/s", "cores": int(nthreads), "kind": kind,
                     "seconds": round(t, 3), "cpu_model": model, "physical_cores": phys,
                     "gpairs_per_s": round(npx * w["N"] * w["M"] / t / 1e9, 4),
                     "sample": f"every {step}th pixel per axis of the same image ({npx} px), full {w['N']}x{w['M']} aperture, "
                               f"float32, OpenMP x{nthreads}; full-frame time extrapolated: {w['I1'] * w['I2'] / (npx / t):.1f} s"})
-    return out
+    return out, lattice[0], lattice[1]
+
+
+def executed_pair_fraction(mask, wave):
+    """Fraction of the (pixel, receiver) stages the fused kernel EXECUTES under a pixel x receiver weight `mask` (I1 x I2 x N, zero =
+    no weight): a wave (wave[0] x wave[1] pixels) skips a receiver's stage only when all its 64 weights are zero (das_tile_impl.h),
+    so the census is per wave footprint, not per pixel.  What `valu_frac_executed` scales the pair count with."""
+    m = np.asarray(mask) != 0
+    I1, I2, N = m.shape
+    wz, wc = wave if wave and wave[0] else (1, 1)
+    p1, p2 = (-I1) % wz, (-I2) % wc
+    if p1 or p2:
+        m = np.pad(m, ((0, p1), (0, p2), (0, 0)))
+    blk = m.reshape((I1 + p1) // wz, wz, (I2 + p2) // wc, wc, N).any(axis=(1, 3))
+    return float(blk.sum()) * wz * wc / float(I1 * I2 * N)
 
 
 def self_launch(args):
@@ -168,6 +191,8 @@ def main():
                     "the kernel hiprtc compiles for this plan's sizes (the reference's benchmark runs const-compiled kernels too: "
                     "src/UltrasoundSystem.m:5626-5748, test/ParTest.m:322-327)")
     ap.add_argument("--jit", action="store_true", help="(default; kept for compatibility)")
+    ap.add_argument("--no-traffic", action="store_true", help="same as --traffic none")
+    ap.add_argument("--checksum", action="store_true", help="add image_checksum (xxh3 / blake2b of the final image bytes on rank 0)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "none"],
                     help="roofline.traffic: rocprofv3 counter passes of this command (live; auto = live at N=1) or profiles/traffic_<w>.json")
     ap.add_argument("--fmod", type=float, default=0.0, help="remodulation frequency [Hz] ('modulation' option): baseband data; not the headline")
@@ -184,6 +209,8 @@ def main():
                     "(qdas_desc.rx_apod_*) instead of streaming the materialised I x N array")
     args = ap.parse_args()
     args.jit = not args.no_jit
+    if args.no_traffic:
+        args.traffic = "none"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -267,8 +294,10 @@ def main():
     plan = DasPlan(prob, device=dev, kernel=args.kernel, i_begin=b, i_count=e - b, reciprocal=not args.no_reciprocal, jit=args.jit)
     from qups_amd.dist import gather_pixels
 
+    yslab = torch.empty((1, 1, 1, e - b), dtype=xc.dtype, device=dev)      # the image buffer of the frame stream (reused: execute_into)
+
     def step():
-        y = plan.execute_colmajor(xc, 1)                       # (1, 1, 1, slab)
+        y = plan.execute_into(xc, yslab, 1)                    # (1, 1, 1, slab)
         if world > 1:
             y = gather_pixels(y, I, world)                     # one RCCL all_gather of the slabs -> (1, 1, 1, I) on every rank
         return y
@@ -280,11 +309,12 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        yimg = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     el = time.perf_counter() - t0
+    yimg = yimg.clone()                                        # the frame of the last timed step (checksum, parity_check)
     if world > 1:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -295,7 +325,7 @@ def main():
         p.set_timing(True)
         ks = []
         for _ in range(reps):
-            p.execute_colmajor(xc, 1)
+            p.execute_into(xc, yslab, 1)
             ks.append(p.last_kernel_ms())
         p.set_timing(False)
         return float(np.mean(ks))
@@ -376,6 +406,26 @@ def main():
         info = _lib.device_info(local)
         ksec = kernel_ms * 1e-3
         exec_fpp = EXEC_FLOP_PER_PAIR.get((w["interp"], reciprocal))
+        # pairs the kernel really executes: a pixel x receiver weight (array or generated rule) drops whole (wave, receiver) stages
+        exec_frac, mask = 1.0, None
+        try:
+            if args.rx_apod and not args.rx_apod_array and plan.kernel == "tiled":
+                from qups_amd import apodization as A
+                kind, _, par = args.rx_apod.partition(":")
+                fn = {"acceptance": A.ap_acceptance_angle, "cosine": A.ap_cosine_angle, "fnumber": A.ap_aperture_growth}[kind]
+                nrm = w.get("nrm")
+                if nrm is None:
+                    nrm = np.tile(np.array([[0.0], [0.0], [1.0]]), (1, N))
+                mask = fn(w["Pi"], w["Pr"], nrm, *([float(par)] if par else []))
+            elif plan.kernel == "tiled" and not args.tx_apod:
+                for a in opts["apod"]:
+                    a = np.asarray(a)
+                    if a.ndim >= 4 and a.shape[0] == w["I1"] and a.shape[1] == w["I2"] and a.shape[3] == N and (a.ndim < 5 or a.shape[4] == 1):
+                        mask = a if mask is None else mask * a
+            if mask is not None:
+                exec_frac = executed_pair_fraction(np.asarray(mask).reshape(w["I1"], w["I2"], N), plan.wave_shape())
+        except Exception:
+            exec_frac = None
         rec = {
             "metric": "beamformed Mpixels/sec (1024^2 px, 256x256 Tx/Rx)" if w["name"] == "c3" else "beamformed Mpixels/sec",
             "value": round(I / (el / args.steps) / 1e6, 4), "unit": "Mpixel/s",
@@ -394,8 +444,9 @@ def main():
                          "valu_tflops_model": round(pairs / world * FLOP_PER_PAIR.get(w["interp"], 42) / ksec / 1e12, 3),
                          "valu_frac": round(pairs / world * FLOP_PER_PAIR.get(w["interp"], 42) / ksec / 1e12 / FP32_PEAK_TFLOPS, 4),
                          "valu_flop_per_pair_executed": exec_fpp,
-                         "valu_frac_executed": None if exec_fpp is None or plan.kernel != "tiled" else
-                                               round(pairs / world * exec_fpp / ksec / 1e12 / FP32_PEAK_TFLOPS, 4)},
+                         "pairs_executed_frac": None if exec_frac is None else round(exec_frac, 4),
+                         "valu_frac_executed": None if exec_fpp is None or exec_frac is None or plan.kernel != "tiled" or args.tx_apod else
+                                               round(pairs / world * exec_frac * exec_fpp / ksec / 1e12 / FP32_PEAK_TFLOPS, 4)},
         }
         if prebuilt_ms is not None:
             rec["prebuilt_kernel_ms"] = round(prebuilt_ms, 3)
@@ -406,14 +457,34 @@ def main():
             rec["multi_gpu"] = multi
         if world == 1 and not args.no_cpu:
             try:
-                xh = torch.view_as_real(xc).cpu().numpy().view(np.complex64).reshape(M, N, T).transpose(2, 1, 0)
-                cb = cpu_baseline(w, xh)
+                xh = torch.view_as_real(xc).float().cpu().numpy().view(np.complex64).reshape(M, N, T).transpose(2, 1, 0)
+                plain = not (args.fmod or args.rx_apod or args.window_apod or args.tx_apod or args.gen_apod)
+                cb, lstep, limg = cpu_baseline(w, xh, apod=w["apod"] if plain else None)
                 rec["cpu_baseline"] = cb[0]
                 if len(cb) > 1:
                     rec["cpu_baseline_tuned"] = cb[1]
+                # parity of the very frame that was timed (last timed step, the kernel named in config.kernel_name) against the CPU
+                # port on the baseline's pixel lattice -- outside the timed region
+                if plain and limg is not None:
+                    img = torch.view_as_real(yimg.reshape(-1)).float().cpu().numpy().view(np.complex64).reshape(w["I1"], w["I2"], order="F")
+                    den = float(np.abs(limg).max())
+                    err = float(np.abs(img[::lstep, ::lstep] - limg).max()) / (den if den > 0 else 1.0)
+                    tol = 2e-3 if w["prec"] == "halfT" else 1e-4
+                    rec["parity_check"] = {"rel_err": float(f"{err:.3e}"), "tol": tol, "pixels": int(limg.size), "ok": bool(err <= tol and den > 0),
+                                           "against": "cpu_baseline (kind 'port': oracle/das_ref.c, float32) on every %dth pixel per axis; "
+                                                      "max |gpu - cpu| / max |cpu|" % lstep,
+                                           "kernel": plan.kernel_name()}
             except Exception as ex:  # report, never hide
                 rec["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"FAILED: {ex!r}"}
+        if args.checksum:
+            raw = torch.view_as_real(yimg.reshape(-1)).cpu().numpy().tobytes()
+            try:
+                import xxhash
+                rec["image_checksum"] = xxhash.xxh3_128_hexdigest(raw)
+            except ImportError:
+                import hashlib
+                rec["image_checksum"] = hashlib.blake2b(raw, digest_size=16).hexdigest()
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -91,6 +91,18 @@ extern "C" {
                                      (QDAS_CACHE_DIR, default ~/.cache/qdas); falls back to the prebuilt kernel with a message
                                      in qdas_last_error() if hiprtc is unavailable                                            */
 
+#define QDAS_PLAN_COPY_INPUTS   4 /* desc.mem == QDAS_MEM_DEVICE: copy Pi, Pr, Pv, Nv, apod, cinv, rx_normals into plan-owned device
+                                     buffers instead of reading the caller's arrays in place.  For hosts whose arrays do not
+                                     outlive the call that created the plan (the MEX gateway's persistent handles: MATLAB frees
+                                     the gpuArrays of das_spec's workspace when it returns)                                  */
+
+/* ---- LIFETIME of caller memory.  Host arrays (QDAS_MEM_HOST) are copied at qdas_plan_create and never touched again.  Device
+ *      arrays (QDAS_MEM_DEVICE) are used IN PLACE: Pi, Pr, Pv, Nv, apod, cinv and rx_normals must stay allocated and unchanged
+ *      until qdas_plan_destroy -- unless the plan was created with QDAS_PLAN_COPY_INPUTS.  acstride is read at creation only.
+ *      x / y belong to the caller and are only accessed by the execute call they are passed to (asynchronously on `stream` for
+ *      device memory: keep them alive until the stream has passed the call).  Every entry restores the calling thread's
+ *      current HIP device before it returns. */
+
 /* ---- error codes */
 #define QDAS_OK            0
 #define QDAS_EINVAL        1 /* bad argument / inconsistent sizes (message says which)  */

@@ -136,6 +136,9 @@ static int create_plan(int nrhs, const mxArray *prhs[]) {
     d.fs = num_at(prhs[8], 0, "tvars"); d.fmod = num_at(prhs[8], 1, "tvars");
     d.mem = dev ? QDAS_MEM_DEVICE : QDAS_MEM_HOST;
     d.device = -1; d.kernel = QDAS_KERNEL_AUTO;
+    /* gpuArray inputs: the handle outlives this call but the caller's gpuArrays do not (das_spec's workspace is freed when it
+       returns `k = h`), and the mxGPUArray views are released below -- the plan must own device copies (qdas.h, LIFETIME) */
+    if (dev) d.plan_flags |= QDAS_PLAN_COPY_INPUTS;
     int ndev = 0, devices[64];
     if (nrhs >= 10 && !mxIsEmpty(prhs[9])) {
         const mxArray *o = prhs[9], *f;

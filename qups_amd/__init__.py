@@ -5,7 +5,8 @@ A from-scratch drop-in for ONE hot path of thorstone25/qups: ``UltrasoundSystem.
 The compute lives in ``libqdas.so`` (hand-written HIP for gfx950, C ABI in ``include/qdas.h``);
 this package is the host-side mirror of the reference's interface for that path.
 """
-from .das_spec import DasError, DasPlan, DasProblem, MultiDevicePlan, build_problem, das_spec, parse_options  # noqa: F401
+from .das_spec import (DasError, DasPlan, DasProblem, MultiDevicePlan, build_problem, clear_plan_cache, das_spec, parse_options,
+                       plan_cache_info, problem_key)  # noqa: F401
 
 from .interpd import das_lut, sample2sep, wsinterpd2  # noqa: F401,E402
 from . import apodization  # noqa: F401,E402

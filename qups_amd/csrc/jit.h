@@ -21,7 +21,7 @@ struct JitSpec {
 
 std::string jit_source(const JitSpec &k);
 // "" on success, else the reason (hiprtc missing, compile log, ...)
-std::string jit_compile(const JitSpec &k, std::vector<char> *code, std::string *key_out);
+std::string jit_compile(const JitSpec &k, std::vector<char> *code, std::string *key_out, bool use_disk = true);
 std::string jit_get_kernel(const JitSpec &k, int device, hipFunction_t *fn, std::string *key_out);
 hipError_t jit_launch(hipFunction_t fn, const TileParams &P, unsigned grid, unsigned block, size_t lds, hipStream_t s);
 

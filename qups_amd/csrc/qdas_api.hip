@@ -54,6 +54,22 @@ extern "C" int qdas_device_info(int device, char *name, size_t name_len, int *cu
     return QDAS_OK;
 }
 
+// Every entry that works on a particular device switches to it for the duration of the call only: the calling thread's current
+// device is restored on every return path (a MEX gateway or a plain C caller keeps issuing its own work where it was).
+struct DeviceGuard {
+    int prev = -1;
+    bool restore = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (dev < 0) return;
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); restore = err == hipSuccess; }
+    }
+    ~DeviceGuard() { if (restore) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 // ------------------------------------------------------------------------------------ plan
 static size_t real_size(int dtype) { return dtype == QDAS_F64 ? 8 : 4; }            // geometry / time type
 static size_t data_size(int dtype) { return dtype == QDAS_F64 ? 16 : (dtype == QDAS_F32 ? 8 : 4); }  // complex sample
@@ -62,6 +78,7 @@ static size_t apod_real_size(int dtype) { return dtype == QDAS_F64 ? 8 : (dtype 
 struct qdas_plan {
     qdas_desc d{};
     uint64_t I = 0, i_count = 0, y_ld = 0, oN = 1, oM = 1;
+    double cinv0 = 0.0;                       // first entry of the sound-speed array (what `delays` uses, kern/das_spec.m:377)
     int device = 0;
     int kernel = QDAS_KERNEL_GENERIC;
     std::vector<void *> owned;                // device allocations made by the plan
@@ -135,13 +152,15 @@ template <class T, bool CPLX> __global__ void apod_fold_kernel(ApodFold f, T *ou
     }
 }
 
-// device copy of a caller array (host -> new device buffer; device -> used in place)
+// device copy of a caller array (host -> new device buffer; device -> used in place, or -- QDAS_PLAN_COPY_INPUTS -- copied
+// into a plan-owned buffer so that the plan outlives the caller's arrays)
 static int import_array(qdas_plan *pl, const void *src, size_t bytes, int mem, const void **out) {
-    if (mem == QDAS_MEM_DEVICE || bytes == 0) { *out = src; return QDAS_OK; }
+    const bool own = (pl->d.plan_flags & QDAS_PLAN_COPY_INPUTS) != 0;
+    if ((mem == QDAS_MEM_DEVICE && !own) || bytes == 0 || !src) { *out = src; return QDAS_OK; }
     void *p;
     int rc = dev_alloc(pl, &p, bytes);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p, src, bytes, mem == QDAS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     *out = p;
     return QDAS_OK;
 }
@@ -320,7 +339,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     if (pl->y_ld < pl->i_count) { delete pl; return fail(QDAS_EINVAL, "y_ld smaller than the pixel count"); }
 
     auto bail = [&](int code) { delete pl; return code; };
-    if (desc->device >= 0) { hipError_t e = hipSetDevice(desc->device); if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipSetDevice(%d): %s", desc->device, hipGetErrorString(e))); }
+    DeviceGuard guard(desc->device);
+    if (guard.err != hipSuccess) return bail(fail(QDAS_EHIP, "hipSetDevice(%d): %s", desc->device, hipGetErrorString(guard.err)));
     { hipError_t e = hipGetDevice(&pl->device); if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipGetDevice: %s", hipGetErrorString(e))); }
 
     if (pl->I == 0 || z.N == 0 || z.M == 0) { *out = pl; return QDAS_OK; }   // empty problem: execute() just zero-fills
@@ -355,6 +375,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     g.gen_kind = desc->rx_apod_kind; g.gen_p0 = desc->rx_apod_p[0]; g.gen_p1 = desc->rx_apod_p[1]; g.rxn = nullptr;
     if (g.gen_kind && desc->rx_normals && (rc = import_array(pl, desc->rx_normals, 3 * z.N * rs, desc->mem, &g.rxn))) return bail(rc);
     g.tile_list = nullptr; g.blocks_per_tile = 0; g.tile_cols = 0; g.tiles_z = 0;
+    if (dt == QDAS_F64) { if ((rc = fetch_host(desc->cinv, sizeof(double), desc->mem, &pl->cinv0))) return bail(rc); }
+    else { float c32; if ((rc = fetch_host(desc->cinv, sizeof(float), desc->mem, &c32))) return bail(rc); pl->cinv0 = (double)c32; }
 
     // ---- kernel selection
     // modes: 'DAS' (sum both apertures), and with fp32 data 'SYN' (keep the receive dimension: a plane per receiver)
@@ -516,9 +538,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             std::swap(t.strN, t.strM);
             t.kindB = 0; t.kindS = txkind;
         }
-        double cinv0;
-        if (dt == QDAS_F64) { if ((rc = fetch_host(desc->cinv, sizeof(double), desc->mem, &cinv0))) return bail(rc); }
-        else { float c32; if ((rc = fetch_host(desc->cinv, sizeof(float), desc->mem, &c32))) return bail(rc); cinv0 = (double)c32; }
+        const double cinv0 = pl->cinv0;
         t.fs = g.fs; t.fmod = g.fmod;
         t.cinv_fs = cinv0 * g.fs;
         t.cinv_pix = cmap ? (const float *)g.cinv + g.cst[5] : nullptr;
@@ -799,13 +819,17 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if ((rc = dev_alloc(pl, &pl->dx, pl->x_bytes))) return bail(rc);
         if ((rc = dev_alloc(pl, &pl->dy, pl->y_bytes))) return bail(rc);
     }
+    // the plan keeps no pointer into caller memory it does not need: host arrays were copied; device arrays are used in place
+    // (g.* / tp.*: they must stay valid for the life of the plan unless QDAS_PLAN_COPY_INPUTS made plan-owned copies)
+    pl->d.Pi = pl->d.Pr = pl->d.Pv = pl->d.Nv = pl->d.apod = pl->d.cinv = pl->d.rx_normals = nullptr;
+    pl->d.acstride = nullptr;
     *out = pl;
     return QDAS_OK;
 }
 
 extern "C" void qdas_plan_destroy(qdas_plan *pl) {
     if (!pl) return;
-    (void)hipSetDevice(pl->device);
+    DeviceGuard guard(pl->device);
     delete pl;
 }
 
@@ -906,7 +930,8 @@ extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, u
     const qdas_sizes &z = pl->d.sz;
     const size_t ds = data_size(z.dtype);
     hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipSetDevice(pl->device));
+    DeviceGuard guard(pl->device);
+    HIPCHK(guard.err);
     const size_t ybytes = (size_t)pl->y_ld * pl->oN * pl->oM * ds;
     if (pl->I == 0 || z.N == 0 || z.M == 0 || pl->i_count == 0 || z.T == 0) {      // empty sum: zeros
         for (uint64_t f = 0; f < F && ybytes; ++f) {
@@ -989,12 +1014,11 @@ extern "C" int qdas_plan_delays(qdas_plan *pl, void *tau, void *stream) {
     if (!pl || !tau) return fail(QDAS_EINVAL, "null argument");
     const qdas_sizes &z = pl->d.sz;
     if (pl->I == 0 || z.N == 0 || z.M == 0 || pl->i_count == 0) return QDAS_OK;
-    HIPCHK(hipSetDevice(pl->device));
+    DeviceGuard guard(pl->device);
+    HIPCHK(guard.err);
     hipStream_t s = (hipStream_t)stream;
     const size_t rs = real_size(z.dtype);
-    double cinv;
-    if (z.dtype == QDAS_F64) { int rc = fetch_host(pl->d.cinv, 8, pl->d.mem, &cinv); if (rc) return rc; }
-    else { float c; int rc = fetch_host(pl->d.cinv, 4, pl->d.mem, &c); if (rc) return rc; cinv = c; }
+    const double cinv = pl->cinv0;                     // (read at plan creation: the caller's arrays are not touched after it)
     GenericParams g = pl->gp;
     g.y_ld = pl->i_count;
     const size_t bytes = (size_t)pl->i_count * z.N * z.M * rs;
@@ -1226,7 +1250,8 @@ extern "C" int qdas_greens(const qdas_greens_desc *d, void *y, void *stream) {
     if (!(d->fs > 0) || !(d->fsr > 0) || !(d->R0 >= 0)) return fail(QDAS_EINVAL, "greens: fs, fsr must be positive and R0 non-negative");
     if (d->N > 65535 || d->M > 65535) return fail(QDAS_EUNSUPPORTED, "greens: at most 65535 receivers / transmitters");
     hipStream_t s = (hipStream_t)stream;
-    if (d->device >= 0) HIPCHK(hipSetDevice(d->device));
+    DeviceGuard guard(d->device);
+    HIPCHK(guard.err);
     if (d->S == 0 || d->N == 0 || d->M == 0) return QDAS_OK;
     if (d->I == 0 || d->T == 0) {
         HIPCHK(hipMemsetAsync(y, 0, d->S * d->N * d->M * data_size(d->dtype), s));
@@ -1258,7 +1283,8 @@ extern "C" int qdas_pre_plan_create(qdas_pre_plan **out, const qdas_pre_desc *d)
     const uint64_t N = d->Nfft ? d->Nfft : d->T;
     if (N >= (1ull << 31) || d->K >= (1ull << 31)) return fail(QDAS_EUNSUPPORTED, "pre: transform length / trace count too large");
     if (d->fdown != 0.0 && !(d->fs > 0)) return fail(QDAS_EINVAL, "Undefined sampling rate.");
-    if (d->device >= 0) HIPCHK(hipSetDevice(d->device));
+    DeviceGuard guard(d->device);
+    HIPCHK(guard.err);
     qdas_pre_plan *pl = new qdas_pre_plan();
     { hipError_t e = hipGetDevice(&pl->device); if (e != hipSuccess) { delete pl; return fail(QDAS_EHIP, "hipGetDevice: %s", hipGetErrorString(e)); } }
     const int rc = qdas::pre_create(&pl->p, d->T, d->K, d->Nfft, d->in_type, d->fs, d->t0, d->fdown);
@@ -1269,7 +1295,8 @@ extern "C" int qdas_pre_plan_create(qdas_pre_plan **out, const qdas_pre_desc *d)
 
 extern "C" int qdas_pre_execute(qdas_pre_plan *pl, const void *x, void *y, void *stream) {
     if (!pl || !y) return fail(QDAS_EINVAL, "null argument");
-    HIPCHK(hipSetDevice(pl->device));
+    DeviceGuard guard(pl->device);
+    HIPCHK(guard.err);
     const int rc = qdas::pre_execute(pl->p, x, y, (hipStream_t)stream);
     if (rc) return fail(QDAS_EHIP, "pre: hipFFT execution failed (%d)", rc);
     return QDAS_OK;
@@ -1277,7 +1304,7 @@ extern "C" int qdas_pre_execute(qdas_pre_plan *pl, const void *x, void *y, void 
 
 extern "C" void qdas_pre_plan_destroy(qdas_pre_plan *pl) {
     if (!pl) return;
-    (void)hipSetDevice(pl->device);
+    DeviceGuard guard(pl->device);
     qdas::pre_destroy(pl->p);
     delete pl;
 }
@@ -1306,7 +1333,8 @@ extern "C" int qdas_convd(const qdas_convd_desc *d, const void *x, const void *y
     const uint64_t ncb = (d->C + 63) / 64;
     if (d->S * (d->C == 1 ? 1 : ncb) >= (1ull << 31) || (L + 15) / 16 > 65535ull * (d->C == 1 ? 64 : 1))
         return fail(QDAS_EUNSUPPORTED, "convd: too many slices / outputs for one launch");
-    if (d->device >= 0) HIPCHK(hipSetDevice(d->device));
+    DeviceGuard guard(d->device);
+    HIPCHK(guard.err);
     ConvParams p{};
     p.x = x; p.y = y; p.z = z;
     p.C = d->C; p.M = d->M; p.N = d->N; p.L = L; p.S = d->S;

@@ -6,13 +6,19 @@
 // split into ndev contiguous slabs of the linear pixel index; geometry and channel data are REPLICATED; every device beamforms
 // its slab with an ordinary plan (qdas_plan_create with i_begin / i_count); the slabs are concatenated into the caller's y.
 // No collective library is needed for that: the data path is
-//     x: caller -> devices[0] (H2D if the caller's memory is host memory) -> peer copies down a binary tree (xGMI; every device
-//        forwards to at most log2(ndev) others, so no link carries the frame more than once per round)
+//     x: caller -> devices[0] (H2D if the caller's memory is host memory) -> SCATTER + ALL-GATHER with peer copies over the distinct
+//        devices: xGMI is a point-to-point mesh (every GPU has its own link to every other GPU of the node), so the frame is cut into
+//        U-1 pieces, device u pulls piece u from the root over the link (0,u), then every device pulls the other pieces from their
+//        holders over the links (u,v) -- all links carry 1/(U-1) of the frame at the same time: 2 |x| / ((U-1) B_link) instead of the
+//        log2(U) |x| / B_link of a tree (each pull runs on its own stream of the destination device, ordered with events only)
 //     y: slab g -> peer copy into its place in y on devices[0] (-> one D2H for host callers)
-// issued on one stream per device and ordered with events only -- the host thread never blocks before the final wait.
+// and the host thread never blocks before the final wait.  A device starts its kernel when its replica is complete: every pixel sums
+// over ALL (receiver, transmit) traces, and summing partial apertures as the pieces arrive would change the summation order -- the
+// sharded image is bit-identical to the single-plan image, by construction and by test.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -32,6 +38,21 @@ struct Shard {
     void *x = nullptr;                                  // this device's replica of the frame (null: shares the root's)
     void *y = nullptr;                                  // slab output, i_count x [N] x [M]
     std::vector<void *> owned;                          // device copies of geometry made for this shard
+    // replication (holders only: the first shard of every distinct device): one pull stream per source holder, an event per pull,
+    // and the event that says "my own piece has arrived" (what the other holders' pulls of that piece wait for)
+    std::vector<hipStream_t> pull_stream;
+    std::vector<hipEvent_t> pull_done;
+    hipEvent_t piece_ready = nullptr;
+};
+
+// the calling thread's current device is restored on every return path
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    DeviceGuard() { ok = hipGetDevice(&prev) == hipSuccess; }
+    ~DeviceGuard() { if (ok) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
 int failf(int code, const char *fmt, const char *a = "", const char *b = "") {
@@ -67,10 +88,18 @@ struct qdas_sharded_plan {
     size_t x_bytes = 0, ds = 0;
     void *y_root = nullptr;                             // host callers: the gathered image on devices[0]
     void *x_root = nullptr;                             // host callers: the uploaded frame on devices[0]
+    std::vector<int> holder;                            // shard index of the first shard on each distinct device (holder[0] = 0)
+    std::vector<int> uidx;                              // shard -> index into holder
+    bool executed = false;                              // (the `done` events of a previous frame exist)
     ~qdas_sharded_plan() {
+        DeviceGuard guard;
         for (Shard &s : sh) {
             (void)hipSetDevice(s.device);
+            (void)hipDeviceSynchronize();               // nothing of this plan may still be in flight when its buffers go
             if (s.plan) qdas_plan_destroy(s.plan);
+            for (hipStream_t ps : s.pull_stream) if (ps) (void)hipStreamDestroy(ps);
+            for (hipEvent_t pe : s.pull_done) if (pe) (void)hipEventDestroy(pe);
+            if (s.piece_ready) (void)hipEventDestroy(s.piece_ready);
             for (void *p : s.owned) (void)hipFree(p);
             if (s.x) (void)hipFree(s.x);
             if (s.y) (void)hipFree(s.y);
@@ -91,6 +120,7 @@ extern "C" int qdas_plan_create_sharded(qdas_sharded_plan **out, const qdas_desc
     if (desc->i_begin || desc->i_count || desc->y_ld) return failf(QDAS_EINVAL, "qdas_plan_create_sharded: the library chooses the pixel slabs (i_begin, i_count, y_ld must be 0)");
     int have = 0;
     SHIP(hipGetDeviceCount(&have));
+    DeviceGuard guard;
     qdas_sharded_plan *sp = new qdas_sharded_plan();
     auto bail = [&](int code) { delete sp; return code; };
     sp->d = *desc;
@@ -126,12 +156,8 @@ extern "C" int qdas_plan_create_sharded(qdas_sharded_plan **out, const qdas_desc
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.x_ready, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
         if (e != hipSuccess) return bail(failf(QDAS_EHIP, "qdas_plan_create_sharded: stream / event creation: %s", hipGetErrorString(e)));
-        if (s.device != root_dev) {                      // peer access makes the copies direct (xGMI); without it HIP stages them
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, s.device, root_dev) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(root_dev, 0);
-            (void)hipGetLastError();                     // (already enabled is fine)
-        }
         qdas_desc d = *desc;
+        if (s.device != root_dev || desc->mem == QDAS_MEM_HOST) d.plan_flags &= ~QDAS_PLAN_COPY_INPUTS;   // (this shard's inputs are plan-owned copies already)
         d.device = s.device;
         d.i_begin = s.i_begin; d.i_count = s.i_count; d.y_ld = 0;
         d.acstride = sp->acs.empty() ? nullptr : sp->acs.data();
@@ -164,10 +190,16 @@ extern "C" int qdas_plan_create_sharded(qdas_sharded_plan **out, const qdas_desc
             if (e == hipSuccess) e = hipMalloc(&s.y, (size_t)s.i_count * sp->oN * sp->oM * sp->ds + 16);
             if (e != hipSuccess) return bail(failf(QDAS_ENOMEM, "qdas_plan_create_sharded: slab buffer: %s", hipGetErrorString(e)));
         }
-        // replica of the frame: one per distinct device (a device listed twice shares it); the root needs one only for host callers
+        // replica of the frame: one per distinct device (a device listed twice shares it); the root needs one only for host callers.
+        // QDAS_SHARDED_FORCE_REPLICAS=1 (tests): every shard is its own holder even on a shared device, so that the replication
+        // machinery -- pull streams, events, pieces -- runs and is checked on a single GPU.
+        const bool force = getenv("QDAS_SHARDED_FORCE_REPLICAS") != nullptr;
         int first = g;
-        for (int q = 0; q < g; ++q) if (sp->sh[q].device == s.device) { first = q; break; }
-        if (first == g && !(s.device == root_dev && desc->mem == QDAS_MEM_DEVICE) && sp->x_bytes) {
+        if (!force) for (int q = 0; q < g; ++q) if (sp->sh[q].device == s.device) { first = q; break; }
+        if (first == g) sp->holder.push_back(g);
+        sp->uidx.push_back(0);
+        for (size_t k = 0; k < sp->holder.size(); ++k) if (sp->holder[k] == first) sp->uidx[g] = (int)k;
+        if (first == g && !(g == 0 && desc->mem == QDAS_MEM_DEVICE) && sp->x_bytes) {
             e = hipSetDevice(s.device);
             if (e == hipSuccess) e = hipMalloc(&s.x, sp->x_bytes);
             if (e != hipSuccess) return bail(failf(QDAS_ENOMEM, "qdas_plan_create_sharded: frame replica: %s", hipGetErrorString(e)));
@@ -177,6 +209,31 @@ extern "C" int qdas_plan_create_sharded(qdas_sharded_plan **out, const qdas_desc
         hipError_t e = hipSetDevice(root_dev);
         if (e == hipSuccess) e = hipMalloc(&sp->y_root, (size_t)sp->I * sp->oN * sp->oM * sp->ds + 16);
         if (e != hipSuccess) return bail(failf(QDAS_ENOMEM, "qdas_plan_create_sharded: gather buffer: %s", hipGetErrorString(e)));
+    }
+    // ---- replication plumbing: a pull stream + event per (destination holder, source holder), direct access between every pair
+    //      of distinct devices (peer copies between devices without it are staged through the host)
+    const int U = (int)sp->holder.size();
+    for (int u = 0; u < U; ++u) {
+        Shard &hu = sp->sh[sp->holder[u]];
+        hipError_t e = hipSetDevice(hu.device);
+        if (e != hipSuccess) return bail(failf(QDAS_EHIP, "qdas_plan_create_sharded: hipSetDevice: %s", hipGetErrorString(e)));
+        for (int v = 0; v < U; ++v) {
+            const int pd = sp->sh[sp->holder[v]].device;
+            if (pd == hu.device) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, hu.device, pd) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(pd, 0);
+            (void)hipGetLastError();                     // (already enabled is fine)
+        }
+        if (u == 0 || U < 2) continue;
+        hu.pull_stream.assign(U, nullptr);
+        hu.pull_done.assign(U, nullptr);
+        e = hipEventCreateWithFlags(&hu.piece_ready, hipEventDisableTiming);
+        for (int v = 0; v < U && e == hipSuccess; ++v) {
+            if (v == u) continue;
+            e = hipStreamCreateWithFlags(&hu.pull_stream[v], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&hu.pull_done[v], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) return bail(failf(QDAS_EHIP, "qdas_plan_create_sharded: pull stream / event creation: %s", hipGetErrorString(e)));
     }
     *out = sp;
     return QDAS_OK;
@@ -192,11 +249,13 @@ extern "C" int qdas_plan_execute_sharded(qdas_sharded_plan *sp, const void *x, v
     if (sp->I == 0 || z.N == 0 || z.M == 0 || z.T == 0) {                // empty sum: zeros
         if (!ybytes) return QDAS_OK;
         if (host) { memset(y, 0, ybytes); return QDAS_OK; }
+        DeviceGuard guard0;
         SHIP(hipSetDevice(root_dev));
         SHIP(hipMemsetAsync(y, 0, ybytes, (hipStream_t)stream));
         return QDAS_OK;
     }
     if (!x) return failf(QDAS_EINVAL, "null data");
+    DeviceGuard guard;
     // ---- the frame on the root device
     Shard &r0 = sp->sh[0];
     const void *x0 = x;
@@ -211,36 +270,53 @@ extern "C" int qdas_plan_execute_sharded(qdas_sharded_plan *sp, const void *x, v
         SHIP(hipStreamWaitEvent(r0.stream, r0.done, 0));
     }
     SHIP(hipEventRecord(r0.x_ready, r0.stream));
-    // ---- replicate down a binary tree over the DISTINCT devices (a device listed twice holds one replica): in round k, holder
-    //      u < 2^k feeds holder u + 2^k.  Each holder's copy runs on the stream of the first shard on that device.
-    std::vector<int> holder;                             // shard index of the first shard on each distinct device (holder[0] = 0)
-    std::vector<int> uidx(G, 0);                         // shard -> index into holder
-    for (int g = 0; g < G; ++g) {
-        int u = -1;
-        for (size_t k = 0; k < holder.size(); ++k) if (sp->sh[holder[k]].device == sp->sh[g].device) { u = (int)k; break; }
-        if (u < 0) { u = (int)holder.size(); holder.push_back(g); }
-        uidx[g] = u;
-    }
-    const int U = (int)holder.size();
+    // ---- replicate: scatter + all-gather over the holders (the first shard of every distinct device).  Piece p (p = 1 .. U-1, cut at
+    //      256-byte boundaries) belongs to holder p: it pulls it from the root, everybody else pulls it from holder p.
+    const int U = (int)sp->holder.size();
     std::vector<const void *> xr(U, nullptr);
     xr[0] = x0;
-    for (int step = 1; step < U; step <<= 1) {
-        for (int q = 0; q < step && q + step < U; ++q) {
-            Shard &src = sp->sh[holder[q]], &dst = sp->sh[holder[q + step]];
+    if (U >= 2) {
+        const size_t K = (size_t)U - 1;
+        auto cut = [&](size_t p) { return p >= K ? sp->x_bytes : (sp->x_bytes / K * p) & ~(size_t)255; };
+        for (int u = 1; u < U; ++u) {                    // scatter
+            Shard &dst = sp->sh[sp->holder[u]];
             if (!dst.x) return failf(QDAS_EINVAL, "qdas_plan_execute_sharded: internal: missing replica buffer");
+            xr[u] = dst.x;
+            const size_t b = cut((size_t)u - 1), e = cut((size_t)u);
             SHIP(hipSetDevice(dst.device));
-            SHIP(hipStreamWaitEvent(dst.stream, src.x_ready, 0));
-            SHIP(hipMemcpyPeerAsync(dst.x, dst.device, xr[q], src.device, sp->x_bytes, dst.stream));
+            hipStream_t ps = dst.pull_stream[0];
+            SHIP(hipStreamWaitEvent(ps, r0.x_ready, 0));
+            // the replica's last readers: the previous frame's kernels on this device, and the other holders' pulls of its piece --
+            // every shard's `done` event lies behind both (a shard launches only after all its pulls)
+            if (sp->executed) for (int g = 0; g < G; ++g) if (sp->sh[g].plan) SHIP(hipStreamWaitEvent(ps, sp->sh[g].done, 0));
+            if (e > b) SHIP(hipMemcpyPeerAsync((char *)dst.x + b, dst.device, (const char *)x0 + b, root_dev, e - b, ps));
+            SHIP(hipEventRecord(dst.piece_ready, ps));
+        }
+        for (int u = 1; u < U; ++u) {                    // all-gather
+            Shard &dst = sp->sh[sp->holder[u]];
+            SHIP(hipSetDevice(dst.device));
+            for (int v = 1; v < U; ++v) {
+                if (v == u) continue;
+                Shard &src = sp->sh[sp->holder[v]];
+                const size_t b = cut((size_t)v - 1), e = cut((size_t)v);
+                hipStream_t ps = dst.pull_stream[v];
+                SHIP(hipStreamWaitEvent(ps, src.piece_ready, 0));
+                SHIP(hipStreamWaitEvent(ps, dst.piece_ready, 0));     // (orders this pull behind the scatter's wait for the previous frame)
+                if (e > b) SHIP(hipMemcpyPeerAsync((char *)dst.x + b, dst.device, (const char *)src.x + b, src.device, e - b, ps));
+                SHIP(hipEventRecord(dst.pull_done[v], ps));
+            }
+            SHIP(hipStreamWaitEvent(dst.stream, dst.piece_ready, 0));
+            for (int v = 1; v < U; ++v) if (v != u) SHIP(hipStreamWaitEvent(dst.stream, dst.pull_done[v], 0));
             SHIP(hipEventRecord(dst.x_ready, dst.stream));
-            xr[q + step] = dst.x;
         }
     }
     std::vector<const void *> xs(G, nullptr);
     for (int g = 0; g < G; ++g) {
-        xs[g] = xr[uidx[g]];
-        if (g != holder[uidx[g]]) {                      // a later shard on the same device: its stream waits for the device's replica
+        const int u = sp->uidx[g];
+        xs[g] = xr[u];
+        if (g != sp->holder[u]) {                        // a later shard on the same device: its stream waits for the device's replica
             SHIP(hipSetDevice(sp->sh[g].device));
-            SHIP(hipStreamWaitEvent(sp->sh[g].stream, sp->sh[holder[uidx[g]]].x_ready, 0));
+            SHIP(hipStreamWaitEvent(sp->sh[g].stream, sp->sh[sp->holder[u]].x_ready, 0));
         }
     }
     // ---- beamform the slabs and gather them into y (on the root device)
@@ -271,6 +347,7 @@ extern "C" int qdas_plan_execute_sharded(qdas_sharded_plan *sp, const void *x, v
     } else {
         for (int g = 0; g < G; ++g) if (sp->sh[g].plan) SHIP(hipStreamWaitEvent((hipStream_t)stream, sp->sh[g].done, 0));
     }
+    sp->executed = true;
     return QDAS_OK;
 }
 

@@ -17,8 +17,10 @@ a GPU; :class:`DasPlan` needs ``libqdas.so`` and a HIP device and fails loudly o
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
+import threading
 from dataclasses import dataclass, field
 from typing import Any, Sequence
 
@@ -513,18 +515,29 @@ class DasPlan:
     def execute_colmajor(self, xc, F: int = 1):
         """``xc``: column-major channel data, i.e. a contiguous tensor shaped ``(F.., M, N, T)`` (or
         ``(F.., N, M, T)`` when transposed) of complex(prec).  Returns ``(F, oM, oN, i_count)``."""
-        torch = _torch()
         p = self.prob
         oN, oM = p.osize
-        y = torch.empty((F, oM, oN, self.i_count), dtype=_data_dtype(p.prec), device=self.device)
+        y = _torch().empty((F, oM, oN, self.i_count), dtype=_data_dtype(p.prec), device=self.device)
+        return self.execute_into(xc, y, F)
+
+    def execute_into(self, xc, y, F: int = 1):
+        """:meth:`execute_colmajor` into a caller-owned output ``y`` (contiguous, ``F * oM * oN * i_count`` elements of complex(prec) on
+        the plan's device): a frame stream reuses one image buffer instead of allocating per frame -- the reference's ``k.feval(yg, ...)``
+        treats ``yg`` as in/out the same way (``kern/das_spec.m:349-351,372``).  Returns ``y``."""
+        if self._h is None or not self._h.value:
+            raise DasError("the plan has been closed")
+        p = self.prob
+        oN, oM = p.osize
         per = p.T * p.N * p.M
+        want = _data_dtype(p.prec)
         if xc.numel() != F * per or not xc.is_contiguous():
             raise DasError("channel data size does not match the plan")
-        if xc.dtype != _data_dtype(p.prec) or xc.device != y.device:       # the library reads raw bytes: a wrong element size would run off the buffer
-            raise DasError(f"channel data must be {_data_dtype(p.prec)} on {y.device} for a '{p.prec}' plan, got {xc.dtype} on {xc.device}")
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.qdas_plan_execute_frames(self._h, C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()),
-                                                         F, per, oM * oN * self.i_count, self._stream()))
+        if xc.dtype != want or xc.device != self.device:       # the library reads raw bytes: a wrong element size would run off the buffer
+            raise DasError(f"channel data must be {want} on {self.device} for a '{p.prec}' plan, got {xc.dtype} on {xc.device}")
+        if y.numel() != F * oM * oN * self.i_count or not y.is_contiguous() or y.dtype != want or y.device != self.device:
+            raise DasError(f"output must be a contiguous {want} tensor of {F * oM * oN * self.i_count} elements on {self.device}")
+        _lib.check(self.lib.qdas_plan_execute_frames(self._h, C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                     F, per, oM * oN * self.i_count, self._stream()))
         return y
 
     def feval(self, x):
@@ -544,9 +557,32 @@ class DasPlan:
         return tau.permute(2, 1, 0)
 
     def close(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            self.lib.qdas_plan_destroy(self._h)
+        """Destroy the native plan (its device allocations, events, staging buffers).  Work already queued on the plan's device is
+        waited for first: the plan's tables must outlive the launches that read them."""
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
             self._h = C.c_void_p()
+            try:
+                _torch().cuda.synchronize(self.device)
+            except Exception:                           # interpreter shutdown: torch may be half gone; hipFree synchronises anyway
+                pass
+            self.lib.qdas_plan_destroy(h)
+
+    @property
+    def closed(self) -> bool:
+        return not (getattr(self, "_h", None) is not None and self._h.value)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class MultiDevicePlan:
@@ -629,11 +665,96 @@ class MultiDevicePlan:
         except Exception:
             pass
 
-    def __del__(self):  # pragma: no cover
-        try:
-            self.close()
-        except Exception:
-            pass
+
+# ------------------------------------------------------------------------------------------
+# plan cache: the reference keeps its compiled kernel object `persistent` between calls (kern/wsinterpd2.m:51,181-190) and hands
+# [k, PRE_ARGS, POST_ARGS] back for frame loops (kern/das_spec.m:72-81,387-390).  Here a call whose problem -- every argument except
+# the channel data -- equals an earlier call's reuses that call's plan: no uploads, no probe launches, no table folding.
+# ------------------------------------------------------------------------------------------
+_PLAN_CACHE: "collections.OrderedDict[bytes, DasPlan]" = collections.OrderedDict()
+_PLAN_CACHE_LOCK = threading.Lock()
+_PLAN_CACHE_STATS = {"hits": 0, "misses": 0, "evictions": 0}
+
+
+def _plan_cache_size() -> int:
+    try:
+        return max(0, int(os.environ.get("QDAS_PLAN_CACHE", "8")))
+    except ValueError:
+        return 8
+
+
+def _hasher():
+    try:                                    # xxh3: ~10 GB/s (BASELINE C5's 268 MB mask in 25 ms); blake2b as the portable stand-in
+        import xxhash
+        return xxhash.xxh3_128()
+    except ImportError:
+        import hashlib
+        return hashlib.blake2b(digest_size=16)
+
+
+def problem_key(prob: DasProblem, *extra) -> bytes:
+    """Digest of everything a plan is built from: sizes, flags, geometry, sound speed, apodization (contents, not identities), plus
+    ``extra`` (device, kernel choice, plan flags) and the ``QDAS_*`` environment, which steers plan construction."""
+    h = _hasher()
+    head = (prob.fun, prob.prec, prob.flag, prob.VS, prob.DV, prob.Isz, prob.T, prob.N, prob.M, prob.fs, prob.fmod, prob.apod_real,
+            prob.S, prob.tpose, prob.interp, prob.osize, extra,
+            tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("QDAS_") and k != "QDAS_PLAN_CACHE")))
+    h.update(repr(head).encode())
+    arrays = [prob.Pi, prob.Pr, prob.Pv, prob.Nv, prob.cinv, prob.apod, prob.acstride]
+    if prob.rx_apod is not None:
+        h.update(repr((prob.rx_apod["kind"], prob.rx_apod["p"])).encode())
+        arrays.append(prob.rx_apod["normals"])
+    for a in arrays:
+        if a is None:
+            h.update(b"\0none")
+        else:
+            a = np.ascontiguousarray(a)
+            h.update(repr((a.dtype.str, a.shape)).encode())
+            h.update(a.view(np.uint8).reshape(-1).data if a.size else b"")
+    return h.digest()
+
+
+def clear_plan_cache():
+    """Destroy every cached plan (their device memory is released)."""
+    with _PLAN_CACHE_LOCK:
+        plans = list(_PLAN_CACHE.values())
+        _PLAN_CACHE.clear()
+    for p in plans:
+        p.close()
+
+
+def plan_cache_info() -> dict:
+    with _PLAN_CACHE_LOCK:
+        return dict(_PLAN_CACHE_STATS, size=len(_PLAN_CACHE), capacity=_plan_cache_size())
+
+
+def _cached_plan(prob: DasProblem, device, kernel, jit):
+    """(plan, owned): the cached plan of an equal problem, else a new one.  ``owned``: the plan is NOT in the cache (cache disabled)
+    and the caller must close it unless it hands it out."""
+    cap = _plan_cache_size()
+    if cap == 0:
+        return DasPlan(prob, device=device, kernel=kernel, jit=jit), True
+    torch = _torch()
+    dev = device if device is not None else (f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else None)
+    key = problem_key(prob, str(dev), int(kernel), bool(jit))
+    with _PLAN_CACHE_LOCK:
+        plan = _PLAN_CACHE.get(key)
+        if plan is not None and not plan.closed:
+            _PLAN_CACHE.move_to_end(key)
+            _PLAN_CACHE_STATS["hits"] += 1
+            return plan, False
+        _PLAN_CACHE_STATS["misses"] += 1
+    plan = DasPlan(prob, device=device, kernel=kernel, jit=jit)
+    evicted = []
+    with _PLAN_CACHE_LOCK:
+        _PLAN_CACHE[key] = plan
+        _PLAN_CACHE.move_to_end(key)
+        while len(_PLAN_CACHE) > cap:
+            evicted.append(_PLAN_CACHE.popitem(last=False)[1])
+            _PLAN_CACHE_STATS["evictions"] += 1
+    for p in evicted:                       # (close() waits for the plan's device: a frame still in flight keeps its tables)
+        p.close()
+    return plan, False
 
 
 def das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs=None, c=None, *varargin, return_plan=False,
@@ -665,19 +786,30 @@ def das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs=None, c=None, *varargin, return_plan
     device = None if (opts["device"] is None or opts["device"] < 0) else f"cuda:{opts['device'] - 1}"
     if jit is None:
         jit = os.environ.get("QDAS_JIT", "0") not in ("", "0")
-    plan = DasPlan(prob, device=device, kernel=kernel, jit=jit)     # jit: hiprtc build for these sizes (qdas.h QDAS_PLAN_JIT)
-    Isz = prob.Isz
-    rev = lambda t: t.permute(*reversed(range(t.ndim)))
-    if fun == "delays":
-        tau = rev(plan.delays()).contiguous()           # (M, N, I) column-major parent
-        y = rev(tau.reshape(prob.M, prob.N, Isz[2], Isz[1], Isz[0]))
-        return (y, plan) if return_plan else y
-    xd = _cast_data(x, prob.prec, plan.device)
-    while xd.ndim < 3:
-        xd = xd.unsqueeze(-1)
-    F = int(np.prod(prob.fsz)) if prob.fsz else 1
-    xc = _colmajor(xd)                                  # (F.., M, N, T): MATLAB memory order
-    yc = plan.execute_colmajor(xc, F)                   # (F, oM, oN, I)
-    oN, oM = prob.osize
-    y = rev(yc.reshape(tuple(reversed(prob.fsz)) + (oM, oN, Isz[2], Isz[1], Isz[0])))
-    return (y, plan) if return_plan else y              # I1 x I2 x I3 x [1|N] x [1|M] x F...
+    # jit: hiprtc build for these sizes (qdas.h QDAS_PLAN_JIT).  The plan comes from the cache when an equal problem has been seen
+    # (QDAS_PLAN_CACHE = number of plans kept, default 8; 0: a fresh plan per call, destroyed before returning unless handed out)
+    plan, owned = _cached_plan(prob, device, kernel, jit)
+    try:
+        Isz = prob.Isz
+        rev = lambda t: t.permute(*reversed(range(t.ndim)))
+        if fun == "delays":
+            tau = rev(plan.delays()).contiguous()           # (M, N, I) column-major parent
+            y = rev(tau.reshape(prob.M, prob.N, Isz[2], Isz[1], Isz[0]))
+        else:
+            xd = _cast_data(x, prob.prec, plan.device)
+            while xd.ndim < 3:
+                xd = xd.unsqueeze(-1)
+            F = int(np.prod(prob.fsz)) if prob.fsz else 1
+            xc = _colmajor(xd)                                  # (F.., M, N, T): MATLAB memory order
+            yc = plan.execute_colmajor(xc, F)                   # (F, oM, oN, I)
+            oN, oM = prob.osize
+            y = rev(yc.reshape(tuple(reversed(prob.fsz)) + (oM, oN, Isz[2], Isz[1], Isz[0])))
+    except BaseException:
+        if owned:
+            plan.close()
+        raise
+    if return_plan:
+        return y, plan
+    if owned:
+        plan.close()
+    return y                                            # I1 x I2 x I3 x [1|N] x [1|M] x F...

@@ -52,18 +52,25 @@ def _oracle_lattice(w, xc, step):
                             apod=ap, prec="double")[..., 0, 0]
 
 
+@pytest.mark.parametrize("jit", [False, True], ids=["prebuilt", "jit"])
 @pytest.mark.parametrize("name,step,tol", [("c1", 1, 1e-4), ("c2", 8, 5e-5), ("c3", 32, 5e-5), ("c5", 16, 2e-3)])
-def test_config_lattice_parity(name, step, tol):
+def test_config_lattice_parity(name, step, tol, jit):
+    """Every BASELINE configuration at full size against the C oracle on a pixel lattice -- with the prebuilt kernel AND with the
+    plan-specialised hiprtc build, which is the kernel ``bench.py`` times (for C3: the reciprocal build with 32-transmit stages)."""
     w, xc, prob = _setup(name)
-    y, plan = _run(prob, xc)
+    y, plan = _run(prob, xc, jit=jit)
+    kname = plan.kernel_name()
     img = y.to(__import__("torch").complex64).cpu().numpy().reshape(w["I1"], w["I2"], order="F")
     ref = _oracle_lattice(w, xc, step)
     assert np.abs(ref).max() > 0
-    assert rel_err(img[::step, ::step, None], ref) <= tol, (name, plan.kernel, plan.fallback_tiles())
+    assert rel_err(img[::step, ::step, None], ref) <= tol, (name, kname, plan.fallback_tiles())
+    assert plan.kernel == "tiled", kname
+    assert ("[jit " in kname) if jit else ("[prebuilt]" in kname), kname       # the kernel that was asked for really ran
     if name in ("c2", "c3"):
-        assert plan.kernel == "tiled" and plan.fallback_tiles() == 0
-    if name == "c5":
-        assert plan.kernel == "tiled"          # I1 x I2 x 1 x N apodization is applied per (pixel, receiver) by the tiled kernel
+        assert plan.fallback_tiles() == 0
+    if name == "c3":                           # the headline kernel: reciprocal mode; 32 transmits per stage in the hiprtc build
+        assert plan.reciprocal and (",mb=32," in kname if jit else ",mb=16," in kname), kname
+    plan.close()
 
 
 @pytest.mark.parametrize("name", ["c2", "c3"])

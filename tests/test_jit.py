@@ -2,6 +2,8 @@
 specialisation (src/UltrasoundSystem.m:5626-5748 getDASConstCudaDef, src/sizes.cu:17-52; its own check: test/ParTest.m:322-327)."""
 import ctypes as C
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -28,8 +30,54 @@ def test_hiprtc_builds_the_specialised_kernel_without_a_device(tmp_path, monkeyp
         assert n.value > 10000 and os.path.exists(tmp_path / (msg.value.decode() + ".hsaco"))     # cached on disk under its key
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import kernel_regs
-    rows = [r for fn in os.listdir(tmp_path) for r in kernel_regs.kernel_table(str(tmp_path / fn))]
+    rows = [r for fn in os.listdir(tmp_path) if fn.endswith(".hsaco") for r in kernel_regs.kernel_table(str(tmp_path / fn))]
     assert len(rows) == 2 and all(r["name"] == "qdas_jit_tile" and r["vgpr_spill"] == 0 and r["scratch"] == 0 for r in rows), rows
+
+
+def test_disk_cache_is_checked_and_private(tmp_path, monkeypatch):
+    """(CPU) the code-object cache: a second request is served from disk, a truncated or tampered file is rejected and rebuilt, a
+    group-/world-writable cache directory is not used at all, and nothing is cached without HOME / QDAS_CACHE_DIR"""
+    import stat
+    import time
+    from qups_amd import _lib
+    L = _lib.lib()
+    f = L.qdas_debug_jit_compile
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_ulonglong, C.c_ulonglong, C.c_ulonglong, C.c_char_p, C.c_size_t, C.POINTER(C.c_ulonglong)]
+
+    def build(N):
+        msg, n = C.create_string_buffer(4000), C.c_ulonglong()
+        t = time.perf_counter()
+        rc = f(1, 1, 0, 0, N, 16, 512, msg, 4000, C.byref(n))
+        if rc and b"hiprtc not available" in msg.value:
+            pytest.skip(msg.value.decode())
+        assert rc == 0, msg.value.decode()
+        return msg.value.decode(), n.value, time.perf_counter() - t
+
+    cache = tmp_path / "c"
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(cache))
+    key, size, t_cold = build(24)
+    path = cache / (key + ".hsaco")
+    raw = path.read_bytes()
+    assert raw[:4] == b"\x7fELF" and raw[-24:-16] == b"QDASHSA1" and len(raw) == size + 24          # the code object + its trailer
+    assert stat.S_IMODE(os.stat(cache).st_mode) == 0o700 and stat.S_IMODE(os.stat(path).st_mode) == 0o600
+    # (a second process would load it from disk; in this process the in-memory cache answers -- so tamper and ask for ANOTHER key)
+    key2, size2, _ = build(40)
+    p2 = cache / (key2 + ".hsaco")
+    good = p2.read_bytes()
+    for bad in (good[:-30], good[:100] + bytes([good[100] ^ 1]) + good[101:], b"\x7fELF" + b"\0" * 64):
+        p2.write_bytes(bad)
+        out = subprocess.run([sys.executable, "-c",
+                              "import ctypes as C, sys; sys.path.insert(0, %r); from qups_amd import _lib; L = _lib.lib(); f = L.qdas_debug_jit_compile;"
+                              "f.argtypes = [C.c_int] * 4 + [C.c_ulonglong] * 3 + [C.c_char_p, C.c_size_t, C.POINTER(C.c_ulonglong)];"
+                              "m = C.create_string_buffer(4000); n = C.c_ulonglong(); rc = f(1, 1, 0, 0, 40, 16, 512, m, 4000, C.byref(n)); print(rc, m.value.decode(), n.value)"
+                              % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))],
+                             capture_output=True, text=True, env=dict(os.environ), timeout=300)
+        assert out.returncode == 0 and out.stdout.split()[:2] == ["0", key2], (out.stdout, out.stderr[-500:])
+        assert p2.read_bytes() == good                                      # rejected, rebuilt, rewritten
+    os.chmod(cache, 0o777)                                                   # a directory others can write to: not used
+    key3, _, _ = build(56)
+    assert not (cache / (key3 + ".hsaco")).exists()
+    os.chmod(cache, 0o700)
 
 
 @pytest.mark.gpu
@@ -57,12 +105,54 @@ def test_jit_plan_matches_prebuilt_and_oracle(seq, interp, prec, extra, tmp_path
         names.append(plan.kernel_name())
         plan.close()
     assert "[prebuilt]" in names[0] and "[jit " in names[1], names          # the hiprtc kernel really ran
-    assert len(os.listdir(tmp_path)) == 1                                    # ... and its code object is in the disk cache
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) == 1      # ... and its code object is in the disk cache
     ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"], cinv_f32(case["c"]),
                      VS=case["VS"], DV=case["DV"], interp=interp, fmod=fmod).reshape(-1, order="F")     # feval: I x 1 x 1, I1 fastest
     tol = 2e-3 if prec == "halfT" else (1e-2 if interp == "nearest" else 2e-5 if not fmod else 2e-4)
     assert rel_err(ys[1].reshape(-1), ref) <= tol
     assert rel_err(ys[1], ys[0]) <= 1e-6                                     # same arithmetic as the prebuilt instantiation
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [32, 64])
+@pytest.mark.parametrize("prec", ["single", "halfT"])
+@pytest.mark.parametrize("wtab", [False, True], ids=["plain", "weight-table"])
+def test_jit_reciprocal_32_transmit_stages(N, prec, wtab, tmp_path, monkeypatch):
+    """The headline kernel variant at test size: FSA with N % 32 == 0 takes the reciprocal mode, and its hiprtc build runs 32-transmit
+    stages (csrc/qdas_api.hip: ``k.mb = 32``) -- a configuration that exists ONLY as a hiprtc build.  fp32 and fp16 data, with and
+    without a pixel-independent N x M weight table; against the float64 oracle and the prebuilt 16-transmit kernel."""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import DasPlan, build_problem, parse_options
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    case = make_case(seq="FSA", interp="lanczos3", seed=77 + N, N=N, I1=160, I2=40, pitch=0.2e-3, zlim=(5e-3, 16e-3), xspan=5e-3)
+    x = torch.from_numpy(case["x"])
+    va = list(case["opt"]) + ["interp", "lanczos3", "input-precision", prec]
+    ap = ()
+    if wtab:                                         # Hann receive x transmit windows: 1 x 1 x 1 x N and 1 x 1 x 1 x 1 x M
+        wn = np.hanning(N + 2)[1:-1].astype(np.float32)
+        a_rx, a_tx = wn.reshape(1, 1, 1, N, 1), (0.5 + 0.5 * wn).reshape(1, 1, 1, 1, N)
+        va += ["apod", a_rx, "apod", a_tx]
+        ap = (a_rx.astype(np.float64), a_tx.astype(np.float64))
+    opts = parse_options(x, va)
+    T = case["x"].shape[0]
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], (T, N, N), case["t0"], case["fs"], case["c"], opts)
+    ys, names, rec = [], [], []
+    for jit in (False, True):
+        with DasPlan(prob, kernel=2, jit=jit) as plan:
+            y = plan.feval(x)
+            ys.append(torch.view_as_real(y).float().cpu().numpy().view(np.complex64)[..., 0] if prec == "halfT" else y.cpu().numpy())
+            names.append(plan.kernel_name()); rec.append(plan.reciprocal)
+            assert plan.fallback_tiles() == 0
+    assert all(rec), names
+    assert "[prebuilt]" in names[0] and "[jit " in names[1] and ",sym" in names[1] and ",mb=32," in names[1], names
+    assert ("wtab" in names[1]) == wtab, names
+    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"], cinv_f32(case["c"]),
+                     VS=case["VS"], DV=case["DV"], interp="lanczos3", apod=ap).reshape(-1, order="F")
+    tol = 2e-3 if prec == "halfT" else 2e-5
+    assert rel_err(ys[1].reshape(-1), ref) <= tol, names[1]
+    assert rel_err(ys[0].reshape(-1), ref) <= tol, names[0]
+    assert rel_err(ys[1], ys[0]) <= (2e-6 if prec == "single" else 1e-5)    # another stage partition: fp32 re-association only
 
 
 @pytest.mark.gpu
