@@ -466,13 +466,24 @@ def main():
                 # parity of the very frame that was timed (last timed step, the kernel named in config.kernel_name) against the CPU
                 # port on the baseline's pixel lattice -- outside the timed region
                 if plain and limg is not None:
+                    from oracle import das_ref
                     img = torch.view_as_real(yimg.reshape(-1)).float().cpu().numpy().view(np.complex64).reshape(w["I1"], w["I2"], order="F")
                     den = float(np.abs(limg).max())
-                    err = float(np.abs(img[::lstep, ::lstep] - limg).max()) / (den if den > 0 else 1.0)
+                    err32 = float(np.abs(img[::lstep, ::lstep] - limg).max()) / (den if den > 0 else 1.0)
+                    # the judge of parity is the DOUBLE-precision port (the float32 port's own rounding -- fp32 delays at tau*fs ~ 3e3
+                    # samples -- is ~1.5e-4 of the maximum at C3, above the kernel's): every other lattice pixel per axis
+                    s2 = 2 * lstep
+                    ap = () if w["apod"] is None else (w["apod"][::s2, ::s2],)
+                    ref = das_ref.das_spec("DAS", w["Pi"][:, ::s2, ::s2, :], w["Pr"], w["Pv"], w["Nv"], xh, w["t0"], w["fs"],
+                                           1.0 / np.float64(np.float32(1.0 / w["c0"])), VS="plane-waves" not in w["opt"],
+                                           DV="diverging-waves" in w["opt"], interp=w["interp"], apod=ap, prec="double")[:, :, 0, 0, 0]
+                    den64 = float(np.abs(ref).max())
+                    err = float(np.abs(img[::s2, ::s2] - ref).max()) / (den64 if den64 > 0 else 1.0)
                     tol = 2e-3 if w["prec"] == "halfT" else 1e-4
-                    rec["parity_check"] = {"rel_err": float(f"{err:.3e}"), "tol": tol, "pixels": int(limg.size), "ok": bool(err <= tol and den > 0),
-                                           "against": "cpu_baseline (kind 'port': oracle/das_ref.c, float32) on every %dth pixel per axis; "
-                                                      "max |gpu - cpu| / max |cpu|" % lstep,
+                    rec["parity_check"] = {"rel_err": float(f"{err:.3e}"), "tol": tol, "pixels": int(ref.size), "ok": bool(err <= tol and den64 > 0),
+                                           "against": "oracle/das_ref.c in double precision (the C restatement the cpu_baseline times in float32) on "
+                                                      "every %dth pixel per axis of the frame of the last timed step; max |gpu - cpu| / max |cpu|" % s2,
+                                           "rel_err_vs_float32_port": float(f"{err32:.3e}"), "pixels_float32_port": int(limg.size),
                                            "kernel": plan.kernel_name()}
             except Exception as ex:  # report, never hide
                 rec["cpu_baseline"] = {"value": None, "unit": "Mpixel/s", "cores": os.cpu_count(), "kind": "port",
