@@ -96,6 +96,10 @@ extern "C" {
                                      outlive the call that created the plan (the MEX gateway's persistent handles: MATLAB frees
                                      the gpuArrays of das_spec's workspace when it returns)                                  */
 
+#define QDAS_PLAN_NO_MIRROR     8 /* never use the lateral-mirror mode of the tiled kernel (scan, array and sequence mirror-symmetric
+                                     about x = 0, detected from the geometry: tap index and weights are shared by a pixel and its
+                                     mirror image)                                                                            */
+
 /* ---- LIFETIME of caller memory.  Host arrays (QDAS_MEM_HOST) are copied at qdas_plan_create and never touched again.  Device
  *      arrays (QDAS_MEM_DEVICE) are used IN PLACE: Pi, Pr, Pv, Nv, apod, cinv and rx_normals must stay allocated and unchanged
  *      until qdas_plan_destroy -- unless the plan was created with QDAS_PLAN_COPY_INPUTS.  acstride is read at creation only.
@@ -188,6 +192,8 @@ int  qdas_plan_tile_shape(const qdas_plan *plan, int *tile_z, int *tile_cols, in
 /* 1 when a QDAS_KERNEL_TILED plan runs in reciprocal mode (transmit elements == receive elements, one t0: every unordered
  * transmit/receive pair is indexed and weighted once), else 0 */
 int  qdas_plan_reciprocal(const qdas_plan *plan);
+/* 1 when a QDAS_KERNEL_TILED plan runs in lateral-mirror mode (QDAS_PLAN_NO_MIRROR), else 0 */
+int  qdas_plan_mirror(const qdas_plan *plan);
 /* human-readable name of the kernel a plan launches for one frame, e.g.
  *   "das_tile_kernel<interp=3,f32,sym,mb=16,W=128> [prebuilt]"   |   "... [jit 5f0c...]"  (QDAS_PLAN_JIT, hiprtc build)   |
  *   "das_generic_kernel<interp=2,f64>"

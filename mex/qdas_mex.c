@@ -145,6 +145,7 @@ static int create_plan(int nrhs, const mxArray *prhs[]) {
         if (!mxIsStruct(o)) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "opts must be a struct.");
         if ((f = mxGetField(o, 0, "jit")) && num_at(f, 0, "opts.jit") != 0) d.plan_flags |= QDAS_PLAN_JIT;
         if ((f = mxGetField(o, 0, "reciprocal")) && num_at(f, 0, "opts.reciprocal") == 0) d.plan_flags |= QDAS_PLAN_NO_RECIPROCAL;
+        if ((f = mxGetField(o, 0, "mirror")) && num_at(f, 0, "opts.mirror") == 0) d.plan_flags |= QDAS_PLAN_NO_MIRROR;
         if ((f = mxGetField(o, 0, "kernel"))) d.kernel = (int32_t)num_at(f, 0, "opts.kernel");
         if ((f = mxGetField(o, 0, "devices"))) {
             ndev = (int)mxGetNumberOfElements(f);

@@ -63,14 +63,14 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const float2 *part, ST
 
 
 
-TileConfig tile_config(int dtype, int sym, int narrow) {
-    const Cfg &g = CFGS[cfg_index(dtype, sym, 1, narrow)];
+TileConfig tile_config(int dtype, int sym, int narrow, int fb) {
+    const Cfg &g = CFGS[cfg_index(dtype, sym, fb, narrow)];
     TileConfig c;
     c.waves = g.waves;
     c.mb = g.mb;
     c.window = g.w;
     c.threads = g.waves * 64;
-    c.lds_bytes = (size_t)g.nbuf * g.mb * (sym ? 2 : 1) * g.w * (dtype == 2 ? 4 : dtype == 0 ? 16 : 8);
+    c.lds_bytes = (size_t)g.nbuf * g.mb * ((sym || fb == 2) ? 2 : 1) * g.w * (dtype == 2 ? 4 : dtype == 0 ? 16 : 8);
     return c;
 }
 
@@ -109,10 +109,13 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M, narrow, P.act_bytes ? 1 : 0, P.wtab ? 1 : 0);    // (the two-frame configurations have the same LDS image)
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
     if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part && !P.bf))) return hipErrorInvalidValue;
-const int nf = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
+    // frames per launch; lateral-mirror plans (one frame) run the two-window-set instantiations as well
+    const int nfr = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
+    if (P.mir && !P.probe && (nfr != 1 || sym || P.big || P.bf || P.lut_tx || P.syn || P.wtab || P.apix || P.gen_kind || narrow)) return hipErrorInvalidValue;
+    const int nf = (P.mir && !P.probe) ? 2 : nfr;
     if ((nf != 1 && nf != 2 && nf != 4) || (nf > 1 && (sym || P.big))) return hipErrorInvalidValue;
     if (P.lut_tx && (sym || nf != 1 || (dtype != 1 && dtype != 2) || (P.syn && dtype != 1))) return hipErrorInvalidValue;
-    if (jit && (P.probe || nf != 1 || P.lut_tx || P.bf)) return hipErrorInvalidValue;
+    if (jit && (P.probe || nfr != 1 || P.lut_tx || P.bf)) return hipErrorInvalidValue;
     if (P.bf && (sym || nf != 1 || dtype != 1 || P.lut_tx || P.big || P.apix || P.gen_kind)) return hipErrorInvalidValue;
     hipError_t e = jit ? jit_launch(jit, P, ntiles * P.ksplit, (unsigned)CFGS[cfg_index(dtype, sym, 1, narrow)].waves * 64u, jit_lds ? jit_lds : lds, s) : P.lut_tx ? (dtype == 2 ? launch_tile_luth(P, ntiles, lds, s) : launch_tile_lut(P, ntiles, lds, s)) : sym ? (dtype == 2 ? launch_tile_symh(P, ntiles, lds, s) : narrow ? launch_tile_symw(P, ntiles, lds, s) : launch_tile_sym(P, ntiles, lds, s))
                  : nf == 4 ? (dtype == 2 ? launch_tile_f16x4(P, ntiles, lds, s) : launch_tile_f32x4(P, ntiles, lds, s))
@@ -120,9 +123,9 @@ const int nf = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
                            : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : narrow == 2 ? launch_tile_f32w(P, ntiles, lds, s) : (P.bf && !P.probe) ? launch_tile_bf(P, ntiles, lds, s) : (P.big && !P.probe) ? launch_tile_f32big(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));
     if (e != hipSuccess || P.probe || P.ksplit <= 1 || P.syn || P.bf) return e;   // ('SYN' planes are accumulated in place, 'BF' planes stored by their owners)
     const unsigned rb = (unsigned)((P.i_count + 255) / 256);
-    for (int f = 0; f < nf; ++f) {                       // partial images: [split][frame][pixel]
+    for (int f = 0; f < nfr; ++f) {                      // partial images: [split][frame][pixel]
         const float2 *src = P.part + (size_t)f * P.i_count;
-        const uint64_t stride = (uint64_t)nf * P.i_count;
+        const uint64_t stride = (uint64_t)nfr * P.i_count;
         if (dtype == 2) tile_reduce_kernel<uint32_t><<<rb, 256, 0, s>>>(src, (uint32_t *)P.y + (size_t)f * P.y_fstride, P.i_count, P.ksplit, stride);
         else            tile_reduce_kernel<float2><<<rb, 256, 0, s>>>(src, (float2 *)P.y + (size_t)f * P.y_fstride, P.i_count, P.ksplit, stride);
     }

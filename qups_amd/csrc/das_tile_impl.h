@@ -252,8 +252,17 @@ template <class C> __device__ __forceinline__ uint32_t Tile<C>::locate(uint32_t 
     // (depth index, column: may lie outside the image -- clamped for the delays, masked at the store)
     i1 = (tz << tzl) + (wave_z << wzl) + (uint32_t)(lane & ((1 << wzl) - 1));
     col = txi * ((uint32_t)(C::WAVES * 64) >> tzl) + (wave_c << (6 - wzl)) + (uint32_t)(lane >> wzl);
-    const uint64_t ig = (uint64_t)i1 + I1 * (uint64_t)col;
-    const bool inside = ((uint64_t)i1 < I1) && ((uint64_t)col < ncols) && (ig >= P.i_begin) && (ig < i_end);
+    const bool mirror = C::FBX && QSPEC(MIR, P.mir);
+    const uint64_t ncols_mine = mirror ? (ncols + 1) / 2 : ncols;      // lateral-mirror mode: the tiles cover the first half of the columns
+    uint64_t ig = (uint64_t)i1 + I1 * (uint64_t)col;
+    bool inside = ((uint64_t)i1 < I1) && ((uint64_t)col < ncols_mine) && (ig >= P.i_begin) && (ig < i_end);
+    if constexpr (C::FBX) {
+        if (!first && mirror) {                       // (second call, from the epilogue: the MIRROR image of my pixel; the centre column is its own)
+            const uint64_t col2 = ncols - 1 - (uint64_t)col;
+            inside = inside && col2 != (uint64_t)col;
+            ig = (uint64_t)i1 + I1 * col2;
+        }
+    }
     uint32_t po = inside ? (uint32_t)(ig - P.i_begin) : NOT_MINE;
     asm volatile("" : "+v"(po));                      // opaque: ONE register carries "mine?" and "where" (never re-derived from the 64-bit (row, column) pair)
     return po;
@@ -288,7 +297,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
 
     uint32_t i1, col;
     pofs = locate(i1, col, true);
-    const uint64_t I1 = QSPEC(I1, P.I1), ncols = P.I2 * P.I3;
+    const uint64_t I1 = QSPEC(I1, P.I1), ncols = (C::FBX && QSPEC(MIR, P.mir)) ? (P.I2 * P.I3 + 1) / 2 : P.I2 * P.I3;
     ipx = ((uint64_t)i1 < I1 ? (uint64_t)i1 : I1 - 1) + I1 * ((uint64_t)col < ncols ? (uint64_t)col : ncols - 1);
     cf = P.cinv_fs;
     if constexpr (C::LUT) {                            // delays from host tables (tau_tx: I x M, tau_rx: I x N, in samples; table-driven plans cover [0, I))
@@ -698,6 +707,22 @@ template <class C> __device__ __forceinline__ void Tile<C>::epilogue() {
         frame_sums(res);
         uint32_t po = pofs;
         if constexpr (C::SYM) { uint32_t i1, col; po = locate(i1, col, false); }      // (nothing in the reciprocal stage loop needs it: not kept alive)
+        if constexpr (C::FB2) {
+            if (QSPEC(MIR, P.mir)) {                     // lateral-mirror mode: the second window set's sum belongs to the mirror image of my pixel
+                uint32_t i1, col;
+                const uint32_t po2 = locate(i1, col, false);
+                const uint32_t pos[2] = {po, po2};
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    uint32_t q = pos[f];
+                    if (q == NOT_MINE) continue;
+                    asm volatile("" : "+v"(q));
+                    if (S > 1) { float2 *base = P.part + (size_t)split * P.i_count; asm volatile("" : "+s"(base)); base[q] = make_float2(res[f].x, res[f].y); }
+                    else { ST *base = (ST *)P.y; asm volatile("" : "+s"(base)); st(base, (size_t)q, cplx<float>{res[f].x, res[f].y}); }
+                }
+                return;
+            }
+        }
         if (po != NOT_MINE) {
             asm volatile("" : "+v"(po));
 #pragma unroll

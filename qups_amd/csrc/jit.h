@@ -17,6 +17,7 @@ struct JitSpec {
     int kindB, kindS, tzl, wzl;                         // delay kinds, tile / wave footprint
     unsigned ksplit;
     int gen_kind, has_apix, apix_real, syn, has_st, has_cinv_pix;
+    int mir;                                            // lateral-mirror mode: the two-window-set instantiation (TileCfg::FB2), one frame
 };
 
 std::string jit_source(const JitSpec &k);

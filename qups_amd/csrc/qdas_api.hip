@@ -322,6 +322,48 @@ static int choose_tile_shape(qdas_plan *pl, const qdas_desc *desc, F &&set_grid)
     return QDAS_OK;
 }
 
+// Lateral-mirror symmetry (tile_params.h `mir`): is pixel column I2-1-c the mirror image (x -> -x) of column c, bit for bit?
+__global__ void mirror_check_kernel(const float *Pi, uint64_t I1, uint64_t I2, uint32_t *bad) {
+    const uint64_t half = (I2 + 1) / 2, n = I1 * half;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i1 = q % I1, c = q / I1;
+        const float *a = Pi + 3 * (i1 + I1 * c), *b = Pi + 3 * (i1 + I1 * (I2 - 1 - c));
+        if (!(a[0] == -b[0] && a[1] == b[1] && a[2] == b[2])) { *bad = 1u; return; }      // (NaN coordinates: not symmetric)
+    }
+}
+// receivers, transmits (positions, normals, t0) and pixel columns mirror-symmetric about x = 0?  fp32 geometry.
+static int mirror_symmetric(const qdas_desc *desc, const float *dPi, bool *yes) {
+    const qdas_sizes &z = desc->sz;
+    *yes = false;
+    std::vector<float> hr(3 * z.N), hv(4 * z.M), hn(3 * z.M);
+    int rc;
+    if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return rc;
+    if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return rc;
+    if ((rc = fetch_host(desc->Nv, hn.size() * 4, desc->mem, hn.data()))) return rc;
+    for (uint64_t n = 0; n < z.N; ++n) {
+        const float *a = &hr[3 * n], *b = &hr[3 * (z.N - 1 - n)];
+        if (!(a[0] == -b[0] && a[1] == b[1] && a[2] == b[2])) return QDAS_OK;
+    }
+    for (uint64_t m = 0; m < z.M; ++m) {
+        const float *a = &hv[4 * m], *b = &hv[4 * (z.M - 1 - m)], *c = &hn[3 * m], *d = &hn[3 * (z.M - 1 - m)];
+        if (!(a[0] == -b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3] && c[0] == -d[0] && c[1] == d[1] && c[2] == d[2])) return QDAS_OK;
+    }
+    uint32_t *flag = nullptr;
+    HIPCHK(hipMalloc(&flag, sizeof(uint32_t)));
+    hipError_t e = hipMemset(flag, 0, sizeof(uint32_t));
+    uint32_t bad = 1;
+    if (e == hipSuccess) {
+        const uint64_t n = z.I1 * ((z.I2 + 1) / 2);
+        mirror_check_kernel<<<(unsigned)std::min<uint64_t>((n + 255) / 256, 4096), 256, 0, 0>>>(dPi, z.I1, z.I2, flag);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(&bad, flag, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(flag);
+    HIPCHK(e);
+    *yes = bad == 0;
+    return QDAS_OK;
+}
+
 extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     if (!out || !desc) return fail(QDAS_EINVAL, "null argument");
     *out = nullptr;
@@ -474,9 +516,18 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         const uint64_t mb = (uint64_t)tile_config(dt, 0).mb;
         if (4 * z.M * ((z.N + mb - 1) / mb) < 3 * z.N * ((z.M + mb - 1) / mb)) swap = true;     // (at least a quarter fewer stages: measured break-even, PW31 on 128 elements)
     }
+    // Lateral-mirror mode (tile_params.h `mir`): a scan, an array and a sequence that are mirror-symmetric about x = 0 -- the usual case: a
+    // centred sector or rectangle under a linear / convex array, plane waves or virtual sources at +- the same angles / positions -- have
+    // tau(pixel', N-1-n, M-1-m) == tau(pixel, n, m) bit for bit: tap index and interpolation weights serve a pixel and its mirror image.
+    // Detected from the geometry itself; the whole image in one plan, plain 'DAS', scalar sound speed, no apodization (yet).
+    bool mir = false;
+    if (eligible && !syn && !bfm && !sym && (dt == QDAS_F32 || dt == QDAS_F16) && z.S == 0 && !g.gen_kind && !cmap && z.I3 == 1 && z.I2 >= 2
+        && z.N >= 2 && desc->i_begin == 0 && pl->i_count == pl->I && !(desc->plan_flags & QDAS_PLAN_NO_MIRROR) && !getenv("QDAS_NO_MIRROR")) {
+        if ((rc = mirror_symmetric(desc, (const float *)g.Pi, &mir))) return bail(rc);
+    }
     // stage / block element counts of the kernel: receivers / transmits, or swapped
     const uint64_t kN = swap ? z.M : z.N, kM = swap ? z.N : z.M;
-    pl->tc = tile_config(dt, sym);
+    pl->tc = tile_config(dt, sym, 0, mir ? 2 : 1);
     const int pixw = (pix_arr >= 0 || g.gen_kind) ? 1 : 0;      // a pixel x receiver weight: the tile keeps a stage list (das_tile_impl.h plan_stages)
     const int wtb = z.S > npix ? 1 : 0;      // pixel-independent arrays: folded into an N x M table, staged per stage in LDS
     if (eligible && tile_lds_bytes(dt, sym, kN, kM, 0, pixw, wtb) > tile_lds_limit(sym)) {
@@ -544,10 +595,11 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         t.cinv_pix = cmap ? (const float *)g.cinv + g.cst[5] : nullptr;
         t.flag = z.flag; t.VS = z.VS; t.DV = z.DV; t.sym = sym; t.big = big;
         // tile grid: (1 << tz_log2) pixels of I1 x tile_cols columns (columns = I2*I3 flattened); the footprint is chosen below
+        t.mir = mir ? 1 : 0;
         auto set_grid = [&](int tzl) {
             t.tz_log2 = tzl;
             pl->tile_cols = ((unsigned)pl->tc.waves * 64u) >> tzl;
-            const uint64_t col0 = desc->i_begin / z.I1, col1 = (desc->i_begin + pl->i_count - 1) / z.I1;
+            const uint64_t col0 = desc->i_begin / z.I1, col1 = t.mir ? (z.I2 + 1) / 2 - 1 : (desc->i_begin + pl->i_count - 1) / z.I1;   // (mirror mode: the first half of the columns)
             t.tiles_z = (uint32_t)((z.I1 + (1u << tzl) - 1) >> tzl);
             t.tile_x0 = (uint32_t)(col0 / pl->tile_cols);
             t.tiles_x = (uint32_t)(col1 / pl->tile_cols) - t.tile_x0 + 1;
@@ -675,6 +727,11 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             pl->tc = tile_config(dt, 1, 0);
             if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
         }
+        if (t.mir && !pl->no_fallback) {                // (a misfit tile is redone by the generic kernel, which knows nothing of mirror images)
+            t.mir = 0; mir = false;
+            pl->tc = tile_config(dt, sym);
+            if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
+        }
         // Focused transmits whose focal planes cut through the image: the delay flips sign there (src/bf.cu:106-108), so the tiles a plane
         // crosses fit no window and would go to the generic kernel -- with a walking aperture that is half the image.  Second attempt:
         // every transmit listed twice, once per side of its plane (tile_params.h kindS == 3); kept if fewer tiles misfit.
@@ -776,7 +833,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         JitSpec k{};
         k.interp = (z.flag & 7) == 4 ? 1 : (z.flag & 7); k.dtype = dt; k.fmod = t.fmod != 0.0; k.wtab = t.wtab != nullptr; k.sym = t.sym; k.big = t.big;
         const int narrow = (t.sym && dt == QDAS_F32 && t.narrow) ? 1 : (!t.sym && dt == QDAS_F32 && t.narrow == 2) ? 2 : 0;
-        const Cfg &cg = CFGS[cfg_index(dt, t.sym, 1, narrow)];
+        const Cfg &cg = CFGS[cfg_index(dt, t.sym, t.mir ? 2 : 1, narrow)];
+        k.mir = t.mir;
         k.waves = cg.waves; k.mb = cg.mb; k.w = cg.w; k.nbuf = cg.nbuf;
         k.N = t.N; k.M = t.M; k.T = t.T; k.I1 = t.I1; k.strN = t.strN; k.strM = t.strM;
         k.kindB = t.kindB; k.kindS = t.kindS; k.tzl = t.tz_log2; k.wzl = t.wz_log2; k.ksplit = t.ksplit;
@@ -798,7 +856,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             const size_t off_act = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + 15) & ~(size_t)15;   // Tile::setup
             const size_t off_wst = off_act + (((size_t)t.act_bytes + 15) & ~(size_t)15);
             const size_t hdr = (off_wst + (t.wtab ? (size_t)k.nbuf * (2 * (size_t)k.mb * 8 + 16) : 0) + 15) & ~(size_t)15;
-            size_t body = (size_t)k.nbuf * k.mb * (t.sym ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
+            size_t body = (size_t)k.nbuf * k.mb * ((t.sym || t.mir) ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
             const size_t scratch = 2 * (size_t)k.waves * MX * 4 + 1024;
             if (body < scratch) body = scratch;
             pl->jit_lds = hdr + body;
@@ -809,7 +867,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; }
         else { pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel"; }
     }
-    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->tp.stage_shift && pl->tp.narrow != 2 && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->jit_fn && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
+    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->tp.mir && !pl->tp.stage_shift && pl->tp.narrow != 2 && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->jit_fn && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
     // four frames per launch: not for fp32 plans with remodulation, a weight table or a pixel x receiver weight (das_tile_impl.h launch_tile_i)
     pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr
                   || (dt == QDAS_F32 && pl->kernel == QDAS_KERNEL_TILED && (pl->tp.fmod != 0.0 || pl->tp.wtab || pl->tp.apix || pl->tp.gen_kind));
@@ -855,6 +913,8 @@ extern "C" int qdas_plan_tile_shape(const qdas_plan *pl, int *tile_z, int *tile_
     return QDAS_OK;
 }
 
+extern "C" int qdas_plan_mirror(const qdas_plan *pl) { return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.mir ? 1 : 0; }
+
 extern "C" int qdas_plan_reciprocal(const qdas_plan *pl) { return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.sym ? 1 : 0; }
 
 extern "C" int qdas_plan_kernel_name(const qdas_plan *pl, char *buf, size_t len) {
@@ -864,7 +924,7 @@ extern "C" int qdas_plan_kernel_name(const qdas_plan *pl, char *buf, size_t len)
     if (pl->kernel == QDAS_KERNEL_TILED) {
         const TileParams &t = pl->tp;
         snprintf(buf, len, "das_tile_kernel<interp=%d,%s%s%s%s%s%s,mb=%d,W=%d> [%s]", z.flag & 7, dts, t.sym ? ",sym" : "", t.fmod != 0.0 ? ",fmod" : "",
-                 t.wtab ? ",wtab" : "", t.big ? ",big" : "", (t.St && !t.syn) ? ",roles swapped" : "", pl->jit_fn ? pl->jit_mb : pl->tc.mb, pl->tc.window, pl->jit_tag.empty() ? "prebuilt" : pl->jit_tag.c_str());
+                 t.wtab ? ",wtab" : "", t.big ? ",big" : "", t.mir ? ",mirror" : ((t.St && !t.syn) ? ",roles swapped" : ""), pl->jit_fn ? pl->jit_mb : pl->tc.mb, pl->tc.window, pl->jit_tag.empty() ? "prebuilt" : pl->jit_tag.c_str());
     } else snprintf(buf, len, "das_generic_kernel<interp=%d,%s>", z.flag & 7, dts);
     return QDAS_OK;
 }

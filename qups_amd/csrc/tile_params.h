@@ -57,6 +57,12 @@ struct TileParams {
     // a SECOND pixel-dependent weight, per (pixel, BLOCK element): real fp32, [pixel + I * block element]; applied per pair (launch configuration 14
     // without table / remodulation only: TileCfg::BPIX) -- the receive-side mask of a focused plan whose stage weight is the transmit-side rule
     const float *bpix;
+    // LATERAL-MIRROR mode (two-window-set instantiations, TileCfg::FBX with nfr == 1): array, sequence and scan are mirror-symmetric about
+    // the plane x = 0 -- Pr[N-1-n] = mirror(Pr[n]), {Pv, Nv, t0}[M-1-m] = mirror({Pv, Nv, t0}[m]), pixel column I2-1-c = mirror(column c),
+    // bit for bit (checked by the host) -- so tau(pixel', N-1-n, M-1-m) == tau(pixel, n, m): the tile grid covers the columns c < (I2+1)/2
+    // only, the second window set of a stage holds the traces x[:, N-1-n, M-1-m], and tap index + interpolation weights -- half of the
+    // pair loop's instructions -- are computed once for a pixel and its mirror image.  Every product of both sums is still formed.
+    int32_t mir;
 };
 
 }  // namespace qdas

@@ -45,6 +45,25 @@ template <class C> __device__ __forceinline__ void Tile<C>::dma_block(uint32_t m
         if constexpr (C::SYM) wb2[r] = am * SB + (int)((long)j * (long)strN * SB);
     }
     if constexpr (C::FBX) rsM = make_rs(o, (uint64_t)fb * P.x_fstride);   // the same traces of the next frame (four frames: of frame fb)
+    if constexpr (C::FB2) {
+        if (QSPEC(MIR, P.mir)) {
+            // lateral-mirror mode: the second window set holds the traces (rx N-1-n, tx M-1-m) of the SAME frame.  Descriptor at the
+            // lowest trace this block touches -- (rx N - n_hi, tx M - m0 - MB), clamped to transmit 0 in the last block --; window j sits
+            // (mt(j) - mlo) transmit strides and (n_hi - 1 - n) receiver strides after it (the receiver offset runs DOWN, soff2)
+            const uint32_t mlo = m0 + (uint32_t)C::MB <= M ? M - m0 - (uint32_t)C::MB : 0u;
+            const uint64_t oM = ((uint64_t)mlo * strM + (uint64_t)(N - n_hi) * strN) * SB;
+            rsM = make_rs(oM, 0);
+            soff2 = (n_hi - 1u - n_lo) * (uint32_t)strN * (uint32_t)SB;
+#pragma unroll
+            for (int r = 0; r < C::WPW; ++r) {
+                const int j = wjr(r);
+                const uint32_t m = m0 + j;
+                const int am = __builtin_amdgcn_readfirstlane(Abase[m < M ? m : M - 1]);
+                const uint32_t mt = m < M ? M - 1u - m : 0u;
+                wb2[r] = am * SB + (int)((long)(mt - mlo) * (long)strM * SB);
+            }
+        }
+    }
     if constexpr (C::SYM) {                           // mirror traces x[:, rx = m0 + j, tx = n] (reciprocal mode starts every block at n = 0)
         offM = (uint64_t)m0 * strN * SB;
         rsM = make_rs(offM, 0);
@@ -68,10 +87,11 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
         }
     }
     if constexpr (C::FBX) {                           // next frame: same offsets, other descriptor, another window set
+        const bool mirror = C::FB2 && QSPEC(MIR, P.mir);   // (lateral-mirror mode: the mirrored traces of the same frame, their own offsets)
 #pragma unroll
         for (int r = 0; r < C::WPW; ++r) {
             const int j = wjr(r);
-            const int so = (int)soff + wb[r] + bs;
+            const int so = mirror ? (int)soff2 + wb2[r] + bs : (int)soff + wb[r] + bs;
 #pragma unroll
             for (int q = 0; q < PCS; ++q) {
                 lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + fb * MB + j) * WB + q * PB));
@@ -81,6 +101,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
         }
     }
     soff += (uint32_t)strN * SB;                      // next receiver, same transmit block
+    if constexpr (C::FB2) { if (QSPEC(MIR, P.mir)) soff2 -= (uint32_t)strN * SB; }      // (its mirror image: one receiver down)
     if constexpr (C::SYM || C::BIG) {
         if (soff >= DMA_REBASE) { offD += soff; soff = 0; rsD = make_rs(offD, 0); }
     }

@@ -425,7 +425,7 @@ class DasPlan:
     (``kern/das_spec.m:72-81,387-390``).  ``plan.feval(x)`` beamforms one ``T x N x M`` frame."""
 
     def __init__(self, prob: DasProblem, device=None, kernel: int = _lib.KERNEL_AUTO,
-                 i_begin: int = 0, i_count: int = 0, reciprocal: bool = True, jit: bool = False):
+                 i_begin: int = 0, i_count: int = 0, reciprocal: bool = True, jit: bool = False, mirror: bool = True):
         torch = _torch()
         self.lib = _lib.lib()
         if not torch.cuda.is_available():
@@ -450,7 +450,7 @@ class DasPlan:
         d.mem, d.apod_real, d.kernel = _lib.MEM_DEVICE, int(prob.apod_real), int(kernel)
         d.device = dev.index if dev.index is not None else torch.cuda.current_device()
         d.i_begin, d.i_count, d.y_ld = self.i_begin, self.i_count, 0
-        d.plan_flags = (0 if reciprocal else _lib.PLAN_NO_RECIPROCAL) | (_lib.PLAN_JIT if jit else 0)
+        d.plan_flags = (0 if reciprocal else _lib.PLAN_NO_RECIPROCAL) | (_lib.PLAN_JIT if jit else 0) | (0 if mirror else _lib.PLAN_NO_MIRROR)
         if prob.rx_apod is not None:                       # generated receive apodization (qdas.h QDAS_RXAPOD_*)
             d.rx_apod_kind = prob.rx_apod["kind"]
             d.rx_apod_p[0], d.rx_apod_p[1] = prob.rx_apod["p"]
@@ -488,6 +488,12 @@ class DasPlan:
     def reciprocal(self) -> bool:
         """True when the tiled kernel runs in reciprocal mode (FSA with transmit elements == receive elements, one t0)."""
         return bool(self.lib.qdas_plan_reciprocal(self._h))
+
+    @property
+    def mirror(self) -> bool:
+        """True when the tiled kernel runs in lateral-mirror mode (scan, array and sequence mirror-symmetric about x = 0: a pixel and
+        its mirror image share tap index and interpolation weights)."""
+        return bool(self.lib.qdas_plan_mirror(self._h))
 
     def kernel_name(self) -> str:
         """name of the kernel the plan launches per frame, with ``[prebuilt]`` or ``[jit <hash>]`` (``qdas_plan_kernel_name``)"""

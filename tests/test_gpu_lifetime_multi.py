@@ -125,7 +125,7 @@ def test_entries_restore_the_current_device():
     prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], (T, N, M), case["t0"], case["fs"], case["c"],
                          parse_options(x, list(case["opt"]) + ["interp", "linear"]))
     last = torch.cuda.device_count() - 1
-    plan = DasPlan(prob, device=f"cuda:{last}")
+    plan = DasPlan(prob, device=f"cuda:{last}", mirror=False)
     mp = MultiDevicePlan(prob, devices=list(range(torch.cuda.device_count())) * (2 if last == 0 else 1))
     assert hip.hipGetDevice(C.byref(cur)) == 0 and cur.value == 0
     y1 = plan.feval(x.to(f"cuda:{last}"))
@@ -144,7 +144,7 @@ def _sharded_vs_single(fun, devices, mem, frames=2, seq="PW"):
     opts = parse_options(xs[0], list(case["opt"]) + ["interp", "cubic"])
     T, N, M = case["x"].shape
     prob = build_problem(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], (T, N, M), case["t0"], case["fs"], case["c"], opts)
-    one = DasPlan(prob, device="cuda:%d" % devices[0])
+    one = DasPlan(prob, device="cuda:%d" % devices[0], mirror=False)     # (slabs run the plain kernel: bit-identical to the plain whole-image plan)
     ref = [one.feval(x) for x in xs]
     if mem == "device":
         mp = MultiDevicePlan(prob, devices=devices)
@@ -217,7 +217,7 @@ def test_bench_two_ranks_over_rccl_matches_one_rank(tmp_path):
     has the checksum of the one-GPU image and the line carries ``multi_gpu.rccl_ranks == 2``"""
     _need_devices(2)
     common = ["--workload", "c2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-traffic", "--checksum"]
-    env = {"QDAS_CACHE_DIR": str(tmp_path), "QDAS_KSPLIT": "1"}        # (one summation order whatever the slab size: bit-identical images)
+    env = {"QDAS_CACHE_DIR": str(tmp_path), "QDAS_KSPLIT": "1", "QDAS_NO_MIRROR": "1"}        # (one summation order whatever the slab size: bit-identical images)
     one = _bench(["--gpus", "1"] + common, env)
     two = _bench(["--gpus", "2"] + common, env)
     assert two["n_gpus"] == 2 and two["multi_gpu"]["rccl_ranks"] == 2 and two["multi_gpu"]["backend"] == "nccl", two
@@ -227,7 +227,7 @@ def test_bench_two_ranks_over_rccl_matches_one_rank(tmp_path):
 def test_bench_shared_gpu_plumbing_prints_one_line(tmp_path):
     """one GPU, two ranks sharing it (gloo): the self-launch, the slab split, the gather and the single JSON line of ``bench.py --gpus 2``"""
     common = ["--workload", "c1", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-traffic", "--checksum"]
-    env = {"QDAS_CACHE_DIR": str(tmp_path), "QDAS_KSPLIT": "1"}
+    env = {"QDAS_CACHE_DIR": str(tmp_path), "QDAS_KSPLIT": "1", "QDAS_NO_MIRROR": "1"}
     one = _bench(["--gpus", "1"] + common, env)
     two = _bench(["--gpus", "2"] + common, dict(env, QDAS_BENCH_SHARE_GPU="1"))
     assert two["n_gpus"] == 2 and two["multi_gpu"]["backend"] == "gloo", two

@@ -1,0 +1,131 @@
+"""Lateral-mirror mode of the fused kernel (csrc/tile_params.h ``mir``): a scan, an array and a sequence that are mirror-symmetric
+about x = 0 have ``tau(pixel', N-1-n, M-1-m) == tau(pixel, n, m)`` bit for bit, so the kernel computes tap index and interpolation
+weights once for a pixel and its mirror image (second window set = the mirrored traces).  The reference has no such mode
+(``src/bf.cu:96-141``: one thread per pixel, every pair on its own); the contract is the same image -- checked here against the
+float64 oracle and against the plan with the mode switched off, for every interpolator, data type, layout and edge case."""
+import numpy as np
+import pytest
+
+from tests.cases import cinv_f32, make_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _plans(case, interp, prec="single", fmod=0.0, tpose=False, jit=False, fun="DAS", kernel=2, **kw):
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options
+    x = case["x"]
+    xin = np.ascontiguousarray(np.swapaxes(x, 1, 2)) if tpose else x
+    xt = torch.from_numpy(xin)
+    opts = parse_options(xt, list(case["opt"]) + ["interp", interp, "input-precision", prec, "modulation", fmod, "transpose", tpose])
+    prob = build_problem(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], opts)
+    out = []
+    for mirror in (True, False):
+        plan = DasPlan(prob, kernel=kernel, jit=jit, mirror=mirror, reciprocal=False, **kw)
+        y = plan.feval(xt)
+        y = torch.view_as_real(y).float().cpu().numpy().view(np.complex64)[..., 0] if prec == "halfT" else y.cpu().numpy()
+        out.append((y.reshape(-1), plan))
+    return out
+
+
+@pytest.mark.parametrize("jit", [False, True], ids=["prebuilt", "jit"])
+@pytest.mark.parametrize("seq,interp,prec,extra", [
+    ("PW", "cubic", "single", {}), ("PW", "lanczos3", "single", {"I2": 37}), ("FSA", "lanczos3", "single", {}), ("FSA", "linear", "halfT", {}),
+    ("DV", "nearest", "single", {}), ("FC", "linear", "single", {}), ("PW", "cubic", "halfT", {"I2": 21}), ("PW", "linear", "single", {"fmod": 2.5e6}),
+    ("FSA", "cubic", "single", {"tpose": True}), ("PW", "cubic_dev", "single", {"N": 17, "M": 5}), ("FSA", "cubic", "single", {"N": 33, "I2": 3}),
+    ("PW", "lanczos3", "halfT", {"fmod": 2.5e6, "tpose": True, "M": 33}),
+])
+def test_mirror_mode_matches_oracle_and_plain_plan(seq, interp, prec, extra, jit, tmp_path, monkeypatch):
+    from oracle import das_oracle as O
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    case = make_case(seq=seq, interp=interp, seed=61, N=extra.get("N", 16), M=extra.get("M", 8 if seq != "FSA" else None),
+                     I1=extra.get("I1", 150), I2=extra.get("I2", 40))
+    x = case["x"]
+    if prec == "halfT":
+        x = (x.real.astype(np.float16).astype(np.float32) + 1j * x.imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
+        case["x"] = x
+    fmod = float(np.float32(extra.get("fmod", 0.0)))
+    tpose = bool(extra.get("tpose", False))
+    (ym, pm), (yp, pp) = _plans(case, interp, prec, fmod, tpose, jit)
+    assert pm.mirror and ",mirror" in pm.kernel_name() and not pp.mirror, (pm.kernel_name(), pp.kernel_name())
+    assert ("[jit " in pm.kernel_name()) == jit
+    assert pm.fallback_tiles() == 0
+    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], np.swapaxes(x, 1, 2) if tpose else x, case["t0"], case["fs"],
+                     cinv_f32(case["c"]), VS=case["VS"], DV=case["DV"], interp=interp, fmod=fmod, tpose=tpose).reshape(-1, order="F")
+    tol = 2e-3 if prec == "halfT" else (1e-2 if interp == "nearest" else 2e-5 if not fmod else 2e-4)
+    assert rel_err(ym, ref) <= tol, pm.kernel_name()
+    assert rel_err(yp, ref) <= tol, pp.kernel_name()
+    # the mirrored half sums its pairs in the opposite order: fp32 re-association only (fp16 images: an output ulp; 'nearest': the fp32
+    # residuals of other window bases round a delay at x.5 the other way -- the statistical tolerance of that interpolator)
+    assert rel_err(ym, yp) <= (1e-2 if interp == "nearest" else 1e-4 if prec == "halfT" else 2e-6)
+    pm.close(); pp.close()
+
+
+def test_mirror_mode_needs_exact_symmetry():
+    """one element one ulp off its mirror position, one pixel column, one transmit normal or a per-transmit t0 that is not symmetric:
+    the plan keeps the ordinary kernel (and still matches the oracle)"""
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options
+    base = make_case(seq="PW", interp="linear", seed=3, N=16, M=6, I1=64, I2=16)
+    x = torch.from_numpy(base["x"])
+
+    def mirror_of(**chg):
+        case = dict(base)
+        case.update(chg)
+        prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(x.shape), case["t0"], case["fs"], case["c"],
+                             parse_options(x, list(case["opt"]) + ["interp", "linear"]))
+        with DasPlan(prob, kernel=2) as plan:
+            return plan.mirror
+
+    assert mirror_of()
+    ulp = lambda v: float(np.nextafter(np.float32(v), np.float32(np.inf)))
+    Pr = base["Pr"].copy(); Pr[0, 3] = ulp(Pr[0, 3])
+    assert not mirror_of(Pr=Pr)
+    Pi = base["Pi"].copy(); Pi[0, 5, 2] = ulp(Pi[0, 5, 2])
+    assert not mirror_of(Pi=Pi)
+    Nv = base["Nv"].copy(); Nv[0, 1] = ulp(Nv[0, 1])
+    assert not mirror_of(Nv=Nv)
+    t0 = np.full((1, 1, 6), base["t0"]); t0[0, 0, 1] += 1.0 / base["fs"]
+    assert not mirror_of(t0=t0)
+    t0s = np.full((1, 1, 6), base["t0"]); t0s[0, 0, 1] += 1.0 / base["fs"]; t0s[0, 0, 4] += 1.0 / base["fs"]
+    assert mirror_of(t0=t0s)                                         # symmetric per-transmit start times are fine
+    Pz = base["Pi"].copy(); Pz[2, :, 0] += np.float32(1e-4)          # depth of the first column differs from the last
+    assert not mirror_of(Pi=Pz)
+
+
+def test_mirror_mode_edges_split_aperture_and_record_ends(monkeypatch):
+    """small image (several workgroups per tile: partial images of both halves), a record that ends inside the image (checked loop:
+    zeros where the reference zeroes), odd column count (the centre column is its own mirror image), per-transmit t0"""
+    from oracle import das_oracle as O
+    case = make_case(seq="PW", interp="cubic", seed=8, N=24, M=6, I1=96, I2=9, T=320)
+    M = case["M"]
+    t0 = np.full((1, 1, M), case["t0"]); t0[0, 0, 1] += 2.0 / case["fs"]; t0[0, 0, M - 2] += 2.0 / case["fs"]
+    case["t0"] = t0
+    for ks in ("2", "3", "1"):
+        monkeypatch.setenv("QDAS_KSPLIT", ks)
+        (ym, pm), (yp, pp) = _plans(case, "cubic")
+        assert pm.mirror and pm.aperture_split() == int(ks)
+        ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], t0, case["fs"], cinv_f32(case["c"]),
+                         VS=case["VS"], DV=case["DV"], interp="cubic").reshape(-1, order="F")
+        assert np.count_nonzero(ref == 0) > 0 and np.count_nonzero(ref) > 0          # the record really ends inside the image
+        assert rel_err(ym, ref) <= 2e-5 and rel_err(ym, yp) <= 2e-6
+        assert np.array_equal(ym == 0, ref == 0)
+        pm.close(); pp.close()
+
+
+def test_mirror_mode_through_das_spec_and_frames():
+    """the reference-shaped entry picks the mode by itself; several frames through one plan run one mirrored launch each"""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import das_spec
+    case = make_case(seq="PW", interp="cubic", seed=12, N=16, M=8, I1=80, I2=24)
+    rng = np.random.default_rng(1)
+    xs = np.stack([case["x"]] + [(rng.standard_normal(case["x"].shape) + 1j * rng.standard_normal(case["x"].shape)).astype(np.complex64) for _ in range(3)], axis=3)
+    y, plan = das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], torch.from_numpy(xs), case["t0"], case["fs"], case["c"],
+                       *case["opt"], "interp", "cubic", return_plan=True)
+    assert plan.mirror
+    y = y.cpu().numpy()
+    for f in range(4):
+        ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs[..., f], case["t0"], case["fs"], cinv_f32(case["c"]),
+                         VS=case["VS"], DV=case["DV"], interp="cubic")
+        assert rel_err(y[..., f].reshape(ref.shape), ref) <= 2e-5

@@ -27,5 +27,7 @@ def test_gateway_runs_over_the_fake_runtime(tmp_path):
            "-L", lib, "-lqdas", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    # (the driver compares multi-device plans -- pixel slabs, plain kernel -- with the one-device plan bit for bit: the lateral-mirror mode of
+    #  a whole-image plan sums the mirrored half in another order, so it is switched off for this comparison)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, QDAS_NO_MIRROR="1"))
     assert r.returncode == 0 and "fake-MEX gateway OK" in r.stdout, r.stdout + r.stderr
