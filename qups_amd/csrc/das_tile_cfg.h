@@ -19,11 +19,14 @@ struct Cfg { int waves, mb, w, nbuf, psz, bpc; };
 // cfg 13: fp64 data (16-byte samples): 16 transmits per stage, 192-sample windows -- the LDS image of cfg 0
 // cfg 14: fp32 data with 384-sample windows and 16 transmits per stage (the LDS image of cfg 0): the second attempt of a plan whose
 //         tiles do not fit 192 samples -- pixel grids coarser than about lambda/2 (volumes, previews), steep delay gradients
-static constexpr Cfg CFGS[15] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1},
+// cfg 15 / 16: reciprocal + lateral-mirror mode (fp32 / fp16 data): FOUR window sets of 16 one-KiB windows per buffer -- the LDS image of the
+//         32-transmit reciprocal stages hiprtc builds run
+static constexpr Cfg CFGS[17] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1},
                                 {16, 16, 192, 2, 16, 1}, {16, 16, 384, 2, 16, 1}, {16, 8, 192, 2, 16, 1}, {16, 8, 384, 2, 16, 1},
                                 {16, 16, 128, 2, 16, 1}, {16, 16, 256, 2, 16, 1}, {16, 32, 192, 2, 16, 1}, {16, 32, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1}, {16, 32, 192, 2, 16, 1},
-                                {16, 16, 192, 2, 16, 1}, {16, 16, 384, 2, 16, 1}};
+                                {16, 16, 192, 2, 16, 1}, {16, 16, 384, 2, 16, 1}, {16, 16, 128, 2, 16, 1}, {16, 16, 256, 2, 16, 1}};
 // fb: frames per launch (1 | 2 | 4)
 // narrow: window variant -- 1: reciprocal mode with 128-sample windows (cfg 7); 2: general mode, fp32 data, 384-sample windows (cfg 14)
-static inline int cfg_index(int dtype, int sym, int fb = 1, int narrow = 0) { return dtype == 0 ? 13 : (!sym && narrow == 2 && dtype == 1 && fb == 1) ? 14 : sym ? (dtype == 2 ? 8 : (narrow ? 7 : 1)) : (fb == 4 ? (dtype == 2 ? 6 : 5) : (fb == 2 ? (dtype == 2 ? 4 : 3) : (dtype == 2 ? 2 : 0))); }
+// mirq: reciprocal + lateral-mirror mode (cfg 15 / 16)
+static inline int cfg_index(int dtype, int sym, int fb = 1, int narrow = 0, int mirq = 0) { return (mirq && sym && dtype != 0) ? (dtype == 2 ? 16 : 15) : dtype == 0 ? 13 : (!sym && narrow == 2 && dtype == 1 && fb == 1) ? 14 : sym ? (dtype == 2 ? 8 : (narrow ? 7 : 1)) : (fb == 4 ? (dtype == 2 ? 6 : 5) : (fb == 2 ? (dtype == 2 ? 4 : 3) : (dtype == 2 ? 2 : 0))); }
 }  // namespace qdas

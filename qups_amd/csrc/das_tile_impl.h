@@ -62,17 +62,22 @@ typedef __attribute__((address_space(3))) void lds_void;
 //   the same traces of the next frames, so tap index and weights -- which depend on the geometry only -- are computed once for all
 //   of them (the reference launches one kernel per frame, kern/das_spec.m:371).  BIG: re-base the DMA descriptors along the
 //   receiver walk (transposed fp32 frames beyond 2 GiB).  LUT: the delays come from host-supplied tables (qdas_das_lut).
-template <int INTERP_, typename ST_, bool FMOD_, bool WTAB_, bool SYM_, bool FB2_, bool FB4_, int WAVES_, int MB_, int W_, int NBUF_, bool BIG_, bool LUT_, bool BF_ = false>
+template <int INTERP_, typename ST_, bool FMOD_, bool WTAB_, bool SYM_, bool FB2_, bool FB4_, int WAVES_, int MB_, int W_, int NBUF_, bool BIG_, bool LUT_, bool BF_ = false, bool MIRQ_ = false>
 struct TileCfg {
     static constexpr int INTERP = INTERP_, WAVES = WAVES_, MB = MB_, W = W_, NBUF = NBUF_;
     using ST = ST_;
     static constexpr bool FMOD = FMOD_, WTAB = WTAB_, SYM = SYM_, FB2 = FB2_, FB4 = FB4_, BIG = BIG_, LUT = LUT_;
     static constexpr bool BF = BF_;                  // keep both aperture dimensions: every pair's sample goes to its own output plane
     static constexpr bool FBX = FB2 || FB4;          // more than one frame per launch
+    // reciprocal mode AND lateral-mirror mode (tile_params.h `mir`): tau(n,m) == tau(m,n) == tau'(N-1-n,N-1-m) == tau'(N-1-m,N-1-n) -- four
+    // window sets per stage: {x[:,n,m], x[:,m,n]} for my pixel, {x[:,N-1-n,N-1-m], x[:,N-1-m,N-1-n]} for its mirror image, ONE tap index
+    // and ONE set of weights for all four
+    static constexpr bool MIRQ = MIRQ_;
+    static constexpr bool QUAD = FB4 || MIRQ;        // four window sets: the pair loop makes two passes over one index / weight evaluation
     static constexpr bool TWO = SYM || FBX;          // (at least) two window sets per stage: direct + (mirror | next frame)
-    static constexpr int NHP = FB4 ? 2 : 1;          // passes of the pair loop: one per frame pair
+    static constexpr int NHP = QUAD ? 2 : 1;         // passes of the pair loop: one per frame pair (MIRQ: my pixel, its mirror image)
     static constexpr int NFR = FB4 ? 4 : (FB2 ? 2 : 1);   // frames per launch
-    static constexpr int NW = FB4 ? 4 * MB : (TWO ? 2 * MB : MB);     // windows per LDS buffer
+    static constexpr int NW = QUAD ? 4 * MB : (TWO ? 2 * MB : MB);     // windows per LDS buffer
     static constexpr int K = tapinfo<INTERP>::K;
     static constexpr int THREADS = WAVES * 64;
     static constexpr int WPW = FB4 ? 1 : MB / WAVES; // windows staged per wave and window set
@@ -96,8 +101,9 @@ struct TileCfg {
     static constexpr int WB = W * SB;                // bytes per window
     static constexpr int PB = 1024;                  // bytes per full DMA piece (one wave-instruction x 16 B)
     static constexpr int PCS = (WB + PB - 1) / PB;   // pieces per window; the last one may use fewer lanes
-    static constexpr int NDMA = WPW * PCS * (TWO ? 2 : 1);    // DMA instructions per wave and stage
+    static constexpr int NDMA = WPW * PCS * (MIRQ ? 4 : TWO ? 2 : 1);    // DMA instructions per wave and stage
     static_assert(!(SYM && FBX) && !(FB2 && FB4), "reciprocal mode runs one frame per launch");
+    static_assert(!MIRQ || (SYM && !WTAB_ && !FMOD_ && MB_ == WAVES_ && 4 * MB_ * W_ * (int)sizeof(ST_) <= 65536), "reciprocal + lateral-mirror mode: one window per wave and set, immediate LDS offsets");
     static_assert(!BIG || (!SYM && !FBX), "the re-basing general kernel runs one frame per launch");
     static_assert(!LUT || (!SYM && !FBX && !BIG), "table-driven delays: general mode, one frame per launch");
     static_assert(!BF || (!SYM && !FBX && !BIG && !LUT && sizeof(ST_) == 8), "'BF': general mode, fp32 data, one frame per launch");
@@ -146,6 +152,7 @@ template <class C> struct Tile {
     bool wpix, syn;
     // ---- LDS-DMA staging (tile_staging.h)
     int wb[C::WPW], wb2[C::WPW];
+    int qo[C::MIRQ ? 4 : 1];                         // MIRQ: absolute byte offsets of this wave's window in the four traces of the stage at the DMA front (without B[n])
     uint32_t soff, soff2;
     __amdgpu_buffer_rsrc_t rsD, rsM;
     uint64_t offD, offM, xbytes;
@@ -154,7 +161,7 @@ template <class C> struct Tile {
     __device__ __forceinline__ Tile(const TileParams &p) : P(p) {}
 
     __device__ __forceinline__ void setup(unsigned char *smem);          // LDS carve-up, tile / pixel of this lane
-    __device__ __forceinline__ uint32_t locate(uint32_t &i1, uint32_t &col, bool first);
+    __device__ __forceinline__ uint32_t locate(uint32_t &i1, uint32_t &col, bool first, bool image = false);
     template <bool PROBE> __device__ __forceinline__ bool prologue();    // window bases + fit verdict           (tile_prologue.h)
     __device__ __forceinline__ void plan_stages();                       // this workgroup's share of the aperture
     template <bool CHECK> __device__ __forceinline__ void run();         // the stage loop
@@ -200,7 +207,8 @@ template <class C> struct Tile {
     __device__ __forceinline__ void pairs_pipelined(float rb, uint32_t cbase);
     template <bool CHECK, bool TAILV> __device__ __forceinline__ void pairs_f64(uint32_t n, uint32_t m0, int bn, double rb, uint32_t cbase);
     __device__ __forceinline__ void frame_sums(v2f (&Sf)[4]) const {
-        if constexpr (C::FB4) { Sf[0] = acc; Sf[1] = acc1; Sf[2] = acc2; Sf[3] = acc3; }
+        if constexpr (C::MIRQ) { Sf[0] = acc + acc1; Sf[1] = acc2 + acc3; }       // my pixel, its mirror image
+        else if constexpr (C::FB4) { Sf[0] = acc; Sf[1] = acc1; Sf[2] = acc2; Sf[3] = acc3; }
         else if constexpr (C::FB2) { Sf[0] = acc + acc1; Sf[1] = acc2 + acc3; }
         else Sf[0] = (acc + acc1) + (acc2 + acc3);
     }
@@ -217,7 +225,8 @@ namespace qdas {
 // ------------------------------------------------------------------------------------------------- which tile, which pixel
 // (row, column) of this lane's pixel and its offset in the plan's slab.  Called by setup() and -- in the register-tight reciprocal
 // kernels -- AGAIN by the epilogue: ~25 mostly scalar instructions once per tile, instead of a register held through the stage loop.
-template <class C> __device__ __forceinline__ uint32_t Tile<C>::locate(uint32_t &i1, uint32_t &col, bool first) {
+// image: the offset of the MIRROR IMAGE of my pixel (lateral-mirror modes; NOT_MINE for the centre column, which is its own image).
+template <class C> __device__ __forceinline__ uint32_t Tile<C>::locate(uint32_t &i1, uint32_t &col, bool first, bool image) {
     // ---- which tile (XCD-aware: consecutive tile ids -> same XCD; dispatch is round-robin mod 8)
     const uint32_t nb = gridDim.x;
     uint32_t bid = blockIdx.x;
@@ -252,14 +261,14 @@ template <class C> __device__ __forceinline__ uint32_t Tile<C>::locate(uint32_t 
     // (depth index, column: may lie outside the image -- clamped for the delays, masked at the store)
     i1 = (tz << tzl) + (wave_z << wzl) + (uint32_t)(lane & ((1 << wzl) - 1));
     col = txi * ((uint32_t)(C::WAVES * 64) >> tzl) + (wave_c << (6 - wzl)) + (uint32_t)(lane >> wzl);
-    const bool mirror = C::FBX && QSPEC(MIR, P.mir);
+    const bool mirror = C::MIRQ || (C::FB2 && QSPEC(MIR, P.mir));
     const uint64_t ncols_mine = mirror ? (ncols + 1) / 2 : ncols;      // lateral-mirror mode: the tiles cover the first half of the columns
     uint64_t ig = (uint64_t)i1 + I1 * (uint64_t)col;
     bool inside = ((uint64_t)i1 < I1) && ((uint64_t)col < ncols_mine) && (ig >= P.i_begin) && (ig < i_end);
-    if constexpr (C::FBX) {
-        if (!first && mirror) {                       // (second call, from the epilogue: the MIRROR image of my pixel; the centre column is its own)
+    if constexpr (C::MIRQ || C::FB2) {
+        if (image) {                                  // (from the epilogue)
             const uint64_t col2 = ncols - 1 - (uint64_t)col;
-            inside = inside && col2 != (uint64_t)col;
+            inside = inside && mirror && col2 != (uint64_t)col;
             ig = (uint64_t)i1 + I1 * col2;
         }
     }
@@ -297,7 +306,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
 
     uint32_t i1, col;
     pofs = locate(i1, col, true);
-    const uint64_t I1 = QSPEC(I1, P.I1), ncols = (C::FBX && QSPEC(MIR, P.mir)) ? (P.I2 * P.I3 + 1) / 2 : P.I2 * P.I3;
+    const uint64_t I1 = QSPEC(I1, P.I1), ncols = (C::MIRQ || (C::FB2 && QSPEC(MIR, P.mir))) ? (P.I2 * P.I3 + 1) / 2 : P.I2 * P.I3;
     ipx = ((uint64_t)i1 < I1 ? (uint64_t)i1 : I1 - 1) + I1 * ((uint64_t)col < ncols ? (uint64_t)col : ncols - 1);
     cf = P.cinv_fs;
     if constexpr (C::LUT) {                            // delays from host tables (tau_tx: I x M, tau_rx: I x N, in samples; table-driven plans cover [0, I))
@@ -306,7 +315,9 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
         ipx = ipx < i_end ? ipx : i_end - 1;
     } else {
         px = geo_Pi()[3 * ipx]; py = geo_Pi()[3 * ipx + 1]; pz = geo_Pi()[3 * ipx + 2];
-        if (QSPEC(HAS_CINV_PIX, P.cinv_pix != nullptr)) cf = (double)P.cinv_pix[ipx] * fs;
+        if constexpr (!C::MIRQ) {                      // (reciprocal + lateral-mirror plans have a scalar sound speed: cf stays uniform -- two registers the four window sets need)
+            if (QSPEC(HAS_CINV_PIX, P.cinv_pix != nullptr)) cf = (double)P.cinv_pix[ipx] * fs;
+        }
     }
     // reciprocal mode: a(i,m) = b(i,m) + C with C = OFF - t0*fs, so A[m] := B[m] + floor(C)
     symC = 0.0; symCi = 0;
@@ -707,10 +718,10 @@ template <class C> __device__ __forceinline__ void Tile<C>::epilogue() {
         frame_sums(res);
         uint32_t po = pofs;
         if constexpr (C::SYM) { uint32_t i1, col; po = locate(i1, col, false); }      // (nothing in the reciprocal stage loop needs it: not kept alive)
-        if constexpr (C::FB2) {
-            if (QSPEC(MIR, P.mir)) {                     // lateral-mirror mode: the second window set's sum belongs to the mirror image of my pixel
+        if constexpr (C::FB2 || C::MIRQ) {
+            if (C::MIRQ || QSPEC(MIR, P.mir)) {          // lateral-mirror modes: the second sum belongs to the mirror image of my pixel
                 uint32_t i1, col;
-                const uint32_t po2 = locate(i1, col, false);
+                const uint32_t po2 = locate(i1, col, false, true);
                 const uint32_t pos[2] = {po, po2};
 #pragma unroll
                 for (int f = 0; f < 2; ++f) {
@@ -755,25 +766,26 @@ template <class C, bool PROBE> __device__ __forceinline__ void das_tile_body(con
 // PSZ / BPC: bytes per lane and DMA piece (16) and workgroups per CU the register budget is sized for -- kept in the kernel's
 // name so that profiles of different rounds list the same kernels.  PROBE is a kernel of its own name: profiles of
 // das_tile_kernel<..., false> hold full frames only.
-template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, bool FB2, bool FB4, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE, bool BIG = false, bool LUT = false, bool BFM = false>
+template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, bool FB2, bool FB4, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE, bool BIG = false, bool LUT = false, bool BFM = false, bool MIRQ = false>
 __global__ void __launch_bounds__(WAVES * 64, WAVES * BPC / 4)
 das_tile_kernel(const TileParams P) {
     static_assert(PSZ == 16, "16-byte DMA pieces");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    das_tile_body<TileCfg<INTERP, ST, FMOD, WTAB, SYM, FB2, FB4, WAVES, MB, W, NBUF, BIG, LUT, BFM>, PROBE>(P, smem);
+    das_tile_body<TileCfg<INTERP, ST, FMOD, WTAB, SYM, FB2, FB4, WAVES, MB, W, NBUF, BIG, LUT, BFM, MIRQ>, PROBE>(P, smem);
 }
 
 #ifndef __HIPCC_RTC__
 template <int INTERP, typename ST, int CI>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
     constexpr Cfg G = CFGS[CI];
-    constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8), FB2 = (CI == 3 || CI == 4), FB4 = (CI == 5 || CI == 6), BIG = (CI == 9), LUT = (CI == 10 || CI == 11), BFM = (CI == 12);
+    constexpr bool MIRQ = (CI == 15 || CI == 16);
+    constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8 || MIRQ), FB2 = (CI == 3 || CI == 4), FB4 = (CI == 5 || CI == 6), BIG = (CI == 9), LUT = (CI == 10 || CI == 11), BFM = (CI == 12);
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
     const dim3 g(ntiles * (P.probe ? 1u : P.ksplit)), b(G.waves * 64);
 #define QDAS_LAUNCH(FM, WT) QDAS_LAUNCH_P(FM, WT, false)
 #define QDAS_LAUNCH_P(FM, WT, PR)                                                                        \
     do {                                                                                                 \
-        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, FB4, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR, BIG && !PR, LUT, BFM && !PR>; \
+        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, FB4, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR, BIG && !PR, LUT, BFM && !PR, MIRQ && !PR>; \
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                   \
         kfn<<<g, b, lds, s>>>(P);                                                                        \
@@ -785,6 +797,11 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
     if constexpr (sizeof(ST) == 16) {                  // fp64 data: no remodulation, no pixel x receiver weight (qdas_api.hip)
         if (fm || P.apix || P.gen_kind || P.syn) return hipErrorInvalidValue;
         if (wt) QDAS_LAUNCH(false, true); else QDAS_LAUNCH(false, false);    // (grid: ntiles * ksplit workgroups, as for the other data types)
+    } else if constexpr (MIRQ) {
+        // (a weight table would have to be mirror-symmetric too, and the remodulating pair loop has no registers for four window sets: such plans
+        //  keep the plain reciprocal mode -- qdas_api.hip)
+        if (wt || fm) return hipErrorInvalidValue;
+        QDAS_LAUNCH(false, false);
     } else if constexpr (SYM) {
         if (fm && wt) QDAS_LAUNCH(true, true);
         else if (fm)  QDAS_LAUNCH(true, false);

@@ -18,6 +18,7 @@ struct JitSpec {
     unsigned ksplit;
     int gen_kind, has_apix, apix_real, syn, has_st, has_cinv_pix;
     int mir;                                            // lateral-mirror mode: the two-window-set instantiation (TileCfg::FB2), one frame
+    int mirq;                                           // reciprocal + lateral-mirror mode: four window sets (TileCfg::MIRQ)
 };
 
 std::string jit_source(const JitSpec &k);

@@ -520,9 +520,14 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // centred sector or rectangle under a linear / convex array, plane waves or virtual sources at +- the same angles / positions -- have
     // tau(pixel', N-1-n, M-1-m) == tau(pixel, n, m) bit for bit: tap index and interpolation weights serve a pixel and its mirror image.
     // Detected from the geometry itself; the whole image in one plan, plain 'DAS', scalar sound speed, no apodization (yet).
+    // A reciprocal plan (FSA) that is also mirror-symmetric runs FOUR window sets per stage (launch configurations 15 / 16, TileCfg::MIRQ):
+    // {x[:,n,m], x[:,m,n]} for a pixel and {x[:,N-1-n,N-1-m], x[:,N-1-m,N-1-n]} for its mirror image share one tap index and one set of
+    // weights; that kernel addresses the frame with one descriptor: frames below 2 GiB.
     bool mir = false;
-    if (eligible && !syn && !bfm && !sym && (dt == QDAS_F32 || dt == QDAS_F16) && z.S == 0 && !g.gen_kind && !cmap && z.I3 == 1 && z.I2 >= 2
-        && z.N >= 2 && desc->i_begin == 0 && pl->i_count == pl->I && !(desc->plan_flags & QDAS_PLAN_NO_MIRROR) && !getenv("QDAS_NO_MIRROR")) {
+    if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && z.S == 0 && !g.gen_kind && !cmap && z.I3 == 1 && z.I2 >= 2
+        && z.N >= 2 && desc->i_begin == 0 && pl->i_count == pl->I && !(desc->plan_flags & QDAS_PLAN_NO_MIRROR) && !getenv("QDAS_NO_MIRROR")
+        && (!sym || (desc->fmod == 0.0 && (uint64_t)z.T * z.N * z.M * data_size(dt) + 65536 < (1ull << 31) && z.M % 16 == 0 && !getenv("QDAS_NO_MIRQ")
+                     && tile_lds_bytes(dt, 1, z.N, z.M, 1, 0, 0, 1) <= tile_lds_limit(1)))) {
         if ((rc = mirror_symmetric(desc, (const float *)g.Pi, &mir))) return bail(rc);
     }
     // stage / block element counts of the kernel: receivers / transmits, or swapped
@@ -719,17 +724,19 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // reciprocal mode: first the 128-sample-window configuration (less staging traffic); it is kept only if some footprint
         // has no misfit tile at all -- otherwise the 192-sample configuration
         t.narrow = (sym && dt == QDAS_F32 && !getenv("QDAS_NO_NARROW")) ? 1 : 0;
-        if (t.narrow) pl->tc = tile_config(dt, 1, 1);
+        if (sym && t.mir && dt == QDAS_F32 && !t.narrow) { t.mir = 0; mir = false; }        // (the four-set configuration has 128-sample windows)
+        if (t.narrow) pl->tc = tile_config(dt, 1, 1, 1, t.mir);
+        else if (sym && t.mir) pl->tc = tile_config(dt, 1, 0, 1, 1);
         if (bpix_mode) { t.narrow = 2; pl->tc = tile_config(dt, 0, 2); }      // (the configuration that applies a per-pair pixel weight)
         if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
+        if (t.mir && !pl->no_fallback) {                // (a misfit tile is redone by the generic kernel, which knows nothing of mirror images;
+            t.mir = 0; mir = false;                      //  reciprocal plans: the four-set configuration exists with the narrow windows only)
+            pl->tc = t.narrow == 1 ? tile_config(dt, 1, 1) : tile_config(dt, sym);
+            if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
+        }
         if (t.narrow == 1 && !pl->no_fallback) {
             t.narrow = 0;
             pl->tc = tile_config(dt, 1, 0);
-            if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
-        }
-        if (t.mir && !pl->no_fallback) {                // (a misfit tile is redone by the generic kernel, which knows nothing of mirror images)
-            t.mir = 0; mir = false;
-            pl->tc = tile_config(dt, sym);
             if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
         }
         // Focused transmits whose focal planes cut through the image: the delay flips sign there (src/bf.cu:106-108), so the tiles a plane
@@ -833,8 +840,9 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         JitSpec k{};
         k.interp = (z.flag & 7) == 4 ? 1 : (z.flag & 7); k.dtype = dt; k.fmod = t.fmod != 0.0; k.wtab = t.wtab != nullptr; k.sym = t.sym; k.big = t.big;
         const int narrow = (t.sym && dt == QDAS_F32 && t.narrow) ? 1 : (!t.sym && dt == QDAS_F32 && t.narrow == 2) ? 2 : 0;
-        const Cfg &cg = CFGS[cfg_index(dt, t.sym, t.mir ? 2 : 1, narrow)];
-        k.mir = t.mir;
+        const int mirq = (t.sym && t.mir) ? 1 : 0;
+        const Cfg &cg = CFGS[cfg_index(dt, t.sym, t.mir ? 2 : 1, narrow, mirq)];
+        k.mir = t.mir && !t.sym; k.mirq = mirq;
         k.waves = cg.waves; k.mb = cg.mb; k.w = cg.w; k.nbuf = cg.nbuf;
         k.N = t.N; k.M = t.M; k.T = t.T; k.I1 = t.I1; k.strN = t.strN; k.strM = t.strM;
         k.kindB = t.kindB; k.kindS = t.kindS; k.tzl = t.tz_log2; k.wzl = t.wz_log2; k.ksplit = t.ksplit;
@@ -845,10 +853,10 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // reciprocal mode: the specialised kernel has the registers for 32-transmit stages (half the stages, barriers and per-stage
         // delay evaluations of the prebuilt 16-transmit configuration) whenever the 64 windows of a buffer stay within the 16-bit
         // immediate offsets of the LDS reads (C3: 30.9 -> 29.2 ms)
-        if (t.sym && z.M % 32 == 0 && 2 * 32 * k.w * (dt == QDAS_F16 ? 4 : 8) <= 65536 && !getenv("QDAS_JIT_NO_MB32")) k.mb = 32;
+        if (t.sym && !mirq && z.M % 32 == 0 && 2 * 32 * k.w * (dt == QDAS_F16 ? 4 : 8) <= 65536 && !getenv("QDAS_JIT_NO_MB32")) k.mb = 32;
         if (const char *e = getenv("QDAS_JIT_MB")) {
             const int mb = atoi(e);
-            if (mb >= 2 && mb % k.waves == 0 && (!t.sym || z.M % (uint64_t)mb == 0)) k.mb = mb;
+            if (mb >= 2 && mb % k.waves == 0 && (!t.sym || z.M % (uint64_t)mb == 0) && !mirq) k.mb = mb;
         }
         if (const char *e = getenv("QDAS_JIT_NBUF")) { const int nb = atoi(e); if (nb >= 2 && nb <= 4) k.nbuf = nb; }
         {
@@ -856,7 +864,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             const size_t off_act = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + 15) & ~(size_t)15;   // Tile::setup
             const size_t off_wst = off_act + (((size_t)t.act_bytes + 15) & ~(size_t)15);
             const size_t hdr = (off_wst + (t.wtab ? (size_t)k.nbuf * (2 * (size_t)k.mb * 8 + 16) : 0) + 15) & ~(size_t)15;
-            size_t body = (size_t)k.nbuf * k.mb * ((t.sym || t.mir) ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
+            size_t body = (size_t)k.nbuf * k.mb * (mirq ? 4 : (t.sym || t.mir) ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
             const size_t scratch = 2 * (size_t)k.waves * MX * 4 + 1024;
             if (body < scratch) body = scratch;
             pl->jit_lds = hdr + body;

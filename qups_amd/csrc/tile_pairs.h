@@ -23,7 +23,7 @@ namespace qdas {
 template <class C> template <bool CHECK, bool TAILV, bool WZ>
 __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, int bn, float rb, uint32_t cbase, float phB, uint32_t wbase, uint32_t wmask, uint32_t xmask) {
     constexpr int K = C::K, MB = C::MB, WB = C::WB, INTERP = C::INTERP, NHP = C::NHP;
-    constexpr bool SYM = C::SYM, FB4 = C::FB4, FBX = C::FBX, TWO = C::TWO, F32 = C::F32, FMOD = C::FMOD, WTAB = C::WTAB, BF = C::BF;
+    constexpr bool SYM = C::SYM, FB4 = C::QUAD, FBX = C::FBX, TWO = C::TWO, F32 = C::F32, FMOD = C::FMOD, WTAB = C::WTAB, BF = C::BF;     // (FB4 here: four window sets, two passes)
     constexpr bool TAIL = !SYM && TAILV, DIAG = SYM && TAILV;
     // (stage weights: does any transmit pair of this stage hold exactly one zero weight?)
     const bool wmixed = C::WST && WZ && ((((wmask ^ (wmask >> 1)) & 0x55555555u) != 0u) || (SYM && C::WTAB && (((xmask ^ (xmask >> 1)) & 0x55555555u) != 0u)));
@@ -65,7 +65,8 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
             constexpr int hp = decltype(hpc)::value;
             constexpr int GSET = FB4 ? 2 * hp : 0, HSET = FB4 ? 2 * hp + 1 : 1;       // window sets of the pass
             v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : &acc1);
-            v2f &B0 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(SYM ? &acc2 : (FB4 ? (hp ? &acc3 : &acc1) : &acc3));
+            // (reciprocal + lateral-mirror mode: ONE accumulator per pixel -- my pixel, its mirror image; the register budget of four window sets)
+            v2f &B0 = *(C::MIRQ ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(C::MIRQ ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : (SYM ? &acc2 : &acc3));
             v2f v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
             v2f u0 = {0.f, 0.f}, u1 = {0.f, 0.f};     // the same two pairs of the second frame (FB2)
             if constexpr (F32) {
@@ -282,7 +283,7 @@ __device__ __forceinline__ void Tile<C>::pairs_f64(uint32_t n, uint32_t m0, int 
 // 8 reads stay in flight) rarely stalls.  A unit = (transmit pair p, frame pair hp); hp only with four frames per launch.
 template <class C> __device__ __forceinline__ void Tile<C>::pairs_pipelined(float rb, uint32_t cbase) {
     constexpr int K = C::K, MB = C::MB, WB = C::WB, INTERP = C::INTERP, NHP = C::NHP;
-    constexpr bool FB4 = C::FB4, F32 = C::F32;
+    constexpr bool FB4 = C::QUAD, F32 = C::F32;      // (four window sets, two passes: four frames, or reciprocal + lateral-mirror mode)
     constexpr int NP = MB / 2, NU = NP * NHP;
     using taps_t = std::conditional_t<F32, taps_f32, taps_f16>;
     taps_t gd0[2], gd1[2];                 // first-set taps of the two halves, double-buffered over units
@@ -318,7 +319,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::pairs_pipelined(floa
         v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : &acc1);
         // (reciprocal mode: both mirror halves share ONE accumulator -- three in all; with 32-transmit stages the fourth costs the two
         //  registers that would otherwise spill, and measures the same: profiles/r02/exp_prio.txt)
-        v2f &B0 = *(FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(C::SYM ? &acc2 : (FB4 ? (hp ? &acc3 : &acc1) : &acc3));
+        v2f &B0 = *(C::MIRQ ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(C::MIRQ ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : (C::SYM ? &acc2 : &acc3));
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             tap_mac(A0, gd0[u & 1], k, w[k].x); tap_mac(A1, gd1[u & 1], k, w[k].y);

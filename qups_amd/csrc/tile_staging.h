@@ -32,6 +32,21 @@ template <class C> __device__ __forceinline__ int Tile<C>::wjr(int r) const {
 
 template <class C> __device__ __forceinline__ void Tile<C>::dma_block(uint32_t m0) {
     constexpr int SB = C::SB;
+    if constexpr (C::MIRQ) {
+        // reciprocal + lateral-mirror mode: ONE descriptor over the whole frame (the host keeps such plans below 2 GiB) and absolute byte
+        // offsets; wave j stages window j (transmit m = m0 + j) of all four window sets.  At receiver n the four traces are
+        //   set 0: (rx n, tx m)   set 1: (rx m, tx n)   set 2: (rx N-1-n, tx N-1-m)   set 3: (rx N-1-m, tx N-1-n)
+        // -- every block starts at n = 0; sets 0 / 1 walk up by one receiver / transmit stride per stage, sets 2 / 3 walk down
+        rsD = make_rs(0, 0);
+        const uint32_t m = m0 + (uint32_t)wjr(0);
+        const uint32_t mc = m < M ? m : M - 1;
+        const long am = (long)__builtin_amdgcn_readfirstlane(Abase[mc]);
+        qo[0] = (int)(((long)mc * (long)strM + am) * SB);
+        qo[1] = (int)(((long)mc * (long)strN + am) * SB);
+        qo[2] = (int)(((long)(N - 1 - mc) * (long)strM + (long)(N - 1) * (long)strN + am) * SB);
+        qo[3] = (int)(((long)(N - 1 - mc) * (long)strN + (long)(N - 1) * (long)strM + am) * SB);
+        return;
+    }
     const uint64_t o = ((uint64_t)m0 * strM + (uint64_t)(n_lo >> (C::ACT ? P.stage_shift : 0)) * strN) * SB;
     if constexpr (C::SYM || C::BIG) offD = o;
     rsD = make_rs(o, (uint64_t)fa * P.x_fstride);
@@ -75,6 +90,21 @@ template <class C> __device__ __forceinline__ void Tile<C>::dma_block(uint32_t m
 template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, int buf) {
     constexpr int SB = C::SB, WB = C::WB, PB = C::PB, PCS = C::PCS, NW = C::NW, MB = C::MB;
     const int bs = bn * SB;
+    if constexpr (C::MIRQ) {
+        const int j = wjr(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int q = 0; q < PCS; ++q) {
+                lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + k * MB + j) * WB + q * PB));
+                if (lane * 16 < WB - q * PB)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, dst, 16, lane * 16, qo[k] + bs + q * PB, 0, 0);
+            }
+        }
+        qo[0] += (int)((uint32_t)strN * SB); qo[1] += (int)((uint32_t)strM * SB);
+        qo[2] -= (int)((uint32_t)strN * SB); qo[3] -= (int)((uint32_t)strM * SB);
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < C::WPW; ++r) {
         const int j = wjr(r);

@@ -129,3 +129,52 @@ def test_mirror_mode_through_das_spec_and_frames():
         ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs[..., f], case["t0"], case["fs"], cinv_f32(case["c"]),
                          VS=case["VS"], DV=case["DV"], interp="cubic")
         assert rel_err(y[..., f].reshape(ref.shape), ref) <= 2e-5
+
+
+@pytest.mark.parametrize("jit", [False, True], ids=["prebuilt", "jit"])
+@pytest.mark.parametrize("N,interp,prec,extra", [
+    (16, "lanczos3", "single", {}), (32, "lanczos3", "single", {"I2": 37}), (48, "cubic", "single", {}), (32, "linear", "single", {"tpose": True}),
+    (16, "nearest", "single", {}), (32, "lanczos3", "halfT", {}), (16, "cubic", "halfT", {"I2": 5}), (32, "cubic_dev", "single", {"ks": "2"}),
+    (64, "lanczos3", "single", {"ks": "4"}), (32, "cubic", "single", {"T": 330}), (32, "linear", "halfT", {"T": 330, "ks": "2"}),
+])
+def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_path, monkeypatch):
+    """A full-synthetic-aperture acquisition (transmit elements == receive elements) on a mirror-symmetric array and scan: FOUR traces share
+    one delay -- x[:,n,m], x[:,m,n] for a pixel and x[:,N-1-n,N-1-m], x[:,N-1-m,N-1-n] for its mirror image (launch configurations 15 / 16:
+    four window sets per stage).  Against the float64 oracle, the reciprocal-only plan and the plain plan; diagonal blocks, split apertures,
+    records that end inside the image, the centre column of an odd column count."""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import DasPlan, build_problem, parse_options
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    if "ks" in extra:
+        monkeypatch.setenv("QDAS_KSPLIT", extra["ks"])
+    case = make_case(seq="FSA", interp=interp, seed=70 + N, N=N, I1=extra.get("I1", 150), I2=extra.get("I2", 40), T=extra.get("T"),
+                     pitch=0.2e-3 if N > 32 else 0.3e-3)
+    x = case["x"]
+    if prec == "halfT":
+        x = (x.real.astype(np.float16).astype(np.float32) + 1j * x.imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
+    tpose = bool(extra.get("tpose", False))
+    xin = np.ascontiguousarray(np.swapaxes(x, 1, 2)) if tpose else x
+    xt = torch.from_numpy(xin)
+    opts = parse_options(xt, list(case["opt"]) + ["interp", interp, "input-precision", prec, "transpose", tpose])
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], opts)
+    ys, names = [], []
+    for kw in (dict(), dict(mirror=False), dict(mirror=False, reciprocal=False)):
+        with DasPlan(prob, kernel=2, jit=jit, **kw) as plan:
+            y = plan.feval(xt)
+            ys.append((torch.view_as_real(y).float().cpu().numpy().view(np.complex64)[..., 0] if prec == "halfT" else y.cpu().numpy()).reshape(-1))
+            names.append((plan.kernel_name(), plan.reciprocal, plan.mirror))
+            assert plan.fallback_tiles() == 0
+    assert names[0][1] and names[0][2] and ",sym" in names[0][0] and ",mirror" in names[0][0], names
+    assert names[1][1] and not names[1][2] and not names[2][1] and not names[2][2], names
+    assert ("[jit " in names[0][0]) == jit
+    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xin, case["t0"], case["fs"], cinv_f32(case["c"]),
+                     VS=case["VS"], DV=case["DV"], interp=interp, tpose=tpose).reshape(-1, order="F")
+    if "T" in extra:
+        assert np.count_nonzero(ref == 0) > 0 and np.count_nonzero(ref) > 0, "the record should end inside the image"
+        assert np.array_equal(ys[0] == 0, ref == 0)
+    tol = 2e-3 if prec == "halfT" else (1e-2 if interp == "nearest" else 2e-5)
+    for y, nm in zip(ys, names):
+        assert rel_err(y, ref) <= tol, nm
+    loose = 1e-2 if interp == "nearest" else 1e-4 if prec == "halfT" else 2e-6
+    assert rel_err(ys[0], ys[1]) <= loose and rel_err(ys[0], ys[2]) <= loose
