@@ -255,7 +255,9 @@ template <class C> __device__ __forceinline__ uint32_t Tile<C>::locate(uint32_t 
     //      to read <= 32 consecutive samples (conflict-free), e.g. 8 x 8 when the delay advances 2 samples per pixel of depth.
     //      Out-of-image lanes are clamped onto a real pixel (keeps them inside the tile's delay window) and masked at the store.
     const uint64_t I1 = QSPEC(I1, P.I1);
-    const uint64_t ncols = P.I2 * P.I3, i_end = P.i_begin + P.i_count;
+    uint64_t ncols = P.I2 * P.I3;
+    asm volatile("" : "+s"(ncols));                   // opaque: what the epilogue's call derives from it is made THERE, not carried through the stage loop (in a vector register pair)
+    const uint64_t i_end = P.i_begin + P.i_count;
     const int tzl = QSPEC(TZL, P.tz_log2), wzl = QSPEC(WZL, P.wz_log2);
     const uint32_t wave_z = (uint32_t)wave & ((1u << (tzl - wzl)) - 1u), wave_c = (uint32_t)wave >> (tzl - wzl);
     // (depth index, column: may lie outside the image -- clamped for the delays, masked at the store)

@@ -148,8 +148,8 @@ def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_pa
     monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
     if "ks" in extra:
         monkeypatch.setenv("QDAS_KSPLIT", extra["ks"])
-    case = make_case(seq="FSA", interp=interp, seed=70 + N, N=N, I1=extra.get("I1", 150), I2=extra.get("I2", 40), T=extra.get("T"),
-                     pitch=0.2e-3 if N > 32 else 0.3e-3)
+    geo = dict(pitch=0.15e-3, zlim=(14e-3, 24e-3), xspan=4e-3) if N > 32 else {}      # (large apertures: deep enough for the 128-sample windows)
+    case = make_case(seq="FSA", interp=interp, seed=70 + N, N=N, I1=extra.get("I1", 150), I2=extra.get("I2", 40), T=extra.get("T"), **geo)
     x = case["x"]
     if prec == "halfT":
         x = (x.real.astype(np.float16).astype(np.float32) + 1j * x.imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
@@ -176,5 +176,5 @@ def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_pa
     tol = 2e-3 if prec == "halfT" else (1e-2 if interp == "nearest" else 2e-5)
     for y, nm in zip(ys, names):
         assert rel_err(y, ref) <= tol, nm
-    loose = 1e-2 if interp == "nearest" else 1e-4 if prec == "halfT" else 2e-6
+    loose = 1e-2 if interp == "nearest" else 1e-4 if prec == "halfT" else 5e-6
     assert rel_err(ys[0], ys[1]) <= loose and rel_err(ys[0], ys[2]) <= loose
