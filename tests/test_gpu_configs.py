@@ -68,8 +68,10 @@ def test_config_lattice_parity(name, step, tol, jit):
     assert ("[jit " in kname) if jit else ("[prebuilt]" in kname), kname       # the kernel that was asked for really ran
     if name in ("c2", "c3"):
         assert plan.fallback_tiles() == 0
-    if name == "c3":                           # the headline kernel: reciprocal mode; 32 transmits per stage in the hiprtc build
-        assert plan.reciprocal and (",mb=32," in kname if jit else ",mb=16," in kname), kname
+    if name == "c3":                           # the headline kernel: reciprocal AND lateral-mirror mode (four window sets of 16 transmits per stage)
+        assert plan.reciprocal and plan.mirror and ",sym,mirror,mb=16,W=128>" in kname, kname
+    if name in ("c1", "c2"):                   # (symmetric array, sequence and scan; C5's pixel x receiver mask keeps the plain kernel for now)
+        assert plan.mirror and ",mirror," in kname, kname
     plan.close()
 
 
@@ -90,7 +92,7 @@ def test_config_linearity_and_slabs(name, monkeypatch):
     yplain, pplain = _run(prob, xa, mirror=False)                                     # (the whole-image plan may run in lateral-mirror mode: another summation order)
     assert not pplain.mirror
     assert torch.equal(torch.cat(parts), yplain)                                      # slabs concatenate bit-exactly
-    assert float((yplain - ya).abs().max()) / float(ya.abs().max()) <= 2e-6
+    assert float((yplain - ya).abs().max()) / float(ya.abs().max()) <= 5e-5       # (fp32 re-association of up to 65 536 terms of random data)
     z, _ = _run(prob, torch.zeros_like(xa))
     assert float(z.abs().max()) == 0.0
     # an eighth of the image (one rank of an 8-GPU job): the plan splits the aperture over several workgroups per tile;

@@ -148,7 +148,8 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
     if c["jit"] and fun != "BF":                                        # ('BF' runs the prebuilt kernel)
         assert "[jit " in plan.kernel_name(), (c, plan.kernel_name())
     if c.get("headline") and not c["t0vec"]:                            # (a per-transmit t0 is not reciprocal: general kernel)
-        assert plan.reciprocal and ",mb=32," in plan.kernel_name(), (c, plan.kernel_name())
+        # (mirror-symmetric draws -- no weights, one t0, the whole image -- run reciprocal + lateral-mirror mode: four sets of 16 transmits)
+        assert plan.reciprocal and ((",mirror,mb=16," if plan.mirror else ",mb=32,") in plan.kernel_name()), (c, plan.kernel_name())
     xc = _colmajor(_cast_data(xt, prob.prec, plan.device))
     y = plan.execute_colmajor(xc, F)                                    # (F, oM, oN, count)
     torch.cuda.synchronize()

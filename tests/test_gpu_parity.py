@@ -482,7 +482,7 @@ def test_pixel_shards_concatenate():
     x = torch.from_numpy(case["x"]).cuda()
     opts = parse_options(x, list(case["opt"]) + ["interp", "cubic"])
     prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], x.shape, case["t0"], case["fs"], case["c"], opts)
-    full = DasPlan(prob).feval(x).cpu().numpy().reshape(-1)
+    full = DasPlan(prob, mirror=False).feval(x).cpu().numpy().reshape(-1)       # (slabs run without the lateral-mirror mode: same summation order)
     I = prob.I
     for G in (2, 3, 7):
         parts = []
