@@ -88,7 +88,9 @@ struct TileCfg {
 #ifdef QDAS_NO_ACT
     static constexpr bool ACT = false;               // (A/B builds)
 #else
-    static constexpr bool ACT = !F64 && !SYM && !BIG && !BF_ && !FB2 && !FB4;     // (frames sharing a launch keep the plain list: no register for it)
+    static constexpr bool ACT = !F64 && !SYM && !BIG && !BF_ && !(FB2 && F32) && !FB4;     // (fp32 frames sharing a launch keep the plain list: no register for it)
+    // a pixel x receiver weight in lateral-mirror mode: the mirror image of a pixel has its OWN weight (fp16 two-window-set kernels)
+    static constexpr bool WMIR = ACT && FB2;
 #endif
     // pixel-independent weights (N x M table) reach the pair loop through LDS: the 32 (reciprocal mode: 2 x 32) table entries of a stage are
     // fetched one stage ahead by a single wave and read back with broadcast ds_reads -- as scalar loads inside the pair loop they cost a
@@ -138,6 +140,7 @@ template <class C> struct Tile {
     uint32_t pofs;                                   // my pixel's offset in this plan's slab, or NOT_MINE (lane outside the image / the slab; slabs stay below 2^32 - 1 pixels)
     __device__ __forceinline__ bool in_shard() const { return pofs != NOT_MINE; }
     uint64_t ipx;                                    // (clamped) linear pixel index: row of per-pixel arrays / delay tables
+    uint64_t ipx2;                                   // lateral-mirror mode with a pixel x receiver weight array: the same of my pixel's mirror image (TileCfg::WMIR)
     GT px, py, pz;
     double cf;                                       // samples per metre (scalar sound speed or this pixel's entry of the map)
     // ---- stage loop
@@ -192,7 +195,7 @@ template <class C> struct Tile {
     __device__ __forceinline__ const GT *geo_Pv() const { return (const GT *)P.Pv; }
     __device__ __forceinline__ const GT *geo_Nv() const { return (const GT *)P.Nv; }
     struct wraw { uint32_t a, b; };                                      // pixel x receiver weight of a stage element as loaded (raw bits)
-    __device__ __forceinline__ wraw wload_raw(uint32_t n) const;
+    __device__ __forceinline__ wraw wload_raw(uint32_t n, bool image = false) const;
     __device__ __forceinline__ v2f wconv(wraw r) const;
     __device__ __forceinline__ v2f wload(uint32_t n) const { return wconv(wload_raw(n)); }
 
@@ -310,6 +313,8 @@ template <class C> __device__ __forceinline__ void Tile<C>::setup(unsigned char 
     pofs = locate(i1, col, true);
     const uint64_t I1 = QSPEC(I1, P.I1), ncols = (C::MIRQ || (C::FB2 && QSPEC(MIR, P.mir))) ? (P.I2 * P.I3 + 1) / 2 : P.I2 * P.I3;
     ipx = ((uint64_t)i1 < I1 ? (uint64_t)i1 : I1 - 1) + I1 * ((uint64_t)col < ncols ? (uint64_t)col : ncols - 1);
+    ipx2 = ipx;
+    if constexpr (C::WMIR) { if (QSPEC(MIR, P.mir)) ipx2 = ((uint64_t)i1 < I1 ? (uint64_t)i1 : I1 - 1) + I1 * (P.I2 * P.I3 - 1 - ((uint64_t)col < ncols ? (uint64_t)col : ncols - 1)); }
     cf = P.cinv_fs;
     if constexpr (C::LUT) {                            // delays from host tables (tau_tx: I x M, tau_rx: I x N, in samples; table-driven plans cover [0, I))
         px = py = pz = 0.f;
@@ -370,7 +375,9 @@ template <class C> __device__ __forceinline__ bool Tile<C>::on_side(uint32_t n, 
     const double dot = rx * (double)P.St[4 * n + 1] + ry * (double)P.St[4 * n + 2] + rz * (double)P.St[4 * n + 3];
     return (__builtin_signbit(dot) != 0) == ((n & 1u) == 0u);
 }
-template <class C> __device__ __forceinline__ typename Tile<C>::wraw Tile<C>::wload_raw(uint32_t n) const {
+// image: the weight of my pixel's MIRROR IMAGE and the mirrored stage element N-1-n (lateral-mirror mode; array weights only: a generated
+// rule has the same value there, the host checks that the element normals are mirror-symmetric too)
+template <class C> __device__ __forceinline__ typename Tile<C>::wraw Tile<C>::wload_raw(uint32_t n, bool image) const {
     const int gen_kind = QSPEC(GEN_KIND, P.gen_kind);
     uint32_t na = n;                                  // the stage element's entry of the weight array
     if constexpr (C::ACT && !C::LUT) {
@@ -389,7 +396,8 @@ template <class C> __device__ __forceinline__ typename Tile<C>::wraw Tile<C>::wl
         const float4 e = nrec[n];
         return wraw{__float_as_uint(rx_apod_generated(gen_kind, P.gen_p0, P.gen_p1, px, py, pz, e.y, e.z, e.w, P.rxn, n)), 0u};
     }
-    const uint64_t k = ipx + (P.apix_pixel_only ? 0ull : P.I1 * P.I2 * P.I3 * na);
+    uint64_t k = ipx + (P.apix_pixel_only ? 0ull : P.I1 * P.I2 * P.I3 * na);
+    if constexpr (C::WMIR) { if (image) k = ipx2 + (P.apix_pixel_only ? 0ull : P.I1 * P.I2 * P.I3 * (uint64_t)(N - 1u - na)); }
     if (QSPEC(APIX_REAL, P.apix_real)) {
         if constexpr (C::F32) return wraw{((const uint32_t *)P.apix)[k], 0u};
         else return wraw{(uint32_t)((const unsigned short *)P.apix)[k], 0u};
@@ -452,7 +460,11 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const v2f w = wconv(r4[q]);
-                        const bool any = __ballot(!(w.x == 0.f && w.y == 0.f)) != 0ull;
+                        bool nz = !(w.x == 0.f && w.y == 0.f);
+                        if constexpr (C::WMIR) {         // (lateral-mirror mode: the stage also serves the mirror images of my pixels at receiver N-1-n)
+                            if (QSPEC(MIR, P.mir)) { const v2f w2 = wconv(wload_raw(n0 + q < n_hi ? n0 + q : n_hi - 1, true)); nz = nz || !(w2.x == 0.f && w2.y == 0.f); }
+                        }
+                        const bool any = __ballot(nz) != 0ull;
                         if (any && lane == 0 && n0 + q < n_hi) atomicOr(&flg[(n0 + q) >> 5], 1u << ((n0 + q) & 31u));
                     }
                 }
@@ -481,10 +493,12 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
     // the k-th stage of a transmit block works on receiver nsel(k); a block has klim(m0) stages
     auto nsel = [&](uint32_t k) -> uint32_t { if constexpr (C::ACT) { if (use_act) return (uint32_t)__builtin_amdgcn_readfirstlane((int)act[k < N ? k : N - 1].x); } return n_lo + k; };   // (uniform: scalar register)
     auto klim = [&](uint32_t mm) -> uint32_t { if constexpr (C::ACT) { if (use_act) return nact; } return nlim(mm) - n_lo; };
-    v2f wcur = {1.f, 0.f};
-    wraw wnext_r = {0x3f800000u, 0u};
+    v2f wcur = {1.f, 0.f}, wcur2 = {1.f, 0.f};      // (wcur2: the weight of my pixel's mirror image, TileCfg::WMIR)
+    wraw wnext_r = {0x3f800000u, 0u}, wnext_r2 = {0x3f800000u, 0u};
     const uint32_t n_first = nstage ? nsel(0) : n_lo;
-    if (wpix) wcur = wload(n_first);
+    bool wmir = false;                                 // array weights in lateral-mirror mode: two weights per stage
+    if constexpr (C::WMIR) wmir = wpix && QSPEC(MIR, P.mir) && QSPEC(HAS_APIX, P.apix != nullptr) && QSPEC(GEN_KIND, P.gen_kind) == 0;
+    if (wpix) { wcur = wload(n_first); wcur2 = wcur; if constexpr (C::WMIR) { if (wmir) wcur2 = wconv(wload_raw(n_first, true)); } }
     float tbc = 0.f, tbn = 0.f;                        // LUT: this / the next stage's receive delay of my pixel
     const uint64_t Ilut = P.i_begin + P.i_count;
     if constexpr (C::LUT) tbc = P.lut_rx[ipx + Ilut * n_first];
@@ -512,7 +526,12 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         front_entry(pk + 1 == klim(pm0) ? 0u : pk + 1);             // of the stage after this one
     };
     auto dma_go = [&](int buf) {
-        if constexpr (C::ACT) { if (use_act) soff = ((dpn >> P.stage_shift) - (n_lo >> P.stage_shift)) * (uint32_t)strN * (uint32_t)C::SB; }   // (stage lists with gaps: no running offset)
+        if constexpr (C::ACT) {                         // (stage lists with gaps: no running offset)
+            if (use_act) {
+                soff = ((dpn >> P.stage_shift) - (n_lo >> P.stage_shift)) * (uint32_t)strN * (uint32_t)C::SB;
+                if constexpr (C::WMIR) { if (QSPEC(MIR, P.mir)) soff2 = (n_hi - 1u - dpn) * (uint32_t)strN * (uint32_t)C::SB; }   // (mirrored receiver N-1-n above the descriptor's base N - n_hi)
+            }
+        }
         stage_dma(dbn, buf);
         if (++pk == klim(pm0)) { pk = 0; pm0 = blk(++pr); dma_block(pm0); }
     };
@@ -553,7 +572,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         const bool more = st + (NBUF - 1) < nstage;
         // receiver of the next stage: with one stage of staging in flight that is where the DMA front stands (no LDS round trip)
         const uint32_t n_next = (NBUF == 2 && C::ACT) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)vpn) : nsel(k + 1 == klim(m0) ? 0u : k + 1);
-        const bool skip = wpix && (__ballot(wcur.x != 0.f || wcur.y != 0.f) == 0ull);   // whole wave weightless: no gathers
+        const bool skip = wpix && (__ballot(wcur.x != 0.f || wcur.y != 0.f || (C::WMIR && (wcur2.x != 0.f || wcur2.y != 0.f))) == 0ull);   // whole wave weightless: no gathers
         // {B[n], receiver position}: one broadcast LDS read (fp64 data: two), issued ahead of the DMA
         int rec_b; GT rec_x, rec_y, rec_z;
         if constexpr (C::F64) { const rec64 r = nrec64[n]; rec_b = r.b; rec_x = r.x; rec_y = r.y; rec_z = r.z; }
@@ -576,7 +595,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         // an s_waitcnt vmcnt(0) in front of an LDS read that follows them -- it cannot tell them from the LDS-DMA it has to order
         // LDS reads behind: each stage then waited out a global-memory latency) and BEFORE this stage's DMA (so that the counted
         // end-of-stage wait covers them)
-        if (wpix && st + 1 < nstage) wnext_r = wload_raw(n_next);
+        if (wpix && st + 1 < nstage) { wnext_r = wload_raw(n_next); if constexpr (C::WMIR) { if (wmir) wnext_r2 = wload_raw(n_next, true); } }
         if constexpr (C::LUT) { if (st + 1 < nstage) tbn = P.lut_rx[ipx + Ilut * n_next]; }
         if (st + 1 < nstage) wst_load(n_next, k + 1 == klim(m0) ? blk(cr + 1) : m0);
         if (dma_now) dma_go((buf + NBUF - 1) % NBUF);            // lands during the next NBUF-1 stages
@@ -693,10 +712,15 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
             v2f Sf[4];
             frame_sums(Sf);
 #pragma unroll
-            for (int f = 0; f < C::NFR; ++f) tot[f] += (v2f){wcur.x * Sf[f].x - wcur.y * Sf[f].y, wcur.x * Sf[f].y + wcur.y * Sf[f].x};
+            for (int f = 0; f < C::NFR; ++f) {
+                const v2f wf = (C::WMIR && f == 1) ? wcur2 : wcur;      // (lateral-mirror mode: the second sum is the mirror image's)
+                tot[f] += (v2f){wf.x * Sf[f].x - wf.y * Sf[f].y, wf.x * Sf[f].y + wf.y * Sf[f].x};
+            }
             acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
             if constexpr (!C::F32) asm volatile("" : "+v"(wnext_r.a));      // (fp16 weights: converted here, a stage after the load)
             wcur = wconv(wnext_r);
+            wcur2 = wcur;
+            if constexpr (C::WMIR) { if (wmir) { asm volatile("" : "+v"(wnext_r2.a)); wcur2 = wconv(wnext_r2); } }
         }
         if constexpr (C::LUT) tbc = tbn;
         if (++k == klim(m0)) { k = 0; m0 = blk(++cr); }

@@ -348,6 +348,14 @@ static int mirror_symmetric(const qdas_desc *desc, const float *dPi, bool *yes) 
         const float *a = &hv[4 * m], *b = &hv[4 * (z.M - 1 - m)], *c = &hn[3 * m], *d = &hn[3 * (z.M - 1 - m)];
         if (!(a[0] == -b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3] && c[0] == -d[0] && c[1] == d[1] && c[2] == d[2])) return QDAS_OK;
     }
+    if (desc->rx_apod_kind && desc->rx_normals) {       // a generated receive apodization: the element normals as well
+        std::vector<float> hx(3 * z.N);
+        if ((rc = fetch_host(desc->rx_normals, hx.size() * 4, desc->mem, hx.data()))) return rc;
+        for (uint64_t n = 0; n < z.N; ++n) {
+            const float *a = &hx[3 * n], *b = &hx[3 * (z.N - 1 - n)];
+            if (!(a[0] == -b[0] && a[1] == b[1] && a[2] == b[2])) return QDAS_OK;
+        }
+    }
     uint32_t *flag = nullptr;
     HIPCHK(hipMalloc(&flag, sizeof(uint32_t)));
     hipError_t e = hipMemset(flag, 0, sizeof(uint32_t));
@@ -523,8 +531,13 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // A reciprocal plan (FSA) that is also mirror-symmetric runs FOUR window sets per stage (launch configurations 15 / 16, TileCfg::MIRQ):
     // {x[:,n,m], x[:,m,n]} for a pixel and {x[:,N-1-n,N-1-m], x[:,N-1-m,N-1-n]} for its mirror image share one tap index and one set of
     // weights; that kernel addresses the frame with one descriptor: frames below 2 GiB.
+    // fp16 data: a pixel x receiver weight rides along -- an I x N array (the image of a pixel has its OWN entry, at the mirrored receiver: the
+    // array need not be symmetric), a pixel-only array, or a generated rule (element normals mirror-symmetric as well: the same value)
     bool mir = false;
-    if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && z.S == 0 && !g.gen_kind && !cmap && z.I3 == 1 && z.I2 >= 2
+    const bool mir_plain = z.S == 0 && !g.gen_kind;
+    const bool mir_wpix = dt == QDAS_F16 && !sym && !swap && !bpix_mode && z.S == npix
+                          && ((pix_arr >= 0 && !pix_is_tx && !g.gen_kind) || (pix_arr < 0 && g.gen_kind >= 1 && g.gen_kind <= 4)) && !getenv("QDAS_NO_MIRROR_WPIX");
+    if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && (mir_plain || mir_wpix) && !cmap && z.I3 == 1 && z.I2 >= 2
         && z.N >= 2 && desc->i_begin == 0 && pl->i_count == pl->I && !(desc->plan_flags & QDAS_PLAN_NO_MIRROR) && !getenv("QDAS_NO_MIRROR")
         && (!sym || (desc->fmod == 0.0 && (uint64_t)z.T * z.N * z.M * data_size(dt) + 65536 < (1ull << 31) && z.M % 16 == 0 && !getenv("QDAS_NO_MIRQ")
                      && tile_lds_bytes(dt, 1, z.N, z.M, 1, 0, 0, 1) <= tile_lds_limit(1)))) {

@@ -178,3 +178,92 @@ def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_pa
         assert rel_err(y, ref) <= tol, nm
     loose = 1e-2 if interp == "nearest" else 1e-4 if prec == "halfT" else 5e-6
     assert rel_err(ys[0], ys[1]) <= loose and rel_err(ys[0], ys[2]) <= loose
+
+
+@pytest.mark.parametrize("jit", [False, True], ids=["prebuilt", "jit"])
+@pytest.mark.parametrize("seq,interp,kind", [("PW", "cubic", "mask"), ("DV", "linear", "mask"), ("PW", "lanczos3", "mask+depth"), ("FSA", "cubic", "pixel-only"),
+                                             ("PW", "cubic", "acceptance"), ("DV", "linear", "fnumber"), ("PW", "nearest", "mask")])
+def test_mirror_mode_with_pixel_by_receiver_weights(seq, interp, kind, jit, tmp_path, monkeypatch):
+    """fp16 data with a pixel x receiver weight (BASELINE C5's shape) in lateral-mirror mode: the mirror image of a pixel carries its OWN
+    weight, taken at the mirrored receiver -- the arrays here are random, NOT symmetric --; generated rules need mirror-symmetric element
+    normals and then have the same value there; the tile's stage list keeps a receiver that matters to either half."""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd import apodization as A
+    from qups_amd import geometry as G
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    N, I1, I2 = 24, 140, 30
+    case = make_case(seq=seq, interp=interp, seed=91, N=N, M=20 if seq != "FSA" else None, I1=I1, I2=I2)
+    x = case["x"]
+    x = (x.real.astype(np.float16).astype(np.float32) + 1j * x.imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
+    rng = np.random.default_rng(4)
+    h = lambda a: a.astype(np.float16).astype(np.float64)
+    apod, extra = [], []
+    if kind.startswith("mask"):
+        a = h((rng.random((I1, I2, 1, N, 1)) > 0.45) * rng.uniform(0.5, 1.0, (I1, I2, 1, N, 1)))
+        a[: I1 // 3, :, :, : N // 2] = 0.0              # shallow pixels: half the aperture only (receivers dropped from the stage list of one half)
+        apod.append(a)
+        if kind == "mask+depth":
+            apod.append(h(rng.uniform(0.5, 1.0, (I1, 1, 1, N, 1))))
+    elif kind == "pixel-only":
+        apod.append(h(rng.uniform(0.0, 1.0, (I1, I2, 1)) > 0.3))
+    else:
+        nrm = np.asarray(G.linear_array(N, 0.3e-3)[1], np.float32).astype(np.float64)
+        kw = dict(theta=35.0) if kind == "acceptance" else dict(f=1.0, Dmax=5e-3)
+        extra = ["rx-apod", A.rx_apod_spec(kind, normals=nrm, **kw)]
+        apod_or = {"acceptance": lambda: A.ap_acceptance_angle(case["Pi"], case["Pr"], nrm, 35.0),
+                   "fnumber": lambda: A.ap_aperture_growth(case["Pi"], case["Pr"], nrm, 1.0, 5e-3)}[kind]()
+    xt = torch.from_numpy(x)
+    va = list(case["opt"]) + ["interp", interp, "input-precision", "halfT"] + extra
+    for a in apod:
+        va += ["apod", a]
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], parse_options(xt, va))
+    ys, plans = [], []
+    for mirror in (True, False):
+        plan = DasPlan(prob, kernel=2, jit=jit, mirror=mirror, reciprocal=False)
+        y = plan.feval(xt)
+        ys.append(torch.view_as_real(y).float().cpu().numpy().view(np.complex64)[..., 0].reshape(-1))
+        plans.append(plan)
+    assert plans[0].mirror and ",mirror" in plans[0].kernel_name() and not plans[1].mirror, [p.kernel_name() for p in plans]
+    assert plans[0].fallback_tiles() == 0 and ("[jit " in plans[0].kernel_name()) == jit
+    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], x, case["t0"], case["fs"], cinv_f32(case["c"]), VS=case["VS"], DV=case["DV"],
+                     interp=interp, apod=apod if apod else [apod_or]).reshape(-1, order="F")
+    assert np.abs(ref).max() > 0
+    tol = 1e-2 if interp == "nearest" else 2e-3
+    assert rel_err(ys[0], ref) <= tol and rel_err(ys[1], ref) <= tol, [p.kernel_name() for p in plans]
+    assert rel_err(ys[0], ys[1]) <= (1e-2 if interp == "nearest" else 2e-4)
+    if kind.startswith("mask"):                          # an asymmetric mask really gives an asymmetric image: left and right halves differ
+        img = ys[0].reshape(I1, I2, order="F")
+        assert rel_err(img[:, : I2 // 2], img[:, ::-1][:, : I2 // 2]) > 1e-2
+    for p in plans:
+        p.close()
+
+
+def test_mirror_mode_is_not_taken_where_it_is_not_built():
+    """fp32 data with a pixel x receiver weight, a weight table, a sound-speed map, kept dimensions, pixel slabs: the ordinary kernels"""
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options
+    case = make_case(seq="PW", interp="linear", seed=3, N=16, M=16, I1=64, I2=16)
+    x = torch.from_numpy(case["x"])
+    rng = np.random.default_rng(0)
+
+    def plan_of(fun="DAS", c=None, **kw):
+        va = list(case["opt"]) + ["interp", "linear"]
+        for a in kw.pop("apod", []):
+            va += ["apod", a]
+        prob = build_problem(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(x.shape), case["t0"], case["fs"], case["c"] if c is None else c, parse_options(x, va))
+        return DasPlan(prob, **kw)
+
+    with plan_of() as p:
+        assert p.mirror
+    with plan_of(apod=[rng.random((64, 16, 1, 16, 1)).astype(np.float32)]) as p:
+        assert not p.mirror and p.kernel == "tiled"
+    with plan_of(apod=[np.hanning(18)[1:-1].astype(np.float32).reshape(1, 1, 1, 16)]) as p:
+        assert not p.mirror and p.kernel == "tiled"
+    with plan_of(c=1540.0 + 10.0 * rng.random((64, 16, 1))) as p:
+        assert not p.mirror
+    with plan_of(fun="SYN") as p:
+        assert not p.mirror
+    with plan_of(i_begin=0, i_count=64 * 8) as p:
+        assert not p.mirror

@@ -77,18 +77,26 @@ def short(dn: str) -> str:
     m = re.match(r"void qdas::das_tile_kernel<(.*)>\(qdas::TileParams\)", dn)
     if not m:
         return re.sub(r"^void ", "", dn)[:110]
+    if "MIRQ" in dn:
+        pass
     a = [x.strip() for x in re.sub(r"HIP_vector_type<double, 2u>", "f64", re.sub(r"HIP_vector_type<float, 2u>", "f32", m.group(1))).replace("unsigned int", "f16").split(",")]
-    keys = ["interp", "data", "fmod", "wtab", "sym", "fb2", "fb4", "waves", "mb", "W", "nbuf", "psz", "bpc", "probe", "big", "lut"]
+    keys = ["interp", "data", "fmod", "wtab", "sym", "fb2", "fb4", "waves", "mb", "W", "nbuf", "psz", "bpc", "probe", "big", "lut", "bf", "mirq"]
     d = dict(zip(keys, a))
-    flags = [k for k in ("fmod", "wtab", "sym", "fb2", "fb4", "probe", "big", "lut") if d.get(k) == "true"]
+    flags = [k for k in ("fmod", "wtab", "sym", "mirq", "fb2", "fb4", "probe", "big", "lut", "bf") if d.get(k) == "true"]
     return f"das_tile interp={d['interp']} {d['data']} mb={d['mb']} W={d['W']} " + (" ".join(flags) if flags else "general")
 
 
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     target = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "qups_amd", "libqdas.so")
-    paths = [os.path.join(target, f) for f in sorted(os.listdir(target))] if os.path.isdir(target) else [target]
-    rows = [r for p in paths for r in kernel_table(p)]
+    isdir = os.path.isdir(target)
+    paths = [os.path.join(target, f) for f in sorted(os.listdir(target)) if not f.endswith(".lock")] if isdir else [target]
+    rows = []
+    for p in paths:
+        for r in kernel_table(p):
+            if isdir:                                   # a hiprtc cache: the file name is the key that qdas_plan_kernel_name() prints as "[jit <key>]"
+                r["name"] = f"qdas_jit_tile [jit {os.path.basename(p).split('.')[0]}]"
+            rows.append(r)
     names = demangle([r["name"] for r in rows])
     print(f"# {target}: {len(rows)} kernels  (vgpr / agpr / sgpr, spilled vgpr / sgpr, scratch bytes per lane, static LDS bytes)")
     bad = 0

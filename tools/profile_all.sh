@@ -1,0 +1,64 @@
+#!/bin/bash
+# Regenerate EVERY measured line quoted in README.md / DESIGN.md at HEAD, on one GPU box, in one go:
+#   tools/profile_all.sh [round]        -> gpurun_out/profiles_<round>/   (copy what is to be judged into profiles/<round>/)
+# bench lines (one JSON per workload / switch), rocprofv3 summaries (kernel trace + separate PMC passes: tools/profile.sh) of the
+# headline and the other BASELINE configurations, and the register tables of the prebuilt kernels AND of the hiprtc builds the
+# benches ran (their code objects are in this run's private cache directory).
+set -u
+R=${1:-r03}
+REPO=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$REPO/gpurun_out/profiles_$R
+mkdir -p $OUT
+export QDAS_CACHE_DIR=$OUT/jit_cache
+cd $REPO
+b() { # name args...
+  local name=$1; shift
+  python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err || echo "bench $name FAILED" >> $OUT/errors.txt
+  [ -s $OUT/bench_$name.err ] || rm -f $OUT/bench_$name.err
+}
+# ---- headline (the driver's command) and the other BASELINE configurations, with cpu_baseline + parity_check + live traffic
+b c3_default
+b c2 --workload c2 --steps 50 --warmup 5
+b c5 --workload c5 --steps 50 --warmup 5
+b c1 --workload c1 --steps 200 --warmup 20
+# ---- what the special modes are worth (no CPU leg, no counter passes)
+Q="--no-cpu --no-traffic --no-general"
+QDAS_NO_MIRROR=1 b c3_no_mirror $Q --steps 10
+QDAS_NO_MIRROR=1 b c2_no_mirror --workload c2 $Q --steps 50
+QDAS_NO_MIRROR=1 b c1_no_mirror --workload c1 $Q --steps 200
+b c3_general --no-reciprocal $Q --steps 10
+QDAS_NO_MIRROR=1 b c3_general_no_mirror --no-reciprocal $Q --steps 10
+b c3_fp16 --prec halfT $Q --steps 10
+b c3_fmod --fmod 5e6 $Q --steps 10
+b c3_window --window-apod $Q --steps 10
+b c3_fnumber1.5 --rx-apod fnumber:1.5 --no-cpu --no-general --steps 10
+b c2_double --workload c2 --prec double $Q --steps 10
+b c2_window --workload c2 --window-apod $Q --steps 20
+b pw9 --workload pw9 $Q --steps 100
+b c1f --workload c1f $Q --steps 100
+b c1_multiline --workload c1 --tx-apod multiline $Q --steps 100
+b c1_multiline_acceptance --workload c1 --tx-apod multiline --rx-apod acceptance:30 --rx-apod-array $Q --steps 100
+# ---- rocprofv3: kernel trace + PMC passes
+for w in c3 c2 c5; do
+  bash tools/profile.sh ${R}_$w --workload $w > /dev/null 2>&1
+  cp gpurun_out/prof_${R}_$w/summary.txt $OUT/rocprofv3_summary_$w.txt 2>/dev/null
+  cp gpurun_out/prof_${R}_$w/traffic.json $OUT/traffic_$w.json 2>/dev/null
+  f=$(ls gpurun_out/prof_${R}_$w/trace/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $OUT/rocprofv3_kernel_stats_$w.csv
+done
+bash tools/profile.sh ${R}_c3_general --workload c3 --no-reciprocal > /dev/null 2>&1
+cp gpurun_out/prof_${R}_c3_general/summary.txt $OUT/rocprofv3_summary_c3_general.txt 2>/dev/null
+# ---- registers: prebuilt library, and the hiprtc builds of this run
+python tools/kernel_regs.py qups_amd/libqdas.so > $OUT/kernel_regs.txt 2>&1
+python tools/kernel_regs.py $QDAS_CACHE_DIR > $OUT/kernel_regs_hiprtc.txt 2>&1
+python - <<PY > $OUT/summary.txt
+import glob, json, os
+for f in sorted(glob.glob("$OUT/bench_*.json")):
+    try:
+        d = json.load(open(f))
+        r = d["roofline"]; pc = d.get("parity_check", {})
+        print(f"{os.path.basename(f)[6:-5]:28s} ms_per_step {d['ms_per_step']:8.3f}  kernel_ms {r['kernel_ms']:8.3f}  prebuilt {d.get('prebuilt_kernel_ms')}  general {d.get('general_ms_per_step')}  "
+              f"Mpixel/s {d['value']:9.2f}  parity {pc.get('rel_err')} ok={pc.get('ok')}  traffic {r.get('traffic')}  exec_frac {r.get('pairs_executed_frac')} valu_exec {r.get('valu_frac_executed')}  {d['config']['kernel_name']}")
+    except Exception as ex:
+        print(os.path.basename(f), "unreadable:", ex)
+PY
+cat $OUT/summary.txt
