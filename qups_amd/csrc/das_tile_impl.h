@@ -754,8 +754,10 @@ template <class C> __device__ __forceinline__ void Tile<C>::epilogue() {
                     uint32_t q = pos[f];
                     if (q == NOT_MINE) continue;
                     asm volatile("" : "+v"(q));
-                    if (S > 1) { float2 *base = P.part + (size_t)split * P.i_count; asm volatile("" : "+s"(base)); base[q] = make_float2(res[f].x, res[f].y); }
-                    else { ST *base = (ST *)P.y; asm volatile("" : "+s"(base)); st(base, (size_t)q, cplx<float>{res[f].x, res[f].y}); }
+                    v2f r = res[f];
+                    if constexpr (!C::MIRQ) { if (wpix) r = tot[f]; }       // (a pixel x receiver weight: the weighted totals)
+                    if (S > 1) { float2 *base = P.part + (size_t)split * P.i_count; asm volatile("" : "+s"(base)); base[q] = make_float2(r.x, r.y); }
+                    else { ST *base = (ST *)P.y; asm volatile("" : "+s"(base)); st(base, (size_t)q, cplx<float>{r.x, r.y}); }
                 }
                 return;
             }
