@@ -50,8 +50,15 @@ FLOP_PER_PAIR = {"nearest": 17, "linear": 24, "cubic": 42, "lanczos3": 54}   # S
 # v_pk_add/mul = 2 flop, v_pk_fma = 4 flop per lane; index math 4 packed adds per transmit pair, weights, 4-tap complex MACs);
 # reciprocal mode shares index + weights between the two traces of an unordered pair.  Cross-checked once against
 # SQ_INSTS_VALU_{FMA,ADD,MUL}_F32 (profiles/r02/).  Per-stage code (receive delay in fp64, DMA issue) is not counted.
-EXEC_FLOP_PER_PAIR = {("nearest", False): 6.0, ("linear", False): 14.0, ("cubic", False): 37.0, ("lanczos3", False): 53.0,
-                      ("nearest", True): 5.0, ("linear", True): 11.0, ("cubic", True): 26.5, ("lanczos3", True): 34.5}
+# The index + weight work is shared by the traces that have the same delay: 2 in reciprocal mode OR lateral-mirror mode, 4 in both.
+EXEC_FLOP_GENERAL = {"nearest": 6.0, "linear": 14.0, "cubic": 37.0, "lanczos3": 53.0}      # one trace per delay
+EXEC_FLOP_MAC = {"nearest": 4.0, "linear": 8.0, "cubic": 16.0, "lanczos3": 16.0}           # of which the complex multiply-accumulates (never shared)
+
+
+def exec_flop_per_pair(interp, share):
+    if interp not in EXEC_FLOP_GENERAL:
+        return None
+    return EXEC_FLOP_MAC[interp] + (EXEC_FLOP_GENERAL[interp] - EXEC_FLOP_MAC[interp]) / share
 
 
 from qups_amd.configs import workload  # noqa: E402  (geometry of the BASELINE configs)
@@ -290,16 +297,20 @@ def main():
         from qups_amd.das_spec import _cast_data
         xc = _cast_data(xc, w["prec"], dev).contiguous()
     prob = build_problem("DAS", w["Pi"], w["Pr"], w["Pv"], w["Nv"], (T, N, M), w["t0"], w["fs"], w["c0"], opts)
-    b, e = I * rank // world, I * (rank + 1) // world       # contiguous slab of the linear pixel index
-    plan = DasPlan(prob, device=dev, kernel=args.kernel, i_begin=b, i_count=e - b, reciprocal=not args.no_reciprocal, jit=args.jit)
-    from qups_amd.dist import gather_pixels
+    # N > 1: qups_amd.dist -- pixel slabs (mirror slabs when every rank's plan takes the lateral-mirror mode: rank r beamforms columns of the
+    # first half AND their mirror images) and ONE RCCL all_gather
+    from qups_amd.dist import ShardedDasPlan
+    splan = ShardedDasPlan(prob, rank, world, device=dev, kernel=args.kernel, reciprocal=not args.no_reciprocal, jit=args.jit)
+    plan = splan.plan
+    b, e = splan.i_begin, splan.i_begin + splan.i_count
+    slab_kw = dict(i_begin=b, i_count=e - b, mirror_slab=splan.mirror_slabs)
 
-    yslab = torch.empty((1, 1, 1, e - b), dtype=xc.dtype, device=dev)      # the image buffer of the frame stream (reused: execute_into)
+    yslab = torch.empty((1, 1, 1, splan.out_count), dtype=xc.dtype, device=dev)      # the image buffer of the frame stream (reused: execute_into)
 
     def step():
         y = plan.execute_into(xc, yslab, 1)                    # (1, 1, 1, slab)
         if world > 1:
-            y = gather_pixels(y, I, world)                     # one RCCL all_gather of the slabs -> (1, 1, 1, I) on every rank
+            y = splan.gather(y)                                # one RCCL all_gather of the slabs -> (1, 1, 1, I) on every rank
         return y
 
     for _ in range(args.warmup):
@@ -341,7 +352,7 @@ def main():
         torch.cuda.synchronize(); dist.barrier()
         tg = time.perf_counter()
         for _ in range(5):
-            gather_pixels(y, I, world)
+            splan.gather(y)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) / 5 * 1e3
         # replicating the channel data from rank 0 (what a single acquisition host has to do once per frame): one RCCL broadcast
@@ -361,14 +372,14 @@ def main():
     reciprocal = bool(plan.reciprocal)
     general_ms = None
     if world == 1 and reciprocal and not args.no_general:      # the same frame without the reciprocal special case (plan flag)
-        gplan = DasPlan(prob, device=dev, kernel=args.kernel, i_begin=b, i_count=e - b, reciprocal=False, jit=args.jit)
+        gplan = DasPlan(prob, device=dev, kernel=args.kernel, reciprocal=False, jit=args.jit, **slab_kw)
         gplan.execute_colmajor(xc, 1)
         general_ms = kernel_time(gplan, 3)
         gplan.close()
 
     prebuilt_ms = None
     if world == 1 and args.jit and not os.environ.get("QDAS_BENCH_CHILD"):      # the same frame on the prebuilt instantiation
-        pplan = DasPlan(prob, device=dev, kernel=args.kernel, i_begin=b, i_count=e - b, reciprocal=not args.no_reciprocal, jit=False)
+        pplan = DasPlan(prob, device=dev, kernel=args.kernel, reciprocal=not args.no_reciprocal, jit=False, **slab_kw)
         pplan.execute_colmajor(xc, 1)
         prebuilt_ms = kernel_time(pplan, 3)
         pplan.close()
@@ -405,7 +416,8 @@ def main():
         alg_bytes = (T * N * M * sb + 12 * I + sb * I + apb) / world      # per launch (per rank): x + Pi + y (+ apod)  (SURVEY 8d "B")
         info = _lib.device_info(local)
         ksec = kernel_ms * 1e-3
-        exec_fpp = EXEC_FLOP_PER_PAIR.get((w["interp"], reciprocal))
+        mirror = bool(plan.mirror)
+        exec_fpp = exec_flop_per_pair(w["interp"], (2 if reciprocal else 1) * (2 if mirror else 1))
         # pairs the kernel really executes: a pixel x receiver weight (array or generated rule) drops whole (wave, receiver) stages
         exec_frac, mask = 1.0, None
         try:
@@ -431,9 +443,9 @@ def main():
             "value": round(I / (el / args.steps) / 1e6, 4), "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"halfT": "f16", "single": "f32", "double": "f64"}[w["prec"]], "data": "synthetic",
-            "config": {"workload": w["label"], "pixels": I, "pairs_per_frame": pairs, "kernel": plan.kernel, "reciprocal_mode": reciprocal,
+            "config": {"workload": w["label"], "pixels": I, "pairs_per_frame": pairs, "kernel": plan.kernel, "reciprocal_mode": reciprocal, "mirror_mode": mirror,
                        "kernel_name": plan.kernel_name(), "jit": bool(args.jit),
-                       "fallback_tiles": fallback, "tile": list(plan.tile_shape()), "wave": list(plan.wave_shape()), "aperture_split": plan.aperture_split(), "parallelism": f"pixel-slab x{world} + RCCL all_gather" if world > 1 else "1 GPU",
+                       "fallback_tiles": fallback, "tile": list(plan.tile_shape()), "wave": list(plan.wave_shape()), "aperture_split": plan.aperture_split(), "parallelism": (f"{'mirror-' if splan.mirror_slabs else ''}pixel-slab x{world} + RCCL all_gather") if world > 1 else "1 GPU",
                        "device": info["name"], "cu": info["cu_count"]},
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / ksec / 1e9, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(alg_bytes / ksec / 1e9 / HBM_PEAK_GBS, 6),

@@ -100,6 +100,13 @@ extern "C" {
                                      about x = 0, detected from the geometry: tap index and weights are shared by a pixel and its
                                      mirror image)                                                                            */
 
+#define QDAS_PLAN_MIRROR_SLAB   16 /* a pixel slab AND its mirror image in one plan (multi-GPU jobs that keep the lateral-mirror mode):
+                                     i_begin / i_count describe slab A -- whole columns [c0, c1) of the FIRST half of an even number of
+                                     columns I2 (I3 == 1) --; the plan also beamforms the mirror-image columns [I2 - c1, I2 - c0) and
+                                     writes them behind slab A: y[0 .. i_count) = slab A, y[i_count .. 2 i_count) = slab B, both in
+                                     natural pixel order ('DAS' only; y holds 2 i_count pixels).  QDAS_EUNSUPPORTED when the geometry
+                                     is not mirror-symmetric or the mode is not available for the problem: use plain slabs then.  */
+
 /* ---- LIFETIME of caller memory.  Host arrays (QDAS_MEM_HOST) are copied at qdas_plan_create and never touched again.  Device
  *      arrays (QDAS_MEM_DEVICE) are used IN PLACE: Pi, Pr, Pv, Nv, apod, cinv and rx_normals must stay allocated and unchanged
  *      until qdas_plan_destroy -- unless the plan was created with QDAS_PLAN_COPY_INPUTS.  acstride is read at creation only.

@@ -127,12 +127,13 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
                  : nf == 2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))
                            : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : narrow == 2 ? launch_tile_f32w(P, ntiles, lds, s) : (P.bf && !P.probe) ? launch_tile_bf(P, ntiles, lds, s) : (P.big && !P.probe) ? launch_tile_f32big(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));
     if (e != hipSuccess || P.probe || P.ksplit <= 1 || P.syn || P.bf) return e;   // ('SYN' planes are accumulated in place, 'BF' planes stored by their owners)
-    const unsigned rb = (unsigned)((P.i_count + 255) / 256);
+    const uint64_t oc = P.mir == 2 ? 2 * P.i_count : P.i_count;     // pixels the plan writes (a mirror slab: slab A and its image)
+    const unsigned rb = (unsigned)((oc + 255) / 256);
     for (int f = 0; f < nfr; ++f) {                      // partial images: [split][frame][pixel]
-        const float2 *src = P.part + (size_t)f * P.i_count;
-        const uint64_t stride = (uint64_t)nfr * P.i_count;
-        if (dtype == 2) tile_reduce_kernel<uint32_t><<<rb, 256, 0, s>>>(src, (uint32_t *)P.y + (size_t)f * P.y_fstride, P.i_count, P.ksplit, stride);
-        else            tile_reduce_kernel<float2><<<rb, 256, 0, s>>>(src, (float2 *)P.y + (size_t)f * P.y_fstride, P.i_count, P.ksplit, stride);
+        const float2 *src = P.part + (size_t)f * oc;
+        const uint64_t stride = (uint64_t)nfr * oc;
+        if (dtype == 2) tile_reduce_kernel<uint32_t><<<rb, 256, 0, s>>>(src, (uint32_t *)P.y + (size_t)f * P.y_fstride, oc, P.ksplit, stride);
+        else            tile_reduce_kernel<float2><<<rb, 256, 0, s>>>(src, (float2 *)P.y + (size_t)f * P.y_fstride, oc, P.ksplit, stride);
     }
     return hipGetLastError();
 }

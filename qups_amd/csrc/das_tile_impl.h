@@ -275,6 +275,8 @@ template <class C> __device__ __forceinline__ uint32_t Tile<C>::locate(uint32_t 
             const uint64_t col2 = ncols - 1 - (uint64_t)col;
             inside = inside && mirror && col2 != (uint64_t)col;
             ig = (uint64_t)i1 + I1 * col2;
+            // (mirror slab: slab B = the images of slab A's columns lies behind slab A in y)
+            if (QSPEC(MIR, P.mir) == 2) ig = ig - (I1 * ncols - i_end) + i_end;
         }
     }
     uint32_t po = inside ? (uint32_t)(ig - P.i_begin) : NOT_MINE;
@@ -756,7 +758,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::epilogue() {
                     asm volatile("" : "+v"(q));
                     v2f r = res[f];
                     if constexpr (!C::MIRQ) { if (wpix) r = tot[f]; }       // (a pixel x receiver weight: the weighted totals)
-                    if (S > 1) { float2 *base = P.part + (size_t)split * P.i_count; asm volatile("" : "+s"(base)); base[q] = make_float2(r.x, r.y); }
+                    if (S > 1) { float2 *base = P.part + (size_t)split * (P.i_count << (QSPEC(MIR, P.mir) == 2 ? 1 : 0)); asm volatile("" : "+s"(base)); base[q] = make_float2(r.x, r.y); }
                     else { ST *base = (ST *)P.y; asm volatile("" : "+s"(base)); st(base, (size_t)q, cplx<float>{r.x, r.y}); }
                 }
                 return;

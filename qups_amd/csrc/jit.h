@@ -19,6 +19,7 @@ struct JitSpec {
     int gen_kind, has_apix, apix_real, syn, has_st, has_cinv_pix;
     int mir;                                            // lateral-mirror mode: the two-window-set instantiation (TileCfg::FB2), one frame
     int mirq;                                           // reciprocal + lateral-mirror mode: four window sets (TileCfg::MIRQ)
+    int mslab;                                          // ... of a mirror slab (tile_params.h mir == 2)
 };
 
 std::string jit_source(const JitSpec &k);

@@ -387,6 +387,12 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     pl->oN = (z.flag & QDAS_FLAG_KEEP_RX) ? z.N : 1;
     pl->oM = (z.flag & QDAS_FLAG_KEEP_TX) ? z.M : 1;
     if (pl->y_ld < pl->i_count) { delete pl; return fail(QDAS_EINVAL, "y_ld smaller than the pixel count"); }
+    if (desc->plan_flags & QDAS_PLAN_MIRROR_SLAB) {
+        const bool ok = z.I3 == 1 && z.I2 % 2 == 0 && z.I1 && desc->i_begin % z.I1 == 0 && pl->i_count % z.I1 == 0 && pl->i_count
+                        && desc->i_begin + pl->i_count <= pl->I / 2 && !(z.flag & (QDAS_FLAG_KEEP_RX | QDAS_FLAG_KEEP_TX)) && desc->kernel != QDAS_KERNEL_GENERIC;
+        if (!ok) { delete pl; return fail(QDAS_EINVAL, "QDAS_PLAN_MIRROR_SLAB: the slab must be whole columns of the first half of an even number of columns (I3 == 1, 'DAS')"); }
+        if (!desc->y_ld) pl->y_ld = 2 * pl->i_count;     // y holds slab A and its mirror image
+    }
 
     auto bail = [&](int code) { delete pl; return code; };
     DeviceGuard guard(desc->device);
@@ -534,11 +540,12 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // fp16 data: a pixel x receiver weight rides along -- an I x N array (the image of a pixel has its OWN entry, at the mirrored receiver: the
     // array need not be symmetric), a pixel-only array, or a generated rule (element normals mirror-symmetric as well: the same value)
     bool mir = false;
+    const bool mslab = (desc->plan_flags & QDAS_PLAN_MIRROR_SLAB) != 0;       // slab A + its mirror image (validated above)
     const bool mir_plain = z.S == 0 && !g.gen_kind;
     const bool mir_wpix = dt == QDAS_F16 && !sym && !swap && !bpix_mode && z.S == npix
                           && ((pix_arr >= 0 && !pix_is_tx && !g.gen_kind) || (pix_arr < 0 && g.gen_kind >= 1 && g.gen_kind <= 4)) && !getenv("QDAS_NO_MIRROR_WPIX");
     if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && (mir_plain || mir_wpix) && !cmap && z.I3 == 1 && z.I2 >= 2
-        && z.N >= 2 && desc->i_begin == 0 && pl->i_count == pl->I && !(desc->plan_flags & QDAS_PLAN_NO_MIRROR) && !getenv("QDAS_NO_MIRROR")
+        && z.N >= 2 && ((desc->i_begin == 0 && pl->i_count == pl->I) || mslab) && !(desc->plan_flags & QDAS_PLAN_NO_MIRROR) && !getenv("QDAS_NO_MIRROR")
         && (!sym || (desc->fmod == 0.0 && (uint64_t)z.T * z.N * z.M * data_size(dt) + 65536 < (1ull << 31) && z.M % 16 == 0 && !getenv("QDAS_NO_MIRQ")
                      && tile_lds_bytes(dt, 1, z.N, z.M, 1, 0, 0, 1) <= tile_lds_limit(1)))) {
         if ((rc = mirror_symmetric(desc, (const float *)g.Pi, &mir))) return bail(rc);
@@ -613,11 +620,11 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         t.cinv_pix = cmap ? (const float *)g.cinv + g.cst[5] : nullptr;
         t.flag = z.flag; t.VS = z.VS; t.DV = z.DV; t.sym = sym; t.big = big;
         // tile grid: (1 << tz_log2) pixels of I1 x tile_cols columns (columns = I2*I3 flattened); the footprint is chosen below
-        t.mir = mir ? 1 : 0;
+        t.mir = mir ? (mslab ? 2 : 1) : 0;
         auto set_grid = [&](int tzl) {
             t.tz_log2 = tzl;
             pl->tile_cols = ((unsigned)pl->tc.waves * 64u) >> tzl;
-            const uint64_t col0 = desc->i_begin / z.I1, col1 = t.mir ? (z.I2 + 1) / 2 - 1 : (desc->i_begin + pl->i_count - 1) / z.I1;   // (mirror mode: the first half of the columns)
+            const uint64_t col0 = desc->i_begin / z.I1, col1 = t.mir == 1 ? (z.I2 + 1) / 2 - 1 : (desc->i_begin + pl->i_count - 1) / z.I1;   // (mirror mode: the first half of the columns)
             t.tiles_z = (uint32_t)((z.I1 + (1u << tzl) - 1) >> tzl);
             t.tile_x0 = (uint32_t)(col0 / pl->tile_cols);
             t.tiles_x = (uint32_t)(col1 / pl->tile_cols) - t.tile_x0 + 1;
@@ -839,12 +846,15 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             t.ksplit = ks;
             if (ks > 1 && !bfm) {
                 void *pb;
-                if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)ks * 4 * pl->i_count))) return bail(rc);   // x4: up to four frames per launch (fp64 data: one complex128 frame -- fits as well)
+                if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)ks * 4 * pl->i_count * (t.mir == 2 ? 2 : 1)))) return bail(rc);   // x4: up to four frames per launch (fp64 data: one complex128 frame -- fits as well)
                 t.part = (float2 *)pb;
             }
         }
     }
 
+    if (mslab && !(pl->kernel == QDAS_KERNEL_TILED && pl->tp.mir == 2))
+        return bail(fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_MIRROR_SLAB: the lateral-mirror mode is not available for this problem (geometry not mirror-symmetric "
+                                            "about x = 0, weights / modes it does not take, or tiles that do not fit the staging windows): use plain slabs"));
     // ---- QDAS_PLAN_JIT: the tiled kernel compiled for this plan's sizes (jit.hip).  A failure is not an error: the plan keeps its
     //      prebuilt kernel and qdas_last_error() says why.
     g_err.clear();
@@ -855,7 +865,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         const int narrow = (t.sym && dt == QDAS_F32 && t.narrow) ? 1 : (!t.sym && dt == QDAS_F32 && t.narrow == 2) ? 2 : 0;
         const int mirq = (t.sym && t.mir) ? 1 : 0;
         const Cfg &cg = CFGS[cfg_index(dt, t.sym, t.mir ? 2 : 1, narrow, mirq)];
-        k.mir = t.mir && !t.sym; k.mirq = mirq;
+        k.mir = t.sym ? 0 : t.mir; k.mirq = mirq; k.mslab = t.mir == 2;
         k.waves = cg.waves; k.mb = cg.mb; k.w = cg.w; k.nbuf = cg.nbuf;
         k.N = t.N; k.M = t.M; k.T = t.T; k.I1 = t.I1; k.strN = t.strN; k.strM = t.strM;
         k.kindB = t.kindB; k.kindS = t.kindS; k.tzl = t.tz_log2; k.wzl = t.wz_log2; k.ksplit = t.ksplit;

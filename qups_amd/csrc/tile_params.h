@@ -62,6 +62,8 @@ struct TileParams {
     // bit for bit (checked by the host) -- so tau(pixel', N-1-n, M-1-m) == tau(pixel, n, m): the tile grid covers the columns c < (I2+1)/2
     // only, the second window set of a stage holds the traces x[:, N-1-n, M-1-m], and tap index + interpolation weights -- half of the
     // pair loop's instructions -- are computed once for a pixel and its mirror image.  Every product of both sums is still formed.
+    // mir == 2 (QDAS_PLAN_MIRROR_SLAB): the plan's pixels [i_begin, i_begin + i_count) are whole columns of the first half; the mirror images go
+    // to y[i_count + (pixel' - (I - i_begin - i_count))] -- slab B behind slab A, natural pixel order.
     int32_t mir;
 };
 

@@ -425,7 +425,9 @@ class DasPlan:
     (``kern/das_spec.m:72-81,387-390``).  ``plan.feval(x)`` beamforms one ``T x N x M`` frame."""
 
     def __init__(self, prob: DasProblem, device=None, kernel: int = _lib.KERNEL_AUTO,
-                 i_begin: int = 0, i_count: int = 0, reciprocal: bool = True, jit: bool = False, mirror: bool = True):
+                 i_begin: int = 0, i_count: int = 0, reciprocal: bool = True, jit: bool = False, mirror: bool = True, mirror_slab: bool = False):
+        """``mirror_slab``: the slab ``[i_begin, i_begin + i_count)`` AND its mirror image in one plan (``QDAS_PLAN_MIRROR_SLAB``, ``include/qdas.h``):
+        the output holds ``2 * i_count`` pixels, slab A then slab B; raises when the lateral-mirror mode is not available for the problem."""
         torch = _torch()
         self.lib = _lib.lib()
         if not torch.cuda.is_available():
@@ -434,6 +436,7 @@ class DasPlan:
         self.prob = prob
         self.i_begin = int(i_begin)
         self.i_count = int(i_count) if i_count else prob.I - int(i_begin)
+        self.out_count = 2 * self.i_count if mirror_slab else self.i_count      # pixels per output plane
         dev = self.device
         up = lambda a: torch.from_numpy(a).to(dev) if a is not None else None
         self._bufs = [up(prob.Pi), up(prob.Pr), up(prob.Pv), up(prob.Nv), up(prob.cinv),
@@ -450,7 +453,8 @@ class DasPlan:
         d.mem, d.apod_real, d.kernel = _lib.MEM_DEVICE, int(prob.apod_real), int(kernel)
         d.device = dev.index if dev.index is not None else torch.cuda.current_device()
         d.i_begin, d.i_count, d.y_ld = self.i_begin, self.i_count, 0
-        d.plan_flags = (0 if reciprocal else _lib.PLAN_NO_RECIPROCAL) | (_lib.PLAN_JIT if jit else 0) | (0 if mirror else _lib.PLAN_NO_MIRROR)
+        d.plan_flags = ((0 if reciprocal else _lib.PLAN_NO_RECIPROCAL) | (_lib.PLAN_JIT if jit else 0) | (0 if mirror else _lib.PLAN_NO_MIRROR)
+                        | (_lib.PLAN_MIRROR_SLAB if mirror_slab else 0))
         if prob.rx_apod is not None:                       # generated receive apodization (qdas.h QDAS_RXAPOD_*)
             d.rx_apod_kind = prob.rx_apod["kind"]
             d.rx_apod_p[0], d.rx_apod_p[1] = prob.rx_apod["p"]
@@ -523,7 +527,7 @@ class DasPlan:
         ``(F.., N, M, T)`` when transposed) of complex(prec).  Returns ``(F, oM, oN, i_count)``."""
         p = self.prob
         oN, oM = p.osize
-        y = _torch().empty((F, oM, oN, self.i_count), dtype=_data_dtype(p.prec), device=self.device)
+        y = _torch().empty((F, oM, oN, self.out_count), dtype=_data_dtype(p.prec), device=self.device)
         return self.execute_into(xc, y, F)
 
     def execute_into(self, xc, y, F: int = 1):
@@ -540,10 +544,10 @@ class DasPlan:
             raise DasError("channel data size does not match the plan")
         if xc.dtype != want or xc.device != self.device:       # the library reads raw bytes: a wrong element size would run off the buffer
             raise DasError(f"channel data must be {want} on {self.device} for a '{p.prec}' plan, got {xc.dtype} on {xc.device}")
-        if y.numel() != F * oM * oN * self.i_count or not y.is_contiguous() or y.dtype != want or y.device != self.device:
-            raise DasError(f"output must be a contiguous {want} tensor of {F * oM * oN * self.i_count} elements on {self.device}")
+        if y.numel() != F * oM * oN * self.out_count or not y.is_contiguous() or y.dtype != want or y.device != self.device:
+            raise DasError(f"output must be a contiguous {want} tensor of {F * oM * oN * self.out_count} elements on {self.device}")
         _lib.check(self.lib.qdas_plan_execute_frames(self._h, C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()),
-                                                     F, per, oM * oN * self.i_count, self._stream()))
+                                                     F, per, oM * oN * self.out_count, self._stream()))
         return y
 
     def feval(self, x):

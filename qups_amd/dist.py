@@ -60,32 +60,120 @@ def lead_has_planes(lead) -> bool:
     return n > 1
 
 
+def mirror_slab_columns(I2: int, rank: int, world: int) -> Tuple[int, int]:
+    """columns ``[c0, c1)`` of the FIRST half of an even number of columns that rank ``rank`` takes as its slab A; its slab B is the
+    mirror image ``[I2 - c1, I2 - c0)``"""
+    h = I2 // 2
+    return h * rank // world, h * (rank + 1) // world
+
+
+def gather_mirror_slabs(y_local, I1: int, I2: int, world: int, group=None):
+    """All-gather the ranks' ``[slab A | slab B]`` outputs (``(..., 2 * count_r)``, one plane) into the image ``(..., I1 * I2)``: one collective
+    (padded to the largest rank), then the slabs A in rank order followed by the slabs B in REVERSE rank order."""
+    import torch
+    import torch.distributed as dist
+
+    cols = [mirror_slab_columns(I2, r, world) for r in range(world)]
+    counts = [(c1 - c0) * I1 for c0, c1 in cols]
+    cmax = max(counts)
+    cplx = y_local.is_complex()
+    src = torch.view_as_real(y_local) if cplx else y_local
+    lead = tuple(y_local.shape[:-1])
+    ax = len(lead)
+    pad = torch.zeros(lead + (2 * cmax,) + tuple(src.shape[ax + 1:]), dtype=src.dtype, device=src.device)
+    cnt = src.shape[ax] // 2
+    pad.narrow(ax, 0, cnt).copy_(src.narrow(ax, 0, cnt))
+    pad.narrow(ax, cmax, cnt).copy_(src.narrow(ax, cnt, cnt))
+    out = torch.empty((world,) + tuple(pad.shape), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, pad.reshape((1,) + tuple(pad.shape)).contiguous(), group=group)
+    parts = [out[r].narrow(ax, 0, counts[r]) for r in range(world)] + [out[r].narrow(ax, cmax, counts[r]) for r in reversed(range(world))]
+    full = torch.cat(parts, dim=ax)
+    return torch.view_as_complex(full.contiguous()) if cplx else full
+
+
 class ShardedDasPlan:
     """``DasPlan`` for rank ``rank`` of ``world``: beamforms this rank's pixel slab and gathers the image.
 
-    ``compute`` defaults to the HIP plan; the CPU tests inject the oracle there to exercise the sharding and
-    the collective under ``gloo`` without a GPU.
+    Two layouts.  Plain: contiguous slabs of the linear pixel index.  Mirror slabs (``mirror_slabs``; default: tried whenever the mode could
+    apply -- ``'DAS'``, one image plane, an even number of columns -- and kept only if EVERY rank's plan accepted it, agreed with one
+    ``all_reduce``): rank r takes columns ``[c0, c1)`` of the first half AND their mirror images, so that the lateral-mirror mode of the
+    fused kernel (a pixel and its image share tap index and weights, ``csrc/tile_params.h``) survives the sharding.
+
+    ``compute`` defaults to the HIP plan; the CPU tests inject the oracle there to exercise the sharding and the collective under ``gloo``
+    without a GPU (``compute(xc, F, i_begin, i_count)``; with ``mirror_slabs=True`` it is called for slab A and for slab B).
     """
 
     def __init__(self, prob, rank: int, world: int, group=None, device=None, kernel: int = 0,
-                 compute: Callable | None = None):
+                 compute: Callable | None = None, mirror_slabs: bool | None = None, **plan_kw):
         self.prob, self.rank, self.world, self.group = prob, rank, world, group
-        self.i_begin, self.i_count = shard_range(prob.I, rank, world)
         self._compute = compute
         self.plan = None
-        if compute is None:
+        I1, I2, I3 = prob.Isz
+        can = world > 1 and prob.fun == "DAS" and I3 == 1 and I2 % 2 == 0 and I2 >= 2 and plan_kw.get("mirror", True)
+        self.mirror_slabs = False
+        if mirror_slabs is None:
+            mirror_slabs = can and compute is None
+        if mirror_slabs and can:
+            c0, c1 = mirror_slab_columns(I2, rank, world)
+            self.i_begin, self.i_count = c0 * I1, (c1 - c0) * I1
+            ok = True
+            if compute is None and self.i_count:
+                from .das_spec import DasPlan
+                try:
+                    self.plan = DasPlan(prob, device=device, kernel=kernel, i_begin=self.i_begin, i_count=self.i_count, mirror_slab=True, **plan_kw)
+                except Exception:                       # (QDAS_EUNSUPPORTED: no lateral-mirror mode for this problem / this slab)
+                    ok = False
+            ok = self._all_agree(ok, device)
+            if ok:
+                self.mirror_slabs = True
+                return
+            if self.plan is not None:
+                self.plan.close()
+                self.plan = None
+        self.i_begin, self.i_count = shard_range(prob.I, rank, world)
+        if compute is None and self.i_count:
             from .das_spec import DasPlan
-            self.plan = DasPlan(prob, device=device, kernel=kernel, i_begin=self.i_begin, i_count=self.i_count)
+            self.plan = DasPlan(prob, device=device, kernel=kernel, i_begin=self.i_begin, i_count=self.i_count, **plan_kw)
+
+    def _all_agree(self, ok: bool, device) -> bool:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized() or self.world == 1:
+            return ok
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=(device if device is not None else "cuda") if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
+    @property
+    def out_count(self) -> int:
+        return 2 * self.i_count if self.mirror_slabs else self.i_count
+
+    def execute_local(self, xc, F: int = 1, out=None):
+        """this rank's share: ``(F, oM, oN, out_count)`` -- the slab, or ``[slab A | slab B]``"""
+        import torch
+        oN, oM = self.prob.osize
+        if not self.i_count:                             # more ranks than pixels / columns
+            return torch.zeros((F, oM, oN, 0), dtype=xc.dtype, device=xc.device)
+        if self._compute is not None:
+            if not self.mirror_slabs:
+                return self._compute(xc, F, self.i_begin, self.i_count)
+            ib = self.prob.I - self.i_begin - self.i_count
+            return torch.cat([self._compute(xc, F, self.i_begin, self.i_count), self._compute(xc, F, ib, self.i_count)], dim=-1)
+        return self.plan.execute_into(xc, out, F) if out is not None else self.plan.execute_colmajor(xc, F)
+
+    def gather(self, y):
+        if self.mirror_slabs:
+            return gather_mirror_slabs(y, self.prob.Isz[0], self.prob.Isz[1], self.world, self.group)
+        return gather_pixels(y, self.prob.I, self.world, self.group)
 
     def execute_colmajor(self, xc, F: int = 1):
         """``(F, oM, oN, I)`` on every rank (see :meth:`DasPlan.execute_colmajor`)."""
-        if self.i_count:
-            y = self.plan.execute_colmajor(xc, F) if self._compute is None else self._compute(xc, F, self.i_begin, self.i_count)
-        else:  # more ranks than pixels
-            import torch
-            oN, oM = self.prob.osize
-            y = torch.zeros((F, oM, oN, 0), dtype=xc.dtype, device=xc.device)
-        return gather_pixels(y, self.prob.I, self.world, self.group)
+        return self.gather(self.execute_local(xc, F))
+
+    def close(self):
+        if self.plan is not None:
+            self.plan.close()
 
 
 # ------------------------------------------------------------------------------------------

@@ -26,7 +26,8 @@ def _worker(rank, world, port, cases, q):
         from oracle import das_oracle as O
         from qups_amd import build_problem, parse_options
         from qups_amd.dist import ShardedDasPlan
-        for fun, I1, I2 in cases:
+        for fun, I1, I2, *rest in cases:
+            mirror_slabs = bool(rest and rest[0])
             case = make_case(seq="PW", interp="linear", seed=3, N=4, M=3, I1=I1, I2=I2)
             x = torch.from_numpy(case["x"])
             opts = parse_options(x, list(case["opt"]) + ["interp", "linear"])
@@ -39,9 +40,9 @@ def _worker(rank, world, port, cases, q):
             def compute(xc, F, b, c, full_cm=full_cm):   # the slab a GPU rank would produce: (1, oM, oN, count)
                 return full_cm[..., b:b + c].contiguous()
 
-            plan = ShardedDasPlan(prob, rank, world, compute=compute)
+            plan = ShardedDasPlan(prob, rank, world, compute=compute, mirror_slabs=mirror_slabs)
             y = plan.execute_colmajor(x.permute(2, 1, 0).contiguous(), 1)
-            ok = bool(torch.equal(y, full_cm)) and tuple(y.shape) == (1, oM, oN, prob.I)
+            ok = bool(torch.equal(y, full_cm)) and tuple(y.shape) == (1, oM, oN, prob.I) and plan.mirror_slabs == mirror_slabs
             q.put((rank, fun, I1 * I2, ok, plan.i_begin, plan.i_count))
     finally:
         dist.destroy_process_group()
@@ -124,3 +125,28 @@ def test_transmit_sharded_allreduce_gloo(world):
         p.join(60)
         assert p.exitcode == 0
     assert all(r[4] and r[3] <= 1e-12 for r in res), res
+
+
+MIRROR_CASES = [("DAS", 16, 4, True), ("DAS", 5, 10, True), ("DAS", 3, 2, True), ("DAS", 7, 12, True)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_mirror_slab_gather_gloo(world):
+    """the mirror-slab layout (rank r: columns [c0, c1) of the first half AND their mirror images, gathered as [A | B] pairs and laid out as
+    A_0 .. A_{G-1} B_{G-1} .. B_0): shard ranges, ragged and empty ranks (fewer half-columns than ranks), the single collective"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, MIRROR_CASES, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world * len(MIRROR_CASES))]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[3] for r in res), res
+    for fun, I1, I2, _ in MIRROR_CASES:
+        spans = sorted((b, c) for _, f, I, _, b, c in res if f == fun and I == I1 * I2)
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == I1 * I2 // 2            # the slabs A tile the first half of the columns
+        for (b0, c0), (b1, _) in zip(spans, spans[1:]):
+            assert b0 + c0 == b1 and b0 % I1 == 0

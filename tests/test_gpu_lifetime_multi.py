@@ -217,7 +217,7 @@ def test_bench_two_ranks_over_rccl_matches_one_rank(tmp_path):
     has the checksum of the one-GPU image and the line carries ``multi_gpu.rccl_ranks == 2``"""
     _need_devices(2)
     common = ["--workload", "c2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-traffic", "--checksum"]
-    env = {"QDAS_CACHE_DIR": str(tmp_path), "QDAS_KSPLIT": "1", "QDAS_NO_MIRROR": "1"}        # (one summation order whatever the slab size: bit-identical images)
+    env = {"QDAS_CACHE_DIR": str(tmp_path), "QDAS_KSPLIT": "1"}        # (one summation order whatever the slab size: bit-identical images; both runs in lateral-mirror mode -- N = 2: mirror slabs)
     one = _bench(["--gpus", "1"] + common, env)
     two = _bench(["--gpus", "2"] + common, env)
     assert two["n_gpus"] == 2 and two["multi_gpu"]["rccl_ranks"] == 2 and two["multi_gpu"]["backend"] == "nccl", two
@@ -227,8 +227,8 @@ def test_bench_two_ranks_over_rccl_matches_one_rank(tmp_path):
 def test_bench_shared_gpu_plumbing_prints_one_line(tmp_path):
     """one GPU, two ranks sharing it (gloo): the self-launch, the slab split, the gather and the single JSON line of ``bench.py --gpus 2``"""
     common = ["--workload", "c1", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-traffic", "--checksum"]
-    env = {"QDAS_CACHE_DIR": str(tmp_path), "QDAS_KSPLIT": "1", "QDAS_NO_MIRROR": "1"}
+    env = {"QDAS_CACHE_DIR": str(tmp_path), "QDAS_KSPLIT": "1"}
     one = _bench(["--gpus", "1"] + common, env)
     two = _bench(["--gpus", "2"] + common, dict(env, QDAS_BENCH_SHARE_GPU="1"))
-    assert two["n_gpus"] == 2 and two["multi_gpu"]["backend"] == "gloo", two
+    assert two["n_gpus"] == 2 and two["multi_gpu"]["backend"] == "gloo" and "mirror-pixel-slab x2" in two["config"]["parallelism"], two
     assert two["image_checksum"] == one["image_checksum"]

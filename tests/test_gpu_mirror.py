@@ -267,3 +267,64 @@ def test_mirror_mode_is_not_taken_where_it_is_not_built():
         assert not p.mirror
     with plan_of(i_begin=0, i_count=64 * 8) as p:
         assert not p.mirror
+
+
+@pytest.mark.parametrize("seq,prec,weights,jit", [("PW", "single", False, False), ("FSA", "single", False, True), ("FSA", "halfT", False, False),
+                                                   ("DV", "halfT", True, True), ("PW", "halfT", True, False)])
+def test_mirror_slabs_tile_the_image(seq, prec, weights, jit, tmp_path, monkeypatch):
+    """QDAS_PLAN_MIRROR_SLAB (the multi-GPU layout that keeps the lateral-mirror mode): rank r's plan beamforms columns [c0, c1) of the
+    first half AND their mirror images, output [slab A | slab B]; the slabs of G = 2, 3, 4 ranks, laid out as qups_amd.dist does, are
+    bit-identical to the whole-image mirror plan (same kernel, same summation order per pixel)"""
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd.dist import mirror_slab_columns
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("QDAS_KSPLIT", "1")
+    I1, I2, N = 100, 24, 16
+    case = make_case(seq=seq, interp="cubic", seed=77, N=N, M=16 if seq != "FSA" else None, I1=I1, I2=I2)
+    x = case["x"]
+    if prec == "halfT":
+        x = (x.real.astype(np.float16).astype(np.float32) + 1j * x.imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
+    xt = torch.from_numpy(x)
+    va = list(case["opt"]) + ["interp", "cubic", "input-precision", prec]
+    if weights:
+        rng = np.random.default_rng(2)
+        va += ["apod", ((rng.random((I1, I2, 1, N, 1)) > 0.4) * rng.uniform(0.5, 1, (I1, I2, 1, N, 1))).astype(np.float16)]
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], parse_options(xt, va))
+    with DasPlan(prob, kernel=2, jit=jit) as whole:
+        assert whole.mirror
+        full = torch.view_as_real(whole.feval(xt)).clone()
+        kname = whole.kernel_name()
+    for G in (2, 3, 4):
+        A, B = [], []
+        for r in range(G):
+            c0, c1 = mirror_slab_columns(I2, r, G)
+            with DasPlan(prob, kernel=2, jit=jit, i_begin=c0 * I1, i_count=(c1 - c0) * I1, mirror_slab=True) as plan:
+                assert plan.mirror and plan.out_count == 2 * (c1 - c0) * I1
+                assert plan.kernel_name().split(" [")[0] == kname.split(" [")[0]
+                y = torch.view_as_real(plan.feval(xt)).reshape(2, (c1 - c0) * I1, -1)
+                A.append(y[0]); B.append(y[1])
+        img = torch.cat(A + B[::-1], dim=0)
+        assert torch.equal(img.reshape(full.shape), full), G
+
+
+def test_mirror_slab_is_refused_where_the_mode_is_not_available():
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options
+    case = make_case(seq="PW", interp="linear", seed=3, N=16, M=16, I1=64, I2=16)
+    x = torch.from_numpy(case["x"])
+
+    def plan(**kw):
+        c = dict(case); c.update(kw.pop("geo", {}))
+        prob = build_problem(kw.pop("fun", "DAS"), c["Pi"], c["Pr"], c["Pv"], c["Nv"], tuple(x.shape), c["t0"], c["fs"], c["c"], parse_options(x, list(c["opt"]) + ["interp", "linear"]))
+        return DasPlan(prob, mirror_slab=True, **kw)
+
+    plan(i_begin=0, i_count=64 * 4).close()
+    Pr = case["Pr"].copy(); Pr[0, 2] = float(np.nextafter(np.float32(Pr[0, 2]), np.float32(1)))
+    for bad in (dict(i_begin=0, i_count=64 * 4, geo=dict(Pr=Pr)),          # not mirror-symmetric
+                dict(i_begin=64 * 6, i_count=64 * 4),                       # reaches into the second half
+                dict(i_begin=10, i_count=64),                               # not whole columns
+                dict(i_begin=0, i_count=64 * 4, fun="SYN"),                 # kept dimension
+                dict(i_begin=0, i_count=64 * 4, mirror=False)):             # the mode switched off
+        with pytest.raises(Exception):
+            plan(**bad)
