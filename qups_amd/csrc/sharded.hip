@@ -38,6 +38,7 @@ struct Shard {
     void *x = nullptr;                                  // this device's replica of the frame (null: shares the root's)
     void *y = nullptr;                                  // slab output, i_count x [N] x [M]
     std::vector<void *> owned;                          // device copies of geometry made for this shard
+    qdas_desc d{};                                      // this shard's problem (its own device copies of the constant inputs)
     // replication (holders only: the first shard of every distinct device): one pull stream per source holder, an event per pull,
     // and the event that says "my own piece has arrived" (what the other holders' pulls of that piece wait for)
     std::vector<hipStream_t> pull_stream;
@@ -91,6 +92,7 @@ struct qdas_sharded_plan {
     std::vector<int> holder;                            // shard index of the first shard on each distinct device (holder[0] = 0)
     std::vector<int> uidx;                              // shard -> index into holder
     bool executed = false;                              // (the `done` events of a previous frame exist)
+    bool mirror = false;                                // mirror slabs (QDAS_PLAN_MIRROR_SLAB): shard g = columns of the first half + their mirror images
     ~qdas_sharded_plan() {
         DeviceGuard guard;
         for (Shard &s : sh) {
@@ -183,13 +185,7 @@ extern "C" int qdas_plan_create_sharded(qdas_sharded_plan **out, const qdas_desc
                 (rc = bring(desc->apod, apod_elems * ael, &d.apod)) || (rc = bring(desc->rx_normals, desc->rx_apod_kind ? 3 * z.N * rs : 0, &d.rx_normals)))
                 return bail(rc);
         }
-        if (s.i_count) {
-            rc = qdas_plan_create(&s.plan, &d);
-            if (rc) return bail(rc);
-            e = hipSetDevice(s.device);
-            if (e == hipSuccess) e = hipMalloc(&s.y, (size_t)s.i_count * sp->oN * sp->oM * sp->ds + 16);
-            if (e != hipSuccess) return bail(failf(QDAS_ENOMEM, "qdas_plan_create_sharded: slab buffer: %s", hipGetErrorString(e)));
-        }
+        s.d = d;                                         // (plans are created below, once the slab layout is decided)
         // replica of the frame: one per distinct device (a device listed twice shares it); the root needs one only for host callers.
         // QDAS_SHARDED_FORCE_REPLICAS=1 (tests): every shard is its own holder even on a shared device, so that the replication
         // machinery -- pull streams, events, pieces -- runs and is checked on a single GPU.
@@ -209,6 +205,49 @@ extern "C" int qdas_plan_create_sharded(qdas_sharded_plan **out, const qdas_desc
         hipError_t e = hipSetDevice(root_dev);
         if (e == hipSuccess) e = hipMalloc(&sp->y_root, (size_t)sp->I * sp->oN * sp->oM * sp->ds + 16);
         if (e != hipSuccess) return bail(failf(QDAS_ENOMEM, "qdas_plan_create_sharded: gather buffer: %s", hipGetErrorString(e)));
+    }
+    // ---- the shards' plans.  First choice: MIRROR SLABS -- shard g takes columns [c0, c1) of the first half of the image and their mirror
+    //      images (QDAS_PLAN_MIRROR_SLAB), so that the lateral-mirror mode of the fused kernel survives the sharding; every shard's plan must
+    //      accept it (a mirror-symmetric geometry, 'DAS', an even number of columns ...), else plain contiguous slabs.
+    auto make_plans = [&](bool mirror) -> int {
+        for (int g = 0; g < ndev; ++g) {
+            Shard &s = sp->sh[g];
+            if (mirror) {
+                const uint64_t h = z.I2 / 2, c0 = h * (uint64_t)g / (uint64_t)ndev, c1 = h * (uint64_t)(g + 1) / (uint64_t)ndev;
+                s.i_begin = c0 * z.I1; s.i_count = (c1 - c0) * z.I1;
+            } else {
+                s.i_begin = sp->I * (uint64_t)g / (uint64_t)ndev;
+                s.i_count = sp->I * (uint64_t)(g + 1) / (uint64_t)ndev - s.i_begin;
+            }
+            if (!s.i_count) continue;
+            qdas_desc d = s.d;
+            d.i_begin = s.i_begin; d.i_count = s.i_count; d.y_ld = 0;
+            if (mirror) d.plan_flags |= QDAS_PLAN_MIRROR_SLAB;
+            int rc = qdas_plan_create(&s.plan, &d);
+            if (rc) return rc;
+            hipError_t e = hipSetDevice(s.device);
+            if (e == hipSuccess) e = hipMalloc(&s.y, (size_t)s.i_count * (mirror ? 2 : 1) * sp->oN * sp->oM * sp->ds + 16);
+            if (e != hipSuccess) return failf(QDAS_ENOMEM, "qdas_plan_create_sharded: slab buffer: %s", hipGetErrorString(e));
+        }
+        return QDAS_OK;
+    };
+    auto drop_plans = [&]() {
+        for (Shard &s : sp->sh) {
+            (void)hipSetDevice(s.device);
+            if (s.plan) { qdas_plan_destroy(s.plan); s.plan = nullptr; }
+            if (s.y) { (void)hipFree(s.y); s.y = nullptr; }
+        }
+    };
+    {
+        const bool try_mirror = ndev > 1 && sp->oN == 1 && sp->oM == 1 && z.I3 == 1 && z.I2 >= 2 && z.I2 % 2 == 0 && sp->I && z.N && z.M
+                                && !(desc->plan_flags & QDAS_PLAN_NO_MIRROR) && desc->kernel != QDAS_KERNEL_GENERIC && !getenv("QDAS_NO_MIRROR");
+        int rc = try_mirror ? make_plans(true) : QDAS_EUNSUPPORTED;
+        if (rc == QDAS_OK) sp->mirror = true;
+        else {
+            drop_plans();
+            if (try_mirror && rc != QDAS_EUNSUPPORTED && rc != QDAS_EINVAL) return bail(rc);
+            if ((rc = make_plans(false))) return bail(rc);
+        }
     }
     // ---- replication plumbing: a pull stream + event per (destination holder, source holder), direct access between every pair
     //      of distinct devices (peer copies between devices without it are staged through the host)
@@ -329,7 +368,17 @@ extern "C" int qdas_plan_execute_sharded(qdas_sharded_plan *sp, const void *x, v
         if (rc) return rc;
         // slab planes (i_count x [N] x [M]) -> their rows of the I x [N] x [M] image
         const size_t planes = (size_t)sp->oN * sp->oM;
-        if (s.device == root_dev)
+        if (sp->mirror) {                                // [slab A | slab B] -> pixels [i_begin, +i_count) and their mirror images [I - i_begin - i_count, +i_count)
+            const size_t nb = (size_t)s.i_count * sp->ds;
+            char *dA = (char *)ydst + s.i_begin * sp->ds, *dB = (char *)ydst + (sp->I - s.i_begin - s.i_count) * sp->ds;
+            if (s.device == root_dev) {
+                SHIP(hipMemcpyAsync(dA, s.y, nb, hipMemcpyDeviceToDevice, s.stream));
+                SHIP(hipMemcpyAsync(dB, (const char *)s.y + nb, nb, hipMemcpyDeviceToDevice, s.stream));
+            } else {
+                SHIP(hipMemcpyPeerAsync(dA, root_dev, s.y, s.device, nb, s.stream));
+                SHIP(hipMemcpyPeerAsync(dB, root_dev, (const char *)s.y + nb, s.device, nb, s.stream));
+            }
+        } else if (s.device == root_dev)
             SHIP(hipMemcpy2DAsync((char *)ydst + s.i_begin * sp->ds, (size_t)sp->I * sp->ds, s.y, (size_t)s.i_count * sp->ds,
                                   (size_t)s.i_count * sp->ds, planes, hipMemcpyDeviceToDevice, s.stream));
         else

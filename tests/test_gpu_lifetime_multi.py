@@ -136,19 +136,23 @@ def test_entries_restore_the_current_device():
     assert hip.hipGetDevice(C.byref(cur)) == 0 and cur.value == 0
 
 
-def _sharded_vs_single(fun, devices, mem, frames=2, seq="PW"):
+def _sharded_vs_single(fun, devices, mem, frames=2, seq="PW", I2=23, mirror=False):
     import torch
     from qups_amd import DasPlan, MultiDevicePlan, _lib, build_problem, parse_options
-    case = make_case(seq=seq, interp="cubic", seed=43, N=12, M=None if seq == "FSA" else 6, I1=203, I2=23)      # ragged slabs
+    case = make_case(seq=seq, interp="cubic", seed=43, N=12 if not mirror else 16, M=None if seq == "FSA" else (6 if not mirror else 16), I1=203, I2=I2)      # ragged slabs
     xs = [torch.from_numpy(case["x"] * (1 + 0.5j * f) + f).to("cuda:%d" % devices[0]) for f in range(frames)]
     opts = parse_options(xs[0], list(case["opt"]) + ["interp", "cubic"])
     T, N, M = case["x"].shape
     prob = build_problem(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], (T, N, M), case["t0"], case["fs"], case["c"], opts)
-    one = DasPlan(prob, device="cuda:%d" % devices[0], mirror=False)     # (slabs run the plain kernel: bit-identical to the plain whole-image plan)
+    # plain slabs run the plain kernel: bit-identical to the plain whole-image plan; mirror slabs (an even number of columns, a symmetric
+    # geometry) to the whole-image plan in lateral-mirror mode
+    one = DasPlan(prob, device="cuda:%d" % devices[0], mirror=mirror)
+    assert one.mirror == mirror
     ref = [one.feval(x) for x in xs]
     if mem == "device":
         mp = MultiDevicePlan(prob, devices=devices)
         assert [d for d, _, _, _ in mp.shards()] == list(devices)
+        assert sum(c for _, _, c, _ in mp.shards()) == (prob.I // 2 if mirror else prob.I)
         got = [mp.feval(x) for x in xs]                   # back-to-back frames: the second replication must wait for the first frame's readers
         torch.cuda.synchronize()
         for g, r in zip(got, ref):
@@ -185,6 +189,16 @@ def test_sharded_replication_machinery_on_one_device(fun, nshard, mem, monkeypat
     _sharded_vs_single(fun, [0] * nshard, mem, frames=3)
 
 
+@pytest.mark.parametrize("seq,nshard,mem", [("PW", 2, "device"), ("FSA", 3, "device"), ("PW", 4, "host"), ("FSA", 8, "device")])
+def test_sharded_mirror_slabs_on_one_device(seq, nshard, mem, monkeypatch):
+    """an even number of columns and a mirror-symmetric geometry: the multi-device entry hands every shard columns of the first half AND
+    their mirror images (QDAS_PLAN_MIRROR_SLAB) -- the lateral-mirror / reciprocal + mirror kernels run on every shard and the image is
+    bit-identical to the one-device plan in that mode; with forced replicas the replication machinery runs as well"""
+    monkeypatch.setenv("QDAS_SHARDED_FORCE_REPLICAS", "1")
+    monkeypatch.setenv("QDAS_KSPLIT", "1")
+    _sharded_vs_single("DAS", [0] * nshard, mem, frames=2, seq=seq, I2=24, mirror=True)
+
+
 def _need_devices(n):
     import torch
     if torch.cuda.device_count() < n:
@@ -193,12 +207,15 @@ def _need_devices(n):
 
 @pytest.mark.parametrize("fun,mem,seq", [("DAS", "device", "PW"), ("DAS", "device", "FSA"), ("SYN", "device", "PW"), ("BF", "device", "PW"),
                                          ("DAS", "host", "PW"), ("MUL", "host", "PW")])
-def test_sharded_over_distinct_devices_is_bit_identical(fun, mem, seq):
+def test_sharded_over_distinct_devices_is_bit_identical(fun, mem, seq, monkeypatch):
     """(>= 2 GPUs) qdas_plan_create_sharded over ordinals [0..G-1]: peer copies of the frame over xGMI, one kernel per device, slabs
     peer-copied back -- bit-identical to the single plan"""
     import torch
     _need_devices(2)
     _sharded_vs_single(fun, list(range(torch.cuda.device_count())), mem, frames=2, seq=seq)
+    if fun == "DAS":                                     # ... and with mirror slabs
+        monkeypatch.setenv("QDAS_KSPLIT", "1")
+        _sharded_vs_single(fun, list(range(torch.cuda.device_count())), mem, frames=2, seq=seq, I2=24, mirror=True)
 
 
 def _bench(args, env=None):
