@@ -90,6 +90,10 @@ struct qdas_plan {
     double misfit_frac = 0.0;                 // fraction of the chosen footprint's tiles that do not fit it
     bool fb2_ok = false;                      // frames of a sequence may share launches, 4 or 2 at a time (decided at plan creation)
     bool fb4_off = false;                     // ... but at most pairwise (QDAS_NO_FB4)
+    // A lateral-mirror plan runs one frame per launch (its second window set is taken).  For a STREAM of frames four frames per launch share
+    // more (index + weights of four traces instead of two): such plans keep a twin without the mirror mode, made at the first stream.
+    qdas_plan *frames_twin = nullptr;
+    bool twin_tried = false;
     uint32_t *fallback = nullptr;             // device: [0] = count, [1..ntiles]
     size_t jit_lds = 0;                       // dynamic LDS of the specialised kernel
     int jit_mb = 0;                           // its transmits per stage
@@ -107,6 +111,7 @@ struct qdas_plan {
     hipEvent_t ex[2] = {nullptr, nullptr}, ek[2] = {nullptr, nullptr};
 
     ~qdas_plan() {
+        if (frames_twin) qdas_plan_destroy(frames_twin);
         for (void *p : owned) (void)hipFree(p);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
@@ -1034,6 +1039,36 @@ extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, u
     }
     if (!x) return fail(QDAS_EINVAL, "null data");
     if (pl->timing) HIPCHK(hipEventRecord(pl->e0, s));
+    // a stream of >= 4 device-resident frames through a general-mode lateral-mirror plan: four frames per launch on the plan's twin
+    if (F >= 4 && pl->kernel == QDAS_KERNEL_TILED && pl->tp.mir == 1 && !pl->tp.sym && !pl->tp.apix && !pl->tp.gen_kind && pl->d.mem == QDAS_MEM_DEVICE
+        && !getenv("QDAS_NO_FB4") && !getenv("QDAS_NO_FB2") && !getenv("QDAS_NO_FRAMES_TWIN")) {
+        if (!pl->twin_tried) {
+            pl->twin_tried = true;
+            qdas_desc d = pl->d;                        // (the plan's own device copies / the caller's device arrays: both stay valid for the plan's life)
+            const GenericParams &g = pl->gp;
+            uint64_t acs[6 * (1 + QDAS_MAX_APOD)];
+            memcpy(acs, g.cst, sizeof g.cst); memcpy(acs + 6, g.ast, sizeof(uint64_t) * 6 * z.S);
+            d.Pi = g.Pi; d.Pr = g.Pr; d.Pv = g.Pv; d.Nv = g.Nv; d.cinv = g.cinv; d.apod = g.apod; d.rx_normals = g.rxn; d.acstride = acs;
+            d.mem = QDAS_MEM_DEVICE; d.device = pl->device;
+            d.plan_flags = (d.plan_flags | QDAS_PLAN_NO_MIRROR) & ~(QDAS_PLAN_COPY_INPUTS | QDAS_PLAN_JIT | QDAS_PLAN_MIRROR_SLAB);
+            const std::string keep = g_err;
+            if (qdas_plan_create(&pl->frames_twin, &d) != QDAS_OK) pl->frames_twin = nullptr;
+            else if (!(pl->frames_twin->fb2_ok && !pl->frames_twin->fb4_off)) { qdas_plan_destroy(pl->frames_twin); pl->frames_twin = nullptr; }
+            g_err = keep;
+        }
+        if (pl->frames_twin) {
+            const uint64_t F4 = F & ~3ull;
+            pl->frames_twin->timing = false;
+            int rc = qdas_plan_execute_frames(pl->frames_twin, x, y, F4, x_stride, y_stride, stream);
+            if (rc) return rc;
+            const bool tm = pl->timing;
+            pl->timing = false;                          // (one pair of events around the whole stream)
+            if (F4 < F) rc = qdas_plan_execute_frames(pl, (const char *)x + F4 * x_stride * ds, (char *)y + F4 * y_stride * ds, F - F4, x_stride, y_stride, stream);
+            pl->timing = tm;
+            if (!rc && pl->timing) { HIPCHK(hipEventRecord(pl->e1, s)); HIPCHK(hipEventSynchronize(pl->e1)); HIPCHK(hipEventElapsedTime(&pl->last_ms, pl->e0, pl->e1)); }
+            return rc;
+        }
+    }
     // frame pairs share one launch (device-resident data, tiled kernel, not the reciprocal mode; QDAS_NO_FB2 disables)
     const bool pairs_ok = pl->fb2_ok && x_stride * ds < (1ull << 40);
     if (pl->d.mem == QDAS_MEM_HOST && F >= 2) {         // host frames: upload f+1 on the copy stream while f is beamformed

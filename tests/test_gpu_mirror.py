@@ -114,18 +114,19 @@ def test_mirror_mode_edges_split_aperture_and_record_ends(monkeypatch):
 
 
 def test_mirror_mode_through_das_spec_and_frames():
-    """the reference-shaped entry picks the mode by itself; several frames through one plan run one mirrored launch each"""
+    """the reference-shaped entry picks the mode by itself; a stream of frames through one plan: four frames per launch share more than a
+    pixel and its image do, so whole groups of four run on the plan's twin without the mirror mode, the rest one mirrored launch each"""
     import torch
     from oracle import das_oracle as O
     from qups_amd import das_spec
     case = make_case(seq="PW", interp="cubic", seed=12, N=16, M=8, I1=80, I2=24)
     rng = np.random.default_rng(1)
-    xs = np.stack([case["x"]] + [(rng.standard_normal(case["x"].shape) + 1j * rng.standard_normal(case["x"].shape)).astype(np.complex64) for _ in range(3)], axis=3)
+    xs = np.stack([case["x"]] + [(rng.standard_normal(case["x"].shape) + 1j * rng.standard_normal(case["x"].shape)).astype(np.complex64) for _ in range(5)], axis=3)
     y, plan = das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], torch.from_numpy(xs), case["t0"], case["fs"], case["c"],
                        *case["opt"], "interp", "cubic", return_plan=True)
     assert plan.mirror
     y = y.cpu().numpy()
-    for f in range(4):
+    for f in range(6):                                  # (frames 0-3: four per launch on the plan's twin without the mirror mode; 4, 5: one mirrored launch each)
         ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs[..., f], case["t0"], case["fs"], cinv_f32(case["c"]),
                          VS=case["VS"], DV=case["DV"], interp="cubic")
         assert rel_err(y[..., f].reshape(ref.shape), ref) <= 2e-5
