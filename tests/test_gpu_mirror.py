@@ -261,7 +261,9 @@ def test_mirror_mode_is_not_taken_where_it_is_not_built():
     with plan_of(apod=[rng.random((64, 16, 1, 16, 1)).astype(np.float32)]) as p:
         assert not p.mirror and p.kernel == "tiled"
     with plan_of(apod=[np.hanning(18)[1:-1].astype(np.float32).reshape(1, 1, 1, 16)]) as p:
-        assert not p.mirror and p.kernel == "tiled"
+        assert p.mirror and p.kernel == "tiled"           # (a mirror-symmetric weight table rides along)
+    with plan_of(apod=[np.linspace(0.2, 1.0, 16).astype(np.float32).reshape(1, 1, 1, 16)]) as p:
+        assert not p.mirror and p.kernel == "tiled"       # (an asymmetric one does not)
     with plan_of(c=1540.0 + 10.0 * rng.random((64, 16, 1))) as p:
         assert not p.mirror
     with plan_of(fun="SYN") as p:
@@ -329,3 +331,39 @@ def test_mirror_slab_is_refused_where_the_mode_is_not_available():
                 dict(i_begin=0, i_count=64 * 4, mirror=False)):             # the mode switched off
         with pytest.raises(Exception):
             plan(**bad)
+
+
+@pytest.mark.parametrize("jit", [False, True], ids=["prebuilt", "jit"])
+@pytest.mark.parametrize("seq,prec,cplx", [("PW", "single", False), ("DV", "single", True), ("PW", "halfT", False), ("FC", "single", False)])
+def test_mirror_mode_with_a_symmetric_weight_table(seq, prec, cplx, jit, tmp_path, monkeypatch):
+    """receive and transmit windows (pixel-independent arrays, folded into one N x M table) are mirror-symmetric: w[n,m] == w[N-1-n,M-1-m] -- the
+    table's entry of a stage serves a pixel and its image; a zero entry still never samples its trace"""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import DasPlan, build_problem, parse_options
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    N, M = 24, 18
+    case = make_case(seq=seq, interp="cubic", seed=15, N=N, M=M, I1=120, I2=28)
+    x = case["x"]
+    if prec == "halfT":
+        x = (x.real.astype(np.float16).astype(np.float32) + 1j * x.imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
+    q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else (lambda a: a.astype(np.float32).astype(np.float64))
+    wn = q(np.hanning(N + 2)[1:-1]).reshape(1, 1, 1, N, 1)
+    wm = q(0.25 + 0.75 * np.hanning(M + 2)[1:-1]).reshape(1, 1, 1, 1, M)
+    wm[..., 3] = 0.0; wm[..., M - 4] = 0.0                 # dead transmits, symmetric
+    if cplx:
+        wm = wm * (1 + 0.5j)
+    xt = torch.from_numpy(x)
+    va = list(case["opt"]) + ["interp", "cubic", "input-precision", prec, "apod", wn, "apod", wm]
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], parse_options(xt, va))
+    ys = []
+    for mirror in (True, False):
+        with DasPlan(prob, kernel=2, jit=jit, mirror=mirror) as plan:
+            assert plan.mirror == mirror and ("wtab" in plan.kernel_name())
+            y = plan.feval(xt)
+            ys.append((torch.view_as_real(y).float().cpu().numpy().view(np.complex64)[..., 0] if prec == "halfT" else y.cpu().numpy()).reshape(-1))
+    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], x, case["t0"], case["fs"], cinv_f32(case["c"]), VS=case["VS"], DV=case["DV"],
+                     interp="cubic", apod=[wn, wm]).reshape(-1, order="F")
+    tol = 2e-3 if prec == "halfT" else 2e-5
+    assert rel_err(ys[0], ref) <= tol and rel_err(ys[1], ref) <= tol
+    assert rel_err(ys[0], ys[1]) <= (1e-4 if prec == "halfT" else 2e-6)
