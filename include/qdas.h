@@ -330,17 +330,20 @@ int qdas_greens(const qdas_greens_desc *desc, void *y /* S x N x M complex */, v
  *   z[c,l,s] = sum_i x[c,i,s] * y[c, l + off - i, s]
  * 'full': L = M+N-1, off = 0; 'same': L = M, off = N-1 - floor((N-1)/2); 'valid': L = max(M-N+1, 0), off = N-1
  * (kern/convd.m:103-114).  A singleton column / slice dimension of x or y is broadcast (bits of `bcast`) instead of being
- * replicated as the reference does (kern/convd.m:75-84).  The half-precision twins (convh / convch) are not provided. */
+ * replicated as the reference does (kern/convd.m:75-84).  QDAS_F16: the half-precision twins convh / convch (src/convd.cu:141,153) --
+ * products and sums in fp32, rounded once at the store (the reference accumulates in half). */
 #define QDAS_CONV_FULL  0
 #define QDAS_CONV_SAME  1
 #define QDAS_CONV_VALID 2
+#define QDAS_CONV_CAUSAL 3         /* extension: L = M, off = 0 -- the first M samples of the full convolution = MATLAB filter(b, 1, x), what
+                                      ChannelData.filter applies with an FIR digitalFilter (reference src/ChannelData.m:857-880)            */
 #define QDAS_CONV_X_ONE_COLUMN 1   /* x is 1 x M x (S | 1) */
 #define QDAS_CONV_X_ONE_SLICE  2   /* x is (C | 1) x M x 1 */
 #define QDAS_CONV_Y_ONE_COLUMN 4
 #define QDAS_CONV_Y_ONE_SLICE  8
 typedef struct qdas_convd_desc {
     uint64_t C, M, N, S;
-    int32_t  dtype;    /* QDAS_F64 | QDAS_F32                    */
+    int32_t  dtype;    /* QDAS_F64 | QDAS_F32 | QDAS_F16         */
     int32_t  cplx;     /* 0: real data, 1: interleaved complex   */
     int32_t  shape;    /* QDAS_CONV_*                            */
     int32_t  bcast;    /* QDAS_CONV_{X,Y}_ONE_{COLUMN,SLICE}     */

@@ -21,7 +21,7 @@ KERNEL_AUTO, KERNEL_GENERIC, KERNEL_TILED = 0, 1, 2
 KERNEL_NAMES = {KERNEL_GENERIC: "generic", KERNEL_TILED: "tiled"}
 MAX_APOD = 6
 QDAS_PRE_F32, QDAS_PRE_I16 = 0, 1
-QDAS_CONV_FULL, QDAS_CONV_SAME, QDAS_CONV_VALID = 0, 1, 2
+QDAS_CONV_FULL, QDAS_CONV_SAME, QDAS_CONV_VALID, QDAS_CONV_CAUSAL = 0, 1, 2, 3
 QDAS_CONV_X_ONE_COLUMN, QDAS_CONV_X_ONE_SLICE, QDAS_CONV_Y_ONE_COLUMN, QDAS_CONV_Y_ONE_SLICE = 1, 2, 4, 8
 PLAN_NO_RECIPROCAL, PLAN_JIT, PLAN_COPY_INPUTS, PLAN_NO_MIRROR, PLAN_MIRROR_SLAB = 1, 2, 4, 8, 16
 RXAPOD_NONE, RXAPOD_ACCEPTANCE, RXAPOD_COSINE, RXAPOD_FNUMBER_PLANAR, RXAPOD_FNUMBER_ORIENTED = 0, 1, 2, 3, 4

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 
-_SHAPES = {"full": _lib.QDAS_CONV_FULL, "same": _lib.QDAS_CONV_SAME, "valid": _lib.QDAS_CONV_VALID}
+_SHAPES = {"full": _lib.QDAS_CONV_FULL, "same": _lib.QDAS_CONV_SAME, "valid": _lib.QDAS_CONV_VALID, "causal": _lib.QDAS_CONV_CAUSAL}
 
 
 def conv_lags(M: int, N: int, shape: str):
@@ -25,6 +25,8 @@ def conv_lags(M: int, N: int, shape: str):
         return np.arange(0, M) - (N - 1) // 2
     if shape == "valid":
         return np.arange(0, M - N + 1)
+    if shape == "causal":                                    # extension: the first M outputs of 'full' (MATLAB filter(b, 1, x))
+        return np.arange(-(N - 1), M - (N - 1))
     raise ValueError("shape must be one of {'full', 'same', 'valid'}")
 
 
@@ -57,10 +59,15 @@ def convd(x, y=None, dim: int | None = None, shape: str = "full", device=None, r
     for t in (xt, yt):
         if not (t.is_floating_point() or t.is_complex()):
             raise TypeError("convd expects floating-point data")
-    # computation type (kern/convd.m:259-268): single if either operand is single, else double; complex if either is complex
-    single = any(t.dtype in (torch.float32, torch.complex64, torch.float16) for t in (xt, yt))
+    # computation type (kern/convd.m:259-268): half if either operand is half (convh / convch, src/convd.cu:141,153), else single if either is
+    # single, else double; complex if either is complex
+    half = any(t.dtype in (torch.float16, torch.complex32) for t in (xt, yt))
+    single = any(t.dtype in (torch.float32, torch.complex64) for t in (xt, yt))
     cplx = xt.is_complex() or yt.is_complex()
-    dt = {(True, True): torch.complex64, (True, False): torch.float32, (False, True): torch.complex128, (False, False): torch.float64}[(single, cplx)]
+    if half:
+        dt = torch.complex32 if cplx else torch.float16
+    else:
+        dt = {(True, True): torch.complex64, (True, False): torch.float32, (False, True): torch.complex128, (False, False): torch.float64}[(single, cplx)]
     sx, sy = list(xt.shape), list(yt.shape)
     other = [k for k in range(D) if k != d]
     if not all(sx[k] == sy[k] or sx[k] == 1 or sy[k] == 1 for k in other):
@@ -84,7 +91,11 @@ def convd(x, y=None, dim: int | None = None, shape: str = "full", device=None, r
             bits |= one_col
         if S > 1 and all(v == 1 for v in lead):
             bits |= one_slice
-        return t.to(device=dev, dtype=dt).contiguous()
+        t = t.to(dev)
+        if dt == torch.complex32 and t.dtype != torch.complex32:             # (torch has no direct cast to complex half)
+            t = torch.complex(t.real.to(torch.float32), t.imag.to(torch.float32)) if t.is_complex() else torch.complex(t.to(torch.float32), torch.zeros_like(t, dtype=torch.float32))
+            t = torch.view_as_complex(torch.view_as_real(t).to(torch.float16).contiguous())
+        return t.to(dtype=dt).contiguous()
 
     xd = prep(xt, sx, _lib.QDAS_CONV_X_ONE_COLUMN, _lib.QDAS_CONV_X_ONE_SLICE)
     yd = prep(yt, sy, _lib.QDAS_CONV_Y_ONE_COLUMN, _lib.QDAS_CONV_Y_ONE_SLICE)
@@ -93,7 +104,7 @@ def convd(x, y=None, dim: int | None = None, shape: str = "full", device=None, r
     osz = list(full); osz[d] = L
     z = torch.empty(osz, dtype=dt, device=dev)
     if z.numel():
-        desc = _lib.ConvdDesc(Cc, M, N, S, _lib.QDAS_F32 if single else _lib.QDAS_F64, int(cplx), _SHAPES[shape], bits,
+        desc = _lib.ConvdDesc(Cc, M, N, S, _lib.QDAS_F16 if half else (_lib.QDAS_F32 if single else _lib.QDAS_F64), int(cplx), _SHAPES[shape], bits,
                               dev.index if dev.index is not None else torch.cuda.current_device(), 0)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().qdas_convd(C.byref(desc), C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), C.c_void_p(z.data_ptr()),

@@ -35,6 +35,22 @@ template <> struct cv_zero<double>  { static __device__ __forceinline__ double  
 template <> struct cv_zero<float2>  { static __device__ __forceinline__ float2  v() { return make_float2(0.f, 0.f); } };
 template <> struct cv_zero<double2> { static __device__ __forceinline__ double2 v() { return make_double2(0.0, 0.0); } };
 
+// storage type S -> compute type T and back: half-precision data (the reference's convh / convch, src/convd.cu:141,153) is multiplied and
+// accumulated in fp32 and rounded once at the store (the reference accumulates in half)
+template <typename T, typename S> struct cv_io {
+    static __device__ __forceinline__ T ld(const S *p, uint64_t i) { return p[i]; }
+    static __device__ __forceinline__ void st(S *p, uint64_t i, T v) { p[i] = v; }
+};
+template <> struct cv_io<float, _Float16> {
+    static __device__ __forceinline__ float ld(const _Float16 *p, uint64_t i) { return (float)p[i]; }
+    static __device__ __forceinline__ void st(_Float16 *p, uint64_t i, float v) { p[i] = (_Float16)v; }
+};
+struct cv_half2 { _Float16 x, y; };
+template <> struct cv_io<float2, cv_half2> {
+    static __device__ __forceinline__ float2 ld(const cv_half2 *p, uint64_t i) { const cv_half2 h = p[i]; return make_float2((float)h.x, (float)h.y); }
+    static __device__ __forceinline__ void st(cv_half2 *p, uint64_t i, float2 v) { p[i] = cv_half2{(_Float16)v.x, (_Float16)v.y}; }
+};
+
 __device__ __forceinline__ void cv_mac(float &a, float x, float y)    { a = fmaf(x, y, a); }
 __device__ __forceinline__ void cv_mac(double &a, double x, double y) { a = fma(x, y, a); }
 __device__ __forceinline__ void cv_mac(float2 &a, float2 x, float2 y) {
@@ -56,13 +72,14 @@ template <typename T> struct cv_row {      // padded row length: row stride = 8 
     static constexpr int LEN = Q + ((8 - Q % MOD) % MOD + MOD) % MOD;
 };
 
-template <typename T>
+template <typename T, typename S>
 __global__ void __launch_bounds__(128) conv_time_kernel(const ConvParams P) {
     constexpr int QP = cv_row<T>::LEN;
+    using IO = cv_io<T, S>;
     __shared__ T X[8][QP];                       // X[w][k] = span element 8k + w
-    const T *__restrict__ x = (const T *)P.x + (uint64_t)blockIdx.x * P.xss;     // slices along grid.x (may exceed 65535)
-    const T *__restrict__ y = (const T *)P.y + (uint64_t)blockIdx.x * P.yss;
-    T *__restrict__ z = (T *)P.z + (uint64_t)blockIdx.x * P.L;
+    const S *__restrict__ x = (const S *)P.x + (uint64_t)blockIdx.x * P.xss;     // slices along grid.x (may exceed 65535)
+    const S *__restrict__ y = (const S *)P.y + (uint64_t)blockIdx.x * P.yss;
+    S *__restrict__ z = (S *)P.z + (uint64_t)blockIdx.x * P.L;
     const int t = threadIdx.x;
     const int64_t M = (int64_t)P.M, N = (int64_t)P.N, L = (int64_t)P.L;
     const int64_t lfb = (int64_t)blockIdx.y * CV_TL + P.off;          // full-convolution index of this tile's first output
@@ -84,7 +101,7 @@ __global__ void __launch_bounds__(128) conv_time_kernel(const ConvParams P) {
             for (int q = 0; q < NLD; ++q) {
                 const int e = e0 + 128 * q;
                 const int64_t i = o + e;
-                v[q] = (e < CV_TL + CV_KC && i >= 0 && i < M) ? x[i] : cv_zero<T>::v();
+                v[q] = (e < CV_TL + CV_KC && i >= 0 && i < M) ? IO::ld(x, (uint64_t)i) : cv_zero<T>::v();
             }
             __syncthreads();
 #pragma unroll
@@ -106,7 +123,7 @@ __global__ void __launch_bounds__(128) conv_time_kernel(const ConvParams P) {
             const int64_t jb = j0 + 8 * g;                            // uniform: scalar loads
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const T tap = (jb + u < N) ? y[jb + u] : cv_zero<T>::v();
+                const T tap = (jb + u < N) ? IO::ld(y, (uint64_t)(jb + u)) : cv_zero<T>::v();
 #pragma unroll
                 for (int r = 0; r < 8; ++r) cv_mac(acc[r], win[8 + r - u], tap);
             }
@@ -123,28 +140,29 @@ __global__ void __launch_bounds__(128) conv_time_kernel(const ConvParams P) {
 #pragma unroll
     for (int q = 0; q < CV_TL / 128; ++q) {
         const int e = t + 128 * q;
-        if (l0 + e < L) z[l0 + e] = X[e & 7][e >> 3];
+        if (l0 + e < L) IO::st(z, (uint64_t)(l0 + e), X[e & 7][e >> 3]);
     }
 }
 
 // ---- strided time: x (C x M x S), y (C x N x S), z (C x L x S); lanes along c, 8 consecutive outputs per lane, the same
 // 16-sample register window fed straight from global memory (a wave's loads are coalesced along c).  YB: y has one column
 // (a filter shared by all traces): its taps are uniform and come through the scalar cache.
-template <typename T, bool YB>
+template <typename T, typename S, bool YB>
 __global__ void __launch_bounds__(256) conv_col_kernel(const ConvParams P) {
+    using IO = cv_io<T, S>;
     const uint32_t ncb = (uint32_t)((P.C + 63) / 64);
     const uint64_t sl = blockIdx.x / ncb;                                // slice; column block = blockIdx.x % ncb
     const uint64_t c = (uint64_t)(blockIdx.x % ncb) * 64 + threadIdx.x;
     const int64_t l = ((int64_t)blockIdx.y * 4 + threadIdx.y) * 8;
     const int64_t M = (int64_t)P.M, N = (int64_t)P.N, L = (int64_t)P.L;
     if (c >= P.C || l >= L) return;
-    const T *__restrict__ x = (const T *)P.x + sl * P.xss + c * P.xcs;
-    const T *__restrict__ y = (const T *)P.y + sl * P.yss + (YB ? 0 : c * P.ycs);
-    T *__restrict__ z = (T *)P.z + (sl * P.L) * P.C + c;
+    const S *__restrict__ x = (const S *)P.x + sl * P.xss + c * P.xcs;
+    const S *__restrict__ y = (const S *)P.y + sl * P.yss + (YB ? 0 : c * P.ycs);
+    S *__restrict__ z = (S *)P.z + (sl * P.L) * P.C + c;
     const int64_t lf = l + P.off;
     int64_t jlo = lf - (M - 1); if (jlo < 0) jlo = 0;
     int64_t jhi = lf + 8; if (jhi > N) jhi = N;
-    auto ldx = [&](int64_t i) -> T { return (i >= 0 && i < M) ? x[(uint64_t)i * P.xts] : cv_zero<T>::v(); };
+    auto ldx = [&](int64_t i) -> T { return (i >= 0 && i < M) ? IO::ld(x, (uint64_t)i * P.xts) : cv_zero<T>::v(); };
     T acc[8], win[16];
 #pragma unroll
     for (int r = 0; r < 8; ++r) acc[r] = cv_zero<T>::v();
@@ -156,7 +174,7 @@ __global__ void __launch_bounds__(256) conv_col_kernel(const ConvParams P) {
         for (int w = 0; w < 8; ++w) win[w] = ldx(lf - j - 8 + w);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const T tap = (j + u < N) ? y[(uint64_t)(j + u) * (YB ? 1 : P.yts)] : cv_zero<T>::v();
+            const T tap = (j + u < N) ? IO::ld(y, (uint64_t)(j + u) * (YB ? 1 : P.yts)) : cv_zero<T>::v();
 #pragma unroll
             for (int r = 0; r < 8; ++r) cv_mac(acc[r], win[8 + r - u], tap);
         }
@@ -165,23 +183,24 @@ __global__ void __launch_bounds__(256) conv_col_kernel(const ConvParams P) {
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r)
-        if (l + r < L) z[(uint64_t)(l + r) * P.C] = acc[r];
+        if (l + r < L) IO::st(z, (uint64_t)(l + r) * P.C, acc[r]);
 }
 
-template <typename T>
+template <typename T, typename S = T>
 static hipError_t launch_conv_t(const ConvParams &P, hipStream_t s) {
     if (P.C == 1) {
         dim3 grid((unsigned)P.S, (unsigned)((P.L + CV_TL - 1) / CV_TL));
-        hipLaunchKernelGGL(conv_time_kernel<T>, grid, dim3(128), 0, s, P);
+        hipLaunchKernelGGL((conv_time_kernel<T, S>), grid, dim3(128), 0, s, P);
     } else {
         dim3 grid((unsigned)(((P.C + 63) / 64) * P.S), (unsigned)((P.L + 31) / 32));
-        if (P.ycs == 0 && P.yts == 1) hipLaunchKernelGGL((conv_col_kernel<T, true>), grid, dim3(64, 4), 0, s, P);
-        else hipLaunchKernelGGL((conv_col_kernel<T, false>), grid, dim3(64, 4), 0, s, P);
+        if (P.ycs == 0 && P.yts == 1) hipLaunchKernelGGL((conv_col_kernel<T, S, true>), grid, dim3(64, 4), 0, s, P);
+        else hipLaunchKernelGGL((conv_col_kernel<T, S, false>), grid, dim3(64, 4), 0, s, P);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_conv(const ConvParams &P, int dtype, int cplx, hipStream_t s) {
+    if (dtype == QDAS_F16) return cplx ? launch_conv_t<float2, cv_half2>(P, s) : launch_conv_t<float, _Float16>(P, s);
     if (dtype == QDAS_F32) return cplx ? launch_conv_t<float2>(P, s) : launch_conv_t<float>(P, s);
     return cplx ? launch_conv_t<double2>(P, s) : launch_conv_t<double>(P, s);
 }

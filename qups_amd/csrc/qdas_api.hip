@@ -1454,14 +1454,15 @@ extern "C" uint64_t qdas_convd_len(uint64_t M, uint64_t N, int shape) {
         case QDAS_CONV_FULL:  return M + N - 1;
         case QDAS_CONV_SAME:  return M;
         case QDAS_CONV_VALID: return M >= N ? M - N + 1 : 0;
+        case QDAS_CONV_CAUSAL: return M;
         default: return 0;
     }
 }
 
 extern "C" int qdas_convd(const qdas_convd_desc *d, const void *x, const void *y, void *z, void *stream) {
     if (!d) return fail(QDAS_EINVAL, "null argument");
-    if (d->dtype != QDAS_F64 && d->dtype != QDAS_F32) return fail(QDAS_EINVAL, "convd: datatype must be double or single");
-    if (d->shape != QDAS_CONV_FULL && d->shape != QDAS_CONV_SAME && d->shape != QDAS_CONV_VALID)
+    if (d->dtype != QDAS_F64 && d->dtype != QDAS_F32 && d->dtype != QDAS_F16) return fail(QDAS_EINVAL, "convd: datatype must be double, single or half");
+    if (d->shape != QDAS_CONV_FULL && d->shape != QDAS_CONV_SAME && d->shape != QDAS_CONV_VALID && d->shape != QDAS_CONV_CAUSAL)
         return fail(QDAS_EINVAL, "convd: shape must be one of {'full', 'same', 'valid'}");
     if (d->bcast & ~15) return fail(QDAS_EINVAL, "convd: unknown broadcast bits");
     if (d->M >= (1ull << 31) || d->N >= (1ull << 31)) return fail(QDAS_EUNSUPPORTED, "convd: at most 2^31 - 1 samples along the convolved dimension");
@@ -1476,7 +1477,7 @@ extern "C" int qdas_convd(const qdas_convd_desc *d, const void *x, const void *y
     ConvParams p{};
     p.x = x; p.y = y; p.z = z;
     p.C = d->C; p.M = d->M; p.N = d->N; p.L = L; p.S = d->S;
-    p.off = d->shape == QDAS_CONV_FULL ? 0 : d->shape == QDAS_CONV_VALID ? (int64_t)d->N - 1 : (int64_t)(d->N - 1 - (d->N - 1) / 2);
+    p.off = (d->shape == QDAS_CONV_FULL || d->shape == QDAS_CONV_CAUSAL) ? 0 : d->shape == QDAS_CONV_VALID ? (int64_t)d->N - 1 : (int64_t)(d->N - 1 - (d->N - 1) / 2);
     const uint64_t Cx = (d->bcast & QDAS_CONV_X_ONE_COLUMN) ? 1 : d->C, Cy = (d->bcast & QDAS_CONV_Y_ONE_COLUMN) ? 1 : d->C;
     p.xcs = Cx == 1 && d->C > 1 ? 0 : 1; p.xts = Cx; p.xss = (d->bcast & QDAS_CONV_X_ONE_SLICE) ? 0 : Cx * d->M;
     p.ycs = Cy == 1 && d->C > 1 ? 0 : 1; p.yts = Cy; p.yss = (d->bcast & QDAS_CONV_Y_ONE_SLICE) ? 0 : Cy * d->N;

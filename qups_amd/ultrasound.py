@@ -148,6 +148,38 @@ class ChannelData:
         return ChannelData(torch.cat([z(B), d, z(A)], ax), np.asarray(self.t0, float) - B / self.fs if np.ndim(self.t0) else float(self.t0) - B / self.fs,
                            self.fs, self.order)
 
+    def filter(self, b, dim=None):
+        """FIR-filter the data along time with coefficients ``b`` -- what ``filter(chd, D)`` does with an FIR ``digitalFilter`` ``D``
+        (reference ``src/ChannelData.m:857-888``: ``filter(D, x)`` along the time dimension, then ``t0 -= (filtord(D) / 2) / fs``): the causal
+        convolution ``y[t] = sum_k b[k] x[t - k]`` on the device (``qdas_convd`` with the ``'causal'`` window).  IIR filters are not provided."""
+        from .convd import convd
+        import torch
+        ax = self.order.index("T") if dim is None else int(dim) - 1
+        d = self._torch_data()
+        bt = b if hasattr(b, "is_cuda") else torch.from_numpy(np.asarray(b))
+        bt = bt.reshape(-1)
+        if not (bt.is_floating_point() or bt.is_complex()):
+            bt = bt.to(torch.float64)
+        if d.dtype in (torch.float32, torch.complex64, torch.float16, torch.complex32) and bt.dtype in (torch.float64, torch.complex128):
+            bt = bt.to(torch.complex64 if bt.is_complex() else torch.float32)      # (coefficients follow the data's precision, as MATLAB's filter does for single data)
+        y = convd(d, bt.reshape((1,) * ax + (-1,) + (1,) * (d.ndim - ax - 1)), ax + 1, "causal")
+        t0 = self.t0
+        if ax == self.order.index("T"):
+            L = (bt.numel() - 1) / 2.0                           # filtord / 2
+            t0 = np.asarray(t0, float) - L / self.fs if np.ndim(t0) else float(t0) - L / self.fs
+        return ChannelData(y, t0, self.fs, self.order)
+
+    def downsample(self, ratio: int):
+        """every ``ratio``-th sample along time (reference ``src/ChannelData.m:1042-1058``: ``subD(chd, 1:ratio:chd.T, chd.tdim)``); ``fs`` follows"""
+        ratio = int(ratio)
+        if ratio < 1:
+            raise DasError("ratio must be a positive integer")
+        d = self._torch_data()
+        ax = self.order.index("T")
+        idx = [slice(None)] * d.ndim
+        idx[ax] = slice(0, None, ratio)
+        return ChannelData(d[tuple(idx)].contiguous(), self.t0, self.fs / ratio, self.order)
+
     def sample(self, tau, interp="linear", w=1, sdim=None, fmod=0.0, **kw):
         """``y = sample(chd, tau, interp, w, sdim, fmod)`` (reference ``src/ChannelData.m:1230-1336``): ``tau`` holds TIMES and
         broadcasts against ``T x N x M x F...`` in every dimension but the first; sample indices ``(tau - t0) * fs`` (``:1317``),

@@ -177,3 +177,57 @@ def test_convd_random_configuration(seed):
     assert z.is_complex() == (cx or cy) and (z.dtype in (torch.float64, torch.complex128)) == dbl
     assert np.array_equal(lg, lags)
     assert rel(z.cpu().numpy(), ref) <= (1e-12 if dbl else 3e-5), (seed, sx, sy, d, shape, cx, cy, dbl)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("sz_x,sz_y,dim", [((1500, 3, 2), (37, 1, 1), 1), ((2, 3, 1100), (1, 1, 300), 3), ((5, 260, 70), (5, 9, 1), 2), ((2049,), (65,), 1)])
+def test_convd_half_precision(sz_x, sz_y, dim, cplx):
+    """the half-precision twins convh / convch (reference src/convd.cu:141,153; dispatch kern/convd.m:263-265): half in, half out, products
+    and sums in fp32 -- against the float64 oracle on the half-rounded inputs, to an output ulp"""
+    import torch
+    from qups_amd import convd
+    rng = np.random.default_rng(11)
+    h16 = lambda a: a.astype(np.float16)
+    xr, xi, yr, yi = (h16(rng.standard_normal(s) * 0.25) for s in (sz_x, sz_x, sz_y, sz_y))
+    if cplx:
+        x64, y64 = xr.astype(np.float64) + 1j * xi, yr.astype(np.float64) + 1j * yi
+        to_t = lambda re, im: torch.view_as_complex(torch.from_numpy(np.stack([re, im], -1)).contiguous())
+        xt, yt = to_t(xr, xi), to_t(yr, yi)
+    else:
+        x64, y64 = xr.astype(np.float64), yr.astype(np.float64)
+        xt, yt = torch.from_numpy(xr), torch.from_numpy(yr)
+    for shape in ("full", "same", "valid"):
+        ref, lags = O.convd(x64, y64, dim, shape)
+        z, lg = convd(xt, yt, dim, shape, return_lags=True)
+        assert z.dtype == (torch.complex32 if cplx else torch.float16) and np.array_equal(lg, lags)
+        zn = torch.view_as_real(z).float().cpu().numpy().view(np.complex64)[..., 0] if cplx else z.float().cpu().numpy()
+        assert zn.shape == ref.shape
+        assert np.abs(zn - ref).max() <= 1.5e-3 * np.abs(ref).max(), shape
+
+
+@pytest.mark.gpu
+def test_channeldata_filter_and_downsample():
+    """ChannelData.filter with an FIR filter (reference src/ChannelData.m:857-888: filter(D, x) along time, t0 -= (order / 2) / fs) and
+    ChannelData.downsample (:1042-1058): against scipy.signal.lfilter per trace; every time-dimension position, real and complex data"""
+    import torch
+    from scipy.signal import firwin, lfilter
+    from qups_amd.ultrasound import ChannelData
+    rng = np.random.default_rng(5)
+    T, N, M, fs = 900, 6, 4, 20e6
+    x = (rng.standard_normal((T, N, M)) + 1j * rng.standard_normal((T, N, M))).astype(np.complex64)
+    b = firwin(26, 0.3)                                        # designfilt('lowpassfir', 'FilterOrder', 25, ...): 26 coefficients
+    chd = ChannelData(torch.from_numpy(x).cuda(), -1e-6, fs)
+    out = chd.filter(b)
+    ref = lfilter(b, 1.0, x.astype(np.complex128), axis=0)
+    assert tuple(out.data.shape) == x.shape and rel(out.data.cpu().numpy(), ref) <= 2e-5
+    assert abs(out.t0 - (-1e-6 - 12.5 / fs)) < 1e-15 and out.fs == fs
+    t0v = np.linspace(0, 1e-6, M).reshape(1, 1, M)             # per-transmit start times move along
+    out2 = ChannelData(torch.from_numpy(x.real.copy()).cuda(), t0v, fs).filter(b)
+    assert rel(out2.data.cpu().numpy(), ref.real) <= 2e-5 and np.allclose(out2.t0, t0v - 12.5 / fs)
+    perm = ChannelData(torch.from_numpy(np.ascontiguousarray(x.transpose(1, 2, 0))).cuda(), 0.0, fs, "NMT").filter(b)       # time last: the LDS kernel
+    assert rel(perm.data.cpu().numpy().transpose(2, 0, 1), ref) <= 2e-5
+    ds = out.downsample(4)
+    assert ds.fs == fs / 4 and ds.t0 == out.t0 and torch.equal(ds.data, out.data[::4]) and ds.data.is_contiguous()
+    with pytest.raises(ValueError):
+        out.downsample(0)
