@@ -208,6 +208,11 @@ class ChannelData:
         return ChannelData(chd.sample(tau, interp), t0_, chd.fs, "TNM")
 
 
+def _cat_tx(parts):
+    import torch
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=4)
+
+
 class UltrasoundSystem:
     def __init__(self, xdc: Transducer, seq: Sequence, scan: Scan, fs=None, rx: Transducer | None = None):
         self.tx, self.rx, self.seq, self.scan, self.fs = xdc, rx or xdc, seq, scan, fs
@@ -363,19 +368,23 @@ class UltrasoundSystem:
         return dr / c, dv / c
 
     def bfDAS(self, chd: ChannelData, *apods, c0=None, apod=1, fmod=0.0, interp="cubic", keep_tx=False, keep_rx=False,
-              prec=None):
+              prec=None, bsize=None):
         """``b = bfDAS(us, chd, ...)`` (reference ``src/UltrasoundSystem.m:4334-4474``): delay tables + ``bfDASLUT``."""
         import torch
         dev = (chd.data.device if hasattr(chd.data, "is_cuda") and chd.data.is_cuda else "cuda") if torch.cuda.is_available() else None
         tau_rx, tau_tx = self.delay_tables(c0, device=dev)
-        return self.bfDASLUT(chd, tau_rx, tau_tx, *apods, apod=apod, fmod=fmod, interp=interp, keep_tx=keep_tx, keep_rx=keep_rx, prec=prec)
+        return self.bfDASLUT(chd, tau_rx, tau_tx, *apods, apod=apod, fmod=fmod, interp=interp, keep_tx=keep_tx, keep_rx=keep_rx, prec=prec, bsize=bsize)
 
     def bfDASLUT(self, chd: ChannelData, tau_rx, tau_tx, *apods, apod=1, fmod=0.0, interp="cubic", keep_tx=False,
-                 keep_rx=False, prec=None):
+                 keep_rx=False, prec=None, bsize=None):
         """``b = bfDASLUT(us, chd, tau_rx, tau_tx, ...)`` (reference ``src/UltrasoundSystem.m:4476-4673``):
         ``tau_rx`` is ``I1 x I2 x I3 x N``, ``tau_tx`` is ``I1 x I2 x I3 x M`` (times).  Output
         ``I1 x I2 x I3 x F... x [N] x [M]``: the aperture dimensions are moved behind the frame dimensions exactly as the
-        reference does (``:4663-4664``) -- the same layout as ``DAS`` (``:3361``)."""
+        reference does (``:4663-4664``) -- the same layout as ``DAS`` (``:3361``).
+
+        ``bsize``: transmits per block (reference ``:4573``: default from a 1 GB bound on the multiplied-out weights; ``:4641-4655``: the
+        transmits are spliced, the apodization arrays with a transmit dimension are indexed per block, blocks are summed -- or, with
+        ``keep_tx``, concatenated).  The multiplied-out ``I x N x M`` weight array never exists for more than one block."""
         if chd.order[:3] != "TNM":
             chd = chd.rectifyDims()
         Isz = self.scan.size
@@ -387,14 +396,34 @@ class UltrasoundSystem:
         if tuple(tt.shape) != Isz + (M,):
             raise DasError(f"Expected a transmit delay table of size {Isz + (M,)}, got {tuple(tt.shape)}.",
                            "QUPS:UltrasoundSystem:bfDASLUT:incompatibleTransmitDelayTable")
-        ws = list(apods) + ([] if (np.isscalar(apod) and apod == 1) else [apod])
-        w = None
-        for a in ws:                                       # separable apodizations multiply (reference :4644)
-            a = np.asarray(a)
-            a = a.reshape(a.shape + (1,) * (5 - a.ndim))
-            w = a if w is None else w * a
+        ws = [np.asarray(a) for a in list(apods) + ([] if (np.isscalar(apod) and apod == 1) else [apod])]
+        ws = [a.reshape(a.shape + (1,) * (5 - a.ndim)) for a in ws]
+        if bsize is None:                                  # the reference's heuristic (:4573): blocks whose multiplied-out weights stay below 1 GB (8-byte entries)
+            full = np.max([a.shape for a in ws], axis=0) if ws else np.ones(5, int)
+            gb = 2.0 ** -30 * 8 * float(np.prod(full))
+            bsize = max(1, min(M, int(np.floor(M / gb)) if gb > 0 else M))
+        bsize = int(bsize)
+        if bsize < 1:
+            raise DasError("bsize must be a positive integer")
         sdim = set() if keep_rx else {"rx"}
         sdim |= set() if keep_tx else {"tx"}
-        b = sample2sep(chd.data, chd.t0, chd.fs, tr, tt, interp=interp, w=w, sdim=sdim, fmod=fmod,
-                       **({"prec": prec} if prec else {}))           # I1 x I2 x I3 x [N] x [M] x F...
+        kw = {"prec": prec} if prec else {}
+        w0 = None                                          # arrays without a transmit dimension: multiplied once (:4644)
+        for a in ws:
+            if a.shape[4] == 1:
+                w0 = a if w0 is None else w0 * a
+        t0a = np.asarray(chd.t0, dtype=np.float64).reshape(-1)
+        parts, total = [], None
+        for m0 in range(0, M, bsize):
+            sl = slice(m0, min(M, m0 + bsize))
+            w = w0
+            for a in ws:                                   # per-block factors (:4647-4650)
+                if a.shape[4] != 1:
+                    w = a[..., sl] if w is None else w * a[..., sl]
+            bm = sample2sep(chd.data[:, :, sl], t0a if t0a.size == 1 else t0a[sl], chd.fs, tr, tt[..., sl], interp=interp, w=w, sdim=sdim, fmod=fmod, **kw)
+            if keep_tx:
+                parts.append(bm)
+            else:
+                total = bm if total is None else total + bm
+        b = _cat_tx(parts) if keep_tx else total          # I1 x I2 x I3 x [N] x [M] x F...
         return b.permute(0, 1, 2, *range(5, b.ndim), 3, 4)           # move the aperture dimensions to the end (:4663-4664)

@@ -383,6 +383,36 @@ def test_us_bfDAS_frames_layout_matches_DAS_and_oracle(keep):
     assert rel_err(_np(b_lut), ref) <= 5e-4                                   # fp32 delay tables
 
 
+@pytest.mark.parametrize("keep_tx", [False, True])
+def test_bfDASLUT_transmit_blocks(keep_tx):
+    """bfDASLUT's transmit blocking (reference src/UltrasoundSystem.m:4573,4641-4655: `bsize`, 1 GB heuristic): the transmits are beamformed
+    block by block, weights with a transmit dimension are indexed per block, blocks are summed or -- keep_tx -- concatenated; the result does
+    not depend on the block size, per-transmit start times included"""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import ChannelData, Scan, Sequence, Transducer, UltrasoundSystem
+    case = make_case(seq="PW", interp="linear", seed=29, N=6, M=7, I1=30, I2=5)
+    N, M = 6, 7
+    xdc = Transducer(case["Pr"], np.stack([0 * case["Pr"][0], 0 * case["Pr"][0], 1 + 0 * case["Pr"][0]]))
+    us = UltrasoundSystem(xdc, Sequence("PW", focus=case["Nv"], c0=case["c"]), Scan(case["Pi"]))
+    t0 = (case["t0"] + np.arange(M) / case["fs"]).reshape(1, 1, M)
+    chd = ChannelData(torch.from_numpy(case["x"]), t0, case["fs"])
+    rng = np.random.default_rng(3)
+    a_nm = rng.uniform(0.2, 1.0, (1, 1, 1, N, M)).astype(np.float32)            # receiver x transmit
+    a_pm = rng.uniform(0.2, 1.0, (30, 5, 1, 1, M)).astype(np.float32)           # pixel x transmit
+    a_n = rng.uniform(0.2, 1.0, (1, 1, 1, N)).astype(np.float32)
+    outs = [us.bfDAS(chd, a_nm, a_pm, a_n, interp="linear", keep_tx=keep_tx, bsize=bs) for bs in (None, 1, 3, M)]
+    fun = "MUL" if keep_tx else "DAS"
+    ref = O.das_spec(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], t0, case["fs"], cinv_f32(case["c"]),
+                     VS=case["VS"], DV=case["DV"], interp="linear", apod=[a_nm.astype(np.float64), a_pm.astype(np.float64), a_n.reshape(1, 1, 1, N, 1).astype(np.float64)])
+    for b in outs:
+        assert tuple(b.shape) == (30, 5, 1, 1, M if keep_tx else 1)
+        assert rel_err(_np(b).reshape(ref.shape), ref) <= 5e-4               # fp32 delay tables
+        assert rel_err(_np(b), _np(outs[0])) <= 5e-5               # (other kernels / other products of the weight factors per block size)
+    with pytest.raises(ValueError):
+        us.bfDAS(chd, interp="linear", bsize=0)
+
+
 def test_all_32_apodization_shapes_through_DAS_and_bfDAS():
     """reference test/USTest.m:333-337 (bfordgeneric): every broadcastable apodization shape -- each of I1, I2, I3, N, M full or
     singleton -- through UltrasoundSystem.DAS and bfDAS.  The reference asserts the output size (:296); here also the values."""
