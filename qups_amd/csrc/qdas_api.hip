@@ -1369,6 +1369,12 @@ extern "C" int qdas_wsinterpd(const qdas_wsinterpd_desc *d, void *y, void *strea
         if (p.sum[k]) { p.n_sum *= d->size[k]; p.any_sum = 1; } else p.n_out *= d->size[k];
     }
     p.omega = d->omega; p.extrap = d->extrap; p.flag = d->flag; p.w_real = d->w_real;
+    for (int k = 0; k < d->ndim; ++k) {                  // the summed dimensions, compacted (size-1 dimensions do not advance anything)
+        if (!p.sum[k] || d->size[k] <= 1) continue;
+        if (d->size[k] > 0xffffffffull) return fail(QDAS_EUNSUPPORTED, "wsinterpd: a summed dimension of more than 2^32 - 1 elements");
+        p.ssz[p.nsd] = (uint32_t)d->size[k]; p.sts[p.nsd] = d->tstride[k]; p.sxs[p.nsd] = d->xstride[k]; p.sws[p.nsd] = d->wstride[k];
+        ++p.nsd;
+    }
     if (p.n_out == 0) return QDAS_OK;
     if (p.n_out >= (1ull << 39)) return fail(QDAS_EUNSUPPORTED, "wsinterpd: too many outputs for one launch");
     hipStream_t s = (hipStream_t)stream;

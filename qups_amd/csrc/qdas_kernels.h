@@ -62,6 +62,11 @@ struct WsParams {
     int64_t tst[8], xst[8], wst[8];  // element strides of t / x (trace base) / w per dimension; 0 = broadcast
     uint8_t sum[8];                  // 1: the dimension is summed
     uint64_t n_out, n_sum;           // product of the kept / summed sizes
+    // the summed dimensions alone, compacted (fastest first): the kernel walks them like an odometer -- uniform scalar adds per term
+    // instead of a 64-bit divide + modulo per dimension and term
+    int32_t nsd;
+    uint32_t ssz[8];
+    int64_t sts[8], sxs[8], sws[8];
     double omega, extrap;
     int32_t flag, w_real, any_sum;
 };

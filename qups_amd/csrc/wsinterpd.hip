@@ -66,14 +66,23 @@ __global__ void __launch_bounds__(256) wsinterpd_kernel(const WsParams P) {
     const R omega = (R)P.omega;
     const bool skip_nan = P.any_sum && !(P.extrap == P.extrap);      // sums omit NaN (kern/wsinterpd.m:262)
     cplx<R> acc = {(R)0, (R)0};
+    // the summed dimensions: an odometer over the compacted list (WsParams::ssz / sts / sxs / sws).  Counters and running offsets are UNIFORM
+    // (every lane sums the same terms of its own output): scalar adds and compares, one carry chain per term -- the reference, and round 2
+    // here, decode every term's index with a 64-bit divide and modulo per dimension (src/interpd.cu:316-331)
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t ut = 0, ux = 0, uw = 0;
     for (uint64_t r = 0; r < P.n_sum; ++r) {
-        int64_t to = tb, xo = xb, wo = wb;
-        uint64_t q = r;
-        for (int d = 0; d < P.nd; ++d) {
-            if (!P.sum[d]) continue;
-            const uint64_t k = q % P.size[d];
-            q /= P.size[d];
-            to += (int64_t)k * P.tst[d]; xo += (int64_t)k * P.xst[d]; wo += (int64_t)k * P.wst[d];
+        const int64_t to = tb + ut, xo = xb + ux, wo = wb + uw;
+        {
+            bool carry = true;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                if (d < P.nsd && carry) {
+                    ut += P.sts[d]; ux += P.sxs[d]; uw += P.sws[d];
+                    if (++cnt[d] == P.ssz[d]) { cnt[d] = 0; ut -= (int64_t)P.ssz[d] * P.sts[d]; ux -= (int64_t)P.ssz[d] * P.sxs[d]; uw -= (int64_t)P.ssz[d] * P.sws[d]; }
+                    else carry = false;
+                }
+            }
         }
         const R tau = t[to];
         if (!(fabs((double)tau) <= 1.0e300) && tau == tau) continue;              // +-inf: excluded (src/interpd.cu:333)

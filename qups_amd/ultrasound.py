@@ -298,8 +298,7 @@ class UltrasoundSystem:
         """``chd = focusTx(us, chd, seq)`` (reference ``src/UltrasoundSystem.m:3374-3503``): synthesise the transmits of ``seq`` from
         full-synthetic-aperture data by delaying and summing over the transmit elements,
         ``z[t', n, m'] = sum_m apd[m, m'] * x(time[t'] - tau[m, m'], n, m)`` with ``tau = -seq.delays(tx)`` shifted so that all delays
-        are non-negative (``:3457-3470``).  One split-delay launch per synthesised transmit (``sample2sep`` at ``:3498``): the
-        "pixels" are the output time samples, the receive delay is the sample index, the transmit delay ``-tau*fs``."""
+        are non-negative (``:3457-3470``; the reference samples with ``sample2sep`` at ``:3498``)."""
         import torch
         from .interpd import das_lut
         seq = seq or self.seq
@@ -317,12 +316,14 @@ class UltrasoundSystem:
         d = chd._torch_data()
         T2, N, M = d.shape[:3]
         dev = d.device if d.is_cuda else torch.device("cuda")
-        trx = torch.arange(T2, dtype=torch.float64, device=dev).reshape(T2, 1).expand(T2, N)
-        out = []
-        for mp in range(tau.shape[1]):
-            ttx = torch.from_numpy(-tau[:, mp] * chd.fs).to(dev).reshape(1, M).expand(T2, M)
-            out.append(das_lut(d, trx, ttx, interp=interp, w=apd[:, mp].reshape(1, 1, M), keep_rx=True, keep_tx=False))   # T' x N x 1 x F...
-        z = torch.cat(out, 2)
+        # ONE launch of the general single-delay kernel over the index space (t', n, m, m', frames...): the sample index depends on
+        # (t', m, m'), the data on (n, m, frames), the weight on (m, m'); the transmit elements m are summed (round 2: one split-delay
+        # launch per synthesised transmit, each with its own layout copy of the record)
+        Mp = tau.shape[1]
+        ntau = torch.arange(T2, dtype=torch.float64, device=dev).reshape(T2, 1, 1, 1) - torch.from_numpy(tau * chd.fs).to(dev).reshape(1, 1, M, Mp)
+        xd = d.to(dev).reshape((T2, N, M, 1) + tuple(d.shape[3:]))
+        z = wsinterpd(xd, ntau, 1, apd.reshape(1, 1, M, Mp), [3], interp, 0.0)        # T' x N x 1 x M' x F...
+        z = z.reshape((T2, N, Mp) + tuple(d.shape[3:]))
         return ChannelData(z, t0, chd.fs, "TNM")
 
     # ------------------------------------------------------------------------------------
