@@ -397,6 +397,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
                         && desc->i_begin + pl->i_count <= pl->I / 2 && !(z.flag & (QDAS_FLAG_KEEP_RX | QDAS_FLAG_KEEP_TX)) && desc->kernel != QDAS_KERNEL_GENERIC;
         if (!ok) { delete pl; return fail(QDAS_EINVAL, "QDAS_PLAN_MIRROR_SLAB: the slab must be whole columns of the first half of an even number of columns (I3 == 1, 'DAS')"); }
         if (!desc->y_ld) pl->y_ld = 2 * pl->i_count;     // y holds slab A and its mirror image
+        else if (desc->y_ld < 2 * pl->i_count) { delete pl; return fail(QDAS_EINVAL, "QDAS_PLAN_MIRROR_SLAB: y_ld smaller than 2 * i_count (y holds slab A and its mirror image)"); }
     }
 
     auto bail = [&](int code) { delete pl; return code; };

@@ -422,7 +422,12 @@ def _cast_data(x, prec, device):
 
 class DasPlan:
     """Reusable beamforming plan: the ``[k, PRE_ARGS, POST_ARGS]`` handle of the reference
-    (``kern/das_spec.m:72-81,387-390``).  ``plan.feval(x)`` beamforms one ``T x N x M`` frame."""
+    (``kern/das_spec.m:72-81,387-390``).  ``plan.feval(x)`` beamforms one ``T x N x M`` frame.
+
+    A plan is NOT re-entrant: it owns scratch on the device (fallback-tile list, partial images of a split aperture), so frames go through
+    it one after the other on ONE stream at a time -- as through the reference's kernel object.  ``das_spec`` hands the same cached plan to
+    every call with an equal problem (``QDAS_PLAN_CACHE=0`` for a private plan per call); threads that beamform the same problem
+    concurrently on different streams should hold their own ``DasPlan``."""
 
     def __init__(self, prob: DasProblem, device=None, kernel: int = _lib.KERNEL_AUTO,
                  i_begin: int = 0, i_count: int = 0, reciprocal: bool = True, jit: bool = False, mirror: bool = True, mirror_slab: bool = False):

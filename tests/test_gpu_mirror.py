@@ -183,7 +183,7 @@ def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_pa
 
 @pytest.mark.parametrize("jit", [False, True], ids=["prebuilt", "jit"])
 @pytest.mark.parametrize("seq,interp,kind", [("PW", "cubic", "mask"), ("DV", "linear", "mask"), ("PW", "lanczos3", "mask+depth"), ("FSA", "cubic", "pixel-only"),
-                                             ("PW", "cubic", "acceptance"), ("DV", "linear", "fnumber"), ("PW", "nearest", "mask")])
+                                             ("PW", "cubic", "acceptance"), ("DV", "linear", "fnumber"), ("PW", "nearest", "mask"), ("DV", "cubic", "mask/split3")])
 def test_mirror_mode_with_pixel_by_receiver_weights(seq, interp, kind, jit, tmp_path, monkeypatch):
     """fp16 data with a pixel x receiver weight (BASELINE C5's shape) in lateral-mirror mode: the mirror image of a pixel carries its OWN
     weight, taken at the mirrored receiver -- the arrays here are random, NOT symmetric --; generated rules need mirror-symmetric element
@@ -194,6 +194,9 @@ def test_mirror_mode_with_pixel_by_receiver_weights(seq, interp, kind, jit, tmp_
     from qups_amd import apodization as A
     from qups_amd import geometry as G
     monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    if "/split" in kind:                                 # several workgroups per tile: each sums a receiver range AND its mirror image
+        monkeypatch.setenv("QDAS_KSPLIT", kind.split("/split")[1])
+        kind = kind.split("/")[0]
     N, I1, I2 = 24, 140, 30
     case = make_case(seq=seq, interp=interp, seed=91, N=N, M=20 if seq != "FSA" else None, I1=I1, I2=I2)
     x = case["x"]
