@@ -32,6 +32,8 @@ b c3_fp16 --prec halfT $Q --steps 10
 b c3_fmod --fmod 5e6 $Q --steps 10
 b c3_window --window-apod $Q --steps 10
 b c3_fnumber1.5 --rx-apod fnumber:1.5 --no-cpu --no-general --steps 10
+b c3_fp16_fnumber1.5 --prec halfT --rx-apod fnumber:1.5 $Q --steps 10
+QDAS_NO_MIRROR=1 b c5_no_mirror --workload c5 $Q --steps 50
 b c2_double --workload c2 --prec double $Q --steps 10
 b c2_window --workload c2 --window-apod $Q --steps 20
 b pw9 --workload pw9 $Q --steps 100
@@ -47,6 +49,9 @@ for w in c3 c2 c5; do
 done
 bash tools/profile.sh ${R}_c3_general --workload c3 --no-reciprocal > /dev/null 2>&1
 cp gpurun_out/prof_${R}_c3_general/summary.txt $OUT/rocprofv3_summary_c3_general.txt 2>/dev/null
+# ---- streams of frames, the general (non-fused) kernels
+python tools/frames_bench.py c2 12 > $OUT/frames_bench.txt 2>/dev/null; python tools/frames_bench.py c5 12 >> $OUT/frames_bench.txt 2>/dev/null; python tools/frames_bench.py c1 12 >> $OUT/frames_bench.txt 2>/dev/null
+python tools/general_time.py 2>/dev/null | grep -v Warn > $OUT/general_time.txt
 # ---- registers: prebuilt library, and the hiprtc builds of this run
 python tools/kernel_regs.py qups_amd/libqdas.so > $OUT/kernel_regs.txt 2>&1
 python tools/kernel_regs.py $QDAS_CACHE_DIR > $OUT/kernel_regs_hiprtc.txt 2>&1
