@@ -424,6 +424,13 @@ template <class C> __device__ __forceinline__ v2f Tile<C>::wconv(wraw r) const {
 template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
     n_lo = C::SYM ? 0u : (uint32_t)((uint64_t)N * split / S);
     n_hi = (uint32_t)((uint64_t)N * (split + 1) / S);
+    // a pixel x receiver weight and a split aperture: the workgroups of a tile take every S-th receiver instead of contiguous ranges -- the
+    // receivers that carry weight form a band (acceptance angle, f-number), which a contiguous split hands to ONE of the workgroups
+    const bool wanted = !C::F64 && !C::SYM && !C::BF && !(C::FBX && C::F32) && (QSPEC(HAS_APIX, P.apix != nullptr) || QSPEC(GEN_KIND, P.gen_kind) != 0);
+    const bool inter = C::ACT && wanted && S > 1 && !QSPEC(SYN, P.syn);
+    const uint32_t a_first = inter ? split : n_lo, a_step = inter ? S : 1u;
+    if (inter) { n_lo = 0; n_hi = N; }
+    const uint32_t a_cnt = inter ? (N > split ? (N - split + S - 1) / S : 0u) : n_hi - n_lo;
     acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
     dacc[0] = dacc[1] = dacc[2] = dacc[3] = 0.0;
 #pragma unroll
@@ -449,33 +456,37 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
             for (uint32_t k = tid; k < (N + 31) / 32; k += C::THREADS) flg[k] = 0u;
             __syncthreads();
             if (QSPEC(GEN_KIND, P.gen_kind) != 0) {   // generated weights: arithmetic only (ONE call site of the out-of-line rule)
-                for (uint32_t n = n_lo; n < n_hi; ++n) {
+                for (uint32_t k = 0; k < a_cnt; ++k) {
+                    const uint32_t n = a_first + a_step * k;
                     const v2f w = wload(n);
                     const bool any = __ballot(!(w.x == 0.f && w.y == 0.f)) != 0ull;
                     if (any && lane == 0) atomicOr(&flg[n >> 5], 1u << (n & 31u));
                 }
             } else {                                   // array weights: four loads in flight
-                for (uint32_t n0 = n_lo; n0 < n_hi; n0 += 4) {
+                for (uint32_t k0 = 0; k0 < a_cnt; k0 += 4) {
                     wraw r4[4];
+                    uint32_t n4[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) r4[q] = wload_raw(n0 + q < n_hi ? n0 + q : n_hi - 1);
+                    for (int q = 0; q < 4; ++q) { n4[q] = a_first + a_step * (k0 + q < a_cnt ? k0 + q : a_cnt - 1); r4[q] = wload_raw(n4[q]); }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const v2f w = wconv(r4[q]);
                         bool nz = !(w.x == 0.f && w.y == 0.f);
                         if constexpr (C::WMIR) {         // (lateral-mirror mode: the stage also serves the mirror images of my pixels at receiver N-1-n)
-                            if (QSPEC(MIR, P.mir)) { const v2f w2 = wconv(wload_raw(n0 + q < n_hi ? n0 + q : n_hi - 1, true)); nz = nz || !(w2.x == 0.f && w2.y == 0.f); }
+                            if (QSPEC(MIR, P.mir)) { const v2f w2 = wconv(wload_raw(n4[q], true)); nz = nz || !(w2.x == 0.f && w2.y == 0.f); }
                         }
                         const bool any = __ballot(nz) != 0ull;
-                        if (any && lane == 0 && n0 + q < n_hi) atomicOr(&flg[(n0 + q) >> 5], 1u << ((n0 + q) & 31u));
+                        if (any && lane == 0 && k0 + q < a_cnt) atomicOr(&flg[n4[q] >> 5], 1u << (n4[q] & 31u));
                     }
                 }
             }
             __syncthreads();
             if (tid == 0) {
                 uint32_t cnt = 0;
-                for (uint32_t n = n_lo; n < n_hi; ++n)
+                for (uint32_t k = 0; k < a_cnt; ++k) {
+                    const uint32_t n = a_first + a_step * k;
                     if ((flg[n >> 5] >> (n & 31u)) & 1u) act[cnt++] = make_uint2(n, __float_as_uint(nrec[n].x));
+                }
                 act[N] = make_uint2(cnt, 0u);
             }
             __syncthreads();
