@@ -861,9 +861,12 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             // (a split costs one more prologue per tile.)  Plans with a pixel x stage-element weight: the tiles' stage lists differ in length by
             // the mask -- BASELINE C5's deep tiles keep every receiver, the shallow ones a few --, so the longest tile sets the kernel time unless
             // there are many more workgroups than CUs: up to 8 per CU, each taking every ks-th receiver (das_tile_impl.h plan_stages; C5 2.77 -> 2.18 ms)
-            const uint64_t want = (t.act_bytes && !t.syn) ? 8ull * cus : (uint64_t)cus;
+            // (as long as a workgroup keeps at least 16 candidate stage elements: a transmit-side rule that leaves two or three stages per tile
+            //  only pays prologues for more workgroups)
             unsigned ks = 1;
-            while (ks * 2 <= cap && (uint64_t)pl->ntiles * ks < want) ks *= 2;
+            while (ks * 2 <= cap && (uint64_t)pl->ntiles * ks < (uint64_t)cus) ks *= 2;
+            if (t.act_bytes && !t.syn)
+                while (ks * 2 <= cap && (uint64_t)pl->ntiles * ks < 8ull * cus && kN_eff / (ks * 2) >= 16) ks *= 2;
             if (const char *e = getenv("QDAS_KSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8 && (unsigned)v <= cap) ks = (unsigned)v; }
             t.ksplit = ks;
             if (ks > 1 && !bfm) {
