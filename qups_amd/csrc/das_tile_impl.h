@@ -105,7 +105,7 @@ struct TileCfg {
     static constexpr int PCS = (WB + PB - 1) / PB;   // pieces per window; the last one may use fewer lanes
     static constexpr int NDMA = WPW * PCS * (MIRQ ? 4 : TWO ? 2 : 1);    // DMA instructions per wave and stage
     static_assert(!(SYM && FBX) && !(FB2 && FB4), "reciprocal mode runs one frame per launch");
-    static_assert(!MIRQ || (SYM && !WTAB_ && !FMOD_ && MB_ == WAVES_ && 4 * MB_ * W_ * (int)sizeof(ST_) <= 65536), "reciprocal + lateral-mirror mode: one window per wave and set, immediate LDS offsets");
+    static_assert(!MIRQ || (SYM && MB_ == WAVES_ && 4 * MB_ * W_ * (int)sizeof(ST_) <= 65536), "reciprocal + lateral-mirror mode: one window per wave and set, immediate LDS offsets");
     static_assert(!BIG || (!SYM && !FBX), "the re-basing general kernel runs one frame per launch");
     static_assert(!LUT || (!SYM && !FBX && !BIG), "table-driven delays: general mode, one frame per launch");
     static_assert(!BF || (!SYM && !FBX && !BIG && !LUT && sizeof(ST_) == 8), "'BF': general mode, fp32 data, one frame per launch");
@@ -264,8 +264,10 @@ template <class C> __device__ __forceinline__ uint32_t Tile<C>::locate(uint32_t 
     const int tzl = QSPEC(TZL, P.tz_log2), wzl = QSPEC(WZL, P.wz_log2);
     const uint32_t wave_z = (uint32_t)wave & ((1u << (tzl - wzl)) - 1u), wave_c = (uint32_t)wave >> (tzl - wzl);
     // (depth index, column: may lie outside the image -- clamped for the delays, masked at the store)
-    i1 = (tz << tzl) + (wave_z << wzl) + (uint32_t)(lane & ((1 << wzl) - 1));
-    col = txi * ((uint32_t)(C::WAVES * 64) >> tzl) + (wave_c << (6 - wzl)) + (uint32_t)(lane >> wzl);
+    uint32_t ln = (uint32_t)lane;
+    if (!first) asm volatile("" : "+v"(ln));          // (the epilogue's calls: recomputed there, not carried through the stage loop in registers -- or scratch)
+    i1 = (tz << tzl) + (wave_z << wzl) + (ln & ((1u << wzl) - 1u));
+    col = txi * ((uint32_t)(C::WAVES * 64) >> tzl) + (wave_c << (6 - wzl)) + (ln >> wzl);
     const bool mirror = C::MIRQ || (C::FB2 && QSPEC(MIR, P.mir));
     const uint64_t ncols_mine = mirror ? (ncols + 1) / 2 : ncols;      // lateral-mirror mode: the tiles cover the first half of the columns
     uint64_t ig = (uint64_t)i1 + I1 * (uint64_t)col;
@@ -591,7 +593,10 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         if constexpr (C::F64) { const rec64 r = nrec64[n]; rec_b = r.b; rec_x = r.x; rec_y = r.y; rec_z = r.z; }
         else { const float4 r = nrec[n]; rec_b = __float_as_int(r.x); rec_x = r.y; rec_y = r.z; rec_z = r.w; }
         float phB = 0.f;                               // remodulation: frac(B[n]*fmod/fs) (tile_prologue.h)
-        if constexpr (C::FMOD) phB = Bext[n];
+        if constexpr (C::FMOD) {
+            phB = Bext[n];
+            if constexpr (C::MIRQ) phB = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(phB)));   // (uniform: a scalar register -- the one vector register the four window sets are short of)
+        }
         uint32_t wmask = 0xffffffffu, xmask = 0xffffffffu;       // which of this stage's table entries are non-zero (zero weights are skipped, src/bf.cu:122,126)
         if constexpr (C::WST) {
             const uint2 mk = *(const uint2 *)(wst + (uint32_t)buf * WBUF + 2 * C::MB * 8);
@@ -838,11 +843,11 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
     if constexpr (sizeof(ST) == 16) {                  // fp64 data: no remodulation, no pixel x receiver weight (qdas_api.hip)
         if (fm || P.apix || P.gen_kind || P.syn) return hipErrorInvalidValue;
         if (wt) QDAS_LAUNCH(false, true); else QDAS_LAUNCH(false, false);    // (grid: ntiles * ksplit workgroups, as for the other data types)
-    } else if constexpr (MIRQ) {
-        // (a weight table would have to be mirror-symmetric too, and the remodulating pair loop has no registers for four window sets: such plans
-        //  keep the plain reciprocal mode -- qdas_api.hip)
-        if (wt || fm) return hipErrorInvalidValue;
-        QDAS_LAUNCH(false, false);
+    } else if constexpr (MIRQ) {                      // (a weight table must be mirror-symmetric too: checked by the host)
+        if (fm && wt) QDAS_LAUNCH(true, true);
+        else if (fm)  QDAS_LAUNCH(true, false);
+        else if (wt)  QDAS_LAUNCH(false, true);
+        else          QDAS_LAUNCH(false, false);
     } else if constexpr (SYM) {
         if (fm && wt) QDAS_LAUNCH(true, true);
         else if (fm)  QDAS_LAUNCH(true, false);

@@ -549,14 +549,14 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     const bool mslab = (desc->plan_flags & QDAS_PLAN_MIRROR_SLAB) != 0;       // slab A + its mirror image (validated above)
     const bool mir_plain = z.S == 0 && !g.gen_kind;
     // pixel-independent weights only (folded into an N x M table): fine when the TABLE is mirror-symmetric, w[n,m] == w[N-1-n,M-1-m] -- receive and
-    // transmit windows are --; checked once the table is folded (below).  General mode only: the four-set reciprocal kernel takes no table.
-    const bool mir_tab = !sym && z.S > 0 && npix == 0 && !g.gen_kind && dt != QDAS_F64;
+    // transmit windows are --; checked once the table is folded (below).
+    const bool mir_tab = z.S > 0 && npix == 0 && !g.gen_kind && dt != QDAS_F64;
     const bool mir_wpix = dt == QDAS_F16 && !sym && !swap && !bpix_mode && z.S == npix
                           && ((pix_arr >= 0 && !pix_is_tx && !g.gen_kind) || (pix_arr < 0 && g.gen_kind >= 1 && g.gen_kind <= 4)) && !getenv("QDAS_NO_MIRROR_WPIX");
     if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && (mir_plain || mir_wpix || mir_tab) && !cmap && z.I3 == 1 && z.I2 >= 2
         && z.N >= 2 && ((desc->i_begin == 0 && pl->i_count == pl->I) || mslab) && !(desc->plan_flags & QDAS_PLAN_NO_MIRROR) && !getenv("QDAS_NO_MIRROR")
-        && (!sym || (desc->fmod == 0.0 && (uint64_t)z.T * z.N * z.M * data_size(dt) + 65536 < (1ull << 31) && z.M % 16 == 0 && !getenv("QDAS_NO_MIRQ")
-                     && tile_lds_bytes(dt, 1, z.N, z.M, 1, 0, 0, 1) <= tile_lds_limit(1)))) {
+        && (!sym || ((uint64_t)z.T * z.N * z.M * data_size(dt) + 65536 < (1ull << 31) && z.M % 16 == 0 && !getenv("QDAS_NO_MIRQ")
+                     && tile_lds_bytes(dt, 1, z.N, z.M, 1, 0, z.S > 0 ? 1 : 0, 1) <= tile_lds_limit(1)))) {
         if ((rc = mirror_symmetric(desc, (const float *)g.Pi, &mir))) return bail(rc);
     }
     // stage / block element counts of the kernel: receivers / transmits, or swapped
@@ -757,7 +757,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
                     const size_t q = swap ? (m + z.M * n) : (n + z.N * m), q2 = swap ? ((z.M - 1 - m) + z.M * (z.N - 1 - n)) : ((z.N - 1 - n) + z.N * (z.M - 1 - m));
                     if (memcmp(&host_tab[2 * q], &host_tab[2 * q2], 8) != 0) { tsym = false; break; }
                 }
-            if (!tsym) { t.mir = 0; mir = false; pl->tc = tile_config(dt, sym); }
+            if (!tsym) { t.mir = 0; mir = false; pl->tc = tile_config(dt, sym); }      // (reciprocal plans: the narrow configuration is chosen just below)
         }
         // reciprocal mode: first the 128-sample-window configuration (less staging traffic); it is kept only if some footprint
         // has no misfit tile at all -- otherwise the 192-sample configuration

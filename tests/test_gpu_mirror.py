@@ -137,6 +137,8 @@ def test_mirror_mode_through_das_spec_and_frames():
     (16, "lanczos3", "single", {}), (32, "lanczos3", "single", {"I2": 37}), (48, "cubic", "single", {}), (32, "linear", "single", {"tpose": True}),
     (16, "nearest", "single", {}), (32, "lanczos3", "halfT", {}), (16, "cubic", "halfT", {"I2": 5}), (32, "cubic_dev", "single", {"ks": "2"}),
     (64, "lanczos3", "single", {"ks": "4"}), (32, "cubic", "single", {"T": 330}), (32, "linear", "halfT", {"T": 330, "ks": "2"}),
+    (32, "lanczos3", "single", {"fmod": 2.5e6}), (32, "cubic", "single", {"wtab": True}), (48, "lanczos3", "single", {"fmod": 2.5e6, "wtab": True}),
+    (32, "cubic", "halfT", {"wtab": True, "fmod": 2.5e6}), (32, "lanczos3", "single", {"wtab": True, "T": 330}), (16, "nearest", "halfT", {"fmod": 2.5e6}),
 ])
 def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_path, monkeypatch):
     """A full-synthetic-aperture acquisition (transmit elements == receive elements) on a mirror-symmetric array and scan: FOUR traces share
@@ -157,7 +159,18 @@ def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_pa
     tpose = bool(extra.get("tpose", False))
     xin = np.ascontiguousarray(np.swapaxes(x, 1, 2)) if tpose else x
     xt = torch.from_numpy(xin)
-    opts = parse_options(xt, list(case["opt"]) + ["interp", interp, "input-precision", prec, "transpose", tpose])
+    fmod = float(np.float32(extra.get("fmod", 0.0)))
+    va = list(case["opt"]) + ["interp", interp, "input-precision", prec, "transpose", tpose, "modulation", fmod]
+    apod = []
+    if extra.get("wtab"):                              # receive x transmit windows, mirror-symmetric (one dead element pair); complex for fp32 data
+        q = (lambda a: a.astype(np.float16).astype(np.float64)) if prec == "halfT" else (lambda a: a.astype(np.float32).astype(np.float64))
+        wn = q(np.hanning(N + 2)[1:-1]).reshape(1, 1, 1, N, 1)
+        wm = q(0.25 + 0.75 * np.hanning(N + 2)[1:-1]).reshape(1, 1, 1, 1, N)
+        wm[..., 2] = 0.0; wm[..., N - 3] = 0.0
+        apod = [wn, wm * (1 + 0.5j) if prec == "single" else wm]
+        for a in apod:
+            va += ["apod", a]
+    opts = parse_options(xt, va)
     prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], opts)
     ys, names = [], []
     for kw in (dict(), dict(mirror=False), dict(mirror=False, reciprocal=False)):
@@ -170,11 +183,12 @@ def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_pa
     assert names[1][1] and not names[1][2] and not names[2][1] and not names[2][2], names
     assert ("[jit " in names[0][0]) == jit
     ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xin, case["t0"], case["fs"], cinv_f32(case["c"]),
-                     VS=case["VS"], DV=case["DV"], interp=interp, tpose=tpose).reshape(-1, order="F")
+                     VS=case["VS"], DV=case["DV"], interp=interp, tpose=tpose, fmod=fmod, apod=apod).reshape(-1, order="F")
+    assert ("fmod" in names[0][0]) == bool(fmod) and ("wtab" in names[0][0]) == bool(apod), names[0]
     if "T" in extra:
         assert np.count_nonzero(ref == 0) > 0 and np.count_nonzero(ref) > 0, "the record should end inside the image"
         assert np.array_equal(ys[0] == 0, ref == 0)
-    tol = 2e-3 if prec == "halfT" else (1e-2 if interp == "nearest" else 2e-5)
+    tol = 2e-3 if prec == "halfT" else (1e-2 if interp == "nearest" else 2e-4 if fmod else 2e-5)
     for y, nm in zip(ys, names):
         assert rel_err(y, ref) <= tol, nm
     loose = 1e-2 if interp == "nearest" else 1e-4 if prec == "halfT" else 5e-6
