@@ -191,7 +191,7 @@ def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_pa
     tol = 2e-3 if prec == "halfT" else (1e-2 if interp == "nearest" else 2e-4 if fmod else 2e-5)
     for y, nm in zip(ys, names):
         assert rel_err(y, ref) <= tol, nm
-    loose = 1e-2 if interp == "nearest" else 1e-4 if prec == "halfT" else 5e-6
+    loose = 1e-2 if interp == "nearest" else 1e-4 if prec == "halfT" else 2e-5 if fmod else 5e-6
     assert rel_err(ys[0], ys[1]) <= loose and rel_err(ys[0], ys[2]) <= loose
 
 
