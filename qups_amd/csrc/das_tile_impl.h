@@ -139,6 +139,13 @@ template <class C> struct Tile {
     static constexpr uint32_t NOT_MINE = 0xffffffffu;
     uint32_t pofs;                                   // my pixel's offset in this plan's slab, or NOT_MINE (lane outside the image / the slab; slabs stay below 2^32 - 1 pixels)
     __device__ __forceinline__ bool in_shard() const { return pofs != NOT_MINE; }
+    // the lane id straight from the hardware (two instructions), for the per-stage code (LDS-DMA, stage weights): as a variable it -- and
+    // lane * 16 -- would be two registers carried through every pair loop, which the register-bound instantiations do not have
+    static __device__ __forceinline__ uint32_t lane_now() {
+        uint32_t l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    }
     uint64_t ipx;                                    // (clamped) linear pixel index: row of per-pixel arrays / delay tables
     uint64_t ipx2;                                   // lateral-mirror mode with a pixel x receiver weight array: the same of my pixel's mirror image (TileCfg::WMIR)
     GT px, py, pz;
@@ -264,10 +271,15 @@ template <class C> __device__ __forceinline__ uint32_t Tile<C>::locate(uint32_t 
     const int tzl = QSPEC(TZL, P.tz_log2), wzl = QSPEC(WZL, P.wz_log2);
     const uint32_t wave_z = (uint32_t)wave & ((1u << (tzl - wzl)) - 1u), wave_c = (uint32_t)wave >> (tzl - wzl);
     // (depth index, column: may lie outside the image -- clamped for the delays, masked at the store)
-    uint32_t ln = (uint32_t)lane;
-    if (!first) asm volatile("" : "+v"(ln));          // (the epilogue's calls: recomputed there, not carried through the stage loop in registers -- or scratch)
-    i1 = (tz << tzl) + (wave_z << wzl) + (ln & ((1u << wzl) - 1u));
-    col = txi * ((uint32_t)(C::WAVES * 64) >> tzl) + (wave_c << (6 - wzl)) + (ln >> wzl);
+    if (first) {
+        i1 = (tz << tzl) + (wave_z << wzl) + (uint32_t)(lane & ((1 << wzl) - 1));
+        col = txi * ((uint32_t)(C::WAVES * 64) >> tzl) + (wave_c << (6 - wzl)) + (uint32_t)(lane >> wzl);
+    } else {                                          // (the epilogue's calls: recomputed THERE from an opaque lane id, not carried through the stage loop in registers -- or scratch)
+        uint32_t ln = (uint32_t)lane;
+        asm volatile("" : "+v"(ln));
+        i1 = (tz << tzl) + (wave_z << wzl) + (ln & ((1u << wzl) - 1u));
+        col = txi * ((uint32_t)(C::WAVES * 64) >> tzl) + (wave_c << (6 - wzl)) + (ln >> wzl);
+    }
     const bool mirror = C::MIRQ || (C::FB2 && QSPEC(MIR, P.mir));
     const uint64_t ncols_mine = mirror ? (ncols + 1) / 2 : ncols;      // lateral-mirror mode: the tiles cover the first half of the columns
     uint64_t ig = (uint64_t)i1 + I1 * (uint64_t)col;
@@ -426,13 +438,6 @@ template <class C> __device__ __forceinline__ v2f Tile<C>::wconv(wraw r) const {
 template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
     n_lo = C::SYM ? 0u : (uint32_t)((uint64_t)N * split / S);
     n_hi = (uint32_t)((uint64_t)N * (split + 1) / S);
-    // a pixel x receiver weight and a split aperture: the workgroups of a tile take every S-th receiver instead of contiguous ranges -- the
-    // receivers that carry weight form a band (acceptance angle, f-number), which a contiguous split hands to ONE of the workgroups
-    const bool wanted = !C::F64 && !C::SYM && !C::BF && !(C::FBX && C::F32) && (QSPEC(HAS_APIX, P.apix != nullptr) || QSPEC(GEN_KIND, P.gen_kind) != 0);
-    const bool inter = C::ACT && wanted && S > 1 && !QSPEC(SYN, P.syn);
-    const uint32_t a_first = inter ? split : n_lo, a_step = inter ? S : 1u;
-    if (inter) { n_lo = 0; n_hi = N; }
-    const uint32_t a_cnt = inter ? (N > split ? (N - split + S - 1) / S : 0u) : n_hi - n_lo;
     acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
     dacc[0] = dacc[1] = dacc[2] = dacc[3] = 0.0;
 #pragma unroll
@@ -454,6 +459,12 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
     if constexpr (C::ACT) {
         if (wpix) {
             use_act = true;
+            // a split aperture: the workgroups of a tile take every S-th receiver instead of contiguous ranges -- the receivers that carry
+            // weight form a band (acceptance angle, f-number), which a contiguous split hands to ONE of the workgroups
+            const bool inter = S > 1 && !QSPEC(SYN, P.syn);
+            const uint32_t a_first = inter ? split : n_lo, a_step = inter ? S : 1u;
+            if (inter) { n_lo = 0; n_hi = N; }
+            const uint32_t a_cnt = inter ? (N > split ? (N - split + S - 1) / S : 0u) : n_hi - n_lo;
             uint32_t *flg = (uint32_t *)part;          // prologue scratch (the windows are not in use yet)
             for (uint32_t k = tid; k < (N + 31) / 32; k += C::THREADS) flg[k] = 0u;
             __syncthreads();
@@ -557,19 +568,20 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
     float2 wnx = {0.f, 0.f};
     auto wst_load = [&](uint32_t nn, uint32_t mm0) {
         if constexpr (C::WST) {
-            const uint32_t mm = mm0 + (uint32_t)lane;
-            if (wave == 0 && lane < C::MB) wnx = mm < M ? ((const float2 *)P.wtab)[nn + (size_t)N * mm] : make_float2(0.f, 0.f);
-            if constexpr (C::SYM) { if (wave == 1 && lane < C::MB) wnx = ((const float2 *)P.wtab)[mm + (size_t)N * nn]; }
+            const uint32_t ln = lane_now(), mm = mm0 + ln;
+            if (wave == 0 && ln < (uint32_t)C::MB) wnx = mm < M ? ((const float2 *)P.wtab)[nn + (size_t)N * mm] : make_float2(0.f, 0.f);
+            if constexpr (C::SYM) { if (wave == 1 && ln < (uint32_t)C::MB) wnx = ((const float2 *)P.wtab)[mm + (size_t)N * nn]; }
         }
     };
     auto wst_store = [&](int b) {
         if constexpr (C::WST) {
             if (wave == 0 || (C::SYM && wave == 1)) {
-                const bool nz = lane < C::MB && !(wnx.x == 0.f && wnx.y == 0.f);
+                const uint32_t ln = lane_now();
+                const bool nz = ln < (uint32_t)C::MB && !(wnx.x == 0.f && wnx.y == 0.f);
                 const uint32_t mask = (uint32_t)__ballot(nz);
                 unsigned char *q = wst + (uint32_t)b * WBUF + (wave ? C::MB * 8 : 0);
-                if (lane < C::MB) ((float2 *)q)[lane] = wnx;
-                if (lane == 0) ((uint32_t *)(wst + (uint32_t)b * WBUF + 2 * C::MB * 8))[wave ? 1 : 0] = mask;
+                if (ln < (uint32_t)C::MB) ((float2 *)q)[ln] = wnx;
+                if (ln == 0) ((uint32_t *)(wst + (uint32_t)b * WBUF + 2 * C::MB * 8))[wave ? 1 : 0] = mask;
             }
         }
     };

@@ -90,6 +90,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::dma_block(uint32_t m
 template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, int buf) {
     constexpr int SB = C::SB, WB = C::WB, PB = C::PB, PCS = C::PCS, NW = C::NW, MB = C::MB;
     const int bs = bn * SB;
+    const int l16 = (int)(lane_now() * 16u);          // (byte offset of this lane's 16 bytes in a piece; see Tile::lane_now)
     if constexpr (C::MIRQ) {
         const int j = wjr(0);
 #pragma unroll
@@ -97,8 +98,8 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
 #pragma unroll
             for (int q = 0; q < PCS; ++q) {
                 lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + k * MB + j) * WB + q * PB));
-                if (lane * 16 < WB - q * PB)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, dst, 16, lane * 16, qo[k] + bs + q * PB, 0, 0);
+                if (l16 < WB - q * PB)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, dst, 16, l16, qo[k] + bs + q * PB, 0, 0);
             }
         }
         qo[0] += (int)((uint32_t)strN * SB); qo[1] += (int)((uint32_t)strM * SB);
@@ -112,8 +113,8 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
 #pragma unroll
         for (int q = 0; q < (hooks::one_dma_piece ? 1 : PCS); ++q) {
             lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + fa * MB + j) * WB + q * PB));
-            if (lane * 16 < WB - q * PB)             // trailing partial piece: upper lanes masked off
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, dst, 16, lane * 16, so + q * PB, 0, 0);
+            if (l16 < WB - q * PB)             // trailing partial piece: upper lanes masked off
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, dst, 16, l16, so + q * PB, 0, 0);
         }
     }
     if constexpr (C::FBX) {                           // next frame: same offsets, other descriptor, another window set
@@ -125,8 +126,8 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
 #pragma unroll
             for (int q = 0; q < PCS; ++q) {
                 lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + fb * MB + j) * WB + q * PB));
-                if (lane * 16 < WB - q * PB)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, dst, 16, lane * 16, so + q * PB, 0, 0);
+                if (l16 < WB - q * PB)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, dst, 16, l16, so + q * PB, 0, 0);
             }
         }
     }
@@ -143,8 +144,8 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
 #pragma unroll
             for (int q = 0; q < PCS; ++q) {
                 lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + MB + j) * WB + q * PB));
-                if (lane * 16 < WB - q * PB)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, dst, 16, lane * 16, so + q * PB, 0, 0);
+                if (l16 < WB - q * PB)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, dst, 16, l16, so + q * PB, 0, 0);
             }
         }
         soff2 += (uint32_t)strM * SB;                 // next "transmit" n of the mirror traces
