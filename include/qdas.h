@@ -362,7 +362,8 @@ int qdas_permute3(const void *in, void *out, uint64_t A, uint64_t B, uint64_t C,
 /* ---- Pre-processing in front of the DAS path: real RF traces -> analytic channel data, optionally downmixed.
  * Replaces ChannelData.hilbert (reference src/ChannelData.m:935-966: fft to N points along time, weights
  * [1; 2...; 1 + mod(N,2); 0...], ifft) and ChannelData.downmix (src/ChannelData.m:757-766: data .* exp(-2i*pi*fc*time))
- * applied after it.  x: T x K real traces (K = N*M*F, device pointer) as fp32 or int16; y: Nfft x K complex64 (device).
+ * applied after it -- one kernel, two real traces per complex transform, forward and inverse FFT stages LDS to LDS (pre.hip).
+ * x: T x K real traces (K = N*M*F, device pointer) as fp32 or int16; y: Nfft x K complex64 (device).
  * Real input is half (fp32) / a quarter (int16) of the bytes of complex64 channel data on the PCIe link. */
 #define QDAS_PRE_F32 0
 #define QDAS_PRE_I16 1
@@ -379,6 +380,9 @@ typedef struct qdas_pre_plan qdas_pre_plan;
 int  qdas_pre_plan_create(qdas_pre_plan **plan, const qdas_pre_desc *desc);
 int  qdas_pre_execute(qdas_pre_plan *plan, const void *x, void *y, void *stream);
 void qdas_pre_plan_destroy(qdas_pre_plan *plan);
+/* 1: the plan runs the one-pass kernel (a trace pair resident in LDS: Nfft = 2^a 3^b 5^c 7^d 11^e 13^f <= 8192 whose stages fit 1024 threads; HBM sees the input once and
+ * the output once); 0: hipFFT passes (any other length, or QDAS_PRE_HIPFFT=1 in the environment) */
+int  qdas_pre_plan_one_pass(const qdas_pre_plan *plan);
 
 const char *qdas_last_error(void);
 int  qdas_version(void);

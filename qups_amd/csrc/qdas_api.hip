@@ -1425,6 +1425,7 @@ struct PrePlan;
 int pre_create(PrePlan **out, uint64_t T, uint64_t K, uint64_t N, int in_type, double fs, double t0, double fd);
 void pre_destroy(PrePlan *p);
 int pre_execute(PrePlan *p, const void *x, void *y, hipStream_t s);
+bool pre_one_pass(const PrePlan *p);
 }
 struct qdas_pre_plan { qdas::PrePlan *p; int device; };
 
@@ -1453,6 +1454,8 @@ extern "C" int qdas_pre_execute(qdas_pre_plan *pl, const void *x, void *y, void 
     if (rc) return fail(QDAS_EHIP, "pre: hipFFT execution failed (%d)", rc);
     return QDAS_OK;
 }
+
+extern "C" int qdas_pre_plan_one_pass(const qdas_pre_plan *pl) { return pl && qdas::pre_one_pass(pl->p) ? 1 : 0; }
 
 extern "C" void qdas_pre_plan_destroy(qdas_pre_plan *pl) {
     if (!pl) return;

@@ -1,8 +1,8 @@
 """Pre-processing in front of the DAS path, on the device: ``hilbert`` (+ fused ``downmix``) of real RF traces.
 
 Mirrors ``ChannelData.hilbert`` (reference src/ChannelData.m:935-966) and ``ChannelData.downmix`` (:757-766) for data whose time
-axis is the first dimension.  The work is done by ``libqdas.so`` (hipFFT plans + HIP kernels, qups_amd/csrc/pre.hip); there is no
-CPU fallback."""
+axis is the first dimension.  The work is done by ``libqdas.so`` (qups_amd/csrc/pre.hip: a one-pass LDS-resident FFT kernel for
+record lengths with prime factors up to 13, hipFFT passes for the rest); there is no CPU fallback."""
 from __future__ import annotations
 
 import ctypes as C
@@ -32,7 +32,11 @@ def hilbert(x, N: int | None = None, fdown: float = 0.0, t0: float = 0.0, fs: fl
     if fdown and not fs:
         raise ValueError("Undefined sampling rate.")
     from .das_spec import _colmajor
-    xc = _colmajor(xt.to(dev).reshape(T, K).contiguous())         # K x T: time fastest (MATLAB memory order of T x K)
+    x2 = xt.to(dev).reshape(T, K)
+    if K == 1 or (T > 0 and x2.stride() == (1, T)):                 # already time-fastest (e.g. a MATLAB-ordered view): no copy
+        xc = x2.t()
+    else:
+        xc = _colmajor(x2.contiguous())                             # K x T: time fastest (MATLAB memory order of T x K)
     y = torch.empty((K, N), dtype=torch.complex64, device=dev)
     d = _lib.PreDesc(T, K, N, _lib.QDAS_PRE_I16 if xt.dtype == torch.int16 else _lib.QDAS_PRE_F32,
                      dev.index if dev.index is not None else torch.cuda.current_device(), float(fs or 0.0), float(t0), float(fdown))
@@ -40,6 +44,7 @@ def hilbert(x, N: int | None = None, fdown: float = 0.0, t0: float = 0.0, fs: fl
     h = C.c_void_p()
     with torch.cuda.device(dev):
         _lib.check(L.qdas_pre_plan_create(C.byref(h), C.byref(d)))
+        hilbert.last_one_pass = bool(L.qdas_pre_plan_one_pass(h))   # which path served the last call (tests / tools)
         try:
             _lib.check(L.qdas_pre_execute(h, C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()),
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)))

@@ -50,6 +50,63 @@ def test_hilbert_matches_numpy(T, N, dtype, fdown):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("force_hipfft", [False, True])
+@pytest.mark.parametrize("T,N,K,dtype,fdown", [(2816, None, 7, "f32", 0.0),       # C3's record length = 2^8 * 11
+                                               (2048, None, 6, "i16", 5.0e6),     # C1 / C2
+                                               (1000, None, 3, "f32", 0.0),       # 2^3 5^3
+                                               (143, None, 5, "f32", 0.0),        # 11 * 13, odd length, odd trace count
+                                               (2, None, 4, "f32", 0.0),
+                                               (252, 5632, 3, "f32", 2.0e6),      # 2^9 11: 11 8 8 8, 704 threads
+                                               (1000, 1820, 3, "f32", 0.0),       # 2^2 5 7 13
+                                               (4000, 3645, 2, "f32", 0.0),       # truncation; 3^6 * 5
+                                               (300, 8192, 1, "i16", 0.0),        # 16 8 8 8, 1024 threads
+                                               (9, None, 2, "f32", 0.0), (16, None, 3, "f32", 0.0), (512, None, 2, "f32", 0.0)])
+def test_one_pass_hilbert_matches_numpy(T, N, K, dtype, fdown, force_hipfft, monkeypatch):
+    """the LDS-resident kernel (two real traces per complex transform, mixed-radix stages LDS to LDS) against the numpy restatement,
+    and the hipFFT passes it replaces against the same numbers"""
+    from qups_amd.preproc import hilbert
+    monkeypatch.setenv("QDAS_PRE_HIPFFT", "1" if force_hipfft else "0")
+    rng = np.random.default_rng(T + K)
+    x = rng.standard_normal((T, K))
+    fs, t0 = 20e6, 1.7e-6
+    xq = np.round(x * 3000).astype(np.int16) if dtype == "i16" else x.astype(np.float32)
+    ref = hilbert_ref(xq.astype(np.float64), N, fdown, t0, fs)
+    y = hilbert(xq, N, fdown, t0, fs).cpu().numpy()
+    assert hilbert.last_one_pass == (not force_hipfft)
+    assert y.shape == ref.shape and y.dtype == np.complex64
+    assert np.abs(y - ref).max() / np.abs(ref).max() <= 2e-5
+    if not fdown:
+        Nn = ref.shape[0]
+        pad = np.zeros((Nn, K), np.float32); pad[:min(T, Nn)] = xq[:min(T, Nn)]
+        assert np.array_equal(y.real, pad)                              # the real part IS the input, bit for bit
+
+
+@pytest.mark.gpu
+def test_hilbert_lengths_the_one_pass_kernel_does_not_serve_fall_to_hipfft():
+    from qups_amd.preproc import hilbert
+    rng = np.random.default_rng(5)
+    for T in (301, 2 * 17, 8190, 10240):                               # 7 * 43; a factor 17; 2 3^2 5 7 13 (4095 radix-2 butterflies); too long
+        x = rng.standard_normal((T, 3)).astype(np.float32)
+        y = hilbert(x).cpu().numpy()
+        assert not hilbert.last_one_pass
+        ref = hilbert_ref(x.astype(np.float64))
+        assert np.abs(y - ref).max() / np.abs(ref).max() <= 2e-5
+
+
+@pytest.mark.gpu
+def test_hilbert_takes_time_fastest_views_without_a_copy():
+    import torch
+    from qups_amd.preproc import hilbert
+    g = torch.Generator(device="cuda").manual_seed(3)
+    xkt = torch.randn((6, 5, 704), generator=g, device="cuda")          # memory: M x N x T  ==  MATLAB's T x N x M
+    x = xkt.permute(2, 1, 0)                                            # T x N x M view, time fastest
+    y = hilbert(x)
+    ref = hilbert_ref(x.cpu().numpy().astype(np.float64))
+    assert y.shape == (704, 5, 6)
+    assert np.abs(y.cpu().numpy() - ref).max() / np.abs(ref).max() <= 2e-5
+
+
+@pytest.mark.gpu
 def test_real_rf_hilbert_then_das_equals_das_of_the_analytic_data():
     """the reference's pipeline (example_.m:261-269): real traces -> hilbert -> DAS, all on the device"""
     import torch

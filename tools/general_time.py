@@ -67,3 +67,66 @@ try:
          f"{T * N * N * Mf / ms / 1e6:.1f} Gsample/s (every output sums {N} transmit elements)")
 except Exception as ex:
     print("focusTx:", repr(ex))
+
+# ---- hilbert (real fp32 traces -> analytic complex64): the one-pass LDS kernel and the hipFFT passes it replaces (QDAS_PRE_HIPFFT=1)
+from qups_amd.preproc import hilbert
+for name, (T, K) in {"C1 2048 x 64x32": (2048, 64 * 32), "C2 2048 x 128x128": (2048, 128 * 128), "C3 2816 x 256x256": (2816, 256 * 256), "1000 x 4096 (5^3 2^3)": (1000, 4096)}.items():
+    xr = torch.randn((K, T), generator=g, device=dev, dtype=torch.float32).t()       # T x K, time fastest (the MATLAB memory order): no layout pass
+    for path, env in (("one pass", "0"), ("hipFFT passes", "1")):
+        os.environ["QDAS_PRE_HIPFFT"] = env
+        try:
+            ms = timed(lambda: hilbert(xr))
+            line(f"hilbert {name} [{path}]", ms, xr.numel() * 4 + xr.numel() * 8, "(plan creation inside the call)")
+        except Exception as ex:
+            print("hilbert:", name, path, repr(ex))
+    del xr
+os.environ.pop("QDAS_PRE_HIPFFT", None)
+
+# ---- convd: matched filter / ChannelData.filter along time, complex64 traces x a real 129-tap kernel, 'same'
+from qups_amd.convd import convd
+for name, (T, K) in {"C1 2048 x 2048": (2048, 2048), "C2 2048 x 16384": (2048, 16384), "C3 2816 x 65536": (2816, 65536)}.items():
+    xc = rn(T, K)
+    h = torch.randn((129, 1), generator=g, device=dev, dtype=torch.float32)
+    try:
+        ms = timed(lambda: convd(xc, h, 1, "same"))
+        line(f"convd 'same' {name} * 129 taps", ms, 2 * xc.numel() * 8, f"{xc.numel() * 129 * 4 * 2 / ms / 1e9:.1f} TFLOP/s fp32 (complex x real MAC = 4 flop)")
+    except Exception as ex:
+        print("convd:", name, repr(ex))
+    del xc
+
+# ---- das_lut (bfDASLUT's kernel: delay tables instead of geometry) at C1 / C2 sizes, cubic, summed over receivers and transmits
+for cfg in ("c1", "c2"):
+    w = workload(cfg)
+    T, N, M, I = w["T"], w["N"], w["M"], w["I1"] * w["I2"]
+    xl = rn(T, N, M)
+    Pi = torch.from_numpy(np.asarray(w["Pi"], np.float32).reshape(3, -1)).to(dev)
+    Prt = torch.from_numpy(np.asarray(w["Pr"], np.float32)).to(dev)
+    Pvt, Nvt = torch.from_numpy(np.asarray(w["Pv"], np.float32)).to(dev), torch.from_numpy(np.asarray(w["Nv"], np.float32)).to(dev)
+    trx = (Pi.t().reshape(I, 1, 3) - Prt.t().reshape(1, N, 3)).norm(dim=2) * (w["fs"] / w["c0"])                 # the tables bfDASLUT builds: receive ...
+    if cfg == "c2":
+        ttx = (Pi.t() @ Nvt[:, :M]) * (w["fs"] / w["c0"]) - w["t0"] * w["fs"]                                   # ... and plane-wave transmit delays
+    else:
+        dv = Pi.t().reshape(I, 1, 3) - Pvt[:3].t().reshape(1, M, 3)
+        ttx = (torch.sign(dv[..., 2]) * dv.norm(dim=2) + Pvt[2].reshape(1, M)) * (w["fs"] / w["c0"]) - w["t0"] * w["fs"]   # virtual sources
+    trx, ttx = trx.contiguous(), ttx.contiguous()
+    try:
+        ms = timed(lambda: das_lut(xl, trx, ttx, interp="cubic"), reps=3)
+        line(f"das_lut {cfg.upper()} I={I} N={N} M={M} cubic (geometric tables)", ms, xl.numel() * 8 + (trx.numel() + ttx.numel()) * 4 + I * 8, f"{I * N * M / ms / 1e6:.1f} Gpair/s")
+    except Exception as ex:
+        print("das_lut:", cfg, repr(ex))
+    del xl
+
+# ---- greens: C1's simulator call (64 x 64 FSA, 2048 samples) with 1000 point scatterers
+from qups_amd.greens import greens
+w = workload("c1")
+Pr = np.asarray(w["Pr"])
+rng = np.random.default_rng(0)
+for S in (1000, 100000):
+    scat = np.stack([rng.uniform(-10e-3, 10e-3, S), np.zeros(S), rng.uniform(10e-3, 40e-3, S)])
+    wv = np.hanning(33) * np.sin(2 * np.pi * 5e6 * np.arange(33) / (4 * w["fs"]))
+    try:
+        ms = timed(lambda: greens(Pr, Pr, scat, np.ones(S), w["c0"], wv, -16 / (4 * w["fs"]), 4 * w["fs"], w["fs"]), reps=3)
+        y, _ = greens(Pr, Pr, scat, np.ones(S), w["c0"], wv, -16 / (4 * w["fs"]), 4 * w["fs"], w["fs"])
+        line(f"greens C1 64x64 FSA, {S} scatterers, {y.shape[0]} samples", ms, y.numel() * 8, f"{S * y.shape[1] * y.shape[2] / ms / 1e6:.2f} G scatterer-paths/s (host marshalling inside the call)")
+    except Exception as ex:
+        print("greens:", S, repr(ex))

@@ -52,6 +52,21 @@ cp gpurun_out/prof_${R}_c3_general/summary.txt $OUT/rocprofv3_summary_c3_general
 # ---- streams of frames, the general (non-fused) kernels
 python tools/frames_bench.py c2 12 > $OUT/frames_bench.txt 2>/dev/null; python tools/frames_bench.py c5 12 >> $OUT/frames_bench.txt 2>/dev/null; python tools/frames_bench.py c1 12 >> $OUT/frames_bench.txt 2>/dev/null
 python tools/general_time.py 2>/dev/null | grep -v Warn > $OUT/general_time.txt
+# per-kernel durations of the same script (kernel-trace only): the launches behind every line of general_time.txt
+(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_general -o g -- python $REPO/tools/general_time.py > /dev/null 2>&1)
+python - <<PYEOF > $OUT/rocprofv3_summary_general.txt
+import csv, glob
+fs = glob.glob("$OUT/trace_general/**/*kernel_stats.csv", recursive=True)
+print("rocprofv3 --kernel-trace --stats -- python tools/general_time.py   (kernel_stats.csv; durations in ns)")
+if fs:
+    rows = list(csv.DictReader(open(fs[0])))
+    print(f"{'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}  kernel")
+    for r in rows[:40]:
+        print(f"{r['Calls']:>6s} {float(r['AverageNs']) / 1e3:10.1f} {float(r['MinNs']) / 1e3:10.1f} {float(r['MaxNs']) / 1e3:10.1f} {float(r['Percentage']):6.2f}  {r['Name'][:150]}")
+else:
+    print("no kernel_stats.csv")
+PYEOF
+rm -rf $OUT/trace_general
 # ---- registers: prebuilt library, and the hiprtc builds of this run
 python tools/kernel_regs.py qups_amd/libqdas.so > $OUT/kernel_regs.txt 2>&1
 python tools/kernel_regs.py $QDAS_CACHE_DIR > $OUT/kernel_regs_hiprtc.txt 2>&1
