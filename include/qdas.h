@@ -348,7 +348,8 @@ typedef struct qdas_convd_desc {
     int32_t  shape;    /* QDAS_CONV_*                            */
     int32_t  bcast;    /* QDAS_CONV_{X,Y}_ONE_{COLUMN,SLICE}     */
     int32_t  device;   /* HIP device ordinal, -1 = current       */
-    int32_t  reserved;
+    int32_t  y_real;   /* extension (cplx == 1): y holds REAL taps of `dtype` -- a real filter on complex traces costs half the multiplies
+                          of the promoted product the reference forms (kern/convd.m:259-268 makes both operands complex) */
 } qdas_convd_desc;
 uint64_t qdas_convd_len(uint64_t M, uint64_t N, int shape);    /* L */
 int qdas_convd(const qdas_convd_desc *desc, const void *x, const void *y, void *z, void *stream);

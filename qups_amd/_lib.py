@@ -81,7 +81,7 @@ class PreDesc(C.Structure):
 
 class ConvdDesc(C.Structure):
     _fields_ = [("C", C.c_uint64), ("M", C.c_uint64), ("N", C.c_uint64), ("S", C.c_uint64), ("dtype", C.c_int32), ("cplx", C.c_int32),
-                ("shape", C.c_int32), ("bcast", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("shape", C.c_int32), ("bcast", C.c_int32), ("device", C.c_int32), ("y_real", C.c_int32)]
 
 
 class QdasError(RuntimeError):

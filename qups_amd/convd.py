@@ -68,6 +68,8 @@ def convd(x, y=None, dim: int | None = None, shape: str = "full", device=None, r
         dt = torch.complex32 if cplx else torch.float16
     else:
         dt = {(True, True): torch.complex64, (True, False): torch.float32, (False, True): torch.complex128, (False, False): torch.float64}[(single, cplx)]
+    y_real = cplx and xt.is_complex() and not yt.is_complex()      # real taps on complex data: kept real (half the multiplies; same numbers)
+    rdt = {torch.complex32: torch.float16, torch.complex64: torch.float32, torch.complex128: torch.float64}.get(dt)
     sx, sy = list(xt.shape), list(yt.shape)
     other = [k for k in range(D) if k != d]
     if not all(sx[k] == sy[k] or sx[k] == 1 or sy[k] == 1 for k in other):
@@ -78,8 +80,9 @@ def convd(x, y=None, dim: int | None = None, shape: str = "full", device=None, r
     Cc = int(np.prod(full[d + 1:])) if d + 1 < D else 1         # fast dimensions
     bits = 0
 
-    def prep(t, sz, one_col, one_slice):
+    def prep(t, sz, one_col, one_slice, to=None):
         nonlocal bits
+        to = to or dt
         lead, trail = sz[:d], sz[d + 1:]
         lead_ok = lead == full[:d] or all(v == 1 for v in lead)
         trail_ok = trail == full[d + 1:] or all(v == 1 for v in trail)
@@ -92,20 +95,20 @@ def convd(x, y=None, dim: int | None = None, shape: str = "full", device=None, r
         if S > 1 and all(v == 1 for v in lead):
             bits |= one_slice
         t = t.to(dev)
-        if dt == torch.complex32 and t.dtype != torch.complex32:             # (torch has no direct cast to complex half)
+        if to == torch.complex32 and t.dtype != torch.complex32:             # (torch has no direct cast to complex half)
             t = torch.complex(t.real.to(torch.float32), t.imag.to(torch.float32)) if t.is_complex() else torch.complex(t.to(torch.float32), torch.zeros_like(t, dtype=torch.float32))
             t = torch.view_as_complex(torch.view_as_real(t).to(torch.float16).contiguous())
-        return t.to(dtype=dt).contiguous()
+        return t.to(dtype=to).contiguous()
 
     xd = prep(xt, sx, _lib.QDAS_CONV_X_ONE_COLUMN, _lib.QDAS_CONV_X_ONE_SLICE)
-    yd = prep(yt, sy, _lib.QDAS_CONV_Y_ONE_COLUMN, _lib.QDAS_CONV_Y_ONE_SLICE)
+    yd = prep(yt, sy, _lib.QDAS_CONV_Y_ONE_COLUMN, _lib.QDAS_CONV_Y_ONE_SLICE, rdt if y_real else None)
     lags = conv_lags(M, N, shape)
     L = len(lags)
     osz = list(full); osz[d] = L
     z = torch.empty(osz, dtype=dt, device=dev)
     if z.numel():
         desc = _lib.ConvdDesc(Cc, M, N, S, _lib.QDAS_F16 if half else (_lib.QDAS_F32 if single else _lib.QDAS_F64), int(cplx), _SHAPES[shape], bits,
-                              dev.index if dev.index is not None else torch.cuda.current_device(), 0)
+                              dev.index if dev.index is not None else torch.cuda.current_device(), int(y_real))
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().qdas_convd(C.byref(desc), C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), C.c_void_p(z.data_ptr()),
                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))

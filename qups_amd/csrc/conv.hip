@@ -57,6 +57,9 @@ __device__ __forceinline__ void cv_mac(float2 &a, float2 x, float2 y) {
     a.x = fmaf(x.x, y.x, a.x); a.x = fmaf(-x.y, y.y, a.x);
     a.y = fmaf(x.x, y.y, a.y); a.y = fmaf(x.y, y.x, a.y);
 }
+// complex data, real taps (a real band-pass / matched filter on analytic traces): half the multiplies
+__device__ __forceinline__ void cv_mac(float2 &a, float2 x, float y)    { a.x = fmaf(x.x, y, a.x); a.y = fmaf(x.y, y, a.y); }
+__device__ __forceinline__ void cv_mac(double2 &a, double2 x, double y) { a.x = fma(x.x, y, a.x); a.y = fma(x.y, y, a.y); }
 __device__ __forceinline__ void cv_mac(double2 &a, double2 x, double2 y) {
     a.x = fma(x.x, y.x, a.x); a.x = fma(-x.y, y.y, a.x);
     a.y = fma(x.x, y.y, a.y); a.y = fma(x.y, y.x, a.y);
@@ -72,13 +75,14 @@ template <typename T> struct cv_row {      // padded row length: row stride = 8 
     static constexpr int LEN = Q + ((8 - Q % MOD) % MOD + MOD) % MOD;
 };
 
-template <typename T, typename S>
+template <typename T, typename S, typename TT, typename ST>
 __global__ void __launch_bounds__(128) conv_time_kernel(const ConvParams P) {
     constexpr int QP = cv_row<T>::LEN;
     using IO = cv_io<T, S>;
+    using IOT = cv_io<TT, ST>;                   // taps: the data's type, or its real type
     __shared__ T X[8][QP];                       // X[w][k] = span element 8k + w
     const S *__restrict__ x = (const S *)P.x + (uint64_t)blockIdx.x * P.xss;     // slices along grid.x (may exceed 65535)
-    const S *__restrict__ y = (const S *)P.y + (uint64_t)blockIdx.x * P.yss;
+    const ST *__restrict__ y = (const ST *)P.y + (uint64_t)blockIdx.x * P.yss;
     S *__restrict__ z = (S *)P.z + (uint64_t)blockIdx.x * P.L;
     const int t = threadIdx.x;
     const int64_t M = (int64_t)P.M, N = (int64_t)P.N, L = (int64_t)P.L;
@@ -123,7 +127,7 @@ __global__ void __launch_bounds__(128) conv_time_kernel(const ConvParams P) {
             const int64_t jb = j0 + 8 * g;                            // uniform: scalar loads
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const T tap = (jb + u < N) ? IO::ld(y, (uint64_t)(jb + u)) : cv_zero<T>::v();
+                const TT tap = (jb + u < N) ? IOT::ld(y, (uint64_t)(jb + u)) : cv_zero<TT>::v();
 #pragma unroll
                 for (int r = 0; r < 8; ++r) cv_mac(acc[r], win[8 + r - u], tap);
             }
@@ -144,62 +148,73 @@ __global__ void __launch_bounds__(128) conv_time_kernel(const ConvParams P) {
     }
 }
 
-// ---- strided time: x (C x M x S), y (C x N x S), z (C x L x S); lanes along c, 8 consecutive outputs per lane, the same
-// 16-sample register window fed straight from global memory (a wave's loads are coalesced along c).  YB: y has one column
+// ---- strided time: x (C x M x S), y (C x N x S), z (C x L x S); lanes along c, 16 (double complex: 8) consecutive outputs per lane, the same
+// kind of register window fed straight from global memory (a wave's loads are coalesced along c).  YB: y has one column
 // (a filter shared by all traces): its taps are uniform and come through the scalar cache.
-template <typename T, typename S, bool YB>
+template <typename T> struct cv_opl { static constexpr int V = sizeof(T) <= 8 ? 16 : 8; };   // outputs per lane (double2: 8, register budget)
+
+template <typename T, typename S, typename TT, typename ST, bool YB>
 __global__ void __launch_bounds__(256) conv_col_kernel(const ConvParams P) {
     using IO = cv_io<T, S>;
+    using IOT = cv_io<TT, ST>;
+    constexpr int R = cv_opl<T>::V;                                       // outputs per lane; taps go in groups of 8
     const uint32_t ncb = (uint32_t)((P.C + 63) / 64);
     const uint64_t sl = blockIdx.x / ncb;                                // slice; column block = blockIdx.x % ncb
     const uint64_t c = (uint64_t)(blockIdx.x % ncb) * 64 + threadIdx.x;
-    const int64_t l = ((int64_t)blockIdx.y * 4 + threadIdx.y) * 8;
+    const int64_t l = ((int64_t)blockIdx.y * 4 + threadIdx.y) * R;
     const int64_t M = (int64_t)P.M, N = (int64_t)P.N, L = (int64_t)P.L;
     if (c >= P.C || l >= L) return;
     const S *__restrict__ x = (const S *)P.x + sl * P.xss + c * P.xcs;
-    const S *__restrict__ y = (const S *)P.y + sl * P.yss + (YB ? 0 : c * P.ycs);
+    const ST *__restrict__ y = (const ST *)P.y + sl * P.yss + (YB ? 0 : c * P.ycs);
     S *__restrict__ z = (S *)P.z + (sl * P.L) * P.C + c;
     const int64_t lf = l + P.off;
     int64_t jlo = lf - (M - 1); if (jlo < 0) jlo = 0;
-    int64_t jhi = lf + 8; if (jhi > N) jhi = N;
+    int64_t jhi = lf + R; if (jhi > N) jhi = N;
     auto ldx = [&](int64_t i) -> T { return (i >= 0 && i < M) ? IO::ld(x, (uint64_t)i * P.xts) : cv_zero<T>::v(); };
-    T acc[8], win[16];
+    // win[w + 8] = x[lf - j + w], w = -8 .. R-1: output r, tap u of the group uses w = r - u
+    T acc[R], win[R + 8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) acc[r] = cv_zero<T>::v();
+    for (int r = 0; r < R; ++r) acc[r] = cv_zero<T>::v();
     int64_t j = jlo;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) win[8 + w] = ldx(lf - j + w);
+    for (int w = 0; w < R; ++w) win[8 + w] = ldx(lf - j + w);
     for (; j < jhi; j += 8) {
 #pragma unroll
         for (int w = 0; w < 8; ++w) win[w] = ldx(lf - j - 8 + w);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const T tap = (j + u < N) ? IO::ld(y, (uint64_t)(j + u) * (YB ? 1 : P.yts)) : cv_zero<T>::v();
+            const TT tap = (j + u < N) ? IOT::ld(y, (uint64_t)(j + u) * (YB ? 1 : P.yts)) : cv_zero<TT>::v();
 #pragma unroll
-            for (int r = 0; r < 8; ++r) cv_mac(acc[r], win[8 + r - u], tap);
+            for (int r = 0; r < R; ++r) cv_mac(acc[r], win[8 + r - u], tap);
         }
 #pragma unroll
-        for (int w = 0; w < 8; ++w) win[8 + w] = win[w];
+        for (int w = R + 7; w >= 8; --w) win[w] = win[w - 8];
     }
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
+    for (int r = 0; r < R; ++r)
         if (l + r < L) IO::st(z, (uint64_t)(l + r) * P.C, acc[r]);
 }
 
-template <typename T, typename S = T>
+template <typename T, typename S = T, typename TT = T, typename ST = S>
 static hipError_t launch_conv_t(const ConvParams &P, hipStream_t s) {
     if (P.C == 1) {
         dim3 grid((unsigned)P.S, (unsigned)((P.L + CV_TL - 1) / CV_TL));
-        hipLaunchKernelGGL((conv_time_kernel<T, S>), grid, dim3(128), 0, s, P);
+        hipLaunchKernelGGL((conv_time_kernel<T, S, TT, ST>), grid, dim3(128), 0, s, P);
     } else {
-        dim3 grid((unsigned)(((P.C + 63) / 64) * P.S), (unsigned)((P.L + 31) / 32));
-        if (P.ycs == 0 && P.yts == 1) hipLaunchKernelGGL((conv_col_kernel<T, S, true>), grid, dim3(64, 4), 0, s, P);
-        else hipLaunchKernelGGL((conv_col_kernel<T, S, false>), grid, dim3(64, 4), 0, s, P);
+        dim3 grid((unsigned)(((P.C + 63) / 64) * P.S), (unsigned)((P.L + 4 * cv_opl<T>::V - 1) / (4 * cv_opl<T>::V)));
+        if (P.ycs == 0 && P.yts == 1) hipLaunchKernelGGL((conv_col_kernel<T, S, TT, ST, true>), grid, dim3(64, 4), 0, s, P);
+        else hipLaunchKernelGGL((conv_col_kernel<T, S, TT, ST, false>), grid, dim3(64, 4), 0, s, P);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_conv(const ConvParams &P, int dtype, int cplx, hipStream_t s) {
+// y_real: complex x and z, real y (cplx must be set)
+hipError_t launch_conv(const ConvParams &P, int dtype, int cplx, int y_real, hipStream_t s) {
+    if (cplx && y_real) {
+        if (dtype == QDAS_F16) return launch_conv_t<float2, cv_half2, float, _Float16>(P, s);
+        if (dtype == QDAS_F32) return launch_conv_t<float2, float2, float, float>(P, s);
+        return launch_conv_t<double2, double2, double, double>(P, s);
+    }
     if (dtype == QDAS_F16) return cplx ? launch_conv_t<float2, cv_half2>(P, s) : launch_conv_t<float, _Float16>(P, s);
     if (dtype == QDAS_F32) return cplx ? launch_conv_t<float2>(P, s) : launch_conv_t<float>(P, s);
     return cplx ? launch_conv_t<double2>(P, s) : launch_conv_t<double>(P, s);

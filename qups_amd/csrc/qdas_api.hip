@@ -1482,6 +1482,7 @@ extern "C" int qdas_convd(const qdas_convd_desc *d, const void *x, const void *y
     if (d->shape != QDAS_CONV_FULL && d->shape != QDAS_CONV_SAME && d->shape != QDAS_CONV_VALID && d->shape != QDAS_CONV_CAUSAL)
         return fail(QDAS_EINVAL, "convd: shape must be one of {'full', 'same', 'valid'}");
     if (d->bcast & ~15) return fail(QDAS_EINVAL, "convd: unknown broadcast bits");
+    if (d->y_real && !d->cplx) return fail(QDAS_EINVAL, "convd: y_real describes complex data with real taps (cplx must be 1)");
     if (d->M >= (1ull << 31) || d->N >= (1ull << 31)) return fail(QDAS_EUNSUPPORTED, "convd: at most 2^31 - 1 samples along the convolved dimension");
     const uint64_t L = qdas_convd_len(d->M, d->N, d->shape);
     if (L == 0 || d->C == 0 || d->S == 0) return QDAS_OK;
@@ -1498,7 +1499,7 @@ extern "C" int qdas_convd(const qdas_convd_desc *d, const void *x, const void *y
     const uint64_t Cx = (d->bcast & QDAS_CONV_X_ONE_COLUMN) ? 1 : d->C, Cy = (d->bcast & QDAS_CONV_Y_ONE_COLUMN) ? 1 : d->C;
     p.xcs = Cx == 1 && d->C > 1 ? 0 : 1; p.xts = Cx; p.xss = (d->bcast & QDAS_CONV_X_ONE_SLICE) ? 0 : Cx * d->M;
     p.ycs = Cy == 1 && d->C > 1 ? 0 : 1; p.yts = Cy; p.yss = (d->bcast & QDAS_CONV_Y_ONE_SLICE) ? 0 : Cy * d->N;
-    HIPCHK(launch_conv(p, d->dtype, d->cplx ? 1 : 0, (hipStream_t)stream));
+    HIPCHK(launch_conv(p, d->dtype, d->cplx ? 1 : 0, d->y_real ? 1 : 0, (hipStream_t)stream));
     return QDAS_OK;
 }
 

@@ -91,7 +91,7 @@ struct ConvParams {
     uint64_t xcs, xts, xss;          // element strides of x: column, time, slice (0 = broadcast)
     uint64_t ycs, yts, yss;
 };
-hipError_t launch_conv(const ConvParams &P, int dtype, int cplx, hipStream_t s);
+hipError_t launch_conv(const ConvParams &P, int dtype, int cplx, int y_real, hipStream_t s);
 
 // ---- layout.hip: out[c][b][a] = in[a][b][c]
 hipError_t launch_permute3(const void *in, void *out, uint64_t A, uint64_t B, uint64_t C, int elem_bytes, hipStream_t s);

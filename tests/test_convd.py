@@ -110,6 +110,13 @@ def test_convd_shapes_dims_and_broadcast(sz_x, sz_y, dim, shape):
     xr, yr = x.real.copy(), y.real.copy()                                                  # real data, mixed precision -> single
     zr = convd(torch.from_numpy(xr.astype(np.float64)), torch.from_numpy(yr), dim, shape)
     assert zr.dtype == torch.float32 and rel(zr.cpu().numpy(), O.convd(xr, yr, dim, shape)[0]) <= 2e-5
+    zm = convd(torch.from_numpy(x), torch.from_numpy(yr), dim, shape)                        # complex traces, real taps: the taps stay real on the device
+    assert zm.dtype == torch.complex64 and rel(zm.cpu().numpy(), O.convd(x, yr, dim, shape)[0]) <= 2e-5
+    zh = convd(torch.from_numpy(x), torch.from_numpy(yr).to(torch.float16), dim, shape)     # ... also in half precision (convch)
+    assert zh.dtype == torch.complex32
+    zh = torch.view_as_complex(torch.view_as_real(zh).float()).cpu().numpy()
+    x16 = x.real.astype(np.float16).astype(np.float64) + 1j * x.imag.astype(np.float16).astype(np.float64)
+    assert rel(zh, O.convd(x16, yr.astype(np.float16).astype(np.float64), dim, shape)[0]) <= 2e-3
 
 
 @pytest.mark.gpu

@@ -89,10 +89,15 @@ for name, (T, K) in {"C1 2048 x 2048": (2048, 2048), "C2 2048 x 16384": (2048, 1
     h = torch.randn((129, 1), generator=g, device=dev, dtype=torch.float32)
     try:
         ms = timed(lambda: convd(xc, h, 1, "same"))
-        line(f"convd 'same' {name} * 129 taps", ms, 2 * xc.numel() * 8, f"{xc.numel() * 129 * 4 * 2 / ms / 1e9:.1f} TFLOP/s fp32 (complex x real MAC = 4 flop)")
+        line(f"convd 'same' {name} * 129 taps", ms, 2 * xc.numel() * 8, f"{xc.numel() * 129 * 4 / ms / 1e9:.1f} TFLOP/s fp32 (complex x real tap = 2 FMA)")
     except Exception as ex:
         print("convd:", name, repr(ex))
     del xc
+xc = rn(16384, 2048)                                                    # the same traces in MATLAB memory order (time fastest): the LDS-staged kernel
+h = torch.randn((1, 129), generator=g, device=dev, dtype=torch.float32)
+ms = timed(lambda: convd(xc, h, 2, "same"))
+line("convd 'same' C2 2048 x 16384 * 129 taps, time fastest", ms, 2 * xc.numel() * 8, f"{xc.numel() * 129 * 4 / ms / 1e9:.1f} TFLOP/s fp32")
+del xc
 
 # ---- das_lut (bfDASLUT's kernel: delay tables instead of geometry) at C1 / C2 sizes, cubic, summed over receivers and transmits
 for cfg in ("c1", "c2"):
@@ -108,7 +113,7 @@ for cfg in ("c1", "c2"):
     else:
         dv = Pi.t().reshape(I, 1, 3) - Pvt[:3].t().reshape(1, M, 3)
         ttx = (torch.sign(dv[..., 2]) * dv.norm(dim=2) + Pvt[2].reshape(1, M)) * (w["fs"] / w["c0"]) - w["t0"] * w["fs"]   # virtual sources
-    trx, ttx = trx.contiguous(), ttx.contiguous()
+    trx, ttx = trx.reshape(w["I1"], w["I2"], N).contiguous(), ttx.reshape(w["I1"], w["I2"], M).contiguous()      # I1 x I2 x N: the image shape lets the fused tiled kernel take the call
     try:
         ms = timed(lambda: das_lut(xl, trx, ttx, interp="cubic"), reps=3)
         line(f"das_lut {cfg.upper()} I={I} N={N} M={M} cubic (geometric tables)", ms, xl.numel() * 8 + (trx.numel() + ttx.numel()) * 4 + I * 8, f"{I * N * M / ms / 1e6:.1f} Gpair/s")
