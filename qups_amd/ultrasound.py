@@ -169,6 +169,40 @@ class ChannelData:
             t0 = np.asarray(t0, float) - L / self.fs if np.ndim(t0) else float(t0) - L / self.fs
         return ChannelData(y, t0, self.fs, self.order)
 
+    def hilbert(self, N=None):
+        """analytic signal along time (reference ``src/ChannelData.m:935-966``: ``hilbert(chd, N)``, zero-padded / truncated to ``N`` points)
+        on the device: real fp32 / int16 traces go through the one-pass kernel of ``qdas_pre_*`` (``qups_amd/csrc/pre.hip``)"""
+        from .preproc import hilbert
+        d = self._torch_data()
+        ax = self.order.index("T")
+        if d.is_complex():
+            raise DasError("hilbert expects real data")
+        y = hilbert(d.movedim(ax, 0), N)
+        return ChannelData(y.movedim(0, ax), self.t0, self.fs, self.order)
+
+    def downmix(self, fc: float):
+        """``chd.data .* exp(-2i*pi*fc*time)`` (reference ``src/ChannelData.m:757-766``); for real traces the Hilbert transform and the mixing are
+        ONE pass over the data (``hilbert`` with ``fdown``), complex data are multiplied on the device"""
+        import torch
+        d = self._torch_data()
+        ax = self.order.index("T")
+        t0 = np.asarray(self.t0, float)
+        if not d.is_cuda:
+            if not torch.cuda.is_available():
+                raise RuntimeError("qups_amd: no HIP device visible -- downmix has no CPU fallback")
+            d = d.cuda()
+        n = torch.arange(d.shape[ax], device=d.device, dtype=torch.float64).reshape((1,) * ax + (-1,) + (1,) * (d.ndim - ax - 1))
+        if t0.size == 1:
+            t0t = float(t0.reshape(-1)[0])
+        else:                                                        # one start time per transmit: an array that broadcasts against the data
+            if t0.ndim > d.ndim or any(a not in (1, b) for a, b in zip(t0.shape, d.shape)):
+                raise DasError("downmix: t0 must be a scalar or broadcast against the data")
+            t0t = torch.from_numpy(t0.reshape(t0.shape + (1,) * (d.ndim - t0.ndim))).to(d.device)
+        cyc = fc * (t0t + n / self.fs)
+        ph = (-2.0 * np.pi) * (cyc - torch.floor(cyc))
+        cdt = torch.complex128 if d.dtype in (torch.float64, torch.complex128) else torch.complex64
+        return ChannelData(d.to(cdt) * torch.polar(torch.ones_like(ph), ph).to(cdt), self.t0, self.fs, self.order)
+
     def downsample(self, ratio: int):
         """every ``ratio``-th sample along time (reference ``src/ChannelData.m:1042-1058``: ``subD(chd, 1:ratio:chd.T, chd.tdim)``); ``fs`` follows"""
         ratio = int(ratio)

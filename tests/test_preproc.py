@@ -123,3 +123,32 @@ def test_real_rf_hilbert_then_das_equals_das_of_the_analytic_data():
     b_ref = das_spec("DAS", *args, torch.from_numpy(ref_x), case["t0"], case["fs"], case["c"], *opts)
     torch.cuda.synchronize()
     assert rel_err(b_dev.cpu().numpy(), b_ref.cpu().numpy()) <= 2e-5
+
+
+@pytest.mark.gpu
+def test_channeldata_hilbert_downmix_downsample_chain():
+    """the reference's demodulation chain (src/ChannelData.m:757-800 example: hilbert -> downmix -> downsample) through the ChannelData mirror:
+    against the numpy restatement, for time first and time last, scalar and per-transmit start times"""
+    import torch
+    from qups_amd.ultrasound import ChannelData
+    rng = np.random.default_rng(8)
+    T, N, M, fs, fc = 1024, 6, 5, 20e6, 5e6
+    x = rng.standard_normal((T, N, M)).astype(np.float32)
+    t0 = -1.3e-6
+    chd = ChannelData(torch.from_numpy(x).cuda(), t0, fs)
+    a = chd.hilbert()
+    ref = hilbert_ref(x.astype(np.float64))
+    assert a.data.dtype == torch.complex64 and np.abs(a.data.cpu().numpy() - ref).max() / np.abs(ref).max() <= 2e-5
+    b = a.downmix(fc)
+    tt = (t0 + np.arange(T) / fs).reshape(T, 1, 1)
+    refb = ref * np.exp(-2j * np.pi * fc * tt)
+    assert np.abs(b.data.cpu().numpy() - refb).max() / np.abs(refb).max() <= 2e-5
+    c = b.downsample(4)
+    assert c.fs == fs / 4 and np.abs(c.data.cpu().numpy() - refb[::4]).max() / np.abs(refb).max() <= 2e-5
+    t0v = np.linspace(-1e-6, 1e-6, M).reshape(1, 1, M)                                    # one start time per transmit
+    bv = ChannelData(a.data, t0v, fs).downmix(fc)
+    refv = ref * np.exp(-2j * np.pi * fc * (t0v + np.arange(T).reshape(T, 1, 1) / fs))
+    assert np.abs(bv.data.cpu().numpy() - refv).max() / np.abs(refv).max() <= 2e-5
+    p = ChannelData(torch.from_numpy(np.ascontiguousarray(x.transpose(1, 2, 0))).cuda(), t0, fs, "NMT").hilbert(1280)      # time last, zero-padded
+    refp = hilbert_ref(x.astype(np.float64), 1280)
+    assert tuple(p.data.shape) == (N, M, 1280) and np.abs(p.data.cpu().numpy().transpose(2, 0, 1) - refp).max() / np.abs(refp).max() <= 2e-5
