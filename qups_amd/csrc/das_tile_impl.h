@@ -109,7 +109,7 @@ struct TileCfg {
     static_assert(!BIG || (!SYM && !FBX), "the re-basing general kernel runs one frame per launch");
     static_assert(!LUT || (!SYM && !FBX && !BIG), "table-driven delays: general mode, one frame per launch");
     static_assert(!BF || (!SYM && !FBX && !BIG && !LUT && sizeof(ST_) == 8), "'BF': general mode, fp32 data, one frame per launch");
-    static_assert(!F64 || (!FMOD && !SYM && !FBX && !BIG && !LUT && !BF), "fp64 data: the plain 'DAS' sum (optionally with a weight table), one frame per launch");
+    static_assert(!F64 || (!SYM && !FBX && !BIG && !LUT && !BF), "fp64 data: the 'DAS' sum (optionally remodulated / with a weight table), one frame per launch");
     static_assert(FB4 ? (2 * MB == WAVES) : (MB % WAVES == 0 && MB % 2 == 0), "staging split");
     static_assert(WB % 16 == 0, "window must be a whole number of 16-byte lanes");
 };
@@ -605,7 +605,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         if constexpr (C::F64) { const rec64 r = nrec64[n]; rec_b = r.b; rec_x = r.x; rec_y = r.y; rec_z = r.z; }
         else { const float4 r = nrec[n]; rec_b = __float_as_int(r.x); rec_x = r.y; rec_y = r.z; rec_z = r.w; }
         float phB = 0.f;                               // remodulation: frac(B[n]*fmod/fs) (tile_prologue.h)
-        if constexpr (C::FMOD) {
+        if constexpr (C::FMOD && !C::F64) {              // (fp64 data: the pair loop forms the whole phase in double)
             phB = Bext[n];
             if constexpr (C::MIRQ) phB = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(phB)));   // (uniform: a scalar register -- the one vector register the four window sets are short of)
         }
@@ -852,9 +852,12 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
         if constexpr (FB2 || FB4) return hipErrorInvalidValue;    // the window fit does not depend on the frame count: probes use one frame
         else { QDAS_LAUNCH_P(false, false, true); return hipGetLastError(); }
     }
-    if constexpr (sizeof(ST) == 16) {                  // fp64 data: no remodulation, no pixel x receiver weight (qdas_api.hip)
-        if (fm || P.apix || P.gen_kind || P.syn) return hipErrorInvalidValue;
-        if (wt) QDAS_LAUNCH(false, true); else QDAS_LAUNCH(false, false);    // (grid: ntiles * ksplit workgroups, as for the other data types)
+    if constexpr (sizeof(ST) == 16) {                  // fp64 data: no pixel x receiver weight, no kept dimension (qdas_api.hip)
+        if (P.apix || P.gen_kind || P.syn) return hipErrorInvalidValue;
+        if (fm && wt) QDAS_LAUNCH(true, true);         // (grid: ntiles * ksplit workgroups, as for the other data types)
+        else if (fm)  QDAS_LAUNCH(true, false);
+        else if (wt)  QDAS_LAUNCH(false, true);
+        else          QDAS_LAUNCH(false, false);
     } else if constexpr (MIRQ) {                      // (a weight table must be mirror-symmetric too: checked by the host)
         if (fm && wt) QDAS_LAUNCH(true, true);
         else if (fm)  QDAS_LAUNCH(true, false);

@@ -450,7 +450,6 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     bool eligible = (!syn && !bfm) || dt == QDAS_F32;
     const char *why = "tiled kernel needs the 'DAS' mode (or fp32 data and 'SYN' / 'MUL' / 'BF')";
     // fp64 data (das_tile_impl.h "F64"): the plain sum with pixel-independent weights, scalar sound speed, no remodulation
-    if (eligible && dt == QDAS_F64 && desc->fmod != 0.0) { eligible = false; why = "tiled kernel, fp64 data: remodulation needs the generic kernel"; }
     if (eligible && dt == QDAS_F64 && desc->rx_apod_kind) { eligible = false; why = "tiled kernel, fp64 data: a generated receive apodization needs the generic kernel"; }
     // sound speed: a scalar, or a full per-pixel map (contiguous I1 x I2 x I3, no aperture dependence): the delay stays separable
     bool cmap = false;

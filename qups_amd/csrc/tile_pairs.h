@@ -234,13 +234,15 @@ template <class C> template <bool CHECK, bool TAILV>
 __device__ __forceinline__ void Tile<C>::pairs_f64(uint32_t n, uint32_t m0, int bn, double rb, uint32_t cbase) {
     constexpr int K = C::K, MB = C::MB, WB = C::WB, INTERP = C::INTERP;
     double lead[4];
-    weights1_lead<INTERP>(lead);
+    weights1_lead<INTERP, !C::FMOD>(lead);
+    const double fq = C::FMOD ? P.fmod / fs : 0.0;    // cycles per sample (uniform)
     unroll<MB>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
         if constexpr (!hooks::no_fair_prio && (p * 4) % MB == 0) __builtin_amdgcn_s_setprio(QDAS_PAIR_PRIO(3 - (p * 4) / MB));     // fair progress, see pairs_plain
         const uint32_t m = m0 + p;
         if constexpr (TAILV) { if (m >= M) return; }
-        double wr = 1.0, wi = 0.0;
+        if constexpr (C::FMOD) __builtin_amdgcn_sched_barrier(0);   // one transmit at a time: the phasor polynomial's registers never meet the next transmit's taps
+        double wr = 1.0, wi = 0.0;                                   // (the other three waves of the SIMD cover the LDS latency: ~60 fp64 operations per pair)
         if constexpr (C::WTAB) {
             const double2 wv = ((const double2 *)P.wtab)[n + (size_t)N * m];
             wr = wv.x; wi = wv.y;
@@ -256,7 +258,7 @@ __device__ __forceinline__ void Tile<C>::pairs_f64(uint32_t n, uint32_t m0, int 
         if constexpr (K > 1) weights1<INTERP>(s, w, lead);  // overlaps the LDS latency
         lds_fence<K>(g, w);
         double &ar = dacc[2 * (p & 1)], &ai = dacc[2 * (p & 1) + 1];
-        if constexpr (K > 1 && !CHECK && !C::WTAB) {
+        if constexpr (K > 1 && !CHECK && !C::WTAB && !C::FMOD) {
 #pragma unroll
             for (int k = 0; k < K; ++k) { ar = __builtin_fma(w[k], g.s[k].x, ar); ai = __builtin_fma(w[k], g.s[k].y, ai); }
         } else {
@@ -271,6 +273,14 @@ __device__ __forceinline__ void Tile<C>::pairs_f64(uint32_t n, uint32_t m0, int 
                 const double lo = (double)tapinfo<INTERP>::LO - 0.5 - (double)ws, hi = (double)(T - K + 1 - ws) - 0.5;
                 const bool keep = (t >= lo) && (t < hi);
                 vr = keep ? vr : 0.0; vi = keep ? vi : 0.0;
+            }
+            if constexpr (C::FMOD) {                  // src/bf.cu:117 in double: exp(2j pi fmod tau), tau*fs = t + 1/2 + (A[m] + B[n]) - OFF
+                __builtin_amdgcn_sched_barrier(0);    // after the taps are consumed: the polynomial's temporaries never overlap them
+                const double ph = (t + ((double)(Abase[m] + bn) + (0.5 - (double)tapinfo<INTERP>::OFF))) * fq;
+                double c, sn;
+                sincos2pi_f64(ph - __builtin_rint(ph), c, sn);
+                const double xr = vr * c - vi * sn, xi = vr * sn + vi * c;
+                vr = xr; vi = xi;
             }
             if constexpr (C::WTAB) { ar += wr * vr - wi * vi; ai += wr * vi + wi * vr; }
             else { ar += vr; ai += vi; }

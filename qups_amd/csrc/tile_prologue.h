@@ -143,7 +143,7 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
     if constexpr (PROBE) return false;
     // every window of every stage strictly inside the record?  (uniform) -> branch-free loop
     tile_interior = (a_lo + b_lo >= 1.0f) && (a_hi + b_hi + (float)(K + 1) < (float)T);
-    if constexpr (C::FMOD) {                           // remodulation phase constants (cycles) of the window bases, tile_pairs.h
+    if constexpr (C::FMOD && !C::F64) {                // remodulation phase constants (cycles) of the window bases, tile_pairs.h
         const double f = P.fmod / fs;
         for (uint32_t m = tid; m < M; m += THREADS) { const double c = ((double)Abase[m] + 0.5 - tapinfo<INTERP>::OFF) * f; Aext[m] = (float)(c - floor(c)); }
         for (uint32_t n = tid; n < N; n += THREADS) { const double c = (double)__float_as_int(nrec[n].x) * f; Bext[n] = (float)(c - floor(c)); }

@@ -74,12 +74,12 @@ template <int D> __device__ __forceinline__ void horner4(const double (&a)[D + 1
     }
 }
 // the four leading coefficients of the fp64 Lanczos polynomials, in vector registers (nothing for the other interpolators)
-template <int INTERP> __device__ __forceinline__ void weights1_lead(double (&lead)[4]) {
+template <int INTERP, bool PIN = true> __device__ __forceinline__ void weights1_lead(double (&lead)[4]) {
     if constexpr (INTERP == 3) {
         constexpr double EI[] = QDAS_LANCZOS64_EI, OI[] = QDAS_LANCZOS64_OI, EO[] = QDAS_LANCZOS64_EO, OO[] = QDAS_LANCZOS64_OO;
         constexpr int D = sizeof(EI) / 8 - 1;
         lead[0] = EI[D]; lead[1] = OI[D]; lead[2] = EO[D]; lead[3] = OO[D];
-        asm volatile("" : "+v"(lead[0]), "+v"(lead[1]), "+v"(lead[2]), "+v"(lead[3]));
+        if constexpr (PIN) asm volatile("" : "+v"(lead[0]), "+v"(lead[1]), "+v"(lead[2]), "+v"(lead[3]));   // (kept in registers unless the variant has none to spare)
     } else { lead[0] = lead[1] = lead[2] = lead[3] = 0.0; }
 }
 template <int INTERP> __device__ __forceinline__ void weights1(double s, double (&w)[4], const double (&lead)[4]) {
@@ -195,6 +195,34 @@ static __device__ __noinline__ double block_residual64(double px, double py, dou
     double dv = dot;
     if (kindB != 2) { const double len = sqrt(rx * rx + ry * ry + rz * rz); dv = kindB == 0 ? len : copysign(len, dot); }
     return (dv * cf - Pv[4 * m + 3] * fs + off) - ((double)Abase_m + 0.5);
+}
+// cos and sin of 2 pi r for |r| <= 1/2 in fp64 (remodulation of fp64 data: the reference's cospi / sinpi, src/bf.cu:117): quarter-turn
+// reduction, then the Taylor polynomials on |y| <= pi/4 (truncation below 1e-16); branch-free, about 27 fp64 operations
+static __device__ __forceinline__ void sincos2pi_f64(double r, double &c, double &s) {
+    const double q = __builtin_rint(4.0 * r);                             // -2 .. 2
+    const double y = (r - 0.25 * q) * 6.283185307179586476925;
+    const double y2 = y * y;
+    double sp = -1.0 / 1307674368000.0;
+    sp = __builtin_fma(sp, y2, 1.0 / 6227020800.0);
+    sp = __builtin_fma(sp, y2, -1.0 / 39916800.0);
+    sp = __builtin_fma(sp, y2, 1.0 / 362880.0);
+    sp = __builtin_fma(sp, y2, -1.0 / 5040.0);
+    sp = __builtin_fma(sp, y2, 1.0 / 120.0);
+    sp = __builtin_fma(sp, y2, -1.0 / 6.0);
+    const double sy = __builtin_fma(sp * y2, y, y);
+    double cp = 1.0 / 20922789888000.0;
+    cp = __builtin_fma(cp, y2, -1.0 / 87178291200.0);
+    cp = __builtin_fma(cp, y2, 1.0 / 479001600.0);
+    cp = __builtin_fma(cp, y2, -1.0 / 3628800.0);
+    cp = __builtin_fma(cp, y2, 1.0 / 40320.0);
+    cp = __builtin_fma(cp, y2, -1.0 / 720.0);
+    cp = __builtin_fma(cp, y2, 1.0 / 24.0);
+    cp = __builtin_fma(cp, y2, -0.5);
+    const double cy = __builtin_fma(cp, y2, 1.0);
+    const int qi = (int)q & 3;                                           // quarter turns: 0: (c, s); 1: (-s, c); 2: (-c, -s); 3: (s, -c)
+    const double cc = (qi & 1) ? sy : cy, ss = (qi & 1) ? cy : sy;
+    c = (qi == 1 || qi == 2) ? -cc : cc;
+    s = (qi >= 2) ? -ss : ss;
 }
 // generated pixel x receiver weight (qdas.h QDAS_RXAPOD_*): element position from the LDS record, normal by scalar loads
 static __device__ __noinline__ float rx_apod_generated(int kind, double p0, double p1, float px, float py, float pz, float ex, float ey, float ez,

@@ -322,10 +322,10 @@ def test_double_precision():
     assert rel_err(out, ref) <= 1e-10
 
 
-def _oracle64(case, apod=(), x=None, t0=None):
+def _oracle64(case, apod=(), x=None, t0=None, fmod=0.0):
     from oracle import das_oracle as O
     return O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"] if x is None else x, case["t0"] if t0 is None else t0,
-                      case["fs"], case["c"], VS=case["VS"], DV=case["DV"], interp=case["interp"], apod=apod)
+                      case["fs"], case["c"], VS=case["VS"], DV=case["DV"], interp=case["interp"], apod=apod, fmod=fmod)
 
 
 @pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3", "cubic_dev"])
@@ -342,6 +342,44 @@ def test_double_precision_in_the_tiled_kernel(seq, interp):
     assert rel_err(out, ref) <= 1e-10
     gen, _ = run_das(case, kernel=1, prec="double")
     assert rel_err(out, gen) <= 1e-10
+
+
+@pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3", "cubic_dev"])
+@pytest.mark.parametrize("seq", ["FSA", "PW", "DV"])
+def test_double_precision_remodulation_in_the_tiled_kernel(seq, interp):
+    """fp64 baseband data on the fused kernel: the remodulation phasor exp(2j pi fmod tau) of every sample (src/bf.cu:117, cospi / sinpi in
+    double) -- phase in fp64 from the window bases, quarter-turn reduction + polynomial -- to the 1e-10 bar of this precision"""
+    case = make_case(seq=seq, interp=interp, seed=5, I1=150, I2=19, M=9 if seq != "FSA" else None)        # (odd transmit count: tail block)
+    fmod = 3.1e6
+    ref = _oracle64(case, fmod=fmod)
+    out, plan = run_das(case, kernel=2, prec="double", fmod=fmod)
+    assert plan.kernel == "tiled" and ",f64" in plan.kernel_name() and ",fmod" in plan.kernel_name(), plan.kernel_name()
+    assert plan.fallback_tiles() == 0
+    assert rel_err(out, ref) <= 1e-10
+    gen, _ = run_das(case, kernel=1, prec="double", fmod=fmod)
+    assert rel_err(out, gen) <= 1e-10
+
+
+def test_double_precision_remodulation_variants():
+    """remodulation of fp64 data together with a weight table (one zero weight), with a record shorter than the path (checked loop) and
+    with a negative modulation frequency"""
+    rng = np.random.default_rng(6)
+    case = make_case(seq="PW", interp="lanczos3", seed=22, I1=90, I2=23, N=24, M=19)
+    N, M = case["N"], case["M"]
+    wn = rng.uniform(0.2, 1, (1, 1, 1, N, 1))
+    wm = rng.uniform(0, 1, (1, 1, 1, 1, M)) * (1 - 0.25j)
+    wm[..., 5] = 0.0
+    for fmod in (4.0e6, -2.5e6):
+        out, plan = run_das(case, kernel=2, prec="double", apod=(wn, wm), fmod=fmod)
+        assert plan.kernel == "tiled" and ",wtab" in plan.kernel_name() and ",fmod" in plan.kernel_name()
+        assert rel_err(out, _oracle64(case, apod=(wn, wm), fmod=fmod)) <= 1e-10
+    for interp in ("nearest", "cubic"):
+        case = make_case(seq="FSA", interp=interp, seed=14, T=300, data="noise", zlim=(1e-3, 30e-3), I1=128, I2=8)
+        ref = _oracle64(case, fmod=2.0e6)
+        out, plan = run_das(case, kernel=2, prec="double", fmod=2.0e6)
+        dead = np.abs(ref) == 0
+        assert plan.kernel == "tiled" and dead.any() and np.all(out[dead] == 0), interp
+        assert rel_err(out, ref) <= 1e-10, interp
 
 
 @pytest.mark.parametrize("ks", [2, 3, 4])
