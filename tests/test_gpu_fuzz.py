@@ -36,8 +36,8 @@ def _draw(seed):
     elif extra["bf"] and cfg["prec"] == "single":
         cfg.update(fun="BF", F=min(cfg["F"], 2))
     cfg.update(extra)
-    if r.integers(0, 8) == 0 and not extra["sym"] and cfg["fun"] != "BF":   # fp64 data on the fused kernel: plain 'DAS', pixel-independent weights
-        cfg.update(prec="double", fmod=0.0, wpix=False, gen="", fun="DAS", cmap=False, jit=False)
+    if r.integers(0, 8) == 0 and not extra["sym"] and cfg["fun"] != "BF":   # fp64 data on the fused kernel: 'DAS', pixel-independent weights,
+        cfg.update(prec="double", wpix=False, gen="", fun="DAS", cmap=False, jit=False)   # remodulation (round 3: the drawn fmod stays)
     # a pixel x TRANSMIT weight (scanline-style transmit apodization): fused with the roles of the apertures swapped
     cfg["wpm"] = bool(r.integers(0, 10) == 0) and cfg["fun"] == "DAS" and not cfg["wpix"] and not cfg["gen"] and not cfg["sym"] and cfg["prec"] != "double"
     # pixel pitch: ~lambda/3 (2.6 samples of delay per pixel), ~lambda (the 384-sample windows of the second attempt), ~1.6 lambda (tiles that fall back)
