@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the whole acquisition -> image chain on one MI355X for a stream of frames:
 
-    pinned host int16 RF (T x N x M real) --H2D--> hilbert (pre.hip, hipFFT) -> [FIR band-pass (conv.hip)] -> DAS (tiled kernel)
+    pinned host int16 RF (T x N x M real) --H2D--> hilbert (pre.hip, one pass) -> [FIR band-pass (conv.hip)] -> DAS (tiled kernel)
 
 Stage by stage (synchronised) and pipelined (uploads on a copy stream, double-buffered, overlapping the kernels of the previous
 frame).  Usage: python tools/pipeline_bench.py [workload=c3] [frames=6] [taps=0]"""
@@ -20,7 +20,7 @@ dev = torch.device("cuda:0")
 xt = torch.zeros((1, 1, 1), dtype=torch.complex64)
 prob = build_problem("DAS", w["Pi"], w["Pr"], w["Pv"], w["Nv"], (T, N, M), w["t0"], w["fs"], w["c0"],
                      parse_options(xt, list(w["opt"]) + ["interp", w["interp"]]))
-plan = DasPlan(prob, device=dev)
+plan = DasPlan(prob, device=dev, jit=True)             # the kernel bench.py times (hiprtc build of the plan)
 L = _lib.lib()
 pd = _lib.PreDesc(T, K, T, _lib.QDAS_PRE_I16, 0, float(w["fs"]), 0.0, 0.0)
 hp = C.c_void_p()
