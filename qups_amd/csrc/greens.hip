@@ -10,27 +10,34 @@
 // branch, src/UltrasoundSystem.m:797-803; its device kernel divides by R0^2 and returns inf there, src/greens.cu:84).
 //
 // MI355X mapping.  The reference runs one thread per (s, n, m) that recomputes both distances for every scatterer.  Here a
-// workgroup owns one (n, m) trace: the delay and amplitude of every (scatterer, sub-aperture pair) is computed ONCE per trace by
-// the workgroup (256 entries per pass, staged in LDS), then every lane walks the LDS table for its output samples and only
-// interpolates entries whose waveform actually covers the sample; the waveform itself sits in LDS when it fits.
+// workgroup owns 1024 samples of one (n, m) trace: the delay and amplitude of every (scatterer, sub-aperture pair) is computed ONCE per
+// block by the workgroup (256 entries per pass), the entries are binned in LDS by the wave whose 256 samples they reach, and every wave
+// walks its own lists only; the waveform itself sits in LDS when it fits.
 #include "qdas_device.h"
 #include "qdas_kernels.h"
 
 namespace qdas {
 
 constexpr int GR_CHUNK = 256;
+constexpr int GR_SPT = 4;                              // output samples per lane: a wave owns 64 * GR_SPT CONSECUTIVE samples of the block
 __device__ __forceinline__ float  gsqrt(float v)  { return sqrtf(v); }
 __device__ __forceinline__ double gsqrt(double v) { return sqrt(v); }
 
+// Round 3: the entries of a chunk are BINNED by the wave whose samples they touch.  Pass 1 (all lanes, one entry each): delay and amplitude,
+// then per consumer wave a ballot + prefix count appends the entry to that wave's list (one segment per producer wave: no cross-wave prefix,
+// and the order within a list is the entry order -- sums are formed in the same order as before, bit for bit).  Pass 2: every wave walks ITS
+// lists only -- entries that actually arrive in its 256 samples -- instead of testing every entry of the chunk.
 template <int INTERP, typename TY>
 __global__ void __launch_bounds__(256) greens_kernel(const GreensParams P) {
     using R  = typename TY::real;
     using ST = typename TY::store;
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
-    R *dly = (R *)gsm;                                   // [GR_CHUNK] first-sample delay of the entry, in output samples
-    cplx<R> *amp = (cplx<R> *)(dly + GR_CHUNK);          // [GR_CHUNK] a_i / (r1 r2 fsr)
-    ST *xl = (ST *)(amp + GR_CHUNK);                     // [T] waveform copy (only if P.x_in_lds)
-    const uint32_t n = blockIdx.y, m = blockIdx.z, tid = threadIdx.x;
+    cplx<R> *amp = (cplx<R> *)gsm;                       // [4 consumer][4 producer][64] a_i / (r1 r2 fsr)
+    R *dly = (R *)(amp + 16 * 64);                       // [4][4][64] first-sample delay of the entry, in output samples
+    int *cnt = (int *)(dly + 16 * 64);                   // [4][4]
+    ST *xl = (ST *)(cnt + 16);                           // [T] waveform copy (only if P.x_in_lds)
+    const uint32_t n = blockIdx.y, m = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const R *Ps = (const R *)P.Ps, *Pr = (const R *)P.Pr, *Pv = (const R *)P.Pv;
     const ST *a = (const ST *)P.a;
     const ST *x = (const ST *)P.x;
@@ -43,20 +50,21 @@ __global__ void __launch_bounds__(256) greens_kernel(const GreensParams P) {
     const R span = (R)((double)T / P.fsr) + (R)2;        // output samples one waveform can touch (+ interpolator margin)
     const int EE = P.En * P.Em;
     const uint64_t entries = I * (uint64_t)EE;
-    // this lane's output samples: s = blockIdx.x*256*SPT + tid + 256*q
-    constexpr int SPT = 4;
-    const uint64_t s0i = (uint64_t)blockIdx.x * (256 * SPT) + tid;
+    constexpr int SPT = GR_SPT, WS = 64 * SPT;           // samples per wave
+    // this lane's output samples: s = blockIdx.x * 256 * SPT + wave * 64 * SPT + lane + 64 * q
+    const uint64_t s0i = (uint64_t)blockIdx.x * (256 * SPT) + (uint64_t)wave * WS + lane;
     cplx<R> acc[SPT];
 #pragma unroll
     for (int q = 0; q < SPT; ++q) acc[q] = {(R)0, (R)0};
-    const R blk_lo = (R)((uint64_t)blockIdx.x * (256 * SPT)), blk_hi = blk_lo + (R)(256 * SPT);
+    const R blk_lo = (R)((uint64_t)blockIdx.x * (256 * SPT));
 
     for (uint64_t e0 = 0; e0 < entries; e0 += GR_CHUNK) {
-        __syncthreads();
+        __syncthreads();                                 // the lists of the previous chunk are consumed (and the waveform copy is complete)
         {   // one entry per lane: (scatterer i, receive sub-aperture ne, transmit sub-aperture me)
             const uint64_t e = e0 + tid;
-            R d = (R)INFINITY;
+            R d = (R)0;
             cplx<R> w = {(R)0, (R)0};
+            int b0 = 1, b1 = 0;                          // consumer waves the entry touches: none
             if (e < entries) {
                 const uint64_t i = e / EE;
                 const int sub = (int)(e % EE), ne = sub % P.En, me = sub / P.En;
@@ -70,23 +78,40 @@ __global__ void __launch_bounds__(256) greens_kernel(const GreensParams P) {
                 const cplx<R> ai = ld(a, i);
                 const R g = (R)1 / (r1 * r2 * fsr);
                 w = {ai.x * g, ai.y * g};
-                // cull: the entry touches output samples [d - 1, d + span]; skip it for this block of samples if disjoint
-                if (!(d + span >= blk_lo && d - (R)2 <= blk_hi)) d = (R)INFINITY;
+                // the entry touches output samples (d - 2, d + span): which waves' ranges [blk_lo + 256 b, blk_lo + 256 (b + 1)) meet that?
+                const R lo = (d - (R)2) - blk_lo, hi = (d + span) - blk_lo;
+                if (hi >= (R)0 && lo < (R)(4 * WS)) {    // (a non-finite delay fails both tests: never listed, as before)
+                    b0 = lo <= (R)0 ? 0 : (int)(lo * (R)(1.0 / WS));
+                    b1 = hi >= (R)(4 * WS) ? 3 : (int)(hi * (R)(1.0 / WS));
+                }
             }
-            dly[tid] = d; amp[tid] = w;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const bool in = b0 <= b && b <= b1;
+                const uint64_t mask = __ballot(in);
+                if (in) {
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    const uint32_t k = (uint32_t)(b * 4 + (int)wave) * 64u + pos;
+                    dly[k] = d; amp[k] = w;
+                }
+                if (lane == 0) cnt[b * 4 + (int)wave] = __builtin_popcountll(mask);
+            }
         }
         __syncthreads();
-        const int cnt = (int)((entries - e0) < (uint64_t)GR_CHUNK ? (entries - e0) : (uint64_t)GR_CHUNK);
-        for (int k = 0; k < cnt; ++k) {
-            const R d = dly[k];                          // broadcast LDS read
-            if (!(d < (R)INFINITY)) continue;            // culled for the whole workgroup (uniform)
-            const cplx<R> w = amp[k];
+#pragma unroll 1
+        for (int pw = 0; pw < 4; ++pw) {                 // this wave's lists, producer by producer: entry order
+            const int nk = __builtin_amdgcn_readfirstlane(cnt[(int)wave * 4 + pw]);
+            const uint32_t base = (uint32_t)((int)wave * 4 + pw) * 64u;
+            for (int k = 0; k < nk; ++k) {
+                const R d = dly[base + k];               // broadcast LDS reads
+                const cplx<R> w = amp[base + k];
 #pragma unroll
-            for (int q = 0; q < SPT; ++q) {
-                const R tau = (R)(s0i + 256 * q) - d;    // src/greens.cu:65: kernel time of this sample, in output samples
-                if (tau > (R)-2 && tau < span) {
-                    const cplx<R> v = sample_global<INTERP, R, ST>(x, (long)T, fsr * tau);   // src/greens.cu:79
-                    acc[q].x += w.x * v.x - w.y * v.y; acc[q].y += w.x * v.y + w.y * v.x;
+                for (int q = 0; q < SPT; ++q) {
+                    const R tau = (R)(s0i + 64 * q) - d; // src/greens.cu:65: kernel time of this sample, in output samples
+                    if (tau > (R)-2 && tau < span) {
+                        const cplx<R> v = sample_global<INTERP, R, ST>(x, (long)T, fsr * tau);   // src/greens.cu:79
+                        acc[q].x += w.x * v.x - w.y * v.y; acc[q].y += w.x * v.y + w.y * v.x;
+                    }
                 }
             }
         }
@@ -94,7 +119,7 @@ __global__ void __launch_bounds__(256) greens_kernel(const GreensParams P) {
     ST *y = (ST *)P.y + ((size_t)n + (size_t)m * P.N) * S;                                      // src/greens.cu:84
 #pragma unroll
     for (int q = 0; q < SPT; ++q) {
-        const uint64_t s = s0i + 256 * q;
+        const uint64_t s = s0i + 64 * q;
         if (s < S) st(y, (size_t)s, acc[q]);
     }
 }
@@ -103,7 +128,7 @@ template <typename TY>
 static hipError_t launch_greens_t(const GreensParams &P, hipStream_t s) {
     GreensParams p = P;
     const size_t esz = sizeof(typename TY::store), rsz = sizeof(typename TY::real);
-    size_t lds = GR_CHUNK * (rsz + esz);
+    size_t lds = 16 * 64 * (rsz + esz) + 16 * sizeof(int);
     p.x_in_lds = (P.T * esz <= 96 * 1024) ? 1 : 0;
     if (p.x_in_lds) lds += P.T * esz;
     const dim3 g((unsigned)((P.S + 1023) / 1024), (unsigned)P.N, (unsigned)P.M), b(256);
