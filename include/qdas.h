@@ -12,7 +12,7 @@
  * the split-delay launch of `wsinterpd2[f|h]` (kern/wsinterpd2.m:236,
  * src/interpd.cu:449-476) used by bfDAS/bfDASLUT.  The steps either side of
  * the path have their own entry points further down: `qdas_greens`
- * (src/greens.cu), `qdas_pre_*` (ChannelData.hilbert / downmix), `qdas_convd`
+ * (src/greens.cu), `qdas_shift_sum` (UltrasoundSystem.focusTx), `qdas_pre_*` (ChannelData.hilbert / downmix), `qdas_convd`
  * (src/convd.cu), and `qdas_permute3` for row-major hosts.
  *
  * Everything is plain C: pointers, sizes, no torch / HIP types in signatures
@@ -322,6 +322,29 @@ typedef struct qdas_greens_desc {
     int32_t  reserved;
 } qdas_greens_desc;
 int qdas_greens(const qdas_greens_desc *desc, void *y /* S x N x M complex */, void *stream);
+
+/* ---- Transmit synthesis (UltrasoundSystem.focusTx, reference src/UltrasoundSystem.m:3374-3503): delay-and-sum over the transmit ELEMENTS of a
+ * full-synthetic-aperture record,
+ *     y[t', n, m'] = sum_m  w[m, m'] * x(t' + shift[m, m'],  n, m),      t' = 0 .. To-1,
+ * the call the reference makes as sample2sep(chd.time, -tau, interp, apd, mdim) (:3498 -> kern/wsinterpd2.m -> src/interpd.cu:344-396) with the
+ * positions written as the record's own time grid plus one offset per (element, synthesised transmit) [samples; shift = -tau * fs after the
+ * reference's re-basing of the time axis, :3457-3463].  qdas_wsinterpd computes the same numbers from a materialised position array; this entry
+ * uses the structure (per-pair tap offset and weights, LDS-staged windows, uniform skips of zero weights; csrc/shiftsum.hip).
+ * x: T x N x M x F, y: To x N x Mo x F column-major DEVICE arrays of `dtype` (QDAS_F64 | QDAS_F32), complex or real; shift: M x Mo real(dtype),
+ * w: M x Mo real(dtype) or complex(dtype) or NULL (ones) -- DEVICE arrays, m fastest.  Real data take real weights.
+ * Edge rule as in every kernel: a term counts iff all its taps lie in [0, T) and its position is >= 0. */
+typedef struct qdas_shift_desc {
+    uint64_t T, To, N, M, Mo, F;
+    int32_t  flag;      /* interpolation, bits 0-2 of QUPS_BF_FLAG */
+    int32_t  dtype;     /* QDAS_F64 | QDAS_F32                     */
+    int32_t  cplx;      /* samples are interleaved complex         */
+    int32_t  w_real;    /* w holds real(dtype) weights             */
+    int32_t  device;    /* HIP device ordinal, -1 = current        */
+    int32_t  reserved;
+    const void *shift;
+    const void *w;
+} qdas_shift_desc;
+int qdas_shift_sum(const qdas_shift_desc *desc, const void *x, void *y, void *stream);
 
 /* ---- Batched 1-D convolution along one dimension (band-pass / matched filtering of the traces in front of DAS).
  * Replaces the kernels conv / convf / convc / convcf (reference src/convd.cu:95-127,130-146) launched by kern/convd.m:150-199

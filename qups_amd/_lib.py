@@ -32,7 +32,7 @@ SYMBOLS = (
     "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_reciprocal", "qdas_plan_mirror", "qdas_plan_kernel_name", "qdas_plan_set_timing",
     "qdas_plan_last_kernel_ms", "qdas_plan_create_sharded", "qdas_plan_execute_sharded", "qdas_plan_sharded_info",
     "qdas_plan_destroy_sharded", "qdas_DAS", "qdas_DASf", "qdas_DASh", "qdas_delays", "qdas_delaysf",
-    "qdas_das_lut", "qdas_wsinterpd", "qdas_greens", "qdas_convd", "qdas_convd_len", "qdas_permute3", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_pre_plan_one_pass", "qdas_last_error", "qdas_version", "qdas_device_info",
+    "qdas_das_lut", "qdas_wsinterpd", "qdas_shift_sum", "qdas_greens", "qdas_convd", "qdas_convd_len", "qdas_permute3", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_pre_plan_one_pass", "qdas_last_error", "qdas_version", "qdas_device_info",
 )
 
 
@@ -77,6 +77,12 @@ class GreensDesc(C.Structure):
 class PreDesc(C.Structure):
     _fields_ = [("T", C.c_uint64), ("K", C.c_uint64), ("Nfft", C.c_uint64), ("in_type", C.c_int32), ("device", C.c_int32),
                 ("fs", C.c_double), ("t0", C.c_double), ("fdown", C.c_double)]
+
+
+class ShiftDesc(C.Structure):
+    _fields_ = [("T", C.c_uint64), ("To", C.c_uint64), ("N", C.c_uint64), ("M", C.c_uint64), ("Mo", C.c_uint64), ("F", C.c_uint64),
+                ("flag", C.c_int32), ("dtype", C.c_int32), ("cplx", C.c_int32), ("w_real", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+                ("shift", C.c_void_p), ("w", C.c_void_p)]
 
 
 class ConvdDesc(C.Structure):
@@ -138,6 +144,7 @@ def lib():
     L.qdas_permute3.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
     L.qdas_convd_len.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
     L.qdas_convd_len.restype = C.c_uint64
+    L.qdas_shift_sum.argtypes = [C.POINTER(ShiftDesc), C.c_void_p, C.c_void_p, C.c_void_p]
     L.qdas_pre_plan_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(PreDesc)]
     L.qdas_pre_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.qdas_pre_plan_destroy.argtypes = [C.c_void_p]

@@ -72,6 +72,14 @@ struct WsParams {
 };
 hipError_t launch_wsinterpd(const WsParams &P, int dtype, hipStream_t s);
 
+// ---- transmit synthesis (shiftsum.hip): y[t', n, m'] = sum_m w[m, m'] x(t' + s[m, m'], n, m)
+struct ShiftParams {
+    const void *x; void *y; const void *tab, *blk;
+    uint64_t T, To, N, M, Mo, F;
+    uint32_t mo_blocks;
+};
+hipError_t launch_shift_sum(const ShiftParams &P, int dtype, int cplx, int interp, const void *sh, const void *w, int w_real, hipStream_t s);
+
 // ---- point-scatterer simulator (greens.hip)
 struct GreensParams {
     const void *Ps, *a, *Pr, *Pv, *x;

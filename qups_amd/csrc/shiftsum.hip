@@ -1,0 +1,291 @@
+// shiftsum.hip -- transmit synthesis (UltrasoundSystem.focusTx): delay-and-sum over the TRANSMIT ELEMENTS of a
+// full-synthetic-aperture record,
+//
+//   y[t', n, m'] = sum_m  w[m, m'] * x(t' + s[m, m'],  n, m)          t' = 0 .. To-1,  s in samples (any real number; M x Mo, m fastest)
+//
+// which is what the reference computes with `sample2sep(chd.time, -tau, interp, apd, mdim)` (src/UltrasoundSystem.m:3498 ->
+// kern/wsinterpd2.m -> src/interpd.cu:344-396): the sampling positions are the record's own time grid plus ONE offset per (element, synthesised
+// transmit).  The general single-delay kernel (wsinterpd.hip) serves that call too -- one lane per output, every term a gather from global memory
+// with its own index and weight evaluation (C1: 1.56 ms).  Here the structure is used:
+//   * the offset does not depend on t': tap offset floor(s), the K interpolation weights and the range of valid t' are properties of (m, m') --
+//     a table of M x Mo entries made by a small kernel (the library's own interp_weights: same numbers as every other kernel), read by the main
+//     kernel through the scalar cache;
+//   * a workgroup owns 256 x TPT consecutive output samples of one receiver and MOB synthesised transmits; per element m it stages ONE window
+//     of the trace x[:, n, m] in LDS (the samples those outputs can reach) and every lane reads its K consecutive taps from there: consecutive
+//     lanes, consecutive addresses;
+//   * zero weights (the apodization of a walking aperture is mostly zeros) are uniform skips; an element with no weight in the block is not staged.
+// Edge rule as everywhere (src/interpd.cu:70-150): a term counts iff all its taps lie in [0, T) and the position is >= 0.
+#include "qdas_device.h"
+#include "qdas_kernels.h"
+#include <type_traits>
+
+namespace qdas {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <typename R> struct ShiftEntry {    // per (m, m'): 16 + 6 R bytes
+    int32_t k0;          // first tap = t' + k0
+    int32_t tlo, thi;    // the term is in support for tlo <= t' <= thi
+    int32_t on;          // weight != 0 and the range is not empty
+    R wr, wi;            // w[m, m']
+    R c[4];              // interpolation weights of the K taps
+};
+
+template <int INTERP, typename R>
+__global__ void __launch_bounds__(256) shift_table_kernel(const R *__restrict__ sh, const void *__restrict__ w, int w_real, uint64_t count, int64_t T, int64_t To,
+                                                          ShiftEntry<R> *__restrict__ tab) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    constexpr int K = interp_taps(INTERP);
+    constexpr int OFF = (K == 4) ? -1 : 0;
+    const R s = sh[i];
+    ShiftEntry<R> e;
+    e.wr = (R)1; e.wi = (R)0;
+    if (w) { if (w_real) e.wr = ((const R *)w)[i]; else { e.wr = ((const R *)w)[2 * i]; e.wi = ((const R *)w)[2 * i + 1]; } }
+    e.c[0] = (R)1; e.c[1] = e.c[2] = e.c[3] = (R)0;
+    int64_t lo = 0, hi = -1, k0 = 0;
+    if (s == s && s > (R)-2.0e9 && s < (R)2.0e9) {     // (a non-finite offset leaves the term out, like a NaN position does)
+        if constexpr (K == 1) {                      // nearest: r = floor(t' + s + 1/2), in support iff t' + s >= 0 and r < T   (src/interpd.cu:70-72)
+            const R f = qfloor(s + (R)0.5);
+            k0 = (int64_t)f;
+            lo = (int64_t)ceil((double)-s);           // t' >= -s
+            hi = T - 1 - k0;
+        } else {
+            const R f = qfloor(s);
+            interp_weights<INTERP, R>(s - f, e.c);
+            k0 = (int64_t)f + OFF;
+            lo = -k0;                                 // first tap >= 0 (then t' + s >= 0 too)
+            hi = T - K - k0;                          // last tap < T
+        }
+        if (lo < 0) lo = 0;
+        if (hi > To - 1) hi = To - 1;
+    }
+    const bool on = (e.wr != (R)0 || e.wi != (R)0) && lo <= hi;
+    if (e.wi == (R)0) {                              // a real weight rides in the interpolation weights (the main kernel then adds the sample as it is)
+        e.c[0] *= e.wr; e.c[1] *= e.wr; e.c[2] *= e.wr; e.c[3] *= e.wr;
+        e.wr = (R)1;
+    }
+    e.k0 = (int32_t)k0; e.tlo = (int32_t)lo; e.thi = (int32_t)hi; e.on = on ? 1 : 0;
+    tab[i] = e;
+}
+
+constexpr int SS_MOB = 8;        // synthesised transmits per workgroup
+constexpr int SS_CAP = 4096;     // samples of one staged window
+
+// per (block of SS_MOB synthesised transmits, element m): smallest / largest tap offset among the weighted entries (kmin > kmax: none) -- what a
+// workgroup needs BEFORE it stages a window; one 8-byte scalar load per element instead of a scan over the block's entries
+template <typename R>
+__global__ void __launch_bounds__(256) shift_block_kernel(const ShiftEntry<R> *__restrict__ tab, uint64_t M, uint64_t Mo, uint32_t mo_blocks, int2 *__restrict__ blk) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * mo_blocks) return;
+    const uint64_t m = i % M, mob = i / M;
+    int kmin = 0x7fffffff, kmax = -0x7fffffff - 1;
+    for (uint64_t mo = mob * SS_MOB; mo < Mo && mo < (mob + 1) * SS_MOB; ++mo) {
+        const ShiftEntry<R> &e = tab[m + M * mo];
+        if (e.on) { kmin = e.k0 < kmin ? e.k0 : kmin; kmax = e.k0 > kmax ? e.k0 : kmax; }
+    }
+    blk[i] = make_int2(kmin, kmax);
+}
+
+// DT: sample type (float2 / double2 / float / double), R its real type, TPT output samples per lane
+template <int K, typename DT, typename R, int TPT>
+__global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ss_lds[];
+    DT *win = (DT *)ss_lds;
+    constexpr int EW = (int)(sizeof(ShiftEntry<R>) / 4);                         // 32-bit words per table entry
+    uint32_t *ent_w = (uint32_t *)(ss_lds + sizeof(DT) * SS_CAP);                // [SS_MOB] this element's entries, copied next to the window
+    const ShiftEntry<R> *ent = (const ShiftEntry<R> *)ent_w;
+    constexpr bool CPLX = sizeof(DT) == 2 * sizeof(R);
+    constexpr int TPB = 256 * TPT;
+    const ShiftEntry<R> *__restrict__ tab = (const ShiftEntry<R> *)P.tab;
+    const uint32_t tid = threadIdx.x;
+    const int64_t tb = (int64_t)blockIdx.x * TPB;
+    const uint64_t n = blockIdx.y;
+    const uint32_t mob = blockIdx.z % P.mo_blocks;
+    const uint64_t f = blockIdx.z / P.mo_blocks;
+    const uint64_t mo0 = (uint64_t)mob * SS_MOB;
+    const int nmo = (int)((P.Mo - mo0) < (uint64_t)SS_MOB ? (P.Mo - mo0) : (uint64_t)SS_MOB);
+    const int64_t T = (int64_t)P.T;
+    R ar[TPT][SS_MOB], ai[TPT][SS_MOB];
+#pragma unroll
+    for (int q = 0; q < TPT; ++q)
+#pragma unroll
+        for (int j = 0; j < SS_MOB; ++j) { ar[q][j] = (R)0; ai[q][j] = (R)0; }
+
+    auto stage = [&](const DT *__restrict__ tr, int64_t wlo, int wlen, const ShiftEntry<R> *row) {   // win[i] = x[wlo + i] (zero outside the record)
+        __syncthreads();                                                        // the previous window is consumed
+        if (row && (int)tid < nmo * EW)                                          // + the element's table entries (one vector load instead of a scalar-load chain)
+            ent_w[tid] = ((const uint32_t *)(row + (uint64_t)(tid / EW) * P.M))[tid % EW];
+        for (int i = (int)tid; i < wlen; i += 256) {
+            const int64_t g = wlo + i;
+            DT v{};
+            if (g >= 0 && g < T) v = tr[g];
+            win[i] = v;
+        }
+        __syncthreads();
+    };
+    // all lanes, their TPT outputs, synthesised transmit j.  rel = (first tap of local output 0) - (window start): every lane's taps lie inside the
+    // staged window whether or not its output is in support, so the reads need no guard; 32-bit index math throughout
+    auto term = [&](const ShiftEntry<R> &e, int j, int rel) {
+        const int64_t lo64 = (int64_t)e.tlo - tb, hi64 = (int64_t)e.thi - tb;
+        const int lo = lo64 < 0 ? 0 : (int)lo64, hi = hi64 > TPB ? TPB : (int)hi64;            // uniform
+        const bool plain = e.wi == (R)0;                                                        // real weight: already in c[]
+#pragma unroll
+        for (int q = 0; q < TPT; ++q) {
+            const int lt = (int)tid + 256 * q;
+            const bool ok = lt >= lo && lt <= hi;
+            const DT *tp = win + (lt + rel);
+            if constexpr (std::is_same<DT, float2>::value) {                                    // packed fp32: one v_pk_fma_f32 per tap
+                v2f v = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < K; ++k) { const float2 s = tp[k]; v = (v2f){s.x, s.y} * e.c[k] + v; }
+                if (!plain) v = (v2f){e.wr * v.x - e.wi * v.y, e.wr * v.y + e.wi * v.x};
+                if (ok) { ar[q][j] += v.x; ai[q][j] += v.y; }
+            } else {
+                R vr = (R)0, vi = (R)0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const DT s = tp[k];
+                    if constexpr (CPLX) { vr += e.c[k] * s.x; vi += e.c[k] * s.y; } else vr += e.c[k] * s;
+                }
+                if constexpr (CPLX) { if (!plain) { const R xr = e.wr * vr - e.wi * vi, xi = e.wr * vi + e.wi * vr; vr = xr; vi = xi; } }
+                if (ok) { ar[q][j] += vr; if constexpr (CPLX) ai[q][j] += vi; }
+            }
+        }
+    };
+
+    // Element loop, software-pipelined: while the lanes work on element m out of LDS, the window (and the table entries) of the next weighted
+    // element are already on their way into registers; they are written to LDS behind the barrier that ends m.  Class 0: the window fits the
+    // prefetch registers (offsets of the block within ~500 samples of each other -- the usual case); class 1: one window, staged without
+    // prefetch; class 2: offsets too far apart for one window -- a window per synthesised transmit.
+    const int2 *__restrict__ blk = (const int2 *)P.blk + (uint64_t)mob * P.M;
+    constexpr int NPF = TPT + 2;
+    DT pre[NPF];
+    uint32_t pre_e = 0;
+    auto find = [&](uint64_t from, int &kmin, int &kmax) -> uint64_t {           // next element with a weight in this block (uniform scalar loads)
+        for (uint64_t m = from; m < P.M; ++m) { const int2 kr = blk[m]; if (kr.x <= kr.y) { kmin = kr.x; kmax = kr.y; return m; } }
+        return P.M;
+    };
+    auto klass = [&](int kmin, int kmax) -> int {
+        const int64_t span = (int64_t)kmax - (int64_t)kmin;
+        return span + TPB + K - 1 <= NPF * 256 ? 0 : (span + TPB + K <= SS_CAP ? 1 : 2);
+    };
+    auto trace = [&](uint64_t m) -> const DT * { return (const DT *)P.x + ((f * P.M + m) * P.N + n) * P.T; };
+    auto fetch = [&](uint64_t m, int kmin, int wlen) {
+        const DT *__restrict__ tr = trace(m);
+        const int64_t wlo = tb + kmin;
+#pragma unroll
+        for (int p = 0; p < NPF; ++p) {
+            const int i = (int)tid + 256 * p;
+            const int64_t g = wlo + i;
+            DT v{};
+            if (i < wlen && g >= 0 && g < T) v = tr[g];
+            pre[p] = v;
+        }
+        if ((int)tid < nmo * EW) pre_e = ((const uint32_t *)(tab + m + P.M * (mo0 + tid / EW)))[tid % EW];
+    };
+    int kmin = 0, kmax = -1;
+    uint64_t m = find(0, kmin, kmax);
+    int kl = m < P.M ? klass(kmin, kmax) : 0;
+    if (m < P.M && kl == 0) fetch(m, kmin, (int)((int64_t)kmax - kmin + TPB + K - 1));
+    while (m < P.M) {
+        const int wl = (int)((int64_t)kmax - (int64_t)kmin + TPB + K - 1);
+        if (kl == 0) {
+            __syncthreads();                                                     // the previous element is consumed
+#pragma unroll
+            for (int p = 0; p < NPF; ++p) { const int i = (int)tid + 256 * p; if (i < wl) win[i] = pre[p]; }
+            if ((int)tid < nmo * EW) ent_w[tid] = pre_e;
+            __syncthreads();
+        } else stage(trace(m), tb + kmin, kl == 1 ? wl : 0, tab + m + P.M * mo0);
+        int kmin2 = 0, kmax2 = -1;
+        const uint64_t m2 = find(m + 1, kmin2, kmax2);
+        const int kl2 = m2 < P.M ? klass(kmin2, kmax2) : 0;
+        if (m2 < P.M && kl2 == 0) fetch(m2, kmin2, (int)((int64_t)kmax2 - kmin2 + TPB + K - 1));       // in flight during the arithmetic below
+#pragma unroll
+        for (int j = 0; j < SS_MOB; ++j) {
+            if (j >= nmo) break;
+            const ShiftEntry<R> e = ent[j];                                      // broadcast LDS reads
+            const bool here = e.on && (int64_t)e.thi >= tb && (int64_t)e.tlo < tb + TPB;
+            if (!__builtin_amdgcn_readfirstlane((int)here)) continue;            // (uniform)
+            if (kl == 2) stage(trace(m), tb + e.k0, TPB + K - 1, nullptr);
+            term(e, j, kl == 2 ? 0 : e.k0 - kmin);
+        }
+        m = m2; kmin = kmin2; kmax = kmax2; kl = kl2;
+    }
+#pragma unroll
+    for (int j = 0; j < SS_MOB; ++j) {
+        if (j >= nmo) break;
+        DT *__restrict__ yo = (DT *)P.y + ((f * P.Mo + mo0 + j) * P.N + n) * P.To;
+#pragma unroll
+        for (int q = 0; q < TPT; ++q) {
+            const int64_t t = tb + (int64_t)tid + 256 * q;
+            if (t < (int64_t)P.To) {
+                if constexpr (CPLX) { DT v; v.x = ar[q][j]; v.y = ai[q][j]; yo[t] = v; }
+                else yo[t] = ar[q][j];
+            }
+        }
+    }
+}
+
+template <typename DT, typename R, int TPT>
+static hipError_t launch_shift_t(const ShiftParams &P, int interp, const void *sh, const void *w, int w_real, hipStream_t s) {
+    const uint64_t count = P.M * P.Mo;
+    ShiftEntry<R> *tab = nullptr;
+    hipError_t e = hipMallocAsync((void **)&tab, sizeof(ShiftEntry<R>) * count, s);
+    if (e != hipSuccess) return e;
+    const unsigned gb = (unsigned)((count + 255) / 256);
+    const R *shr = (const R *)sh;
+    switch (interp) {
+        case 0: shift_table_kernel<0, R><<<gb, 256, 0, s>>>(shr, w, w_real, count, (int64_t)P.T, (int64_t)P.To, tab); break;
+        case 1: case 4: shift_table_kernel<1, R><<<gb, 256, 0, s>>>(shr, w, w_real, count, (int64_t)P.T, (int64_t)P.To, tab); break;
+        case 2: shift_table_kernel<2, R><<<gb, 256, 0, s>>>(shr, w, w_real, count, (int64_t)P.T, (int64_t)P.To, tab); break;
+        case 3: shift_table_kernel<3, R><<<gb, 256, 0, s>>>(shr, w, w_real, count, (int64_t)P.T, (int64_t)P.To, tab); break;
+        case 5: shift_table_kernel<5, R><<<gb, 256, 0, s>>>(shr, w, w_real, count, (int64_t)P.T, (int64_t)P.To, tab); break;
+        default: (void)hipFreeAsync(tab, s); return hipErrorInvalidValue;
+    }
+    ShiftParams p = P;
+    p.tab = tab;
+    p.mo_blocks = (uint32_t)((P.Mo + SS_MOB - 1) / SS_MOB);
+    int2 *blk = nullptr;
+    e = hipMallocAsync((void **)&blk, sizeof(int2) * P.M * p.mo_blocks, s);
+    if (e != hipSuccess) { (void)hipFreeAsync(tab, s); return e; }
+    shift_block_kernel<R><<<(unsigned)((P.M * p.mo_blocks + 255) / 256), 256, 0, s>>>(tab, P.M, P.Mo, p.mo_blocks, blk);
+    p.blk = blk;
+    constexpr int TPB = 256 * TPT;
+    const dim3 g((unsigned)((P.To + TPB - 1) / TPB), (unsigned)P.N, (unsigned)(p.mo_blocks * P.F));
+    const size_t lds = sizeof(DT) * SS_CAP + sizeof(ShiftEntry<R>) * SS_MOB;
+    const int K = interp_taps(interp);
+#define QSS(KK)                                                                                                                         \
+    do {                                                                                                                                \
+        auto kfn = shift_sum_kernel<KK, DT, R, TPT>;                                                                                     \
+        e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+        if (e == hipSuccess) kfn<<<g, 256, lds, s>>>(p);                                                                                \
+    } while (0)
+    if (K == 1) QSS(1); else if (K == 2) QSS(2); else QSS(4);
+#undef QSS
+    if (e == hipSuccess) e = hipGetLastError();
+    (void)hipFreeAsync(tab, s);                                                  // stream-ordered: after the kernel
+    (void)hipFreeAsync(blk, s);
+    return e;
+}
+
+// dtype: QDAS_F64 (0) | QDAS_F32 (1); cplx: samples are interleaved complex
+hipError_t launch_shift_sum(const ShiftParams &P, int dtype, int cplx, int interp, const void *sh, const void *w, int w_real, hipStream_t s) {
+    if (P.To == 0 || P.N == 0 || P.Mo == 0 || P.F == 0) return hipSuccess;
+    if (dtype == 1) {
+        // outputs per lane: the choice among 4 / 3 / 2 that leaves the fewest idle outputs in the last block of a trace (To = 2200: 3 -> 2304 covered, 4 -> 3072)
+        int best = 4;
+        uint64_t waste = ~0ull;
+        for (int tpt = 4; tpt >= 2; --tpt) {
+            const uint64_t tpb = 256ull * tpt, cov = (P.To + tpb - 1) / tpb * tpb - P.To;
+            if (cov * 8 < waste * 8 && (waste == ~0ull || (waste - cov) * 16 > P.To)) { waste = cov; best = tpt; }   // a smaller block only if it saves > 6 % of the outputs
+        }
+        if (cplx) return best == 4 ? launch_shift_t<float2, float, 4>(P, interp, sh, w, w_real, s) : best == 3 ? launch_shift_t<float2, float, 3>(P, interp, sh, w, w_real, s)
+                                                                                                                 : launch_shift_t<float2, float, 2>(P, interp, sh, w, w_real, s);
+        return best == 4 ? launch_shift_t<float, float, 4>(P, interp, sh, w, w_real, s) : best == 3 ? launch_shift_t<float, float, 3>(P, interp, sh, w, w_real, s)
+                                                                                                     : launch_shift_t<float, float, 2>(P, interp, sh, w, w_real, s);
+    }
+    return cplx ? launch_shift_t<double2, double, 2>(P, interp, sh, w, w_real, s) : launch_shift_t<double, double, 4>(P, interp, sh, w, w_real, s);
+}
+
+}  // namespace qdas

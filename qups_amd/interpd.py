@@ -114,6 +114,56 @@ def das_lut(x, tau_rx, tau_tx, *, interp="linear", w=None, keep_rx=False, keep_t
     return rev(y.reshape(tuple(reversed(fsz)) + (oM, oN) + tuple(reversed(Isz))))
 
 
+def shift_sum(x, shift, w=None, interp="linear", To=None, device=None):
+    """Transmit synthesis: ``y[t', n, m', f] = sum_m w[m, m'] * x(t' + shift[m, m'], n, m, f)`` for ``t' = 0 .. To-1`` (``qdas_shift_sum``,
+    ``qups_amd/csrc/shiftsum.hip``) -- what ``UltrasoundSystem.focusTx`` asks of ``sample2sep`` (reference ``src/UltrasoundSystem.m:3498``) with the
+    positions written as the record's time grid plus one offset per (element, synthesised transmit).
+
+    ``x``: ``T x N x M x F...`` float32 / float64 / complex64 / complex128; ``shift``: ``M x Mo`` in samples; ``w``: ``M x Mo`` (real, or complex for
+    complex data) or ``None``.  Returns ``To x N x Mo x F...`` on the device."""
+    torch = _torch()
+    L = _lib.lib()
+    if not torch.cuda.is_available():
+        raise RuntimeError("qups_amd: no HIP device visible -- the sampling path has no CPU fallback")
+    if interp not in _lib.INTERP_FLAGS:
+        raise DasError("Interp option not recognized: " + str(interp))
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    xt = (x if _is_torch(x) else torch.from_numpy(np.asarray(x))).to(dev)
+    if xt.dtype not in (torch.float32, torch.float64, torch.complex64, torch.complex128):
+        raise DasError("shift_sum: single or double precision data")
+    while xt.ndim < 3:
+        xt = xt.unsqueeze(-1)
+    T, N, M = (int(v) for v in xt.shape[:3])
+    fsz = tuple(int(v) for v in xt.shape[3:])
+    F = int(np.prod(fsz)) if fsz else 1
+    dbl = xt.dtype in (torch.float64, torch.complex128)
+    rt = torch.float64 if dbl else torch.float32
+    sh = (shift if _is_torch(shift) else torch.from_numpy(np.asarray(shift, np.float64))).to(dev)
+    if sh.ndim != 2 or sh.shape[0] != M:
+        raise DasError("shift_sum: shift must be M x Mo")
+    Mo = int(sh.shape[1])
+    shc = sh.to(rt).t().contiguous()                                  # memory: m fastest
+    wc = None
+    w_real = 1
+    if w is not None:
+        wt = (w if _is_torch(w) else torch.from_numpy(np.asarray(w))).to(dev)
+        wt = torch.broadcast_to(wt, (M, Mo))
+        if wt.is_complex():
+            if not xt.is_complex():
+                raise DasError("shift_sum: real data take real weights")
+            wc, w_real = wt.to(torch.complex128 if dbl else torch.complex64).t().contiguous(), 0
+        else:
+            wc = wt.to(rt).t().contiguous()
+    To = T if To is None else int(To)
+    xc = _colmajor(xt.reshape((T, N, M) if F == 1 else (T, N, M, F)).contiguous())    # (F, M, N, T); three dimensions take the LDS-tiled transpose
+    y = torch.empty((F, Mo, N, To), dtype=xt.dtype, device=dev)
+    d = _lib.ShiftDesc(T, To, N, M, Mo, F, _lib.INTERP_FLAGS[interp], 0 if dbl else 1, int(xt.is_complex()), w_real,
+                       dev.index if dev.index is not None else torch.cuda.current_device(), 0, shc.data_ptr(), wc.data_ptr() if wc is not None else None)
+    with torch.cuda.device(dev):
+        _lib.check(L.qdas_shift_sum(C.byref(d), C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return y.permute(3, 2, 1, 0).reshape((To, N, Mo) + fsz)
+
+
 def sample2sep(x, t0, fs, tau1, tau2, interp="linear", w=None, sdim=(), fmod=0.0, **kw):
     """``ChannelData.sample2sep`` for data ordered ``T x N x M x F...`` (reference ``src/ChannelData.m:1338-1447``):
     ``tau1`` (``I... x N``, receive) and ``tau2`` (``I... x M``, transmit) are TIMES; the sample delays are

@@ -350,10 +350,15 @@ class UltrasoundSystem:
         d = chd._torch_data()
         T2, N, M = d.shape[:3]
         dev = d.device if d.is_cuda else torch.device("cuda")
-        # ONE launch of the general single-delay kernel over the index space (t', n, m, m', frames...): the sample index depends on
-        # (t', m, m'), the data on (n, m, frames), the weight on (m, m'); the transmit elements m are summed (round 2: one split-delay
-        # launch per synthesised transmit, each with its own layout copy of the record)
         Mp = tau.shape[1]
+        if d.dtype in (torch.float32, torch.float64, torch.complex64, torch.complex128):
+            # the positions are the record's own time grid plus ONE offset per (element, synthesised transmit): the shift-and-sum kernel
+            # (qdas_shift_sum: per-pair tap offset and weights, LDS-staged windows, zero weights skipped; round 3)
+            from .interpd import shift_sum
+            z = shift_sum(d.to(dev), -tau * chd.fs, apd, interp)
+            return ChannelData(z, t0, chd.fs, "TNM")
+        # other data types: ONE launch of the general single-delay kernel over the index space (t', n, m, m', frames...): the sample index depends
+        # on (t', m, m'), the data on (n, m, frames), the weight on (m, m'); the transmit elements m are summed
         ntau = torch.arange(T2, dtype=torch.float64, device=dev).reshape(T2, 1, 1, 1) - torch.from_numpy(tau * chd.fs).to(dev).reshape(1, 1, M, Mp)
         xd = d.to(dev).reshape((T2, N, M, 1) + tuple(d.shape[3:]))
         z = wsinterpd(xd, ntau, 1, apd.reshape(1, 1, M, Mp), [3], interp, 0.0)        # T' x N x 1 x M' x F...

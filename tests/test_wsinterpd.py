@@ -163,3 +163,73 @@ def test_channeldata_sample_rectify_and_focusTx():
     assert np.allclose(seq.delays(xdc), O.sequence_delays("PW", xdc.positions(), seq.focus, c0))
     for typ, foc in (("FC", np.array([[0.0], [0.0], [20e-3]])), ("DV", np.array([[0.0], [0.0], [-5e-3]])), ("VS", np.array([[0.0, 1e-3], [0.0, 0.0], [10e-3, -4e-3]]))):
         assert np.allclose(Sequence(typ, focus=foc, c0=c0).delays(xdc), O.sequence_delays(typ, xdc.positions(), foc, c0))
+
+
+def _shift_ref(x, shift, w, interp, To):
+    """y[t', n, m', f] = sum_m w[m, m'] x(t' + shift[m, m'], n, m, f) through the float64 oracle sampler, one (m, m') pair at a time"""
+    T, N, M = x.shape[:3]
+    F = int(np.prod(x.shape[3:])) if x.ndim > 3 else 1
+    Mo = shift.shape[1]
+    xf = x.reshape(T, N, M, F).astype(np.complex128 if np.iscomplexobj(x) else np.float64)
+    y = np.zeros((To, N, Mo, F), xf.dtype if not np.iscomplexobj(w) else np.complex128)
+    tp = np.arange(To, dtype=np.float64)
+    for m in range(M):
+        for mo in range(Mo):
+            if w[m, mo] == 0 or not np.isfinite(shift[m, mo]):
+                continue
+            pos = tp + shift[m, mo]
+            for n in range(N):
+                for f in range(F):
+                    y[:, n, mo, f] += w[m, mo] * O.sample(xf[:, n, m, f], pos, interp)
+    return y.reshape((To, N, Mo) + tuple(x.shape[3:]))
+
+
+@pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3", "cubic_dev"])
+@pytest.mark.parametrize("dtype", ["complex64", "complex128", "float32", "float64"])
+def test_shift_sum_matches_the_oracle_and_the_general_kernel(interp, dtype):
+    """qdas_shift_sum (transmit synthesis: one offset per (element, synthesised transmit)) against the float64 oracle sampler and against
+    the general single-delay kernel fed the materialised positions; offsets beyond both ends of the record, zero and complex weights, an
+    odd block of synthesised transmits, frames, more and fewer output samples than the record holds"""
+    import torch
+    from qups_amd.interpd import shift_sum, wsinterpd
+    rng = np.random.default_rng(31)
+    T, N, M, Mo, F = 700, 5, 11, 13, 2
+    cplx = dtype.startswith("complex")
+    x = rng.standard_normal((T, N, M, F)) + (1j * rng.standard_normal((T, N, M, F)) if cplx else 0)
+    x = x.astype(dtype)
+    shift = rng.uniform(-60, 60, (M, Mo))
+    shift[0, 0], shift[1, 1], shift[2, 2], shift[3, 3] = -800.0, 800.0, 2.5, -3.5       # nothing in range twice; half-integers (nearest ties)
+    shift[4, :] = np.round(shift[4, :])                                                  # integer offsets
+    w = rng.uniform(0.2, 1, (M, Mo)) * (1 + (0.5j if cplx else 0))
+    w[rng.random((M, Mo)) < 0.3] = 0
+    w[5, :] = 0                                                                           # an element nobody uses
+    dbl = dtype in ("complex128", "float64")
+    tol = 1e-11 if dbl else 2e-5
+    if not dbl:
+        shift = shift.astype(np.float32).astype(np.float64)
+    for To in (T, T + 150, 300):
+        y = shift_sum(torch.from_numpy(x), shift, w, interp, To=To)
+        ref = _shift_ref(x, shift, w, interp, To)
+        assert tuple(y.shape) == ref.shape and y.dtype == getattr(torch, dtype)
+        assert rel_err(_np(y), ref) <= tol, (To, interp)
+    if interp == "nearest":                                                               # (discontinuous: a position rounded to fp32 may pick the neighbour)
+        return
+    # the general kernel on the same call (positions t' + shift as an array, summed over m)
+    pos = (np.arange(T).reshape(T, 1, 1, 1) + shift.reshape(1, 1, M, Mo))
+    z = wsinterpd(torch.from_numpy(x.reshape(T, N, M, 1, F)), torch.from_numpy(pos), 1, w.reshape(1, 1, M, Mo), [3], interp, 0.0)
+    assert rel_err(_np(z).reshape(T, N, Mo, F), _np(shift_sum(torch.from_numpy(x), shift, w, interp))) <= (1e-11 if dbl else 2e-4)
+
+
+def test_shift_sum_offsets_too_far_apart_for_one_window_and_no_weights():
+    """offsets spread over more than a staged window holds (a window per synthesised transmit), weights omitted (ones), one receiver"""
+    import torch
+    from qups_amd.interpd import shift_sum
+    rng = np.random.default_rng(32)
+    T, N, M, Mo = 9000, 1, 3, 9
+    x = (rng.standard_normal((T, N, M)) + 1j * rng.standard_normal((T, N, M))).astype(np.complex64)
+    shift = rng.uniform(-4000, 4000, (M, Mo)).astype(np.float32).astype(np.float64)
+    y = shift_sum(torch.from_numpy(x), shift, None, "cubic")
+    ref = _shift_ref(x, shift, np.ones((M, Mo)), "cubic", T)
+    assert rel_err(_np(y), ref) <= 2e-5
+    with pytest.raises(Exception):
+        shift_sum(torch.from_numpy(x.real.copy()), shift, np.ones((M, Mo)) * 1j, "cubic")     # real data take real weights
