@@ -33,9 +33,16 @@ namespace qdas {
 // again coalesced -- and writes the result to HBM from registers.
 struct FftStages { int n; int r[14]; };
 
-static __device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-static __device__ __forceinline__ float2 caddf(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-static __device__ __forceinline__ float2 csubf(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// complex arithmetic on packed fp32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: one instruction per complex add, two per complex multiply)
+typedef float pre_v2f __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ pre_v2f pv(float2 a) { return (pre_v2f){a.x, a.y}; }
+static __device__ __forceinline__ float2 pf(pre_v2f a) { return make_float2(a.x, a.y); }
+static __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+    const pre_v2f bb = pv(b);
+    return pf((pre_v2f){-a.y, a.y} * bb.yx + (pre_v2f){a.x, a.x} * bb);
+}
+static __device__ __forceinline__ float2 caddf(float2 a, float2 b) { return pf(pv(a) + pv(b)); }
+static __device__ __forceinline__ float2 csubf(float2 a, float2 b) { return pf(pv(a) - pv(b)); }
 static __device__ __forceinline__ float2 cmulmi(float2 a) { return make_float2(a.y, -a.x); }              // a * (-i)
 
 // length-4 DFT of (a, b, c, d) in place
@@ -116,13 +123,17 @@ template <int R> static __device__ __forceinline__ void dft_small(float2 (&v)[R]
             for (int t = 1; t <= H; ++t) {
                 const int m = (u * t) % R;                               // cos(2 pi m/R) = cos(2 pi (R-m)/R), sin flips
                 const float cc = m <= H ? c[m] : c[R - m], ss = m <= H ? sn[m] : -sn[R - m];
-                P.x += cc * a[t].x; P.y += cc * a[t].y; Q.x += ss * b[t].x; Q.y += ss * b[t].y;
+                P = pf(pv(a[t]) * cc + pv(P)); Q = pf(pv(b[t]) * ss + pv(Q));
             }
             v[u] = make_float2(P.x + Q.y, P.y - Q.x);
             v[R - u] = make_float2(P.x - Q.y, P.y + Q.x);
         }
     }
 }
+
+// LDS index of point i: one spare slot per 16 points, so that the stride-r writes of the early stages (points r j + t: 128-byte strides for
+// r = 16 -- every second lane on the same pair of banks) spread over all banks
+static __device__ __forceinline__ uint32_t lds_pad(uint32_t i) { return i + (i >> 4); }
 
 struct HilbertArgs {
     const void *x; float2 *y; const float2 *tw;
@@ -150,7 +161,7 @@ static __device__ __forceinline__ void fft_stage(float2 *buf, const HilbertArgs 
             for (int t = 0; t < R; ++t) {
                 const uint32_t idx = j + t * NR;
                 if constexpr (ING) v[it][t] = make_float2(idx < A.T ? (float)x1[idx] : 0.f, (two && idx < A.T) ? (float)x2[idx] : 0.f);
-                else v[it][t] = buf[idx];
+                else v[it][t] = buf[lds_pad(idx)];
                 if constexpr (WGT) {                                     // w = [1; 2 ...; 1 + mod(N,2); 0 ...]  (src/ChannelData.m:961-963)
                     const uint32_t h = N / 2;
                     const float g = idx == 0 ? 1.f : idx < h ? 2.f : idx == h ? (float)(1 + (N & 1)) : 0.f;
@@ -176,7 +187,7 @@ static __device__ __forceinline__ void fft_stage(float2 *buf, const HilbertArgs 
             const uint32_t k = j % Ns, j0 = (j - k) * R + k;
             if constexpr (!OUTG) {
 #pragma unroll
-                for (int t = 0; t < R; ++t) buf[j0 + t * Ns] = v[it][t];
+                for (int t = 0; t < R; ++t) buf[lds_pad(j0 + t * Ns)] = v[it][t];
             } else {                                                     // Ns == N / R here: j0 == j, points j + t NR
                 const float sc = 1.0f / (float)N;
                 float2 *y1 = A.y + (uint64_t)N * k1, *y2 = y1 + N;
@@ -374,11 +385,15 @@ int pre_create(PrePlan **out, uint64_t T, uint64_t K, uint64_t N, int in_type, d
             const double a = -2.0 * M_PI * (double)k / (double)p->N;
             h[k] = make_float2((float)cos(a), (float)sin(a));
         }
-        const size_t lds_bytes = sizeof(float2) * p->N;
+        const size_t lds_bytes = sizeof(float2) * (p->N + p->N / 16 + 1);
         bool ok = hipMalloc(&p->tw, sizeof(float2) * p->N) == hipSuccess &&
                   hipMemcpy(p->tw, h.data(), sizeof(float2) * p->N, hipMemcpyHostToDevice) == hipSuccess;
         if (ok && lds_bytes > 65536) {
-            ok = false;                                                  // cannot happen: N <= 8192
+            const void *fns[4] = {(const void *)hilbert_lds_kernel<float, false>, (const void *)hilbert_lds_kernel<float, true>,
+                                  (const void *)hilbert_lds_kernel<int16_t, false>, (const void *)hilbert_lds_kernel<int16_t, true>};
+            for (const void *fn : fns) ok = ok && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+            for (const FixedList &fl : FIXED_LISTS) ok = ok && hipFuncSetAttribute((const void *)fl.f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess
+                                                         && hipFuncSetAttribute((const void *)fl.i16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
         }
         if (ok) { p->lds = p->have = true; *out = p; return 0; }
         if (p->tw) { (void)hipFree(p->tw); p->tw = nullptr; }
@@ -410,7 +425,7 @@ int pre_execute(PrePlan *p, const void *x, void *y, hipStream_t s) {
     if (p->lds) {
         HilbertArgs A{x, (float2 *)y, p->tw, (uint32_t)p->T, (uint32_t)p->N, p->K, p->st, p->fd, p->t0, p->fs};
         const unsigned nb = (unsigned)((p->K + 1) / 2);
-        const size_t lds_bytes = sizeof(float2) * p->N;
+        const size_t lds_bytes = sizeof(float2) * (p->N + p->N / 16 + 1);
         const unsigned th = p->threads & 0xffffu;
         const bool big = (p->threads >> 16) != 0;
         if (const FixedList *f = fixed_list(p->st, big)) {
