@@ -20,6 +20,7 @@ struct JitSpec {
     int mir;                                            // lateral-mirror mode: the two-window-set instantiation (TileCfg::FB2), one frame
     int mirq;                                           // reciprocal + lateral-mirror mode: four window sets (TileCfg::MIRQ)
     int mslab;                                          // ... of a mirror slab (tile_params.h mir == 2)
+    int wreal;                                          // the weight table is real: the weighted accumulation is one packed FMA per sample
 };
 
 std::string jit_source(const JitSpec &k);

@@ -88,6 +88,7 @@ struct qdas_plan {
     unsigned ntiles = 0, tile_cols = 0;
     bool no_fallback = false;                 // the probe found no tile whose delay spread exceeds the LDS window
     double misfit_frac = 0.0;                 // fraction of the chosen footprint's tiles that do not fit it
+    bool wtab_real = false;                   // the folded weight table has no imaginary part
     bool fb2_ok = false;                      // frames of a sequence may share launches, 4 or 2 at a time (decided at plan creation)
     bool fb4_off = false;                     // ... but at most pairwise (QDAS_NO_FB4)
     // A lateral-mirror plan runs one frame per launch (its second window set is taken).  For a STREAM of frames four frames per launch share
@@ -749,6 +750,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e)));
             t.wtab = dtab;
         }
+        pl->wtab_real = !host_tab.empty();               // every entry of the table real?  (apodization windows usually are: hiprtc builds then accumulate with ONE packed FMA per sample)
+        for (size_t k = 1; k < host_tab.size(); k += 2) if (host_tab[k] != 0.f) { pl->wtab_real = false; break; }
         if (t.mir && !host_tab.empty()) {               // lateral-mirror mode with a weight table: the table itself must be mirror-symmetric
             bool tsym = true;
             for (uint64_t m = 0; m < z.M && tsym; ++m)
@@ -895,6 +898,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         k.kindB = t.kindB; k.kindS = t.kindS; k.tzl = t.tz_log2; k.wzl = t.wz_log2; k.ksplit = t.ksplit;
         k.gen_kind = t.gen_kind; k.has_apix = t.apix != nullptr; k.apix_real = t.apix_real; k.syn = t.syn;
         k.has_st = t.St != nullptr; k.has_cinv_pix = t.cinv_pix != nullptr;
+        k.wreal = (t.wtab && pl->wtab_real && !getenv("QDAS_NO_WREAL")) ? 1 : 0;
         // tuning: a specialised build may use another number of transmits per stage than the prebuilt configuration (its register
         // budget is smaller); the LDS image grows with it
         // reciprocal mode: the specialised kernel has the registers for 32-transmit stages (half the stages, barriers and per-stage

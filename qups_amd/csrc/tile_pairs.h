@@ -218,9 +218,9 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                     if constexpr (SW) { if (!((xmask >> (2 * p)) & 1u)) { u0 = z; } if (!((xmask >> (2 * p + 1)) & 1u)) { u1 = z; } }
                   }
                 }
-                rot_acc(A0, v0, wr0, wi0); rot_acc(A1, v1, wr1, wi1);             // complex weight folded into the accumulation
-                if constexpr (FBX) { rot_acc(B0, u0, wr0, wi0); rot_acc(B1, u1, wr1, wi1); }
-                if constexpr (SW) { rot_acc(B0, u0, xr0, xi0); rot_acc(B1, u1, xr1, xi1); }      // mirror pairs, their own weights
+                wgt_acc(A0, v0, wr0, wi0); wgt_acc(A1, v1, wr1, wi1);             // complex weight folded into the accumulation
+                if constexpr (FBX) { wgt_acc(B0, u0, wr0, wi0); wgt_acc(B1, u1, wr1, wi1); }
+                if constexpr (SW) { wgt_acc(B0, u0, xr0, xi0); wgt_acc(B1, u1, xr1, xi1); }      // mirror pairs, their own weights
             } else if constexpr (FMOD) {              // (accumulated by the rotation above)
             } else if constexpr (SPLIT || K == 1) { A0 += v0; A0 += v1; if constexpr (FBX) { B0 += u0; B0 += u1; } }
         });

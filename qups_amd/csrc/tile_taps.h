@@ -125,6 +125,11 @@ __device__ __forceinline__ void rot_acc(v2f &acc, v2f v, float c, float s) {
     acc = v * c + acc;
     acc = (v2f){v.y, v.x} * (v2f){-s, s} + acc;
 }
+// acc += v * (wr + i wi), a weight-table entry; plan-specialised builds of a plan whose table is real (apodization windows) drop the second FMA
+__device__ __forceinline__ void wgt_acc(v2f &acc, v2f v, float wr, float wi) {
+    if (QSPEC(WREAL, 0)) acc = v * wr + acc;
+    else rot_acc(acc, v, wr, wi);
+}
 // acc += w * tap k, either data type (software-pipelined loop)
 __device__ __forceinline__ void tap_mac(v2f &acc, const taps_f32 &t, int k, float w) { acc = w * t.s[k] + acc; }
 __device__ __forceinline__ void tap_mac(v2f &acc, const taps_f16 &t, int k, float w) { mix_mac(acc, t.r[k], w); }
