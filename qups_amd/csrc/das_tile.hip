@@ -116,7 +116,7 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part && !P.bf))) return hipErrorInvalidValue;
     // frames per launch; lateral-mirror plans (one frame) run the two-window-set instantiations as well
     const int nfr = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
-    if (P.mir && !P.probe && (nfr != 1 || P.big || P.bf || P.lut_tx || P.syn || ((P.apix || P.gen_kind) && (dtype != 2 || sym || P.stage_shift || P.bpix)) || (!sym && narrow) || (sym && dtype == 1 && !narrow))) return hipErrorInvalidValue;
+    if (P.mir && !P.probe && (nfr != 1 || P.big || P.bf || P.lut_tx || P.syn || ((P.apix || P.gen_kind) && ((dtype != 2 && !jit) || sym || P.stage_shift || P.bpix)) || (!sym && narrow) || (sym && dtype == 1 && !narrow))) return hipErrorInvalidValue;
     const int nf = (P.mir && !P.probe && !sym) ? 2 : nfr;
     if ((nf != 1 && nf != 2 && nf != 4) || (nf > 1 && (sym || P.big))) return hipErrorInvalidValue;
     if (P.lut_tx && (sym || nf != 1 || (dtype != 1 && dtype != 2) || (P.syn && dtype != 1))) return hipErrorInvalidValue;

@@ -85,10 +85,15 @@ struct TileCfg {
     static constexpr bool F32 = (SB == 8);
     static constexpr bool F64 = (SB == 16);          // double data: geometry, delays, weights and sums in fp64 (tile_pairs.h pairs_f64)
     // instantiations that may run a pixel x receiver weight: their stage list holds the ACTIVE receivers only
+#ifdef QDAS_JIT
+    static constexpr bool JITB = true;               // plan-specialised build: constants folded, registers to spare
+#else
+    static constexpr bool JITB = false;
+#endif
 #ifdef QDAS_NO_ACT
     static constexpr bool ACT = false;               // (A/B builds)
 #else
-    static constexpr bool ACT = !F64 && !SYM && !BIG && !BF_ && !(FB2 && F32) && !FB4;     // (fp32 frames sharing a launch keep the plain list: no register for it)
+    static constexpr bool ACT = !F64 && !SYM && !BIG && !BF_ && !(FB2 && F32 && !JITB) && !FB4;     // (fp32 frames sharing a launch keep the plain list: no register for it)
     // a pixel x receiver weight in lateral-mirror mode: the mirror image of a pixel has its OWN weight (fp16 two-window-set kernels)
     static constexpr bool WMIR = ACT && FB2;
 #endif
@@ -444,7 +449,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
     for (int f = 0; f < C::NFR; ++f) tot[f] = (v2f){0.f, 0.f};
     // weights from an I x N array, or generated from the geometry (fp32 frames with such a weight do not share launches: their single-frame
     // kernel has the stage list of the active receivers instead, and the two-frame kernels have no registers for the weight bookkeeping)
-    wpix = !C::F64 && !C::SYM && !C::BF && !(C::FBX && C::F32) && (QSPEC(HAS_APIX, P.apix != nullptr) || QSPEC(GEN_KIND, P.gen_kind) != 0);
+    wpix = !C::F64 && !C::SYM && !C::BF && !(C::FBX && C::F32 && !C::WMIR) && (QSPEC(HAS_APIX, P.apix != nullptr) || QSPEC(GEN_KIND, P.gen_kind) != 0);
     bp = false;
     if constexpr (C::BPIX) bp = P.bpix != nullptr;
     syn = !C::SYM && !C::BF && C::F32 && QSPEC(SYN, P.syn);          // keep the stage dimension: one output plane per stage element

@@ -551,7 +551,10 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // pixel-independent weights only (folded into an N x M table): fine when the TABLE is mirror-symmetric, w[n,m] == w[N-1-n,M-1-m] -- receive and
     // transmit windows are --; checked once the table is folded (below).
     const bool mir_tab = z.S > 0 && npix == 0 && !g.gen_kind && dt != QDAS_F64;
-    const bool mir_wpix = dt == QDAS_F16 && !sym && !swap && !bpix_mode && z.S == npix
+    // fp32 data: the two-window-set instantiation has the registers for the weight bookkeeping only as a plan-specialised (hiprtc) build --
+    // taken when the plan asks for one; if that build fails the plan is re-made without the mirror mode (below)
+    const bool jit_asked = (desc->plan_flags & QDAS_PLAN_JIT) && !getenv("QDAS_NO_JIT") && !getenv("QDAS_NO_MIRROR_WPIX32");
+    const bool mir_wpix = (dt == QDAS_F16 || (dt == QDAS_F32 && jit_asked)) && !sym && !swap && !bpix_mode && z.S == npix
                           && ((pix_arr >= 0 && !pix_is_tx && !g.gen_kind) || (pix_arr < 0 && g.gen_kind >= 1 && g.gen_kind <= 4)) && !getenv("QDAS_NO_MIRROR_WPIX");
     if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && (mir_plain || mir_wpix || mir_tab) && !cmap && z.I3 == 1 && z.I2 >= 2
         && z.N >= 2 && ((desc->i_begin == 0 && pl->i_count == pl->I) || mslab) && !(desc->plan_flags & QDAS_PLAN_NO_MIRROR) && !getenv("QDAS_NO_MIRROR")
@@ -924,7 +927,18 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         const std::string err = pl->jit_lds > (size_t)160 * 1024 ? std::string("LDS image too large for the requested configuration")
                                                                  : jit_get_kernel(k, pl->device, &pl->jit_fn, &key);
         if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; }
-        else { pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel"; }
+        else {
+            pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel";
+            if (dt == QDAS_F32 && t.mir && !t.sym && (t.apix || t.gen_kind)) {      // exists only as a hiprtc build: the same plan without the mirror mode
+                qdas_desc d2 = *desc;
+                d2.plan_flags |= QDAS_PLAN_NO_MIRROR;
+                const std::string keep = g_err;
+                delete pl;
+                const int rc2 = qdas_plan_create(out, &d2);
+                if (rc2 == QDAS_OK) g_err = keep;
+                return rc2;
+            }
+        }
     }
     pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->tp.mir && !pl->tp.stage_shift && pl->tp.narrow != 2 && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->jit_fn && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
     // four frames per launch: not for fp32 plans with remodulation, a weight table or a pixel x receiver weight (das_tile_impl.h launch_tile_i)

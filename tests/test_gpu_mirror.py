@@ -195,11 +195,12 @@ def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_pa
     assert rel_err(ys[0], ys[1]) <= loose and rel_err(ys[0], ys[2]) <= loose
 
 
-@pytest.mark.parametrize("jit", [False, True], ids=["prebuilt", "jit"])
+@pytest.mark.parametrize("prec,jit", [("halfT", False), ("halfT", True), ("single", True)], ids=["f16-prebuilt", "f16-jit", "f32-jit"])
 @pytest.mark.parametrize("seq,interp,kind", [("PW", "cubic", "mask"), ("DV", "linear", "mask"), ("PW", "lanczos3", "mask+depth"), ("FSA", "cubic", "pixel-only"),
                                              ("PW", "cubic", "acceptance"), ("DV", "linear", "fnumber"), ("PW", "nearest", "mask"), ("DV", "cubic", "mask/split3")])
-def test_mirror_mode_with_pixel_by_receiver_weights(seq, interp, kind, jit, tmp_path, monkeypatch):
-    """fp16 data with a pixel x receiver weight (BASELINE C5's shape) in lateral-mirror mode: the mirror image of a pixel carries its OWN
+def test_mirror_mode_with_pixel_by_receiver_weights(seq, interp, kind, prec, jit, tmp_path, monkeypatch):
+    """fp16 data -- and fp32 data through a plan-specialised (hiprtc) build, the only form in which the two-window-set fp32 kernel has the registers for
+    the weight bookkeeping -- with a pixel x receiver weight (BASELINE C5's shape) in lateral-mirror mode: the mirror image of a pixel carries its OWN
     weight, taken at the mirrored receiver -- the arrays here are random, NOT symmetric --; generated rules need mirror-symmetric element
     normals and then have the same value there; the tile's stage list keeps a receiver that matters to either half."""
     import torch
@@ -233,29 +234,51 @@ def test_mirror_mode_with_pixel_by_receiver_weights(seq, interp, kind, jit, tmp_
         apod_or = {"acceptance": lambda: A.ap_acceptance_angle(case["Pi"], case["Pr"], nrm, 35.0),
                    "fnumber": lambda: A.ap_aperture_growth(case["Pi"], case["Pr"], nrm, 1.0, 5e-3)}[kind]()
     xt = torch.from_numpy(x)
-    va = list(case["opt"]) + ["interp", interp, "input-precision", "halfT"] + extra
+    va = list(case["opt"]) + ["interp", interp, "input-precision", prec] + extra
     for a in apod:
-        va += ["apod", a]
+        va += ["apod", a.astype(np.float32) if prec == "single" else a]
     prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], parse_options(xt, va))
     ys, plans = [], []
     for mirror in (True, False):
         plan = DasPlan(prob, kernel=2, jit=jit, mirror=mirror, reciprocal=False)
         y = plan.feval(xt)
-        ys.append(torch.view_as_real(y).float().cpu().numpy().view(np.complex64)[..., 0].reshape(-1))
+        ys.append((torch.view_as_real(y).float().cpu().numpy().view(np.complex64)[..., 0] if prec == "halfT" else y.cpu().numpy()).reshape(-1))
         plans.append(plan)
     assert plans[0].mirror and ",mirror" in plans[0].kernel_name() and not plans[1].mirror, [p.kernel_name() for p in plans]
     assert plans[0].fallback_tiles() == 0 and ("[jit " in plans[0].kernel_name()) == jit
     ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], x, case["t0"], case["fs"], cinv_f32(case["c"]), VS=case["VS"], DV=case["DV"],
                      interp=interp, apod=apod if apod else [apod_or]).reshape(-1, order="F")
     assert np.abs(ref).max() > 0
-    tol = 1e-2 if interp == "nearest" else 2e-3
+    tol = 1e-2 if interp == "nearest" else (2e-3 if prec == "halfT" else 2e-5)
     assert rel_err(ys[0], ref) <= tol and rel_err(ys[1], ref) <= tol, [p.kernel_name() for p in plans]
-    assert rel_err(ys[0], ys[1]) <= (1e-2 if interp == "nearest" else 2e-4)
+    assert rel_err(ys[0], ys[1]) <= (1e-2 if interp == "nearest" else 2e-4 if prec == "halfT" else 1e-5)
     if kind.startswith("mask"):                          # an asymmetric mask really gives an asymmetric image: left and right halves differ
         img = ys[0].reshape(I1, I2, order="F")
         assert rel_err(img[:, : I2 // 2], img[:, ::-1][:, : I2 // 2]) > 1e-2
     for p in plans:
         p.close()
+
+
+def test_fp32_pixel_weight_mirror_plan_falls_back_when_the_hiprtc_build_fails(tmp_path, monkeypatch):
+    """the fp32 mirror plan with a pixel x receiver weight exists only as a hiprtc build: if that build fails the plan is re-made without the
+    mirror mode (and says so) instead of failing at the first frame"""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import DasPlan, build_problem, parse_options, _lib
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("QDAS_JIT_DEFINES", "uint32_t=@@")                  # (breaks the translation unit)
+    case = make_case(seq="PW", interp="cubic", seed=92, N=16, M=12, I1=96, I2=20)
+    rng = np.random.default_rng(2)
+    a = ((rng.random((96, 20, 1, 16, 1)) > 0.4) * rng.uniform(0.5, 1.0, (96, 20, 1, 16, 1))).astype(np.float32)
+    xt = torch.from_numpy(case["x"])
+    va = list(case["opt"]) + ["interp", "cubic", "apod", a]
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], parse_options(xt, va))
+    with DasPlan(prob, kernel=2, jit=True) as plan:
+        assert not plan.mirror and "[prebuilt]" in plan.kernel_name() and plan.kernel == "tiled"
+        y = plan.feval(xt).cpu().numpy().reshape(-1)
+    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"], cinv_f32(case["c"]), VS=case["VS"], DV=case["DV"],
+                     interp="cubic", apod=[a.astype(np.float64)]).reshape(-1, order="F")
+    assert rel_err(y, ref) <= 2e-5
 
 
 def test_mirror_mode_is_not_taken_where_it_is_not_built():
