@@ -8,11 +8,12 @@
 // transmit).  The general single-delay kernel (wsinterpd.hip) serves that call too -- one lane per output, every term a gather from global memory
 // with its own index and weight evaluation (C1: 1.56 ms).  Here the structure is used:
 //   * the offset does not depend on t': tap offset floor(s), the K interpolation weights and the range of valid t' are properties of (m, m') --
-//     a table of M x Mo entries made by a small kernel (the library's own interp_weights: same numbers as every other kernel), read by the main
-//     kernel through the scalar cache;
+//     a table of M x Mo entries made by a small kernel (the library's own interp_weights: same numbers as every other kernel; a real weight is
+//     folded into them); the main kernel copies an element's entries into LDS together with its window (a chain of dependent scalar loads per
+//     entry was the first version's bottleneck);
 //   * a workgroup owns 256 x TPT consecutive output samples of one receiver and MOB synthesised transmits; per element m it stages ONE window
-//     of the trace x[:, n, m] in LDS (the samples those outputs can reach) and every lane reads its K consecutive taps from there: consecutive
-//     lanes, consecutive addresses;
+//     of the trace x[:, n, m] in LDS (the samples those outputs can reach; prefetched into registers while the previous element is worked on)
+//     and every lane reads its K consecutive taps from there: consecutive lanes, consecutive addresses, packed FMAs;
 //   * zero weights (the apodization of a walking aperture is mostly zeros) are uniform skips; an element with no weight in the block is not staged.
 // Edge rule as everywhere (src/interpd.cu:70-150): a term counts iff all its taps lie in [0, T) and the position is >= 0.
 #include "qdas_device.h"
