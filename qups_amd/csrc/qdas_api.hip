@@ -940,7 +940,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             }
         }
     }
-    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->tp.mir && !pl->tp.stage_shift && pl->tp.narrow != 2 && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->jit_fn && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
+    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->tp.mir && !pl->tp.stage_shift && pl->tp.narrow != 2 && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
     // four frames per launch: not for fp32 plans with remodulation, a weight table or a pixel x receiver weight (das_tile_impl.h launch_tile_i)
     pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr
                   || (dt == QDAS_F32 && pl->kernel == QDAS_KERNEL_TILED && (pl->tp.fmod != 0.0 || pl->tp.wtab || pl->tp.apix || pl->tp.gen_kind));
@@ -1030,9 +1030,12 @@ static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s, int n
             for (int f = 0; f < nf; ++f)
                 HIPCHK(hipMemset2DAsync((char *)y + (size_t)f * y_fstride * ds, (size_t)pl->y_ld * ds, 0, (size_t)pl->i_count * ds, pl->oN * pl->oM, s));
         }
-        if (pl->no_fallback) return hip_rc(launch_tile(t, z.dtype, pl->ntiles, s, pl->jit_fn, pl->jit_lds));     // one launch per frame (+ the reduce of a split aperture)
+        // (frames that share a launch run the prebuilt two- / four-frame kernels also in plans with a hiprtc build: shared tap indices and
+        //  weights are worth more than the specialisation -- C2: 1.49 ms per frame in pairs, 1.64 ms one by one on the hiprtc build)
+        const hipFunction_t jf = nf == 1 ? pl->jit_fn : nullptr;
+        if (pl->no_fallback) return hip_rc(launch_tile(t, z.dtype, pl->ntiles, s, jf, pl->jit_lds));     // one launch per frame (+ the reduce of a split aperture)
         HIPCHK(hipMemsetAsync(pl->fallback, 0, sizeof(uint32_t), s));
-        HIPCHK(launch_tile(t, z.dtype, pl->ntiles, s, pl->jit_fn, pl->jit_lds));
+        HIPCHK(launch_tile(t, z.dtype, pl->ntiles, s, jf, pl->jit_lds));
         // tiles whose delay window overflowed LDS are redone by the generic kernel; the launch is
         // sized for the worst case and exits immediately for ids >= the device-side count
         GenericParams g = pl->gp;

@@ -190,3 +190,31 @@ def test_environment_default_builds_the_specialised_kernel(tmp_path, monkeypatch
     assert "[prebuilt]" in p0.kernel_name() and "[jit " in p1.kernel_name()
     a, b = y0.cpu().numpy(), y1.cpu().numpy()
     assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mirror", [False, True], ids=["plain", "mirror"])
+def test_jit_plan_streams_share_launches(mirror, tmp_path, monkeypatch):
+    """a stream of frames through a plan with a hiprtc build: groups of four / two frames run the prebuilt frame-sharing kernels (shared tap
+    indices and weights beat the specialisation), the odd frame the hiprtc build; every frame equals its one-by-one result"""
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd.das_spec import _colmajor
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    case = make_case(seq="PW", interp="cubic", seed=41, N=16, M=12, I1=128, I2=24)
+    rng = np.random.default_rng(9)
+    F = 7
+    xs = np.stack([case["x"]] + [(rng.standard_normal(case["x"].shape) + 1j * rng.standard_normal(case["x"].shape)).astype(np.complex64) for _ in range(F - 1)], axis=3)
+    xt = torch.from_numpy(xs)
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"],
+                         parse_options(xt, list(case["opt"]) + ["interp", "cubic"]))
+    xc = _colmajor(xt.cuda())
+    with DasPlan(prob, kernel=2, jit=True, mirror=mirror) as plan:
+        assert "[jit " in plan.kernel_name() and plan.mirror == mirror
+        y = plan.execute_colmajor(xc, F).cpu().numpy().reshape(F, -1)
+        monkeypatch.setenv("QDAS_NO_FB2", "1")
+        monkeypatch.setenv("QDAS_NO_FRAMES_TWIN", "1")
+        y1 = plan.execute_colmajor(xc, F).cpu().numpy().reshape(F, -1)
+    for f in range(F):
+        assert rel_err(y[f], y1[f]) <= (3e-5 if mirror else 2e-6), f    # (mirror plans stream groups of four through their twin without the mirror mode: another summation order)
+    assert rel_err(y[0], y[1]) > 1e-2                       # (different frames)
