@@ -98,10 +98,10 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     const int sym = P.sym ? 1 : 0;
     if (sym && dtype != 1 && dtype != 2) return hipErrorInvalidValue;
     if (dtype == 0) {                                    // fp64 data: one frame, one workgroup per tile, plain 'DAS' sum, prebuilt kernels
-        if (jit || P.lut_tx || P.bf || P.syn || P.big || P.nfr > 1 || (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part)))) return hipErrorInvalidValue;
+        if (P.lut_tx || P.bf || P.syn || P.big || P.nfr > 1 || (jit && P.probe) || (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part)))) return hipErrorInvalidValue;
         const size_t lds64 = tile_lds_bytes(0, 0, P.N, P.M, 0);
         if (lds64 > tile_lds_limit(0)) return hipErrorInvalidValue;
-        hipError_t e64 = launch_tile_f64(P, ntiles, lds64, s);
+        hipError_t e64 = jit ? jit_launch(jit, P, ntiles * P.ksplit, (unsigned)CFGS[13].waves * 64u, lds64, s) : launch_tile_f64(P, ntiles, lds64, s);
         if (e64 != hipSuccess || P.probe || P.ksplit <= 1) return e64;
         tile_reduce_kernel_f64<<<(unsigned)((P.i_count + 255) / 256), 256, 0, s>>>((const double2 *)P.part, (double2 *)P.y, P.i_count, P.ksplit);
         return hipGetLastError();

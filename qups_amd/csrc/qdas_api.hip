@@ -888,7 +888,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // ---- QDAS_PLAN_JIT: the tiled kernel compiled for this plan's sizes (jit.hip).  A failure is not an error: the plan keeps its
     //      prebuilt kernel and qdas_last_error() says why.
     g_err.clear();
-    if ((desc->plan_flags & QDAS_PLAN_JIT) && pl->kernel == QDAS_KERNEL_TILED && !pl->tp.bf && dt != QDAS_F64 && !getenv("QDAS_NO_JIT")) {
+    if ((desc->plan_flags & QDAS_PLAN_JIT) && pl->kernel == QDAS_KERNEL_TILED && !pl->tp.bf && !getenv("QDAS_NO_JIT")) {
         const TileParams &t = pl->tp;
         JitSpec k{};
         k.interp = (z.flag & 7) == 4 ? 1 : (z.flag & 7); k.dtype = dt; k.fmod = t.fmod != 0.0; k.wtab = t.wtab != nullptr; k.sym = t.sym; k.big = t.big;
@@ -921,7 +921,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             size_t body = (size_t)k.nbuf * k.mb * (mirq ? 4 : (t.sym || t.mir) ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
             const size_t scratch = 2 * (size_t)k.waves * MX * 4 + 1024;
             if (body < scratch) body = scratch;
-            pl->jit_lds = hdr + body;
+            pl->jit_lds = dt == QDAS_F64 ? 0 : hdr + body;       // (fp64 data: the prebuilt configuration's own LDS image, das_tile.hip)
         }
         std::string key;
         const std::string err = pl->jit_lds > (size_t)160 * 1024 ? std::string("LDS image too large for the requested configuration")

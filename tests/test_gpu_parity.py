@@ -360,6 +360,33 @@ def test_double_precision_remodulation_in_the_tiled_kernel(seq, interp):
     assert rel_err(out, gen) <= 1e-10
 
 
+@pytest.mark.parametrize("interp,fmod,wtab", [("cubic", 0.0, False), ("lanczos3", 3.1e6, True), ("linear", -2.0e6, False), ("nearest", 0.0, True)])
+def test_double_precision_hiprtc_build(interp, fmod, wtab, tmp_path, monkeypatch):
+    """fp64 plans take a plan-specialised (hiprtc) build as well: same numbers as the prebuilt kernel to re-association, 1e-10 against the oracle"""
+    torch = _torch()
+    from qups_amd import DasPlan, build_problem, parse_options
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    rng = np.random.default_rng(7)
+    case = make_case(seq="PW", interp=interp, seed=23, I1=150, I2=21, N=24, M=19)
+    N, M = case["N"], case["M"]
+    ap = ()
+    va = list(case["opt"]) + ["interp", interp, "input-precision", "double", "modulation", fmod]
+    if wtab:
+        ap = (rng.uniform(0.2, 1, (1, 1, 1, N, 1)), rng.uniform(0.1, 1, (1, 1, 1, 1, M)) * (1 + 0.5j))
+        for a in ap:
+            va += ["apod", a]
+    xt = torch.from_numpy(case["x"].astype(np.complex128))
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], parse_options(xt, va))
+    ys = []
+    for jit in (False, True):
+        with DasPlan(prob, kernel=2, jit=jit) as plan:
+            assert ("[jit " in plan.kernel_name()) == jit and ",f64" in plan.kernel_name(), plan.kernel_name()
+            ys.append(plan.feval(xt).cpu().numpy().reshape(-1))
+    ref = _oracle64(case, apod=ap, fmod=fmod).reshape(-1, order="F")
+    assert rel_err(ys[1], ref) <= 1e-10 and rel_err(ys[0], ref) <= 1e-10
+    assert rel_err(ys[1], ys[0]) <= 1e-12
+
+
 def test_double_precision_remodulation_variants():
     """remodulation of fp64 data together with a weight table (one zero weight), with a record shorter than the path (checked loop) and
     with a negative modulation frequency"""
