@@ -35,6 +35,7 @@ b c3_fnumber1.5 --rx-apod fnumber:1.5 --no-cpu --no-general --steps 10
 b c3_fp16_fnumber1.5 --prec halfT --rx-apod fnumber:1.5 $Q --steps 10
 QDAS_NO_MIRROR=1 b c5_no_mirror --workload c5 $Q --steps 50
 b c2_double --workload c2 --prec double $Q --steps 10
+b c2_double_fmod --workload c2 --prec double --fmod 5e6 $Q --steps 10
 b c2_window --workload c2 --window-apod $Q --steps 20
 b pw9 --workload pw9 $Q --steps 100
 b c1f --workload c1f $Q --steps 100
