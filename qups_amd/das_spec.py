@@ -257,7 +257,9 @@ def build_problem(fun, Pi, Pr, Pv, Nv, xshape, t0, fs, c, opts: dict) -> DasProb
             raise DasError("Undefined sampling rate.")
     fs = float(_to_numpy(fs).reshape(-1)[0])
 
-    Pi = _mod_dim(_mod_size(_to_numpy(Pi, np.float64)))
+    Pi = _mod_dim(_mod_size(_to_numpy(Pi)))                  # (kept in its own type: the pixel grid is the one large geometry array, and col() casts it)
+    if Pi.dtype.kind not in "fiu":
+        Pi = Pi.astype(np.float64)
     Pr = _mod_dim(_mod_size(_to_numpy(Pr, np.float64)))
     Pv = _mod_dim(_mod_size(_to_numpy(Pv, np.float64)))
     Nv = _mod_dim(_mod_size(_to_numpy(Nv, np.float64)))
@@ -354,7 +356,7 @@ def build_problem(fun, Pi, Pr, Pv, Nv, xshape, t0, fs, c, opts: dict) -> DasProb
     # data is transposed.  (The reference then labels that buffer [Isz N M], kern/das_spec.m:381 -- "perm(N x M)",
     # src/UltrasoundSystem.m:3357; here the array is returned with the shape it actually has.)
     osize = {"DAS": (1, 1), "SYN": (N, 1), "MUL": (1, M), "BF": (M, N) if tpose else (N, M), "delays": (N, M)}[fun]
-    col = lambda A: np.ascontiguousarray(A.reshape(-1, order="F").astype(rt))
+    col = lambda A: _col_cached(A, rt)
     rxa = opts.get("rx_apod")
     if rxa is not None:
         if not isinstance(rxa, dict) or "kind" not in rxa:
@@ -698,6 +700,38 @@ def _plan_cache_size() -> int:
         return 8
 
 
+_COL_CACHE: "collections.OrderedDict[tuple, np.ndarray]" = collections.OrderedDict()
+_COL_DIGEST: dict = {}
+
+
+def _col_cached(A, rt):
+    """``A`` flattened in column-major order as ``rt`` -- memoised by CONTENT (a 64-bit xxh3 of the bytes, ~10 GB/s): a frame loop through
+    ``das_spec`` / ``UltrasoundSystem.DAS`` hands over the same pixel grid every call, and the strided flatten of a 3 x 1024 x 1024 grid costs
+    19 ms -- as much as beamforming the C3 frame.  (The reference keeps these arrays on the device between calls.)"""
+    A = np.asarray(A)
+    if A.size < 4096:
+        return np.ascontiguousarray(A.reshape(-1, order="F").astype(rt))
+    Ac = np.ascontiguousarray(A)
+    try:
+        import xxhash
+        dig = xxhash.xxh3_128(Ac.view(np.uint8).reshape(-1).data).digest()
+    except ImportError:
+        import hashlib
+        dig = hashlib.blake2b(Ac.view(np.uint8).reshape(-1).data, digest_size=16).digest()
+    key = (A.shape, A.dtype.str, np.dtype(rt).str, dig)
+    hit = _COL_CACHE.get(key)
+    if hit is not None:
+        _COL_CACHE.move_to_end(key)
+        return hit
+    out = np.ascontiguousarray(Ac.reshape(-1, order="F").astype(rt))
+    _COL_CACHE[key] = out
+    _COL_DIGEST[id(out)] = (out, dig)                        # problem_key() takes the digest instead of hashing the flattened copy again
+    while len(_COL_CACHE) > 16 or sum(v.nbytes for v in _COL_CACHE.values()) > (1 << 30):
+        _, old = _COL_CACHE.popitem(last=False)
+        _COL_DIGEST.pop(id(old), None)
+    return out
+
+
 def _hasher():
     try:                                    # xxh3: ~10 GB/s (BASELINE C5's 268 MB mask in 25 ms); blake2b as the portable stand-in
         import xxhash
@@ -723,6 +757,11 @@ def problem_key(prob: DasProblem, *extra) -> bytes:
         if a is None:
             h.update(b"\0none")
         else:
+            known = _COL_DIGEST.get(id(a))
+            if known is not None and known[0] is a:              # a memoised flatten: its content digest (of the source array) stands for it
+                h.update(repr((a.dtype.str, a.shape)).encode())
+                h.update(b"digest" + known[1])
+                continue
             a = np.ascontiguousarray(a)
             h.update(repr((a.dtype.str, a.shape)).encode())
             h.update(a.view(np.uint8).reshape(-1).data if a.size else b"")

@@ -383,17 +383,22 @@ class UltrasoundSystem:
             e = lambda P: P[:, None, None, None, :]
             ct = tt(np.asarray(c0, float))
             ct = ct.reshape(tuple(ct.shape) + (1,) * (4 - ct.ndim)) if ct.ndim else ct
-            tau_rx = torch.stack([torch.linalg.norm(Pi_t - Pr_t[:, n, None, None, None], dim=0) for n in range(Pr_t.shape[1])], -1) / ct
+            # blocks of elements whose 3 x I x block temporary stays below ~256 MB: a handful of launches instead of one per element
+            I = int(np.prod(Pi_t.shape[1:]))
+            nb = max(1, (1 << 25) // max(3 * I, 1))
+            ex = lambda P, a, b: P[:, None, None, None, a:b]
+            tau_rx = torch.cat([torch.linalg.norm(Pi_t[..., None] - ex(Pr_t, a, min(a + nb, Pr_t.shape[1])), dim=0)
+                                for a in range(0, Pr_t.shape[1], nb)], -1) / ct
             cols = []
-            for m in range(M):                                     # one transmit at a time: no 3 x I x M temporary
-                rv = Pi_t - Pv_t[:, m, None, None, None]
+            for a in range(0, M, nb):
+                rv = Pi_t[..., None] - ex(Pv_t, a, min(a + nb, M))
                 if self.seq.type in ("DV", "FSA"):
                     cols.append(torch.linalg.norm(rv, dim=0))
                 elif self.seq.type in ("VS", "FC"):
-                    cols.append(torch.linalg.norm(rv, dim=0) * torch.sign((rv * Nv_t[:, m, None, None, None]).sum(0)))
+                    cols.append(torch.linalg.norm(rv, dim=0) * torch.sign((rv * ex(Nv_t, a, min(a + nb, M))).sum(0)))
                 else:
-                    cols.append((rv * Nv_t[:, m, None, None, None]).sum(0))
-            return tau_rx, torch.stack(cols, -1) / ct
+                    cols.append((rv * ex(Nv_t, a, min(a + nb, M))).sum(0))
+            return tau_rx, torch.cat(cols, -1) / ct
         dr = np.linalg.norm(Pi[..., None] - Pr[:, None, None, None, :], axis=0)
         rv = Pi[..., None] - Pv[:, None, None, None, :]
         t = self.seq.type
