@@ -122,7 +122,10 @@ def _flat_colmajor(a: np.ndarray, dtype) -> np.ndarray:
     if a.size < (1 << 16) or tdt is None or not a.flags.c_contiguous or not a.flags.aligned or a.dtype.byteorder == ">" or a.dtype.kind not in "biufc":
         return a.reshape(-1, order="F").astype(dtype)
     import torch
-    t = torch.from_numpy(a).to(getattr(torch, tdt))
+    import warnings
+    with warnings.catch_warnings():                     # (a read-only array is only read here)
+        warnings.simplefilter("ignore", UserWarning)
+        t = torch.from_numpy(a).to(getattr(torch, tdt))
     return t.permute(*reversed(range(t.ndim))).contiguous().reshape(-1).numpy()
 
 
@@ -341,7 +344,8 @@ def build_problem(fun, Pi, Pr, Pv, Nv, xshape, t0, fs, c, opts: dict) -> DasProb
             flat = np.concatenate([np.stack([a.real, a.imag], 0).reshape(2, -1, order="F").T.reshape(-1)
                                    for a in apods]).astype(np.float16)
         else:
-            flat = np.concatenate([_flat_colmajor(a, adt) for a in apods])
+            parts = [_flat_cached(a, adt) for a in apods]
+            flat = parts[0] if len(parts) == 1 else np.concatenate(parts)
     else:
         flat = None
 
@@ -729,6 +733,55 @@ def _col_cached(A, rt):
     while len(_COL_CACHE) > 16 or sum(v.nbytes for v in _COL_CACHE.values()) > (1 << 30):
         _, old = _COL_CACHE.popitem(last=False)
         _COL_DIGEST.pop(id(old), None)
+    return out
+
+
+def _immutable(a: np.ndarray) -> bool:
+    """nobody can change the bytes behind ``a``: read-only, and so is every array it is a view of"""
+    while isinstance(a, np.ndarray):
+        if a.flags.writeable:
+            return False
+        a = a.base
+    return a is None or isinstance(a, (bytes, memoryview)) and getattr(a, "readonly", True)
+
+
+_FLAT_CACHE: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
+
+
+def _flat_cached(a: np.ndarray, adt) -> np.ndarray:
+    """``_flat_colmajor(a, adt)`` memoised for large apodization arrays: by IDENTITY when the array is immutable (``a.setflags(write=False)`` --
+    the generators of ``qups_amd.apodization`` return such arrays), else by content (xxh3 of the bytes: 27 ms for BASELINE C5's 268 MB mask, where
+    the transposing cast takes 60-130 ms).  A frame loop through ``das_spec`` / ``UltrasoundSystem.DAS`` hands over the same mask every call; the
+    plan API (``DasPlan`` / ``return_plan=True``) skips all of this."""
+    if a.size < (1 << 16):
+        return _flat_colmajor(a, adt)
+    ident = None
+    if _immutable(a):
+        # (the cache entry keeps a reference to the array: its memory cannot be freed and handed to another array while the entry lives)
+        ident = ("buffer", a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str, np.dtype(adt).str)
+        hit = _FLAT_CACHE.get(ident)
+        if hit is not None:
+            _FLAT_CACHE.move_to_end(ident)
+            return hit[1]
+    ac = np.ascontiguousarray(a)
+    h = _hasher()
+    h.update(ac.view(np.uint8).reshape(-1).data)
+    dig = h.digest()
+    key = ("content", a.shape, a.dtype.str, np.dtype(adt).str, dig)
+    hit = _FLAT_CACHE.get(key)
+    if hit is None:
+        out = _flat_colmajor(a, adt)
+        _FLAT_CACHE[key] = (None, out)
+        _COL_DIGEST[id(out)] = (out, dig)
+    else:
+        _FLAT_CACHE.move_to_end(key)
+        out = hit[1]
+    if ident is not None:
+        _FLAT_CACHE[ident] = (a, out)
+    while len(_FLAT_CACHE) > 12 or sum(v[1].nbytes for v in _FLAT_CACHE.values()) > (3 << 30):
+        _, old = _FLAT_CACHE.popitem(last=False)
+        if not any(v[1] is old[1] for v in _FLAT_CACHE.values()):
+            _COL_DIGEST.pop(id(old[1]), None)
     return out
 
 

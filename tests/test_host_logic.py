@@ -219,3 +219,36 @@ def test_problem_key_is_content_addressed(monkeypatch):
     monkeypatch.setenv("QDAS_TILE_Z", "16")
     others.append(key())
     assert len(set(others + [k0])) == len(others) + 1
+
+
+def test_marshalling_memos_follow_content_and_immutability():
+    """the memoised column-major copies (pixel grid, large apodization arrays): same content -> same plan key and the same cached object;
+    changed content -> a new key; a read-only array is recognised by its buffer without hashing"""
+    import torch
+    from qups_amd.das_spec import build_problem, parse_options, problem_key, _FLAT_CACHE
+    rng = np.random.default_rng(0)
+    I1, I2, N, M, T = 96, 80, 12, 9, 64
+    Pi = np.stack(np.meshgrid(np.linspace(1e-3, 9e-3, I1), [0.0], np.linspace(-4e-3, 4e-3, I2), indexing="ij"), 0)[:, :, 0, :].transpose(0, 1, 2)
+    Pi = np.stack([Pi[2], Pi[1], Pi[0]], 0).reshape(3, I1, I2, 1)
+    Pr = np.stack([np.linspace(-2e-3, 2e-3, N), np.zeros(N), np.zeros(N)])
+    Pv = np.stack([np.zeros(M), np.zeros(M), -np.linspace(1e-3, 2e-3, M)]); Nv = np.tile(np.array([[0.0], [0.0], [1.0]]), (1, M))
+    x = torch.zeros((T, N, M), dtype=torch.complex64)
+    ap = rng.random((I1, I2, 1, N, 1)).astype(np.float32)                  # 92 160 elements: above the memo threshold
+
+    def key(Pi_, ap_):
+        prob = build_problem("DAS", Pi_, Pr, Pv, Nv, (T, N, M), 0.0, 20e6, 1540.0, parse_options(x, ["apod", ap_]))
+        return problem_key(prob, 0), prob
+
+    k1, p1 = key(Pi, ap)
+    k2, p2 = key(Pi.copy(), ap.copy())
+    assert k1 == k2 and p1.Pi is p2.Pi and p1.apod is p2.apod               # equal content: the memoised objects
+    ap2 = ap.copy(); ap2[5, 7, 0, 3, 0] += 0.25
+    k3, p3 = key(Pi, ap2)
+    assert k3 != k1 and p3.apod is not p1.apod
+    Pi2 = Pi.copy(); Pi2[0, 4, 4, 0] += 1e-4
+    assert key(Pi2, ap)[0] != k1
+    ro = ap.copy(); ro.setflags(write=False)
+    k4, p4 = key(Pi, ro)
+    assert k4 == k1 and any(k[0] == "buffer" for k in _FLAT_CACHE)
+    k5, p5 = key(Pi, ro)
+    assert k5 == k1 and p5.apod is p4.apod
