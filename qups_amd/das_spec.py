@@ -794,13 +794,21 @@ def _hasher():
         return hashlib.blake2b(digest_size=16)
 
 
+def _qdas_env():
+    """the ``QDAS_*`` environment as a sorted tuple (from the raw byte table where there is one: no decode of the other ~100 variables per call)"""
+    raw = getattr(os.environ, "_data", None)
+    if isinstance(raw, dict) and raw and isinstance(next(iter(raw)), bytes):
+        return tuple(sorted((k, v) for k, v in raw.items() if k.startswith(b"QDAS_") and k != b"QDAS_PLAN_CACHE"))
+    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("QDAS_") and k != "QDAS_PLAN_CACHE"))
+
+
 def problem_key(prob: DasProblem, *extra) -> bytes:
     """Digest of everything a plan is built from: sizes, flags, geometry, sound speed, apodization (contents, not identities), plus
     ``extra`` (device, kernel choice, plan flags) and the ``QDAS_*`` environment, which steers plan construction."""
     h = _hasher()
     head = (prob.fun, prob.prec, prob.flag, prob.VS, prob.DV, prob.Isz, prob.T, prob.N, prob.M, prob.fs, prob.fmod, prob.apod_real,
             prob.S, prob.tpose, prob.interp, prob.osize, extra,
-            tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("QDAS_") and k != "QDAS_PLAN_CACHE")))
+            _qdas_env())
     h.update(repr(head).encode())
     arrays = [prob.Pi, prob.Pr, prob.Pv, prob.Nv, prob.cinv, prob.apod, prob.acstride]
     if prob.rx_apod is not None:
