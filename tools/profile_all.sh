@@ -71,6 +71,7 @@ rm -rf $OUT/trace_general
 # ---- PCIe-inclusive: host-resident frames through the C ABI, and the int16 RF -> hilbert -> band-pass -> DAS chain for a stream
 python tools/host_frames.py > $OUT/host_frames.txt 2>/dev/null
 python tools/pipeline_bench.py c3 6 64 > $OUT/pipeline_bench.txt 2>/dev/null; python tools/pipeline_bench.py c2 12 64 >> $OUT/pipeline_bench.txt 2>/dev/null
+python tools/c1_chain.py 1000 2>/dev/null | grep -v Warn > $OUT/c1_chain.txt; python tools/c1_chain.py 3 2>/dev/null | grep -v Warn >> $OUT/c1_chain.txt
 # ---- registers: prebuilt library, and the hiprtc builds of this run
 python tools/kernel_regs.py qups_amd/libqdas.so > $OUT/kernel_regs.txt 2>&1
 python tools/kernel_regs.py $QDAS_CACHE_DIR > $OUT/kernel_regs_hiprtc.txt 2>&1
