@@ -152,3 +152,29 @@ def test_channeldata_hilbert_downmix_downsample_chain():
     p = ChannelData(torch.from_numpy(np.ascontiguousarray(x.transpose(1, 2, 0))).cuda(), t0, fs, "NMT").hilbert(1280)      # time last, zero-padded
     refp = hilbert_ref(x.astype(np.float64), 1280)
     assert tuple(p.data.shape) == (N, M, 1280) and np.abs(p.data.cpu().numpy().transpose(2, 0, 1) - refp).max() / np.abs(refp).max() <= 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("QDAS_PRE_FUZZ", "32"))))
+def test_hilbert_random_lengths_and_batches(seed):
+    """random record lengths (smooth numbers for the one-pass kernel -- fixed stage lists, run-time lists, the 512-thread variant -- and arbitrary
+    ones for the hipFFT passes), transform lengths, trace counts, input types and downmix frequencies"""
+    from qups_amd.preproc import hilbert
+    r = np.random.default_rng(9000 + seed)
+    if r.integers(0, 3):
+        N = 1
+        while N < 2 or N > 8192:                                       # a random smooth number
+            N = int(np.prod(r.choice([2, 2, 2, 2, 3, 3, 5, 7, 11, 13], size=int(r.integers(1, 11)))))
+    else:
+        N = int(r.integers(2, 9000))
+    T = int(max(1, N + r.integers(-N // 2, N // 2 + 1))) if r.integers(0, 2) else N
+    K = int(r.choice([1, 2, 3, 8, 33]))
+    i16 = bool(r.integers(0, 2))
+    fdown = float(r.choice([0.0, 0.0, 3.3e6, -1.7e6]))
+    x = r.standard_normal((T, K))
+    xq = np.round(x * 1500).astype(np.int16) if i16 else x.astype(np.float32)
+    fs, t0 = 25e6, -2.1e-6
+    y = hilbert(xq, N if N != T else None, fdown, t0, fs).cpu().numpy()
+    ref = hilbert_ref(xq.astype(np.float64), N, fdown, t0, fs)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() / max(np.abs(ref).max(), 1e-30) <= 3e-5, (N, T, K, i16, fdown, hilbert.last_one_pass)
