@@ -233,3 +233,35 @@ def test_shift_sum_offsets_too_far_apart_for_one_window_and_no_weights():
     assert rel_err(_np(y), ref) <= 2e-5
     with pytest.raises(Exception):
         shift_sum(torch.from_numpy(x.real.copy()), shift, np.ones((M, Mo)) * 1j, "cubic")     # real data take real weights
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("QDAS_SHIFT_FUZZ", "32"))))
+def test_shift_sum_random_configuration(seed):
+    """random record / output lengths (around the 256 x {2,3,4}-sample blocks), element and transmit counts (ragged blocks of 8), frames, types,
+    interpolators, offsets (clustered: one window per element; scattered: a window per transmit), sparse real / complex weights"""
+    import torch
+    from qups_amd.interpd import shift_sum
+    r = np.random.default_rng(12000 + seed)
+    T = int(r.choice([5, 64, 255, 256, 257, 700, 1023, 1025, 2100, 5000]))
+    To = int(r.choice([T, T, max(1, T // 2), T + 37, 1]))
+    N, M, Mo, F = int(r.integers(1, 4)), int(r.choice([1, 2, 7, 12])), int(r.choice([1, 3, 8, 9, 17])), int(r.choice([1, 1, 2]))
+    dtype = str(r.choice(["complex64", "complex64", "complex128", "float32", "float64"]))
+    interp = str(r.choice(["nearest", "linear", "cubic", "lanczos3", "cubic_dev"]))
+    cplx = dtype.startswith("complex")
+    x = (r.standard_normal((T, N, M, F)) + (1j * r.standard_normal((T, N, M, F)) if cplx else 0)).astype(dtype)
+    spread = float(r.choice([3.0, 40.0, 600.0, 6000.0]))
+    shift = r.uniform(-spread, spread, (M, Mo)) + r.choice([0.0, -T / 3, T / 3])
+    if r.integers(0, 3) == 0:
+        shift = np.round(shift * 2) / 2                                                  # integers and half-integers
+    dbl = dtype in ("complex128", "float64")
+    if not dbl:
+        shift = shift.astype(np.float32).astype(np.float64)
+    wkind = int(r.integers(0, 4))
+    w = None if wkind == 0 else r.uniform(0.1, 1, (M, Mo)) * ((1 + 0.3j) if (wkind == 3 and cplx) else 1)
+    if w is not None:
+        w[r.random((M, Mo)) < float(r.choice([0.0, 0.4, 0.9]))] = 0
+    y = shift_sum(torch.from_numpy(x), shift, w, interp, To=To)
+    ref = _shift_ref(x, shift, np.ones((M, Mo)) if w is None else w, interp, To)
+    scale = max(np.abs(ref).max(), 1e-30)
+    assert tuple(y.shape) == ref.shape
+    assert np.abs(_np(y) - ref).max() / scale <= (1e-11 if dbl else 3e-5) or np.abs(ref).max() == 0 and np.abs(_np(y)).max() == 0, (seed, T, To, N, M, Mo, F, dtype, interp, spread, wkind)
