@@ -706,9 +706,15 @@ def _plan_cache_size() -> int:
 
 _COL_CACHE: "collections.OrderedDict[tuple, np.ndarray]" = collections.OrderedDict()
 _COL_DIGEST: dict = {}
+_MEMO_LOCK = threading.RLock()                            # the marshalling memos below are shared by every thread that calls das_spec
 
 
 def _col_cached(A, rt):
+    with _MEMO_LOCK:
+        return _col_cached_locked(A, rt)
+
+
+def _col_cached_locked(A, rt):
     """``A`` flattened in column-major order as ``rt`` -- memoised by CONTENT (a 64-bit xxh3 of the bytes, ~10 GB/s): a frame loop through
     ``das_spec`` / ``UltrasoundSystem.DAS`` hands over the same pixel grid every call, and the strided flatten of a 3 x 1024 x 1024 grid costs
     19 ms -- as much as beamforming the C3 frame.  (The reference keeps these arrays on the device between calls.)"""
@@ -749,6 +755,11 @@ _FLAT_CACHE: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
 
 
 def _flat_cached(a: np.ndarray, adt) -> np.ndarray:
+    with _MEMO_LOCK:
+        return _flat_cached_locked(a, adt)
+
+
+def _flat_cached_locked(a: np.ndarray, adt) -> np.ndarray:
     """``_flat_colmajor(a, adt)`` memoised for large apodization arrays: by IDENTITY when the array is immutable (``a.setflags(write=False)`` --
     the generators of ``qups_amd.apodization`` return such arrays), else by content (xxh3 of the bytes: 27 ms for BASELINE C5's 268 MB mask, where
     the transposing cast takes 60-130 ms).  A frame loop through ``das_spec`` / ``UltrasoundSystem.DAS`` hands over the same mask every call; the
@@ -818,7 +829,8 @@ def problem_key(prob: DasProblem, *extra) -> bytes:
         if a is None:
             h.update(b"\0none")
         else:
-            known = _COL_DIGEST.get(id(a))
+            with _MEMO_LOCK:
+                known = _COL_DIGEST.get(id(a))
             if known is not None and known[0] is a:              # a memoised flatten: its content digest (of the source array) stands for it
                 h.update(repr((a.dtype.str, a.shape)).encode())
                 h.update(b"digest" + known[1])
