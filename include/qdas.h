@@ -58,7 +58,7 @@ extern "C" {
 #define QDAS_MEM_DEVICE 1
 
 /* ---- kernel selection (QDAS_KERNEL_AUTO picks the tiled kernel when eligible)
- * Eligible: 'DAS' with any data precision -- fp64 data: pixel-independent apodization, scalar sound speed --,
+ * Eligible: 'DAS' with any data precision -- fp64 data: pixel-independent apodization and / or one pixel x receiver (pixel-only) array, scalar sound speed --,
  * 'SYN' / 'MUL' / 'BF' with fp32 data; scalar sound speed or a full per-pixel map; any number of pixel-independent apodization arrays
  * (folded into an N x M table) plus pixel-dependent arrays of ONE side: I x N (pixel x receiver), or I x 1 x M (pixel x transmit: 'DAS' / 'MUL';
  * the roles of the two apertures are swapped), with any I-only arrays (spatial weights / region-of-interest masks) -- several of them, or arrays

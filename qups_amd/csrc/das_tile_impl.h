@@ -96,6 +96,7 @@ struct TileCfg {
     static constexpr bool ACT = !F64 && !SYM && !BIG && !BF_ && !(FB2 && F32 && !JITB) && !FB4;     // (fp32 frames sharing a launch keep the plain list: no register for it)
     // a pixel x receiver weight in lateral-mirror mode: the mirror image of a pixel has its OWN weight (fp16 two-window-set kernels)
     static constexpr bool WMIR = ACT && FB2;
+    static constexpr bool W64 = F64 && !FMOD_;       // fp64 data: a pixel x receiver (or pixel-only) weight ARRAY, plain list of stages (the remodulation variants have no registers for it)
 #endif
     // pixel-independent weights (N x M table) reach the pair loop through LDS: the 32 (reciprocal mode: 2 x 32) table entries of a stage are
     // fetched one stage ahead by a single wave and read back with broadcast ds_reads -- as scalar loads inside the pair loop they cost a
@@ -164,6 +165,7 @@ template <class C> struct Tile {
     double rad[C::F64 ? C::MB : 1];                  // fp64 data: the same residuals, one double per transmit
     double dacc[4];                                  // fp64 data: two independent complex partial sums {re, im, re, im}
     v2f tot[C::NFR];                                 // weighted totals per frame when a pixel x receiver weight is applied
+    double dtot[2], w64[2];                          // fp64 data: the same in double (weighted total, this stage's weight); instantiations without remodulation only
     bool wpix, syn;
     // ---- LDS-DMA staging (tile_staging.h)
     int wb[C::WPW], wb2[C::WPW];
@@ -450,6 +452,8 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
     // weights from an I x N array, or generated from the geometry (fp32 frames with such a weight do not share launches: their single-frame
     // kernel has the stage list of the active receivers instead, and the two-frame kernels have no registers for the weight bookkeeping)
     wpix = !C::F64 && !C::SYM && !C::BF && !(C::FBX && C::F32 && !C::WMIR) && (QSPEC(HAS_APIX, P.apix != nullptr) || QSPEC(GEN_KIND, P.gen_kind) != 0);
+    if constexpr (C::W64) wpix = P.apix != nullptr;      // (fp64 data: arrays only, checked by the host)
+    dtot[0] = dtot[1] = 0.0; w64[0] = 1.0; w64[1] = 0.0;
     bp = false;
     if constexpr (C::BPIX) bp = P.bpix != nullptr;
     syn = !C::SYM && !C::BF && C::F32 && QSPEC(SYN, P.syn);          // keep the stage dimension: one output plane per stage element
@@ -529,7 +533,15 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
     const uint32_t n_first = nstage ? nsel(0) : n_lo;
     bool wmir = false;                                 // array weights in lateral-mirror mode: two weights per stage
     if constexpr (C::WMIR) wmir = wpix && QSPEC(MIR, P.mir) && QSPEC(HAS_APIX, P.apix != nullptr) && QSPEC(GEN_KIND, P.gen_kind) == 0;
-    if (wpix) { wcur = wload(n_first); wcur2 = wcur; if constexpr (C::WMIR) { if (wmir) wcur2 = wconv(wload_raw(n_first, true)); } }
+    // fp64 data: the weight of (my pixel, stage element n) as a double pair, straight from the array (real or complex128)
+    auto wload64 = [&](uint32_t nn, double &wr, double &wi) {
+        const uint64_t k = ipx + (P.apix_pixel_only ? 0ull : P.I1 * P.I2 * P.I3 * (uint64_t)nn);
+        if (P.apix_real) { wr = ((const double *)P.apix)[k]; wi = 0.0; }
+        else { const double2 v = ((const double2 *)P.apix)[k]; wr = v.x; wi = v.y; }
+    };
+    double w64n[2] = {1.0, 0.0};                     // the next stage's weight, requested a stage ahead
+    if constexpr (C::W64) { if (wpix) wload64(n_first, w64[0], w64[1]); }
+    else if (wpix) { wcur = wload(n_first); wcur2 = wcur; if constexpr (C::WMIR) { if (wmir) wcur2 = wconv(wload_raw(n_first, true)); } }
     float tbc = 0.f, tbn = 0.f;                        // LUT: this / the next stage's receive delay of my pixel
     const uint64_t Ilut = P.i_begin + P.i_count;
     if constexpr (C::LUT) tbc = P.lut_rx[ipx + Ilut * n_first];
@@ -630,7 +642,8 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         // an s_waitcnt vmcnt(0) in front of an LDS read that follows them -- it cannot tell them from the LDS-DMA it has to order
         // LDS reads behind: each stage then waited out a global-memory latency) and BEFORE this stage's DMA (so that the counted
         // end-of-stage wait covers them)
-        if (wpix && st + 1 < nstage) { wnext_r = wload_raw(n_next); if constexpr (C::WMIR) { if (wmir) wnext_r2 = wload_raw(n_next, true); } }
+        if constexpr (C::W64) { if (wpix && st + 1 < nstage) wload64(n_next, w64n[0], w64n[1]); }
+        else if (wpix && st + 1 < nstage) { wnext_r = wload_raw(n_next); if constexpr (C::WMIR) { if (wmir) wnext_r2 = wload_raw(n_next, true); } }
         if constexpr (C::LUT) { if (st + 1 < nstage) tbn = P.lut_rx[ipx + Ilut * n_next]; }
         if (st + 1 < nstage) wst_load(n_next, k + 1 == klim(m0) ? blk(cr + 1) : m0);
         if (dma_now) dma_go((buf + NBUF - 1) % NBUF);            // lands during the next NBUF-1 stages
@@ -684,8 +697,11 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
             const int bn = rec_b;
             const double rbd = s_at(n, rec_x, rec_y, rec_z) - (double)bn;
             const uint32_t cbase = win_off + (uint32_t)buf * (C::NW * C::WB);
-            if (m0 + C::MB <= M) pairs_f64<CHECK, false>(n, m0, bn, rbd, cbase);
-            else                 pairs_f64<CHECK, true>(n, m0, bn, rbd, cbase);
+            bool skip64 = false;                       // (a stage whose weight is zero for the whole wave reads no sample: src/bf.cu:122,126)
+            if constexpr (C::W64) skip64 = wpix && __ballot(w64[0] != 0.0 || w64[1] != 0.0) == 0ull;
+            if (skip64) {}
+            else if (m0 + C::MB <= M) pairs_f64<CHECK, false>(n, m0, bn, rbd, cbase);
+            else                      pairs_f64<CHECK, true>(n, m0, bn, rbd, cbase);
         } else if (!skip) {
             const int bn = rec_b;
             const float rb = C::LUT ? tbc - (float)bn : hooks::fake_rx_delay ? (float)(lane * 2 + 3) + 0.37f * (float)(n & 7)
@@ -743,6 +759,13 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
             }
             if (wpix) { if constexpr (!C::F32) asm volatile("" : "+v"(wnext_r.a)); wcur = wconv(wnext_r); }   // (fp16 weights: converted here, a stage after the load)
             acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
+        } else if (C::W64 && wpix) {                   // fp64 data: the stage's sum times the stage element's weight joins the weighted total
+            if constexpr (C::W64) {
+                const double sr = dacc[0] + dacc[2], si = dacc[1] + dacc[3];
+                dtot[0] += w64[0] * sr - w64[1] * si; dtot[1] += w64[0] * si + w64[1] * sr;
+                dacc[0] = dacc[1] = dacc[2] = dacc[3] = 0.0;
+                w64[0] = w64n[0]; w64[1] = w64n[1];
+            }
         } else if (wpix) {                             // weight the stage's partial sum (the weight does not depend on m)
             v2f Sf[4];
             frame_sums(Sf);
@@ -772,7 +795,8 @@ template <class C> __device__ __forceinline__ void Tile<C>::epilogue() {
             asm volatile("" : "+v"(po));
             ST *base = S > 1 ? (ST *)P.part + (size_t)split * P.i_count : (ST *)P.y;
             asm volatile("" : "+s"(base));
-            st(base, (size_t)po, cplx<double>{dacc[0] + dacc[2], dacc[1] + dacc[3]});
+            if (C::W64 && wpix) st(base, (size_t)po, cplx<double>{dtot[0], dtot[1]});
+            else st(base, (size_t)po, cplx<double>{dacc[0] + dacc[2], dacc[1] + dacc[3]});
         }
     } else {
         v2f res[4];
@@ -857,8 +881,8 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
         if constexpr (FB2 || FB4) return hipErrorInvalidValue;    // the window fit does not depend on the frame count: probes use one frame
         else { QDAS_LAUNCH_P(false, false, true); return hipGetLastError(); }
     }
-    if constexpr (sizeof(ST) == 16) {                  // fp64 data: no pixel x receiver weight, no kept dimension (qdas_api.hip)
-        if (P.apix || P.gen_kind || P.syn) return hipErrorInvalidValue;
+    if constexpr (sizeof(ST) == 16) {                  // fp64 data: no generated weight rule, no kept dimension (qdas_api.hip)
+        if ((P.apix && fm) || P.gen_kind || P.syn) return hipErrorInvalidValue;   // (a weight array: the instantiations without remodulation, TileCfg::W64)
         if (fm && wt) QDAS_LAUNCH(true, true);         // (grid: ntiles * ksplit workgroups, as for the other data types)
         else if (fm)  QDAS_LAUNCH(true, false);
         else if (wt)  QDAS_LAUNCH(false, true);

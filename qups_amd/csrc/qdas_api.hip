@@ -496,7 +496,10 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
                 if (ok) { bpix_mode = true; pix_is_tx = true; for (uint64_t s = 0; s < z.S; ++s) is_pix[s] = true; npix = z.S; }
                 else { eligible = false; why = "tiled kernel: pixel x receiver and pixel x transmit apodization arrays together run fused for fp32 data, real weights, 'DAS', no remodulation, no N x M array only"; }
             }
-            else if (dt == QDAS_F64) { eligible = false; why = "tiled kernel, fp64 data: a pixel-dependent apodization array needs the generic kernel"; }
+            else if (dt == QDAS_F64 && !(npix == 1 && direct && !dep_tx && desc->fmod == 0.0 && !syn && !bfm && !mul && !getenv("QDAS_NO_W64"))) {
+                // fp64 data: ONE pixel x receiver (or pixel-only) array, used in place, plain 'DAS', no remodulation (das_tile_impl.h TileCfg::W64)
+                eligible = false; why = "tiled kernel, fp64 data: only a single pixel x receiver / pixel-only apodization array without remodulation runs fused";
+            }
             else if (dep_tx) {
                 if ((!syn || mul) && !bfm) pix_is_tx = true;           // ('MUL': the transmit is the stage element anyway)
                 else { eligible = false; why = "tiled kernel: a pixel x transmit apodization array with 'SYN' / 'BF' needs the generic kernel"; }
@@ -700,12 +703,13 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             t.apix = (const unsigned char *)g.apod + g.ast[6 * pix_arr + 5] * ael;
         }
         t.apix_pixel_only = pix_only ? 1 : 0;
-        t.act_bytes = (t.apix || t.gen_kind) ? (uint32_t)(8 * (t.N + 1)) : 0u;
+        t.act_bytes = ((t.apix || t.gen_kind) && dt != QDAS_F64) ? (uint32_t)(8 * (t.N + 1)) : 0u;      // (fp64 data: the plain list of stages)
         std::vector<float> host_tab;                    // the folded N x M table as uploaded ([stage element + stages * block element])
-        if (z.S > 0 && dt == QDAS_F64) {                // fp64 data: the same table in double (complex128 entries)
+        if (z.S > npix && dt == QDAS_F64) {             // fp64 data: the same table in double (complex128 entries)
             std::vector<double> tab(2 * z.N * z.M);
             for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.0; tab[2 * k + 1] = 0.0; }
             for (uint64_t s = 0; s < z.S; ++s) {
+                if (is_pix[s]) continue;                 // (the pixel x receiver array is applied per stage: das_tile_impl.h TileCfg::W64)
                 const uint64_t *st = &g.ast[6 * s];
                 const uint64_t nel = bcast_numel(st, z);
                 std::vector<double> raw(nel * (desc->apod_real ? 1 : 2));
@@ -724,7 +728,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             hipError_t e = hipMemcpy(dtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
             if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e)));
             t.wtab = dtab;
-        } else if (z.S > npix) {
+        } else if (z.S > npix && dt != QDAS_F64) {
             std::vector<float> &tab = host_tab;
             tab.assign(2 * z.N * z.M, 0.f);
             for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.f; tab[2 * k + 1] = 0.f; }

@@ -37,12 +37,14 @@ def _draw(seed):
         cfg.update(fun="BF", F=min(cfg["F"], 2))
     cfg.update(extra)
     if r.integers(0, 8) == 0 and not extra["sym"] and cfg["fun"] != "BF":   # fp64 data on the fused kernel: 'DAS', pixel-independent weights,
-        cfg.update(prec="double", wpix=False, gen="", fun="DAS", cmap=False, jit=False)   # remodulation (round 3: the drawn fmod stays)
+        cfg.update(prec="double", wpix=cfg["wpix"] and cfg["fmod"] == 0.0, gen="", fun="DAS", cmap=False, jit=False)   # remodulation OR one pixel x receiver array (round 3: the drawn fmod / wpix stay)
     # a pixel x TRANSMIT weight (scanline-style transmit apodization): fused with the roles of the apertures swapped
     cfg["wpm"] = bool(r.integers(0, 10) == 0) and cfg["fun"] == "DAS" and not cfg["wpix"] and not cfg["gen"] and not cfg["sym"] and cfg["prec"] != "double"
     # pixel pitch: ~lambda/3 (2.6 samples of delay per pixel), ~lambda (the 384-sample windows of the second attempt), ~1.6 lambda (tiles that fall back)
     cfg["coarse"] = int(r.choice([1, 1, 1, 1, 3, 5]))
     cfg["fold"] = bool(r.integers(0, 3) == 0)        # a second pixel-dependent array on the same side (per depth x element): folded per plan
+    if cfg["prec"] == "double":
+        cfg["fold"] = False                           # (fp64 data: one pixel x receiver array, used in place)
     # a transmit-side AND a receive-side pixel array (real weights, fp32 data, plain 'DAS'): per-pair pixel weights on the wide-window configuration
     if r.integers(0, 12) == 0 and cfg["prec"] == "single" and not cfg["sym"] and not cfg["bf"] and cfg["N"] > 1 and cfg["M"] > 1:
         cfg.update(wpix=True, wpm=True, wm=False, gen="", fun="DAS", fmod=0.0)

@@ -387,6 +387,44 @@ def test_double_precision_hiprtc_build(interp, fmod, wtab, tmp_path, monkeypatch
     assert rel_err(ys[1], ys[0]) <= 1e-12
 
 
+@pytest.mark.parametrize("kind", ["real", "complex", "pixel-only", "mask"])
+@pytest.mark.parametrize("interp", ["linear", "lanczos3"])
+def test_double_precision_pixel_by_receiver_weights_in_the_tiled_kernel(kind, interp):
+    """fp64 data with ONE pixel x receiver (or pixel-only) apodization array: the fused kernel multiplies every stage's sum by the stage
+    element's weight in double (plain list of stages; weightless stages of a wave read no sample) -- 1e-10 against the oracle; with
+    remodulation, a second pixel array or a pixel x transmit array the plan is the generic kernel's"""
+    rng = np.random.default_rng(11)
+    case = make_case(seq="PW", interp=interp, seed=31, I1=140, I2=22, N=20, M=11)
+    I1, I2, N = 140, 22, case["N"]
+    if kind == "real":
+        a = rng.uniform(0.1, 1.0, (I1, I2, 1, N, 1))
+    elif kind == "complex":
+        a = rng.uniform(0.1, 1.0, (I1, I2, 1, N, 1)) * np.exp(1j * rng.uniform(0, 1, (I1, I2, 1, N, 1)))
+    elif kind == "pixel-only":
+        a = rng.uniform(0.0, 1.0, (I1, I2, 1)) * (rng.random((I1, I2, 1)) > 0.3)
+    else:
+        a = (rng.random((I1, I2, 1, N, 1)) > 0.5) * 1.0
+        a[: I1 // 2, :, :, : N // 2] = 0.0                               # shallow pixels: half the aperture carries no weight at all
+    ref = _oracle64(case, apod=(a,))
+    out, plan = run_das(case, kernel=2, prec="double", apod=(a,))
+    assert plan.kernel == "tiled" and ",f64" in plan.kernel_name() and plan.fallback_tiles() == 0, plan.kernel_name()
+    assert rel_err(out, ref) <= 1e-10
+    gen, _ = run_das(case, kernel=1, prec="double", apod=(a,))
+    assert rel_err(out, gen) <= 1e-10
+    if kind in ("real", "mask"):                                          # ... together with pixel-independent windows (an N x M table in double)
+        wn = np.hanning(N + 2)[1:-1].reshape(1, 1, 1, N, 1)
+        wm = (0.5 + 0.5 * np.hanning(case["M"] + 2)[1:-1]).reshape(1, 1, 1, 1, case["M"]) * (1 + 0.2j)
+        o3, p3 = run_das(case, kernel=2, prec="double", apod=(wn, a, wm))
+        assert p3.kernel == "tiled" and ",wtab" in p3.kernel_name()
+        assert rel_err(o3, _oracle64(case, apod=(wn, a, wm))) <= 1e-10
+    if kind == "real":                                                    # what stays on the generic kernel
+        for kw in (dict(fmod=2.0e6), dict(apod=(a, a))):
+            kw.setdefault("apod", (a,))
+            o2, p2 = run_das(case, kernel=0, prec="double", **kw)
+            assert p2.kernel == "generic"
+            assert rel_err(o2, _oracle64(case, apod=kw["apod"], fmod=kw.get("fmod", 0.0))) <= 1e-10
+
+
 def test_double_precision_remodulation_variants():
     """remodulation of fp64 data together with a weight table (one zero weight), with a record shorter than the path (checked loop) and
     with a negative modulation frequency"""
