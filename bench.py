@@ -146,42 +146,89 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+SQ_PASS = ("GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_SALU")
+
+
 def measure_traffic(argv):
-    """HBM bytes per launch of the dominant kernel from rocprofv3 counter passes of THIS command (one pass per counter: FETCH_SIZE
-    and WRITE_SIZE do not fit together), corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KiB) x 2 for 16 B/lane
-    streaming reads, WRITE_SIZE (KiB) as is.  Returns (bytes | None, source string)."""
+    """Counters of the dominant kernel from rocprofv3 passes of THIS command (one pass per TCC counter: FETCH_SIZE and WRITE_SIZE do not
+    fit together; one more pass for the clock / issue / LDS counters -- never combined with any tracing domain but --kernel-trace).
+    HBM bytes per launch are corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE (KiB) x 2 for 16 B/lane streaming
+    reads, WRITE_SIZE (KiB) as is.  Returns (bytes | None, source string, {counter: average per full-frame dispatch, 'pass_kernel_ms': ...})."""
     import csv
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", {}
     vals = {}
     tmp = tempfile.mkdtemp(prefix="qdas_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", QDAS_BENCH_CHILD="1")
+    err = None
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, ctr)
-            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
+        for ctrs in (("FETCH_SIZE",), ("WRITE_SIZE",), SQ_PASS):
+            d = os.path.join(tmp, ctrs[0])
+            cmd = [exe, "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__)] + argv + ["--steps", "2", "--warmup", "1", "--no-cpu", "--traffic", "none",
                                                                        "--no-general"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
-                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
-            rows = [x for x in csv.DictReader(open(files[0])) if x["Counter_Name"] == ctr]
+                err = f"rocprofv3 --pmc {' '.join(ctrs)} failed (rc {r.returncode})"
+                if ctrs[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    return None, err, {}
+                break                                         # (the issue / LDS pass is an extra: the traffic figure stands without it)
+            allrows = list(csv.DictReader(open(files[0])))
             tot = {}
-            for x in rows:                                   # the dominant kernel = largest total duration (the frame kernel: prebuilt
-                tot[x["Kernel_Name"]] = tot.get(x["Kernel_Name"], 0) + int(x["End_Timestamp"]) - int(x["Start_Timestamp"])   # das_tile_kernel<...> or hiprtc-built qdas_jit_tile)
+            for x in allrows:                                # the dominant kernel = largest total duration (the frame kernel: prebuilt
+                if x["Counter_Name"] == ctrs[0]:             # das_tile_kernel<...> or hiprtc-built qdas_jit_tile)
+                    tot[x["Kernel_Name"]] = tot.get(x["Kernel_Name"], 0) + int(x["End_Timestamp"]) - int(x["Start_Timestamp"])
             dom = max(tot, key=tot.get)
-            rows = [x for x in rows if x["Kernel_Name"] == dom]
-            dur = [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in rows]
-            full = [float(x["Counter_Value"]) for x, t in zip(rows, dur) if t >= 0.5 * max(dur)]   # (plan-time probe launches are short)
-            vals[ctr] = sum(full) / len(full)
+            rows = [x for x in allrows if x["Kernel_Name"] == dom]
+            dmax = max(int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in rows)
+            rows = [x for x in rows if int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) >= 0.5 * dmax]   # (plan-time probe launches are short)
+            for ctr in ctrs:
+                full = [float(x["Counter_Value"]) for x in rows if x["Counter_Name"] == ctr]
+                if full:
+                    vals[ctr] = sum(full) / len(full)
+            if ctrs[0] == "GRBM_GUI_ACTIVE":
+                dur = [int(x["End_Timestamp"]) - int(x["Start_Timestamp"]) for x in rows if x["Counter_Name"] == ctrs[0]]
+                vals["pass_kernel_ms"] = sum(dur) / len(dur) / 1e6
     except Exception as ex:
-        return None, f"rocprofv3 counter pass failed: {ex!r}"
+        if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+            return None, f"rocprofv3 counter pass failed: {ex!r}", {}
+        err = f"issue / LDS counter pass failed: {ex!r}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return int(vals["FETCH_SIZE"] * 2048 + vals["WRITE_SIZE"] * 1024), \
-        "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command (FETCH_SIZE KiB x2 gfx950 correction + WRITE_SIZE KiB)"
+    src = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command (FETCH_SIZE KiB x2 gfx950 correction + WRITE_SIZE KiB)"
+    if err:
+        src += "; " + err
+    return int(vals["FETCH_SIZE"] * 2048 + vals["WRITE_SIZE"] * 1024), src, vals
+
+
+def binding_roofs(vals, cu, pairs, taps, sample_bytes):
+    """The roofs that actually bind this path, from the SQ / GRBM counters of the same run:
+    effective_ghz = GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the counter pass;  valu_issue_frac = wave64 VALU instructions x 4 cycles
+    / (4 SIMDs x CUs) / active cycles;  lds_busy_frac = LDS-array cycles / CUs / active cycles;  lds_gather_floor_ms = the pair loop's tap
+    bytes (pairs x taps x bytes per sample) at 256 B/clk/CU (MI355X_MICROARCH.md, LDS table: ds_read_b64) and the measured clock."""
+    if not vals or "GRBM_GUI_ACTIVE" not in vals or not vals.get("pass_kernel_ms"):
+        return {}
+    act = vals["GRBM_GUI_ACTIVE"] / 8.0                        # active cycles of one XCD's clock domain
+    ghz = act / (vals["pass_kernel_ms"] * 1e-3) / 1e9
+    out = {"effective_ghz": round(ghz, 3), "counter_pass_kernel_ms": round(vals["pass_kernel_ms"], 3)}
+    if "SQ_INSTS_VALU" in vals:
+        out["valu_insts"] = int(vals["SQ_INSTS_VALU"])
+        out["valu_issue_frac"] = round(vals["SQ_INSTS_VALU"] * 4.0 / (4 * cu) / act, 4)
+        out["valu_insts_per_pair"] = round(vals["SQ_INSTS_VALU"] * 64.0 / pairs, 3)
+    if "SQ_INSTS_SALU" in vals:
+        out["salu_insts"] = int(vals["SQ_INSTS_SALU"])
+    if "SQ_LDS_IDX_ACTIVE" in vals:
+        out["lds_busy_frac"] = round(vals["SQ_LDS_IDX_ACTIVE"] / cu / act, 4)
+        out["lds_bank_conflict_frac"] = round(vals.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(vals["SQ_LDS_IDX_ACTIVE"], 1.0), 5)
+    if "SQ_INSTS_LDS" in vals:
+        out["lds_insts"] = int(vals["SQ_INSTS_LDS"])
+    out["lds_gather_bytes"] = int(pairs * taps * sample_bytes)
+    out["lds_gather_floor_ms"] = round(pairs * taps * sample_bytes / (256.0 * cu * ghz * 1e9) * 1e3, 3)
+    out["binding_note"] = ("VALU issue and the LDS gathers co-limit this kernel; the HBM frac above is the BASELINE's nominal roof, "
+                           "unreachable at ~2.5e3 flop/byte")
+    return out
 
 
 def main():
@@ -384,7 +431,7 @@ def main():
         prebuilt_ms = kernel_time(pplan, 3)
         pplan.close()
 
-    traffic, tsrc = None, "not measured"
+    traffic, tsrc, ctrs = None, "not measured", {}
     if rank == 0 and not os.environ.get("QDAS_BENCH_CHILD"):
         mode = args.traffic
         if mode == "auto":
@@ -393,7 +440,7 @@ def main():
             argv = ["--workload", args.workload] + (["--kernel", str(args.kernel)] if args.kernel else []) + \
                    (["--prec", args.prec] if args.prec else []) + (["--fmod", str(args.fmod)] if args.fmod else []) + (["--rx-apod", args.rx_apod] if args.rx_apod else []) + (["--rx-apod-array"] if args.rx_apod_array else []) + (["--window-apod"] if args.window_apod else []) + (["--tx-apod", args.tx_apod] if args.tx_apod else []) + (["--gen-apod"] if args.gen_apod else []) + \
                    (["--no-reciprocal"] if args.no_reciprocal else []) + (["--no-jit"] if args.no_jit else [])
-            traffic, tsrc = measure_traffic(argv)
+            traffic, tsrc, ctrs = measure_traffic(argv)
             if traffic is None:
                 mode = "file"
                 tsrc += "; "
@@ -461,6 +508,11 @@ def main():
                          "valu_frac_executed": None if exec_fpp is None or exec_frac is None or plan.kernel != "tiled" or args.tx_apod else
                                                round(pairs / world * exec_frac * exec_fpp / ksec / 1e12 / FP32_PEAK_TFLOPS, 4)},
         }
+        try:
+            taps = {"nearest": 1, "linear": 2, "cubic": 4, "lanczos3": 4}.get(w["interp"], 4)
+            rec["roofline"].update(binding_roofs(ctrs, info["cu_count"], pairs / world * (exec_frac or 1.0), taps, sb))
+        except Exception as ex:
+            rec["roofline"]["binding_note"] = f"counter post-processing failed: {ex!r}"
         if prebuilt_ms is not None:
             rec["prebuilt_kernel_ms"] = round(prebuilt_ms, 3)
         if general_ms is not None:

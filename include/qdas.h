@@ -179,7 +179,12 @@ int  qdas_plan_create(qdas_plan **plan, const qdas_desc *desc);
  * overwritten.  Asynchronous on `stream` when desc.mem == QDAS_MEM_DEVICE. */
 int  qdas_plan_execute(qdas_plan *plan, const void *x, void *y, void *stream);
 /* F frames in one call (kern/das_spec.m:371-373 host loop): frame f uses
- * x + f*x_stride and y + f*y_stride (strides in complex elements). */
+ * x + f*x_stride and y + f*y_stride (strides in complex elements).  Device-resident frames of a tiled plan share launches
+ * (four / two per launch: tap index and interpolation weights are evaluated once per group), so a frame's image equals
+ * qdas_plan_execute's to fp32 re-association, not bit for bit, and every frame of ONE call is summed in the same order.
+ * A general-mode lateral-mirror plan streams F >= 4 frames through a twin plan without the mode, created at the first such
+ * call (device allocations and probe launches of a plan creation, synchronous, ~plan memory x2): that first call is not
+ * asynchronous and not graph-capturable; set QDAS_NO_FRAMES_TWIN=1 to keep streams on the plan's own kernel. */
 int  qdas_plan_execute_frames(qdas_plan *plan, const void *x, void *y, uint64_t F,
                               uint64_t x_stride, uint64_t y_stride, void *stream);
 /* 'delays' (src/bf.cu:209-298, kern/das_spec.m:377): tau is i_count x N x M real(prec),
@@ -214,8 +219,10 @@ int  qdas_plan_last_kernel_ms(const qdas_plan *plan, float *ms);
 /* ---- one host thread, several devices: the image is split into ndev contiguous slabs of the linear pixel
  *      index, one per entry of devices[] (NULL: 0 .. ndev-1; an ordinal may repeat: several streams on one device); geometry and
  *      channel data are replicated, every device beamforms its slab with an ordinary plan, the slabs are concatenated into y.
- *      desc->mem == QDAS_MEM_DEVICE: the constant inputs and x / y live on devices[0]; x is replicated with peer copies down a binary
- *      tree (xGMI), slabs come back with peer copies; asynchronous on `stream` (a stream of devices[0]).
+ *      desc->mem == QDAS_MEM_DEVICE: the constant inputs and x / y live on devices[0]; x is replicated with peer copies over the xGMI mesh --
+ *      scatter (device u pulls piece u of the frame from devices[0]) + all-gather (every device pulls the other pieces from their holders:
+ *      all links carry 1/(U-1) of the frame at once) --, slabs (mirror slabs when the geometry allows: a slab of the first half of the
+ *      columns AND its mirror image per device) come back with peer copies; asynchronous on `stream` (a stream of devices[0]).
  *      desc->mem == QDAS_MEM_HOST: x is uploaded once to devices[0] and replicated from there; y is downloaded; synchronous.
  *      desc->i_begin / i_count / y_ld must be 0; y is I x [1|N] x [1|M].  The reference has no multi-device path (one gpuDevice
  *      per MATLAB process, README.md:232): this is what lets its single-process host reach a whole node. */
@@ -224,6 +231,9 @@ int  qdas_plan_create_sharded(qdas_sharded_plan **plan, const qdas_desc *desc, i
 int  qdas_plan_execute_sharded(qdas_sharded_plan *plan, const void *x, void *y, void *stream);
 /* shard < 0: the number of shards in *device.  Else the shard's device, pixel slab and kernel (QDAS_KERNEL_*; 0: empty slab). */
 int  qdas_plan_sharded_info(const qdas_sharded_plan *plan, int shard, int *device, uint64_t *i_begin, uint64_t *i_count, int *kernel);
+/* 1 when the plan runs MIRROR SLABS: shard g then owns the slab qdas_plan_sharded_info reports (whole columns of the first half of the image)
+ * AND its mirror image, the pixels [I - i_begin - i_count, I - i_begin); 0: plain contiguous slabs */
+int  qdas_plan_sharded_mirror(const qdas_sharded_plan *plan);
 void qdas_plan_destroy_sharded(qdas_sharded_plan *plan);
 
 /* ---- one-shot entries shaped like the reference kernels' argument lists

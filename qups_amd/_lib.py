@@ -30,7 +30,7 @@ RXAPOD_NONE, RXAPOD_ACCEPTANCE, RXAPOD_COSINE, RXAPOD_FNUMBER_PLANAR, RXAPOD_FNU
 SYMBOLS = (
     "qdas_plan_create", "qdas_plan_execute", "qdas_plan_execute_frames", "qdas_plan_delays",
     "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_reciprocal", "qdas_plan_mirror", "qdas_plan_kernel_name", "qdas_plan_set_timing",
-    "qdas_plan_last_kernel_ms", "qdas_plan_create_sharded", "qdas_plan_execute_sharded", "qdas_plan_sharded_info",
+    "qdas_plan_last_kernel_ms", "qdas_plan_create_sharded", "qdas_plan_execute_sharded", "qdas_plan_sharded_info", "qdas_plan_sharded_mirror",
     "qdas_plan_destroy_sharded", "qdas_DAS", "qdas_DASf", "qdas_DASh", "qdas_delays", "qdas_delaysf",
     "qdas_das_lut", "qdas_wsinterpd", "qdas_shift_sum", "qdas_greens", "qdas_convd", "qdas_convd_len", "qdas_permute3", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_pre_plan_one_pass", "qdas_last_error", "qdas_version", "qdas_device_info",
 )
@@ -135,6 +135,7 @@ def lib():
     L.qdas_plan_create_sharded.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Desc), C.c_int, C.POINTER(C.c_int)]
     L.qdas_plan_execute_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.qdas_plan_sharded_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    L.qdas_plan_sharded_mirror.argtypes = [C.c_void_p]
     L.qdas_plan_destroy_sharded.argtypes = [C.c_void_p]
     L.qdas_plan_destroy_sharded.restype = None
     L.qdas_das_lut.argtypes = [C.POINTER(LutDesc), C.c_void_p, C.c_void_p, C.c_void_p]

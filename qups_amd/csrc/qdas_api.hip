@@ -586,12 +586,14 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         const uint64_t smax = strM > strN ? strM : strN;
         if (sym && (uint64_t)(tile_config(dt, 1).mb + 1) * smax * data_size(dt) + slack >= (1ull << 30)) {
             sym = 0;
-            pl->tc = tile_config(dt, 0);
+            pl->tc = tile_config(dt, 0, 0, mir ? 2 : 1);     // (a mirror-symmetric plan keeps the two-window-set configuration of the general mode)
             if (eligible && tile_lds_bytes(dt, 0, z.N, z.M, 0, pixw, wtb) > tile_lds_limit(0)) { eligible = false; why = "tiled kernel: N + M too large for the LDS header"; }
         }
         if (eligible && !sym && (kN * strN + (uint64_t)pl->tc.mb * strM) * data_size(dt) + slack >= (1ull << 31)) {
             // fp32, one frame per launch: the re-basing instantiation of the general kernel (launch configuration 9)
-            if (dt == QDAS_F32 && !bfm && ((uint64_t)pl->tc.mb * strM + strN) * data_size(dt) + slack < (1ull << 30)) big = 1;
+            // (the re-basing instantiation is a plain general-mode kernel: no lateral-mirror mode there -- the mirrored window set's offsets are
+            //  32-bit offsets of the same magnitude; launch_tile rejects mir && big)
+            if (dt == QDAS_F32 && !bfm && ((uint64_t)tile_config(dt, 0).mb * strM + strN) * data_size(dt) + slack < (1ull << 30)) { big = 1; mir = false; pl->tc = tile_config(dt, 0); }
             else { eligible = false; why = "tiled kernel: trace strides too large for 32-bit DMA offsets (transposed data of more than 2 GiB)"; }
         }
     }
@@ -1101,14 +1103,11 @@ extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, u
             g_err = keep;
         }
         if (pl->frames_twin) {
-            const uint64_t F4 = F & ~3ull;
+            // the WHOLE stream goes through the twin (groups of four, then a pair, then a single frame on its own kernels): every frame of
+            // one call is summed in the same order -- round 3 sent the tail through the mirror kernel.  The images equal
+            // qdas_plan_execute's to fp32 re-association, not bit for bit (another kernel): include/qdas.h says so.
             pl->frames_twin->timing = false;
-            int rc = qdas_plan_execute_frames(pl->frames_twin, x, y, F4, x_stride, y_stride, stream);
-            if (rc) return rc;
-            const bool tm = pl->timing;
-            pl->timing = false;                          // (one pair of events around the whole stream)
-            if (F4 < F) rc = qdas_plan_execute_frames(pl, (const char *)x + F4 * x_stride * ds, (char *)y + F4 * y_stride * ds, F - F4, x_stride, y_stride, stream);
-            pl->timing = tm;
+            int rc = qdas_plan_execute_frames(pl->frames_twin, x, y, F, x_stride, y_stride, stream);
             if (!rc && pl->timing) { HIPCHK(hipEventRecord(pl->e1, s)); HIPCHK(hipEventSynchronize(pl->e1)); HIPCHK(hipEventElapsedTime(&pl->last_ms, pl->e0, pl->e1)); }
             return rc;
         }

@@ -412,4 +412,7 @@ extern "C" int qdas_plan_sharded_info(const qdas_sharded_plan *sp, int shard, in
     return QDAS_OK;
 }
 
+// 1: mirror slabs -- shard g beamforms [i_begin, +i_count) AND the mirror images of those columns, pixels [I - i_begin - i_count, +i_count)
+extern "C" int qdas_plan_sharded_mirror(const qdas_sharded_plan *sp) { return sp && sp->mirror ? 1 : 0; }
+
 extern "C" void qdas_plan_destroy_sharded(qdas_sharded_plan *sp) { delete sp; }

@@ -473,6 +473,7 @@ class DasPlan:
             d.rx_normals = ptr(self._bufs[-1])
         self._desc = d
         self._h = C.c_void_p()
+        self._lock = threading.RLock()          # execute / delays / close exclude each other: a cached plan evicted by another thread is never freed mid-call
         with torch.cuda.device(dev):
             _lib.check(self.lib.qdas_plan_create(C.byref(self._h), C.byref(d)))
 
@@ -545,8 +546,6 @@ class DasPlan:
         """:meth:`execute_colmajor` into a caller-owned output ``y`` (contiguous, ``F * oM * oN * i_count`` elements of complex(prec) on
         the plan's device): a frame stream reuses one image buffer instead of allocating per frame -- the reference's ``k.feval(yg, ...)``
         treats ``yg`` as in/out the same way (``kern/das_spec.m:349-351,372``).  Returns ``y``."""
-        if self._h is None or not self._h.value:
-            raise DasError("the plan has been closed")
         p = self.prob
         oN, oM = p.osize
         per = p.T * p.N * p.M
@@ -557,8 +556,11 @@ class DasPlan:
             raise DasError(f"channel data must be {want} on {self.device} for a '{p.prec}' plan, got {xc.dtype} on {xc.device}")
         if y.numel() != F * oM * oN * self.out_count or not y.is_contiguous() or y.dtype != want or y.device != self.device:
             raise DasError(f"output must be a contiguous {want} tensor of {F * oM * oN * self.out_count} elements on {self.device}")
-        _lib.check(self.lib.qdas_plan_execute_frames(self._h, C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()),
-                                                     F, per, oM * oN * self.out_count, self._stream()))
+        with self._lock:
+            if self._h is None or not self._h.value:
+                raise DasError("the plan has been closed")
+            _lib.check(self.lib.qdas_plan_execute_frames(self._h, C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()),
+                                                         F, per, oM * oN * self.out_count, self._stream()))
         return y
 
     def feval(self, x):
@@ -573,21 +575,27 @@ class DasPlan:
         p = self.prob
         rt = torch.float64 if p.prec == "double" else torch.float32
         tau = torch.empty((p.M, p.N, self.i_count), dtype=rt, device=self.device)
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), self._lock:
+            if self._h is None or not self._h.value:
+                raise DasError("the plan has been closed")
             _lib.check(self.lib.qdas_plan_delays(self._h, C.c_void_p(tau.data_ptr()), self._stream()))
         return tau.permute(2, 1, 0)
 
     def close(self):
         """Destroy the native plan (its device allocations, events, staging buffers).  Work already queued on the plan's device is
         waited for first: the plan's tables must outlive the launches that read them."""
-        h = getattr(self, "_h", None)
-        if h is not None and h.value:
-            self._h = C.c_void_p()
-            try:
-                _torch().cuda.synchronize(self.device)
-            except Exception:                           # interpreter shutdown: torch may be half gone; hipFree synchronises anyway
-                pass
-            self.lib.qdas_plan_destroy(h)
+        lock = getattr(self, "_lock", None)
+        if lock is None:                                # (constructor failed before the native plan existed)
+            return
+        with lock:                                      # (waits for a call of another thread that is inside the native plan)
+            h = getattr(self, "_h", None)
+            if h is not None and h.value:
+                self._h = C.c_void_p()
+                try:
+                    _torch().cuda.synchronize(self.device)
+                except Exception:                       # interpreter shutdown: torch may be half gone; hipFree synchronises anyway
+                    pass
+                self.lib.qdas_plan_destroy(h)
 
     @property
     def closed(self) -> bool:
@@ -646,8 +654,13 @@ class MultiDevicePlan:
         with torch.cuda.device(dev):
             _lib.check(self.lib.qdas_plan_create_sharded(C.byref(self._h), C.byref(d), len(self.devices), devs))
 
+    @property
+    def mirror_slabs(self) -> bool:
+        """True: every shard owns the slab :meth:`shards` reports AND its mirror image, the pixels ``[I - i_begin - i_count, I - i_begin)``"""
+        return bool(self.lib.qdas_plan_sharded_mirror(self._h))
+
     def shards(self):
-        """[(device, i_begin, i_count, kernel name)] per slab"""
+        """[(device, i_begin, i_count, kernel name)] per slab (with :attr:`mirror_slabs`: slab A of the shard; slab B is its mirror image)"""
         n = C.c_int()
         _lib.check(self.lib.qdas_plan_sharded_info(self._h, -1, C.byref(n), None, None, None))
         out = []
@@ -704,6 +717,16 @@ def _plan_cache_size() -> int:
         return 8
 
 
+def _memo_bytes() -> int:
+    """host RAM the marshalling memos below may hold, EACH (``QDAS_HOST_MEMO_MB``, default 256; 0 switches them off): the column-major copies
+    of geometry and apodization arrays a frame loop through ``das_spec`` would otherwise rebuild per call.  An array larger than the bound
+    is simply not kept (BASELINE C5's 268 MB mask: set ``QDAS_HOST_MEMO_MB=1024``, or hold the plan -- the plan API needs none of this)."""
+    try:
+        return max(0, int(os.environ.get("QDAS_HOST_MEMO_MB", "256"))) << 20
+    except ValueError:
+        return 256 << 20
+
+
 _COL_CACHE: "collections.OrderedDict[tuple, np.ndarray]" = collections.OrderedDict()
 _COL_DIGEST: dict = {}
 _MEMO_LOCK = threading.RLock()                            # the marshalling memos below are shared by every thread that calls das_spec
@@ -719,7 +742,9 @@ def _col_cached_locked(A, rt):
     ``das_spec`` / ``UltrasoundSystem.DAS`` hands over the same pixel grid every call, and the strided flatten of a 3 x 1024 x 1024 grid costs
     19 ms -- as much as beamforming the C3 frame.  (The reference keeps these arrays on the device between calls.)"""
     A = np.asarray(A)
-    if A.size < 4096:
+    if A.size < 4096 or _memo_bytes() == 0:
+        if A.size >= 4096:                                   # (memos switched off: drop what an earlier setting kept)
+            _COL_CACHE.clear(); _FLAT_CACHE.clear(); _COL_DIGEST.clear()
         return np.ascontiguousarray(A.reshape(-1, order="F").astype(rt))
     Ac = np.ascontiguousarray(A)
     try:
@@ -736,7 +761,7 @@ def _col_cached_locked(A, rt):
     out = np.ascontiguousarray(Ac.reshape(-1, order="F").astype(rt))
     _COL_CACHE[key] = out
     _COL_DIGEST[id(out)] = (out, dig)                        # problem_key() takes the digest instead of hashing the flattened copy again
-    while len(_COL_CACHE) > 16 or sum(v.nbytes for v in _COL_CACHE.values()) > (1 << 30):
+    while _COL_CACHE and (len(_COL_CACHE) > 16 or sum(v.nbytes for v in _COL_CACHE.values()) > _memo_bytes()):
         _, old = _COL_CACHE.popitem(last=False)
         _COL_DIGEST.pop(id(old), None)
     return out
@@ -760,14 +785,15 @@ def _flat_cached(a: np.ndarray, adt) -> np.ndarray:
 
 
 def _flat_cached_locked(a: np.ndarray, adt) -> np.ndarray:
-    """``_flat_colmajor(a, adt)`` memoised for large apodization arrays: by IDENTITY when the array is immutable (``a.setflags(write=False)`` --
-    the generators of ``qups_amd.apodization`` return such arrays), else by content (xxh3 of the bytes: 27 ms for BASELINE C5's 268 MB mask, where
+    """``_flat_colmajor(a, adt)`` memoised for large apodization arrays: by content, or -- opt-in, ``QDAS_HOST_MEMO_BY_IDENTITY=1`` -- by
+    IDENTITY when the array is immutable (``a.setflags(write=False)``: the generators of ``qups_amd.apodization`` return such arrays; by content = xxh3 of the bytes: 27 ms for BASELINE C5's 268 MB mask, where
     the transposing cast takes 60-130 ms).  A frame loop through ``das_spec`` / ``UltrasoundSystem.DAS`` hands over the same mask every call; the
     plan API (``DasPlan`` / ``return_plan=True``) skips all of this."""
-    if a.size < (1 << 16):
+    if a.size < (1 << 16) or _memo_bytes() == 0:
         return _flat_colmajor(a, adt)
     ident = None
-    if _immutable(a):
+    # (opt-in: a caller who flips the write flag, edits and flips it back would be served the OLD weights -- nothing but the content can tell)
+    if os.environ.get("QDAS_HOST_MEMO_BY_IDENTITY", "0") not in ("", "0") and _immutable(a):
         # (the cache entry keeps a reference to the array: its memory cannot be freed and handed to another array while the entry lives)
         ident = ("buffer", a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str, np.dtype(adt).str)
         hit = _FLAT_CACHE.get(ident)
@@ -789,7 +815,7 @@ def _flat_cached_locked(a: np.ndarray, adt) -> np.ndarray:
         out = hit[1]
     if ident is not None:
         _FLAT_CACHE[ident] = (a, out)
-    while len(_FLAT_CACHE) > 12 or sum(v[1].nbytes for v in _FLAT_CACHE.values()) > (3 << 30):
+    while _FLAT_CACHE and (len(_FLAT_CACHE) > 12 or sum(v[1].nbytes for v in {id(v[1]): v for v in _FLAT_CACHE.values()}.values()) > _memo_bytes()):
         _, old = _FLAT_CACHE.popitem(last=False)
         if not any(v[1] is old[1] for v in _FLAT_CACHE.values()):
             _COL_DIGEST.pop(id(old[1]), None)
@@ -809,8 +835,8 @@ def _qdas_env():
     """the ``QDAS_*`` environment as a sorted tuple (from the raw byte table where there is one: no decode of the other ~100 variables per call)"""
     raw = getattr(os.environ, "_data", None)
     if isinstance(raw, dict) and raw and isinstance(next(iter(raw)), bytes):
-        return tuple(sorted((k, v) for k, v in raw.items() if k.startswith(b"QDAS_") and k != b"QDAS_PLAN_CACHE"))
-    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("QDAS_") and k != "QDAS_PLAN_CACHE"))
+        return tuple(sorted((k, v) for k, v in raw.items() if k.startswith(b"QDAS_") and k != b"QDAS_PLAN_CACHE" and not k.startswith(b"QDAS_HOST_MEMO")))
+    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("QDAS_") and k != "QDAS_PLAN_CACHE" and not k.startswith("QDAS_HOST_MEMO")))
 
 
 def problem_key(prob: DasProblem, *extra) -> bytes:
@@ -936,6 +962,13 @@ def das_spec(fun, Pi, Pr, Pv, Nv, x, t0, fs=None, c=None, *varargin, return_plan
             plan.close()
         raise
     if return_plan:
+        # A plan that is handed out belongs to the caller from here on: it leaves the cache, so that no later call shares its scratch
+        # (fallback list, partial images) on another stream and no LRU eviction closes it under the caller's frame loop.
+        if not owned:
+            with _PLAN_CACHE_LOCK:
+                for k, v in list(_PLAN_CACHE.items()):
+                    if v is plan:
+                        del _PLAN_CACHE[k]
         return y, plan
     if owned:
         plan.close()

@@ -119,11 +119,21 @@ class ShardedDasPlan:
             ok = True
             if compute is None and self.i_count:
                 from .das_spec import DasPlan
+                from ._lib import QdasError
+                failure = None
                 try:
                     self.plan = DasPlan(prob, device=device, kernel=kernel, i_begin=self.i_begin, i_count=self.i_count, mirror_slab=True, **plan_kw)
-                except Exception:                       # (QDAS_EUNSUPPORTED: no lateral-mirror mode for this problem / this slab)
-                    ok = False
+                except QdasError as ex:                 # QDAS_EUNSUPPORTED (2): no lateral-mirror mode for this problem / this slab -> plain slabs.
+                    ok = False                          # Anything else (out of memory, a bad device, an invalid argument) is a real error: it still
+                    if ex.code != 2:                    # takes part in the agreement below -- the other ranks are waiting in it -- and is raised after.
+                        failure = ex
+                except Exception as ex:
+                    ok, failure = False, ex
+            else:
+                failure = None
             ok = self._all_agree(ok, device)
+            if failure is not None:
+                raise failure
             if ok:
                 self.mirror_slabs = True
                 return

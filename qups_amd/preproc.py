@@ -33,7 +33,9 @@ def hilbert(x, N: int | None = None, fdown: float = 0.0, t0: float = 0.0, fs: fl
         raise ValueError("Undefined sampling rate.")
     from .das_spec import _colmajor
     x2 = xt.to(dev).reshape(T, K)
-    if K == 1 or (T > 0 and x2.stride() == (1, T)):                 # already time-fastest (e.g. a MATLAB-ordered view): no copy
+    # already time-fastest (a MATLAB-ordered view; a CONTIGUOUS single trace): no copy.  A strided single trace -- hilbert(x[:, j]) of a
+    # T x N tensor, x[::2] -- has K == 1 but stride(0) != 1: the library reads T consecutive elements, so it is copied like the rest.
+    if T > 0 and ((K == 1 and x2.stride(0) == 1) or (K > 1 and x2.stride() == (1, T))):
         xc = x2.t()
     else:
         xc = _colmajor(x2.contiguous())                             # K x T: time fastest (MATLAB memory order of T x K)

@@ -285,14 +285,56 @@ class UltrasoundSystem:
         from . import apodization as A
         return A.rx_apod_spec(kind, normals=self.rx.normals, **kw)
 
+    @staticmethod
+    def _chd_array(chd):
+        """``(list of ChannelData, concatenation dimension | None)`` of an ND-array of ChannelData (reference ``src/UltrasoundSystem.m:3301-3305``,
+        ``:4670-4672``): a single object, a numpy object array with at most one non-singleton dimension, or a list / tuple -- MATLAB's
+        ``[chd1, chd2, ...]``, a 1 x K row.  The dimension is 0-based here (MATLAB's ``chddim - 1``): the images are concatenated along it."""
+        if isinstance(chd, ChannelData):
+            return [chd], None
+        if isinstance(chd, (list, tuple)):
+            arr = np.empty((1, len(chd)), dtype=object)
+            for k, c in enumerate(chd):
+                arr[0, k] = c
+        else:
+            arr = np.asarray(chd, dtype=object)
+            if arr.ndim < 2:
+                arr = arr.reshape(1, -1)                       # (MATLAB has no 1-D arrays: a vector is a row)
+        items = list(arr.reshape(-1, order="F"))
+        if not items or not all(isinstance(c, ChannelData) for c in items):
+            raise DasError("chd must be a ChannelData or an array of ChannelData")
+        dims = [d for d, n in enumerate(arr.shape) if n > 1]
+        if len(dims) > 1:
+            raise DasError("ChannelData array can only contain up to one non-scalar dimension.")     # (:3304)
+        return items, (dims[0] if dims else None)
+
     def DAS(self, chd: ChannelData, *apods, c0=None, fmod=0.0, prec="single", device=-1, apod=1, interp="cubic",
             keep_tx=False, keep_rx=False, return_plan=False, kernel=0, rx_apod=None):
         """``b = DAS(us, chd, A1, ..., 'c0', c0, 'fmod', fc, 'interp', method, 'prec', type, 'keep_tx', tf, 'keep_rx', tf)``
 
-        reference ``src/UltrasoundSystem.m:3172-3372``.  Output ``I1 x I2 x I3 x F... x [N] x [M]`` (``:3361``).
+        reference ``src/UltrasoundSystem.m:3172-3372``.  Output ``I1 x I2 x I3 x F... x [N] x [M]`` (``:3361``).  ``chd`` may be an array of
+        ChannelData with one non-scalar dimension (``:3301-3305``): each is beamformed on its own (``:3325``) and the images are
+        concatenated along that dimension (``:3368``); with ``return_plan`` the plan of the first element comes back (the reference's
+        loop runs from the last element to the first and keeps the last call's kernel handle).
         """
         if prec not in ("single", "double", "halfT"):
             raise DasError("prec must be one of {'double', 'single', 'halfT'}")
+        chds, chddim = self._chd_array(chd)
+        if len(chds) > 1 or chddim is not None:
+            import torch
+            kw = dict(c0=c0, fmod=fmod, prec=prec, device=device, apod=apod, interp=interp, keep_tx=keep_tx, keep_rx=keep_rx, kernel=kernel, rx_apod=rx_apod)
+            D = max([c.data.ndim for c in chds] + [0 if chddim is None else chddim + 1])        # max dimension of data (:3305)
+            outs, plan = [], None
+            for k, c in enumerate(chds):
+                o = self.DAS(c, *apods, return_plan=(return_plan and k == 0), **kw)
+                if return_plan and k == 0:
+                    o, plan = o
+                outs.append(o)
+            nd = max(max(o.ndim for o in outs), (chddim or 0) + 1, D)
+            outs = [o.reshape(tuple(o.shape) + (1,) * (nd - o.ndim)) for o in outs]
+            b = outs[0] if chddim is None else torch.cat(outs, dim=chddim)
+            return (b, plan) if return_plan else b
+        chd = chds[0]
         c0 = self.seq.c0 if c0 is None else c0
         apods = list(apods) + ([] if (np.isscalar(apod) and apod == 1) else [apod])
         fun = {(True, True): "DAS", (True, False): "SYN", (False, True): "MUL", (False, False): "BF"}[(not keep_tx, not keep_rx)]   # :3318-3322
@@ -430,11 +472,29 @@ class UltrasoundSystem:
         ``bsize``: transmits per block (reference ``:4573``: default from a 1 GB bound on the multiplied-out weights; ``:4641-4655``: the
         transmits are spliced, the apodization arrays with a transmit dimension are indexed per block, blocks are summed -- or, with
         ``keep_tx``, concatenated).  The multiplied-out ``I x N x M`` weight array never exists for more than one block."""
+        chds, chddim = self._chd_array(chd)
+        # (:4580-4587, :4604-4611) the tables serve every ChannelData of the array: one receiver count, one transmit count
+        Ns = sorted({int(c.data.shape[c.order.index("N")]) for c in chds})
+        if len(Ns) != 1:
+            raise DasError("Expected a single receiver size, but instead they have sizes [" + ",".join(str(v) for v in Ns) + "].",
+                           "QUPS:UltrasoundSystem:bfDASLUT:nonUniqueReceiverSize")
+        Ms = sorted({int(c.data.shape[c.order.index("M")]) for c in chds})
+        if len(Ms) != 1:
+            raise DasError("Expected a single transmit size, but instead they have sizes [" + ",".join(str(v) for v in Ms) + "].",
+                           "QUPS:UltrasoundSystem:bfDASLUT:nonUniqueTransmitSize")
+        if len(chds) > 1 or chddim is not None:          # each ChannelData on its own (:4629), images concatenated along the array's dimension (:4670-4672)
+            import torch
+            outs = [self.bfDASLUT(c, tau_rx, tau_tx, *apods, apod=apod, fmod=fmod, interp=interp, keep_tx=keep_tx, keep_rx=keep_rx, prec=prec, bsize=bsize)
+                    for c in chds]
+            nd = max(max(o.ndim for o in outs), (chddim or 0) + 1)
+            outs = [o.reshape(tuple(o.shape) + (1,) * (nd - o.ndim)) for o in outs]
+            return outs[0] if chddim is None else torch.cat(outs, dim=chddim)
+        chd = chds[0]
         if chd.order[:3] != "TNM":
             chd = chd.rectifyDims()
         Isz = self.scan.size
         tr, tt = np.asarray(tau_rx) if not hasattr(tau_rx, "shape") else tau_rx, tau_tx
-        N, M = self.rx.numel, (self.seq.numPulse or tt.shape[-1])
+        N, M = Ns[0], Ms[0]
         if tuple(tr.shape) != Isz + (N,):
             raise DasError(f"Expected a receive delay table of size {Isz + (N,)}, got {tuple(tr.shape)}.",
                            "QUPS:UltrasoundSystem:bfDASLUT:incompatibleReceiveDelayTable")

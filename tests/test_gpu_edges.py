@@ -186,6 +186,8 @@ def test_channel_data_larger_than_4_GiB(kernel, tpose, monkeypatch):
                      "transpose", tpose, kernel=kernel or 1)          # (the same kernel on both sides: same fp32 delay rounding)
     torch.cuda.synchronize()
     assert plan.kernel == ("tiled" if kernel == 2 else "generic")
+    if ",big" in plan.kernel_name():                                      # the re-basing instantiation never runs in lateral-mirror mode (ADVICE r3:
+        assert not plan.mirror, plan.kernel_name()                        # the mode was decided before the stride check and every execute failed)
     b, s = big.cpu().numpy(), small.cpu().numpy()
     assert np.abs(s).max() > 0 and rel_err(b, s) <= 2e-6
 

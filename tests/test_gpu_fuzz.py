@@ -63,6 +63,12 @@ def _draw(seed):
     return r, cfg
 
 
+# Seeds (and frames) that needed the shifted-oracle explanation below -- the one place where an edge-rule bug could hide: counted,
+# reported and bounded by test_fuzz_escape_rate at the end of this file.
+_ESCAPES: list = []
+_RAN: list = []
+ESCAPE_RATE_MAX = 0.05          # of the seeds that ran; rounds 1-3 saw well under 1 % in soaks of > 100 000 seeds
+
 _SEED0 = int(os.environ.get("QDAS_FUZZ_OFFSET", "0"))          # soak runs: QDAS_FUZZ_OFFSET=2000 QDAS_FUZZ_SEEDS=2000 pytest -n 8 ...
 
 
@@ -73,6 +79,7 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
     from qups_amd.das_spec import _cast_data, _colmajor
     from oracle import das_oracle as O
     r, c = _draw(seed)
+    _RAN.append(seed)
     zspan = (4e-3, 4e-3 + max(c["I1"], 2) * 0.1e-3 * c["coarse"])
     case = make_case(seq=c["seq"], interp=c["interp"], seed=seed, N=c["N"], M=c["M"], I1=c["I1"], I2=c["I2"], zlim=zspan,
                      xspan=2e-3 * c["coarse"], data=c["data"])
@@ -198,6 +205,7 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
             # must be explained by the float64 oracle with its time origin moved by 2e-4 samples either way.
             e = np.abs(out - refv).max(axis=1) / den
             bad = np.nonzero(e > tol)[0]
+            _ESCAPES.append(dict(seed=int(seed), frame=int(f), pixels=int(bad.size), of=int(e.size), err=float(err), tol=float(tol), seq=str(c["seq"]), interp=str(c["interp"])))
             # (focused waves: the delay changes sign with (Pi - Pv).Nv, src/bf.cu:107 -- at the focal depth the fp32 geometry of the kernels and the
             #  float64 oracle may disagree on the sign of a dot product that is ~0: a row of pixels, visible pair by pair in 'BF')
             lim = max(2, e.size // 500) if c["seq"] != "FC" else max(4, e.size // 150)
@@ -210,3 +218,21 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
                     r2 = r2[kw["i_begin"]: kw["i_begin"] + kw["i_count"]]
                 best = np.minimum(best, np.abs(out[bad] - r2[bad]).max(axis=1) / den)
             assert best.max() <= 10 * tol, (seed, c, f, plan.tile_shape(), plan.wave_shape(), plan.aperture_split(), plan.fallback_tiles(), err, float(best.max()))
+
+
+def test_fuzz_escape_rate():
+    """How often did the shifted-oracle explanation fire?  (it is the only place a real edge-rule bug could hide.)  Prints the
+    census, leaves it in ``gpurun_out/fuzz_escapes.json`` when that directory exists, and fails above ESCAPE_RATE_MAX of the seeds."""
+    import json
+    import warnings
+    seeds = sorted({e["seed"] for e in _ESCAPES})
+    rec = dict(seeds_run=len(_RAN), seeds_with_escape=len(seeds), events=_ESCAPES, rate_max=ESCAPE_RATE_MAX)
+    msg = f"fuzz: {len(seeds)} of {len(_RAN)} seeds took the shifted-oracle escape ({len(_ESCAPES)} frames): seeds {seeds}"
+    print(msg)
+    warnings.warn(msg)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "fuzz_escapes.json"), "w") as fh:
+            json.dump(rec, fh, indent=1)
+    if _RAN:
+        assert len(seeds) <= max(1, int(ESCAPE_RATE_MAX * len(_RAN))), msg

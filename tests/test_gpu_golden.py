@@ -383,6 +383,45 @@ def test_us_bfDAS_frames_layout_matches_DAS_and_oracle(keep):
     assert rel_err(_np(b_lut), ref) <= 5e-4                                   # fp32 delay tables
 
 
+@pytest.mark.parametrize("shape", ["row", "column", "dim4", "scalar-array"])
+def test_channeldata_arrays_in_DAS_and_bfDAS(shape):
+    """ND-arrays of ChannelData (reference src/UltrasoundSystem.m:3301-3305,3325,3368 and :4629,4670-4672): every element is beamformed on
+    its own and the images are concatenated along the array's one non-scalar dimension -- the reference's ``cat(chddim, bi{:})``: a row
+    ``[chd1, chd2, chd3]`` concatenates along the image's second dimension, a 1 x 1 x 1 x K array (``splice(chd, 4, 1)``) along the frame
+    dimension."""
+    import torch
+    from qups_amd import ChannelData, Scan, Sequence, Transducer, UltrasoundSystem
+    case = make_case(seq="FSA", interp="linear", seed=31, N=5, I1=20, I2=4)
+    xdc = Transducer(case["Pr"], np.stack([0 * case["Pr"][0], 0 * case["Pr"][0], 1 + 0 * case["Pr"][0]]))
+    us = UltrasoundSystem(xdc, Sequence("FSA", c0=case["c"]), Scan(case["Pi"]))
+    scal = [1.0, 2j, -0.5]
+    one = [ChannelData(torch.from_numpy(case["x"] * s), case["t0"], case["fs"]) for s in scal]
+    if shape == "row":
+        arr, dim = one, 1                                                     # a list is MATLAB's [a, b, c]: 1 x 3
+    elif shape == "column":
+        arr, dim = np.array(one, dtype=object).reshape(3, 1), 0
+    elif shape == "dim4":
+        arr, dim = np.array(one, dtype=object).reshape(1, 1, 1, 3), 3
+    else:
+        arr, dim = np.array(one[:1], dtype=object).reshape(1, 1), None
+    single = [us.DAS(c, interp="linear") for c in one]                        # I1 x I2 x I3 each
+    for f in (us.DAS, us.bfDAS):
+        b = f(arr, interp="linear")
+        refs = [f(c, interp="linear") for c in one]
+        if dim is None:
+            assert tuple(b.shape) == tuple(refs[0].shape) and torch.equal(b, refs[0])
+            continue
+        nd = max(refs[0].ndim, dim + 1)
+        want = torch.cat([r.reshape(tuple(r.shape) + (1,) * (nd - r.ndim)) for r in refs], dim=dim)
+        assert tuple(b.shape) == tuple(want.shape) and torch.equal(b, want)
+        assert b.shape[dim] == 3 * want.shape[dim] // 3 and b.shape[dim] == (3 if dim >= 3 else 3 * single[0].shape[dim])
+    b, plan = us.DAS(arr, interp="linear", return_plan=True)
+    assert plan is not None and not plan.closed
+    plan.close()
+    with pytest.raises(Exception, match="up to one non-scalar dimension"):
+        us.DAS(np.array(one + one[:1], dtype=object).reshape(2, 2), interp="linear")
+
+
 @pytest.mark.parametrize("keep_tx", [False, True])
 def test_bfDASLUT_transmit_blocks(keep_tx):
     """bfDASLUT's transmit blocking (reference src/UltrasoundSystem.m:4573,4641-4655: `bsize`, 1 GB heuristic): the transmits are beamformed

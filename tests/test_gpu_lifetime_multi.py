@@ -58,9 +58,10 @@ def test_das_spec_frame_loop_has_flat_device_memory(cache, monkeypatch):
     clear_plan_cache()
 
 
-def test_plan_cache_distinguishes_problems_and_survives_close(monkeypatch):
-    """the key is the problem's CONTENT: another weight array, interpolator or kernel choice is another plan; a plan the caller closed
-    is rebuilt, not reused"""
+def test_plan_cache_distinguishes_problems_and_handed_out_plans_are_private(monkeypatch):
+    """the key is the problem's CONTENT: another weight array, interpolator or kernel choice is another plan.  A plan handed out with
+    ``return_plan=True`` LEAVES the cache: no later call shares its scratch, no LRU eviction closes it under the caller's frame
+    loop; plain calls keep sharing the cached plan."""
     import torch
     from qups_amd import clear_plan_cache, das_spec, plan_cache_info
     monkeypatch.setenv("QDAS_PLAN_CACHE", "4")
@@ -73,20 +74,70 @@ def test_plan_cache_distinguishes_problems_and_survives_close(monkeypatch):
     yb, pb = das_spec("DAS", *args, *case["opt"], "interp", "linear", "apod", w, return_plan=True)
     yc, pc = das_spec("DAS", *args, *case["opt"], "interp", "cubic", return_plan=True)
     assert pa is not pb and pa is not pc and not torch.equal(ya, yb) and not torch.equal(ya, yc)
-    w2 = w.copy()                                                     # equal content, another object: the same plan
-    yb2, pb2 = das_spec("DAS", *args, *case["opt"], "interp", "linear", "apod", w2, return_plan=True)
-    assert pb2 is pb and torch.equal(yb2, yb)
-    w2[0, 0, 0, 3] = 0.25                                             # changed content: another plan
-    yd, pd = das_spec("DAS", *args, *case["opt"], "interp", "linear", "apod", w2, return_plan=True)
-    assert pd is not pb and not torch.equal(yd, yb)
-    pa.close()
-    ya2, pa2 = das_spec("DAS", *args, *case["opt"], "interp", "linear", return_plan=True)
-    assert pa2 is not pa and not pa2.closed and torch.equal(ya2, ya)
-    for _ in range(6):                                                # eviction closes the oldest plans, capacity holds
-        das_spec("DAS", *args, *case["opt"], "interp", "nearest", "modulation", float(np.float32(1e6 * (1 + _))))
+    assert plan_cache_info()["size"] == 0                             # all three were handed out
+    yb2, pb2 = das_spec("DAS", *args, *case["opt"], "interp", "linear", "apod", w.copy(), return_plan=True)
+    assert pb2 is not pb and torch.equal(yb2, yb)                     # equal content: an equal image from a private plan
+    # plain calls: equal content -> the same cached plan (hits), changed content -> another
+    h0 = plan_cache_info()["hits"]
+    y1 = das_spec("DAS", *args, *case["opt"], "interp", "linear", "apod", w)
+    y2 = das_spec("DAS", *args, *case["opt"], "interp", "linear", "apod", w.copy())
+    assert torch.equal(y1, yb) and torch.equal(y2, yb) and plan_cache_info()["hits"] == h0 + 1 and plan_cache_info()["size"] == 1
+    w2 = w.copy(); w2[0, 0, 0, 3] = 0.25
+    yd = das_spec("DAS", *args, *case["opt"], "interp", "linear", "apod", w2)
+    assert not torch.equal(yd, yb) and plan_cache_info()["size"] == 2
+    # a handed-out plan survives any number of other problems going through the cache (round 3: evicted and closed after 8 of them)
+    for k in range(10):
+        das_spec("DAS", *args, *case["opt"], "interp", "nearest", "modulation", float(np.float32(1e6 * (1 + k))))
     assert plan_cache_info()["size"] == 4
+    assert not pa.closed and not pb.closed and not pc.closed
+    from qups_amd.das_spec import _colmajor
+    assert torch.equal(pb.execute_colmajor(_colmajor(x), 1).reshape(-1), yb.permute(*reversed(range(yb.ndim))).reshape(-1))      # (column-major buffer vs the MATLAB-shaped image)
+    # ... and a hit that is handed out leaves the cache too
+    y3 = das_spec("DAS", *args, *case["opt"], "interp", "cubic")
+    n = plan_cache_info()["size"]
+    y4, p4 = das_spec("DAS", *args, *case["opt"], "interp", "cubic", return_plan=True)
+    assert plan_cache_info()["size"] == n - 1 and torch.equal(y3, y4) and torch.equal(y4, yc)
     clear_plan_cache()
-    assert plan_cache_info()["size"] == 0 and pb.closed
+    assert plan_cache_info()["size"] == 0 and not p4.closed and not pb.closed
+    for p in (pa, pb, pb2, pc, p4):
+        p.close()
+    with pytest.raises(Exception, match="closed"):
+        pa.execute_colmajor(_colmajor(x), 1)
+
+
+def test_cached_plan_is_not_freed_under_a_running_call():
+    """eviction / clear_plan_cache from one thread while another is inside execute on the same cached plan: close() waits on the plan's lock
+    (the native handle was freed mid-call)"""
+    import threading
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd.das_spec import _colmajor
+    case = make_case(seq="PW", interp="cubic", seed=3, N=32, M=16, I1=256, I2=64)
+    x = torch.from_numpy(case["x"]).cuda()
+    T, N, M = x.shape
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], (T, N, M), case["t0"], case["fs"], case["c"],
+                         parse_options(x, list(case["opt"]) + ["interp", "cubic"]))
+    plan = DasPlan(prob)
+    xc = _colmajor(x)
+    y0 = plan.execute_colmajor(xc, 1).clone()
+    errs, done = [], []
+
+    def worker():
+        try:
+            for _ in range(200):
+                y = plan.execute_colmajor(xc, 1)
+            torch.cuda.synchronize()
+            done.append(y)
+        except Exception as ex:                                       # "the plan has been closed" is the only acceptable way out
+            errs.append(ex)
+
+    th = threading.Thread(target=worker)
+    th.start()
+    plan.close()                                                      # races with the loop
+    th.join()
+    assert plan.closed
+    assert all("closed" in str(e) for e in errs), errs
+    assert (errs and not done) or (done and torch.equal(done[0], y0))
 
 
 def test_execute_into_reuses_the_output_buffer():
@@ -153,6 +204,7 @@ def _sharded_vs_single(fun, devices, mem, frames=2, seq="PW", I2=23, mirror=Fals
         mp = MultiDevicePlan(prob, devices=devices)
         assert [d for d, _, _, _ in mp.shards()] == list(devices)
         assert sum(c for _, _, c, _ in mp.shards()) == (prob.I // 2 if mirror else prob.I)
+        assert mp.mirror_slabs == mirror                  # (qdas_plan_sharded_mirror: a shard also owns the mirror image of the slab it reports)
         got = [mp.feval(x) for x in xs]                   # back-to-back frames: the second replication must wait for the first frame's readers
         torch.cuda.synchronize()
         for g, r in zip(got, ref):

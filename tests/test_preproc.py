@@ -107,6 +107,21 @@ def test_hilbert_takes_time_fastest_views_without_a_copy():
 
 
 @pytest.mark.gpu
+def test_hilbert_of_a_strided_single_trace():
+    """hilbert(x[:, j]) of a T x N tensor and a decimated slice x[::2]: one trace (K == 1) whose samples are NOT consecutive in memory
+    (the K == 1 fast path handed the raw pointer over and the library read the wrong samples)"""
+    import torch
+    from qups_amd.preproc import hilbert
+    g = torch.Generator(device="cuda").manual_seed(4)
+    x = torch.randn((512, 3), generator=g, device="cuda")
+    for v in (x[:, 1], x[::2, 2], x[:, 0].contiguous(), x.t().contiguous()[1]):
+        y = hilbert(v)
+        ref = hilbert_ref(v.cpu().numpy().astype(np.float64))
+        assert y.shape == v.shape
+        assert np.abs(y.cpu().numpy() - ref).max() / np.abs(ref).max() <= 2e-5, v.stride()
+
+
+@pytest.mark.gpu
 def test_real_rf_hilbert_then_das_equals_das_of_the_analytic_data():
     """the reference's pipeline (example_.m:261-269): real traces -> hilbert -> DAS, all on the device"""
     import torch
