@@ -55,10 +55,13 @@ EXEC_FLOP_GENERAL = {"nearest": 6.0, "linear": 14.0, "cubic": 37.0, "lanczos3": 
 EXEC_FLOP_MAC = {"nearest": 4.0, "linear": 8.0, "cubic": 16.0, "lanczos3": 16.0}           # of which the complex multiply-accumulates (never shared)
 
 
-def exec_flop_per_pair(interp, share):
+def exec_flop_per_pair(interp, share, folded=False):
+    """per (pixel, rx, tx) pair of the sum; a reciprocity-folded plan (fold.hip) forms ONE product per unordered pair on the pre-added traces:
+    half the multiply-accumulates too (plus one add per sample and frame in the fold pass, not counted here)"""
     if interp not in EXEC_FLOP_GENERAL:
         return None
-    return EXEC_FLOP_MAC[interp] + (EXEC_FLOP_GENERAL[interp] - EXEC_FLOP_MAC[interp]) / share
+    f = EXEC_FLOP_MAC[interp] + (EXEC_FLOP_GENERAL[interp] - EXEC_FLOP_MAC[interp]) / share
+    return f / 2 if folded else f
 
 
 from qups_amd.configs import workload  # noqa: E402  (geometry of the BASELINE configs, SURVEY.md section 8d)
@@ -241,6 +244,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-general", action="store_true", help="skip the reciprocal-mode-off measurement")
     ap.add_argument("--no-reciprocal", action="store_true", help="disable the reciprocal mode for the headline measurement itself (plan flag)")
+    ap.add_argument("--no-fold", action="store_true", help="reciprocal plans: do not fold the frame (plan flag QDAS_PLAN_NO_FOLD): both traces of every unordered "
+                    "transmit / receive pair are gathered per pixel, as in rounds 1-3")
     ap.add_argument("--no-jit", action="store_true", help="do not set the plan flag QDAS_PLAN_JIT: run the prebuilt instantiation instead of "
                     "the kernel hiprtc compiles for this plan's sizes (the reference's benchmark runs const-compiled kernels too: "
                     "src/UltrasoundSystem.m:5626-5748, test/ParTest.m:322-327)")
@@ -347,7 +352,7 @@ def main():
     # N > 1: qups_amd.dist -- pixel slabs (mirror slabs when every rank's plan takes the lateral-mirror mode: rank r beamforms columns of the
     # first half AND their mirror images) and ONE RCCL all_gather
     from qups_amd.dist import ShardedDasPlan
-    splan = ShardedDasPlan(prob, rank, world, device=dev, kernel=args.kernel, reciprocal=not args.no_reciprocal, jit=args.jit)
+    splan = ShardedDasPlan(prob, rank, world, device=dev, kernel=args.kernel, reciprocal=not args.no_reciprocal, jit=args.jit, fold=not args.no_fold)
     plan = splan.plan
     b, e = splan.i_begin, splan.i_begin + splan.i_count
     slab_kw = dict(i_begin=b, i_count=e - b, mirror_slab=splan.mirror_slabs)
@@ -417,16 +422,23 @@ def main():
                  "ms_per_step_incl_replication": round(el / args.steps * 1e3 + bcast_ms, 3),
                  "value_incl_replication": round(I / (el / args.steps + bcast_ms * 1e-3) / 1e6, 4)}
     reciprocal = bool(plan.reciprocal)
+    folded = bool(plan.folded)
+    unfolded_ms = None
+    if world == 1 and folded and not args.no_general:          # the same frame with both traces of every pair gathered (rounds 1-3: plan flag QDAS_PLAN_NO_FOLD)
+        uplan = DasPlan(prob, device=dev, kernel=args.kernel, reciprocal=True, jit=args.jit, fold=False, **slab_kw)
+        uplan.execute_colmajor(xc, 1)
+        unfolded_ms = kernel_time(uplan, 3)
+        uplan.close()
     general_ms = None
     if world == 1 and reciprocal and not args.no_general:      # the same frame without the reciprocal special case (plan flag)
-        gplan = DasPlan(prob, device=dev, kernel=args.kernel, reciprocal=False, jit=args.jit, **slab_kw)
+        gplan = DasPlan(prob, device=dev, kernel=args.kernel, reciprocal=False, jit=args.jit, **slab_kw)       # (no reciprocal mode: no fold either)
         gplan.execute_colmajor(xc, 1)
         general_ms = kernel_time(gplan, 3)
         gplan.close()
 
     prebuilt_ms = None
     if world == 1 and args.jit and not os.environ.get("QDAS_BENCH_CHILD"):      # the same frame on the prebuilt instantiation
-        pplan = DasPlan(prob, device=dev, kernel=args.kernel, reciprocal=not args.no_reciprocal, jit=False, **slab_kw)
+        pplan = DasPlan(prob, device=dev, kernel=args.kernel, reciprocal=not args.no_reciprocal, jit=False, fold=not args.no_fold, **slab_kw)
         pplan.execute_colmajor(xc, 1)
         prebuilt_ms = kernel_time(pplan, 3)
         pplan.close()
@@ -439,7 +451,7 @@ def main():
         if mode == "live":
             argv = ["--workload", args.workload] + (["--kernel", str(args.kernel)] if args.kernel else []) + \
                    (["--prec", args.prec] if args.prec else []) + (["--fmod", str(args.fmod)] if args.fmod else []) + (["--rx-apod", args.rx_apod] if args.rx_apod else []) + (["--rx-apod-array"] if args.rx_apod_array else []) + (["--window-apod"] if args.window_apod else []) + (["--tx-apod", args.tx_apod] if args.tx_apod else []) + (["--gen-apod"] if args.gen_apod else []) + \
-                   (["--no-reciprocal"] if args.no_reciprocal else []) + (["--no-jit"] if args.no_jit else [])
+                   (["--no-reciprocal"] if args.no_reciprocal else []) + (["--no-jit"] if args.no_jit else []) + (["--no-fold"] if args.no_fold else [])
             traffic, tsrc, ctrs = measure_traffic(argv)
             if traffic is None:
                 mode = "file"
@@ -464,7 +476,7 @@ def main():
         info = _lib.device_info(local)
         ksec = kernel_ms * 1e-3
         mirror = bool(plan.mirror)
-        exec_fpp = exec_flop_per_pair(w["interp"], (2 if reciprocal else 1) * (2 if mirror else 1))
+        exec_fpp = exec_flop_per_pair(w["interp"], (2 if mirror else 1) if folded else (2 if reciprocal else 1) * (2 if mirror else 1), folded)
         # pairs the kernel really executes: a pixel x receiver weight (array or generated rule) drops whole (wave, receiver) stages
         exec_frac, mask = 1.0, None
         try:
@@ -490,7 +502,7 @@ def main():
             "value": round(I / (el / args.steps) / 1e6, 4), "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"halfT": "f16", "single": "f32", "double": "f64"}[w["prec"]], "data": "synthetic",
-            "config": {"workload": w["label"], "pixels": I, "pairs_per_frame": pairs, "kernel": plan.kernel, "reciprocal_mode": reciprocal, "mirror_mode": mirror,
+            "config": {"workload": w["label"], "pixels": I, "pairs_per_frame": pairs, "kernel": plan.kernel, "reciprocal_mode": reciprocal, "reciprocity_fold": folded, "mirror_mode": mirror,
                        "kernel_name": plan.kernel_name(), "jit": bool(args.jit),
                        "fallback_tiles": fallback, "tile": list(plan.tile_shape()), "wave": list(plan.wave_shape()), "aperture_split": plan.aperture_split(), "parallelism": (f"{'mirror-' if splan.mirror_slabs else ''}pixel-slab x{world} + RCCL all_gather") if world > 1 else "1 GPU",
                        "device": info["name"], "cu": info["cu_count"]},
@@ -510,11 +522,19 @@ def main():
         }
         try:
             taps = {"nearest": 1, "linear": 2, "cubic": 4, "lanczos3": 4}.get(w["interp"], 4)
-            rec["roofline"].update(binding_roofs(ctrs, info["cu_count"], pairs / world * (exec_frac or 1.0), taps, sb))
+            rec["roofline"].update(binding_roofs(ctrs, info["cu_count"], pairs / world * (exec_frac or 1.0) * ((N + 1) / (2.0 * N) if folded else 1.0), taps, sb))
         except Exception as ex:
             rec["roofline"]["binding_note"] = f"counter post-processing failed: {ex!r}"
         if prebuilt_ms is not None:
             rec["prebuilt_kernel_ms"] = round(prebuilt_ms, 3)
+        if folded:
+            rec["roofline"]["fold_note"] = ("reciprocal acquisition: every step first adds the two traces of each unordered transmit / receive pair (fold.hip: one pass over "
+                                            "HBM, inside the timed region and inside kernel_ms), then the fused kernel sums the N(N+1)/2 folded traces -- the image is the "
+                                            "full N x M sum (linearity of the interpolators; parity_check on random, non-symmetric data); products_formed_frac = "
+                                            "share of the N x M products formed per pixel; unfolded_ms_per_step = the same frame with the plan flag QDAS_PLAN_NO_FOLD")
+            rec["roofline"]["products_formed_frac"] = round((N + 1) / (2.0 * N), 4)
+        if unfolded_ms is not None:
+            rec["unfolded_ms_per_step"] = round(unfolded_ms, 3)
         if general_ms is not None:
             rec["general_ms_per_step"] = round(general_ms, 3)
             rec["general_value"] = round(I / (general_ms * 1e-3) / 1e6, 4)

@@ -107,6 +107,10 @@ extern "C" {
                                      natural pixel order ('DAS' only; y holds 2 i_count pixels).  QDAS_EUNSUPPORTED when the geometry
                                      is not mirror-symmetric or the mode is not available for the problem: use plain slabs then.  */
 
+#define QDAS_PLAN_NO_FOLD       32 /* reciprocal plans with fp32 data: do NOT fold the frame (qdas_plan_folded) -- gather both traces of every
+                                     unordered pair per pixel and share only tap index and weights between them, as rounds 1-3 did.  The fold
+                                     costs a plan-owned copy of the frame (T x N x M complex64) and one streaming pass per frame            */
+
 /* ---- LIFETIME of caller memory.  Host arrays (QDAS_MEM_HOST) are copied at qdas_plan_create and never touched again.  Device
  *      arrays (QDAS_MEM_DEVICE) are used IN PLACE: Pi, Pr, Pv, Nv, apod, cinv and rx_normals must stay allocated and unchanged
  *      until qdas_plan_destroy -- unless the plan was created with QDAS_PLAN_COPY_INPUTS.  acstride is read at creation only.
@@ -204,6 +208,10 @@ int  qdas_plan_tile_shape(const qdas_plan *plan, int *tile_z, int *tile_cols, in
 /* 1 when a QDAS_KERNEL_TILED plan runs in reciprocal mode (transmit elements == receive elements, one t0: every unordered
  * transmit/receive pair is indexed and weighted once), else 0 */
 int  qdas_plan_reciprocal(const qdas_plan *plan);
+/* 1 when a reciprocal plan beamforms the RECIPROCITY-FOLDED frame (fp32 data; QDAS_PLAN_NO_FOLD): every execute first adds the two traces of
+ * each unordered transmit/receive pair, xs[:,n,m] = w[n,m] x[:,n,m] + w[m,n] x[:,m,n] (n <= m; one pass over HBM into a plan-owned copy of the
+ * frame, pixel-independent apodization applied on the way), and the fused kernel then walks the upper triangle only */
+int  qdas_plan_folded(const qdas_plan *plan);
 /* 1 when a QDAS_KERNEL_TILED plan runs in lateral-mirror mode (QDAS_PLAN_NO_MIRROR), else 0 */
 int  qdas_plan_mirror(const qdas_plan *plan);
 /* human-readable name of the kernel a plan launches for one frame, e.g.

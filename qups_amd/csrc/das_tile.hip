@@ -20,6 +20,7 @@
 #include "das_tile_f32w.hip"
 #include "das_tile_symq.hip"
 #include "das_tile_symqh.hip"
+#include "das_tile_fold.hip"
 #else
 #include "qdas_device.h"
 #include "das_tile_cfg.h"
@@ -46,6 +47,7 @@ hipError_t launch_tile_f64(const TileParams &P, unsigned ntiles, size_t lds, hip
 hipError_t launch_tile_f32w(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_symq(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_symqh(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
+hipError_t launch_tile_fold(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 
 // y[i] = sum over the ksplit partial images, in split order (deterministic)
 // (fp64 data: complex128 partial images)
@@ -67,20 +69,21 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const float2 *part, ST
 
 
 
-TileConfig tile_config(int dtype, int sym, int narrow, int fb, int mirq) {
-    const Cfg &g = CFGS[cfg_index(dtype, sym, fb, narrow, mirq)];
+TileConfig tile_config(int dtype, int sym, int narrow, int fb, int mirq, int fold) {
+    const Cfg &g = CFGS[cfg_index(dtype, sym, fb, narrow, mirq, fold)];
     TileConfig c;
     c.waves = g.waves;
     c.mb = g.mb;
     c.window = g.w;
     c.threads = g.waves * 64;
-    c.lds_bytes = (size_t)g.nbuf * g.mb * ((mirq && sym) ? 4 : (sym || fb == 2) ? 2 : 1) * g.w * (dtype == 2 ? 4 : dtype == 0 ? 16 : 8);
+    const int sets = (fold && sym && dtype == 1) ? (mirq ? 2 : 1) : (mirq && sym) ? 4 : (sym || fb == 2) ? 2 : 1;      // window sets per buffer
+    c.lds_bytes = (size_t)g.nbuf * g.mb * sets * g.w * (dtype == 2 ? 4 : dtype == 0 ? 16 : 8);
     return c;
 }
 
-size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow, int pixw, int wtab, int mirq) {
-    const Cfg &g = CFGS[cfg_index(dtype, sym, 1, narrow, mirq)];
-    const TileConfig c = tile_config(dtype, sym, narrow, 1, mirq);
+size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow, int pixw, int wtab, int mirq, int fold) {
+    const Cfg &g = CFGS[cfg_index(dtype, sym, 1, narrow, mirq, fold)];
+    const TileConfig c = tile_config(dtype, sym, narrow, 1, mirq, fold);
     const size_t MX = std::min<size_t>(M > N ? M : N, QDAS_PROLOGUE_CHUNK);
     // (geometry tables in the plan's real type: 32-byte receiver records and 8-byte table entries for fp64 data -- Tile::setup)
     const size_t off_act = (((((2 * M + N) * 4 + 15) & ~(size_t)15) + (dtype == 0 ? 32 : 16) * N + 7 * M * (dtype == 0 ? 8 : 4)) + 15) & ~(size_t)15;
@@ -110,19 +113,21 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     if (narrow == 2 && (P.lut_tx || P.bf || P.big || (!P.probe && P.nfr > 1))) return hipErrorInvalidValue;
     if (P.bpix && (narrow != 2 || P.wtab || P.fmod != 0.0 || P.syn || sym)) return hipErrorInvalidValue;      // (TileCfg::BPIX instantiations only)
     if (P.act_bytes != 0 && P.act_bytes != 8 * (P.N + 1)) return hipErrorInvalidValue;
-    const int mirq = (sym && P.mir && !P.probe) ? 1 : 0;   // reciprocal + lateral-mirror mode: four window sets (launch configurations 15 / 16)
-    const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M, narrow, P.act_bytes ? 1 : 0, P.wtab ? 1 : 0, mirq);    // (the two-frame configurations have the same LDS image)
+    const int fold = (sym && P.fold && dtype == 1) ? 1 : 0;   // reciprocity-folded data (launch configurations 17 / 18 / 19)
+    if (P.fold && (!fold || P.wtab)) return hipErrorInvalidValue;
+    const int mirq = (sym && P.mir && (!P.probe || fold)) ? 1 : 0;   // reciprocal + lateral-mirror mode: four window sets (launch configurations 15 / 16; folded data: two)
+    const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M, narrow, P.act_bytes ? 1 : 0, P.wtab ? 1 : 0, mirq, fold);    // (the two-frame configurations have the same LDS image)
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
     if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part && !P.bf))) return hipErrorInvalidValue;
     // frames per launch; lateral-mirror plans (one frame) run the two-window-set instantiations as well
     const int nfr = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
-    if (P.mir && !P.probe && (nfr != 1 || P.big || P.bf || P.lut_tx || P.syn || ((P.apix || P.gen_kind) && ((dtype != 2 && !jit) || sym || P.stage_shift || P.bpix)) || (!sym && narrow) || (sym && dtype == 1 && !narrow))) return hipErrorInvalidValue;
+    if (P.mir && !P.probe && (nfr != 1 || P.big || P.bf || P.lut_tx || P.syn || ((P.apix || P.gen_kind) && ((dtype != 2 && !jit) || sym || P.stage_shift || P.bpix)) || (!sym && narrow) || (sym && dtype == 1 && !narrow && !fold))) return hipErrorInvalidValue;
     const int nf = (P.mir && !P.probe && !sym) ? 2 : nfr;
     if ((nf != 1 && nf != 2 && nf != 4) || (nf > 1 && (sym || P.big))) return hipErrorInvalidValue;
     if (P.lut_tx && (sym || nf != 1 || (dtype != 1 && dtype != 2) || (P.syn && dtype != 1))) return hipErrorInvalidValue;
     if (jit && (P.probe || nfr != 1 || P.lut_tx || P.bf)) return hipErrorInvalidValue;
     if (P.bf && (sym || nf != 1 || dtype != 1 || P.lut_tx || P.big || P.apix || P.gen_kind)) return hipErrorInvalidValue;
-    hipError_t e = jit ? jit_launch(jit, P, ntiles * P.ksplit, (unsigned)CFGS[cfg_index(dtype, sym, 1, narrow, mirq)].waves * 64u, jit_lds ? jit_lds : lds, s) : P.lut_tx ? (dtype == 2 ? launch_tile_luth(P, ntiles, lds, s) : launch_tile_lut(P, ntiles, lds, s)) : mirq ? (dtype == 2 ? launch_tile_symqh(P, ntiles, lds, s) : launch_tile_symq(P, ntiles, lds, s)) : sym ? (dtype == 2 ? launch_tile_symh(P, ntiles, lds, s) : narrow ? launch_tile_symw(P, ntiles, lds, s) : launch_tile_sym(P, ntiles, lds, s))
+    hipError_t e = jit ? jit_launch(jit, P, ntiles * P.ksplit, (unsigned)CFGS[cfg_index(dtype, sym, 1, narrow, mirq, fold)].waves * 64u, jit_lds ? jit_lds : lds, s) : fold ? launch_tile_fold(P, ntiles, lds, s) : P.lut_tx ? (dtype == 2 ? launch_tile_luth(P, ntiles, lds, s) : launch_tile_lut(P, ntiles, lds, s)) : mirq ? (dtype == 2 ? launch_tile_symqh(P, ntiles, lds, s) : launch_tile_symq(P, ntiles, lds, s)) : sym ? (dtype == 2 ? launch_tile_symh(P, ntiles, lds, s) : narrow ? launch_tile_symw(P, ntiles, lds, s) : launch_tile_sym(P, ntiles, lds, s))
                  : nf == 4 ? (dtype == 2 ? launch_tile_f16x4(P, ntiles, lds, s) : launch_tile_f32x4(P, ntiles, lds, s))
                  : nf == 2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))
                            : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : narrow == 2 ? launch_tile_f32w(P, ntiles, lds, s) : (P.bf && !P.probe) ? launch_tile_bf(P, ntiles, lds, s) : (P.big && !P.probe) ? launch_tile_f32big(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));

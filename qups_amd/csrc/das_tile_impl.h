@@ -62,7 +62,12 @@ typedef __attribute__((address_space(3))) void lds_void;
 //   the same traces of the next frames, so tap index and weights -- which depend on the geometry only -- are computed once for all
 //   of them (the reference launches one kernel per frame, kern/das_spec.m:371).  BIG: re-base the DMA descriptors along the
 //   receiver walk (transposed fp32 frames beyond 2 GiB).  LUT: the delays come from host-supplied tables (qdas_das_lut).
-template <int INTERP_, typename ST_, bool FMOD_, bool WTAB_, bool SYM_, bool FB2_, bool FB4_, int WAVES_, int MB_, int W_, int NBUF_, bool BIG_, bool LUT_, bool BF_ = false, bool MIRQ_ = false>
+//   FOLD: the channel data are RECIPROCITY-FOLDED (fold.hip; reciprocal plans, fp32): xs[:,n,m] = w[n,m] x[:,n,m] + w[m,n] x[:,m,n] for n < m,
+//   xs[:,n,n] = w[n,n] x[:,n,n] -- tau(n,m) == tau(m,n), and interpolation is linear in the data, so the two traces of an unordered pair are
+//   added ONCE per frame (one streaming pass over HBM) instead of being gathered and weighted separately for every pixel: the stage loop
+//   walks the upper triangle n <= m only, with ONE window set (FOLD && MIRQ: two -- my pixel's trace (n, m) and, for its lateral mirror image,
+//   (N-1-m, N-1-n), which lies in the upper triangle too).  Pixel-independent weights ride in the fold pass: such kernels carry no table.
+template <int INTERP_, typename ST_, bool FMOD_, bool WTAB_, bool SYM_, bool FB2_, bool FB4_, int WAVES_, int MB_, int W_, int NBUF_, bool BIG_, bool LUT_, bool BF_ = false, bool MIRQ_ = false, bool FOLD_ = false>
 struct TileCfg {
     static constexpr int INTERP = INTERP_, WAVES = WAVES_, MB = MB_, W = W_, NBUF = NBUF_;
     using ST = ST_;
@@ -73,8 +78,10 @@ struct TileCfg {
     // window sets per stage: {x[:,n,m], x[:,m,n]} for my pixel, {x[:,N-1-n,N-1-m], x[:,N-1-m,N-1-n]} for its mirror image, ONE tap index
     // and ONE set of weights for all four
     static constexpr bool MIRQ = MIRQ_;
-    static constexpr bool QUAD = FB4 || MIRQ;        // four window sets: the pair loop makes two passes over one index / weight evaluation
-    static constexpr bool TWO = SYM || FBX;          // (at least) two window sets per stage: direct + (mirror | next frame)
+    static constexpr bool FOLD = FOLD_;              // reciprocity-folded data (above): upper triangle only, no reciprocal window set
+    static constexpr bool FOLDQ = FOLD_ && MIRQ_;    // ... in lateral-mirror mode: window set 0 = my pixel's trace, set 1 = its mirror image's
+    static constexpr bool QUAD = FB4 || (MIRQ && !FOLD);   // four window sets: the pair loop makes two passes over one index / weight evaluation
+    static constexpr bool TWO = (SYM && !FOLD) || FBX || FOLDQ;   // (at least) two window sets per stage: direct + (reciprocal | next frame | mirror image)
     static constexpr int NHP = QUAD ? 2 : 1;         // passes of the pair loop: one per frame pair (MIRQ: my pixel, its mirror image)
     static constexpr int NFR = FB4 ? 4 : (FB2 ? 2 : 1);   // frames per launch
     static constexpr int NW = QUAD ? 4 * MB : (TWO ? 2 * MB : MB);     // windows per LDS buffer
@@ -109,9 +116,11 @@ struct TileCfg {
     static constexpr int WB = W * SB;                // bytes per window
     static constexpr int PB = 1024;                  // bytes per full DMA piece (one wave-instruction x 16 B)
     static constexpr int PCS = (WB + PB - 1) / PB;   // pieces per window; the last one may use fewer lanes
-    static constexpr int NDMA = WPW * PCS * (MIRQ ? 4 : TWO ? 2 : 1);    // DMA instructions per wave and stage
+    static constexpr int NDMA = WPW * PCS * (QUAD ? (FB4 ? 2 : 4) : TWO ? 2 : 1);    // DMA instructions per wave and stage
     static_assert(!(SYM && FBX) && !(FB2 && FB4), "reciprocal mode runs one frame per launch");
-    static_assert(!MIRQ || (SYM && MB_ == WAVES_ && 4 * MB_ * W_ * (int)sizeof(ST_) <= 65536), "reciprocal + lateral-mirror mode: one window per wave and set, immediate LDS offsets");
+    static_assert(!MIRQ || FOLD || (SYM && MB_ == WAVES_ && 4 * MB_ * W_ * (int)sizeof(ST_) <= 65536), "reciprocal + lateral-mirror mode: one window per wave and set, immediate LDS offsets");
+    static_assert(!FOLD || (SYM && !WTAB_ && !FBX && !BIG && !LUT && !BF_ && sizeof(ST_) == 8), "folded data: reciprocal plans, fp32, weights folded into the data, one frame per launch");
+    static_assert(!FOLDQ || (MB_ % WAVES_ == 0 && 2 * MB_ * W_ * (int)sizeof(ST_) <= 65536), "folded data + lateral-mirror mode: two window sets within the immediate LDS offsets");
     static_assert(!BIG || (!SYM && !FBX), "the re-basing general kernel runs one frame per launch");
     static_assert(!LUT || (!SYM && !FBX && !BIG), "table-driven delays: general mode, one frame per launch");
     static_assert(!BF || (!SYM && !FBX && !BIG && !LUT && sizeof(ST_) == 8), "'BF': general mode, fp32 data, one frame per launch");
@@ -169,7 +178,7 @@ template <class C> struct Tile {
     bool wpix, syn;
     // ---- LDS-DMA staging (tile_staging.h)
     int wb[C::WPW], wb2[C::WPW];
-    int qo[C::MIRQ ? 4 : 1];                         // MIRQ: absolute byte offsets of this wave's window in the four traces of the stage at the DMA front (without B[n])
+    int qo[C::MIRQ ? (C::FOLD ? 2 * C::WPW : 4) : 1];   // MIRQ: absolute byte offsets of this wave's window(s) in the four (folded data: two) traces of the stage at the DMA front (without B[n])
     uint32_t soff, soff2;
     __amdgpu_buffer_rsrc_t rsD, rsM;
     uint64_t offD, offM, xbytes;
@@ -709,7 +718,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
             // LDS byte address of a tap = bits(t + MAGIC)*SB + cbase + (window, tap) immediate
             const uint32_t cbase = win_off + (uint32_t)buf * (C::NW * C::WB) - (MAGIC_BITS * (uint32_t)C::SB);
             // full block (reciprocal mode: block entirely above the diagonal): check-free; else the tail / diagonal variant
-            if (C::SYM ? (n < m0) : (m0 + C::MB <= M)) {
+            if (C::SYM ? (n < m0 && (!C::FOLD || m0 + C::MB <= M)) : (m0 + C::MB <= M)) {
                 if constexpr (C::TWO && (C::F32 || C::SYM) && C::K == 4 && !(CHECK || C::FMOD || C::WTAB) && !hooks::no_pipeline)
                     pairs_pipelined(rb, cbase);
                 else
@@ -853,26 +862,27 @@ template <class C, bool PROBE> __device__ __forceinline__ void das_tile_body(con
 // PSZ / BPC: bytes per lane and DMA piece (16) and workgroups per CU the register budget is sized for -- kept in the kernel's
 // name so that profiles of different rounds list the same kernels.  PROBE is a kernel of its own name: profiles of
 // das_tile_kernel<..., false> hold full frames only.
-template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, bool FB2, bool FB4, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE, bool BIG = false, bool LUT = false, bool BFM = false, bool MIRQ = false>
+template <int INTERP, typename ST, bool FMOD, bool WTAB, bool SYM, bool FB2, bool FB4, int WAVES, int MB, int W, int NBUF, int PSZ, int BPC, bool PROBE, bool BIG = false, bool LUT = false, bool BFM = false, bool MIRQ = false, bool FOLD = false>
 __global__ void __launch_bounds__(WAVES * 64, WAVES * BPC / 4)
 das_tile_kernel(const TileParams P) {
     static_assert(PSZ == 16, "16-byte DMA pieces");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    das_tile_body<TileCfg<INTERP, ST, FMOD, WTAB, SYM, FB2, FB4, WAVES, MB, W, NBUF, BIG, LUT, BFM, MIRQ>, PROBE>(P, smem);
+    das_tile_body<TileCfg<INTERP, ST, FMOD, WTAB, SYM, FB2, FB4, WAVES, MB, W, NBUF, BIG, LUT, BFM, MIRQ, FOLD>, PROBE>(P, smem);
 }
 
 #ifndef __HIPCC_RTC__
 template <int INTERP, typename ST, int CI>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
     constexpr Cfg G = CFGS[CI];
-    constexpr bool MIRQ = (CI == 15 || CI == 16);
-    constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8 || MIRQ), FB2 = (CI == 3 || CI == 4), FB4 = (CI == 5 || CI == 6), BIG = (CI == 9), LUT = (CI == 10 || CI == 11), BFM = (CI == 12);
+    constexpr bool FOLD = (CI == 17 || CI == 18 || CI == 19);       // folded data: with the lateral-mirror mode (narrow / wide windows), without
+    constexpr bool MIRQ = (CI == 15 || CI == 16 || CI == 17 || CI == 18);
+    constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8 || MIRQ || FOLD), FB2 = (CI == 3 || CI == 4), FB4 = (CI == 5 || CI == 6), BIG = (CI == 9), LUT = (CI == 10 || CI == 11), BFM = (CI == 12);
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
     const dim3 g(ntiles * (P.probe ? 1u : P.ksplit)), b(G.waves * 64);
 #define QDAS_LAUNCH(FM, WT) QDAS_LAUNCH_P(FM, WT, false)
 #define QDAS_LAUNCH_P(FM, WT, PR)                                                                        \
     do {                                                                                                 \
-        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, FB4, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR, BIG && !PR, LUT, BFM && !PR, MIRQ && !PR>; \
+        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, FB4, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR, BIG && !PR, LUT, BFM && !PR, MIRQ && !PR, FOLD && !PR>; \
         hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return e;                                                                   \
         kfn<<<g, b, lds, s>>>(P);                                                                        \
@@ -887,6 +897,10 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
         else if (fm)  QDAS_LAUNCH(true, false);
         else if (wt)  QDAS_LAUNCH(false, true);
         else          QDAS_LAUNCH(false, false);
+    } else if constexpr (FOLD) {                      // (pixel-independent weights were applied by the fold pass: no table here)
+        if (wt) return hipErrorInvalidValue;
+        if (fm) QDAS_LAUNCH(true, false);
+        else    QDAS_LAUNCH(false, false);
     } else if constexpr (MIRQ) {                      // (a weight table must be mirror-symmetric too: checked by the host)
         if (fm && wt) QDAS_LAUNCH(true, true);
         else if (fm)  QDAS_LAUNCH(true, false);

@@ -21,6 +21,7 @@ struct JitSpec {
     int mirq;                                           // reciprocal + lateral-mirror mode: four window sets (TileCfg::MIRQ)
     int mslab;                                          // ... of a mirror slab (tile_params.h mir == 2)
     int wreal;                                          // the weight table is real: the weighted accumulation is one packed FMA per sample
+    int fold;                                           // reciprocity-folded data (TileCfg::FOLD; with mirq: two window sets)
 };
 
 std::string jit_source(const JitSpec &k);

@@ -89,6 +89,10 @@ struct qdas_plan {
     bool no_fallback = false;                 // the probe found no tile whose delay spread exceeds the LDS window
     double misfit_frac = 0.0;                 // fraction of the chosen footprint's tiles that do not fit it
     bool wtab_real = false;                   // the folded weight table has no imaginary part
+    // reciprocity fold (fold.hip; tile_params.h `fold`): the plan's folded copy of a frame (T x N x M complex64, upper triangle written per frame)
+    // and the N x M weight table the fold pass applies (null: ones) -- the folded kernels themselves carry no table
+    void *fold_buf = nullptr;
+    const void *fold_wtab = nullptr;
     bool fb2_ok = false;                      // frames of a sequence may share launches, 4 or 2 at a time (decided at plan creation)
     bool fb4_off = false;                     // ... but at most pairwise (QDAS_NO_FB4)
     // A lateral-mirror plan runs one frame per launch (its second window set is taken).  For a STREAM of frames four frames per launch share
@@ -521,7 +525,11 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     }
     // reciprocal mode (das_tile_impl.h "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
     // elements and share one t0 has tau(n,m) == tau(m,n); detected from the geometry itself, bit-exactly.
-    int sym = 0, big = 0;
+    // RECIPROCITY FOLD (fold.hip, das_tile_impl.h TileCfg::FOLD; fp32 data): interpolation is linear in the data, so the two traces of an unordered
+    // pair are ADDED once per frame -- one streaming pass over HBM, pixel-independent weights applied on the way -- and the fused kernel walks the
+    // upper triangle of the folded frame: half the staging, gathers and multiply-accumulates.  QDAS_PLAN_NO_FOLD / QDAS_NO_FOLD=1: the reciprocal
+    // mode as it was (both traces gathered, tap index and weights shared).
+    int sym = 0, big = 0, rfold = 0;
     if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && z.VS && z.DV && z.N == z.M && pix_arr < 0 && !g.gen_kind && !(desc->plan_flags & QDAS_PLAN_NO_RECIPROCAL) && !getenv("QDAS_NO_SYM")) {
         std::vector<float> hr(3 * z.N), hv(4 * z.M);
         if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
@@ -529,7 +537,9 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         sym = 1;
         for (uint64_t m = 0; m < z.M && sym; ++m)
             if (memcmp(&hv[4 * m], &hr[3 * m], 12) != 0 || memcmp(&hv[4 * m + 3], &hv[3], 4) != 0) sym = 0;
-        if (sym && (z.M % tile_config(dt, 1).mb != 0 || tile_lds_bytes(dt, 1, z.N, z.M) > tile_lds_limit(1))) sym = 0;
+        rfold = sym && dt == QDAS_F32 && z.N >= 2 && z.N <= 65535 && !(desc->plan_flags & QDAS_PLAN_NO_FOLD) && !getenv("QDAS_NO_FOLD")
+               && tile_lds_bytes(dt, 1, z.N, z.M, 0, 0, 0, 0, 1) <= tile_lds_limit(1);
+        if (sym && !rfold && (z.M % tile_config(dt, 1).mb != 0 || tile_lds_bytes(dt, 1, z.N, z.M) > tile_lds_limit(1))) sym = 0;
     }
     // Roles of the two apertures (das_tile_impl.h): a stage = one STAGE element x a block of 32 BLOCK elements.  'DAS' / 'SYN': stage =
     // receiver, block = transmits; 'MUL': swapped.  The full sum may run either way, and runs swapped when that gives fewer, fuller
@@ -561,15 +571,15 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
                           && ((pix_arr >= 0 && !pix_is_tx && !g.gen_kind) || (pix_arr < 0 && g.gen_kind >= 1 && g.gen_kind <= 4)) && !getenv("QDAS_NO_MIRROR_WPIX");
     if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && (mir_plain || mir_wpix || mir_tab) && !cmap && z.I3 == 1 && z.I2 >= 2
         && z.N >= 2 && ((desc->i_begin == 0 && pl->i_count == pl->I) || mslab) && !(desc->plan_flags & QDAS_PLAN_NO_MIRROR) && !getenv("QDAS_NO_MIRROR")
-        && (!sym || ((uint64_t)z.T * z.N * z.M * data_size(dt) + 65536 < (1ull << 31) && z.M % 16 == 0 && !getenv("QDAS_NO_MIRQ")
-                     && tile_lds_bytes(dt, 1, z.N, z.M, 1, 0, z.S > 0 ? 1 : 0, 1) <= tile_lds_limit(1)))) {
+        && (!sym || ((uint64_t)z.T * z.N * z.M * data_size(dt) + 65536 < (1ull << 31) && (rfold || z.M % 16 == 0) && !getenv("QDAS_NO_MIRQ")
+                     && tile_lds_bytes(dt, 1, z.N, z.M, 1, 0, (z.S > 0 && !rfold) ? 1 : 0, 1, rfold) <= tile_lds_limit(1)))) {
         if ((rc = mirror_symmetric(desc, (const float *)g.Pi, &mir))) return bail(rc);
     }
     // stage / block element counts of the kernel: receivers / transmits, or swapped
     const uint64_t kN = swap ? z.M : z.N, kM = swap ? z.N : z.M;
-    pl->tc = tile_config(dt, sym, 0, mir ? 2 : 1);
+    pl->tc = tile_config(dt, sym, 0, mir ? 2 : 1, 0, rfold);
     const int pixw = (pix_arr >= 0 || g.gen_kind) ? 1 : 0;      // a pixel x receiver weight: the tile keeps a stage list (das_tile_impl.h plan_stages)
-    const int wtb = z.S > npix ? 1 : 0;      // pixel-independent arrays: folded into an N x M table, staged per stage in LDS
+    const int wtb = (z.S > npix && !rfold) ? 1 : 0;      // pixel-independent arrays: folded into an N x M table, staged per stage in LDS (folded data: applied by the fold pass)
     if (eligible && tile_lds_bytes(dt, sym, kN, kM, 0, pixw, wtb) > tile_lds_limit(sym)) {
         eligible = false; why = "tiled kernel: N + M too large for the LDS header";
     }
@@ -584,8 +594,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (swap) std::swap(strM, strN);
         const uint64_t slack = 65536;
         const uint64_t smax = strM > strN ? strM : strN;
-        if (sym && (uint64_t)(tile_config(dt, 1).mb + 1) * smax * data_size(dt) + slack >= (1ull << 30)) {
-            sym = 0;
+        if (sym && (uint64_t)(tile_config(dt, 1, 0, 1, 0, rfold).mb + 1) * smax * data_size(dt) + slack >= (1ull << 30)) {
+            sym = 0; rfold = 0;
             pl->tc = tile_config(dt, 0, 0, mir ? 2 : 1);     // (a mirror-symmetric plan keeps the two-window-set configuration of the general mode)
             if (eligible && tile_lds_bytes(dt, 0, z.N, z.M, 0, pixw, wtb) > tile_lds_limit(0)) { eligible = false; why = "tiled kernel: N + M too large for the LDS header"; }
         }
@@ -635,7 +645,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         t.fs = g.fs; t.fmod = g.fmod;
         t.cinv_fs = cinv0 * g.fs;
         t.cinv_pix = cmap ? (const float *)g.cinv + g.cst[5] : nullptr;
-        t.flag = z.flag; t.VS = z.VS; t.DV = z.DV; t.sym = sym; t.big = big;
+        t.flag = z.flag; t.VS = z.VS; t.DV = z.DV; t.sym = sym; t.big = big; t.fold = rfold;
         // tile grid: (1 << tz_log2) pixels of I1 x tile_cols columns (columns = I2*I3 flattened); the footprint is chosen below
         t.mir = mir ? (mslab ? 2 : 1) : 0;
         auto set_grid = [&](int tzl) {
@@ -759,9 +769,10 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e)));
             t.wtab = dtab;
         }
+        if (rfold && t.wtab) { pl->fold_wtab = t.wtab; t.wtab = nullptr; }      // (folded data: the fold pass applies the table, trace by trace -- it need not be symmetric in any way)
         pl->wtab_real = !host_tab.empty();               // every entry of the table real?  (apodization windows usually are: hiprtc builds then accumulate with ONE packed FMA per sample)
         for (size_t k = 1; k < host_tab.size(); k += 2) if (host_tab[k] != 0.f) { pl->wtab_real = false; break; }
-        if (t.mir && !host_tab.empty()) {               // lateral-mirror mode with a weight table: the table itself must be mirror-symmetric
+        if (t.mir && !host_tab.empty() && !rfold) {      // lateral-mirror mode with a weight table: the table itself must be mirror-symmetric
             bool tsym = true;
             for (uint64_t m = 0; m < z.M && tsym; ++m)
                 for (uint64_t n = 0; n < z.N; ++n) {
@@ -770,6 +781,31 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
                 }
             if (!tsym) { t.mir = 0; mir = false; pl->tc = tile_config(dt, sym); }      // (reciprocal plans: the narrow configuration is chosen just below)
         }
+        // reciprocal mode: first the 128-sample-window configuration (less staging traffic); it is kept only if some footprint
+        // has no misfit tile at all -- otherwise the 192-sample configuration
+        if (rfold) {
+            // folded data: with the lateral-mirror mode two window sets -- 32 x 128 samples when every tile of some footprint fits them (launch
+            // configuration 17), else 16 x 192 (18) --; when that leaves misfit tiles too (a misfit tile is redone by the generic kernel, which knows
+            // nothing of mirror images) or without the mode: one set of 32 x 192 samples (19), misfit tiles to the generic kernel as ever
+            if ((rc = dev_alloc(pl, &pl->fold_buf, (size_t)z.T * z.N * z.M * 8))) return bail(rc);
+            HIPCHK(hipMemset(pl->fold_buf, 0, (size_t)z.T * z.N * z.M * 8));      // (the lower triangle is never written: zeros, not garbage, where a border window reaches into it)
+            if (t.mir) {
+                t.narrow = getenv("QDAS_NO_NARROW") ? 0 : 1;
+                pl->tc = tile_config(dt, 1, t.narrow, 1, 1, 1);
+                if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
+                if (t.narrow && !pl->no_fallback) {
+                    t.narrow = 0;
+                    pl->tc = tile_config(dt, 1, 0, 1, 1, 1);
+                    if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
+                }
+                if (!pl->no_fallback) { t.mir = 0; mir = false; }
+            }
+            if (!t.mir) {
+                t.narrow = 0;
+                pl->tc = tile_config(dt, 1, 0, 1, 0, 1);
+                if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
+            }
+        } else {
         // reciprocal mode: first the 128-sample-window configuration (less staging traffic); it is kept only if some footprint
         // has no misfit tile at all -- otherwise the 192-sample configuration
         t.narrow = (sym && dt == QDAS_F32 && !getenv("QDAS_NO_NARROW")) ? 1 : 0;
@@ -787,6 +823,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             t.narrow = 0;
             pl->tc = tile_config(dt, 1, 0);
             if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
+        }
         }
         // Focused transmits whose focal planes cut through the image: the delay flips sign there (src/bf.cu:106-108), so the tiles a plane
         // crosses fit no window and would go to the generic kernel -- with a walking aperture that is half the image.  Second attempt:
@@ -853,6 +890,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             const double keep_frac = pl->misfit_frac;
             const unsigned keep_ntiles = pl->ntiles, keep_cols = pl->tile_cols;
             t.narrow = 2; t.sym = 0;
+            if (t.fold) { t.fold = 0; t.wtab = pl->fold_wtab; }      // (the wide-window configuration is a general-mode kernel on the frame as it is)
             pl->tc = tile_config(dt, 0, 2);
             if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
             if (!(pl->misfit_frac < keep_frac)) {
@@ -900,8 +938,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         k.interp = (z.flag & 7) == 4 ? 1 : (z.flag & 7); k.dtype = dt; k.fmod = t.fmod != 0.0; k.wtab = t.wtab != nullptr; k.sym = t.sym; k.big = t.big;
         const int narrow = (t.sym && dt == QDAS_F32 && t.narrow) ? 1 : (!t.sym && dt == QDAS_F32 && t.narrow == 2) ? 2 : 0;
         const int mirq = (t.sym && t.mir) ? 1 : 0;
-        const Cfg &cg = CFGS[cfg_index(dt, t.sym, t.mir ? 2 : 1, narrow, mirq)];
-        k.mir = t.sym ? 0 : t.mir; k.mirq = mirq; k.mslab = t.mir == 2;
+        const Cfg &cg = CFGS[cfg_index(dt, t.sym, t.mir ? 2 : 1, narrow, mirq, t.fold)];
+        k.mir = t.sym ? 0 : t.mir; k.mirq = mirq; k.mslab = t.mir == 2; k.fold = t.fold;
         k.waves = cg.waves; k.mb = cg.mb; k.w = cg.w; k.nbuf = cg.nbuf;
         k.N = t.N; k.M = t.M; k.T = t.T; k.I1 = t.I1; k.strN = t.strN; k.strM = t.strM;
         k.kindB = t.kindB; k.kindS = t.kindS; k.tzl = t.tz_log2; k.wzl = t.wz_log2; k.ksplit = t.ksplit;
@@ -913,10 +951,10 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // reciprocal mode: the specialised kernel has the registers for 32-transmit stages (half the stages, barriers and per-stage
         // delay evaluations of the prebuilt 16-transmit configuration) whenever the 64 windows of a buffer stay within the 16-bit
         // immediate offsets of the LDS reads (C3: 30.9 -> 29.2 ms)
-        if (t.sym && !mirq && z.M % 32 == 0 && 2 * 32 * k.w * (dt == QDAS_F16 ? 4 : 8) <= 65536 && !getenv("QDAS_JIT_NO_MB32")) k.mb = 32;
+        if (t.sym && !mirq && !t.fold && z.M % 32 == 0 && 2 * 32 * k.w * (dt == QDAS_F16 ? 4 : 8) <= 65536 && !getenv("QDAS_JIT_NO_MB32")) k.mb = 32;
         if (const char *e = getenv("QDAS_JIT_MB")) {
             const int mb = atoi(e);
-            if (mb >= 2 && mb % k.waves == 0 && (!t.sym || z.M % (uint64_t)mb == 0) && !mirq) k.mb = mb;
+            if (mb >= 2 && mb % k.waves == 0 && (!t.sym || t.fold || z.M % (uint64_t)mb == 0) && (!mirq || t.fold)) k.mb = mb;
         }
         if (const char *e = getenv("QDAS_JIT_NBUF")) { const int nb = atoi(e); if (nb >= 2 && nb <= 4) k.nbuf = nb; }
         {
@@ -924,7 +962,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             const size_t off_act = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + 15) & ~(size_t)15;   // Tile::setup
             const size_t off_wst = off_act + (((size_t)t.act_bytes + 15) & ~(size_t)15);
             const size_t hdr = (off_wst + (t.wtab ? (size_t)k.nbuf * (2 * (size_t)k.mb * 8 + 16) : 0) + 15) & ~(size_t)15;
-            size_t body = (size_t)k.nbuf * k.mb * (mirq ? 4 : (t.sym || t.mir) ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
+            size_t body = (size_t)k.nbuf * k.mb * (t.fold ? (mirq ? 2 : 1) : mirq ? 4 : (t.sym || t.mir) ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
             const size_t scratch = 2 * (size_t)k.waves * MX * 4 + 1024;
             if (body < scratch) body = scratch;
             pl->jit_lds = dt == QDAS_F64 ? 0 : hdr + body;       // (fp64 data: the prebuilt configuration's own LDS image, das_tile.hip)
@@ -996,14 +1034,16 @@ extern "C" int qdas_plan_mirror(const qdas_plan *pl) { return pl && pl->kernel =
 
 extern "C" int qdas_plan_reciprocal(const qdas_plan *pl) { return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.sym ? 1 : 0; }
 
+extern "C" int qdas_plan_folded(const qdas_plan *pl) { return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.fold ? 1 : 0; }
+
 extern "C" int qdas_plan_kernel_name(const qdas_plan *pl, char *buf, size_t len) {
     if (!pl || !buf || !len) return fail(QDAS_EINVAL, "null argument");
     const qdas_sizes &z = pl->d.sz;
     const char *dts = z.dtype == QDAS_F64 ? "f64" : (z.dtype == QDAS_F32 ? "f32" : "f16");
     if (pl->kernel == QDAS_KERNEL_TILED) {
         const TileParams &t = pl->tp;
-        snprintf(buf, len, "das_tile_kernel<interp=%d,%s%s%s%s%s%s,mb=%d,W=%d> [%s]", z.flag & 7, dts, t.sym ? ",sym" : "", t.fmod != 0.0 ? ",fmod" : "",
-                 t.wtab ? ",wtab" : "", t.big ? ",big" : "", t.mir ? ",mirror" : ((t.St && !t.syn) ? ",roles swapped" : ""), pl->jit_fn ? pl->jit_mb : pl->tc.mb, pl->tc.window, pl->jit_tag.empty() ? "prebuilt" : pl->jit_tag.c_str());
+        snprintf(buf, len, "das_tile_kernel<interp=%d,%s%s%s%s%s%s%s,mb=%d,W=%d> [%s]", z.flag & 7, dts, t.sym ? ",sym" : "", t.fold ? ",fold" : "", t.fmod != 0.0 ? ",fmod" : "",
+                 (t.wtab || (t.fold && pl->fold_wtab)) ? ",wtab" : "", t.big ? ",big" : "", t.mir ? ",mirror" : ((t.St && !t.syn) ? ",roles swapped" : ""), pl->jit_fn ? pl->jit_mb : pl->tc.mb, pl->tc.window, pl->jit_tag.empty() ? "prebuilt" : pl->jit_tag.c_str());
     } else snprintf(buf, len, "das_generic_kernel<interp=%d,%s>", z.flag & 7, dts);
     return QDAS_OK;
 }
@@ -1031,6 +1071,10 @@ static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s, int n
         TileParams t = pl->tp;
         t.x = x; t.y = y;
         t.nfr = nf; t.x_fstride = x_fstride; t.y_fstride = y_fstride;
+        if (t.fold) {                                   // the reciprocity fold of this frame (fold.hip): one pass over HBM, then the fused kernel on the folded copy
+            HIPCHK(launch_fold(x, pl->fold_buf, pl->fold_wtab, z.T, z.N, t.strN, t.strM, s));
+            t.x = pl->fold_buf;
+        }
         if (t.syn) {                                    // planes are accumulated with atomics: start from zero
             const size_t ds = data_size(z.dtype);        // (only this plan's pixels of every plane: y_ld may span a full-size buffer)
             for (int f = 0; f < nf; ++f)

@@ -24,7 +24,8 @@ template <class C> template <bool CHECK, bool TAILV, bool WZ>
 __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, int bn, float rb, uint32_t cbase, float phB, uint32_t wbase, uint32_t wmask, uint32_t xmask) {
     constexpr int K = C::K, MB = C::MB, WB = C::WB, INTERP = C::INTERP, NHP = C::NHP;
     constexpr bool SYM = C::SYM, FB4 = C::QUAD, FBX = C::FBX, TWO = C::TWO, F32 = C::F32, FMOD = C::FMOD, WTAB = C::WTAB, BF = C::BF;     // (FB4 here: four window sets, two passes)
-    constexpr bool TAIL = !SYM && TAILV, DIAG = SYM && TAILV;
+    // (folded data: any N == M -- the last transmit block may be partial AND holds the diagonal: both rules at once)
+    constexpr bool TAIL = (!SYM || C::FOLD) && TAILV, DIAG = SYM && TAILV;
     // (stage weights: does any transmit pair of this stage hold exactly one zero weight?)
     const bool wmixed = C::WST && WZ && ((((wmask ^ (wmask >> 1)) & 0x55555555u) != 0u) || (SYM && C::WTAB && (((xmask ^ (xmask >> 1)) & 0x55555555u) != 0u)));
     unroll<MB / 2>([&](auto pc) {
@@ -41,6 +42,8 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
         float wr0 = 1.f, wi0 = 0.f, wr1 = 1.f, wi1 = 0.f;
         float xr0 = 1.f, xi0 = 0.f, xr1 = 1.f, xi1 = 0.f;          // reciprocal mode: weights of the MIRROR pairs (receiver m | m+1, transmit n)
         constexpr bool SW = SYM && WTAB;                          // the two traces of an unordered pair carry different weights: separate sums
+        constexpr bool SEP = FBX || SW || C::FOLDQ;               // the second window set has its OWN sums (next frame | its own weights | the mirror image of my pixel)
+        constexpr bool RECIP = SYM && !SW && !C::FOLD;            // ... or holds the reciprocal trace of the same pair: one sum for both
         v4f wv = {1.f, 0.f, 1.f, 0.f}, xv = {1.f, 0.f, 1.f, 0.f};    // stage weights from LDS: {w[n,m], w[n,m+1]} and, reciprocal mode, {w[m,n], w[m+1,n]}
         if constexpr (C::WST) {
             // zero weights: skipped (src/bf.cu:122,126) -- the stage's non-zero masks are uniform, the tests scalar
@@ -64,9 +67,9 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
         unroll<NHP>([&](auto hpc) {
             constexpr int hp = decltype(hpc)::value;
             constexpr int GSET = FB4 ? 2 * hp : 0, HSET = FB4 ? 2 * hp + 1 : 1;       // window sets of the pass
-            v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : &acc1);
+            v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : (C::FOLDQ ? &acc : &acc1));      // (FOLDQ: one accumulator per pixel, as MIRQ -- the 32-transmit stages need the registers)
             // (reciprocal + lateral-mirror mode: ONE accumulator per pixel -- my pixel, its mirror image; the register budget of four window sets)
-            v2f &B0 = *(C::MIRQ ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(C::MIRQ ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : (SYM ? &acc2 : &acc3));
+            v2f &B0 = *((C::MIRQ && !C::FOLD) ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *((C::MIRQ && !C::FOLD) ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : (SYM ? &acc2 : &acc3));
             v2f v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
             v2f u0 = {0.f, 0.f}, u1 = {0.f, 0.f};     // the same two pairs of the second frame (FB2)
             if constexpr (F32) {
@@ -84,24 +87,28 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                 if constexpr (DIAG) {                 // uniform, only in the block that holds the diagonal
                     const v2f z = {0.f, 0.f};
                     if (m < n)      { for (int k = 0; k < K; ++k) g0.s[k] = z; }     // pair (n, m<n): done as the mirror of (m, n)
-                    if (m <= n)     { for (int k = 0; k < K; ++k) h0.s[k] = z; }     // m == n: the trace is its own mirror
-                    if (m + 1 <= n) { for (int k = 0; k < K; ++k) h1.s[k] = z; }
+                    if constexpr (C::FOLD) {                                          // (folded data: the mirror image's trace of the same pair, same rule)
+                        if constexpr (TWO) { if (m < n) { for (int k = 0; k < K; ++k) h0.s[k] = z; } }
+                    } else {
+                        if (m <= n)     { for (int k = 0; k < K; ++k) h0.s[k] = z; }     // m == n: the trace is its own mirror
+                        if (m + 1 <= n) { for (int k = 0; k < K; ++k) h1.s[k] = z; }
+                    }
                 }
                 if constexpr (TAIL) {
                     if (!upper) {                       // odd M: no transmit in the upper half (uniform, rare)
 #pragma unroll
-                        for (int k = 0; k < K; ++k) { g1.s[k] = (v2f){0.f, 0.f}; if constexpr (FBX) h1.s[k] = (v2f){0.f, 0.f}; }
+                        for (int k = 0; k < K; ++k) { g1.s[k] = (v2f){0.f, 0.f}; if constexpr (FBX || C::FOLDQ) h1.s[k] = (v2f){0.f, 0.f}; }
                     }
                 }
-                if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; if constexpr (FBX || SW) { u0 = h0.s[0]; u1 = h1.s[0]; } }
+                if constexpr (K == 1) { v0 = g0.s[0]; v1 = g1.s[0]; if constexpr (SEP) { u0 = h0.s[0]; u1 = h1.s[0]; } }
                 else if constexpr (SPLIT) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) { v0 = w[k].x * g0.s[k] + v0; v1 = w[k].y * g1.s[k] + v1; }
-                    if constexpr (SYM && !SW) {
+                    if constexpr (RECIP) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { v0 = w[k].x * h0.s[k] + v0; v1 = w[k].y * h1.s[k] + v1; }
                     }
-                    if constexpr (FBX || SW) {
+                    if constexpr (SEP) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { u0 = w[k].x * h0.s[k] + u0; u1 = w[k].y * h1.s[k] + u1; }
                     }
@@ -113,7 +120,7 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                         for (int k = 0; k < K; ++k) { B0 = w[k].x * h0.s[k] + B0; B1 = w[k].y * h1.s[k] + B1; }
                     }
                 }
-                if constexpr (SYM && !SW && K == 1) { v0 += h0.s[0]; v1 += h1.s[0]; }
+                if constexpr (RECIP && K == 1) { v0 += h0.s[0]; v1 += h1.s[0]; }
             } else {
                 taps_f16 g0, g1, h0, h1;
                 lds_issue<K, (GSET * MB + 2 * p) * WB>(g0, ad0); lds_issue<K, (GSET * MB + 2 * p + 1) * WB>(g1, ad1);
@@ -122,27 +129,31 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                 if constexpr (TWO) lds_fence2<K>(g0, g1, h0, h1, w); else lds_fence<K>(g0, g1, w);
                 if constexpr (DIAG) {                 // (as for fp32 data above)
                     if (m < n)      { for (int k = 0; k < K; ++k) g0.r[k] = 0u; }
-                    if (m <= n)     { for (int k = 0; k < K; ++k) h0.r[k] = 0u; }
-                    if (m + 1 <= n) { for (int k = 0; k < K; ++k) h1.r[k] = 0u; }
+                    if constexpr (C::FOLD) {
+                        if constexpr (TWO) { if (m < n) { for (int k = 0; k < K; ++k) h0.r[k] = 0u; } }
+                    } else {
+                        if (m <= n)     { for (int k = 0; k < K; ++k) h0.r[k] = 0u; }
+                        if (m + 1 <= n) { for (int k = 0; k < K; ++k) h1.r[k] = 0u; }
+                    }
                 }
                 if constexpr (TAIL) {
                     if (!upper) {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) { g1.r[k] = 0u; if constexpr (FBX) h1.r[k] = 0u; }
+                        for (int k = 0; k < K; ++k) { g1.r[k] = 0u; if constexpr (FBX || C::FOLDQ) h1.r[k] = 0u; }
                     }
                 }
                 if constexpr (K == 1) {
                     v0 = half2_to_v2f(g0.r[0]); v1 = half2_to_v2f(g1.r[0]);
-                    if constexpr (FBX || SW) { u0 = half2_to_v2f(h0.r[0]); u1 = half2_to_v2f(h1.r[0]); }
-                    if constexpr (SYM && !SW) { v0 += half2_to_v2f(h0.r[0]); v1 += half2_to_v2f(h1.r[0]); }
+                    if constexpr (SEP) { u0 = half2_to_v2f(h0.r[0]); u1 = half2_to_v2f(h1.r[0]); }
+                    if constexpr (RECIP) { v0 += half2_to_v2f(h0.r[0]); v1 += half2_to_v2f(h1.r[0]); }
                 } else if constexpr (SPLIT) {
 #pragma unroll
                     for (int k = 0; k < K; ++k) { mix_mac(v0, g0.r[k], w[k].x); mix_mac(v1, g1.r[k], w[k].y); }
-                    if constexpr (SYM && !SW) {
+                    if constexpr (RECIP) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { mix_mac(v0, h0.r[k], w[k].x); mix_mac(v1, h1.r[k], w[k].y); }
                     }
-                    if constexpr (FBX || SW) {
+                    if constexpr (SEP) {
 #pragma unroll
                         for (int k = 0; k < K; ++k) { mix_mac(u0, h0.r[k], w[k].x); mix_mac(u1, h1.r[k], w[k].y); }
                     }
@@ -167,7 +178,7 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                 const float lo1 = tapinfo<INTERP>::LO - 0.5f - (float)ws1, hi1 = (float)(T - K + 1 - ws1) - 0.5f;
                 const bool k0 = (t.x >= lo0) && (t.x < hi0), k1 = (t.y >= lo1) && (t.y < hi1) && upper;
                 v0 = k0 ? v0 : (v2f){0.f, 0.f}; v1 = k1 ? v1 : (v2f){0.f, 0.f};
-                if constexpr (FBX || SW) { u0 = k0 ? u0 : (v2f){0.f, 0.f}; u1 = k1 ? u1 : (v2f){0.f, 0.f}; }
+                if constexpr (SEP) { u0 = k0 ? u0 : (v2f){0.f, 0.f}; u1 = k1 ? u1 : (v2f){0.f, 0.f}; }
             }
             if constexpr (C::BPIX) {                  // pixel x block-element weights; a zero weight never samples its trace (src/bf.cu:122,126)
                 {
@@ -186,11 +197,11 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                 const float c1 = __builtin_amdgcn_cosf(ph.y), s1 = __builtin_amdgcn_sinf(ph.y);
                 if constexpr (!BF && !WTAB) {       // rotate and accumulate in one go: two packed FMAs per sample (acc += v*c; acc += (v.y, v.x)*(-s, s))
                     rot_acc(A0, v0, c0, s0); rot_acc(A1, v1, c1, s1);
-                    if constexpr (FBX) { rot_acc(B0, u0, c0, s0); rot_acc(B1, u1, c1, s1); }
+                    if constexpr (FBX || C::FOLDQ) { rot_acc(B0, u0, c0, s0); rot_acc(B1, u1, c1, s1); }
                 } else {
                     v0 = (v2f){v0.x * c0 - v0.y * s0, v0.x * s0 + v0.y * c0};
                     v1 = (v2f){v1.x * c1 - v1.y * s1, v1.x * s1 + v1.y * c1};
-                    if constexpr (FBX || SW) {
+                    if constexpr (SEP) {
                         u0 = (v2f){u0.x * c0 - u0.y * s0, u0.x * s0 + u0.y * c0};
                         u1 = (v2f){u1.x * c1 - u1.y * s1, u1.x * s1 + u1.y * c1};
                     }
@@ -222,7 +233,7 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                 if constexpr (FBX) { wgt_acc(B0, u0, wr0, wi0); wgt_acc(B1, u1, wr1, wi1); }
                 if constexpr (SW) { wgt_acc(B0, u0, xr0, xi0); wgt_acc(B1, u1, xr1, xi1); }      // mirror pairs, their own weights
             } else if constexpr (FMOD) {              // (accumulated by the rotation above)
-            } else if constexpr (SPLIT || K == 1) { A0 += v0; A0 += v1; if constexpr (FBX) { B0 += u0; B0 += u1; } }
+            } else if constexpr (SPLIT || K == 1) { A0 += v0; A0 += v1; if constexpr (FBX || C::FOLDQ) { B0 += u0; B0 += u1; } }
         });
     });
 }
@@ -326,10 +337,10 @@ template <class C> __device__ __forceinline__ void Tile<C>::pairs_pipelined(floa
         }
         if constexpr (u + 1 < NU) lds_fence2_keep<8>(gd0[u & 1], gd1[u & 1], h0, h1, w);
         else                      lds_fence2_keep<0>(gd0[u & 1], gd1[u & 1], h0, h1, w);
-        v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : &acc1);
+        v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : (C::FOLDQ ? &acc : &acc1));      // (FOLDQ: one accumulator per pixel, as MIRQ -- the 32-transmit stages need the registers)
         // (reciprocal mode: both mirror halves share ONE accumulator -- three in all; with 32-transmit stages the fourth costs the two
         //  registers that would otherwise spill, and measures the same: profiles/r02/exp_prio.txt)
-        v2f &B0 = *(C::MIRQ ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *(C::MIRQ ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : (C::SYM ? &acc2 : &acc3));
+        v2f &B0 = *((C::MIRQ && !C::FOLD) ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *((C::MIRQ && !C::FOLD) ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : (C::SYM ? &acc2 : &acc3));
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             tap_mac(A0, gd0[u & 1], k, w[k].x); tap_mac(A1, gd1[u & 1], k, w[k].y);

@@ -65,6 +65,9 @@ struct TileParams {
     // mir == 2 (QDAS_PLAN_MIRROR_SLAB): the plan's pixels [i_begin, i_begin + i_count) are whole columns of the first half; the mirror images go
     // to y[i_count + (pixel' - (I - i_begin - i_count))] -- slab B behind slab A, natural pixel order.
     int32_t mir;
+    // RECIPROCITY-FOLDED data (das_tile_impl.h TileCfg::FOLD; reciprocal fp32 plans): x points at the plan's folded copy of the frame
+    // (fold.hip: xs[:,n,m] = w[n,m] x[:,n,m] + w[m,n] x[:,m,n], n <= m) and the stage loop walks the upper triangle only; wtab is null
+    int32_t fold;
 };
 
 }  // namespace qdas

@@ -38,6 +38,19 @@ template <class C> __device__ __forceinline__ void Tile<C>::dma_block(uint32_t m
         //   set 0: (rx n, tx m)   set 1: (rx m, tx n)   set 2: (rx N-1-n, tx N-1-m)   set 3: (rx N-1-m, tx N-1-n)
         // -- every block starts at n = 0; sets 0 / 1 walk up by one receiver / transmit stride per stage, sets 2 / 3 walk down
         rsD = make_rs(0, 0);
+        if constexpr (C::FOLD) {
+            // folded data: my pixel's trace (rx n, tx m) -- walking up one receiver stride per stage -- and its mirror image's
+            // (rx N-1-m, tx N-1-n) -- the upper-triangle twin of (N-1-n, N-1-m) --, walking DOWN one transmit stride per stage
+#pragma unroll
+            for (int r = 0; r < C::WPW; ++r) {
+                const uint32_t m = m0 + (uint32_t)wjr(r);
+                const uint32_t mc = m < M ? m : M - 1;
+                const long am = (long)__builtin_amdgcn_readfirstlane(Abase[mc]);
+                qo[2 * r] = (int)(((long)mc * (long)strM + am) * SB);
+                qo[2 * r + 1] = (int)(((long)(N - 1 - mc) * (long)strN + (long)(N - 1) * (long)strM + am) * SB);
+            }
+            return;
+        }
         const uint32_t m = m0 + (uint32_t)wjr(0);
         const uint32_t mc = m < M ? m : M - 1;
         const long am = (long)__builtin_amdgcn_readfirstlane(Abase[mc]);
@@ -57,7 +70,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::dma_block(uint32_t m
         const uint32_t m = m0 + j;
         const int am = __builtin_amdgcn_readfirstlane(Abase[m < M ? m : M - 1]);
         wb[r] = am * SB + (int)((long)j * (long)strM * SB);
-        if constexpr (C::SYM) wb2[r] = am * SB + (int)((long)j * (long)strN * SB);
+        if constexpr (C::SYM && !C::FOLD) wb2[r] = am * SB + (int)((long)j * (long)strN * SB);
     }
     if constexpr (C::FBX) rsM = make_rs(o, (uint64_t)fb * P.x_fstride);   // the same traces of the next frame (four frames: of frame fb)
     if constexpr (C::FB2) {
@@ -79,7 +92,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::dma_block(uint32_t m
             }
         }
     }
-    if constexpr (C::SYM) {                           // mirror traces x[:, rx = m0 + j, tx = n] (reciprocal mode starts every block at n = 0)
+    if constexpr (C::SYM && !C::FOLD) {               // mirror traces x[:, rx = m0 + j, tx = n] (reciprocal mode starts every block at n = 0)
         offM = (uint64_t)m0 * strN * SB;
         rsM = make_rs(offM, 0);
         soff2 = 0;
@@ -91,7 +104,23 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
     constexpr int SB = C::SB, WB = C::WB, PB = C::PB, PCS = C::PCS, NW = C::NW, MB = C::MB;
     const int bs = bn * SB;
     const int l16 = (int)(lane_now() * 16u);          // (byte offset of this lane's 16 bytes in a piece; see Tile::lane_now)
-    if constexpr (C::MIRQ) {
+    if constexpr (C::FOLDQ) {
+#pragma unroll
+        for (int r = 0; r < C::WPW; ++r) {
+            const int j = wjr(r);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int q = 0; q < PCS; ++q) {
+                    lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + k * MB + j) * WB + q * PB));
+                    if (l16 < WB - q * PB)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, dst, 16, l16, qo[2 * r + k] + bs + q * PB, 0, 0);
+                }
+            }
+            qo[2 * r] += (int)((uint32_t)strN * SB); qo[2 * r + 1] -= (int)((uint32_t)strM * SB);
+        }
+        return;
+    } else if constexpr (C::MIRQ) {
         const int j = wjr(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -136,7 +165,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
     if constexpr (C::SYM || C::BIG) {
         if (soff >= DMA_REBASE) { offD += soff; soff = 0; rsD = make_rs(offD, 0); }
     }
-    if constexpr (C::SYM) {                           // same window start A[m] + B[n] in the mirror trace
+    if constexpr (C::SYM && !C::FOLD) {               // same window start A[m] + B[n] in the mirror trace
 #pragma unroll
         for (int r = 0; r < C::WPW; ++r) {
             const int j = __builtin_amdgcn_readfirstlane(wave + C::WAVES * r);

@@ -458,7 +458,8 @@ class UltrasoundSystem:
               prec=None, bsize=None):
         """``b = bfDAS(us, chd, ...)`` (reference ``src/UltrasoundSystem.m:4334-4474``): delay tables + ``bfDASLUT``."""
         import torch
-        dev = (chd.data.device if hasattr(chd.data, "is_cuda") and chd.data.is_cuda else "cuda") if torch.cuda.is_available() else None
+        first = self._chd_array(chd)[0][0]                 # (an array of ChannelData: the tables serve every element, :4429-4463)
+        dev = (first.data.device if hasattr(first.data, "is_cuda") and first.data.is_cuda else "cuda") if torch.cuda.is_available() else None
         tau_rx, tau_tx = self.delay_tables(c0, device=dev)
         return self.bfDASLUT(chd, tau_rx, tau_tx, *apods, apod=apod, fmod=fmod, interp=interp, keep_tx=keep_tx, keep_rx=keep_rx, prec=prec, bsize=bsize)
 

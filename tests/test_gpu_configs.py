@@ -75,8 +75,8 @@ def test_config_lattice_parity(name, step, tol, jit):
     assert ("[jit " in kname) if jit else ("[prebuilt]" in kname), kname       # the kernel that was asked for really ran
     if name in ("c2", "c3"):
         assert plan.fallback_tiles() == 0
-    if name == "c3":                           # the headline kernel: reciprocal AND lateral-mirror mode (four window sets of 16 transmits per stage)
-        assert plan.reciprocal and plan.mirror and ",sym,mirror,mb=16,W=128>" in kname, kname
+    if name == "c3":                           # the headline kernel: reciprocity-folded frame AND lateral-mirror mode (two window sets of 32 transmits per stage)
+        assert plan.reciprocal and plan.folded and plan.mirror and ",sym,fold,mirror,mb=32,W=128>" in kname, kname
     if name in ("c1", "c2"):                   # (symmetric array, sequence and scan; C5's pixel x receiver mask keeps the plain kernel for now)
         assert plan.mirror and ",mirror," in kname, kname
     plan.close()

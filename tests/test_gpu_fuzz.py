@@ -158,7 +158,12 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
         assert "[jit " in plan.kernel_name(), (c, plan.kernel_name())
     if c.get("headline") and not c["t0vec"]:                            # (a per-transmit t0 is not reciprocal: general kernel)
         # (mirror-symmetric draws -- no weights, one t0, the whole image -- run reciprocal + lateral-mirror mode: four sets of 16 transmits)
-        assert plan.reciprocal and ((",mirror,mb=16," if plan.mirror else ",mb=32,") in plan.kernel_name()), (c, plan.kernel_name())
+        # (fp32: the reciprocity-folded frame -- 32-transmit stages with or without the mirror mode (16 when its tiles need 192-sample windows);
+        #  fp16 data keep both traces: four window sets of 16 transmits in mirror mode, 32-transmit stages otherwise)
+        if c["prec"] == "single":
+            assert plan.reciprocal and plan.folded and ",fold" in plan.kernel_name(), (c, plan.kernel_name())
+        else:
+            assert plan.reciprocal and not plan.folded and ((",mirror,mb=16," if plan.mirror else ",mb=32,") in plan.kernel_name()), (c, plan.kernel_name())
     xc = _colmajor(_cast_data(xt, prob.prec, plan.device))
     y = plan.execute_colmajor(xc, F)                                    # (F, oM, oN, count)
     torch.cuda.synchronize()

@@ -139,12 +139,17 @@ def test_mirror_mode_through_das_spec_and_frames():
     (64, "lanczos3", "single", {"ks": "4"}), (32, "cubic", "single", {"T": 330}), (32, "linear", "halfT", {"T": 330, "ks": "2"}),
     (32, "lanczos3", "single", {"fmod": 2.5e6}), (32, "cubic", "single", {"wtab": True}), (48, "lanczos3", "single", {"fmod": 2.5e6, "wtab": True}),
     (32, "cubic", "halfT", {"wtab": True, "fmod": 2.5e6}), (32, "lanczos3", "single", {"wtab": True, "T": 330}), (16, "nearest", "halfT", {"fmod": 2.5e6}),
+    (32, "lanczos3", "single", {"wtab": "asym"}), (24, "cubic", "single", {}), (7, "lanczos3", "single", {"I2": 12}), (40, "linear", "single", {"wtab": "asym", "fmod": 2.5e6, "ks": "2"}),
+    (33, "cubic", "single", {"I2": 21}), (24, "linear", "single", {"T": 330}),
 ])
 def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_path, monkeypatch):
     """A full-synthetic-aperture acquisition (transmit elements == receive elements) on a mirror-symmetric array and scan: FOUR traces share
-    one delay -- x[:,n,m], x[:,m,n] for a pixel and x[:,N-1-n,N-1-m], x[:,N-1-m,N-1-n] for its mirror image (launch configurations 15 / 16:
-    four window sets per stage).  Against the float64 oracle, the reciprocal-only plan and the plain plan; diagonal blocks, split apertures,
-    records that end inside the image, the centre column of an odd column count."""
+    one delay -- x[:,n,m], x[:,m,n] for a pixel and x[:,N-1-n,N-1-m], x[:,N-1-m,N-1-n] for its mirror image.  fp32 data run on the
+    RECIPROCITY-FOLDED frame by default (fold.hip: the two traces of an unordered pair added once per frame, weights applied on the way; launch
+    configurations 17 / 18 / 19: two window sets in mirror mode, one without; any N == M, tables that need no symmetry of their own), with
+    ``fold=False`` and for fp16 data on launch configurations 15 / 16 (four window sets per stage).  Against the float64 oracle, the unfolded
+    plans, the reciprocal-only plans and the plain plan; diagonal blocks, partial last blocks, split apertures, records that end inside the
+    image, the centre column of an odd column count."""
     import torch
     from oracle import das_oracle as O
     from qups_amd import DasPlan, build_problem, parse_options
@@ -167,20 +172,33 @@ def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_pa
         wn = q(np.hanning(N + 2)[1:-1]).reshape(1, 1, 1, N, 1)
         wm = q(0.25 + 0.75 * np.hanning(N + 2)[1:-1]).reshape(1, 1, 1, 1, N)
         wm[..., 2] = 0.0; wm[..., N - 3] = 0.0
-        apod = [wn, wm * (1 + 0.5j) if prec == "single" else wm]
+        if extra["wtab"] == "asym":                    # no symmetry at all: a ramp on receive, a dead transmit on one side only, a full N x M array on top
+            rng = np.random.default_rng(N)
+            wn = q(np.linspace(0.3, 1.0, N)).reshape(1, 1, 1, N, 1)
+            wm = q(0.25 + 0.75 * np.hanning(N + 2)[1:-1]).reshape(1, 1, 1, 1, N); wm[..., 1] = 0.0
+            apod = [wn, wm * (1 + 0.5j), q(rng.uniform(0.5, 1.0, (1, 1, 1, N, N)))]
+        else:
+            apod = [wn, wm * (1 + 0.5j) if prec == "single" else wm]
         for a in apod:
             va += ["apod", a]
     opts = parse_options(xt, va)
     prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], opts)
     ys, names = [], []
-    for kw in (dict(), dict(mirror=False), dict(mirror=False, reciprocal=False)):
+    asym = extra.get("wtab") == "asym"
+    old_ok = N % 16 == 0                               # (the unfolded reciprocal kernels need whole 16-transmit blocks)
+    for kw in (dict(), dict(fold=False), dict(mirror=False), dict(mirror=False, fold=False), dict(mirror=False, reciprocal=False)):
         with DasPlan(prob, kernel=2, jit=jit, **kw) as plan:
             y = plan.feval(xt)
             ys.append((torch.view_as_real(y).float().cpu().numpy().view(np.complex64)[..., 0] if prec == "halfT" else y.cpu().numpy()).reshape(-1))
-            names.append((plan.kernel_name(), plan.reciprocal, plan.mirror))
+            names.append((plan.kernel_name(), plan.reciprocal, plan.mirror, plan.folded))
             assert plan.fallback_tiles() == 0
     assert names[0][1] and names[0][2] and ",sym" in names[0][0] and ",mirror" in names[0][0], names
-    assert names[1][1] and not names[1][2] and not names[2][1] and not names[2][2], names
+    assert names[0][3] == (prec == "single") and (",fold" in names[0][0]) == (prec == "single"), names
+    assert not names[1][3] and not names[3][3] and not names[4][3] and names[2][3] == (prec == "single"), names
+    if old_ok:
+        assert names[1][1] and names[3][1], names
+        assert names[1][2] == (not asym), names         # (unfolded: the mirror mode needs a mirror-symmetric weight table)
+    assert names[2][1] and not names[2][2] and not names[3][2] and not names[4][1] and not names[4][2], names
     assert ("[jit " in names[0][0]) == jit
     ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xin, case["t0"], case["fs"], cinv_f32(case["c"]),
                      VS=case["VS"], DV=case["DV"], interp=interp, tpose=tpose, fmod=fmod, apod=apod).reshape(-1, order="F")
@@ -192,7 +210,8 @@ def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_pa
     for y, nm in zip(ys, names):
         assert rel_err(y, ref) <= tol, nm
     loose = 1e-2 if interp == "nearest" else 1e-4 if prec == "halfT" else 2e-5 if fmod else 5e-6
-    assert rel_err(ys[0], ys[1]) <= loose and rel_err(ys[0], ys[2]) <= loose
+    for k in range(1, 5):
+        assert rel_err(ys[0], ys[k]) <= loose, (k, names[k])
 
 
 @pytest.mark.parametrize("prec,jit", [("halfT", False), ("halfT", True), ("single", True)], ids=["f16-prebuilt", "f16-jit", "f32-jit"])
