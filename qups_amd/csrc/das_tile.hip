@@ -76,14 +76,14 @@ TileConfig tile_config(int dtype, int sym, int narrow, int fb, int mirq, int fol
     c.mb = g.mb;
     c.window = g.w;
     c.threads = g.waves * 64;
-    const int sets = (fold && sym && dtype == 1) ? (mirq ? 2 : 1) : (mirq && sym) ? 4 : (sym || fb == 2) ? 2 : 1;      // window sets per buffer
+    const int sets = (fold && sym && dtype == 1) ? (mirq ? 2 : 1) * (fb == 2 ? 2 : 1) : (mirq && sym) ? 4 : (sym || fb == 2) ? 2 : 1;      // window sets per buffer
     c.lds_bytes = (size_t)g.nbuf * g.mb * sets * g.w * (dtype == 2 ? 4 : dtype == 0 ? 16 : 8);
     return c;
 }
 
-size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow, int pixw, int wtab, int mirq, int fold) {
-    const Cfg &g = CFGS[cfg_index(dtype, sym, 1, narrow, mirq, fold)];
-    const TileConfig c = tile_config(dtype, sym, narrow, 1, mirq, fold);
+size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow, int pixw, int wtab, int mirq, int fold, int fb) {
+    const Cfg &g = CFGS[cfg_index(dtype, sym, fold ? fb : 1, narrow, mirq, fold)];
+    const TileConfig c = tile_config(dtype, sym, narrow, fold ? fb : 1, mirq, fold);
     const size_t MX = std::min<size_t>(M > N ? M : N, QDAS_PROLOGUE_CHUNK);
     // (geometry tables in the plan's real type: 32-byte receiver records and 8-byte table entries for fp64 data -- Tile::setup)
     const size_t off_act = (((((2 * M + N) * 4 + 15) & ~(size_t)15) + (dtype == 0 ? 32 : 16) * N + 7 * M * (dtype == 0 ? 8 : 4)) + 15) & ~(size_t)15;
@@ -116,14 +116,14 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     const int fold = (sym && P.fold && dtype == 1) ? 1 : 0;   // reciprocity-folded data (launch configurations 17 / 18 / 19)
     if (P.fold && (!fold || P.wtab)) return hipErrorInvalidValue;
     const int mirq = (sym && P.mir && (!P.probe || fold)) ? 1 : 0;   // reciprocal + lateral-mirror mode: four window sets (launch configurations 15 / 16; folded data: two)
-    const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M, narrow, P.act_bytes ? 1 : 0, P.wtab ? 1 : 0, mirq, fold);    // (the two-frame configurations have the same LDS image)
+    const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M, narrow, P.act_bytes ? 1 : 0, P.wtab ? 1 : 0, mirq, fold, (fold && P.nfr == 2 && !P.probe) ? 2 : 1);   // (two frames of folded data: launch configurations 20 / 21)    // (the two-frame configurations have the same LDS image)
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
     if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part && !P.bf))) return hipErrorInvalidValue;
     // frames per launch; lateral-mirror plans (one frame) run the two-window-set instantiations as well
     const int nfr = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
-    if (P.mir && !P.probe && (nfr != 1 || P.big || P.bf || P.lut_tx || P.syn || ((P.apix || P.gen_kind) && ((dtype != 2 && !jit) || sym || P.stage_shift || P.bpix)) || (!sym && narrow) || (sym && dtype == 1 && !narrow && !fold))) return hipErrorInvalidValue;
+    if (P.mir && !P.probe && ((nfr != 1 && !(fold && nfr == 2)) || P.big || P.bf || P.lut_tx || P.syn || ((P.apix || P.gen_kind) && ((dtype != 2 && !jit) || sym || P.stage_shift || P.bpix)) || (!sym && narrow) || (sym && dtype == 1 && !narrow && !fold))) return hipErrorInvalidValue;
     const int nf = (P.mir && !P.probe && !sym) ? 2 : nfr;
-    if ((nf != 1 && nf != 2 && nf != 4) || (nf > 1 && (sym || P.big))) return hipErrorInvalidValue;
+    if ((nf != 1 && nf != 2 && nf != 4) || (nf > 1 && ((sym && !(fold && nf == 2)) || P.big))) return hipErrorInvalidValue;     // (folded data: two frames may share a launch)
     if (P.lut_tx && (sym || nf != 1 || (dtype != 1 && dtype != 2) || (P.syn && dtype != 1))) return hipErrorInvalidValue;
     if (jit && (P.probe || nfr != 1 || P.lut_tx || P.bf)) return hipErrorInvalidValue;
     if (P.bf && (sym || nf != 1 || dtype != 1 || P.lut_tx || P.big || P.apix || P.gen_kind)) return hipErrorInvalidValue;

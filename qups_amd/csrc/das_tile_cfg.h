@@ -24,14 +24,15 @@ struct Cfg { int waves, mb, w, nbuf, psz, bpc; };
 // cfg 17 / 18 / 19: reciprocity-FOLDED fp32 data (TileCfg::FOLD, fold.hip) -- with the lateral-mirror mode: TWO window sets of 32 one-KiB windows
 //         (cfg 17; the LDS image of cfg 15) or of 16 192-sample windows (cfg 18: tiles that do not fit 128 samples); without it: ONE set of 32
 //         192-sample windows (cfg 19: the LDS image of cfg 0)
-static constexpr Cfg CFGS[20] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1},
+// cfg 20 / 21: two FRAMES of folded data per launch -- mirror mode: four window sets of 16 one-KiB windows (the LDS image of cfg 15); without: two sets of 16 x 192
+static constexpr Cfg CFGS[22] = {{16, 32, 192, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1},
                                 {16, 16, 192, 2, 16, 1}, {16, 16, 384, 2, 16, 1}, {16, 8, 192, 2, 16, 1}, {16, 8, 384, 2, 16, 1},
                                 {16, 16, 128, 2, 16, 1}, {16, 16, 256, 2, 16, 1}, {16, 32, 192, 2, 16, 1}, {16, 32, 192, 2, 16, 1}, {16, 32, 384, 2, 16, 1}, {16, 32, 192, 2, 16, 1},
                                 {16, 16, 192, 2, 16, 1}, {16, 16, 384, 2, 16, 1}, {16, 16, 128, 2, 16, 1}, {16, 16, 256, 2, 16, 1},
-                                {16, 32, 128, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 192, 2, 16, 1}};
+                                {16, 32, 128, 2, 16, 1}, {16, 16, 192, 2, 16, 1}, {16, 32, 192, 2, 16, 1}, {16, 16, 128, 2, 16, 1}, {16, 16, 192, 2, 16, 1}};
 // fb: frames per launch (1 | 2 | 4)
 // narrow: window variant -- 1: reciprocal mode with 128-sample windows (cfg 7); 2: general mode, fp32 data, 384-sample windows (cfg 14)
 // mirq: reciprocal + lateral-mirror mode (cfg 15 / 16)
 // fold: reciprocity-folded fp32 data (cfg 17 / 18 with mirq: narrow / 192-sample windows; cfg 19 without)
-static inline int cfg_index(int dtype, int sym, int fb = 1, int narrow = 0, int mirq = 0, int fold = 0) { return (fold && sym && dtype == 1) ? (mirq ? (narrow ? 17 : 18) : 19) : (mirq && sym && dtype != 0) ? (dtype == 2 ? 16 : 15) : dtype == 0 ? 13 : (!sym && narrow == 2 && dtype == 1 && fb == 1) ? 14 : sym ? (dtype == 2 ? 8 : (narrow ? 7 : 1)) : (fb == 4 ? (dtype == 2 ? 6 : 5) : (fb == 2 ? (dtype == 2 ? 4 : 3) : (dtype == 2 ? 2 : 0))); }
+static inline int cfg_index(int dtype, int sym, int fb = 1, int narrow = 0, int mirq = 0, int fold = 0) { return (fold && sym && dtype == 1) ? (fb == 2 ? (mirq ? 20 : 21) : mirq ? (narrow ? 17 : 18) : 19) : (mirq && sym && dtype != 0) ? (dtype == 2 ? 16 : 15) : dtype == 0 ? 13 : (!sym && narrow == 2 && dtype == 1 && fb == 1) ? 14 : sym ? (dtype == 2 ? 8 : (narrow ? 7 : 1)) : (fb == 4 ? (dtype == 2 ? 6 : 5) : (fb == 2 ? (dtype == 2 ? 4 : 3) : (dtype == 2 ? 2 : 0))); }
 }  // namespace qdas

@@ -80,7 +80,9 @@ struct TileCfg {
     static constexpr bool MIRQ = MIRQ_;
     static constexpr bool FOLD = FOLD_;              // reciprocity-folded data (above): upper triangle only, no reciprocal window set
     static constexpr bool FOLDQ = FOLD_ && MIRQ_;    // ... in lateral-mirror mode: window set 0 = my pixel's trace, set 1 = its mirror image's
-    static constexpr bool QUAD = FB4 || (MIRQ && !FOLD);   // four window sets: the pair loop makes two passes over one index / weight evaluation
+    // (folded data, TWO FRAMES per launch: FOLD && FB2 -- window sets {frame 0, frame 1}; with the mirror mode {f0 mine, f0 image, f1 mine, f1 image}:
+    //  one tap index and one set of weights for two folded traces of two frames, i.e. for EIGHT products of the reference's loop)
+    static constexpr bool QUAD = FB4 || (MIRQ && !FOLD) || (FOLDQ && FB2);   // four window sets: the pair loop makes two passes over one index / weight evaluation
     static constexpr bool TWO = (SYM && !FOLD) || FBX || FOLDQ;   // (at least) two window sets per stage: direct + (reciprocal | next frame | mirror image)
     static constexpr int NHP = QUAD ? 2 : 1;         // passes of the pair loop: one per frame pair (MIRQ: my pixel, its mirror image)
     static constexpr int NFR = FB4 ? 4 : (FB2 ? 2 : 1);   // frames per launch
@@ -117,11 +119,12 @@ struct TileCfg {
     static constexpr int PB = 1024;                  // bytes per full DMA piece (one wave-instruction x 16 B)
     static constexpr int PCS = (WB + PB - 1) / PB;   // pieces per window; the last one may use fewer lanes
     static constexpr int NDMA = WPW * PCS * (QUAD ? (FB4 ? 2 : 4) : TWO ? 2 : 1);    // DMA instructions per wave and stage
-    static_assert(!(SYM && FBX) && !(FB2 && FB4), "reciprocal mode runs one frame per launch");
+    static_assert(!(SYM && FBX && !FOLD_) && !(FB2 && FB4) && !(FOLD_ && FB4), "reciprocal mode runs one frame per launch (folded data: one or two)");
     static_assert(!MIRQ || FOLD || (SYM && MB_ == WAVES_ && 4 * MB_ * W_ * (int)sizeof(ST_) <= 65536), "reciprocal + lateral-mirror mode: one window per wave and set, immediate LDS offsets");
-    static_assert(!FOLD || (SYM && !WTAB_ && !FBX && !BIG && !LUT && !BF_ && sizeof(ST_) == 8), "folded data: reciprocal plans, fp32, weights folded into the data, one frame per launch");
-    static_assert(!FOLDQ || (MB_ % WAVES_ == 0 && 2 * MB_ * W_ * (int)sizeof(ST_) <= 65536), "folded data + lateral-mirror mode: two window sets within the immediate LDS offsets");
+    static_assert(!FOLD || (SYM && !WTAB_ && !BIG && !LUT && !BF_ && sizeof(ST_) == 8), "folded data: reciprocal plans, fp32, weights folded into the data");
+    static_assert(!FOLDQ || (MB_ % WAVES_ == 0 && (FB2 ? 4 : 2) * MB_ * W_ * (int)sizeof(ST_) <= 65536), "folded data + lateral-mirror mode: two (two frames: four) window sets within the immediate LDS offsets");
     static_assert(!BIG || (!SYM && !FBX), "the re-basing general kernel runs one frame per launch");
+    static_assert(!(FOLDQ && FB2) || MB_ == WAVES_, "folded data + mirror mode, two frames: one window per wave and set");
     static_assert(!LUT || (!SYM && !FBX && !BIG), "table-driven delays: general mode, one frame per launch");
     static_assert(!BF || (!SYM && !FBX && !BIG && !LUT && sizeof(ST_) == 8), "'BF': general mode, fp32 data, one frame per launch");
     static_assert(!F64 || (!SYM && !FBX && !BIG && !LUT && !BF), "fp64 data: the 'DAS' sum (optionally remodulated / with a weight table), one frame per launch");
@@ -233,7 +236,8 @@ template <class C> struct Tile {
     __device__ __forceinline__ void pairs_pipelined(float rb, uint32_t cbase);
     template <bool CHECK, bool TAILV> __device__ __forceinline__ void pairs_f64(uint32_t n, uint32_t m0, int bn, double rb, uint32_t cbase);
     __device__ __forceinline__ void frame_sums(v2f (&Sf)[4]) const {
-        if constexpr (C::MIRQ) { Sf[0] = acc + acc1; Sf[1] = acc2 + acc3; }       // my pixel, its mirror image
+        if constexpr (C::FOLDQ && C::FB2) { Sf[0] = acc; Sf[1] = acc1; Sf[2] = acc2; Sf[3] = acc3; }   // {frame 0: my pixel, its image; frame 1: my pixel, its image}
+        else if constexpr (C::MIRQ) { Sf[0] = acc + acc1; Sf[1] = acc2 + acc3; }       // my pixel, its mirror image
         else if constexpr (C::FB4) { Sf[0] = acc; Sf[1] = acc1; Sf[2] = acc2; Sf[3] = acc3; }
         else if constexpr (C::FB2) { Sf[0] = acc + acc1; Sf[1] = acc2 + acc3; }
         else Sf[0] = (acc + acc1) + (acc2 + acc3);
@@ -812,6 +816,24 @@ template <class C> __device__ __forceinline__ void Tile<C>::epilogue() {
         frame_sums(res);
         uint32_t po = pofs;
         if constexpr (C::SYM) { uint32_t i1, col; po = locate(i1, col, false); }      // (nothing in the reciprocal stage loop needs it: not kept alive)
+        if constexpr (C::FOLDQ && C::FB2) {           // two frames of folded data in mirror mode: res = {f0 mine, f0 image, f1 mine, f1 image}
+            uint32_t i1, col;
+            const uint32_t po2 = locate(i1, col, false, true);
+            const uint32_t pos[2] = {po, po2};
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    uint32_t q = pos[h];
+                    if (q == NOT_MINE) continue;
+                    asm volatile("" : "+v"(q));
+                    const v2f r = res[2 * f + h];
+                    if (S > 1) { float2 *base = P.part + ((size_t)split * 2 + f) * (P.i_count << (QSPEC(MIR, P.mir) == 2 ? 1 : 0)); asm volatile("" : "+s"(base)); base[q] = make_float2(r.x, r.y); }
+                    else { ST *base = (ST *)P.y + (size_t)f * P.y_fstride; asm volatile("" : "+s"(base)); st(base, (size_t)q, cplx<float>{r.x, r.y}); }
+                }
+            }
+            return;
+        }
         if constexpr (C::FB2 || C::MIRQ) {
             if (C::MIRQ || QSPEC(MIR, P.mir)) {          // lateral-mirror modes: the second sum belongs to the mirror image of my pixel
                 uint32_t i1, col;
@@ -874,9 +896,9 @@ das_tile_kernel(const TileParams P) {
 template <int INTERP, typename ST, int CI>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
     constexpr Cfg G = CFGS[CI];
-    constexpr bool FOLD = (CI == 17 || CI == 18 || CI == 19);       // folded data: with the lateral-mirror mode (narrow / wide windows), without
-    constexpr bool MIRQ = (CI == 15 || CI == 16 || CI == 17 || CI == 18);
-    constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8 || MIRQ || FOLD), FB2 = (CI == 3 || CI == 4), FB4 = (CI == 5 || CI == 6), BIG = (CI == 9), LUT = (CI == 10 || CI == 11), BFM = (CI == 12);
+    constexpr bool FOLD = (CI >= 17 && CI <= 21);       // folded data: with the lateral-mirror mode (narrow / wide windows), without; 20 / 21: two frames per launch
+    constexpr bool MIRQ = (CI == 15 || CI == 16 || CI == 17 || CI == 18 || CI == 20);
+    constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8 || MIRQ || FOLD), FB2 = (CI == 3 || CI == 4 || CI == 20 || CI == 21), FB4 = (CI == 5 || CI == 6), BIG = (CI == 9), LUT = (CI == 10 || CI == 11), BFM = (CI == 12);
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
     const dim3 g(ntiles * (P.probe ? 1u : P.ksplit)), b(G.waves * 64);
 #define QDAS_LAUNCH(FM, WT) QDAS_LAUNCH_P(FM, WT, false)

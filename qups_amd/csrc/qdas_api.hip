@@ -95,6 +95,8 @@ struct qdas_plan {
     const void *fold_wtab = nullptr;
     bool fb2_ok = false;                      // frames of a sequence may share launches, 4 or 2 at a time (decided at plan creation)
     bool fb4_off = false;                     // ... but at most pairwise (QDAS_NO_FB4)
+    bool fold2_ok = false;                    // folded data: two frames may share a launch
+    void *fold_buf2 = nullptr;                // ... and the folded copy of the second one (made at the first stream of frames)
     // A lateral-mirror plan runs one frame per launch (its second window set is taken).  For a STREAM of frames four frames per launch share
     // more (index + weights of four traces instead of two): such plans keep a twin without the mirror mode, made at the first stream.
     qdas_plan *frames_twin = nullptr;
@@ -938,7 +940,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         k.interp = (z.flag & 7) == 4 ? 1 : (z.flag & 7); k.dtype = dt; k.fmod = t.fmod != 0.0; k.wtab = t.wtab != nullptr; k.sym = t.sym; k.big = t.big;
         const int narrow = (t.sym && dt == QDAS_F32 && t.narrow) ? 1 : (!t.sym && dt == QDAS_F32 && t.narrow == 2) ? 2 : 0;
         const int mirq = (t.sym && t.mir) ? 1 : 0;
-        const Cfg &cg = CFGS[cfg_index(dt, t.sym, t.mir ? 2 : 1, narrow, mirq, t.fold)];
+        const Cfg &cg = CFGS[cfg_index(dt, t.sym, t.fold ? 1 : (t.mir ? 2 : 1), narrow, mirq, t.fold)];      // (fb = 2 selects the two-window-set configuration of a general-mode mirror plan; folded plans: one frame)
         k.mir = t.sym ? 0 : t.mir; k.mirq = mirq; k.mslab = t.mir == 2; k.fold = t.fold;
         k.waves = cg.waves; k.mb = cg.mb; k.w = cg.w; k.nbuf = cg.nbuf;
         k.N = t.N; k.M = t.M; k.T = t.T; k.I1 = t.I1; k.strN = t.strN; k.strM = t.strM;
@@ -985,6 +987,10 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         }
     }
     pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->tp.mir && !pl->tp.stage_shift && pl->tp.narrow != 2 && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
+    // folded data: TWO frames per launch (launch configurations 20 / 21 -- tap index and weights serve two folded traces of two frames, in mirror mode four);
+    // the mirror mode needs the 128-sample windows for it (four window sets), and the plan a second folded copy of a frame (allocated at the first stream)
+    pl->fold2_ok = pl->kernel == QDAS_KERNEL_TILED && pl->tp.fold && (!pl->tp.mir || pl->tp.narrow) && !pl->tp.syn && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2")
+                   && tile_lds_bytes(dt, 1, z.N, z.M, pl->tp.narrow, 0, 0, pl->tp.mir ? 1 : 0, 1, 2) <= tile_lds_limit(1);
     // four frames per launch: not for fp32 plans with remodulation, a weight table or a pixel x receiver weight (das_tile_impl.h launch_tile_i)
     pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr
                   || (dt == QDAS_F32 && pl->kernel == QDAS_KERNEL_TILED && (pl->tp.fmod != 0.0 || pl->tp.wtab || pl->tp.apix || pl->tp.gen_kind));
@@ -1074,6 +1080,11 @@ static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s, int n
         if (t.fold) {                                   // the reciprocity fold of this frame (fold.hip): one pass over HBM, then the fused kernel on the folded copy
             HIPCHK(launch_fold(x, pl->fold_buf, pl->fold_wtab, z.T, z.N, t.strN, t.strM, s));
             t.x = pl->fold_buf;
+            if (nf == 2) {                              // (two frames per launch: the second frame's folded copy; the kernel reads it x_fstride BYTES after the first)
+                if (!pl->fold_buf2) return fail(QDAS_EINVAL, "internal: no second fold buffer");
+                HIPCHK(launch_fold((const char *)x + x_fstride, pl->fold_buf2, pl->fold_wtab, z.T, z.N, t.strN, t.strM, s));
+                t.x_fstride = (uint64_t)((intptr_t)pl->fold_buf2 - (intptr_t)pl->fold_buf);      // (modulo 2^64: the kernel adds it to the base pointer)
+            }
         }
         if (t.syn) {                                    // planes are accumulated with atomics: start from zero
             const size_t ds = data_size(z.dtype);        // (only this plan's pixels of every plane: y_ld may span a full-size buffer)
@@ -1157,7 +1168,19 @@ extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, u
         }
     }
     // frame pairs share one launch (device-resident data, tiled kernel, not the reciprocal mode; QDAS_NO_FB2 disables)
-    const bool pairs_ok = pl->fb2_ok && x_stride * ds < (1ull << 40);
+    bool pairs_ok = pl->fb2_ok && x_stride * ds < (1ull << 40);
+    if (pl->fold2_ok && F >= 2) {                       // folded data: frame pairs share a launch; the second folded copy is made now (once)
+        if (!pl->fold_buf2) {
+            const size_t fb = (size_t)z.T * z.N * z.M * 8;
+            void *p2 = nullptr;
+            if (hipMalloc(&p2, fb) == hipSuccess) {
+                pl->owned.push_back(p2);
+                if (hipMemsetAsync(p2, 0, fb, s) == hipSuccess) pl->fold_buf2 = p2;
+            } else (void)hipGetLastError();
+            if (!pl->fold_buf2) pl->fold2_ok = false;   // (no memory for it: one frame per launch)
+        }
+        pairs_ok = pl->fold_buf2 != nullptr;
+    }
     if (pl->d.mem == QDAS_MEM_HOST && F >= 2) {         // host frames: upload f+1 on the copy stream while f is beamformed
         if (!pl->copy_stream) {
             int rc;
@@ -1194,7 +1217,7 @@ extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, u
         const char *xf = (const char *)x + f * x_stride * ds;
         char *yf = (char *)y + f * y_stride * ds;
         if (pairs_ok && f + 1 < F) {                    // four (else two) frames share a launch
-            const int nf = (f + 3 < F && !pl->fb4_off) ? 4 : 2;
+            const int nf = (f + 3 < F && !pl->fb4_off && !pl->tp.fold) ? 4 : 2;
             int rc = run_frame(pl, xf, yf, s, nf, x_stride * ds, y_stride);
             if (rc) return rc;
             f += nf - 1;

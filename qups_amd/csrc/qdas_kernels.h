@@ -36,7 +36,7 @@ hipError_t launch_delays(const GenericParams &P, int dtype, void *tau, double ci
 // ---- tiled kernel (das_tile_impl.h); parameter block in tile_params.h
 struct TileConfig { int waves; int mb; int window; size_t lds_bytes; int threads; };
 TileConfig tile_config(int dtype, int sym, int narrow = 0, int fb = 1, int mirq = 0, int fold = 0);   // fb = 2: the two-window-set configuration of the general mode (frames sharing a launch; lateral-mirror mode)
-size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow = 0, int pixw = 0, int wtab = 0, int mirq = 0, int fold = 0);   // dynamic LDS of one workgroup (pixw: a pixel x receiver weight -> room for the stage list)
+size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow = 0, int pixw = 0, int wtab = 0, int mirq = 0, int fold = 0, int fb = 1);   // dynamic LDS of one workgroup (pixw: a pixel x receiver weight -> room for the stage list)
 size_t tile_lds_limit(int sym);                               // LDS budget of one workgroup in that configuration
 // jit: plan-specialised kernel (jit.hip) to launch instead of the prebuilt instantiation; one frame per launch only
 hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s, hipFunction_t jit = nullptr, size_t jit_lds = 0);

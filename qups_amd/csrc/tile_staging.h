@@ -38,6 +38,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::dma_block(uint32_t m
         //   set 0: (rx n, tx m)   set 1: (rx m, tx n)   set 2: (rx N-1-n, tx N-1-m)   set 3: (rx N-1-m, tx N-1-n)
         // -- every block starts at n = 0; sets 0 / 1 walk up by one receiver / transmit stride per stage, sets 2 / 3 walk down
         rsD = make_rs(0, 0);
+        if constexpr (C::FOLD && C::FB2) rsM = make_rs(0, P.x_fstride);      // the folded copy of the second frame: the same offsets
         if constexpr (C::FOLD) {
             // folded data: my pixel's trace (rx n, tx m) -- walking up one receiver stride per stage -- and its mirror image's
             // (rx N-1-m, tx N-1-n) -- the upper-triangle twin of (N-1-n, N-1-m) --, walking DOWN one transmit stride per stage
@@ -109,12 +110,15 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
         for (int r = 0; r < C::WPW; ++r) {
             const int j = wjr(r);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int f = 0; f < (C::FB2 ? 2 : 1); ++f) {           // (two frames: window sets {f0 mine, f0 image, f1 mine, f1 image})
 #pragma unroll
-                for (int q = 0; q < PCS; ++q) {
-                    lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + k * MB + j) * WB + q * PB));
-                    if (l16 < WB - q * PB)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, dst, 16, l16, qo[2 * r + k] + bs + q * PB, 0, 0);
+                for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                    for (int q = 0; q < PCS; ++q) {
+                        lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + (2 * f + k) * MB + j) * WB + q * PB));
+                        if (l16 < WB - q * PB)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(f ? rsM : rsD, dst, 16, l16, qo[2 * r + k] + bs + q * PB, 0, 0);
+                    }
                 }
             }
             qo[2 * r] += (int)((uint32_t)strN * SB); qo[2 * r + 1] -= (int)((uint32_t)strM * SB);

@@ -426,3 +426,47 @@ def test_mirror_mode_with_a_symmetric_weight_table(seq, prec, cplx, jit, tmp_pat
     tol = 2e-3 if prec == "halfT" else 2e-5
     assert rel_err(ys[0], ref) <= tol and rel_err(ys[1], ref) <= tol
     assert rel_err(ys[0], ys[1]) <= (1e-4 if prec == "halfT" else 2e-6)
+
+
+@pytest.mark.parametrize("N,interp,extra", [(32, "lanczos3", {}), (32, "cubic", {"mirror": False}), (48, "linear", {"fmod": 2.5e6}), (40, "lanczos3", {"wtab": True, "ks": "2"}),
+                                            (16, "linear", {"mirror": False, "wtab": True}), (32, "cubic", {"T": 330}), (64, "cubic_dev", {"I2": 37, "ks": "2"})])
+def test_streams_of_frames_through_folded_plans(N, interp, extra, monkeypatch):
+    """Reciprocal fp32 plans on the folded frame: a stream of frames shares launches PAIRWISE (launch configurations 20 / 21: window sets {frame 0,
+    frame 1}, in mirror mode {f0 mine, f0 image, f1 mine, f1 image} -- one tap index and one set of weights for up to eight products of the
+    reference's loop); an odd last frame runs alone.  Every frame against the float64 oracle and against the same plan fed one frame at a time."""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd.das_spec import _colmajor
+    if "ks" in extra:
+        monkeypatch.setenv("QDAS_KSPLIT", extra["ks"])
+    geo = dict(pitch=0.15e-3, zlim=(14e-3, 24e-3), xspan=4e-3) if N > 32 else {}
+    case = make_case(seq="FSA", interp=interp, seed=90 + N, N=N, I1=150, I2=extra.get("I2", 40), T=extra.get("T"), **geo)
+    rng = np.random.default_rng(N)
+    F = 5
+    xs = np.stack([case["x"]] + [(rng.standard_normal(case["x"].shape) + 1j * rng.standard_normal(case["x"].shape)).astype(np.complex64) * 0.05 for _ in range(F - 1)], axis=3)
+    fmod = float(np.float32(extra.get("fmod", 0.0)))
+    va = list(case["opt"]) + ["interp", interp, "modulation", fmod]
+    apod = []
+    if extra.get("wtab"):
+        apod = [np.linspace(0.3, 1.0, N).astype(np.float32).astype(np.float64).reshape(1, 1, 1, N, 1),
+                (np.float32(1.0) * rng.uniform(0.5, 1.0, (1, 1, 1, N, N))).astype(np.float32).astype(np.float64) * (1 + 0.25j)]
+        apod[1][..., 3, :] = 0.0
+        for a in apod:
+            va += ["apod", a]
+    xt = torch.from_numpy(xs)
+    opts = parse_options(xt, va)
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], opts)
+    with DasPlan(prob, kernel=2, mirror=extra.get("mirror", True)) as plan:
+        assert plan.folded and plan.mirror == extra.get("mirror", True), plan.kernel_name()
+        xc = _colmajor(xt.cuda())                                     # (F, M, N, T)
+        y = plan.execute_colmajor(xc, F).cpu().numpy().reshape(F, -1)
+        one = np.stack([plan.execute_colmajor(xc[f:f + 1].contiguous(), 1).cpu().numpy().reshape(-1) for f in range(F)])
+        assert plan.fallback_tiles() == 0
+    tol = 1e-2 if interp == "nearest" else 2e-4 if fmod else 2e-5
+    for f in range(F):
+        ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs[..., f], case["t0"], case["fs"], cinv_f32(case["c"]),
+                         VS=case["VS"], DV=case["DV"], interp=interp, fmod=fmod, apod=apod).reshape(-1, order="F")
+        assert rel_err(y[f], ref) <= tol, (f, rel_err(y[f], ref))
+        assert rel_err(y[f], one[f]) <= (1e-2 if interp == "nearest" else 1e-5), f       # (another kernel: fp32 re-association only)
+    assert np.array_equal(y[F - 1], one[F - 1])                       # the odd last frame ran alone: the same kernel, bit for bit

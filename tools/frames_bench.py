@@ -20,14 +20,18 @@ if w["prec"] == "halfT":
     from qups_amd.das_spec import _cast_data
     xc = _cast_data(xc, "halfT", dev).contiguous()
 prob = build_problem("DAS", w["Pi"], w["Pr"], w["Pv"], w["Nv"], (T, N, M, F), w["t0"], w["fs"], w["c0"], opts)
-for mode in ("pairs", "pairs, hiprtc plan", "single", "single, hiprtc plan"):
+modes = ("pairs", "pairs, hiprtc plan", "single", "single, hiprtc plan")
+if name == "c3":          # reciprocal: the folded frame (two frames per launch / one) and, for reference, the unfolded reciprocal + mirror kernel
+    modes += ("single, hiprtc plan, no fold",)
+for mode in modes:
     os.environ.pop("QDAS_NO_FB2", None)
     if mode.startswith("single"):
         os.environ["QDAS_NO_FB2"] = "1"
-    plan = DasPlan(prob, device=dev, jit="hiprtc" in mode)
+    plan = DasPlan(prob, device=dev, jit="hiprtc" in mode, fold="no fold" not in mode)
     plan.set_timing(True)
     ms = []
     for _ in range(4):
         plan.execute_colmajor(xc, F)
         ms.append(plan.last_kernel_ms())
-    print(f"{name} F={F} {mode:20s}: {np.mean(ms[1:]) / F:8.3f} ms/frame  ({w['I1'] * w['I2'] * F / np.mean(ms[1:]) / 1e3:8.1f} Mpixel/s)  kernel {plan.kernel}")
+    print(f"{name} F={F} {mode:28s}: {np.mean(ms[1:]) / F:8.3f} ms/frame  ({w['I1'] * w['I2'] * F / np.mean(ms[1:]) / 1e3:8.1f} Mpixel/s)  {plan.kernel_name()}")
+    plan.close()
