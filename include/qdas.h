@@ -307,6 +307,13 @@ typedef struct qdas_wsinterpd_desc {
     double   omega;           /* imag(omega)                                                        */
     double   extrap;          /* value of out-of-record samples                                     */
     const void *t, *w, *x;    /* w may be NULL                                                      */
+    /* extension (round 4): the layout of y.  ystride all 0: dense column-major over the kept dimensions (the reference's output).  Else element
+       strides per dimension (summed dimensions ignored): lets a row-major / arbitrarily strided x be sampled IN PLACE into a y of the same layout
+       -- together with x_tstride / xstride no layout pass is needed.  `lane_dim`: the kept dimension the lanes of a wave run along (choose the
+       one along which x -- or, where x broadcasts, t -- is contiguous); -1: the first kept dimension.                                         */
+    int64_t  ystride[8];
+    int32_t  lane_dim;
+    int32_t  reserved;
 } qdas_wsinterpd_desc;
 int qdas_wsinterpd(const qdas_wsinterpd_desc *d, void *y, void *stream);
 

@@ -63,7 +63,7 @@ class WsDesc(C.Structure):
     _fields_ = [("T", C.c_uint64), ("x_tstride", C.c_uint64), ("ndim", C.c_int32), ("flag", C.c_int32), ("dtype", C.c_int32),
                 ("w_real", C.c_int32), ("size", C.c_uint64 * 8), ("tstride", C.c_int64 * 8), ("xstride", C.c_int64 * 8),
                 ("wstride", C.c_int64 * 8), ("sum", C.c_uint8 * 8), ("omega", C.c_double), ("extrap", C.c_double),
-                ("t", C.c_void_p), ("w", C.c_void_p), ("x", C.c_void_p)]
+                ("t", C.c_void_p), ("w", C.c_void_p), ("x", C.c_void_p), ("ystride", C.c_int64 * 8), ("lane_dim", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GreensDesc(C.Structure):

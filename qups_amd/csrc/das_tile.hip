@@ -4,13 +4,11 @@
 // pass -DQDAS_ABL / -DQDAS_PROF: tools/ablate.sh).
 #ifdef QDAS_UNITY
 #include "das_tile_f32.hip"
-#include "das_tile_sym.hip"
 #include "das_tile_f16.hip"
 #include "das_tile_f32x2.hip"
 #include "das_tile_f16x2.hip"
 #include "das_tile_f32x4.hip"
 #include "das_tile_f16x4.hip"
-#include "das_tile_symw.hip"
 #include "das_tile_symh.hip"
 #include "das_tile_f32big.hip"
 #include "das_tile_lut.hip"
@@ -18,7 +16,6 @@
 #include "das_tile_bf.hip"
 #include "das_tile_f64.hip"
 #include "das_tile_f32w.hip"
-#include "das_tile_symq.hip"
 #include "das_tile_symqh.hip"
 #include "das_tile_fold.hip"
 #else
@@ -31,13 +28,11 @@
 namespace qdas {
 
 hipError_t launch_tile_f32(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
-hipError_t launch_tile_sym(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f16(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f32x2(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f16x2(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f32x4(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f16x4(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
-hipError_t launch_tile_symw(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_symh(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f32big(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_lut(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
@@ -45,7 +40,6 @@ hipError_t launch_tile_luth(const TileParams &P, unsigned ntiles, size_t lds, hi
 hipError_t launch_tile_bf(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f64(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_f32w(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
-hipError_t launch_tile_symq(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_symqh(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 hipError_t launch_tile_fold(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s);
 
@@ -113,10 +107,16 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     if (narrow == 2 && (P.lut_tx || P.bf || P.big || (!P.probe && P.nfr > 1))) return hipErrorInvalidValue;
     if (P.bpix && (narrow != 2 || P.wtab || P.fmod != 0.0 || P.syn || sym)) return hipErrorInvalidValue;      // (TileCfg::BPIX instantiations only)
     if (P.act_bytes != 0 && P.act_bytes != 8 * (P.N + 1)) return hipErrorInvalidValue;
-    const int fold = (sym && P.fold && dtype == 1) ? 1 : 0;   // reciprocity-folded data (launch configurations 17 / 18 / 19)
+    // fp32 reciprocal plans WITHOUT the fold (QDAS_PLAN_NO_FOLD) exist as hiprtc builds only (round 4: their prebuilt instantiations -- launch
+    // configurations 1 / 7 / 15 -- were pruned); the plan-time probes of every fp32 reciprocal plan run the probe kernels of the folded
+    // configurations (the same prologue; 128- or 192-sample windows)
+    const int fold = (sym && P.fold && dtype == 1) ? 1 : 0;   // reciprocity-folded data (launch configurations 17 ... 21)
     if (P.fold && (!fold || P.wtab)) return hipErrorInvalidValue;
-    const int mirq = (sym && P.mir && (!P.probe || fold)) ? 1 : 0;   // reciprocal + lateral-mirror mode: four window sets (launch configurations 15 / 16; folded data: two)
-    const size_t lds = tile_lds_bytes(dtype, sym, P.N, P.M, narrow, P.act_bytes ? 1 : 0, P.wtab ? 1 : 0, mirq, fold, (fold && P.nfr == 2 && !P.probe) ? 2 : 1);   // (two frames of folded data: launch configurations 20 / 21)    // (the two-frame configurations have the same LDS image)
+    const bool probe_f32sym = P.probe && sym && dtype == 1;
+    if (sym && dtype == 1 && !fold && !jit && !P.probe) return hipErrorInvalidValue;
+    const int mirq = (sym && P.mir && !P.probe) ? 1 : 0;   // reciprocal + lateral-mirror mode: four window sets (launch configurations 15 / 16; folded data: two)
+    const size_t lds = probe_f32sym ? tile_lds_bytes(dtype, 1, P.N, P.M, narrow, 0, 0, narrow ? 1 : 0, 1)
+                                    : tile_lds_bytes(dtype, sym, P.N, P.M, narrow, P.act_bytes ? 1 : 0, P.wtab ? 1 : 0, mirq, fold, (fold && P.nfr == 2) ? 2 : 1);   // (two frames of folded data: launch configurations 20 / 21)
     if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
     if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part && !P.bf))) return hipErrorInvalidValue;
     // frames per launch; lateral-mirror plans (one frame) run the two-window-set instantiations as well
@@ -127,7 +127,7 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
     if (P.lut_tx && (sym || nf != 1 || (dtype != 1 && dtype != 2) || (P.syn && dtype != 1))) return hipErrorInvalidValue;
     if (jit && (P.probe || nfr != 1 || P.lut_tx || P.bf)) return hipErrorInvalidValue;
     if (P.bf && (sym || nf != 1 || dtype != 1 || P.lut_tx || P.big || P.apix || P.gen_kind)) return hipErrorInvalidValue;
-    hipError_t e = jit ? jit_launch(jit, P, ntiles * P.ksplit, (unsigned)CFGS[cfg_index(dtype, sym, 1, narrow, mirq, fold)].waves * 64u, jit_lds ? jit_lds : lds, s) : fold ? launch_tile_fold(P, ntiles, lds, s) : P.lut_tx ? (dtype == 2 ? launch_tile_luth(P, ntiles, lds, s) : launch_tile_lut(P, ntiles, lds, s)) : mirq ? (dtype == 2 ? launch_tile_symqh(P, ntiles, lds, s) : launch_tile_symq(P, ntiles, lds, s)) : sym ? (dtype == 2 ? launch_tile_symh(P, ntiles, lds, s) : narrow ? launch_tile_symw(P, ntiles, lds, s) : launch_tile_sym(P, ntiles, lds, s))
+    hipError_t e = jit ? jit_launch(jit, P, ntiles * P.ksplit, (unsigned)CFGS[cfg_index(dtype, sym, 1, narrow, mirq, fold)].waves * 64u, jit_lds ? jit_lds : lds, s) : (fold || probe_f32sym) ? launch_tile_fold(P, ntiles, lds, s) : P.lut_tx ? (dtype == 2 ? launch_tile_luth(P, ntiles, lds, s) : launch_tile_lut(P, ntiles, lds, s)) : (mirq && dtype == 2) ? launch_tile_symqh(P, ntiles, lds, s) : (sym && dtype == 2) ? launch_tile_symh(P, ntiles, lds, s) : sym ? hipErrorInvalidValue
                  : nf == 4 ? (dtype == 2 ? launch_tile_f16x4(P, ntiles, lds, s) : launch_tile_f32x4(P, ntiles, lds, s))
                  : nf == 2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))
                            : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : narrow == 2 ? launch_tile_f32w(P, ntiles, lds, s) : (P.bf && !P.probe) ? launch_tile_bf(P, ntiles, lds, s) : (P.big && !P.probe) ? launch_tile_f32big(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));

@@ -16,6 +16,7 @@ template <int CI> static hipError_t launch_fold_ci(const TileParams &P, unsigned
 }
 
 hipError_t launch_tile_fold(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
+    if (P.probe) return P.narrow ? launch_fold_ci<17>(P, ntiles, lds, s) : launch_fold_ci<19>(P, ntiles, lds, s);     // (window-fit probes: 128- / 192-sample windows)
     if (P.nfr == 2 && !P.probe) return P.mir ? (P.narrow ? launch_fold_ci<20>(P, ntiles, lds, s) : hipErrorInvalidValue) : launch_fold_ci<21>(P, ntiles, lds, s);
     if (P.nfr > 2) return hipErrorInvalidValue;
     if (!P.mir) return launch_fold_ci<19>(P, ntiles, lds, s);

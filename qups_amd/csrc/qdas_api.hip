@@ -542,6 +542,9 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         rfold = sym && dt == QDAS_F32 && z.N >= 2 && z.N <= 65535 && !(desc->plan_flags & QDAS_PLAN_NO_FOLD) && !getenv("QDAS_NO_FOLD")
                && tile_lds_bytes(dt, 1, z.N, z.M, 0, 0, 0, 0, 1) <= tile_lds_limit(1);
         if (sym && !rfold && (z.M % tile_config(dt, 1).mb != 0 || tile_lds_bytes(dt, 1, z.N, z.M) > tile_lds_limit(1))) sym = 0;
+        // fp32 data without the fold (QDAS_PLAN_NO_FOLD): that reciprocal mode exists as a plan-specialised (hiprtc) build only -- its prebuilt
+        // instantiations were pruned in round 4 --; without QDAS_PLAN_JIT such a plan runs the general kernels
+        if (sym && !rfold && dt == QDAS_F32 && !((desc->plan_flags & QDAS_PLAN_JIT) && !getenv("QDAS_NO_JIT"))) sym = 0;
     }
     // Roles of the two apertures (das_tile_impl.h): a stage = one STAGE element x a block of 32 BLOCK elements.  'DAS' / 'SYN': stage =
     // receiver, block = transmits; 'MUL': swapped.  The full sum may run either way, and runs swapped when that gives fewer, fuller
@@ -975,9 +978,10 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; }
         else {
             pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel";
-            if (dt == QDAS_F32 && t.mir && !t.sym && (t.apix || t.gen_kind)) {      // exists only as a hiprtc build: the same plan without the mirror mode
+            const bool unfolded = dt == QDAS_F32 && t.sym && !t.fold;                  // (likewise: the general kernels then)
+            if ((dt == QDAS_F32 && t.mir && !t.sym && (t.apix || t.gen_kind)) || unfolded) {      // exists only as a hiprtc build: the same plan without the mirror mode
                 qdas_desc d2 = *desc;
-                d2.plan_flags |= QDAS_PLAN_NO_MIRROR;
+                d2.plan_flags |= unfolded ? QDAS_PLAN_NO_RECIPROCAL : QDAS_PLAN_NO_MIRROR;
                 const std::string keep = g_err;
                 delete pl;
                 const int rc2 = qdas_plan_create(out, &d2);
@@ -1472,6 +1476,42 @@ extern "C" int qdas_wsinterpd(const qdas_wsinterpd_desc *d, void *y, void *strea
         if (d->size[k] > 0xffffffffull) return fail(QDAS_EUNSUPPORTED, "wsinterpd: a summed dimension of more than 2^32 - 1 elements");
         p.ssz[p.nsd] = (uint32_t)d->size[k]; p.sts[p.nsd] = d->tstride[k]; p.sxs[p.nsd] = d->xstride[k]; p.sws[p.nsd] = d->wstride[k];
         ++p.nsd;
+    }
+    // kept dimensions in decode order: lane_dim first (default: the first kept dimension with more than one element), then the others ascending;
+    // y dense column-major over the kept dimensions unless the caller gave strides
+    {
+        bool ygiven = false;
+        for (int k = 0; k < d->ndim; ++k) if (d->ystride[k] != 0) ygiven = true;
+        int64_t acc = 1;
+        for (int k = 0; k < d->ndim; ++k) {
+            if (p.sum[k]) { p.yst[k] = 0; continue; }
+            p.yst[k] = ygiven ? d->ystride[k] : acc;
+            acc *= (int64_t)d->size[k];
+        }
+        int lane = d->lane_dim;
+        if (lane < 0 || lane >= d->ndim || p.sum[lane]) {
+            lane = -1;
+            for (int k = 0; k < d->ndim && lane < 0; ++k) if (!p.sum[k] && d->size[k] > 1) lane = k;
+            if (lane < 0) for (int k = 0; k < d->ndim && lane < 0; ++k) if (!p.sum[k]) lane = k;
+        }
+        if (lane < 0) { lane = 0; }                     // (every dimension summed: one output; dimension 0 then has size 1 in the output)
+        p.nkd = 0; p.n_rest = 1;
+        if (!p.sum[lane]) p.kord[p.nkd++] = lane;
+        for (int k = 0; k < d->ndim; ++k) if (!p.sum[k] && k != lane) { p.kord[p.nkd++] = k; p.n_rest *= d->size[k]; }
+        if (p.nkd == 0) {                               // all summed: a single output -- decode nothing (a pseudo dimension of size 1)
+            p.kord[0] = 0; p.nkd = 1;
+            static_assert(sizeof(p.size) / sizeof(p.size[0]) == 8, "");
+            // dimension 0 is summed here: give the lane loop a size-1 view of it through a spare slot
+            if (d->ndim < 8) { p.size[d->ndim] = 1; p.tst[d->ndim] = p.xst[d->ndim] = p.wst[d->ndim] = 0; p.yst[d->ndim] = 0; p.kord[0] = d->ndim; }
+            else return fail(QDAS_EUNSUPPORTED, "wsinterpd: all 8 dimensions summed");
+        }
+        p.n_lane = p.size[p.kord[0]];
+        p.lane2 = 0;
+        if (p.nkd >= 2 && p.n_lane < 128) {             // a short fastest dimension: the lanes also cover the next one
+            p.lane2 = 1;
+            p.n_lane *= p.size[p.kord[1]];
+            p.n_rest /= p.size[p.kord[1]] ? p.size[p.kord[1]] : 1;
+        }
     }
     if (p.n_out == 0) return QDAS_OK;
     if (p.n_out >= (1ull << 39)) return fail(QDAS_EUNSUPPORTED, "wsinterpd: too many outputs for one launch");

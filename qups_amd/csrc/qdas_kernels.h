@@ -66,6 +66,11 @@ struct WsParams {
     int64_t tst[8], xst[8], wst[8];  // element strides of t / x (trace base) / w per dimension; 0 = broadcast
     uint8_t sum[8];                  // 1: the dimension is summed
     uint64_t n_out, n_sum;           // product of the kept / summed sizes
+    // the kept dimensions in decode order (kord[0]: the one the lanes run along), the product of the sizes of kord[1..], and y's element strides
+    int32_t nkd, kord[8];
+    uint64_t n_rest, n_lane;         // (n_lane: outputs the lanes of grid.x cover -- size[kord[0]], times size[kord[1]] with lane2)
+    int32_t lane2;
+    int64_t yst[8];
     // the summed dimensions alone, compacted (fastest first): the kernel walks them like an odometer -- uniform scalar adds per term
     // instead of a 64-bit divide + modulo per dimension and term
     int32_t nsd;

@@ -48,19 +48,30 @@ __global__ void __launch_bounds__(256) wsinterpd_kernel(const WsParams P) {
     using R  = typename TY::real;
     using ST = typename TY::store;
     using AR = typename TY::apod_real_t;
-    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= P.n_out) return;
     const R *__restrict__ t = (const R *)P.t;
     const ST *__restrict__ x = (const ST *)P.x;
-    // kept dimensions: decode the output index (dense, column-major over the kept dimensions)
-    int64_t tb = 0, xb = 0, wb = 0;
+    // kept dimensions, in the order WsParams::kord lists them (fastest first: the host puts the dimension along which x is contiguous there, so
+    // that the lanes of a wave read neighbouring samples and write neighbouring outputs -- y has its own strides, WsParams::yst).
+    // Lanes run along kord[0] (no per-lane division); the other kept dimensions are decoded from the block id: uniform, scalar arithmetic.
+    int64_t tb = 0, xb = 0, wb = 0, yo = 0;
     {
-        uint64_t q = o;
-        for (int d = 0; d < P.nd; ++d) {
-            if (P.sum[d]) continue;
-            const uint64_t k = q % P.size[d];
+        const int d0 = P.kord[0];
+        uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i0 >= P.n_lane) return;
+        if (P.lane2) {                                   // a short fastest dimension: the lanes cover kord[0] x kord[1] (one division per lane)
+            const int d1 = P.kord[1];
+            const uint64_t i1 = i0 / P.size[d0];
+            i0 -= i1 * P.size[d0];
+            tb = (int64_t)i1 * P.tst[d1]; xb = (int64_t)i1 * P.xst[d1]; wb = (int64_t)i1 * P.wst[d1]; yo = (int64_t)i1 * P.yst[d1];
+        }
+        tb += (int64_t)i0 * P.tst[d0]; xb += (int64_t)i0 * P.xst[d0]; wb += (int64_t)i0 * P.wst[d0]; yo += (int64_t)i0 * P.yst[d0];
+        uint64_t q = (uint64_t)blockIdx.y + (uint64_t)gridDim.y * blockIdx.z;
+        if (q >= P.n_rest) return;
+        for (int k = P.lane2 ? 2 : 1; k < P.nkd; ++k) {
+            const int d = P.kord[k];
+            const uint64_t idx = q % P.size[d];
             q /= P.size[d];
-            tb += (int64_t)k * P.tst[d]; xb += (int64_t)k * P.xst[d]; wb += (int64_t)k * P.wst[d];
+            tb += (int64_t)idx * P.tst[d]; xb += (int64_t)idx * P.xst[d]; wb += (int64_t)idx * P.wst[d]; yo += (int64_t)idx * P.yst[d];
         }
     }
     const R omega = (R)P.omega;
@@ -103,11 +114,14 @@ __global__ void __launch_bounds__(256) wsinterpd_kernel(const WsParams P) {
         }
         acc.x += v.x; acc.y += v.y;
     }
-    st((ST *)P.y, (size_t)o, acc);
+    st((ST *)P.y, (size_t)yo, acc);
 }
 
 template <typename TY> static hipError_t launch_ws_t(const WsParams &P, hipStream_t s) {
-    const dim3 g((unsigned)((P.n_out + 255) / 256)), b(256);
+    // grid: x = blocks along the fastest kept dimension, (y, z) = the other kept dimensions flattened
+    const uint64_t n0 = P.n_lane, gy = P.n_rest < 65535 ? (P.n_rest ? P.n_rest : 1) : 65535, gz = (P.n_rest + gy - 1) / gy;
+    if (gz > 65535 || (n0 + 255) / 256 > 0x7fffffffull) return hipErrorInvalidValue;
+    const dim3 g((unsigned)((n0 + 255) / 256), (unsigned)gy, (unsigned)(gz ? gz : 1)), b(256);
     switch (P.flag & 7) {
         case 0: wsinterpd_kernel<0, TY><<<g, b, 0, s>>>(P); break;
         case 1: case 4: wsinterpd_kernel<1, TY><<<g, b, 0, s>>>(P); break;

@@ -298,12 +298,30 @@ def wsinterpd(x, t, dim=1, w=1, sdim=None, interp="linear", extrapval=float("nan
     xd = _cast_data(xt, prec, dev)
     rt = _real_dtype(prec)
     td = tt.to(dev).to(rt)
-    xc, tc = _colmajor(xd), _colmajor(td)
+    # x and t are sampled IN PLACE, whatever their memory order (round 3 made a column-major copy of both first -- a read + write pass over the
+    # record that cost as much as the sampling itself): the kernel takes element strides per dimension, y is laid out like x (dimension order of
+    # x's memory) and the lanes of a wave run along the dimension in which x is contiguous.
+    def _dense(a):
+        """strides usable as they are: no two elements of `a` alias (expanded / overlapping views are copied)"""
+        if a.numel() == 0:
+            return True
+        sz_st = sorted(((a.shape[k], abs(a.stride(k))) for k in range(a.ndim) if a.shape[k] > 1), key=lambda v: v[1])
+        need = 1
+        for n, st in sz_st:
+            if st < need:
+                return False
+            need = st * (n - 1) + need
+        return all(a.stride(k) >= 0 for k in range(a.ndim))
+    if not _dense(xd):
+        xd = xd.contiguous()
+    if not _dense(td):
+        td = td.contiguous()
+    xc, tc = xd, td
     d = _lib.WsDesc()
-    d.T, d.x_tstride, d.ndim, d.flag, d.dtype = T, 1, nd, _lib.INTERP_FLAGS[interp], _PREC[prec]
-    xs_ = _col_strides(xt.shape)
+    d.T, d.x_tstride, d.ndim, d.flag, d.dtype = T, (xd.stride(0) if T > 1 else 1), nd, _lib.INTERP_FLAGS[interp], _PREC[prec]
+    xs_ = [0 if xd.shape[k] == 1 else xd.stride(k) for k in range(nd)]
     xs_[0] = 0
-    ts_ = _col_strides(tt.shape)
+    ts_ = [0 if td.shape[k] == 1 else td.stride(k) for k in range(nd)]
     for k in range(nd):
         d.size[k], d.tstride[k], d.xstride[k] = size[k], ts_[k], xs_[k]
         d.sum[k] = 1 if (k + 1) in sd else 0
@@ -323,10 +341,21 @@ def wsinterpd(x, t, dim=1, w=1, sdim=None, interp="linear", extrapval=float("nan
     d.t, d.x = tc.data_ptr(), xc.data_ptr()
     osz = [1 if (k + 1) in sd else size[k] for k in range(nd)]
     from .das_spec import _data_dtype
-    y = torch.empty(tuple(reversed(osz)), dtype=_data_dtype(prec), device=dev)
+    # y: the dimension order of x's memory (fastest first: smallest x stride; dimensions x broadcasts over ordered by t's stride, then by index);
+    # dimension 0 -- the sampled one -- takes the place of x's time dimension
+    key = lambda k: (xd.stride(0) if k == 0 else xs_[k]) if (k == 0 or xs_[k]) else (1 << 62) + (ts_[k] if ts_[k] else (1 << 61) + k)
+    order = sorted(range(nd), key=key)
+    yst, acc = [0] * nd, 1
+    for k in order:
+        yst[k] = acc
+        acc *= osz[k]
+    y = torch.empty_strided(tuple(osz), tuple(yst), dtype=_data_dtype(prec), device=dev)
+    kept = [k for k in order if osz[k] > 1 and (k + 1) not in sd]
+    for k in range(nd):
+        d.ystride[k] = yst[k]
+    d.lane_dim = kept[0] if kept else -1
     with torch.cuda.device(dev):
         _lib.check(L.qdas_wsinterpd(C.byref(d), C.c_void_p(y.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-    y = y.permute(*reversed(range(nd)))
     return sw(y)
 
 
