@@ -1497,7 +1497,17 @@ extern "C" int qdas_wsinterpd(const qdas_wsinterpd_desc *d, void *y, void *strea
         if (lane < 0) { lane = 0; }                     // (every dimension summed: one output; dimension 0 then has size 1 in the output)
         p.nkd = 0; p.n_rest = 1;
         if (!p.sum[lane]) p.kord[p.nkd++] = lane;
+        // (the others by ascending memory stride of x -- dimension 0: the sample stride; where x broadcasts: of t --, so that a second lane dimension and
+        //  consecutive workgroups stay close in memory)
+        auto skey = [&](int k) -> uint64_t {
+            const uint64_t xs = k == 0 ? p.x_tstride : (uint64_t)(d->xstride[k] < 0 ? -d->xstride[k] : d->xstride[k]);
+            if (xs && (k == 0 || d->size[k] > 1)) return xs;
+            const uint64_t ts = (uint64_t)(d->tstride[k] < 0 ? -d->tstride[k] : d->tstride[k]);
+            return (1ull << 62) + (ts ? ts : (1ull << 61) + (uint64_t)k);
+        };
         for (int k = 0; k < d->ndim; ++k) if (!p.sum[k] && k != lane) { p.kord[p.nkd++] = k; p.n_rest *= d->size[k]; }
+        for (int a = 1; a < p.nkd; ++a)                 // (insertion sort of at most 7 entries)
+            for (int b = a; b > 1 && skey(p.kord[b]) < skey(p.kord[b - 1]); --b) std::swap(p.kord[b], p.kord[b - 1]);
         if (p.nkd == 0) {                               // all summed: a single output -- decode nothing (a pseudo dimension of size 1)
             p.kord[0] = 0; p.nkd = 1;
             static_assert(sizeof(p.size) / sizeof(p.size[0]) == 8, "");
@@ -1507,11 +1517,24 @@ extern "C" int qdas_wsinterpd(const qdas_wsinterpd_desc *d, void *y, void *strea
         }
         p.n_lane = p.size[p.kord[0]];
         p.lane2 = 0;
-        if (p.nkd >= 2 && p.n_lane < 128) {             // a short fastest dimension: the lanes also cover the next one
+        if (p.nkd >= 2 && (p.n_lane < 2048 || p.n_lane % 256 != 0) && p.n_lane * p.size[p.kord[1]] < (1ull << 31)) {   // a short (or ragged) fastest dimension: the lanes also cover the next one -- full workgroups
             p.lane2 = 1;
             p.n_lane *= p.size[p.kord[1]];
             p.n_rest /= p.size[p.kord[1]] ? p.size[p.kord[1]] : 1;
         }
+    }
+    {   // the lean streaming kernel (wsinterpd.hip interpd_stream_kernel): plain sampling, dimension 0 among the block-level dimensions, 32-bit extents
+        bool ok = !p.any_sum && !d->w && d->omega == 0.0 && p.nkd >= 2 && !getenv("QDAS_WS_GENERAL");
+        const int nl = p.lane2 ? 2 : 1;
+        for (int k = 0; k < nl && ok; ++k) if (p.kord[k] == 0) ok = false;
+        if (ok && p.nkd <= nl) ok = false;
+        auto ext = [&](const int64_t *st) { uint64_t e = 0; for (int k = 0; k < d->ndim; ++k) if (d->size[k] > 1) e += (uint64_t)(st[k] < 0 ? -st[k] : st[k]) * (d->size[k] - 1); return e; };
+        if (ok) {
+            for (int k = 0; k < d->ndim; ++k) if (p.tst[k] < 0 || p.xst[k] < 0 || p.yst[k] < 0) ok = false;
+            const uint64_t ex = ext(p.xst) + (uint64_t)p.x_tstride * (d->T ? d->T - 1 : 0);
+            if (ext(p.tst) >= (1ull << 31) || ex >= (1ull << 31) || ext(p.yst) >= (1ull << 31) || d->size[0] >= (1ull << 31) || d->T >= (1ull << 24)) ok = false;
+        }
+        p.stream_ok = ok ? 1 : 0;
     }
     if (p.n_out == 0) return QDAS_OK;
     if (p.n_out >= (1ull << 39)) return fail(QDAS_EUNSUPPORTED, "wsinterpd: too many outputs for one launch");

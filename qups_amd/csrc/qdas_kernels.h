@@ -70,6 +70,7 @@ struct WsParams {
     int32_t nkd, kord[8];
     uint64_t n_rest, n_lane;         // (n_lane: outputs the lanes of grid.x cover -- size[kord[0]], times size[kord[1]] with lane2)
     int32_t lane2;
+    int32_t stream_ok;               // the lean streaming kernel applies (no sums / weights / rotation, 32-bit extents, dimension 0 outside the lane dimensions)
     int64_t yst[8];
     // the summed dimensions alone, compacted (fastest first): the kernel walks them like an odometer -- uniform scalar adds per term
     // instead of a 64-bit divide + modulo per dimension and term

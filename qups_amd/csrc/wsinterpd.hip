@@ -60,8 +60,8 @@ __global__ void __launch_bounds__(256) wsinterpd_kernel(const WsParams P) {
         if (i0 >= P.n_lane) return;
         if (P.lane2) {                                   // a short fastest dimension: the lanes cover kord[0] x kord[1] (one division per lane)
             const int d1 = P.kord[1];
-            const uint64_t i1 = i0 / P.size[d0];
-            i0 -= i1 * P.size[d0];
+            const uint32_t s0 = (uint32_t)P.size[d0], i1 = (uint32_t)i0 / s0;      // (n_lane < 2^31: 32-bit division)
+            i0 -= (uint64_t)i1 * s0;
             tb = (int64_t)i1 * P.tst[d1]; xb = (int64_t)i1 * P.xst[d1]; wb = (int64_t)i1 * P.wst[d1]; yo = (int64_t)i1 * P.yst[d1];
         }
         tb += (int64_t)i0 * P.tst[d0]; xb += (int64_t)i0 * P.xst[d0]; wb += (int64_t)i0 * P.wst[d0]; yo += (int64_t)i0 * P.yst[d0];
@@ -117,7 +117,89 @@ __global__ void __launch_bounds__(256) wsinterpd_kernel(const WsParams P) {
     st((ST *)P.y, (size_t)yo, acc);
 }
 
+// ---- the streaming case: no summed dimension, no weights, no phase rotation (kern/interpd.m; ChannelData.sample without apodization; rectifyt0), every
+// extent below 2^31 elements, dimension 0 (the sampled one) NOT among the lane dimensions.  Lean on purpose -- the general kernel above spends ~210 VALU
+// instructions per output on 64-bit index arithmetic and the (empty) odometer, as much time as the memory system needs for the data --:
+//   * 32-bit lane offsets on top of uniform 64-bit bases;
+//   * a lane makes RUN consecutive outputs along dimension 0: for the usual monotone t (rectifyt0, resampling) consecutive outputs share all but
+//     one tap -- re-read from L1 instead of L2 / HBM, where 32 output rows in flight at once overran the XCD's L2 (hit rate 25 %);
+template <int INTERP, typename TY, int RUN>
+__global__ void __launch_bounds__(256) interpd_stream_kernel(const WsParams P) {
+    using R  = typename TY::real;
+    using ST = typename TY::store;
+    const int d0 = P.kord[0];
+    uint32_t i0 = blockIdx.x * 256u + threadIdx.x;
+    if (i0 >= (uint32_t)P.n_lane) return;
+    uint32_t lt = 0, lx = 0, ly = 0;                     // this lane's offsets (elements)
+    if (P.lane2) {
+        const int d1 = P.kord[1];
+        const uint32_t s0 = (uint32_t)P.size[d0], i1 = i0 / s0;
+        i0 -= i1 * s0;
+        lt = i1 * (uint32_t)P.tst[d1]; lx = i1 * (uint32_t)P.xst[d1]; ly = i1 * (uint32_t)P.yst[d1];
+    }
+    lt += i0 * (uint32_t)P.tst[d0]; lx += i0 * (uint32_t)P.xst[d0]; ly += i0 * (uint32_t)P.yst[d0];
+    // the other kept dimensions from the block id (uniform); dimension 0 in chunks of RUN
+    uint64_t q = (uint64_t)blockIdx.y + (uint64_t)gridDim.y * blockIdx.z;
+    if (q >= P.n_rest) return;
+    int64_t tb = 0, xb = 0, yb = 0;
+    uint32_t ic = 0;
+    for (int k = P.lane2 ? 2 : 1; k < P.nkd; ++k) {
+        const int d = P.kord[k];
+        const uint64_t sz = d == 0 ? (P.size[0] + RUN - 1) / RUN : P.size[d];
+        const uint64_t idx = q % sz;
+        q /= sz;
+        if (d == 0) ic = (uint32_t)idx;
+        else { tb += (int64_t)idx * P.tst[d]; xb += (int64_t)idx * P.xst[d]; yb += (int64_t)idx * P.yst[d]; }
+    }
+    const R *__restrict__ t = (const R *)P.t + tb;
+    const ST *__restrict__ x = (const ST *)P.x + xb;
+    ST *__restrict__ y = (ST *)P.y + yb;
+    const uint32_t I = (uint32_t)P.size[0], T = (uint32_t)P.T, xts = (uint32_t)P.x_tstride, tts = (uint32_t)P.tst[0], yts = (uint32_t)P.yst[0];
+    constexpr int K = interp_taps(INTERP);
+    constexpr int OFF = (K == 1) ? 0 : (K == 2) ? 0 : -1;
+#pragma unroll
+    for (int r = 0; r < RUN; ++r) {
+        const uint32_t i = ic * RUN + r;
+        if (i >= I) break;
+        const R tau = t[lt + i * tts];
+        cplx<R> v = {(R)P.extrap, (R)0};
+        // support: tau >= 0 and every tap in [0, T) (the rule of sample_strided above; NaN and +-inf fall out of it)
+        const R base = INTERP == 0 ? qfloor(tau + (R)0.5) : qfloor(tau);
+        if (tau >= (R)0 && base + (R)(K - 1 + OFF) < (R)T && base + (R)OFF >= (R)0) {
+            const uint32_t first = (uint32_t)((int)base + OFF);
+            R w[4] = {(R)1, (R)0, (R)0, (R)0};
+            if constexpr (K > 1) interp_weights<INTERP>(tau - base, w);
+            v = {(R)0, (R)0};
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const cplx<R> u = ld(x, (size_t)(lx + (first + k) * xts));
+                v.x += w[k] * u.x; v.y += w[k] * u.y;
+            }
+        }
+        st(y, (size_t)(ly + i * yts), v);
+    }
+}
+
 template <typename TY> static hipError_t launch_ws_t(const WsParams &P, hipStream_t s) {
+    if (P.stream_ok) {                                    // the lean streaming kernel (conditions checked by the host: qdas_api.hip)
+        constexpr int RUN = 8;
+        const uint64_t nr = P.n_rest / P.size[0] * ((P.size[0] + RUN - 1) / RUN);       // dimension 0 in chunks of RUN
+        const uint64_t gy = nr < 65535 ? (nr ? nr : 1) : 65535, gz = (nr + gy - 1) / gy;
+        if (gz <= 65535) {
+            WsParams Q = P;
+            Q.n_rest = nr;
+            const dim3 g((unsigned)((P.n_lane + 255) / 256), (unsigned)gy, (unsigned)(gz ? gz : 1)), b(256);
+            switch (P.flag & 7) {
+                case 0: interpd_stream_kernel<0, TY, RUN><<<g, b, 0, s>>>(Q); break;
+                case 1: case 4: interpd_stream_kernel<1, TY, RUN><<<g, b, 0, s>>>(Q); break;
+                case 2: interpd_stream_kernel<2, TY, RUN><<<g, b, 0, s>>>(Q); break;
+                case 3: interpd_stream_kernel<3, TY, RUN><<<g, b, 0, s>>>(Q); break;
+                case 5: interpd_stream_kernel<5, TY, RUN><<<g, b, 0, s>>>(Q); break;
+                default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
+    }
     // grid: x = blocks along the fastest kept dimension, (y, z) = the other kept dimensions flattened
     const uint64_t n0 = P.n_lane, gy = P.n_rest < 65535 ? (P.n_rest ? P.n_rest : 1) : 65535, gz = (P.n_rest + gy - 1) / gy;
     if (gz > 65535 || (n0 + 255) / 256 > 0x7fffffffull) return hipErrorInvalidValue;

@@ -316,6 +316,12 @@ def wsinterpd(x, t, dim=1, w=1, sdim=None, interp="linear", extrapval=float("nan
         xd = xd.contiguous()
     if not _dense(td):
         td = td.contiguous()
+    # ... unless the dimension in which x is contiguous is SUMMED: a lane then walks its own row term by term and neighbouring lanes sit a whole
+    # row apart -- the column-major copies (time fastest: lanes along the sampled dimension, sums by uniform strides) are the better layout there
+    nz = [k for k in range(1, nd) if xd.shape[k] > 1]
+    fastest = min(nz, key=lambda k: xd.stride(k)) if nz else 0
+    if nz and T > 1 and xd.stride(fastest) < xd.stride(0) and (fastest + 1) in sd:
+        xd, td = _colmajor(xd).permute(*reversed(range(nd))), _colmajor(td).permute(*reversed(range(nd)))
     xc, tc = xd, td
     d = _lib.WsDesc()
     d.T, d.x_tstride, d.ndim, d.flag, d.dtype = T, (xd.stride(0) if T > 1 else 1), nd, _lib.INTERP_FLAGS[interp], _PREC[prec]
