@@ -406,6 +406,14 @@ def main():
         km = torch.tensor([kernel_ms], device=dev, dtype=torch.float64)
         allk = [torch.zeros_like(km) for _ in range(world)]
         dist.all_gather(allk, km)
+        # what every rank's plan looks like (the first multi-GPU run should say where the time goes): slab, tile / wave footprint,
+        # workgroups per tile, modes -- gathered as one small integer tensor per rank
+        tz, tcx = plan.tile_shape()
+        wz, wc = plan.wave_shape()
+        info_t = torch.tensor([rank, b, e - b, tz, tcx, wz, wc, plan.aperture_split(), int(plan.mirror), int(plan.folded), int(plan.reciprocal), plan.fallback_tiles()],
+                              device=dev, dtype=torch.int64)
+        infos = [torch.zeros_like(info_t) for _ in range(world)]
+        dist.all_gather(infos, info_t)
         y = plan.execute_colmajor(xc, F)
         torch.cuda.synchronize(); dist.barrier()
         tg = time.perf_counter()
@@ -424,6 +432,12 @@ def main():
         bcast_ms = (time.perf_counter() - tb) / 3 * 1e3
         multi = {"backend": backend, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
                  "per_rank_kernel_ms": [round(float(k.item()), 3) for k in allk], "gather_ms": round(gather_ms, 3),
+                 "slowest_rank": int(np.argmax([float(k.item()) for k in allk])),
+                 "kernel_balance": round(float(np.mean([float(k.item()) for k in allk]) / max(float(k.item()) for k in allk)), 4),
+                 "per_rank_plan": [dict(zip(("rank", "i_begin", "i_count", "tile_z", "tile_cols", "wave_z", "wave_cols", "aperture_split", "mirror", "folded", "reciprocal", "fallback_tiles"),
+                                            [int(v) for v in it.tolist()])) for it in infos],
+                 "note": "per_rank_kernel_ms includes each rank's own reciprocity fold of the replicated frame (a fixed ~0.5 ms pass at C3 that does not shrink with "
+                         "the slab: the Amdahl term of this layout); gather_ms / broadcast_x_ms are measured alone, outside the timed region",
                  "broadcast_x_ms": round(bcast_ms, 3), "x_bytes": int(xc.numel() * xc.element_size()),
                  "ms_per_step_incl_replication": round(el / args.steps * 1e3 + bcast_ms, 3),
                  "value_incl_replication": round(I * F / (el / args.steps + bcast_ms * 1e-3) / 1e6, 4)}

@@ -111,6 +111,15 @@ extern "C" {
                                      unordered pair per pixel and share only tap index and weights between them, as rounds 1-3 did.  The fold
                                      costs a plan-owned copy of the frame (T x N x M complex64) and one streaming pass per frame            */
 
+#define QDAS_PLAN_APPROX_SYMMETRY 64 /* take the reciprocal / lateral-mirror modes also when the geometry is symmetric only WITHIN A TOLERANCE: element and
+                                     pixel POSITIONS may deviate from their partners' (mirror) images as long as the bound on the delay error this commits,
+                                     cinv fs (2 max|M(p') - p| + max|M(r') - r| + max|M(v') - v|) resp. 2 cinv fs max|r_m - v_m|, stays <= 1e-5 sample
+                                     (QDAS_SYM_TOL=<samples> overrides; normals and start times must match exactly).  Off by default: the modes then need
+                                     bit-exact symmetry.  1e-5 sample is 0.8 nm of path at 20 MHz / 1540 m/s -- sub-ulp deviations of coordinates of a
+                                     few mm; a delay error d sample shows up as a relative image error of about 2 pi (fc / fs) d: the image tolerance
+                                     of 1e-4 allows ~6e-5 sample, i.e. ~5 nm, NOT micrometres -- a calibrated probe is simply not symmetric.
+                                     qdas_plan_symmetry_bound reports the bounds of the modes in use                                          */
+
 /* ---- LIFETIME of caller memory.  Host arrays (QDAS_MEM_HOST) are copied at qdas_plan_create and never touched again.  Device
  *      arrays (QDAS_MEM_DEVICE) are used IN PLACE: Pi, Pr, Pv, Nv, apod, cinv and rx_normals must stay allocated and unchanged
  *      until qdas_plan_destroy -- unless the plan was created with QDAS_PLAN_COPY_INPUTS.  acstride is read at creation only.
@@ -212,6 +221,9 @@ int  qdas_plan_reciprocal(const qdas_plan *plan);
  * each unordered transmit/receive pair, xs[:,n,m] = w[n,m] x[:,n,m] + w[m,n] x[:,m,n] (n <= m; one pass over HBM into a plan-owned copy of the
  * frame, pixel-independent apodization applied on the way), and the fused kernel then walks the upper triangle only */
 int  qdas_plan_folded(const qdas_plan *plan);
+/* bounds [samples] of the delay error committed by the lateral-mirror / reciprocal mode of the plan: 0 = exact symmetry, > 0 = accepted within
+ * the tolerance of QDAS_PLAN_APPROX_SYMMETRY, -1 = that mode is not in use (either pointer may be NULL) */
+int  qdas_plan_symmetry_bound(const qdas_plan *plan, double *mirror_samples, double *reciprocal_samples);
 /* 1 when a QDAS_KERNEL_TILED plan runs in lateral-mirror mode (QDAS_PLAN_NO_MIRROR), else 0 */
 int  qdas_plan_mirror(const qdas_plan *plan);
 /* human-readable name of the kernel a plan launches for one frame, e.g.

@@ -93,6 +93,8 @@ struct qdas_plan {
     // and the N x M weight table the fold pass applies (null: ones) -- the folded kernels themselves carry no table
     void *fold_buf = nullptr;
     const void *fold_wtab = nullptr;
+    // tolerance mode (QDAS_PLAN_APPROX_SYMMETRY): bounds [samples] of the delay error the symmetry modes in use commit; 0 = exact symmetry, -1 = mode not in use
+    double mirror_bound = -1.0, recip_bound = -1.0;
     bool fb2_ok = false;                      // frames of a sequence may share launches, 4 or 2 at a time (decided at plan creation)
     bool fb4_off = false;                     // ... but at most pairwise (QDAS_NO_FB4)
     bool fold2_ok = false;                    // folded data: two frames may share a launch
@@ -334,31 +336,57 @@ static int choose_tile_shape(qdas_plan *pl, const qdas_desc *desc, F &&set_grid)
     return QDAS_OK;
 }
 
-// Lateral-mirror symmetry (tile_params.h `mir`): is pixel column I2-1-c the mirror image (x -> -x) of column c, bit for bit?
-__global__ void mirror_check_kernel(const float *Pi, uint64_t I1, uint64_t I2, uint32_t *bad) {
+// Lateral-mirror symmetry (tile_params.h `mir`): is pixel column I2-1-c the mirror image (x -> -x) of column c, bit for bit?  `dev`: the largest
+// distance |mirror(p') - p| over the pixels, as float bits (non-negative floats order like their bit patterns): what the tolerance mode bounds
+__global__ void mirror_check_kernel(const float *Pi, uint64_t I1, uint64_t I2, uint32_t *bad, uint32_t *dev) {
     const uint64_t half = (I2 + 1) / 2, n = I1 * half;
+    float worst = 0.f;
+    bool exact = true;
     for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t i1 = q % I1, c = q / I1;
         const float *a = Pi + 3 * (i1 + I1 * c), *b = Pi + 3 * (i1 + I1 * (I2 - 1 - c));
-        if (!(a[0] == -b[0] && a[1] == b[1] && a[2] == b[2])) { *bad = 1u; return; }      // (NaN coordinates: not symmetric)
+        if (!(a[0] == -b[0] && a[1] == b[1] && a[2] == b[2])) {      // (NaN coordinates: not symmetric, in either mode)
+            exact = false;
+            const float dx = a[0] + b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+            worst = (d == d) ? fmaxf(worst, d) : INFINITY;
+        }
     }
+    if (!exact) { *bad = 1u; atomicMax(dev, __float_as_uint(worst)); }
 }
 // receivers, transmits (positions, normals, t0) and pixel columns mirror-symmetric about x = 0?  fp32 geometry.
-static int mirror_symmetric(const qdas_desc *desc, const float *dPi, bool *yes) {
+// Exact mode (`tol` < 0): bit for bit.  Tolerance mode (QDAS_PLAN_APPROX_SYMMETRY, `tol` >= 0 in SAMPLES): positions may deviate -- distance is
+// 1-Lipschitz in either end point, so |tau(p', N-1-n, M-1-m) - tau(p, n, m)| * fs <= cinv * fs * (2 max|M(p') - p| + max|M(r') - r| + max|M(v') - v|) =: bound,
+// and the mode is taken when bound <= tol; normals and start times (which enter the plane-wave delay and the focused-wave sign) must still match exactly.
+static int mirror_symmetric(const qdas_desc *desc, const float *dPi, bool *yes, double tol = -1.0, double cinv_fs = 0.0, double *bound = nullptr) {
     const qdas_sizes &z = desc->sz;
     *yes = false;
+    if (bound) *bound = 0.0;
     std::vector<float> hr(3 * z.N), hv(4 * z.M), hn(3 * z.M);
     int rc;
     if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return rc;
     if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return rc;
     if ((rc = fetch_host(desc->Nv, hn.size() * 4, desc->mem, hn.data()))) return rc;
+    double dr = 0.0, dv = 0.0;                          // largest deviation of a receiver / transmit position from its mirror partner's image
+    auto dist3 = [](const float *a, const float *b) { const double dx = (double)a[0] + (double)b[0], dy = (double)a[1] - (double)b[1], dz = (double)a[2] - (double)b[2]; return sqrt(dx * dx + dy * dy + dz * dz); };
     for (uint64_t n = 0; n < z.N; ++n) {
         const float *a = &hr[3 * n], *b = &hr[3 * (z.N - 1 - n)];
-        if (!(a[0] == -b[0] && a[1] == b[1] && a[2] == b[2])) return QDAS_OK;
+        if (!(a[0] == -b[0] && a[1] == b[1] && a[2] == b[2])) {
+            if (tol < 0) return QDAS_OK;
+            const double d = dist3(a, b);
+            if (!(d == d)) return QDAS_OK;
+            dr = std::max(dr, d);
+        }
     }
     for (uint64_t m = 0; m < z.M; ++m) {
         const float *a = &hv[4 * m], *b = &hv[4 * (z.M - 1 - m)], *c = &hn[3 * m], *d = &hn[3 * (z.M - 1 - m)];
-        if (!(a[0] == -b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3] && c[0] == -d[0] && c[1] == d[1] && c[2] == d[2])) return QDAS_OK;
+        if (!(a[3] == b[3] && c[0] == -d[0] && c[1] == d[1] && c[2] == d[2])) return QDAS_OK;       // start times and normals: exact in both modes
+        if (!(a[0] == -b[0] && a[1] == b[1] && a[2] == b[2])) {
+            if (tol < 0) return QDAS_OK;
+            const double e = dist3(a, b);
+            if (!(e == e)) return QDAS_OK;
+            dv = std::max(dv, e);
+        }
     }
     if (desc->rx_apod_kind && desc->rx_normals) {       // a generated receive apodization: the element normals as well
         std::vector<float> hx(3 * z.N);
@@ -369,18 +397,24 @@ static int mirror_symmetric(const qdas_desc *desc, const float *dPi, bool *yes) 
         }
     }
     uint32_t *flag = nullptr;
-    HIPCHK(hipMalloc(&flag, sizeof(uint32_t)));
-    hipError_t e = hipMemset(flag, 0, sizeof(uint32_t));
-    uint32_t bad = 1;
+    HIPCHK(hipMalloc(&flag, 2 * sizeof(uint32_t)));
+    hipError_t e = hipMemset(flag, 0, 2 * sizeof(uint32_t));
+    uint32_t res[2] = {1u, 0x7f800000u};
     if (e == hipSuccess) {
         const uint64_t n = z.I1 * ((z.I2 + 1) / 2);
-        mirror_check_kernel<<<(unsigned)std::min<uint64_t>((n + 255) / 256, 4096), 256, 0, 0>>>(dPi, z.I1, z.I2, flag);
+        mirror_check_kernel<<<(unsigned)std::min<uint64_t>((n + 255) / 256, 4096), 256, 0, 0>>>(dPi, z.I1, z.I2, flag, flag + 1);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpy(&bad, flag, sizeof(uint32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(res, flag, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost);
     }
     (void)hipFree(flag);
     HIPCHK(e);
-    *yes = bad == 0;
+    float dpf;
+    memcpy(&dpf, &res[1], 4);
+    const double dp = res[0] ? (double)dpf : 0.0;
+    if (tol < 0) { *yes = res[0] == 0; return QDAS_OK; }
+    const double b = cinv_fs * (2.0 * dp + dr + dv);
+    if (bound) *bound = b;
+    *yes = b == b && b <= tol;
     return QDAS_OK;
 }
 
@@ -532,13 +566,32 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // upper triangle of the folded frame: half the staging, gathers and multiply-accumulates.  QDAS_PLAN_NO_FOLD / QDAS_NO_FOLD=1: the reciprocal
     // mode as it was (both traces gathered, tap index and weights shared).
     int sym = 0, big = 0, rfold = 0;
+    // tolerance mode of the symmetry tests (QDAS_PLAN_APPROX_SYMMETRY; bound in SAMPLES, default 1e-5, QDAS_SYM_TOL overrides): < 0 = exact only
+    double sym_tol = -1.0, recip_bound = 0.0, mirror_bound = 0.0;
+    if ((desc->plan_flags & QDAS_PLAN_APPROX_SYMMETRY) && !cmap) {
+        sym_tol = 1.0e-5;
+        if (const char *e = getenv("QDAS_SYM_TOL")) { const double v = atof(e); if (v >= 0.0 && v <= 0.5) sym_tol = v; }
+    }
     if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && z.VS && z.DV && z.N == z.M && pix_arr < 0 && !g.gen_kind && !(desc->plan_flags & QDAS_PLAN_NO_RECIPROCAL) && !getenv("QDAS_NO_SYM")) {
         std::vector<float> hr(3 * z.N), hv(4 * z.M);
         if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
         if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);
         sym = 1;
-        for (uint64_t m = 0; m < z.M && sym; ++m)
-            if (memcmp(&hv[4 * m], &hr[3 * m], 12) != 0 || memcmp(&hv[4 * m + 3], &hv[3], 4) != 0) sym = 0;
+        double drv = 0.0;                              // tolerance mode: the largest distance between a transmit element and "its" receive element
+        for (uint64_t m = 0; m < z.M && sym; ++m) {
+            if (memcmp(&hv[4 * m + 3], &hv[3], 4) != 0) sym = 0;                 // one start time: exact in both modes
+            else if (memcmp(&hv[4 * m], &hr[3 * m], 12) != 0) {
+                if (sym_tol < 0) sym = 0;
+                else {
+                    const double dx = (double)hv[4 * m] - hr[3 * m], dy = (double)hv[4 * m + 1] - hr[3 * m + 1], dz = (double)hv[4 * m + 2] - hr[3 * m + 2];
+                    const double dd = sqrt(dx * dx + dy * dy + dz * dz);
+                    if (!(dd == dd)) sym = 0; else drv = std::max(drv, dd);
+                }
+            }
+        }
+        // |tau(n,m) - tau(m,n)| fs <= cinv fs (|r_n - v_n| + |r_m - v_m|) <= 2 cinv fs max|r - v|
+        recip_bound = 2.0 * pl->cinv0 * desc->fs * drv;
+        if (sym && !(recip_bound <= (sym_tol < 0 ? 0.0 : sym_tol))) sym = 0;
         rfold = sym && dt == QDAS_F32 && z.N >= 2 && z.N <= 65535 && !(desc->plan_flags & QDAS_PLAN_NO_FOLD) && !getenv("QDAS_NO_FOLD")
                && tile_lds_bytes(dt, 1, z.N, z.M, 0, 0, 0, 0, 1) <= tile_lds_limit(1);
         if (sym && !rfold && (z.M % tile_config(dt, 1).mb != 0 || tile_lds_bytes(dt, 1, z.N, z.M) > tile_lds_limit(1))) sym = 0;
@@ -578,7 +631,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         && z.N >= 2 && ((desc->i_begin == 0 && pl->i_count == pl->I) || mslab) && !(desc->plan_flags & QDAS_PLAN_NO_MIRROR) && !getenv("QDAS_NO_MIRROR")
         && (!sym || ((uint64_t)z.T * z.N * z.M * data_size(dt) + 65536 < (1ull << 31) && (rfold || z.M % 16 == 0) && !getenv("QDAS_NO_MIRQ")
                      && tile_lds_bytes(dt, 1, z.N, z.M, 1, 0, (z.S > 0 && !rfold) ? 1 : 0, 1, rfold) <= tile_lds_limit(1)))) {
-        if ((rc = mirror_symmetric(desc, (const float *)g.Pi, &mir))) return bail(rc);
+        if ((rc = mirror_symmetric(desc, (const float *)g.Pi, &mir, sym_tol, pl->cinv0 * desc->fs, &mirror_bound))) return bail(rc);
     }
     // stage / block element counts of the kernel: receivers / transmits, or swapped
     const uint64_t kN = swap ? z.M : z.N, kM = swap ? z.N : z.M;
@@ -1006,6 +1059,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     }
     // the plan keeps no pointer into caller memory it does not need: host arrays were copied; device arrays are used in place
     // (g.* / tp.*: they must stay valid for the life of the plan unless QDAS_PLAN_COPY_INPUTS made plan-owned copies)
+    pl->mirror_bound = mirror_bound; pl->recip_bound = recip_bound;
     pl->d.Pi = pl->d.Pr = pl->d.Pv = pl->d.Nv = pl->d.apod = pl->d.cinv = pl->d.rx_normals = nullptr;
     pl->d.acstride = nullptr;
     *out = pl;
@@ -1043,6 +1097,14 @@ extern "C" int qdas_plan_tile_shape(const qdas_plan *pl, int *tile_z, int *tile_
 extern "C" int qdas_plan_mirror(const qdas_plan *pl) { return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.mir ? 1 : 0; }
 
 extern "C" int qdas_plan_reciprocal(const qdas_plan *pl) { return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.sym ? 1 : 0; }
+
+extern "C" int qdas_plan_symmetry_bound(const qdas_plan *pl, double *mirror_samples, double *reciprocal_samples) {
+    if (!pl) return fail(QDAS_EINVAL, "null plan");
+    const bool tiled = pl->kernel == QDAS_KERNEL_TILED;
+    if (mirror_samples) *mirror_samples = (tiled && pl->tp.mir) ? pl->mirror_bound : -1.0;
+    if (reciprocal_samples) *reciprocal_samples = (tiled && pl->tp.sym) ? pl->recip_bound : -1.0;
+    return QDAS_OK;
+}
 
 extern "C" int qdas_plan_folded(const qdas_plan *pl) { return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.fold ? 1 : 0; }
 

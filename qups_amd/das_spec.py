@@ -437,7 +437,7 @@ class DasPlan:
 
     def __init__(self, prob: DasProblem, device=None, kernel: int = _lib.KERNEL_AUTO,
                  i_begin: int = 0, i_count: int = 0, reciprocal: bool = True, jit: bool = False, mirror: bool = True, mirror_slab: bool = False,
-                 fold: bool = True):
+                 fold: bool = True, approx_symmetry: bool = False):
         """``mirror_slab``: the slab ``[i_begin, i_begin + i_count)`` AND its mirror image in one plan (``QDAS_PLAN_MIRROR_SLAB``, ``include/qdas.h``):
         the output holds ``2 * i_count`` pixels, slab A then slab B; raises when the lateral-mirror mode is not available for the problem."""
         torch = _torch()
@@ -466,7 +466,8 @@ class DasPlan:
         d.device = dev.index if dev.index is not None else torch.cuda.current_device()
         d.i_begin, d.i_count, d.y_ld = self.i_begin, self.i_count, 0
         d.plan_flags = ((0 if reciprocal else _lib.PLAN_NO_RECIPROCAL) | (_lib.PLAN_JIT if jit else 0) | (0 if mirror else _lib.PLAN_NO_MIRROR)
-                        | (_lib.PLAN_MIRROR_SLAB if mirror_slab else 0) | (0 if fold else _lib.PLAN_NO_FOLD))
+                        | (_lib.PLAN_MIRROR_SLAB if mirror_slab else 0) | (0 if fold else _lib.PLAN_NO_FOLD)
+                        | (_lib.PLAN_APPROX_SYMMETRY if approx_symmetry else 0))
         if prob.rx_apod is not None:                       # generated receive apodization (qdas.h QDAS_RXAPOD_*)
             d.rx_apod_kind = prob.rx_apod["kind"]
             d.rx_apod_p[0], d.rx_apod_p[1] = prob.rx_apod["p"]
@@ -505,6 +506,13 @@ class DasPlan:
     def reciprocal(self) -> bool:
         """True when the tiled kernel runs in reciprocal mode (FSA with transmit elements == receive elements, one t0)."""
         return bool(self.lib.qdas_plan_reciprocal(self._h))
+
+    def symmetry_bound(self) -> tuple:
+        """``(mirror, reciprocal)``: bounds [samples] of the delay error the plan's symmetry modes commit (``qdas_plan_symmetry_bound``): 0 exact symmetry,
+        > 0 accepted within the tolerance of ``approx_symmetry=True`` (``QDAS_PLAN_APPROX_SYMMETRY``), -1 mode not in use"""
+        a, b = C.c_double(), C.c_double()
+        _lib.check(self.lib.qdas_plan_symmetry_bound(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
 
     @property
     def folded(self) -> bool:

@@ -472,3 +472,61 @@ def test_streams_of_frames_through_folded_plans(N, interp, extra, monkeypatch):
         assert rel_err(y[f], ref) <= tol, (f, rel_err(y[f], ref))
         assert rel_err(y[f], one[f]) <= (1e-2 if interp == "nearest" else 1e-5), f       # (another kernel: fp32 re-association only)
     assert np.array_equal(y[F - 1], one[F - 1])                       # the odd last frame ran alone: the same kernel, bit for bit
+
+
+def test_symmetry_within_a_tolerance(monkeypatch):
+    """QDAS_PLAN_APPROX_SYMMETRY: the reciprocal / lateral-mirror modes survive deviations of element and pixel POSITIONS from exact
+    symmetry as long as the bound on the delay error they commit stays below 1e-5 sample (QDAS_SYM_TOL overrides); the bound is reported; exact symmetry
+    stays the default.  One ulp off (the case that cost the headline its mode in round 3) is within it; a micrometre -- 0.013 sample at 20 MHz -- is not:
+    accepting it by raising the tolerance costs image accuracy in proportion (about 2 pi fc / fs per sample of delay error), which this test pins."""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import DasPlan, build_problem, parse_options
+    base = make_case(seq="FSA", interp="lanczos3", seed=5, N=32, I1=96, I2=24)
+    x = torch.from_numpy(base["x"])
+
+    def run(Pr, Pv, **kw):
+        prob = build_problem("DAS", base["Pi"], Pr, Pv, base["Nv"], tuple(x.shape), base["t0"], base["fs"], base["c"],
+                             parse_options(x, list(base["opt"]) + ["interp", "lanczos3"]))
+        with DasPlan(prob, kernel=2, **kw) as plan:
+            y = plan.feval(x).cpu().numpy().reshape(-1)
+            return y, plan.mirror, plan.reciprocal, plan.symmetry_bound(), plan.kernel_name()
+
+    ref = lambda Pr, Pv: O.das_spec("DAS", base["Pi"], Pr, Pv, base["Nv"], base["x"], base["t0"], base["fs"], cinv_f32(base["c"]),
+                                    VS=base["VS"], DV=base["DV"], interp="lanczos3").reshape(-1, order="F")
+    # exact geometry: both modes, bounds 0
+    y0, mir, rec, bnd, _ = run(base["Pr"], base["Pv"])
+    assert mir and rec and bnd == (0.0, 0.0)
+    assert rel_err(y0, ref(base["Pr"], base["Pv"])) <= 2e-5
+    # one receive element AND the same transmit element one ulp off in x (still reciprocal: Pv == Pr bit for bit; no longer mirror-symmetric)
+    ulp = lambda v: np.nextafter(np.float32(v), np.float32(np.inf))
+    Pr1 = np.asarray(base["Pr"], np.float32).copy(); Pr1[0, 5] = ulp(Pr1[0, 5])
+    Pv1 = np.asarray(base["Pv"], np.float32).copy(); Pv1[0, 5] = Pr1[0, 5]
+    y1, mir, rec, bnd, name = run(Pr1, Pv1)
+    assert rec and not mir and bnd[0] == -1.0, (name, bnd)                     # default: exact symmetry only
+    y2, mir, rec, bnd, name = run(Pr1, Pv1, approx_symmetry=True)
+    assert rec and mir and 0.0 < bnd[0] <= 1e-5 and bnd[1] == 0.0, (name, bnd)
+    r1 = ref(Pr1, Pv1)
+    assert rel_err(y1, r1) <= 2e-5 and rel_err(y2, r1) <= 2e-5             # a bound of < 1e-5 sample is invisible at the image tolerance
+    # only the TRANSMIT element one ulp off: no longer bit-exactly reciprocal either
+    Pv2 = np.asarray(base["Pv"], np.float32).copy(); Pv2[0, 5] = ulp(Pv2[0, 5])
+    y3, mir, rec, bnd, name = run(base["Pr"], Pv2)
+    assert not rec, name
+    y4, mir, rec, bnd, name = run(base["Pr"], Pv2, approx_symmetry=True)
+    assert rec and mir and 0.0 < bnd[1] <= 1e-5 and 0.0 < bnd[0] <= 1e-5, (name, bnd)
+    r2 = ref(base["Pr"], Pv2)
+    assert rel_err(y3, r2) <= 2e-5 and rel_err(y4, r2) <= 2e-5
+    # a micrometre (a calibrated probe): 0.013 sample -- refused at the default tolerance ...
+    Pr3 = np.asarray(base["Pr"], np.float32).copy(); Pr3[0, 5] += np.float32(1e-6)
+    Pv3 = np.asarray(base["Pv"], np.float32).copy(); Pv3[0, 5] = Pr3[0, 5]
+    y5, mir, rec, bnd, name = run(Pr3, Pv3, approx_symmetry=True)
+    assert rec and not mir, (name, bnd)
+    r3 = ref(Pr3, Pv3)
+    assert rel_err(y5, r3) <= 2e-5
+    # ... and what accepting it would cost: the mirror image of every pixel takes the delays of the unperturbed side -- an error of up to 0.013 sample on the pairs
+    # of ONE element, i.e. ~2 / N of the terms: visible above the kernel's own 2e-5, far below a wrong image
+    monkeypatch.setenv("QDAS_SYM_TOL", "0.05")
+    y6, mir, rec, bnd, name = run(Pr3, Pv3, approx_symmetry=True)
+    assert mir and 0.02 < bnd[0] < 0.03, (name, bnd)                         # (the receive AND the transmit element: 2 x 0.013 sample)
+    e6 = rel_err(y6, r3)
+    assert 1e-5 < e6 < 5e-3, e6
