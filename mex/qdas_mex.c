@@ -23,7 +23,8 @@
  *   acstride : uint64 6 x (1+S)  [cstride, astride]                                     (kern/das_spec.m:257-260)
  *   tvars    : [fs fmod], any real numeric class
  *   opts     : struct, all fields optional: devices (row of device ordinals: a multi-GPU plan, qdas_plan_create_sharded),
- *              jit (true: QDAS_PLAN_JIT), reciprocal (false: QDAS_PLAN_NO_RECIPROCAL), kernel (0 auto | 1 generic | 2 tiled)
+ *              jit (true: QDAS_PLAN_JIT), reciprocal (false: QDAS_PLAN_NO_RECIPROCAL), mirror (false: QDAS_PLAN_NO_MIRROR), fold (false: QDAS_PLAN_NO_FOLD),
+ *              approx_symmetry (true: QDAS_PLAN_APPROX_SYMMETRY), kernel (0 auto | 1 generic | 2 tiled)
  *   x, y     : complex(prec); half precision travels as uint16 arrays with a leading dimension of 2 (re, im), as the reference
  *              passes ushort2 (src/bf.cu:164-171)
  * Host arrays use QDAS_MEM_HOST (the library stages them through HBM).  With -DQDAS_MEX_GPU, gpuArray arguments are passed as
@@ -146,6 +147,8 @@ static int create_plan(int nrhs, const mxArray *prhs[]) {
         if ((f = mxGetField(o, 0, "jit")) && num_at(f, 0, "opts.jit") != 0) d.plan_flags |= QDAS_PLAN_JIT;
         if ((f = mxGetField(o, 0, "reciprocal")) && num_at(f, 0, "opts.reciprocal") == 0) d.plan_flags |= QDAS_PLAN_NO_RECIPROCAL;
         if ((f = mxGetField(o, 0, "mirror")) && num_at(f, 0, "opts.mirror") == 0) d.plan_flags |= QDAS_PLAN_NO_MIRROR;
+        if ((f = mxGetField(o, 0, "fold")) && num_at(f, 0, "opts.fold") == 0) d.plan_flags |= QDAS_PLAN_NO_FOLD;
+        if ((f = mxGetField(o, 0, "approx_symmetry")) && num_at(f, 0, "opts.approx_symmetry") != 0) d.plan_flags |= QDAS_PLAN_APPROX_SYMMETRY;
         if ((f = mxGetField(o, 0, "kernel"))) d.kernel = (int32_t)num_at(f, 0, "opts.kernel");
         if ((f = mxGetField(o, 0, "devices"))) {
             ndev = (int)mxGetNumberOfElements(f);

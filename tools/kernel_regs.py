@@ -80,9 +80,9 @@ def short(dn: str) -> str:
     if "MIRQ" in dn:
         pass
     a = [x.strip() for x in re.sub(r"HIP_vector_type<double, 2u>", "f64", re.sub(r"HIP_vector_type<float, 2u>", "f32", m.group(1))).replace("unsigned int", "f16").split(",")]
-    keys = ["interp", "data", "fmod", "wtab", "sym", "fb2", "fb4", "waves", "mb", "W", "nbuf", "psz", "bpc", "probe", "big", "lut", "bf", "mirq"]
+    keys = ["interp", "data", "fmod", "wtab", "sym", "fb2", "fb4", "waves", "mb", "W", "nbuf", "psz", "bpc", "probe", "big", "lut", "bf", "mirq", "fold"]
     d = dict(zip(keys, a))
-    flags = [k for k in ("fmod", "wtab", "sym", "mirq", "fb2", "fb4", "probe", "big", "lut", "bf") if d.get(k) == "true"]
+    flags = [k for k in ("fmod", "wtab", "sym", "fold", "mirq", "fb2", "fb4", "probe", "big", "lut", "bf") if d.get(k) == "true"]
     return f"das_tile interp={d['interp']} {d['data']} mb={d['mb']} W={d['W']} " + (" ".join(flags) if flags else "general")
 
 

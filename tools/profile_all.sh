@@ -5,7 +5,7 @@
 # headline and the other BASELINE configurations, and the register tables of the prebuilt kernels AND of the hiprtc builds the
 # benches ran (their code objects are in this run's private cache directory).
 set -u
-R=${1:-r03}
+R=${1:-r04}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/profiles_$R
 mkdir -p $OUT
@@ -23,7 +23,10 @@ b c5 --workload c5 --steps 50 --warmup 5
 b c1 --workload c1 --steps 200 --warmup 20
 # ---- what the special modes are worth (no CPU leg, no counter passes)
 Q="--no-cpu --no-traffic --no-general"
+b c3_no_fold --no-fold $Q --steps 10
+b c3_frames4 --frames 4 --no-cpu --no-general --steps 5
 QDAS_NO_MIRROR=1 b c3_no_mirror $Q --steps 10
+QDAS_NO_MIRROR=1 b c3_no_mirror_no_fold --no-fold $Q --steps 10
 QDAS_NO_MIRROR=1 b c2_no_mirror --workload c2 $Q --steps 50
 QDAS_NO_MIRROR=1 b c1_no_mirror --workload c1 $Q --steps 200
 b c3_general --no-reciprocal $Q --steps 10
@@ -51,7 +54,7 @@ done
 bash tools/profile.sh ${R}_c3_general --workload c3 --no-reciprocal > /dev/null 2>&1
 cp gpurun_out/prof_${R}_c3_general/summary.txt $OUT/rocprofv3_summary_c3_general.txt 2>/dev/null
 # ---- streams of frames, the general (non-fused) kernels
-python tools/frames_bench.py c2 12 > $OUT/frames_bench.txt 2>/dev/null; python tools/frames_bench.py c5 12 >> $OUT/frames_bench.txt 2>/dev/null; python tools/frames_bench.py c1 12 >> $OUT/frames_bench.txt 2>/dev/null
+python tools/frames_bench.py c3 6 2>/dev/null | grep -v amdgpu.ids > $OUT/frames_bench.txt; python tools/frames_bench.py c2 12 >> $OUT/frames_bench.txt 2>/dev/null; python tools/frames_bench.py c5 12 >> $OUT/frames_bench.txt 2>/dev/null; python tools/frames_bench.py c1 12 >> $OUT/frames_bench.txt 2>/dev/null
 python tools/general_time.py 2>/dev/null | grep -v Warn > $OUT/general_time.txt
 # per-kernel durations of the same script (kernel-trace only): the launches behind every line of general_time.txt
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_general -o g -- python $REPO/tools/general_time.py > /dev/null 2>&1)
@@ -68,6 +71,15 @@ else:
     print("no kernel_stats.csv")
 PYEOF
 rm -rf $OUT/trace_general
+# ---- one rank's slab on one GPU (NOT a scaling curve), the issue-cost microbenchmark, the ablation of the headline kernel
+python tools/slab_scaling.py c3 2>/dev/null | grep -v amdgpu.ids > $OUT/slab_kernel_times_c3.txt
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/microbench_src/issue.hip -o /tmp/qdas_issue 2>/dev/null && /tmp/qdas_issue > $OUT/issue_costs.txt 2>&1
+{ echo "# tools/abl_sweep.sh: hiprtc builds with QDAS_JIT_DEFINES=QDAS_ABL=<bits> (tile_hooks.h), interleaved rounds, kernel ms (fold pass included).  Bits: 1 no LDS-DMA, 4 taps from registers,";
+  echo "# 8 trivial weights, 16 no end-of-stage wait / barrier, 256 plain instead of software-pipelined pair loop, 1024 no late DMA, 2048 no priority staircase.";
+  echo "# --- headline (reciprocity-folded frame + lateral-mirror mode)";
+  tools/abl_sweep.sh 2 "" - QDAS_ABL=1 QDAS_ABL=4 QDAS_ABL=8 QDAS_ABL=12 QDAS_ABL=16 QDAS_ABL=256 QDAS_ABL=1024 QDAS_ABL=2048;
+  echo "# --- the unfolded reciprocal + mirror kernel of round 3 (--no-fold)";
+  tools/abl_sweep.sh 2 "--no-fold" - QDAS_ABL=1 QDAS_ABL=4 QDAS_ABL=8 QDAS_ABL=12 QDAS_ABL=16 QDAS_ABL=2048; } > $OUT/ablation_c3.txt 2>&1
 # ---- PCIe-inclusive: host-resident frames through the C ABI, and the int16 RF -> hilbert -> band-pass -> DAS chain for a stream
 python tools/host_frames.py > $OUT/host_frames.txt 2>/dev/null
 python tools/pipeline_bench.py c3 6 64 > $OUT/pipeline_bench.txt 2>/dev/null; python tools/pipeline_bench.py c2 12 64 >> $OUT/pipeline_bench.txt 2>/dev/null
