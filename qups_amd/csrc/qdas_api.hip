@@ -594,6 +594,11 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         if (sym && !(recip_bound <= (sym_tol < 0 ? 0.0 : sym_tol))) sym = 0;
         rfold = sym && dt == QDAS_F32 && z.N >= 2 && z.N <= 65535 && !(desc->plan_flags & QDAS_PLAN_NO_FOLD) && !getenv("QDAS_NO_FOLD")
                && tile_lds_bytes(dt, 1, z.N, z.M, 0, 0, 0, 0, 1) <= tile_lds_limit(1);
+        if (rfold) {                                    // the plan's folded copy of a frame: without the memory for it, the plan simply does not fold
+            void *fbuf = nullptr;
+            if (hipMalloc(&fbuf, (size_t)z.T * z.N * z.M * 8) != hipSuccess) { (void)hipGetLastError(); rfold = 0; }
+            else { pl->owned.push_back(fbuf); pl->fold_buf = fbuf; }
+        }
         if (sym && !rfold && (z.M % tile_config(dt, 1).mb != 0 || tile_lds_bytes(dt, 1, z.N, z.M) > tile_lds_limit(1))) sym = 0;
         // fp32 data without the fold (QDAS_PLAN_NO_FOLD): that reciprocal mode exists as a plan-specialised (hiprtc) build only -- its prebuilt
         // instantiations were pruned in round 4 --; without QDAS_PLAN_JIT such a plan runs the general kernels
@@ -845,7 +850,6 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             // folded data: with the lateral-mirror mode two window sets -- 32 x 128 samples when every tile of some footprint fits them (launch
             // configuration 17), else 16 x 192 (18) --; when that leaves misfit tiles too (a misfit tile is redone by the generic kernel, which knows
             // nothing of mirror images) or without the mode: one set of 32 x 192 samples (19), misfit tiles to the generic kernel as ever
-            if ((rc = dev_alloc(pl, &pl->fold_buf, (size_t)z.T * z.N * z.M * 8))) return bail(rc);
             HIPCHK(hipMemset(pl->fold_buf, 0, (size_t)z.T * z.N * z.M * 8));      // (the lower triangle is never written: zeros, not garbage, where a border window reaches into it)
             if (t.mir) {
                 t.narrow = getenv("QDAS_NO_NARROW") ? 0 : 1;
@@ -1060,6 +1064,11 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // the plan keeps no pointer into caller memory it does not need: host arrays were copied; device arrays are used in place
     // (g.* / tp.*: they must stay valid for the life of the plan unless QDAS_PLAN_COPY_INPUTS made plan-owned copies)
     pl->mirror_bound = mirror_bound; pl->recip_bound = recip_bound;
+    if (pl->fold_buf && !(pl->kernel == QDAS_KERNEL_TILED && pl->tp.fold)) {      // (the plan left the fold after all: wide windows, strides, generic kernel)
+        for (size_t k = 0; k < pl->owned.size(); ++k) if (pl->owned[k] == pl->fold_buf) { pl->owned.erase(pl->owned.begin() + (long)k); break; }
+        (void)hipFree(pl->fold_buf);
+        pl->fold_buf = nullptr;
+    }
     pl->d.Pi = pl->d.Pr = pl->d.Pv = pl->d.Nv = pl->d.apod = pl->d.cinv = pl->d.rx_normals = nullptr;
     pl->d.acstride = nullptr;
     *out = pl;
