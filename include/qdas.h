@@ -120,6 +120,11 @@ extern "C" {
                                      of 1e-4 allows ~6e-5 sample, i.e. ~5 nm, NOT micrometres -- a calibrated probe is simply not symmetric.
                                      qdas_plan_symmetry_bound reports the bounds of the modes in use                                          */
 
+#define QDAS_PLAN_PREFOLDED     128 /* the frames handed to execute ARE folded frames (qdas_fold: complex64, upper triangle n <= m; weights applied there): the plan
+                                     runs no fold pass and owns no folded copy.  For hosts that fold once per acquisition and replicate the folded frame (half
+                                     the bytes) to several devices.  Needs a reciprocal fp32 'DAS' problem without apodization arrays whose tiles all fit the
+                                     staging windows, else QDAS_EUNSUPPORTED                                                                       */
+
 /* ---- LIFETIME of caller memory.  Host arrays (QDAS_MEM_HOST) are copied at qdas_plan_create and never touched again.  Device
  *      arrays (QDAS_MEM_DEVICE) are used IN PLACE: Pi, Pr, Pv, Nv, apod, cinv and rx_normals must stay allocated and unchanged
  *      until qdas_plan_destroy -- unless the plan was created with QDAS_PLAN_COPY_INPUTS.  acstride is read at creation only.
@@ -221,6 +226,17 @@ int  qdas_plan_reciprocal(const qdas_plan *plan);
  * each unordered transmit/receive pair, xs[:,n,m] = w[n,m] x[:,n,m] + w[m,n] x[:,m,n] (n <= m; one pass over HBM into a plan-owned copy of the
  * frame, pixel-independent apodization applied on the way), and the fused kernel then walks the upper triangle only */
 int  qdas_plan_folded(const qdas_plan *plan);
+/* The reciprocity fold on its own: xs[:,n,m] = w[n,m] x[:,n,m] + w[m,n] x[:,m,n] for n < m, xs[:,n,n] = w[n,n] x[:,n,n]; traces of T samples at (n strN + m strM)
+ * samples in x AND xs (0: T, T N); x complex64 (QDAS_F32) or complex32 (QDAS_F16), xs complex64 always; wtab: device N x N complex64 [n + N m] or NULL (ones);
+ * only the upper triangle of xs is written (zero-fill it once).  Device pointers; asynchronous on `stream`. */
+typedef struct qdas_fold_desc {
+    uint64_t T, N;
+    uint64_t strN, strM;
+    int32_t  dtype;       /* QDAS_F32 | QDAS_F16: type of x */
+    int32_t  device;      /* HIP device ordinal, -1 = current */
+    const void *wtab;
+} qdas_fold_desc;
+int  qdas_fold(const qdas_fold_desc *d, const void *x, void *xs, void *stream);
 /* bounds [samples] of the delay error committed by the lateral-mirror / reciprocal mode of the plan: 0 = exact symmetry, > 0 = accepted within
  * the tolerance of QDAS_PLAN_APPROX_SYMMETRY, -1 = that mode is not in use (either pointer may be NULL) */
 int  qdas_plan_symmetry_bound(const qdas_plan *plan, double *mirror_samples, double *reciprocal_samples);

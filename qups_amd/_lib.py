@@ -23,13 +23,13 @@ MAX_APOD = 6
 QDAS_PRE_F32, QDAS_PRE_I16 = 0, 1
 QDAS_CONV_FULL, QDAS_CONV_SAME, QDAS_CONV_VALID, QDAS_CONV_CAUSAL = 0, 1, 2, 3
 QDAS_CONV_X_ONE_COLUMN, QDAS_CONV_X_ONE_SLICE, QDAS_CONV_Y_ONE_COLUMN, QDAS_CONV_Y_ONE_SLICE = 1, 2, 4, 8
-PLAN_NO_RECIPROCAL, PLAN_JIT, PLAN_COPY_INPUTS, PLAN_NO_MIRROR, PLAN_MIRROR_SLAB, PLAN_NO_FOLD, PLAN_APPROX_SYMMETRY = 1, 2, 4, 8, 16, 32, 64
+PLAN_NO_RECIPROCAL, PLAN_JIT, PLAN_COPY_INPUTS, PLAN_NO_MIRROR, PLAN_MIRROR_SLAB, PLAN_NO_FOLD, PLAN_APPROX_SYMMETRY, PLAN_PREFOLDED = 1, 2, 4, 8, 16, 32, 64, 128
 RXAPOD_NONE, RXAPOD_ACCEPTANCE, RXAPOD_COSINE, RXAPOD_FNUMBER_PLANAR, RXAPOD_FNUMBER_ORIENTED = 0, 1, 2, 3, 4
 
 # every symbol include/qdas.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "qdas_plan_create", "qdas_plan_execute", "qdas_plan_execute_frames", "qdas_plan_delays",
-    "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_reciprocal", "qdas_plan_folded", "qdas_plan_symmetry_bound", "qdas_plan_mirror", "qdas_plan_kernel_name", "qdas_plan_set_timing",
+    "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_reciprocal", "qdas_plan_folded", "qdas_fold", "qdas_plan_symmetry_bound", "qdas_plan_mirror", "qdas_plan_kernel_name", "qdas_plan_set_timing",
     "qdas_plan_last_kernel_ms", "qdas_plan_create_sharded", "qdas_plan_execute_sharded", "qdas_plan_sharded_info", "qdas_plan_sharded_mirror",
     "qdas_plan_destroy_sharded", "qdas_DAS", "qdas_DASf", "qdas_DASh", "qdas_delays", "qdas_delaysf",
     "qdas_das_lut", "qdas_wsinterpd", "qdas_shift_sum", "qdas_greens", "qdas_convd", "qdas_convd_len", "qdas_permute3", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_pre_plan_one_pass", "qdas_last_error", "qdas_version", "qdas_device_info",
@@ -64,6 +64,10 @@ class WsDesc(C.Structure):
                 ("w_real", C.c_int32), ("size", C.c_uint64 * 8), ("tstride", C.c_int64 * 8), ("xstride", C.c_int64 * 8),
                 ("wstride", C.c_int64 * 8), ("sum", C.c_uint8 * 8), ("omega", C.c_double), ("extrap", C.c_double),
                 ("t", C.c_void_p), ("w", C.c_void_p), ("x", C.c_void_p), ("ystride", C.c_int64 * 8), ("lane_dim", C.c_int32), ("reserved", C.c_int32)]
+
+
+class FoldDesc(C.Structure):
+    _fields_ = [("T", C.c_uint64), ("N", C.c_uint64), ("strN", C.c_uint64), ("strM", C.c_uint64), ("dtype", C.c_int32), ("device", C.c_int32), ("wtab", C.c_void_p)]
 
 
 class GreensDesc(C.Structure):
@@ -130,6 +134,7 @@ def lib():
     L.qdas_plan_reciprocal.argtypes = [C.c_void_p]
     L.qdas_plan_mirror.argtypes = [C.c_void_p]
     L.qdas_plan_folded.argtypes = [C.c_void_p]
+    L.qdas_fold.argtypes = [C.POINTER(FoldDesc), C.c_void_p, C.c_void_p, C.c_void_p]
     L.qdas_plan_symmetry_bound.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.qdas_plan_kernel_name.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.qdas_plan_set_timing.argtypes = [C.c_void_p, C.c_int]

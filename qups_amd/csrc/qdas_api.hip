@@ -95,6 +95,11 @@ struct qdas_plan {
     const void *fold_wtab = nullptr;
     // tolerance mode (QDAS_PLAN_APPROX_SYMMETRY): bounds [samples] of the delay error the symmetry modes in use commit; 0 = exact symmetry, -1 = mode not in use
     double mirror_bound = -1.0, recip_bound = -1.0;
+    bool prefolded = false;                   // QDAS_PLAN_PREFOLDED: execute is handed the folded frame (qdas_fold) -- no fold pass, no fold buffer
+    // fp16 reciprocal data: the frame is folded into a complex64 copy (fold.hip, fp16 in) and beamformed by an fp32 PREFOLDED child plan into a complex64
+    // image, which is rounded to the plan's complex32 output: the folded fp32 kernels serve fp16 data (C3 with fp16 data 23.7 -> 15 ms)
+    qdas_plan *f16_child = nullptr;
+    void *y32 = nullptr;
     bool fb2_ok = false;                      // frames of a sequence may share launches, 4 or 2 at a time (decided at plan creation)
     bool fb4_off = false;                     // ... but at most pairwise (QDAS_NO_FB4)
     bool fold2_ok = false;                    // folded data: two frames may share a launch
@@ -121,6 +126,7 @@ struct qdas_plan {
 
     ~qdas_plan() {
         if (frames_twin) qdas_plan_destroy(frames_twin);
+        if (f16_child) qdas_plan_destroy(f16_child);
         for (void *p : owned) (void)hipFree(p);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
@@ -592,9 +598,11 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // |tau(n,m) - tau(m,n)| fs <= cinv fs (|r_n - v_n| + |r_m - v_m|) <= 2 cinv fs max|r - v|
         recip_bound = 2.0 * pl->cinv0 * desc->fs * drv;
         if (sym && !(recip_bound <= (sym_tol < 0 ? 0.0 : sym_tol))) sym = 0;
-        rfold = sym && dt == QDAS_F32 && z.N >= 2 && z.N <= 65535 && !(desc->plan_flags & QDAS_PLAN_NO_FOLD) && !getenv("QDAS_NO_FOLD")
+        const bool prefolded = (desc->plan_flags & QDAS_PLAN_PREFOLDED) != 0;
+        rfold = sym && dt == QDAS_F32 && z.N >= 2 && z.N <= 65535 && ((!(desc->plan_flags & QDAS_PLAN_NO_FOLD) && !getenv("QDAS_NO_FOLD")) || prefolded)
                && tile_lds_bytes(dt, 1, z.N, z.M, 0, 0, 0, 0, 1) <= tile_lds_limit(1);
-        if (rfold) {                                    // the plan's folded copy of a frame: without the memory for it, the plan simply does not fold
+        pl->prefolded = prefolded && rfold;
+        if (rfold && !prefolded) {                                    // the plan's folded copy of a frame: without the memory for it, the plan simply does not fold
             void *fbuf = nullptr;
             if (hipMalloc(&fbuf, (size_t)z.T * z.N * z.M * 8) != hipSuccess) { (void)hipGetLastError(); rfold = 0; }
             else { pl->owned.push_back(fbuf); pl->fold_buf = fbuf; }
@@ -604,6 +612,9 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // instantiations were pruned in round 4 --; without QDAS_PLAN_JIT such a plan runs the general kernels
         if (sym && !rfold && dt == QDAS_F32 && !((desc->plan_flags & QDAS_PLAN_JIT) && !getenv("QDAS_NO_JIT"))) sym = 0;
     }
+    if ((desc->plan_flags & QDAS_PLAN_PREFOLDED) && !rfold)
+        return bail(fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_PREFOLDED: a folded frame can only be beamformed by a reciprocal fp32 'DAS' plan without apodization arrays "
+                                            "(transmit elements == receive elements bit for bit, one t0, N == M >= 2; weights belong to qdas_fold)"));
     // Roles of the two apertures (das_tile_impl.h): a stage = one STAGE element x a block of 32 BLOCK elements.  'DAS' / 'SYN': stage =
     // receiver, block = transmits; 'MUL': swapped.  The full sum may run either way, and runs swapped when that gives fewer, fuller
     // stages: plane-wave compounding with a handful of angles (N = 128, M = 9: 128 stages of 9 transmits -> 36 stages of 32 receivers).
@@ -850,7 +861,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             // folded data: with the lateral-mirror mode two window sets -- 32 x 128 samples when every tile of some footprint fits them (launch
             // configuration 17), else 16 x 192 (18) --; when that leaves misfit tiles too (a misfit tile is redone by the generic kernel, which knows
             // nothing of mirror images) or without the mode: one set of 32 x 192 samples (19), misfit tiles to the generic kernel as ever
-            HIPCHK(hipMemset(pl->fold_buf, 0, (size_t)z.T * z.N * z.M * 8));      // (the lower triangle is never written: zeros, not garbage, where a border window reaches into it)
+            if (pl->fold_buf) HIPCHK(hipMemset(pl->fold_buf, 0, (size_t)z.T * z.N * z.M * 8));      // (the lower triangle is never written: zeros, not garbage, where a border window reaches into it)
             if (t.mir) {
                 t.narrow = getenv("QDAS_NO_NARROW") ? 0 : 1;
                 pl->tc = tile_config(dt, 1, t.narrow, 1, 1, 1);
@@ -944,7 +955,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // Tiles that still do not fit (a pixel grid coarser than about lambda/2 -- volumes, previews --, steep delay gradients): fp32 plans
         // try the 384-sample windows of launch configuration 14 (16 transmits per stage, same LDS image); kept if fewer tiles misfit.
         // (a reciprocal plan gives up its mode for them: an image on the generic kernel costs ten times more than the shared index work saves)
-        if (!pl->no_fallback && dt == QDAS_F32 && !bfm && !big && t.narrow != 2 && !getenv("QDAS_NO_WIDE")
+        if (!pl->no_fallback && dt == QDAS_F32 && !bfm && !big && t.narrow != 2 && !getenv("QDAS_NO_WIDE") && !pl->prefolded
             && tile_lds_bytes(dt, 0, t.N, t.M, 2, t.act_bytes ? 1 : 0, t.wtab ? 1 : 0) <= tile_lds_limit(0)
             && ((uint64_t)t.N * t.strN + (uint64_t)tile_config(dt, 0, 2).mb * t.strM) * data_size(dt) + 65536 < (1ull << 31)) {
             const TileParams keep = t;
@@ -1047,6 +1058,37 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             }
         }
     }
+    if (pl->prefolded && pl->kernel == QDAS_KERNEL_TILED && !pl->no_fallback)
+        return bail(fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_PREFOLDED: tiles of this image do not fit the staging windows (they would be redone from the unfolded frame)"));
+    // ---- fp16 reciprocal data on the folded fp32 kernels: an fp32 PREFOLDED child plan over the same geometry and slab; this plan folds each frame into a
+    //      complex64 copy (its weight table applied on the way), the child beamforms it, the complex64 image is rounded to complex32.  If anything of that is
+    //      not available (memory, a child that does not fit) the plan keeps its own fp16 reciprocal kernels.
+    if (pl->kernel == QDAS_KERNEL_TILED && dt == QDAS_F16 && pl->tp.sym && !pl->tp.syn && !pl->tp.bf && !(desc->plan_flags & QDAS_PLAN_NO_FOLD) && !getenv("QDAS_NO_FOLD")
+        && !getenv("QDAS_NO_FOLD16") && z.N >= 2 && z.N <= 65535) {
+        qdas_desc d = *desc;
+        const GenericParams &gg = pl->gp;
+        uint64_t acs[6] = {gg.cst[0], gg.cst[1], gg.cst[2], gg.cst[3], gg.cst[4], gg.cst[5]};
+        d.sz.dtype = QDAS_F32; d.sz.S = 0;
+        d.Pi = gg.Pi; d.Pr = gg.Pr; d.Pv = gg.Pv; d.Nv = gg.Nv; d.cinv = gg.cinv; d.apod = nullptr; d.rx_normals = nullptr; d.rx_apod_kind = 0; d.acstride = acs;
+        d.mem = QDAS_MEM_DEVICE; d.device = pl->device; d.y_ld = 0;
+        d.plan_flags = (d.plan_flags | QDAS_PLAN_PREFOLDED) & ~(QDAS_PLAN_COPY_INPUTS | QDAS_PLAN_NO_FOLD);
+        const std::string keep = g_err;
+        qdas_plan *child = nullptr;
+        void *fb = nullptr, *yb = nullptr;
+        if (qdas_plan_create(&child, &d) == QDAS_OK && child && child->kernel == QDAS_KERNEL_TILED && child->prefolded
+            && hipMalloc(&fb, (size_t)z.T * z.N * z.M * 8) == hipSuccess && hipMalloc(&yb, (size_t)child->y_ld * 8 + 16) == hipSuccess
+            && hipMemset(fb, 0, (size_t)z.T * z.N * z.M * 8) == hipSuccess) {
+            pl->owned.push_back(fb); pl->owned.push_back(yb);
+            pl->fold_buf = fb; pl->y32 = yb; pl->f16_child = child;
+            pl->fold_wtab = pl->tp.wtab;               // (this plan's N x M table, float2: applied by the fold pass)
+        } else {
+            (void)hipGetLastError();
+            if (fb) (void)hipFree(fb);
+            if (yb) (void)hipFree(yb);
+            if (child) qdas_plan_destroy(child);
+        }
+        g_err = keep;
+    }
     pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->tp.mir && !pl->tp.stage_shift && pl->tp.narrow != 2 && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
     // folded data: TWO frames per launch (launch configurations 20 / 21 -- tap index and weights serve two folded traces of two frames, in mirror mode four);
     // the mirror mode needs the 128-sample windows for it (four window sets), and the plan a second folded copy of a frame (allocated at the first stream)
@@ -1064,7 +1106,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     // the plan keeps no pointer into caller memory it does not need: host arrays were copied; device arrays are used in place
     // (g.* / tp.*: they must stay valid for the life of the plan unless QDAS_PLAN_COPY_INPUTS made plan-owned copies)
     pl->mirror_bound = mirror_bound; pl->recip_bound = recip_bound;
-    if (pl->fold_buf && !(pl->kernel == QDAS_KERNEL_TILED && pl->tp.fold)) {      // (the plan left the fold after all: wide windows, strides, generic kernel)
+    if (pl->fold_buf && !pl->f16_child && !(pl->kernel == QDAS_KERNEL_TILED && pl->tp.fold)) {      // (the plan left the fold after all: wide windows, strides, generic kernel)
         for (size_t k = 0; k < pl->owned.size(); ++k) if (pl->owned[k] == pl->fold_buf) { pl->owned.erase(pl->owned.begin() + (long)k); break; }
         (void)hipFree(pl->fold_buf);
         pl->fold_buf = nullptr;
@@ -1085,6 +1127,7 @@ extern "C" int qdas_plan_kernel(const qdas_plan *pl) { return pl ? pl->kernel : 
 
 extern "C" int qdas_plan_fallback_tiles(const qdas_plan *pl, uint64_t *n) {
     if (!pl || !n) return fail(QDAS_EINVAL, "null argument");
+    if (pl->f16_child) return qdas_plan_fallback_tiles(pl->f16_child, n);
     *n = 0;
     if (pl->kernel != QDAS_KERNEL_TILED || !pl->fallback) return QDAS_OK;
     uint32_t c = 0;
@@ -1095,6 +1138,7 @@ extern "C" int qdas_plan_fallback_tiles(const qdas_plan *pl, uint64_t *n) {
 
 extern "C" int qdas_plan_tile_shape(const qdas_plan *pl, int *tile_z, int *tile_cols, int *wave_z, int *ksplit) {
     if (!pl || !tile_z || !tile_cols) return fail(QDAS_EINVAL, "null argument");
+    if (pl->f16_child) return qdas_plan_tile_shape(pl->f16_child, tile_z, tile_cols, wave_z, ksplit);
     const bool tiled = pl->kernel == QDAS_KERNEL_TILED;
     *tile_z = tiled ? (1 << pl->tp.tz_log2) : 0;
     *tile_cols = tiled ? (int)pl->tile_cols : 0;
@@ -1103,22 +1147,45 @@ extern "C" int qdas_plan_tile_shape(const qdas_plan *pl, int *tile_z, int *tile_
     return QDAS_OK;
 }
 
-extern "C" int qdas_plan_mirror(const qdas_plan *pl) { return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.mir ? 1 : 0; }
+extern "C" int qdas_plan_mirror(const qdas_plan *pl) { if (pl && pl->f16_child) return qdas_plan_mirror(pl->f16_child); return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.mir ? 1 : 0; }
 
 extern "C" int qdas_plan_reciprocal(const qdas_plan *pl) { return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.sym ? 1 : 0; }
 
 extern "C" int qdas_plan_symmetry_bound(const qdas_plan *pl, double *mirror_samples, double *reciprocal_samples) {
     if (!pl) return fail(QDAS_EINVAL, "null plan");
+    if (pl->f16_child) return qdas_plan_symmetry_bound(pl->f16_child, mirror_samples, reciprocal_samples);
     const bool tiled = pl->kernel == QDAS_KERNEL_TILED;
     if (mirror_samples) *mirror_samples = (tiled && pl->tp.mir) ? pl->mirror_bound : -1.0;
     if (reciprocal_samples) *reciprocal_samples = (tiled && pl->tp.sym) ? pl->recip_bound : -1.0;
     return QDAS_OK;
 }
 
-extern "C" int qdas_plan_folded(const qdas_plan *pl) { return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.fold ? 1 : 0; }
+extern "C" int qdas_plan_folded(const qdas_plan *pl) { if (pl && pl->f16_child) return 1; return pl && pl->kernel == QDAS_KERNEL_TILED && pl->tp.fold ? 1 : 0; }
+
+// ---- the reciprocity fold as an entry of its own (qdas.h): for hosts that fold once and hand folded frames to QDAS_PLAN_PREFOLDED plans
+extern "C" int qdas_fold(const qdas_fold_desc *d, const void *x, void *xs, void *stream) {
+    if (!d || !x || !xs) return fail(QDAS_EINVAL, "null argument");
+    if (d->dtype != QDAS_F32 && d->dtype != QDAS_F16) return fail(QDAS_EINVAL, "qdas_fold: complex64 or complex32 (fp16) frames");
+    if (d->N > 65535) return fail(QDAS_EUNSUPPORTED, "qdas_fold: at most 65535 elements");
+    DeviceGuard guard(d->device);
+    HIPCHK(guard.err);
+    HIPCHK(launch_fold(x, xs, d->wtab, d->T, d->N, d->strN ? d->strN : d->T, d->strM ? d->strM : d->T * d->N, (hipStream_t)stream, d->dtype == QDAS_F16));
+    return QDAS_OK;
+}
 
 extern "C" int qdas_plan_kernel_name(const qdas_plan *pl, char *buf, size_t len) {
     if (!pl || !buf || !len) return fail(QDAS_EINVAL, "null argument");
+    if (pl->f16_child) {                                // "das_tile_kernel<interp=3,f16>f32,sym,fold,...": fp16 data on the folded fp32 kernels
+        char tmp[256];
+        int rc = qdas_plan_kernel_name(pl->f16_child, tmp, sizeof tmp);
+        if (rc) return rc;
+        std::string nm(tmp);
+        const size_t at = nm.find(",f32");
+        if (at != std::string::npos) nm.replace(at, 4, ",f16>f32");
+        if (pl->fold_wtab && nm.find(",wtab") == std::string::npos) { const size_t f = nm.find(",fold"); if (f != std::string::npos) nm.insert(f + 5, ",wtab"); }
+        snprintf(buf, len, "%s", nm.c_str());
+        return QDAS_OK;
+    }
     const qdas_sizes &z = pl->d.sz;
     const char *dts = z.dtype == QDAS_F64 ? "f64" : (z.dtype == QDAS_F32 ? "f32" : "f16");
     if (pl->kernel == QDAS_KERNEL_TILED) {
@@ -1148,11 +1215,21 @@ static int hip_rc(hipError_t e) { HIPCHK(e); return QDAS_OK; }
 // x + x_fstride bytes / y + y_fstride elements and shares tap indices and weights with frame 0 (das_tile_impl.h "FB2").
 static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s, int nf = 1, uint64_t x_fstride = 0, uint64_t y_fstride = 0) {
     const qdas_sizes &z = pl->d.sz;
+    if (pl->f16_child && nf == 1) {                     // fp16 reciprocal data: fold into complex64, the folded fp32 kernels, round the image to complex32
+        const TileParams &c = pl->f16_child->tp;
+        HIPCHK(launch_fold(x, pl->fold_buf, pl->fold_wtab, z.T, z.N, c.strN, c.strM, s, 1));
+        int rc = run_frame(pl->f16_child, pl->fold_buf, pl->y32, s);
+        if (rc) return rc;
+        HIPCHK(launch_y32_to_y16(pl->y32, y, pl->f16_child->y_ld, s));
+        return QDAS_OK;
+    }
     if (pl->kernel == QDAS_KERNEL_TILED) {
         TileParams t = pl->tp;
         t.x = x; t.y = y;
         t.nfr = nf; t.x_fstride = x_fstride; t.y_fstride = y_fstride;
-        if (t.fold) {                                   // the reciprocity fold of this frame (fold.hip): one pass over HBM, then the fused kernel on the folded copy
+        if (t.fold && pl->prefolded) {                  // (the caller folded the frames: qdas_fold)
+            if (!pl->no_fallback) return fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_PREFOLDED: tiles of this image do not fit the staging windows and would need the unfolded frame");
+        } else if (t.fold) {                            // the reciprocity fold of this frame (fold.hip): one pass over HBM, then the fused kernel on the folded copy
             HIPCHK(launch_fold(x, pl->fold_buf, pl->fold_wtab, z.T, z.N, t.strN, t.strM, s));
             t.x = pl->fold_buf;
             if (nf == 2) {                              // (two frames per launch: the second frame's folded copy; the kernel reads it x_fstride BYTES after the first)
@@ -1244,7 +1321,8 @@ extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, u
     }
     // frame pairs share one launch (device-resident data, tiled kernel, not the reciprocal mode; QDAS_NO_FB2 disables)
     bool pairs_ok = pl->fb2_ok && x_stride * ds < (1ull << 40);
-    if (pl->fold2_ok && F >= 2) {                       // folded data: frame pairs share a launch; the second folded copy is made now (once)
+    if (pl->fold2_ok && F >= 2 && pl->prefolded) pairs_ok = x_stride * ds < (1ull << 40);      // (the caller's folded frames, as they lie)
+    else if (pl->fold2_ok && F >= 2) {                  // folded data: frame pairs share a launch; the second folded copy is made now (once)
         if (!pl->fold_buf2) {
             const size_t fb = (size_t)z.T * z.N * z.M * 8;
             void *p2 = nullptr;

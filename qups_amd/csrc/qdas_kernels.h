@@ -43,7 +43,8 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
 
 // ---- reciprocity fold (fold.hip): xs[:,n,m] = w[n,m] x[:,n,m] + w[m,n] x[:,m,n] for n < m, xs[:,n,n] = w[n,n] x[:,n,n]; complex64, traces of T samples at
 //      (n*strN + m*strM) samples; wtab: N x N float2 [n + N*m] or null (ones); only the upper triangle n <= m of xs is written
-hipError_t launch_fold(const void *x, void *xs, const void *wtab, uint64_t T, uint64_t N, uint64_t strN, uint64_t strM, hipStream_t s);
+hipError_t launch_fold(const void *x, void *xs, const void *wtab, uint64_t T, uint64_t N, uint64_t strN, uint64_t strM, hipStream_t s, int in_f16 = 0);   // in_f16: x holds fp16 samples (xs is complex64 always)
+hipError_t launch_y32_to_y16(const void *y32, void *y16, uint64_t n, hipStream_t s);       // complex64 image -> complex32 image (fp16 plans on the folded fp32 kernels)
 
 // ---- split-delay kernel (das_lut.hip)
 struct LutParams {

@@ -437,7 +437,7 @@ class DasPlan:
 
     def __init__(self, prob: DasProblem, device=None, kernel: int = _lib.KERNEL_AUTO,
                  i_begin: int = 0, i_count: int = 0, reciprocal: bool = True, jit: bool = False, mirror: bool = True, mirror_slab: bool = False,
-                 fold: bool = True, approx_symmetry: bool = False):
+                 fold: bool = True, approx_symmetry: bool = False, prefolded: bool = False):
         """``mirror_slab``: the slab ``[i_begin, i_begin + i_count)`` AND its mirror image in one plan (``QDAS_PLAN_MIRROR_SLAB``, ``include/qdas.h``):
         the output holds ``2 * i_count`` pixels, slab A then slab B; raises when the lateral-mirror mode is not available for the problem."""
         torch = _torch()
@@ -467,7 +467,7 @@ class DasPlan:
         d.i_begin, d.i_count, d.y_ld = self.i_begin, self.i_count, 0
         d.plan_flags = ((0 if reciprocal else _lib.PLAN_NO_RECIPROCAL) | (_lib.PLAN_JIT if jit else 0) | (0 if mirror else _lib.PLAN_NO_MIRROR)
                         | (_lib.PLAN_MIRROR_SLAB if mirror_slab else 0) | (0 if fold else _lib.PLAN_NO_FOLD)
-                        | (_lib.PLAN_APPROX_SYMMETRY if approx_symmetry else 0))
+                        | (_lib.PLAN_APPROX_SYMMETRY if approx_symmetry else 0) | (_lib.PLAN_PREFOLDED if prefolded else 0))
         if prob.rx_apod is not None:                       # generated receive apodization (qdas.h QDAS_RXAPOD_*)
             d.rx_apod_kind = prob.rx_apod["kind"]
             d.rx_apod_p[0], d.rx_apod_p[1] = prob.rx_apod["p"]

@@ -193,8 +193,11 @@ def test_reciprocal_and_mirror_mode_together(N, interp, prec, extra, jit, tmp_pa
             names.append((plan.kernel_name(), plan.reciprocal, plan.mirror, plan.folded))
             assert plan.fallback_tiles() == 0
     assert names[0][1] and names[0][2] and ",sym" in names[0][0] and ",mirror" in names[0][0], names
-    assert names[0][3] == (prec == "single") and (",fold" in names[0][0]) == (prec == "single"), names
-    assert not names[1][3] and not names[3][3] and not names[4][3] and names[2][3] == (prec == "single"), names
+    # (fp16 data: folded into a complex64 copy and beamformed by the folded fp32 kernels -- "f16>f32" in the name -- when N is a multiple of 16)
+    fold0 = prec == "single" or old_ok
+    assert names[0][3] == fold0 and (",fold" in names[0][0]) == fold0, names
+    assert (prec == "single") or ("f16>f32" in names[0][0]) == fold0, names
+    assert not names[1][3] and not names[3][3] and not names[4][3] and names[2][3] == fold0, names
     # (unfolded fp32 reciprocal plans exist as hiprtc builds only -- round 4 pruned their prebuilt instantiations --: without one, the general kernels)
     unfolded_recip = old_ok and (jit or prec == "halfT")
     assert names[1][1] == unfolded_recip and names[3][1] == unfolded_recip, names
@@ -530,3 +533,56 @@ def test_symmetry_within_a_tolerance(monkeypatch):
     assert mir and 0.02 < bnd[0] < 0.03, (name, bnd)                         # (the receive AND the transmit element: 2 x 0.013 sample)
     e6 = rel_err(y6, r3)
     assert 1e-5 < e6 < 5e-3, e6
+
+
+@pytest.mark.parametrize("prec", ["single", "halfT"])
+def test_prefolded_plans_and_the_fold_entry(prec):
+    """``qdas_fold`` + ``QDAS_PLAN_PREFOLDED``: a host that folds once per acquisition (and replicates the FOLDED frame -- half the bytes -- to several
+    devices) hands folded frames to plans that run no fold pass of their own; the image is the folding plan's, bit for bit (the same kernels).  fp16 frames
+    fold into complex64 (the plan for the folded frame is an fp32 plan)."""
+    import ctypes as C
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import DasPlan, build_problem, parse_options, _lib
+    from qups_amd.das_spec import _colmajor, _cast_data
+    case = make_case(seq="FSA", interp="lanczos3", seed=17, N=32, I1=150, I2=40)
+    x = case["x"]
+    if prec == "halfT":
+        x = (x.real.astype(np.float16).astype(np.float32) + 1j * x.imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
+    xt = torch.from_numpy(x)
+    T, N, M = x.shape
+    mk = lambda p: build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"],
+                                 parse_options(xt, list(case["opt"]) + ["interp", "lanczos3", "input-precision", p]))
+    with DasPlan(mk(prec), kernel=2) as plan:
+        assert plan.folded
+        xc = _colmajor(_cast_data(xt, prec, plan.device))                    # (M, N, T) complex(prec)
+        y_fold = plan.execute_colmajor(xc, 1)
+        y_fold = (torch.view_as_real(y_fold).float() if prec == "halfT" else torch.view_as_real(y_fold)).cpu().numpy()
+    # the host's own fold, then a PREFOLDED fp32 plan
+    xs = torch.zeros((M, N, T), dtype=torch.complex64, device="cuda")
+    d = _lib.FoldDesc(T, N, 0, 0, 2 if prec == "halfT" else 1, -1, None)
+    _lib.check(_lib.lib().qdas_fold(C.byref(d), C.c_void_p(xc.data_ptr()), C.c_void_p(xs.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    xsc = xs.cpu().numpy()                                                    # [m, n, t]
+    xr = x.transpose(2, 1, 0)                                                 # [m, n, t]
+    for (n, m) in ((3, 7), (0, 31), (5, 5)):
+        want = xr[m, n] + (xr[n, m] if n != m else 0)
+        assert np.allclose(xsc[m, n], want, rtol=0, atol=1e-6 * np.abs(want).max())
+    assert not xsc[3, 7].any()                                                # (rx 7 > tx 3: the lower triangle is not written)
+    with DasPlan(mk("single"), kernel=2, prefolded=True) as pp:
+        assert pp.folded and pp.reciprocal
+        y_pre = torch.view_as_real(pp.execute_colmajor(xs, 1)).cpu().numpy()
+    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], x, case["t0"], case["fs"], cinv_f32(case["c"]),
+                     VS=case["VS"], DV=case["DV"], interp="lanczos3").reshape(-1, order="F")
+    cplx = lambda a: (a[..., 0] + 1j * a[..., 1]).reshape(-1)
+    assert rel_err(cplx(y_pre), ref) <= 2e-5
+    assert rel_err(cplx(y_fold), ref) <= (2e-3 if prec == "halfT" else 2e-5)
+    if prec == "single":
+        assert np.array_equal(y_pre, y_fold)                                  # the same fold, the same kernel
+    else:
+        assert rel_err(cplx(y_fold), cplx(y_pre)) <= 1e-3                     # (the fp16 plan rounds its image to complex32)
+    # a problem that is not reciprocal cannot take folded frames
+    pw = make_case(seq="PW", interp="linear", seed=1, N=16, M=16, I1=64, I2=16)
+    xp = torch.from_numpy(pw["x"])
+    prob = build_problem("DAS", pw["Pi"], pw["Pr"], pw["Pv"], pw["Nv"], tuple(xp.shape), pw["t0"], pw["fs"], pw["c"], parse_options(xp, list(pw["opt"]) + ["interp", "linear"]))
+    with pytest.raises(Exception, match="PREFOLDED"):
+        DasPlan(prob, kernel=2, prefolded=True)

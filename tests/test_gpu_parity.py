@@ -1028,11 +1028,11 @@ def test_tile_shape_follows_the_axial_pitch():
 
 
 @pytest.mark.parametrize("ks", [2, 3, 4, 8])
-@pytest.mark.parametrize("seq,N,prec,mask", [("FSA", 128, "single", False), ("FSA", 72, "single", False), ("FSA", 32, "halfT", False), ("PW", 16, "single", True),
+@pytest.mark.parametrize("seq,N,prec,mask", [("FSA", 128, "single", False), ("FSA", 72, "single", False), ("FSA", 64, "halfT", False), ("PW", 16, "single", True),
                                              ("DV", 16, "halfT", True)])
 def test_aperture_split(ks, seq, N, prec, mask, monkeypatch):
-    """ksplit workgroups per tile (reciprocal mode: interleaved transmit blocks -- of 32 transmits on the reciprocity-folded fp32 frame, the last one
-    partial at N = 72; of 16 for fp16 data --; otherwise receiver ranges) + fixed-order reduce"""
+    """ksplit workgroups per tile (reciprocal mode: interleaved transmit blocks -- of 32 transmits on the reciprocity-folded frame, the last one
+    partial at N = 72; fp16 data: folded into complex64 --; otherwise receiver ranges) + fixed-order reduce"""
     monkeypatch.setenv("QDAS_KSPLIT", str(ks))
     geo = dict(pitch=0.1e-3, zlim=(10e-3, 16e-3)) if N > 32 else dict(zlim=(4e-3, 14e-3))
     case = make_case(seq=seq, interp="lanczos3", seed=31, N=N, I1=100, I2=21, xspan=3e-3, **geo)
@@ -1047,7 +1047,7 @@ def test_aperture_split(ks, seq, N, prec, mask, monkeypatch):
         xq = xq.real.astype(np.float16).astype(np.float64) + 1j * xq.imag.astype(np.float16).astype(np.float64)
     ref = run_oracle(case, x=xq, apod=apod)
     out, plan = run_das(case, kernel=2, prec=prec, apod=apod)
-    cap = min(8, ((N + 31) // 32 if prec == "single" else N // 16) if seq == "FSA" else N)
+    cap = min(8, (N + 31) // 32 if seq == "FSA" else N)              # (fp16 reciprocal data run the folded fp32 kernels too)
     auto = 1 << (cap.bit_length() - 1)                         # tiny image: the plan itself splits as far as it may
     assert plan.aperture_split() == (ks if ks <= cap else auto)
     assert plan.fallback_tiles() == 0
