@@ -24,6 +24,10 @@
 #endif
 #include "qdas_kernels.h"
 #include "jit.h"
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <set>
 
 namespace qdas {
 
@@ -62,6 +66,20 @@ __global__ void __launch_bounds__(256) tile_reduce_kernel(const float2 *part, ST
 }
 
 
+
+// Which prebuilt instantiations does a workload launch?  $QDAS_KERNEL_CENSUS=<file> appends one line "ci interp sample_bytes fm wt probe" per distinct
+// instantiation and process (tools/kernel_census.py sums the files of a test run: the prebuilt matrix is what the suite and the benches use, the rest
+// of the template's variants are built on demand -- das_tile_cfg.h tile_prebuilt).
+void tile_census(int ci, int interp, int sample_bytes, bool fm, bool wt, bool probe) {
+    static const char *path = getenv("QDAS_KERNEL_CENSUS");
+    if (!path || !*path) return;
+    static std::mutex mu;
+    static std::set<uint32_t> seen;
+    const uint32_t key = (uint32_t)ci | ((uint32_t)interp << 8) | ((uint32_t)sample_bytes << 12) | (fm ? 1u << 20 : 0u) | (wt ? 1u << 21 : 0u) | (probe ? 1u << 22 : 0u);
+    std::lock_guard<std::mutex> lk(mu);
+    if (!seen.insert(key).second) return;
+    if (FILE *f = fopen(path, "a")) { fprintf(f, "%d %d %d %d %d %d\n", ci, interp, sample_bytes, (int)fm, (int)wt, (int)probe); fclose(f); }
+}
 
 TileConfig tile_config(int dtype, int sym, int narrow, int fb, int mirq, int fold) {
     const Cfg &g = CFGS[cfg_index(dtype, sym, fb, narrow, mirq, fold)];

@@ -893,6 +893,8 @@ das_tile_kernel(const TileParams P) {
 }
 
 #ifndef __HIPCC_RTC__
+// $QDAS_KERNEL_CENSUS=<file>: every distinct prebuilt instantiation a process launches is appended to <file> (das_tile.hip; tools/kernel_census.py)
+void tile_census(int ci, int interp, int sample_bytes, bool fm, bool wt, bool probe);
 template <int INTERP, typename ST, int CI>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
     constexpr Cfg G = CFGS[CI];
@@ -901,6 +903,7 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
     constexpr bool SYM = (CI == 1 || CI == 7 || CI == 8 || MIRQ || FOLD), FB2 = (CI == 3 || CI == 4 || CI == 20 || CI == 21), FB4 = (CI == 5 || CI == 6), BIG = (CI == 9), LUT = (CI == 10 || CI == 11), BFM = (CI == 12);
     const bool fm = P.fmod != 0.0, wt = P.wtab != nullptr;
     const dim3 g(ntiles * (P.probe ? 1u : P.ksplit)), b(G.waves * 64);
+    tile_census(CI, INTERP, (int)sizeof(ST), fm, wt, P.probe != 0);
 #define QDAS_LAUNCH(FM, WT) QDAS_LAUNCH_P(FM, WT, false)
 #define QDAS_LAUNCH_P(FM, WT, PR)                                                                        \
     do {                                                                                                 \
