@@ -461,6 +461,18 @@ void qdas_pre_plan_destroy(qdas_pre_plan *plan);
  * the output once); 0: hipFFT passes (any other length, or QDAS_PRE_HIPFFT=1 in the environment) */
 int  qdas_pre_plan_one_pass(const qdas_pre_plan *plan);
 
+/* ---- Variants of the fused kernel that are built on demand.  libqdas.so carries the instantiations the BASELINE configurations and frame streams
+ * launch (csrc/das_tile_cfg.h TILE_PREBUILT); any other point of the template's matrix -- launch configuration `cfg` (das_tile_cfg.h) x interpolator
+ * flag x remodulation x weight table -- is compiled by hiprtc when a plan first needs it (qdas_plan_create; ~2 s, then cached in memory and under
+ * $QDAS_CACHE_DIR | ~/.cache/qdas), as the reference compiles its kernels per UltrasoundSystem (src/UltrasoundSystem.m:5527-5625).  This entry
+ * builds one variant ahead of time (deployment, test sessions; `python -m qups_amd.warm` runs it over a list with one process per core).
+ * Returns 0: built or already cached, 1: failed (qdas_last_error), 2: libqdas.so carries it, 3: no such variant.  Needs no device.
+ * Without libhiprtc.so (or with QDAS_NO_LAZY=1) a plan that needs such a variant runs the generic kernel; qdas_last_error() after
+ * qdas_plan_create says so, and a QDAS_KERNEL_TILED request fails with QDAS_EUNSUPPORTED. */
+int  qdas_kernel_variant_build(int cfg, int interp, int fmod, int wtab);
+/* 1: libqdas.so carries the variant, 0: it is built on demand, -1: no such variant */
+int  qdas_kernel_variant_prebuilt(int cfg, int interp, int fmod, int wtab);
+
 const char *qdas_last_error(void);
 int  qdas_version(void);
 /* device properties the host side reports next to measurements */

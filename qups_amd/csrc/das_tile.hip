@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <set>
+#include <string>
 
 namespace qdas {
 
@@ -81,6 +82,19 @@ void tile_census(int ci, int interp, int sample_bytes, bool fm, bool wt, bool pr
     if (FILE *f = fopen(path, "a")) { fprintf(f, "%d %d %d %d %d %d\n", ci, interp, sample_bytes, (int)fm, (int)wt, (int)probe); fclose(f); }
 }
 
+// Resolving a plan's kernels without launching them (qdas_plan_create): instantiations that libqdas.so does not carry are compiled here, so that
+// no execute ever waits for a compiler (das_tile_impl.h QDAS_LAUNCH_P, jit.hip lazy_tile_launch).
+static thread_local bool g_prepare_only = false;
+bool tile_prepare_only() { return g_prepare_only; }
+hipError_t prepare_tile(const TileParams &P, int dtype, unsigned ntiles, std::string *built) {
+    lazy_tile_reset();
+    g_prepare_only = true;
+    const hipError_t e = launch_tile(P, dtype, ntiles ? ntiles : 1u, nullptr);
+    g_prepare_only = false;
+    if (built) *built = lazy_tile_last();
+    return e;
+}
+
 TileConfig tile_config(int dtype, int sym, int narrow, int fb, int mirq, int fold) {
     const Cfg &g = CFGS[cfg_index(dtype, sym, fb, narrow, mirq, fold)];
     TileConfig c;
@@ -117,7 +131,7 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
         const size_t lds64 = tile_lds_bytes(0, 0, P.N, P.M, 0);
         if (lds64 > tile_lds_limit(0)) return hipErrorInvalidValue;
         hipError_t e64 = jit ? jit_launch(jit, P, ntiles * P.ksplit, (unsigned)CFGS[13].waves * 64u, lds64, s) : launch_tile_f64(P, ntiles, lds64, s);
-        if (e64 != hipSuccess || P.probe || P.ksplit <= 1) return e64;
+        if (e64 != hipSuccess || P.probe || P.ksplit <= 1 || g_prepare_only) return e64;
         tile_reduce_kernel_f64<<<(unsigned)((P.i_count + 255) / 256), 256, 0, s>>>((const double2 *)P.part, (double2 *)P.y, P.i_count, P.ksplit);
         return hipGetLastError();
     }
@@ -149,7 +163,7 @@ hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStrea
                  : nf == 4 ? (dtype == 2 ? launch_tile_f16x4(P, ntiles, lds, s) : launch_tile_f32x4(P, ntiles, lds, s))
                  : nf == 2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))
                            : (dtype == 2 ? launch_tile_f16(P, ntiles, lds, s) : narrow == 2 ? launch_tile_f32w(P, ntiles, lds, s) : (P.bf && !P.probe) ? launch_tile_bf(P, ntiles, lds, s) : (P.big && !P.probe) ? launch_tile_f32big(P, ntiles, lds, s) : launch_tile_f32(P, ntiles, lds, s));
-    if (e != hipSuccess || P.probe || P.ksplit <= 1 || P.syn || P.bf) return e;   // ('SYN' planes are accumulated in place, 'BF' planes stored by their owners)
+    if (e != hipSuccess || P.probe || P.ksplit <= 1 || P.syn || P.bf || g_prepare_only) return e;   // ('SYN' planes are accumulated in place, 'BF' planes stored by their owners)
     const uint64_t oc = P.mir == 2 ? 2 * P.i_count : P.i_count;     // pixels the plan writes (a mirror slab: slab A and its image)
     const unsigned rb = (unsigned)((oc + 255) / 256);
     for (int f = 0; f < nfr; ++f) {                      // partial images: [split][frame][pixel]

@@ -893,8 +893,12 @@ das_tile_kernel(const TileParams P) {
 }
 
 #ifndef __HIPCC_RTC__
+}  // namespace qdas
+#include "jit.h"
+namespace qdas {
 // $QDAS_KERNEL_CENSUS=<file>: every distinct prebuilt instantiation a process launches is appended to <file> (das_tile.hip; tools/kernel_census.py)
 void tile_census(int ci, int interp, int sample_bytes, bool fm, bool wt, bool probe);
+bool tile_prepare_only();          // das_tile.hip: this thread is resolving a plan's kernels (TilePrepare), not launching
 template <int INTERP, typename ST, int CI>
 static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds, hipStream_t s) {
     constexpr Cfg G = CFGS[CI];
@@ -905,12 +909,19 @@ static hipError_t launch_tile_i(const TileParams &P, unsigned ntiles, size_t lds
     const dim3 g(ntiles * (P.probe ? 1u : P.ksplit)), b(G.waves * 64);
     tile_census(CI, INTERP, (int)sizeof(ST), fm, wt, P.probe != 0);
 #define QDAS_LAUNCH(FM, WT) QDAS_LAUNCH_P(FM, WT, false)
+    // instantiations libqdas.so does not carry (das_tile_cfg.h tile_prebuilt) are built on demand from the same template arguments (jit.hip lazy_tile_launch);
+    // tile_prepare_only(): resolve the kernel, launch nothing (plan creation: the first execute of a plan never compiles)
 #define QDAS_LAUNCH_P(FM, WT, PR)                                                                        \
     do {                                                                                                 \
-        auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, FB4, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR, BIG && !PR, LUT, BFM && !PR, MIRQ && !PR, FOLD && !PR>; \
-        hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e != hipSuccess) return e;                                                                   \
-        kfn<<<g, b, lds, s>>>(P);                                                                        \
+        if constexpr (tile_prebuilt(CI, INTERP, FM, WT, PR)) {                                           \
+            if (tile_prepare_only()) return hipSuccess;                                                  \
+            auto kfn = das_tile_kernel<INTERP, ST, FM, WT, SYM, FB2, FB4, G.waves, G.mb, G.w, G.nbuf, G.psz, G.bpc, PR, BIG && !PR, LUT, BFM && !PR, MIRQ && !PR, FOLD && !PR>; \
+            hipError_t e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                               \
+            kfn<<<g, b, lds, s>>>(P);                                                                    \
+        } else {                                                                                         \
+            return lazy_tile_launch(LazySpec{INTERP, (int)sizeof(ST), FM, WT, CI, PR}, P, g.x, b.x, lds, s, tile_prepare_only()); \
+        }                                                                                                \
     } while (0)
     if (P.probe) {
         if constexpr (FB2 || FB4) return hipErrorInvalidValue;    // the window fit does not depend on the frame count: probes use one frame

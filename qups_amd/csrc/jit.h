@@ -24,6 +24,15 @@ struct JitSpec {
     int fold;                                           // reciprocity-folded data (TileCfg::FOLD; with mirq: two window sets)
 };
 
+// One point of the template's matrix as the prebuilt instantiations name it: built on demand when libqdas.so does not carry it (jit.hip)
+struct LazySpec { int interp, sample_bytes, fm, wt, ci, probe; };
+std::string lazy_tile_source(const LazySpec &k);
+hipError_t lazy_tile_launch(const LazySpec &k, const TileParams &P, unsigned grid, unsigned block, size_t lds, hipStream_t s, bool prepare_only);
+void lazy_tile_reset();
+const std::string &lazy_tile_last();
+std::string jit_compile_source(const std::string &src, std::vector<char> *code, std::string *key_out, bool use_disk);
+std::string jit_get_kernel_source(const std::string &src, int device, hipFunction_t *fn, std::string *key_out);
+
 std::string jit_source(const JitSpec &k);
 // "" on success, else the reason (hiprtc missing, compile log, ...)
 std::string jit_compile(const JitSpec &k, std::vector<char> *code, std::string *key_out, bool use_disk = true);

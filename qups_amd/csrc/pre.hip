@@ -449,4 +449,147 @@ int pre_execute(PrePlan *p, const void *x, void *y, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : 3;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- FFT convolution (convd, long filters)
+// convd of complex64 traces with ONE filter (ChannelData.filter's band-pass: reference kern/convd.m + src/convd.cu:95-146 form every product, M x N per
+// trace) through the same LDS-resident transform: a trace is read once, zero-padded to a length Nf >= M + N - 1 that the stage list above takes,
+// transformed, multiplied by the filter's spectrum, transformed back (ifft(Z) = conj(fft(conj(Z))) / Nf) and the outputs [off, off + L) of the linear
+// convolution are written -- O(Nf log Nf) per trace instead of M x N products: from about a hundred taps on the direct kernel (conv.hip, bound by
+// packed-FMA issue) is the slower one.  One trace per workgroup.  The spectrum H (times 1 / Nf) and the twiddle table are made on the stream by two
+// tiny kernels in double precision; nothing is synchronised.  Rounding: a few 1e-7 of the largest output, like the direct sum of fp32 products.
+struct FftConvArgs {
+    const float2 *x; float2 *z; const float2 *H; const float2 *tw;
+    uint32_t M, N, off, L; uint64_t K;
+    FftStages st;
+};
+
+__global__ void __launch_bounds__(256) fftconv_tables_kernel(const void *taps, int taps_real, uint32_t ntaps, uint32_t N, float2 *H, float2 *tw) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    double sn, cs;
+    sincospi(-2.0 * (double)k / (double)N, &sn, &cs);
+    tw[k] = make_float2((float)cs, (float)sn);
+    double re = 0.0, im = 0.0;
+    for (uint32_t n = 0; n < ntaps; ++n) {
+        const double yr = taps_real ? (double)((const float *)taps)[n] : (double)((const float2 *)taps)[n].x;
+        const double yi = taps_real ? 0.0 : (double)((const float2 *)taps)[n].y;
+        sincospi(-2.0 * (double)(((uint64_t)k * n) % N) / (double)N, &sn, &cs);
+        re += yr * cs - yi * sn; im += yr * sn + yi * cs;
+    }
+    H[k] = make_float2((float)(re / (double)N), (float)(im / (double)N));
+}
+
+//   ING: opens the forward transform (points from the trace in HBM, zero beyond M);  WGT: opens the inverse one (times H, conjugated);
+//   OUTG: closes it (conjugate back, outputs [off, off + L) to HBM)
+template <int R, bool ING, bool WGT, bool OUTG, bool BIG>
+static __device__ __forceinline__ void fftconv_stage(float2 *buf, const FftConvArgs &A, const uint32_t N, const uint32_t Ns, uint64_t k1) {
+    constexpr int ITER = (BIG && R <= 8) ? 2 : 1;
+    const uint32_t NR = N / R;
+    float2 v[ITER][R];
+    const float2 *x = A.x + (uint64_t)A.M * k1;
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const uint32_t j = threadIdx.x + it * blockDim.x;
+        if (j < NR) {
+            const uint32_t k = j % Ns;
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const uint32_t idx = j + t * NR;
+                if constexpr (ING) v[it][t] = idx < A.M ? x[idx] : make_float2(0.f, 0.f);
+                else v[it][t] = buf[lds_pad(idx)];
+                if constexpr (WGT) { const float2 p = cmulf(v[it][t], A.H[idx]); v[it][t] = make_float2(p.x, -p.y); }
+            }
+            if (Ns > 1) {
+                float2 w[R];
+                w[1] = A.tw[k * (NR / Ns)];
+#pragma unroll
+                for (int t = 2; t < R; ++t) w[t] = cmulf(w[t / 2], w[t - t / 2]);
+#pragma unroll
+                for (int t = 1; t < R; ++t) v[it][t] = cmulf(v[it][t], w[t]);
+            }
+            dft_small<R>(v[it], A.tw, NR);
+        }
+    }
+    if constexpr (!ING) __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const uint32_t j = threadIdx.x + it * blockDim.x;
+        if (j < NR) {
+            const uint32_t k = j % Ns, j0 = (j - k) * R + k;
+            if constexpr (!OUTG) {
+#pragma unroll
+                for (int t = 0; t < R; ++t) buf[lds_pad(j0 + t * Ns)] = v[it][t];
+            } else {
+                float2 *z = A.z + (uint64_t)A.L * k1;
+#pragma unroll
+                for (int t = 0; t < R; ++t) {
+                    const uint32_t i = j0 + t * Ns;
+                    if (i >= A.off && i - A.off < A.L) z[i - A.off] = make_float2(v[it][t].x, -v[it][t].y);
+                }
+            }
+        }
+    }
+    if constexpr (!OUTG) __syncthreads();
+}
+
+template <bool ING, bool WGT, bool OUTG, bool BIG>
+static __device__ __forceinline__ void fftconv_stage_r(int R, float2 *buf, const FftConvArgs &A, uint32_t Ns, uint64_t k1) {
+    const uint32_t N = A.N;
+    switch (R) {
+        case 2: fftconv_stage<2, ING, WGT, OUTG, BIG>(buf, A, N, Ns, k1); break;
+        case 3: fftconv_stage<3, ING, WGT, OUTG, BIG>(buf, A, N, Ns, k1); break;
+        case 4: fftconv_stage<4, ING, WGT, OUTG, BIG>(buf, A, N, Ns, k1); break;
+        case 5: fftconv_stage<5, ING, WGT, OUTG, BIG>(buf, A, N, Ns, k1); break;
+        case 7: fftconv_stage<7, ING, WGT, OUTG, BIG>(buf, A, N, Ns, k1); break;
+        case 8: fftconv_stage<8, ING, WGT, OUTG, BIG>(buf, A, N, Ns, k1); break;
+        case 9: fftconv_stage<9, ING, WGT, OUTG, BIG>(buf, A, N, Ns, k1); break;
+        case 11: fftconv_stage<11, ING, WGT, OUTG, BIG>(buf, A, N, Ns, k1); break;
+        case 13: fftconv_stage<13, ING, WGT, OUTG, BIG>(buf, A, N, Ns, k1); break;
+        default: fftconv_stage<16, ING, WGT, OUTG, BIG>(buf, A, N, Ns, k1); break;
+    }
+}
+
+template <bool BIG>
+__global__ void __launch_bounds__(BIG ? 512 : 256) fftconv_lds_kernel(const FftConvArgs A) {
+    extern __shared__ float2 pre_lds[];
+    const uint64_t k1 = blockIdx.x;
+    const int n = A.st.n;
+    uint32_t Ns = 1;
+    fftconv_stage_r<true, false, false, BIG>(A.st.r[0], pre_lds, A, Ns, k1);
+    Ns = A.st.r[0];
+    for (int s = 1; s < n; ++s) { fftconv_stage_r<false, false, false, BIG>(A.st.r[s], pre_lds, A, Ns, k1); Ns *= A.st.r[s]; }
+    if (n == 1) { fftconv_stage_r<false, true, true, BIG>(A.st.r[0], pre_lds, A, 1, k1); return; }
+    fftconv_stage_r<false, true, false, BIG>(A.st.r[1], pre_lds, A, 1, k1);
+    Ns = A.st.r[1];
+    for (int s = 2; s < n; ++s) { fftconv_stage_r<false, false, false, BIG>(A.st.r[s], pre_lds, A, Ns, k1); Ns *= A.st.r[s]; }
+    fftconv_stage_r<false, false, true, BIG>(A.st.r[0], pre_lds, A, Ns, k1);
+}
+
+// 0: done (asynchronously on `s`), 1: not this path (no transform length up to 8192 takes M + ntaps - 1 points), 2: HIP error
+int fftconv_launch(const void *x, const void *taps, int taps_real, void *z, uint64_t M, uint64_t ntaps, uint64_t K, uint64_t off, uint64_t L, hipStream_t s) {
+    const uint64_t need = M + ntaps - 1;
+    if (need > 8192 || K == 0 || K >= (1ull << 31)) return 1;
+    FftStages st{};
+    unsigned threads = 0;
+    uint64_t N = 0;
+    for (uint64_t n = need; n <= 8192 && n <= need + need / 8 + 64; ++n)       // the shortest length the stage list takes (at most an eighth longer)
+        if (fft_factor(n, st, threads)) { N = n; break; }
+    if (!N) return 1;
+    const bool big = (threads >> 16) != 0;
+    const unsigned th = threads & 0xffffu;
+    const size_t lds_bytes = sizeof(float2) * (N + N / 16 + 1);
+    if (lds_bytes > 65536) {
+        const void *fn = big ? (const void *)fftconv_lds_kernel<true> : (const void *)fftconv_lds_kernel<false>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
+    }
+    float2 *tab = nullptr;                                               // [H | tw]
+    if (hipMallocAsync((void **)&tab, sizeof(float2) * 2 * N, s) != hipSuccess || !tab) { (void)hipGetLastError(); return 1; }
+    fftconv_tables_kernel<<<(unsigned)((N + 255) / 256), 256, 0, s>>>(taps, taps_real, (uint32_t)ntaps, (uint32_t)N, tab, tab + N);
+    FftConvArgs A{(const float2 *)x, (float2 *)z, tab, tab + N, (uint32_t)M, (uint32_t)N, (uint32_t)off, (uint32_t)L, K, st};
+    if (big) fftconv_lds_kernel<true><<<(unsigned)K, th, lds_bytes, s>>>(A); else fftconv_lds_kernel<false><<<(unsigned)K, th, lds_bytes, s>>>(A);
+    const hipError_t e = hipGetLastError();
+    (void)hipFreeAsync(tab, s);
+    return e == hipSuccess ? 0 : 2;
+}
+
 }  // namespace qdas

@@ -113,6 +113,7 @@ struct qdas_plan {
     int jit_mb = 0;                           // its transmits per stage
     hipFunction_t jit_fn = nullptr;           // plan-specialised kernel (QDAS_PLAN_JIT, jit.hip); null: prebuilt instantiation
     std::string jit_tag;                      // "jit <hash>" when the plan runs a hiprtc-specialised kernel (QDAS_PLAN_JIT)
+    bool prep2 = false, prep4 = false;        // the two- / four-frame instantiations have been resolved (qdas_plan_execute_frames)
     bool timing = false;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     float last_ms = 0.f;
@@ -1058,6 +1059,28 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             }
         }
     }
+    // ---- the instantiation this plan launches for one frame: libqdas.so carries it, or it is built now (das_tile_cfg.h tile_prebuilt, jit.hip
+    //      lazy_tile_launch) -- never inside an execute.  Without a compiler at hand (no libhiprtc.so, QDAS_NO_LAZY) the plan is re-made on the generic
+    //      kernel (identical semantics, 5-12x slower), or fails when the caller insisted on QDAS_KERNEL_TILED; qdas_last_error() says which variant it was.
+    if (pl->kernel == QDAS_KERNEL_TILED && !pl->jit_fn) {
+        std::string built;
+        TileParams t1 = pl->tp;
+        t1.nfr = 1;
+        const hipError_t pe = prepare_tile(t1, dt, pl->ntiles, &built);
+        if (pe == hipErrorSharedObjectInitFailed) {
+            const std::string why = g_err;
+            if (desc->kernel == QDAS_KERNEL_TILED || mslab || pl->prefolded)
+                return bail(fail(QDAS_EUNSUPPORTED, "%s", why.c_str()));
+            qdas_desc d2 = *desc;
+            d2.kernel = QDAS_KERNEL_GENERIC;
+            delete pl;
+            const int rc2 = qdas_plan_create(out, &d2);
+            if (rc2 == QDAS_OK) g_err = why + " -- using the generic kernel";
+            return rc2;
+        }
+        if (pe != hipSuccess) (void)hipGetLastError();      // (anything else is the launch's to report)
+        if (!built.empty()) pl->jit_tag = "built on demand " + built;
+    }
     if (pl->prefolded && pl->kernel == QDAS_KERNEL_TILED && !pl->no_fallback)
         return bail(fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_PREFOLDED: tiles of this image do not fit the staging windows (they would be redone from the unfolded frame)"));
     // ---- fp16 reciprocal data on the folded fp32 kernels: an fp32 PREFOLDED child plan over the same geometry and slab; this plan folds each frame into a
@@ -1334,6 +1357,23 @@ extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, u
         }
         pairs_ok = pl->fold_buf2 != nullptr;
     }
+    // the frame-sharing instantiations are resolved (built on demand when libqdas.so does not carry them) at the plan's FIRST stream, not inside the
+    // frame loop; without a compiler the stream runs one frame per launch
+    if (pairs_ok && F >= 2 && pl->kernel == QDAS_KERNEL_TILED) {
+        const std::string keep = g_err;
+        for (int nf = 2; nf <= 4; nf += 2) {
+            bool &done = nf == 2 ? pl->prep2 : pl->prep4;
+            if (done || (nf == 4 && (F < 4 || pl->fb4_off || pl->tp.fold))) continue;
+            done = true;
+            TileParams t = pl->tp;
+            t.nfr = nf;
+            if (prepare_tile(t, z.dtype, pl->ntiles, nullptr) == hipErrorSharedObjectInitFailed) {
+                if (nf == 2) { pl->fb2_ok = false; pl->fold2_ok = false; pairs_ok = false; } else pl->fb4_off = true;
+            }
+            (void)hipGetLastError();
+        }
+        g_err = keep;
+    }
     if (pl->d.mem == QDAS_MEM_HOST && F >= 2) {         // host frames: upload f+1 on the copy stream while f is beamformed
         if (!pl->copy_stream) {
             int rc;
@@ -1577,6 +1617,7 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     if (hipMemsetAsync(counter, 0, sizeof(uint32_t), s) != hipSuccess) return 0;
     const hipError_t e = launch_tile(t, dt, ntiles, s);
     if (part) (void)hipFreeAsync(part, s);
+    if (e == hipErrorSharedObjectInitFailed) { (void)hipGetLastError(); return 1; }      // (a variant that is built on demand, and no compiler at hand: the any-shape kernel)
     return e == hipSuccess ? -1 : 0;     // (the probe of this footprint found no misfit on these very tables: every tile is written)
 }
 
@@ -1825,6 +1866,19 @@ extern "C" int qdas_convd(const qdas_convd_desc *d, const void *x, const void *y
     const uint64_t Cx = (d->bcast & QDAS_CONV_X_ONE_COLUMN) ? 1 : d->C, Cy = (d->bcast & QDAS_CONV_Y_ONE_COLUMN) ? 1 : d->C;
     p.xcs = Cx == 1 && d->C > 1 ? 0 : 1; p.xts = Cx; p.xss = (d->bcast & QDAS_CONV_X_ONE_SLICE) ? 0 : Cx * d->M;
     p.ycs = Cy == 1 && d->C > 1 ? 0 : 1; p.yts = Cy; p.yss = (d->bcast & QDAS_CONV_Y_ONE_SLICE) ? 0 : Cy * d->N;
+    // long filters on complex64 traces, ONE filter for all of them, time contiguous (ChannelData.filter's band-pass): FFT convolution with the trace
+    // resident in LDS (pre.hip fftconv_launch) -- from QDAS_CONV_FFT_MIN_TAPS taps on (default 96: where it overtakes the direct kernel on the C3 record)
+    {
+        static const bool no_fft = getenv("QDAS_CONV_NO_FFT") != nullptr;
+        uint64_t min_taps = 96;
+        if (const char *e = getenv("QDAS_CONV_FFT_MIN_TAPS")) { const long long v = atoll(e); if (v >= 2) min_taps = (uint64_t)v; }
+        const bool one_filter = d->S == 1 || (d->bcast & QDAS_CONV_Y_ONE_SLICE), every_trace = d->S == 1 || !(d->bcast & QDAS_CONV_X_ONE_SLICE);
+        if (!no_fft && d->dtype == QDAS_F32 && d->cplx && d->C == 1 && one_filter && every_trace && d->N >= min_taps) {
+            const int rc = fftconv_launch(x, y, d->y_real ? 1 : 0, z, d->M, d->N, d->S, (uint64_t)p.off, L, (hipStream_t)stream);
+            if (rc == 0) return QDAS_OK;
+            if (rc == 2) return fail(QDAS_EHIP, "convd: the FFT convolution kernel failed to launch");
+        }
+    }
     HIPCHK(launch_conv(p, d->dtype, d->cplx ? 1 : 0, d->y_real ? 1 : 0, (hipStream_t)stream));
     return QDAS_OK;
 }

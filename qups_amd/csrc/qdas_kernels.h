@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string>
 #include "tile_params.h"
 
 #define QDAS_MAX_APOD 6
@@ -40,6 +41,8 @@ size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow = 0
 size_t tile_lds_limit(int sym);                               // LDS budget of one workgroup in that configuration
 // jit: plan-specialised kernel (jit.hip) to launch instead of the prebuilt instantiation; one frame per launch only
 hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s, hipFunction_t jit = nullptr, size_t jit_lds = 0);
+// resolve (build on demand, if libqdas.so does not carry it) the instantiation launch_tile(P, ...) would run, without launching; *built = its cache key or ""
+hipError_t prepare_tile(const TileParams &P, int dtype, unsigned ntiles, std::string *built);
 
 // ---- reciprocity fold (fold.hip): xs[:,n,m] = w[n,m] x[:,n,m] + w[m,n] x[:,m,n] for n < m, xs[:,n,n] = w[n,n] x[:,n,n]; complex64, traces of T samples at
 //      (n*strN + m*strM) samples; wtab: N x N float2 [n + N*m] or null (ones); only the upper triangle n <= m of xs is written
@@ -111,6 +114,9 @@ struct ConvParams {
     uint64_t ycs, yts, yss;
 };
 hipError_t launch_conv(const ConvParams &P, int dtype, int cplx, int y_real, hipStream_t s);
+// FFT convolution of K complex64 traces of M samples with one filter of `ntaps` (real fp32 | complex64) taps: outputs [off, off + L) of the linear convolution
+// (pre.hip).  0: launched, 1: not this path, 2: HIP error
+int fftconv_launch(const void *x, const void *taps, int taps_real, void *z, uint64_t M, uint64_t ntaps, uint64_t K, uint64_t off, uint64_t L, hipStream_t s);
 
 // ---- layout.hip: out[c][b][a] = in[a][b][c]
 hipError_t launch_permute3(const void *in, void *out, uint64_t A, uint64_t B, uint64_t C, int elem_bytes, hipStream_t s);

@@ -74,3 +74,9 @@ def rel_err(a, b):
     b = np.asarray(b)
     den = np.abs(b).max()
     return float(np.abs(a - b).max() / (den if den > 0 else 1.0))
+
+
+def stock_kernel(name: str) -> bool:
+    """the plan runs an instantiation of the fused kernel with run-time sizes -- carried by libqdas.so ("[prebuilt]") or built on demand from
+    the same template arguments ("[built on demand <key>]", csrc/das_tile_cfg.h TILE_PREBUILT) -- not a plan-specialised hiprtc build ("[jit <key>]")"""
+    return "[prebuilt]" in name or "[built on demand " in name

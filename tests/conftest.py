@@ -16,3 +16,23 @@ def pytest_configure(config):
 def has_gpu():
     import torch
     return torch.cuda.is_available()
+
+
+def pytest_collection_finish(session):
+    """GPU sessions: the variants of the fused kernel that this suite launches and libqdas.so does not carry (tests/suite_kernels.txt: the census of
+    a full run, tools/kernel_census.py) are built ahead of the tests, one compiler process per core (qups_amd/warm.py) -- instead of one by one,
+    ~2 s each, inside the first plan that needs them.  A stale list only means that a variant is built on demand after all."""
+    if os.environ.get("QDAS_NO_WARM") or not any(item.get_closest_marker("gpu") for item in session.items):
+        return
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            return
+        import time
+        from qups_amd import warm
+        t = time.perf_counter()
+        vs = warm.read_census([os.path.join(ROOT, "tests", "suite_kernels.txt")])
+        bad = warm.warm(vs)
+        sys.stderr.write(f"[conftest] kernel cache warmed: {len(vs)} variants listed, {bad} worker(s) failed, {time.perf_counter() - t:.1f} s\n")
+    except Exception as ex:                                  # (never fatal: the variants are then built on demand)
+        sys.stderr.write(f"[conftest] kernel cache not warmed: {ex}\n")

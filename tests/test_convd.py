@@ -238,3 +238,34 @@ def test_channeldata_filter_and_downsample():
     assert ds.fs == fs / 4 and ds.t0 == out.t0 and torch.equal(ds.data, out.data[::4]) and ds.data.is_contiguous()
     with pytest.raises(ValueError):
         out.downsample(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("taps_complex", [False, True], ids=["real-taps", "complex-taps"])
+@pytest.mark.parametrize("T,K", [(700, 129), (2816, 129), (1000, 97), (2048, 301), (5000, 500), (90, 200)])
+def test_convd_long_filters_take_the_fft_path(T, K, taps_complex, monkeypatch):
+    """complex64 traces, time contiguous, one filter of >= 96 taps: the FFT convolution with the trace resident in LDS (csrc/pre.hip fftconv_launch)
+    -- every shape against numpy's direct sum in float64 and against the direct kernel (QDAS_CONV_FFT_MIN_TAPS switches the path per call)"""
+    import torch
+    from qups_amd import convd
+    rng = np.random.default_rng(T + K)
+    S = 37
+    x = (rng.standard_normal((S, T)) + 1j * rng.standard_normal((S, T))).astype(np.complex64)
+    h = rng.standard_normal(K) * np.hanning(K)
+    h = (h + 1j * rng.standard_normal(K) * np.hanning(K)).astype(np.complex64) if taps_complex else h.astype(np.float32)
+    xt, ht = torch.from_numpy(x).cuda(), torch.from_numpy(h).cuda().reshape(1, K)
+    full = np.stack([np.convolve(x[s].astype(np.complex128), h.astype(np.complex128 if taps_complex else np.float64), "full") for s in range(S)])
+    for shape in ("full", "same", "valid"):
+        if shape == "valid" and T < K:
+            continue
+        off = {"full": 0, "same": (K - 1) - (K - 1) // 2, "valid": K - 1}[shape]
+        L = {"full": T + K - 1, "same": T, "valid": T - K + 1}[shape]
+        ref = full[:, off:off + L]
+        monkeypatch.setenv("QDAS_CONV_FFT_MIN_TAPS", "96")
+        z = convd(xt, ht, 2, shape).cpu().numpy()
+        monkeypatch.setenv("QDAS_CONV_FFT_MIN_TAPS", "1000000")
+        zd = convd(xt, ht, 2, shape).cpu().numpy()
+        assert z.shape == ref.shape and rel(z, ref) <= 2e-6, (shape, rel(z, ref))
+        assert rel(zd, ref) <= 2e-6 and rel(z, zd) <= 3e-6
+        if T + K - 1 <= 8192:
+            assert not np.array_equal(z, zd), "the two paths round differently: identical bits mean the FFT path did not run"

@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from tests.cases import cinv_f32, make_case, rel_err
+from tests.cases import stock_kernel, cinv_f32, make_case, rel_err
 
 
 def test_hiprtc_builds_the_specialised_kernel_without_a_device(tmp_path, monkeypatch):
@@ -104,7 +104,7 @@ def test_jit_plan_matches_prebuilt_and_oracle(seq, interp, prec, extra, tmp_path
         ys.append(torch.view_as_real(y).float().cpu().numpy().view(np.complex64)[..., 0] if prec == "halfT" else y.cpu().numpy())
         names.append(plan.kernel_name())
         plan.close()
-    assert "[prebuilt]" in names[0] and "[jit " in names[1], names          # the hiprtc kernel really ran
+    assert stock_kernel(names[0]) and "[jit " in names[1], names          # the hiprtc kernel really ran
     # ... and its code object is in the disk cache (unless this process had built the same key before: then the in-memory cache answered)
     assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) <= 1
     ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"], cinv_f32(case["c"]),
@@ -146,7 +146,7 @@ def test_jit_reciprocal_32_transmit_stages(N, prec, wtab, tmp_path, monkeypatch)
             names.append(plan.kernel_name()); rec.append(plan.reciprocal)
             assert plan.fallback_tiles() == 0
     assert all(rec), names
-    assert "[prebuilt]" in names[0] and "[jit " in names[1] and ",sym" in names[1] and ",mb=32," in names[1], names
+    assert stock_kernel(names[0]) and "[jit " in names[1] and ",sym" in names[1] and ",mb=32," in names[1], names
     assert ("wtab" in names[1]) == wtab, names
     ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"], cinv_f32(case["c"]),
                      VS=case["VS"], DV=case["DV"], interp="lanczos3", apod=ap).reshape(-1, order="F")
@@ -170,7 +170,7 @@ def test_jit_modes_syn_mul_and_pixel_weights(tmp_path, monkeypatch):
         extra = ["apod", ap] if ap is not None else []
         y0, p0 = das_spec(fun, *args, *case["opt"], "interp", "cubic", *extra, return_plan=True, kernel=2)
         y1, p1 = das_spec(fun, *args, *case["opt"], "interp", "cubic", *extra, return_plan=True, kernel=2, jit=True)
-        assert "[jit " in p1.kernel_name() and "[prebuilt]" in p0.kernel_name()
+        assert "[jit " in p1.kernel_name() and stock_kernel(p0.kernel_name())
         assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) <= 1e-6, fun
         p0.close(); p1.close()
 
@@ -187,7 +187,7 @@ def test_environment_default_builds_the_specialised_kernel(tmp_path, monkeypatch
     y0, p0 = das_spec("DAS", *args, *case["opt"], "interp", "linear", return_plan=True)
     monkeypatch.setenv("QDAS_JIT", "1")
     y1, p1 = das_spec("DAS", *args, *case["opt"], "interp", "linear", return_plan=True)
-    assert "[prebuilt]" in p0.kernel_name() and "[jit " in p1.kernel_name()
+    assert stock_kernel(p0.kernel_name()) and "[jit " in p1.kernel_name()
     a, b = y0.cpu().numpy(), y1.cpu().numpy()
     assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
 
@@ -218,3 +218,99 @@ def test_jit_plan_streams_share_launches(mirror, tmp_path, monkeypatch):
     for f in range(F):
         assert rel_err(y[f], y1[f]) <= (3e-5 if mirror else 2e-6), f    # (mirror plans stream groups of four through their twin without the mirror mode: another summation order)
     assert rel_err(y[0], y[1]) > 1e-2                       # (different frames)
+
+
+# ------------------------------------------------------------------------------------------ variants built on demand (das_tile_cfg.h TILE_PREBUILT)
+def test_on_demand_variants_build_without_a_device(tmp_path, monkeypatch):
+    """(CPU) a point of the template's matrix that libqdas.so does not carry compiles from the embedded headers with the template arguments the
+    prebuilt instantiation would have had -- no spills, no scratch --, lands in the disk cache, and the matrix query answers consistently"""
+    import sys
+    from qups_amd import _lib, warm
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    L = _lib.lib()
+    assert L.qdas_kernel_variant_prebuilt(17, 3, 0, 0) == 1          # the headline: folded, mirror, lanczos3
+    assert L.qdas_kernel_variant_prebuilt(0, 5, 0, 0) == 0           # cubic_dev: on demand
+    assert L.qdas_kernel_variant_prebuilt(1, 1, 0, 0) == -1 and L.qdas_kernel_variant_prebuilt(19, 1, 0, 1) == -1 and L.qdas_kernel_variant_prebuilt(0, 4, 0, 0) == -1
+    assert L.qdas_kernel_variant_build(17, 3, 0, 0) == 2 and L.qdas_kernel_variant_build(1, 1, 0, 0) == 3
+    rc = L.qdas_kernel_variant_build(2, 5, 1, 1)                      # fp16, cubic_dev, remodulation + weight table
+    if rc == 1 and b"hiprtc not available" in (L.qdas_last_error() or b""):
+        pytest.skip("hiprtc not available")
+    assert rc == 0, L.qdas_last_error()
+    assert warm.warm([(19, 1, 1, 0), (17, 3, 0, 0)], jobs=2) == 0     # one worker process per variant; the second is prebuilt: nothing to do
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]
+    assert len(files) == 2, files
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_regs
+    rows = [r for fn in files for r in kernel_regs.kernel_table(str(tmp_path / fn))]
+    assert len(rows) == 2 and all(r["name"] == "qdas_jit_tile" and r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 128 for r in rows), rows
+    # the suite's own list (tests/conftest.py warms it on a GPU box) names variants of the matrix only
+    vs = warm.read_census([os.path.join(os.path.dirname(os.path.abspath(__file__)), "suite_kernels.txt")])
+    assert len(vs) > 50 and all(L.qdas_kernel_variant_prebuilt(*v) >= 0 for v in vs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seq,interp,prec,fmod", [("PW", "cubic_dev", "single", 0.0), ("FSA", "linear", "single", 2.5e6), ("DV", "nearest", "halfT", 2.5e6)])
+def test_on_demand_variant_runs_and_matches_oracle(seq, interp, prec, fmod, tmp_path, monkeypatch):
+    """a plan whose instantiation libqdas.so does not carry builds it at plan creation (never inside an execute), says so in its kernel name, and
+    matches the oracle and the generic kernel"""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import DasPlan, build_problem, parse_options
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    case = make_case(seq=seq, interp=interp if interp != "cubic_dev" else "cubic", seed=57, N=16, I1=150, I2=36)
+    x = torch.from_numpy(case["x"])
+    fm = float(np.float32(fmod))
+    va = list(case["opt"]) + ["interp", interp, "input-precision", prec, "modulation", fm]
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"].shape, case["t0"], case["fs"], case["c"], parse_options(x, va))
+    out = {}
+    for kernel in (2, 1):
+        with DasPlan(prob, kernel=kernel) as plan:
+            y = plan.feval(x)
+            out[kernel] = (torch.view_as_real(y).float().cpu().numpy().view(np.complex64)[..., 0] if prec == "halfT" else y.cpu().numpy()).reshape(-1)
+            if kernel == 2:
+                name = plan.kernel_name()
+                assert plan.kernel == "tiled" and "[built on demand " in name, name
+    tol = 2e-3 if prec == "halfT" else 2e-4 if fm else 2e-5
+    assert rel_err(out[2], out[1]) <= tol
+    if interp != "cubic_dev":
+        ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"], cinv_f32(case["c"]),
+                         VS=case["VS"], DV=case["DV"], interp=interp, fmod=fm).reshape(-1, order="F")
+        assert rel_err(out[2], ref) <= (1e-2 if interp == "nearest" else tol)
+
+
+@pytest.mark.gpu
+def test_without_a_compiler_on_demand_variants_run_the_generic_kernel(tmp_path, monkeypatch):
+    """QDAS_NO_LAZY=1 stands for a host without libhiprtc.so: a plan that needs a variant libqdas.so does not carry is made on the generic kernel (and
+    says why), a QDAS_KERNEL_TILED request fails with QDAS_EUNSUPPORTED; a stream of frames whose two-frame variant cannot be built runs one frame per launch"""
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options, _lib
+    from qups_amd.das_spec import _colmajor
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    case = make_case(seq="PW", interp="cubic", seed=58, N=16, M=12, I1=128, I2=24)
+    x = torch.from_numpy(case["x"])
+    va = list(case["opt"]) + ["interp", "cubic_dev"]
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"].shape, case["t0"], case["fs"], case["c"], parse_options(x, va))
+    with DasPlan(prob, kernel=2, mirror=False) as plan:
+        y_ref = plan.feval(x).cpu().numpy()
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path / "other"))          # (this process has the variant in memory: another one is needed)
+    va2 = list(case["opt"]) + ["interp", "cubic_dev", "modulation", float(np.float32(1e6))]
+    prob2 = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"].shape, case["t0"], case["fs"], case["c"], parse_options(x, va2))
+    monkeypatch.setenv("QDAS_NO_LAZY", "1")
+    with pytest.raises(_lib.QdasError) as ei:
+        DasPlan(prob2, kernel=2, mirror=False)
+    assert ei.value.code == 2 and "built on demand" in str(ei.value)
+    with DasPlan(prob2, kernel=0, mirror=False) as plan:
+        assert plan.kernel == "generic"
+    # streams: PW + cubic + fp32 is prebuilt one frame per launch (cfg 0) and two per launch (cfg 3); cubic_dev's two-frame variant is not
+    F = 3
+    rng = np.random.default_rng(4)
+    xs = np.stack([case["x"]] + [(rng.standard_normal(case["x"].shape) + 1j * rng.standard_normal(case["x"].shape)).astype(np.complex64) for _ in range(F - 1)], axis=3)
+    xt = torch.from_numpy(xs)
+    prob3 = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], parse_options(xt, va))
+    monkeypatch.delenv("QDAS_NO_LAZY")
+    plan = DasPlan(prob3, kernel=2, mirror=False)                            # (the one-frame variant: in memory since the first plan)
+    monkeypatch.setenv("QDAS_NO_LAZY", "1")
+    ys = plan.execute_colmajor(_colmajor(xt.cuda()), F).cpu().numpy().reshape(F, -1)
+    plan.close()
+    assert rel_err(ys[0], y_ref.reshape(-1)) <= 1e-6
+    assert rel_err(ys[1], ys[0]) > 1e-2
