@@ -572,8 +572,16 @@ int fftconv_launch(const void *x, const void *taps, int taps_real, void *z, uint
     FftStages st{};
     unsigned threads = 0;
     uint64_t N = 0;
-    for (uint64_t n = need; n <= 8192 && n <= need + need / 8 + 64; ++n)       // the shortest length the stage list takes (at most an eighth longer)
-        if (fft_factor(n, st, threads)) { N = n; break; }
+    // the transform length: among the lengths up to a quarter beyond M + ntaps - 1 that the stage list takes, the one with the least points x stages
+    // (every stage is a pass over the trace in LDS between two barriers: 2944 points needed -> 3328 = 13 x 16 x 16 beats 2970 = 11 x 5 x 9 x 3 x 2)
+    double best = 0.0;
+    for (uint64_t n = need; n <= 8192 && n <= need + need / 4 + 64; ++n) {
+        FftStages c{};
+        unsigned th = 0;
+        if (!fft_factor(n, c, th)) continue;
+        const double cost = (double)n * ((double)c.n + ((th >> 16) ? 0.5 : 0.0));
+        if (!N || cost < best) { N = n; st = c; threads = th; best = cost; }
+    }
     if (!N) return 1;
     const bool big = (threads >> 16) != 0;
     const unsigned th = threads & 0xffffu;

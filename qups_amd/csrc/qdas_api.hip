@@ -1059,28 +1059,6 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             }
         }
     }
-    // ---- the instantiation this plan launches for one frame: libqdas.so carries it, or it is built now (das_tile_cfg.h tile_prebuilt, jit.hip
-    //      lazy_tile_launch) -- never inside an execute.  Without a compiler at hand (no libhiprtc.so, QDAS_NO_LAZY) the plan is re-made on the generic
-    //      kernel (identical semantics, 5-12x slower), or fails when the caller insisted on QDAS_KERNEL_TILED; qdas_last_error() says which variant it was.
-    if (pl->kernel == QDAS_KERNEL_TILED && !pl->jit_fn) {
-        std::string built;
-        TileParams t1 = pl->tp;
-        t1.nfr = 1;
-        const hipError_t pe = prepare_tile(t1, dt, pl->ntiles, &built);
-        if (pe == hipErrorSharedObjectInitFailed) {
-            const std::string why = g_err;
-            if (desc->kernel == QDAS_KERNEL_TILED || mslab || pl->prefolded)
-                return bail(fail(QDAS_EUNSUPPORTED, "%s", why.c_str()));
-            qdas_desc d2 = *desc;
-            d2.kernel = QDAS_KERNEL_GENERIC;
-            delete pl;
-            const int rc2 = qdas_plan_create(out, &d2);
-            if (rc2 == QDAS_OK) g_err = why + " -- using the generic kernel";
-            return rc2;
-        }
-        if (pe != hipSuccess) (void)hipGetLastError();      // (anything else is the launch's to report)
-        if (!built.empty()) pl->jit_tag = "built on demand " + built;
-    }
     if (pl->prefolded && pl->kernel == QDAS_KERNEL_TILED && !pl->no_fallback)
         return bail(fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_PREFOLDED: tiles of this image do not fit the staging windows (they would be redone from the unfolded frame)"));
     // ---- fp16 reciprocal data on the folded fp32 kernels: an fp32 PREFOLDED child plan over the same geometry and slab; this plan folds each frame into a
@@ -1111,6 +1089,28 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
             if (child) qdas_plan_destroy(child);
         }
         g_err = keep;
+    }
+    // ---- the instantiation this plan launches for one frame: libqdas.so carries it, or it is built now (das_tile_cfg.h tile_prebuilt, jit.hip
+    //      lazy_tile_launch) -- never inside an execute.  Without a compiler at hand (no libhiprtc.so, QDAS_NO_LAZY) the plan is re-made on the generic
+    //      kernel (identical semantics, 5-12x slower), or fails when the caller insisted on QDAS_KERNEL_TILED; qdas_last_error() says which variant it was.
+    if (pl->kernel == QDAS_KERNEL_TILED && !pl->jit_fn && !pl->f16_child) {      // (fp16 reciprocal data: the fp32 child plan above resolved its own)
+        std::string built;
+        TileParams t1 = pl->tp;
+        t1.nfr = 1;
+        const hipError_t pe = prepare_tile(t1, dt, pl->ntiles, &built);
+        if (pe == hipErrorSharedObjectInitFailed) {
+            const std::string why = g_err;
+            if (desc->kernel == QDAS_KERNEL_TILED || mslab || pl->prefolded)
+                return bail(fail(QDAS_EUNSUPPORTED, "%s", why.c_str()));
+            qdas_desc d2 = *desc;
+            d2.kernel = QDAS_KERNEL_GENERIC;
+            delete pl;
+            const int rc2 = qdas_plan_create(out, &d2);
+            if (rc2 == QDAS_OK) g_err = why + " -- using the generic kernel";
+            return rc2;
+        }
+        if (pe != hipSuccess) (void)hipGetLastError();      // (anything else is the launch's to report)
+        if (!built.empty()) pl->jit_tag = "built on demand " + built;
     }
     pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->tp.mir && !pl->tp.stage_shift && pl->tp.narrow != 2 && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
     // folded data: TWO frames per launch (launch configurations 20 / 21 -- tap index and weights serve two folded traces of two frames, in mirror mode four);
@@ -1867,10 +1867,10 @@ extern "C" int qdas_convd(const qdas_convd_desc *d, const void *x, const void *y
     p.xcs = Cx == 1 && d->C > 1 ? 0 : 1; p.xts = Cx; p.xss = (d->bcast & QDAS_CONV_X_ONE_SLICE) ? 0 : Cx * d->M;
     p.ycs = Cy == 1 && d->C > 1 ? 0 : 1; p.yts = Cy; p.yss = (d->bcast & QDAS_CONV_Y_ONE_SLICE) ? 0 : Cy * d->N;
     // long filters on complex64 traces, ONE filter for all of them, time contiguous (ChannelData.filter's band-pass): FFT convolution with the trace
-    // resident in LDS (pre.hip fftconv_launch) -- from QDAS_CONV_FFT_MIN_TAPS taps on (default 96: where it overtakes the direct kernel on the C3 record)
+    // resident in LDS (pre.hip fftconv_launch) -- from QDAS_CONV_FFT_MIN_TAPS taps on (default 128: it overtakes the direct kernel at about 120 taps on the C3 record, profiles/r04/convd_fft_time.txt)
     {
         static const bool no_fft = getenv("QDAS_CONV_NO_FFT") != nullptr;
-        uint64_t min_taps = 96;
+        uint64_t min_taps = 128;
         if (const char *e = getenv("QDAS_CONV_FFT_MIN_TAPS")) { const long long v = atoll(e); if (v >= 2) min_taps = (uint64_t)v; }
         const bool one_filter = d->S == 1 || (d->bcast & QDAS_CONV_Y_ONE_SLICE), every_trace = d->S == 1 || !(d->bcast & QDAS_CONV_X_ONE_SLICE);
         if (!no_fft && d->dtype == QDAS_F32 && d->cplx && d->C == 1 && one_filter && every_trace && d->N >= min_taps) {

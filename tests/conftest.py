@@ -29,6 +29,9 @@ def pytest_collection_finish(session):
         if not torch.cuda.is_available():
             return
         import time
+        if not os.environ.get("QDAS_CACHE_DIR") and not os.environ.get("HOME"):      # (no private place for the disk cache: make one for this session)
+            import tempfile
+            os.environ["QDAS_CACHE_DIR"] = tempfile.mkdtemp(prefix="qdas_cache_")
         from qups_amd import warm
         t = time.perf_counter()
         vs = warm.read_census([os.path.join(ROOT, "tests", "suite_kernels.txt")])

@@ -87,7 +87,8 @@ def test_convd_reference_test_case(prec, cplx):
     assert rel(z, np.correlate(A.astype(np.complex128), A.astype(np.complex128), "full")) <= tol
     zb = convd(torch.from_numpy(np.stack([A, A], -1).reshape(1024, 1, 1, 2)), torch.from_numpy(B))   # cat(4, A, A) broadcast
     z1 = convd(torch.from_numpy(A), torch.from_numpy(B))
-    assert torch.equal(zb[:, 0, 0, 0], z1) and torch.equal(zb[:, 0, 0, 1], z1)
+    # (two columns: the direct kernel; the single 1024-tap complex64 trace: the FFT convolution -- other roundings, the same numbers)
+    assert torch.equal(zb[:, 0, 0, 0], zb[:, 0, 0, 1]) and rel(zb[:, 0, 0, 0].cpu().numpy(), z1.cpu().numpy()) <= tol
 
 
 @pytest.mark.gpu
@@ -244,7 +245,7 @@ def test_channeldata_filter_and_downsample():
 @pytest.mark.parametrize("taps_complex", [False, True], ids=["real-taps", "complex-taps"])
 @pytest.mark.parametrize("T,K", [(700, 129), (2816, 129), (1000, 97), (2048, 301), (5000, 500), (90, 200)])
 def test_convd_long_filters_take_the_fft_path(T, K, taps_complex, monkeypatch):
-    """complex64 traces, time contiguous, one filter of >= 96 taps: the FFT convolution with the trace resident in LDS (csrc/pre.hip fftconv_launch)
+    """complex64 traces, time contiguous, one filter of >= 128 taps (QDAS_CONV_FFT_MIN_TAPS): the FFT convolution with the trace resident in LDS (csrc/pre.hip fftconv_launch)
     -- every shape against numpy's direct sum in float64 and against the direct kernel (QDAS_CONV_FFT_MIN_TAPS switches the path per call)"""
     import torch
     from qups_amd import convd
@@ -261,11 +262,11 @@ def test_convd_long_filters_take_the_fft_path(T, K, taps_complex, monkeypatch):
         off = {"full": 0, "same": (K - 1) - (K - 1) // 2, "valid": K - 1}[shape]
         L = {"full": T + K - 1, "same": T, "valid": T - K + 1}[shape]
         ref = full[:, off:off + L]
-        monkeypatch.setenv("QDAS_CONV_FFT_MIN_TAPS", "96")
+        monkeypatch.setenv("QDAS_CONV_FFT_MIN_TAPS", "90")
         z = convd(xt, ht, 2, shape).cpu().numpy()
         monkeypatch.setenv("QDAS_CONV_FFT_MIN_TAPS", "1000000")
         zd = convd(xt, ht, 2, shape).cpu().numpy()
-        assert z.shape == ref.shape and rel(z, ref) <= 2e-6, (shape, rel(z, ref))
-        assert rel(zd, ref) <= 2e-6 and rel(z, zd) <= 3e-6
+        assert z.shape == ref.shape and rel(z, ref) <= 5e-6, (shape, rel(z, ref))     # (fp32 transforms of up to 8192 points: a few 1e-6 of the largest output)
+        assert rel(zd, ref) <= 5e-6 and rel(z, zd) <= 6e-6
         if T + K - 1 <= 8192:
             assert not np.array_equal(z, zd), "the two paths round differently: identical bits mean the FFT path did not run"

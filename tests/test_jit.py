@@ -106,7 +106,7 @@ def test_jit_plan_matches_prebuilt_and_oracle(seq, interp, prec, extra, tmp_path
         plan.close()
     assert stock_kernel(names[0]) and "[jit " in names[1], names          # the hiprtc kernel really ran
     # ... and its code object is in the disk cache (unless this process had built the same key before: then the in-memory cache answered)
-    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) <= 1
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".hsaco")]) <= 2       # (+ the stock variant, when it is one that is built on demand)
     ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"], cinv_f32(case["c"]),
                      VS=case["VS"], DV=case["DV"], interp=interp, fmod=fmod).reshape(-1, order="F")     # feval: I x 1 x 1, I1 fastest
     tol = 2e-3 if prec == "halfT" else (1e-2 if interp == "nearest" else 2e-5 if not fmod else 2e-4)
@@ -249,7 +249,7 @@ def test_on_demand_variants_build_without_a_device(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seq,interp,prec,fmod", [("PW", "cubic_dev", "single", 0.0), ("FSA", "linear", "single", 2.5e6), ("DV", "nearest", "halfT", 2.5e6)])
+@pytest.mark.parametrize("seq,interp,prec,fmod", [("PW", "cubic_dev", "single", 0.0), ("FSA", "linear", "single", 2.5e6), ("DV", "linear", "halfT", 2.5e6)])
 def test_on_demand_variant_runs_and_matches_oracle(seq, interp, prec, fmod, tmp_path, monkeypatch):
     """a plan whose instantiation libqdas.so does not carry builds it at plan creation (never inside an execute), says so in its kernel name, and
     matches the oracle and the generic kernel"""
