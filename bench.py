@@ -452,7 +452,38 @@ def main():
             stream_ms = (time.perf_counter() - ts) / nfs * 1e3
         except Exception as ex:                                    # (reported, never fatal: the headline above stands on its own)
             stream_ms = f"failed: {ex!r}"
+        # the same stream with the frame travelling FOLDED (reciprocal acquisitions: qups_amd.dist.FoldedReplicator -- rank 0 folds once, ONE broadcast of the
+        # packed upper triangle = half the bytes, every rank beamforms the folded frame on a QDAS_PLAN_PREFOLDED plan: no per-rank fold pass either)
+        folded_stream = None
+        if bool(plan.folded) and F == 1 and w["prec"] == "single" and not args.no_fold:
+            try:
+                from qups_amd.dist import FoldedReplicator
+                fsplan = ShardedDasPlan(prob, rank, world, device=dev, kernel=args.kernel, reciprocal=True, jit=args.jit, prefolded=True,
+                                        mirror_slabs=splan.mirror_slabs)
+                rep = FoldedReplicator(N, T, dev, src=0)
+                yf = torch.empty((1, 1, 1, fsplan.out_count), dtype=xc.dtype, device=dev)
+                slot, work = rep.send(xc if rank == 0 else None, rank, async_op=True)
+                xs = rep.receive(slot, rank, work)
+                ychk = fsplan.gather(fsplan.plan.execute_into(xs, yf, 1)).reshape(-1)       # (also: warm-up)
+                fold_err = float((torch.view_as_real(ychk) - torch.view_as_real(yimg.reshape(-1))).abs().max() / torch.view_as_real(yimg).abs().max())
+                slot, work = rep.send(xc if rank == 0 else None, rank, async_op=True)
+                torch.cuda.synchronize(); dist.barrier()
+                ts = time.perf_counter()
+                nfs = 4
+                for f in range(nfs):
+                    xs = rep.receive(slot, rank, work)                 # frame f has arrived (unpacked on the receiving ranks)
+                    if f + 1 < nfs:
+                        slot, work = rep.send(xc if rank == 0 else None, rank, async_op=True)   # frame f + 1: fold + pack on rank 0, then the broadcast
+                    fsplan.gather(fsplan.plan.execute_into(xs, yf, 1))
+                torch.cuda.synchronize(); dist.barrier()
+                folded_stream = {"ms_per_step": round((time.perf_counter() - ts) / nfs * 1e3, 3), "bytes_per_frame": rep.bytes_per_frame,
+                                 "image_vs_headline": float(f"{fold_err:.2e}"),
+                                 "note": "rank 0 folds each frame once (qdas_fold), ONE broadcast of the packed upper triangle (half the frame), PREFOLDED plans on every rank"}
+                fsplan.close()
+            except Exception as ex:
+                folded_stream = {"ms_per_step": None, "note": f"failed: {ex!r}"}
         multi = {"backend": backend, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
+                 "stream_folded_replication": folded_stream,
                  "stream_ms_per_step_incl_overlapped_replication": round(stream_ms, 3) if isinstance(stream_ms, float) else stream_ms,
                  "per_rank_kernel_ms": [round(float(k.item()), 3) for k in allk], "gather_ms": round(gather_ms, 3),
                  "slowest_rank": int(np.argmax([float(k.item()) for k in allk])),

@@ -99,6 +99,8 @@ class ShardedDasPlan:
     ``all_reduce``): rank r takes columns ``[c0, c1)`` of the first half AND their mirror images, so that the lateral-mirror mode of the
     fused kernel (a pixel and its image share tap index and weights, ``csrc/tile_params.h``) survives the sharding.
 
+    ``prefolded=True`` (a plan keyword): execute is handed FOLDED frames (``FoldedReplicator``), the rank runs no fold pass of its own.
+
     ``compute`` defaults to the HIP plan; the CPU tests inject the oracle there to exercise the sharding and the collective under ``gloo``
     without a GPU (``compute(xc, F, i_begin, i_count)``; with ``mirror_slabs=True`` it is called for slab A and for slab B).
     """
@@ -184,6 +186,99 @@ class ShardedDasPlan:
     def close(self):
         if self.plan is not None:
             self.plan.close()
+
+
+# ------------------------------------------------------------------------------------------
+# Replicating a reciprocal acquisition FOLDED.  Pixel slabs replicate the channel data; for a full-synthetic-aperture frame that is the larger part of a
+# multi-GPU step (1.48 GB at C3 over xGMI against ~2-4 ms of kernel per rank).  A reciprocal frame can travel folded (csrc/fold.hip: xs[:, n, m] =
+# x[:, n, m] + x[:, m, n] for n <= m -- exact by the linearity of the interpolators): the acquisition rank folds ONCE (qdas_fold), packs the upper
+# triangle (N (N + 1) / 2 of the N x N traces: half the bytes), ONE broadcast moves it, every rank unpacks it into its folded-frame buffer and hands
+# it to a QDAS_PLAN_PREFOLDED plan (ShardedDasPlan(..., prefolded=True)) -- which also takes the per-rank fold pass, the Amdahl term of this layout
+# (DESIGN.md section 7), out of the ranks.  The reference has no counterpart (one gpuDevice per process, README.md:232).
+# ------------------------------------------------------------------------------------------
+def triangle_rows(N: int, device=None):
+    """row indices ``m * N + n`` (``n <= m``) of the upper triangle in a column-major frame ``(M, N, T)`` viewed as ``(M * N, T)``: the traces the fold writes"""
+    import torch
+    m = torch.arange(N, device=device).repeat_interleave(torch.arange(1, N + 1, device=device))
+    n = torch.cat([torch.arange(k + 1, device=device) for k in range(N)]) if N else torch.zeros(0, dtype=torch.long, device=device)
+    return m * N + n
+
+
+def fold_frame(xc, out=None, wtab=None):
+    """``qdas_fold`` of one column-major frame ``xc`` ``(M, N, T)`` (complex64 or complex32, ``M == N``, on a HIP device) into the complex64 folded frame
+    ``out`` (same shape; allocated zero-filled when not given: only the upper triangle ``n <= m`` is written)"""
+    import ctypes as C
+    import torch
+    from . import _lib
+    M, N, T = xc.shape
+    if M != N:
+        raise ValueError("a reciprocal frame has as many transmits as receivers")
+    if out is None:
+        out = torch.zeros((M, N, T), dtype=torch.complex64, device=xc.device)
+    d = _lib.FoldDesc(T, N, 0, 0, 1 if xc.dtype == torch.complex64 else 2, xc.device.index if xc.device.index is not None else -1,
+                      None if wtab is None else C.c_void_p(wtab.data_ptr()))
+    with torch.cuda.device(xc.device):
+        _lib.check(_lib.lib().qdas_fold(C.byref(d), C.c_void_p(xc.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(xc.device).cuda_stream)))
+    return out
+
+
+def pack_triangle(xs, rows=None):
+    """the ``N (N + 1) / 2`` folded traces of ``xs`` ``(N, N, T)`` as one contiguous ``(N (N + 1) / 2, T)`` tensor (what travels)"""
+    N, _, T = xs.shape
+    rows = triangle_rows(N, xs.device) if rows is None else rows
+    return xs.reshape(N * N, T).index_select(0, rows)
+
+
+def unpack_triangle(packed, xs, rows=None):
+    """the inverse of :func:`pack_triangle`: ``packed`` into the upper triangle of the folded-frame buffer ``xs`` ``(N, N, T)`` (the rest of it is never read)"""
+    N, _, T = xs.shape
+    rows = triangle_rows(N, xs.device) if rows is None else rows
+    xs.reshape(N * N, T).index_copy_(0, rows, packed)
+    return xs
+
+
+class FoldedReplicator:
+    """A stream of reciprocal frames from ONE acquisition rank to every rank of the group, folded: ``src`` calls :meth:`send` with a frame (any rank may
+    pass ``None``), every rank then owns the folded frame ``(N, N, T)`` complex64 for its ``ShardedDasPlan(..., prefolded=True)``.  Two buffers:
+    ``send(..., async_op=True)`` returns the work handle, so the transfer of frame ``f + 1`` overlaps the beamforming of frame ``f``.
+
+    ``fold`` replaces ``qdas_fold`` in the CPU tests (``fold(xc) -> xs``) to exercise packing and the collective under ``gloo`` without a GPU."""
+
+    def __init__(self, N: int, T: int, device, src: int = 0, group=None, fold: Callable | None = None, nbuf: int = 2):
+        import torch
+        self.N, self.T, self.src, self.group, self._fold = N, T, src, group, fold
+        self.rows = triangle_rows(N, device)
+        self.packed = [torch.zeros((N * (N + 1) // 2, T), dtype=torch.complex64, device=device) for _ in range(nbuf)]
+        self.frames = [torch.zeros((N, N, T), dtype=torch.complex64, device=device) for _ in range(nbuf)]
+        self._k = 0
+
+    @property
+    def bytes_per_frame(self) -> int:
+        return self.packed[0].numel() * 8
+
+    def send(self, xc, rank: int, async_op: bool = False):
+        """start replicating one frame; returns ``(slot, work)`` -- ``work`` is None for a blocking call or a one-rank group"""
+        import torch
+        import torch.distributed as dist
+        slot = self._k % len(self.packed)
+        self._k += 1
+        if rank == self.src:
+            xs = self._fold(xc) if self._fold is not None else fold_frame(xc, self.frames[slot])
+            if xs is not self.frames[slot]:
+                self.frames[slot].copy_(xs)
+            torch.index_select(self.frames[slot].reshape(self.N * self.N, self.T), 0, self.rows, out=self.packed[slot])
+        work = None
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            work = dist.broadcast(torch.view_as_real(self.packed[slot]), self.src, group=self.group, async_op=async_op)
+        return slot, (work if async_op else None)
+
+    def receive(self, slot: int, rank: int, work=None):
+        """the folded frame of ``slot`` on this rank (waits for ``work``; the acquisition rank already holds it)"""
+        if work is not None:
+            work.wait()
+        if rank != self.src:
+            unpack_triangle(self.packed[slot], self.frames[slot], self.rows)
+        return self.frames[slot]
 
 
 # ------------------------------------------------------------------------------------------

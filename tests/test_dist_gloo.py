@@ -150,3 +150,70 @@ def test_mirror_slab_gather_gloo(world):
         assert spans[0][0] == 0 and sum(c for _, c in spans) == I1 * I2 // 2            # the slabs A tile the first half of the columns
         for (b0, c0), (b1, _) in zip(spans, spans[1:]):
             assert b0 + c0 == b1 and b0 % I1 == 0
+
+
+def _fold_np(x):
+    """numpy restatement of csrc/fold.hip on a column-major frame [m, n, t]: xs[m, n] = x[m, n] + x[n, m] for n < m, xs[m, m] = x[m, m], nothing below"""
+    M, N, T = x.shape
+    xs = np.zeros_like(x)
+    for m in range(M):
+        for n in range(m + 1):
+            xs[m, n] = x[m, n] + (x[n, m] if n != m else 0)
+    return xs
+
+
+def _folded_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import das_oracle as O
+        from qups_amd import build_problem, parse_options
+        from qups_amd.dist import FoldedReplicator, ShardedDasPlan
+        case = make_case(seq="FSA", interp="linear", seed=5, N=6, I1=10, I2=4)
+        xfull = case["x"]                                           # T x N x M on every rank; only the acquisition rank may look at it
+        T, N, M = xfull.shape
+        full = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xfull, case["t0"], case["fs"], cinv_f32(case["c"]),
+                          VS=case["VS"], DV=case["DV"], interp="linear").reshape(-1, order="F")
+        x = torch.from_numpy(xfull)
+        prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], x.shape, case["t0"], case["fs"], case["c"],
+                             parse_options(x, list(case["opt"]) + ["interp", "linear"]))
+
+        def compute(xs_cm, F, b, c):                                # the slab from the FOLDED frame: the oracle over it sums the upper triangle = every pair
+            xs = xs_cm.numpy().transpose(2, 1, 0)                   # T x N x M, zeros where n > m
+            y = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs, case["t0"], case["fs"], cinv_f32(case["c"]),
+                           VS=case["VS"], DV=case["DV"], interp="linear").reshape(-1, order="F")
+            return torch.from_numpy(y[b:b + c].astype(np.complex64)).reshape(1, 1, 1, c)
+
+        rep = FoldedReplicator(N, T, "cpu", src=0, fold=lambda xc: torch.from_numpy(_fold_np(xc.numpy())))
+        plan = ShardedDasPlan(prob, rank, world, compute=compute, mirror_slabs=False)
+        oks = []
+        for f in range(3):                                          # a stream: the transfer of frame f + 1 is started before frame f is beamformed
+            frames = [(xfull * (1 + f)).astype(np.complex64), None]
+            xc = torch.from_numpy(np.ascontiguousarray(frames[0].transpose(2, 1, 0))) if rank == 0 else None
+            slot, work = rep.send(xc, rank, async_op=True)
+            xs = rep.receive(slot, rank, work)
+            y = plan.execute_colmajor(xs, 1).reshape(-1).numpy()
+            oks.append(bool(np.abs(y - (1 + f) * full).max() <= 2e-6 * np.abs(full).max() * (1 + f)))
+            # nothing below the diagonal arrived, and exactly the triangle's bytes travelled
+            low = xs.numpy()[np.triu_indices(N, 1)]
+            oks.append(not low.any() and rep.bytes_per_frame == N * (N + 1) // 2 * T * 8)
+        q.put((rank, all(oks)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_folded_replication_gloo(world):
+    """a reciprocal frame travels FOLDED from the acquisition rank (half the bytes: the packed upper triangle, one broadcast), every rank beamforms its
+    slab from the folded frame: the image is the full N x M sum (linearity of the interpolators)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_folded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

@@ -301,3 +301,15 @@ def test_bench_shared_gpu_plumbing_prints_one_line(tmp_path):
     two = _bench(["--gpus", "2"] + common, dict(env, QDAS_BENCH_SHARE_GPU="1"))
     assert two["n_gpus"] == 2 and two["multi_gpu"]["backend"] == "gloo" and "mirror-pixel-slab x2" in two["config"]["parallelism"], two
     assert two["image_checksum"] == one["image_checksum"]
+
+
+def test_bench_shared_gpu_folded_replication_stream(tmp_path):
+    """one GPU, two ranks sharing it (gloo), the headline workload: ``bench.py --gpus 2`` also streams frames FOLDED from rank 0 (qups_amd.dist.FoldedReplicator:
+    one broadcast of the packed upper triangle, PREFOLDED mirror-slab plans) -- the plumbing of that leg, the bytes that travel, and the image against the
+    headline's (the same kernels on the same folded samples)"""
+    env = {"QDAS_CACHE_DIR": str(tmp_path), "QDAS_BENCH_SHARE_GPU": "1"}
+    two = _bench(["--gpus", "2", "--workload", "c3", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-traffic", "--no-general"], env)
+    fs = two["multi_gpu"]["stream_folded_replication"]
+    assert two["n_gpus"] == 2 and fs and isinstance(fs["ms_per_step"], float), two["multi_gpu"]
+    assert fs["bytes_per_frame"] == 256 * 257 // 2 * 2816 * 8 and fs["bytes_per_frame"] * 2 < two["multi_gpu"]["x_bytes"] * 1.01
+    assert fs["image_vs_headline"] <= 1e-6, fs

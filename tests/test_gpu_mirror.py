@@ -586,3 +586,35 @@ def test_prefolded_plans_and_the_fold_entry(prec):
     prob = build_problem("DAS", pw["Pi"], pw["Pr"], pw["Pv"], pw["Nv"], tuple(xp.shape), pw["t0"], pw["fs"], pw["c"], parse_options(xp, list(pw["opt"]) + ["interp", "linear"]))
     with pytest.raises(Exception, match="PREFOLDED"):
         DasPlan(prob, kernel=2, prefolded=True)
+
+
+@pytest.mark.gpu
+def test_folded_replicator_on_the_device():
+    """qups_amd.dist.FoldedReplicator on a HIP device (a one-rank group: no collective): the acquisition rank's fold + pack, a receiver's unpack, and a
+    PREFOLDED sharded plan over the folded frame -- the image is the folding plan's bit for bit, and what would travel is the upper triangle only"""
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd.das_spec import _colmajor
+    from qups_amd.dist import FoldedReplicator, ShardedDasPlan, pack_triangle, unpack_triangle
+    case = make_case(seq="FSA", interp="lanczos3", seed=19, N=32, I1=150, I2=40)
+    xt = torch.from_numpy(case["x"])
+    T, N, M = case["x"].shape
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"],
+                         parse_options(xt, list(case["opt"]) + ["interp", "lanczos3"]))
+    xc = _colmajor(xt.cuda())
+    with DasPlan(prob, kernel=2) as plan:
+        assert plan.folded
+        y0 = plan.execute_colmajor(xc, 1)
+    rep = FoldedReplicator(N, T, xc.device)
+    assert rep.bytes_per_frame == N * (N + 1) // 2 * T * 8
+    for _ in range(3):                                         # (both buffers, twice)
+        slot, work = rep.send(xc, 0, async_op=True)
+        xs = rep.receive(slot, 0, work)
+    other = torch.zeros_like(xs)                               # what a receiving rank does with the packed triangle
+    unpack_triangle(rep.packed[slot], other, rep.rows)
+    assert torch.equal(other, xs) and torch.equal(pack_triangle(other), rep.packed[slot])
+    sp = ShardedDasPlan(prob, 0, 1, device=xc.device, kernel=2, prefolded=True)
+    assert sp.plan.folded
+    y1 = sp.execute_colmajor(other, 1)
+    sp.close()
+    assert torch.equal(y0, y1)
