@@ -15,6 +15,8 @@
 // walks its own lists only; the waveform itself sits in LDS when it fits.
 #include "qdas_device.h"
 #include "qdas_kernels.h"
+#include <math.h>
+#include <stdlib.h>
 
 namespace qdas {
 
@@ -124,6 +126,248 @@ __global__ void __launch_bounds__(256) greens_kernel(const GreensParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Many scatterers: IMPULSE TRAINS (round 4).  With an integer waveform-to-data sampling ratio Q = fsr the waveform position of output sample s for
+// an entry with delay d (output samples) is p = Q s - Q d = (Q s - c) + u with c = ceil(Q d) and u = c - Q d in [0, 1): the tap index ti = Q s - c
+// runs over the samples, the FRACTION u -- hence the interpolation weights -- is ONE per entry.  So
+//     y[s] = sum_k sum_t H_k[Q s - t] x[t + o_k],     H_k[c] = sum over the entries with ceil(Q d_i) = c of  a_i g_i w_k(u_i),
+// (o_k: tap offsets of the interpolator; t over the tap indices the edge rule of qdas_device.h admits): every entry costs its delay, its K weights
+// and K complex adds into K impulse trains -- whatever the length of the waveform --, and ONE dense convolution of the trains with the waveform per
+// block of samples follows (K x T multiply-adds per output sample, whatever the number of scatterers).  The kernel above evaluates the waveform per
+// (entry, sample) -- ~1.3 divergent sample evaluations of 256 lanes per entry and wave --: 100 000 scatterers on the C1 geometry 95 ms; this one 6 ms.
+// Exactly the reference's sum (src/greens.cu:8-86) re-associated, with the edge rule per train.
+// The trains are accumulated in LDS with 64-bit INTEGER atomics (ds_add_u64) on fixed-point values: integer addition is associative, so the result
+// does not depend on the order in which the lanes arrive -- bit-reproducible, unlike float atomics (the reference's own wsinterpd2 path, src/interpd.cu:393).
+// Scale: 2^46 / (largest single contribution, greens_bound_kernel): 17 bits of headroom for coincident entries; a contribution 2^-22 of the largest
+// still carries fp32's 24 bits.  fp32 data only (fixed point would cost fp64 data its last bits); non-integer fsr and few entries keep the kernel above.
+// ------------------------------------------------------------------------------------------
+constexpr int GT_THREADS = 1024;
+
+__global__ void __launch_bounds__(256) greens_bound_kernel(const GreensParams P, unsigned int *bound_bits) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.I) return;
+    const float *Ps = (const float *)P.Ps, *Pr = (const float *)P.Pr, *Pv = (const float *)P.Pv;
+    const float2 ai = ((const float2 *)P.a)[i];
+    float b = sqrtf(ai.x * ai.x + ai.y * ai.y) / (float)P.fsr;
+    const float R0 = (float)P.R0;
+    if (R0 != 0.f) {                                     // 1 / (max(r1, R0) max(r2, R0)) at the nearest receive / transmit (sub-)element
+        const float px = Ps[3 * i], py = Ps[3 * i + 1], pz = Ps[3 * i + 2];
+        float m1 = INFINITY, m2 = INFINITY;
+        for (uint64_t k = 0; k < P.N * (uint64_t)P.En; ++k) { const float ax = px - Pr[3 * k], ay = py - Pr[3 * k + 1], az = pz - Pr[3 * k + 2]; m1 = fminf(m1, ax * ax + ay * ay + az * az); }
+        for (uint64_t k = 0; k < P.M * (uint64_t)P.Em; ++k) { const float ax = px - Pv[3 * k], ay = py - Pv[3 * k + 1], az = pz - Pv[3 * k + 2]; m2 = fminf(m2, ax * ax + ay * ay + az * az); }
+        b /= fmaxf(sqrtf(m1), R0) * fmaxf(sqrtf(m2), R0);
+    }
+    b *= 1.5f;                                           // |w_k| <= 1 for every interpolator here (Lanczos peaks at 1, the cubics at 1): margin for rounding
+    if (!(b >= 0.f) || b > 3.0e38f) b = INFINITY;        // a non-finite amplitude: the trains cannot carry it (the kernel writes NaN)
+    atomicMax(bound_bits, __float_as_uint(b));           // non-negative floats order like their bit patterns
+}
+
+// element-to-scatterer distances, ONCE per launch: the delay is separable, r1 depends on (scatterer, receive element) and r2 on (scatterer, transmit
+// element) only -- (N En + M Em) I square roots instead of the N En M Em I x 2 (x blocks per trace) of a scan that recomputes them
+__global__ void __launch_bounds__(256) greens_dist_kernel(const float *__restrict__ Ps, const float *__restrict__ Pe, float *__restrict__ R, uint64_t I) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= I) return;
+    const size_t k = 3 * (size_t)blockIdx.y;
+    const float ax = Ps[3 * i] - Pe[k], ay = Ps[3 * i + 1] - Pe[k + 1], az = Ps[3 * i + 2] - Pe[k + 2];
+    R[(size_t)blockIdx.y * I + i] = sqrtf(ax * ax + ay * ay + az * az);          // src/greens.cu:61-62
+}
+
+// |t| < 2^53 float -> the nearest 64-bit integer, without the generic conversion sequence: t = hi 2^23 + lo with hi = rint(t 2^-23) (|hi| < 2^30) and
+// lo = t - hi 2^23 exactly (one FMA; |lo| <= 2^22), both through v_cvt_i32_f32
+__device__ __forceinline__ long long gt_fixed(float t) {
+    const float hi = rintf(t * 1.1920928955078125e-7f);
+    const float lo = fmaf(hi, -8388608.0f, t);
+    return ((long long)(int)hi << 23) + (long long)(int)rintf(lo);
+}
+
+constexpr int GT_WQ = 128;                               // entries a wave queues before it works 64 of them off
+
+template <int INTERP>
+__global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensParams P, const unsigned int *bound_bits) {
+    constexpr int K = INTERP == 0 ? 2 : interp_taps(INTERP);         // nearest: two trains (the sample at ti, or at ti + 1)
+    constexpr int O0 = K == 4 ? -1 : 0;                              // tap offset of train 0 (train k: O0 + k)
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    const long T = (long)P.T;
+    const int Q = P.q;
+    const uint32_t SB = P.sb, PARTS = GT_THREADS / SB;
+    // tap indices ti the edge rule admits (qdas_device.h sample_global): 4 taps: 1 <= ti <= T-3; linear: 0 <= ti <= T-2; nearest: ti >= 0 and ti (+1) < T
+    const long tlo = K == 4 ? 1 : 0;
+    const long thi_k0 = K == 4 ? T - 3 : (INTERP == 0 ? T - 1 : T - 2), thi_k1 = K == 4 ? T - 3 : T - 2;      // (trains 2, 3 as train 1)
+    const long thi = thi_k0;
+    const uint32_t NSLOT = (uint32_t)((long)Q * (SB - 1) + thi - tlo + 1);
+    long long *H = (long long *)gsm;                                 // [K][NSLOT] {re, im} fixed point, later float2 in place
+    float4 *wq = (float4 *)(H + (size_t)K * NSLOT * 2);              // [waves][GT_WQ] {slot, u, scatterer, r1 r2}: this wave's entries that land in the block
+    float2 *red = (float2 *)(wq + (GT_THREADS / 64) * GT_WQ);        // [PARTS][SB]
+    float2 *xl = red + GT_THREADS;                                   // [T]
+    const uint32_t n = blockIdx.y, m = blockIdx.z, tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const float2 *a = (const float2 *)P.a, *x = (const float2 *)P.x;
+    for (uint32_t k = tid; k < (uint32_t)K * NSLOT * 2; k += GT_THREADS) H[k] = 0;
+    for (long k = tid; k < T; k += GT_THREADS) xl[k] = x[k];
+    const float bound = __uint_as_float(*bound_bits);
+    const float Sc = bound > 0.f ? fminf(70368744177664.0f / bound, 1.0e37f) : 0.f;   // 2^46 / largest single contribution
+    const float fs = (float)P.fs, fsr = (float)P.fsr, cinv = (float)P.cinv, R0 = (float)P.R0, toff = (float)(P.t0 - P.s0);
+    const int EE = P.En * P.Em;
+    const uint64_t s_lo = (uint64_t)blockIdx.x * SB, I = P.I;
+    const long cbase = (long)Q * (long)s_lo - thi;                   // fine index of slot 0
+    __syncthreads();
+    if (bound <= 3.0e38f) {
+        // Scan: one scatterer per lane and pass, the (receive, transmit) sub-aperture pairs in the outer loop; two coalesced table reads, the delay,
+        // the slot test.  Entries that land in this block -- 1 / (blocks per trace) of them -- go to the WAVE's queue in LDS (ballot + prefix: no
+        // barrier, no atomic); whenever 64 are queued the wave works them off with every lane busy: amplitude, weights, fixed point, K complex adds.
+        float4 *myq = wq + (size_t)wave * GT_WQ;
+        uint32_t qn = 0;                                             // queued entries (uniform)
+        auto work_off = [&](uint32_t first, uint32_t count) {
+            if (lane < count) {
+                const float4 it = myq[first + lane];
+                const uint32_t slot = __float_as_uint(it.x);
+                const float u = it.y;
+                const float2 ai = a[__float_as_uint(it.z)];
+                const float g = Sc / (it.w * fsr);
+                float w[4];
+                if constexpr (INTERP == 0) { w[0] = u < 0.5f ? 1.f : 0.f; w[1] = 1.f - w[0]; }
+                else interp_weights<INTERP>(u, w);
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const long long vr = gt_fixed(ai.x * g * w[k]), vi = gt_fixed(ai.y * g * w[k]);
+                    unsigned long long *h = (unsigned long long *)(H + ((size_t)k * NSLOT + slot) * 2);
+                    if (vr) atomicAdd(h, (unsigned long long)vr);
+                    if (vi) atomicAdd(h + 1, (unsigned long long)vi);
+                }
+            }
+        };
+        for (int sub = 0; sub < EE; ++sub) {
+            const int ne = sub % P.En, me = sub / P.En;
+            const float *R1 = P.r1tab + ((size_t)n + (size_t)ne * P.N) * I, *R2 = P.r2tab + ((size_t)m + (size_t)me * P.M) * I;
+            // (four scatterers per lane and iteration: the eight table loads are in flight together -- one exposed L2 latency per 4096 entries, not per 1024)
+            const uint32_t I32 = (uint32_t)I;                        // (I < 2^32: host)
+            for (uint32_t i0 = 0; i0 < I32; i0 += 4 * GT_THREADS) {
+                float r1v[4], r2v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t i = i0 + tid + (uint32_t)q * GT_THREADS;
+                    r1v[q] = i < I32 ? R1[i] : INFINITY;             // (an infinite distance: never in a block)
+                    r2v[q] = i < I32 ? R2[i] : INFINITY;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t i = i0 + tid + (uint32_t)q * GT_THREADS;
+                    float r1 = r1v[q], r2 = r2v[q];
+                    const float d = (cinv * (r1 + r2) + toff) * fs;                                           // src/greens.cu:65
+                    const float ef = (float)Q * d, cf = ceilf(ef);
+                    const float sl = cf - (float)cbase;              // slot of the entry; a non-finite delay fails the test
+                    const bool hit = sl >= 0.f && sl < (float)NSLOT;
+                    const uint64_t mask = __ballot(hit);
+                    if (mask) {
+                        if (hit) {
+                            if (R0 != 0.f) { r1 = r1 < R0 ? R0 : r1; r2 = r2 < R0 ? R0 : r2; } else { r1 = 1.f; r2 = 1.f; }
+                            myq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] =
+                                make_float4(__uint_as_float((uint32_t)sl), cf - ef, __uint_as_float(i), r1 * r2);      // (u = cf - ef in [0, 1): exact)
+                        }
+                        qn += (uint32_t)__builtin_popcountll(mask);
+                        __builtin_amdgcn_wave_barrier();
+                        if (qn >= 64u) { qn -= 64u; work_off(qn, 64u); __builtin_amdgcn_wave_barrier(); }
+                    }
+                }
+            }
+        }
+        work_off(0u, qn);
+    }
+    __syncthreads();
+    // fixed point -> float2, in place, train by train (the float image of train k lies inside the fixed-point images of trains <= k)
+    const float inv = Sc > 0.f ? 1.0f / Sc : 0.f;
+    float2 *Hf = (float2 *)gsm;
+    for (int k = 0; k < K; ++k) {
+        float2 v[4];                                                 // NSLOT <= 4 * GT_THREADS (host)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t j = tid + q * GT_THREADS;
+            v[q] = j < NSLOT ? make_float2((float)H[((size_t)k * NSLOT + j) * 2] * inv, (float)H[((size_t)k * NSLOT + j) * 2 + 1] * inv) : make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const uint32_t j = tid + q * GT_THREADS; if (j < NSLOT) Hf[(size_t)k * NSLOT + j] = v[q]; }
+        __syncthreads();
+    }
+    // the convolution: output s_lo + sl, the (train, tap index) pairs dealt out to PARTS threads per output
+    const uint32_t so = tid % SB, part = tid / SB;
+    float2 acc = make_float2(0.f, 0.f);
+    {
+        const long len0 = thi_k0 - tlo + 1, len1 = thi_k1 - tlo + 1;
+        const long J = len0 + (K - 1) * len1;                        // pairs per output
+        long j0 = J * (long)part / (long)PARTS, j1 = J * (long)(part + 1) / (long)PARTS;
+        for (int k = 0; k < K; ++k) {
+            const long lenk = k == 0 ? len0 : len1, base = k == 0 ? 0 : len0 + (k - 1) * len1;
+            const long a0 = j0 > base ? j0 - base : 0, a1 = (j1 - base) < lenk ? (j1 - base) : lenk;
+            const float2 *hk = Hf + (size_t)k * NSLOT + (size_t)Q * so + (size_t)(thi - tlo);    // slot of t = tlo; t + 1 is one slot down
+            for (long q = a0; q < a1; ++q) {
+                const float2 h = hk[-q], xv = xl[tlo + q + O0 + k];
+                acc.x += h.x * xv.x - h.y * xv.y; acc.y += h.x * xv.y + h.y * xv.x;
+            }
+        }
+    }
+    red[part * SB + so] = acc;
+    __syncthreads();
+    if (part == 0) {
+        for (uint32_t p2 = 1; p2 < PARTS; ++p2) { const float2 r = red[p2 * SB + so]; acc.x += r.x; acc.y += r.y; }
+        const uint64_t s = s_lo + so;
+        if (!(bound <= 3.0e38f)) acc = make_float2(NAN, NAN);
+        if (s < P.S) ((float2 *)P.y)[((size_t)n + (size_t)m * P.N) * P.S + s] = acc;
+    }
+}
+
+// 0: launched; 1: not this path (the kernel above runs)
+static int launch_greens_train(const GreensParams &P, hipStream_t s) {
+    static const bool off = getenv("QDAS_GREENS_NO_TRAINS") != nullptr;
+    if (off) return 1;
+    uint64_t min_entries = 1024;
+    if (const char *e = getenv("QDAS_GREENS_TRAIN_MIN")) { const long long v = atoll(e); if (v >= 0) min_entries = (uint64_t)v; }
+    const double q = floor(P.fsr + 0.5);
+    if (q != P.fsr || q < 1 || q > 16 || P.I * (uint64_t)(P.En * P.Em) < min_entries || P.T >= (1u << 20)) return 1;
+    const int K = P.interp == 0 ? 2 : interp_taps(P.interp);
+    const long T = (long)P.T, tlo = K == 4 ? 1 : 0, thi = K == 4 ? T - 3 : (P.interp == 0 ? T - 1 : T - 2);
+    if (thi < tlo) return 1;                                         // (a waveform shorter than the interpolator: nothing is ever in support)
+    GreensParams p = P;
+    p.q = (int)q;
+    size_t lds = 0;
+    for (uint32_t sb : {512u, 256u, 128u, 64u}) {
+        const uint64_t nslot = (uint64_t)q * (sb - 1) + (uint64_t)(thi - tlo) + 1;
+        lds = (size_t)K * nslot * 16 + (size_t)(GT_THREADS / 64) * GT_WQ * 16 + (size_t)GT_THREADS * 8 + (size_t)T * 8;
+        if (nslot <= 4ull * GT_THREADS && lds <= 150 * 1024) { p.sb = sb; break; }
+    }
+    if (!p.sb) return 1;
+    const uint64_t ne_tot = P.N * (uint64_t)P.En, me_tot = P.M * (uint64_t)P.Em;
+    if (ne_tot > 65535 || me_tot > 65535 || P.I + 4ull * GT_THREADS >= (1ull << 32) || (ne_tot + me_tot) * P.I * 4 > (8ull << 30)) return 1;      // (distance tables: at most 8 GiB)
+    unsigned int *bound = nullptr;
+    float *tabs = nullptr;
+    if (hipMallocAsync((void **)&bound, 16 + sizeof(float) * (ne_tot + me_tot) * P.I, s) != hipSuccess || !bound) { (void)hipGetLastError(); return 1; }
+    if (hipMemsetAsync(bound, 0, sizeof(unsigned int), s) != hipSuccess) { (void)hipGetLastError(); (void)hipFreeAsync(bound, s); return 1; }
+    tabs = (float *)((char *)bound + 16);
+    p.r1tab = tabs; p.r2tab = tabs + ne_tot * P.I;
+    greens_dist_kernel<<<dim3((unsigned)((P.I + 255) / 256), (unsigned)ne_tot), 256, 0, s>>>((const float *)P.Ps, (const float *)P.Pr, tabs, P.I);
+    greens_dist_kernel<<<dim3((unsigned)((P.I + 255) / 256), (unsigned)me_tot), 256, 0, s>>>((const float *)P.Ps, (const float *)P.Pv, tabs + ne_tot * P.I, P.I);
+    greens_bound_kernel<<<(unsigned)((P.I + 255) / 256), 256, 0, s>>>(p, bound);
+    const dim3 g((unsigned)((P.S + p.sb - 1) / p.sb), (unsigned)P.N, (unsigned)P.M), b(GT_THREADS);
+    hipError_t err = hipSuccess;
+#define QT(I)                                                                                       \
+    do {                                                                                            \
+        auto kfn = greens_train_kernel<I>;                                                          \
+        err = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (err == hipSuccess) kfn<<<g, b, lds, s>>>(p, bound);                                     \
+    } while (0)
+    switch (P.interp) {
+        case 0: QT(0); break;
+        case 1: case 4: QT(1); break;
+        case 2: QT(2); break;
+        case 3: QT(3); break;
+        case 5: QT(5); break;
+        default: err = hipErrorInvalidValue;
+    }
+#undef QT
+    (void)hipFreeAsync(bound, s);
+    return (err == hipSuccess && hipGetLastError() == hipSuccess) ? 0 : 1;
+}
+
 template <typename TY>
 static hipError_t launch_greens_t(const GreensParams &P, hipStream_t s) {
     GreensParams p = P;
@@ -155,7 +399,7 @@ hipError_t launch_greens(const GreensParams &P, int dtype, hipStream_t s) {
     if (P.S == 0 || P.N == 0 || P.M == 0) return hipSuccess;
     switch (dtype) {
         case 0: return launch_greens_t<st_f64>(P, s);
-        case 1: return launch_greens_t<st_f32>(P, s);
+        case 1: if (launch_greens_train(P, s) == 0) return hipSuccess; return launch_greens_t<st_f32>(P, s);
     }
     return hipErrorInvalidValue;
 }

@@ -52,11 +52,15 @@ def test_oracle_single_scatterer_arrives_on_time_and_is_linear():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["per-sample", "trains"])
 @pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3"])
 @pytest.mark.parametrize("prec,En,Em,fsr,R0", [("single", 1, 1, 2.0, None), ("single", 2, 3, 1.0, None), ("double", 1, 2, 4.0, None),
-                                                ("single", 1, 1, 2.0, 0.0)])
-def test_greens_kernel_matches_oracle(interp, prec, En, Em, fsr, R0):
+                                                ("single", 1, 1, 2.0, 0.0), ("single", 1, 2, 4.0, None), ("single", 1, 1, 1.5, None)])
+def test_greens_kernel_matches_oracle(interp, prec, En, Em, fsr, R0, path, monkeypatch):
+    """both kernels of csrc/greens.hip: the per-(entry, sample) one, and -- integer fsr, fp32 -- the impulse trains + one convolution per block
+    (QDAS_GREENS_TRAIN_MIN switches per call; fp64 data and fsr = 1.5 stay on the first whatever it says)"""
     import torch
+    monkeypatch.setenv("QDAS_GREENS_TRAIN_MIN", "0" if path == "trains" else "1000000000000")
     from oracle import greens_oracle as GO
     from qups_amd.greens import greens_kernel
     g = _setup(seed=5, N=9, M=7, I=300 if En == 1 else 40, En=En, Em=Em, fsr=fsr)     # > one 256-entry pass
@@ -108,3 +112,35 @@ def test_examples_psf_demo_finds_both_targets():
     peaks = mod.main()
     (x0, z0, _), (x1, z1, _) = peaks
     assert abs(x0 + 3.0) <= 1.1 and abs(z0 - 22.0) <= 1.1 and abs(x1 - 2.0) <= 1.1 and abs(z1 - 15.0) <= 1.1
+
+
+@pytest.mark.gpu
+def test_greens_impulse_trains_many_scatterers_edges_and_reproducibility(monkeypatch):
+    """the impulse-train kernel where it matters and where it could go wrong: thousands of scatterers (coincident slots, several blocks of samples),
+    a SHORT waveform whose edges are far from zero (the edge rule per train: a sample whose taps cross the waveform's end is exactly zero, not a
+    partial sum), amplitudes over six decades (fixed-point scale), and bit-identical results run after run (integer atomics)"""
+    import torch
+    from oracle import greens_oracle as GO
+    from qups_amd.greens import greens_kernel
+    g = _setup(seed=11, N=5, M=4, I=3000, fsr=4.0)
+    r = np.random.default_rng(1)
+    g["a"] = (g["a"] * 10.0 ** r.uniform(-6, 0, g["a"].shape)).astype(np.complex64)
+    x_short = (r.standard_normal(9) + 1j * r.standard_normal(9)).astype(np.complex64)       # 9 waveform samples, no taper
+    for x in (g["x"], x_short):
+        for interp in ("nearest", "linear", "cubic", "lanczos3"):
+            ref = GO.greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], x, 1500, g["s0"], g["t0"], g["fs"], 4.0, g["cinv"], g["R0"], interp)
+            monkeypatch.setenv("QDAS_GREENS_TRAIN_MIN", "0")
+            y1 = greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], x, 1500, g["s0"], g["t0"], g["fs"], 4.0, g["cinv"], g["R0"], interp, "single")
+            y2 = greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], x, 1500, g["s0"], g["t0"], g["fs"], 4.0, g["cinv"], g["R0"], interp, "single")
+            monkeypatch.setenv("QDAS_GREENS_TRAIN_MIN", "1000000000000")
+            y0 = greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], x, 1500, g["s0"], g["t0"], g["fs"], 4.0, g["cinv"], g["R0"], interp, "single")
+            torch.cuda.synchronize()
+            assert torch.equal(y1, y2)                                    # order-independent accumulation
+            o1, o0 = y1.cpu().numpy(), y0.cpu().numpy()
+            den = np.abs(ref).max()
+            # (against the float64 oracle both kernels carry the fp32 delay: a sample on a rounding / support boundary picks the neighbour or the zero)
+            assert (np.abs(o1 - ref) / den > 1e-4).mean() < (0.02 if interp == "nearest" else 1e-3), (interp, len(x))
+            if interp not in ("nearest",) and len(x) > 9:
+                assert np.abs(o1 - ref).max() / den <= 3e-4, (interp, len(x))
+            assert np.abs(o1 - o0).max() / den <= 5e-6, (interp, len(x))         # the same sum, re-associated
+            assert not np.array_equal(o1, o0)                             # (the two kernels round differently: identical bits would mean the switch did nothing)
