@@ -180,6 +180,11 @@ __device__ __forceinline__ long long gt_fixed(float t) {
     return ((long long)(int)hi << 23) + (long long)(int)rintf(lo);
 }
 
+// ... and back: (float)v without the generic 64-bit conversion sequence (two 32-bit conversions and an FMA; the sum is rounded once more, 2^-24 relative)
+__device__ __forceinline__ float gt_float(long long v) {
+    return fmaf((float)(int)(v >> 32), 4294967296.0f, (float)(unsigned int)(v & 0xffffffffll));
+}
+
 constexpr int GT_WQ = 128;                               // entries a wave queues before it works 64 of them off
 
 template <int INTERP>
@@ -196,7 +201,7 @@ __global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensPa
     const long thi = thi_k0;
     const uint32_t NSLOT = (uint32_t)((long)Q * (SB - 1) + thi - tlo + 1);
     long long *H = (long long *)gsm;                                 // [K][NSLOT] {re, im} fixed point, later float2 in place
-    float4 *wq = (float4 *)(H + (size_t)K * NSLOT * 2);              // [waves][GT_WQ] {slot, u, scatterer, r1 r2}: this wave's entries that land in the block
+    float4 *wq = (float4 *)(H + (size_t)K * NSLOT * 2);              // [waves][GT_WQ] {scatterer, r1, r2}: this wave's entries that (may) land in the block
     float2 *red = (float2 *)(wq + (GT_THREADS / 64) * GT_WQ);        // [PARTS][SB]
     float2 *xl = red + GT_THREADS;                                   // [T]
     const uint32_t n = blockIdx.y, m = blockIdx.z, tid = threadIdx.x, lane = tid & 63u;
@@ -217,25 +222,37 @@ __global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensPa
         // barrier, no atomic); whenever 64 are queued the wave works them off with every lane busy: amplitude, weights, fixed point, K complex adds.
         float4 *myq = wq + (size_t)wave * GT_WQ;
         uint32_t qn = 0;                                             // queued entries (uniform)
+        // (the scan's test is a window on r1 + r2, a hair wider than the block: the exact slot -- the reference's own fp32 delay arithmetic -- is found here)
         auto work_off = [&](uint32_t first, uint32_t count) {
             if (lane < count) {
                 const float4 it = myq[first + lane];
-                const uint32_t slot = __float_as_uint(it.x);
-                const float u = it.y;
-                const float2 ai = a[__float_as_uint(it.z)];
-                const float g = Sc / (it.w * fsr);
-                float w[4];
-                if constexpr (INTERP == 0) { w[0] = u < 0.5f ? 1.f : 0.f; w[1] = 1.f - w[0]; }
-                else interp_weights<INTERP>(u, w);
+                float r1 = it.y, r2 = it.z;
+                const float d = (cinv * (r1 + r2) + toff) * fs;                                               // src/greens.cu:65
+                const float ef = (float)Q * d, cf = ceilf(ef);
+                const float sl = cf - (float)cbase;                  // slot of the entry; a non-finite delay fails the test
+                if (sl >= 0.f && sl < (float)NSLOT) {
+                    const uint32_t slot = (uint32_t)sl;
+                    const float u = cf - ef;                         // in [0, 1): exact
+                    if (R0 != 0.f) { r1 = r1 < R0 ? R0 : r1; r2 = r2 < R0 ? R0 : r2; } else { r1 = 1.f; r2 = 1.f; }
+                    const float2 ai = a[__float_as_uint(it.x)];
+                    const float g = Sc / (r1 * r2 * fsr);
+                    float w[4];
+                    if constexpr (INTERP == 0) { w[0] = u < 0.5f ? 1.f : 0.f; w[1] = 1.f - w[0]; }
+                    else interp_weights<INTERP>(u, w);
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const long long vr = gt_fixed(ai.x * g * w[k]), vi = gt_fixed(ai.y * g * w[k]);
-                    unsigned long long *h = (unsigned long long *)(H + ((size_t)k * NSLOT + slot) * 2);
-                    if (vr) atomicAdd(h, (unsigned long long)vr);
-                    if (vi) atomicAdd(h + 1, (unsigned long long)vi);
+                    for (int k = 0; k < K; ++k) {
+                        const long long vr = gt_fixed(ai.x * g * w[k]), vi = gt_fixed(ai.y * g * w[k]);
+                        unsigned long long *h = (unsigned long long *)(H + ((size_t)k * NSLOT + slot) * 2);
+                        if (vr) atomicAdd(h, (unsigned long long)vr);
+                        if (vi) atomicAdd(h + 1, (unsigned long long)vi);
+                    }
                 }
             }
         };
+        // r1 + r2 of the entries whose slot can lie in [0, NSLOT): ceil(Q d) - cbase in [0, NSLOT) <=> Q d in (cbase - 1, cbase + NSLOT - 1], d = (cinv r + toff) fs
+        const double rlo_d = (((double)cbase - 1.0) / ((double)Q * P.fs) - (P.t0 - P.s0)) / P.cinv, rhi_d = (((double)cbase + (double)NSLOT - 1.0) / ((double)Q * P.fs) - (P.t0 - P.s0)) / P.cinv;
+        const double mar = 4e-6 * (fabs(rlo_d) + fabs(rhi_d)) + 1e-30;      // (fp32 roundings of the delay: ~3 ulp of r)
+        const float rlo = (float)(rlo_d - mar), rhi = (float)(rhi_d + mar);
         for (int sub = 0; sub < EE; ++sub) {
             const int ne = sub % P.En, me = sub / P.En;
             const float *R1 = P.r1tab + ((size_t)n + (size_t)ne * P.N) * I, *R2 = P.r2tab + ((size_t)m + (size_t)me * P.M) * I;
@@ -251,19 +268,12 @@ __global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensPa
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const uint32_t i = i0 + tid + (uint32_t)q * GT_THREADS;
-                    float r1 = r1v[q], r2 = r2v[q];
-                    const float d = (cinv * (r1 + r2) + toff) * fs;                                           // src/greens.cu:65
-                    const float ef = (float)Q * d, cf = ceilf(ef);
-                    const float sl = cf - (float)cbase;              // slot of the entry; a non-finite delay fails the test
-                    const bool hit = sl >= 0.f && sl < (float)NSLOT;
+                    const float r = r1v[q] + r2v[q];
+                    const bool hit = r >= rlo && r <= rhi;           // (infinite / NaN distances fail)
                     const uint64_t mask = __ballot(hit);
                     if (mask) {
-                        if (hit) {
-                            if (R0 != 0.f) { r1 = r1 < R0 ? R0 : r1; r2 = r2 < R0 ? R0 : r2; } else { r1 = 1.f; r2 = 1.f; }
-                            myq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] =
-                                make_float4(__uint_as_float((uint32_t)sl), cf - ef, __uint_as_float(i), r1 * r2);      // (u = cf - ef in [0, 1): exact)
-                        }
+                        if (hit) myq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] =
+                                     make_float4(__uint_as_float(i0 + tid + (uint32_t)q * GT_THREADS), r1v[q], r2v[q], 0.f);
                         qn += (uint32_t)__builtin_popcountll(mask);
                         __builtin_amdgcn_wave_barrier();
                         if (qn >= 64u) { qn -= 64u; work_off(qn, 64u); __builtin_amdgcn_wave_barrier(); }
@@ -282,7 +292,7 @@ __global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensPa
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const uint32_t j = tid + q * GT_THREADS;
-            v[q] = j < NSLOT ? make_float2((float)H[((size_t)k * NSLOT + j) * 2] * inv, (float)H[((size_t)k * NSLOT + j) * 2 + 1] * inv) : make_float2(0.f, 0.f);
+            v[q] = j < NSLOT ? make_float2(gt_float(H[((size_t)k * NSLOT + j) * 2]) * inv, gt_float(H[((size_t)k * NSLOT + j) * 2 + 1]) * inv) : make_float2(0.f, 0.f);
         }
         __syncthreads();
 #pragma unroll
@@ -323,7 +333,7 @@ static int launch_greens_train(const GreensParams &P, hipStream_t s) {
     uint64_t min_entries = 1024;
     if (const char *e = getenv("QDAS_GREENS_TRAIN_MIN")) { const long long v = atoll(e); if (v >= 0) min_entries = (uint64_t)v; }
     const double q = floor(P.fsr + 0.5);
-    if (q != P.fsr || q < 1 || q > 16 || P.I * (uint64_t)(P.En * P.Em) < min_entries || P.T >= (1u << 20)) return 1;
+    if (q != P.fsr || q < 1 || q > 16 || !(P.cinv > 0) || !(P.fs > 0) || P.I * (uint64_t)(P.En * P.Em) < min_entries || P.T >= (1u << 20)) return 1;
     const int K = P.interp == 0 ? 2 : interp_taps(P.interp);
     const long T = (long)P.T, tlo = K == 4 ? 1 : 0, thi = K == 4 ? T - 3 : (P.interp == 0 ? T - 1 : T - 2);
     if (thi < tlo) return 1;                                         // (a waveform shorter than the interpolator: nothing is ever in support)
