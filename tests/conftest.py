@@ -32,6 +32,8 @@ def pytest_collection_finish(session):
         if not os.environ.get("QDAS_CACHE_DIR") and not os.environ.get("HOME"):      # (no private place for the disk cache: make one for this session)
             import tempfile
             os.environ["QDAS_CACHE_DIR"] = tempfile.mkdtemp(prefix="qdas_cache_")
+        # the variants live in ONE directory for the whole session, whatever scratch directory a test points QDAS_CACHE_DIR at (csrc/jit.hip cache_dir)
+        os.environ.setdefault("QDAS_VARIANT_CACHE_DIR", os.environ.get("QDAS_CACHE_DIR") or os.path.join(os.environ["HOME"], ".cache", "qdas"))
         from qups_amd import warm
         t = time.perf_counter()
         vs = warm.read_census([os.path.join(ROOT, "tests", "suite_kernels.txt")])

