@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) greens_kernel(const GreensParams P) {
 // (o_k: tap offsets of the interpolator; t over the tap indices the edge rule of qdas_device.h admits): every entry costs its delay, its K weights
 // and K complex adds into K impulse trains -- whatever the length of the waveform --, and ONE dense convolution of the trains with the waveform per
 // block of samples follows (K x T multiply-adds per output sample, whatever the number of scatterers).  The kernel above evaluates the waveform per
-// (entry, sample) -- ~1.3 divergent sample evaluations of 256 lanes per entry and wave --: 100 000 scatterers on the C1 geometry 95 ms; this one 6 ms.
+// (entry, sample) -- ~1.3 divergent sample evaluations of 256 lanes per entry and wave --: 100 000 scatterers on the C1 geometry 95 ms per call; this one 7.5 ms.
 // Exactly the reference's sum (src/greens.cu:8-86) re-associated, with the edge rule per train.
 // The trains are accumulated in LDS with 64-bit INTEGER atomics (ds_add_u64) on fixed-point values: integer addition is associative, so the result
 // does not depend on the order in which the lanes arrive -- bit-reproducible, unlike float atomics (the reference's own wsinterpd2 path, src/interpd.cu:393).
@@ -204,7 +204,15 @@ __global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensPa
     float4 *wq = (float4 *)(H + (size_t)K * NSLOT * 2);              // [waves][GT_WQ] {scatterer, r1, r2}: this wave's entries that (may) land in the block
     float2 *red = (float2 *)(wq + (GT_THREADS / 64) * GT_WQ);        // [PARTS][SB]
     float2 *xl = red + GT_THREADS;                                   // [T]
-    const uint32_t n = blockIdx.y, m = blockIdx.z, tid = threadIdx.x, lane = tid & 63u;
+    // XCD-aware order: the hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own L2), so workgroup g runs as item
+    // (g % 8) * G8 / 8 + g / 8 of a list that walks the blocks of a trace, then the receivers, then the transmits: the workgroups an XCD runs at
+    // a time share their distance rows (2 x 4 I bytes per trace) in ITS L2 -- in launch order every XCD saw every receiver's row
+    // (100 000 scatterers on a 256 x 256 x 2816 acquisition: 126 -> 104 ms)
+    const uint32_t nblk = P.nblk;
+    const uint64_t G8 = gridDim.x, item = (uint64_t)(blockIdx.x & 7u) * (G8 >> 3) + (blockIdx.x >> 3);
+    if (item >= (uint64_t)nblk * P.N * P.M) return;
+    const uint32_t blk = (uint32_t)(item % nblk), trace = (uint32_t)(item / nblk);
+    const uint32_t n = trace % (uint32_t)P.N, m = trace / (uint32_t)P.N, tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const float2 *a = (const float2 *)P.a, *x = (const float2 *)P.x;
     for (uint32_t k = tid; k < (uint32_t)K * NSLOT * 2; k += GT_THREADS) H[k] = 0;
@@ -213,7 +221,7 @@ __global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensPa
     const float Sc = bound > 0.f ? fminf(70368744177664.0f / bound, 1.0e37f) : 0.f;   // 2^46 / largest single contribution
     const float fs = (float)P.fs, fsr = (float)P.fsr, cinv = (float)P.cinv, R0 = (float)P.R0, toff = (float)(P.t0 - P.s0);
     const int EE = P.En * P.Em;
-    const uint64_t s_lo = (uint64_t)blockIdx.x * SB, I = P.I;
+    const uint64_t s_lo = (uint64_t)blk * SB, I = P.I;
     const long cbase = (long)Q * (long)s_lo - thi;                   // fine index of slot 0
     __syncthreads();
     if (bound <= 3.0e38f) {
@@ -357,7 +365,10 @@ static int launch_greens_train(const GreensParams &P, hipStream_t s) {
     greens_dist_kernel<<<dim3((unsigned)((P.I + 255) / 256), (unsigned)ne_tot), 256, 0, s>>>((const float *)P.Ps, (const float *)P.Pr, tabs, P.I);
     greens_dist_kernel<<<dim3((unsigned)((P.I + 255) / 256), (unsigned)me_tot), 256, 0, s>>>((const float *)P.Ps, (const float *)P.Pv, tabs + ne_tot * P.I, P.I);
     greens_bound_kernel<<<(unsigned)((P.I + 255) / 256), 256, 0, s>>>(p, bound);
-    const dim3 g((unsigned)((P.S + p.sb - 1) / p.sb), (unsigned)P.N, (unsigned)P.M), b(GT_THREADS);
+    p.nblk = (uint32_t)((P.S + p.sb - 1) / p.sb);
+    const uint64_t items = (uint64_t)p.nblk * P.N * P.M, g8 = (items + 7) / 8 * 8;
+    if (g8 >= (1ull << 31)) { (void)hipFreeAsync(bound, s); return 1; }
+    const dim3 g((unsigned)g8), b(GT_THREADS);
     hipError_t err = hipSuccess;
 #define QT(I)                                                                                       \
     do {                                                                                            \

@@ -102,7 +102,7 @@ struct GreensParams {
     int32_t En, Em, interp, x_in_lds;
     double s0, t0, fs, fsr, cinv, R0;
     int32_t q;                       // impulse-train kernel (greens.hip): the integer waveform-to-data sampling ratio, output samples per workgroup
-    uint32_t sb;
+    uint32_t sb, nblk;
     const float *r1tab, *r2tab;      // ... and the scatterer-to-element distances, [N En][I] and [M Em][I]
 };
 hipError_t launch_greens(const GreensParams &P, int dtype, hipStream_t s);
