@@ -352,7 +352,11 @@ int qdas_wsinterpd(const qdas_wsinterpd_desc *d, void *y, void *stream);
  *   y[s,n,m] = 1/fsr * sum_i sum_ne sum_me a_i * sample(x, fsr*(s - (cinv*(r1+r2) + t0 - s0)*fs)) / (max(r1,R0)*max(r2,R0))
  * All pointers are DEVICE pointers; real = double (QDAS_F64) or float (QDAS_F32), complex = interleaved pairs.
  * The reference's `sb` / `blocks` arguments (per-scatterer sample windows for culling) are not needed: the kernel
- * derives the windows itself.  R0 == 0: no propagation loss (the reference's CPU branch, :797-803). */
+ * derives the windows itself.  R0 == 0: no propagation loss (the reference's CPU branch, :797-803).
+ * Two kernels, the same sum: per (entry, sample), and -- fp32 data, an integer fsr, at least QDAS_GREENS_TRAIN_MIN (1024) entries per trace -- impulse
+ * trains: the interpolation fraction is one per entry, so every entry adds its K weighted amplitudes to K fixed-point trains (64-bit integer LDS atomics:
+ * the result does not depend on the order of arrival, bit-reproducible) and one dense convolution with the waveform per block of samples follows.  The two
+ * agree to fp32 re-association (~1e-6 of the peak); an entry whose fp32 delay lies on a tap boundary may land on either side (csrc/greens.hip). */
 typedef struct qdas_greens_desc {
     uint64_t S;            /* output samples per trace                          (QUPS_S) */
     uint64_t T;            /* samples of the waveform x                          (QUPS_T) */
@@ -407,7 +411,9 @@ int qdas_shift_sum(const qdas_shift_desc *desc, const void *x, void *y, void *st
  * 'full': L = M+N-1, off = 0; 'same': L = M, off = N-1 - floor((N-1)/2); 'valid': L = max(M-N+1, 0), off = N-1
  * (kern/convd.m:103-114).  A singleton column / slice dimension of x or y is broadcast (bits of `bcast`) instead of being
  * replicated as the reference does (kern/convd.m:75-84).  QDAS_F16: the half-precision twins convh / convch (src/convd.cu:141,153) --
- * products and sums in fp32, rounded once at the store (the reference accumulates in half). */
+ * products and sums in fp32, rounded once at the store (the reference accumulates in half).
+ * Long filters: complex64 traces with C == 1 (time contiguous), one filter for all slices, N >= QDAS_CONV_FFT_MIN_TAPS (128) and M + N - 1 <= 8192 take an
+ * FFT convolution with the trace resident in LDS (csrc/pre.hip): the same outputs to fp32 rounding (a few 1e-6 of the largest), O(L log L) per trace. */
 #define QDAS_CONV_FULL  0
 #define QDAS_CONV_SAME  1
 #define QDAS_CONV_VALID 2
