@@ -33,7 +33,10 @@
 extern "C" {
 #endif
 
-#define QDAS_VERSION 100
+/* 100: rounds 1-3.  101 (round 5): qdas_wsinterpd_desc carries ystride[8] / lane_dim / reserved (added in round 4 without a bump), QDAS_PLAN_PREFOLDED rejects
+ * apodization arrays.  EVERY descriptor of this header must be ZERO-INITIALISED by the caller (memset / `= {0}`) before its fields are set: fields added by
+ * later versions then read as "default", and a caller compiled against an older header must check qdas_version() against the QDAS_VERSION it was built with. */
+#define QDAS_VERSION 101
 
 /* ---- data precision: the reference's kernel postfix (kern/das_spec.m:218-222) */
 #define QDAS_F64 0 /* 'DAS'  : double2 data/apod/y, double geometry + time            */
@@ -205,6 +208,11 @@ int  qdas_plan_execute(qdas_plan *plan, const void *x, void *y, void *stream);
  * asynchronous and not graph-capturable; set QDAS_NO_FRAMES_TWIN=1 to keep streams on the plan's own kernel. */
 int  qdas_plan_execute_frames(qdas_plan *plan, const void *x, void *y, uint64_t F,
                               uint64_t x_stride, uint64_t y_stride, void *stream);
+/* Everything a stream of F frames does ONCE per plan -- the twin plan above; for a reciprocity-folded plan the second folded copy of a frame (T x N x M
+ * complex64) that lets two frames share a launch; the frame-sharing kernel instantiations libqdas.so does not carry (built through hiprtc, ~2 s each);
+ * the second staging set of host-resident frames -- done now, synchronously.  Optional: qdas_plan_execute_frames does the same at the plan's first
+ * stream, which makes THAT call synchronous and not graph-capturable; after qdas_plan_prepare_frames(plan, F) every stream of up to F frames only enqueues. */
+int  qdas_plan_prepare_frames(qdas_plan *plan, uint64_t F);
 /* 'delays' (src/bf.cu:209-298, kern/das_spec.m:377): tau is i_count x N x M real(prec),
  * tau = cinv(1) * (dv + dr); no t0, like the reference. */
 int  qdas_plan_delays(qdas_plan *plan, void *tau, void *stream);
@@ -338,7 +346,8 @@ typedef struct qdas_wsinterpd_desc {
     /* extension (round 4): the layout of y.  ystride all 0: dense column-major over the kept dimensions (the reference's output).  Else element
        strides per dimension (summed dimensions ignored): lets a row-major / arbitrarily strided x be sampled IN PLACE into a y of the same layout
        -- together with x_tstride / xstride no layout pass is needed.  `lane_dim`: the kept dimension the lanes of a wave run along (choose the
-       one along which x -- or, where x broadcasts, t -- is contiguous); -1: the first kept dimension.                                         */
+       one along which x -- or, where x broadcasts, t -- is contiguous); -1, a summed dimension or a dimension of one element (so also the 0 of a
+       zero-initialised descriptor whose first dimension is a singleton): the first kept dimension with more than one element.                   */
     int64_t  ystride[8];
     int32_t  lane_dim;
     int32_t  reserved;

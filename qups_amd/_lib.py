@@ -28,7 +28,7 @@ RXAPOD_NONE, RXAPOD_ACCEPTANCE, RXAPOD_COSINE, RXAPOD_FNUMBER_PLANAR, RXAPOD_FNU
 
 # every symbol include/qdas.h declares (tests check the library exports all of them)
 SYMBOLS = (
-    "qdas_plan_create", "qdas_plan_execute", "qdas_plan_execute_frames", "qdas_plan_delays",
+    "qdas_plan_create", "qdas_plan_execute", "qdas_plan_execute_frames", "qdas_plan_prepare_frames", "qdas_plan_delays",
     "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_reciprocal", "qdas_plan_folded", "qdas_fold", "qdas_plan_symmetry_bound", "qdas_plan_mirror", "qdas_plan_kernel_name", "qdas_plan_set_timing",
     "qdas_plan_last_kernel_ms", "qdas_plan_create_sharded", "qdas_plan_execute_sharded", "qdas_plan_sharded_info", "qdas_plan_sharded_mirror",
     "qdas_plan_destroy_sharded", "qdas_DAS", "qdas_DASf", "qdas_DASh", "qdas_delays", "qdas_delaysf",
@@ -125,6 +125,7 @@ def lib():
     L.qdas_plan_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Desc)]
     L.qdas_plan_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.qdas_plan_execute_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.qdas_plan_prepare_frames.argtypes = [C.c_void_p, C.c_uint64]
     L.qdas_plan_delays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.qdas_plan_destroy.argtypes = [C.c_void_p]
     L.qdas_plan_destroy.restype = None

@@ -218,7 +218,11 @@ __global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensPa
     for (uint32_t k = tid; k < (uint32_t)K * NSLOT * 2; k += GT_THREADS) H[k] = 0;
     for (long k = tid; k < T; k += GT_THREADS) xl[k] = x[k];
     const float bound = __uint_as_float(*bound_bits);
-    const float Sc = bound > 0.f ? fminf(70368744177664.0f / bound, 1.0e37f) : 0.f;   // 2^46 / largest single contribution
+    // scale: 2^46 / largest single contribution -- and never more than 2^62 / (entries of the trace x largest contribution): a slot can at most receive
+    // every entry of its trace, so the 64-bit sums cannot wrap however dense the scatterer cloud (beyond 2^16 entries per trace the resolution drops from
+    // 2^-46 to 2^-62 x entries of the largest contribution: still 2^-32 at 10^9 entries, far below the fp32 rounding of the result)
+    const float ent = (float)P.I * (float)(P.En * P.Em);
+    const float Sc = bound > 0.f ? fminf(fminf(70368744177664.0f, 4.611686018427388e18f / fmaxf(ent, 1.f)) / bound, 1.0e37f) : 0.f;
     const float fs = (float)P.fs, fsr = (float)P.fsr, cinv = (float)P.cinv, R0 = (float)P.R0, toff = (float)(P.t0 - P.s0);
     const int EE = P.En * P.Em;
     const uint64_t s_lo = (uint64_t)blk * SB, I = P.I;
@@ -259,7 +263,8 @@ __global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensPa
         };
         // r1 + r2 of the entries whose slot can lie in [0, NSLOT): ceil(Q d) - cbase in [0, NSLOT) <=> Q d in (cbase - 1, cbase + NSLOT - 1], d = (cinv r + toff) fs
         const double rlo_d = (((double)cbase - 1.0) / ((double)Q * P.fs) - (P.t0 - P.s0)) / P.cinv, rhi_d = (((double)cbase + (double)NSLOT - 1.0) / ((double)Q * P.fs) - (P.t0 - P.s0)) / P.cinv;
-        const double mar = 4e-6 * (fabs(rlo_d) + fabs(rhi_d)) + 1e-30;      // (fp32 roundings of the delay: ~3 ulp of r)
+        // (fp32 roundings of the delay (cinv r + toff) fs: ~3 ulp of r -- and of the offset, expressed as a path length, when |toff| is the larger term)
+        const double mar = 4e-6 * (fabs(rlo_d) + fabs(rhi_d) + 2.0 * fabs(P.t0 - P.s0) / P.cinv) + 1e-30;
         const float rlo = (float)(rlo_d - mar), rhi = (float)(rhi_d + mar);
         for (int sub = 0; sub < EE; ++sub) {
             const int ne = sub % P.En, me = sub / P.En;

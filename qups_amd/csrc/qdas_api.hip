@@ -613,6 +613,8 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // instantiations were pruned in round 4 --; without QDAS_PLAN_JIT such a plan runs the general kernels
         if (sym && !rfold && dt == QDAS_F32 && !((desc->plan_flags & QDAS_PLAN_JIT) && !getenv("QDAS_NO_JIT"))) sym = 0;
     }
+    if ((desc->plan_flags & QDAS_PLAN_PREFOLDED) && z.S > 0)      // (a prefolded plan runs no fold pass: nothing would apply the table -- include/qdas.h QDAS_PLAN_PREFOLDED)
+        return bail(fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_PREFOLDED: apodization arrays belong to the fold (qdas_fold_desc.wtab), not to the plan that is handed folded frames"));
     if ((desc->plan_flags & QDAS_PLAN_PREFOLDED) && !rfold)
         return bail(fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_PREFOLDED: a folded frame can only be beamformed by a reciprocal fp32 'DAS' plan without apodization arrays "
                                             "(transmit elements == receive elements bit for bit, one t0, N == M >= 2; weights belong to qdas_fold)"));
@@ -957,7 +959,7 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
         // try the 384-sample windows of launch configuration 14 (16 transmits per stage, same LDS image); kept if fewer tiles misfit.
         // (a reciprocal plan gives up its mode for them: an image on the generic kernel costs ten times more than the shared index work saves)
         if (!pl->no_fallback && dt == QDAS_F32 && !bfm && !big && t.narrow != 2 && !getenv("QDAS_NO_WIDE") && !pl->prefolded
-            && tile_lds_bytes(dt, 0, t.N, t.M, 2, t.act_bytes ? 1 : 0, t.wtab ? 1 : 0) <= tile_lds_limit(0)
+            && tile_lds_bytes(dt, 0, t.N, t.M, 2, t.act_bytes ? 1 : 0, (t.wtab || (t.fold && pl->fold_wtab)) ? 1 : 0) <= tile_lds_limit(0)      // (a folded plan's table comes back into the kernel there)
             && ((uint64_t)t.N * t.strN + (uint64_t)tile_config(dt, 0, 2).mb * t.strM) * data_size(dt) + 65536 < (1ull << 31)) {
             const TileParams keep = t;
             const TileConfig keep_tc = pl->tc;
@@ -1294,6 +1296,111 @@ static int run_frame(qdas_plan *pl, const void *x, void *y, hipStream_t s, int n
     return QDAS_OK;
 }
 
+// One-time preparations of a STREAM of F frames (twin plan, second folded copy, frame-sharing instantiations, host staging): everything that allocates,
+// compiles or synchronises.  qdas_plan_execute_frames runs it at the plan's first stream; qdas_plan_prepare_frames lets a caller run it ahead of time, so that
+// the stream calls themselves only enqueue work (graph capture, latency-critical first frames).  Idempotent.
+static int prepare_stream(qdas_plan *pl, uint64_t F, hipStream_t s) {
+    const qdas_sizes &z = pl->d.sz;
+    if (pl->I == 0 || z.N == 0 || z.M == 0 || pl->i_count == 0 || z.T == 0 || F < 2) return QDAS_OK;
+    // a stream of >= 4 device-resident frames through a general-mode lateral-mirror plan: four frames per launch on the plan's twin
+    if (F >= 4 && pl->kernel == QDAS_KERNEL_TILED && pl->tp.mir == 1 && !pl->tp.sym && !pl->tp.apix && !pl->tp.gen_kind && pl->d.mem == QDAS_MEM_DEVICE
+        && !getenv("QDAS_NO_FB4") && !getenv("QDAS_NO_FB2") && !getenv("QDAS_NO_FRAMES_TWIN") && !pl->twin_tried) {
+        pl->twin_tried = true;
+        qdas_desc d = pl->d;                            // (the plan's own device copies / the caller's device arrays: both stay valid for the plan's life)
+        const GenericParams &g = pl->gp;
+        uint64_t acs[6 * (1 + QDAS_MAX_APOD)];
+        memcpy(acs, g.cst, sizeof g.cst); memcpy(acs + 6, g.ast, sizeof(uint64_t) * 6 * z.S);
+        d.Pi = g.Pi; d.Pr = g.Pr; d.Pv = g.Pv; d.Nv = g.Nv; d.cinv = g.cinv; d.apod = g.apod; d.rx_normals = g.rxn; d.acstride = acs;
+        d.mem = QDAS_MEM_DEVICE; d.device = pl->device;
+        d.plan_flags = (d.plan_flags | QDAS_PLAN_NO_MIRROR) & ~(QDAS_PLAN_COPY_INPUTS | QDAS_PLAN_JIT | QDAS_PLAN_MIRROR_SLAB);
+        const std::string keep = g_err;
+        if (qdas_plan_create(&pl->frames_twin, &d) != QDAS_OK) pl->frames_twin = nullptr;
+        else if (!(pl->frames_twin->fb2_ok && !pl->frames_twin->fb4_off)) { qdas_plan_destroy(pl->frames_twin); pl->frames_twin = nullptr; }
+        g_err = keep;
+    }
+    if (pl->frames_twin && F >= 4) return prepare_stream(pl->frames_twin, F, s);
+    // folded data: frame pairs share a launch; the second folded copy is made now (once)
+    if (pl->fold2_ok && !pl->prefolded && !pl->fold_buf2) {
+        const size_t fb = (size_t)z.T * z.N * z.M * 8;
+        void *p2 = nullptr;
+        if (hipMalloc(&p2, fb) == hipSuccess) {
+            pl->owned.push_back(p2);
+            if (hipMemsetAsync(p2, 0, fb, s) == hipSuccess) pl->fold_buf2 = p2;
+        } else (void)hipGetLastError();
+        if (!pl->fold_buf2) pl->fold2_ok = false;       // (no memory for it: one frame per launch)
+    }
+    // the frame-sharing instantiations are resolved (built on demand when libqdas.so does not carry them) here, not inside the frame loop; without a
+    // compiler the stream runs one frame per launch
+    if ((pl->fb2_ok || pl->fold2_ok) && pl->kernel == QDAS_KERNEL_TILED) {
+        const std::string keep = g_err;
+        for (int nf = 2; nf <= 4; nf += 2) {
+            bool &done = nf == 2 ? pl->prep2 : pl->prep4;
+            if (done || (nf == 4 && (F < 4 || pl->fb4_off || pl->tp.fold))) continue;
+            done = true;
+            TileParams t = pl->tp;
+            t.nfr = nf;
+            if (prepare_tile(t, z.dtype, pl->ntiles, nullptr) == hipErrorSharedObjectInitFailed) {
+                if (nf == 2) { pl->fb2_ok = false; pl->fold2_ok = false; } else pl->fb4_off = true;
+            }
+            (void)hipGetLastError();
+        }
+        g_err = keep;
+    }
+    if (pl->d.mem == QDAS_MEM_HOST && !pl->copy_stream) {      // host frames: a second staging set + copy stream (frame f+1 is uploaded while f is beamformed)
+        int rc;
+        if ((rc = dev_alloc(pl, &pl->dx2, pl->x_bytes)) || (rc = dev_alloc(pl, &pl->dy2, pl->y_bytes))) return rc;
+        HIPCHK(hipStreamCreateWithFlags(&pl->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(hipEventCreateWithFlags(&pl->ex[k], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&pl->ek[k], hipEventDisableTiming));
+        }
+    }
+    return QDAS_OK;
+}
+
+extern "C" int qdas_plan_prepare_frames(qdas_plan *pl, uint64_t F) {
+    if (!pl) return fail(QDAS_EINVAL, "null plan");
+    DeviceGuard guard(pl->device);
+    HIPCHK(guard.err);
+    int rc = prepare_stream(pl, F, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return QDAS_OK;
+}
+
+// host-resident frames: upload f+1 on the copy stream while f is beamformed
+static int stream_host_frames(qdas_plan *pl, const void *x, void *y, uint64_t F, uint64_t x_stride, uint64_t y_stride, hipStream_t s) {
+    const size_t ds = data_size(pl->d.sz.dtype);
+    void *dxs[2] = {pl->dx, pl->dx2}, *dys[2] = {pl->dy, pl->dy2};
+    hipStream_t sc = pl->copy_stream;
+    HIPCHK(hipMemcpyAsync(dxs[0], x, pl->x_bytes, hipMemcpyHostToDevice, sc));
+    HIPCHK(hipEventRecord(pl->ex[0], sc));
+    for (uint64_t f = 0; f < F; ++f) {
+        const int b = (int)(f & 1), nb = b ^ 1;
+        HIPCHK(hipStreamWaitEvent(s, pl->ex[b], 0));
+        int rc = run_frame(pl, dxs[b], dys[b], s);
+        if (rc) return rc;
+        HIPCHK(hipEventRecord(pl->ek[b], s));
+        if (f + 1 < F) {                                // the other buffer's last reader was frame f-1
+            if (f >= 1) HIPCHK(hipStreamWaitEvent(sc, pl->ek[nb], 0));
+            HIPCHK(hipMemcpyAsync(dxs[nb], (const char *)x + (f + 1) * x_stride * ds, pl->x_bytes, hipMemcpyHostToDevice, sc));
+            HIPCHK(hipEventRecord(pl->ex[nb], sc));
+        }
+        HIPCHK(hipMemcpyAsync((char *)y + f * y_stride * ds, dys[b], pl->y_bytes, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipStreamSynchronize(sc));
+    return QDAS_OK;
+}
+
+static int stop_timer(qdas_plan *pl, hipStream_t s) {
+    if (!pl->timing) return QDAS_OK;
+    HIPCHK(hipEventRecord(pl->e1, s));
+    HIPCHK(hipEventSynchronize(pl->e1));
+    HIPCHK(hipEventElapsedTime(&pl->last_ms, pl->e0, pl->e1));
+    return QDAS_OK;
+}
+
 extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, uint64_t F, uint64_t x_stride,
                                         uint64_t y_stride, void *stream) {
     if (!pl) return fail(QDAS_EINVAL, "null plan");
@@ -1315,124 +1422,46 @@ extern "C" int qdas_plan_execute_frames(qdas_plan *pl, const void *x, void *y, u
     }
     if (!x) return fail(QDAS_EINVAL, "null data");
     if (pl->timing) HIPCHK(hipEventRecord(pl->e0, s));
-    // a stream of >= 4 device-resident frames through a general-mode lateral-mirror plan: four frames per launch on the plan's twin
-    if (F >= 4 && pl->kernel == QDAS_KERNEL_TILED && pl->tp.mir == 1 && !pl->tp.sym && !pl->tp.apix && !pl->tp.gen_kind && pl->d.mem == QDAS_MEM_DEVICE
-        && !getenv("QDAS_NO_FB4") && !getenv("QDAS_NO_FB2") && !getenv("QDAS_NO_FRAMES_TWIN")) {
-        if (!pl->twin_tried) {
-            pl->twin_tried = true;
-            qdas_desc d = pl->d;                        // (the plan's own device copies / the caller's device arrays: both stay valid for the plan's life)
-            const GenericParams &g = pl->gp;
-            uint64_t acs[6 * (1 + QDAS_MAX_APOD)];
-            memcpy(acs, g.cst, sizeof g.cst); memcpy(acs + 6, g.ast, sizeof(uint64_t) * 6 * z.S);
-            d.Pi = g.Pi; d.Pr = g.Pr; d.Pv = g.Pv; d.Nv = g.Nv; d.cinv = g.cinv; d.apod = g.apod; d.rx_normals = g.rxn; d.acstride = acs;
-            d.mem = QDAS_MEM_DEVICE; d.device = pl->device;
-            d.plan_flags = (d.plan_flags | QDAS_PLAN_NO_MIRROR) & ~(QDAS_PLAN_COPY_INPUTS | QDAS_PLAN_JIT | QDAS_PLAN_MIRROR_SLAB);
-            const std::string keep = g_err;
-            if (qdas_plan_create(&pl->frames_twin, &d) != QDAS_OK) pl->frames_twin = nullptr;
-            else if (!(pl->frames_twin->fb2_ok && !pl->frames_twin->fb4_off)) { qdas_plan_destroy(pl->frames_twin); pl->frames_twin = nullptr; }
-            g_err = keep;
-        }
-        if (pl->frames_twin) {
-            // the WHOLE stream goes through the twin (groups of four, then a pair, then a single frame on its own kernels): every frame of
-            // one call is summed in the same order -- round 3 sent the tail through the mirror kernel.  The images equal
-            // qdas_plan_execute's to fp32 re-association, not bit for bit (another kernel): include/qdas.h says so.
-            pl->frames_twin->timing = false;
-            int rc = qdas_plan_execute_frames(pl->frames_twin, x, y, F, x_stride, y_stride, stream);
-            if (!rc && pl->timing) { HIPCHK(hipEventRecord(pl->e1, s)); HIPCHK(hipEventSynchronize(pl->e1)); HIPCHK(hipEventElapsedTime(&pl->last_ms, pl->e0, pl->e1)); }
-            return rc;
-        }
+    int rc = prepare_stream(pl, F, s);                  // (a no-op after the plan's first stream, or after qdas_plan_prepare_frames)
+    if (rc) return rc;
+    if (F >= 4 && pl->frames_twin) {
+        // the WHOLE stream goes through the twin (groups of four, then a pair, then a single frame on its own kernels): every frame of
+        // one call is summed in the same order -- round 3 sent the tail through the mirror kernel.  The images equal
+        // qdas_plan_execute's to fp32 re-association, not bit for bit (another kernel): include/qdas.h says so.
+        pl->frames_twin->timing = false;
+        rc = qdas_plan_execute_frames(pl->frames_twin, x, y, F, x_stride, y_stride, stream);
+        return rc ? rc : stop_timer(pl, s);
     }
-    // frame pairs share one launch (device-resident data, tiled kernel, not the reciprocal mode; QDAS_NO_FB2 disables)
+    // frame pairs share one launch (device-resident data, tiled kernel; QDAS_NO_FB2 disables); folded data: the caller's folded frames as they lie
+    // (prefolded plans), or the plan's two folded copies
     bool pairs_ok = pl->fb2_ok && x_stride * ds < (1ull << 40);
-    if (pl->fold2_ok && F >= 2 && pl->prefolded) pairs_ok = x_stride * ds < (1ull << 40);      // (the caller's folded frames, as they lie)
-    else if (pl->fold2_ok && F >= 2) {                  // folded data: frame pairs share a launch; the second folded copy is made now (once)
-        if (!pl->fold_buf2) {
-            const size_t fb = (size_t)z.T * z.N * z.M * 8;
-            void *p2 = nullptr;
-            if (hipMalloc(&p2, fb) == hipSuccess) {
-                pl->owned.push_back(p2);
-                if (hipMemsetAsync(p2, 0, fb, s) == hipSuccess) pl->fold_buf2 = p2;
-            } else (void)hipGetLastError();
-            if (!pl->fold_buf2) pl->fold2_ok = false;   // (no memory for it: one frame per launch)
-        }
-        pairs_ok = pl->fold_buf2 != nullptr;
-    }
-    // the frame-sharing instantiations are resolved (built on demand when libqdas.so does not carry them) at the plan's FIRST stream, not inside the
-    // frame loop; without a compiler the stream runs one frame per launch
-    if (pairs_ok && F >= 2 && pl->kernel == QDAS_KERNEL_TILED) {
-        const std::string keep = g_err;
-        for (int nf = 2; nf <= 4; nf += 2) {
-            bool &done = nf == 2 ? pl->prep2 : pl->prep4;
-            if (done || (nf == 4 && (F < 4 || pl->fb4_off || pl->tp.fold))) continue;
-            done = true;
-            TileParams t = pl->tp;
-            t.nfr = nf;
-            if (prepare_tile(t, z.dtype, pl->ntiles, nullptr) == hipErrorSharedObjectInitFailed) {
-                if (nf == 2) { pl->fb2_ok = false; pl->fold2_ok = false; pairs_ok = false; } else pl->fb4_off = true;
-            }
-            (void)hipGetLastError();
-        }
-        g_err = keep;
-    }
-    if (pl->d.mem == QDAS_MEM_HOST && F >= 2) {         // host frames: upload f+1 on the copy stream while f is beamformed
-        if (!pl->copy_stream) {
-            int rc;
-            if ((rc = dev_alloc(pl, &pl->dx2, pl->x_bytes)) || (rc = dev_alloc(pl, &pl->dy2, pl->y_bytes))) return rc;
-            HIPCHK(hipStreamCreateWithFlags(&pl->copy_stream, hipStreamNonBlocking));
-            for (int k = 0; k < 2; ++k) {
-                HIPCHK(hipEventCreateWithFlags(&pl->ex[k], hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&pl->ek[k], hipEventDisableTiming));
-            }
-        }
-        void *dxs[2] = {pl->dx, pl->dx2}, *dys[2] = {pl->dy, pl->dy2};
-        hipStream_t sc = pl->copy_stream;
-        HIPCHK(hipMemcpyAsync(dxs[0], x, pl->x_bytes, hipMemcpyHostToDevice, sc));
-        HIPCHK(hipEventRecord(pl->ex[0], sc));
-        for (uint64_t f = 0; f < F; ++f) {
-            const int b = (int)(f & 1), nb = b ^ 1;
-            HIPCHK(hipStreamWaitEvent(s, pl->ex[b], 0));
-            int rc = run_frame(pl, dxs[b], dys[b], s);
-            if (rc) return rc;
-            HIPCHK(hipEventRecord(pl->ek[b], s));
-            if (f + 1 < F) {                            // the other buffer's last reader was frame f-1
-                if (f >= 1) HIPCHK(hipStreamWaitEvent(sc, pl->ek[nb], 0));
-                HIPCHK(hipMemcpyAsync(dxs[nb], (const char *)x + (f + 1) * x_stride * ds, pl->x_bytes, hipMemcpyHostToDevice, sc));
-                HIPCHK(hipEventRecord(pl->ex[nb], sc));
-            }
-            HIPCHK(hipMemcpyAsync((char *)y + f * y_stride * ds, dys[b], pl->y_bytes, hipMemcpyDeviceToHost, s));
-        }
-        HIPCHK(hipStreamSynchronize(s));
-        HIPCHK(hipStreamSynchronize(sc));
-        if (pl->timing) { HIPCHK(hipEventRecord(pl->e1, s)); HIPCHK(hipEventSynchronize(pl->e1)); HIPCHK(hipEventElapsedTime(&pl->last_ms, pl->e0, pl->e1)); }
-        return QDAS_OK;
+    if (pl->fold2_ok && F >= 2) pairs_ok = pl->prefolded ? x_stride * ds < (1ull << 40) : pl->fold_buf2 != nullptr;
+    if (pl->d.mem == QDAS_MEM_HOST && F >= 2) {
+        rc = stream_host_frames(pl, x, y, F, x_stride, y_stride, s);
+        return rc ? rc : stop_timer(pl, s);
     }
     for (uint64_t f = 0; f < F; ++f) {
         const char *xf = (const char *)x + f * x_stride * ds;
         char *yf = (char *)y + f * y_stride * ds;
         if (pairs_ok && f + 1 < F) {                    // four (else two) frames share a launch
             const int nf = (f + 3 < F && !pl->fb4_off && !pl->tp.fold) ? 4 : 2;
-            int rc = run_frame(pl, xf, yf, s, nf, x_stride * ds, y_stride);
+            rc = run_frame(pl, xf, yf, s, nf, x_stride * ds, y_stride);
             if (rc) return rc;
             f += nf - 1;
             continue;
         }
         if (pl->d.mem == QDAS_MEM_HOST) {
             HIPCHK(hipMemcpyAsync(pl->dx, xf, pl->x_bytes, hipMemcpyHostToDevice, s));
-            int rc = run_frame(pl, pl->dx, pl->dy, s);
+            rc = run_frame(pl, pl->dx, pl->dy, s);
             if (rc) return rc;
             HIPCHK(hipMemcpyAsync(yf, pl->dy, pl->y_bytes, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
         } else {
-            int rc = run_frame(pl, xf, yf, s);
+            rc = run_frame(pl, xf, yf, s);
             if (rc) return rc;
         }
     }
-    if (pl->timing) {
-        HIPCHK(hipEventRecord(pl->e1, s));
-        HIPCHK(hipEventSynchronize(pl->e1));
-        HIPCHK(hipEventElapsedTime(&pl->last_ms, pl->e0, pl->e1));
-    }
-    return QDAS_OK;
+    return stop_timer(pl, s);
 }
 
 extern "C" int qdas_plan_execute(qdas_plan *pl, const void *x, void *y, void *stream) {
@@ -1679,7 +1708,7 @@ extern "C" int qdas_wsinterpd(const qdas_wsinterpd_desc *d, void *y, void *strea
             acc *= (int64_t)d->size[k];
         }
         int lane = d->lane_dim;
-        if (lane < 0 || lane >= d->ndim || p.sum[lane]) {
+        if (lane < 0 || lane >= d->ndim || p.sum[lane] || d->size[lane] <= 1) {
             lane = -1;
             for (int k = 0; k < d->ndim && lane < 0; ++k) if (!p.sum[k] && d->size[k] > 1) lane = k;
             if (lane < 0) for (int k = 0; k < d->ndim && lane < 0; ++k) if (!p.sum[k]) lane = k;

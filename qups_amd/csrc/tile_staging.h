@@ -167,7 +167,12 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
     soff += (uint32_t)strN * SB;                      // next receiver, same transmit block
     if constexpr (C::FB2) { if (QSPEC(MIR, P.mir)) soff2 -= (uint32_t)strN * SB; }      // (its mirror image: one receiver down)
     if constexpr (C::SYM || C::BIG) {
-        if (soff >= DMA_REBASE) { offD += soff; soff = 0; rsD = make_rs(offD, 0); }
+        if (soff >= DMA_REBASE) {
+            offD += soff; soff = 0; rsD = make_rs(offD, (uint64_t)fa * P.x_fstride);
+            // (a second window set that shares `soff` -- the same traces of another frame: launch configuration 21, two folded frames
+            //  without the mirror mode -- moves with it; the lateral-mirror set walks its own offset, soff2, from its own base)
+            if constexpr (C::FBX) { if (!(C::FB2 && QSPEC(MIR, P.mir))) rsM = make_rs(offD, (uint64_t)fb * P.x_fstride); }
+        }
     }
     if constexpr (C::SYM && !C::FOLD) {               // same window start A[m] + B[n] in the mirror trace
 #pragma unroll

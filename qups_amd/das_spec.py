@@ -578,6 +578,15 @@ class DasPlan:
                                                          F, per, oM * oN * self.out_count, self._stream()))
         return y
 
+    def prepare_frames(self, F: int):
+        """Do now what the plan's first stream of ``F`` frames would do once (``qdas_plan_prepare_frames``: the second folded copy of a reciprocal plan, the
+        frame-sharing kernel instantiations, a mirror plan's twin): afterwards :meth:`execute_into` with up to ``F`` frames only enqueues work."""
+        with self._lock:
+            if self._h is None or not self._h.value:
+                raise DasError("the plan has been closed")
+            _lib.check(self.lib.qdas_plan_prepare_frames(self._h, int(F)))
+        return self
+
     def feval(self, x):
         """One frame ``x`` (``T x N x M``, MATLAB order) -> ``I x [1|N] x [1|M]`` like ``k.feval`` at
         reference ``kern/das_spec.m:372``."""

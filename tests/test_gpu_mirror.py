@@ -618,3 +618,75 @@ def test_folded_replicator_on_the_device():
     y1 = sp.execute_colmajor(other, 1)
     sp.close()
     assert torch.equal(y0, y1)
+
+
+@pytest.mark.gpu
+def test_prefolded_plan_rejects_apodization_arrays():
+    """a QDAS_PLAN_PREFOLDED plan runs no fold pass, so nothing would apply a pixel-independent weight table -- include/qdas.h promises
+    QDAS_EUNSUPPORTED for it (the weights belong to qdas_fold); round 4 built the table and silently dropped it."""
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options
+    case = make_case(seq="FSA", interp="cubic", seed=23, N=32, I1=96, I2=24)
+    xt = torch.from_numpy(case["x"])
+    w = np.linspace(0.2, 1.0, 32).reshape(1, 1, 1, 32, 1)
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"],
+                         parse_options(xt, list(case["opt"]) + ["interp", "cubic", "apod", w]))
+    with pytest.raises(Exception, match="PREFOLDED"):
+        DasPlan(prob, kernel=2, prefolded=True)
+    with DasPlan(prob, kernel=2) as plan:                                     # (the folding plan takes the table along in its fold pass)
+        assert plan.folded
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mirror", [True, False])
+def test_prepare_frames_ahead_of_the_first_stream(mirror):
+    """qdas_plan_prepare_frames: the one-time work of a plan's first stream (second folded copy, frame-sharing instantiations) done ahead of time; the
+    stream that follows gives the very images of a plan that prepared itself inside its first execute_frames."""
+    import torch
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd.das_spec import _colmajor
+    case = make_case(seq="FSA", interp="lanczos3", seed=29, N=32, I1=150, I2=40)
+    rng = np.random.default_rng(3)
+    F = 5
+    xs = np.stack([case["x"]] + [(rng.standard_normal(case["x"].shape) + 1j * rng.standard_normal(case["x"].shape)).astype(np.complex64) * 0.05 for _ in range(F - 1)], axis=3)
+    xt = torch.from_numpy(xs)
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"],
+                         parse_options(xt, list(case["opt"]) + ["interp", "lanczos3"]))
+    xc = _colmajor(xt.cuda())
+    with DasPlan(prob, kernel=2, mirror=mirror) as a, DasPlan(prob, kernel=2, mirror=mirror) as b:
+        assert a.folded
+        a.prepare_frames(F)
+        a.prepare_frames(F)                                                    # idempotent
+        ya = a.execute_colmajor(xc, F).cpu().numpy()
+        yb = b.execute_colmajor(xc, F).cpu().numpy()
+    assert np.abs(ya).max() > 0 and np.array_equal(ya, yb)
+
+
+@pytest.mark.gpu
+def test_two_folded_frames_per_launch_beyond_1_GiB():
+    """launch configuration 21 (two folded frames per launch, no lateral-mirror mode) reads frame 1 through a second descriptor that shares the
+    running receiver offset of frame 0; when that offset passes 2^30 bytes the kernel re-bases -- BOTH descriptors (round 4 moved only the first: every
+    later stage read frame 1 at the wrong receiver rows).  A 1.3 GB frame (128 x 128 elements, 10 240 samples) streamed pairwise against one frame at a time."""
+    import torch
+    from qups_amd import das_spec
+    from qups_amd import geometry as G
+    from qups_amd import DasPlan, build_problem, parse_options
+    T, N = 10240, 128                                                         # 10240 * 128 * 128 * 8 B = 1.34 GB per frame
+    fc, c0 = 5e6, 1540.0
+    fs = 4 * fc
+    Pr, nrm = G.linear_array(N, 0.2e-3)
+    Pv, Nv, opt = G.sequence_args("FSA", tx_pos=Pr, tx_normals=nrm)
+    Pi = G.scan_cartesian(np.linspace(-3e-3, 3e-3, 32), np.linspace(20e-3, 20e-3 + 63 * 77e-6, 64))
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x = torch.view_as_complex(torch.randn((2, N, N, T, 2), generator=g, device="cuda", dtype=torch.float32))      # (F, M, N, T): the ABI's order
+    f32 = lambda a: np.asarray(a, np.float32)
+    xshape = (T, N, N, 2)
+    prob = build_problem("DAS", f32(Pi), f32(Pr), f32(Pv), f32(Nv), xshape, 0.0, fs, c0, parse_options(torch.empty(1, dtype=torch.complex64), list(opt) + ["interp", "cubic"]))
+    with DasPlan(prob, kernel=2, mirror=False) as plan:
+        assert plan.folded and not plan.mirror, plan.kernel_name()
+        pair = plan.execute_colmajor(x, 2).cpu().numpy().reshape(2, -1)
+        one = np.stack([plan.execute_colmajor(x[f:f + 1].contiguous(), 1).cpu().numpy().reshape(-1) for f in range(2)])
+    torch.cuda.synchronize()
+    assert np.abs(one).max() > 0
+    for f in range(2):
+        assert rel_err(pair[f], one[f]) <= 1e-5, (f, rel_err(pair[f], one[f]))
