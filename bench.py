@@ -234,6 +234,25 @@ def binding_roofs(vals, cu, pairs, taps, sample_bytes):
     return out
 
 
+def saturated_issue_rate(lib, cu):
+    """csrc/probe.hip: ns per wave64 VALU instruction and SIMD at saturation for {broadcast pk_fma, v_fma_f32, the pair loop's VALU mix}, measured now, on this device."""
+    import ctypes as C
+    try:
+        f = lib.qdas_debug_issue_rate
+        f.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        ns = {}
+        for name, mix in (("pk_fma_bcast", 0), ("fma_f32", 1), ("pair_mix", 2)):
+            v, ms = C.c_double(), C.c_double()
+            if f(-1, mix, C.byref(v), C.byref(ms)) != 0:
+                return None
+            ns[name] = round(v.value, 4)
+        return {"ns": ns, "pair_mix_ginst_s": 4.0 * cu / ns["pair_mix"],
+                "note": f"qdas_debug_issue_rate (csrc/probe.hip) in this run: {ns['pair_mix']} ns per wave64 VALU instruction and SIMD for the pair loop's VALU mix at 4 waves/SIMD on "
+                        f"{cu} CUs ({ns['pk_fma_bcast']} ns broadcast v_pk_fma_f32, {ns['fma_f32']} ns v_fma_f32): peak = 4 SIMDs x CUs / ns"}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -503,6 +522,12 @@ def main():
         uplan.execute_colmajor(xc, F)
         unfolded_ms = kernel_time(uplan, 3)
         uplan.close()
+    fold_only_ms = None
+    if world == 1 and folded and bool(plan.mirror) and not args.no_general:   # the same frame on the folded kernel WITHOUT the lateral-mirror mode: what a reciprocal acquisition
+        fplan = DasPlan(prob, device=dev, kernel=args.kernel, reciprocal=True, jit=args.jit, mirror=False, **slab_kw)   # with a calibrated (not mirror-symmetric) probe costs
+        fplan.execute_colmajor(xc, F)
+        fold_only_ms = kernel_time(fplan, 3)
+        fplan.close()
     general_ms = None
     if world == 1 and reciprocal and not args.no_general:      # the same frame without the reciprocal special case (plan flag)
         gplan = DasPlan(prob, device=dev, kernel=args.kernel, reciprocal=False, jit=args.jit, **slab_kw)       # (no reciprocal mode: no fold either)
@@ -636,6 +661,24 @@ def main():
             rec["roofline"].update(binding_roofs(ctrs, info["cu_count"], pairs / world * (exec_frac or 1.0) * ((N + 1) / (2.0 * N) if folded else 1.0), taps, sb))
         except Exception as ex:
             rec["roofline"]["binding_note"] = f"counter post-processing failed: {ex!r}"
+        # The roof that BINDS: VALU issue under the part's power limit.  achieved = wave64 VALU instructions the dominant kernel issued
+        # (SQ_INSTS_VALU of the counter pass of this command) / its launch time; peak = the SATURATED issue rate of the pair loop's own VALU mix, measured on
+        # this device in this run (csrc/probe.hip qdas_debug_issue_rate, mix 2: 16 broadcast pk_fma + 16 SGPR-coefficient pk_fma + 5 index instructions, four
+        # waves per SIMD on every CU, no LDS reads -- so frac < 1 also prices the gathers, the staging and the per-stage code).  The BASELINE's HBM roof stays
+        # in the line as nominal_hbm_*: SURVEY 8d predicted, and every round measured, that compulsory traffic is ~1 % of it.
+        rf = rec["roofline"]
+        rf["nominal_hbm_achieved"], rf["nominal_hbm_peak"], rf["nominal_hbm_frac"], rf["nominal_hbm_unit"] = rf["achieved"], rf["peak"], rf["frac"], "GB/s"
+        sat = saturated_issue_rate(_lib.lib(), info["cu_count"])
+        if sat and plan.kernel == "tiled" and "valu_insts" in rf and rf.get("counter_pass_kernel_ms"):
+            ach = rf["valu_insts"] / (rf["counter_pass_kernel_ms"] * 1e-3) / 1e9
+            rf.update({"bound": "valu_issue", "achieved": round(ach, 2), "peak": round(sat["pair_mix_ginst_s"], 2), "unit": "Gwave-inst/s", "frac": round(ach / sat["pair_mix_ginst_s"], 4),
+                       "peak_source": sat["note"], "saturated_ns_per_inst_simd": sat["ns"]})
+            rf.pop("valu_issue_frac", None)             # (rounds 3-4: instructions x 4 cycles / active cycles -- a convention, not a measured roof)
+            rf["binding_note"] = ("VALU issue under the power limit binds (frac: against the measured saturated rate of the loop's own VALU mix on this box); LDS gathers second "
+                                  "(lds_busy_frac); nominal_hbm_frac is the BASELINE's roof, unreachable at ~2.5e3 flop/byte")
+        elif sat:
+            rf["bound_note"] = "bound = hbm is the BASELINE's nominal roof only: no SQ counters in this run to price the VALU-issue roof that binds"
+            rf["saturated_ns_per_inst_simd"] = sat["ns"]
         if F > 1:
             rec["frames_per_step"] = F
             rec["ms_per_frame"] = round(ms / F, 3)
@@ -653,6 +696,8 @@ def main():
             rec["roofline"]["products_formed_frac"] = round((N + 1) / (2.0 * N), 4)
         if unfolded_ms is not None:
             rec["unfolded_ms_per_step"] = round(unfolded_ms, 3)
+        if fold_only_ms is not None:
+            rec["fold_only_ms_per_step"] = round(fold_only_ms, 3)
         if general_ms is not None:
             rec["general_ms_per_step"] = round(general_ms, 3)
             rec["general_value"] = round(I / (general_ms * 1e-3) / 1e6, 4)

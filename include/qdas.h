@@ -445,6 +445,15 @@ typedef struct qdas_convd_desc {
 uint64_t qdas_convd_len(uint64_t M, uint64_t N, int shape);    /* L */
 int qdas_convd(const qdas_convd_desc *desc, const void *x, const void *y, void *z, void *stream);
 
+/* ---- Device staging for HOST callers of the device-pointer entries above (qdas_delays*, qdas_das_lut, qdas_wsinterpd, qdas_greens, qdas_convd,
+ * qdas_pre_execute ...): the reference reaches those kernels with gpuArrays (kern/wsinterpd2.m:236, src/UltrasoundSystem.m:681-718, kern/convd.m:150-199),
+ * a MEX gateway built WITHOUT the mxGPUArray API has host arrays only and must not need the HIP headers -- it allocates, copies and frees through
+ * these three (mex/qdas_mex.c dev_in / dev_out).  device: HIP ordinal, -1 = current.  qdas_device_copy is synchronous; kind 0: host -> device,
+ * 1: device -> host, 2: device -> device. */
+int qdas_device_malloc(void **p, size_t bytes, int device);
+int qdas_device_free(void *p, int device);
+int qdas_device_copy(void *dst, const void *src, size_t bytes, int kind, int device);
+
 /* ---- Layout conversion for row-major hosts (numpy / torch; no reference counterpart: MATLAB arrays are column-major already and
  * the ABI follows the reference's memory order, e.g. kern/das_spec.m:367-372 passes x(:,:,:,f) as it lies in memory).
  * out[c][b][a] = in[a][b][c] for a row-major A x B x C array of elem_bytes-sized elements (2 | 4 | 8 | 16): the column-major

@@ -16,6 +16,21 @@
  *   s = qdas_mex('info', h)                                                             char: kernel name, shards
  *       qdas_mex('destroy' [, h])
  *
+ * The other launch sites of the path, one command each (stateless; arguments in the order of the reference's own k.feval lists):
+ *   tau = qdas_mex('delays', sizes, Pi, Pr, Pv, Nv, cinv)                 kern/das_spec.m:376-377  k.feval(yg, Pi, Pr, Pv, Nv, cinv(1))       -> I x N x M real(prec)
+ *   tau = qdas_mex('delays', h)                                           the same from a live plan (its geometry is on the device already)
+ *   y   = qdas_mex('lut', lsizes, w, x, t1, t2, wstride, omega)           kern/wsinterpd2.m:236    k.feval(y, w, x, t1, t2, sizes, iflags, strides, flagnum, imag(omega))
+ *         as bfDASLUT -> sample2sep calls it (src/UltrasoundSystem.m:4641-4660): lsizes = [T N M I flag dtype I1 w_real], t1 = receive table I x N, t2 = transmit
+ *         table I x M (samples), w = [] or weights with element strides wstride = uint64 [si sn sm] (0 where singleton); y is I x [1|N] x [1|M] complex(prec)
+ *   y   = qdas_mex('greens', gsizes, ps, as, pn, pv, x, tvars)            src/UltrasoundSystem.m:681-718  k.feval(x, ps, as, pn, pv, kn, sb, blocks, [t0k t0x fso fsr cinv R0], [E E], flagnum)
+ *         gsizes = [S T N M I En Em flagnum dtype], tvars = [t0k t0x fso fsr cinv R0]; the sb / blocks culling tables are not needed; y is S x N x M complex
+ *   z   = qdas_mex('convd', csizes, x, y)                                 kern/convd.m:150-199     kern.feval(x, y, z, sizes)
+ *         csizes = [C M N S dtype cplx shape bcast y_real] (include/qdas.h qdas_convd_desc); z is C x L x S
+ *   y   = qdas_mex('hilbert', psizes, x, tvars)                           src/ChannelData.m:935-966 (+ downmix :757-766)
+ *         psizes = [T K Nfft in_type], tvars = [fs t0 fdown]; x real single or int16 T x K; y is Nfft x K complex single
+ * Host arrays are staged through device memory by the gateway (qdas_device_malloc / _copy / _free: no HIP headers needed); with -DQDAS_MEX_GPU gpuArrays
+ * pass as device pointers and the result is a gpuArray.
+ *
  *   sizes    : numeric row [T N M I1 I2 I3 S flag VS DV dtype]  (dtype: 0 double, 1 single, 2 half)   -- any real numeric class;
  *              the QUPS_* constants of kern/das_spec.m:294-298.  The one-call form takes a 12th entry F (frames).
  *   Pi..Nv   : real(prec) arrays laid out 3 x I, 3 x N, 4 x M (row 4 = t0, kern/das_spec.m:361), 3 x M
@@ -224,6 +239,217 @@ static plan_slot *slot_of(const mxArray *h) {
     return &g_slots[k];
 }
 
+/* ---- the stateless commands: device-pointer entries of the C ABI behind host arrays (staged here) or gpuArrays (passed through) */
+typedef struct { const void *ptr; void *owned; argptr a; } devarg;
+#define QDAS_MEX_MAX_DEVARGS 8
+static devarg g_da[QDAS_MEX_MAX_DEVARGS];
+static int g_nda = 0;
+static void *g_out_dev = NULL;                          /* device image of a host output */
+static void release_devargs(void) {
+    for (int k = 0; k < g_nda; ++k) { if (g_da[k].owned) qdas_device_free(g_da[k].owned, -1); arg_release(&g_da[k].a); }
+    g_nda = 0;
+    if (g_out_dev) { qdas_device_free(g_out_dev, -1); g_out_dev = NULL; }
+}
+/* raise after releasing what the command staged (mexErrMsgIdAndTxt does not return) */
+#define CFAIL(...) do { release_devargs(); mexErrMsgIdAndTxt("QUPS:das_spec:qdas", __VA_ARGS__); } while (0)
+
+/* device pointer of an input of `bytes` bytes ([] -> NULL); *any_dev collects whether some argument was a gpuArray */
+static const void *dev_in(const mxArray *a, size_t bytes, const char *what, int *any_dev) {
+    if (g_nda >= QDAS_MEX_MAX_DEVARGS) CFAIL("too many array arguments.");
+    devarg *d = &g_da[g_nda++];
+    memset(d, 0, sizeof *d);
+    d->a = arg_data(a);
+    if (!d->a.ptr) return NULL;
+    const size_t have = (size_t)mxGetNumberOfElements(a) * (mxGetClassID(a) == mxDOUBLE_CLASS || mxGetClassID(a) == mxINT64_CLASS || mxGetClassID(a) == mxUINT64_CLASS ? 8 :
+                        mxGetClassID(a) == mxSINGLE_CLASS || mxGetClassID(a) == mxINT32_CLASS || mxGetClassID(a) == mxUINT32_CLASS ? 4 :
+                        mxGetClassID(a) == mxINT16_CLASS || mxGetClassID(a) == mxUINT16_CLASS ? 2 : 1) * (mxIsComplex(a) ? 2 : 1);
+    if (have < bytes) CFAIL("%s: %llu bytes expected, the array holds %llu (class / complexity / size mismatch).", what, (unsigned long long)bytes, (unsigned long long)have);
+    if (d->a.is_dev) { *any_dev = 1; d->ptr = d->a.ptr; return d->ptr; }
+    if (qdas_device_malloc(&d->owned, bytes, -1) || qdas_device_copy(d->owned, d->a.ptr, bytes, 0, -1)) CFAIL("%s", qdas_last_error());
+    d->ptr = d->owned;
+    return d->ptr;
+}
+
+/* output array of `nd` dims: a gpuArray when the inputs were (GPU build), else a host array with a device image in g_out_dev; returns the device pointer */
+#ifdef QDAS_MEX_GPU
+static mxGPUArray *g_out_gpu = NULL;
+#endif
+static void *dev_out(mwSize nd, const mwSize *dims, mxClassID cls, int cplx, int on_dev, size_t bytes, mxArray **host) {
+    *host = NULL;
+#ifdef QDAS_MEX_GPU
+    if (on_dev) { g_out_gpu = mxGPUCreateGPUArray(nd, dims, cls, cplx ? mxCOMPLEX : mxREAL, MX_GPU_DO_NOT_INITIALIZE); return mxGPUGetData(g_out_gpu); }
+#endif
+    (void)on_dev;
+    *host = mxCreateNumericArray(nd, dims, cls, cplx ? mxCOMPLEX : mxREAL);
+    if (qdas_device_malloc(&g_out_dev, bytes, -1)) { mxDestroyArray(*host); *host = NULL; CFAIL("%s", qdas_last_error()); }
+    return g_out_dev;
+}
+/* after the launch: the host image is fetched (synchronises) ... */
+static int fetch_out(int rc, mxArray *host, size_t bytes) {
+    if (!rc && host && g_out_dev) rc = qdas_device_copy(mxGetData(host), g_out_dev, bytes, 1, -1);
+    return rc;
+}
+/* ... and everything staged is released; rc != 0 raises with the library's message */
+static mxArray *conclude(int rc, mxArray *host) {
+    mxArray *ret = host;
+#ifdef QDAS_MEX_GPU
+    if (g_out_gpu) { if (!rc) ret = mxGPUCreateMxArrayOnGPU(g_out_gpu); mxGPUDestroyGPUArray(g_out_gpu); g_out_gpu = NULL; }
+#endif
+    if (rc) { if (host) mxDestroyArray(host); CFAIL("%s", qdas_last_error()); }
+    release_devargs();
+    return ret;
+}
+static mxArray *finish(int rc, mxArray *host, size_t bytes) { return conclude(fetch_out(rc, host, bytes), host); }
+static size_t cbytes(int dtype) { return dtype == QDAS_F64 ? 16 : (dtype == QDAS_F32 ? 8 : 4); }     /* complex sample */
+static size_t rbytes(int dtype) { return dtype == QDAS_F64 ? 8 : 4; }                                   /* geometry / time (half data: single) */
+
+/* tau = qdas_mex('delays', sizes, Pi, Pr, Pv, Nv, cinv) | qdas_mex('delays', h) -- kern/das_spec.m:376-377, src/bf.cu:209-298 */
+static mxArray *cmd_delays(int nrhs, const mxArray *prhs[]) {
+    mxArray *host;
+    if (nrhs == 1) {                                    /* a live plan */
+        plan_slot *s = slot_of(prhs[0]);
+        if (!s->plan) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "'delays' needs a single-device plan.");
+        const qdas_sizes *z = &s->sz;
+        const mwSize dims[3] = {(mwSize)(z->I1 * z->I2 * z->I3), (mwSize)z->N, (mwSize)z->M};
+        const size_t bytes = (size_t)dims[0] * dims[1] * dims[2] * rbytes(z->dtype);
+        void *tau = dev_out(3, dims, z->dtype == QDAS_F64 ? mxDOUBLE_CLASS : mxSINGLE_CLASS, 0, s->mem == QDAS_MEM_DEVICE, bytes, &host);
+        return finish(qdas_plan_delays(s->plan, tau, NULL), host, bytes);
+    }
+    if (nrhs != 6) mexErrMsgIdAndTxt("QUPS:das_spec:nargin", "qdas_mex('delays', sizes, Pi, Pr, Pv, Nv, cinv) or qdas_mex('delays', h)");
+    qdas_sizes z;
+    read_sizes(prhs[0], &z, NULL);
+    if (z.dtype == QDAS_F16) z.dtype = QDAS_F32;        /* (delays of half data are single: kern/das_spec.m:354-357) */
+    const size_t rs = rbytes(z.dtype), I = (size_t)(z.I1 * z.I2 * z.I3);
+    int dev = 0;
+    const void *Pi = dev_in(prhs[1], 3 * I * rs, "Pi", &dev), *Pr = dev_in(prhs[2], 3 * z.N * rs, "Pr", &dev);
+    const void *Pv = dev_in(prhs[3], 4 * z.M * rs, "Pv", &dev), *Nv = dev_in(prhs[4], 3 * z.M * rs, "Nv", &dev);
+    const double cinv = num_at(prhs[5], 0, "cinv");    /* cinv(1), as the reference passes it */
+    const mwSize dims[3] = {(mwSize)I, (mwSize)z.N, (mwSize)z.M};
+    const size_t bytes = I * z.N * z.M * rs;
+    void *tau = dev_out(3, dims, z.dtype == QDAS_F64 ? mxDOUBLE_CLASS : mxSINGLE_CLASS, 0, dev, bytes, &host);
+    const int rc = z.dtype == QDAS_F64 ? qdas_delays(&z, (double *)tau, (const double *)Pi, (const double *)Pr, (const double *)Pv, (const double *)Nv, cinv, NULL)
+                                       : qdas_delaysf(&z, (float *)tau, (const float *)Pi, (const float *)Pr, (const float *)Pv, (const float *)Nv, (float)cinv, NULL);
+    return finish(rc, host, bytes);
+}
+
+/* y = qdas_mex('lut', lsizes, w, x, t1, t2, wstride, omega) -- kern/wsinterpd2.m:236 as bfDASLUT -> sample2sep reaches it */
+static mxArray *cmd_lut(int nrhs, const mxArray *prhs[]) {
+    if (nrhs != 7) mexErrMsgIdAndTxt("QUPS:das_spec:nargin", "qdas_mex('lut', lsizes, w, x, t1, t2, wstride, omega)");
+    qdas_lut_desc d;
+    memset(&d, 0, sizeof d);
+    const mxArray *ls = prhs[0];
+    d.T = (uint64_t)num_at(ls, 0, "lsizes"); d.N = (uint64_t)num_at(ls, 1, "lsizes"); d.M = (uint64_t)num_at(ls, 2, "lsizes"); d.I = (uint64_t)num_at(ls, 3, "lsizes");
+    d.flag = (int32_t)num_at(ls, 4, "lsizes"); d.dtype = (int32_t)num_at(ls, 5, "lsizes");
+    d.I1 = mxGetNumberOfElements(ls) > 6 ? (uint64_t)num_at(ls, 6, "lsizes") : 0;
+    d.w_real = mxGetNumberOfElements(ls) > 7 ? (int32_t)num_at(ls, 7, "lsizes") : 0;
+    d.omega = num_at(prhs[6], 0, "omega");
+    if (d.dtype < QDAS_F64 || d.dtype > QDAS_F16) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "lsizes(6): dtype must be 0 (double), 1 (single) or 2 (half).");
+    const size_t cs = cbytes(d.dtype), ts = rbytes(d.dtype), ws = d.w_real ? cs / 2 : cs;
+    const uint64_t oN = (d.flag & QDAS_FLAG_KEEP_RX) ? d.N : 1, oM = (d.flag & QDAS_FLAG_KEEP_TX) ? d.M : 1;
+    int dev = 0;
+    if (!mxIsEmpty(prhs[1])) {
+        if (mxGetClassID(prhs[5]) != mxUINT64_CLASS || mxGetNumberOfElements(prhs[5]) < 3) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "wstride must be uint64 [si sn sm].");
+        memcpy(d.wstride, mxGetData(prhs[5]), 3 * sizeof(uint64_t));
+        const uint64_t nel = 1 + (d.I ? d.I - 1 : 0) * d.wstride[0] + (d.N ? d.N - 1 : 0) * d.wstride[1] + (d.M ? d.M - 1 : 0) * d.wstride[2];
+        d.w = dev_in(prhs[1], (size_t)nel * ws, "w", &dev);
+    }
+    const void *x = dev_in(prhs[2], (size_t)(d.T * d.N * d.M) * cs, "x", &dev);
+    d.tau_rx = dev_in(prhs[3], (size_t)(d.I * d.N) * ts, "t1", &dev);
+    d.tau_tx = dev_in(prhs[4], (size_t)(d.I * d.M) * ts, "t2", &dev);
+    const int half = d.dtype == QDAS_F16;
+    mwSize dims[4], nd = 0;
+    if (half) dims[nd++] = 2;
+    dims[nd++] = (mwSize)d.I; dims[nd++] = (mwSize)oN; dims[nd++] = (mwSize)oM;
+    const size_t bytes = (size_t)(d.I * oN * oM) * cs;
+    mxArray *host;
+    void *y = dev_out(nd, dims, class_of(d.dtype), !half, dev, bytes, &host);
+    return finish(qdas_das_lut(&d, x, y, NULL), host, bytes);
+}
+
+/* y = qdas_mex('greens', gsizes, ps, as, pn, pv, x, tvars) -- src/UltrasoundSystem.m:681-718, src/greens.cu:88-121 */
+static mxArray *cmd_greens(int nrhs, const mxArray *prhs[]) {
+    if (nrhs != 7) mexErrMsgIdAndTxt("QUPS:das_spec:nargin", "qdas_mex('greens', gsizes, ps, as, pn, pv, x, tvars)");
+    qdas_greens_desc d;
+    memset(&d, 0, sizeof d);
+    const mxArray *g = prhs[0], *tv = prhs[6];
+    d.S = (uint64_t)num_at(g, 0, "gsizes"); d.T = (uint64_t)num_at(g, 1, "gsizes"); d.N = (uint64_t)num_at(g, 2, "gsizes"); d.M = (uint64_t)num_at(g, 3, "gsizes");
+    d.I = (uint64_t)num_at(g, 4, "gsizes"); d.En = (int32_t)num_at(g, 5, "gsizes"); d.Em = (int32_t)num_at(g, 6, "gsizes");
+    d.interp = (int32_t)num_at(g, 7, "gsizes"); d.dtype = (int32_t)num_at(g, 8, "gsizes");
+    d.s0 = num_at(tv, 0, "tvars"); d.t0 = num_at(tv, 1, "tvars"); d.fs = num_at(tv, 2, "tvars"); d.fsr = num_at(tv, 3, "tvars"); d.cinv = num_at(tv, 4, "tvars"); d.R0 = num_at(tv, 5, "tvars");
+    d.device = -1;
+    if (d.dtype != QDAS_F64 && d.dtype != QDAS_F32) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "greens: datatype must be double or single");
+    if (d.En < 1 || d.Em < 1) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "greens: element subdivisions must be >= 1");
+    const size_t rs = rbytes(d.dtype), cs = cbytes(d.dtype);
+    int dev = 0;
+    d.Ps = dev_in(prhs[1], 3 * (size_t)d.I * rs, "ps", &dev);
+    d.a = dev_in(prhs[2], (size_t)d.I * cs, "as", &dev);
+    d.Pr = dev_in(prhs[3], 3 * (size_t)d.N * (size_t)d.En * rs, "pn", &dev);
+    d.Pv = dev_in(prhs[4], 3 * (size_t)d.M * (size_t)d.Em * rs, "pv", &dev);
+    d.x = dev_in(prhs[5], (size_t)d.T * cs, "x", &dev);
+    const mwSize dims[3] = {(mwSize)d.S, (mwSize)d.N, (mwSize)d.M};
+    const size_t bytes = (size_t)(d.S * d.N * d.M) * cs;
+    mxArray *host;
+    void *y = dev_out(3, dims, d.dtype == QDAS_F64 ? mxDOUBLE_CLASS : mxSINGLE_CLASS, 1, dev, bytes, &host);
+    return finish(qdas_greens(&d, y, NULL), host, bytes);
+}
+
+/* z = qdas_mex('convd', csizes, x, y) -- kern/convd.m:150-199, src/convd.cu:95-146 */
+static mxArray *cmd_convd(int nrhs, const mxArray *prhs[]) {
+    if (nrhs != 3) mexErrMsgIdAndTxt("QUPS:das_spec:nargin", "qdas_mex('convd', csizes, x, y)");
+    qdas_convd_desc d;
+    memset(&d, 0, sizeof d);
+    const mxArray *c = prhs[0];
+    d.C = (uint64_t)num_at(c, 0, "csizes"); d.M = (uint64_t)num_at(c, 1, "csizes"); d.N = (uint64_t)num_at(c, 2, "csizes"); d.S = (uint64_t)num_at(c, 3, "csizes");
+    d.dtype = (int32_t)num_at(c, 4, "csizes"); d.cplx = (int32_t)num_at(c, 5, "csizes"); d.shape = (int32_t)num_at(c, 6, "csizes");
+    d.bcast = mxGetNumberOfElements(c) > 7 ? (int32_t)num_at(c, 7, "csizes") : 0;
+    d.y_real = mxGetNumberOfElements(c) > 8 ? (int32_t)num_at(c, 8, "csizes") : 0;
+    d.device = -1;
+    if (d.dtype < QDAS_F64 || d.dtype > QDAS_F16) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "csizes(5): dtype must be 0 (double), 1 (single) or 2 (half).");
+    const size_t es = (d.dtype == QDAS_F64 ? 8 : d.dtype == QDAS_F32 ? 4 : 2), xs = es * (d.cplx ? 2 : 1), ys = es * ((d.cplx && !d.y_real) ? 2 : 1);
+    const uint64_t L = qdas_convd_len(d.M, d.N, d.shape);
+    const uint64_t xC = (d.bcast & QDAS_CONV_X_ONE_COLUMN) ? 1 : d.C, xS = (d.bcast & QDAS_CONV_X_ONE_SLICE) ? 1 : d.S;
+    const uint64_t yC = (d.bcast & QDAS_CONV_Y_ONE_COLUMN) ? 1 : d.C, yS = (d.bcast & QDAS_CONV_Y_ONE_SLICE) ? 1 : d.S;
+    int dev = 0;
+    const void *x = dev_in(prhs[1], (size_t)(xC * d.M * xS) * xs, "x", &dev);
+    const void *y = dev_in(prhs[2], (size_t)(yC * d.N * yS) * ys, "y", &dev);
+    const int half = d.dtype == QDAS_F16;
+    mwSize dims[4], nd = 0;
+    if (half && d.cplx) dims[nd++] = 2;                 /* (half complex travels as uint16 pairs, like the DAS data) */
+    dims[nd++] = (mwSize)d.C; dims[nd++] = (mwSize)L; dims[nd++] = (mwSize)d.S;
+    const size_t bytes = (size_t)(d.C * L * d.S) * xs;
+    mxArray *host;
+    void *z = dev_out(nd, dims, class_of(d.dtype), d.cplx && !half, dev, bytes, &host);
+    return finish(qdas_convd(&d, x, y, z, NULL), host, bytes);
+}
+
+/* y = qdas_mex('hilbert', psizes, x, tvars) -- src/ChannelData.m:935-966 (+ downmix :757-766): plan, one execute, destroy */
+static mxArray *cmd_hilbert(int nrhs, const mxArray *prhs[]) {
+    if (nrhs != 3) mexErrMsgIdAndTxt("QUPS:das_spec:nargin", "qdas_mex('hilbert', psizes, x, tvars)");
+    qdas_pre_desc d;
+    memset(&d, 0, sizeof d);
+    const mxArray *p = prhs[0], *tv = prhs[2];
+    d.T = (uint64_t)num_at(p, 0, "psizes"); d.K = (uint64_t)num_at(p, 1, "psizes"); d.Nfft = (uint64_t)num_at(p, 2, "psizes");
+    d.in_type = mxGetNumberOfElements(p) > 3 ? (int32_t)num_at(p, 3, "psizes") : QDAS_PRE_F32;
+    d.device = -1;
+    d.fs = num_at(tv, 0, "tvars"); d.t0 = num_at(tv, 1, "tvars"); d.fdown = num_at(tv, 2, "tvars");
+    if (d.in_type != QDAS_PRE_F32 && d.in_type != QDAS_PRE_I16) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "psizes(4): in_type must be 0 (single) or 1 (int16).");
+    if (mxIsComplex(prhs[1]) || mxGetClassID(prhs[1]) != (d.in_type == QDAS_PRE_I16 ? mxINT16_CLASS : mxSINGLE_CLASS))
+        mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "x must be real %s for this in_type.", d.in_type == QDAS_PRE_I16 ? "int16" : "single");
+    const uint64_t Nf = d.Nfft ? d.Nfft : d.T;
+    int dev = 0;
+    const void *x = dev_in(prhs[1], (size_t)(d.T * d.K) * (d.in_type == QDAS_PRE_I16 ? 2 : 4), "x", &dev);
+    const mwSize dims[2] = {(mwSize)Nf, (mwSize)d.K};
+    const size_t bytes = (size_t)(Nf * d.K) * 8;
+    mxArray *host;
+    void *y = dev_out(2, dims, mxSINGLE_CLASS, 1, dev, bytes, &host);
+    qdas_pre_plan *pl = NULL;
+    int rc = qdas_pre_plan_create(&pl, &d);
+    if (!rc) rc = qdas_pre_execute(pl, x, y, NULL);
+    rc = fetch_out(rc, host, bytes);                    /* (host output: synchronises before the plan goes; gpuArray output: the plan's hipFree does) */
+    if (pl) qdas_pre_plan_destroy(pl);
+    return conclude(rc, host);
+}
+
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
 #ifdef QDAS_MEX_GPU
     mxInitGPU();
@@ -254,6 +480,11 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
                 snprintf(buf, sizeof buf, "sharded over %d device slab(s)", n);
             }
             plhs[0] = mxCreateString(buf);
+        } else if (!strcmp(cmd, "delays")) { plhs[0] = cmd_delays(nrhs - 1, prhs + 1);
+        } else if (!strcmp(cmd, "lut")) { plhs[0] = cmd_lut(nrhs - 1, prhs + 1);
+        } else if (!strcmp(cmd, "greens")) { plhs[0] = cmd_greens(nrhs - 1, prhs + 1);
+        } else if (!strcmp(cmd, "convd")) { plhs[0] = cmd_convd(nrhs - 1, prhs + 1);
+        } else if (!strcmp(cmd, "hilbert")) { plhs[0] = cmd_hilbert(nrhs - 1, prhs + 1);
         } else if (!strcmp(cmd, "destroy")) {
             if (nrhs >= 2) destroy_slot(slot_of(prhs[1])); else destroy_all();
         } else mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "unknown command '%s'.", cmd);

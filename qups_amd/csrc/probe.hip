@@ -1,0 +1,107 @@
+// probe.hip -- qdas_debug_issue_rate: the SATURATED VALU issue rate of this device, measured in wall time, for bench.py's roofline.
+//
+// The fused DAS kernel is bound by VALU issue under the part's power limit (DESIGN.md 4.1 "What binds"): the clock follows the instruction
+// mix (2.0-2.4 GHz idle-ish, ~1.2-1.3 GHz under saturated packed FMAs), so neither "4 cycles per wave64 instruction" nor a nominal clock prices
+// an instruction -- only a measurement on the box that ran the bench does.  One workgroup of 16 waves per CU (4 per SIMD, as the DAS kernel runs),
+// every wave issues REP x 64 independent instructions of the chosen mix; the rate is (instructions per SIMD) / (hipEvent time of the launch).
+//   mix 0: v_pk_fma_f32 with a broadcast operand (the tap multiply-accumulates)
+//   mix 1: v_fma_f32
+//   mix 2: the pair loop's own VALU mix without its LDS reads: per 37 instructions 16 broadcast pk_fma (MACs), 16 pk_fma with SGPR-pair
+//          coefficients (weights), 3 v_add_f32 / 2 v_lshl_add_u32 (index) -- tile_pairs.h, folded + lateral-mirror configuration
+// tools/microbench_src/issue.hip is the long form of this probe (shader cycles, LDS mixes, one wave per SIMD); this entry exists so that the
+// bench line carries a roof measured IN THE SAME RUN.  Test / bench infrastructure: no product path calls it.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "../../include/qdas.h"
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define R8(S) S S S S S S S S
+template <int MIX>
+__global__ void __launch_bounds__(1024) issue_probe_kernel(float *sink, int rep, float seed, v2f coef) {
+    extern __shared__ unsigned char probe_lds[];       // (sized to keep ONE workgroup per CU)
+    const int lane = threadIdx.x & 63;
+    float a0 = seed + lane, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    v2f p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a0}, p5 = {a3, a2}, p6 = {a5, a4}, p7 = {a7, a6};
+    const v2f m2 = {1.0001f, 0.9999f}, c2 = {0.5f, 0.25f};
+    uint32_t u0 = lane, u1 = lane + 1;
+    for (int i = 0; i < rep; ++i) {
+        if constexpr (MIX == 0) {
+            asm volatile(R8("v_pk_fma_f32 %0, %9, %8, %0 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, %9, %8, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"
+                            "v_pk_fma_f32 %2, %9, %8, %2 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %3, %9, %8, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"
+                            "v_pk_fma_f32 %4, %9, %8, %4 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %5, %9, %8, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"
+                            "v_pk_fma_f32 %6, %9, %8, %6 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %7, %9, %8, %7 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n")
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(m2), "v"(c2));
+        } else if constexpr (MIX == 1) {
+            asm volatile(R8("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                            "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m2.x), "v"(c2.x));
+        } else {
+            // 37 instructions, twice (74 per iteration): 16 MACs, 16 weight FMAs (SGPR-pair coefficients), 3 adds, 2 shift-adds
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                asm volatile("v_pk_fma_f32 %0, %9, %8, %0 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, %9, %8, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"
+                             "v_pk_fma_f32 %2, %9, %8, %2 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %3, %9, %8, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"
+                             "v_pk_fma_f32 %4, %4, %10, %9\n v_pk_fma_f32 %5, %5, %10, %9\n v_pk_fma_f32 %6, %6, %10, %9\n v_pk_fma_f32 %7, %7, %10, %9\n"
+                             "v_pk_fma_f32 %0, %9, %8, %0 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, %9, %8, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"
+                             "v_pk_fma_f32 %2, %9, %8, %2 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %3, %9, %8, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"
+                             "v_pk_fma_f32 %4, %4, %10, %9\n v_pk_fma_f32 %5, %5, %10, %9\n v_pk_fma_f32 %6, %6, %10, %9\n v_pk_fma_f32 %7, %7, %10, %9\n"
+                             "v_pk_fma_f32 %0, %9, %8, %0 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, %9, %8, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"
+                             "v_pk_fma_f32 %2, %9, %8, %2 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %3, %9, %8, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"
+                             "v_pk_fma_f32 %4, %4, %10, %9\n v_pk_fma_f32 %5, %5, %10, %9\n v_pk_fma_f32 %6, %6, %10, %9\n v_pk_fma_f32 %7, %7, %10, %9\n"
+                             "v_pk_fma_f32 %0, %9, %8, %0 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %1, %9, %8, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"
+                             "v_pk_fma_f32 %2, %9, %8, %2 op_sel_hi:[1,0,1]\n v_pk_fma_f32 %3, %9, %8, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n"
+                             "v_pk_fma_f32 %4, %4, %10, %9\n v_pk_fma_f32 %5, %5, %10, %9\n v_pk_fma_f32 %6, %6, %10, %9\n v_pk_fma_f32 %7, %7, %10, %9\n"
+                             : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(m2), "v"(c2), "s"(coef));
+                asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %0, %0, %1\n v_lshl_add_u32 %2, %2, 3, %3\n v_lshl_add_u32 %3, %3, 3, %2\n"
+                             : "+v"(a0), "+v"(a1), "+v"(u0), "+v"(u1) : "v"(m2.x));
+            }
+        }
+    }
+    const v2f s = p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7;
+    const float r = s.x + s.y + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(u0 ^ u1);
+    if (r == 12345.678f) sink[threadIdx.x] = r;           // (never true: keeps the chains alive)
+    (void)probe_lds;
+}
+
+// ns per wave64 VALU instruction and SIMD at saturation (4 waves per SIMD on every CU) for the chosen mix, and the instructions per SIMD and launch
+extern "C" int qdas_debug_issue_rate(int device, int mix, double *ns_per_inst, double *launch_ms) {
+    if (!ns_per_inst || mix < 0 || mix > 2) return QDAS_EINVAL;
+    int prev = -1;
+    if (device >= 0) { if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) return QDAS_EHIP; }
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    float *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.f;
+    const int rep = mix == 1 ? 16384 : 8192, per_iter = mix == 2 ? 74 : 64;
+    const size_t lds = 96 * 1024;
+    if (e == hipSuccess) e = hipMalloc(&sink, 4096);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    auto launch = [&]() -> hipError_t {
+        const v2f coef = {0.75f, -0.125f};
+        hipError_t r = hipSuccess;
+#define QP(M) do { auto k = issue_probe_kernel<M>; r = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                   if (r == hipSuccess) { k<<<dim3((unsigned)cus), dim3(1024), lds, 0>>>(sink, rep, 1.0f, coef); r = hipGetLastError(); } } while (0)
+        if (mix == 0) QP(0); else if (mix == 1) QP(1); else QP(2);
+#undef QP
+        return r;
+    };
+    if (e == hipSuccess) e = launch();                      // warm-up: lets the clock settle under this mix
+    if (e == hipSuccess) e = hipEventRecord(e0, 0);
+    if (e == hipSuccess) e = launch();
+    if (e == hipSuccess) e = hipEventRecord(e1, 0);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (sink) (void)hipFree(sink);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (e != hipSuccess) { (void)hipGetLastError(); return QDAS_EHIP; }
+    const double inst_per_simd = 4.0 * (double)rep * (double)per_iter;      // 4 waves per SIMD
+    *ns_per_inst = (double)ms * 1e6 / inst_per_simd;
+    if (launch_ms) *launch_ms = ms;
+    return QDAS_OK;
+}

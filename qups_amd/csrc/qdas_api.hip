@@ -1921,3 +1921,29 @@ extern "C" int qdas_permute3(const void *in, void *out, uint64_t A, uint64_t B, 
     HIPCHK(launch_permute3(in, out, A, B, C, elem_bytes, (hipStream_t)stream));
     return QDAS_OK;
 }
+
+// ---- device staging for host callers of the device-pointer entries (include/qdas.h; the MEX gateway's host-array path)
+extern "C" int qdas_device_malloc(void **p, size_t bytes, int device) {
+    if (!p) return fail(QDAS_EINVAL, "null argument");
+    *p = nullptr;
+    DeviceGuard guard(device);
+    HIPCHK(guard.err);
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(QDAS_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    return QDAS_OK;
+}
+extern "C" int qdas_device_free(void *p, int device) {
+    if (!p) return QDAS_OK;
+    DeviceGuard guard(device);
+    HIPCHK(guard.err);
+    HIPCHK(hipFree(p));
+    return QDAS_OK;
+}
+extern "C" int qdas_device_copy(void *dst, const void *src, size_t bytes, int kind, int device) {
+    if (!bytes) return QDAS_OK;
+    if (!dst || !src || kind < 0 || kind > 2) return fail(QDAS_EINVAL, "qdas_device_copy: null pointer or unknown kind");
+    DeviceGuard guard(device);
+    HIPCHK(guard.err);
+    HIPCHK(hipMemcpy(dst, src, bytes, kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice));
+    return QDAS_OK;
+}

@@ -31,7 +31,7 @@ def test_hiprtc_builds_the_specialised_kernel_without_a_device(tmp_path, monkeyp
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import kernel_regs
     rows = [r for fn in os.listdir(tmp_path) if fn.endswith(".hsaco") for r in kernel_regs.kernel_table(str(tmp_path / fn))]
-    assert len(rows) == 2 and all(r["name"] == "qdas_jit_tile" and r["vgpr_spill"] == 0 and r["scratch"] == 0 for r in rows), rows
+    assert len(rows) == 2 and all(r["name"].startswith("qdas_jit_tile__") and r["vgpr_spill"] == 0 and r["scratch"] == 0 for r in rows), rows
 
 
 def test_disk_cache_is_checked_and_private(tmp_path, monkeypatch):
@@ -242,7 +242,7 @@ def test_on_demand_variants_build_without_a_device(tmp_path, monkeypatch):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import kernel_regs
     rows = [r for fn in files for r in kernel_regs.kernel_table(str(tmp_path / fn))]
-    assert len(rows) == 2 and all(r["name"] == "qdas_jit_tile" and r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 128 for r in rows), rows
+    assert len(rows) == 2 and all(r["name"].startswith("qdas_jit_tile__") and r["vgpr_spill"] == 0 and r["scratch"] == 0 and r["vgpr"] + r["agpr"] <= 128 for r in rows), rows
     # the suite's own list (tests/conftest.py warms it on a GPU box) names variants of the matrix only
     vs = warm.read_census([os.path.join(os.path.dirname(os.path.abspath(__file__)), "suite_kernels.txt")])
     assert len(vs) > 50 and all(L.qdas_kernel_variant_prebuilt(*v) >= 0 for v in vs)

@@ -1,6 +1,6 @@
 """mex/qdas_mex.c, the MATLAB binding of the C ABI, checked without MATLAB: compiled against tests/fake_mex/ (a stand-in that
 declares only the mx / mex prototypes the gateway uses -- a syntax / ABI check, NOT a MATLAB), and, on a GPU box, driven through
-create / execute / info / destroy, multi-device plans and its error paths over a malloc-backed fake runtime and the real libqdas.so."""
+create / execute / info / destroy, multi-device plans, the stateless commands of the other launch sites (delays, lut, greens, convd, hilbert) and its error paths over a malloc-backed fake runtime and the real libqdas.so."""
 import os
 import subprocess
 
@@ -31,3 +31,6 @@ def test_gateway_runs_over_the_fake_runtime(tmp_path):
     #  a whole-image plan sums the mirrored half in another order, so it is switched off for this comparison)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, QDAS_NO_MIRROR="1"))
     assert r.returncode == 0 and "fake-MEX gateway OK" in r.stdout, r.stdout + r.stderr
+    # (the launch sites beside DAS -- delays, wsinterpd2 as bfDASLUT reaches it, greens, convd, hilbert -- each driven through the gateway
+    #  and compared bit for bit with the C ABI called directly on device arrays)
+    assert "delays / lut / greens / convd / hilbert through the gateway: bit-identical to the C ABI" in r.stdout, r.stdout

@@ -95,7 +95,7 @@ def main():
     for p in paths:
         for r in kernel_table(p):
             if isdir:                                   # a hiprtc cache: the file name is the key that qdas_plan_kernel_name() prints as "[jit <key>]"
-                r["name"] = f"qdas_jit_tile [jit {os.path.basename(p).split('.')[0]}]"
+                r["name"] = f"{r['name']} [jit {os.path.basename(p).split('.')[0]}]"      # (the symbol names the template arguments since round 5)
             rows.append(r)
     names = demangle([r["name"] for r in rows])
     print(f"# {target}: {len(rows)} kernels  (vgpr / agpr / sgpr, spilled vgpr / sgpr, scratch bytes per lane, static LDS bytes)")

@@ -42,7 +42,8 @@ for f in sorted(glob.glob(os.path.join(out, "pmc_*/**/*counter_collection.csv"),
         vals[k] = sum(v) / len(v)
         print(f"{k:28s} {vals[k]:18.1f}   (n={len(v)})")
 if kt and "GRBM_GUI_ACTIVE" in vals:
-    print(f"effective clock = GRBM_GUI_ACTIVE / kernel time = {vals['GRBM_GUI_ACTIVE'] / (avg_ms * 1e-3) / 1e9:.3f} GHz  (kernel {avg_ms:.3f} ms)")
+    # (GRBM_GUI_ACTIVE sums the busy cycles of the 8 XCDs' clock domains: / 8 for the clock of one -- bench.py binding_roofs does the same)
+    print(f"effective clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time = {vals['GRBM_GUI_ACTIVE'] / 8.0 / (avg_ms * 1e-3) / 1e9:.3f} GHz  (kernel {avg_ms:.3f} ms)")
 if "FETCH_SIZE" in vals:
     print(f"FETCH_SIZE raw (KiB units -> bytes x1024): {vals['FETCH_SIZE'] * 1024 / 1e9:.3f} GB; x2 gfx950 correction for wide loads: {vals['FETCH_SIZE'] * 2048 / 1e9:.3f} GB")
 if "WRITE_SIZE" in vals:
