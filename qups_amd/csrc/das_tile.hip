@@ -95,70 +95,30 @@ hipError_t prepare_tile(const TileParams &P, int dtype, unsigned ntiles, std::st
     return e;
 }
 
-TileConfig tile_config(int dtype, int sym, int narrow, int fb, int mirq, int fold) {
-    const Cfg &g = CFGS[cfg_index(dtype, sym, fb, narrow, mirq, fold)];
-    TileConfig c;
-    c.waves = g.waves;
-    c.mb = g.mb;
-    c.window = g.w;
-    c.threads = g.waves * 64;
-    const int sets = (fold && sym && dtype == 1) ? (mirq ? 2 : 1) * (fb == 2 ? 2 : 1) : (mirq && sym) ? 4 : (sym || fb == 2) ? 2 : 1;      // window sets per buffer
-    c.lds_bytes = (size_t)g.nbuf * g.mb * sets * g.w * (dtype == 2 ? 4 : dtype == 0 ? 16 : 8);
-    return c;
+// the launcher's view of a parameter block (plan_modes.h launch_legal: the admission rules, shared with the GPU-less mode tests)
+modes::LaunchShape launch_shape(const TileParams &P, int dtype, bool jit) {
+    modes::LaunchShape L;
+    L.dtype = dtype; L.sym = P.sym ? 1 : 0; L.fold = P.fold; L.mir = P.mir; L.narrow_raw = P.narrow; L.big = P.big; L.bf = P.bf; L.syn = P.syn; L.stage_shift = P.stage_shift;
+    L.probe = P.probe; L.nfr = P.nfr; L.lut = P.lut_tx != nullptr; L.has_wtab = P.wtab != nullptr; L.has_apix = P.apix != nullptr; L.has_bpix = P.bpix != nullptr;
+    L.has_part = P.part != nullptr; L.jit = jit; L.gen_kind = P.gen_kind; L.fmod = P.fmod; L.act_bytes = P.act_bytes; L.ksplit = P.ksplit; L.N = P.N; L.M = P.M;
+    return L;
 }
-
-size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow, int pixw, int wtab, int mirq, int fold, int fb) {
-    const Cfg &g = CFGS[cfg_index(dtype, sym, fold ? fb : 1, narrow, mirq, fold)];
-    const TileConfig c = tile_config(dtype, sym, narrow, fold ? fb : 1, mirq, fold);
-    const size_t MX = std::min<size_t>(M > N ? M : N, QDAS_PROLOGUE_CHUNK);
-    // (geometry tables in the plan's real type: 32-byte receiver records and 8-byte table entries for fp64 data -- Tile::setup)
-    const size_t off_act = (((((2 * M + N) * 4 + 15) & ~(size_t)15) + (dtype == 0 ? 32 : 16) * N + 7 * M * (dtype == 0 ? 8 : 4)) + 15) & ~(size_t)15;
-    const size_t off_wst = off_act + (((pixw ? 8 * (N + 1) : 0) + 15) & ~(size_t)15);
-    const size_t hdr = (off_wst + ((wtab && dtype != 0) ? (size_t)g.nbuf * (2 * (size_t)g.mb * 8 + 16) : 0) + 15) & ~(size_t)15;     // Tile::setup
-    size_t body = c.lds_bytes;
-    const size_t scratch = 2 * (size_t)g.waves * MX * 4 + 1024;   // prologue scratch aliases the windows
-    if (body < scratch) body = scratch;
-    return hdr + body;
-}
-size_t tile_lds_limit(int sym) { return (size_t)(160 * 1024) / CFGS[sym ? 1 : 0].bpc; }
 
 hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s, hipFunction_t jit, size_t jit_lds) {
     if (ntiles == 0) return hipSuccess;
+    modes::LaunchChoice ch;
+    if (modes::launch_legal(launch_shape(P, dtype, jit != nullptr), &ch)) return hipErrorInvalidValue;
     const int sym = P.sym ? 1 : 0;
-    if (sym && dtype != 1 && dtype != 2) return hipErrorInvalidValue;
     if (dtype == 0) {                                    // fp64 data: one frame, one workgroup per tile, plain 'DAS' sum, prebuilt kernels
-        if (P.lut_tx || P.bf || P.syn || P.big || P.nfr > 1 || (jit && P.probe) || (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part)))) return hipErrorInvalidValue;
-        const size_t lds64 = tile_lds_bytes(0, 0, P.N, P.M, 0);
-        if (lds64 > tile_lds_limit(0)) return hipErrorInvalidValue;
+        const size_t lds64 = ch.lds;
         hipError_t e64 = jit ? jit_launch(jit, P, ntiles * P.ksplit, (unsigned)CFGS[13].waves * 64u, lds64, s) : launch_tile_f64(P, ntiles, lds64, s);
         if (e64 != hipSuccess || P.probe || P.ksplit <= 1 || g_prepare_only) return e64;
         tile_reduce_kernel_f64<<<(unsigned)((P.i_count + 255) / 256), 256, 0, s>>>((const double2 *)P.part, (double2 *)P.y, P.i_count, P.ksplit);
         return hipGetLastError();
     }
-    const int narrow = (sym && dtype == 1 && P.narrow) ? 1 : (!sym && dtype == 1 && P.narrow == 2) ? 2 : 0;     // window variant (das_tile_cfg.h)
-    if (narrow == 2 && (P.lut_tx || P.bf || P.big || (!P.probe && P.nfr > 1))) return hipErrorInvalidValue;
-    if (P.bpix && (narrow != 2 || P.wtab || P.fmod != 0.0 || P.syn || sym)) return hipErrorInvalidValue;      // (TileCfg::BPIX instantiations only)
-    if (P.act_bytes != 0 && P.act_bytes != 8 * (P.N + 1)) return hipErrorInvalidValue;
-    // fp32 reciprocal plans WITHOUT the fold (QDAS_PLAN_NO_FOLD) exist as hiprtc builds only (round 4: their prebuilt instantiations -- launch
-    // configurations 1 / 7 / 15 -- were pruned); the plan-time probes of every fp32 reciprocal plan run the probe kernels of the folded
-    // configurations (the same prologue; 128- or 192-sample windows)
-    const int fold = (sym && P.fold && dtype == 1) ? 1 : 0;   // reciprocity-folded data (launch configurations 17 ... 21)
-    if (P.fold && (!fold || P.wtab)) return hipErrorInvalidValue;
-    const bool probe_f32sym = P.probe && sym && dtype == 1;
-    if (sym && dtype == 1 && !fold && !jit && !P.probe) return hipErrorInvalidValue;
-    const int mirq = (sym && P.mir && !P.probe) ? 1 : 0;   // reciprocal + lateral-mirror mode: four window sets (launch configurations 15 / 16; folded data: two)
-    const size_t lds = probe_f32sym ? tile_lds_bytes(dtype, 1, P.N, P.M, narrow, 0, 0, narrow ? 1 : 0, 1)
-                                    : tile_lds_bytes(dtype, sym, P.N, P.M, narrow, P.act_bytes ? 1 : 0, P.wtab ? 1 : 0, mirq, fold, (fold && P.nfr == 2) ? 2 : 1);   // (two frames of folded data: launch configurations 20 / 21)
-    if (lds > tile_lds_limit(sym)) return hipErrorInvalidValue;
-    if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.part && !P.bf))) return hipErrorInvalidValue;
-    // frames per launch; lateral-mirror plans (one frame) run the two-window-set instantiations as well
-    const int nfr = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
-    if (P.mir && !P.probe && ((nfr != 1 && !(fold && nfr == 2)) || P.big || P.bf || P.lut_tx || P.syn || ((P.apix || P.gen_kind) && ((dtype != 2 && !jit) || sym || P.stage_shift || P.bpix)) || (!sym && narrow) || (sym && dtype == 1 && !narrow && !fold))) return hipErrorInvalidValue;
-    const int nf = (P.mir && !P.probe && !sym) ? 2 : nfr;
-    if ((nf != 1 && nf != 2 && nf != 4) || (nf > 1 && ((sym && !(fold && nf == 2)) || P.big))) return hipErrorInvalidValue;     // (folded data: two frames may share a launch)
-    if (P.lut_tx && (sym || nf != 1 || (dtype != 1 && dtype != 2) || (P.syn && dtype != 1))) return hipErrorInvalidValue;
-    if (jit && (P.probe || nfr != 1 || P.lut_tx || P.bf)) return hipErrorInvalidValue;
-    if (P.bf && (sym || nf != 1 || dtype != 1 || P.lut_tx || P.big || P.apix || P.gen_kind)) return hipErrorInvalidValue;
+    const int narrow = ch.narrow, fold = ch.fold, mirq = ch.mirq, nfr = ch.nfr, nf = ch.nf;
+    const bool probe_f32sym = ch.probe_f32sym;
+    const size_t lds = ch.lds;
     hipError_t e = jit ? jit_launch(jit, P, ntiles * P.ksplit, (unsigned)CFGS[cfg_index(dtype, sym, 1, narrow, mirq, fold)].waves * 64u, jit_lds ? jit_lds : lds, s) : (fold || probe_f32sym) ? launch_tile_fold(P, ntiles, lds, s) : P.lut_tx ? (dtype == 2 ? launch_tile_luth(P, ntiles, lds, s) : launch_tile_lut(P, ntiles, lds, s)) : (mirq && dtype == 2) ? launch_tile_symqh(P, ntiles, lds, s) : (sym && dtype == 2) ? launch_tile_symh(P, ntiles, lds, s) : sym ? hipErrorInvalidValue
                  : nf == 4 ? (dtype == 2 ? launch_tile_f16x4(P, ntiles, lds, s) : launch_tile_f32x4(P, ntiles, lds, s))
                  : nf == 2 ? (dtype == 2 ? launch_tile_f16x2(P, ntiles, lds, s) : launch_tile_f32x2(P, ntiles, lds, s))

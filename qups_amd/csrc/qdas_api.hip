@@ -425,57 +425,77 @@ static int mirror_symmetric(const qdas_desc *desc, const float *dPi, bool *yes, 
     return QDAS_OK;
 }
 
-extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
-    if (!out || !desc) return fail(QDAS_EINVAL, "null argument");
-    *out = nullptr;
-    int rc = validate(desc);
-    if (rc) return rc;
-    qdas_plan *pl = new qdas_plan();
+// ------------------------------------------------------------------------------------ plan creation
+// qdas_plan_create in steps.  WHAT a plan runs -- kernel, launch configuration, symmetry modes, and why not -- is decided by the pure functions of
+// plan_modes.h (testable without a GPU: tests/modes/enumerate_modes.cpp); the steps below gather the facts those functions ask for (host comparisons of
+// the geometry, the device's mirror check, allocations, window-fit probes) and carry out their decisions (uploads, tables, kernel builds).
+static modes::Switches read_switches() {
+    modes::Switches sw;
+    auto on = [](const char *n) { return getenv(n) != nullptr; };
+    sw.no_sym = on("QDAS_NO_SYM"); sw.no_fold = on("QDAS_NO_FOLD"); sw.no_jit = on("QDAS_NO_JIT"); sw.no_mirror = on("QDAS_NO_MIRROR"); sw.no_mirq = on("QDAS_NO_MIRQ");
+    sw.no_narrow = on("QDAS_NO_NARROW"); sw.no_role_swap = on("QDAS_NO_ROLE_SWAP"); sw.no_bpix = on("QDAS_NO_BPIX"); sw.no_w64 = on("QDAS_NO_W64");
+    sw.no_mirror_wpix = on("QDAS_NO_MIRROR_WPIX"); sw.no_mirror_wpix32 = on("QDAS_NO_MIRROR_WPIX32"); sw.no_side_split = on("QDAS_NO_SIDE_SPLIT"); sw.no_wide = on("QDAS_NO_WIDE");
+    sw.no_fb2 = on("QDAS_NO_FB2"); sw.no_fb4 = on("QDAS_NO_FB4"); sw.no_fold16 = on("QDAS_NO_FOLD16");
+    if (const char *e = getenv("QDAS_SYM_TOL")) { const double v = atof(e); if (v >= 0.0 && v <= 0.5) sw.sym_tol = v; }
+    if (const char *e = getenv("QDAS_KSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8) sw.ksplit = v; }
+    return sw;
+}
+
+// working state of one qdas_plan_create
+struct PlanBuild {
+    const qdas_desc *desc = nullptr;
+    modes::Switches sw;
+    modes::Request rq;
+    modes::Symmetry sy;
+    size_t ael = 0;                         // bytes per apodization entry
+    int txkind = 0;                         // distance | signed distance | plane wave
+    std::vector<float> host_tab;            // the folded N x M table as uploaded ([stage element + stages * block element])
+    uint64_t kN_eff = 0;                    // stage elements after a side split
+};
+
+// sizes, slab, output planes; QDAS_PLAN_MIRROR_SLAB validation
+static int plan_init(qdas_plan *pl, const qdas_desc *desc) {
     pl->d = *desc;
     const qdas_sizes &z = pl->d.sz;
-    const int dt = z.dtype;
     pl->I = z.I1 * z.I2 * z.I3;
     pl->i_count = desc->i_count ? desc->i_count : pl->I - desc->i_begin;
     pl->y_ld = desc->y_ld ? desc->y_ld : pl->i_count;
     pl->oN = (z.flag & QDAS_FLAG_KEEP_RX) ? z.N : 1;
     pl->oM = (z.flag & QDAS_FLAG_KEEP_TX) ? z.M : 1;
-    if (pl->y_ld < pl->i_count) { delete pl; return fail(QDAS_EINVAL, "y_ld smaller than the pixel count"); }
+    if (pl->y_ld < pl->i_count) return fail(QDAS_EINVAL, "y_ld smaller than the pixel count");
     if (desc->plan_flags & QDAS_PLAN_MIRROR_SLAB) {
         const bool ok = z.I3 == 1 && z.I2 % 2 == 0 && z.I1 && desc->i_begin % z.I1 == 0 && pl->i_count % z.I1 == 0 && pl->i_count
                         && desc->i_begin + pl->i_count <= pl->I / 2 && !(z.flag & (QDAS_FLAG_KEEP_RX | QDAS_FLAG_KEEP_TX)) && desc->kernel != QDAS_KERNEL_GENERIC;
-        if (!ok) { delete pl; return fail(QDAS_EINVAL, "QDAS_PLAN_MIRROR_SLAB: the slab must be whole columns of the first half of an even number of columns (I3 == 1, 'DAS')"); }
+        if (!ok) return fail(QDAS_EINVAL, "QDAS_PLAN_MIRROR_SLAB: the slab must be whole columns of the first half of an even number of columns (I3 == 1, 'DAS')");
         if (!desc->y_ld) pl->y_ld = 2 * pl->i_count;     // y holds slab A and its mirror image
-        else if (desc->y_ld < 2 * pl->i_count) { delete pl; return fail(QDAS_EINVAL, "QDAS_PLAN_MIRROR_SLAB: y_ld smaller than 2 * i_count (y holds slab A and its mirror image)"); }
+        else if (desc->y_ld < 2 * pl->i_count) return fail(QDAS_EINVAL, "QDAS_PLAN_MIRROR_SLAB: y_ld smaller than 2 * i_count (y holds slab A and its mirror image)");
     }
+    return QDAS_OK;
+}
 
-    auto bail = [&](int code) { delete pl; return code; };
-    DeviceGuard guard(desc->device);
-    if (guard.err != hipSuccess) return bail(fail(QDAS_EHIP, "hipSetDevice(%d): %s", desc->device, hipGetErrorString(guard.err)));
-    { hipError_t e = hipGetDevice(&pl->device); if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipGetDevice: %s", hipGetErrorString(e))); }
-
-    if (pl->I == 0 || z.N == 0 || z.M == 0) { *out = pl; return QDAS_OK; }   // empty problem: execute() just zero-fills
-
-    // ---- stride tables (host pointer, reference kern/das_spec.m:257-260)
+// stride tables (host pointer, reference kern/das_spec.m:257-260) + device copies of the constant inputs -> the generic kernel's parameter block
+static int plan_import_inputs(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
+    const qdas_sizes &z = pl->d.sz;
+    const int dt = z.dtype;
     GenericParams &g = pl->gp;
+    int rc;
     memcpy(g.cst, desc->acstride, sizeof g.cst);
     memset(g.ast, 0, sizeof g.ast);
     memcpy(g.ast, desc->acstride + 6, sizeof(uint64_t) * 6 * z.S);
-
-    // ---- device copies of the constant inputs
     const size_t rs = real_size(dt);
     uint64_t apod_elems = 0;
     for (uint64_t s = 0; s < z.S; ++s) {
         const uint64_t end = g.ast[6 * s + 5] + bcast_numel(&g.ast[6 * s], z);
         if (end > apod_elems) apod_elems = end;
     }
-    const size_t ael = desc->apod_real ? apod_real_size(dt) : data_size(dt);
+    b.ael = desc->apod_real ? apod_real_size(dt) : data_size(dt);
     const uint64_t cinv_elems = bcast_numel(g.cst, z);
-    if ((rc = import_array(pl, desc->Pi, 3 * pl->I * rs, desc->mem, &g.Pi))) return bail(rc);
-    if ((rc = import_array(pl, desc->Pr, 3 * z.N * rs, desc->mem, &g.Pr))) return bail(rc);
-    if ((rc = import_array(pl, desc->Pv, 4 * z.M * rs, desc->mem, &g.Pv))) return bail(rc);
-    if ((rc = import_array(pl, desc->Nv, 3 * z.M * rs, desc->mem, &g.Nv))) return bail(rc);
-    if ((rc = import_array(pl, desc->cinv, cinv_elems * rs, desc->mem, &g.cinv))) return bail(rc);
-    if ((rc = import_array(pl, desc->apod, apod_elems * ael, desc->mem, &g.apod))) return bail(rc);
+    if ((rc = import_array(pl, desc->Pi, 3 * pl->I * rs, desc->mem, &g.Pi))) return rc;
+    if ((rc = import_array(pl, desc->Pr, 3 * z.N * rs, desc->mem, &g.Pr))) return rc;
+    if ((rc = import_array(pl, desc->Pv, 4 * z.M * rs, desc->mem, &g.Pv))) return rc;
+    if ((rc = import_array(pl, desc->Nv, 3 * z.M * rs, desc->mem, &g.Nv))) return rc;
+    if ((rc = import_array(pl, desc->cinv, cinv_elems * rs, desc->mem, &g.cinv))) return rc;
+    if ((rc = import_array(pl, desc->apod, apod_elems * b.ael, desc->mem, &g.apod))) return rc;
     g.T = z.T; g.N = z.N; g.M = z.M; g.I1 = z.I1; g.I2 = z.I2; g.I3 = z.I3;
     g.i_begin = desc->i_begin; g.i_count = pl->i_count; g.y_ld = pl->y_ld;
     // the reference passes [fs, fmod] in the kernel's real type (src/bf.cu:57-58)
@@ -483,654 +503,513 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     g.fmod = dt == QDAS_F64 ? desc->fmod : (double)(float)desc->fmod;
     g.S = (int32_t)z.S; g.flag = z.flag; g.VS = z.VS; g.DV = z.DV; g.apod_real = desc->apod_real;
     g.gen_kind = desc->rx_apod_kind; g.gen_p0 = desc->rx_apod_p[0]; g.gen_p1 = desc->rx_apod_p[1]; g.rxn = nullptr;
-    if (g.gen_kind && desc->rx_normals && (rc = import_array(pl, desc->rx_normals, 3 * z.N * rs, desc->mem, &g.rxn))) return bail(rc);
+    if (g.gen_kind && desc->rx_normals && (rc = import_array(pl, desc->rx_normals, 3 * z.N * rs, desc->mem, &g.rxn))) return rc;
     g.tile_list = nullptr; g.blocks_per_tile = 0; g.tile_cols = 0; g.tiles_z = 0;
-    if (dt == QDAS_F64) { if ((rc = fetch_host(desc->cinv, sizeof(double), desc->mem, &pl->cinv0))) return bail(rc); }
-    else { float c32; if ((rc = fetch_host(desc->cinv, sizeof(float), desc->mem, &c32))) return bail(rc); pl->cinv0 = (double)c32; }
+    if (dt == QDAS_F64) { if ((rc = fetch_host(desc->cinv, sizeof(double), desc->mem, &pl->cinv0))) return rc; }
+    else { float c32; if ((rc = fetch_host(desc->cinv, sizeof(float), desc->mem, &c32))) return rc; pl->cinv0 = (double)c32; }
+    return QDAS_OK;
+}
 
-    // ---- kernel selection
-    // modes: 'DAS' (sum both apertures), and with fp32 data 'SYN' (keep the receive dimension: a plane per receiver)
-    // and 'MUL' (keep the transmit dimension: the same kernel with the roles of the two apertures swapped)
-    const bool mul = (z.flag & QDAS_FLAG_KEEP_TX) && !(z.flag & QDAS_FLAG_KEEP_RX);
-    const bool syn = ((z.flag & QDAS_FLAG_KEEP_RX) && !(z.flag & QDAS_FLAG_KEEP_TX)) || mul;      // one output plane per STAGE element
-    // 'BF' (both dimensions kept, fp32 data): the same stage loop, every pair's weighted sample stored to its own plane
-    const bool bfm = (z.flag & QDAS_FLAG_KEEP_TX) && (z.flag & QDAS_FLAG_KEEP_RX);
-    bool eligible = (!syn && !bfm) || dt == QDAS_F32;
-    const char *why = "tiled kernel needs the 'DAS' mode (or fp32 data and 'SYN' / 'MUL' / 'BF')";
-    // fp64 data (das_tile_impl.h "F64"): the plain sum with pixel-independent weights, scalar sound speed, no remodulation
-    if (eligible && dt == QDAS_F64 && desc->rx_apod_kind) { eligible = false; why = "tiled kernel, fp64 data: a generated receive apodization needs the generic kernel"; }
-    // sound speed: a scalar, or a full per-pixel map (contiguous I1 x I2 x I3, no aperture dependence): the delay stays separable
-    bool cmap = false;
-    if (eligible && (g.cst[0] || g.cst[1] || g.cst[2] || g.cst[3] || g.cst[4])) {
-        cmap = !g.cst[3] && !g.cst[4] && (g.cst[0] == 1 || z.I1 == 1) && (g.cst[1] == z.I1 || z.I2 == 1) && (g.cst[2] == z.I1 * z.I2 || z.I3 == 1);
-        if (!cmap) { eligible = false; why = "tiled kernel needs a scalar sound speed or a full per-pixel map without aperture dependence"; }
-        else if (dt == QDAS_F64) { eligible = false; why = "tiled kernel, fp64 data: a sound-speed map needs the generic kernel"; }
-    }
-    // apodization arrays: pixel-independent ones fold into an N x M table; ONE array may be a full I1 x I2 x I3 x [N] array
-    // (contiguous pixel strides, no transmit dependence) -- it is applied per (pixel, receiver) by the tiled kernel
-    // A full I1 x I2 x I3 x 1 x M array -- a weight per (pixel, TRANSMIT): scanline / multiline / parallelogram transmit apodization of
-    // focused sequences -- is the same thing with the roles of the apertures swapped (stage element = transmit): 'DAS' only.
-    // Several pixel-dependent arrays of ONE family -- receive side (I x N, I), transmit side (I x M, I) -- and arrays that broadcast over some
-    // pixel dimension (a weight per depth and receiver: I1 x 1 x 1 x N) are multiplied into one plan-owned I x [N | M] array (apod_fold_kernel).
-    // A receive-side and a transmit-side pixel array together, or an I x N x M array: generic kernel.
-    int pix_arr = -1;                               // first pixel-dependent array (-1: none)
-    bool pix_is_tx = false, pix_only = false, pix_fold = false, bpix_mode = false;
-    bool is_pix[QDAS_MAX_APOD] = {};
-    uint64_t npix = 0;
-    {
-        const uint64_t I = z.I1 * z.I2 * z.I3;
-        bool dep_rx = false, dep_tx = false, direct = true;
-        for (uint64_t s = 0; s < z.S && eligible; ++s) {
-            const uint64_t *a = &g.ast[6 * s];
-            if (!a[0] && !a[1] && !a[2]) continue;
-            const bool dn = a[3] && z.N > 1, dm = a[4] && z.M > 1;
-            if (dn && dm) { eligible = false; why = "tiled kernel: an apodization array over pixels x receivers x transmits needs the generic kernel"; break; }
-            const bool pixstr = (a[0] == 1 || z.I1 == 1) && (a[1] == z.I1 || z.I2 == 1) && (a[2] == z.I1 * z.I2 || z.I3 == 1);
-            if (!pixstr || (dn && a[3] != I) || (dm && a[4] != I)) direct = false;
-            is_pix[s] = true; ++npix; dep_rx |= dn; dep_tx |= dm;
-            if (pix_arr < 0) pix_arr = (int)s;
-        }
-        if (eligible && npix) {
-            if (dep_rx && dep_tx) {
-                // a transmit-side rule AND a receive-side mask (multiline x acceptance angle): the transmit is the stage element with its weight, the
-                // receive-side product is a second weight per (pixel, block element) applied per pair -- launch configuration 14 (das_tile_impl.h BPIX):
-                // fp32 data, real weights, plain 'DAS', no remodulation; pixel-independent arrays must belong to one aperture (they join that side's product)
-                bool ok = dt == QDAS_F32 && desc->apod_real && !syn && !bfm && desc->fmod == 0.0 && I < (1ull << 30) && !getenv("QDAS_NO_BPIX");
-                for (uint64_t s = 0; s < z.S && ok; ++s) {
-                    const uint64_t *a = &g.ast[6 * s];
-                    if (!is_pix[s] && a[3] && z.N > 1 && a[4] && z.M > 1) ok = false;
-                }
-                if (ok) { bpix_mode = true; pix_is_tx = true; for (uint64_t s = 0; s < z.S; ++s) is_pix[s] = true; npix = z.S; }
-                else { eligible = false; why = "tiled kernel: pixel x receiver and pixel x transmit apodization arrays together run fused for fp32 data, real weights, 'DAS', no remodulation, no N x M array only"; }
-            }
-            else if (dt == QDAS_F64 && !(npix == 1 && direct && !dep_tx && desc->fmod == 0.0 && !syn && !bfm && !mul && !getenv("QDAS_NO_W64"))) {
-                // fp64 data: ONE pixel x receiver (or pixel-only) array, used in place, plain 'DAS', no remodulation (das_tile_impl.h TileCfg::W64)
-                eligible = false; why = "tiled kernel, fp64 data: only a single pixel x receiver / pixel-only apodization array without remodulation runs fused";
-            }
-            else if (dep_tx) {
-                if ((!syn || mul) && !bfm) pix_is_tx = true;           // ('MUL': the transmit is the stage element anyway)
-                else { eligible = false; why = "tiled kernel: a pixel x transmit apodization array with 'SYN' / 'BF' needs the generic kernel"; }
-            } else if (!dep_rx && z.N > 1) {
-                if (!bfm && !mul) pix_only = true;                     // a spatial weight / ROI mask
-                else { eligible = false; why = "tiled kernel: a pixel-only apodization array needs the generic kernel"; }
-            }
-            pix_fold = eligible && (npix > 1 || !direct || bpix_mode);
+// FACT (plan_modes.h Facts::recip_*): do the transmit elements equal the receive elements, with one start time?  Host comparison of the fp32 geometry.
+static int gather_recip_facts(const qdas_desc *desc, modes::Facts *f) {
+    const qdas_sizes &z = desc->sz;
+    std::vector<float> hr(3 * z.N), hv(4 * z.M);
+    int rc;
+    if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return rc;
+    if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return rc;
+    f->recip_known = true; f->recip_one_t0 = true; f->recip_exact = true; f->recip_finite = true; f->recip_dev = 0.0;
+    for (uint64_t m = 0; m < z.M; ++m) {
+        if (memcmp(&hv[4 * m + 3], &hv[3], 4) != 0) { f->recip_one_t0 = false; break; }                 // one start time: exact in both modes
+        if (memcmp(&hv[4 * m], &hr[3 * m], 12) != 0) {
+            f->recip_exact = false;
+            const double dx = (double)hv[4 * m] - hr[3 * m], dy = (double)hv[4 * m + 1] - hr[3 * m + 1], dz = (double)hv[4 * m + 2] - hr[3 * m + 2];
+            const double dd = sqrt(dx * dx + dy * dy + dz * dz);      // tolerance mode: the largest distance between a transmit element and "its" receive element
+            if (!(dd == dd)) f->recip_finite = false; else f->recip_dev = std::max(f->recip_dev, dd);
         }
     }
-    if (eligible && g.gen_kind && pix_arr >= 0) {
-        eligible = false; why = "tiled kernel: a generated receive apodization and a pixel-dependent array need the generic kernel";
-    }
-    if (eligible && bfm && (pix_arr >= 0 || g.gen_kind)) {
-        eligible = false; why = "tiled kernel: 'BF' with a pixel x receiver apodization needs the generic kernel";
-    }
-    if (eligible && mul && ((pix_arr >= 0 && !pix_is_tx) || g.gen_kind)) {
-        eligible = false; why = "tiled kernel: 'MUL' with a pixel x receiver apodization needs the generic kernel";
-    }
-    // reciprocal mode (das_tile_impl.h "SYM"): a full-synthetic-aperture acquisition whose transmit elements are the receive
-    // elements and share one t0 has tau(n,m) == tau(m,n); detected from the geometry itself, bit-exactly.
-    // RECIPROCITY FOLD (fold.hip, das_tile_impl.h TileCfg::FOLD; fp32 data): interpolation is linear in the data, so the two traces of an unordered
-    // pair are ADDED once per frame -- one streaming pass over HBM, pixel-independent weights applied on the way -- and the fused kernel walks the
-    // upper triangle of the folded frame: half the staging, gathers and multiply-accumulates.  QDAS_PLAN_NO_FOLD / QDAS_NO_FOLD=1: the reciprocal
-    // mode as it was (both traces gathered, tap index and weights shared).
-    int sym = 0, big = 0, rfold = 0;
-    // tolerance mode of the symmetry tests (QDAS_PLAN_APPROX_SYMMETRY; bound in SAMPLES, default 1e-5, QDAS_SYM_TOL overrides): < 0 = exact only
-    double sym_tol = -1.0, recip_bound = 0.0, mirror_bound = 0.0;
-    if ((desc->plan_flags & QDAS_PLAN_APPROX_SYMMETRY) && !cmap) {
-        sym_tol = 1.0e-5;
-        if (const char *e = getenv("QDAS_SYM_TOL")) { const double v = atof(e); if (v >= 0.0 && v <= 0.5) sym_tol = v; }
-    }
-    if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && z.VS && z.DV && z.N == z.M && pix_arr < 0 && !g.gen_kind && !(desc->plan_flags & QDAS_PLAN_NO_RECIPROCAL) && !getenv("QDAS_NO_SYM")) {
-        std::vector<float> hr(3 * z.N), hv(4 * z.M);
-        if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
-        if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);
-        sym = 1;
-        double drv = 0.0;                              // tolerance mode: the largest distance between a transmit element and "its" receive element
-        for (uint64_t m = 0; m < z.M && sym; ++m) {
-            if (memcmp(&hv[4 * m + 3], &hv[3], 4) != 0) sym = 0;                 // one start time: exact in both modes
-            else if (memcmp(&hv[4 * m], &hr[3 * m], 12) != 0) {
-                if (sym_tol < 0) sym = 0;
-                else {
-                    const double dx = (double)hv[4 * m] - hr[3 * m], dy = (double)hv[4 * m + 1] - hr[3 * m + 1], dz = (double)hv[4 * m + 2] - hr[3 * m + 2];
-                    const double dd = sqrt(dx * dx + dy * dy + dz * dz);
-                    if (!(dd == dd)) sym = 0; else drv = std::max(drv, dd);
-                }
-            }
-        }
-        // |tau(n,m) - tau(m,n)| fs <= cinv fs (|r_n - v_n| + |r_m - v_m|) <= 2 cinv fs max|r - v|
-        recip_bound = 2.0 * pl->cinv0 * desc->fs * drv;
-        if (sym && !(recip_bound <= (sym_tol < 0 ? 0.0 : sym_tol))) sym = 0;
-        const bool prefolded = (desc->plan_flags & QDAS_PLAN_PREFOLDED) != 0;
-        rfold = sym && dt == QDAS_F32 && z.N >= 2 && z.N <= 65535 && ((!(desc->plan_flags & QDAS_PLAN_NO_FOLD) && !getenv("QDAS_NO_FOLD")) || prefolded)
-               && tile_lds_bytes(dt, 1, z.N, z.M, 0, 0, 0, 0, 1) <= tile_lds_limit(1);
-        pl->prefolded = prefolded && rfold;
-        if (rfold && !prefolded) {                                    // the plan's folded copy of a frame: without the memory for it, the plan simply does not fold
+    return QDAS_OK;
+}
+
+// steps 1 + 2 of plan_modes.h: the request, then the symmetry modes -- gathering each fact the resolver asks for
+static int plan_resolve_modes(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
+    const qdas_sizes &z = pl->d.sz;
+    b.rq = modes::analyze_request(*desc, b.sw);
+    modes::Facts f;
+    f.cinv0 = pl->cinv0;
+    int rc;
+    for (;;) {
+        const int need = modes::resolve_symmetry(*desc, pl->i_count, b.rq, f, b.sw, &b.sy);
+        if (need == modes::NEED_NOTHING) break;
+        if (need == modes::NEED_RECIP) { if ((rc = gather_recip_facts(desc, &f))) return rc; }
+        else if (need == modes::NEED_FOLD_BUF) {          // the plan's folded copy of a frame: without the memory for it, the plan simply does not fold
             void *fbuf = nullptr;
-            if (hipMalloc(&fbuf, (size_t)z.T * z.N * z.M * 8) != hipSuccess) { (void)hipGetLastError(); rfold = 0; }
-            else { pl->owned.push_back(fbuf); pl->fold_buf = fbuf; }
-        }
-        if (sym && !rfold && (z.M % tile_config(dt, 1).mb != 0 || tile_lds_bytes(dt, 1, z.N, z.M) > tile_lds_limit(1))) sym = 0;
-        // fp32 data without the fold (QDAS_PLAN_NO_FOLD): that reciprocal mode exists as a plan-specialised (hiprtc) build only -- its prebuilt
-        // instantiations were pruned in round 4 --; without QDAS_PLAN_JIT such a plan runs the general kernels
-        if (sym && !rfold && dt == QDAS_F32 && !((desc->plan_flags & QDAS_PLAN_JIT) && !getenv("QDAS_NO_JIT"))) sym = 0;
-    }
-    if ((desc->plan_flags & QDAS_PLAN_PREFOLDED) && z.S > 0)      // (a prefolded plan runs no fold pass: nothing would apply the table -- include/qdas.h QDAS_PLAN_PREFOLDED)
-        return bail(fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_PREFOLDED: apodization arrays belong to the fold (qdas_fold_desc.wtab), not to the plan that is handed folded frames"));
-    if ((desc->plan_flags & QDAS_PLAN_PREFOLDED) && !rfold)
-        return bail(fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_PREFOLDED: a folded frame can only be beamformed by a reciprocal fp32 'DAS' plan without apodization arrays "
-                                            "(transmit elements == receive elements bit for bit, one t0, N == M >= 2; weights belong to qdas_fold)"));
-    // Roles of the two apertures (das_tile_impl.h): a stage = one STAGE element x a block of 32 BLOCK elements.  'DAS' / 'SYN': stage =
-    // receiver, block = transmits; 'MUL': swapped.  The full sum may run either way, and runs swapped when that gives fewer, fuller
-    // stages: plane-wave compounding with a handful of angles (N = 128, M = 9: 128 stages of 9 transmits -> 36 stages of 32 receivers).
-    bool swap = mul || pix_is_tx;
-    if (eligible && !syn && !bfm && !sym && dt != QDAS_F64 && pix_arr < 0 && !g.gen_kind && !getenv("QDAS_NO_ROLE_SWAP")) {
-        const uint64_t mb = (uint64_t)tile_config(dt, 0).mb;
-        if (4 * z.M * ((z.N + mb - 1) / mb) < 3 * z.N * ((z.M + mb - 1) / mb)) swap = true;     // (at least a quarter fewer stages: measured break-even, PW31 on 128 elements)
-    }
-    // Lateral-mirror mode (tile_params.h `mir`): a scan, an array and a sequence that are mirror-symmetric about x = 0 -- the usual case: a
-    // centred sector or rectangle under a linear / convex array, plane waves or virtual sources at +- the same angles / positions -- have
-    // tau(pixel', N-1-n, M-1-m) == tau(pixel, n, m) bit for bit: tap index and interpolation weights serve a pixel and its mirror image.
-    // Detected from the geometry itself; the whole image in one plan, plain 'DAS', scalar sound speed, no apodization (yet).
-    // A reciprocal plan (FSA) that is also mirror-symmetric runs FOUR window sets per stage (launch configurations 15 / 16, TileCfg::MIRQ):
-    // {x[:,n,m], x[:,m,n]} for a pixel and {x[:,N-1-n,N-1-m], x[:,N-1-m,N-1-n]} for its mirror image share one tap index and one set of
-    // weights; that kernel addresses the frame with one descriptor: frames below 2 GiB.
-    // fp16 data: a pixel x receiver weight rides along -- an I x N array (the image of a pixel has its OWN entry, at the mirrored receiver: the
-    // array need not be symmetric), a pixel-only array, or a generated rule (element normals mirror-symmetric as well: the same value)
-    bool mir = false;
-    const bool mslab = (desc->plan_flags & QDAS_PLAN_MIRROR_SLAB) != 0;       // slab A + its mirror image (validated above)
-    const bool mir_plain = z.S == 0 && !g.gen_kind;
-    // pixel-independent weights only (folded into an N x M table): fine when the TABLE is mirror-symmetric, w[n,m] == w[N-1-n,M-1-m] -- receive and
-    // transmit windows are --; checked once the table is folded (below).
-    const bool mir_tab = z.S > 0 && npix == 0 && !g.gen_kind && dt != QDAS_F64;
-    // fp32 data: the two-window-set instantiation has the registers for the weight bookkeeping only as a plan-specialised (hiprtc) build --
-    // taken when the plan asks for one; if that build fails the plan is re-made without the mirror mode (below)
-    const bool jit_asked = (desc->plan_flags & QDAS_PLAN_JIT) && !getenv("QDAS_NO_JIT") && !getenv("QDAS_NO_MIRROR_WPIX32");
-    const bool mir_wpix = (dt == QDAS_F16 || (dt == QDAS_F32 && jit_asked)) && !sym && !swap && !bpix_mode && z.S == npix
-                          && ((pix_arr >= 0 && !pix_is_tx && !g.gen_kind) || (pix_arr < 0 && g.gen_kind >= 1 && g.gen_kind <= 4)) && !getenv("QDAS_NO_MIRROR_WPIX");
-    if (eligible && !syn && !bfm && (dt == QDAS_F32 || dt == QDAS_F16) && (mir_plain || mir_wpix || mir_tab) && !cmap && z.I3 == 1 && z.I2 >= 2
-        && z.N >= 2 && ((desc->i_begin == 0 && pl->i_count == pl->I) || mslab) && !(desc->plan_flags & QDAS_PLAN_NO_MIRROR) && !getenv("QDAS_NO_MIRROR")
-        && (!sym || ((uint64_t)z.T * z.N * z.M * data_size(dt) + 65536 < (1ull << 31) && (rfold || z.M % 16 == 0) && !getenv("QDAS_NO_MIRQ")
-                     && tile_lds_bytes(dt, 1, z.N, z.M, 1, 0, (z.S > 0 && !rfold) ? 1 : 0, 1, rfold) <= tile_lds_limit(1)))) {
-        if ((rc = mirror_symmetric(desc, (const float *)g.Pi, &mir, sym_tol, pl->cinv0 * desc->fs, &mirror_bound))) return bail(rc);
-    }
-    // stage / block element counts of the kernel: receivers / transmits, or swapped
-    const uint64_t kN = swap ? z.M : z.N, kM = swap ? z.N : z.M;
-    pl->tc = tile_config(dt, sym, 0, mir ? 2 : 1, 0, rfold);
-    const int pixw = (pix_arr >= 0 || g.gen_kind) ? 1 : 0;      // a pixel x receiver weight: the tile keeps a stage list (das_tile_impl.h plan_stages)
-    const int wtb = (z.S > npix && !rfold) ? 1 : 0;      // pixel-independent arrays: folded into an N x M table, staged per stage in LDS (folded data: applied by the fold pass)
-    if (eligible && tile_lds_bytes(dt, sym, kN, kM, 0, pixw, wtb) > tile_lds_limit(sym)) {
-        eligible = false; why = "tiled kernel: N + M too large for the LDS header";
-    }
-    if (eligible && (z.T < 8)) { eligible = false; why = "tiled kernel needs T >= 8"; }
-    // (a lane keeps its pixel's offset in the plan's slab in 32 bits, 0xffffffff = "not mine": das_tile_impl.h Tile::pofs)
-    if (eligible && pl->i_count >= 0xffffffffull) { eligible = false; why = "tiled kernel: more than 2^32 - 2 pixels in one plan (shard the image)"; }
-    {   // LDS-DMA offsets are 32-bit and signed: inside one transmit block, N receivers + mb transmits + a window must stay below
-        // 2^31 bytes.  The reciprocal kernel re-bases its descriptors whenever a running offset reaches 2^30 (its mirror traces
-        // walk the whole frame), so there only one trace stride and the span of a block have to stay below 2^30.
-        uint64_t strM = (z.flag & QDAS_FLAG_TPOSE) ? z.T : z.T * z.N;
-        uint64_t strN = (z.flag & QDAS_FLAG_TPOSE) ? z.T * z.M : z.T;
-        if (swap) std::swap(strM, strN);
-        const uint64_t slack = 65536;
-        const uint64_t smax = strM > strN ? strM : strN;
-        if (sym && (uint64_t)(tile_config(dt, 1, 0, 1, 0, rfold).mb + 1) * smax * data_size(dt) + slack >= (1ull << 30)) {
-            sym = 0; rfold = 0;
-            pl->tc = tile_config(dt, 0, 0, mir ? 2 : 1);     // (a mirror-symmetric plan keeps the two-window-set configuration of the general mode)
-            if (eligible && tile_lds_bytes(dt, 0, z.N, z.M, 0, pixw, wtb) > tile_lds_limit(0)) { eligible = false; why = "tiled kernel: N + M too large for the LDS header"; }
-        }
-        if (eligible && !sym && (kN * strN + (uint64_t)pl->tc.mb * strM) * data_size(dt) + slack >= (1ull << 31)) {
-            // fp32, one frame per launch: the re-basing instantiation of the general kernel (launch configuration 9)
-            // (the re-basing instantiation is a plain general-mode kernel: no lateral-mirror mode there -- the mirrored window set's offsets are
-            //  32-bit offsets of the same magnitude; launch_tile rejects mir && big)
-            if (dt == QDAS_F32 && !bfm && ((uint64_t)tile_config(dt, 0).mb * strM + strN) * data_size(dt) + slack < (1ull << 30)) { big = 1; mir = false; pl->tc = tile_config(dt, 0); }
-            else { eligible = false; why = "tiled kernel: trace strides too large for 32-bit DMA offsets (transposed data of more than 2 GiB)"; }
+            f.fold_buf_known = true;
+            if (hipMalloc(&fbuf, (size_t)z.T * z.N * z.M * 8) != hipSuccess) { (void)hipGetLastError(); f.fold_buf_ok = false; }
+            else { pl->owned.push_back(fbuf); pl->fold_buf = fbuf; f.fold_buf_ok = true; }
+        } else if (need == modes::NEED_MIRROR) {
+            bool yes = false;
+            double bound = 0.0;
+            if ((rc = mirror_symmetric(desc, (const float *)pl->gp.Pi, &yes, b.sy.sym_tol, pl->cinv0 * desc->fs, &bound))) return rc;
+            f.mirror_known = true; f.mirror_yes = yes; f.mirror_bound = bound;
         }
     }
-    if (desc->kernel == QDAS_KERNEL_TILED && !eligible) return bail(fail(QDAS_EUNSUPPORTED, "%s", why));
-    pl->kernel = (eligible && desc->kernel != QDAS_KERNEL_GENERIC) ? QDAS_KERNEL_TILED : QDAS_KERNEL_GENERIC;
+    if (b.sy.prefolded_refused)
+        return fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_PREFOLDED: a folded frame can only be beamformed by a reciprocal fp32 'DAS' plan without apodization arrays "
+                                       "(transmit elements == receive elements bit for bit, one t0, N == M >= 2; weights belong to qdas_fold)");
+    pl->prefolded = b.sy.prefolded;
+    pl->tc = b.sy.tc();
+    if (desc->kernel == QDAS_KERNEL_TILED && !b.sy.eligible) return fail(QDAS_EUNSUPPORTED, "%s", b.sy.why);
+    pl->kernel = (b.sy.eligible && desc->kernel != QDAS_KERNEL_GENERIC) ? QDAS_KERNEL_TILED : QDAS_KERNEL_GENERIC;
+    return QDAS_OK;
+}
 
-    if (pl->kernel == QDAS_KERNEL_TILED) {
-        TileParams &t = pl->tp;
-        t.Pi = (const float *)g.Pi; t.Pr = (const float *)g.Pr; t.Pv = (const float *)g.Pv; t.Nv = (const float *)g.Nv; t.St = nullptr;
-        t.T = z.T; t.N = z.N; t.M = z.M; t.I1 = z.I1; t.I2 = z.I2; t.I3 = z.I3;
-        t.i_begin = desc->i_begin; t.i_count = pl->i_count;
-        const bool tp = z.flag & QDAS_FLAG_TPOSE;
-        t.strN = tp ? z.T * z.M : z.T;                  // reference src/bf.cu:100
-        t.strM = tp ? z.T : z.T * z.N;
-        const int txkind = z.VS ? (z.DV ? 0 : 1) : 2;   // distance | signed distance | plane wave
-        t.kindB = txkind; t.kindS = 0;
-        if (swap) {                                     // roles swapped: stage elements = transmits, block elements = receivers
-            std::vector<float> hr(3 * z.N), hv(4 * z.M), hn(3 * z.M);
-            if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
-            if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);
-            if ((rc = fetch_host(desc->Nv, hn.size() * 4, desc->mem, hn.data()))) return bail(rc);
-            std::vector<float> spos(3 * z.M), sst(4 * z.M), bpos(4 * z.N), bnrm(3 * z.N, 0.f);
-            for (uint64_t m = 0; m < z.M; ++m) {
-                for (int k = 0; k < 3; ++k) { spos[3 * m + k] = hv[4 * m + k]; sst[4 * m + 1 + k] = hn[3 * m + k]; }
-                sst[4 * m] = hv[4 * m + 3];
-            }
-            for (uint64_t n = 0; n < z.N; ++n) { for (int k = 0; k < 3; ++k) bpos[4 * n + k] = hr[3 * n + k]; bpos[4 * n + 3] = 0.f; }
-            const void *d0, *d1, *d2, *d3;
-            if ((rc = import_array(pl, spos.data(), spos.size() * 4, QDAS_MEM_HOST, &d0))) return bail(rc);
-            if ((rc = import_array(pl, sst.data(), sst.size() * 4, QDAS_MEM_HOST, &d1))) return bail(rc);
-            if ((rc = import_array(pl, bpos.data(), bpos.size() * 4, QDAS_MEM_HOST, &d2))) return bail(rc);
-            if ((rc = import_array(pl, bnrm.data(), bnrm.size() * 4, QDAS_MEM_HOST, &d3))) return bail(rc);
-            t.Pr = (const float *)d0; t.St = (const float *)d1; t.Pv = (const float *)d2; t.Nv = (const float *)d3;
-            t.N = z.M; t.M = z.N;
-            std::swap(t.strN, t.strM);
-            t.kindB = 0; t.kindS = txkind;
-        }
-        const double cinv0 = pl->cinv0;
-        t.fs = g.fs; t.fmod = g.fmod;
-        t.cinv_fs = cinv0 * g.fs;
-        t.cinv_pix = cmap ? (const float *)g.cinv + g.cst[5] : nullptr;
-        t.flag = z.flag; t.VS = z.VS; t.DV = z.DV; t.sym = sym; t.big = big; t.fold = rfold;
-        // tile grid: (1 << tz_log2) pixels of I1 x tile_cols columns (columns = I2*I3 flattened); the footprint is chosen below
-        t.mir = mir ? (mslab ? 2 : 1) : 0;
-        auto set_grid = [&](int tzl) {
-            t.tz_log2 = tzl;
-            pl->tile_cols = ((unsigned)pl->tc.waves * 64u) >> tzl;
-            const uint64_t col0 = desc->i_begin / z.I1, col1 = t.mir == 1 ? (z.I2 + 1) / 2 - 1 : (desc->i_begin + pl->i_count - 1) / z.I1;   // (mirror mode: the first half of the columns)
-            t.tiles_z = (uint32_t)((z.I1 + (1u << tzl) - 1) >> tzl);
-            t.tile_x0 = (uint32_t)(col0 / pl->tile_cols);
-            t.tiles_x = (uint32_t)(col1 / pl->tile_cols) - t.tile_x0 + 1;
-            pl->ntiles = t.tiles_z * t.tiles_x;
-        };
-        unsigned max_tiles = 0;
-        for (int l = 3; l <= 6; ++l) { set_grid(l); if (pl->ntiles > max_tiles) max_tiles = pl->ntiles; }
-        void *fb;
-        if ((rc = dev_alloc(pl, &fb, sizeof(uint32_t) * (max_tiles + 1)))) return bail(rc);
-        pl->fallback = (uint32_t *)fb;
-        t.fallback_list = pl->fallback; t.fallback_cap = max_tiles;
-        t.probe = 0; t.wz_log2 = 6; t.ksplit = 1; t.part = nullptr; t.nfr = 1; t.x_fstride = 0; t.y_fstride = 0;
-        t.syn = syn ? 1 : 0; t.y_ld = pl->y_ld;
-        t.bf = bfm ? 1 : 0;
-        t.bf_pn = (z.flag & QDAS_FLAG_TPOSE) ? z.M : 1;      // plane nm = the data's aperture order (src/bf.cu:100,135)
-        t.bf_pm = (z.flag & QDAS_FLAG_TPOSE) ? 1 : z.N;
-        // fold the (pixel-independent) apodization stack into one N x M complex64 table
-        t.wtab = nullptr; t.apix = nullptr; t.apix_real = desc->apod_real;
-        t.gen_kind = g.gen_kind; t.gen_p0 = g.gen_p0; t.gen_p1 = g.gen_p1; t.rxn = (const float *)g.rxn;
-        t.bpix = nullptr;
-        // product of the arrays `take` selects, broadcast to I x E entries (E = M: indexed by the transmit; N: by the receiver; 1: pixel-only)
-        auto fold = [&](int side, auto take, void **out) -> int {
-            ApodFold f;
-            memset(&f, 0, sizeof f);
-            f.base = g.apod; f.I1 = z.I1; f.I2 = z.I2; f.I3 = z.I3;
-            f.E = side == 2 ? 1 : side == 1 ? z.M : z.N;
-            for (uint64_t s = 0; s < z.S; ++s) {
-                if (!take(s)) continue;
-                const uint64_t *a = &g.ast[6 * s];
-                uint64_t *q = f.st[f.ns++];
-                q[0] = a[0]; q[1] = a[1]; q[2] = a[2]; q[3] = side == 2 ? 0 : side == 1 ? (z.M > 1 ? a[4] : 0) : (z.N > 1 ? a[3] : 0); q[4] = a[5];
-            }
-            const uint64_t nel = z.I1 * z.I2 * z.I3 * f.E;
-            void *fb;
-            int frc = dev_alloc(pl, &fb, nel * ael);
-            if (frc) return frc;
-            const unsigned nb = (unsigned)std::min<uint64_t>((nel + 255) / 256, 1u << 20);
-            if (desc->apod_real) {
-                if (dt == QDAS_F32) apod_fold_kernel<float, false><<<nb, 256, 0, 0>>>(f, (float *)fb, nel);
-                else apod_fold_kernel<_Float16, false><<<nb, 256, 0, 0>>>(f, (_Float16 *)fb, nel);
-            } else {
-                if (dt == QDAS_F32) apod_fold_kernel<float, true><<<nb, 256, 0, 0>>>(f, (float *)fb, nel);
-                else apod_fold_kernel<_Float16, true><<<nb, 256, 0, 0>>>(f, (_Float16 *)fb, nel);
-            }
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(0));
-            *out = fb;
-            return QDAS_OK;
-        };
-        if (bpix_mode) {                                // transmit side (+ pixel-only arrays) -> stage weight; receive side -> per-pair weight (real fp32)
-            void *fa_ = nullptr, *fb_ = nullptr;
-            auto on_rx = [&](uint64_t s) { return g.ast[6 * s + 3] != 0 && z.N > 1; };
-            if ((rc = fold(1, [&](uint64_t s) { return !on_rx(s); }, &fa_))) return bail(rc);
-            if ((rc = fold(0, on_rx, &fb_))) return bail(rc);
-            t.apix = (const unsigned char *)fa_; t.bpix = (const float *)fb_;
-        } else if (pix_fold) {
-            void *fb = nullptr;
-            if ((rc = fold(pix_only ? 2 : pix_is_tx ? 1 : 0, [&](uint64_t s) { return is_pix[s]; }, &fb))) return bail(rc);
-            t.apix = (const unsigned char *)fb;
-        } else if (pix_arr >= 0) {
-            t.apix = (const unsigned char *)g.apod + g.ast[6 * pix_arr + 5] * ael;
-        }
-        t.apix_pixel_only = pix_only ? 1 : 0;
-        t.act_bytes = ((t.apix || t.gen_kind) && dt != QDAS_F64) ? (uint32_t)(8 * (t.N + 1)) : 0u;      // (fp64 data: the plain list of stages)
-        std::vector<float> host_tab;                    // the folded N x M table as uploaded ([stage element + stages * block element])
-        if (z.S > npix && dt == QDAS_F64) {             // fp64 data: the same table in double (complex128 entries)
-            std::vector<double> tab(2 * z.N * z.M);
-            for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.0; tab[2 * k + 1] = 0.0; }
-            for (uint64_t s = 0; s < z.S; ++s) {
-                if (is_pix[s]) continue;                 // (the pixel x receiver array is applied per stage: das_tile_impl.h TileCfg::W64)
-                const uint64_t *st = &g.ast[6 * s];
-                const uint64_t nel = bcast_numel(st, z);
-                std::vector<double> raw(nel * (desc->apod_real ? 1 : 2));
-                if ((rc = fetch_host((const unsigned char *)desc->apod + st[5] * ael, nel * ael, desc->mem, raw.data()))) return bail(rc);
-                for (uint64_t m = 0; m < z.M; ++m)
-                    for (uint64_t n = 0; n < z.N; ++n) {
-                        const uint64_t k = n * st[3] + m * st[4];
-                        const double ar = desc->apod_real ? raw[k] : raw[2 * k], ai = desc->apod_real ? 0.0 : raw[2 * k + 1];
-                        double &tr = tab[2 * (n + z.N * m)], &ti = tab[2 * (n + z.N * m) + 1];
-                        const double nr = tr * ar - ti * ai, ni = tr * ai + ti * ar;
-                        tr = nr; ti = ni;
-                    }
-            }
-            void *dtab;
-            if ((rc = dev_alloc(pl, &dtab, tab.size() * sizeof(double)))) return bail(rc);
-            hipError_t e = hipMemcpy(dtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
-            if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e)));
-            t.wtab = dtab;
-        } else if (z.S > npix && dt != QDAS_F64) {
-            std::vector<float> &tab = host_tab;
-            tab.assign(2 * z.N * z.M, 0.f);
-            for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.f; tab[2 * k + 1] = 0.f; }
-            for (uint64_t s = 0; s < z.S; ++s) {
-                if (is_pix[s]) continue;
-                const uint64_t *st = &g.ast[6 * s];
-                const uint64_t nel = bcast_numel(st, z);
-                std::vector<unsigned char> raw(nel * ael);
-                if ((rc = fetch_host((const unsigned char *)desc->apod + st[5] * ael, nel * ael, desc->mem, raw.data()))) return bail(rc);
-                for (uint64_t m = 0; m < z.M; ++m)
-                    for (uint64_t n = 0; n < z.N; ++n) {
-                        const uint64_t k = n * st[3] + m * st[4];
-                        float ar, ai = 0.f;
-                        if (desc->apod_real) ar = dt == QDAS_F32 ? ((const float *)raw.data())[k] : half_to_float(((const uint16_t *)raw.data())[k]);
-                        else if (dt == QDAS_F32) { ar = ((const float *)raw.data())[2 * k]; ai = ((const float *)raw.data())[2 * k + 1]; }
-                        else { ar = half_to_float(((const uint16_t *)raw.data())[2 * k]); ai = half_to_float(((const uint16_t *)raw.data())[2 * k + 1]); }
-                        const size_t q = swap ? (m + z.M * n) : (n + z.N * m);       // [stage element + stages * block element]
-                        float &tr = tab[2 * q], &ti = tab[2 * q + 1];
-                        const float nr = tr * ar - ti * ai, ni = tr * ai + ti * ar;
-                        tr = nr; ti = ni;
-                    }
-            }
-            void *dtab;
-            if ((rc = dev_alloc(pl, &dtab, tab.size() * sizeof(float)))) return bail(rc);
-            hipError_t e = hipMemcpy(dtab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
-            if (e != hipSuccess) return bail(fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e)));
-            t.wtab = dtab;
-        }
-        if (rfold && t.wtab) { pl->fold_wtab = t.wtab; t.wtab = nullptr; }      // (folded data: the fold pass applies the table, trace by trace -- it need not be symmetric in any way)
-        pl->wtab_real = !host_tab.empty();               // every entry of the table real?  (apodization windows usually are: hiprtc builds then accumulate with ONE packed FMA per sample)
-        for (size_t k = 1; k < host_tab.size(); k += 2) if (host_tab[k] != 0.f) { pl->wtab_real = false; break; }
-        if (t.mir && !host_tab.empty() && !rfold) {      // lateral-mirror mode with a weight table: the table itself must be mirror-symmetric
-            bool tsym = true;
-            for (uint64_t m = 0; m < z.M && tsym; ++m)
+// roles swapped: stage elements = transmits (positions + {t0, normal} records), block elements = receivers (zero normals, zero start times)
+static int upload_swapped_geometry(qdas_plan *pl, const qdas_desc *desc, uint64_t E, int shift) {      // E stage elements; element e reads transmit e >> shift
+    const qdas_sizes &z = pl->d.sz;
+    TileParams &t = pl->tp;
+    std::vector<float> hr(3 * z.N), hv(4 * z.M), hn(3 * z.M);
+    int rc;
+    if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return rc;
+    if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return rc;
+    if ((rc = fetch_host(desc->Nv, hn.size() * 4, desc->mem, hn.data()))) return rc;
+    std::vector<float> spos(3 * E), sst(4 * E), bpos(4 * z.N), bnrm(3 * z.N, 0.f);
+    for (uint64_t e = 0; e < E; ++e) {
+        const uint64_t m = e >> shift;
+        for (int k = 0; k < 3; ++k) { spos[3 * e + k] = hv[4 * m + k]; sst[4 * e + 1 + k] = hn[3 * m + k]; }
+        sst[4 * e] = hv[4 * m + 3];
+    }
+    for (uint64_t n = 0; n < z.N; ++n) { for (int k = 0; k < 3; ++k) bpos[4 * n + k] = hr[3 * n + k]; bpos[4 * n + 3] = 0.f; }
+    const void *d0, *d1, *d2, *d3;
+    if ((rc = import_array(pl, spos.data(), spos.size() * 4, QDAS_MEM_HOST, &d0))) return rc;
+    if ((rc = import_array(pl, sst.data(), sst.size() * 4, QDAS_MEM_HOST, &d1))) return rc;
+    if ((rc = import_array(pl, bpos.data(), bpos.size() * 4, QDAS_MEM_HOST, &d2))) return rc;
+    if ((rc = import_array(pl, bnrm.data(), bnrm.size() * 4, QDAS_MEM_HOST, &d3))) return rc;
+    t.Pr = (const float *)d0; t.St = (const float *)d1; t.Pv = (const float *)d2; t.Nv = (const float *)d3;
+    return QDAS_OK;
+}
+
+// tile grid: (1 << tz_log2) pixels of I1 x tile_cols columns (columns = I2*I3 flattened)
+static void plan_set_grid(qdas_plan *pl, int tzl) {
+    TileParams &t = pl->tp;
+    const qdas_sizes &z = pl->d.sz;
+    t.tz_log2 = tzl;
+    pl->tile_cols = ((unsigned)pl->tc.waves * 64u) >> tzl;
+    const uint64_t col0 = pl->d.i_begin / z.I1, col1 = t.mir == 1 ? (z.I2 + 1) / 2 - 1 : (pl->d.i_begin + pl->i_count - 1) / z.I1;   // (mirror mode: the first half of the columns)
+    t.tiles_z = (uint32_t)((z.I1 + (1u << tzl) - 1) >> tzl);
+    t.tile_x0 = (uint32_t)(col0 / pl->tile_cols);
+    t.tiles_x = (uint32_t)(col1 / pl->tile_cols) - t.tile_x0 + 1;
+    pl->ntiles = t.tiles_z * t.tiles_x;
+}
+
+// the tiled kernel's parameter block from the resolved modes (everything except weights and the probed shape)
+static int plan_setup_tile_params(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
+    const qdas_sizes &z = pl->d.sz;
+    const GenericParams &g = pl->gp;
+    TileParams &t = pl->tp;
+    int rc;
+    t.Pi = (const float *)g.Pi; t.Pr = (const float *)g.Pr; t.Pv = (const float *)g.Pv; t.Nv = (const float *)g.Nv; t.St = nullptr;
+    t.T = z.T; t.N = z.N; t.M = z.M; t.I1 = z.I1; t.I2 = z.I2; t.I3 = z.I3;
+    t.i_begin = desc->i_begin; t.i_count = pl->i_count;
+    const bool tp = z.flag & QDAS_FLAG_TPOSE;
+    t.strN = tp ? z.T * z.M : z.T;                  // reference src/bf.cu:100
+    t.strM = tp ? z.T : z.T * z.N;
+    b.txkind = z.VS ? (z.DV ? 0 : 1) : 2;           // distance | signed distance | plane wave
+    t.kindB = b.txkind; t.kindS = 0;
+    if (b.sy.swap) {                                // roles swapped: stage elements = transmits, block elements = receivers
+        if ((rc = upload_swapped_geometry(pl, desc, z.M, 0))) return rc;
+        t.N = z.M; t.M = z.N;
+        std::swap(t.strN, t.strM);
+        t.kindB = 0; t.kindS = b.txkind;
+    }
+    t.fs = g.fs; t.fmod = g.fmod;
+    t.cinv_fs = pl->cinv0 * g.fs;
+    t.cinv_pix = b.rq.cmap ? (const float *)g.cinv + g.cst[5] : nullptr;
+    t.flag = z.flag; t.VS = z.VS; t.DV = z.DV; t.sym = b.sy.sym; t.big = b.sy.big; t.fold = b.sy.rfold;
+    t.mir = b.sy.mir ? (b.sy.mslab ? 2 : 1) : 0;
+    unsigned max_tiles = 0;
+    for (int l = 3; l <= 6; ++l) { plan_set_grid(pl, l); if (pl->ntiles > max_tiles) max_tiles = pl->ntiles; }
+    void *fb;
+    if ((rc = dev_alloc(pl, &fb, sizeof(uint32_t) * (max_tiles + 1)))) return rc;
+    pl->fallback = (uint32_t *)fb;
+    t.fallback_list = pl->fallback; t.fallback_cap = max_tiles;
+    t.probe = 0; t.wz_log2 = 6; t.ksplit = 1; t.part = nullptr; t.nfr = 1; t.x_fstride = 0; t.y_fstride = 0;
+    t.syn = b.rq.syn ? 1 : 0; t.y_ld = pl->y_ld;
+    t.bf = b.rq.bfm ? 1 : 0;
+    t.bf_pn = (z.flag & QDAS_FLAG_TPOSE) ? z.M : 1;      // plane nm = the data's aperture order (src/bf.cu:100,135)
+    t.bf_pm = (z.flag & QDAS_FLAG_TPOSE) ? 1 : z.N;
+    t.wtab = nullptr; t.apix = nullptr; t.apix_real = desc->apod_real;
+    t.gen_kind = g.gen_kind; t.gen_p0 = g.gen_p0; t.gen_p1 = g.gen_p1; t.rxn = (const float *)g.rxn;
+    t.bpix = nullptr;
+    return QDAS_OK;
+}
+
+// product of the arrays `take` selects, broadcast to I x E entries (E = M: indexed by the transmit; N: by the receiver; 1: pixel-only)
+template <class Take>
+static int fold_pixel_arrays(qdas_plan *pl, const qdas_desc *desc, size_t ael, int side, Take take, void **out) {
+    const qdas_sizes &z = pl->d.sz;
+    const GenericParams &g = pl->gp;
+    const int dt = z.dtype;
+    ApodFold f;
+    memset(&f, 0, sizeof f);
+    f.base = g.apod; f.I1 = z.I1; f.I2 = z.I2; f.I3 = z.I3;
+    f.E = side == 2 ? 1 : side == 1 ? z.M : z.N;
+    for (uint64_t s = 0; s < z.S; ++s) {
+        if (!take(s)) continue;
+        const uint64_t *a = &g.ast[6 * s];
+        uint64_t *q = f.st[f.ns++];
+        q[0] = a[0]; q[1] = a[1]; q[2] = a[2]; q[3] = side == 2 ? 0 : side == 1 ? (z.M > 1 ? a[4] : 0) : (z.N > 1 ? a[3] : 0); q[4] = a[5];
+    }
+    const uint64_t nel = z.I1 * z.I2 * z.I3 * f.E;
+    void *fb;
+    int frc = dev_alloc(pl, &fb, nel * ael);
+    if (frc) return frc;
+    const unsigned nb = (unsigned)std::min<uint64_t>((nel + 255) / 256, 1u << 20);
+    if (desc->apod_real) {
+        if (dt == QDAS_F32) apod_fold_kernel<float, false><<<nb, 256, 0, 0>>>(f, (float *)fb, nel);
+        else apod_fold_kernel<_Float16, false><<<nb, 256, 0, 0>>>(f, (_Float16 *)fb, nel);
+    } else {
+        if (dt == QDAS_F32) apod_fold_kernel<float, true><<<nb, 256, 0, 0>>>(f, (float *)fb, nel);
+        else apod_fold_kernel<_Float16, true><<<nb, 256, 0, 0>>>(f, (_Float16 *)fb, nel);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(0));
+    *out = fb;
+    return QDAS_OK;
+}
+
+// the pixel-dependent apodization of the plan: used in place, or multiplied into one plan-owned I x [N | M | 1] array (two with per-pair weights)
+static int plan_pixel_weights(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
+    const qdas_sizes &z = pl->d.sz;
+    const GenericParams &g = pl->gp;
+    TileParams &t = pl->tp;
+    const modes::Request &rq = b.rq;
+    int rc;
+    if (rq.bpix_mode) {                                // transmit side (+ pixel-only arrays) -> stage weight; receive side -> per-pair weight (real fp32)
+        void *fa_ = nullptr, *fb_ = nullptr;
+        auto on_rx = [&](uint64_t s) { return g.ast[6 * s + 3] != 0 && z.N > 1; };
+        if ((rc = fold_pixel_arrays(pl, desc, b.ael, 1, [&](uint64_t s) { return !on_rx(s); }, &fa_))) return rc;
+        if ((rc = fold_pixel_arrays(pl, desc, b.ael, 0, on_rx, &fb_))) return rc;
+        t.apix = (const unsigned char *)fa_; t.bpix = (const float *)fb_;
+    } else if (rq.pix_fold) {
+        void *fb = nullptr;
+        if ((rc = fold_pixel_arrays(pl, desc, b.ael, rq.pix_only ? 2 : rq.pix_is_tx ? 1 : 0, [&](uint64_t s) { return rq.is_pix[s]; }, &fb))) return rc;
+        t.apix = (const unsigned char *)fb;
+    } else if (rq.pix_arr >= 0) {
+        t.apix = (const unsigned char *)g.apod + g.ast[6 * rq.pix_arr + 5] * b.ael;
+    }
+    t.apix_pixel_only = rq.pix_only ? 1 : 0;
+    t.act_bytes = ((t.apix || t.gen_kind) && z.dtype != QDAS_F64) ? (uint32_t)(8 * (t.N + 1)) : 0u;      // (fp64 data: the plain list of stages)
+    return QDAS_OK;
+}
+
+// the pixel-independent apodization arrays folded into one N x M table (complex128 for fp64 data, else complex64; folded plans hand it to the fold pass)
+static int plan_weight_table(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
+    const qdas_sizes &z = pl->d.sz;
+    const GenericParams &g = pl->gp;
+    TileParams &t = pl->tp;
+    const int dt = z.dtype;
+    const size_t ael = b.ael;
+    int rc;
+    if (z.S > b.rq.npix && dt == QDAS_F64) {             // fp64 data: the table in double (complex128 entries)
+        std::vector<double> tab(2 * z.N * z.M);
+        for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.0; tab[2 * k + 1] = 0.0; }
+        for (uint64_t s = 0; s < z.S; ++s) {
+            if (b.rq.is_pix[s]) continue;                 // (the pixel x receiver array is applied per stage: das_tile_impl.h TileCfg::W64)
+            const uint64_t *st = &g.ast[6 * s];
+            const uint64_t nel = bcast_numel(st, z);
+            std::vector<double> raw(nel * (desc->apod_real ? 1 : 2));
+            if ((rc = fetch_host((const unsigned char *)desc->apod + st[5] * ael, nel * ael, desc->mem, raw.data()))) return rc;
+            for (uint64_t m = 0; m < z.M; ++m)
                 for (uint64_t n = 0; n < z.N; ++n) {
-                    const size_t q = swap ? (m + z.M * n) : (n + z.N * m), q2 = swap ? ((z.M - 1 - m) + z.M * (z.N - 1 - n)) : ((z.N - 1 - n) + z.N * (z.M - 1 - m));
-                    if (memcmp(&host_tab[2 * q], &host_tab[2 * q2], 8) != 0) { tsym = false; break; }
+                    const uint64_t k = n * st[3] + m * st[4];
+                    const double ar = desc->apod_real ? raw[k] : raw[2 * k], ai = desc->apod_real ? 0.0 : raw[2 * k + 1];
+                    double &tr = tab[2 * (n + z.N * m)], &ti = tab[2 * (n + z.N * m) + 1];
+                    const double nr = tr * ar - ti * ai, ni = tr * ai + ti * ar;
+                    tr = nr; ti = ni;
                 }
-            if (!tsym) { t.mir = 0; mir = false; pl->tc = tile_config(dt, sym); }      // (reciprocal plans: the narrow configuration is chosen just below)
         }
-        // reciprocal mode: first the 128-sample-window configuration (less staging traffic); it is kept only if some footprint
-        // has no misfit tile at all -- otherwise the 192-sample configuration
-        if (rfold) {
-            // folded data: with the lateral-mirror mode two window sets -- 32 x 128 samples when every tile of some footprint fits them (launch
-            // configuration 17), else 16 x 192 (18) --; when that leaves misfit tiles too (a misfit tile is redone by the generic kernel, which knows
-            // nothing of mirror images) or without the mode: one set of 32 x 192 samples (19), misfit tiles to the generic kernel as ever
-            if (pl->fold_buf) HIPCHK(hipMemset(pl->fold_buf, 0, (size_t)z.T * z.N * z.M * 8));      // (the lower triangle is never written: zeros, not garbage, where a border window reaches into it)
-            if (t.mir) {
-                t.narrow = getenv("QDAS_NO_NARROW") ? 0 : 1;
-                pl->tc = tile_config(dt, 1, t.narrow, 1, 1, 1);
-                if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
-                if (t.narrow && !pl->no_fallback) {
-                    t.narrow = 0;
-                    pl->tc = tile_config(dt, 1, 0, 1, 1, 1);
-                    if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
+        void *dtab;
+        if ((rc = dev_alloc(pl, &dtab, tab.size() * sizeof(double)))) return rc;
+        hipError_t e = hipMemcpy(dtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e));
+        t.wtab = dtab;
+    } else if (z.S > b.rq.npix && dt != QDAS_F64) {
+        std::vector<float> &tab = b.host_tab;
+        tab.assign(2 * z.N * z.M, 0.f);
+        for (size_t k = 0; k < z.N * z.M; ++k) { tab[2 * k] = 1.f; tab[2 * k + 1] = 0.f; }
+        for (uint64_t s = 0; s < z.S; ++s) {
+            if (b.rq.is_pix[s]) continue;
+            const uint64_t *st = &g.ast[6 * s];
+            const uint64_t nel = bcast_numel(st, z);
+            std::vector<unsigned char> raw(nel * ael);
+            if ((rc = fetch_host((const unsigned char *)desc->apod + st[5] * ael, nel * ael, desc->mem, raw.data()))) return rc;
+            for (uint64_t m = 0; m < z.M; ++m)
+                for (uint64_t n = 0; n < z.N; ++n) {
+                    const uint64_t k = n * st[3] + m * st[4];
+                    float ar, ai = 0.f;
+                    if (desc->apod_real) ar = dt == QDAS_F32 ? ((const float *)raw.data())[k] : half_to_float(((const uint16_t *)raw.data())[k]);
+                    else if (dt == QDAS_F32) { ar = ((const float *)raw.data())[2 * k]; ai = ((const float *)raw.data())[2 * k + 1]; }
+                    else { ar = half_to_float(((const uint16_t *)raw.data())[2 * k]); ai = half_to_float(((const uint16_t *)raw.data())[2 * k + 1]); }
+                    const size_t q = b.sy.swap ? (m + z.M * n) : (n + z.N * m);       // [stage element + stages * block element]
+                    float &tr = tab[2 * q], &ti = tab[2 * q + 1];
+                    const float nr = tr * ar - ti * ai, ni = tr * ai + ti * ar;
+                    tr = nr; ti = ni;
                 }
-                if (!pl->no_fallback) { t.mir = 0; mir = false; }
-            }
-            if (!t.mir) {
-                t.narrow = 0;
-                pl->tc = tile_config(dt, 1, 0, 1, 0, 1);
-                if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
-            }
-        } else {
-        // reciprocal mode: first the 128-sample-window configuration (less staging traffic); it is kept only if some footprint
-        // has no misfit tile at all -- otherwise the 192-sample configuration
-        t.narrow = (sym && dt == QDAS_F32 && !getenv("QDAS_NO_NARROW")) ? 1 : 0;
-        if (sym && t.mir && dt == QDAS_F32 && !t.narrow) { t.mir = 0; mir = false; }        // (the four-set configuration has 128-sample windows)
-        if (t.narrow) pl->tc = tile_config(dt, 1, 1, 1, t.mir);
-        else if (sym && t.mir) pl->tc = tile_config(dt, 1, 0, 1, 1);
-        if (bpix_mode) { t.narrow = 2; pl->tc = tile_config(dt, 0, 2); }      // (the configuration that applies a per-pair pixel weight)
-        if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
-        if (t.mir && !pl->no_fallback) {                // (a misfit tile is redone by the generic kernel, which knows nothing of mirror images;
-            t.mir = 0; mir = false;                      //  reciprocal plans: the four-set configuration exists with the narrow windows only)
-            pl->tc = t.narrow == 1 ? tile_config(dt, 1, 1) : tile_config(dt, sym);
-            if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
         }
-        if (t.narrow == 1 && !pl->no_fallback) {
-            t.narrow = 0;
-            pl->tc = tile_config(dt, 1, 0);
-            if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
-        }
-        }
-        // Focused transmits whose focal planes cut through the image: the delay flips sign there (src/bf.cu:106-108), so the tiles a plane
-        // crosses fit no window and would go to the generic kernel -- with a walking aperture that is half the image.  Second attempt:
-        // every transmit listed twice, once per side of its plane (tile_params.h kindS == 3); kept if fewer tiles misfit.
-        uint64_t kN_eff = kN;
-        if (!pl->no_fallback && txkind == 1 && !syn && !bfm && !sym && !big && (pix_arr < 0 || ((pix_is_tx || pix_only) && !(desc->fmod != 0.0 && wtb))) && !g.gen_kind && (dt == QDAS_F32 || dt == QDAS_F16)
-            && z.M < (1u << 15) && tile_lds_bytes(dt, 0, 2 * z.M, z.N, 0, 1, wtb) <= tile_lds_limit(0) && !getenv("QDAS_NO_SIDE_SPLIT")) {
-            const TileParams keep = t;
-            const double keep_frac = pl->misfit_frac;
-            const unsigned keep_ntiles = pl->ntiles, keep_cols = pl->tile_cols;
-            std::vector<float> hr(3 * z.N), hv(4 * z.M), hn(3 * z.M);
-            if ((rc = fetch_host(desc->Pr, hr.size() * 4, desc->mem, hr.data()))) return bail(rc);
-            if ((rc = fetch_host(desc->Pv, hv.size() * 4, desc->mem, hv.data()))) return bail(rc);
-            if ((rc = fetch_host(desc->Nv, hn.size() * 4, desc->mem, hn.data()))) return bail(rc);
-            const uint64_t E = 2 * z.M;                  // stage elements: (transmit, side)
-            std::vector<float> spos(3 * E), sst(4 * E), bpos(4 * z.N), bnrm(3 * z.N, 0.f);
-            for (uint64_t e = 0; e < E; ++e) {
-                const uint64_t m = e >> 1;
-                for (int k = 0; k < 3; ++k) { spos[3 * e + k] = hv[4 * m + k]; sst[4 * e + 1 + k] = hn[3 * m + k]; }
-                sst[4 * e] = hv[4 * m + 3];
-            }
-            for (uint64_t n = 0; n < z.N; ++n) { for (int k = 0; k < 3; ++k) bpos[4 * n + k] = hr[3 * n + k]; bpos[4 * n + 3] = 0.f; }
-            const void *d0, *d1, *d2, *d3;
-            if ((rc = import_array(pl, spos.data(), spos.size() * 4, QDAS_MEM_HOST, &d0))) return bail(rc);
-            if ((rc = import_array(pl, sst.data(), sst.size() * 4, QDAS_MEM_HOST, &d1))) return bail(rc);
-            if ((rc = import_array(pl, bpos.data(), bpos.size() * 4, QDAS_MEM_HOST, &d2))) return bail(rc);
-            if ((rc = import_array(pl, bnrm.data(), bnrm.size() * 4, QDAS_MEM_HOST, &d3))) return bail(rc);
-            t.Pr = (const float *)d0; t.St = (const float *)d1; t.Pv = (const float *)d2; t.Nv = (const float *)d3;
-            t.N = E; t.M = z.N;
-            t.strN = tp ? z.T : z.T * z.N;               // stage element = transmit, block element = receiver
-            t.strM = tp ? z.T * z.M : z.T;
-            t.kindB = 0; t.kindS = 3; t.stage_shift = 1;
-            t.gen_kind = t.apix ? 6 : 5; t.gen_p0 = t.gen_p1 = 0.0; t.rxn = nullptr;      // (6: the side rule times the plan's pixel x transmit / pixel-only array)
-            t.act_bytes = (uint32_t)(8 * (E + 1));
-            if (t.wtab) {                                // the table in the new element order: [(2m + side) + 2M * n]
-                std::vector<float> tab2(2 * E * z.N);
-                for (uint64_t n = 0; n < z.N; ++n)
-                    for (uint64_t e = 0; e < E; ++e) {
-                        const uint64_t m = e >> 1, q = swap ? (m + z.M * n) : (n + z.N * m);
-                        tab2[2 * (e + E * n)] = host_tab[2 * q]; tab2[2 * (e + E * n) + 1] = host_tab[2 * q + 1];
-                    }
-                void *dtab2;
-                if ((rc = dev_alloc(pl, &dtab2, tab2.size() * sizeof(float)))) return bail(rc);
-                hipError_t e2 = hipMemcpy(dtab2, tab2.data(), tab2.size() * sizeof(float), hipMemcpyHostToDevice);
-                if (e2 != hipSuccess) return bail(fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e2)));
-                t.wtab = dtab2;
-            }
-            if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
-            if (pl->misfit_frac < keep_frac) kN_eff = E;
-            else {                                       // no better: the plan as it was
-                t = keep;
-                pl->misfit_frac = keep_frac; pl->no_fallback = keep_frac == 0.0; pl->ntiles = keep_ntiles; pl->tile_cols = keep_cols;
-                HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));
-            }
-        }
-        // Tiles that still do not fit (a pixel grid coarser than about lambda/2 -- volumes, previews --, steep delay gradients): fp32 plans
-        // try the 384-sample windows of launch configuration 14 (16 transmits per stage, same LDS image); kept if fewer tiles misfit.
-        // (a reciprocal plan gives up its mode for them: an image on the generic kernel costs ten times more than the shared index work saves)
-        if (!pl->no_fallback && dt == QDAS_F32 && !bfm && !big && t.narrow != 2 && !getenv("QDAS_NO_WIDE") && !pl->prefolded
-            && tile_lds_bytes(dt, 0, t.N, t.M, 2, t.act_bytes ? 1 : 0, (t.wtab || (t.fold && pl->fold_wtab)) ? 1 : 0) <= tile_lds_limit(0)      // (a folded plan's table comes back into the kernel there)
-            && ((uint64_t)t.N * t.strN + (uint64_t)tile_config(dt, 0, 2).mb * t.strM) * data_size(dt) + 65536 < (1ull << 31)) {
-            const TileParams keep = t;
-            const TileConfig keep_tc = pl->tc;
-            const double keep_frac = pl->misfit_frac;
-            const unsigned keep_ntiles = pl->ntiles, keep_cols = pl->tile_cols;
-            t.narrow = 2; t.sym = 0;
-            if (t.fold) { t.fold = 0; t.wtab = pl->fold_wtab; }      // (the wide-window configuration is a general-mode kernel on the frame as it is)
-            pl->tc = tile_config(dt, 0, 2);
-            if ((rc = choose_tile_shape(pl, desc, set_grid))) return bail(rc);
-            if (!(pl->misfit_frac < keep_frac)) {
-                t = keep; pl->tc = keep_tc;
-                pl->misfit_frac = keep_frac; pl->no_fallback = keep_frac == 0.0; pl->ntiles = keep_ntiles; pl->tile_cols = keep_cols;
-                HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));
-            }
-        }
-        // Too few tiles for the GPU (a pixel slab of a multi-GPU job, a small image): several workgroups per tile, each summing a
-        // slice of the aperture (das_tile_impl.h) until every CU has a workgroup.  QDAS_KSPLIT overrides.
-        {
-            int ncu = 0;
-            HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device));
-            const unsigned cus = ncu > 0 ? (unsigned)ncu : 256u;
-            const uint64_t nmb = (z.M + pl->tc.mb - 1) / pl->tc.mb;
-            const unsigned cap = (unsigned)std::min<uint64_t>(8, t.sym ? nmb : kN_eff);
-            // (a split costs one more prologue per tile.)  Plans with a pixel x stage-element weight: the tiles' stage lists differ in length by
-            // the mask -- BASELINE C5's deep tiles keep every receiver, the shallow ones a few --, so the longest tile sets the kernel time unless
-            // there are many more workgroups than CUs: up to 8 per CU, each taking every ks-th receiver (das_tile_impl.h plan_stages; C5 2.77 -> 2.18 ms)
-            // (as long as a workgroup keeps at least 16 candidate stage elements: a transmit-side rule that leaves two or three stages per tile
-            //  only pays prologues for more workgroups)
-            unsigned ks = 1;
-            while (ks * 2 <= cap && (uint64_t)pl->ntiles * ks < (uint64_t)cus) ks *= 2;
-            if (t.act_bytes && !t.syn)
-                while (ks * 2 <= cap && (uint64_t)pl->ntiles * ks < 8ull * cus && kN_eff / (ks * 2) >= 16) ks *= 2;
-            if (const char *e = getenv("QDAS_KSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8 && (unsigned)v <= cap) ks = (unsigned)v; }
-            t.ksplit = ks;
-            if (ks > 1 && !bfm) {
-                void *pb;
-                if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)ks * 4 * pl->i_count * (t.mir == 2 ? 2 : 1)))) return bail(rc);   // x4: up to four frames per launch (fp64 data: one complex128 frame -- fits as well)
-                t.part = (float2 *)pb;
-            }
-        }
+        void *dtab;
+        if ((rc = dev_alloc(pl, &dtab, tab.size() * sizeof(float)))) return rc;
+        hipError_t e = hipMemcpy(dtab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e));
+        t.wtab = dtab;
     }
+    if (t.fold && t.wtab) { pl->fold_wtab = t.wtab; t.wtab = nullptr; }      // (folded data: the fold pass applies the table, trace by trace -- it need not be symmetric in any way)
+    pl->wtab_real = !b.host_tab.empty();               // every entry of the table real?  (apodization windows usually are: hiprtc builds then accumulate with ONE packed FMA per sample)
+    for (size_t k = 1; k < b.host_tab.size(); k += 2) if (b.host_tab[k] != 0.f) { pl->wtab_real = false; break; }
+    return QDAS_OK;
+}
 
-    if (mslab && !(pl->kernel == QDAS_KERNEL_TILED && pl->tp.mir == 2))
-        return bail(fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_MIRROR_SLAB: the lateral-mirror mode is not available for this problem (geometry not mirror-symmetric "
-                                            "about x = 0, weights / modes it does not take, or tiles that do not fit the staging windows): use plain slabs"));
-    // ---- QDAS_PLAN_JIT: the tiled kernel compiled for this plan's sizes (jit.hip).  A failure is not an error: the plan keeps its
-    //      prebuilt kernel and qdas_last_error() says why.
-    g_err.clear();
-    if ((desc->plan_flags & QDAS_PLAN_JIT) && pl->kernel == QDAS_KERNEL_TILED && !pl->tp.bf && !getenv("QDAS_NO_JIT")) {
-        const TileParams &t = pl->tp;
-        JitSpec k{};
-        k.interp = (z.flag & 7) == 4 ? 1 : (z.flag & 7); k.dtype = dt; k.fmod = t.fmod != 0.0; k.wtab = t.wtab != nullptr; k.sym = t.sym; k.big = t.big;
-        const int narrow = (t.sym && dt == QDAS_F32 && t.narrow) ? 1 : (!t.sym && dt == QDAS_F32 && t.narrow == 2) ? 2 : 0;
-        const int mirq = (t.sym && t.mir) ? 1 : 0;
-        const Cfg &cg = CFGS[cfg_index(dt, t.sym, t.fold ? 1 : (t.mir ? 2 : 1), narrow, mirq, t.fold)];      // (fb = 2 selects the two-window-set configuration of a general-mode mirror plan; folded plans: one frame)
-        k.mir = t.sym ? 0 : t.mir; k.mirq = mirq; k.mslab = t.mir == 2; k.fold = t.fold;
-        k.waves = cg.waves; k.mb = cg.mb; k.w = cg.w; k.nbuf = cg.nbuf;
-        k.N = t.N; k.M = t.M; k.T = t.T; k.I1 = t.I1; k.strN = t.strN; k.strM = t.strM;
-        k.kindB = t.kindB; k.kindS = t.kindS; k.tzl = t.tz_log2; k.wzl = t.wz_log2; k.ksplit = t.ksplit;
-        k.gen_kind = t.gen_kind; k.has_apix = t.apix != nullptr; k.apix_real = t.apix_real; k.syn = t.syn;
-        k.has_st = t.St != nullptr; k.has_cinv_pix = t.cinv_pix != nullptr;
-        k.wreal = (t.wtab && pl->wtab_real && !getenv("QDAS_NO_WREAL")) ? 1 : 0;
-        // tuning: a specialised build may use another number of transmits per stage than the prebuilt configuration (its register
-        // budget is smaller); the LDS image grows with it
-        // reciprocal mode: the specialised kernel has the registers for 32-transmit stages (half the stages, barriers and per-stage
-        // delay evaluations of the prebuilt 16-transmit configuration) whenever the 64 windows of a buffer stay within the 16-bit
-        // immediate offsets of the LDS reads (C3: 30.9 -> 29.2 ms)
-        if (t.sym && !mirq && !t.fold && z.M % 32 == 0 && 2 * 32 * k.w * (dt == QDAS_F16 ? 4 : 8) <= 65536 && !getenv("QDAS_JIT_NO_MB32")) k.mb = 32;
-        if (const char *e = getenv("QDAS_JIT_MB")) {
-            const int mb = atoi(e);
-            if (mb >= 2 && mb % k.waves == 0 && (!t.sym || t.fold || z.M % (uint64_t)mb == 0) && (!mirq || t.fold)) k.mb = mb;
+// FACT: the folded table equals its own mirror image, w[n,m] == w[N-1-n,M-1-m] bit for bit (receive and transmit windows are)
+static bool table_mirror_symmetric(const qdas_sizes &z, const std::vector<float> &tab, bool swap) {
+    for (uint64_t m = 0; m < z.M; ++m)
+        for (uint64_t n = 0; n < z.N; ++n) {
+            const size_t q = swap ? (m + z.M * n) : (n + z.N * m), q2 = swap ? ((z.M - 1 - m) + z.M * (z.N - 1 - n)) : ((z.N - 1 - n) + z.N * (z.M - 1 - m));
+            if (memcmp(&tab[2 * q], &tab[2 * q2], 8) != 0) return false;
         }
-        if (const char *e = getenv("QDAS_JIT_NBUF")) { const int nb = atoi(e); if (nb >= 2 && nb <= 4) k.nbuf = nb; }
-        {
-            const size_t MX = std::min<size_t>(t.M > t.N ? t.M : t.N, QDAS_PROLOGUE_CHUNK);
-            const size_t off_act = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + 15) & ~(size_t)15;   // Tile::setup
-            const size_t off_wst = off_act + (((size_t)t.act_bytes + 15) & ~(size_t)15);
-            const size_t hdr = (off_wst + (t.wtab ? (size_t)k.nbuf * (2 * (size_t)k.mb * 8 + 16) : 0) + 15) & ~(size_t)15;
-            size_t body = (size_t)k.nbuf * k.mb * (t.fold ? (mirq ? 2 : 1) : mirq ? 4 : (t.sym || t.mir) ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
-            const size_t scratch = 2 * (size_t)k.waves * MX * 4 + 1024;
-            if (body < scratch) body = scratch;
-            pl->jit_lds = dt == QDAS_F64 ? 0 : hdr + body;       // (fp64 data: the prebuilt configuration's own LDS image, das_tile.hip)
-        }
-        std::string key;
-        const std::string err = pl->jit_lds > (size_t)160 * 1024 ? std::string("LDS image too large for the requested configuration")
-                                                                 : jit_get_kernel(k, pl->device, &pl->jit_fn, &key);
-        if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; }
-        else {
-            pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel";
-            const bool unfolded = dt == QDAS_F32 && t.sym && !t.fold;                  // (likewise: the general kernels then)
-            if ((dt == QDAS_F32 && t.mir && !t.sym && (t.apix || t.gen_kind)) || unfolded) {      // exists only as a hiprtc build: the same plan without the mirror mode
-                qdas_desc d2 = *desc;
-                d2.plan_flags |= unfolded ? QDAS_PLAN_NO_RECIPROCAL : QDAS_PLAN_NO_MIRROR;
-                const std::string keep = g_err;
-                delete pl;
-                const int rc2 = qdas_plan_create(out, &d2);
-                if (rc2 == QDAS_OK) g_err = keep;
-                return rc2;
+    return true;
+}
+
+// step 3 of plan_modes.h: the chain of window-fit probes; each step = one choose_tile_shape (four footprints on the device)
+static int plan_probe_chain(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
+    const qdas_sizes &z = pl->d.sz;
+    TileParams &t = pl->tp;
+    modes::ProbeState ps;
+    ps.dtype = z.dtype; ps.sym = t.sym; ps.rfold = t.fold; ps.mir = t.mir; ps.narrow = 0; ps.bpix = b.rq.bpix_mode;
+    ps.set_tc(b.sy.tc_sym, b.sy.tc_narrow, b.sy.tc_fb, b.sy.tc_mirq, b.sy.tc_fold);
+    if (t.fold && pl->fold_buf) HIPCHK(hipMemset(pl->fold_buf, 0, (size_t)z.T * z.N * z.M * 8));      // (the lower triangle is never written: zeros, not garbage, where a border window reaches into it)
+    const bool has_table = !b.host_tab.empty();
+    const bool tsym = (t.mir && has_table && !t.fold) ? table_mirror_symmetric(z, b.host_tab, b.sy.swap) : true;
+    auto set_grid = [&](int tzl) { plan_set_grid(pl, tzl); };
+    auto probe = [&](const modes::ProbeState &s, bool *fit) -> int {
+        t.mir = s.mir; t.narrow = s.narrow;
+        pl->tc = s.tc();
+        const int rc = choose_tile_shape(pl, desc, set_grid);
+        *fit = pl->no_fallback;
+        return rc;
+    };
+    int err = 0;
+    (void)modes::run_probe_chain(ps, b.sw, has_table, tsym, probe, &err);
+    if (err) return err;
+    t.mir = ps.mir; t.narrow = ps.narrow;                // (the chain's last probe ran the final state: tc, grid and shape are the plan's)
+    b.sy.mir = ps.mir != 0;
+    return QDAS_OK;
+}
+
+// Focused transmits whose focal planes cut through the image: the delay flips sign there (src/bf.cu:106-108), so the tiles a plane
+// crosses fit no window and would go to the generic kernel -- with a walking aperture that is half the image.  Second attempt:
+// every transmit listed twice, once per side of its plane (tile_params.h kindS == 3); kept if fewer tiles misfit.
+static int plan_side_split(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
+    const qdas_sizes &z = pl->d.sz;
+    TileParams &t = pl->tp;
+    b.kN_eff = b.sy.kN;
+    if (!modes::side_split_applicable(*desc, b.rq, b.sy, pl->no_fallback, b.txkind, b.sy.wtb != 0, b.sw)) return QDAS_OK;
+    int rc;
+    const TileParams keep = t;
+    const double keep_frac = pl->misfit_frac;
+    const unsigned keep_ntiles = pl->ntiles, keep_cols = pl->tile_cols;
+    const bool tp = z.flag & QDAS_FLAG_TPOSE;
+    const uint64_t E = 2 * z.M;                          // stage elements: (transmit, side)
+    if ((rc = upload_swapped_geometry(pl, desc, E, 1))) return rc;
+    t.N = E; t.M = z.N;
+    t.strN = tp ? z.T : z.T * z.N;                       // stage element = transmit, block element = receiver
+    t.strM = tp ? z.T * z.M : z.T;
+    t.kindB = 0; t.kindS = 3; t.stage_shift = 1;
+    t.gen_kind = t.apix ? 6 : 5; t.gen_p0 = t.gen_p1 = 0.0; t.rxn = nullptr;      // (6: the side rule times the plan's pixel x transmit / pixel-only array)
+    t.act_bytes = (uint32_t)(8 * (E + 1));
+    if (t.wtab) {                                        // the table in the new element order: [(2m + side) + 2M * n]
+        std::vector<float> tab2(2 * E * z.N);
+        for (uint64_t n = 0; n < z.N; ++n)
+            for (uint64_t e = 0; e < E; ++e) {
+                const uint64_t m = e >> 1, q = b.sy.swap ? (m + z.M * n) : (n + z.N * m);
+                tab2[2 * (e + E * n)] = b.host_tab[2 * q]; tab2[2 * (e + E * n) + 1] = b.host_tab[2 * q + 1];
             }
-        }
+        void *dtab2;
+        if ((rc = dev_alloc(pl, &dtab2, tab2.size() * sizeof(float)))) return rc;
+        hipError_t e2 = hipMemcpy(dtab2, tab2.data(), tab2.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e2 != hipSuccess) return fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e2));
+        t.wtab = dtab2;
     }
-    if (pl->prefolded && pl->kernel == QDAS_KERNEL_TILED && !pl->no_fallback)
-        return bail(fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_PREFOLDED: tiles of this image do not fit the staging windows (they would be redone from the unfolded frame)"));
-    // ---- fp16 reciprocal data on the folded fp32 kernels: an fp32 PREFOLDED child plan over the same geometry and slab; this plan folds each frame into a
-    //      complex64 copy (its weight table applied on the way), the child beamforms it, the complex64 image is rounded to complex32.  If anything of that is
-    //      not available (memory, a child that does not fit) the plan keeps its own fp16 reciprocal kernels.
-    if (pl->kernel == QDAS_KERNEL_TILED && dt == QDAS_F16 && pl->tp.sym && !pl->tp.syn && !pl->tp.bf && !(desc->plan_flags & QDAS_PLAN_NO_FOLD) && !getenv("QDAS_NO_FOLD")
-        && !getenv("QDAS_NO_FOLD16") && z.N >= 2 && z.N <= 65535) {
-        qdas_desc d = *desc;
-        const GenericParams &gg = pl->gp;
-        uint64_t acs[6] = {gg.cst[0], gg.cst[1], gg.cst[2], gg.cst[3], gg.cst[4], gg.cst[5]};
-        d.sz.dtype = QDAS_F32; d.sz.S = 0;
-        d.Pi = gg.Pi; d.Pr = gg.Pr; d.Pv = gg.Pv; d.Nv = gg.Nv; d.cinv = gg.cinv; d.apod = nullptr; d.rx_normals = nullptr; d.rx_apod_kind = 0; d.acstride = acs;
-        d.mem = QDAS_MEM_DEVICE; d.device = pl->device; d.y_ld = 0;
-        d.plan_flags = (d.plan_flags | QDAS_PLAN_PREFOLDED) & ~(QDAS_PLAN_COPY_INPUTS | QDAS_PLAN_NO_FOLD);
-        const std::string keep = g_err;
-        qdas_plan *child = nullptr;
-        void *fb = nullptr, *yb = nullptr;
-        if (qdas_plan_create(&child, &d) == QDAS_OK && child && child->kernel == QDAS_KERNEL_TILED && child->prefolded
-            && hipMalloc(&fb, (size_t)z.T * z.N * z.M * 8) == hipSuccess && hipMalloc(&yb, (size_t)child->y_ld * 8 + 16) == hipSuccess
-            && hipMemset(fb, 0, (size_t)z.T * z.N * z.M * 8) == hipSuccess) {
-            pl->owned.push_back(fb); pl->owned.push_back(yb);
-            pl->fold_buf = fb; pl->y32 = yb; pl->f16_child = child;
-            pl->fold_wtab = pl->tp.wtab;               // (this plan's N x M table, float2: applied by the fold pass)
-        } else {
-            (void)hipGetLastError();
-            if (fb) (void)hipFree(fb);
-            if (yb) (void)hipFree(yb);
-            if (child) qdas_plan_destroy(child);
-        }
-        g_err = keep;
+    auto set_grid = [&](int tzl) { plan_set_grid(pl, tzl); };
+    if ((rc = choose_tile_shape(pl, desc, set_grid))) return rc;
+    if (pl->misfit_frac < keep_frac) b.kN_eff = E;
+    else {                                               // no better: the plan as it was
+        t = keep;
+        pl->misfit_frac = keep_frac; pl->no_fallback = keep_frac == 0.0; pl->ntiles = keep_ntiles; pl->tile_cols = keep_cols;
+        HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));
     }
-    // ---- the instantiation this plan launches for one frame: libqdas.so carries it, or it is built now (das_tile_cfg.h tile_prebuilt, jit.hip
-    //      lazy_tile_launch) -- never inside an execute.  Without a compiler at hand (no libhiprtc.so, QDAS_NO_LAZY) the plan is re-made on the generic
-    //      kernel (identical semantics, 5-12x slower), or fails when the caller insisted on QDAS_KERNEL_TILED; qdas_last_error() says which variant it was.
-    if (pl->kernel == QDAS_KERNEL_TILED && !pl->jit_fn && !pl->f16_child) {      // (fp16 reciprocal data: the fp32 child plan above resolved its own)
-        std::string built;
-        TileParams t1 = pl->tp;
-        t1.nfr = 1;
-        const hipError_t pe = prepare_tile(t1, dt, pl->ntiles, &built);
-        if (pe == hipErrorSharedObjectInitFailed) {
-            const std::string why = g_err;
-            if (desc->kernel == QDAS_KERNEL_TILED || mslab || pl->prefolded)
-                return bail(fail(QDAS_EUNSUPPORTED, "%s", why.c_str()));
-            qdas_desc d2 = *desc;
-            d2.kernel = QDAS_KERNEL_GENERIC;
-            delete pl;
-            const int rc2 = qdas_plan_create(out, &d2);
-            if (rc2 == QDAS_OK) g_err = why + " -- using the generic kernel";
-            return rc2;
-        }
-        if (pe != hipSuccess) (void)hipGetLastError();      // (anything else is the launch's to report)
-        if (!built.empty()) pl->jit_tag = "built on demand " + built;
+    return QDAS_OK;
+}
+
+// Tiles that still do not fit (a pixel grid coarser than about lambda/2 -- volumes, previews --, steep delay gradients): fp32 plans
+// try the 384-sample windows of launch configuration 14 (16 transmits per stage, same LDS image); kept if fewer tiles misfit.
+// (a reciprocal plan gives up its mode for them: an image on the generic kernel costs ten times more than the shared index work saves)
+static int plan_wide_windows(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
+    const qdas_sizes &z = pl->d.sz;
+    TileParams &t = pl->tp;
+    if (!modes::wide_applicable(z.dtype, pl->no_fallback, b.rq.bfm, t.big, t.narrow, pl->prefolded, t.N, t.M, t.strN, t.strM, t.act_bytes != 0,
+                                t.wtab || (t.fold && pl->fold_wtab), b.sw)) return QDAS_OK;      // (a folded plan's table comes back into the kernel there)
+    int rc;
+    const TileParams keep = t;
+    const TileConfig keep_tc = pl->tc;
+    const double keep_frac = pl->misfit_frac;
+    const unsigned keep_ntiles = pl->ntiles, keep_cols = pl->tile_cols;
+    t.narrow = 2; t.sym = 0;
+    if (t.fold) { t.fold = 0; t.wtab = pl->fold_wtab; }      // (the wide-window configuration is a general-mode kernel on the frame as it is)
+    pl->tc = tile_config(z.dtype, 0, 2);
+    auto set_grid = [&](int tzl) { plan_set_grid(pl, tzl); };
+    if ((rc = choose_tile_shape(pl, desc, set_grid))) return rc;
+    if (!(pl->misfit_frac < keep_frac)) {
+        t = keep; pl->tc = keep_tc;
+        pl->misfit_frac = keep_frac; pl->no_fallback = keep_frac == 0.0; pl->ntiles = keep_ntiles; pl->tile_cols = keep_cols;
+        HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));
     }
-    pl->fb2_ok = pl->kernel == QDAS_KERNEL_TILED && dt != QDAS_F64 && !pl->tp.mir && !pl->tp.stage_shift && pl->tp.narrow != 2 && !(dt == QDAS_F32 && (pl->tp.apix || pl->tp.gen_kind)) && !pl->tp.bf && !pl->tp.sym && !pl->tp.big && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2");
-    // folded data: TWO frames per launch (launch configurations 20 / 21 -- tap index and weights serve two folded traces of two frames, in mirror mode four);
-    // the mirror mode needs the 128-sample windows for it (four window sets), and the plan a second folded copy of a frame (allocated at the first stream)
-    pl->fold2_ok = pl->kernel == QDAS_KERNEL_TILED && pl->tp.fold && (!pl->tp.mir || pl->tp.narrow) && !pl->tp.syn && desc->mem == QDAS_MEM_DEVICE && !getenv("QDAS_NO_FB2")
-                   && tile_lds_bytes(dt, 1, z.N, z.M, pl->tp.narrow, 0, 0, pl->tp.mir ? 1 : 0, 1, 2) <= tile_lds_limit(1);
-    // four frames per launch: not for fp32 plans with remodulation, a weight table or a pixel x receiver weight (das_tile_impl.h launch_tile_i)
-    pl->fb4_off = getenv("QDAS_NO_FB4") != nullptr
-                  || (dt == QDAS_F32 && pl->kernel == QDAS_KERNEL_TILED && (pl->tp.fmod != 0.0 || pl->tp.wtab || pl->tp.apix || pl->tp.gen_kind));
+    return QDAS_OK;
+}
+
+// step 4 of plan_modes.h: workgroups per tile (+ the partial images of a split aperture)
+static int plan_split_aperture(qdas_plan *pl, PlanBuild &b) {
+    const qdas_sizes &z = pl->d.sz;
+    TileParams &t = pl->tp;
+    int ncu = 0, rc;
+    HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device));
+    const unsigned cus = ncu > 0 ? (unsigned)ncu : 256u;
+    t.ksplit = modes::choose_ksplit(pl->ntiles, cus, z.M, pl->tc.mb, t.sym != 0, b.kN_eff, t.act_bytes != 0, t.syn != 0, b.sw);
+    if (t.ksplit > 1 && !t.bf) {
+        void *pb;
+        if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)t.ksplit * 4 * pl->i_count * (t.mir == 2 ? 2 : 1)))) return rc;   // x4: up to four frames per launch (fp64 data: one complex128 frame -- fits as well)
+        t.part = (float2 *)pb;
+    }
+    return QDAS_OK;
+}
+
+// QDAS_PLAN_JIT: the tiled kernel compiled for this plan's sizes (jit.hip).  A failure is not an error: the plan keeps its prebuilt kernel and
+// qdas_last_error() says why -- unless the plan's mode exists as a hiprtc build only: *remake = the plan flag to add for a second attempt without it.
+static int plan_jit(qdas_plan *pl, const qdas_desc *desc, int *remake) {
+    const qdas_sizes &z = pl->d.sz;
+    const int dt = z.dtype;
+    *remake = 0;
+    g_err.clear();
+    if (!((desc->plan_flags & QDAS_PLAN_JIT) && pl->kernel == QDAS_KERNEL_TILED && !pl->tp.bf && !getenv("QDAS_NO_JIT"))) return QDAS_OK;
+    const TileParams &t = pl->tp;
+    JitSpec k{};
+    k.interp = (z.flag & 7) == 4 ? 1 : (z.flag & 7); k.dtype = dt; k.fmod = t.fmod != 0.0; k.wtab = t.wtab != nullptr; k.sym = t.sym; k.big = t.big;
+    const int narrow = (t.sym && dt == QDAS_F32 && t.narrow) ? 1 : (!t.sym && dt == QDAS_F32 && t.narrow == 2) ? 2 : 0;
+    const int mirq = (t.sym && t.mir) ? 1 : 0;
+    const Cfg &cg = CFGS[cfg_index(dt, t.sym, t.fold ? 1 : (t.mir ? 2 : 1), narrow, mirq, t.fold)];      // (fb = 2 selects the two-window-set configuration of a general-mode mirror plan; folded plans: one frame)
+    k.mir = t.sym ? 0 : t.mir; k.mirq = mirq; k.mslab = t.mir == 2; k.fold = t.fold;
+    k.waves = cg.waves; k.mb = cg.mb; k.w = cg.w; k.nbuf = cg.nbuf;
+    k.N = t.N; k.M = t.M; k.T = t.T; k.I1 = t.I1; k.strN = t.strN; k.strM = t.strM;
+    k.kindB = t.kindB; k.kindS = t.kindS; k.tzl = t.tz_log2; k.wzl = t.wz_log2; k.ksplit = t.ksplit;
+    k.gen_kind = t.gen_kind; k.has_apix = t.apix != nullptr; k.apix_real = t.apix_real; k.syn = t.syn;
+    k.has_st = t.St != nullptr; k.has_cinv_pix = t.cinv_pix != nullptr;
+    k.wreal = (t.wtab && pl->wtab_real && !getenv("QDAS_NO_WREAL")) ? 1 : 0;
+    // tuning: a specialised build may use another number of transmits per stage than the prebuilt configuration (its register
+    // budget is smaller); the LDS image grows with it
+    // reciprocal mode: the specialised kernel has the registers for 32-transmit stages (half the stages, barriers and per-stage
+    // delay evaluations of the prebuilt 16-transmit configuration) whenever the 64 windows of a buffer stay within the 16-bit
+    // immediate offsets of the LDS reads (C3: 30.9 -> 29.2 ms)
+    if (t.sym && !mirq && !t.fold && z.M % 32 == 0 && 2 * 32 * k.w * (dt == QDAS_F16 ? 4 : 8) <= 65536 && !getenv("QDAS_JIT_NO_MB32")) k.mb = 32;
+    if (const char *e = getenv("QDAS_JIT_MB")) {
+        const int mb = atoi(e);
+        if (mb >= 2 && mb % k.waves == 0 && (!t.sym || t.fold || z.M % (uint64_t)mb == 0) && (!mirq || t.fold)) k.mb = mb;
+    }
+    if (const char *e = getenv("QDAS_JIT_NBUF")) { const int nb = atoi(e); if (nb >= 2 && nb <= 4) k.nbuf = nb; }
+    {
+        const size_t MX = std::min<size_t>(t.M > t.N ? t.M : t.N, QDAS_PROLOGUE_CHUNK);
+        const size_t off_act = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + 15) & ~(size_t)15;   // Tile::setup
+        const size_t off_wst = off_act + (((size_t)t.act_bytes + 15) & ~(size_t)15);
+        const size_t hdr = (off_wst + (t.wtab ? (size_t)k.nbuf * (2 * (size_t)k.mb * 8 + 16) : 0) + 15) & ~(size_t)15;
+        size_t body = (size_t)k.nbuf * k.mb * (t.fold ? (mirq ? 2 : 1) : mirq ? 4 : (t.sym || t.mir) ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
+        const size_t scratch = 2 * (size_t)k.waves * MX * 4 + 1024;
+        if (body < scratch) body = scratch;
+        pl->jit_lds = dt == QDAS_F64 ? 0 : hdr + body;       // (fp64 data: the prebuilt configuration's own LDS image, das_tile.hip)
+    }
+    std::string key;
+    const std::string err = pl->jit_lds > (size_t)160 * 1024 ? std::string("LDS image too large for the requested configuration")
+                                                             : jit_get_kernel(k, pl->device, &pl->jit_fn, &key);
+    if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; return QDAS_OK; }
+    pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel";
+    const bool unfolded = dt == QDAS_F32 && t.sym && !t.fold;                  // (likewise: the general kernels then)
+    if ((dt == QDAS_F32 && t.mir && !t.sym && (t.apix || t.gen_kind)) || unfolded)      // exists only as a hiprtc build: the same plan without the mode
+        *remake = unfolded ? QDAS_PLAN_NO_RECIPROCAL : QDAS_PLAN_NO_MIRROR;
+    return QDAS_OK;
+}
+
+// fp16 reciprocal data on the folded fp32 kernels: an fp32 PREFOLDED child plan over the same geometry and slab; this plan folds each frame into a
+// complex64 copy (its weight table applied on the way), the child beamforms it, the complex64 image is rounded to complex32.  If anything of that is
+// not available (memory, a child that does not fit) the plan keeps its own fp16 reciprocal kernels.
+static void plan_f16_child(qdas_plan *pl, const qdas_desc *desc) {
+    const qdas_sizes &z = pl->d.sz;
+    if (!(pl->kernel == QDAS_KERNEL_TILED && z.dtype == QDAS_F16 && pl->tp.sym && !pl->tp.syn && !pl->tp.bf && !(desc->plan_flags & QDAS_PLAN_NO_FOLD) && !getenv("QDAS_NO_FOLD")
+          && !getenv("QDAS_NO_FOLD16") && z.N >= 2 && z.N <= 65535)) return;
+    qdas_desc d = *desc;
+    const GenericParams &gg = pl->gp;
+    uint64_t acs[6] = {gg.cst[0], gg.cst[1], gg.cst[2], gg.cst[3], gg.cst[4], gg.cst[5]};
+    d.sz.dtype = QDAS_F32; d.sz.S = 0;
+    d.Pi = gg.Pi; d.Pr = gg.Pr; d.Pv = gg.Pv; d.Nv = gg.Nv; d.cinv = gg.cinv; d.apod = nullptr; d.rx_normals = nullptr; d.rx_apod_kind = 0; d.acstride = acs;
+    d.mem = QDAS_MEM_DEVICE; d.device = pl->device; d.y_ld = 0;
+    d.plan_flags = (d.plan_flags | QDAS_PLAN_PREFOLDED) & ~(QDAS_PLAN_COPY_INPUTS | QDAS_PLAN_NO_FOLD);
+    const std::string keep = g_err;
+    qdas_plan *child = nullptr;
+    void *fb = nullptr, *yb = nullptr;
+    if (qdas_plan_create(&child, &d) == QDAS_OK && child && child->kernel == QDAS_KERNEL_TILED && child->prefolded
+        && hipMalloc(&fb, (size_t)z.T * z.N * z.M * 8) == hipSuccess && hipMalloc(&yb, (size_t)child->y_ld * 8 + 16) == hipSuccess
+        && hipMemset(fb, 0, (size_t)z.T * z.N * z.M * 8) == hipSuccess) {
+        pl->owned.push_back(fb); pl->owned.push_back(yb);
+        pl->fold_buf = fb; pl->y32 = yb; pl->f16_child = child;
+        pl->fold_wtab = pl->tp.wtab;               // (this plan's N x M table, float2: applied by the fold pass)
+    } else {
+        (void)hipGetLastError();
+        if (fb) (void)hipFree(fb);
+        if (yb) (void)hipFree(yb);
+        if (child) qdas_plan_destroy(child);
+    }
+    g_err = keep;
+}
+
+// the instantiation this plan launches for one frame: libqdas.so carries it, or it is built now (das_tile_cfg.h tile_prebuilt, jit.hip lazy_tile_launch) --
+// never inside an execute.  *no_compiler: the variant is missing and cannot be built (no libhiprtc.so, QDAS_NO_LAZY); g_err says which one it was.
+static void plan_resolve_kernel(qdas_plan *pl, bool *no_compiler) {
+    *no_compiler = false;
+    if (!(pl->kernel == QDAS_KERNEL_TILED && !pl->jit_fn && !pl->f16_child)) return;      // (fp16 reciprocal data: the fp32 child plan resolved its own)
+    std::string built;
+    TileParams t1 = pl->tp;
+    t1.nfr = 1;
+    const hipError_t pe = prepare_tile(t1, pl->d.sz.dtype, pl->ntiles, &built);
+    if (pe == hipErrorSharedObjectInitFailed) { *no_compiler = true; return; }
+    if (pe != hipSuccess) (void)hipGetLastError();      // (anything else is the launch's to report)
+    if (!built.empty()) pl->jit_tag = "built on demand " + built;
+}
+
+// step 5 of plan_modes.h (frames per launch of a stream), host staging, and what the plan must not keep
+static int plan_finish(qdas_plan *pl, const qdas_desc *desc, const PlanBuild &b) {
+    const qdas_sizes &z = pl->d.sz;
+    const int dt = z.dtype;
+    int rc;
+    modes::PlanShape ps;
+    ps.dtype = dt; ps.tiled = pl->kernel == QDAS_KERNEL_TILED; ps.sym = pl->tp.sym; ps.fold = pl->tp.fold; ps.mir = pl->tp.mir; ps.narrow = pl->tp.narrow; ps.big = pl->tp.big;
+    ps.bf = pl->tp.bf; ps.syn = pl->tp.syn; ps.stage_shift = pl->tp.stage_shift; ps.has_apix = pl->tp.apix != nullptr; ps.has_wtab = pl->tp.wtab != nullptr;
+    ps.has_bpix = pl->tp.bpix != nullptr; ps.gen_kind = pl->tp.gen_kind; ps.fmod = pl->tp.fmod; ps.N = pl->tp.N; ps.M = pl->tp.M; ps.mem_device = desc->mem == QDAS_MEM_DEVICE;
+    const modes::StreamModes sm = modes::stream_modes(ps, z.N, z.M, b.sw);
+    pl->fb2_ok = sm.fb2_ok; pl->fold2_ok = sm.fold2_ok; pl->fb4_off = sm.fb4_off;
     if (desc->mem == QDAS_MEM_HOST) {                   // staging buffers for x / y
         pl->x_bytes = (size_t)z.T * z.N * z.M * data_size(dt);
         pl->y_bytes = (size_t)pl->y_ld * pl->oN * pl->oM * data_size(dt);
-        if ((rc = dev_alloc(pl, &pl->dx, pl->x_bytes))) return bail(rc);
-        if ((rc = dev_alloc(pl, &pl->dy, pl->y_bytes))) return bail(rc);
+        if ((rc = dev_alloc(pl, &pl->dx, pl->x_bytes))) return rc;
+        if ((rc = dev_alloc(pl, &pl->dy, pl->y_bytes))) return rc;
     }
     // the plan keeps no pointer into caller memory it does not need: host arrays were copied; device arrays are used in place
     // (g.* / tp.*: they must stay valid for the life of the plan unless QDAS_PLAN_COPY_INPUTS made plan-owned copies)
-    pl->mirror_bound = mirror_bound; pl->recip_bound = recip_bound;
+    pl->mirror_bound = b.sy.mirror_bound; pl->recip_bound = b.sy.recip_bound;
     if (pl->fold_buf && !pl->f16_child && !(pl->kernel == QDAS_KERNEL_TILED && pl->tp.fold)) {      // (the plan left the fold after all: wide windows, strides, generic kernel)
         for (size_t k = 0; k < pl->owned.size(); ++k) if (pl->owned[k] == pl->fold_buf) { pl->owned.erase(pl->owned.begin() + (long)k); break; }
         (void)hipFree(pl->fold_buf);
@@ -1138,6 +1017,80 @@ extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
     }
     pl->d.Pi = pl->d.Pr = pl->d.Pv = pl->d.Nv = pl->d.apod = pl->d.cinv = pl->d.rx_normals = nullptr;
     pl->d.acstride = nullptr;
+    return QDAS_OK;
+}
+
+// the tiled kernel's side of a plan: parameter block, weights, probed shape, split aperture
+static int plan_build_tiled(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
+    int rc;
+    if ((rc = plan_setup_tile_params(pl, desc, b))) return rc;
+    if ((rc = plan_pixel_weights(pl, desc, b))) return rc;
+    if ((rc = plan_weight_table(pl, desc, b))) return rc;
+    if ((rc = plan_probe_chain(pl, desc, b))) return rc;
+    if ((rc = plan_side_split(pl, desc, b))) return rc;
+    if ((rc = plan_wide_windows(pl, desc, b))) return rc;
+    return plan_split_aperture(pl, b);
+}
+
+static int plan_create_impl(qdas_plan *pl, qdas_plan **out, const qdas_desc *desc, bool *replaced) {
+    *replaced = false;
+    int rc = plan_init(pl, desc);
+    if (rc) return rc;
+    const qdas_sizes &z = pl->d.sz;
+    DeviceGuard guard(desc->device);
+    if (guard.err != hipSuccess) return fail(QDAS_EHIP, "hipSetDevice(%d): %s", desc->device, hipGetErrorString(guard.err));
+    { hipError_t e = hipGetDevice(&pl->device); if (e != hipSuccess) return fail(QDAS_EHIP, "hipGetDevice: %s", hipGetErrorString(e)); }
+    if (pl->I == 0 || z.N == 0 || z.M == 0) return QDAS_OK;   // empty problem: execute() just zero-fills
+    if ((desc->plan_flags & QDAS_PLAN_PREFOLDED) && z.S > 0)      // (a prefolded plan runs no fold pass: nothing would apply the table -- include/qdas.h QDAS_PLAN_PREFOLDED)
+        return fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_PREFOLDED: apodization arrays belong to the fold (qdas_fold_desc.wtab), not to the plan that is handed folded frames");
+    PlanBuild b;
+    b.desc = desc;
+    b.sw = read_switches();
+    if ((rc = plan_import_inputs(pl, desc, b))) return rc;
+    if ((rc = plan_resolve_modes(pl, desc, b))) return rc;
+    if (pl->kernel == QDAS_KERNEL_TILED && (rc = plan_build_tiled(pl, desc, b))) return rc;
+    const bool mslab = (desc->plan_flags & QDAS_PLAN_MIRROR_SLAB) != 0;
+    if (mslab && !(pl->kernel == QDAS_KERNEL_TILED && pl->tp.mir == 2))
+        return fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_MIRROR_SLAB: the lateral-mirror mode is not available for this problem (geometry not mirror-symmetric "
+                                       "about x = 0, weights / modes it does not take, or tiles that do not fit the staging windows): use plain slabs");
+    int remake = 0;
+    if ((rc = plan_jit(pl, desc, &remake))) return rc;
+    if (remake) {                                       // the plan's mode exists only as a hiprtc build, which failed: the same plan without the mode
+        qdas_desc d2 = *desc;
+        d2.plan_flags |= remake;
+        const std::string keep = g_err;
+        *replaced = true;
+        const int rc2 = qdas_plan_create(out, &d2);
+        if (rc2 == QDAS_OK) g_err = keep;
+        return rc2;
+    }
+    if (pl->prefolded && pl->kernel == QDAS_KERNEL_TILED && !pl->no_fallback)
+        return fail(QDAS_EUNSUPPORTED, "QDAS_PLAN_PREFOLDED: tiles of this image do not fit the staging windows (they would be redone from the unfolded frame)");
+    plan_f16_child(pl, desc);
+    bool no_compiler = false;
+    plan_resolve_kernel(pl, &no_compiler);
+    if (no_compiler) {                                  // re-made on the generic kernel (identical semantics, 5-12x slower), or an error when the caller insisted on the fused kernel
+        const std::string why = g_err;
+        if (desc->kernel == QDAS_KERNEL_TILED || mslab || pl->prefolded) return fail(QDAS_EUNSUPPORTED, "%s", why.c_str());
+        qdas_desc d2 = *desc;
+        d2.kernel = QDAS_KERNEL_GENERIC;
+        *replaced = true;
+        const int rc2 = qdas_plan_create(out, &d2);
+        if (rc2 == QDAS_OK) g_err = why + " -- using the generic kernel";
+        return rc2;
+    }
+    return plan_finish(pl, desc, b);
+}
+
+extern "C" int qdas_plan_create(qdas_plan **out, const qdas_desc *desc) {
+    if (!out || !desc) return fail(QDAS_EINVAL, "null argument");
+    *out = nullptr;
+    int rc = validate(desc);
+    if (rc) return rc;
+    qdas_plan *pl = new qdas_plan();
+    bool replaced = false;
+    rc = plan_create_impl(pl, out, desc, &replaced);
+    if (rc || replaced) { delete pl; return rc; }      // (replaced: *out holds the plan that was made in this one's stead)
     *out = pl;
     return QDAS_OK;
 }

@@ -4,8 +4,11 @@
 #include <stdint.h>
 #include <string>
 #include "tile_params.h"
+#include "plan_modes.h"
 
+#ifndef QDAS_MAX_APOD
 #define QDAS_MAX_APOD 6
+#endif
 
 namespace qdas {
 
@@ -34,11 +37,7 @@ struct GenericParams {
 hipError_t launch_generic(const GenericParams &P, int dtype, unsigned grid, hipStream_t s);
 hipError_t launch_delays(const GenericParams &P, int dtype, void *tau, double cinv, hipStream_t s);
 
-// ---- tiled kernel (das_tile_impl.h); parameter block in tile_params.h
-struct TileConfig { int waves; int mb; int window; size_t lds_bytes; int threads; };
-TileConfig tile_config(int dtype, int sym, int narrow = 0, int fb = 1, int mirq = 0, int fold = 0);   // fb = 2: the two-window-set configuration of the general mode (frames sharing a launch; lateral-mirror mode)
-size_t tile_lds_bytes(int dtype, int sym, uint64_t N, uint64_t M, int narrow = 0, int pixw = 0, int wtab = 0, int mirq = 0, int fold = 0, int fb = 1);   // dynamic LDS of one workgroup (pixw: a pixel x receiver weight -> room for the stage list)
-size_t tile_lds_limit(int sym);                               // LDS budget of one workgroup in that configuration
+// ---- tiled kernel (das_tile_impl.h); parameter block in tile_params.h; TileConfig / tile_config / tile_lds_bytes / tile_lds_limit: plan_modes.h (pure host code)
 // jit: plan-specialised kernel (jit.hip) to launch instead of the prebuilt instantiation; one frame per launch only
 hipError_t launch_tile(const TileParams &P, int dtype, unsigned ntiles, hipStream_t s, hipFunction_t jit = nullptr, size_t jit_lds = 0);
 // resolve (build on demand, if libqdas.so does not carry it) the instantiation launch_tile(P, ...) would run, without launching; *built = its cache key or ""
