@@ -460,5 +460,39 @@ inline const char *launch_legal(const LaunchShape &P, LaunchChoice *c) {
     return nullptr;
 }
 
+// ---- the MODEL of a built plan: what the launcher will be handed, derived from the decisions alone.  qdas_plan_create checks its parameter block against
+// this after the build (a mismatch is an internal error: the model and the code have drifted), and the GPU-less enumeration runs launch_legal on it.
+struct BuildOutcome {
+    int mir = 0, narrow = 0;              // the probe chain's final state
+    bool side_split = false, wide = false;
+    unsigned ksplit = 1;
+};
+inline LaunchShape derive_launch_shape(const qdas_desc &d, const Request &rq, const Symmetry &sy, const BuildOutcome &o) {
+    LaunchShape L;
+    const qdas_sizes &z = d.sz;
+    const int dt = z.dtype;
+    L.dtype = dt; L.sym = sy.sym; L.fold = sy.rfold; L.big = sy.big; L.mir = o.mir; L.narrow_raw = o.narrow;
+    L.bf = rq.bfm ? 1 : 0; L.syn = rq.syn ? 1 : 0;
+    uint64_t tN = sy.swap ? z.M : z.N, tM = sy.swap ? z.N : z.M;
+    const bool apix = rq.bpix_mode || rq.pix_fold || rq.pix_arr >= 0;
+    const bool table = z.S > rq.npix;
+    L.has_apix = apix; L.has_bpix = rq.bpix_mode; L.gen_kind = d.rx_apod_kind;
+    L.has_wtab = table && !L.fold;
+    if (o.side_split) { tN = 2 * z.M; tM = z.N; L.stage_shift = 1; L.gen_kind = apix ? 6 : 5; }
+    L.act_bytes = ((apix || L.gen_kind) && dt != QDAS_F64) ? (uint32_t)(8 * (tN + 1)) : 0u;
+    if (o.wide) { L.narrow_raw = 2; L.sym = 0; if (L.fold) { L.fold = 0; L.has_wtab = table; } }
+    L.N = tN; L.M = tM; L.ksplit = o.ksplit; L.has_part = o.ksplit > 1 && !L.bf;
+    L.fmod = dt == QDAS_F64 ? d.fmod : (double)(float)d.fmod;
+    return L;
+}
+// the first field in which two launch shapes differ (nullptr: none); `jit`, `probe`, `nfr` are the launch's, not the plan's
+inline const char *shape_mismatch(const LaunchShape &a, const LaunchShape &b) {
+#define QDAS_CMP(f) if (a.f != b.f) return #f;
+    QDAS_CMP(dtype) QDAS_CMP(sym) QDAS_CMP(fold) QDAS_CMP(mir) QDAS_CMP(narrow_raw) QDAS_CMP(big) QDAS_CMP(bf) QDAS_CMP(syn) QDAS_CMP(stage_shift) QDAS_CMP(lut)
+    QDAS_CMP(has_wtab) QDAS_CMP(has_apix) QDAS_CMP(has_bpix) QDAS_CMP(has_part) QDAS_CMP(gen_kind) QDAS_CMP(fmod) QDAS_CMP(act_bytes) QDAS_CMP(ksplit) QDAS_CMP(N) QDAS_CMP(M)
+#undef QDAS_CMP
+    return nullptr;
+}
+
 }  // namespace modes
 }  // namespace qdas

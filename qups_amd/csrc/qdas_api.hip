@@ -451,6 +451,7 @@ struct PlanBuild {
     int txkind = 0;                         // distance | signed distance | plane wave
     std::vector<float> host_tab;            // the folded N x M table as uploaded ([stage element + stages * block element])
     uint64_t kN_eff = 0;                    // stage elements after a side split
+    modes::BuildOutcome outcome;            // what the build steps did (plan_modes.h derive_launch_shape: the model the finished plan is checked against)
 };
 
 // sizes, slab, output planes; QDAS_PLAN_MIRROR_SLAB validation
@@ -801,6 +802,7 @@ static int plan_probe_chain(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) 
     if (err) return err;
     t.mir = ps.mir; t.narrow = ps.narrow;                // (the chain's last probe ran the final state: tc, grid and shape are the plan's)
     b.sy.mir = ps.mir != 0;
+    b.outcome.mir = ps.mir; b.outcome.narrow = ps.narrow;
     return QDAS_OK;
 }
 
@@ -840,7 +842,7 @@ static int plan_side_split(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
     }
     auto set_grid = [&](int tzl) { plan_set_grid(pl, tzl); };
     if ((rc = choose_tile_shape(pl, desc, set_grid))) return rc;
-    if (pl->misfit_frac < keep_frac) b.kN_eff = E;
+    if (pl->misfit_frac < keep_frac) { b.kN_eff = E; b.outcome.side_split = true; }
     else {                                               // no better: the plan as it was
         t = keep;
         pl->misfit_frac = keep_frac; pl->no_fallback = keep_frac == 0.0; pl->ntiles = keep_ntiles; pl->tile_cols = keep_cols;
@@ -867,7 +869,8 @@ static int plan_wide_windows(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b)
     pl->tc = tile_config(z.dtype, 0, 2);
     auto set_grid = [&](int tzl) { plan_set_grid(pl, tzl); };
     if ((rc = choose_tile_shape(pl, desc, set_grid))) return rc;
-    if (!(pl->misfit_frac < keep_frac)) {
+    b.outcome.wide = pl->misfit_frac < keep_frac;
+    if (!b.outcome.wide) {
         t = keep; pl->tc = keep_tc;
         pl->misfit_frac = keep_frac; pl->no_fallback = keep_frac == 0.0; pl->ntiles = keep_ntiles; pl->tile_cols = keep_cols;
         HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));
@@ -1020,7 +1023,9 @@ static int plan_finish(qdas_plan *pl, const qdas_desc *desc, const PlanBuild &b)
     return QDAS_OK;
 }
 
-// the tiled kernel's side of a plan: parameter block, weights, probed shape, split aperture
+namespace qdas { modes::LaunchShape launch_shape(const TileParams &P, int dtype, bool jit); }      // das_tile.hip: the launcher's view of a parameter block
+
+// the tiled kernel's side of a plan: parameter block, weights, probed shape, split aperture -- then checked against the model of plan_modes.h
 static int plan_build_tiled(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
     int rc;
     if ((rc = plan_setup_tile_params(pl, desc, b))) return rc;
@@ -1029,7 +1034,12 @@ static int plan_build_tiled(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) 
     if ((rc = plan_probe_chain(pl, desc, b))) return rc;
     if ((rc = plan_side_split(pl, desc, b))) return rc;
     if ((rc = plan_wide_windows(pl, desc, b))) return rc;
-    return plan_split_aperture(pl, b);
+    if ((rc = plan_split_aperture(pl, b))) return rc;
+    b.outcome.ksplit = pl->tp.ksplit;
+    const modes::LaunchShape model = modes::derive_launch_shape(*desc, b.rq, b.sy, b.outcome), built = launch_shape(pl->tp, pl->d.sz.dtype, false);
+    if (const char *f = modes::shape_mismatch(model, built))
+        return fail(QDAS_EINVAL, "internal: the built plan differs from the mode model of plan_modes.h in '%s' -- please report the descriptor", f);
+    return QDAS_OK;
 }
 
 static int plan_create_impl(qdas_plan *pl, qdas_plan **out, const qdas_desc *desc, bool *replaced) {
