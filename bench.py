@@ -286,6 +286,11 @@ def main():
     ap.add_argument("--rx-apod-array", action="store_true", help="with --rx-apod: pass the MATERIALISED I x N array instead of the in-kernel rule "
                     "(with --tx-apod: a transmit-side rule and a receive-side mask together -- per-pair pixel weights)")
     ap.add_argument("--prec", default=None, help="override the workload's data precision (single | halfT | double); not the headline")
+    ap.add_argument("--no-balance", action="store_true", help="--gpus N > 1: mirror slabs of equal WIDTH instead of equal measured COST (default: rank 0 times the column "
+                    "blocks of the first half once at plan creation, broadcasts the profile, every rank takes columns of equal cost: qups_amd.dist balanced_column_bounds)")
+    ap.add_argument("--prefolded", action="store_true", help="--gpus N > 1, reciprocal fp32 workloads: the timed region is handed FOLDED frames (folded once per acquisition by rank 0 "
+                    "and replicated as the packed upper triangle, outside the timed region; QDAS_PLAN_PREFOLDED plans: no per-rank fold pass -- the fixed ~0.4 ms per rank that "
+                    "does not shrink with the slab).  Reported as such (config.prefolded_timed_region), with the fold + replication time beside it; not the default")
     ap.add_argument("--gen-apod", action="store_true", help="generate the workload's receive apodization inside the kernel "
                     "(qdas_desc.rx_apod_*) instead of streaming the materialised I x N array")
     args = ap.parse_args()
@@ -377,8 +382,23 @@ def main():
     # N > 1: qups_amd.dist -- pixel slabs (mirror slabs when every rank's plan takes the lateral-mirror mode: rank r beamforms columns of the
     # first half AND their mirror images) and ONE RCCL all_gather
     from qups_amd.dist import ShardedDasPlan
-    splan = ShardedDasPlan(prob, rank, world, device=dev, kernel=args.kernel, reciprocal=not args.no_reciprocal, jit=args.jit, fold=not args.no_fold)
+    balance = "measure" if (world > 1 and not args.no_balance) else None
+    prefolded_run = bool(args.prefolded and world > 1 and w["prec"] == "single" and not args.no_fold and not args.no_reciprocal and F == 1)
+    splan = ShardedDasPlan(prob, rank, world, device=dev, kernel=args.kernel, reciprocal=not args.no_reciprocal, jit=args.jit, fold=not args.no_fold, balance=balance,
+                           **({"prefolded": True} if prefolded_run else {}))
     plan = splan.plan
+    prefold_ms = None
+    if prefolded_run:                                   # the acquisition rank folds ONCE, the packed upper triangle travels, every rank unpacks: outside the timed region, timed alone
+        from qups_amd.dist import FoldedReplicator
+        rep0 = FoldedReplicator(N, T, dev, src=0)
+        slot0, work0 = rep0.send(xc if rank == 0 else None, rank, async_op=True)
+        xc_unfolded, xc = xc, rep0.receive(slot0, rank, work0)
+        torch.cuda.synchronize(); dist.barrier()
+        tpf = time.perf_counter()
+        slot0, work0 = rep0.send(xc_unfolded if rank == 0 else None, rank, async_op=True)
+        xc = rep0.receive(slot0, rank, work0)
+        torch.cuda.synchronize(); dist.barrier()
+        prefold_ms = (time.perf_counter() - tpf) * 1e3
     b, e = splan.i_begin, splan.i_begin + splan.i_count
     slab_kw = dict(i_begin=b, i_count=e - b, mirror_slab=splan.mirror_slabs)
 
@@ -474,7 +494,7 @@ def main():
         # the same stream with the frame travelling FOLDED (reciprocal acquisitions: qups_amd.dist.FoldedReplicator -- rank 0 folds once, ONE broadcast of the
         # packed upper triangle = half the bytes, every rank beamforms the folded frame on a QDAS_PLAN_PREFOLDED plan: no per-rank fold pass either)
         folded_stream = None
-        if bool(plan.folded) and F == 1 and w["prec"] == "single" and not args.no_fold:
+        if bool(plan.folded) and F == 1 and w["prec"] == "single" and not args.no_fold and not prefolded_run:      # (--prefolded: the headline itself ran that way)
             try:
                 from qups_amd.dist import FoldedReplicator
                 fsplan = ShardedDasPlan(prob, rank, world, device=dev, kernel=args.kernel, reciprocal=True, jit=args.jit, prefolded=True,
@@ -501,7 +521,18 @@ def main():
                 fsplan.close()
             except Exception as ex:
                 folded_stream = {"ms_per_step": None, "note": f"failed: {ex!r}"}
-        multi = {"backend": backend, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
+        seen = [None] * world
+        try:                                            # who is in the process group: rank, local device ordinal, device name, PCI bus id (one tiny object gather)
+            props = torch.cuda.get_device_properties(dev)
+            dist.all_gather_object(seen, {"rank": rank, "local_device": int(dev.index if dev.index is not None else local), "name": props.name,
+                                          "pci": getattr(props, "pci_bus_id", None), "host": os.uname().nodename})
+        except Exception as ex:
+            seen = [f"all_gather_object failed: {ex!r}"]
+        multi = {"backend": backend, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "ranks_seen": seen,
+                 "slab_columns": None if splan.col_bounds is None else [int(v) for v in splan.col_bounds],
+                 "slab_layout": ("mirror slabs of equal measured cost (rank 0's per-block kernel times, broadcast)" if splan.col_bounds is not None else
+                                 "mirror slabs of equal width" if splan.mirror_slabs else "contiguous pixel slabs"),
+                 "prefolded_timed_region": prefolded_run, "fold_and_replicate_ms": None if prefold_ms is None else round(prefold_ms, 3),
                  "stream_folded_replication": folded_stream,
                  "stream_ms_per_step_incl_overlapped_replication": round(stream_ms, 3) if isinstance(stream_ms, float) else stream_ms,
                  "per_rank_kernel_ms": [round(float(k.item()), 3) for k in allk], "gather_ms": round(gather_ms, 3),

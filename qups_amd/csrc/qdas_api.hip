@@ -1025,6 +1025,29 @@ static int plan_finish(qdas_plan *pl, const qdas_desc *desc, const PlanBuild &b)
 
 namespace qdas { modes::LaunchShape launch_shape(const TileParams &P, int dtype, bool jit); }      // das_tile.hip: the launcher's view of a parameter block
 
+// The tile prologue's tables (window bases, extents, tile statistics: tile_params.h pro_tab) depend on the geometry only: computed ONCE per plan by the probe
+// kernels -- the same prologue code, writing to a plan-owned buffer -- and loaded by every workgroup of every execute instead of being recomputed
+// ((M + N) wave-wide reductions per wave and workgroup: 25 % of BASELINE C5's kernel time, ~10 % of C2's).  QDAS_NO_PRO_TAB=1: as before.
+static int plan_cache_prologue(qdas_plan *pl) {
+    TileParams &t = pl->tp;
+    t.pro_tab = nullptr; t.pro_out = nullptr;
+    if (getenv("QDAS_NO_PRO_TAB") || !pl->ntiles) return QDAS_OK;
+    const size_t stride = 2 * ((size_t)t.M + t.N) + 8, bytes = (size_t)pl->ntiles * stride * sizeof(float);
+    if (bytes > (1ull << 30)) return QDAS_OK;           // (thousands of elements x tens of thousands of tiles: not worth a GiB)
+    void *buf = nullptr;
+    if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); return QDAS_OK; }      // (no memory for it: the kernels compute their tables themselves)
+    pl->owned.push_back(buf);
+    TileParams p = t;
+    p.probe = 1; p.x = nullptr; p.y = nullptr; p.wtab = nullptr; p.apix = nullptr; p.pro_out = (float *)buf;
+    HIPCHK(hipMemsetAsync(buf, 0, bytes, 0));
+    const hipError_t e = launch_tile(p, pl->d.sz.dtype, pl->ntiles, nullptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return QDAS_OK; }      // (a configuration without a probe kernel: as before)
+    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));      // (the probe re-listed the misfit tiles: the frame kernels list them per launch)
+    t.pro_tab = (const float *)buf;
+    return QDAS_OK;
+}
+
 // the tiled kernel's side of a plan: parameter block, weights, probed shape, split aperture -- then checked against the model of plan_modes.h
 static int plan_build_tiled(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
     int rc;
@@ -1035,6 +1058,7 @@ static int plan_build_tiled(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) 
     if ((rc = plan_side_split(pl, desc, b))) return rc;
     if ((rc = plan_wide_windows(pl, desc, b))) return rc;
     if ((rc = plan_split_aperture(pl, b))) return rc;
+    if ((rc = plan_cache_prologue(pl))) return rc;
     b.outcome.ksplit = pl->tp.ksplit;
     const modes::LaunchShape model = modes::derive_launch_shape(*desc, b.rq, b.sy, b.outcome), built = launch_shape(pl->tp, pl->d.sz.dtype, false);
     if (const char *f = modes::shape_mismatch(model, built))

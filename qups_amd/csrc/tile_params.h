@@ -68,6 +68,13 @@ struct TileParams {
     // RECIPROCITY-FOLDED data (das_tile_impl.h TileCfg::FOLD; reciprocal fp32 plans): x points at the plan's folded copy of the frame
     // (fold.hip: xs[:,n,m] = w[n,m] x[:,n,m] + w[m,n] x[:,m,n], n <= m) and the stage loop walks the upper triangle only; wtab is null
     int32_t fold;
+    // PROLOGUE TABLES (round 5).  The window bases A[m], B[n], their extents and the tile-wide window statistics depend on the GEOMETRY only -- not on the
+    // frame --, yet every workgroup of every execute recomputed them: (M + N) wave-wide min / max reductions per wave, a quarter of BASELINE C5's kernel time
+    // (8 workgroups per tile, each with the whole prologue), a tenth of C2's.  The plan computes them ONCE (a probe launch with pro_out set, after the tile
+    // shape is final) and the stage kernels load them: per tile 2 (M + N) + 8 floats -- {base (int bits), extent} per block / stage element, then
+    // {a_lo, b_lo, a_hi, b_hi, a_ext, b_ext}.  Tile slot = tz + tiles_z * (column tile - tile_x0).  Null: computed in the kernel, as before.
+    const float *pro_tab;
+    float *pro_out;
 };
 
 }  // namespace qdas

@@ -20,6 +20,26 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
     const uint64_t Ilut = P.i_begin + P.i_count;
     const bool has_st = QSPEC(HAS_ST, P.St != nullptr);
     float a_lo = INFINITY, a_hi = -INFINITY, a_ext = 0.f;            // per-thread partials of tile-wide stats
+    // the plan's cached tables of this tile (tile_params.h pro_tab): loaded instead of computed; pro_out (plan creation, probe kernels): computed AND stored
+    const size_t pro_stride = 2 * ((size_t)M + N) + 8;
+    const uint32_t tile_slot = tile_id - P.tiles_z * P.tile_x0;
+    const float *ptab = nullptr;
+    if constexpr (!PROBE && !LUT) { if (P.pro_tab) ptab = P.pro_tab + (size_t)tile_slot * pro_stride; }
+    float b_lo = INFINITY, b_hi = -INFINITY, b_ext = 0.f;
+    if (ptab) {
+        if constexpr (!SYM) {
+            for (uint32_t m = tid; m < M; m += THREADS) { Abase[m] = __float_as_int(ptab[2 * m]); Aext[m] = ptab[2 * m + 1]; }
+        }
+        for (uint32_t n = tid; n < N; n += THREADS) {
+            const float bb = ptab[2 * ((size_t)M + n)], e = ptab[2 * ((size_t)M + n) + 1];
+            if constexpr (C::F64) nrec64[n] = rec64{gPr[3 * n], gPr[3 * n + 1], gPr[3 * n + 2], __float_as_int(bb), 0};
+            else nrec[n] = make_float4(bb, gPr[3 * n], gPr[3 * n + 1], gPr[3 * n + 2]);
+            Bext[n] = e;
+            if constexpr (SYM) { Abase[n] = __float_as_int(bb) + symCi; Aext[n] = e + 1.0f; }
+        }
+        const float *st6 = ptab + 2 * ((size_t)M + N);
+        a_lo = st6[0]; b_lo = st6[1]; a_hi = st6[2]; b_hi = st6[3]; a_ext = st6[4]; b_ext = st6[5];
+    } else {
     // The window bases / extents only need the delays to a small fraction of a sample: fp32 estimates with an explicit error
     // margin (DLT, below) -- a quarter of the fp64 cost.  Focused transmits keep fp64: their delay flips sign with
     // (Pi - Pv).Nv (copysign, src/bf.cu:107) and the two precisions must agree on the sign of a dot product that may be ~0.
@@ -86,7 +106,6 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
         __syncthreads();
       }
     }
-    float b_lo = INFINITY, b_hi = -INFINITY, b_ext = 0.f;
     for (uint32_t c0 = 0; c0 < N; c0 += PCH) {
       const uint32_t c1 = c0 + PCH < N ? c0 + PCH : N;
       for (uint32_t n = c0; n < c1; n += 4) {
@@ -131,6 +150,19 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
         const float *q = part + w * 8;
         a_lo = fminf(a_lo, q[0]); b_lo = fminf(b_lo, q[1]); a_hi = fmaxf(a_hi, q[2]); b_hi = fmaxf(b_hi, q[3]);
         a_ext = fmaxf(a_ext, q[4]); b_ext = fmaxf(b_ext, q[5]);
+    }
+    }       // (!ptab)
+    if constexpr (PROBE && !LUT) {                     // plan creation: this tile's tables go to the plan's buffer (the LDS copies are complete: the loops above end in barriers)
+        if (P.pro_out) {
+            float *o = P.pro_out + (size_t)tile_slot * pro_stride;
+            if constexpr (!SYM) { for (uint32_t m = tid; m < M; m += THREADS) { o[2 * m] = __int_as_float(Abase[m]); o[2 * m + 1] = Aext[m]; } }
+            for (uint32_t n = tid; n < N; n += THREADS) {
+                float bb;
+                if constexpr (C::F64) bb = __int_as_float(nrec64[n].b); else bb = nrec[n].x;
+                o[2 * ((size_t)M + n)] = bb; o[2 * ((size_t)M + n) + 1] = Bext[n];
+            }
+            if (tid == 0) { float *q = o + 2 * ((size_t)M + N); q[0] = a_lo; q[1] = b_lo; q[2] = a_hi; q[3] = b_hi; q[4] = a_ext; q[5] = b_ext; }
+        }
     }
     // every lane's last tap (+1 for the rint/floor ambiguity at exact integers) must be inside the staged window
     if (!(a_ext + b_ext + (float)(K + 1) <= (float)C::W)) {

@@ -67,13 +67,91 @@ def mirror_slab_columns(I2: int, rank: int, world: int) -> Tuple[int, int]:
     return h * rank // world, h * (rank + 1) // world
 
 
-def gather_mirror_slabs(y_local, I1: int, I2: int, world: int, group=None):
+def balanced_column_bounds(cost, world: int):
+    """Column boundaries ``b[0] = 0 <= b[1] <= ... <= b[world] = len(cost)`` that give every rank (nearly) the same share of ``sum(cost)``:
+    ``cost[c]`` = what column ``c`` of the first half of the image (and its mirror image) costs to beamform -- measured per column block by
+    :func:`measure_column_cost`, or any model.  Equal column counts (:func:`mirror_slab_columns`) leave the rank with the outermost columns the
+    slowest: the delay gradient -- and with it the spread of the LDS gathers -- grows away from the array (C3 at 8 ranks: 2.65 ms against
+    2.36 ms, ``profiles/r04/slab_kernel_times_c3.txt``).  Greedy on the cumulative cost at column granularity; every rank gets at least one column
+    while there are columns left; identical on every rank that passes the same ``cost`` (pure, deterministic)."""
+    import numpy as np
+    c = np.asarray(cost, dtype=np.float64).reshape(-1)
+    h = int(c.size)
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    if h == 0:
+        return [0] * (world + 1)
+    if not np.all(np.isfinite(c)) or np.any(c < 0) or c.sum() <= 0:
+        c = np.ones(h)
+    cum = np.concatenate([[0.0], np.cumsum(c)])
+    total = cum[-1]
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        k = int(np.searchsorted(cum, target, side="left"))             # first boundary whose cumulative cost reaches the target ...
+        if k > 0 and abs(cum[k - 1] - target) <= abs(cum[min(k, h)] - target):
+            k -= 1                                                       # ... or the one before it, whichever is closer
+        k = max(k, min(bounds[-1] + 1, h))                              # rank r-1 gets at least one column while there are columns
+        if h >= world:
+            k = min(k, h - (world - r))                                  # ... and so does every rank that follows
+        bounds.append(min(k, h))
+    bounds.append(h)
+    return bounds
+
+
+def expand_block_cost(block_cost, ncols: int):
+    """per-column cost from a per-BLOCK measurement (``len(block_cost)`` equal blocks over ``ncols`` columns): every column of a block takes its block's
+    cost per column"""
+    import numpy as np
+    b = np.asarray(block_cost, dtype=np.float64).reshape(-1)
+    nb = b.size
+    edges = [ncols * k // nb for k in range(nb + 1)]
+    out = np.zeros(ncols)
+    for k in range(nb):
+        w = edges[k + 1] - edges[k]
+        if w > 0:
+            out[edges[k]:edges[k + 1]] = b[k] / w
+    return out
+
+
+def measure_column_cost(prob, device=None, nblocks: int = 8, reps: int = 3, fixed_ms: float | None = None, **plan_kw):
+    """Kernel time [ms] of the mirror-slab plan of each of ``nblocks`` equal column blocks of the first half of the image, on THIS device, minus the
+    per-launch cost that does not depend on the slab (``fixed_ms``; default: estimated as the part of the times that does not scale with the block --
+    the reciprocity fold pass of the whole frame above all).  The channel data are zeros: the kernels' time does not depend on the data.  Costs a few
+    plan creations (~0.1 s each once the kernel is built); meant to run once per geometry, on one rank, and be broadcast (``ShardedDasPlan(balance=...)``)."""
+    import numpy as np
+    import torch
+    from .das_spec import DasPlan, _data_dtype
+    I1, I2, _ = prob.Isz
+    h = I2 // 2
+    nblocks = max(1, min(nblocks, h))
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    xc = torch.zeros((1, prob.M, prob.N, prob.T), dtype=_data_dtype(prob.prec), device=dev)
+    times = []
+    for k in range(nblocks):
+        c0, c1 = h * k // nblocks, h * (k + 1) // nblocks
+        with DasPlan(prob, device=dev, i_begin=c0 * I1, i_count=(c1 - c0) * I1, mirror_slab=True, **plan_kw) as plan:
+            plan.set_timing(True)
+            ks = []
+            for _ in range(reps + 1):
+                plan.execute_colmajor(xc, 1)
+                ks.append(plan.last_kernel_ms())
+            times.append(float(np.median(ks[1:])))
+    t = np.asarray(times)
+    if fixed_ms is None:
+        # blocks have (nearly) equal column counts: what they share is bounded by the cheapest block; half of it is a conservative estimate of the fixed part
+        fixed_ms = 0.5 * float(t.min())
+    return np.maximum(t - fixed_ms, 1e-3 * float(t.max())), t
+
+
+def gather_mirror_slabs(y_local, I1: int, I2: int, world: int, group=None, bounds=None):
     """All-gather the ranks' ``[slab A | slab B]`` outputs (``(..., 2 * count_r)``, one plane) into the image ``(..., I1 * I2)``: one collective
-    (padded to the largest rank), then the slabs A in rank order followed by the slabs B in REVERSE rank order."""
+    (padded to the largest rank), then the slabs A in rank order followed by the slabs B in REVERSE rank order.  ``bounds``: the ranks' column
+    boundaries in the first half (``balanced_column_bounds``); default: equal column counts."""
     import torch
     import torch.distributed as dist
 
-    cols = [mirror_slab_columns(I2, r, world) for r in range(world)]
+    cols = [mirror_slab_columns(I2, r, world) for r in range(world)] if bounds is None else [(int(bounds[r]), int(bounds[r + 1])) for r in range(world)]
     counts = [(c1 - c0) * I1 for c0, c1 in cols]
     cmax = max(counts)
     cplx = y_local.is_complex()
@@ -106,17 +184,25 @@ class ShardedDasPlan:
     """
 
     def __init__(self, prob, rank: int, world: int, group=None, device=None, kernel: int = 0,
-                 compute: Callable | None = None, mirror_slabs: bool | None = None, **plan_kw):
+                 compute: Callable | None = None, mirror_slabs: bool | None = None, balance=None, **plan_kw):
+        """``balance`` (mirror slabs only): per-column (or per-block) cost of the first half of the image -- an array every rank passes identically, e.g. rank 0's
+        :func:`measure_column_cost` after a broadcast -- or ``"measure"``: rank 0 measures it now and broadcasts it.  The ranks then take column ranges
+        of equal COST (:func:`balanced_column_bounds`) instead of equal width."""
         self.prob, self.rank, self.world, self.group = prob, rank, world, group
         self._compute = compute
         self.plan = None
+        self.col_bounds = None
         I1, I2, I3 = prob.Isz
         can = world > 1 and prob.fun == "DAS" and I3 == 1 and I2 % 2 == 0 and I2 >= 2 and plan_kw.get("mirror", True)
         self.mirror_slabs = False
         if mirror_slabs is None:
             mirror_slabs = can and compute is None
         if mirror_slabs and can:
-            c0, c1 = mirror_slab_columns(I2, rank, world)
+            if balance is not None:
+                cost = self._agreed_cost(balance, device, kernel, plan_kw)
+                if cost is not None:
+                    self.col_bounds = balanced_column_bounds(expand_block_cost(cost, I2 // 2), world)
+            c0, c1 = mirror_slab_columns(I2, rank, world) if self.col_bounds is None else (self.col_bounds[rank], self.col_bounds[rank + 1])
             self.i_begin, self.i_count = c0 * I1, (c1 - c0) * I1
             ok = True
             if compute is None and self.i_count:
@@ -147,6 +233,30 @@ class ShardedDasPlan:
             from .das_spec import DasPlan
             self.plan = DasPlan(prob, device=device, kernel=kernel, i_begin=self.i_begin, i_count=self.i_count, **plan_kw)
 
+    def _agreed_cost(self, balance, device, kernel, plan_kw):
+        """the cost profile every rank uses: the caller's array as it is (the caller vouches that the ranks pass the same one), or rank 0's measurement, broadcast"""
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        if not isinstance(balance, str):
+            return np.asarray(balance, dtype=np.float64).reshape(-1)
+        if balance != "measure":
+            raise ValueError("balance: an array of column / block costs, or 'measure'")
+        nb = min(16, max(1, self.prob.Isz[1] // 2))
+        t = torch.zeros(nb, dtype=torch.float64)
+        if self.rank == 0:
+            try:
+                cost, _ = measure_column_cost(self.prob, device=device, nblocks=nb, kernel=kernel, **{k: v for k, v in plan_kw.items() if k != "prefolded"})
+                t = torch.from_numpy(np.asarray(cost, dtype=np.float64))
+            except Exception:                               # (no mirror mode for this problem, no device ...: zeros = "no profile", equal widths)
+                t = torch.zeros(nb, dtype=torch.float64)
+        if dist.is_initialized() and self.world > 1:
+            on_gpu = dist.get_backend(self.group) == "nccl"
+            tt = t.to((device if device is not None else "cuda") if on_gpu else "cpu")
+            dist.broadcast(tt, src=0, group=self.group)
+            t = tt.cpu()
+        return None if float(t.sum()) <= 0 else t.numpy()
+
     def _all_agree(self, ok: bool, device) -> bool:
         import torch
         import torch.distributed as dist
@@ -176,7 +286,7 @@ class ShardedDasPlan:
 
     def gather(self, y):
         if self.mirror_slabs:
-            return gather_mirror_slabs(y, self.prob.Isz[0], self.prob.Isz[1], self.world, self.group)
+            return gather_mirror_slabs(y, self.prob.Isz[0], self.prob.Isz[1], self.world, self.group, bounds=self.col_bounds)
         return gather_pixels(y, self.prob.I, self.world, self.group)
 
     def execute_colmajor(self, xc, F: int = 1):

@@ -28,6 +28,7 @@ def _worker(rank, world, port, cases, q):
         from qups_amd.dist import ShardedDasPlan
         for fun, I1, I2, *rest in cases:
             mirror_slabs = bool(rest and rest[0])
+            balance = rest[1] if len(rest) > 1 else None
             case = make_case(seq="PW", interp="linear", seed=3, N=4, M=3, I1=I1, I2=I2)
             x = torch.from_numpy(case["x"])
             opts = parse_options(x, list(case["opt"]) + ["interp", "linear"])
@@ -40,7 +41,7 @@ def _worker(rank, world, port, cases, q):
             def compute(xc, F, b, c, full_cm=full_cm):   # the slab a GPU rank would produce: (1, oM, oN, count)
                 return full_cm[..., b:b + c].contiguous()
 
-            plan = ShardedDasPlan(prob, rank, world, compute=compute, mirror_slabs=mirror_slabs)
+            plan = ShardedDasPlan(prob, rank, world, compute=compute, mirror_slabs=mirror_slabs, balance=balance)
             y = plan.execute_colmajor(x.permute(2, 1, 0).contiguous(), 1)
             ok = bool(torch.equal(y, full_cm)) and tuple(y.shape) == (1, oM, oN, prob.I) and plan.mirror_slabs == mirror_slabs
             q.put((rank, fun, I1 * I2, ok, plan.i_begin, plan.i_count))
@@ -150,6 +151,62 @@ def test_mirror_slab_gather_gloo(world):
         assert spans[0][0] == 0 and sum(c for _, c in spans) == I1 * I2 // 2            # the slabs A tile the first half of the columns
         for (b0, c0), (b1, _) in zip(spans, spans[1:]):
             assert b0 + c0 == b1 and b0 % I1 == 0
+
+
+BALANCED_CASES = [("DAS", 9, 10, True, [5.0, 1.0, 1.0, 1.0, 1.0]),                      # 5 half-columns, the outermost five times as expensive: ragged at 2 and 3 ranks
+                  ("DAS", 4, 16, True, [3.0, 1.0]),                                     # a per-BLOCK profile (2 blocks over 8 half-columns)
+                  ("DAS", 6, 4, True, [1.0, 1.0]),                                      # fewer half-columns than ranks at world 3
+                  ("DAS", 5, 14, True, "measure")]                                      # rank 0 "measures" (no device here: no profile) -> equal widths, agreed by broadcast
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_balanced_mirror_slabs_gloo(world):
+    """mirror slabs of equal COST instead of equal width (``ShardedDasPlan(balance=...)``, ``balanced_column_bounds``): the ranks derive the same
+    ragged column boundaries from the same profile, the padded all_gather lays the unequal slabs out as A_0 .. A_{G-1} B_{G-1} .. B_0 -- the image is the whole-image
+    plan's bit for bit"""
+    from qups_amd.dist import balanced_column_bounds, expand_block_cost
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, BALANCED_CASES, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world * len(BALANCED_CASES))]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[3] for r in res), res
+    for fun, I1, I2, _, cost in BALANCED_CASES:
+        spans = sorted((b, c) for _, f, I, _, b, c in res if f == fun and I == I1 * I2)
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == I1 * I2 // 2
+        for (b0, c0), (b1, _) in zip(spans, spans[1:]):
+            assert b0 + c0 == b1 and b0 % I1 == 0
+        if not isinstance(cost, str):
+            want = balanced_column_bounds(expand_block_cost(cost, I2 // 2), world)
+            assert [b // I1 for b, _ in spans] == want[:-1], (spans, want)
+    # the expensive outer column got a rank of its own; the profile changed the layout
+    first = sorted((b, c) for _, f, I, _, b, c in res if I == 90)
+    assert first[0][1] == 9 and len({c for _, c in first}) > 1, first
+
+
+def test_balanced_column_bounds_properties():
+    from qups_amd.dist import balanced_column_bounds, expand_block_cost
+    rng = np.random.default_rng(0)
+    for _ in range(500):
+        h, w = int(rng.integers(0, 40)), int(rng.integers(1, 10))
+        c = rng.uniform(0, 1, h) ** 3
+        b = balanced_column_bounds(c, w)
+        assert len(b) == w + 1 and b[0] == 0 and b[-1] == h and all(b[i] <= b[i + 1] for i in range(w))
+        if h >= w:
+            assert all(b[i] < b[i + 1] for i in range(w))               # nobody idle while there are columns
+    # a smooth profile is balanced to within one column's cost
+    c = 1 + 0.15 * np.linspace(1, 0, 512)
+    b = balanced_column_bounds(c, 8)
+    share = [c[b[i]:b[i + 1]].sum() for i in range(8)]
+    assert max(share) - min(share) <= 2 * c.max() and b != [64 * k for k in range(9)]
+    assert balanced_column_bounds(np.ones(512), 8) == [64 * k for k in range(9)]       # a flat profile: equal widths
+    assert balanced_column_bounds([np.nan, 1.0], 2) == [0, 1, 2] and balanced_column_bounds([], 3) == [0, 0, 0, 0]
+    assert np.allclose(expand_block_cost([2, 1], 5), [1, 1, 1 / 3, 1 / 3, 1 / 3])
 
 
 def _fold_np(x):

@@ -313,3 +313,21 @@ def test_bench_shared_gpu_folded_replication_stream(tmp_path):
     assert two["n_gpus"] == 2 and fs and isinstance(fs["ms_per_step"], float), two["multi_gpu"]
     assert fs["bytes_per_frame"] == 256 * 257 // 2 * 2816 * 8 and fs["bytes_per_frame"] * 2 < two["multi_gpu"]["x_bytes"] * 1.01
     assert fs["image_vs_headline"] <= 1e-6, fs
+
+
+def test_bench_shared_gpu_prefolded_timed_region_and_balanced_slabs(tmp_path):
+    """VERDICT r4 item 5 on one GPU shared by two ranks (gloo): ``bench.py --gpus 2 --prefolded`` hands the timed region FOLDED frames (folded once by rank 0, the packed
+    upper triangle replicated, QDAS_PLAN_PREFOLDED mirror-slab plans), reports the fold + replication time beside it, the column ranges of equal measured cost and who
+    was in the process group; the image is the folding run's bit for bit."""
+    env = {"QDAS_CACHE_DIR": str(tmp_path), "QDAS_BENCH_SHARE_GPU": "1"}
+    common = ["--gpus", "2", "--workload", "c3", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-traffic", "--no-general", "--checksum"]
+    plain = _bench(common, env)
+    pre = _bench(common + ["--prefolded"], env)
+    mg = pre["multi_gpu"]
+    assert pre["n_gpus"] == 2 and mg["prefolded_timed_region"] is True and isinstance(mg["fold_and_replicate_ms"], float) and mg["fold_and_replicate_ms"] > 0, mg
+    assert plain["multi_gpu"]["prefolded_timed_region"] is False
+    assert [r["rank"] for r in mg["ranks_seen"]] == [0, 1] and all("name" in r for r in mg["ranks_seen"]), mg["ranks_seen"]
+    cols = mg["slab_columns"]
+    assert cols and cols[0] == 0 and cols[-1] == 512 and 0 < cols[1] < 512, cols               # two ranks: columns [0, c) and [c, 512) of the first half, by measured cost
+    assert "equal measured cost" in mg["slab_layout"]
+    assert pre["image_checksum"] == plain["image_checksum"]
