@@ -151,6 +151,7 @@ template <class C> struct Tile {
     unsigned char *wst; uint32_t wst_off;            // stage weights (TileCfg::WST), and their LDS byte address
     uint2 *act;                                      // [N + 1] {receiver, its window base B} of the receivers with a non-zero weight somewhere in the tile, then {count, -} (pixel x receiver weights)
     uint32_t split, S, tile_id;
+    uint32_t Sm, sm;                   // transmit-block groups of a two-dimensional split (tile_params.h ksplit_m) and mine; 1, 0 otherwise
     double fs, symC; int symCi;
     bool tile_interior;
     // ---- this lane's pixel
@@ -199,6 +200,7 @@ template <class C> struct Tile {
     // aperture share
     __device__ __forceinline__ uint32_t blk(uint32_t r) const {          // first transmit of my r-th block (>= M: exhausted)
         if constexpr (C::SYM) return (r * S + ((r & 1u) ? S - 1u - split : split)) * C::MB;
+        else if constexpr (C::ACT) return (r * Sm + sm) * C::MB;
         else return r * C::MB;
     }
     __device__ __forceinline__ uint32_t nlim(uint32_t m0) const { return C::SYM ? (m0 + C::MB < N ? m0 + C::MB : N) : n_hi; }
@@ -458,6 +460,7 @@ template <class C> __device__ __forceinline__ v2f Tile<C>::wconv(wraw r) const {
 template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
     n_lo = C::SYM ? 0u : (uint32_t)((uint64_t)N * split / S);
     n_hi = (uint32_t)((uint64_t)N * (split + 1) / S);
+    Sm = 1u; sm = 0u;
     acc = acc1 = acc2 = acc3 = (v2f){0.f, 0.f};
     dacc[0] = dacc[1] = dacc[2] = dacc[3] = 0.0;
 #pragma unroll
@@ -483,14 +486,22 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
             use_act = true;
             // a split aperture: the workgroups of a tile take every S-th receiver instead of contiguous ranges -- the receivers that carry
             // weight form a band (acceptance angle, f-number), which a contiguous split hands to ONE of the workgroups
-            const bool inter = S > 1 && !QSPEC(SYN, P.syn);
-            const uint32_t a_first = inter ? split : n_lo, a_step = inter ? S : 1u;
+            const bool wmode = P.pro_mask == 2;        // (plan creation's mask pass: ALL stage elements, whatever split the kernel was built for)
+            if (wmode) { n_lo = 0; n_hi = N; }
+            const bool inter = !wmode && S > 1 && !QSPEC(SYN, P.syn);
+            // two-dimensional split (tile_params.h ksplit_m): my transmit-block group, and my class of stage elements among S / Sm
+            if (inter && P.ksplit_m > 1u) { Sm = P.ksplit_m; sm = split % Sm; }
+            const uint32_t Sn = S / Sm, sn = split / Sm;
+            const uint32_t a_first = inter ? sn : n_lo, a_step = inter ? Sn : 1u;
             if (inter) { n_lo = 0; n_hi = N; }
-            const uint32_t a_cnt = inter ? (N > split ? (N - split + S - 1) / S : 0u) : n_hi - n_lo;
+            const uint32_t a_cnt = inter ? (N > sn ? (N - sn + Sn - 1) / Sn : 0u) : n_hi - n_lo;
             uint32_t *flg = (uint32_t *)part;          // prologue scratch (the windows are not in use yet)
-            for (uint32_t k = tid; k < (N + 31) / 32; k += C::THREADS) flg[k] = 0u;
+            // the plan's cached activity mask of this tile (tile_params.h pro_mask): loaded instead of found
+            const uint32_t *cmask = (P.pro_tab && P.pro_mask == 1) ? (const uint32_t *)(P.pro_tab + (size_t)(tile_id - P.tiles_z * P.tile_x0) * (2 * ((size_t)M + N) + 8 + (N + 31) / 32) + 2 * ((size_t)M + N) + 8) : nullptr;
+            for (uint32_t k = tid; k < (N + 31) / 32; k += C::THREADS) flg[k] = cmask ? cmask[k] : 0u;
             __syncthreads();
-            if (QSPEC(GEN_KIND, P.gen_kind) != 0) {   // generated weights: arithmetic only (ONE call site of the out-of-line rule)
+            if (cmask) {}
+            else if (QSPEC(GEN_KIND, P.gen_kind) != 0) {   // generated weights: arithmetic only (ONE call site of the out-of-line rule)
                 for (uint32_t k = 0; k < a_cnt; ++k) {
                     const uint32_t n = a_first + a_step * k;
                     const v2f w = wload(n);
@@ -516,6 +527,12 @@ template <class C> __device__ __forceinline__ void Tile<C>::plan_stages() {
                 }
             }
             __syncthreads();
+            if (wmode) {                                // plan creation (qdas_api.hip plan_cache_activity): the tile's mask over ALL stage elements goes to the plan's table; nothing else runs
+                uint32_t *o = (uint32_t *)(P.pro_out + (size_t)(tile_id - P.tiles_z * P.tile_x0) * (2 * ((size_t)M + N) + 8 + (N + 31) / 32) + 2 * ((size_t)M + N) + 8);
+                for (uint32_t k = tid; k < (N + 31) / 32; k += C::THREADS) o[k] = flg[k];
+                nact = 0; nstage = 0;
+                return;
+            }
             if (tid == 0) {
                 uint32_t cnt = 0;
                 for (uint32_t k = 0; k < a_cnt; ++k) {
@@ -875,6 +892,7 @@ template <class C, bool PROBE> __device__ __forceinline__ void das_tile_body(con
     if constexpr (!PROBE) {
         t.timer.prologue_done();
         t.plan_stages();
+        if (P.pro_mask == 2) return;                    // (uniform: the mask pass of plan creation ends here)
         if (t.tile_interior) t.template run<false>(); else t.template run<true>();
         t.timer.finish(t.lane, t.wave, C::WAVES);
         t.epilogue();

@@ -71,6 +71,7 @@ struct Switches {
          no_w64 = false, no_mirror_wpix = false, no_mirror_wpix32 = false, no_side_split = false, no_wide = false, no_fb2 = false, no_fb4 = false, no_fold16 = false;
     double sym_tol = -1.0;      // QDAS_SYM_TOL in [0, 0.5], else < 0
     int ksplit = 0;             // QDAS_KSPLIT in 1..8, else 0
+    int ksplit_m = 0;           // QDAS_KSPLIT_M in 1..8 (transmit-block groups of a two-dimensional split), else 0
 };
 
 // ---- 1. what the descriptor asks for
@@ -378,6 +379,25 @@ inline unsigned choose_ksplit(unsigned ntiles, unsigned cus, uint64_t M, int mb,
         while (ks * 2 <= cap && (uint64_t)ntiles * ks < 8ull * cus && kN_eff / (ks * 2) >= 16) ks *= 2;
     if (sw.ksplit >= 1 && sw.ksplit <= 8 && (unsigned)sw.ksplit <= cap) ks = (unsigned)sw.ksplit;
     return ks;
+}
+
+// Plans with a stage list (pixel x stage-element weights): the split is two-dimensional (tile_params.h ksplit_m) -- first over the TRANSMIT BLOCKS, so that a
+// workgroup refreshes its block residuals once or twice instead of once per handful of stages, then over interleaved classes of stage elements.  Returns the
+// number of transmit-block groups and adjusts *ksplit to groups x classes (<= 8).  QDAS_KSPLIT (a forced split) keeps the one-dimensional split unless
+// QDAS_KSPLIT_M says otherwise.
+inline unsigned choose_ksplit_m(uint32_t *ksplit, uint64_t tM, int mb, bool sym, bool stage_list, bool syn, int dtype, const Switches &sw) {
+    if (!stage_list || syn || sym || dtype == QDAS_F64 || *ksplit <= 1) return 1;
+    const unsigned nblk = (unsigned)((tM + (uint64_t)mb - 1) / (uint64_t)mb);
+    if (sw.ksplit_m >= 1) {                              // forced: must divide the split
+        const unsigned f = (unsigned)sw.ksplit_m;
+        return (f <= nblk && *ksplit % f == 0) ? f : 1;
+    }
+    if (sw.ksplit >= 1 || nblk < 2) return 1;
+    const unsigned sm = nblk < 8u ? nblk : 8u;           // a group per transmit block (at most 8) ...
+    unsigned sn = *ksplit / sm;                          // ... times as many classes of stage elements as the chosen split leaves room for
+    if (sn < 1) sn = 1;
+    *ksplit = sm * sn;
+    return sm;
 }
 
 // ---- 5. frames per launch of a stream

@@ -438,6 +438,7 @@ static modes::Switches read_switches() {
     sw.no_fb2 = on("QDAS_NO_FB2"); sw.no_fb4 = on("QDAS_NO_FB4"); sw.no_fold16 = on("QDAS_NO_FOLD16");
     if (const char *e = getenv("QDAS_SYM_TOL")) { const double v = atof(e); if (v >= 0.0 && v <= 0.5) sw.sym_tol = v; }
     if (const char *e = getenv("QDAS_KSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 8) sw.ksplit = v; }
+    if (const char *e = getenv("QDAS_KSPLIT_M")) { const int v = atoi(e); if (v >= 1 && v <= 8) sw.ksplit_m = v; }
     return sw;
 }
 
@@ -886,6 +887,7 @@ static int plan_split_aperture(qdas_plan *pl, PlanBuild &b) {
     HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device));
     const unsigned cus = ncu > 0 ? (unsigned)ncu : 256u;
     t.ksplit = modes::choose_ksplit(pl->ntiles, cus, z.M, pl->tc.mb, t.sym != 0, b.kN_eff, t.act_bytes != 0, t.syn != 0, b.sw);
+    t.ksplit_m = modes::choose_ksplit_m(&t.ksplit, t.M, pl->tc.mb, t.sym != 0, t.act_bytes != 0, t.syn != 0, z.dtype, b.sw);
     if (t.ksplit > 1 && !t.bf) {
         void *pb;
         if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)t.ksplit * 4 * pl->i_count * (t.mir == 2 ? 2 : 1)))) return rc;   // x4: up to four frames per launch (fp64 data: one complex128 frame -- fits as well)
@@ -1032,20 +1034,40 @@ static int plan_cache_prologue(qdas_plan *pl) {
     TileParams &t = pl->tp;
     t.pro_tab = nullptr; t.pro_out = nullptr;
     if (getenv("QDAS_NO_PRO_TAB") || !pl->ntiles) return QDAS_OK;
-    const size_t stride = 2 * ((size_t)t.M + t.N) + 8, bytes = (size_t)pl->ntiles * stride * sizeof(float);
+    t.pro_mask = 0;
+    const bool with_mask = t.act_bytes != 0 && !getenv("QDAS_NO_PRO_MASK");      // (a stage list: the tile's activity mask rides behind the statistics, plan_cache_activity)
+    const size_t stride = 2 * ((size_t)t.M + t.N) + 8 + (with_mask ? (t.N + 31) / 32 : 0), bytes = (size_t)pl->ntiles * stride * sizeof(float);
     if (bytes > (1ull << 30)) return QDAS_OK;           // (thousands of elements x tens of thousands of tiles: not worth a GiB)
     void *buf = nullptr;
     if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); return QDAS_OK; }      // (no memory for it: the kernels compute their tables themselves)
     pl->owned.push_back(buf);
     TileParams p = t;
-    p.probe = 1; p.x = nullptr; p.y = nullptr; p.wtab = nullptr; p.apix = nullptr; p.pro_out = (float *)buf;
+    p.probe = 1; p.x = nullptr; p.y = nullptr; p.wtab = nullptr; p.apix = nullptr; p.pro_out = (float *)buf; p.pro_mask = with_mask ? 1 : 0;
     HIPCHK(hipMemsetAsync(buf, 0, bytes, 0));
     const hipError_t e = launch_tile(p, pl->d.sz.dtype, pl->ntiles, nullptr);
     if (e != hipSuccess) { (void)hipGetLastError(); return QDAS_OK; }      // (a configuration without a probe kernel: as before)
     HIPCHK(hipStreamSynchronize(nullptr));
     HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));      // (the probe re-listed the misfit tiles: the frame kernels list them per launch)
     t.pro_tab = (const float *)buf;
+    t.pro_mask = with_mask ? 3 : 0;                     // (3: room for the masks, not yet written -- plan_cache_activity, once the plan's kernel is resolved)
     return QDAS_OK;
+}
+
+// The tiles' activity masks (tile_params.h pro_mask): ONE launch of the plan's own kernel in mask mode -- every tile tests all its stage elements with exactly
+// the rule the frames use (array / generated / side weights, the mirror image's share) and stores the mask; the frame kernels then load it instead of
+// re-loading up to N weights per lane, workgroup and execute.  Any failure: the plan runs without the tables.
+static void plan_cache_activity(qdas_plan *pl) {
+    TileParams &t = pl->tp;
+    if (pl->kernel != QDAS_KERNEL_TILED || t.pro_mask != 3) return;
+    TileParams p = t;
+    p.nfr = 1; p.x = nullptr; p.y = nullptr; p.ksplit = 1; p.ksplit_m = 1; p.part = nullptr; p.pro_mask = 2; p.pro_out = const_cast<float *>(t.pro_tab);
+    const std::string keep = g_err;
+    hipError_t e = launch_tile(p, pl->d.sz.dtype, pl->ntiles, nullptr, pl->jit_fn, pl->jit_lds);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e == hipSuccess && !pl->no_fallback) e = hipMemset(pl->fallback, 0, sizeof(uint32_t));
+    g_err = keep;
+    if (e == hipSuccess) t.pro_mask = 1;
+    else { (void)hipGetLastError(); t.pro_mask = 0; t.pro_tab = nullptr; }      // (the table's stride counted the masks: without them, no table)
 }
 
 // the tiled kernel's side of a plan: parameter block, weights, probed shape, split aperture -- then checked against the model of plan_modes.h
@@ -1113,6 +1135,7 @@ static int plan_create_impl(qdas_plan *pl, qdas_plan **out, const qdas_desc *des
         if (rc2 == QDAS_OK) g_err = why + " -- using the generic kernel";
         return rc2;
     }
+    plan_cache_activity(pl);
     return plan_finish(pl, desc, b);
 }
 

@@ -75,6 +75,15 @@ struct TileParams {
     // {a_lo, b_lo, a_hi, b_hi, a_ext, b_ext}.  Tile slot = tz + tiles_z * (column tile - tile_x0).  Null: computed in the kernel, as before.
     const float *pro_tab;
     float *pro_out;
+    // ... and, for plans with a pixel x stage-element weight, the tile's ACTIVITY MASK behind the statistics: ceil(N / 32) words, bit n = stage element n carries
+    // weight for some pixel of the tile (or, lateral-mirror mode, for the mirror image of one) -- what plan_stages() found by loading every candidate's weights in
+    // every workgroup of every execute.  pro_mask = 1: the table holds it (stride 2 (M + N) + 8 + ceil(N / 32) floats).
+    int32_t pro_mask;
+    // TWO-DIMENSIONAL SPLIT of the aperture (plans with a stage list): the ksplit workgroups of a tile are ksplit_m groups over the TRANSMIT BLOCKS (group g takes
+    // blocks g, g + ksplit_m, ...) times ksplit / ksplit_m interleaved classes of stage elements.  A workgroup that owns few transmit blocks refreshes the block
+    // residuals (one fp64 delay per pixel and transmit) rarely -- BASELINE C5 with 8 receiver classes x all 6 blocks: a refresh every 3.4 stages, 9-15 % of the
+    // kernel; one block per workgroup: once.  0 / 1: the one-dimensional split.
+    uint32_t ksplit_m;
 };
 
 }  // namespace qdas

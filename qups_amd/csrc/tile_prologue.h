@@ -21,7 +21,7 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
     const bool has_st = QSPEC(HAS_ST, P.St != nullptr);
     float a_lo = INFINITY, a_hi = -INFINITY, a_ext = 0.f;            // per-thread partials of tile-wide stats
     // the plan's cached tables of this tile (tile_params.h pro_tab): loaded instead of computed; pro_out (plan creation, probe kernels): computed AND stored
-    const size_t pro_stride = 2 * ((size_t)M + N) + 8;
+    const size_t pro_stride = 2 * ((size_t)M + N) + 8 + (P.pro_mask ? (N + 31) / 32 : 0);
     const uint32_t tile_slot = tile_id - P.tiles_z * P.tile_x0;
     const float *ptab = nullptr;
     if constexpr (!PROBE && !LUT) { if (P.pro_tab) ptab = P.pro_tab + (size_t)tile_slot * pro_stride; }

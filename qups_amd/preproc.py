@@ -12,6 +12,39 @@ import numpy as np
 from . import _lib
 
 
+# Plans by shape: a qdas_pre_plan owns its twiddles -- and, for record lengths the one-pass kernel does not take (a prime factor above 13, more than 8192
+# samples), two hipFFT plans and three work buffers whose creation costs 11-15 ms (profiles/r04/general_time.txt) against 0.1-0.7 ms of transform.  A frame
+# loop calls hilbert() with ONE shape: the last few plans are kept, destroyed on eviction and at interpreter exit.
+_PLANS: "dict[tuple, C.c_void_p]" = {}
+_PLAN_CACHE_MAX = 8
+_plans_lock = __import__("threading").Lock()
+
+
+def clear_pre_plan_cache():
+    with _plans_lock:
+        L = _lib.lib() if _PLANS else None
+        for h in _PLANS.values():
+            L.qdas_pre_plan_destroy(h)
+        _PLANS.clear()
+
+
+__import__("atexit").register(lambda: clear_pre_plan_cache() if _PLANS else None)
+
+
+def _pre_plan(key, d):
+    """the cached plan of this shape (created on a miss; the oldest entry is evicted beyond _PLAN_CACHE_MAX); call with _plans_lock held"""
+    L = _lib.lib()
+    h = _PLANS.pop(key, None)
+    if h is None:
+        h = C.c_void_p()
+        _lib.check(L.qdas_pre_plan_create(C.byref(h), C.byref(d)))
+        hilbert.plans_created = getattr(hilbert, "plans_created", 0) + 1
+    _PLANS[key] = h                                                  # (most recently used last)
+    while len(_PLANS) > _PLAN_CACHE_MAX:
+        L.qdas_pre_plan_destroy(_PLANS.pop(next(iter(_PLANS))))
+    return h
+
+
 def hilbert(x, N: int | None = None, fdown: float = 0.0, t0: float = 0.0, fs: float | None = None, device=None):
     """Analytic signal along dim 0 of real ``x`` (``T x ...``; float32 or int16; numpy array or torch tensor), transform length
     ``N`` (default ``T``; zero-padded or truncated like MATLAB's ``hilbert(x, N)``); with ``fdown`` the result is also multiplied by
@@ -43,14 +76,11 @@ def hilbert(x, N: int | None = None, fdown: float = 0.0, t0: float = 0.0, fs: fl
     d = _lib.PreDesc(T, K, N, _lib.QDAS_PRE_I16 if xt.dtype == torch.int16 else _lib.QDAS_PRE_F32,
                      dev.index if dev.index is not None else torch.cuda.current_device(), float(fs or 0.0), float(t0), float(fdown))
     L = _lib.lib()
-    h = C.c_void_p()
-    with torch.cuda.device(dev):
-        _lib.check(L.qdas_pre_plan_create(C.byref(h), C.byref(d)))
+    key = (T, K, N, int(d.in_type), int(d.device), float(d.fs), float(d.t0), float(d.fdown), __import__("os").environ.get("QDAS_PRE_HIPFFT"))      # (the switch is read at plan creation: part of the key)
+    with torch.cuda.device(dev), _plans_lock:                       # (the lock also serialises executes on one plan: its hipFFT work buffers are the plan's)
+        h = _pre_plan(key, d)
         hilbert.last_one_pass = bool(L.qdas_pre_plan_one_pass(h))   # which path served the last call (tests / tools)
-        try:
-            _lib.check(L.qdas_pre_execute(h, C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()),
-                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-            torch.cuda.current_stream().synchronize()
-        finally:
-            L.qdas_pre_plan_destroy(h)
+        _lib.check(L.qdas_pre_execute(h, C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.current_stream().synchronize()
     return y.t().reshape((N,) + rest)

@@ -193,3 +193,30 @@ def test_hilbert_random_lengths_and_batches(seed):
     ref = hilbert_ref(xq.astype(np.float64), N, fdown, t0, fs)
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() / max(np.abs(ref).max(), 1e-30) <= 3e-5, (N, T, K, i16, fdown, hilbert.last_one_pass)
+
+
+@pytest.mark.gpu
+def test_hilbert_plans_are_cached_by_shape(monkeypatch):
+    """a frame loop calls ``hilbert`` with ONE record shape -- the plan (for lengths outside the one-pass kernel: two hipFFT plans and three work
+    buffers, 11-15 ms to create) is made once and reused; another shape, another plan; the cache is bounded; results do not depend on it."""
+    import torch
+    from qups_amd import preproc
+    from qups_amd.preproc import hilbert
+    monkeypatch.setenv("QDAS_PRE_HIPFFT", "1")                        # (the hipFFT passes: where plan creation dominated)
+    preproc.clear_pre_plan_cache()
+    hilbert.plans_created = 0
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.standard_normal((1031, 24)).astype(np.float32)).cuda()      # 1031 is prime: never the one-pass kernel
+    y0 = hilbert(x)
+    for _ in range(5):
+        y = hilbert(x)
+    assert hilbert.plans_created == 1 and not hilbert.last_one_pass and torch.equal(y, y0)
+    hilbert(x[:, :7].contiguous())
+    assert hilbert.plans_created == 2
+    for k in range(preproc._PLAN_CACHE_MAX + 2):                       # more shapes than the cache holds: the oldest are destroyed, the newest stay
+        hilbert(x[: 500 + k].contiguous())
+    assert len(preproc._PLANS) == preproc._PLAN_CACHE_MAX
+    ref = np.asarray(__import__("scipy.signal", fromlist=["hilbert"]).hilbert(x.cpu().numpy().astype(np.float64), axis=0))
+    assert np.abs(y0.cpu().numpy() - ref).max() / np.abs(ref).max() <= 3e-5
+    preproc.clear_pre_plan_cache()
+    assert not preproc._PLANS
