@@ -928,6 +928,7 @@ static int plan_jit(qdas_plan *pl, const qdas_desc *desc, int *remake) {
         if (mb >= 2 && mb % k.waves == 0 && (!t.sym || t.fold || z.M % (uint64_t)mb == 0) && (!mirq || t.fold)) k.mb = mb;
     }
     if (const char *e = getenv("QDAS_JIT_NBUF")) { const int nb = atoi(e); if (nb >= 2 && nb <= 4) k.nbuf = nb; }
+    if (const char *e = getenv("QDAS_JIT_W")) { const int wv = atoi(e); if (wv >= 64 && wv <= 1024 && wv % 64 == 0) k.w = wv; }      // (experiments: tiles that do not fit go to the generic kernel)
     {
         const size_t MX = std::min<size_t>(t.M > t.N ? t.M : t.N, QDAS_PROLOGUE_CHUNK);
         const size_t off_act = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + 15) & ~(size_t)15;   // Tile::setup
