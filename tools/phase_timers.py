@@ -45,3 +45,11 @@ for wv, lab in ((0, "wave 0"), (1, "wave 15")):
         print(f"   {names[k]:18s} {b[:, wv, k].mean():12.0f} ticks  {100 * b[:, wv, k].mean() / tot:5.1f} %   per stage {b[:, wv, k].mean() / b[:, wv, 6].mean():8.2f}")
     rest = tot - b[:, wv, :5].sum(1).mean()
     print(f"   {'unaccounted':18s} {rest:12.0f} ticks  {100 * rest / tot:5.1f} %")
+# distribution of the workgroups' lifetimes (wave 0): how uneven are the tiles?  (a kernel with W workgroups per CU-slot ends when the slowest chain does)
+tot0 = b[:, 0, 5]
+q = np.percentile(tot0, [0, 5, 25, 50, 75, 95, 100])
+print("workgroup lifetime percentiles (0/5/25/50/75/95/100):", " ".join(f"{v:.0f}" for v in q), f" max/mean {tot0.max() / tot0.mean():.3f}")
+nz = plan.tile_shape()
+if os.environ.get("QDAS_PT_DUMP"):
+    np.save(os.environ["QDAS_PT_DUMP"], b)
+

@@ -5,7 +5,7 @@
 # headline and the other BASELINE configurations, and the register tables of the prebuilt kernels AND of the hiprtc builds the
 # benches ran (their code objects are in this run's private cache directory).
 set -u
-R=${1:-r04}
+R=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/profiles_$R
 mkdir -p $OUT
@@ -75,6 +75,7 @@ PYEOF
 rm -rf $OUT/trace_general
 # ---- one rank's slab on one GPU (NOT a scaling curve), the issue-cost microbenchmark, the ablation of the headline kernel
 python tools/slab_scaling.py c3 2>/dev/null | grep -v amdgpu.ids > $OUT/slab_kernel_times_c3.txt
+python tools/issue_rates.py 2>/dev/null | grep -v amdgpu.ids > $OUT/issue_rates.txt
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/microbench_src/issue.hip -o /tmp/qdas_issue 2>/dev/null && /tmp/qdas_issue > $OUT/issue_costs.txt 2>&1
 { echo "# tools/abl_sweep.sh: hiprtc builds with QDAS_JIT_DEFINES=QDAS_ABL=<bits> (tile_hooks.h), interleaved rounds, kernel ms (fold pass included).  Bits: 1 no LDS-DMA, 4 taps from registers,";
   echo "# 8 trivial weights, 16 no end-of-stage wait / barrier, 256 plain instead of software-pipelined pair loop, 1024 no late DMA, 2048 no priority staircase.";
