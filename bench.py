@@ -286,8 +286,9 @@ def main():
     ap.add_argument("--rx-apod-array", action="store_true", help="with --rx-apod: pass the MATERIALISED I x N array instead of the in-kernel rule "
                     "(with --tx-apod: a transmit-side rule and a receive-side mask together -- per-pair pixel weights)")
     ap.add_argument("--prec", default=None, help="override the workload's data precision (single | halfT | double); not the headline")
-    ap.add_argument("--no-balance", action="store_true", help="--gpus N > 1: mirror slabs of equal WIDTH instead of equal measured COST (default: rank 0 times the column "
-                    "blocks of the first half once at plan creation, broadcasts the profile, every rank takes columns of equal cost: qups_amd.dist balanced_column_bounds)")
+    ap.add_argument("--balance", action="store_true", help="--gpus N > 1: mirror slabs of equal measured COST instead of equal width (rank 0 times the column blocks of the first "
+                    "half once at plan creation, broadcasts the profile; boundaries in multiples of the 32-column tiles: qups_amd.dist balanced_column_bounds).  Off by default: "
+                    "at C3 the ranks' slabs are one tile round each and whole tiles are too coarse to trade (profiles/r05/slab_kernel_times_c3.txt)")
     ap.add_argument("--prefolded", action="store_true", help="--gpus N > 1, reciprocal fp32 workloads: the timed region is handed FOLDED frames (folded once per acquisition by rank 0 "
                     "and replicated as the packed upper triangle, outside the timed region; QDAS_PLAN_PREFOLDED plans: no per-rank fold pass -- the fixed ~0.4 ms per rank that "
                     "does not shrink with the slab).  Reported as such (config.prefolded_timed_region), with the fold + replication time beside it; not the default")
@@ -382,7 +383,7 @@ def main():
     # N > 1: qups_amd.dist -- pixel slabs (mirror slabs when every rank's plan takes the lateral-mirror mode: rank r beamforms columns of the
     # first half AND their mirror images) and ONE RCCL all_gather
     from qups_amd.dist import ShardedDasPlan
-    balance = "measure" if (world > 1 and not args.no_balance) else None
+    balance = "measure" if (world > 1 and args.balance) else None
     prefolded_run = bool(args.prefolded and world > 1 and w["prec"] == "single" and not args.no_fold and not args.no_reciprocal and F == 1)
     splan = ShardedDasPlan(prob, rank, world, device=dev, kernel=args.kernel, reciprocal=not args.no_reciprocal, jit=args.jit, fold=not args.no_fold, balance=balance,
                            **({"prefolded": True} if prefolded_run else {}))

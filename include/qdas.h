@@ -445,6 +445,22 @@ typedef struct qdas_convd_desc {
 uint64_t qdas_convd_len(uint64_t M, uint64_t N, int shape);    /* L */
 int qdas_convd(const qdas_convd_desc *desc, const void *x, const void *y, void *z, void *stream);
 
+/* ---- Recursive (IIR) filtering along time: what ChannelData.filter applies with an IIR digitalFilter (reference src/ChannelData.m:857-888:
+ * filter(D, x) -- a cascade of second-order sections, each the direct-form II transposed recursion -- then t0 -= filtord(D) / fs).
+ * x, y: T x K DEVICE arrays of `dtype` (QDAS_F64 | QDAS_F32), real or interleaved complex, time contiguous (K = every other dimension flattened); y may be x.
+ * sos: HOST array, nsec x 6 row-major [b0 b1 b2 a0 a1 a2] per section (MATLAB's D.Coefficients / scipy's sos); gain: overall scale (0 = 1).
+ * One read and one write of the record whatever the order (iir.hip); the state is kept in double. */
+typedef struct qdas_iir_desc {
+    uint64_t T, K;
+    int32_t  nsec;     /* 1 .. 16 second-order sections */
+    int32_t  dtype;    /* QDAS_F64 | QDAS_F32           */
+    int32_t  cplx;     /* samples are interleaved complex */
+    int32_t  device;   /* HIP device ordinal, -1 = current */
+    double   gain;
+    const double *sos;
+} qdas_iir_desc;
+int qdas_iir(const qdas_iir_desc *desc, const void *x, void *y, void *stream);
+
 /* ---- Device staging for HOST callers of the device-pointer entries above (qdas_delays*, qdas_das_lut, qdas_wsinterpd, qdas_greens, qdas_convd,
  * qdas_pre_execute ...): the reference reaches those kernels with gpuArrays (kern/wsinterpd2.m:236, src/UltrasoundSystem.m:681-718, kern/convd.m:150-199),
  * a MEX gateway built WITHOUT the mxGPUArray API has host arrays only and must not need the HIP headers -- it allocates, copies and frees through

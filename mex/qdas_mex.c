@@ -22,6 +22,12 @@
  *   y   = qdas_mex('lut', lsizes, w, x, t1, t2, wstride, omega)           kern/wsinterpd2.m:236    k.feval(y, w, x, t1, t2, sizes, iflags, strides, flagnum, imag(omega))
  *         as bfDASLUT -> sample2sep calls it (src/UltrasoundSystem.m:4641-4660): lsizes = [T N M I flag dtype I1 w_real], t1 = receive table I x N, t2 = transmit
  *         table I x M (samples), w = [] or weights with element strides wstride = uint64 [si sn sm] (0 where singleton); y is I x [1|N] x [1|M] complex(prec)
+ *   y   = qdas_mex('wsinterpd', wsz, size, strides, sumdims, w, x, t, tvars)   kern/wsinterpd.m:221-236  k.feval(y, w, x, t, sizes, iflags, strides, flagnum, imag(omega))
+ *         the general single-delay launch (ChannelData.sample, rectifyt0): wsz = [T x_tstride ndim flag dtype w_real], size = the ndim sizes of the broadcast index
+ *         space (dimension 1 = the sampled one), strides = int64 3 x ndim element strides of [t; x; w] (0 where singleton; the trace bases of x: row 2, entry 1 is 0),
+ *         sumdims = 1 x ndim flags, tvars = [imag(omega) extrapval]; y is dense column-major over the kept dimensions (summed ones singleton), complex(prec)
+ *   y   = qdas_mex('shiftsum', ssz, x, shift, w)                               src/UltrasoundSystem.m:3498 (focusTx: sample2sep(chd.time, -tau, interp, apd, mdim))
+ *         ssz = [T To N M Mo F flag dtype cplx w_real]; x: T x N x M x F, shift: M x Mo real(prec) samples, w: M x Mo real or complex(prec) or []; y: To x N x Mo x F
  *   y   = qdas_mex('greens', gsizes, ps, as, pn, pv, x, tvars)            src/UltrasoundSystem.m:681-718  k.feval(x, ps, as, pn, pv, kn, sb, blocks, [t0k t0x fso fsr cinv R0], [E E], flagnum)
  *         gsizes = [S T N M I En Em flagnum dtype], tvars = [t0k t0x fso fsr cinv R0]; the sb / blocks culling tables are not needed; y is S x N x M complex
  *   z   = qdas_mex('convd', csizes, x, y)                                 kern/convd.m:150-199     kern.feval(x, y, z, sizes)
@@ -366,6 +372,67 @@ static mxArray *cmd_lut(int nrhs, const mxArray *prhs[]) {
     return finish(qdas_das_lut(&d, x, y, NULL), host, bytes);
 }
 
+/* y = qdas_mex('wsinterpd', wsz, size, strides, sumdims, w, x, t, tvars) -- kern/wsinterpd.m:221-236, src/interpd.cu:295-342 */
+static mxArray *cmd_wsinterpd(int nrhs, const mxArray *prhs[]) {
+    if (nrhs != 8) mexErrMsgIdAndTxt("QUPS:das_spec:nargin", "qdas_mex('wsinterpd', wsz, size, strides, sumdims, w, x, t, tvars)");
+    qdas_wsinterpd_desc d;
+    memset(&d, 0, sizeof d);
+    const mxArray *z = prhs[0];
+    d.T = (uint64_t)num_at(z, 0, "wsz"); d.x_tstride = (uint64_t)num_at(z, 1, "wsz"); d.ndim = (int32_t)num_at(z, 2, "wsz"); d.flag = (int32_t)num_at(z, 3, "wsz");
+    d.dtype = (int32_t)num_at(z, 4, "wsz"); d.w_real = (int32_t)num_at(z, 5, "wsz"); d.lane_dim = -1;
+    if (d.ndim < 1 || d.ndim > 8) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "wsz(3): 1 to 8 dimensions.");
+    if (d.dtype < QDAS_F64 || d.dtype > QDAS_F16) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "wsz(5): dtype must be 0 (double), 1 (single) or 2 (half).");
+    if (mxGetNumberOfElements(prhs[1]) < (size_t)d.ndim || mxGetNumberOfElements(prhs[2]) < 3 * (size_t)d.ndim || mxGetNumberOfElements(prhs[3]) < (size_t)d.ndim)
+        mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "size, strides (3 x ndim: t, x, w) and sumdims must cover ndim dimensions.");
+    uint64_t nt = 1, nx = 1, nw = 1, ny = 1;               /* extents of t, x (trace bases), w, y in elements */
+    for (int k = 0; k < d.ndim; ++k) {
+        d.size[k] = (uint64_t)num_at(prhs[1], (mwSize)k, "size");
+        d.tstride[k] = (int64_t)num_at(prhs[2], (mwSize)(3 * k), "strides"); d.xstride[k] = (int64_t)num_at(prhs[2], (mwSize)(3 * k + 1), "strides");
+        d.wstride[k] = (int64_t)num_at(prhs[2], (mwSize)(3 * k + 2), "strides");
+        d.sum[k] = num_at(prhs[3], (mwSize)k, "sumdims") != 0;
+        if (d.tstride[k] < 0 || d.xstride[k] < 0 || d.wstride[k] < 0) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "strides must be non-negative (column-major MATLAB arrays).");
+        if (d.size[k]) { nt += (d.size[k] - 1) * (uint64_t)d.tstride[k]; nx += (d.size[k] - 1) * (uint64_t)d.xstride[k]; nw += (d.size[k] - 1) * (uint64_t)d.wstride[k]; }
+        if (!d.sum[k]) ny *= d.size[k];
+    }
+    d.omega = num_at(prhs[7], 0, "tvars"); d.extrap = num_at(prhs[7], 1, "tvars");
+    const size_t cs = cbytes(d.dtype), ts = rbytes(d.dtype), ws = d.w_real ? cs / 2 : cs;
+    int dev = 0;
+    d.w = mxIsEmpty(prhs[4]) ? NULL : dev_in(prhs[4], (size_t)nw * ws, "w", &dev);
+    d.x = dev_in(prhs[5], (size_t)(nx - 1 + (d.T ? (d.T - 1) * d.x_tstride + 1 : 0)) * cs, "x", &dev);
+    d.t = dev_in(prhs[6], (size_t)nt * ts, "t", &dev);
+    const int half = d.dtype == QDAS_F16;
+    mwSize dims[9], nd = 0;
+    if (half) dims[nd++] = 2;
+    for (int k = 0; k < d.ndim; ++k) dims[nd++] = (mwSize)(d.sum[k] ? 1 : d.size[k]);
+    const size_t bytes = (size_t)ny * cs;
+    mxArray *host;
+    void *y = dev_out(nd, dims, class_of(d.dtype), !half, dev, bytes, &host);
+    return finish(qdas_wsinterpd(&d, y, NULL), host, bytes);
+}
+
+/* y = qdas_mex('shiftsum', ssz, x, shift, w) -- UltrasoundSystem.focusTx, src/UltrasoundSystem.m:3374-3503 (:3498) */
+static mxArray *cmd_shiftsum(int nrhs, const mxArray *prhs[]) {
+    if (nrhs != 4) mexErrMsgIdAndTxt("QUPS:das_spec:nargin", "qdas_mex('shiftsum', ssz, x, shift, w)");
+    qdas_shift_desc d;
+    memset(&d, 0, sizeof d);
+    const mxArray *z = prhs[0];
+    d.T = (uint64_t)num_at(z, 0, "ssz"); d.To = (uint64_t)num_at(z, 1, "ssz"); d.N = (uint64_t)num_at(z, 2, "ssz"); d.M = (uint64_t)num_at(z, 3, "ssz");
+    d.Mo = (uint64_t)num_at(z, 4, "ssz"); d.F = (uint64_t)num_at(z, 5, "ssz"); d.flag = (int32_t)num_at(z, 6, "ssz"); d.dtype = (int32_t)num_at(z, 7, "ssz");
+    d.cplx = (int32_t)num_at(z, 8, "ssz"); d.w_real = mxGetNumberOfElements(z) > 9 ? (int32_t)num_at(z, 9, "ssz") : 1;
+    d.device = -1;
+    if (d.dtype != QDAS_F64 && d.dtype != QDAS_F32) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "shiftsum: datatype must be double or single");
+    const size_t rs = rbytes(d.dtype), es = rs * (d.cplx ? 2 : 1);
+    int dev = 0;
+    const void *x = dev_in(prhs[1], (size_t)(d.T * d.N * d.M * d.F) * es, "x", &dev);
+    d.shift = dev_in(prhs[2], (size_t)(d.M * d.Mo) * rs, "shift", &dev);
+    d.w = mxIsEmpty(prhs[3]) ? NULL : dev_in(prhs[3], (size_t)(d.M * d.Mo) * (d.w_real ? rs : 2 * rs), "w", &dev);
+    const mwSize dims[4] = {(mwSize)d.To, (mwSize)d.N, (mwSize)d.Mo, (mwSize)d.F};
+    const size_t bytes = (size_t)(d.To * d.N * d.Mo * d.F) * es;
+    mxArray *host;
+    void *y = dev_out(4, dims, d.dtype == QDAS_F64 ? mxDOUBLE_CLASS : mxSINGLE_CLASS, d.cplx, dev, bytes, &host);
+    return finish(qdas_shift_sum(&d, x, y, NULL), host, bytes);
+}
+
 /* y = qdas_mex('greens', gsizes, ps, as, pn, pv, x, tvars) -- src/UltrasoundSystem.m:681-718, src/greens.cu:88-121 */
 static mxArray *cmd_greens(int nrhs, const mxArray *prhs[]) {
     if (nrhs != 7) mexErrMsgIdAndTxt("QUPS:das_spec:nargin", "qdas_mex('greens', gsizes, ps, as, pn, pv, x, tvars)");
@@ -482,6 +549,8 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
             plhs[0] = mxCreateString(buf);
         } else if (!strcmp(cmd, "delays")) { plhs[0] = cmd_delays(nrhs - 1, prhs + 1);
         } else if (!strcmp(cmd, "lut")) { plhs[0] = cmd_lut(nrhs - 1, prhs + 1);
+        } else if (!strcmp(cmd, "wsinterpd")) { plhs[0] = cmd_wsinterpd(nrhs - 1, prhs + 1);
+        } else if (!strcmp(cmd, "shiftsum")) { plhs[0] = cmd_shiftsum(nrhs - 1, prhs + 1);
         } else if (!strcmp(cmd, "greens")) { plhs[0] = cmd_greens(nrhs - 1, prhs + 1);
         } else if (!strcmp(cmd, "convd")) { plhs[0] = cmd_convd(nrhs - 1, prhs + 1);
         } else if (!strcmp(cmd, "hilbert")) { plhs[0] = cmd_hilbert(nrhs - 1, prhs + 1);

@@ -79,3 +79,27 @@ def convd_direct(x, y, shape="full"):
             i += 1
             j += 1
     return z
+
+
+def sosfilt(x, sos, axis=0, gain=1.0):
+    """IIR filtering as ``filter(D, x)`` applies an IIR ``digitalFilter`` (reference src/ChannelData.m:857-888 -> MATLAB ``filter``): the second-order sections
+    ``[b0 b1 b2 a0 a1 a2]`` one after the other, each the direct-form II transposed recursion from rest
+        y[t] = b0 x[t] + s1;  s1 = b1 x[t] - a1 y[t] + s2;  s2 = b2 x[t] - a2 y[t]        (coefficients / a0),
+    ``gain`` applied once.  float64 (complex128), plain loops over time: TEST INFRASTRUCTURE (small cases; pinned against scipy.signal.sosfilt / lfilter in
+    tests/test_convd.py)."""
+    x = np.moveaxis(np.asarray(x), axis, 0)
+    y = x.astype(np.complex128 if np.iscomplexobj(x) else np.float64) * gain
+    for sec in np.asarray(sos, dtype=np.float64).reshape(-1, 6):
+        b0, b1, b2, a0, a1, a2 = sec
+        b0, b1, b2, a1, a2 = b0 / a0, b1 / a0, b2 / a0, a1 / a0, a2 / a0
+        s1 = np.zeros(y.shape[1:], dtype=y.dtype)
+        s2 = np.zeros(y.shape[1:], dtype=y.dtype)
+        out = np.empty_like(y)
+        for t in range(y.shape[0]):
+            xt = y[t]
+            yt = b0 * xt + s1
+            s1 = b1 * xt - a1 * yt + s2
+            s2 = b2 * xt - a2 * yt
+            out[t] = yt
+        y = out
+    return np.moveaxis(y, 0, axis)

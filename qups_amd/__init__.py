@@ -11,7 +11,7 @@ from .das_spec import (DasError, DasPlan, DasProblem, MultiDevicePlan, build_pro
 from .interpd import das_lut, sample2sep, wsinterpd2  # noqa: F401,E402
 from . import apodization  # noqa: F401,E402
 from . import preproc  # noqa: F401,E402
-from .convd import convd  # noqa: F401,E402
+from .convd import convd, sosfilt  # noqa: F401,E402
 from .ultrasound import ChannelData, Scan, Sequence, Transducer, UltrasoundSystem  # noqa: F401,E402
 
 __all__ = ["das_spec", "DasPlan", "MultiDevicePlan", "DasProblem", "DasError", "build_problem", "parse_options", "das_lut", "sample2sep",

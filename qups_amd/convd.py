@@ -116,3 +116,35 @@ def convd(x, y=None, dim: int | None = None, shape: str = "full", device=None, r
         lsz = [1] * D; lsz[d] = L
         return z, lags.reshape(lsz)
     return z
+
+
+def sosfilt(x, sos, dim: int = 1, gain: float = 1.0, device=None):
+    """Recursive (IIR) filtering along ``dim`` (1-based) with second-order sections ``sos`` (``n x 6``: ``[b0 b1 b2 a0 a1 a2]`` per row -- MATLAB's
+    ``digitalFilter.Coefficients`` / ``scipy.signal`` ``sos``) and an overall ``gain``: what ``filter(D, x)`` computes for an IIR ``digitalFilter``
+    (reference ``src/ChannelData.m:857-888``).  float32 / float64, real or complex, on the device (``qdas_iir``, ``csrc/iir.hip``: one read and one write of
+    the record whatever the order); no CPU fallback.  Returns a tensor of ``x``'s shape."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("qups_amd: no HIP device visible -- sosfilt has no CPU fallback")
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    xt = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+    if not (xt.is_floating_point() or xt.is_complex()):
+        xt = xt.to(torch.float64)
+    if xt.dtype in (torch.float16, torch.complex32, torch.bfloat16):
+        raise ValueError("sosfilt: double or single data")
+    s = np.ascontiguousarray(np.asarray(sos, dtype=np.float64).reshape(-1, 6))
+    if not (1 <= s.shape[0] <= 16):
+        raise ValueError("sosfilt: 1 to 16 second-order sections")
+    ax = int(dim) - 1
+    xm = xt.to(dev).movedim(ax, -1).contiguous()                  # (..., T): time fastest = the ABI's T x K column-major
+    T = int(xm.shape[-1])
+    K = int(xm.numel() // T) if T else 0
+    y = torch.empty_like(xm)
+    dbl = xm.dtype in (torch.float64, torch.complex128)
+    d = _lib.IirDesc(T, K, int(s.shape[0]), _lib.QDAS_F64 if dbl else _lib.QDAS_F32, int(xm.is_complex()),
+                     dev.index if dev.index is not None else torch.cuda.current_device(), float(gain), s.ctypes.data_as(C.POINTER(C.c_double)))
+    L = _lib.lib()
+    L.qdas_iir.argtypes = [C.POINTER(_lib.IirDesc), C.c_void_p, C.c_void_p, C.c_void_p]
+    with torch.cuda.device(dev):
+        _lib.check(L.qdas_iir(C.byref(d), C.c_void_p(xm.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return y.movedim(-1, ax)

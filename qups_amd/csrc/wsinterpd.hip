@@ -82,37 +82,76 @@ __global__ void __launch_bounds__(256) wsinterpd_kernel(const WsParams P) {
     // here, decode every term's index with a 64-bit divide and modulo per dimension (src/interpd.cu:316-331)
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t ut = 0, ux = 0, uw = 0;
-    for (uint64_t r = 0; r < P.n_sum; ++r) {
-        const int64_t to = tb + ut, xo = xb + ux, wo = wb + uw;
-        {
-            bool carry = true;
+    auto advance = [&]() {                               // odometer: the next term's uniform offsets
+        bool carry = true;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                if (d < P.nsd && carry) {
-                    ut += P.sts[d]; ux += P.sxs[d]; uw += P.sws[d];
-                    if (++cnt[d] == P.ssz[d]) { cnt[d] = 0; ut -= (int64_t)P.ssz[d] * P.sts[d]; ux -= (int64_t)P.ssz[d] * P.sxs[d]; uw -= (int64_t)P.ssz[d] * P.sws[d]; }
-                    else carry = false;
-                }
+        for (int d = 0; d < 8; ++d) {
+            if (d < P.nsd && carry) {
+                ut += P.sts[d]; ux += P.sxs[d]; uw += P.sws[d];
+                if (++cnt[d] == P.ssz[d]) { cnt[d] = 0; ut -= (int64_t)P.ssz[d] * P.sts[d]; ux -= (int64_t)P.ssz[d] * P.sxs[d]; uw -= (int64_t)P.ssz[d] * P.sws[d]; }
+                else carry = false;
             }
         }
-        const R tau = t[to];
-        if (!(fabs((double)tau) <= 1.0e300) && tau == tau) continue;              // +-inf: excluded (src/interpd.cu:333)
-        cplx<R> v;
-        if (!sample_strided<INTERP, R, ST>(x + xo, (long)P.x_tstride, (long)P.T, tau, v)) {
-            if (skip_nan) continue;
-            v = {(R)P.extrap, (R)0};
+    };
+    // A lane sums its output's terms one after the other, and every term is a chain of two dependent memory round trips (t, then the taps of x): with one
+    // term in flight per lane the sum-over-transmits shape (ChannelData.sample with sdim: 128 terms per output, 16 waves per CU) ran at the memory LATENCY,
+    // 0.04-0.08 of the HBM roof (profiles/r04/general_time.txt).  Four terms per pass: their delays are loaded together, then their taps -- from CLAMPED
+    // (always in-record) indices, so that no load hides behind a branch; the support test selects afterwards --, then they are added in term order.
+    constexpr int U = 4;
+    constexpr int K = INTERP == 0 ? 1 : interp_taps(INTERP);
+    constexpr int OFF = (K <= 2) ? 0 : -1;
+    const long T = (long)P.T, xts = (long)P.x_tstride;
+    for (uint64_t r = 0; r < P.n_sum; r += U) {
+        int64_t xo[U], wo[U];
+        R tau[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            live[u] = r + u < P.n_sum;
+            const int64_t to = tb + ut;
+            xo[u] = xb + ux; wo[u] = wb + uw;
+            tau[u] = live[u] ? t[to] : (R)0;
+            if (live[u]) advance();
         }
-        if (omega != (R)0) {                                                       // src/interpd.cu:334
-            R sn, cs;
-            if constexpr (sizeof(R) == 8) sincos((double)(omega * tau), (double *)&sn, (double *)&cs);
-            else sincosf((float)(omega * tau), (float *)&sn, (float *)&cs);
-            v = cmul(v, cplx<R>{cs, sn});
+        cplx<R> tap[U][K];
+        R wk[U][4];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const R sft = INTERP == 0 ? qfloor(tau[u] + (R)0.5) : qfloor(tau[u]);
+            // support: tau >= 0 and every tap in [0, T) (sample_strided above; NaN and +-inf fall out of it)
+            ok[u] = tau[u] >= (R)0 && sft + (R)(K - 1 + OFF) < (R)T && sft + (R)OFF >= (R)0;
+            long first = ok[u] ? (long)sft + OFF : 0;
+            if (T < K) first = 0;
+            wk[u][0] = (R)1; wk[u][1] = wk[u][2] = wk[u][3] = (R)0;
+            if constexpr (K > 1) interp_weights<INTERP>(ok[u] ? tau[u] - sft : (R)0, wk[u]);
+#pragma unroll
+            for (int k = 0; k < K; ++k) tap[u][k] = (live[u] && T >= K) ? ld(x + xo[u], (size_t)((first + k) * xts)) : cplx<R>{(R)0, (R)0};
         }
-        if (P.w) {
-            if (P.w_real) { const R w = (R)ldr((const AR *)P.w, (size_t)wo); v.x *= w; v.y *= w; }
-            else v = cmul(v, ld((const ST *)P.w, (size_t)wo));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            if (!(fabs((double)tau[u]) <= 1.0e300) && tau[u] == tau[u]) continue;      // +-inf: excluded (src/interpd.cu:333)
+            cplx<R> v = {(R)0, (R)0};
+            if (ok[u] && T >= K) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) { v.x += wk[u][k] * tap[u][k].x; v.y += wk[u][k] * tap[u][k].y; }
+            } else {
+                if (skip_nan) continue;
+                v = {(R)P.extrap, (R)0};
+            }
+            if (omega != (R)0) {                                                       // src/interpd.cu:334
+                R sn, cs;
+                if constexpr (sizeof(R) == 8) sincos((double)(omega * tau[u]), (double *)&sn, (double *)&cs);
+                else sincosf((float)(omega * tau[u]), (float *)&sn, (float *)&cs);
+                v = cmul(v, cplx<R>{cs, sn});
+            }
+            if (P.w) {
+                if (P.w_real) { const R w = (R)ldr((const AR *)P.w, (size_t)wo[u]); v.x *= w; v.y *= w; }
+                else v = cmul(v, ld((const ST *)P.w, (size_t)wo[u]));
+            }
+            acc.x += v.x; acc.y += v.y;
         }
-        acc.x += v.x; acc.y += v.y;
     }
     st((ST *)P.y, (size_t)yo, acc);
 }

@@ -67,15 +67,25 @@ def mirror_slab_columns(I2: int, rank: int, world: int) -> Tuple[int, int]:
     return h * rank // world, h * (rank + 1) // world
 
 
-def balanced_column_bounds(cost, world: int):
+def balanced_column_bounds(cost, world: int, granule: int = 1):
     """Column boundaries ``b[0] = 0 <= b[1] <= ... <= b[world] = len(cost)`` that give every rank (nearly) the same share of ``sum(cost)``:
     ``cost[c]`` = what column ``c`` of the first half of the image (and its mirror image) costs to beamform -- measured per column block by
     :func:`measure_column_cost`, or any model.  Equal column counts (:func:`mirror_slab_columns`) leave the rank with the outermost columns the
     slowest: the delay gradient -- and with it the spread of the LDS gathers -- grows away from the array (C3 at 8 ranks: 2.65 ms against
     2.36 ms, ``profiles/r04/slab_kernel_times_c3.txt``).  Greedy on the cumulative cost at column granularity; every rank gets at least one column
-    while there are columns left; identical on every rank that passes the same ``cost`` (pure, deterministic)."""
+    while there are columns left; identical on every rank that passes the same ``cost`` (pure, deterministic).
+
+    ``granule``: boundaries are multiples of it.  The fused kernel works in TILES of 16-128 columns and a rank's kernel time is set by the number of
+    tile ROUNDS its slab needs on the device's CUs, not by its column count: at C3 a slab of 266 columns (9 column tiles x 32 depth tiles = 288 workgroups on
+    256 CUs: two rounds) takes 13.4 ms where 256 columns take 7.2 ms (``profiles/r05/slab_kernel_times_c3.txt``) -- pass the plans' tile width
+    (``DasPlan.tile_shape()[1]``) so that no rank gets a partial column tile."""
     import numpy as np
     c = np.asarray(cost, dtype=np.float64).reshape(-1)
+    if granule > 1 and c.size:
+        ng = (c.size + granule - 1) // granule
+        cg = np.array([c[g * granule:(g + 1) * granule].sum() for g in range(ng)])
+        bg = balanced_column_bounds(cg, world, 1)
+        return [min(int(b) * granule, int(c.size)) for b in bg]
     h = int(c.size)
     if world < 1:
         raise ValueError("world must be >= 1")
@@ -184,10 +194,11 @@ class ShardedDasPlan:
     """
 
     def __init__(self, prob, rank: int, world: int, group=None, device=None, kernel: int = 0,
-                 compute: Callable | None = None, mirror_slabs: bool | None = None, balance=None, **plan_kw):
+                 compute: Callable | None = None, mirror_slabs: bool | None = None, balance=None, balance_granule: int = 32, **plan_kw):
         """``balance`` (mirror slabs only): per-column (or per-block) cost of the first half of the image -- an array every rank passes identically, e.g. rank 0's
         :func:`measure_column_cost` after a broadcast -- or ``"measure"``: rank 0 measures it now and broadcasts it.  The ranks then take column ranges
-        of equal COST (:func:`balanced_column_bounds`) instead of equal width."""
+        of equal COST (:func:`balanced_column_bounds`) instead of equal width -- in multiples of ``balance_granule`` columns (the fused kernel's tiles are 16-128
+        columns wide and a partial column tile costs a whole one: see there)."""
         self.prob, self.rank, self.world, self.group = prob, rank, world, group
         self._compute = compute
         self.plan = None
@@ -201,7 +212,7 @@ class ShardedDasPlan:
             if balance is not None:
                 cost = self._agreed_cost(balance, device, kernel, plan_kw)
                 if cost is not None:
-                    self.col_bounds = balanced_column_bounds(expand_block_cost(cost, I2 // 2), world)
+                    self.col_bounds = balanced_column_bounds(expand_block_cost(cost, I2 // 2), world, max(1, int(balance_granule)))
             c0, c1 = mirror_slab_columns(I2, rank, world) if self.col_bounds is None else (self.col_bounds[rank], self.col_bounds[rank + 1])
             self.i_begin, self.i_count = c0 * I1, (c1 - c0) * I1
             ok = True

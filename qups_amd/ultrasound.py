@@ -148,14 +148,33 @@ class ChannelData:
         return ChannelData(torch.cat([z(B), d, z(A)], ax), np.asarray(self.t0, float) - B / self.fs if np.ndim(self.t0) else float(self.t0) - B / self.fs,
                            self.fs, self.order)
 
-    def filter(self, b, dim=None):
-        """FIR-filter the data along time with coefficients ``b`` -- what ``filter(chd, D)`` does with an FIR ``digitalFilter`` ``D``
-        (reference ``src/ChannelData.m:857-888``: ``filter(D, x)`` along the time dimension, then ``t0 -= (filtord(D) / 2) / fs``): the causal
-        convolution ``y[t] = sum_k b[k] x[t - k]`` on the device (``qdas_convd`` with the ``'causal'`` window).  IIR filters are not provided."""
-        from .convd import convd
+    def filter(self, b, dim=None, a=None, sos=None, gain=1.0):
+        """Filter the data along time -- what ``filter(chd, D)`` does with a ``digitalFilter`` ``D`` (reference ``src/ChannelData.m:857-888``: ``filter(D, x)``
+        along the time dimension, then ``t0 -= L / fs`` with ``L = filtord(D) / 2`` for an FIR and ``L = filtord(D)`` for an IIR filter, ``:876-879``).
+        FIR (``b`` alone): the causal convolution ``y[t] = sum_k b[k] x[t - k]`` on the device (``qdas_convd`` with the ``'causal'`` window).
+        IIR: second-order sections ``sos`` (``n x 6``, MATLAB's ``D.Coefficients``) with ``gain``, or a transfer function ``(b, a)`` -- converted to sections
+        (``scipy.signal.tf2sos``: MATLAB's own ``filter(b, a, x)`` runs the direct form; the two agree to rounding) -- on the device (``qdas_iir``)."""
         import torch
         ax = self.order.index("T") if dim is None else int(dim) - 1
         d = self._torch_data()
+        if sos is not None or a is not None:
+            from .convd import sosfilt
+            if sos is None:
+                from scipy.signal import tf2sos
+                bb, aa = np.atleast_1d(np.asarray(b, float)), np.atleast_1d(np.asarray(a, float))
+                order = max(len(bb), len(aa)) - 1
+                sos = tf2sos(bb, aa) if order > 0 else np.array([[bb[0], 0, 0, aa[0], 0, 0]], float)
+            else:
+                sos = np.asarray(sos, float).reshape(-1, 6)
+                order = int(sum(2 - int(r[2] == 0 and r[5] == 0) - int(r[1] == 0 and r[2] == 0 and r[4] == 0 and r[5] == 0) for r in sos))      # filtord of the cascade
+            if d.dtype in (torch.float16, torch.complex32):
+                d = d.to(torch.complex64 if d.is_complex() else torch.float32)
+            y = sosfilt(d, sos, ax + 1, gain)
+            t0 = self.t0
+            if ax == self.order.index("T"):
+                t0 = np.asarray(t0, float) - order / self.fs if np.ndim(t0) else float(t0) - order / self.fs
+            return ChannelData(y, t0, self.fs, self.order)
+        from .convd import convd
         bt = b if hasattr(b, "is_cuda") else torch.from_numpy(np.asarray(b))
         bt = bt.reshape(-1)
         if not (bt.is_floating_point() or bt.is_complex()):

@@ -222,6 +222,46 @@ int main(void) {
         CHECK(dxr && qdas_pre_plan_create(&pp, &pd) == 0 && qdas_pre_execute(pp, dxr, dz, NULL) == 0 && qdas_device_copy(zc, dz, sizeof(float) * 2 * T * N * M, 1, -1) == 0);
         qdas_pre_plan_destroy(pp);
         CHECK(memcmp(zc, mxGetData(out[0]), sizeof(float) * 2 * T * N * M) == 0 && (zc[100] != 0 || zc[101] != 0));
+        /* 6e'. wsinterpd (the general single-delay launch): x T x N x M sampled at t (I x N, broadcast over the transmits), weights 1 x N, summed over the receivers */
+        {
+            mxArray *cmd_ws = mxCreateString("wsinterpd"), *wsz = arr(1, 6, mxDOUBLE_CLASS, 0), *wsize = arr(1, 3, mxDOUBLE_CLASS, 0), *wstr = arr(3, 3, mxINT64_CLASS, 0),
+                    *wsum = arr(1, 3, mxDOUBLE_CLASS, 0), *ww = arr(1, N, mxSINGLE_CLASS, 0), *wtv = arr(1, 2, mxDOUBLE_CLASS, 0);
+            const double wszv[6] = {T, 1, 3, 2 /* cubic */, 1 /* single */, 1 /* real weights */}, wsizev[3] = {I, N, M}, wsumv[3] = {0, 1, 0}, wtvv[2] = {0.3, 0.0};
+            const int64_t wstrv[9] = {1, 0, 0, /* dim 1: t, x, w */ I, T, 1, /* dim 2 */ 0, (int64_t)T * N, 0 /* dim 3 */};
+            memcpy(mxGetData(wsz), wszv, sizeof wszv); memcpy(mxGetData(wsize), wsizev, sizeof wsizev); memcpy(mxGetData(wsum), wsumv, sizeof wsumv);
+            memcpy(mxGetData(wstr), wstrv, sizeof wstrv); memcpy(mxGetData(wtv), wtvv, sizeof wtvv);
+            for (int n = 0; n < N; ++n) ((float *)mxGetData(ww))[n] = 0.5f + 0.1f * n;
+            const mxArray *w1[9] = {cmd_ws, wsz, wsize, wstr, wsum, ww, x1, t1, wtv};
+            CHECK(call(1, out, 9, w1) == 0);
+            CHECK(mxIsComplex(out[0]) && mxGetNumberOfElements(out[0]) == (size_t)I * M);
+            qdas_wsinterpd_desc wd;
+            memset(&wd, 0, sizeof wd);
+            wd.T = T; wd.x_tstride = 1; wd.ndim = 3; wd.flag = 2; wd.dtype = QDAS_F32; wd.w_real = 1; wd.lane_dim = -1;
+            for (int k = 0; k < 3; ++k) { wd.size[k] = (uint64_t)wsizev[k]; wd.tstride[k] = wstrv[3 * k]; wd.xstride[k] = wstrv[3 * k + 1]; wd.wstride[k] = wstrv[3 * k + 2]; wd.sum[k] = wsumv[k] != 0; }
+            wd.omega = 0.3; wd.extrap = 0.0;
+            void *dww = dup_dev(mxGetData(ww), sizeof(float) * N);
+            wd.t = dt1; wd.x = dx; wd.w = dww;
+            CHECK(dww && qdas_wsinterpd(&wd, dz, NULL) == 0 && qdas_device_copy(zc, dz, sizeof(float) * 2 * I * M, 1, -1) == 0);
+            CHECK(memcmp(zc, mxGetData(out[0]), sizeof(float) * 2 * I * M) == 0 && (zc[10] != 0 || zc[11] != 0));
+            CHECK(qdas_device_free(dww, -1) == 0);
+            /* 6e''. shiftsum (focusTx): 3 synthesised transmits from the M elements of one frame */
+            enum { MO = 3, TO = 280 };
+            mxArray *cmd_ss = mxCreateString("shiftsum"), *ssz = arr(1, 10, mxDOUBLE_CLASS, 0), *sh = arr(M, MO, mxSINGLE_CLASS, 0), *sw = arr(M, MO, mxSINGLE_CLASS, 0);
+            const double sszv[10] = {T, TO, N, M, MO, 1, 2 /* cubic */, 1 /* single */, 1 /* complex */, 1 /* real weights */};
+            memcpy(mxGetData(ssz), sszv, sizeof sszv);
+            for (int k = 0; k < M * MO; ++k) { ((float *)mxGetData(sh))[k] = 3.25f + 0.7f * (k % 5); ((float *)mxGetData(sw))[k] = (k % 4) ? 1.0f - 0.05f * k : 0.0f; }
+            const mxArray *s1[5] = {cmd_ss, ssz, x1, sh, sw};
+            CHECK(call(1, out, 5, s1) == 0);
+            CHECK(mxIsComplex(out[0]) && mxGetNumberOfElements(out[0]) == (size_t)TO * N * MO);
+            qdas_shift_desc sd;
+            memset(&sd, 0, sizeof sd);
+            sd.T = T; sd.To = TO; sd.N = N; sd.M = M; sd.Mo = MO; sd.F = 1; sd.flag = 2; sd.dtype = QDAS_F32; sd.cplx = 1; sd.w_real = 1; sd.device = -1;
+            void *dsh = dup_dev(mxGetData(sh), sizeof(float) * M * MO), *dsw = dup_dev(mxGetData(sw), sizeof(float) * M * MO);
+            sd.shift = dsh; sd.w = dsw;
+            CHECK(dsh && dsw && qdas_shift_sum(&sd, dx, dz, NULL) == 0 && qdas_device_copy(zc, dz, sizeof(float) * 2 * TO * N * MO, 1, -1) == 0);
+            CHECK(memcmp(zc, mxGetData(out[0]), sizeof(float) * 2 * TO * N * MO) == 0 && (zc[100] != 0 || zc[101] != 0));
+            CHECK(qdas_device_free(dsh, -1) == 0 && qdas_device_free(dsw, -1) == 0);
+        }
         /* 6f. their error paths: wrong argument counts, a wrong class, a short array */
         CHECK(call(1, out, 3, v1) == 1 && strstr(fake_mex_last_id, "QUPS:das_spec:nargin"));
         const mxArray *p2[4] = {cmd_hilbert, psz, x1 /* complex */, ptv};
@@ -230,7 +270,7 @@ int main(void) {
         CHECK(call(1, out, 8, c2) == 1 && strstr(fake_mex_last_msg, "bytes expected"));
         void *frees[] = {dPi, dPr, dPv, dNv, dtau, dx, dt1, dt2, dw, dy, (void *)gd.Ps, (void *)gd.a, (void *)gd.Pr, (void *)gd.Pv, (void *)gd.x, dgy, dtaps, dz, dxr};
         for (size_t k = 0; k < sizeof frees / sizeof frees[0]; ++k) CHECK(qdas_device_free(frees[k], -1) == 0);
-        printf("delays / lut / greens / convd / hilbert through the gateway: bit-identical to the C ABI\n");
+        printf("delays / lut / greens / convd / hilbert / wsinterpd / shiftsum through the gateway: bit-identical to the C ABI\n");
     }
     fake_mex_run_atexit();                                                            /* 'clear mex' */
     CHECK(!mexIsLocked());

@@ -270,3 +270,57 @@ def test_convd_long_filters_take_the_fft_path(T, K, taps_complex, monkeypatch):
         assert rel(zd, ref) <= 5e-6 and rel(z, zd) <= 6e-6
         if T + K - 1 <= 8192:
             assert not np.array_equal(z, zd), "the two paths round differently: identical bits mean the FFT path did not run"
+
+
+# ---------------------------------------------------------------- IIR filtering (ChannelData.filter with an IIR digitalFilter: qdas_iir)
+def test_oracle_sosfilt_is_matlab_filter():
+    """the restated cascade of direct-form II transposed sections against scipy.signal.sosfilt and -- as a transfer function -- lfilter (= MATLAB filter(b, a, x))"""
+    from scipy import signal
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((300, 5)) + 1j * rng.standard_normal((300, 5))
+    for order, wn, kind in ((4, 0.2, "low"), (6, [0.1, 0.4], "band"), (3, 0.3, "high")):
+        sos = signal.butter(order, wn, kind, output="sos")
+        assert rel(O.sosfilt(x, sos), signal.sosfilt(sos, x, axis=0)) <= 1e-12
+        b, a = signal.butter(order, wn, kind)
+        assert rel(O.sosfilt(x, sos), signal.lfilter(b, a, x, axis=0)) <= 1e-9
+    sos1 = np.array([[0.5, 0.25, 0.0, 2.0, -0.6, 0.0]])                 # a first-order section with a0 != 1
+    assert rel(O.sosfilt(x.real, sos1, gain=3.0), 3.0 * signal.lfilter([0.25, 0.125], [1.0, -0.3], x.real, axis=0)) <= 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,cplx", [("float32", True), ("float32", False), ("float64", True), ("float64", False)])
+def test_sosfilt_on_the_device(dtype, cplx):
+    """qdas_iir against the oracle: ragged trace counts (not a multiple of 64), record lengths that are not a multiple of the 32-sample tile, along either dimension,
+    8th-order band-pass and a first-order section with a gain; fp32 data with double state: 1e-6 of the peak"""
+    import torch
+    from scipy import signal
+    from qups_amd import sosfilt
+    rng = np.random.default_rng(7)
+    for shape, dim, sos, gain in (((301, 70), 1, signal.butter(4, [0.1, 0.4], "band", output="sos"), 1.0),
+                                  ((3, 129, 5), 2, signal.cheby1(5, 1.0, 0.3, output="sos"), 0.5),
+                                  ((33, 1), 1, np.array([[0.5, 0.25, 0.0, 2.0, -0.6, 0.0]]), 3.0)):
+        x = rng.standard_normal(shape)
+        if cplx:
+            x = x + 1j * rng.standard_normal(shape)
+        x = x.astype({"float32": np.complex64 if cplx else np.float32, "float64": np.complex128 if cplx else np.float64}[dtype])
+        y = sosfilt(torch.from_numpy(x), sos, dim, gain).cpu().numpy()
+        ref = O.sosfilt(x.astype(np.complex128 if cplx else np.float64), sos, dim - 1, gain)
+        assert y.shape == x.shape and rel(y, ref) <= (1e-6 if dtype == "float32" else 1e-13), (shape, dim, rel(y, ref))
+
+
+@pytest.mark.gpu
+def test_channeldata_filter_with_an_iir_filter():
+    """ChannelData.filter with second-order sections / a transfer function: the data are filtered along time and t0 moves by filtord / fs (reference src/ChannelData.m:876-884)"""
+    import torch
+    from scipy import signal
+    from qups_amd import ChannelData
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal((200, 6, 4)) + 1j * rng.standard_normal((200, 6, 4))).astype(np.complex64)
+    chd = ChannelData(torch.from_numpy(x), 1e-6, 20e6)
+    sos = signal.butter(3, 0.25, output="sos")                          # order 3: one second-order + one first-order section
+    out = chd.filter(None, sos=sos)
+    assert abs(out.t0 - (1e-6 - 3 / 20e6)) < 1e-15
+    assert rel(out.data.cpu().numpy(), O.sosfilt(x.astype(np.complex128), sos, 0)) <= 1e-6
+    b, a = signal.butter(3, 0.25)
+    out2 = chd.filter(b, a=a)
+    assert abs(out2.t0 - out.t0) < 1e-15 and rel(out2.data.cpu().numpy(), signal.lfilter(b, a, x.astype(np.complex128), axis=0)) <= 1e-6

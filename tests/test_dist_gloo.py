@@ -41,7 +41,7 @@ def _worker(rank, world, port, cases, q):
             def compute(xc, F, b, c, full_cm=full_cm):   # the slab a GPU rank would produce: (1, oM, oN, count)
                 return full_cm[..., b:b + c].contiguous()
 
-            plan = ShardedDasPlan(prob, rank, world, compute=compute, mirror_slabs=mirror_slabs, balance=balance)
+            plan = ShardedDasPlan(prob, rank, world, compute=compute, mirror_slabs=mirror_slabs, balance=balance, balance_granule=1)
             y = plan.execute_colmajor(x.permute(2, 1, 0).contiguous(), 1)
             ok = bool(torch.equal(y, full_cm)) and tuple(y.shape) == (1, oM, oN, prob.I) and plan.mirror_slabs == mirror_slabs
             q.put((rank, fun, I1 * I2, ok, plan.i_begin, plan.i_count))
@@ -207,6 +207,10 @@ def test_balanced_column_bounds_properties():
     assert balanced_column_bounds(np.ones(512), 8) == [64 * k for k in range(9)]       # a flat profile: equal widths
     assert balanced_column_bounds([np.nan, 1.0], 2) == [0, 1, 2] and balanced_column_bounds([], 3) == [0, 0, 0, 0]
     assert np.allclose(expand_block_cost([2, 1], 5), [1, 1, 1 / 3, 1 / 3, 1 / 3])
+    # boundaries snapped to the kernel's tile width: no rank gets a partial column tile (a 266-column slab of C3 costs two tile rounds, a 256-column one a single round)
+    bq = balanced_column_bounds(c, 8, 32)
+    assert all(v % 32 == 0 for v in bq) and bq[0] == 0 and bq[-1] == 512 and all(bq[i] < bq[i + 1] for i in range(8))
+    assert balanced_column_bounds(np.ones(100), 3, 32) == [0, 32, 64, 100]
 
 
 def _fold_np(x):

@@ -322,12 +322,12 @@ def test_bench_shared_gpu_prefolded_timed_region_and_balanced_slabs(tmp_path):
     env = {"QDAS_CACHE_DIR": str(tmp_path), "QDAS_BENCH_SHARE_GPU": "1"}
     common = ["--gpus", "2", "--workload", "c3", "--steps", "1", "--warmup", "1", "--no-cpu", "--no-traffic", "--no-general", "--checksum"]
     plain = _bench(common, env)
-    pre = _bench(common + ["--prefolded"], env)
+    pre = _bench(common + ["--prefolded", "--balance"], env)
     mg = pre["multi_gpu"]
     assert pre["n_gpus"] == 2 and mg["prefolded_timed_region"] is True and isinstance(mg["fold_and_replicate_ms"], float) and mg["fold_and_replicate_ms"] > 0, mg
     assert plain["multi_gpu"]["prefolded_timed_region"] is False
     assert [r["rank"] for r in mg["ranks_seen"]] == [0, 1] and all("name" in r for r in mg["ranks_seen"]), mg["ranks_seen"]
     cols = mg["slab_columns"]
-    assert cols and cols[0] == 0 and cols[-1] == 512 and 0 < cols[1] < 512, cols               # two ranks: columns [0, c) and [c, 512) of the first half, by measured cost
+    assert cols and cols[0] == 0 and cols[-1] == 512 and 0 < cols[1] < 512 and cols[1] % 32 == 0, cols      # two ranks: columns [0, c) and [c, 512) of the first half, by measured cost, whole column tiles
     assert "equal measured cost" in mg["slab_layout"]
     assert pre["image_checksum"] == plain["image_checksum"]

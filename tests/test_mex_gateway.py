@@ -33,4 +33,4 @@ def test_gateway_runs_over_the_fake_runtime(tmp_path):
     assert r.returncode == 0 and "fake-MEX gateway OK" in r.stdout, r.stdout + r.stderr
     # (the launch sites beside DAS -- delays, wsinterpd2 as bfDASLUT reaches it, greens, convd, hilbert -- each driven through the gateway
     #  and compared bit for bit with the C ABI called directly on device arrays)
-    assert "delays / lut / greens / convd / hilbert through the gateway: bit-identical to the C ABI" in r.stdout, r.stdout
+    assert "delays / lut / greens / convd / hilbert / wsinterpd / shiftsum through the gateway: bit-identical to the C ABI" in r.stdout, r.stdout

@@ -41,10 +41,12 @@ def time_slab(c0, c1, prefolded):
         return float(np.median(k[1:])), plan.aperture_split(), plan.tile_shape()
 
 
-for label, balanced, prefolded in (("equal width, every rank folds  ", False, False), ("equal cost, prefolded frames   ", True, True), ("equal cost, every rank folds   ", True, False)):
+# (label, granule of the balanced boundaries -- 0: equal width --, prefolded frames)
+for label, balanced, prefolded in (("equal width, every rank folds  ", 0, False), ("equal width, prefolded frames  ", 0, True), ("equal cost (32-column tiles), prefolded", 32, True),
+                                   ("equal cost (any column), prefolded    ", 1, True)):
     base = None
     for world in (1, 2, 4, 8):
-        bounds = balanced_column_bounds(expand_block_cost(cost, I2 // 2), world) if balanced else [mirror_slab_columns(I2, r, world)[0] for r in range(world)] + [I2 // 2]
+        bounds = balanced_column_bounds(expand_block_cost(cost, I2 // 2), world, balanced) if balanced else [mirror_slab_columns(I2, r, world)[0] for r in range(world)] + [I2 // 2]
         ts = []
         for rank in range(world):
             c0, c1 = bounds[rank], bounds[rank + 1]
