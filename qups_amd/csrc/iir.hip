@@ -88,8 +88,9 @@ hipError_t launch_iir(const IirParams &P, int dtype, int cplx, hipStream_t s) {
 
 }  // namespace qdas
 
+void qdas_internal_set_error(const char *msg);          // qdas_api.hip: the library's thread-local last-error string
+
 extern "C" int qdas_iir(const qdas_iir_desc *d, const void *x, void *y, void *stream) {
-    extern void qdas_internal_set_error(const char *msg);
     if (!d) { qdas_internal_set_error("null argument"); return QDAS_EINVAL; }
     if (d->dtype != QDAS_F64 && d->dtype != QDAS_F32) { qdas_internal_set_error("iir: datatype must be double or single"); return QDAS_EINVAL; }
     if (d->nsec < 1 || d->nsec > qdas::IIR_MAXSEC || !d->sos) { qdas_internal_set_error("iir: 1 to 16 second-order sections [b0 b1 b2 a0 a1 a2]"); return QDAS_EINVAL; }

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) wsinterpd_kernel(const WsParams P) {
     // term in flight per lane the sum-over-transmits shape (ChannelData.sample with sdim: 128 terms per output, 16 waves per CU) ran at the memory LATENCY,
     // 0.04-0.08 of the HBM roof (profiles/r04/general_time.txt).  Four terms per pass: their delays are loaded together, then their taps -- from CLAMPED
     // (always in-record) indices, so that no load hides behind a branch; the support test selects afterwards --, then they are added in term order.
-    constexpr int U = 4;
+    constexpr int U = INTERP == 3 ? 2 : 4;              // (lanczos3: its sinpi weights need the registers -- four terms in flight spilled to scratch)
     constexpr int K = INTERP == 0 ? 1 : interp_taps(INTERP);
     constexpr int OFF = (K <= 2) ? 0 : -1;
     const long T = (long)P.T, xts = (long)P.x_tstride;
