@@ -677,6 +677,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(alg_bytes / ksec / 1e9, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(alg_bytes / ksec / 1e9 / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_source": tsrc, "kernel_ms": round(kernel_ms, 3), "algorithmic_bytes": int(alg_bytes),
+                         **({} if not apb else {"algorithmic_bytes_reference_convention": int(alg_bytes + apb / world),
+                                                "algorithmic_bytes_note": "algorithmic_bytes counts the apodization array as this ABI takes it -- REAL weights in the data precision (apod_real), "
+                                                                          "half the bytes; the reference casts weights to complex (kern/das_spec.m:243,345), which is what SURVEY 8d / BASELINE.md price "
+                                                                          "(algorithmic_bytes_reference_convention)"}),
                          "note": "compulsory-traffic accounting: this path is FP32-VALU / LDS-gather bound "
                                  "(~2.5e3 flop/byte): valu_frac_executed = flops the pair loop executes / fp32 vector peak; "
                                  "reference_model_tflops = the REFERENCE kernel's per-pair flop count (SURVEY 8d) x pairs / time -- an equivalent rate that can exceed "

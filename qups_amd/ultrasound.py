@@ -166,7 +166,8 @@ class ChannelData:
                 sos = tf2sos(bb, aa) if order > 0 else np.array([[bb[0], 0, 0, aa[0], 0, 0]], float)
             else:
                 sos = np.asarray(sos, float).reshape(-1, 6)
-                order = int(sum(2 - int(r[2] == 0 and r[5] == 0) - int(r[1] == 0 and r[2] == 0 and r[4] == 0 and r[5] == 0) for r in sos))      # filtord of the cascade
+                deg = lambda c: 2 if c[2] != 0 else (1 if c[1] != 0 else 0)
+                order = int(max(sum(deg(r[0:3]) for r in sos), sum(deg(r[3:6]) for r in sos)))      # filtord of the cascade: the degree of its transfer function
             if d.dtype in (torch.float16, torch.complex32):
                 d = d.to(torch.complex64 if d.is_complex() else torch.float32)
             y = sosfilt(d, sos, ax + 1, gain)
