@@ -154,6 +154,7 @@ template <class C> struct Tile {
     uint32_t Sm, sm;                   // transmit-block groups of a two-dimensional split (tile_params.h ksplit_m) and mine; 1, 0 otherwise
     double fs, symC; int symCi;
     bool tile_interior;
+    int need_b;                        // bytes of a staged window that some lane of the tile can touch (<= WB; tile_prologue.h): the LDS-DMA moves no more
     // ---- this lane's pixel
     static constexpr uint32_t NOT_MINE = 0xffffffffu;
     uint32_t pofs;                                   // my pixel's offset in this plan's slab, or NOT_MINE (lane outside the image / the slab; slabs stay below 2^32 - 1 pixels)

@@ -175,6 +175,13 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
     if constexpr (PROBE) return false;
     // every window of every stage strictly inside the record?  (uniform) -> branch-free loop
     tile_interior = (a_lo + b_lo >= 1.0f) && (a_hi + b_hi + (float)(K + 1) < (float)T);
+    // every tap of every lane lies in [0, a_ext + b_ext + K + 1) samples of its window (the fit test above): samples beyond are never read -- nor staged
+#ifdef QDAS_DMA_TRIM
+    need_b = __builtin_amdgcn_readfirstlane((((int)(a_ext + b_ext) + K + 3) * (int)C::SB + 15) & ~15);
+    if (need_b > (int)C::WB) need_b = (int)C::WB;
+#else
+    need_b = (int)C::WB;
+#endif
     if constexpr (C::FMOD && !C::F64) {                // remodulation phase constants (cycles) of the window bases, tile_pairs.h
         const double f = P.fmod / fs;
         for (uint32_t m = tid; m < M; m += THREADS) { const double c = ((double)Abase[m] + 0.5 - tapinfo<INTERP>::OFF) * f; Aext[m] = (float)(c - floor(c)); }

@@ -116,7 +116,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
 #pragma unroll
                     for (int q = 0; q < PCS; ++q) {
                         lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + (2 * f + k) * MB + j) * WB + q * PB));
-                        if (l16 < WB - q * PB)
+                        if (l16 < need_b - q * PB)
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(f ? rsM : rsD, dst, 16, l16, qo[2 * r + k] + bs + q * PB, 0, 0);
                     }
                 }
@@ -131,7 +131,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
 #pragma unroll
             for (int q = 0; q < PCS; ++q) {
                 lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + k * MB + j) * WB + q * PB));
-                if (l16 < WB - q * PB)
+                if (l16 < need_b - q * PB)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, dst, 16, l16, qo[k] + bs + q * PB, 0, 0);
             }
         }
@@ -146,7 +146,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
 #pragma unroll
         for (int q = 0; q < (hooks::one_dma_piece ? 1 : PCS); ++q) {
             lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + fa * MB + j) * WB + q * PB));
-            if (l16 < WB - q * PB)             // trailing partial piece: upper lanes masked off
+            if (l16 < need_b - q * PB)             // trailing partial piece: upper lanes masked off
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, dst, 16, l16, so + q * PB, 0, 0);
         }
     }
@@ -159,7 +159,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
 #pragma unroll
             for (int q = 0; q < PCS; ++q) {
                 lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + fb * MB + j) * WB + q * PB));
-                if (l16 < WB - q * PB)
+                if (l16 < need_b - q * PB)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, dst, 16, l16, so + q * PB, 0, 0);
             }
         }
@@ -182,7 +182,7 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
 #pragma unroll
             for (int q = 0; q < PCS; ++q) {
                 lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + MB + j) * WB + q * PB));
-                if (l16 < WB - q * PB)
+                if (l16 < need_b - q * PB)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsM, dst, 16, l16, so + q * PB, 0, 0);
             }
         }
