@@ -20,6 +20,7 @@
 //     uniform and come through the scalar cache).
 // A singleton column / slice dimension of either operand is broadcast by a zero stride instead of being replicated
 // (the reference repmat's, kern/convd.m:75-84).
+#include <type_traits>
 #include "qdas_device.h"
 #include "qdas_kernels.h"
 #include "../../include/qdas.h"
@@ -151,48 +152,79 @@ __global__ void __launch_bounds__(128) conv_time_kernel(const ConvParams P) {
 // ---- strided time: x (C x M x S), y (C x N x S), z (C x L x S); lanes along c, 16 (double complex: 8) consecutive outputs per lane, the same
 // kind of register window fed straight from global memory (a wave's loads are coalesced along c).  YB: y has one column
 // (a filter shared by all traces): its taps are uniform and come through the scalar cache.
-template <typename T> struct cv_opl { static constexpr int V = sizeof(T) <= 8 ? 16 : 8; };   // outputs per lane (double2: 8, register budget)
+// outputs per lane (register budget: R accumulators + R + 8 window entries): 32 for 4-byte data and for complex fp32 data with REAL taps (the band-pass case),
+// 16 for 8-byte data whose taps are as wide (complex x complex: the product's temporaries), 8 for double2
+template <typename T, typename TT = T> struct cv_opl { static constexpr int V = sizeof(T) > 8 ? 8 : (sizeof(T) == 8 && sizeof(TT) == 8) ? 16 : 32; };
+
+template <int N, class F> __device__ __forceinline__ void cv_unroll(F &&f) {
+    if constexpr (N > 0) { cv_unroll<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
 
 template <typename T, typename S, typename TT, typename ST, bool YB>
 __global__ void __launch_bounds__(256) conv_col_kernel(const ConvParams P) {
     using IO = cv_io<T, S>;
     using IOT = cv_io<TT, ST>;
-    constexpr int R = cv_opl<T>::V;                                       // outputs per lane; taps go in groups of 8
+    constexpr int R = cv_opl<T, TT>::V;                                   // outputs per lane; taps go in groups of 8
+    constexpr int WN = R + 8;                                             // registers of the sliding window
+    constexpr int NG = WN / 8;                                            // groups after which the window's rotation is back where it started
     const uint32_t ncb = (uint32_t)((P.C + 63) / 64);
     const uint64_t sl = blockIdx.x / ncb;                                // slice; column block = blockIdx.x % ncb
     const uint64_t c = (uint64_t)(blockIdx.x % ncb) * 64 + threadIdx.x;
-    const int64_t l = ((int64_t)blockIdx.y * 4 + threadIdx.y) * R;
+    // (the four waves of a block take four consecutive output ranges: the range -- and with it every record index below -- is UNIFORM per wave: scalar
+    //  registers, scalar bounds tests, scalar address products; round 4 formed them per lane: 64-bit multiplies, compares and exec masks around every load)
+    const int ty = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+    const int64_t l = ((int64_t)blockIdx.y * 4 + ty) * R;
     const int64_t M = (int64_t)P.M, N = (int64_t)P.N, L = (int64_t)P.L;
-    if (c >= P.C || l >= L) return;
-    const S *__restrict__ x = (const S *)P.x + sl * P.xss + c * P.xcs;
-    const ST *__restrict__ y = (const ST *)P.y + sl * P.yss + (YB ? 0 : c * P.ycs);
-    S *__restrict__ z = (S *)P.z + (sl * P.L) * P.C + c;
-    const int64_t lf = l + P.off;
-    int64_t jlo = lf - (M - 1); if (jlo < 0) jlo = 0;
-    int64_t jhi = lf + R; if (jhi > N) jhi = N;
-    auto ldx = [&](int64_t i) -> T { return (i >= 0 && i < M) ? IO::ld(x, (uint64_t)i * P.xts) : cv_zero<T>::v(); };
-    // win[w + 8] = x[lf - j + w], w = -8 .. R-1: output r, tap u of the group uses w = r - u
-    T acc[R], win[R + 8];
+    if (l >= L) return;
+    const bool mine = c < P.C;
+    const uint64_t cc = mine ? c : P.C - 1;                              // (lanes past the last column compute on a real one and store nothing: no divergence inside the loop)
+    const S *__restrict__ x = (const S *)P.x + sl * P.xss + cc * P.xcs;
+    const ST *__restrict__ y = (const ST *)P.y + sl * P.yss + (YB ? 0 : cc * P.ycs);
+    S *__restrict__ z = (S *)P.z + (sl * P.L) * P.C + cc;
+    // (32-bit, scalar: M, N < 2^31 by the host's check; readfirstlane tells the compiler what it cannot see -- that these are uniform)
+    const int Mi = __builtin_amdgcn_readfirstlane((int)M), Ni = __builtin_amdgcn_readfirstlane((int)N);
+    const int lf = __builtin_amdgcn_readfirstlane((int)(l + P.off));
+    int jlo = lf - (Mi - 1); if (jlo < 0) jlo = 0;
+    int jhi = lf + R; if (jhi > Ni) jhi = Ni;
+    const uint64_t xts = P.xts;
+    auto ldx = [&](int i) -> T {                                          // i is uniform: one scalar test, one scalar product
+        T v = cv_zero<T>::v();
+        if (i >= 0 && i < Mi) v = IO::ld(x, (uint64_t)(uint32_t)i * xts);
+        return v;
+    };
+    // The window: logical entry w = -8 .. R-1 holds x[lf - j + w] (output r, tap u of the group uses w = r - u).  Advancing j by 8 moves every entry up by 8:
+    // instead of copying R registers per group (a quarter of the loop's instructions in round 4) the PHYSICAL register of logical w in group g is
+    // (w + 8 - 8 g) mod (R + 8) -- the loop is unrolled over the NG groups of one rotation, all indices are compile-time constants.
+    T acc[R], win[WN];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = cv_zero<T>::v();
-    int64_t j = jlo;
+    int j = jlo;
 #pragma unroll
     for (int w = 0; w < R; ++w) win[8 + w] = ldx(lf - j + w);
-    for (; j < jhi; j += 8) {
+    while (j < jhi) {
+        cv_unroll<NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if (j < jhi) {                                                // (uniform)
+                auto ph = [](int w) constexpr { return ((w + 8 - 8 * g) % WN + WN) % WN; };
+                const int i0 = lf - j - 8;                                // record index of the group's first new row
+                // (ONE path: an interior-group fast path without the tests doubled the loop's code to ~45 KB and ran 40 % slower -- the instruction cache)
 #pragma unroll
-        for (int w = 0; w < 8; ++w) win[w] = ldx(lf - j - 8 + w);
+                for (int w = 0; w < 8; ++w) win[ph(w - 8)] = ldx(i0 + w);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const TT tap = (j + u < N) ? IOT::ld(y, (uint64_t)(j + u) * (YB ? 1 : P.yts)) : cv_zero<TT>::v();
+                for (int u = 0; u < 8; ++u) {
+                    const TT tap = (j + u < Ni) ? IOT::ld(y, (uint64_t)(uint32_t)(j + u) * (YB ? 1 : P.yts)) : cv_zero<TT>::v();
 #pragma unroll
-            for (int r = 0; r < R; ++r) cv_mac(acc[r], win[8 + r - u], tap);
-        }
-#pragma unroll
-        for (int w = R + 7; w >= 8; --w) win[w] = win[w - 8];
+                    for (int r = 0; r < R; ++r) cv_mac(acc[r], win[ph(r - u)], tap);
+                }
+                j += 8;
+            }
+        });
     }
+    if (mine) {
 #pragma unroll
-    for (int r = 0; r < R; ++r)
-        if (l + r < L) IO::st(z, (uint64_t)(l + r) * P.C, acc[r]);
+        for (int r = 0; r < R; ++r)
+            if (l + r < L) IO::st(z, (uint64_t)(l + r) * P.C, acc[r]);
+    }
 }
 
 template <typename T, typename S = T, typename TT = T, typename ST = S>
@@ -201,7 +233,7 @@ static hipError_t launch_conv_t(const ConvParams &P, hipStream_t s) {
         dim3 grid((unsigned)P.S, (unsigned)((P.L + CV_TL - 1) / CV_TL));
         hipLaunchKernelGGL((conv_time_kernel<T, S, TT, ST>), grid, dim3(128), 0, s, P);
     } else {
-        dim3 grid((unsigned)(((P.C + 63) / 64) * P.S), (unsigned)((P.L + 4 * cv_opl<T>::V - 1) / (4 * cv_opl<T>::V)));
+        dim3 grid((unsigned)(((P.C + 63) / 64) * P.S), (unsigned)((P.L + 4 * cv_opl<T, TT>::V - 1) / (4 * cv_opl<T, TT>::V)));
         if (P.ycs == 0 && P.yts == 1) hipLaunchKernelGGL((conv_col_kernel<T, S, TT, ST, true>), grid, dim3(64, 4), 0, s, P);
         else hipLaunchKernelGGL((conv_col_kernel<T, S, TT, ST, false>), grid, dim3(64, 4), 0, s, P);
     }
