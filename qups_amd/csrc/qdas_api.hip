@@ -110,7 +110,8 @@ struct qdas_plan {
     bool twin_tried = false;
     uint32_t *fallback = nullptr;             // device: [0] = count, [1..ntiles]
     size_t jit_lds = 0;                       // dynamic LDS of the specialised kernel
-    int jit_mb = 0;                           // its transmits per stage
+    int jit_mb = 0, jit_w = 0;                // its transmits per stage, samples per window
+    int hint_mb = 0, hint_w = 0;              // stage shape a plan-specialised build should take instead of the prebuilt configuration's (plan_narrow_mirror)
     hipFunction_t jit_fn = nullptr;           // plan-specialised kernel (QDAS_PLAN_JIT, jit.hip); null: prebuilt instantiation
     std::string jit_tag;                      // "jit <hash>" when the plan runs a hiprtc-specialised kernel (QDAS_PLAN_JIT)
     bool prep2 = false, prep4 = false;        // the two- / four-frame instantiations have been resolved (qdas_plan_execute_frames)
@@ -879,6 +880,37 @@ static int plan_wide_windows(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b)
     return QDAS_OK;
 }
 
+// General-mode lateral-mirror plans with fp32 data (BASELINE C2, plane-wave compounding): the prebuilt configuration stages 16 transmits x 2 window sets x 192 samples
+// per stage.  A plan-specialised build takes any stage shape: when every tile of some footprint fits 128-sample windows, 32 transmits x 2 sets x 128 samples -- the
+// same 64 KiB per buffer, HALF the stages (barriers, receive-delay evaluations, DMA issue) -- is the better one (C2: 1.70 -> 1.61 ms).  Asked with the prebuilt
+// probe kernels (tile_params.h probe_w); if the build fails later the plan runs the prebuilt kernel on the footprint chosen here (128 samples fit 192).
+static int plan_narrow_mirror(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
+    const qdas_sizes &z = pl->d.sz;
+    TileParams &t = pl->tp;
+    const bool jit_on = (desc->plan_flags & QDAS_PLAN_JIT) && !b.sw.no_jit;
+    if (!(jit_on && z.dtype == QDAS_F32 && t.mir == 1 && !t.sym && !t.big && !t.bf && !t.syn && !t.apix && !t.gen_kind && !t.bpix && t.narrow == 0 && !t.stage_shift
+          && pl->no_fallback && t.M >= 32 && !getenv("QDAS_NO_NARROW_MIRROR") && !getenv("QDAS_JIT_MB") && !getenv("QDAS_JIT_W"))) return QDAS_OK;
+    // LDS image of the specialised build: header + 2 buffers x 2 sets x 32 windows x 1 KiB
+    if (tile_lds_bytes(z.dtype, 0, t.N, t.M, 0, 0, t.wtab ? 1 : 0) - tile_config(z.dtype, 0, 0, 2).lds_bytes + (size_t)2 * 2 * 32 * 128 * 8 > (size_t)160 * 1024) return QDAS_OK;
+    int rc;
+    const TileParams keep = t;
+    const double keep_frac = pl->misfit_frac;
+    const unsigned keep_ntiles = pl->ntiles, keep_cols = pl->tile_cols;
+    const bool keep_nf = pl->no_fallback;
+    t.probe_w = 128;
+    auto set_grid = [&](int tzl) { plan_set_grid(pl, tzl); };
+    if ((rc = choose_tile_shape(pl, desc, set_grid))) return rc;
+    const bool fits = pl->no_fallback;
+    t.probe_w = 0;
+    if (fits) { pl->hint_mb = 32; pl->hint_w = 128; }
+    else {
+        t = keep;
+        pl->misfit_frac = keep_frac; pl->no_fallback = keep_nf; pl->ntiles = keep_ntiles; pl->tile_cols = keep_cols;
+        HIPCHK(hipMemset(pl->fallback, 0, sizeof(uint32_t)));
+    }
+    return QDAS_OK;
+}
+
 // step 4 of plan_modes.h: workgroups per tile (+ the partial images of a split aperture)
 static int plan_split_aperture(qdas_plan *pl, PlanBuild &b) {
     const qdas_sizes &z = pl->d.sz;
@@ -923,6 +955,7 @@ static int plan_jit(qdas_plan *pl, const qdas_desc *desc, int *remake) {
     // delay evaluations of the prebuilt 16-transmit configuration) whenever the 64 windows of a buffer stay within the 16-bit
     // immediate offsets of the LDS reads (C3: 30.9 -> 29.2 ms)
     if (t.sym && !mirq && !t.fold && z.M % 32 == 0 && 2 * 32 * k.w * (dt == QDAS_F16 ? 4 : 8) <= 65536 && !getenv("QDAS_JIT_NO_MB32")) k.mb = 32;
+    if (pl->hint_mb && pl->hint_w) { k.mb = pl->hint_mb; k.w = pl->hint_w; }      // (plan_narrow_mirror: the tiles were probed for this window)
     if (const char *e = getenv("QDAS_JIT_MB")) {
         const int mb = atoi(e);
         if (mb >= 2 && mb % k.waves == 0 && (!t.sym || t.fold || z.M % (uint64_t)mb == 0) && (!mirq || t.fold)) k.mb = mb;
@@ -942,7 +975,7 @@ static int plan_jit(qdas_plan *pl, const qdas_desc *desc, int *remake) {
     std::string key;
     const std::string err = pl->jit_lds > (size_t)160 * 1024 ? std::string("LDS image too large for the requested configuration")
                                                              : jit_get_kernel(k, pl->device, &pl->jit_fn, &key);
-    if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; return QDAS_OK; }
+    if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; pl->jit_w = k.w; return QDAS_OK; }
     pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel";
     const bool unfolded = dt == QDAS_F32 && t.sym && !t.fold;                  // (likewise: the general kernels then)
     if ((dt == QDAS_F32 && t.mir && !t.sym && (t.apix || t.gen_kind)) || unfolded)      // exists only as a hiprtc build: the same plan without the mode
@@ -1080,6 +1113,7 @@ static int plan_build_tiled(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) 
     if ((rc = plan_probe_chain(pl, desc, b))) return rc;
     if ((rc = plan_side_split(pl, desc, b))) return rc;
     if ((rc = plan_wide_windows(pl, desc, b))) return rc;
+    if ((rc = plan_narrow_mirror(pl, desc, b))) return rc;
     if ((rc = plan_split_aperture(pl, b))) return rc;
     if ((rc = plan_cache_prologue(pl))) return rc;
     b.outcome.ksplit = pl->tp.ksplit;
@@ -1227,7 +1261,7 @@ extern "C" int qdas_plan_kernel_name(const qdas_plan *pl, char *buf, size_t len)
     if (pl->kernel == QDAS_KERNEL_TILED) {
         const TileParams &t = pl->tp;
         snprintf(buf, len, "das_tile_kernel<interp=%d,%s%s%s%s%s%s%s,mb=%d,W=%d> [%s]", z.flag & 7, dts, t.sym ? ",sym" : "", t.fold ? ",fold" : "", t.fmod != 0.0 ? ",fmod" : "",
-                 (t.wtab || (t.fold && pl->fold_wtab)) ? ",wtab" : "", t.big ? ",big" : "", t.mir ? ",mirror" : ((t.St && !t.syn) ? ",roles swapped" : ""), pl->jit_fn ? pl->jit_mb : pl->tc.mb, pl->tc.window, pl->jit_tag.empty() ? "prebuilt" : pl->jit_tag.c_str());
+                 (t.wtab || (t.fold && pl->fold_wtab)) ? ",wtab" : "", t.big ? ",big" : "", t.mir ? ",mirror" : ((t.St && !t.syn) ? ",roles swapped" : ""), pl->jit_fn ? pl->jit_mb : pl->tc.mb, (pl->jit_fn && pl->jit_w) ? pl->jit_w : pl->tc.window, pl->jit_tag.empty() ? "prebuilt" : pl->jit_tag.c_str());
     } else snprintf(buf, len, "das_generic_kernel<interp=%d,%s>", z.flag & 7, dts);
     return QDAS_OK;
 }

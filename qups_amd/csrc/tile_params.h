@@ -84,6 +84,9 @@ struct TileParams {
     // residuals (one fp64 delay per pixel and transmit) rarely -- BASELINE C5 with 8 receiver classes x all 6 blocks: a refresh every 3.4 stages, 9-15 % of the
     // kernel; one block per workgroup: once.  0 / 1: the one-dimensional split.
     uint32_t ksplit_m;
+    // plan-time probes only: the window length [samples] the fit test assumes instead of the probe kernel's own (0: its own) -- lets the plan ask "would these
+    // tiles fit the 128-sample windows of a plan-specialised build?" with the prebuilt 192-sample probe kernels
+    int32_t probe_w;
 };
 
 }  // namespace qdas

@@ -165,7 +165,7 @@ template <class C> template <bool PROBE> __device__ __forceinline__ bool Tile<C>
         }
     }
     // every lane's last tap (+1 for the rint/floor ambiguity at exact integers) must be inside the staged window
-    if (!(a_ext + b_ext + (float)(K + 1) <= (float)C::W)) {
+    if (!(a_ext + b_ext + (float)(K + 1) <= (float)((PROBE && P.probe_w > 0) ? P.probe_w : C::W))) {
         if (tid == 0 && split == 0) {
             const uint32_t slot = atomicAdd(&P.fallback_list[0], 1u);
             if (slot < P.fallback_cap) P.fallback_list[1 + slot] = tile_id;
