@@ -888,7 +888,7 @@ static int plan_narrow_mirror(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b
     const qdas_sizes &z = pl->d.sz;
     TileParams &t = pl->tp;
     const bool jit_on = (desc->plan_flags & QDAS_PLAN_JIT) && !b.sw.no_jit;
-    if (!(jit_on && z.dtype == QDAS_F32 && t.mir == 1 && !t.sym && !t.big && !t.bf && !t.syn && !t.apix && !t.gen_kind && !t.bpix && t.narrow == 0 && !t.stage_shift
+    if (!(jit_on && z.dtype == QDAS_F32 && t.mir && !t.sym && !t.big && !t.bf && !t.syn && !t.apix && !t.gen_kind && !t.bpix && t.narrow == 0 && !t.stage_shift
           && pl->no_fallback && t.M >= 32 && !getenv("QDAS_NO_NARROW_MIRROR") && !getenv("QDAS_JIT_MB") && !getenv("QDAS_JIT_W"))) return QDAS_OK;
     // LDS image of the specialised build: header + 2 buffers x 2 sets x 32 windows x 1 KiB
     if (tile_lds_bytes(z.dtype, 0, t.N, t.M, 0, 0, t.wtab ? 1 : 0) - tile_config(z.dtype, 0, 0, 2).lds_bytes + (size_t)2 * 2 * 32 * 128 * 8 > (size_t)160 * 1024) return QDAS_OK;
