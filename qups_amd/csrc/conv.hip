@@ -121,7 +121,9 @@ __global__ void __launch_bounds__(128) conv_time_kernel(const ConvParams P) {
         int k = CV_KC / 8 + t;
 #pragma unroll
         for (int w = 0; w < 8; ++w) win[8 + w] = X[w][k];
-        for (int g = 0; g < no; ++g) {
+        // two groups per pass: the second one loads its eight new entries into the UPPER half and reads the window rotated by eight -- no register copies
+        // (round 4 moved the lower half up after every group: 16 moves per 64 multiply-accumulates)
+        for (int g = 0; g < no; g += 2) {
             --k;
 #pragma unroll
             for (int w = 0; w < 8; ++w) win[w] = X[w][k];
@@ -132,8 +134,17 @@ __global__ void __launch_bounds__(128) conv_time_kernel(const ConvParams P) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) cv_mac(acc[r], win[8 + r - u], tap);
             }
+            if (g + 1 < no) {                                         // (uniform)
+                --k;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) win[8 + w] = win[w];
+                for (int w = 0; w < 8; ++w) win[8 + w] = X[w][k];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const TT tap = (jb + 8 + u < N) ? IOT::ld(y, (uint64_t)(jb + 8 + u)) : cv_zero<TT>::v();
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) cv_mac(acc[r], win[(16 + r - u) & 15], tap);
+                }
+            }
         }
     }
     // outputs 8t .. 8t+7 of a lane go through LDS (same de-interleaved mapping as the span) so that the stores are coalesced
