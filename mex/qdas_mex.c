@@ -13,6 +13,7 @@
  *   y = qdas_mex(sizes, Pi, Pr, Pv, Nv, apod, cinv, acstride, x, tvars)               one call = create + execute + destroy
  *   h = qdas_mex('create', sizes, Pi, Pr, Pv, Nv, apod, cinv, acstride, tvars [, opts]) plan handle (uint64 scalar), kept until
  *   y = qdas_mex('execute', h, x)                                                       'destroy' / clear mex; x: T x N x M x F
+ *       qdas_mex('prepare', h, F)                                                       do now what the plan's first stream of F frames would do once (qdas_plan_prepare_frames)
  *   s = qdas_mex('info', h)                                                             char: kernel name, shards
  *       qdas_mex('destroy' [, h])
  *
@@ -533,6 +534,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
             if (nrhs != 3) mexErrMsgIdAndTxt("QUPS:das_spec:nargin", "qdas_mex('execute', h, x)");
             const char *err = execute_plan(slot_of(prhs[1]), prhs[2], 0, &plhs[0]);
             if (err) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "%s", err);
+        } else if (!strcmp(cmd, "prepare")) {
+            if (nrhs != 3) mexErrMsgIdAndTxt("QUPS:das_spec:nargin", "qdas_mex('prepare', h, F)");
+            plan_slot *s = slot_of(prhs[1]);
+            if (s->plan && qdas_plan_prepare_frames(s->plan, (uint64_t)num_at(prhs[2], 0, "F"))) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "%s", qdas_last_error());
         } else if (!strcmp(cmd, "info")) {
             if (nrhs != 2) mexErrMsgIdAndTxt("QUPS:das_spec:nargin", "qdas_mex('info', h)");
             plan_slot *s = slot_of(prhs[1]);

@@ -111,7 +111,7 @@ struct qdas_plan {
     uint32_t *fallback = nullptr;             // device: [0] = count, [1..ntiles]
     size_t jit_lds = 0;                       // dynamic LDS of the specialised kernel
     int jit_mb = 0, jit_w = 0;                // its transmits per stage, samples per window
-    int hint_mb = 0, hint_w = 0;              // stage shape a plan-specialised build should take instead of the prebuilt configuration's (plan_narrow_mirror)
+    int hint_mb = 0, hint_w = 0;              // stage shape a plan-specialised build should take instead of the prebuilt configuration's (plan_stage_shape)
     hipFunction_t jit_fn = nullptr;           // plan-specialised kernel (QDAS_PLAN_JIT, jit.hip); null: prebuilt instantiation
     std::string jit_tag;                      // "jit <hash>" when the plan runs a hiprtc-specialised kernel (QDAS_PLAN_JIT)
     bool prep2 = false, prep4 = false;        // the two- / four-frame instantiations have been resolved (qdas_plan_execute_frames)
@@ -880,18 +880,24 @@ static int plan_wide_windows(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b)
     return QDAS_OK;
 }
 
-// General-mode lateral-mirror plans with fp32 data (BASELINE C2, plane-wave compounding): the prebuilt configuration stages 16 transmits x 2 window sets x 192 samples
-// per stage.  A plan-specialised build takes any stage shape: when every tile of some footprint fits 128-sample windows, 32 transmits x 2 sets x 128 samples -- the
-// same 64 KiB per buffer, HALF the stages (barriers, receive-delay evaluations, DMA issue) -- is the better one (C2: 1.70 -> 1.61 ms).  Asked with the prebuilt
-// probe kernels (tile_params.h probe_w); if the build fails later the plan runs the prebuilt kernel on the footprint chosen here (128 samples fit 192).
-static int plan_narrow_mirror(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
+// Stage shape of plan-specialised builds (fp32 data).  The prebuilt configurations stage 16 transmits x 2 window sets x 192 samples (general-mode lateral-mirror plans:
+// BASELINE C2, plane-wave compounding) or 32 transmits x 192 samples (one window set: general mode, the reciprocity fold without the mirror mode).  A hiprtc build takes any
+// shape: when every tile of some footprint fits 128-sample windows, 32 x 2 x 128 resp. 64 x 128 samples -- the same 64 KiB per buffer (the one-set plans: 64 instead of 48),
+// HALF the stages (barriers, receive-delay evaluations, DMA issue) -- is the better one (C2 1.70 -> 1.61 ms; C3 without any symmetry -6 %, the fold alone -3 %).  Asked
+// with the prebuilt probe kernels (tile_params.h probe_w); if the build fails later the plan runs the prebuilt kernel on the footprint chosen here (128 samples fit 192).
+static int plan_stage_shape(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
     const qdas_sizes &z = pl->d.sz;
     TileParams &t = pl->tp;
     const bool jit_on = (desc->plan_flags & QDAS_PLAN_JIT) && !b.sw.no_jit;
-    if (!(jit_on && z.dtype == QDAS_F32 && t.mir && !t.sym && !t.big && !t.bf && !t.syn && !t.apix && !t.gen_kind && !t.bpix && t.narrow == 0 && !t.stage_shift
-          && pl->no_fallback && t.M >= 32 && !getenv("QDAS_NO_NARROW_MIRROR") && !getenv("QDAS_JIT_MB") && !getenv("QDAS_JIT_W"))) return QDAS_OK;
-    // LDS image of the specialised build: header + 2 buffers x 2 sets x 32 windows x 1 KiB
-    if (tile_lds_bytes(z.dtype, 0, t.N, t.M, 0, 0, t.wtab ? 1 : 0) - tile_config(z.dtype, 0, 0, 2).lds_bytes + (size_t)2 * 2 * 32 * 128 * 8 > (size_t)160 * 1024) return QDAS_OK;
+    if (!(jit_on && z.dtype == QDAS_F32 && !t.big && !t.bf && !t.syn && !t.apix && !t.gen_kind && !t.bpix && t.narrow == 0 && !t.stage_shift && !t.cinv_pix
+          && pl->no_fallback && !getenv("QDAS_NO_STAGE_SHAPE") && !getenv("QDAS_JIT_MB") && !getenv("QDAS_JIT_W"))) return QDAS_OK;
+    int mb = 0, sets = 1;
+    if (t.mir && !t.sym) { mb = 32; sets = 2; }                          // two window sets: a pixel and its mirror image
+    else if (!t.mir && (!t.sym || t.fold)) { mb = 64; sets = 1; }        // one window set
+    if (!mb || t.M < (uint64_t)mb) return QDAS_OK;
+    // LDS image of the specialised build: the header of the prebuilt configuration (+ the stage weights of the longer stages) + 2 buffers x sets x mb windows x 1 KiB
+    const size_t hdr = tile_lds_bytes(z.dtype, t.sym, t.N, t.M, 0, 0, t.wtab ? 1 : 0, 0, t.fold) - tile_config(z.dtype, t.sym, 0, t.mir ? 2 : 1, 0, t.fold).lds_bytes;
+    if (hdr + (t.wtab ? (size_t)2 * 2 * (size_t)mb * 8 : 0) + (size_t)2 * sets * mb * 128 * 8 > (size_t)158 * 1024) return QDAS_OK;
     int rc;
     const TileParams keep = t;
     const double keep_frac = pl->misfit_frac;
@@ -902,7 +908,7 @@ static int plan_narrow_mirror(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b
     if ((rc = choose_tile_shape(pl, desc, set_grid))) return rc;
     const bool fits = pl->no_fallback;
     t.probe_w = 0;
-    if (fits) { pl->hint_mb = 32; pl->hint_w = 128; }
+    if (fits) { pl->hint_mb = mb; pl->hint_w = 128; }
     else {
         t = keep;
         pl->misfit_frac = keep_frac; pl->no_fallback = keep_nf; pl->ntiles = keep_ntiles; pl->tile_cols = keep_cols;
@@ -918,7 +924,8 @@ static int plan_split_aperture(qdas_plan *pl, PlanBuild &b) {
     int ncu = 0, rc;
     HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device));
     const unsigned cus = ncu > 0 ? (unsigned)ncu : 256u;
-    t.ksplit = modes::choose_ksplit(pl->ntiles, cus, z.M, pl->tc.mb, t.sym != 0, b.kN_eff, t.act_bytes != 0, t.syn != 0, b.sw);
+    const int mb_eff = pl->hint_mb ? pl->hint_mb : pl->tc.mb;       // (transmits per stage of the kernel the plan means to run: plan_stage_shape)
+    t.ksplit = modes::choose_ksplit(pl->ntiles, cus, z.M, mb_eff, t.sym != 0, b.kN_eff, t.act_bytes != 0, t.syn != 0, b.sw);
     t.ksplit_m = modes::choose_ksplit_m(&t.ksplit, t.M, pl->tc.mb, t.sym != 0, t.act_bytes != 0, t.syn != 0, z.dtype, b.sw);
     if (t.ksplit > 1 && !t.bf) {
         void *pb;
@@ -955,7 +962,7 @@ static int plan_jit(qdas_plan *pl, const qdas_desc *desc, int *remake) {
     // delay evaluations of the prebuilt 16-transmit configuration) whenever the 64 windows of a buffer stay within the 16-bit
     // immediate offsets of the LDS reads (C3: 30.9 -> 29.2 ms)
     if (t.sym && !mirq && !t.fold && z.M % 32 == 0 && 2 * 32 * k.w * (dt == QDAS_F16 ? 4 : 8) <= 65536 && !getenv("QDAS_JIT_NO_MB32")) k.mb = 32;
-    if (pl->hint_mb && pl->hint_w) { k.mb = pl->hint_mb; k.w = pl->hint_w; }      // (plan_narrow_mirror: the tiles were probed for this window)
+    if (pl->hint_mb && pl->hint_w) { k.mb = pl->hint_mb; k.w = pl->hint_w; }      // (plan_stage_shape: the tiles were probed for this window)
     if (const char *e = getenv("QDAS_JIT_MB")) {
         const int mb = atoi(e);
         if (mb >= 2 && mb % k.waves == 0 && (!t.sym || t.fold || z.M % (uint64_t)mb == 0) && (!mirq || t.fold)) k.mb = mb;
@@ -1113,7 +1120,7 @@ static int plan_build_tiled(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) 
     if ((rc = plan_probe_chain(pl, desc, b))) return rc;
     if ((rc = plan_side_split(pl, desc, b))) return rc;
     if ((rc = plan_wide_windows(pl, desc, b))) return rc;
-    if ((rc = plan_narrow_mirror(pl, desc, b))) return rc;
+    if ((rc = plan_stage_shape(pl, desc, b))) return rc;
     if ((rc = plan_split_aperture(pl, b))) return rc;
     if ((rc = plan_cache_prologue(pl))) return rc;
     b.outcome.ksplit = pl->tp.ksplit;

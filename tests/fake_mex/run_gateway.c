@@ -66,6 +66,10 @@ int main(void) {
     char info[512];
     CHECK(mxGetString(out[0], info, sizeof info) == 0 && strstr(info, "das_") != NULL);
     printf("plan: %s\n", info);
+    mxArray *cmd_prepare = mxCreateString("prepare"), *nfr = arr(1, 1, mxDOUBLE_CLASS, 0);
+    ((double *)mxGetData(nfr))[0] = 2;
+    const mxArray *a3b[3] = {cmd_prepare, h, nfr};
+    CHECK(call(0, out, 3, a3b) == 0);                                             /* the one-time work of the first stream, ahead of it */
     const mxArray *a4[3] = {cmd_exec, h, x};
     CHECK(call(1, out, 3, a4) == 0);
     mxArray *y_a = out[0];
