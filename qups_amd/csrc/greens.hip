@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(256) greens_kernel(const GreensParams P) {
 // Scale: 2^46 / (largest single contribution, greens_bound_kernel): 17 bits of headroom for coincident entries; a contribution 2^-22 of the largest
 // still carries fp32's 24 bits.  fp32 data only (fixed point would cost fp64 data its last bits); non-integer fsr and few entries keep the kernel above.
 // ------------------------------------------------------------------------------------------
-constexpr int GT_THREADS = 1024;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 __global__ void __launch_bounds__(256) greens_bound_kernel(const GreensParams P, unsigned int *bound_bits) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -160,16 +160,99 @@ __global__ void __launch_bounds__(256) greens_bound_kernel(const GreensParams P,
     b *= 1.5f;                                           // |w_k| <= 1 for every interpolator here (Lanczos peaks at 1, the cubics at 1): margin for rounding
     if (!(b >= 0.f) || b > 3.0e38f) b = INFINITY;        // a non-finite amplitude: the trains cannot carry it (the kernel writes NaN)
     atomicMax(bound_bits, __float_as_uint(b));           // non-negative floats order like their bit patterns
+    if (ai.y != 0.f) bound_bits[1] = 1u;                 // (any complex amplitude: real clouds -- the usual ones -- skip the imaginary trains' arithmetic; same value from every writer)
 }
 
 // element-to-scatterer distances, ONCE per launch: the delay is separable, r1 depends on (scatterer, receive element) and r2 on (scatterer, transmit
-// element) only -- (N En + M Em) I square roots instead of the N En M Em I x 2 (x blocks per trace) of a scan that recomputes them
-__global__ void __launch_bounds__(256) greens_dist_kernel(const float *__restrict__ Ps, const float *__restrict__ Pe, float *__restrict__ R, uint64_t I) {
+// element) only -- (N En + M Em) I square roots instead of the N En M Em I x 2 (x blocks per trace) of a scan that recomputes them.
+// One workgroup = one CHUNK of 256 scatterers of one element: it also leaves the chunk's {smallest, largest} distance (fminf / fmaxf: a NaN distance
+// never lands anywhere and is ignored; a chunk of NaNs gets {+inf, -inf}: never visited)
+constexpr int GT_CHUNK = 256;
+__global__ void __launch_bounds__(GT_CHUNK) greens_dist_kernel(const float *__restrict__ Ps, const float *__restrict__ Pe, float *__restrict__ R, float2 *__restrict__ cb, uint64_t I) {
+    __shared__ float2 part[GT_CHUNK / 64];
+    const uint64_t i = (uint64_t)blockIdx.x * GT_CHUNK + threadIdx.x;
+    float lo = INFINITY, hi = -INFINITY;
+    if (i < I) {
+        const size_t k = 3 * (size_t)blockIdx.y;
+        const float ax = Ps[3 * i] - Pe[k], ay = Ps[3 * i + 1] - Pe[k + 1], az = Ps[3 * i + 2] - Pe[k + 2];
+        const float r = sqrtf(ax * ax + ay * ay + az * az);                      // src/greens.cu:61-62
+        R[(size_t)blockIdx.y * I + i] = r;
+        lo = fminf(lo, r); hi = fmaxf(hi, r);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = make_float2(lo, hi);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < GT_CHUNK / 64; ++w) { lo = fminf(lo, part[w].x); hi = fmaxf(hi, part[w].y); }
+        cb[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = make_float2(lo, hi);
+    }
+}
+
+// Scatterers grouped by the MORTON cell of their positions (6 bits per axis of the cloud's bounding box; a counting sort: histogram, prefix, scatter --
+// the order inside a cell is whatever the atomics make it): a chunk of 256 consecutive scatterers is a compact run of cells, so its distances to any
+// one element span a few cell diameters and a workgroup -- 1 / (blocks per trace) of the delay range -- can tell from the chunk bounds alone that
+// most chunks do not reach it.  The trains are INTEGER sums: the order of the scatterers does not change a bit of the result.
+constexpr uint32_t GT_CELLS = 1u << 18;
+__device__ __forceinline__ uint32_t gt_ordered(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float gt_unordered(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+__global__ void __launch_bounds__(256) greens_bbox_kernel(const float *__restrict__ Ps, uint64_t I, uint32_t *__restrict__ bb) {      // bb: {min x, y, z, max x, y, z}, ordered bits
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    float v[3] = {0.f, 0.f, 0.f};
+    bool ok = false;
+    if (i < I) { v[0] = Ps[3 * i]; v[1] = Ps[3 * i + 1]; v[2] = Ps[3 * i + 2]; ok = fabsf(v[0]) <= 3.0e38f && fabsf(v[1]) <= 3.0e38f && fabsf(v[2]) <= 3.0e38f; }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float lo = ok ? v[d] : INFINITY, hi = ok ? v[d] : -INFINITY;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+        if ((threadIdx.x & 63u) == 0 && lo <= hi) { atomicMin(bb + d, gt_ordered(lo)); atomicMax(bb + 3 + d, gt_ordered(hi)); }
+    }
+}
+__device__ __forceinline__ uint32_t gt_spread3(uint32_t v) {       // 6 bits -> every third bit
+    v &= 0x3fu; v = (v | (v << 8)) & 0x300fu; v = (v | (v << 4)) & 0x30c3u; v = (v | (v << 2)) & 0x9249u;
+    return v;
+}
+__global__ void __launch_bounds__(256) greens_key_kernel(const float *__restrict__ Ps, uint64_t I, const uint32_t *__restrict__ bb, uint32_t *__restrict__ key, uint32_t *__restrict__ hist) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= I) return;
-    const size_t k = 3 * (size_t)blockIdx.y;
-    const float ax = Ps[3 * i] - Pe[k], ay = Ps[3 * i + 1] - Pe[k + 1], az = Ps[3 * i + 2] - Pe[k + 2];
-    R[(size_t)blockIdx.y * I + i] = sqrtf(ax * ax + ay * ay + az * az);          // src/greens.cu:61-62
+    uint32_t k = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float lo = gt_unordered(bb[d]), hi = gt_unordered(bb[3 + d]), v = Ps[3 * i + d];
+        const float sc = hi > lo ? 63.0f / (hi - lo) : 0.f;
+        float c = (v - lo) * sc;
+        c = c >= 0.f ? (c <= 63.f ? c : 63.f) : 0.f;                              // (NaN -> 0: any order is a valid order)
+        k |= gt_spread3((uint32_t)c) << d;
+    }
+    key[i] = k;
+    atomicAdd(hist + k, 1u);
+}
+// counts -> first positions, in place (one workgroup: 1024 threads x 256 cells)
+__global__ void __launch_bounds__(1024) greens_cellscan_kernel(uint32_t *__restrict__ hist) {
+    __shared__ uint32_t part[1024];
+    constexpr uint32_t PER = GT_CELLS / 1024;
+    const uint32_t tid = threadIdx.x;
+    uint32_t sum = 0;
+    for (uint32_t c = 0; c < PER; ++c) sum += hist[tid * PER + c];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = tid >= o ? part[tid - o] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;                                               // exclusive
+    for (uint32_t c = 0; c < PER; ++c) { const uint32_t n = hist[tid * PER + c]; hist[tid * PER + c] = run; run += n; }
+}
+__global__ void __launch_bounds__(256) greens_gather_kernel(const float *__restrict__ Ps, const float2 *__restrict__ a, const uint32_t *__restrict__ key, uint32_t *__restrict__ cursor, uint64_t I,
+                                                            float *__restrict__ Pso, float2 *__restrict__ ao) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= I) return;
+    const size_t j = atomicAdd(cursor + key[i], 1u);
+    Pso[3 * j] = Ps[3 * i]; Pso[3 * j + 1] = Ps[3 * i + 1]; Pso[3 * j + 2] = Ps[3 * i + 2];
+    ao[j] = a[i];
 }
 
 // |t| < 2^53 float -> the nearest 64-bit integer, without the generic conversion sequence: t = hi 2^23 + lo with hi = rint(t 2^-23) (|hi| < 2^30) and
@@ -185,25 +268,61 @@ __device__ __forceinline__ float gt_float(long long v) {
     return fmaf((float)(int)(v >> 32), 4294967296.0f, (float)(unsigned int)(v & 0xffffffffll));
 }
 
+// The convolution's tap list, ONCE per launch: with t = Q j + p the sum over the taps of train k is a sum over the phases p of plain FIR filters on
+// unit-stride sequences (see the kernel below).  Every (train, phase) segment is cut into GROUPS of 8 taps (the last one padded with zero taps):
+// per group the offset of its first element in the de-interleaved trains, and the 8 waveform taps {x, i x} as float4 -- read by the kernel through
+// SCALAR loads (group and taps are the same for a whole wave): one wait per 8 taps.
+constexpr int GT_SEGS = 64;                              // K Q at most
+typedef float gt_f4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) gt_f4 *gt_cf4;      // (constant address space: uniform indices become s_load)
+typedef const __attribute__((address_space(4))) int *gt_ci;
+__global__ void __launch_bounds__(256) greens_xtab_kernel(const float2 *__restrict__ x, int K, int Q, int O0, int tlo, int thi0, int thi1, int ALP, int jmax, int *__restrict__ grp,
+                                                          float4 *__restrict__ xt) {
+    __shared__ int4 sg[GT_SEGS + 1];                     // {first j, taps, first group, groups}
+    const int tid = (int)threadIdx.x;
+    if (tid < K * Q) {
+        const int k = tid / Q, ph = tid % Q, thk = k == 0 ? thi0 : thi1;
+        const int jlo = tlo > ph ? 1 : 0, jhi = thk >= ph ? (thk - ph) / Q : -1, cnt = jhi >= jlo ? jhi - jlo + 1 : 0;
+        sg[tid] = make_int4(jlo, cnt, 0, (cnt + 7) / 8);
+    }
+    __syncthreads();
+    if (tid == 0) { int base = 0; for (int c = 0; c < K * Q; ++c) { sg[c].z = base; base += sg[c].w; } sg[GT_SEGS] = make_int4(base, 0, 0, 0); }
+    __syncthreads();
+    const long G = sg[GT_SEGS].x;
+    if (blockIdx.x == 0 && tid == 0) grp[0] = (int)G;    // grp[0]: the number of groups; grp[1 + g]: group g
+    const long st = (long)blockIdx.x * 256 + tid;
+    if (st >= 8 * G) return;
+    const long g = st >> 3;
+    int c = 0;
+    while (c + 1 < K * Q && g >= (long)sg[c + 1].z) ++c;
+    const int k = c / Q, ph = c % Q, u = (int)(st - 8 * (long)sg[c].z), j = sg[c].x + u;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);          // (a padded tap)
+    if (u < sg[c].y) { const float2 xv = x[(long)Q * j + ph + O0 + k]; v = make_float4(xv.x, xv.y, -xv.y, xv.x); }
+    xt[st] = v;
+    if ((st & 7) == 0) grp[1 + g] = c * ALP + jmax - j;  // element of A_kp[s - j] for output 0 (output so: + so; the next taps: - 1 each)
+}
+
 constexpr int GT_WQ = 128;                               // entries a wave queues before it works 64 of them off
 
-template <int INTERP>
-__global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensParams P, const unsigned int *bound_bits) {
+// TH threads per workgroup: 256 with blocks of 64 / 128 outputs (a few tens of KB of LDS: several workgroups per CU, so one's barriers and exposed
+// latencies -- the chunk list, the table reads, the amplitude gather, the conversion passes -- are covered by another's work) whenever the trains of
+// such a block fit; 1024 with the longest block that fits for long waveforms / large ratios.
+template <int INTERP, int TH>
+__global__ void __launch_bounds__(TH) greens_train_kernel(const GreensParams P, const unsigned int *bound_bits) {
+    constexpr uint32_t GT_THREADS = TH, GT_LCAP = 2 * TH, CGRP = TH / GT_CHUNK;
     constexpr int K = INTERP == 0 ? 2 : interp_taps(INTERP);         // nearest: two trains (the sample at ti, or at ti + 1)
-    constexpr int O0 = K == 4 ? -1 : 0;                              // tap offset of train 0 (train k: O0 + k)
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     const long T = (long)P.T;
     const int Q = P.q;
-    const uint32_t SB = P.sb, PARTS = GT_THREADS / SB;
+    const uint32_t SB = P.sb;
     // tap indices ti the edge rule admits (qdas_device.h sample_global): 4 taps: 1 <= ti <= T-3; linear: 0 <= ti <= T-2; nearest: ti >= 0 and ti (+1) < T
     const long tlo = K == 4 ? 1 : 0;
-    const long thi_k0 = K == 4 ? T - 3 : (INTERP == 0 ? T - 1 : T - 2), thi_k1 = K == 4 ? T - 3 : T - 2;      // (trains 2, 3 as train 1)
+    const long thi_k0 = K == 4 ? T - 3 : (INTERP == 0 ? T - 1 : T - 2);       // (trains 1.. of 'nearest': T - 2)
     const long thi = thi_k0;
     const uint32_t NSLOT = (uint32_t)((long)Q * (SB - 1) + thi - tlo + 1);
     long long *H = (long long *)gsm;                                 // [K][NSLOT] {re, im} fixed point, later float2 in place
     float4 *wq = (float4 *)(H + (size_t)K * NSLOT * 2);              // [waves][GT_WQ] {scatterer, r1, r2}: this wave's entries that (may) land in the block
-    float2 *red = (float2 *)(wq + (GT_THREADS / 64) * GT_WQ);        // [PARTS][SB]
-    float2 *xl = red + GT_THREADS;                                   // [T]
+    uint32_t *clist = (uint32_t *)(gsm + P.x_off);                   // (behind the part sums of the convolution, which reuse everything before it) [GT_LCAP + 16] chunks of 256 scatterers that can reach this block, then the count
     // XCD-aware order: the hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own L2), so workgroup g runs as item
     // (g % 8) * G8 / 8 + g / 8 of a list that walks the blocks of a trace, then the receivers, then the transmits: the workgroups an XCD runs at
     // a time share their distance rows (2 x 4 I bytes per trace) in ITS L2 -- in launch order every XCD saw every receiver's row
@@ -214,10 +333,10 @@ __global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensPa
     const uint32_t blk = (uint32_t)(item % nblk), trace = (uint32_t)(item / nblk);
     const uint32_t n = trace % (uint32_t)P.N, m = trace / (uint32_t)P.N, tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const float2 *a = (const float2 *)P.a, *x = (const float2 *)P.x;
+    const float2 *a = (const float2 *)P.a;
     for (uint32_t k = tid; k < (uint32_t)K * NSLOT * 2; k += GT_THREADS) H[k] = 0;
-    for (long k = tid; k < T; k += GT_THREADS) xl[k] = x[k];
-    const float bound = __uint_as_float(*bound_bits);
+    const float bound = __uint_as_float(bound_bits[0]);
+    const bool a_cplx = __builtin_amdgcn_readfirstlane((int)bound_bits[1]) != 0;
     // scale: 2^46 / largest single contribution -- and never more than 2^62 / (entries of the trace x largest contribution): a slot can at most receive
     // every entry of its trace, so the 64-bit sums cannot wrap however dense the scatterer cloud (beyond 2^16 entries per trace the resolution drops from
     // 2^-46 to 2^-62 x entries of the largest contribution: still 2^-32 at 10^9 entries, far below the fp32 rounding of the result)
@@ -228,6 +347,7 @@ __global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensPa
     const uint64_t s_lo = (uint64_t)blk * SB, I = P.I;
     const long cbase = (long)Q * (long)s_lo - thi;                   // fine index of slot 0
     __syncthreads();
+    if (P.dbg & 4) return;
     if (bound <= 3.0e38f) {
         // Scan: one scatterer per lane and pass, the (receive, transmit) sub-aperture pairs in the outer loop; two coalesced table reads, the delay,
         // the slot test.  Entries that land in this block -- 1 / (blocks per trace) of them -- go to the WAVE's queue in LDS (ballot + prefix: no
@@ -235,10 +355,19 @@ __global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensPa
         float4 *myq = wq + (size_t)wave * GT_WQ;
         uint32_t qn = 0;                                             // queued entries (uniform)
         // (the scan's test is a window on r1 + r2, a hair wider than the block: the exact slot -- the reference's own fp32 delay arithmetic -- is found here)
-        auto work_off = [&](uint32_t first, uint32_t count) {
-            if (lane < count) {
-                const float4 it = myq[first + lane];
-                float r1 = it.y, r2 = it.z;
+        // Work-off in two halves: `take` moves 64 queued entries into registers and ISSUES their amplitude gathers; `retire` -- at the next trigger,
+        // a few scan passes later -- finishes them.  The gather's latency (the one dependent global read of an entry) runs under the scan.
+        float4 pit = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 pai = make_float2(0.f, 0.f);
+        uint32_t pcount = 0;                                         // entries taken and not retired (uniform)
+        auto take = [&](uint32_t first, uint32_t count) {
+            if (lane < count) { pit = myq[first + lane]; pai = a[__float_as_uint(pit.x)]; }
+            pcount = count;
+        };
+        auto retire = [&]() {
+            if (P.dbg & 2) { pcount = 0; return; }
+            if (lane < pcount) {
+                float r1 = pit.y, r2 = pit.z;
                 const float d = (cinv * (r1 + r2) + toff) * fs;                                               // src/greens.cu:65
                 const float ef = (float)Q * d, cf = ceilf(ef);
                 const float sl = cf - (float)cbase;                  // slot of the entry; a non-finite delay fails the test
@@ -246,96 +375,176 @@ __global__ void __launch_bounds__(GT_THREADS) greens_train_kernel(const GreensPa
                     const uint32_t slot = (uint32_t)sl;
                     const float u = cf - ef;                         // in [0, 1): exact
                     if (R0 != 0.f) { r1 = r1 < R0 ? R0 : r1; r2 = r2 < R0 ? R0 : r2; } else { r1 = 1.f; r2 = 1.f; }
-                    const float2 ai = a[__float_as_uint(it.x)];
-                    const float g = Sc / (r1 * r2 * fsr);
+                    const float2 ai = pai;
+                    const float g = Sc * __builtin_amdgcn_rcpf(r1 * r2 * fsr);    // (v_rcp_f32: 1 ulp -- the sum is compared at 1e-4; the full division sequence is a tenth of this loop)
                     float w[4];
                     if constexpr (INTERP == 0) { w[0] = u < 0.5f ? 1.f : 0.f; w[1] = 1.f - w[0]; }
                     else interp_weights<INTERP>(u, w);
+                    unsigned long long *h = (unsigned long long *)(H + (size_t)slot * 2);
+                    if (a_cplx) {
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const long long vr = gt_fixed(ai.x * g * w[k]), vi = gt_fixed(ai.y * g * w[k]);
-                        unsigned long long *h = (unsigned long long *)(H + ((size_t)k * NSLOT + slot) * 2);
-                        if (vr) atomicAdd(h, (unsigned long long)vr);
-                        if (vi) atomicAdd(h + 1, (unsigned long long)vi);
+                        for (int k = 0; k < K; ++k) {
+                            const long long vr = gt_fixed(ai.x * g * w[k]), vi = gt_fixed(ai.y * g * w[k]);
+                            if (vr) atomicAdd(h + (size_t)k * NSLOT * 2, (unsigned long long)vr);
+                            if (vi) atomicAdd(h + (size_t)k * NSLOT * 2 + 1, (unsigned long long)vi);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const long long vr = gt_fixed(ai.x * g * w[k]);
+                            if (vr) atomicAdd(h + (size_t)k * NSLOT * 2, (unsigned long long)vr);
+                        }
                     }
                 }
             }
+            pcount = 0;
         };
         // r1 + r2 of the entries whose slot can lie in [0, NSLOT): ceil(Q d) - cbase in [0, NSLOT) <=> Q d in (cbase - 1, cbase + NSLOT - 1], d = (cinv r + toff) fs
-        const double rlo_d = (((double)cbase - 1.0) / ((double)Q * P.fs) - (P.t0 - P.s0)) / P.cinv, rhi_d = (((double)cbase + (double)NSLOT - 1.0) / ((double)Q * P.fs) - (P.t0 - P.s0)) / P.cinv;
+        // (host: path_per_fine = 1 / (Q fs cinv), path_off = (t0 - s0) / cinv -- their roundings are far inside the margin)
+        const double rlo_d = ((double)cbase - 1.0) * P.path_per_fine - P.path_off, rhi_d = ((double)cbase + (double)NSLOT - 1.0) * P.path_per_fine - P.path_off;
         // (fp32 roundings of the delay (cinv r + toff) fs: ~3 ulp of r -- and of the offset, expressed as a path length, when |toff| is the larger term)
-        const double mar = 4e-6 * (fabs(rlo_d) + fabs(rhi_d) + 2.0 * fabs(P.t0 - P.s0) / P.cinv) + 1e-30;
+        const double mar = 4e-6 * (fabs(rlo_d) + fabs(rhi_d) + 2.0 * fabs(P.path_off)) + 1e-30;
         const float rlo = (float)(rlo_d - mar), rhi = (float)(rhi_d + mar);
+        const uint32_t I32 = (uint32_t)I, nchunk = P.nchunk;         // (I < 2^32: host)
+        uint32_t *ccount = clist + GT_LCAP + 16;
         for (int sub = 0; sub < EE; ++sub) {
             const int ne = sub % P.En, me = sub / P.En;
-            const float *R1 = P.r1tab + ((size_t)n + (size_t)ne * P.N) * I, *R2 = P.r2tab + ((size_t)m + (size_t)me * P.M) * I;
-            // (four scatterers per lane and iteration: the eight table loads are in flight together -- one exposed L2 latency per 4096 entries, not per 1024)
-            const uint32_t I32 = (uint32_t)I;                        // (I < 2^32: host)
-            for (uint32_t i0 = 0; i0 < I32; i0 += 4 * GT_THREADS) {
-                float r1v[4], r2v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t i = i0 + tid + (uint32_t)q * GT_THREADS;
-                    r1v[q] = i < I32 ? R1[i] : INFINITY;             // (an infinite distance: never in a block)
-                    r2v[q] = i < I32 ? R2[i] : INFINITY;
+            const size_t row1 = (size_t)n + (size_t)ne * P.N, row2 = (size_t)m + (size_t)me * P.M;
+            const float *R1 = P.r1tab + row1 * I, *R2 = P.r2tab + row2 * I;
+            const float2 *B1 = (const float2 *)P.cb1 + row1 * nchunk, *B2 = (const float2 *)P.cb2 + row2 * nchunk;
+            for (uint32_t c0 = 0; c0 < nchunk; c0 += GT_LCAP) {
+                // the chunks whose distance sums [min1 + min2, max1 + max2] meet the window (fp32 addition is monotone: the chunk test can only
+                // be wider than the entry test below), in any order
+                if (tid == 0) *ccount = 0;
+                __syncthreads();
+                const uint32_t c1 = c0 + GT_LCAP < nchunk ? c0 + GT_LCAP : nchunk;
+                for (uint32_t c = c0 + tid; c < c1; c += GT_THREADS) {
+                    const float2 b1 = B1[c], b2 = B2[c];
+                    if (b1.x + b2.x <= rhi && b1.y + b2.y >= rlo) clist[atomicAdd(ccount, 1u)] = c;
                 }
+                __syncthreads();
+                const uint32_t nact = *ccount;
+                if (tid < 16u) clist[nact + tid] = 0xffffffffu;      // (whole groups of 16 below)
+                __syncthreads();
+                // 4 CGRP chunks per pass -- four per lane, eight table loads -- and the NEXT pass's loads are issued before this pass's entries are
+                // tested: the table latency is paid once per list, not once per pass
+                float r1n[4], r2n[4];
+                uint32_t ivn[4];
+                auto load_pass = [&](uint32_t e0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float r = r1v[q] + r2v[q];
-                    const bool hit = r >= rlo && r <= rhi;           // (infinite / NaN distances fail)
-                    const uint64_t mask = __ballot(hit);
-                    if (mask) {
-                        if (hit) myq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] =
-                                     make_float4(__uint_as_float(i0 + tid + (uint32_t)q * GT_THREADS), r1v[q], r2v[q], 0.f);
-                        qn += (uint32_t)__builtin_popcountll(mask);
-                        __builtin_amdgcn_wave_barrier();
-                        if (qn >= 64u) { qn -= 64u; work_off(qn, 64u); __builtin_amdgcn_wave_barrier(); }
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t c = clist[e0 + (uint32_t)q * CGRP + (wave >> 2)];
+                        const uint32_t i = c * (uint32_t)GT_CHUNK + (tid & (uint32_t)(GT_CHUNK - 1));
+                        const bool in = c != 0xffffffffu && i < I32;
+                        ivn[q] = i;
+                        r1n[q] = in ? R1[i] : INFINITY;              // (an infinite distance: never in a block)
+                        r2n[q] = in ? R2[i] : INFINITY;
+                    }
+                };
+                if (nact) load_pass(0u);
+                for (uint32_t e0 = 0; e0 < nact; e0 += 4u * CGRP) {
+                    float r1v[4], r2v[4];
+                    uint32_t iv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { r1v[q] = r1n[q]; r2v[q] = r2n[q]; iv[q] = ivn[q]; }
+                    if (e0 + 4u * CGRP < nact) load_pass(e0 + 4u * CGRP);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float r = r1v[q] + r2v[q];
+                        const bool hit = r >= rlo && r <= rhi;       // (infinite / NaN distances fail)
+                        const uint64_t mask = __ballot(hit);
+                        if (mask) {
+                            if (hit) myq[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] =
+                                         make_float4(__uint_as_float(iv[q]), r1v[q], r2v[q], 0.f);
+                            qn += (uint32_t)__builtin_popcountll(mask);
+                            __builtin_amdgcn_wave_barrier();
+                            if (qn >= 64u) { retire(); qn -= 64u; take(qn, 64u); __builtin_amdgcn_wave_barrier(); }
+                        }
                     }
                 }
+                __syncthreads();                                     // (the list is rebuilt)
             }
         }
-        work_off(0u, qn);
+        retire();
+        take(0u, qn);
+        retire();
     }
     __syncthreads();
-    // fixed point -> float2, in place, train by train (the float image of train k lies inside the fixed-point images of trains <= k)
+    if (P.dbg & 8) return;
+    // fixed point -> float2, in place, train by train (the float image of train k lies inside the fixed-point images of trains <= k) -- and
+    // DE-INTERLEAVED by phase: with t = Q j + p the sum over the taps is  y[s] = sum_k sum_p sum_j A_kp[s - j] x[Q j + p + o_k],  A_kp[s'] = H_k[Q s' - p]:
+    // K Q plain FIR filters of ~T / Q taps on unit-stride sequences -- the lanes of a wave read consecutive elements (the interleaved trains had them
+    // Q elements apart: a Q-way bank conflict on every read), and the waveform tap is the same for the whole wave: a scalar load.
     const float inv = Sc > 0.f ? 1.0f / Sc : 0.f;
-    float2 *Hf = (float2 *)gsm;
-    for (int k = 0; k < K; ++k) {
-        float2 v[4];                                                 // NSLOT <= 4 * GT_THREADS (host)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t j = tid + q * GT_THREADS;
-            v[q] = j < NSLOT ? make_float2(gt_float(H[((size_t)k * NSLOT + j) * 2]) * inv, gt_float(H[((size_t)k * NSLOT + j) * 2 + 1]) * inv) : make_float2(0.f, 0.f);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const uint32_t j = tid + q * GT_THREADS; if (j < NSLOT) Hf[(size_t)k * NSLOT + j] = v[q]; }
-        __syncthreads();
-    }
-    // the convolution: output s_lo + sl, the (train, tap index) pairs dealt out to PARTS threads per output
-    const uint32_t so = tid % SB, part = tid / SB;
-    float2 acc = make_float2(0.f, 0.f);
+    const int jmax = (int)(thi / (long)Q);
+    const float rQ = 1.0f / (float)Q;
+    const uint32_t AL = SB + (uint32_t)jmax, ALP = AL | 1u;          // (odd: the scatter below walks the phases, ALP elements apart)
+    float2 *Af = (float2 *)gsm + 8;                                  // [K][Q][ALP], 8 zero elements before it
     {
-        const long len0 = thi_k0 - tlo + 1, len1 = thi_k1 - tlo + 1;
-        const long J = len0 + (K - 1) * len1;                        // pairs per output
-        long j0 = J * (long)part / (long)PARTS, j1 = J * (long)(part + 1) / (long)PARTS;
-        for (int k = 0; k < K; ++k) {
-            const long lenk = k == 0 ? len0 : len1, base = k == 0 ? 0 : len0 + (k - 1) * len1;
-            const long a0 = j0 > base ? j0 - base : 0, a1 = (j1 - base) < lenk ? (j1 - base) : lenk;
-            const float2 *hk = Hf + (size_t)k * NSLOT + (size_t)Q * so + (size_t)(thi - tlo);    // slot of t = tlo; t + 1 is one slot down
-            for (long q = a0; q < a1; ++q) {
-                const float2 h = hk[-q], xv = xl[tlo + q + O0 + k];
-                acc.x += h.x * xv.x - h.y * xv.y; acc.y += h.x * xv.y + h.y * xv.x;
+        float2 v[K][4];                                              // NSLOT <= 4 * GT_THREADS (host): every train in registers before the first float is written
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t j = tid + q * GT_THREADS;
+                v[k][q] = j < NSLOT ? make_float2(gt_float(H[((size_t)k * NSLOT + j) * 2]) * inv, gt_float(H[((size_t)k * NSLOT + j) * 2 + 1]) * inv) : make_float2(0.f, 0.f);
             }
+        __syncthreads();
+        if (tid < 8u) ((float2 *)gsm)[tid] = make_float2(0.f, 0.f);
+        // positions no slot maps to -- the first and last element of a sequence (some phases) and the pad -- are zeroed, the others written: disjoint
+        for (uint32_t e = tid; e < (uint32_t)(K * Q) * 3u; e += GT_THREADS) {
+            const uint32_t c = e / 3u, w = e - 3u * c, aa = w == 0 ? 0u : (w == 1 ? AL - 1u : ALP - 1u);
+            const int ph = (int)(c % (uint32_t)Q), slot = Q * ((int)aa - jmax) - ph + (int)thi;
+            if (aa >= AL || slot < 0 || slot >= (int)NSLOT) Af[(size_t)c * ALP + aa] = make_float2(0.f, 0.f);
         }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t j = tid + q * GT_THREADS;
+                if (j < NSLOT) {                                     // slot = Q (a - jmax) - p + thi
+                    // (u >= -(Q - 1); floor(n / Q) = floor((n + 1/2) / Q), 1 / (2 Q) away from an integer: exact in fp32 for n < 2^20)
+                    const int u = (int)j - (int)thi + Q * jmax, aq = (int)(((float)(u + Q - 1) + 0.5f) * rQ), ph = Q * aq - u;
+                    Af[((size_t)k * Q + ph) * ALP + aq] = v[k][q];
+                }
+            }
+        __syncthreads();
     }
-    red[part * SB + so] = acc;
+    if (P.dbg & 16) return;
+    // the convolution: output s_lo + so, the groups of 8 taps dealt out to PARTS threads per output (a wave: one part, 64 outputs); per group
+    // three scalar loads (its offset, its taps), eight LDS reads of consecutive elements, sixteen packed multiply-adds.  A padded tap multiplies
+    // whatever finite element precedes the sequence by zero (the 8 elements before the first sequence are zeros).
+    const uint32_t PARTS = GT_THREADS / SB, so = tid % SB;
+    const int part = __builtin_amdgcn_readfirstlane((int)(tid / SB));                // (SB >= 64: uniform)
+    v2f acc = {0.f, 0.f}, acc2 = {0.f, 0.f};
+    {
+        const gt_ci grp = (gt_ci)P.segs;
+        const gt_cf4 xt = (gt_cf4)P.xtab;
+        const int G = grp[0];
+        const int g0 = (int)((long)G * part / (long)PARTS), g1 = (int)((long)G * (part + 1) / (long)PARTS);
+        const float2 *As = Af + so;
+        for (int g = g0; g < g1; ++g) {
+            const float2 *Ak = As + grp[1 + g];
+            gt_f4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = xt[8 * (long)g + u];
+            float2 h[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = Ak[-u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc = (v2f){t[u].x, t[u].y} * h[u].x + acc; acc2 = (v2f){t[u].z, t[u].w} * h[u].y + acc2; }
+        }
+        acc += acc2;
+    }
+    float2 *red = (float2 *)(gsm + P.pb_off);                        // [PARTS][SB]
+    red[(size_t)part * SB + so] = make_float2(acc.x, acc.y);
     __syncthreads();
     if (part == 0) {
-        for (uint32_t p2 = 1; p2 < PARTS; ++p2) { const float2 r = red[p2 * SB + so]; acc.x += r.x; acc.y += r.y; }
+        float2 sum = make_float2(acc.x, acc.y);
+        for (uint32_t p2 = 1; p2 < PARTS; ++p2) { const float2 r = red[p2 * SB + so]; sum.x += r.x; sum.y += r.y; }
         const uint64_t s = s_lo + so;
-        if (!(bound <= 3.0e38f)) acc = make_float2(NAN, NAN);
-        if (s < P.S) ((float2 *)P.y)[((size_t)n + (size_t)m * P.N) * P.S + s] = acc;
+        if (!(bound <= 3.0e38f)) sum = make_float2(NAN, NAN);
+        if (s < P.S) ((float2 *)P.y)[((size_t)n + (size_t)m * P.N) * P.S + s] = sum;
     }
 }
 
@@ -352,32 +561,82 @@ static int launch_greens_train(const GreensParams &P, hipStream_t s) {
     if (thi < tlo) return 1;                                         // (a waveform shorter than the interpolator: nothing is ever in support)
     GreensParams p = P;
     p.q = (int)q;
+    // (threads, outputs per block): 256 threads with 64 (else 128) outputs if the workgroup stays under 48 KB of LDS (three or more per CU);
+    // else 1024 threads with the longest block that fits at all
     size_t lds = 0;
-    for (uint32_t sb : {512u, 256u, 128u, 64u}) {
+    int th = 0;
+    static const struct { int th; uint32_t sb; size_t cap; } shapes[] = {{256, 64, 48 * 1024}, {256, 128, 48 * 1024}, {1024, 512, 150 * 1024}, {1024, 256, 150 * 1024},
+                                                                         {1024, 128, 150 * 1024}, {1024, 64, 150 * 1024}};
+    int only_th = 0;
+    uint32_t only_sb = 0;
+    if (const char *e = getenv("QDAS_GREENS_THREADS")) only_th = atoi(e);                 // (experiments)
+    if (const char *e = getenv("QDAS_GREENS_SB")) only_sb = (uint32_t)atoi(e);
+    for (const auto &sh : shapes) {
+        if ((only_th && sh.th != only_th) || (only_sb && sh.sb != only_sb)) continue;
+        const uint32_t sb = sh.sb;
         const uint64_t nslot = (uint64_t)q * (sb - 1) + (uint64_t)(thi - tlo) + 1;
-        lds = (size_t)K * nslot * 16 + (size_t)(GT_THREADS / 64) * GT_WQ * 16 + (size_t)GT_THREADS * 8 + (size_t)T * 8;
-        if (nslot <= 4ull * GT_THREADS && lds <= 150 * 1024) { p.sb = sb; break; }
+        // scan: trains (fixed point) | wave queues ... waveform | chunk list | segments;  convolution: trains (float, de-interleaved) | part sums ... waveform ...
+        const uint64_t alp = (sb + (uint64_t)thi / (uint64_t)q) | 1u;
+        const size_t scan_end = (size_t)K * nslot * 16 + (size_t)(sh.th / 64) * GT_WQ * 16, pb = ((size_t)K * (size_t)q * alp * 8 + 64 + 15) / 16 * 16;
+        const size_t conv_end = pb + (size_t)sh.th * 8;
+        const size_t xo = scan_end > conv_end ? scan_end : conv_end;
+        lds = xo + (size_t)(2 * sh.th + 20) * 4;
+        if (nslot <= 4ull * sh.th && (uint64_t)q * alp <= 2 * nslot && K * (int)q <= 64 && lds <= sh.cap) { p.sb = sb; th = sh.th; p.pb_off = (uint32_t)pb; p.x_off = (uint32_t)xo; break; }
     }
     if (!p.sb) return 1;
-    const uint64_t ne_tot = P.N * (uint64_t)P.En, me_tot = P.M * (uint64_t)P.Em;
-    if (ne_tot > 65535 || me_tot > 65535 || P.I + 4ull * GT_THREADS >= (1ull << 32) || (ne_tot + me_tot) * P.I * 4 > (8ull << 30)) return 1;      // (distance tables: at most 8 GiB)
-    unsigned int *bound = nullptr;
-    float *tabs = nullptr;
-    if (hipMallocAsync((void **)&bound, 16 + sizeof(float) * (ne_tot + me_tot) * P.I, s) != hipSuccess || !bound) { (void)hipGetLastError(); return 1; }
-    if (hipMemsetAsync(bound, 0, sizeof(unsigned int), s) != hipSuccess) { (void)hipGetLastError(); (void)hipFreeAsync(bound, s); return 1; }
-    tabs = (float *)((char *)bound + 16);
-    p.r1tab = tabs; p.r2tab = tabs + ne_tot * P.I;
-    greens_dist_kernel<<<dim3((unsigned)((P.I + 255) / 256), (unsigned)ne_tot), 256, 0, s>>>((const float *)P.Ps, (const float *)P.Pr, tabs, P.I);
-    greens_dist_kernel<<<dim3((unsigned)((P.I + 255) / 256), (unsigned)me_tot), 256, 0, s>>>((const float *)P.Ps, (const float *)P.Pv, tabs + ne_tot * P.I, P.I);
-    greens_bound_kernel<<<(unsigned)((P.I + 255) / 256), 256, 0, s>>>(p, bound);
+    const uint64_t ne_tot = P.N * (uint64_t)P.En, me_tot = P.M * (uint64_t)P.Em, I = P.I;
+    if (ne_tot > 65535 || me_tot > 65535 || I + 4096ull >= (1ull << 32) || (ne_tot + me_tot) * I * 4 > (8ull << 30)) return 1;      // (distance tables: at most 8 GiB)
+    const bool no_sort = getenv("QDAS_GREENS_NO_SORT") != nullptr;      // (read per call: the tests switch it)
+    const bool sorted = !no_sort && I >= 4096;           // (fewer: a handful of chunks, nothing to skip)
+    const uint64_t nchunk = (I + GT_CHUNK - 1) / GT_CHUNK;
+    // one stream-ordered allocation: bound | bounding box | distance tables | chunk bounds | sorted positions, amplitudes | cell keys | cell counts | segments | taps
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t o_tab = 256, o_cb = o_tab + up(sizeof(float) * (ne_tot + me_tot) * I), o_ps = o_cb + up(sizeof(float2) * (ne_tot + me_tot) * nchunk),
+                 o_a = o_ps + (sorted ? up(12 * I) : 0), o_key = o_a + (sorted ? up(8 * I) : 0), o_hist = o_key + (sorted ? up(4 * I) : 0), o_seg = o_hist + (sorted ? up(4 * (size_t)GT_CELLS) : 0),
+                 o_xt = o_seg + up(sizeof(int) * ((size_t)K * (size_t)T / 8 + (size_t)K * (size_t)q + 8)), total = o_xt + up(sizeof(float4) * ((size_t)K * (size_t)T + 8 * (size_t)K * (size_t)q + 8));
+    unsigned char *buf = nullptr;
+    if (hipMallocAsync((void **)&buf, total, s) != hipSuccess || !buf) { (void)hipGetLastError(); return 1; }
+    unsigned int *bound = (unsigned int *)buf;
+    float *tabs = (float *)(buf + o_tab);
+    float2 *cb = (float2 *)(buf + o_cb);
+    auto bail = [&]() { (void)hipGetLastError(); (void)hipFreeAsync(buf, s); return 1; };
+    static const uint32_t init[8] = {0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};               // bound; any complex amplitude; box {min x y z = all ones, max x y z = 0}
+    if (hipMemcpyAsync(buf, init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess) return bail();
+    const float *ps = (const float *)P.Ps;
+    const unsigned gI = (unsigned)((I + 255) / 256);
+    if (sorted) {
+        uint32_t *bb = (uint32_t *)buf + 2, *key = (uint32_t *)(buf + o_key), *hist = (uint32_t *)(buf + o_hist);
+        float *pso = (float *)(buf + o_ps);
+        float2 *ao = (float2 *)(buf + o_a);
+        if (hipMemsetAsync(hist, 0, 4 * (size_t)GT_CELLS, s) != hipSuccess) return bail();
+        greens_bbox_kernel<<<gI, 256, 0, s>>>(ps, I, bb);
+        greens_key_kernel<<<gI, 256, 0, s>>>(ps, I, bb, key, hist);
+        greens_cellscan_kernel<<<1, 1024, 0, s>>>(hist);
+        greens_gather_kernel<<<gI, 256, 0, s>>>(ps, (const float2 *)P.a, key, hist, I, pso, ao);
+        ps = pso; p.a = ao;
+    }
+    p.r1tab = tabs; p.r2tab = tabs + ne_tot * I;
+    p.cb1 = (const float *)cb; p.cb2 = (const float *)(cb + ne_tot * nchunk);
+    p.nchunk = (uint32_t)nchunk;
+    p.path_per_fine = 1.0 / (q * P.fs * P.cinv); p.path_off = (P.t0 - P.s0) / P.cinv;
+    p.dbg = getenv("QDAS_GREENS_DBG") ? atoi(getenv("QDAS_GREENS_DBG")) : 0;
+    greens_dist_kernel<<<dim3((unsigned)nchunk, (unsigned)ne_tot), GT_CHUNK, 0, s>>>(ps, (const float *)P.Pr, tabs, cb, I);
+    greens_dist_kernel<<<dim3((unsigned)nchunk, (unsigned)me_tot), GT_CHUNK, 0, s>>>(ps, (const float *)P.Pv, tabs + ne_tot * I, cb + ne_tot * nchunk, I);
+    greens_bound_kernel<<<gI, 256, 0, s>>>(P, bound);
+    p.segs = buf + o_seg; p.xtab = buf + o_xt;
+    {
+        const int jmax = (int)(thi / (long)q), alp = (int)((p.sb + (uint32_t)jmax) | 1u);                 // (as the kernel lays the trains out)
+        greens_xtab_kernel<<<(unsigned)(((size_t)K * (size_t)T + 8 * (size_t)K * (size_t)q + 255) / 256), 256, 0, s>>>((const float2 *)P.x, K, (int)q, K == 4 ? -1 : 0, (int)tlo, (int)thi,
+                                                                                                                     (int)(K == 4 ? T - 3 : T - 2), alp, jmax, (int *)(buf + o_seg), (float4 *)(buf + o_xt));
+    }
     p.nblk = (uint32_t)((P.S + p.sb - 1) / p.sb);
     const uint64_t items = (uint64_t)p.nblk * P.N * P.M, g8 = (items + 7) / 8 * 8;
-    if (g8 >= (1ull << 31)) { (void)hipFreeAsync(bound, s); return 1; }
-    const dim3 g((unsigned)g8), b(GT_THREADS);
+    if (g8 >= (1ull << 31)) return bail();
+    const dim3 g((unsigned)g8), b((unsigned)th);
     hipError_t err = hipSuccess;
 #define QT(I)                                                                                       \
     do {                                                                                            \
-        auto kfn = greens_train_kernel<I>;                                                          \
+        auto kfn = th == 256 ? greens_train_kernel<I, 256> : greens_train_kernel<I, 1024>;          \
         err = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (err == hipSuccess) kfn<<<g, b, lds, s>>>(p, bound);                                     \
     } while (0)
@@ -390,7 +649,7 @@ static int launch_greens_train(const GreensParams &P, hipStream_t s) {
         default: err = hipErrorInvalidValue;
     }
 #undef QT
-    (void)hipFreeAsync(bound, s);
+    (void)hipFreeAsync(buf, s);
     return (err == hipSuccess && hipGetLastError() == hipSuccess) ? 0 : 1;
 }
 

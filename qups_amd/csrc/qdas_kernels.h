@@ -103,6 +103,12 @@ struct GreensParams {
     int32_t q;                       // impulse-train kernel (greens.hip): the integer waveform-to-data sampling ratio, output samples per workgroup
     uint32_t sb, nblk;
     const float *r1tab, *r2tab;      // ... and the scatterer-to-element distances, [N En][I] and [M Em][I]
+    const float *cb1, *cb2;          // ... their {min, max} per chunk of 256 scatterers, [N En][nchunk][2] and [M Em][nchunk][2]
+    uint32_t nchunk;
+    int32_t dbg;
+    double path_per_fine, path_off;  // path length r1 + r2 per fine (waveform-rate) sample, and of the time offset t0 - s0
+    const void *segs, *xtab;         // the convolution's groups of 8 taps: {count, element offset per group}, and the taps (greens_xtab_kernel)
+    uint32_t pb_off, x_off;          // LDS byte offsets: slice sums of the convolution, the waveform
 };
 hipError_t launch_greens(const GreensParams &P, int dtype, hipStream_t s);
 

@@ -149,6 +149,45 @@ def test_greens_impulse_trains_many_scatterers_edges_and_reproducibility(monkeyp
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("interp", ["linear", "lanczos3"])
+def test_greens_morton_sorted_scan_changes_no_bit(interp, monkeypatch):
+    """from 4096 scatterers on, the impulse-train kernel works on the scatterers in Morton order and visits only the chunks of 256 whose distance
+    bounds reach its block of samples (csrc/greens.hip: greens_key_kernel, greens_dist_kernel).  The trains are integer sums, so the image must be
+    bit-identical to the unsorted scan (QDAS_GREENS_NO_SORT) -- with coincident scatterers, a degenerate axis (a planar cloud) and non-finite
+    positions in the cloud -- and agree with the float64 oracle."""
+    import torch
+    from oracle import greens_oracle as GO
+    from qups_amd.greens import greens_kernel
+    g = _setup(seed=5, N=3, M=2, I=4300, fsr=2.0)
+    r = np.random.default_rng(2)
+    Ps = g["Ps"].copy()
+    Ps[1, :] = 0.0                                                        # planar cloud: the y axis of the bounding box has no extent
+    Ps[:, 100:140] = Ps[:, 99:100]                                        # 41 coincident scatterers
+    g["a"] = (g["a"] * 10.0 ** r.uniform(-3, 0, g["a"].shape)).astype(np.complex64)
+    args = (g["a"], g["Pr"], g["Pv"], g["x"], 900, g["s0"], g["t0"], g["fs"], 2.0, g["cinv"], g["R0"], interp)
+    monkeypatch.setenv("QDAS_GREENS_TRAIN_MIN", "0")
+    ref = GO.greens_kernel(Ps, *args)
+    ys = []
+    for no_sort in (False, True):
+        if no_sort:
+            monkeypatch.setenv("QDAS_GREENS_NO_SORT", "1")
+        ys.append(greens_kernel(Ps, *args, "single"))
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], ys[1])
+    o = ys[0].cpu().numpy()
+    den = np.abs(ref).max()
+    assert den > 0 and np.abs(o - ref).max() / den <= 3e-4
+    # non-finite positions: the scatterer contributes NaN / nothing exactly as in the unsorted scan
+    monkeypatch.delenv("QDAS_GREENS_NO_SORT")
+    Pn = Ps.copy(); Pn[0, 7] = np.nan; Pn[2, 4200] = np.inf
+    y_s = greens_kernel(Pn, *args, "single")
+    monkeypatch.setenv("QDAS_GREENS_NO_SORT", "1")
+    y_u = greens_kernel(Pn, *args, "single")
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(y_s).view(torch.int32), torch.view_as_real(y_u).view(torch.int32))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("QDAS_GREENS_FUZZ", "16"))))
 def test_greens_random_configuration(seed, monkeypatch):
     """random simulator configurations (elements, sub-apertures, scatterer counts around the chunk sizes of both kernels, record lengths around the block
