@@ -36,7 +36,7 @@ extern "C" {
 /* 100: rounds 1-3.  101 (round 5): qdas_wsinterpd_desc carries ystride[8] / lane_dim / reserved (added in round 4 without a bump), QDAS_PLAN_PREFOLDED rejects
  * apodization arrays.  EVERY descriptor of this header must be ZERO-INITIALISED by the caller (memset / `= {0}`) before its fields are set: fields added by
  * later versions then read as "default", and a caller compiled against an older header must check qdas_version() against the QDAS_VERSION it was built with. */
-#define QDAS_VERSION 101
+#define QDAS_VERSION 102
 
 /* ---- data precision: the reference's kernel postfix (kern/das_spec.m:218-222) */
 #define QDAS_F64 0 /* 'DAS'  : double2 data/apod/y, double geometry + time            */
@@ -467,7 +467,8 @@ int qdas_iir(const qdas_iir_desc *desc, const void *x, void *y, void *stream);
  * these three (mex/qdas_mex.c dev_in / dev_out).  device: HIP ordinal, -1 = current.  qdas_device_copy is synchronous; kind 0: host -> device,
  * 1: device -> host, 2: device -> device. */
 int qdas_device_malloc(void **p, size_t bytes, int device);
-int qdas_device_free(void *p, int device);
+int qdas_device_free(void *p, int device);      /* (buffers of qdas_device_malloc are kept for reuse, at most 256 MiB: a call-per-launch gateway does not map / unmap) */
+int qdas_device_trim(void);                      /* ... and released here */
 int qdas_device_copy(void *dst, const void *src, size_t bytes, int kind, int device);
 
 /* ---- Layout conversion for row-major hosts (numpy / torch; no reference counterpart: MATLAB arrays are column-major already and

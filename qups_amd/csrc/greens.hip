@@ -255,12 +255,12 @@ __global__ void __launch_bounds__(256) greens_gather_kernel(const float *__restr
     ao[j] = a[i];
 }
 
-// |t| < 2^53 float -> the nearest 64-bit integer, without the generic conversion sequence: t = hi 2^23 + lo with hi = rint(t 2^-23) (|hi| < 2^30) and
-// lo = t - hi 2^23 exactly (one FMA; |lo| <= 2^22), both through v_cvt_i32_f32
+// |t| < 2^51 float -> the nearest 64-bit integer (ties to even), without the generic conversion sequence: the float is exact as a double, and
+// adding 1.5 x 2^52 leaves the integer in the low mantissa bits -- a conversion, a double add and a 64-bit subtract (the two-rounding fp32 split that
+// stood here took eleven instructions and was a fifth of the work-off loop)
 __device__ __forceinline__ long long gt_fixed(float t) {
-    const float hi = rintf(t * 1.1920928955078125e-7f);
-    const float lo = fmaf(hi, -8388608.0f, t);
-    return ((long long)(int)hi << 23) + (long long)(int)rintf(lo);
+    const double d = (double)t + 6755399441055744.0;
+    return (long long)__double_as_longlong(d) - 0x4338000000000000ll;
 }
 
 // ... and back: (float)v without the generic 64-bit conversion sequence (two 32-bit conversions and an FMA; the sum is rounded once more, 2^-24 relative)
@@ -385,14 +385,14 @@ __global__ void __launch_bounds__(TH) greens_train_kernel(const GreensParams P, 
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
                             const long long vr = gt_fixed(ai.x * g * w[k]), vi = gt_fixed(ai.y * g * w[k]);
-                            if (vr) atomicAdd(h + (size_t)k * NSLOT * 2, (unsigned long long)vr);
-                            if (vi) atomicAdd(h + (size_t)k * NSLOT * 2 + 1, (unsigned long long)vi);
+                            atomicAdd(h + (size_t)k * NSLOT * 2, (unsigned long long)vr);
+                            atomicAdd(h + (size_t)k * NSLOT * 2 + 1, (unsigned long long)vi);
                         }
                     } else {
 #pragma unroll
                         for (int k = 0; k < K; ++k) {
                             const long long vr = gt_fixed(ai.x * g * w[k]);
-                            if (vr) atomicAdd(h + (size_t)k * NSLOT * 2, (unsigned long long)vr);
+                            atomicAdd(h + (size_t)k * NSLOT * 2, (unsigned long long)vr);
                         }
                     }
                 }
@@ -600,8 +600,8 @@ static int launch_greens_train(const GreensParams &P, hipStream_t s) {
     float *tabs = (float *)(buf + o_tab);
     float2 *cb = (float2 *)(buf + o_cb);
     auto bail = [&]() { (void)hipGetLastError(); (void)hipFreeAsync(buf, s); return 1; };
-    static const uint32_t init[8] = {0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};               // bound; any complex amplitude; box {min x y z = all ones, max x y z = 0}
-    if (hipMemcpyAsync(buf, init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess) return bail();
+    // bound = 0; any complex amplitude = 0; bounding box {min x y z = all ones, max x y z = 0} (ordered bits)
+    if (hipMemsetAsync(buf, 0, 32, s) != hipSuccess || hipMemsetAsync(buf + 8, 0xff, 12, s) != hipSuccess) return bail();
     const float *ps = (const float *)P.Ps;
     const unsigned gI = (unsigned)((I + 255) / 256);
     if (sorted) {

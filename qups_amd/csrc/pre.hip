@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <vector>
+extern "C" int qdas_internal_upload(void *dst, const void *src, size_t bytes);      // qdas_api.hip: host -> device through pinned staging
 
 namespace qdas {
 
@@ -387,7 +388,7 @@ int pre_create(PrePlan **out, uint64_t T, uint64_t K, uint64_t N, int in_type, d
         }
         const size_t lds_bytes = sizeof(float2) * (p->N + p->N / 16 + 1);
         bool ok = hipMalloc(&p->tw, sizeof(float2) * p->N) == hipSuccess &&
-                  hipMemcpy(p->tw, h.data(), sizeof(float2) * p->N, hipMemcpyHostToDevice) == hipSuccess;
+                  qdas_internal_upload(p->tw, h.data(), sizeof(float2) * p->N) == (int)hipSuccess;
         if (ok && lds_bytes > 65536) {
             const void *fns[4] = {(const void *)hilbert_lds_kernel<float, false>, (const void *)hilbert_lds_kernel<float, true>,
                                   (const void *)hilbert_lds_kernel<int16_t, false>, (const void *)hilbert_lds_kernel<int16_t, true>};

@@ -56,14 +56,34 @@ extern "C" int qdas_device_info(int device, char *name, size_t name_len, int *cu
 
 // Every entry that works on a particular device switches to it for the duration of the call only: the calling thread's current
 // device is restored on every return path (a MEX gateway or a plain C caller keeps issuing its own work where it was).
+// The library's temporaries (table / bound / sort buffers of the one-shot entries) come from the device's default stream-ordered pool.  Its release
+// threshold is 0 as shipped: at every synchronisation the pool hands its free memory back to the driver and the next call maps new pages.  Once per
+// device the threshold is raised to 64 MiB (never lowered): the small temporaries recycle inside the pool, anything larger is still trimmed.
+static void keep_pool_memory(int dev) {
+    static std::mutex mu;
+    static bool done[64] = {};
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done[dev]) return;
+    done[dev] = true;
+    hipMemPool_t pool = nullptr;
+    uint64_t cur = 0, want = 64ull << 20;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess || !pool) { (void)hipGetLastError(); return; }
+    if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &cur) != hipSuccess) { (void)hipGetLastError(); cur = 0; }
+    if (cur < want && hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &want) != hipSuccess) (void)hipGetLastError();
+}
+
 struct DeviceGuard {
     int prev = -1;
     bool restore = false;
     hipError_t err = hipSuccess;
     explicit DeviceGuard(int dev) {
-        if (dev < 0) return;
-        err = hipGetDevice(&prev);
-        if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); restore = err == hipSuccess; }
+        if (dev >= 0) {
+            err = hipGetDevice(&prev);
+            if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); restore = err == hipSuccess; }
+        }
+        if (err == hipSuccess) keep_pool_memory(dev);
     }
     ~DeviceGuard() { if (restore) (void)hipSetDevice(prev); }
     DeviceGuard(const DeviceGuard &) = delete;
@@ -174,6 +194,35 @@ template <class T, bool CPLX> __global__ void apod_fold_kernel(ApodFold f, T *ou
     }
 }
 
+// Host -> device, synchronous, for the library's own (mostly small) uploads: staged in pinned memory and written by a KERNEL.  On this platform a
+// kernel launched behind a copy-engine (or CPU) upload into freshly allocated memory has been seen reading what the ADDRESS held before it was freed and
+// reallocated (tests/fake_mex: `shiftsum`'s shifts and weights swapped -- one fresh process in four; see also qdas_device_malloc).  Whatever the stale
+// layer is, a write issued by the shader engines goes through the same translation and caches as the reads that follow it.
+__global__ void __launch_bounds__(256) upload_kernel(unsigned char *__restrict__ dst, const unsigned char *__restrict__ src, size_t bytes) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n16 = bytes / 16;
+    if (((uintptr_t)dst & 15u) == 0) {
+        if (i < n16) ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
+        if (i < bytes - 16 * n16) dst[16 * n16 + i] = src[16 * n16 + i];
+    } else {
+        for (size_t b = 16 * i; b < 16 * i + 16 && b < bytes; ++b) dst[b] = src[b];
+    }
+}
+extern "C" int qdas_internal_upload(void *dst, const void *src, size_t bytes) {
+    constexpr size_t CAP = 1u << 20;
+    if (!bytes) return (int)hipSuccess;
+    if (bytes > CAP) return (int)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    static std::mutex mu;
+    static void *pin = nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pin && hipHostMalloc(&pin, CAP, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { pin = nullptr; (void)hipGetLastError(); return (int)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
+    memcpy(pin, src, bytes);
+    upload_kernel<<<(unsigned)((bytes + 4095) / 4096), 256, 0, nullptr>>>((unsigned char *)dst, (const unsigned char *)pin, bytes);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    return (int)e;
+}
+static inline hipError_t upload(void *dst, const void *src, size_t bytes) { return (hipError_t)qdas_internal_upload(dst, src, bytes); }
+
 // device copy of a caller array (host -> new device buffer; device -> used in place, or -- QDAS_PLAN_COPY_INPUTS -- copied
 // into a plan-owned buffer so that the plan outlives the caller's arrays)
 static int import_array(qdas_plan *pl, const void *src, size_t bytes, int mem, const void **out) {
@@ -182,7 +231,8 @@ static int import_array(qdas_plan *pl, const void *src, size_t bytes, int mem, c
     void *p;
     int rc = dev_alloc(pl, &p, bytes);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(p, src, bytes, mem == QDAS_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    if (mem == QDAS_MEM_DEVICE) HIPCHK(hipMemcpy(p, src, bytes, hipMemcpyDeviceToDevice));
+    else HIPCHK(upload(p, src, bytes));
     *out = p;
     return QDAS_OK;
 }
@@ -733,7 +783,7 @@ static int plan_weight_table(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b)
         }
         void *dtab;
         if ((rc = dev_alloc(pl, &dtab, tab.size() * sizeof(double)))) return rc;
-        hipError_t e = hipMemcpy(dtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+        hipError_t e = upload(dtab, tab.data(), tab.size() * sizeof(double));
         if (e != hipSuccess) return fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e));
         t.wtab = dtab;
     } else if (z.S > b.rq.npix && dt != QDAS_F64) {
@@ -761,7 +811,7 @@ static int plan_weight_table(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b)
         }
         void *dtab;
         if ((rc = dev_alloc(pl, &dtab, tab.size() * sizeof(float)))) return rc;
-        hipError_t e = hipMemcpy(dtab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice);
+        hipError_t e = upload(dtab, tab.data(), tab.size() * sizeof(float));
         if (e != hipSuccess) return fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e));
         t.wtab = dtab;
     }
@@ -838,7 +888,7 @@ static int plan_side_split(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
             }
         void *dtab2;
         if ((rc = dev_alloc(pl, &dtab2, tab2.size() * sizeof(float)))) return rc;
-        hipError_t e2 = hipMemcpy(dtab2, tab2.data(), tab2.size() * sizeof(float), hipMemcpyHostToDevice);
+        hipError_t e2 = upload(dtab2, tab2.data(), tab2.size() * sizeof(float));
         if (e2 != hipSuccess) return fail(QDAS_EHIP, "hipMemcpy(wtab): %s", hipGetErrorString(e2));
         t.wtab = dtab2;
     }
@@ -1975,27 +2025,98 @@ extern "C" int qdas_permute3(const void *in, void *out, uint64_t A, uint64_t B, 
 }
 
 // ---- device staging for host callers of the device-pointer entries (include/qdas.h; the MEX gateway's host-array path)
+// Staging buffers are RECYCLED: a gateway call allocates its arguments and frees them again, and on this platform a free -> malloc -> upload -> launch
+// cycle that gets its old virtual addresses back has been seen handing the kernel what the addresses held BEFORE the upload (one fresh process in four
+// in tests/fake_mex: `shiftsum`'s shifts and weights swapped after they were reallocated in the other order).  A buffer that stays mapped does not do
+// that -- and hipMalloc / hipFree (synchronising, ~100 us each) leave the call path.  Freed buffers are kept per device and size class (256-byte steps
+// below 1 MiB, 1 MiB steps above), at most 256 MiB in all; qdas_device_trim releases them.
+namespace {
+struct StagingCache {
+    std::mutex mu;
+    struct Item { void *p; size_t bytes; int dev; };
+    std::vector<Item> free_list;
+    std::vector<Item> live;                               // (what qdas_device_malloc handed out: size class and device of a pointer)
+    size_t cached = 0;
+};
+StagingCache &staging() { static StagingCache c; return c; }
+size_t size_class(size_t bytes) { const size_t step = bytes < (1u << 20) ? 256 : (1u << 20); return (std::max<size_t>(bytes, 1) + step - 1) / step * step; }
+}  // namespace
+
 extern "C" int qdas_device_malloc(void **p, size_t bytes, int device) {
     if (!p) return fail(QDAS_EINVAL, "null argument");
     *p = nullptr;
     DeviceGuard guard(device);
     HIPCHK(guard.err);
-    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
-    if (e != hipSuccess) { (void)hipGetLastError(); return fail(QDAS_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    int dev = device;
+    if (dev < 0) HIPCHK(hipGetDevice(&dev));
+    const size_t cls = size_class(bytes);
+    StagingCache &c = staging();
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        for (size_t k = c.free_list.size(); k-- > 0;)
+            if (c.free_list[k].bytes == cls && c.free_list[k].dev == dev) {
+                *p = c.free_list[k].p;
+                c.cached -= cls;
+                c.live.push_back(c.free_list[k]);
+                c.free_list.erase(c.free_list.begin() + (long)k);
+                return QDAS_OK;
+            }
+    }
+    hipError_t e = hipMalloc(p, cls);
+    if (e != hipSuccess) {                                // (out of memory: give the cache back and try once more)
+        (void)hipGetLastError();
+        qdas_device_trim();
+        e = hipMalloc(p, cls);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return fail(QDAS_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.live.push_back({*p, cls, dev});
     return QDAS_OK;
 }
 extern "C" int qdas_device_free(void *p, int device) {
     if (!p) return QDAS_OK;
+    StagingCache &c = staging();
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        for (size_t k = 0; k < c.live.size(); ++k)
+            if (c.live[k].p == p) {
+                const StagingCache::Item it = c.live[k];
+                c.live.erase(c.live.begin() + (long)k);
+                if (c.cached + it.bytes <= (256ull << 20)) {
+                    // (the buffer's last reader may still run on the null stream: a later owner uploads to it with a copy ORDERED on that stream -- qdas_device_copy --)
+                    c.free_list.push_back(it);
+                    c.cached += it.bytes;
+                    return QDAS_OK;
+                }
+                break;
+            }
+    }
     DeviceGuard guard(device);
     HIPCHK(guard.err);
     HIPCHK(hipFree(p));
     return QDAS_OK;
+}
+extern "C" int qdas_device_trim(void) {
+    StagingCache &c = staging();
+    std::vector<StagingCache::Item> drop;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        drop.swap(c.free_list);
+        c.cached = 0;
+    }
+    int rc = QDAS_OK;
+    for (const auto &it : drop) {
+        DeviceGuard guard(it.dev);
+        if (guard.err != hipSuccess || hipFree(it.p) != hipSuccess) { (void)hipGetLastError(); rc = QDAS_EHIP; }
+    }
+    return rc;
 }
 extern "C" int qdas_device_copy(void *dst, const void *src, size_t bytes, int kind, int device) {
     if (!bytes) return QDAS_OK;
     if (!dst || !src || kind < 0 || kind > 2) return fail(QDAS_EINVAL, "qdas_device_copy: null pointer or unknown kind");
     DeviceGuard guard(device);
     HIPCHK(guard.err);
-    HIPCHK(hipMemcpy(dst, src, bytes, kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice));
+    if (kind == 0) HIPCHK(upload(dst, src, bytes));
+    else HIPCHK(hipMemcpy(dst, src, bytes, kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice));
     return QDAS_OK;
 }

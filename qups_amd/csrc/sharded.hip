@@ -22,6 +22,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+extern "C" int qdas_internal_upload(void *dst, const void *src, size_t bytes);      // qdas_api.hip: host -> device through pinned staging
 
 #include "../../include/qdas.h"
 
@@ -173,7 +174,7 @@ extern "C" int qdas_plan_create_sharded(qdas_sharded_plan **out, const qdas_desc
             hipError_t e2 = hipMalloc(&p, bytes);
             if (e2 != hipSuccess) return failf(QDAS_ENOMEM, "qdas_plan_create_sharded: hipMalloc: %s", hipGetErrorString(e2));
             s.owned.push_back(p);
-            e2 = desc->mem == QDAS_MEM_HOST ? hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) : hipMemcpyPeer(p, s.device, src, root_dev, bytes);
+            e2 = desc->mem == QDAS_MEM_HOST ? (hipError_t)qdas_internal_upload(p, src, bytes) : hipMemcpyPeer(p, s.device, src, root_dev, bytes);
             if (e2 != hipSuccess) return failf(QDAS_EHIP, "qdas_plan_create_sharded: replicating inputs: %s", hipGetErrorString(e2));
             *dst = p;
             return QDAS_OK;
