@@ -166,6 +166,10 @@ def lib():
     L.qdas_pre_plan_one_pass.argtypes = [C.c_void_p]
     L.qdas_kernel_variant_build.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.qdas_kernel_variant_prebuilt.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.qdas_device_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_int]
+    L.qdas_device_free.argtypes = [C.c_void_p, C.c_int]
+    L.qdas_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+    L.qdas_device_trim.argtypes = []
     L.qdas_device_info.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                    C.POINTER(C.c_uint64)]
     vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)

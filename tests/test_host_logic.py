@@ -300,3 +300,29 @@ def test_bfDASLUT_error_identifiers_of_the_reference():
     assert UltrasoundSystem._chd_array(mk(4, 4))[1] is None
     with pytest.raises(DasError, match="up to one non-scalar dimension"):
         UltrasoundSystem._chd_array(np.array([mk(4, 4)] * 4, dtype=object).reshape(2, 2))
+
+
+@pytest.mark.gpu
+def test_staging_buffers_are_recycled_and_trimmed():
+    """qdas_device_malloc / free keep their buffers (a call-per-launch gateway maps nothing between calls: csrc/qdas_api.hip StagingCache): the same
+    size class comes back with the same address, another class does not, uploads through qdas_device_copy land whole (odd sizes, unaligned tails),
+    and qdas_device_trim releases the cache."""
+    L = _lib.lib()
+    p1, p2, p3 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert L.qdas_device_malloc(C.byref(p1), 1000, -1) == 0 and p1.value
+    a1 = p1.value
+    assert L.qdas_device_free(p1, -1) == 0
+    assert L.qdas_device_malloc(C.byref(p2), 900, -1) == 0 and p2.value == a1          # 900 and 1000 bytes: one 1024-byte class
+    assert L.qdas_device_malloc(C.byref(p3), 5000, -1) == 0 and p3.value not in (None, a1)
+    for nbytes in (1, 15, 16, 17, 900):
+        src = np.arange(nbytes, dtype=np.uint8) * 7 + 3
+        dst = np.zeros(nbytes, np.uint8)
+        assert L.qdas_device_copy(p2, src.ctypes.data_as(C.c_void_p), nbytes, 0, -1) == 0
+        assert L.qdas_device_copy(dst.ctypes.data_as(C.c_void_p), p2, nbytes, 1, -1) == 0
+        assert np.array_equal(src, dst), nbytes
+    off = C.c_void_p(p3.value + 3)                                                     # an unaligned destination
+    src = np.arange(200, dtype=np.uint8)
+    dst = np.zeros(200, np.uint8)
+    assert L.qdas_device_copy(off, src.ctypes.data_as(C.c_void_p), 200, 0, -1) == 0 and L.qdas_device_copy(dst.ctypes.data_as(C.c_void_p), off, 200, 1, -1) == 0
+    assert np.array_equal(src, dst)
+    assert L.qdas_device_free(p2, -1) == 0 and L.qdas_device_free(p3, -1) == 0 and L.qdas_device_trim() == 0

@@ -57,9 +57,9 @@ cp gpurun_out/prof_${R}_c3_general/summary.txt $OUT/rocprofv3_summary_c3_general
 python tools/frames_bench.py c3 6 2>/dev/null | grep -v amdgpu.ids > $OUT/frames_bench.txt; python tools/frames_bench.py c2 12 >> $OUT/frames_bench.txt 2>/dev/null; python tools/frames_bench.py c5 12 >> $OUT/frames_bench.txt 2>/dev/null; python tools/frames_bench.py c1 12 >> $OUT/frames_bench.txt 2>/dev/null
 python tools/general_time.py 2>/dev/null | grep -v Warn > $OUT/general_time.txt
 python tools/convd_fft_time.py 2>/dev/null | grep -v amdgpu.ids > $OUT/convd_fft_time.txt
-{ python tools/greens_time.py 2>/dev/null | grep -v amdgpu.ids; echo '# QDAS_GREENS_NO_TRAINS=1 (round 3 kernel):'; QDAS_GREENS_NO_TRAINS=1 python tools/greens_time.py 2>/dev/null | grep -v amdgpu.ids; echo '# general_time.py greens lines, trains / QDAS_GREENS_NO_TRAINS=1:'; grep -i '^greens' $OUT/general_time.txt; QDAS_GREENS_NO_TRAINS=1 python tools/general_time.py 2>/dev/null | grep -i '^greens'; } > $OUT/greens_time.txt
+{ timeout 600 python tools/greens_time.py --stages 2>/dev/null | grep -v amdgpu.ids; echo '# QDAS_GREENS_NO_TRAINS=1 (round 3 kernel):'; QDAS_GREENS_NO_TRAINS=1 python tools/greens_time.py 2>/dev/null | grep -v amdgpu.ids; echo '# general_time.py greens lines, trains / QDAS_GREENS_NO_TRAINS=1:'; grep -i '^greens' $OUT/general_time.txt; QDAS_GREENS_NO_TRAINS=1 python tools/general_time.py 2>/dev/null | grep -i '^greens'; } > $OUT/greens_time.txt
 # per-kernel durations of the same script (kernel-trace only): the launches behind every line of general_time.txt
-(cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_general -o g -- python $REPO/tools/general_time.py > /dev/null 2>&1)
+(cd /tmp && TMPDIR=/tmp timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_general -o g -- python $REPO/tools/general_time.py > /dev/null 2>&1)
 python - <<PYEOF > $OUT/rocprofv3_summary_general.txt
 import csv, glob
 fs = glob.glob("$OUT/trace_general/**/*kernel_stats.csv", recursive=True)
