@@ -168,8 +168,7 @@ __global__ void __launch_bounds__(256) greens_bound_kernel(const GreensParams P,
 // One workgroup = one CHUNK of 256 scatterers of one element: it also leaves the chunk's {smallest, largest} distance (fminf / fmaxf: a NaN distance
 // never lands anywhere and is ignored; a chunk of NaNs gets {+inf, -inf}: never visited)
 constexpr int GT_CHUNK = 256;
-__global__ void __launch_bounds__(GT_CHUNK) greens_dist_kernel(const float *__restrict__ Ps, const float *__restrict__ Pe, float *__restrict__ R, float2 *__restrict__ cb, float2 *__restrict__ cbs,
-                                                                uint64_t I) {
+__global__ void __launch_bounds__(GT_CHUNK) greens_dist_kernel(const float *__restrict__ Ps, const float *__restrict__ Pe, float *__restrict__ R, float2 *__restrict__ cb, uint64_t I) {
     __shared__ float2 part[GT_CHUNK / 64];
     const uint64_t i = (uint64_t)blockIdx.x * GT_CHUNK + threadIdx.x;
     float lo = INFINITY, hi = -INFINITY;
@@ -182,10 +181,7 @@ __global__ void __launch_bounds__(GT_CHUNK) greens_dist_kernel(const float *__re
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
-    if ((threadIdx.x & 63u) == 0) {                      // ... and of its four SUB-CHUNKS of 64 (second level of the scan's list)
-        part[threadIdx.x >> 6] = make_float2(lo, hi);
-        cbs[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = make_float2(lo, hi);
-    }
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = make_float2(lo, hi);
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < GT_CHUNK / 64; ++w) { lo = fminf(lo, part[w].x); hi = fmaxf(hi, part[w].y); }
@@ -313,7 +309,7 @@ constexpr int GT_WQ = 128;                               // entries a wave queue
 // such a block fit; 1024 with the longest block that fits for long waveforms / large ratios.
 template <int INTERP, int TH>
 __global__ void __launch_bounds__(TH) greens_train_kernel(const GreensParams P, const unsigned int *bound_bits) {
-    constexpr uint32_t GT_THREADS = TH, GT_LCAP = 2 * TH, WAVES = TH / 64;
+    constexpr uint32_t GT_THREADS = TH, GT_LCAP = 2 * TH, CGRP = TH / GT_CHUNK;
     constexpr int K = INTERP == 0 ? 2 : interp_taps(INTERP);         // nearest: two trains (the sample at ti, or at ti + 1)
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     const long T = (long)P.T;
@@ -326,7 +322,7 @@ __global__ void __launch_bounds__(TH) greens_train_kernel(const GreensParams P, 
     const uint32_t NSLOT = (uint32_t)((long)Q * (SB - 1) + thi - tlo + 1);
     long long *H = (long long *)gsm;                                 // [K][NSLOT] {re, im} fixed point, later float2 in place
     float4 *wq = (float4 *)(H + (size_t)K * NSLOT * 2);              // [waves][GT_WQ] {scatterer, r1, r2}: this wave's entries that (may) land in the block
-    uint32_t *clist = (uint32_t *)(gsm + P.x_off);                   // (behind the part sums of the convolution, which reuse everything before it) [GT_LCAP + 4 WAVES] chunks of 256 scatterers that can reach this block, then the count
+    uint32_t *clist = (uint32_t *)(gsm + P.x_off);                   // (behind the part sums of the convolution, which reuse everything before it) [GT_LCAP + 16] chunks of 256 scatterers that can reach this block, then the count
     // XCD-aware order: the hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own L2), so workgroup g runs as item
     // (g % 8) * G8 / 8 + g / 8 of a list that walks the blocks of a trace, then the receivers, then the transmits: the workgroups an XCD runs at
     // a time share their distance rows (2 x 4 I bytes per trace) in ITS L2 -- in launch order every XCD saw every receiver's row
@@ -410,42 +406,35 @@ __global__ void __launch_bounds__(TH) greens_train_kernel(const GreensParams P, 
         const double mar = 4e-6 * (fabs(rlo_d) + fabs(rhi_d) + 2.0 * fabs(P.path_off)) + 1e-30;
         const float rlo = (float)(rlo_d - mar), rhi = (float)(rhi_d + mar);
         const uint32_t I32 = (uint32_t)I, nchunk = P.nchunk;         // (I < 2^32: host)
-        uint32_t *ccount = clist + GT_LCAP + 4 * WAVES;
+        uint32_t *ccount = clist + GT_LCAP + 16;
         for (int sub = 0; sub < EE; ++sub) {
             const int ne = sub % P.En, me = sub / P.En;
             const size_t row1 = (size_t)n + (size_t)ne * P.N, row2 = (size_t)m + (size_t)me * P.M;
             const float *R1 = P.r1tab + row1 * I, *R2 = P.r2tab + row2 * I;
             const float2 *B1 = (const float2 *)P.cb1 + row1 * nchunk, *B2 = (const float2 *)P.cb2 + row2 * nchunk;
-            const float2 *S1 = (const float2 *)P.cb1s + row1 * nchunk * 4, *S2 = (const float2 *)P.cb2s + row2 * nchunk * 4;
-            for (uint32_t c0 = 0; c0 < nchunk; c0 += GT_LCAP / 4) {
-                // two levels: the chunks of 256 whose distance sums [min1 + min2, max1 + max2] meet the window (fp32 addition is monotone: the test can
-                // only be wider than the entry test below), and of those the sub-chunks of 64 that do -- listed in any order
+            for (uint32_t c0 = 0; c0 < nchunk; c0 += GT_LCAP) {
+                // the chunks whose distance sums [min1 + min2, max1 + max2] meet the window (fp32 addition is monotone: the chunk test can only
+                // be wider than the entry test below), in any order
                 if (tid == 0) *ccount = 0;
                 __syncthreads();
-                const uint32_t c1 = c0 + GT_LCAP / 4 < nchunk ? c0 + GT_LCAP / 4 : nchunk;
+                const uint32_t c1 = c0 + GT_LCAP < nchunk ? c0 + GT_LCAP : nchunk;
                 for (uint32_t c = c0 + tid; c < c1; c += GT_THREADS) {
                     const float2 b1 = B1[c], b2 = B2[c];
-                    if (b1.x + b2.x <= rhi && b1.y + b2.y >= rlo) {
-                        const float4 s1a = ((const float4 *)S1)[2 * c], s1b = ((const float4 *)S1)[2 * c + 1], s2a = ((const float4 *)S2)[2 * c], s2b = ((const float4 *)S2)[2 * c + 1];
-                        if (s1a.x + s2a.x <= rhi && s1a.y + s2a.y >= rlo) clist[atomicAdd(ccount, 1u)] = 4u * c;
-                        if (s1a.z + s2a.z <= rhi && s1a.w + s2a.w >= rlo) clist[atomicAdd(ccount, 1u)] = 4u * c + 1u;
-                        if (s1b.x + s2b.x <= rhi && s1b.y + s2b.y >= rlo) clist[atomicAdd(ccount, 1u)] = 4u * c + 2u;
-                        if (s1b.z + s2b.z <= rhi && s1b.w + s2b.w >= rlo) clist[atomicAdd(ccount, 1u)] = 4u * c + 3u;
-                    }
+                    if (b1.x + b2.x <= rhi && b1.y + b2.y >= rlo) clist[atomicAdd(ccount, 1u)] = c;
                 }
                 __syncthreads();
                 const uint32_t nact = *ccount;
-                if (tid < 4u * WAVES) clist[nact + tid] = 0xffffffffu;                  // (whole passes below)
+                if (tid < 16u) clist[nact + tid] = 0xffffffffu;      // (whole groups of 16 below)
                 __syncthreads();
-                // a sub-chunk per wave and load, four per lane and pass (eight table loads) -- and the NEXT pass's loads are issued before this
-                // pass's entries are tested: the table latency is paid once per list, not once per pass
+                // 4 CGRP chunks per pass -- four per lane, eight table loads -- and the NEXT pass's loads are issued before this pass's entries are
+                // tested: the table latency is paid once per list, not once per pass
                 float r1n[4], r2n[4];
                 uint32_t ivn[4];
                 auto load_pass = [&](uint32_t e0) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const uint32_t c = clist[e0 + (uint32_t)q * WAVES + wave];
-                        const uint32_t i = c * 64u + lane;
+                        const uint32_t c = clist[e0 + (uint32_t)q * CGRP + (wave >> 2)];
+                        const uint32_t i = c * (uint32_t)GT_CHUNK + (tid & (uint32_t)(GT_CHUNK - 1));
                         const bool in = c != 0xffffffffu && i < I32;
                         ivn[q] = i;
                         r1n[q] = in ? R1[i] : INFINITY;              // (an infinite distance: never in a block)
@@ -453,12 +442,12 @@ __global__ void __launch_bounds__(TH) greens_train_kernel(const GreensParams P, 
                     }
                 };
                 if (nact) load_pass(0u);
-                for (uint32_t e0 = 0; e0 < nact; e0 += 4u * WAVES) {
+                for (uint32_t e0 = 0; e0 < nact; e0 += 4u * CGRP) {
                     float r1v[4], r2v[4];
                     uint32_t iv[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { r1v[q] = r1n[q]; r2v[q] = r2n[q]; iv[q] = ivn[q]; }
-                    if (e0 + 4u * WAVES < nact) load_pass(e0 + 4u * WAVES);
+                    if (e0 + 4u * CGRP < nact) load_pass(e0 + 4u * CGRP);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float r = r1v[q] + r2v[q];
@@ -591,7 +580,7 @@ static int launch_greens_train(const GreensParams &P, hipStream_t s) {
         const size_t scan_end = (size_t)K * nslot * 16 + (size_t)(sh.th / 64) * GT_WQ * 16, pb = ((size_t)K * (size_t)q * alp * 8 + 64 + 15) / 16 * 16;
         const size_t conv_end = pb + (size_t)sh.th * 8;
         const size_t xo = scan_end > conv_end ? scan_end : conv_end;
-        lds = xo + (size_t)(2 * sh.th + sh.th / 16 + 4) * 4;
+        lds = xo + (size_t)(2 * sh.th + 20) * 4;
         if (nslot <= 4ull * sh.th && (uint64_t)q * alp <= 2 * nslot && K * (int)q <= 64 && lds <= sh.cap) { p.sb = sb; th = sh.th; p.pb_off = (uint32_t)pb; p.x_off = (uint32_t)xo; break; }
     }
     if (!p.sb) return 1;
@@ -602,7 +591,7 @@ static int launch_greens_train(const GreensParams &P, hipStream_t s) {
     const uint64_t nchunk = (I + GT_CHUNK - 1) / GT_CHUNK;
     // one stream-ordered allocation: bound | bounding box | distance tables | chunk bounds | sorted positions, amplitudes | cell keys | cell counts | segments | taps
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
-    const size_t o_tab = 256, o_cb = o_tab + up(sizeof(float) * (ne_tot + me_tot) * I), o_cbs = o_cb + up(sizeof(float2) * (ne_tot + me_tot) * nchunk), o_ps = o_cbs + up(sizeof(float2) * (ne_tot + me_tot) * nchunk * 4),
+    const size_t o_tab = 256, o_cb = o_tab + up(sizeof(float) * (ne_tot + me_tot) * I), o_ps = o_cb + up(sizeof(float2) * (ne_tot + me_tot) * nchunk),
                  o_a = o_ps + (sorted ? up(12 * I) : 0), o_key = o_a + (sorted ? up(8 * I) : 0), o_hist = o_key + (sorted ? up(4 * I) : 0), o_seg = o_hist + (sorted ? up(4 * (size_t)GT_CELLS) : 0),
                  o_xt = o_seg + up(sizeof(int) * ((size_t)K * (size_t)T / 8 + (size_t)K * (size_t)q + 8)), total = o_xt + up(sizeof(float4) * ((size_t)K * (size_t)T + 8 * (size_t)K * (size_t)q + 8));
     unsigned char *buf = nullptr;
@@ -627,14 +616,12 @@ static int launch_greens_train(const GreensParams &P, hipStream_t s) {
         ps = pso; p.a = ao;
     }
     p.r1tab = tabs; p.r2tab = tabs + ne_tot * I;
-    float2 *cbs = (float2 *)(buf + o_cbs);               // (sub-chunk bounds: 32 bytes per chunk)
     p.cb1 = (const float *)cb; p.cb2 = (const float *)(cb + ne_tot * nchunk);
-    p.cb1s = (const float *)cbs; p.cb2s = (const float *)(cbs + ne_tot * nchunk * 4);
     p.nchunk = (uint32_t)nchunk;
     p.path_per_fine = 1.0 / (q * P.fs * P.cinv); p.path_off = (P.t0 - P.s0) / P.cinv;
     p.dbg = getenv("QDAS_GREENS_DBG") ? atoi(getenv("QDAS_GREENS_DBG")) : 0;
-    greens_dist_kernel<<<dim3((unsigned)nchunk, (unsigned)ne_tot), GT_CHUNK, 0, s>>>(ps, (const float *)P.Pr, tabs, cb, cbs, I);
-    greens_dist_kernel<<<dim3((unsigned)nchunk, (unsigned)me_tot), GT_CHUNK, 0, s>>>(ps, (const float *)P.Pv, tabs + ne_tot * I, cb + ne_tot * nchunk, cbs + ne_tot * nchunk * 4, I);
+    greens_dist_kernel<<<dim3((unsigned)nchunk, (unsigned)ne_tot), GT_CHUNK, 0, s>>>(ps, (const float *)P.Pr, tabs, cb, I);
+    greens_dist_kernel<<<dim3((unsigned)nchunk, (unsigned)me_tot), GT_CHUNK, 0, s>>>(ps, (const float *)P.Pv, tabs + ne_tot * I, cb + ne_tot * nchunk, I);
     greens_bound_kernel<<<gI, 256, 0, s>>>(P, bound);
     p.segs = buf + o_seg; p.xtab = buf + o_xt;
     {

@@ -103,7 +103,6 @@ struct GreensParams {
     int32_t q;                       // impulse-train kernel (greens.hip): the integer waveform-to-data sampling ratio, output samples per workgroup
     uint32_t sb, nblk;
     const float *r1tab, *r2tab;      // ... and the scatterer-to-element distances, [N En][I] and [M Em][I]
-    const float *cb1s, *cb2s;        // ... and per sub-chunk of 64, [..][nchunk][4][2]
     const float *cb1, *cb2;          // ... their {min, max} per chunk of 256 scatterers, [N En][nchunk][2] and [M Em][nchunk][2]
     uint32_t nchunk;
     int32_t dbg;
