@@ -159,6 +159,41 @@ def test_jit_reciprocal_32_transmit_stages(N, prec, wtab, tmp_path, monkeypatch)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["general", "fold", "mirror"])
+def test_jit_stage_shapes_of_plans_whose_tiles_fit_128_sample_windows(mode, tmp_path, monkeypatch):
+    """csrc/qdas_api.hip plan_stage_shape: a plan-specialised build takes 64 transmits x 128 samples per stage for one-set plans (general mode, the fold
+    without the mirror mode) and 32 x 2 x 128 for mirror plans when every tile fits 128-sample windows -- shapes that exist ONLY as hiprtc builds.  Against
+    the float64 oracle and the prebuilt shape of the same mode (another stage partition: fp32 re-association only); QDAS_NO_STAGE_SHAPE keeps the prebuilt shape."""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import DasPlan, build_problem, parse_options
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    N = 128
+    case = make_case(seq="FSA", interp="cubic", seed=5, N=N, I1=128, I2=64, pitch=0.2e-3, zlim=(20e-3, 24e-3), xspan=4e-3)
+    x = torch.from_numpy(case["x"])
+    opts = parse_options(x, list(case["opt"]) + ["interp", "cubic"])
+    T = case["x"].shape[0]
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], (T, N, N), case["t0"], case["fs"], case["c"], opts)
+    kw = dict(general=dict(reciprocal=False, mirror=False), fold=dict(reciprocal=True, mirror=False), mirror=dict(reciprocal=False, mirror=True))[mode]
+    want = dict(general=",mb=64,W=128>", fold=",sym,fold,mb=64,W=128>", mirror=",mirror,mb=32,W=128>")[mode]
+    ys, names = [], []
+    for shape_off in (False, True):
+        if shape_off:
+            monkeypatch.setenv("QDAS_NO_STAGE_SHAPE", "1")
+        with DasPlan(prob, kernel=2, jit=True, **kw) as plan:
+            ys.append(plan.feval(x).cpu().numpy())
+            names.append(plan.kernel_name())
+            assert plan.fallback_tiles() == 0
+    assert want in names[0] and "[jit " in names[0], names
+    assert want not in names[1], names
+    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"], cinv_f32(case["c"]),
+                     VS=case["VS"], DV=case["DV"], interp="cubic").reshape(-1, order="F")
+    assert rel_err(ys[0].reshape(-1), ref) <= 2e-5, names[0]
+    assert rel_err(ys[1].reshape(-1), ref) <= 2e-5, names[1]
+    assert rel_err(ys[0], ys[1]) <= 2e-6, names
+
+
+@pytest.mark.gpu
 def test_jit_modes_syn_mul_and_pixel_weights(tmp_path, monkeypatch):
     """the specialised kernel also serves kept dimensions (planes) and a pixel x receiver apodization"""
     import torch
