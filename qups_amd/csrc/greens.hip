@@ -304,127 +304,125 @@ __global__ void __launch_bounds__(256) greens_xtab_kernel(const float2 *__restri
 
 constexpr int GT_WQ = 128;                               // entries a wave queues before it works 64 of them off
 
+// One block of SB output samples of one (receiver, transmit) trace, in three stages over the same LDS (TrainBlock::deposit, ::convert, ::convolve).
 // TH threads per workgroup: 256 with blocks of 64 / 128 outputs (a few tens of KB of LDS: several workgroups per CU, so one's barriers and exposed
 // latencies -- the chunk list, the table reads, the amplitude gather, the conversion passes -- are covered by another's work) whenever the trains of
 // such a block fit; 1024 with the longest block that fits for long waveforms / large ratios.
 template <int INTERP, int TH>
-__global__ void __launch_bounds__(TH) greens_train_kernel(const GreensParams P, const unsigned int *bound_bits) {
-    constexpr uint32_t GT_THREADS = TH, GT_LCAP = 2 * TH, CGRP = TH / GT_CHUNK;
-    constexpr int K = INTERP == 0 ? 2 : interp_taps(INTERP);         // nearest: two trains (the sample at ti, or at ti + 1)
-    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
-    const long T = (long)P.T;
-    const int Q = P.q;
-    const uint32_t SB = P.sb;
-    // tap indices ti the edge rule admits (qdas_device.h sample_global): 4 taps: 1 <= ti <= T-3; linear: 0 <= ti <= T-2; nearest: ti >= 0 and ti (+1) < T
-    const long tlo = K == 4 ? 1 : 0;
-    const long thi_k0 = K == 4 ? T - 3 : (INTERP == 0 ? T - 1 : T - 2);       // (trains 1.. of 'nearest': T - 2)
-    const long thi = thi_k0;
-    const uint32_t NSLOT = (uint32_t)((long)Q * (SB - 1) + thi - tlo + 1);
-    long long *H = (long long *)gsm;                                 // [K][NSLOT] {re, im} fixed point, later float2 in place
-    float4 *wq = (float4 *)(H + (size_t)K * NSLOT * 2);              // [waves][GT_WQ] {scatterer, r1, r2}: this wave's entries that (may) land in the block
-    uint32_t *clist = (uint32_t *)(gsm + P.x_off);                   // (behind the part sums of the convolution, which reuse everything before it) [GT_LCAP + 16] chunks of 256 scatterers that can reach this block, then the count
-    // XCD-aware order: the hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own L2), so workgroup g runs as item
-    // (g % 8) * G8 / 8 + g / 8 of a list that walks the blocks of a trace, then the receivers, then the transmits: the workgroups an XCD runs at
-    // a time share their distance rows (2 x 4 I bytes per trace) in ITS L2 -- in launch order every XCD saw every receiver's row
-    // (100 000 scatterers on a 256 x 256 x 2816 acquisition: 126 -> 104 ms)
-    const uint32_t nblk = P.nblk;
-    const uint64_t G8 = gridDim.x, item = (uint64_t)(blockIdx.x & 7u) * (G8 >> 3) + (blockIdx.x >> 3);
-    if (item >= (uint64_t)nblk * P.N * P.M) return;
-    const uint32_t blk = (uint32_t)(item % nblk), trace = (uint32_t)(item / nblk);
-    const uint32_t n = trace % (uint32_t)P.N, m = trace / (uint32_t)P.N, tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const float2 *a = (const float2 *)P.a;
-    for (uint32_t k = tid; k < (uint32_t)K * NSLOT * 2; k += GT_THREADS) H[k] = 0;
-    const float bound = __uint_as_float(bound_bits[0]);
-    const bool a_cplx = __builtin_amdgcn_readfirstlane((int)bound_bits[1]) != 0;
-    // scale: 2^46 / largest single contribution -- and never more than 2^62 / (entries of the trace x largest contribution): a slot can at most receive
-    // every entry of its trace, so the 64-bit sums cannot wrap however dense the scatterer cloud (beyond 2^16 entries per trace the resolution drops from
-    // 2^-46 to 2^-62 x entries of the largest contribution: still 2^-32 at 10^9 entries, far below the fp32 rounding of the result)
-    const float ent = (float)P.I * (float)(P.En * P.Em);
-    const float Sc = bound > 0.f ? fminf(fminf(70368744177664.0f, 4.611686018427388e18f / fmaxf(ent, 1.f)) / bound, 1.0e37f) : 0.f;
-    const float fs = (float)P.fs, fsr = (float)P.fsr, cinv = (float)P.cinv, R0 = (float)P.R0, toff = (float)(P.t0 - P.s0);
-    const int EE = P.En * P.Em;
-    const uint64_t s_lo = (uint64_t)blk * SB, I = P.I;
-    const long cbase = (long)Q * (long)s_lo - thi;                   // fine index of slot 0
-    __syncthreads();
-    if (P.dbg & 4) return;
-    if (bound <= 3.0e38f) {
-        // Scan: one scatterer per lane and pass, the (receive, transmit) sub-aperture pairs in the outer loop; two coalesced table reads, the delay,
-        // the slot test.  Entries that land in this block -- 1 / (blocks per trace) of them -- go to the WAVE's queue in LDS (ballot + prefix: no
-        // barrier, no atomic); whenever 64 are queued the wave works them off with every lane busy: amplitude, weights, fixed point, K complex adds.
-        float4 *myq = wq + (size_t)wave * GT_WQ;
-        uint32_t qn = 0;                                             // queued entries (uniform)
-        // (the scan's test is a window on r1 + r2, a hair wider than the block: the exact slot -- the reference's own fp32 delay arithmetic -- is found here)
-        // Work-off in two halves: `take` moves 64 queued entries into registers and ISSUES their amplitude gathers; `retire` -- at the next trigger,
-        // a few scan passes later -- finishes them.  The gather's latency (the one dependent global read of an entry) runs under the scan.
-        float4 pit = make_float4(0.f, 0.f, 0.f, 0.f);
-        float2 pai = make_float2(0.f, 0.f);
-        uint32_t pcount = 0;                                         // entries taken and not retired (uniform)
-        auto take = [&](uint32_t first, uint32_t count) {
-            if (lane < count) { pit = myq[first + lane]; pai = a[__float_as_uint(pit.x)]; }
-            pcount = count;
-        };
-        auto retire = [&]() {
-            if (P.dbg & 2) { pcount = 0; return; }
-            if (lane < pcount) {
-                float r1 = pit.y, r2 = pit.z;
-                const float d = (cinv * (r1 + r2) + toff) * fs;                                               // src/greens.cu:65
-                const float ef = (float)Q * d, cf = ceilf(ef);
-                const float sl = cf - (float)cbase;                  // slot of the entry; a non-finite delay fails the test
-                if (sl >= 0.f && sl < (float)NSLOT) {
-                    const uint32_t slot = (uint32_t)sl;
-                    const float u = cf - ef;                         // in [0, 1): exact
-                    if (R0 != 0.f) { r1 = r1 < R0 ? R0 : r1; r2 = r2 < R0 ? R0 : r2; } else { r1 = 1.f; r2 = 1.f; }
-                    const float2 ai = pai;
-                    const float g = Sc * __builtin_amdgcn_rcpf(r1 * r2 * fsr);    // (v_rcp_f32: 1 ulp -- the sum is compared at 1e-4; the full division sequence is a tenth of this loop)
-                    float w[4];
-                    if constexpr (INTERP == 0) { w[0] = u < 0.5f ? 1.f : 0.f; w[1] = 1.f - w[0]; }
-                    else interp_weights<INTERP>(u, w);
-                    unsigned long long *h = (unsigned long long *)(H + (size_t)slot * 2);
-                    if (a_cplx) {
+struct TrainBlock {
+    static constexpr uint32_t THREADS = TH, LCAP = 2 * TH, CGRP = TH / GT_CHUNK;
+    static constexpr int K = INTERP == 0 ? 2 : interp_taps(INTERP);  // nearest: two trains (the sample at ti, or at ti + 1)
+    const GreensParams &P;
+    unsigned char *gsm;
+    // the block: tap indices ti the edge rule admits (qdas_device.h sample_global): 4 taps: 1 <= ti <= T-3; linear: 0 <= ti <= T-2; nearest: ti >= 0 and ti (+1) < T
+    long tlo, thi;                                       // (thi: train 0; trains 1.. of 'nearest': T - 2 -- greens_xtab_kernel)
+    int Q;
+    uint32_t SB, NSLOT, n, m, tid, lane, wave;
+    uint64_t s_lo;
+    long cbase;                                          // fine index of slot 0
+    long long *H;                                        // [K][NSLOT] {re, im} fixed point
+    float bound, Sc;
+    bool a_cplx;
+    // the wave's queue and the 64 entries it has taken and not retired
+    float4 *myq;
+    uint32_t qn = 0, pcount = 0;                         // (uniform)
+    float4 pit = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 pai = make_float2(0.f, 0.f);
+
+    __device__ TrainBlock(const GreensParams &P_, unsigned char *gsm_, uint32_t blk, uint32_t trace, const unsigned int *bound_bits) : P(P_), gsm(gsm_) {
+        const long T = (long)P.T;
+        Q = P.q; SB = P.sb;
+        tlo = K == 4 ? 1 : 0;
+        thi = K == 4 ? T - 3 : (INTERP == 0 ? T - 1 : T - 2);
+        NSLOT = (uint32_t)((long)Q * (SB - 1) + thi - tlo + 1);
+        n = trace % (uint32_t)P.N; m = trace / (uint32_t)P.N;
+        tid = threadIdx.x; lane = tid & 63u;
+        wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+        s_lo = (uint64_t)blk * SB;
+        cbase = (long)Q * (long)s_lo - thi;
+        H = (long long *)gsm;
+        myq = (float4 *)(H + (size_t)K * NSLOT * 2) + (size_t)wave * GT_WQ;          // [waves][GT_WQ] {scatterer, r1, r2}: this wave's entries that (may) land in the block
+        bound = __uint_as_float(bound_bits[0]);
+        a_cplx = __builtin_amdgcn_readfirstlane((int)bound_bits[1]) != 0;
+        // scale: 2^46 / largest single contribution -- and never more than 2^62 / (entries of the trace x largest contribution): a slot can at most receive
+        // every entry of its trace, so the 64-bit sums cannot wrap however dense the scatterer cloud (beyond 2^16 entries per trace the resolution drops from
+        // 2^-46 to 2^-62 x entries of the largest contribution: still 2^-32 at 10^9 entries, far below the fp32 rounding of the result)
+        const float ent = (float)P.I * (float)(P.En * P.Em);
+        Sc = bound > 0.f ? fminf(fminf(70368744177664.0f, 4.611686018427388e18f / fmaxf(ent, 1.f)) / bound, 1.0e37f) : 0.f;
+    }
+
+    // Work-off in two halves: `take` moves 64 queued entries into registers and ISSUES their amplitude gathers; `retire` -- at the next trigger,
+    // a few scan passes later -- finishes them.  The gather's latency (the one dependent global read of an entry) runs under the scan.
+    __device__ __forceinline__ void take(uint32_t first, uint32_t count) {
+        if (lane < count) { pit = myq[first + lane]; pai = ((const float2 *)P.a)[__float_as_uint(pit.x)]; }
+        pcount = count;
+    }
+    __device__ __forceinline__ void retire() {
+        if (P.dbg & 2) { pcount = 0; return; }
+        if (lane < pcount) {
+            const float fs = (float)P.fs, fsr = (float)P.fsr, cinv = (float)P.cinv, R0 = (float)P.R0, toff = (float)(P.t0 - P.s0);
+            float r1 = pit.y, r2 = pit.z;
+            const float d = (cinv * (r1 + r2) + toff) * fs;                                                   // src/greens.cu:65
+            const float ef = (float)Q * d, cf = ceilf(ef);
+            const float sl = cf - (float)cbase;                      // slot of the entry (the reference's own fp32 delay arithmetic); a non-finite delay fails the test
+            if (sl >= 0.f && sl < (float)NSLOT) {
+                const uint32_t slot = (uint32_t)sl;
+                const float u = cf - ef;                             // in [0, 1): exact
+                if (R0 != 0.f) { r1 = r1 < R0 ? R0 : r1; r2 = r2 < R0 ? R0 : r2; } else { r1 = 1.f; r2 = 1.f; }
+                const float g = Sc * __builtin_amdgcn_rcpf(r1 * r2 * fsr);        // (v_rcp_f32: 1 ulp -- the sum is compared at 1e-4; the full division sequence was a tenth of this loop)
+                float w[4];
+                if constexpr (INTERP == 0) { w[0] = u < 0.5f ? 1.f : 0.f; w[1] = 1.f - w[0]; }
+                else interp_weights<INTERP>(u, w);
+                unsigned long long *h = (unsigned long long *)(H + (size_t)slot * 2);
+                if (a_cplx) {
 #pragma unroll
-                        for (int k = 0; k < K; ++k) {
-                            const long long vr = gt_fixed(ai.x * g * w[k]), vi = gt_fixed(ai.y * g * w[k]);
-                            atomicAdd(h + (size_t)k * NSLOT * 2, (unsigned long long)vr);
-                            atomicAdd(h + (size_t)k * NSLOT * 2 + 1, (unsigned long long)vi);
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < K; ++k) {
-                            const long long vr = gt_fixed(ai.x * g * w[k]);
-                            atomicAdd(h + (size_t)k * NSLOT * 2, (unsigned long long)vr);
-                        }
+                    for (int k = 0; k < K; ++k) {
+                        const long long vr = gt_fixed(pai.x * g * w[k]), vi = gt_fixed(pai.y * g * w[k]);
+                        atomicAdd(h + (size_t)k * NSLOT * 2, (unsigned long long)vr);
+                        atomicAdd(h + (size_t)k * NSLOT * 2 + 1, (unsigned long long)vi);
                     }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) atomicAdd(h + (size_t)k * NSLOT * 2, (unsigned long long)gt_fixed(pai.x * g * w[k]));
                 }
             }
-            pcount = 0;
-        };
+        }
+        pcount = 0;
+    }
+
+    // Stage 1.  Scan: one scatterer per lane and load, the (receive, transmit) sub-aperture pairs in the outer loop; two coalesced table reads and a window
+    // test on r1 + r2 (a hair wider than the block).  Entries that pass -- about a third of the listed chunks' -- go to the WAVE's queue in LDS (ballot + prefix:
+    // no barrier, no atomic); whenever 64 are queued the wave works them off with every lane busy: exact slot, amplitude, weights, fixed point, K adds.
+    __device__ void deposit() {
+        uint32_t *clist = (uint32_t *)(gsm + P.x_off);               // [LCAP + 16] chunks of 256 scatterers that can reach this block, then the count (behind everything the convolution reuses)
+        uint32_t *ccount = clist + LCAP + 16;
         // r1 + r2 of the entries whose slot can lie in [0, NSLOT): ceil(Q d) - cbase in [0, NSLOT) <=> Q d in (cbase - 1, cbase + NSLOT - 1], d = (cinv r + toff) fs
         // (host: path_per_fine = 1 / (Q fs cinv), path_off = (t0 - s0) / cinv -- their roundings are far inside the margin)
         const double rlo_d = ((double)cbase - 1.0) * P.path_per_fine - P.path_off, rhi_d = ((double)cbase + (double)NSLOT - 1.0) * P.path_per_fine - P.path_off;
         // (fp32 roundings of the delay (cinv r + toff) fs: ~3 ulp of r -- and of the offset, expressed as a path length, when |toff| is the larger term)
         const double mar = 4e-6 * (fabs(rlo_d) + fabs(rhi_d) + 2.0 * fabs(P.path_off)) + 1e-30;
         const float rlo = (float)(rlo_d - mar), rhi = (float)(rhi_d + mar);
+        const uint64_t I = P.I;
         const uint32_t I32 = (uint32_t)I, nchunk = P.nchunk;         // (I < 2^32: host)
-        uint32_t *ccount = clist + GT_LCAP + 16;
+        const int EE = P.En * P.Em;
         for (int sub = 0; sub < EE; ++sub) {
             const int ne = sub % P.En, me = sub / P.En;
             const size_t row1 = (size_t)n + (size_t)ne * P.N, row2 = (size_t)m + (size_t)me * P.M;
             const float *R1 = P.r1tab + row1 * I, *R2 = P.r2tab + row2 * I;
             const float2 *B1 = (const float2 *)P.cb1 + row1 * nchunk, *B2 = (const float2 *)P.cb2 + row2 * nchunk;
-            for (uint32_t c0 = 0; c0 < nchunk; c0 += GT_LCAP) {
+            for (uint32_t c0 = 0; c0 < nchunk; c0 += LCAP) {
                 // the chunks whose distance sums [min1 + min2, max1 + max2] meet the window (fp32 addition is monotone: the chunk test can only
                 // be wider than the entry test below), in any order
                 if (tid == 0) *ccount = 0;
                 __syncthreads();
-                const uint32_t c1 = c0 + GT_LCAP < nchunk ? c0 + GT_LCAP : nchunk;
-                for (uint32_t c = c0 + tid; c < c1; c += GT_THREADS) {
+                const uint32_t c1 = c0 + LCAP < nchunk ? c0 + LCAP : nchunk;
+                for (uint32_t c = c0 + tid; c < c1; c += THREADS) {
                     const float2 b1 = B1[c], b2 = B2[c];
                     if (b1.x + b2.x <= rhi && b1.y + b2.y >= rlo) clist[atomicAdd(ccount, 1u)] = c;
                 }
                 __syncthreads();
                 const uint32_t nact = *ccount;
-                if (tid < 16u) clist[nact + tid] = 0xffffffffu;      // (whole groups of 16 below)
+                if (tid < 16u) clist[nact + tid] = 0xffffffffu;      // (whole passes below)
                 __syncthreads();
                 // 4 CGRP chunks per pass -- four per lane, eight table loads -- and the NEXT pass's loads are issued before this pass's entries are
                 // tested: the table latency is paid once per list, not once per pass
@@ -469,30 +467,29 @@ __global__ void __launch_bounds__(TH) greens_train_kernel(const GreensParams P, 
         take(0u, qn);
         retire();
     }
-    __syncthreads();
-    if (P.dbg & 8) return;
-    // fixed point -> float2, in place, train by train (the float image of train k lies inside the fixed-point images of trains <= k) -- and
-    // DE-INTERLEAVED by phase: with t = Q j + p the sum over the taps is  y[s] = sum_k sum_p sum_j A_kp[s - j] x[Q j + p + o_k],  A_kp[s'] = H_k[Q s' - p]:
+
+    // Stage 2.  fixed point -> float2, DE-INTERLEAVED by phase: with t = Q j + p the sum over the taps is
+    //     y[s] = sum_k sum_p sum_j A_kp[s - j] x[Q j + p + o_k],   A_kp[s'] = H_k[Q s' - p]:
     // K Q plain FIR filters of ~T / Q taps on unit-stride sequences -- the lanes of a wave read consecutive elements (the interleaved trains had them
-    // Q elements apart: a Q-way bank conflict on every read), and the waveform tap is the same for the whole wave: a scalar load.
-    const float inv = Sc > 0.f ? 1.0f / Sc : 0.f;
-    const int jmax = (int)(thi / (long)Q);
-    const float rQ = 1.0f / (float)Q;
-    const uint32_t AL = SB + (uint32_t)jmax, ALP = AL | 1u;          // (odd: the scatter below walks the phases, ALP elements apart)
-    float2 *Af = (float2 *)gsm + 8;                                  // [K][Q][ALP], 8 zero elements before it
-    {
-        float2 v[K][4];                                              // NSLOT <= 4 * GT_THREADS (host): every train in registers before the first float is written
+    // Q elements apart: a Q-way bank conflict on every read).  Every train goes through registers before the first float is written.
+    __device__ float2 *convert(int &jmax_out, uint32_t &alp_out) {
+        const float inv = Sc > 0.f ? 1.0f / Sc : 0.f;
+        const int jmax = (int)(thi / (long)Q);
+        const float rQ = 1.0f / (float)Q;
+        const uint32_t AL = SB + (uint32_t)jmax, ALP = AL | 1u;      // (odd: the scatter below walks the phases, ALP elements apart)
+        float2 *Af = (float2 *)gsm + 8;                              // [K][Q][ALP], 8 zero elements before it
+        float2 v[K][4];                                              // NSLOT <= 4 * THREADS (host)
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t j = tid + q * GT_THREADS;
+                const uint32_t j = tid + q * THREADS;
                 v[k][q] = j < NSLOT ? make_float2(gt_float(H[((size_t)k * NSLOT + j) * 2]) * inv, gt_float(H[((size_t)k * NSLOT + j) * 2 + 1]) * inv) : make_float2(0.f, 0.f);
             }
         __syncthreads();
         if (tid < 8u) ((float2 *)gsm)[tid] = make_float2(0.f, 0.f);
         // positions no slot maps to -- the first and last element of a sequence (some phases) and the pad -- are zeroed, the others written: disjoint
-        for (uint32_t e = tid; e < (uint32_t)(K * Q) * 3u; e += GT_THREADS) {
+        for (uint32_t e = tid; e < (uint32_t)(K * Q) * 3u; e += THREADS) {
             const uint32_t c = e / 3u, w = e - 3u * c, aa = w == 0 ? 0u : (w == 1 ? AL - 1u : ALP - 1u);
             const int ph = (int)(c % (uint32_t)Q), slot = Q * ((int)aa - jmax) - ph + (int)thi;
             if (aa >= AL || slot < 0 || slot >= (int)NSLOT) Af[(size_t)c * ALP + aa] = make_float2(0.f, 0.f);
@@ -501,7 +498,7 @@ __global__ void __launch_bounds__(TH) greens_train_kernel(const GreensParams P, 
         for (int k = 0; k < K; ++k)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint32_t j = tid + q * GT_THREADS;
+                const uint32_t j = tid + q * THREADS;
                 if (j < NSLOT) {                                     // slot = Q (a - jmax) - p + thi
                     // (u >= -(Q - 1); floor(n / Q) = floor((n + 1/2) / Q), 1 / (2 Q) away from an integer: exact in fp32 for n < 2^20)
                     const int u = (int)j - (int)thi + Q * jmax, aq = (int)(((float)(u + Q - 1) + 0.5f) * rQ), ph = Q * aq - u;
@@ -509,15 +506,17 @@ __global__ void __launch_bounds__(TH) greens_train_kernel(const GreensParams P, 
                 }
             }
         __syncthreads();
+        jmax_out = jmax; alp_out = ALP;
+        return Af;
     }
-    if (P.dbg & 16) return;
-    // the convolution: output s_lo + so, the groups of 8 taps dealt out to PARTS threads per output (a wave: one part, 64 outputs); per group
-    // three scalar loads (its offset, its taps), eight LDS reads of consecutive elements, sixteen packed multiply-adds.  A padded tap multiplies
-    // whatever finite element precedes the sequence by zero (the 8 elements before the first sequence are zeros).
-    const uint32_t PARTS = GT_THREADS / SB, so = tid % SB;
-    const int part = __builtin_amdgcn_readfirstlane((int)(tid / SB));                // (SB >= 64: uniform)
-    v2f acc = {0.f, 0.f}, acc2 = {0.f, 0.f};
-    {
+
+    // Stage 3.  The convolution: output s_lo + so, the groups of 8 taps (greens_xtab_kernel) dealt out to PARTS threads per output (a wave: one part, 64
+    // outputs); per group three scalar loads (its offset, its taps), eight LDS reads of consecutive elements, sixteen packed multiply-adds.  A padded tap
+    // multiplies whatever finite element precedes the sequence by zero (the 8 elements before the first sequence are zeros).
+    __device__ void convolve(const float2 *Af) {
+        const uint32_t PARTS = THREADS / SB, so = tid % SB;
+        const int part = __builtin_amdgcn_readfirstlane((int)(tid / SB));            // (SB >= 64: uniform)
+        v2f acc = {0.f, 0.f}, acc2 = {0.f, 0.f};
         const gt_ci grp = (gt_ci)P.segs;
         const gt_cf4 xt = (gt_cf4)P.xtab;
         const int G = grp[0];
@@ -535,17 +534,40 @@ __global__ void __launch_bounds__(TH) greens_train_kernel(const GreensParams P, 
             for (int u = 0; u < 8; ++u) { acc = (v2f){t[u].x, t[u].y} * h[u].x + acc; acc2 = (v2f){t[u].z, t[u].w} * h[u].y + acc2; }
         }
         acc += acc2;
+        float2 *red = (float2 *)(gsm + P.pb_off);                    // [PARTS][SB]
+        red[(size_t)part * SB + so] = make_float2(acc.x, acc.y);
+        __syncthreads();
+        if (part == 0) {
+            float2 sum = make_float2(acc.x, acc.y);
+            for (uint32_t p2 = 1; p2 < PARTS; ++p2) { const float2 r = red[p2 * SB + so]; sum.x += r.x; sum.y += r.y; }
+            const uint64_t s = s_lo + so;
+            if (!(bound <= 3.0e38f)) sum = make_float2(NAN, NAN);
+            if (s < P.S) ((float2 *)P.y)[((size_t)n + (size_t)m * P.N) * P.S + s] = sum;
+        }
     }
-    float2 *red = (float2 *)(gsm + P.pb_off);                        // [PARTS][SB]
-    red[(size_t)part * SB + so] = make_float2(acc.x, acc.y);
+};
+
+template <int INTERP, int TH>
+__global__ void __launch_bounds__(TH) greens_train_kernel(const GreensParams P, const unsigned int *bound_bits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    // XCD-aware order: the hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own L2), so workgroup g runs as item
+    // (g % 8) * G8 / 8 + g / 8 of a list that walks the blocks of a trace, then the receivers, then the transmits: the workgroups an XCD runs at
+    // a time share their distance rows (2 x 4 I bytes per trace) in ITS L2 -- in launch order every XCD saw every receiver's row
+    const uint32_t nblk = P.nblk;
+    const uint64_t G8 = gridDim.x, item = (uint64_t)(blockIdx.x & 7u) * (G8 >> 3) + (blockIdx.x >> 3);
+    if (item >= (uint64_t)nblk * P.N * P.M) return;
+    TrainBlock<INTERP, TH> B(P, gsm, (uint32_t)(item % nblk), (uint32_t)(item / nblk), bound_bits);
+    for (uint32_t k = B.tid; k < (uint32_t)B.K * B.NSLOT * 2; k += TH) B.H[k] = 0;
     __syncthreads();
-    if (part == 0) {
-        float2 sum = make_float2(acc.x, acc.y);
-        for (uint32_t p2 = 1; p2 < PARTS; ++p2) { const float2 r = red[p2 * SB + so]; sum.x += r.x; sum.y += r.y; }
-        const uint64_t s = s_lo + so;
-        if (!(bound <= 3.0e38f)) sum = make_float2(NAN, NAN);
-        if (s < P.S) ((float2 *)P.y)[((size_t)n + (size_t)m * P.N) * P.S + s] = sum;
-    }
+    if (P.dbg & 4) return;                               // (QDAS_GREENS_DBG: stage timing, tools/greens_time.py --stages)
+    if (B.bound <= 3.0e38f) B.deposit();                 // (a non-finite amplitude: the trains cannot carry it -- the block is written as NaN)
+    __syncthreads();
+    if (P.dbg & 8) return;
+    int jmax;
+    uint32_t alp;
+    const float2 *Af = B.convert(jmax, alp);
+    if (P.dbg & 16) return;
+    B.convolve(Af);
 }
 
 // 0: launched; 1: not this path (the kernel above runs)
