@@ -189,14 +189,17 @@ __global__ void __launch_bounds__(GT_CHUNK) greens_dist_kernel(const float *__re
     }
 }
 
-// Scatterers grouped by the MORTON cell of their positions (6 bits per axis of the cloud's bounding box; a counting sort: histogram, prefix, scatter --
+// Scatterers grouped by the MORTON cell of their positions (4 to 6 bits per axis of the cloud's bounding box: about four scatterers per cell of a volume;
+// a counting sort: histogram, prefix, scatter --
 // the order inside a cell is whatever the atomics make it): a chunk of 256 consecutive scatterers is a compact run of cells, so its distances to any
 // one element span a few cell diameters and a workgroup -- 1 / (blocks per trace) of the delay range -- can tell from the chunk bounds alone that
 // most chunks do not reach it.  The trains are INTEGER sums: the order of the scatterers does not change a bit of the result.
-constexpr uint32_t GT_CELLS = 1u << 18;
+constexpr uint32_t GT_CELLS = 1u << 18;                // (6 bits per axis: the most)
+static int gt_cell_bits(uint64_t I) { int b = 4; while (b < 6 && (4ull << (3 * b)) < I) ++b; return b; }
 __device__ __forceinline__ uint32_t gt_ordered(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 __device__ __forceinline__ float gt_unordered(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 __global__ void __launch_bounds__(256) greens_bbox_kernel(const float *__restrict__ Ps, uint64_t I, uint32_t *__restrict__ bb) {      // bb: {min x, y, z, max x, y, z}, ordered bits
+    __shared__ float part[4][6];
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     float v[3] = {0.f, 0.f, 0.f};
     bool ok = false;
@@ -206,33 +209,39 @@ __global__ void __launch_bounds__(256) greens_bbox_kernel(const float *__restric
         float lo = ok ? v[d] : INFINITY, hi = ok ? v[d] : -INFINITY;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
-        if ((threadIdx.x & 63u) == 0 && lo <= hi) { atomicMin(bb + d, gt_ordered(lo)); atomicMax(bb + 3 + d, gt_ordered(hi)); }
+        if ((threadIdx.x & 63u) == 0) { part[threadIdx.x >> 6][d] = lo; part[threadIdx.x >> 6][3 + d] = hi; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3u) {                              // (six atomics per workgroup, not per wave: they all land on the same six words)
+        const int d = (int)threadIdx.x;
+        float lo = part[0][d], hi = part[0][3 + d];
+        for (int w = 1; w < 4; ++w) { lo = fminf(lo, part[w][d]); hi = fmaxf(hi, part[w][3 + d]); }
+        if (lo <= hi) { atomicMin(bb + d, gt_ordered(lo)); atomicMax(bb + 3 + d, gt_ordered(hi)); }
     }
 }
-__device__ __forceinline__ uint32_t gt_spread3(uint32_t v) {       // 6 bits -> every third bit
+__device__ __forceinline__ uint32_t gt_spread3(uint32_t v) {       // (up to) 6 bits -> every third bit
     v &= 0x3fu; v = (v | (v << 8)) & 0x300fu; v = (v | (v << 4)) & 0x30c3u; v = (v | (v << 2)) & 0x9249u;
     return v;
 }
-__global__ void __launch_bounds__(256) greens_key_kernel(const float *__restrict__ Ps, uint64_t I, const uint32_t *__restrict__ bb, uint32_t *__restrict__ key, uint32_t *__restrict__ hist) {
+__global__ void __launch_bounds__(256) greens_key_kernel(const float *__restrict__ Ps, uint64_t I, const uint32_t *__restrict__ bb, int bits, uint32_t *__restrict__ key, uint32_t *__restrict__ hist) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= I) return;
     uint32_t k = 0;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const float lo = gt_unordered(bb[d]), hi = gt_unordered(bb[3 + d]), v = Ps[3 * i + d];
-        const float sc = hi > lo ? 63.0f / (hi - lo) : 0.f;
+        const float top = (float)((1 << bits) - 1), sc = hi > lo ? top / (hi - lo) : 0.f;
         float c = (v - lo) * sc;
-        c = c >= 0.f ? (c <= 63.f ? c : 63.f) : 0.f;                              // (NaN -> 0: any order is a valid order)
+        c = c >= 0.f ? (c <= top ? c : top) : 0.f;                                // (NaN -> 0: any order is a valid order)
         k |= gt_spread3((uint32_t)c) << d;
     }
     key[i] = k;
     atomicAdd(hist + k, 1u);
 }
 // counts -> first positions, in place (one workgroup: 1024 threads x 256 cells)
-__global__ void __launch_bounds__(1024) greens_cellscan_kernel(uint32_t *__restrict__ hist) {
+__global__ void __launch_bounds__(1024) greens_cellscan_kernel(uint32_t *__restrict__ hist, uint32_t cells) {
     __shared__ uint32_t part[1024];
-    constexpr uint32_t PER = GT_CELLS / 1024;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t PER = cells / 1024, tid = threadIdx.x;          // (cells: 4096 and up)
     uint32_t sum = 0;
     for (uint32_t c = 0; c < PER; ++c) sum += hist[tid * PER + c];
     part[tid] = sum;
@@ -630,10 +639,11 @@ static int launch_greens_train(const GreensParams &P, hipStream_t s) {
         uint32_t *bb = (uint32_t *)buf + 2, *key = (uint32_t *)(buf + o_key), *hist = (uint32_t *)(buf + o_hist);
         float *pso = (float *)(buf + o_ps);
         float2 *ao = (float2 *)(buf + o_a);
-        if (hipMemsetAsync(hist, 0, 4 * (size_t)GT_CELLS, s) != hipSuccess) return bail();
+        const int bits = gt_cell_bits(I);
+        if (hipMemsetAsync(hist, 0, 4 * ((size_t)1 << (3 * bits)), s) != hipSuccess) return bail();
         greens_bbox_kernel<<<gI, 256, 0, s>>>(ps, I, bb);
-        greens_key_kernel<<<gI, 256, 0, s>>>(ps, I, bb, key, hist);
-        greens_cellscan_kernel<<<1, 1024, 0, s>>>(hist);
+        greens_key_kernel<<<gI, 256, 0, s>>>(ps, I, bb, bits, key, hist);
+        greens_cellscan_kernel<<<1, 1024, 0, s>>>(hist, 1u << (3 * bits));
         greens_gather_kernel<<<gI, 256, 0, s>>>(ps, (const float2 *)P.a, key, hist, I, pso, ao);
         ps = pso; p.a = ao;
     }
