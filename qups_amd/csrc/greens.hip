@@ -583,7 +583,9 @@ __global__ void __launch_bounds__(TH) greens_train_kernel(const GreensParams P, 
 static int launch_greens_train(const GreensParams &P, hipStream_t s) {
     static const bool off = getenv("QDAS_GREENS_NO_TRAINS") != nullptr;
     if (off) return 1;
-    uint64_t min_entries = 1024;
+    // (measured crossover with the direct kernel, whose time grows with the scatterers while this one's is mostly fixed -- zeroing, conversion, convolution --:
+    //  ~2600 entries on a 256 x 256 x 2816 record (18.9 / 20.4 / 21.9 ms at 1000 / 2000 / 3000 against 8.2 / 16.2 / 23.9), ~2000 on 64 x 64 x 1955)
+    uint64_t min_entries = 2048;
     if (const char *e = getenv("QDAS_GREENS_TRAIN_MIN")) { const long long v = atoll(e); if (v >= 0) min_entries = (uint64_t)v; }
     const double q = floor(P.fsr + 0.5);
     if (q != P.fsr || q < 1 || q > 16 || !(P.cinv > 0) || !(P.fs > 0) || P.I * (uint64_t)(P.En * P.Em) < min_entries || P.T >= (1u << 20)) return 1;
