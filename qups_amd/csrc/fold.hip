@@ -53,24 +53,11 @@ __global__ void __launch_bounds__(256) fold_kernel(const IN *__restrict__ x, flo
     if constexpr (V4 && sizeof(IN) == 8) {
         const float4 *a4 = (const float4 *)a, *b4 = (const float4 *)b;
         float4 *o4 = (float4 *)o;
-        // three steps per pass: the six 16-byte loads of a lane are in flight together (a trace of 2816 samples is 5.5 steps: two passes)
-        const uint64_t T2 = T / 2;
-        for (uint64_t k0 = threadIdx.x; k0 < T2; k0 += 768) {
-            float4 va[3], vb[3];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const uint64_t k = k0 + 256u * u;
-                va[u] = (!za && k < T2) ? a4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-                vb[u] = (!zb && k < T2) ? b4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const uint64_t k = k0 + 256u * u;
-                if (k >= T2) break;
-                const float2 p = term(make_float2(va[u].x, va[u].y), wa), q = term(make_float2(va[u].z, va[u].w), wa);
-                const float2 p2 = term(make_float2(vb[u].x, vb[u].y), wb), q2 = term(make_float2(vb[u].z, vb[u].w), wb);
-                o4[k] = make_float4(p.x + p2.x, p.y + p2.y, q.x + q2.x, q.y + q2.y);
-            }
+        for (uint64_t k = threadIdx.x; k < T / 2; k += 256) {
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!za) { const float4 v = a4[k]; const float2 p = term(make_float2(v.x, v.y), wa), q = term(make_float2(v.z, v.w), wa); r = make_float4(p.x, p.y, q.x, q.y); }
+            if (!zb) { const float4 v = b4[k]; const float2 p = term(make_float2(v.x, v.y), wb), q = term(make_float2(v.z, v.w), wb); r.x += p.x; r.y += p.y; r.z += q.x; r.w += q.y; }
+            o4[k] = r;
         }
     } else {
         for (uint64_t k = threadIdx.x; k < T; k += 256) {
