@@ -38,7 +38,7 @@ def greens_kernel(Ps, a, Pr, Pv, x, S, s0, t0, fs, fsr, cinv, R0, interp="cubic"
     col = lambda A, t: torch.from_numpy(np.ascontiguousarray(np.asarray(A).reshape(-1, order="F").astype(t))).to(dev)
     bufs = [col(Ps, rt), col(np.asarray(a).reshape(-1), ct), col(Pr, rt), col(Pv, rt), col(np.asarray(x).reshape(-1), ct)]
     T = int(np.asarray(x).size)
-    y = torch.zeros((M, N, int(S)), dtype=torch.complex64 if prec == "single" else torch.complex128, device=dev)
+    y = torch.empty((M, N, int(S)), dtype=torch.complex64 if prec == "single" else torch.complex128, device=dev)      # (every sample is written: qdas_greens zero-fills the empty cases itself)
     d = _lib.GreensDesc()
     d.S, d.T, d.N, d.M, d.I = int(S), T, N, M, I
     d.En, d.Em, d.interp, d.dtype = En, Em, _lib.INTERP_FLAGS[interp], 1 if prec == "single" else 0
