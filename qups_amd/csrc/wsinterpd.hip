@@ -14,6 +14,8 @@
 // sums treat like MATLAB's sum(..., 'omitnan') when it is NaN (kern/wsinterpd.m:262).
 #include "qdas_device.h"
 #include "qdas_kernels.h"
+#include <type_traits>
+#include <stdlib.h>
 
 namespace qdas {
 
@@ -43,7 +45,10 @@ __device__ __forceinline__ bool sample_strided(const ST *__restrict__ tr, long t
     }
 }
 
-template <int INTERP, typename TY>
+// SPL = 4: the four waves of a workgroup share 64 outputs, each sums a quarter of the terms (a contiguous range of the odometer's order) and wave 0 adds
+// the four partial sums in range order.  A lane sums its terms one after the other; with few outputs and many terms (ChannelData.sample with sdim at C2
+// size: 262 144 outputs x 128 terms = 16 waves per CU, each walking 128 terms) the kernel's time was ONE wave's chain of memory round trips.
+template <int INTERP, typename TY, int SPL = 1>
 __global__ void __launch_bounds__(256) wsinterpd_kernel(const WsParams P) {
     using R  = typename TY::real;
     using ST = typename TY::store;
@@ -56,7 +61,7 @@ __global__ void __launch_bounds__(256) wsinterpd_kernel(const WsParams P) {
     int64_t tb = 0, xb = 0, wb = 0, yo = 0;
     {
         const int d0 = P.kord[0];
-        uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        uint64_t i0 = (uint64_t)blockIdx.x * (256 / SPL) + (threadIdx.x % (256 / SPL));
         if (i0 >= P.n_lane) return;
         if (P.lane2) {                                   // a short fastest dimension: the lanes cover kord[0] x kord[1] (one division per lane)
             const int d1 = P.kord[1];
@@ -101,13 +106,25 @@ __global__ void __launch_bounds__(256) wsinterpd_kernel(const WsParams P) {
     constexpr int K = INTERP == 0 ? 1 : interp_taps(INTERP);
     constexpr int OFF = (K <= 2) ? 0 : -1;
     const long T = (long)P.T, xts = (long)P.x_tstride;
-    for (uint64_t r = 0; r < P.n_sum; r += U) {
+    uint64_t r_lo = 0, r_hi = P.n_sum;
+    if constexpr (SPL > 1) {                             // this wave's share of the terms; the odometer starts there (divisions once per wave)
+        const uint64_t sp = (uint64_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / (256 / SPL)));
+        r_lo = P.n_sum * sp / SPL; r_hi = P.n_sum * (sp + 1) / SPL;
+        uint64_t q = r_lo;
+        for (int d = 0; d < 8; ++d) {
+            if (d < P.nsd) {
+                cnt[d] = (uint32_t)(q % P.ssz[d]); q /= P.ssz[d];
+                ut += (int64_t)cnt[d] * P.sts[d]; ux += (int64_t)cnt[d] * P.sxs[d]; uw += (int64_t)cnt[d] * P.sws[d];
+            }
+        }
+    }
+    for (uint64_t r = r_lo; r < r_hi; r += U) {
         int64_t xo[U], wo[U];
         R tau[U];
         bool live[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            live[u] = r + u < P.n_sum;
+            live[u] = r + u < r_hi;
             const int64_t to = tb + ut;
             xo[u] = xb + ux; wo[u] = wb + uw;
             tau[u] = live[u] ? t[to] : (R)0;
@@ -152,6 +169,15 @@ __global__ void __launch_bounds__(256) wsinterpd_kernel(const WsParams P) {
             }
             acc.x += v.x; acc.y += v.y;
         }
+    }
+    if constexpr (SPL > 1) {
+        __shared__ cplx<R> part[SPL][256 / SPL];
+        const uint32_t sp = threadIdx.x / (256 / SPL), ln = threadIdx.x % (256 / SPL);
+        part[sp][ln] = acc;
+        __syncthreads();
+        if (sp != 0) return;
+#pragma unroll
+        for (int k = 1; k < SPL; ++k) { acc.x += part[k][ln].x; acc.y += part[k][ln].y; }
     }
     st((ST *)P.y, (size_t)yo, acc);
 }
@@ -242,6 +268,19 @@ template <typename TY> static hipError_t launch_ws_t(const WsParams &P, hipStrea
     // grid: x = blocks along the fastest kept dimension, (y, z) = the other kept dimensions flattened
     const uint64_t n0 = P.n_lane, gy = P.n_rest < 65535 ? (P.n_rest ? P.n_rest : 1) : 65535, gz = (P.n_rest + gy - 1) / gy;
     if (gz > 65535 || (n0 + 255) / 256 > 0x7fffffffull) return hipErrorInvalidValue;
+    // many terms per output: four waves share the terms of 64 outputs (fp32 / fp16 data; QDAS_WS_NO_SPLIT keeps one wave per output)
+    if (P.n_sum >= 32 && !std::is_same<TY, st_f64>::value && (n0 + 63) / 64 <= 0x7fffffffull && !getenv("QDAS_WS_NO_SPLIT")) {
+        const dim3 g4((unsigned)((n0 + 63) / 64), (unsigned)gy, (unsigned)(gz ? gz : 1)), b4(256);
+        switch (P.flag & 7) {
+            case 0: wsinterpd_kernel<0, TY, 4><<<g4, b4, 0, s>>>(P); break;
+            case 1: case 4: wsinterpd_kernel<1, TY, 4><<<g4, b4, 0, s>>>(P); break;
+            case 2: wsinterpd_kernel<2, TY, 4><<<g4, b4, 0, s>>>(P); break;
+            case 3: wsinterpd_kernel<3, TY, 4><<<g4, b4, 0, s>>>(P); break;
+            case 5: wsinterpd_kernel<5, TY, 4><<<g4, b4, 0, s>>>(P); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     const dim3 g((unsigned)((n0 + 255) / 256), (unsigned)gy, (unsigned)(gz ? gz : 1)), b(256);
     switch (P.flag & 7) {
         case 0: wsinterpd_kernel<0, TY><<<g, b, 0, s>>>(P); break;
