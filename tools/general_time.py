@@ -2,7 +2,7 @@
 """The general (non-fused) kernels that ChannelData.sample / rectifyt0 / focusTx / bfDAS fall onto, timed on shapes of the BASELINE
 configurations with a bytes-based roofline each:  tools/general_time.py  ->  one line per case:
    ms, algorithmic GB moved (inputs read once + outputs written once), GB/s, fraction of the 8 TB/s HBM roof.
-Times are torch.cuda.Event pairs on torch's current stream -- the stream every call here launches on."""
+Times are torch.cuda.Event pairs on torch's current stream -- the stream every call here launches on -- around four calls issued back to back."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,13 +12,18 @@ dev = torch.device("cuda:0")
 HBM = 8000.0
 
 
-def timed(fn, reps=5):
+def timed(fn, reps=5, inner=4):
+    """median over `reps` of the time per call of `inner` calls issued back to back (a stream of calls: the device works on call k while the host prepares
+    call k + 1; one call between two events on an idle device also counts the ~0.07 ms the host needs to get the first launch out)"""
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ms = []
     for _ in range(reps):
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-        ms.append(e0.elapsed_time(e1))
+        e0.record()
+        for _ in range(inner):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1) / inner)
     return float(np.median(ms))
 
 
@@ -29,6 +34,10 @@ def line(name, ms, nbytes, note=""):
 
 g = torch.Generator(device=dev).manual_seed(0)
 rn = lambda *s: torch.view_as_complex(torch.randn(tuple(s) + (2,), generator=g, device=dev, dtype=torch.float32))
+# the same in MATLAB's (column-major) memory order -- time fastest --, which is how the reference hands its records to these kernels; a torch-order
+# (last dimension fastest) record makes `wsinterpd` transpose x and t first when the fastest dimension is the summed one (qups_amd/interpd.py)
+rn_cm = lambda *s: rn(*reversed(s)).permute(*reversed(range(len(s))))
+cm = lambda a: a.permute(*reversed(range(a.ndim))).contiguous().permute(*reversed(range(a.ndim)))
 
 # ---- wsinterpd, kept dimensions only (ChannelData.sample / rectifyt0 at C1 size: T x N x M = 2048 x 64 x 32, one delay per (sample, transmit))
 T, N, M = 2048, 64, 32
@@ -37,18 +46,25 @@ t = (torch.arange(T, device=dev, dtype=torch.float32).reshape(T, 1, 1) + torch.r
 for interp in ("linear", "cubic"):
     ms = timed(lambda: wsinterpd(x, t, 1, 1, None, interp, 0.0))
     line(f"wsinterpd rectifyt0-like C1 {T}x{N}x{M} {interp}", ms, 2 * x.numel() * 8 + t.numel() * 4)
-# ---- wsinterpd with a summed dimension (sample + sum over M: the general single-delay reduction)
+# ---- wsinterpd with a summed dimension (sample + sum over M: the general single-delay reduction); records in column-major order (and, second line, in torch order)
+xc_, tc_ = cm(x), cm(t)
 for interp in ("linear", "cubic"):
-    ms = timed(lambda: wsinterpd(x, t, 1, 1, [3], interp, 0.0))
+    ms = timed(lambda: wsinterpd(xc_, tc_, 1, 1, [3], interp, 0.0))
     line(f"wsinterpd sum over M  C1 {T}x{N}x{M} {interp}", ms, x.numel() * 8 + T * N * 8 + t.numel() * 4, f"{T * N * M / ms / 1e6:.1f} Gsample/s")
+ms = timed(lambda: wsinterpd(x, t, 1, 1, [3], "cubic", 0.0))
+line(f"  ... torch-order record (transposed first) cubic", ms, x.numel() * 8 + T * N * 8 + t.numel() * 4, f"{T * N * M / ms / 1e6:.1f} Gsample/s")
 # ---- C2-sized: T x N x M = 2048 x 128 x 128
 T, N, M = 2048, 128, 128
 x = rn(T, N, M)
 t = (torch.arange(T, device=dev, dtype=torch.float32).reshape(T, 1, 1) + torch.rand((1, 1, M), generator=g, device=dev) * 3).expand(T, 1, M).contiguous()
 ms = timed(lambda: wsinterpd(x, t, 1, 1, None, "cubic", 0.0))
 line(f"wsinterpd rectifyt0-like C2 {T}x{N}x{M} cubic", ms, 2 * x.numel() * 8 + t.numel() * 4)
-ms = timed(lambda: wsinterpd(x, t, 1, 1, [3], "cubic", 0.0))
+xc_, tc_ = cm(x), cm(t)
+ms = timed(lambda: wsinterpd(xc_, tc_, 1, 1, [3], "cubic", 0.0))
 line(f"wsinterpd sum over M  C2 {T}x{N}x{M} cubic", ms, x.numel() * 8 + T * N * 8 + t.numel() * 4, f"{T * N * M / ms / 1e6:.1f} Gsample/s")
+ms = timed(lambda: wsinterpd(x, t, 1, 1, [3], "cubic", 0.0))
+line(f"  ... torch-order record (transposed first) cubic", ms, x.numel() * 8 + T * N * 8 + t.numel() * 4, f"{T * N * M / ms / 1e6:.1f} Gsample/s")
+del xc_, tc_
 
 # ---- focusTx at C1 (64-element FSA record -> 32 focused transmits): one split-delay launch per synthesised transmit, keep_rx
 from qups_amd import ChannelData, Sequence, Transducer, UltrasoundSystem, Scan
