@@ -467,7 +467,7 @@ int qdas_iir(const qdas_iir_desc *desc, const void *x, void *y, void *stream);
  * these three (mex/qdas_mex.c dev_in / dev_out).  device: HIP ordinal, -1 = current.  qdas_device_copy is synchronous; kind 0: host -> device,
  * 1: device -> host, 2: device -> device. */
 int qdas_device_malloc(void **p, size_t bytes, int device);
-int qdas_device_free(void *p, int device);      /* (buffers of qdas_device_malloc are kept for reuse, at most 256 MiB: a call-per-launch gateway does not map / unmap) */
+int qdas_device_free(void *p, int device);      /* (buffers of qdas_device_malloc are kept for reuse, at most 4 GiB -- QDAS_STAGING_CACHE_MB --: a call-per-launch gateway does not map / unmap) */
 int qdas_device_trim(void);                      /* ... and released here */
 int qdas_device_copy(void *dst, const void *src, size_t bytes, int kind, int device);
 

@@ -2029,7 +2029,8 @@ extern "C" int qdas_permute3(const void *in, void *out, uint64_t A, uint64_t B, 
 // cycle that gets its old virtual addresses back has been seen handing the kernel what the addresses held BEFORE the upload (one fresh process in four
 // in tests/fake_mex: `shiftsum`'s shifts and weights swapped after they were reallocated in the other order).  A buffer that stays mapped does not do
 // that -- and hipMalloc / hipFree (synchronising, ~100 us each) leave the call path.  Freed buffers are kept per device and size class (256-byte steps
-// below 1 MiB, 1 MiB steps above), at most 256 MiB in all; qdas_device_trim releases them.
+// below 1 MiB, 1 MiB steps above), at most 4 GiB in all (QDAS_STAGING_CACHE_MB; a gateway that stages a 1.5 GB record per call keeps that buffer too);
+// qdas_device_trim releases them.
 namespace {
 struct StagingCache {
     std::mutex mu;
@@ -2082,7 +2083,8 @@ extern "C" int qdas_device_free(void *p, int device) {
             if (c.live[k].p == p) {
                 const StagingCache::Item it = c.live[k];
                 c.live.erase(c.live.begin() + (long)k);
-                if (c.cached + it.bytes <= (256ull << 20)) {
+                static const size_t cap = [] { const char *e = getenv("QDAS_STAGING_CACHE_MB"); return (size_t)(e && atoll(e) >= 0 ? atoll(e) : 4096) << 20; }();
+                if (c.cached + it.bytes <= cap) {
                     // (the buffer's last reader may still run on the null stream: a later owner uploads to it with a copy ORDERED on that stream -- qdas_device_copy --)
                     c.free_list.push_back(it);
                     c.cached += it.bytes;
