@@ -622,17 +622,18 @@ static int launch_greens_train(const GreensParams &P, hipStream_t s) {
     const bool no_sort = getenv("QDAS_GREENS_NO_SORT") != nullptr;      // (read per call: the tests switch it)
     const bool sorted = !no_sort && I >= 4096;           // (fewer: a handful of chunks, nothing to skip)
     const uint64_t nchunk = (I + GT_CHUNK - 1) / GT_CHUNK;
-    // one stream-ordered allocation: bound | bounding box | distance tables | chunk bounds | sorted positions, amplitudes | cell keys | cell counts | segments | taps
+    // one allocation: bound | bounding box | distance tables | chunk bounds | sorted positions, amplitudes | cell keys | cell counts | segments | taps
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t o_tab = 256, o_cb = o_tab + up(sizeof(float) * (ne_tot + me_tot) * I), o_ps = o_cb + up(sizeof(float2) * (ne_tot + me_tot) * nchunk),
                  o_a = o_ps + (sorted ? up(12 * I) : 0), o_key = o_a + (sorted ? up(8 * I) : 0), o_hist = o_key + (sorted ? up(4 * I) : 0), o_seg = o_hist + (sorted ? up(4 * (size_t)GT_CELLS) : 0),
                  o_xt = o_seg + up(sizeof(int) * ((size_t)K * (size_t)T / 8 + (size_t)K * (size_t)q + 8)), total = o_xt + up(sizeof(float4) * ((size_t)K * (size_t)T + 8 * (size_t)K * (size_t)q + 8));
-    unsigned char *buf = nullptr;
-    if (hipMallocAsync((void **)&buf, total, s) != hipSuccess || !buf) { (void)hipGetLastError(); return 1; }
+    Scratch scratch(s);                                  // (kept arena of this stream, or -- beyond 64 MiB -- a block that lives until this call returns: scratch.hip)
+    unsigned char *buf = (unsigned char *)scratch.get(total);
+    if (!buf) return 1;
     unsigned int *bound = (unsigned int *)buf;
     float *tabs = (float *)(buf + o_tab);
     float2 *cb = (float2 *)(buf + o_cb);
-    auto bail = [&]() { (void)hipGetLastError(); (void)hipFreeAsync(buf, s); return 1; };
+    auto bail = [&]() { (void)hipGetLastError(); return 1; };
     // bound = 0; any complex amplitude = 0; bounding box {min x y z = all ones, max x y z = 0} (ordered bits)
     if (hipMemsetAsync(buf, 0, 32, s) != hipSuccess || hipMemsetAsync(buf + 8, 0xff, 12, s) != hipSuccess) return bail();
     const float *ps = (const float *)P.Ps;
@@ -683,7 +684,6 @@ static int launch_greens_train(const GreensParams &P, hipStream_t s) {
         default: err = hipErrorInvalidValue;
     }
 #undef QT
-    (void)hipFreeAsync(buf, s);
     return (err == hipSuccess && hipGetLastError() == hipSuccess) ? 0 : 1;
 }
 

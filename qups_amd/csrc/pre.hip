@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <vector>
+#include "qdas_kernels.h"
 extern "C" int qdas_internal_upload(void *dst, const void *src, size_t bytes);      // qdas_api.hip: host -> device through pinned staging
 
 namespace qdas {
@@ -591,13 +592,13 @@ int fftconv_launch(const void *x, const void *taps, int taps_real, void *z, uint
         const void *fn = big ? (const void *)fftconv_lds_kernel<true> : (const void *)fftconv_lds_kernel<false>;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) { (void)hipGetLastError(); return 1; }
     }
-    float2 *tab = nullptr;                                               // [H | tw]
-    if (hipMallocAsync((void **)&tab, sizeof(float2) * 2 * N, s) != hipSuccess || !tab) { (void)hipGetLastError(); return 1; }
+    Scratch scratch(s);
+    float2 *tab = (float2 *)scratch.get(sizeof(float2) * 2 * N);         // [H | tw]
+    if (!tab) return 1;
     fftconv_tables_kernel<<<(unsigned)((N + 255) / 256), 256, 0, s>>>(taps, taps_real, (uint32_t)ntaps, (uint32_t)N, tab, tab + N);
     FftConvArgs A{(const float2 *)x, (float2 *)z, tab, tab + N, (uint32_t)M, (uint32_t)N, (uint32_t)off, (uint32_t)L, K, st};
     if (big) fftconv_lds_kernel<true><<<(unsigned)K, th, lds_bytes, s>>>(A); else fftconv_lds_kernel<false><<<(unsigned)K, th, lds_bytes, s>>>(A);
     const hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(tab, s);
     return e == hipSuccess ? 0 : 2;
 }
 

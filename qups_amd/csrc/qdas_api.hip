@@ -56,34 +56,14 @@ extern "C" int qdas_device_info(int device, char *name, size_t name_len, int *cu
 
 // Every entry that works on a particular device switches to it for the duration of the call only: the calling thread's current
 // device is restored on every return path (a MEX gateway or a plain C caller keeps issuing its own work where it was).
-// The library's temporaries (table / bound / sort buffers of the one-shot entries) come from the device's default stream-ordered pool.  Its release
-// threshold is 0 as shipped: at every synchronisation the pool hands its free memory back to the driver and the next call maps new pages.  Once per
-// device the threshold is raised to 64 MiB (never lowered): the small temporaries recycle inside the pool, anything larger is still trimmed.
-static void keep_pool_memory(int dev) {
-    static std::mutex mu;
-    static bool done[64] = {};
-    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
-    if (dev < 0 || dev >= 64) return;
-    std::lock_guard<std::mutex> lk(mu);
-    if (done[dev]) return;
-    done[dev] = true;
-    hipMemPool_t pool = nullptr;
-    uint64_t cur = 0, want = 64ull << 20;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess || !pool) { (void)hipGetLastError(); return; }
-    if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &cur) != hipSuccess) { (void)hipGetLastError(); cur = 0; }
-    if (cur < want && hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &want) != hipSuccess) (void)hipGetLastError();
-}
-
 struct DeviceGuard {
     int prev = -1;
     bool restore = false;
     hipError_t err = hipSuccess;
     explicit DeviceGuard(int dev) {
-        if (dev >= 0) {
-            err = hipGetDevice(&prev);
-            if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); restore = err == hipSuccess; }
-        }
-        if (err == hipSuccess) keep_pool_memory(dev);
+        if (dev < 0) return;
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); restore = err == hipSuccess; }
     }
     ~DeviceGuard() { if (restore) (void)hipSetDevice(prev); }
     DeviceGuard(const DeviceGuard &) = delete;
@@ -194,10 +174,9 @@ template <class T, bool CPLX> __global__ void apod_fold_kernel(ApodFold f, T *ou
     }
 }
 
-// Host -> device, synchronous, for the library's own (mostly small) uploads: staged in pinned memory and written by a KERNEL.  On this platform a
-// kernel launched behind a copy-engine (or CPU) upload into freshly allocated memory has been seen reading what the ADDRESS held before it was freed and
-// reallocated (tests/fake_mex: `shiftsum`'s shifts and weights swapped -- one fresh process in four; see also qdas_device_malloc).  Whatever the stale
-// layer is, a write issued by the shader engines goes through the same translation and caches as the reads that follow it.
+// Host -> device, synchronous, for the library's own (mostly small) uploads: staged in pinned memory and written by a KERNEL -- whatever sits between a
+// copy-engine (or CPU) write into freshly allocated memory and the kernel launched behind it (see csrc/scratch.hip for what was seen on this platform), a
+// write issued by the shader engines goes through the same translation and caches as the reads that follow it.
 __global__ void __launch_bounds__(256) upload_kernel(unsigned char *__restrict__ dst, const unsigned char *__restrict__ src, size_t bytes) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n16 = bytes / 16;
     if (((uintptr_t)dst & 15u) == 0) {
@@ -1691,11 +1670,11 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     if ((kN * strN + (uint64_t)tc.mb * strM) * data_size(dt) + 65536 >= (1ull << 31)) return 1;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1;
-    // misfit counter of THIS call, allocated and released in stream order on the caller's stream: concurrent calls (other host
+    // misfit counter of THIS call, from the arena of the caller's stream (one call at a time per stream holds it): concurrent calls (other host
     // threads, other streams of the device) never share it, so no probe result can be cleared or read by another call
-    uint32_t *counter = nullptr;
-    if (hipMallocAsync((void **)&counter, 64, s) != hipSuccess || !counter) return 1;
-    struct CounterGuard { uint32_t *p; hipStream_t s; ~CounterGuard() { (void)hipFreeAsync(p, s); } } guard{counter, s};
+    Scratch scratch(s);                                  // (this stream's arena, csrc/scratch.hip)
+    uint32_t *counter = (uint32_t *)scratch.get(64);
+    if (!counter) return 1;
     const bool shaped = d->I1 && d->I1 < d->I && d->I % d->I1 == 0;    // (a per-pixel array needs the true image shape: no ragged rows)
     if ((w_pix || w_pixm) && !shaped && d->I1 != d->I) return 1;
     TileParams t{};
@@ -1741,13 +1720,13 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     while (ks * 2 <= cap && (uint64_t)ntiles * ks < (uint64_t)ncu) ks *= 2;
     void *part = nullptr;
     if (ks > 1) {
-        if (hipMallocAsync(&part, sizeof(float) * 2 * (size_t)ks * d->I, s) != hipSuccess) { part = nullptr; ks = 1; }
+        part = scratch.get(sizeof(float) * 2 * (size_t)ks * d->I);
+        if (!part) ks = 1;
     }
     t.ksplit = ks; t.part = (float2 *)part;
     if (keep && hipMemsetAsync(y, 0, d->I * kN * sizeof(float2), s) != hipSuccess) return 0;   // planes are accumulated with atomics
     if (hipMemsetAsync(counter, 0, sizeof(uint32_t), s) != hipSuccess) return 0;
     const hipError_t e = launch_tile(t, dt, ntiles, s);
-    if (part) (void)hipFreeAsync(part, s);
     if (e == hipErrorSharedObjectInitFailed) { (void)hipGetLastError(); return 1; }      // (a variant that is built on demand, and no compiler at hand: the any-shape kernel)
     return e == hipSuccess ? -1 : 0;     // (the probe of this footprint found no misfit on these very tables: every tile is written)
 }
@@ -2025,12 +2004,11 @@ extern "C" int qdas_permute3(const void *in, void *out, uint64_t A, uint64_t B, 
 }
 
 // ---- device staging for host callers of the device-pointer entries (include/qdas.h; the MEX gateway's host-array path)
-// Staging buffers are RECYCLED: a gateway call allocates its arguments and frees them again, and on this platform a free -> malloc -> upload -> launch
-// cycle that gets its old virtual addresses back has been seen handing the kernel what the addresses held BEFORE the upload (one fresh process in four
-// in tests/fake_mex: `shiftsum`'s shifts and weights swapped after they were reallocated in the other order).  A buffer that stays mapped does not do
-// that -- and hipMalloc / hipFree (synchronising, ~100 us each) leave the call path.  Freed buffers are kept per device and size class (256-byte steps
-// below 1 MiB, 1 MiB steps above), at most 4 GiB in all (QDAS_STAGING_CACHE_MB; a gateway that stages a 1.5 GB record per call keeps that buffer too);
-// qdas_device_trim releases them.
+// Staging buffers are RECYCLED: a gateway call allocates its arguments and frees them again, and on this platform hipMalloc / hipFree around calls that
+// use temporaries of the stream-ordered pool had the second call of a fresh process read stale memory (tools/repro/stale_pool.hip: 4 of 30 boxes; 0 of 30
+// with the staged buffers kept; csrc/scratch.hip removes the pool side as well).  A buffer that stays mapped does not do that -- and hipMalloc / hipFree
+// (synchronising, ~100 us each) leave the call path.  Freed buffers are kept per device and size class (256-byte steps below 1 MiB, 1 MiB steps above),
+// at most 4 GiB in all (QDAS_STAGING_CACHE_MB; a gateway that stages a 1.5 GB record per call keeps that buffer too); qdas_device_trim releases them.
 namespace {
 struct StagingCache {
     std::mutex mu;
@@ -2099,6 +2077,7 @@ extern "C" int qdas_device_free(void *p, int device) {
     return QDAS_OK;
 }
 extern "C" int qdas_device_trim(void) {
+    scratch_trim();                                       // (the one-shot entries' arenas of idle streams)
     StagingCache &c = staging();
     std::vector<StagingCache::Item> drop;
     {

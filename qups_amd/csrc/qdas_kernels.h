@@ -1,6 +1,7 @@
 // qdas_kernels.h -- host<->kernel parameter blocks and launchers (internal).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdint.h>
 #include <string>
 #include "tile_params.h"
@@ -111,6 +112,22 @@ struct GreensParams {
     uint32_t pb_off, x_off;          // LDS byte offsets: slice sums of the convolution, the waveform
 };
 hipError_t launch_greens(const GreensParams &P, int dtype, hipStream_t s);
+
+// ---- temporaries of one call on one stream (scratch.hip): from a kept, hipMalloc'ed arena per (device, stream) -- not from the stream-ordered pool
+class Scratch {
+public:
+    explicit Scratch(hipStream_t s);
+    ~Scratch();
+    void *get(size_t bytes);         // 256-byte aligned; nullptr: no memory
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+private:
+    hipStream_t stream_;
+    void *arena_ = nullptr;
+    size_t off_ = 0;
+    std::vector<void *> big_;
+};
+void scratch_trim();
 
 // ---- batched 1-D convolution (conv.hip)
 struct ConvParams {

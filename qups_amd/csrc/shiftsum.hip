@@ -231,9 +231,10 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
 template <typename DT, typename R, int TPT>
 static hipError_t launch_shift_t(const ShiftParams &P, int interp, const void *sh, const void *w, int w_real, hipStream_t s) {
     const uint64_t count = P.M * P.Mo;
-    ShiftEntry<R> *tab = nullptr;
-    hipError_t e = hipMallocAsync((void **)&tab, sizeof(ShiftEntry<R>) * count, s);
-    if (e != hipSuccess) return e;
+    Scratch scratch(s);                                  // (the stream's arena: scratch.hip)
+    ShiftEntry<R> *tab = (ShiftEntry<R> *)scratch.get(sizeof(ShiftEntry<R>) * count);
+    if (!tab) return hipErrorOutOfMemory;
+    hipError_t e = hipSuccess;
     const unsigned gb = (unsigned)((count + 255) / 256);
     const R *shr = (const R *)sh;
     switch (interp) {
@@ -242,14 +243,13 @@ static hipError_t launch_shift_t(const ShiftParams &P, int interp, const void *s
         case 2: shift_table_kernel<2, R><<<gb, 256, 0, s>>>(shr, w, w_real, count, (int64_t)P.T, (int64_t)P.To, tab); break;
         case 3: shift_table_kernel<3, R><<<gb, 256, 0, s>>>(shr, w, w_real, count, (int64_t)P.T, (int64_t)P.To, tab); break;
         case 5: shift_table_kernel<5, R><<<gb, 256, 0, s>>>(shr, w, w_real, count, (int64_t)P.T, (int64_t)P.To, tab); break;
-        default: (void)hipFreeAsync(tab, s); return hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
     }
     ShiftParams p = P;
     p.tab = tab;
     p.mo_blocks = (uint32_t)((P.Mo + SS_MOB - 1) / SS_MOB);
-    int2 *blk = nullptr;
-    e = hipMallocAsync((void **)&blk, sizeof(int2) * P.M * p.mo_blocks, s);
-    if (e != hipSuccess) { (void)hipFreeAsync(tab, s); return e; }
+    int2 *blk = (int2 *)scratch.get(sizeof(int2) * P.M * p.mo_blocks);
+    if (!blk) return hipErrorOutOfMemory;
     shift_block_kernel<R><<<(unsigned)((P.M * p.mo_blocks + 255) / 256), 256, 0, s>>>(tab, P.M, P.Mo, p.mo_blocks, blk);
     p.blk = blk;
     constexpr int TPB = 256 * TPT;
@@ -265,8 +265,6 @@ static hipError_t launch_shift_t(const ShiftParams &P, int interp, const void *s
     if (K == 1) QSS(1); else if (K == 2) QSS(2); else QSS(4);
 #undef QSS
     if (e == hipSuccess) e = hipGetLastError();
-    (void)hipFreeAsync(tab, s);                                                  // stream-ordered: after the kernel
-    (void)hipFreeAsync(blk, s);
     return e;
 }
 
