@@ -9,6 +9,7 @@
 // issued; a call that needs more than the arena holds gets blocks of its own (released -- after a stream synchronisation -- when the stream's next call
 // begins, and the arena is regrown to what was needed); more than 64 MiB never stays: such a block is freed when its call returns (which then waits for it).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -17,7 +18,8 @@
 namespace qdas {
 
 namespace {
-constexpr size_t ARENA_MAX = 64ull << 20;
+// (QDAS_SCRATCH_ARENA_MAX_MB: read per call -- the tests set it to 0 to send every temporary down the per-call path)
+size_t arena_max() { const char *e = getenv("QDAS_SCRATCH_ARENA_MAX_MB"); return (size_t)(e && atoll(e) >= 0 ? atoll(e) : 64) << 20; }
 struct Arena {
     int dev = 0;
     hipStream_t s = nullptr;
@@ -61,6 +63,7 @@ void *Scratch::get(size_t bytes) {
     Arena *a = (Arena *)arena_;
     const size_t b = up256(bytes ? bytes : 1);
     void *p = nullptr;
+    const size_t ARENA_MAX = arena_max();
     if (b > ARENA_MAX) {                                 // never kept
         if (hipMalloc(&p, b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         big_.push_back(p);

@@ -178,6 +178,14 @@ def test_greens_morton_sorted_scan_changes_no_bit(interp, monkeypatch):
     den = np.abs(ref).max()
     assert den > 0 and np.abs(o - ref).max() / den <= 3e-4
     if interp == "linear":
+        # the temporaries from per-call blocks instead of the stream's arena (csrc/scratch.hip: what clouds beyond 64 MiB of tables get): the same bits
+        monkeypatch.delenv("QDAS_GREENS_NO_SORT")
+        monkeypatch.setenv("QDAS_SCRATCH_ARENA_MAX_MB", "0")
+        y_blk = greens_kernel(Ps, *args, "single")
+        monkeypatch.delenv("QDAS_SCRATCH_ARENA_MAX_MB")
+        torch.cuda.synchronize()
+        assert torch.equal(y_blk, ys[0])
+        monkeypatch.setenv("QDAS_GREENS_NO_SORT", "1")
         # purely real amplitudes (the usual clouds) take the path that skips the imaginary trains' arithmetic (TrainBlock::retire, a_cplx == false)
         a_re = np.abs(g["a"]).astype(np.complex64)
         args_re = (a_re,) + args[1:]
