@@ -241,7 +241,9 @@ inline int resolve_symmetry(const qdas_desc &d, uint64_t i_count, const Request 
     }
     // Lateral-mirror mode (tile_params.h `mir`): a scan, an array and a sequence that are mirror-symmetric about x = 0 have
     // tau(pixel', N-1-n, M-1-m) == tau(pixel, n, m) bit for bit: tap index and interpolation weights serve a pixel and its mirror image.
-    // Detected from the geometry itself (a fact); the whole image in one plan (or a mirror slab), plain 'DAS', scalar sound speed.
+    // Detected from the geometry itself (a fact); the whole image in one plan (or a mirror slab), plain 'DAS'; a per-pixel sound-speed map must be
+    // mirror-symmetric itself, bit for bit (part of the same fact: a pixel and its image then share `cinv` as they share everything else) -- general mode
+    // only: the reciprocal + mirror kernels keep the sound speed uniform (two registers their four window sets need), a reciprocal plan with a map stays reciprocal.
     // A reciprocal plan that is also mirror-symmetric runs FOUR window sets per stage (launch configurations 15 / 16; folded data: two, 17 / 18):
     // that kernel addresses the frame with one descriptor: frames below 2 GiB.
     // fp16 data: a pixel x receiver weight rides along (an I x N array, a pixel-only array, or a generated rule); fp32 data: as a hiprtc build only.
@@ -252,7 +254,7 @@ inline int resolve_symmetry(const qdas_desc &d, uint64_t i_count, const Request 
     const bool jit_asked = jit_on && !sw.no_mirror_wpix32;
     const bool mir_wpix = (dt == QDAS_F16 || (dt == QDAS_F32 && jit_asked)) && !s.sym && !s.swap && !rq.bpix_mode && z.S == rq.npix
                           && ((rq.pix_arr >= 0 && !rq.pix_is_tx && !d.rx_apod_kind) || (rq.pix_arr < 0 && d.rx_apod_kind >= 1 && d.rx_apod_kind <= 4)) && !sw.no_mirror_wpix;
-    if (rq.eligible && !rq.syn && !rq.bfm && (dt == QDAS_F32 || dt == QDAS_F16) && (mir_plain || mir_wpix || mir_tab) && !rq.cmap && z.I3 == 1 && z.I2 >= 2
+    if (rq.eligible && !rq.syn && !rq.bfm && (dt == QDAS_F32 || dt == QDAS_F16) && (mir_plain || mir_wpix || mir_tab) && !(rq.cmap && s.sym) && z.I3 == 1 && z.I2 >= 2
         && z.N >= 2 && ((d.i_begin == 0 && i_count == I) || s.mslab) && !(d.plan_flags & QDAS_PLAN_NO_MIRROR) && !sw.no_mirror
         && (!s.sym || ((uint64_t)z.T * z.N * z.M * data_size(dt) + 65536 < (1ull << 31) && (s.rfold || z.M % 16 == 0) && !sw.no_mirq
                        && tile_lds_bytes(dt, 1, z.N, z.M, 1, 0, (z.S > 0 && !s.rfold) ? 1 : 0, 1, s.rfold) <= tile_lds_limit(1)))) {

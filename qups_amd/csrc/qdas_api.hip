@@ -391,6 +391,32 @@ __global__ void mirror_check_kernel(const float *Pi, uint64_t I1, uint64_t I2, u
     }
     if (!exact) { *bad = 1u; atomicMax(dev, __float_as_uint(worst)); }
 }
+// a per-pixel map (I1 x I2, contiguous): c[i1, I2-1-col] == c[i1, col] bit for bit?
+__global__ void mirror_map_check_kernel(const uint32_t *c, uint64_t I1, uint64_t I2, uint32_t *bad) {
+    const uint64_t n = I1 * (I2 / 2);
+    bool same = true;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i1 = q % I1, col = q / I1;
+        if (c[i1 + I1 * col] != c[i1 + I1 * (I2 - 1 - col)]) same = false;
+    }
+    if (!same) *bad = 1u;
+}
+static int mirror_symmetric_map(const float *dmap, uint64_t I1, uint64_t I2, bool *yes) {
+    *yes = false;
+    uint32_t *flag = nullptr, res = 1;
+    HIPCHK(hipMalloc((void **)&flag, sizeof(uint32_t)));
+    hipError_t e = hipMemset(flag, 0, sizeof(uint32_t));
+    if (e == hipSuccess) {
+        const uint64_t n = I1 * (I2 / 2);
+        mirror_map_check_kernel<<<(unsigned)std::min<uint64_t>((n + 255) / 256 + 1, 4096), 256, 0, 0>>>((const uint32_t *)dmap, I1, I2, flag);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(&res, flag, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(flag);
+    HIPCHK(e);
+    *yes = res == 0;
+    return QDAS_OK;
+}
 // receivers, transmits (positions, normals, t0) and pixel columns mirror-symmetric about x = 0?  fp32 geometry.
 // Exact mode (`tol` < 0): bit for bit.  Tolerance mode (QDAS_PLAN_APPROX_SYMMETRY, `tol` >= 0 in SAMPLES): positions may deviate -- distance is
 // 1-Lipschitz in either end point, so |tau(p', N-1-n, M-1-m) - tau(p, n, m)| * fs <= cinv * fs * (2 max|M(p') - p| + max|M(r') - r| + max|M(v') - v|) =: bound,
@@ -582,6 +608,8 @@ static int plan_resolve_modes(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b
             bool yes = false;
             double bound = 0.0;
             if ((rc = mirror_symmetric(desc, (const float *)pl->gp.Pi, &yes, b.sy.sym_tol, pl->cinv0 * desc->fs, &bound))) return rc;
+            // (a sound-speed map: exact mode only -- plan_modes.h leaves sym_tol unset for maps --, and the map itself mirror-symmetric bit for bit)
+            if (yes && b.rq.cmap && (rc = mirror_symmetric_map((const float *)pl->gp.cinv + pl->gp.cst[5], z.I1, z.I2, &yes))) return rc;
             f.mirror_known = true; f.mirror_yes = yes; f.mirror_bound = bound;
         }
     }

@@ -165,7 +165,7 @@ int main(int argc, char **argv) {
             EXPECT(!(sy.sym && rf >= 1) || (sy.sym_tol >= 0 && sy.recip_bound <= sy.sym_tol && (d.plan_flags & QDAS_PLAN_APPROX_SYMMETRY)), "reciprocal mode beyond its tolerance: %s", D.text.c_str());
             EXPECT(!(sy.sym && rf == 0) || sy.recip_bound == 0.0, "%s", D.text.c_str());
             EXPECT(!(sy.mir && sy.big), "mirror mode on the re-basing configuration: %s", D.text.c_str());
-            EXPECT(!sy.mir || (mf == 0 && !rq.syn && !rq.bfm && !rq.cmap && z.I3 == 1 && !(d.plan_flags & QDAS_PLAN_NO_MIRROR)), "mirror mode on %s", D.text.c_str());
+            EXPECT(!sy.mir || (mf == 0 && !rq.syn && !rq.bfm && !(rq.cmap && sy.sym) && z.I3 == 1 && !(d.plan_flags & QDAS_PLAN_NO_MIRROR)), "mirror mode on %s", D.text.c_str());
             EXPECT(!sy.big || (dt == QDAS_F32 && !sy.sym), "re-basing configuration on %s", D.text.c_str());
             EXPECT(!(sy.rfold && !sy.prefolded && fb == 1), "folds without a fold buffer: %s", D.text.c_str());
             EXPECT(sy.eligible || (sy.why && *sy.why), "%s", D.text.c_str());

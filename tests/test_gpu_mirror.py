@@ -93,6 +93,40 @@ def test_mirror_mode_needs_exact_symmetry():
     assert not mirror_of(Pi=Pz)
 
 
+@pytest.mark.parametrize("seq,prec", [("FSA", "single"), ("PW", "single"), ("PW", "halfT")])
+def test_mirror_mode_with_a_mirror_symmetric_sound_speed_map(seq, prec, monkeypatch):
+    """a per-pixel sound-speed map that is mirror-symmetric itself (bit for bit) leaves the lateral-mirror mode on -- a pixel and its image share `cinv` as
+    they share tap index and weights (csrc/plan_modes.h; the map is part of the mirror fact: csrc/qdas_api.hip mirror_symmetric_map) --; a map that is not
+    keeps the ordinary kernel.  Both against the float64 oracle, and the mirror plan against the same plan without the mode (another summation order)."""
+    from oracle import das_oracle as O
+    from tests.test_gpu_parity import run_das, f32r
+    case = make_case(seq=seq, interp="cubic", seed=23, N=16, I1=140, I2=24, zlim=(4e-3, 18e-3), xspan=4e-3)
+    zz, xx = np.meshgrid(np.linspace(0, 1, 140), np.linspace(-1, 1, 24), indexing="ij")
+    sym = f32r(1.0 / f32r(1.0 / (1540.0 + 25.0 * np.sin(2.1 * zz + 0.4) * np.cos(1.7 * xx))))[:, :, None]       # even in x
+    sym = 0.5 * (sym + sym[:, ::-1])                                       # (exactly: the two halves are the same float32 values)
+    sym = f32r(1.0 / f32r(1.0 / sym)); sym[:, 12:] = sym[:, 11::-1]
+    skew = sym.copy(); skew[70, 3, 0] = f32r(1.0 / np.nextafter(np.float32(1.0 / skew[70, 3, 0]), np.float32(1.0)))     # one pixel, one ulp of 1/c
+    xq = case["x"]
+    if prec == "halfT":
+        xq = xq.real.astype(np.float16).astype(np.float64) + 1j * xq.imag.astype(np.float16).astype(np.float64)
+    tol = 2e-3 if prec == "halfT" else 2e-5
+    for cmap, want in ((sym, True), (skew, False)):
+        ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xq, case["t0"], case["fs"], 1.0 / f32r(1.0 / cmap), VS=case["VS"], DV=case["DV"], interp="cubic")
+        out, plan = run_das(case, c=cmap, prec=prec, kernel=2)
+        assert plan.kernel == "tiled" and plan.fallback_tiles() == 0
+        # (a reciprocal plan -- FSA -- stays reciprocal: its mirror kernels keep the sound speed uniform)
+        want_mirror = want and not plan.reciprocal
+        assert bool(plan.mirror) == want_mirror, plan.kernel_name()
+        assert seq != "PW" or not plan.reciprocal
+        assert rel_err(out, ref) <= tol
+        if want_mirror:
+            monkeypatch.setenv("QDAS_NO_MIRROR", "1")
+            plain, plan0 = run_das(case, c=cmap, prec=prec, kernel=2)
+            monkeypatch.delenv("QDAS_NO_MIRROR")
+            assert not plan0.mirror
+            assert rel_err(out, plain) <= (1e-3 if prec == "halfT" else 3e-6)
+
+
 def test_mirror_mode_edges_split_aperture_and_record_ends(monkeypatch):
     """small image (several workgroups per tile: partial images of both halves), a record that ends inside the image (checked loop:
     zeros where the reference zeroes), odd column count (the centre column is its own mirror image), per-transmit t0"""
