@@ -220,6 +220,32 @@ def test_shift_sum_matches_the_oracle_and_the_general_kernel(interp, dtype):
     assert rel_err(_np(z).reshape(T, N, Mo, F), _np(shift_sum(torch.from_numpy(x), shift, w, interp))) <= (1e-11 if dbl else 2e-4)
 
 
+def test_temporaries_of_interleaved_streams_do_not_collide():
+    """the one-shot entries take their temporaries from an arena per (device, stream) (csrc/scratch.hip): calls of growing and shrinking size issued
+    alternately on two streams -- each stream's arena regrown on the way -- give the bits of the same calls issued one by one"""
+    import torch
+    from qups_amd.interpd import shift_sum
+    rng = np.random.default_rng(7)
+    calls = []
+    for k, (M, Mo) in enumerate([(5, 3), (40, 33), (7, 2), (64, 64), (3, 70), (64, 64)]):
+        T, N = 300 + 17 * k, 4
+        x = (rng.standard_normal((T, N, M)) + 1j * rng.standard_normal((T, N, M))).astype(np.complex64)
+        shift = rng.uniform(-20, 20, (M, Mo)).astype(np.float32).astype(np.float64)
+        w = rng.uniform(0.2, 1, (M, Mo))
+        calls.append((torch.from_numpy(x).cuda(), shift, w))
+    ref = [shift_sum(x, sh, w, "cubic").clone() for x, sh, w in calls]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    out = [None] * len(calls)
+    for rep in range(3):
+        for k, (x, sh, w) in enumerate(calls):
+            with torch.cuda.stream(s1 if (k + rep) % 2 == 0 else s2):
+                out[k] = shift_sum(x, sh, w, "cubic")
+        torch.cuda.synchronize()
+        for k in range(len(calls)):
+            assert torch.equal(out[k], ref[k]), (rep, k)
+
+
 def test_shift_sum_offsets_too_far_apart_for_one_window_and_no_weights():
     """offsets spread over more than a staged window holds (a window per synthesised transmit), weights omitted (ones), one receiver"""
     import torch
