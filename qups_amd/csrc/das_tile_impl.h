@@ -47,6 +47,9 @@
 //  * Cold fp64 code (transmit-block refresh, generated apodization) is called, not inlined (tile_util.h): no instantiation
 //    uses scratch memory (tests/test_build_regs.py).
 #include "tile_params.h"
+#ifndef QDAS_F16_PIPE
+#define QDAS_F16_PIPE 0          // tuning builds (QDAS_JIT_DEFINES): the software-pipelined pair loop for fp16 two-window-set kernels too
+#endif
 #include "tile_util.h"
 #include "tile_taps.h"
 #include "tile_hooks.h"
@@ -439,7 +442,15 @@ template <class C> __device__ __forceinline__ typename Tile<C>::wraw Tile<C>::wl
     if constexpr (C::WMIR) { if (image) k = ipx2 + (P.apix_pixel_only ? 0ull : P.I1 * P.I2 * P.I3 * (uint64_t)(N - 1u - na)); }
     if (QSPEC(APIX_REAL, P.apix_real)) {
         if constexpr (C::F32) return wraw{((const uint32_t *)P.apix)[k], 0u};
-        else return wraw{(uint32_t)((const unsigned short *)P.apix)[k], 0u};
+        else {
+            // the 16 bits land in the low half of a register whose upper half is left UNDEFINED: as `(uint32_t)ushort` the zero extension was a
+            // v_and_b32 right behind the load -- an s_waitcnt vmcnt and a full global-memory latency in every stage head (round 6: read off the
+            // ISA of BASELINE C5's kernel; phase timers 17-30 % of a workgroup's life).  wconv() reads the low half only (v_cvt_f32_f16).
+            typedef _Float16 h2raw __attribute__((ext_vector_type(2)));
+            h2raw hv;
+            hv.x = ((const _Float16 *)P.apix)[k];
+            return wraw{__builtin_bit_cast(uint32_t, hv), 0u};
+        }
     } else {
         if constexpr (C::F32) { const uint2 v = ((const uint2 *)P.apix)[k]; return wraw{v.x, v.y}; }
         else return wraw{((const uint32_t *)P.apix)[k], 0u};
@@ -741,7 +752,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
             const uint32_t cbase = win_off + (uint32_t)buf * (C::NW * C::WB) - (MAGIC_BITS * (uint32_t)C::SB);
             // full block (reciprocal mode: block entirely above the diagonal): check-free; else the tail / diagonal variant
             if (C::SYM ? (n < m0 && (!C::FOLD || m0 + C::MB <= M)) : (m0 + C::MB <= M)) {
-                if constexpr (C::TWO && (C::F32 || C::SYM) && C::K == 4 && !(CHECK || C::FMOD || C::WTAB) && !hooks::no_pipeline)
+                if constexpr (C::TWO && (C::F32 || C::SYM || QDAS_F16_PIPE) && C::K == 4 && !(CHECK || C::FMOD || C::WTAB) && !hooks::no_pipeline)
                     pairs_pipelined(rb, cbase);
                 else
                 {

@@ -937,35 +937,41 @@ static int plan_wide_windows(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b)
     return QDAS_OK;
 }
 
-// Stage shape of plan-specialised builds (fp32 data).  The prebuilt configurations stage 16 transmits x 2 window sets x 192 samples (general-mode lateral-mirror plans:
-// BASELINE C2, plane-wave compounding) or 32 transmits x 192 samples (one window set: general mode, the reciprocity fold without the mirror mode).  A hiprtc build takes any
-// shape: when every tile of some footprint fits 128-sample windows, 32 x 2 x 128 resp. 64 x 128 samples -- the same 64 KiB per buffer (the one-set plans: 64 instead of 48),
-// HALF the stages (barriers, receive-delay evaluations, DMA issue) -- is the better one (C2 1.70 -> 1.61 ms; C3 without any symmetry -6 %, the fold alone -3 %).  Asked
-// with the prebuilt probe kernels (tile_params.h probe_w); if the build fails later the plan runs the prebuilt kernel on the footprint chosen here (128 samples fit 192).
+// Stage shape of plan-specialised builds.  The prebuilt configurations stage 16 transmits x 2 window sets x 192 samples (general-mode lateral-mirror plans:
+// BASELINE C2, plane-wave compounding) or 32 transmits x 192 samples (one window set: general mode, the reciprocity fold without the mirror mode); fp16 data: 384 samples.  A
+// hiprtc build takes any shape: when every tile of some footprint fits ONE-KiB windows (128 samples of fp32, 256 of fp16 data), 32 x 2 resp. 64 x 1 of them -- the same 64 KiB
+// per buffer (the one-set plans: 64 instead of 48), HALF the stages (barriers, receive-delay evaluations, weight loads, DMA issue) -- is the better shape (C2 1.70 -> 1.61 ms;
+// C3 without any symmetry -6 %, the fold alone -3 %; round 6, fp16 data incl. plans with a pixel x receiver weight: BASELINE C5 1.73 -> 1.59 ms, same box).  Asked with the
+// prebuilt probe kernels (tile_params.h probe_w); if the build fails later the plan runs the prebuilt kernel on the footprint chosen here (the narrower window fits the wider).
 static int plan_stage_shape(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) {
     const qdas_sizes &z = pl->d.sz;
     TileParams &t = pl->tp;
     const bool jit_on = (desc->plan_flags & QDAS_PLAN_JIT) && !b.sw.no_jit;
-    if (!(jit_on && z.dtype == QDAS_F32 && !t.big && !t.bf && !t.syn && !t.apix && !t.gen_kind && !t.bpix && t.narrow == 0 && !t.stage_shift && !t.cinv_pix
-          && pl->no_fallback && !getenv("QDAS_NO_STAGE_SHAPE") && !getenv("QDAS_JIT_MB") && !getenv("QDAS_JIT_W"))) return QDAS_OK;
+    const bool f16 = z.dtype == QDAS_F16;
+    // (fp32 frames with a pixel x receiver weight keep their 16-transmit stages: the weighted totals leave no register for 16 more residual pairs; fp16 taps are half the registers.
+    //  fp16 data: the two-window-set plans only -- one set of 64 transmits measured SLOWER on BASELINE C5 without the mirror mode, 2.37 -> 2.80 ms: M = 96 is 1.5 such blocks)
+    if (!(jit_on && (z.dtype == QDAS_F32 || f16) && !t.big && !t.bf && !t.syn && (f16 || (!t.apix && !t.gen_kind)) && !t.bpix && t.narrow == 0 && !t.stage_shift && !t.cinv_pix
+          && !(f16 && (t.sym || !t.mir)) && pl->no_fallback && !getenv("QDAS_NO_STAGE_SHAPE") && !getenv("QDAS_JIT_MB") && !getenv("QDAS_JIT_W"))) return QDAS_OK;
     int mb = 0, sets = 1;
     if (t.mir && !t.sym) { mb = 32; sets = 2; }                          // two window sets: a pixel and its mirror image
     else if (!t.mir && (!t.sym || t.fold)) { mb = 64; sets = 1; }        // one window set
     if (!mb || t.M < (uint64_t)mb) return QDAS_OK;
+    const int w1k = f16 ? 256 : 128;                                     // samples of a one-KiB window
     // LDS image of the specialised build: the header of the prebuilt configuration (+ the stage weights of the longer stages) + 2 buffers x sets x mb windows x 1 KiB
-    const size_t hdr = tile_lds_bytes(z.dtype, t.sym, t.N, t.M, 0, 0, t.wtab ? 1 : 0, 0, t.fold) - tile_config(z.dtype, t.sym, 0, t.mir ? 2 : 1, 0, t.fold).lds_bytes;
-    if (hdr + (t.wtab ? (size_t)2 * 2 * (size_t)mb * 8 : 0) + (size_t)2 * sets * mb * 128 * 8 > (size_t)158 * 1024) return QDAS_OK;
+    const int pixw = t.act_bytes ? 1 : 0;
+    const size_t hdr = tile_lds_bytes(z.dtype, t.sym, t.N, t.M, 0, pixw, t.wtab ? 1 : 0, 0, t.fold) - tile_config(z.dtype, t.sym, 0, t.mir ? 2 : 1, 0, t.fold).lds_bytes;
+    if (hdr + (t.wtab ? (size_t)2 * 2 * (size_t)mb * 8 : 0) + (size_t)2 * sets * mb * 1024 > (size_t)158 * 1024) return QDAS_OK;
     int rc;
     const TileParams keep = t;
     const double keep_frac = pl->misfit_frac;
     const unsigned keep_ntiles = pl->ntiles, keep_cols = pl->tile_cols;
     const bool keep_nf = pl->no_fallback;
-    t.probe_w = 128;
+    t.probe_w = w1k;
     auto set_grid = [&](int tzl) { plan_set_grid(pl, tzl); };
     if ((rc = choose_tile_shape(pl, desc, set_grid))) return rc;
     const bool fits = pl->no_fallback;
     t.probe_w = 0;
-    if (fits) { pl->hint_mb = mb; pl->hint_w = 128; }
+    if (fits) { pl->hint_mb = mb; pl->hint_w = w1k; }
     else {
         t = keep;
         pl->misfit_frac = keep_frac; pl->no_fallback = keep_nf; pl->ntiles = keep_ntiles; pl->tile_cols = keep_cols;
@@ -981,9 +987,11 @@ static int plan_split_aperture(qdas_plan *pl, PlanBuild &b) {
     int ncu = 0, rc;
     HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, pl->device));
     const unsigned cus = ncu > 0 ? (unsigned)ncu : 256u;
-    const int mb_eff = pl->hint_mb ? pl->hint_mb : pl->tc.mb;       // (transmits per stage of the kernel the plan means to run: plan_stage_shape)
+    int mb_eff = pl->hint_mb ? pl->hint_mb : pl->tc.mb;             // (transmits per stage of the kernel the plan means to run: plan_stage_shape)
+    int mb_grp = pl->hint_mb ? pl->hint_mb : pl->tc.mb;             // (... and of the transmit-block groups of a two-dimensional split)
+    if (const char *e = getenv("QDAS_JIT_MB")) { const int mb = atoi(e); if (mb >= 2 && mb % pl->tc.waves == 0 && (b.desc->plan_flags & QDAS_PLAN_JIT) && !b.sw.no_jit) { mb_eff = mb; mb_grp = mb; } }      // (tuning builds, plan_jit)
     t.ksplit = modes::choose_ksplit(pl->ntiles, cus, z.M, mb_eff, t.sym != 0, b.kN_eff, t.act_bytes != 0, t.syn != 0, b.sw);
-    t.ksplit_m = modes::choose_ksplit_m(&t.ksplit, t.M, pl->tc.mb, t.sym != 0, t.act_bytes != 0, t.syn != 0, z.dtype, b.sw);
+    t.ksplit_m = modes::choose_ksplit_m(&t.ksplit, t.M, mb_grp, t.sym != 0, t.act_bytes != 0, t.syn != 0, z.dtype, b.sw);
     if (t.ksplit > 1 && !t.bf) {
         void *pb;
         if ((rc = dev_alloc(pl, &pb, sizeof(float) * 2 * (size_t)t.ksplit * 4 * pl->i_count * (t.mir == 2 ? 2 : 1)))) return rc;   // x4: up to four frames per launch (fp64 data: one complex128 frame -- fits as well)
