@@ -47,6 +47,9 @@
 //  * Cold fp64 code (transmit-block refresh, generated apodization) is called, not inlined (tile_util.h): no instantiation
 //    uses scratch memory (tests/test_build_regs.py).
 #include "tile_params.h"
+#ifndef QDAS_ONEACC_PLAIN
+#define QDAS_ONEACC_PLAIN 0      // tuning builds: the plain (not software-pipelined) pair loop for the long-stage two-window-set fp32 builds
+#endif
 #ifndef QDAS_F16_PIPE
 #define QDAS_F16_PIPE 0          // tuning builds (QDAS_JIT_DEFINES): the software-pipelined pair loop for fp16 two-window-set kernels too
 #endif
@@ -87,6 +90,12 @@ struct TileCfg {
     //  one tap index and one set of weights for two folded traces of two frames, i.e. for EIGHT products of the reference's loop)
     static constexpr bool QUAD = FB4 || (MIRQ && !FOLD) || (FOLDQ && FB2);   // four window sets: the pair loop makes two passes over one index / weight evaluation
     static constexpr bool TWO = (SYM && !FOLD) || FBX || FOLDQ;   // (at least) two window sets per stage: direct + (reciprocal | next frame | mirror image)
+    // long-stage two-window-set fp32 builds (hiprtc: 32 transmits x 2 sets, plan_stage_shape): ONE accumulator per pixel (my pixel, its mirror image / the next frame), as
+    // MIRQ and FOLDQ run -- the second accumulator of each is the register pair the 16 residual pairs of such a stage leave no room for (round 5's builds kept one residual
+    // pair in scratch and re-loaded it in every stage behind an s_waitcnt vmcnt(0) that also drained the LDS-DMA: profiles/r05/kernel_regs_hiprtc.txt)
+    // (likewise the one general-mode variant that is two registers short: fp32, lanczos3 weights, remodulation AND a weight table -- built on demand, found by
+    //  tests/test_jit.py::test_bench_and_suite_hiprtc_kernels_do_not_spill in round 6)
+    static constexpr bool ONEACC = (FB2 && !SYM && sizeof(ST_) == 8 && MB_ >= 32) || (!TWO && sizeof(ST_) == 8 && FMOD_ && WTAB_ && INTERP_ == 3 && !BF_ && !LUT_ && !BIG_);
     static constexpr int NHP = QUAD ? 2 : 1;         // passes of the pair loop: one per frame pair (MIRQ: my pixel, its mirror image)
     static constexpr int NFR = FB4 ? 4 : (FB2 ? 2 : 1);   // frames per launch
     static constexpr int NW = QUAD ? 4 * MB : (TWO ? 2 * MB : MB);     // windows per LDS buffer
@@ -752,7 +761,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
             const uint32_t cbase = win_off + (uint32_t)buf * (C::NW * C::WB) - (MAGIC_BITS * (uint32_t)C::SB);
             // full block (reciprocal mode: block entirely above the diagonal): check-free; else the tail / diagonal variant
             if (C::SYM ? (n < m0 && (!C::FOLD || m0 + C::MB <= M)) : (m0 + C::MB <= M)) {
-                if constexpr (C::TWO && (C::F32 || C::SYM || QDAS_F16_PIPE) && C::K == 4 && !(CHECK || C::FMOD || C::WTAB) && !hooks::no_pipeline)
+                if constexpr (C::TWO && (C::F32 || C::SYM || QDAS_F16_PIPE) && C::K == 4 && !(CHECK || C::FMOD || C::WTAB) && !hooks::no_pipeline && !((QDAS_ONEACC_PLAIN || C::INTERP == 3) && C::ONEACC))      // (Lanczos weights + double-buffered taps + 16 residual pairs do not fit 128 registers: the plain loop, same-box 27.95 -> 28.2 ms on C3 without reciprocity, profiles/r06/oneacc_ab.txt)
                     pairs_pipelined(rb, cbase);
                 else
                 {

@@ -22,6 +22,7 @@ struct JitSpec {
     int mslab;                                          // ... of a mirror slab (tile_params.h mir == 2)
     int wreal;                                          // the weight table is real: the weighted accumulation is one packed FMA per sample
     int fold;                                           // reciprocity-folded data (TileCfg::FOLD; with mirq: two window sets)
+    int plain;                                          // the plain instead of the software-pipelined pair loop (QDAS_ONEACC_PLAIN: plan_jit's second attempt when a build uses scratch)
 };
 
 // One point of the template's matrix as the prebuilt instantiations name it: built on demand when libqdas.so does not carry it (jit.hip)
@@ -34,6 +35,7 @@ std::string jit_compile_source(const std::string &src, std::vector<char> *code, 
 std::string jit_get_kernel_source(const std::string &src, int device, hipFunction_t *fn, std::string *key_out);
 
 std::string jit_source(const JitSpec &k);
+std::string jit_spec_string(const JitSpec &k);      // every field, "raw:name=value,..." (QDAS_JIT_SPEC_LOG; qdas_debug_jit_compile parses it back)
 // "" on success, else the reason (hiprtc missing, compile log, ...)
 std::string jit_compile(const JitSpec &k, std::vector<char> *code, std::string *key_out, bool use_disk = true);
 std::string jit_get_kernel(const JitSpec &k, int device, hipFunction_t *fn, std::string *key_out);

@@ -1045,8 +1045,24 @@ static int plan_jit(qdas_plan *pl, const qdas_desc *desc, int *remake) {
         pl->jit_lds = dt == QDAS_F64 ? 0 : hdr + body;       // (fp64 data: the prebuilt configuration's own LDS image, das_tile.hip)
     }
     std::string key;
-    const std::string err = pl->jit_lds > (size_t)160 * 1024 ? std::string("LDS image too large for the requested configuration")
-                                                             : jit_get_kernel(k, pl->device, &pl->jit_fn, &key);
+    std::string err = pl->jit_lds > (size_t)160 * 1024 ? std::string("LDS image too large for the requested configuration")
+                                                       : jit_get_kernel(k, pl->device, &pl->jit_fn, &key);
+    // "No kernel spills" is a property the plan enforces, not a sentence: a build that uses scratch memory (the long-stage two-window-set fp32 shapes are at the
+    // register limit -- delay kinds, a split aperture, roles swapped move them by a register or two) is rebuilt with the plain instead of the software-pipelined
+    // pair loop (16 tap registers less; same-box A/B < 1 %: profiles/r06/oneacc_ab.txt).  tests/test_jit.py rebuilds the specs this logs without a device.
+    if (err.empty() && !k.plain && k.mir && !k.sym && dt == QDAS_F32 && k.mb >= 32) {
+        int scratch = 0;
+        if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, pl->jit_fn) == hipSuccess && scratch > 0) {
+            k.plain = 1;
+            hipFunction_t fn2 = nullptr;
+            std::string key2;
+            const std::string err2 = jit_get_kernel(k, pl->device, &fn2, &key2);
+            if (err2.empty()) { pl->jit_fn = fn2; key = key2; } else k.plain = 0;
+        } else (void)hipGetLastError();
+    }
+    if (const char *lf = getenv("QDAS_JIT_SPEC_LOG")) {      // every plan-specialised build of a run, re-buildable without a device (tests/jit_kernels.txt)
+        if (FILE *f = fopen(lf, "a")) { fprintf(f, "%s\n", jit_spec_string(k).c_str()); fclose(f); }
+    }
     if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; pl->jit_w = k.w; return QDAS_OK; }
     pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel";
     const bool unfolded = dt == QDAS_F32 && t.sym && !t.fold;                  // (likewise: the general kernels then)

@@ -67,9 +67,9 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
         unroll<NHP>([&](auto hpc) {
             constexpr int hp = decltype(hpc)::value;
             constexpr int GSET = FB4 ? 2 * hp : 0, HSET = FB4 ? 2 * hp + 1 : 1;       // window sets of the pass
-            v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : (C::FOLDQ ? &acc : &acc1));      // (FOLDQ: one accumulator per pixel, as MIRQ -- the 32-transmit stages need the registers)
+            v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : ((C::FOLDQ || C::ONEACC) ? &acc : &acc1));      // (FOLDQ: one accumulator per pixel, as MIRQ -- the 32-transmit stages need the registers)
             // (reciprocal + lateral-mirror mode: ONE accumulator per pixel -- my pixel, its mirror image; the register budget of four window sets)
-            v2f &B0 = *((C::MIRQ && !C::FOLD) ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *((C::MIRQ && !C::FOLD) ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : (SYM ? &acc2 : &acc3));
+            v2f &B0 = *((C::MIRQ && !C::FOLD) ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *((C::MIRQ && !C::FOLD) ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : ((SYM || C::ONEACC) ? &acc2 : &acc3));
             v2f v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
             v2f u0 = {0.f, 0.f}, u1 = {0.f, 0.f};     // the same two pairs of the second frame (FB2)
             if constexpr (F32) {
@@ -337,10 +337,10 @@ template <class C> __device__ __forceinline__ void Tile<C>::pairs_pipelined(floa
         }
         if constexpr (u + 1 < NU) lds_fence2_keep<8>(gd0[u & 1], gd1[u & 1], h0, h1, w);
         else                      lds_fence2_keep<0>(gd0[u & 1], gd1[u & 1], h0, h1, w);
-        v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : (C::FOLDQ ? &acc : &acc1));      // (FOLDQ: one accumulator per pixel, as MIRQ -- the 32-transmit stages need the registers)
+        v2f &A0 = *(FB4 ? (hp ? &acc2 : &acc) : &acc), &A1 = *(FB4 ? (hp ? &acc2 : &acc) : ((C::FOLDQ || C::ONEACC) ? &acc : &acc1));      // (FOLDQ: one accumulator per pixel, as MIRQ -- the 32-transmit stages need the registers)
         // (reciprocal mode: both mirror halves share ONE accumulator -- three in all; with 32-transmit stages the fourth costs the two
         //  registers that would otherwise spill, and measures the same: profiles/r02/exp_prio.txt)
-        v2f &B0 = *((C::MIRQ && !C::FOLD) ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *((C::MIRQ && !C::FOLD) ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : (C::SYM ? &acc2 : &acc3));
+        v2f &B0 = *((C::MIRQ && !C::FOLD) ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : &acc2), &B1 = *((C::MIRQ && !C::FOLD) ? (hp ? &acc2 : &acc) : FB4 ? (hp ? &acc3 : &acc1) : ((C::SYM || C::ONEACC) ? &acc2 : &acc3));
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             tap_mac(A0, gd0[u & 1], k, w[k].x); tap_mac(A1, gd1[u & 1], k, w[k].y);
