@@ -34,9 +34,10 @@ extern "C" {
 #endif
 
 /* 100: rounds 1-3.  101 (round 5): qdas_wsinterpd_desc carries ystride[8] / lane_dim / reserved (added in round 4 without a bump), QDAS_PLAN_PREFOLDED rejects
- * apodization arrays.  EVERY descriptor of this header must be ZERO-INITIALISED by the caller (memset / `= {0}`) before its fields are set: fields added by
+ * apodization arrays.  102 (round 5): the device staging entries recycle their buffers (qdas_device_trim), one-shot entries take temporaries from kept arenas.
+ * 103 (round 6): qdas_device_free waits for the device before a buffer can be handed out again (it used to be caller's business, unstated).  EVERY descriptor of this header must be ZERO-INITIALISED by the caller (memset / `= {0}`) before its fields are set: fields added by
  * later versions then read as "default", and a caller compiled against an older header must check qdas_version() against the QDAS_VERSION it was built with. */
-#define QDAS_VERSION 102
+#define QDAS_VERSION 103
 
 /* ---- data precision: the reference's kernel postfix (kern/das_spec.m:218-222) */
 #define QDAS_F64 0 /* 'DAS'  : double2 data/apod/y, double geometry + time            */
@@ -461,13 +462,20 @@ typedef struct qdas_iir_desc {
 } qdas_iir_desc;
 int qdas_iir(const qdas_iir_desc *desc, const void *x, void *y, void *stream);
 
+/* ---- Temporaries of the stream entries (qdas_shift_sum, qdas_das_lut, qdas_greens, qdas_convd's FFT path): taken from an arena the library keeps per (device,
+ * stream).  One such call at a time runs per (device, stream) -- a second thread on the same stream waits --, and a call MAY BLOCK the host: when the stream's
+ * previous call outgrew the arena (the next call waits for it, then regrows the arena to what that call needed, up to 512 MiB) or asks for a single temporary above
+ * 64 MiB (freed, after a stream synchronisation, when the call returns).  Otherwise the calls only enqueue work.  qdas_device_trim releases idle arenas. */
+
 /* ---- Device staging for HOST callers of the device-pointer entries above (qdas_delays*, qdas_das_lut, qdas_wsinterpd, qdas_greens, qdas_convd,
  * qdas_pre_execute ...): the reference reaches those kernels with gpuArrays (kern/wsinterpd2.m:236, src/UltrasoundSystem.m:681-718, kern/convd.m:150-199),
  * a MEX gateway built WITHOUT the mxGPUArray API has host arrays only and must not need the HIP headers -- it allocates, copies and frees through
  * these three (mex/qdas_mex.c dev_in / dev_out).  device: HIP ordinal, -1 = current.  qdas_device_copy is synchronous; kind 0: host -> device,
  * 1: device -> host, 2: device -> device. */
 int qdas_device_malloc(void **p, size_t bytes, int device);
-int qdas_device_free(void *p, int device);      /* (buffers of qdas_device_malloc are kept for reuse, at most 4 GiB -- QDAS_STAGING_CACHE_MB --: a call-per-launch gateway does not map / unmap) */
+int qdas_device_free(void *p, int device);      /* (buffers of qdas_device_malloc are kept for reuse, at most 4 GiB -- QDAS_STAGING_CACHE_MB --: a call-per-launch gateway does not map / unmap.
+                                                 *  Like hipFree, qdas_device_free WAITS for the buffer's device -- every stream, blocking or not -- before the buffer can be handed
+                                                 *  out again: work the caller launched on any stream may still be using it when it is freed.) */
 int qdas_device_trim(void);                      /* ... and released here */
 int qdas_device_copy(void *dst, const void *src, size_t bytes, int kind, int device);
 

@@ -136,6 +136,8 @@ def sosfilt(x, sos, dim: int = 1, gain: float = 1.0, device=None):
     if not (1 <= s.shape[0] <= 16):
         raise ValueError("sosfilt: 1 to 16 second-order sections")
     ax = int(dim) - 1
+    if float(gain) == 0.0:                                        # (the C descriptor reads gain == 0 as "not set" = 1, include/qdas.h; an EXPLICIT zero gain is zero output)
+        return torch.zeros_like(xt.to(dev))
     xm = xt.to(dev).movedim(ax, -1).contiguous()                  # (..., T): time fastest = the ABI's T x K column-major
     T = int(xm.shape[-1])
     K = int(xm.numel() // T) if T else 0

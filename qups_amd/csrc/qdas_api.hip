@@ -189,15 +189,20 @@ __global__ void __launch_bounds__(256) upload_kernel(unsigned char *__restrict__
 extern "C" int qdas_internal_upload(void *dst, const void *src, size_t bytes) {
     constexpr size_t CAP = 1u << 20;
     if (!bytes) return (int)hipSuccess;
-    if (bytes > CAP) return (int)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    // (larger uploads go through the same pinned buffer, one MiB at a time -- ADVICE r5: they fell back to a plain hipMemcpy, the call the stale read of round 5
+    //  involved; root cause unknown, tools/repro keeps reproducing it on fresh boxes -- so no upload of the library takes that path any more)
     static std::mutex mu;
     static void *pin = nullptr;
     std::lock_guard<std::mutex> lk(mu);
     if (!pin && hipHostMalloc(&pin, CAP, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { pin = nullptr; (void)hipGetLastError(); return (int)hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
-    memcpy(pin, src, bytes);
-    upload_kernel<<<(unsigned)((bytes + 4095) / 4096), 256, 0, nullptr>>>((unsigned char *)dst, (const unsigned char *)pin, bytes);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    hipError_t e = hipSuccess;
+    for (size_t at = 0; at < bytes && e == hipSuccess; at += CAP) {
+        const size_t nb = bytes - at < CAP ? bytes - at : CAP;
+        memcpy(pin, (const unsigned char *)src + at, nb);
+        upload_kernel<<<(unsigned)((nb + 4095) / 4096), 256, 0, nullptr>>>((unsigned char *)dst + at, (const unsigned char *)pin, nb);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);      // (the pinned buffer is rewritten by the next piece)
+    }
     return (int)e;
 }
 static inline hipError_t upload(void *dst, const void *src, size_t bytes) { return (hipError_t)qdas_internal_upload(dst, src, bytes); }
@@ -2115,7 +2120,14 @@ extern "C" int qdas_device_free(void *p, int device) {
                 c.live.erase(c.live.begin() + (long)k);
                 static const size_t cap = [] { const char *e = getenv("QDAS_STAGING_CACHE_MB"); return (size_t)(e && atoll(e) >= 0 ? atoll(e) : 4096) << 20; }();
                 if (c.cached + it.bytes <= cap) {
-                    // (the buffer's last reader may still run on the null stream: a later owner uploads to it with a copy ORDERED on that stream -- qdas_device_copy --)
+                    // hipFree waits for the device before it unmaps; a RECYCLED buffer must be as idle as a freed one: the next qdas_device_malloc of
+                    // this size class hands it out at once, and a kernel the caller launched on a non-blocking stream may still be reading or writing it -- the
+                    // next owner's upload (null stream: not ordered with hipStreamNonBlocking streams) would race with it.  One device-wide wait, outside the lock.
+                    c.mu.unlock();
+                    hipError_t se;
+                    { DeviceGuard guard(it.dev); se = guard.err != hipSuccess ? guard.err : getenv("QDAS_DEVICE_FREE_NO_SYNC") ? hipSuccess : hipDeviceSynchronize(); }      // (the switch: tests show the hazard with it)
+                    c.mu.lock();
+                    if (se != hipSuccess) { (void)hipGetLastError(); c.live.push_back(it); return fail(QDAS_EHIP, "qdas_device_free: hipDeviceSynchronize: %s", hipGetErrorString(se)); }
                     c.free_list.push_back(it);
                     c.cached += it.bytes;
                     return QDAS_OK;

@@ -7,7 +7,8 @@
 // temporaries from hipMalloc (profiles/r05/stale_read_repro.txt).  The gateway test had found it as `shiftsum` images that were wrong in every sample.
 // So: one ARENA per (device, stream), hipMalloc'ed, kept.  Calls on one stream run in stream order, so the next call may reuse the arena as soon as it is
 // issued; a call that needs more than the arena holds gets blocks of its own (released -- after a stream synchronisation -- when the stream's next call
-// begins, and the arena is regrown to what was needed); more than 64 MiB never stays: such a block is freed when its call returns (which then waits for it).
+// begins, and the arena is regrown to what the call needed in total, up to 8 x 64 MiB); a single request above 64 MiB never stays: such a block is freed when its call
+// returns (which then waits for it).  The arena's mutex is held for the life of a Scratch object: one one-shot call at a time per (device, stream).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <memory>
@@ -71,7 +72,10 @@ void *Scratch::get(size_t bytes) {
     }
     if (off_ + b <= a->cap) { p = (char *)a->base + off_; off_ += b; return p; }
     off_ += b;
-    if (off_ > a->want) a->want = off_ < ARENA_MAX ? off_ : ARENA_MAX;
+    // the arena regrows to the call's real total (clamped to ARENA_MAX, a call whose SMALL requests add up to more overflowed on every call -- a stream
+    // synchronisation, hipFree and hipMalloc per call: the churn the arena exists to remove); a total beyond 8 x ARENA_MAX is not kept: that call pattern keeps the
+    // per-call blocks, and each such call begins by waiting for the stream's previous one (include/qdas.h: one-shot entries may block)
+    if (off_ > a->want && off_ <= 8 * ARENA_MAX) a->want = off_;
     if (hipMalloc(&p, b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     a->extra.push_back(p);
     return p;

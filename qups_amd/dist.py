@@ -115,12 +115,17 @@ def expand_block_cost(block_cost, ncols: int):
     import numpy as np
     b = np.asarray(block_cost, dtype=np.float64).reshape(-1)
     nb = b.size
-    edges = [ncols * k // nb for k in range(nb + 1)]
     out = np.zeros(ncols)
+    if ncols <= 0 or nb == 0:
+        return out
+    if nb > ncols:                                  # more blocks than columns: a column takes the SUM of the blocks that fall on it (nothing of the profile is dropped)
+        for k in range(nb):
+            out[min(ncols - 1, k * ncols // nb)] += b[k]
+        return out
+    edges = [ncols * k // nb for k in range(nb + 1)]
     for k in range(nb):
         w = edges[k + 1] - edges[k]
-        if w > 0:
-            out[edges[k]:edges[k + 1]] = b[k] / w
+        out[edges[k]:edges[k + 1]] = b[k] / w       # (nb <= ncols: every block has at least one column)
     return out
 
 
@@ -264,7 +269,7 @@ class ShardedDasPlan:
         if dist.is_initialized() and self.world > 1:
             on_gpu = dist.get_backend(self.group) == "nccl"
             tt = t.to((device if device is not None else "cuda") if on_gpu else "cpu")
-            dist.broadcast(tt, src=0, group=self.group)
+            dist.broadcast(tt, src=(dist.get_global_rank(self.group, 0) if self.group is not None else 0), group=self.group)      # (rank 0 OF THE GROUP measured)
             t = tt.cpu()
         return None if float(t.sum()) <= 0 else t.numpy()
 

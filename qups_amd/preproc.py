@@ -15,40 +15,64 @@ from . import _lib
 # Plans by shape: a qdas_pre_plan owns its twiddles -- and, for record lengths the one-pass kernel does not take (a prime factor above 13, more than 8192
 # samples), two hipFFT plans and three work buffers whose creation costs 11-15 ms (profiles/r04/general_time.txt) against 0.1-0.7 ms of transform.  A frame
 # loop calls hilbert() with ONE shape: the last few plans are kept, destroyed on eviction and at interpreter exit.
-_PLANS: "dict[tuple, C.c_void_p]" = {}
+_PLANS: "dict[tuple, tuple]" = {}           # key -> (plan handle, the plan's own lock)
 _PLAN_CACHE_MAX = 8
-_plans_lock = __import__("threading").Lock()
+_plans_lock = __import__("threading").Lock()      # guards the DICTIONARY only (it used to be held across execute + stream synchronisation: every hilbert() of every device and thread in a row)
+
+
+def _destroy(h, lk):
+    with lk:                                      # (never under a running execute)
+        try:
+            _lib.lib().qdas_pre_plan_destroy(h)
+        except Exception:                         # (interpreter exit: the HIP runtime may be gone before this hook runs)
+            pass
 
 
 def clear_pre_plan_cache():
     with _plans_lock:
-        L = _lib.lib() if _PLANS else None
-        for h in _PLANS.values():
-            L.qdas_pre_plan_destroy(h)
+        items = list(_PLANS.values())
         _PLANS.clear()
+    for h, lk in items:
+        _destroy(h, lk)
 
 
-__import__("atexit").register(lambda: clear_pre_plan_cache() if _PLANS else None)
+def _at_exit():
+    try:
+        clear_pre_plan_cache()
+    except Exception:
+        pass
+
+
+__import__("atexit").register(_at_exit)
 
 
 def _pre_plan(key, d):
-    """the cached plan of this shape (created on a miss; the oldest entry is evicted beyond _PLAN_CACHE_MAX); call with _plans_lock held"""
+    """(plan, lock) of this shape: created on a miss, the oldest entry evicted beyond _PLAN_CACHE_MAX (destroyed once no execute holds it)"""
     L = _lib.lib()
-    h = _PLANS.pop(key, None)
-    if h is None:
-        h = C.c_void_p()
-        _lib.check(L.qdas_pre_plan_create(C.byref(h), C.byref(d)))
-        hilbert.plans_created = getattr(hilbert, "plans_created", 0) + 1
-    _PLANS[key] = h                                                  # (most recently used last)
-    while len(_PLANS) > _PLAN_CACHE_MAX:
-        L.qdas_pre_plan_destroy(_PLANS.pop(next(iter(_PLANS))))
-    return h
+    evicted = []
+    with _plans_lock:
+        e = _PLANS.pop(key, None)
+        if e is None:
+            h = C.c_void_p()
+            _lib.check(L.qdas_pre_plan_create(C.byref(h), C.byref(d)))
+            hilbert.plans_created = getattr(hilbert, "plans_created", 0) + 1
+            e = (h, __import__("threading").Lock())
+        _PLANS[key] = e                                              # (most recently used last)
+        while len(_PLANS) > _PLAN_CACHE_MAX:
+            evicted.append(_PLANS.pop(next(iter(_PLANS))))
+    for h, lk in evicted:
+        _destroy(h, lk)
+    return e
 
 
 def hilbert(x, N: int | None = None, fdown: float = 0.0, t0: float = 0.0, fs: float | None = None, device=None):
     """Analytic signal along dim 0 of real ``x`` (``T x ...``; float32 or int16; numpy array or torch tensor), transform length
     ``N`` (default ``T``; zero-padded or truncated like MATLAB's ``hilbert(x, N)``); with ``fdown`` the result is also multiplied by
-    ``exp(-2j*pi*fdown*(t0 + k/fs))``.  Returns a complex64 torch tensor ``N x ...`` on the device."""
+    ``exp(-2j*pi*fdown*(t0 + k/fs))``.  Returns a complex64 torch tensor ``N x ...`` on the device.
+
+    ``t0``, ``fs`` and ``fdown`` are constants of the underlying plan (``qdas_pre_desc``), so they are part of the plan cache's key: a frame loop whose ``t0`` changes
+    per frame creates a plan per value (0.1 ms on the one-pass path, 11-15 ms where hipFFT plans are made) -- downmix with ``t0 = 0`` and multiply the frame by the
+    scalar ``exp(-2j*pi*fdown*t0)`` instead."""
     import torch
     if not torch.cuda.is_available():
         raise RuntimeError("qups_amd: no HIP device visible -- hilbert has no CPU fallback")
@@ -77,8 +101,8 @@ def hilbert(x, N: int | None = None, fdown: float = 0.0, t0: float = 0.0, fs: fl
                      dev.index if dev.index is not None else torch.cuda.current_device(), float(fs or 0.0), float(t0), float(fdown))
     L = _lib.lib()
     key = (T, K, N, int(d.in_type), int(d.device), float(d.fs), float(d.t0), float(d.fdown), __import__("os").environ.get("QDAS_PRE_HIPFFT"))      # (the switch is read at plan creation: part of the key)
-    with torch.cuda.device(dev), _plans_lock:                       # (the lock also serialises executes on one plan: its hipFFT work buffers are the plan's)
-        h = _pre_plan(key, d)
+    h, plan_lock = _pre_plan(key, d)
+    with torch.cuda.device(dev), plan_lock:                         # (one execute at a time per PLAN: its hipFFT work buffers are the plan's; other shapes / devices run beside it)
         hilbert.last_one_pass = bool(L.qdas_pre_plan_one_pass(h))   # which path served the last call (tests / tools)
         _lib.check(L.qdas_pre_execute(h, C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()),
                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))

@@ -306,6 +306,9 @@ def test_sosfilt_on_the_device(dtype, cplx):
         y = sosfilt(torch.from_numpy(x), sos, dim, gain).cpu().numpy()
         ref = O.sosfilt(x.astype(np.complex128 if cplx else np.float64), sos, dim - 1, gain)
         assert y.shape == x.shape and rel(y, ref) <= (1e-6 if dtype == "float32" else 1e-13), (shape, dim, rel(y, ref))
+    # an EXPLICIT zero gain is zero output (the C descriptor reads 0 as "not set" = 1: ADVICE r5)
+    z = sosfilt(torch.from_numpy(x), sos, dim, 0.0).cpu().numpy()
+    assert z.shape == x.shape and not z.any()
 
 
 @pytest.mark.gpu

@@ -207,6 +207,8 @@ def test_balanced_column_bounds_properties():
     assert balanced_column_bounds(np.ones(512), 8) == [64 * k for k in range(9)]       # a flat profile: equal widths
     assert balanced_column_bounds([np.nan, 1.0], 2) == [0, 1, 2] and balanced_column_bounds([], 3) == [0, 0, 0, 0]
     assert np.allclose(expand_block_cost([2, 1], 5), [1, 1, 1 / 3, 1 / 3, 1 / 3])
+    e = expand_block_cost([1, 2, 3, 4, 5], 2)              # more blocks than columns: nothing of the profile is dropped
+    assert np.isclose(e.sum(), 15.0) and e.shape == (2,) and np.all(e > 0)
     # boundaries snapped to the kernel's tile width: no rank gets a partial column tile (a 266-column slab of C3 costs two tile rounds, a 256-column one a single round)
     bq = balanced_column_bounds(c, 8, 32)
     assert all(v % 32 == 0 for v in bq) and bq[0] == 0 and bq[-1] == 512 and all(bq[i] < bq[i + 1] for i in range(8))

@@ -326,3 +326,42 @@ def test_staging_buffers_are_recycled_and_trimmed():
     assert L.qdas_device_copy(off, src.ctypes.data_as(C.c_void_p), 200, 0, -1) == 0 and L.qdas_device_copy(dst.ctypes.data_as(C.c_void_p), off, 200, 1, -1) == 0
     assert np.array_equal(src, dst)
     assert L.qdas_device_free(p2, -1) == 0 and L.qdas_device_free(p3, -1) == 0 and L.qdas_device_trim() == 0
+
+
+@pytest.mark.gpu
+def test_a_freed_staging_buffer_is_idle_on_every_stream_before_it_is_handed_out_again():
+    """qdas_device_free recycles buffers, so -- like hipFree -- it must WAIT for the device first.  Work queued on a NON-BLOCKING stream still writes the buffer
+    when it is freed; the next owner gets the same address and uploads through qdas_device_copy (null stream: not ordered with non-blocking streams).  Without the wait
+    the late writes land on top of the upload."""
+    import torch
+    L = _lib.lib()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    n = 256 << 20
+    stream = torch.cuda.Stream()                                       # (torch's pool streams are created hipStreamNonBlocking)
+
+    def late_writes_seen():
+        p, q = C.c_void_p(), C.c_void_p()
+        assert L.qdas_device_malloc(C.byref(p), n, -1) == 0 and p.value
+        addr = p.value
+        for _ in range(200):                                           # ~50 GB of fills: tens of milliseconds still queued when the buffer is freed
+            assert hip.hipMemsetAsync(p, 0xAB, n, C.c_void_p(stream.cuda_stream)) == 0
+        assert L.qdas_device_free(p, -1) == 0
+        assert L.qdas_device_malloc(C.byref(q), n, -1) == 0 and q.value == addr      # the same buffer, recycled
+        src = np.zeros(1 << 20, np.uint8)
+        assert L.qdas_device_copy(C.c_void_p(q.value + n - src.size), src.ctypes.data_as(C.c_void_p), src.size, 0, -1) == 0
+        assert hip.hipStreamSynchronize(C.c_void_p(stream.cuda_stream)) == 0
+        dst = np.ones(1 << 20, np.uint8)
+        assert L.qdas_device_copy(dst.ctypes.data_as(C.c_void_p), C.c_void_p(q.value + n - src.size), dst.size, 1, -1) == 0
+        assert L.qdas_device_free(q, -1) == 0
+        return bool(dst.any())
+
+    os.environ["QDAS_DEVICE_FREE_NO_SYNC"] = "1"                       # the hazard, shown: without the wait the queued fills land on top of the next owner's upload
+    try:
+        hazard = late_writes_seen()
+    finally:
+        del os.environ["QDAS_DEVICE_FREE_NO_SYNC"]
+    assert hazard, "the test no longer provokes the race it guards against"
+    assert not late_writes_seen()
+    assert L.qdas_device_trim() == 0
