@@ -321,6 +321,9 @@ typedef struct qdas_lut_desc {
                                  calls run on the fused tiled kernel, whose tiles must be compact in depth */
 } qdas_lut_desc;
 int qdas_das_lut(const qdas_lut_desc *d, const void *x, void *y, void *stream);
+/* which kernel served the calling thread's last qdas_das_lut (diagnostic, like qdas_plan_kernel_name): "tiled,mirror [jit <key>]" (tables that are their own
+ * lateral mirror images, checked bit for bit per call: a pixel and its image share tap index and weights -- fp32 full sums without weights), "tiled", "generic" */
+int qdas_das_lut_last_kernel(char *buf, size_t len);
 
 /* ---- General single-delay flavour: weighted, phase-rotated sampling over an N-D broadcast index space.  Replaces the launches of
  *      wsinterpd[f|h] (reference kern/wsinterpd.m:221-236, kernel src/interpd.cu:295-342) and interpd[f|h] (kern/interpd.m,

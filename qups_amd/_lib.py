@@ -32,7 +32,7 @@ SYMBOLS = (
     "qdas_plan_destroy", "qdas_plan_kernel", "qdas_plan_fallback_tiles", "qdas_plan_tile_shape", "qdas_plan_reciprocal", "qdas_plan_folded", "qdas_fold", "qdas_plan_symmetry_bound", "qdas_plan_mirror", "qdas_plan_kernel_name", "qdas_plan_set_timing",
     "qdas_plan_last_kernel_ms", "qdas_plan_create_sharded", "qdas_plan_execute_sharded", "qdas_plan_sharded_info", "qdas_plan_sharded_mirror",
     "qdas_plan_destroy_sharded", "qdas_DAS", "qdas_DASf", "qdas_DASh", "qdas_delays", "qdas_delaysf",
-    "qdas_das_lut", "qdas_wsinterpd", "qdas_shift_sum", "qdas_greens", "qdas_convd", "qdas_convd_len", "qdas_permute3", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_pre_plan_one_pass", "qdas_last_error", "qdas_version", "qdas_device_malloc", "qdas_device_free", "qdas_device_trim", "qdas_device_copy", "qdas_iir", "qdas_device_info", "qdas_kernel_variant_build", "qdas_kernel_variant_prebuilt",
+    "qdas_das_lut", "qdas_das_lut_last_kernel", "qdas_wsinterpd", "qdas_shift_sum", "qdas_greens", "qdas_convd", "qdas_convd_len", "qdas_permute3", "qdas_pre_plan_create", "qdas_pre_execute", "qdas_pre_plan_destroy", "qdas_pre_plan_one_pass", "qdas_last_error", "qdas_version", "qdas_device_malloc", "qdas_device_free", "qdas_device_trim", "qdas_device_copy", "qdas_iir", "qdas_device_info", "qdas_kernel_variant_build", "qdas_kernel_variant_prebuilt",
 )
 
 

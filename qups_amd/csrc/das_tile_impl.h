@@ -137,7 +137,7 @@ struct TileCfg {
     static_assert(!FOLDQ || (MB_ % WAVES_ == 0 && (FB2 ? 4 : 2) * MB_ * W_ * (int)sizeof(ST_) <= 65536), "folded data + lateral-mirror mode: two (two frames: four) window sets within the immediate LDS offsets");
     static_assert(!BIG || (!SYM && !FBX), "the re-basing general kernel runs one frame per launch");
     static_assert(!(FOLDQ && FB2) || MB_ == WAVES_, "folded data + mirror mode, two frames: one window per wave and set");
-    static_assert(!LUT || (!SYM && !FBX && !BIG), "table-driven delays: general mode, one frame per launch");
+    static_assert(!LUT || (!SYM && !FB4 && !BIG && (!FB2 || JITB)), "table-driven delays: general mode, one frame per launch (hiprtc builds: the lateral-mirror mode's two window sets)");
     static_assert(!BF || (!SYM && !FBX && !BIG && !LUT && sizeof(ST_) == 8), "'BF': general mode, fp32 data, one frame per launch");
     static_assert(!F64 || (!SYM && !FBX && !BIG && !LUT && !BF), "fp64 data: the 'DAS' sum (optionally remodulated / with a weight table), one frame per launch");
     static_assert(FB4 ? (2 * MB == WAVES) : (MB % WAVES == 0 && MB % 2 == 0), "staging split");

@@ -22,6 +22,7 @@ struct JitSpec {
     int mslab;                                          // ... of a mirror slab (tile_params.h mir == 2)
     int wreal;                                          // the weight table is real: the weighted accumulation is one packed FMA per sample
     int fold;                                           // reciprocity-folded data (TileCfg::FOLD; with mirq: two window sets)
+    int lut;                                            // table-driven delays (qdas_das_lut) in lateral-mirror mode: exists as a hiprtc build only (round 6)
     int plain;                                          // the plain instead of the software-pipelined pair loop (QDAS_ONEACC_PLAIN: plan_jit's second attempt when a build uses scratch)
 };
 

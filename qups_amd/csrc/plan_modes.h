@@ -468,13 +468,14 @@ inline const char *launch_legal(const LaunchShape &P, LaunchChoice *c) {
     if (!P.probe && (P.ksplit < 1 || (P.ksplit > 1 && !P.has_part && !P.bf))) return "split aperture without partial images";
     // frames per launch; lateral-mirror plans (one frame) run the two-window-set instantiations as well
     const int nfr = P.probe ? 1 : (P.nfr > 1 ? P.nfr : 1);
-    if (P.mir && !P.probe && ((nfr != 1 && !(fold && nfr == 2)) || P.big || P.bf || P.lut || P.syn || ((P.has_apix || P.gen_kind) && ((dtype != 2 && !P.jit) || sym || P.stage_shift || P.has_bpix))
+    if (P.mir && !P.probe && ((nfr != 1 && !(fold && nfr == 2)) || P.big || P.bf || (P.lut && !P.jit) || P.syn || ((P.has_apix || P.gen_kind) && ((dtype != 2 && !P.jit) || sym || P.stage_shift || P.has_bpix))
                               || (!sym && narrow) || (sym && dtype == 1 && !narrow && !fold)))
         return "lateral-mirror mode: one frame (folded data: two), no re-basing / 'BF' / 'SYN' / tables of delays, pixel weights for fp16 data or hiprtc builds, narrow windows when reciprocal";
     const int nf = (P.mir && !P.probe && !sym) ? 2 : nfr;
     if ((nf != 1 && nf != 2 && nf != 4) || (nf > 1 && ((sym && !(fold && nf == 2)) || P.big))) return "frames per launch: 1, 2 or 4; reciprocal plans one (folded: two); no re-basing";     // (folded data: two frames may share a launch)
-    if (P.lut && (sym || nf != 1 || (dtype != 1 && dtype != 2) || (P.syn && dtype != 1))) return "table-driven delays: general mode, one frame";
-    if (P.jit && (P.probe || nfr != 1 || P.lut || P.bf)) return "hiprtc builds: one frame, no probe / table-driven delays / 'BF'";
+    // (table-driven delays in lateral-mirror mode -- symmetric tables, qdas_das_lut checks them per call -- exist as a hiprtc build only: round 6)
+    if (P.lut && (sym || (nf != 1 && !(P.mir && P.jit && nf == 2 && dtype == 1 && !P.syn)) || (dtype != 1 && dtype != 2) || (P.syn && dtype != 1))) return "table-driven delays: general mode, one frame";
+    if (P.jit && (P.probe || nfr != 1 || (P.lut && !P.mir) || P.bf)) return "hiprtc builds: one frame, no probe / 'BF'; table-driven delays in lateral-mirror mode only";
     if (P.bf && (sym || nf != 1 || dtype != 1 || P.lut || P.big || P.has_apix || P.gen_kind)) return "'BF': fp32 general mode without pixel weights";
     ch.narrow = narrow; ch.fold = fold; ch.mirq = mirq; ch.nf = nf; ch.nfr = nfr; ch.probe_f32sym = probe_f32sym; ch.lds = lds;
     ch.cfg = cfg_index(dtype, sym, 1, narrow, mirq, fold);

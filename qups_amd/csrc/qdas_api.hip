@@ -1005,6 +1005,42 @@ static int plan_split_aperture(qdas_plan *pl, PlanBuild &b) {
     return QDAS_OK;
 }
 
+// dynamic LDS of a plan-specialised build: header (Tile::setup) + window buffers (or the prologue's scratch, which aliases them)
+static size_t jit_tile_lds(const JitSpec &k, uint64_t tN, uint64_t tM, uint32_t act_bytes, bool wtab) {
+    const size_t MX = std::min<size_t>(tM > tN ? tM : tN, QDAS_PROLOGUE_CHUNK);
+    const size_t off_act = (((((2 * tM + tN) * 4 + 15) & ~(size_t)15) + 16 * tN + 7 * tM * 4) + 15) & ~(size_t)15;   // Tile::setup
+    const size_t off_wst = off_act + (((size_t)act_bytes + 15) & ~(size_t)15);
+    const size_t hdr = (off_wst + (wtab ? (size_t)k.nbuf * (2 * (size_t)k.mb * 8 + 16) : 0) + 15) & ~(size_t)15;
+    size_t body = (size_t)k.nbuf * k.mb * (k.fold ? (k.mirq ? 2 : 1) : k.mirq ? 4 : (k.sym || k.mir) ? 2 : 1) * k.w * (k.dtype == QDAS_F16 ? 4 : 8);
+    const size_t scratch = 2 * (size_t)k.waves * MX * 4 + 1024;
+    if (body < scratch) body = scratch;
+    return hdr + body;
+}
+
+// "No kernel spills" is a property the library enforces, not a sentence: a build that uses scratch memory (the long-stage two-window-set fp32 shapes are at the
+// register limit -- delay kinds, a split aperture, roles swapped move them by a register or two) is rebuilt with the plain instead of the software-pipelined
+// pair loop (16 tap registers less; same-box A/B < 1 %: profiles/r06/oneacc_ab.txt).  QDAS_JIT_SPEC_LOG=<file> logs the final spec of every build:
+// tests/test_jit.py rebuilds those (tests/jit_kernels.txt) without a device and fails on a spilled register.
+static std::string jit_get_kernel_nospill(JitSpec &k, int device, hipFunction_t *fn, std::string *key) {
+    std::string err = jit_get_kernel(k, device, fn, key);
+    if (err.empty() && !k.plain && k.mir && !k.sym && k.dtype == QDAS_F32 && k.mb >= 32) {
+        int scratch = 0;
+        if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, *fn) == hipSuccess && scratch > 0) {
+            k.plain = 1;
+            hipFunction_t fn2 = nullptr;
+            std::string key2;
+            const std::string err2 = jit_get_kernel(k, device, &fn2, &key2);
+            if (err2.empty()) { *fn = fn2; *key = key2; } else k.plain = 0;
+        } else (void)hipGetLastError();
+    }
+    if (err.empty()) {
+        if (const char *lf = getenv("QDAS_JIT_SPEC_LOG")) {
+            if (FILE *f = fopen(lf, "a")) { fprintf(f, "%s\n", jit_spec_string(k).c_str()); fclose(f); }
+        }
+    }
+    return err;
+}
+
 // QDAS_PLAN_JIT: the tiled kernel compiled for this plan's sizes (jit.hip).  A failure is not an error: the plan keeps its prebuilt kernel and
 // qdas_last_error() says why -- unless the plan's mode exists as a hiprtc build only: *remake = the plan flag to add for a second attempt without it.
 static int plan_jit(qdas_plan *pl, const qdas_desc *desc, int *remake) {
@@ -1039,35 +1075,10 @@ static int plan_jit(qdas_plan *pl, const qdas_desc *desc, int *remake) {
     }
     if (const char *e = getenv("QDAS_JIT_NBUF")) { const int nb = atoi(e); if (nb >= 2 && nb <= 4) k.nbuf = nb; }
     if (const char *e = getenv("QDAS_JIT_W")) { const int wv = atoi(e); if (wv >= 64 && wv <= 1024 && wv % 64 == 0) k.w = wv; }      // (experiments: tiles that do not fit go to the generic kernel)
-    {
-        const size_t MX = std::min<size_t>(t.M > t.N ? t.M : t.N, QDAS_PROLOGUE_CHUNK);
-        const size_t off_act = (((((2 * t.M + t.N) * 4 + 15) & ~(size_t)15) + 16 * t.N + 7 * t.M * 4) + 15) & ~(size_t)15;   // Tile::setup
-        const size_t off_wst = off_act + (((size_t)t.act_bytes + 15) & ~(size_t)15);
-        const size_t hdr = (off_wst + (t.wtab ? (size_t)k.nbuf * (2 * (size_t)k.mb * 8 + 16) : 0) + 15) & ~(size_t)15;
-        size_t body = (size_t)k.nbuf * k.mb * (t.fold ? (mirq ? 2 : 1) : mirq ? 4 : (t.sym || t.mir) ? 2 : 1) * k.w * (dt == QDAS_F16 ? 4 : 8);
-        const size_t scratch = 2 * (size_t)k.waves * MX * 4 + 1024;
-        if (body < scratch) body = scratch;
-        pl->jit_lds = dt == QDAS_F64 ? 0 : hdr + body;       // (fp64 data: the prebuilt configuration's own LDS image, das_tile.hip)
-    }
+    pl->jit_lds = dt == QDAS_F64 ? 0 : jit_tile_lds(k, t.N, t.M, t.act_bytes, t.wtab != nullptr);       // (fp64 data: the prebuilt configuration's own LDS image, das_tile.hip)
     std::string key;
     std::string err = pl->jit_lds > (size_t)160 * 1024 ? std::string("LDS image too large for the requested configuration")
-                                                       : jit_get_kernel(k, pl->device, &pl->jit_fn, &key);
-    // "No kernel spills" is a property the plan enforces, not a sentence: a build that uses scratch memory (the long-stage two-window-set fp32 shapes are at the
-    // register limit -- delay kinds, a split aperture, roles swapped move them by a register or two) is rebuilt with the plain instead of the software-pipelined
-    // pair loop (16 tap registers less; same-box A/B < 1 %: profiles/r06/oneacc_ab.txt).  tests/test_jit.py rebuilds the specs this logs without a device.
-    if (err.empty() && !k.plain && k.mir && !k.sym && dt == QDAS_F32 && k.mb >= 32) {
-        int scratch = 0;
-        if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, pl->jit_fn) == hipSuccess && scratch > 0) {
-            k.plain = 1;
-            hipFunction_t fn2 = nullptr;
-            std::string key2;
-            const std::string err2 = jit_get_kernel(k, pl->device, &fn2, &key2);
-            if (err2.empty()) { pl->jit_fn = fn2; key = key2; } else k.plain = 0;
-        } else (void)hipGetLastError();
-    }
-    if (const char *lf = getenv("QDAS_JIT_SPEC_LOG")) {      // every plan-specialised build of a run, re-buildable without a device (tests/jit_kernels.txt)
-        if (FILE *f = fopen(lf, "a")) { fprintf(f, "%s\n", jit_spec_string(k).c_str()); fclose(f); }
-    }
+                                                       : jit_get_kernel_nospill(k, pl->device, &pl->jit_fn, &key);
     if (err.empty()) { pl->jit_tag = "jit " + key; pl->jit_mb = k.mb; pl->jit_w = k.w; return QDAS_OK; }
     pl->jit_fn = nullptr; g_err = "QDAS_PLAN_JIT: " + err + " -- using the prebuilt kernel";
     const bool unfolded = dt == QDAS_F32 && t.sym && !t.fold;                  // (likewise: the general kernels then)
@@ -1689,10 +1700,58 @@ extern "C" int qdas_delaysf(const qdas_sizes *sz, float *tau, const float *Pi, c
     return delays_one_shot(sz, 1, tau, Pi, Pr, Pv, Nv, cinv, stream);
 }
 
+// Split-delay tables in lateral-mirror mode: tau[i', E-1-e] == tau[i, e] bit for bit for both tables (i' = the pixel of column I2-1-c in the same row)?  The tables
+// are data of the call, so the test runs per call (one pass over both tables: 0.27 GB at BASELINE C2's size), ahead of the probe that is read back anyway.
+__global__ void __launch_bounds__(256) lut_mirror_check_kernel(const uint32_t *ta, uint64_t Ea, const uint32_t *tb, uint64_t Eb, uint64_t I1, uint64_t I2, uint32_t *bad) {
+    // blockIdx.y: element e of table a (e < Ea) or b; blockIdx.x / threads: the pixels of the first half of the columns, four rows of depth per lane when I1 allows
+    const uint64_t I = I1 * I2, half = (I2 + 1) / 2;
+    const uint64_t e = blockIdx.y;
+    const uint32_t *t = e < Ea ? ta : tb;
+    const uint64_t E = e < Ea ? Ea : Eb, f = e < Ea ? e : e - Ea;
+    const uint32_t *p = t + I * f, *q = t + I * (E - 1 - f);
+    bool same = true;
+    if ((I1 & 3) == 0 && (((uintptr_t)t) & 15) == 0) {
+        const uint64_t r4 = I1 / 4, n4 = r4 * half;
+        for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n4; k += (uint64_t)gridDim.x * blockDim.x) {
+            const uint64_t c = k / r4, r = k - c * r4;
+            const uint4 a = ((const uint4 *)(p + I1 * c))[r], b = ((const uint4 *)(q + I1 * (I2 - 1 - c)))[r];
+            if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) same = false;
+        }
+    } else {
+        const uint64_t n = I1 * half;
+        for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+            const uint64_t c = k / I1, r = k - c * I1;
+            if (p[r + I1 * c] != q[r + I1 * (I2 - 1 - c)]) same = false;
+        }
+    }
+    if (!same) *bad = 1u;
+}
+
+// what the last call with these very arguments found (footprint; tables their own mirror images): the next call launches the kernel straight away and CHECKS
+// afterwards -- the kernel's own prologue counts the tiles that do not fit, the symmetry test runs ahead of it on the stream -- instead of probing first
+namespace {
+struct LutMemo { uint64_t I, I1, N, M, T; const void *rx, *tx; int flag, dtype, level; bool fm; };
+std::mutex g_lut_memo_mu;
+std::vector<LutMemo> g_lut_memo;
+bool lut_memo_same(const LutMemo &a, const LutMemo &b) { return a.I == b.I && a.I1 == b.I1 && a.N == b.N && a.M == b.M && a.T == b.T && a.rx == b.rx && a.tx == b.tx && a.flag == b.flag && a.dtype == b.dtype && a.fm == b.fm; }
+int lut_memo_get(const LutMemo &k) { std::lock_guard<std::mutex> lk(g_lut_memo_mu); for (const auto &m : g_lut_memo) if (lut_memo_same(m, k)) return m.level; return -1; }
+void lut_memo_put(const LutMemo &k, int level) {      // level < 0: forget
+    std::lock_guard<std::mutex> lk(g_lut_memo_mu);
+    for (size_t i = 0; i < g_lut_memo.size(); ++i) if (lut_memo_same(g_lut_memo[i], k)) { g_lut_memo.erase(g_lut_memo.begin() + (long)i); break; }
+    if (level >= 0) { LutMemo m = k; m.level = level; g_lut_memo.push_back(m); if (g_lut_memo.size() > 16) g_lut_memo.erase(g_lut_memo.begin()); }
+}
+}  // namespace
+
 // ------------------------------------------------------------------------------------ split-delay flavour
 // The split-delay flavour through the tiled kernel (fp32 / fp16 data).  Returns -1 when the launch was made, +1 when the problem has to run on
 // das_lut_kernel (double precision / kept dimensions / pixel-dependent weights / a tile whose delay spread does not fit the
 // LDS window for any footprint / QDAS_LUT_GENERIC=1), 0 on a HIP error.
+static thread_local std::string g_lut_last;          // the kernel of this thread's last qdas_das_lut (qdas_das_lut_last_kernel)
+extern "C" int qdas_das_lut_last_kernel(char *buf, size_t len) {
+    if (!buf || !len) return fail(QDAS_EINVAL, "null argument");
+    snprintf(buf, len, "%s", g_lut_last.c_str());
+    return QDAS_OK;
+}
 static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t s) {
     const int dt = d->dtype;
     const bool keep_rx = d->flag & QDAS_FLAG_KEEP_RX, keep_tx = d->flag & QDAS_FLAG_KEEP_TX;
@@ -1749,6 +1808,85 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     t.nfr = 1; t.ksplit = 1;
     t.lut_tx = (const float *)tab_b; t.lut_rx = (const float *)tab_s;
     t.fallback_list = counter; t.fallback_cap = 0;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+    // ---- lateral-mirror mode (round 6; VERDICT r5 item 5: `bfDAS` within 1.25x of `DAS`).  Tables whose mirror images are their own -- a centred scan under a symmetric
+    // probe and sequence: what bfDASLUT computes for every BASELINE configuration -- let a pixel and its mirror image share tap index and weights exactly as geometry-
+    // driven plans do.  Checked per call, bit for bit, on the device (one pass over both tables, read back with the probe's counter); the kernel is the
+    // plan-specialised two-window-set build with 32-transmit stages of 128-sample windows, so it exists when hiprtc does and when every tile of some footprint fits those
+    // windows; anything else falls through to the general table-driven kernel below.  fp32 data, full sum, no weights.
+    if (dt == QDAS_F32 && !keep && !d->w && shaped && t.I2 >= 2 && kM >= 32 && !getenv("QDAS_LUT_NO_MIRROR") && !getenv("QDAS_NO_MIRROR") && !getenv("QDAS_NO_JIT")) {
+        uint32_t hc[2] = {1u, 1u};
+        int found = -1;
+        unsigned nt2 = 0;
+        const uint64_t halfc = (t.I2 + 1) / 2;
+        const LutMemo mk{d->I, t.I1, d->N, d->M, d->T, d->tau_rx, d->tau_tx, d->flag, dt, -1, t.fmod != 0.0};
+        const int memo = lut_memo_get(mk);
+        auto set_grid = [&](int l) {
+            t.tz_log2 = l; t.wz_log2 = 3;
+            const unsigned cols = ((unsigned)tc.waves * 64u) >> l;
+            t.tiles_z = (uint32_t)((t.I1 + (1u << l) - 1) >> l);
+            t.tile_x0 = 0;
+            t.tiles_x = (uint32_t)((halfc + cols - 1) / cols);      // (the tiles of the first half of the columns: their mirror images have the same delays)
+            nt2 = t.tiles_z * t.tiles_x;
+        };
+        bool ok = hipMemsetAsync(counter, 0, 2 * sizeof(uint32_t), s) == hipSuccess;
+        if (ok) {
+            const uint64_t rows = (t.I1 & 3) == 0 ? t.I1 / 4 : t.I1;
+            const unsigned gx = (unsigned)std::min<uint64_t>((rows * halfc + 255) / 256, 1024);
+            lut_mirror_check_kernel<<<dim3(gx, (unsigned)(kN + kM)), 256, 0, s>>>((const uint32_t *)tab_s, kN, (const uint32_t *)tab_b, kM, t.I1, t.I2, counter + 1);
+            ok = hipGetLastError() == hipSuccess;
+        }
+        // the launch of a resolved footprint: `verify` = no probe went before it (a remembered footprint): the kernel's own fit test and the symmetry flag are read afterwards
+        auto run_mirror = [&](int l, bool verify) -> int {      // -1 launched and good, 0 HIP error, 1 not taken
+            set_grid(l);
+            JitSpec k{};
+            k.interp = (d->flag & 7) == 4 ? 1 : (d->flag & 7); k.dtype = dt; k.fmod = t.fmod != 0.0; k.lut = 1; k.mir = 1;
+            k.waves = tc.waves; k.mb = 32; k.w = 128; k.nbuf = 2;
+            k.N = kN; k.M = kM; k.T = d->T; k.I1 = t.I1; k.strN = strN; k.strM = strM; k.tzl = l; k.wzl = t.wz_log2;
+            unsigned ks2 = 1;
+            while (ks2 * 2 <= (unsigned)std::min<uint64_t>(8, kN) && (uint64_t)nt2 * ks2 < (uint64_t)ncu) ks2 *= 2;
+            void *part2 = ks2 > 1 ? scratch.get(sizeof(float) * 2 * (size_t)ks2 * d->I) : nullptr;
+            if (ks2 > 1 && !part2) ks2 = 1;
+            k.ksplit = ks2;
+            const size_t lds = jit_tile_lds(k, kN, kM, 0, false);
+            hipFunction_t fn = nullptr;
+            std::string key;
+            const std::string keep_err = g_err;
+            if (lds > (size_t)160 * 1024 || !jit_get_kernel_nospill(k, dev, &fn, &key).empty()) { g_err = keep_err; (void)hipGetLastError(); return 1; }      // (no compiler: not an error)
+            t.probe = 0; t.probe_w = 0; t.mir = 1; t.ksplit = ks2; t.part = (float2 *)part2;
+            if (hipMemsetAsync(counter, 0, sizeof(uint32_t), s) != hipSuccess) return 0;
+            if (launch_tile(t, dt, nt2, s, fn, lds) != hipSuccess) return 0;
+            if (verify) {
+                if (hipMemcpyAsync(hc, counter, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) return 0;
+                if (hc[0] != 0 || hc[1] != 0) return 1;          // the tables changed under the same pointers: redone below, every pixel rewritten
+            }
+            g_lut_last = "tiled,mirror,mb=32,W=128 [jit " + key + "]";
+            return -1;
+        };
+        if (ok && memo >= 3 && memo <= 6) {
+            const int r = run_mirror(memo, true);
+            if (r <= 0) return r;
+            lut_memo_put(mk, -1);
+            ok = hipMemsetAsync(counter + 1, 0, sizeof(uint32_t), s) == hipSuccess;      // (the flag stays valid for the loop below only if it was clean)
+            if (ok && hc[1] != 0) ok = false;
+        }
+        for (int l = 6; ok && l >= 3 && found < 0; --l) {
+            set_grid(l);
+            t.probe = 1; t.probe_w = 128; t.mir = 0; t.ksplit = 1; t.part = nullptr;
+            ok = hipMemsetAsync(counter, 0, sizeof(uint32_t), s) == hipSuccess && launch_tile(t, dt, nt2, s) == hipSuccess
+                 && hipMemcpyAsync(hc, counter, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+            if (!ok || hc[1] != 0) break;                           // (tables that are not their own mirror images: the general kernel)
+            if (hc[0] == 0) found = l;
+        }
+        t.probe = 0; t.probe_w = 0;
+        if (!ok) (void)hipGetLastError();
+        if (ok && found >= 0 && hc[1] == 0) {
+            const int r = run_mirror(found, false);
+            if (r <= 0) { if (r < 0) lut_memo_put(mk, found); return r; }
+        }
+        t.mir = 0; t.ksplit = 1; t.part = nullptr;
+    }
     // footprint: the deepest tile (of 64, 32, 16, 8 pixels of I1) whose delay spreads all fit the window; the tables are data
     // of this call, so the fit is probed per call (prologue-only launches)
     int best = -1;
@@ -1770,8 +1908,6 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     if (best < 0) return 1;
     t.probe = 0;
     // too few tiles for the GPU: several workgroups per tile, each summing a range of receivers (as plans do)
-    int ncu = 0;
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
     unsigned ks = 1;
     const unsigned cap = (unsigned)std::min<uint64_t>(8, kN);
     while (ks * 2 <= cap && (uint64_t)ntiles * ks < (uint64_t)ncu) ks *= 2;
@@ -1785,6 +1921,7 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
     if (hipMemsetAsync(counter, 0, sizeof(uint32_t), s) != hipSuccess) return 0;
     const hipError_t e = launch_tile(t, dt, ntiles, s);
     if (e == hipErrorSharedObjectInitFailed) { (void)hipGetLastError(); return 1; }      // (a variant that is built on demand, and no compiler at hand: the any-shape kernel)
+    g_lut_last = "tiled";
     return e == hipSuccess ? -1 : 0;     // (the probe of this footprint found no misfit on these very tables: every tile is written)
 }
 
@@ -1804,6 +1941,7 @@ extern "C" int qdas_das_lut(const qdas_lut_desc *d, const void *x, void *y, void
         const int rc = lut_tiled(d, x, y, s);
         if (rc <= 0) return rc < 0 ? QDAS_OK : fail(QDAS_EHIP, "das_lut: tiled launch failed");
     }
+    g_lut_last = "generic";
     LutParams p{};
     p.tau_rx = d->tau_rx; p.tau_tx = d->tau_tx; p.w = d->w; p.x = x; p.y = y;
     p.T = d->T; p.N = d->N; p.M = d->M; p.I = d->I;

@@ -110,6 +110,10 @@ def das_lut(x, tau_rx, tau_tx, *, interp="linear", w=None, keep_rx=False, keep_t
         for f in range(F):
             _lib.check(L.qdas_das_lut(C.byref(d), C.c_void_p(xc.data_ptr() + f * T * N * M * es),
                                       C.c_void_p(y.data_ptr() + f * oM * oN * I * es), stream))
+    buf = C.create_string_buffer(200)
+    L.qdas_das_lut_last_kernel.argtypes = [C.c_char_p, C.c_size_t]
+    if L.qdas_das_lut_last_kernel(buf, 200) == 0:
+        das_lut.last_kernel = buf.value.decode()         # which kernel served the last frame (tests / tools): "tiled,mirror ... [jit <key>]" | "tiled" | "generic"
     rev = lambda t: t.permute(*reversed(range(t.ndim)))
     return rev(y.reshape(tuple(reversed(fsz)) + (oM, oN) + tuple(reversed(Isz))))
 

@@ -78,6 +78,56 @@ def warm(variants: Iterable[Variant], jobs: int | None = None, quiet: bool = Tru
     return bad
 
 
+_SPEC_WORKER = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, sys.argv[1])
+from qups_amd import _lib
+L = _lib.lib()
+f = L.qdas_debug_jit_compile
+f.argtypes = [C.c_int] * 4 + [C.c_ulonglong] * 3 + [C.c_char_p, C.c_size_t, C.POINTER(C.c_ulonglong)]
+bad = 0
+for spec in sys.argv[2:]:
+    os.environ["QDAS_JIT_DEBUG_SPEC"] = spec
+    msg, n = C.create_string_buffer(4000), C.c_ulonglong()
+    if f(0, 0, 0, 0, 0, 0, 0, msg, 4000, C.byref(n)):
+        print("FAILED", spec[:120], msg.value.decode(errors="replace")[:400])
+        bad += 1
+sys.exit(1 if bad else 0)
+"""
+
+
+def read_specs(paths: Iterable[str]) -> List[str]:
+    """complete JitSpecs (lines ``raw:name=value,...``: what ``QDAS_JIT_SPEC_LOG=<file>`` appends per plan-specialised build)"""
+    out = set()
+    for path in paths:
+        with open(path) as fh:
+            out.update(ln.strip() for ln in fh if ln.startswith("raw:"))
+    return sorted(out)
+
+
+def warm_specs(specs: Iterable[str], cache_dir: str, jobs: int | None = None, quiet: bool = True) -> int:
+    """Build plan-specialised (hiprtc) kernels from their logged specs into ``cache_dir``, one compiler process per core: a later process finds them there through
+    ``QDAS_CACHE_DIR`` or -- read-only, copied into its own cache on a hit -- ``QDAS_JIT_WARM_DIR`` (csrc/jit.hip).  No device needed.  Returns the number of failed workers."""
+    sp = sorted(set(specs))
+    if not sp:
+        return 0
+    os.makedirs(cache_dir, mode=0o700, exist_ok=True)
+    jobs = max(1, min(jobs or min(os.cpu_count() or 4, 64), len(sp)))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, QDAS_CACHE_DIR=cache_dir)
+    for k in ("QDAS_JIT_DEFINES", "QDAS_JIT_FLAGS", "QDAS_JIT_MB", "QDAS_JIT_W", "QDAS_JIT_NBUF", "QDAS_JIT_WARM_DIR", "QDAS_JIT_SPEC_LOG"):
+        env.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, "-c", _SPEC_WORKER, root] + sp[j::jobs], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for j in range(jobs)]
+    bad = 0
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode:
+            bad += 1
+        if not quiet or p.returncode:
+            sys.stderr.write(out)
+    return bad
+
+
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     if argv[:1] == ["--worker"]:

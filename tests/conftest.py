@@ -39,5 +39,17 @@ def pytest_collection_finish(session):
         vs = warm.read_census([os.path.join(ROOT, "tests", "suite_kernels.txt")])
         bad = warm.warm(vs)
         sys.stderr.write(f"[conftest] kernel cache warmed: {len(vs)} variants listed, {bad} worker(s) failed, {time.perf_counter() - t:.1f} s\n")
+        # the PLAN-SPECIALISED builds of the suite (tests/suite_jit_kernels.txt: the QDAS_JIT_SPEC_LOG of a full run; ~3 s of hiprtc each, one by one inside the tests:
+        # a quarter of round 5's suite time) go into a read-only warm directory the same way (csrc/jit.hip QDAS_JIT_WARM_DIR: a hit is copied into the cache directory
+        # the test watches, as if it had been built there)
+        jl = os.path.join(ROOT, "tests", "suite_jit_kernels.txt")
+        if os.path.exists(jl) and not os.environ.get("QDAS_NO_JIT_WARM"):
+            import tempfile
+            t = time.perf_counter()
+            wd = tempfile.mkdtemp(prefix="qdas_jit_warm_")
+            specs = warm.read_specs([jl])
+            bad = warm.warm_specs(specs, wd)
+            os.environ["QDAS_JIT_WARM_DIR"] = wd
+            sys.stderr.write(f"[conftest] hiprtc builds warmed: {len(specs)} specs, {bad} worker(s) failed, {time.perf_counter() - t:.1f} s\n")
     except Exception as ex:                                  # (never fatal: the variants are then built on demand)
         sys.stderr.write(f"[conftest] kernel cache not warmed: {ex}\n")

@@ -161,6 +161,53 @@ def test_das_lut_full_sum_runs_the_fused_kernel(interp, seq, tpose, wtab, fm, mo
     assert np.all(a[np.abs(ref) == 0] == 0)
 
 
+@pytest.mark.parametrize("interp,seq,fm", [("cubic", "PW", 0.0), ("lanczos3", "FSA", 0.0), ("linear", "PW", 1.5e6), ("cubic", "DV", 0.0)])
+def test_das_lut_mirror_symmetric_tables_take_the_mirror_mode(interp, seq, fm, monkeypatch):
+    """delay tables that are their own lateral mirror images (a centred scan, a symmetric probe and sequence: what bfDASLUT builds for the BASELINE
+    configurations) run the two-window-set build -- a pixel and its image share tap index and weights, as geometry-driven plans do -- and agree with the oracle and
+    with the general table-driven kernel (QDAS_LUT_NO_MIRROR=1).  The symmetry is checked PER CALL, bit for bit: ONE table entry one ulp off must NOT take the mode
+    (and still be exact)."""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import das_lut
+    case = make_case(seq=seq, interp=interp, seed=29, N=32, M=32, I1=140, I2=40, data="noise")
+    N, M = case["N"], case["M"]
+    dv, dr = O.tx_rx_distances(case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["VS"], case["DV"])
+    c = cinv_f32(case["c"])
+    f32 = lambda a: np.asarray(a, np.float32)
+    tau_tx = f32((dv[:, :, :, 0, :] / c - case["t0"]) * case["fs"])[:, :, 0]           # I1 x I2 x M, samples
+    tau_rx = f32(dr[:, :, :, :, 0] / c * case["fs"])[:, :, 0]                           # I1 x I2 x N
+    # make the tables EXACTLY symmetric (the fp32 geometry of make_case is symmetric to rounding only): second half := mirror image of the first
+    h = tau_rx.shape[1] // 2
+    tau_rx[:, -h:, :] = tau_rx[:, :h, :][:, ::-1, ::-1]
+    tau_tx[:, -h:, :] = tau_tx[:, :h, :][:, ::-1, ::-1]
+    omega = 2 * np.pi * fm / case["fs"]
+    x = case["x"]
+    ref = np.asarray(O.das_lut(x, tau_rx.astype(np.float64)[:, :, None] / case["fs"], tau_tx.astype(np.float64)[:, :, None] / case["fs"], 0.0, case["fs"], interp=interp, fmod=fm)).reshape(140, 40)
+    run = lambda trx, ttx: _np(das_lut(torch.from_numpy(x), trx, ttx, interp=interp, omega=omega, prec="single")).reshape(140, 40)
+    monkeypatch.delenv("QDAS_LUT_NO_MIRROR", raising=False)
+    a = run(tau_rx, tau_tx)
+    if "mirror" not in das_lut.last_kernel:                   # (no hiprtc on this box: the mode exists as a specialised build only)
+        pytest.skip("no mirror build: " + das_lut.last_kernel)
+    assert das_lut.last_kernel.startswith("tiled,mirror") and "[jit " in das_lut.last_kernel
+    monkeypatch.setenv("QDAS_LUT_NO_MIRROR", "1")
+    b = run(tau_rx, tau_tx)
+    assert das_lut.last_kernel == "tiled"
+    monkeypatch.delenv("QDAS_LUT_NO_MIRROR")
+    assert rel_err(a, ref) <= 2e-5 and rel_err(a, b) <= 2e-5, (rel_err(a, ref), rel_err(a, b))      # (two summation orders of fp32 sums)
+    assert not np.array_equal(a, b)                           # two different kernels did run
+    # one entry of one table one ulp off: not symmetric -> the general kernel, same image as ITS oracle
+    t2 = tau_rx.copy()
+    t2[17, 3, 5] = np.nextafter(t2[17, 3, 5], np.float32(np.inf))
+    c2 = run(t2, tau_tx)
+    assert das_lut.last_kernel == "tiled"
+    assert rel_err(c2, b) <= 1e-5
+    t3 = tau_tx.copy()
+    t3[100, 39, M - 1] = np.nextafter(t3[100, 39, M - 1], np.float32(-np.inf))
+    run(tau_rx, t3)
+    assert das_lut.last_kernel == "tiled"
+
+
 @pytest.mark.parametrize("prec,real,keep_rx", [("single", True, False), ("single", False, False), ("single", True, True), ("halfT", True, False), ("halfT", False, False)])
 def test_das_lut_receive_apodization_array_on_the_fused_kernel(prec, real, keep_rx, monkeypatch):
     """the usual bfDASLUT call: a pixel x receiver apodization (I1 x I2 x N, real or complex, data precision) -- applied per stage by

@@ -134,7 +134,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(L, s), s
-    assert L.qdas_version() == 102
+    assert L.qdas_version() == 103
     assert C.sizeof(_lib.Sizes) == 7 * 8 + 4 * 4
     assert C.sizeof(_lib.Desc) == C.sizeof(_lib.Sizes) + 2 * 8 + 7 * 8 + 4 * 4 + 3 * 8 + 4 * 8
 

@@ -130,11 +130,18 @@ for cfg in ("c1", "c2"):
         dv = Pi.t().reshape(I, 1, 3) - Pvt[:3].t().reshape(1, M, 3)
         ttx = (torch.sign(dv[..., 2]) * dv.norm(dim=2) + Pvt[2].reshape(1, M)) * (w["fs"] / w["c0"]) - w["t0"] * w["fs"]   # virtual sources
     trx, ttx = trx.reshape(w["I1"], w["I2"], N).contiguous(), ttx.reshape(w["I1"], w["I2"], M).contiguous()      # I1 x I2 x N: the image shape lets the fused tiled kernel take the call
+    # the record and the tables in the REFERENCE's memory order (MATLAB column-major: fast time / depth contiguous -- what bfDASLUT hands wsinterpd2, kern/wsinterpd2.m:236):
+    # views of buffers laid out the other way round, which the wrapper uses in place; torch-order tensors cost three layout copies per call (printed beside it)
+    cm = lambda a: a.permute(*reversed(range(a.ndim))).contiguous().permute(*reversed(range(a.ndim)))
+    xl_c, trx_c, ttx_c = cm(xl), cm(trx), cm(ttx)
     try:
-        ms = timed(lambda: das_lut(xl, trx, ttx, interp="cubic"), reps=3)
-        line(f"das_lut {cfg.upper()} I={I} N={N} M={M} cubic (geometric tables)", ms, xl.numel() * 8 + (trx.numel() + ttx.numel()) * 4 + I * 8, f"{I * N * M / ms / 1e6:.1f} Gpair/s")
+        ms = timed(lambda: das_lut(xl_c, trx_c, ttx_c, interp="cubic"), reps=3)
+        kern = getattr(das_lut, "last_kernel", "?")
+        ms_t = timed(lambda: das_lut(xl, trx, ttx, interp="cubic"), reps=3)
+        line(f"das_lut {cfg.upper()} I={I} N={N} M={M} cubic (geometric tables)", ms, xl.numel() * 8 + (trx.numel() + ttx.numel()) * 4 + I * 8, f"{I * N * M / ms / 1e6:.1f} Gpair/s  [{kern}]  (torch-order record and tables: {ms_t:.3f} ms)")
     except Exception as ex:
         print("das_lut:", cfg, repr(ex))
+    del xl_c, trx_c, ttx_c
     del xl
 
 # ---- greens: C1's simulator call (64 x 64 FSA, 2048 samples) with 1000 point scatterers
