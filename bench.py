@@ -522,6 +522,41 @@ def main():
                 fsplan.close()
             except Exception as ex:
                 folded_stream = {"ms_per_step": None, "note": f"failed: {ex!r}"}
+        # the OTHER slab layouts beside the one the timed region ran (the first run on real hardware uses the driver's flag-less command and should
+        # yield all of them): the same barrier-bracketed loop over `steps` steps, max over ranks, outside the headline's timed region.  Reciprocal fp32 frames only.
+        layouts = {}
+        this_layout = ("equal_cost_" if splan.col_bounds is not None else "equal_width_") + ("prefolded" if prefolded_run else "each_rank_folds" if bool(plan.folded) else "no_fold")
+        layouts[this_layout] = {"ms_per_step": round(el / args.steps * 1e3, 3), "timed_region": True}
+        if bool(plan.folded) and F == 1 and w["prec"] == "single" and not args.no_fold and not args.no_reciprocal:
+            from qups_amd.dist import FoldedReplicator
+            x_unf = xc_unfolded if prefolded_run else xc
+            xfold = xc if prefolded_run else None
+            for name, kw in (("equal_width_each_rank_folds", dict()), ("equal_width_prefolded", dict(prefolded=True)), ("equal_cost_prefolded", dict(prefolded=True, balance="measure"))):
+                if name in layouts:
+                    continue
+                try:
+                    sp2 = ShardedDasPlan(prob, rank, world, device=dev, kernel=args.kernel, reciprocal=True, jit=args.jit, **kw)
+                    if kw.get("prefolded") and xfold is None:
+                        rp = FoldedReplicator(N, T, dev, src=0)
+                        sl, wk = rp.send(x_unf if rank == 0 else None, rank, async_op=True)
+                        xfold = rp.receive(sl, rank, wk).clone()
+                    xin = xfold if kw.get("prefolded") else x_unf
+                    y2 = torch.empty((F, 1, 1, sp2.out_count), dtype=xc.dtype, device=dev)
+                    for _ in range(max(1, args.warmup)):
+                        sp2.gather(sp2.plan.execute_into(xin, y2, F))
+                    torch.cuda.synchronize(); dist.barrier()
+                    t2 = time.perf_counter()
+                    for _ in range(args.steps):
+                        yl = sp2.gather(sp2.plan.execute_into(xin, y2, F))
+                    torch.cuda.synchronize(); dist.barrier()
+                    tl = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
+                    dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+                    err2 = float((torch.view_as_real(yl.reshape(-1)) - torch.view_as_real(yimg.reshape(-1))).abs().max() / torch.view_as_real(yimg).abs().max())
+                    layouts[name] = {"ms_per_step": round(float(tl.item()) / args.steps * 1e3, 3), "timed_region": False, "image_vs_headline": float(f"{err2:.2e}"),
+                                     "slab_columns": None if sp2.col_bounds is None else [int(v) for v in sp2.col_bounds]}
+                    sp2.close()
+                except Exception as ex:
+                    layouts[name] = {"ms_per_step": None, "note": f"failed: {ex!r}"}
         seen = [None] * world
         try:                                            # who is in the process group: rank, local device ordinal, device name, PCI bus id (one tiny object gather)
             props = torch.cuda.get_device_properties(dev)
@@ -533,6 +568,10 @@ def main():
                  "slab_columns": None if splan.col_bounds is None else [int(v) for v in splan.col_bounds],
                  "slab_layout": ("mirror slabs of equal measured cost (rank 0's per-block kernel times, broadcast)" if splan.col_bounds is not None else
                                  "mirror slabs of equal width" if splan.mirror_slabs else "contiguous pixel slabs"),
+                 "layout": this_layout, "layouts": layouts,
+                 "layouts_note": "layout = what the timed region ran; layouts = every slab layout measured in this invocation with the same loop (prefolded: rank 0 folds the frame ONCE "
+                                 "and replicates the packed upper triangle outside the loop -- fold_and_replicate_ms; equal_cost: column ranges of equal measured cost, in whole tiles); one "
+                                 "GPU timing every rank's slab predicted 74 / 93 / 92 % at 8 ranks for the three (profiles/r05/slab_kernel_times_c3.txt): NOT a measured curve",
                  "prefolded_timed_region": prefolded_run, "fold_and_replicate_ms": None if prefold_ms is None else round(prefold_ms, 3),
                  "stream_folded_replication": folded_stream,
                  "stream_ms_per_step_incl_overlapped_replication": round(stream_ms, 3) if isinstance(stream_ms, float) else stream_ms,
@@ -598,6 +637,26 @@ def main():
             stream = {"frames": FS, "ms_per_frame": round(sms, 3), "value": round(I / (sms * 1e-3) / 1e6, 4), "unit": "Mpixel/s",
                       "last_frame_vs_its_single_execute": float(f"{dev_err:.2e}"),
                       "note": "four distinct frames per call of qdas_plan_execute_frames, wall clock around 3 calls; folds (if any) included"}
+            # the same stream through a plan WITHOUT any symmetry mode (no reciprocity fold, no lateral mirror): what an acquisition with a calibrated -- not
+            # bit-symmetric -- probe gets.  Four frames share a launch (tap index and weights once per group): the only sharing the general loop has
+            general_stream = None
+            if (reciprocal_hint := bool(plan.reciprocal) or bool(plan.mirror)):
+                try:
+                    gs = DasPlan(prob, device=dev, kernel=args.kernel, reciprocal=False, mirror=False, jit=args.jit, **slab_kw)
+                    gs.execute_into(xs, ys, FS)
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    for _ in range(2):
+                        gs.execute_into(xs, ys, FS)
+                    torch.cuda.synchronize()
+                    gms = (time.perf_counter() - ts) / 2 / FS * 1e3
+                    yg1 = torch.view_as_real(gs.execute_colmajor(xs[FS - 1], 1).reshape(-1)).float()
+                    general_stream = {"ms_per_frame": round(gms, 3), "frames": FS, "kernel_name": gs.kernel_name(),
+                                      "last_frame_vs_its_single_execute": float(f"{float((torch.view_as_real(ys[FS - 1].reshape(-1)).float() - yg1).abs().max() / yg1.abs().max()):.2e}")}
+                    gs.close()
+                except Exception as ex:
+                    general_stream = {"ms_per_frame": None, "note": f"failed: {ex!r}"}
+            stream["general_stream"] = general_stream
             del xs, ys
         except Exception as ex:
             stream = {"frames": 4, "ms_per_frame": None, "note": f"failed: {ex!r}"}
@@ -737,6 +796,8 @@ def main():
             rec["fold_only_ms_per_step"] = round(fold_only_ms, 3)
         if general_ms is not None:
             rec["general_ms_per_step"] = round(general_ms, 3)
+        if stream and stream.get("general_stream") and stream["general_stream"].get("ms_per_frame") is not None:
+            rec["general_stream_ms_per_frame"] = stream["general_stream"]["ms_per_frame"]      # (no symmetry mode at all, four frames per launch: beside the headline, never `value`)
             rec["general_value"] = round(I / (general_ms * 1e-3) / 1e6, 4)
         if multi:
             rec["multi_gpu"] = multi

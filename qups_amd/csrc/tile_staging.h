@@ -116,8 +116,13 @@ template <class C> __device__ __forceinline__ void Tile<C>::stage_dma(int bn, in
 #pragma unroll
                     for (int q = 0; q < PCS; ++q) {
                         lds_void *dst = (lds_void *)((unsigned char *)win + ((buf * NW + (2 * f + k) * MB + j) * WB + q * PB));
+#ifdef QDAS_DMA_SAME_SRC                               // (measurement builds, profiles/r06/dma_ab_c3.txt: every window from ONE hot source address -- the DMA's issue and LDS-write side without its memory side)
+                        if (l16 < need_b - q * PB)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(f ? rsM : rsD, dst, 16, l16, (j & 1) * PB + q * PB, 0, 0);
+#else
                         if (l16 < need_b - q * PB)
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(f ? rsM : rsD, dst, 16, l16, qo[2 * r + k] + bs + q * PB, 0, 0);
+#endif
                     }
                 }
             }

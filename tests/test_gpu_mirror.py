@@ -569,6 +569,64 @@ def test_symmetry_within_a_tolerance(monkeypatch):
     assert 1e-5 < e6 < 5e-3, e6
 
 
+def test_c3_with_a_calibrated_probe_every_element_10_um_off(monkeypatch, capsys):
+    """BASELINE C3 with a probe whose 256 elements are each displaced by a seeded N(0, 10 um) in x and z -- what element calibration returns.
+    Transmit elements ARE the receive elements, so the acquisition is still reciprocal bit for bit: the plan keeps the reciprocity FOLD (exact) and loses only the
+    lateral-mirror mode -- the frame costs the fold-only time (~21 ms; asserted <= 24 for the slower boxes of the pool), with the tight parity of an exact mode.
+    The mirror mode would commit up to `bound` samples of delay error (reported by the plan: ~0.6 sample for 10 um of element error -- 4.6 sigma over 256 elements,
+    transmit and receive side); FORCING it (QDAS_SYM_TOL above the bound) is measured here to cost 1e-2 .. 1 of the image: the physics is stated, not papered over.
+    The line printed by this test is profiles/r06/perturbed_probe.txt."""
+    import torch
+    from oracle import das_ref
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd.configs import workload
+    w = workload("c3")
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(77)
+    xc = torch.view_as_complex(torch.randn((w["M"], w["N"], w["T"], 2), generator=g, device=dev, dtype=torch.float32))
+    rng = np.random.default_rng(10)
+    Pr = np.asarray(w["Pr"], np.float64).copy()
+    Pr[0] += rng.normal(0.0, 10e-6, Pr.shape[1]); Pr[2] += rng.normal(0.0, 10e-6, Pr.shape[1])
+    Pr = Pr.astype(np.float32)
+    Pv = np.asarray(w["Pv"], np.float32).copy(); Pv[:3] = Pr                      # FSA: the transmit elements are the (calibrated) receive elements
+    opts = parse_options(xc, list(w["opt"]) + ["interp", w["interp"], "input-precision", "single"])
+    prob = build_problem("DAS", w["Pi"], Pr, Pv, w["Nv"], (w["T"], w["N"], w["M"]), w["t0"], w["fs"], w["c0"], opts)
+
+    def run(**kw):
+        plan = DasPlan(prob, jit=True, **kw)
+        plan.set_timing(True)
+        y = plan.execute_colmajor(xc, 1).reshape(-1)
+        y = plan.execute_colmajor(xc, 1).reshape(-1)
+        torch.cuda.synchronize()
+        out = (y.cpu().numpy().reshape(w["I1"], w["I2"], order="F"), plan.last_kernel_ms(), bool(plan.folded), bool(plan.mirror), plan.symmetry_bound(), plan.kernel_name())
+        plan.close()
+        return out
+
+    step = 31
+    xh = xc.cpu().numpy().transpose(2, 1, 0)
+    ref = das_ref.das_spec("DAS", w["Pi"][:, ::step, ::step, :], Pr, Pv, w["Nv"], xh, w["t0"], w["fs"], 1.0 / np.float64(np.float32(1.0 / w["c0"])),
+                           VS=True, DV=True, interp=w["interp"], prec="double")[..., 0, 0]
+    img, ms, folded, mirror, bnd, name = run()
+    assert folded and not mirror and "[jit " in name, name                      # exact modes only: the fold stays, the mirror mode goes
+    e_exact = rel_err(img[::step, ::step, None], ref)
+    assert e_exact <= 5e-5, e_exact
+    assert ms <= 24.0, ms
+    # what the mirror mode would cost: the bound the plan reports, and the image when it is forced
+    _, _, _, mir_a, bnd_a, _ = run(approx_symmetry=True)
+    assert not mir_a                                                            # refused at the default tolerance (1e-5 sample)
+    monkeypatch.setenv("QDAS_SYM_TOL", "0.5")
+    img_f, ms_f, folded_f, mir_f, bnd_f, name_f = run(approx_symmetry=True)
+    line = f"C3, every element N(0, 10 um) off in x and z (seed 10): exact modes -> fold only {ms:.2f} ms, parity {e_exact:.2e} (5e-5 asked); "
+    if mir_f:
+        e_forced = rel_err(img_f[::step, ::step, None], ref)
+        line += f"mirror mode forced at QDAS_SYM_TOL=0.5: bound {bnd_f[0]:.3f} sample, {ms_f:.2f} ms, image error {e_forced:.2e}"
+        assert 0.05 < bnd_f[0] <= 0.5 and e_forced > 1e-3, (bnd_f, e_forced)
+    else:
+        line += f"mirror mode refused even at QDAS_SYM_TOL=0.5: the bound exceeds it ({name_f})"
+    with capsys.disabled():
+        print("\n[perturbed probe] " + line)
+
+
 @pytest.mark.parametrize("prec", ["single", "halfT"])
 def test_prefolded_plans_and_the_fold_entry(prec):
     """``qdas_fold`` + ``QDAS_PLAN_PREFOLDED``: a host that folds once per acquisition (and replicates the FOLDED frame -- half the bytes -- to several

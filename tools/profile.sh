@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="env QDAS_BENCH_CHILD=1 python $REPO/bench.py --steps 2 --warmup 1 --no-cpu --no-traffic --no-general $*"
+BENCH="env QDAS_BENCH_CHILD=1 python $REPO/bench.py --steps 6 --warmup 1 --no-cpu --no-traffic --no-general $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/bench_trace.json 2> $OUT/trace.err
 pass() { # name counters...
   local name=$1; shift

@@ -85,7 +85,7 @@ python tools/issue_rates.py 2>/dev/null | grep -v amdgpu.ids > $OUT/issue_rates.
   tools/abl_sweep.sh 2 "--no-fold" - QDAS_ABL=1 QDAS_ABL=4 QDAS_ABL=8 QDAS_ABL=12 QDAS_ABL=16 QDAS_ABL=2048; } > $OUT/ablation_c3.txt 2>&1
 # ---- PCIe-inclusive: host-resident frames through the C ABI, and the int16 RF -> hilbert -> band-pass -> DAS chain for a stream
 python tools/host_frames.py > $OUT/host_frames.txt 2>/dev/null
-python tools/pipeline_bench.py c3 6 64 > $OUT/pipeline_bench.txt 2>/dev/null; python tools/pipeline_bench.py c2 12 64 >> $OUT/pipeline_bench.txt 2>/dev/null
+python tools/pipeline_bench.py c3 12 64 > $OUT/pipeline_bench.txt 2>/dev/null; python tools/pipeline_bench.py c2 12 64 >> $OUT/pipeline_bench.txt 2>/dev/null
 python tools/c1_chain.py 1000 2>/dev/null | grep -v Warn > $OUT/c1_chain.txt; python tools/c1_chain.py 3 2>/dev/null | grep -v Warn >> $OUT/c1_chain.txt
 # ---- registers: prebuilt library, and the hiprtc builds of this run
 python tools/kernel_regs.py qups_amd/libqdas.so > $OUT/kernel_regs.txt 2>&1
