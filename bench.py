@@ -796,9 +796,9 @@ def main():
             rec["fold_only_ms_per_step"] = round(fold_only_ms, 3)
         if general_ms is not None:
             rec["general_ms_per_step"] = round(general_ms, 3)
+            rec["general_value"] = round(I / (general_ms * 1e-3) / 1e6, 4)
         if stream and stream.get("general_stream") and stream["general_stream"].get("ms_per_frame") is not None:
             rec["general_stream_ms_per_frame"] = stream["general_stream"]["ms_per_frame"]      # (no symmetry mode at all, four frames per launch: beside the headline, never `value`)
-            rec["general_value"] = round(I / (general_ms * 1e-3) / 1e6, 4)
         if multi:
             rec["multi_gpu"] = multi
         if world == 1 and not args.no_cpu:
