@@ -573,8 +573,8 @@ def test_c3_with_a_calibrated_probe_every_element_10_um_off(monkeypatch, capsys)
     """BASELINE C3 with a probe whose 256 elements are each displaced by a seeded N(0, 10 um) in x and z -- what element calibration returns.
     Transmit elements ARE the receive elements, so the acquisition is still reciprocal bit for bit: the plan keeps the reciprocity FOLD (exact) and loses only the
     lateral-mirror mode -- the frame costs the fold-only time (~21 ms; asserted <= 24 for the slower boxes of the pool), with the tight parity of an exact mode.
-    The mirror mode would commit up to `bound` samples of delay error (reported by the plan: ~0.6 sample for 10 um of element error -- 4.6 sigma over 256 elements,
-    transmit and receive side); FORCING it (QDAS_SYM_TOL above the bound) is measured here to cost 1e-2 .. 1 of the image: the physics is stated, not papered over.
+    The mirror mode would commit up to `bound` samples of delay error (10 um is 0.13 sample per element and side; the bound over 256 elements and both sides exceeds the
+    largest tolerance the library accepts, QDAS_SYM_TOL <= 0.5 sample: the mode is refused even when forced -- measured in round 6; had it been admitted, the image error is checked).
     The line printed by this test is profiles/r06/perturbed_probe.txt."""
     import torch
     from oracle import das_ref

@@ -5,11 +5,12 @@
 # headline and the other BASELINE configurations, and the register tables of the prebuilt kernels AND of the hiprtc builds the
 # benches ran (their code objects are in this run's private cache directory).
 set -u
-R=${1:-r05}
+R=${1:-r06}
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/profiles_$R
 mkdir -p $OUT
 export QDAS_CACHE_DIR=$OUT/jit_cache
+export QDAS_JIT_SPEC_LOG=$OUT/jit_specs.txt      # every hiprtc build of this run as a complete spec: sort -u into tests/jit_kernels.txt (rebuilt without a device by tests/test_jit.py)
 cd $REPO
 b() { # name args...
   local name=$1; shift
@@ -37,6 +38,9 @@ b c3_window --window-apod $Q --steps 10
 b c3_fnumber1.5 --rx-apod fnumber:1.5 --no-cpu --no-general --steps 10
 b c3_fp16_fnumber1.5 --prec halfT --rx-apod fnumber:1.5 $Q --steps 10
 QDAS_NO_MIRROR=1 b c5_no_mirror --workload c5 $Q --steps 50
+b c5_single --workload c5 --prec single $Q --steps 50
+QDAS_NO_STAGE_SHAPE=1 b c5_r05_shape --workload c5 $Q --steps 50
+b c2_fp16 --workload c2 --prec halfT $Q --steps 50
 b c2_double --workload c2 --prec double $Q --steps 10
 b c2_double_fmod --workload c2 --prec double --fmod 5e6 $Q --steps 10
 b c2_window --workload c2 --window-apod $Q --steps 20
@@ -76,6 +80,9 @@ rm -rf $OUT/trace_general
 # ---- one rank's slab on one GPU (NOT a scaling curve), the issue-cost microbenchmark, the ablation of the headline kernel
 python tools/slab_scaling.py c3 2>/dev/null | grep -v amdgpu.ids > $OUT/slab_kernel_times_c3.txt
 python tools/issue_rates.py 2>/dev/null | grep -v amdgpu.ids > $OUT/issue_rates.txt
+mkdir -p tools/scratch && /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/microbench_src/f16mix.hip -o tools/scratch/f16mix 2>/dev/null && tools/scratch/f16mix > $OUT/f16mix.txt 2>&1
+bash tools/dma_ab.sh 2 > $OUT/dma_ab_c3_raw.txt 2>&1
+{ echo '# tools/abl_sweep.sh 2 "--workload c5": hiprtc builds of BASELINE C5 with QDAS_ABL bits (1 no LDS-DMA, 16 no barrier, 2048 no priority staircase), kernel ms'; tools/abl_sweep.sh 2 "--workload c5" - QDAS_ABL=1 QDAS_ABL=16 QDAS_ABL=17 QDAS_ABL=2048; } > $OUT/ablation_c5_raw.txt 2>&1
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/microbench_src/issue.hip -o /tmp/qdas_issue 2>/dev/null && /tmp/qdas_issue > $OUT/issue_costs.txt 2>&1
 { echo "# tools/abl_sweep.sh: hiprtc builds with QDAS_JIT_DEFINES=QDAS_ABL=<bits> (tile_hooks.h), interleaved rounds, kernel ms (fold pass included).  Bits: 1 no LDS-DMA, 4 taps from registers,";
   echo "# 8 trivial weights, 16 no end-of-stage wait / barrier, 256 plain instead of software-pipelined pair loop, 1024 no late DMA, 2048 no priority staircase.";
@@ -90,6 +97,7 @@ python tools/c1_chain.py 1000 2>/dev/null | grep -v Warn > $OUT/c1_chain.txt; py
 # ---- registers: prebuilt library, and the hiprtc builds of this run
 python tools/kernel_regs.py qups_amd/libqdas.so > $OUT/kernel_regs.txt 2>&1
 python tools/kernel_regs.py $QDAS_CACHE_DIR > $OUT/kernel_regs_hiprtc.txt 2>&1
+sort -u $OUT/jit_specs.txt > $OUT/jit_kernels.txt 2>/dev/null
 python - <<PY > $OUT/summary.txt
 import glob, json, os
 for f in sorted(glob.glob("$OUT/bench_*.json")):
