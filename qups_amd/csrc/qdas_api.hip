@@ -953,9 +953,10 @@ static int plan_stage_shape(qdas_plan *pl, const qdas_desc *desc, PlanBuild &b) 
     TileParams &t = pl->tp;
     const bool jit_on = (desc->plan_flags & QDAS_PLAN_JIT) && !b.sw.no_jit;
     const bool f16 = z.dtype == QDAS_F16;
-    // (fp32 frames with a pixel x receiver weight keep their 16-transmit stages: the weighted totals leave no register for 16 more residual pairs; fp16 taps are half the registers.
+    // (fp32 frames with a pixel x receiver weight took this shape in round 6 as well: one accumulator per pixel -- TileCfg::ONEACC -- made room for the weighted totals, and a build
+    //  that still needs scratch is rebuilt with the plain pair loop, jit_get_kernel_nospill: C3 with a generated f/1.5 mask 13.3 -> see profiles/r06.
     //  fp16 data: the two-window-set plans only -- one set of 64 transmits measured SLOWER on BASELINE C5 without the mirror mode, 2.37 -> 2.80 ms: M = 96 is 1.5 such blocks)
-    if (!(jit_on && (z.dtype == QDAS_F32 || f16) && !t.big && !t.bf && !t.syn && (f16 || (!t.apix && !t.gen_kind)) && !t.bpix && t.narrow == 0 && !t.stage_shift && !t.cinv_pix
+    if (!(jit_on && (z.dtype == QDAS_F32 || f16) && !t.big && !t.bf && !t.syn && !t.bpix && t.narrow == 0 && !t.stage_shift && !t.cinv_pix
           && !(f16 && (t.sym || !t.mir)) && pl->no_fallback && !getenv("QDAS_NO_STAGE_SHAPE") && !getenv("QDAS_JIT_MB") && !getenv("QDAS_JIT_W"))) return QDAS_OK;
     int mb = 0, sets = 1;
     if (t.mir && !t.sym) { mb = 32; sets = 2; }                          // two window sets: a pixel and its mirror image

@@ -19,13 +19,15 @@
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define R8(S) S S S S S S S S
 
-enum { PKFMA32, FMA32, FMAMIX, PKFMA16, DOT2, DOT2C, CVT_F32_F16, CVT_PKRTZ, PKMUL16, L0, L1, L2, L3, L4, L5, NMODES };
+enum { PKFMA32, FMA32, FMAMIX, PKFMA16, DOT2, DOT2C, CVT_F32_F16, CVT_PKRTZ, PKMUL16, L0, L1, L2, L3, L4, L5, L6, L7, NMODES };
 static const char *NAMES[NMODES] = {"v_pk_fma_f32 (broadcast operand)", "v_fma_f32", "v_fma_mix_f32 (fp16 tap x fp32 weight + fp32)", "v_pk_fma_f16 (broadcast operand)",
                                     "v_dot2_f32_f16", "v_dot2c_f32_f16", "v_cvt_f32_f16", "v_cvt_pkrtz_f16_f32", "v_pk_mul_f16",
                                     "L0 loop: fp16 as shipped (32 v_fma_mix_f32, 16 ds_read_b32)", "L1 loop: fp32 data (16 v_pk_fma_f32, 16 ds_read_b64)",
                                     "L2 loop: pair-planar fp16 (16 v_dot2_f32_f16, 8 ds_read_b64, 4 cvt_pkrtz)", "L3 loop: pair-planar fp16 with v_dot2c_f32_f16",
-                                    "L4 loop: fp16 partial sums (16 v_pk_*_f16 + 8 widening v_fma_mix, 16 ds_read_b32)", "L5 loop: convert in registers (32 v_cvt + 16 v_pk_fma_f32, 16 ds_read_b32)"};
-static const int PER_ITER[NMODES] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 1, 1, 1, 1, 1, 1};
+                                    "L4 loop: fp16 partial sums (16 v_pk_*_f16 + 8 widening v_fma_mix, 16 ds_read_b32)", "L5 loop: convert in registers (32 v_cvt + 16 v_pk_fma_f32, 16 ds_read_b32)",
+                                    "L6 loop: fp32 data, taps two at a time (8 ds_read2_b64 + 4 v_add_u32 for the window addresses, 16 v_pk_fma_f32)",
+                                    "L7 loop: fp32 data, C3 headline pattern (8 x 8 pixel waves, lanczos-sized weights: 16 weight FMAs), 16 ds_read_b64 -- reference for L6"};
+static const int PER_ITER[NMODES] = {64, 64, 64, 64, 64, 64, 64, 64, 64, 1, 1, 1, 1, 1, 1, 1, 1};
 
 template <int MODE>
 __global__ void __launch_bounds__(1024) probe(float *sink, int rep, float seed, v2f coef) {
@@ -86,7 +88,7 @@ __global__ void __launch_bounds__(1024) probe(float *sink, int rep, float seed, 
         } else {
             // one transmit pair: index (5) + cubic weights (10 packed FMAs with SGPR-pair coefficients) as the shipped loop, then the form's gathers and MACs
             // gather pattern of C5's waves (4 pixels of depth x 16 angles, ~5.6 samples per pixel of depth), SB bytes per sample
-            constexpr uint32_t SB = (MODE == L0 || MODE == L4 || MODE == L5) ? 4u : 8u;
+            constexpr uint32_t SB = (MODE == L0 || MODE == L4 || MODE == L5) ? 4u : 8u;      // (L6 / L7 form their own address below)
             const uint32_t ad = (((uint32_t)(lane & 3) * 6u + (uint32_t)(lane >> 2) * 1u + (uint32_t)wave * 24u + (uint32_t)(i & 15) * 4u) * SB) + (u0 & 0u);
             asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %0, %0, %1\n v_lshl_add_u32 %2, %2, 3, %3\n v_lshl_add_u32 %3, %3, 3, %2\n"
                          : "+v"(a0), "+v"(a1), "+v"(u0), "+v"(u1) : "v"(m2.x));
@@ -136,6 +138,31 @@ __global__ void __launch_bounds__(1024) probe(float *sink, int rep, float seed, 
                         asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(f), "v"(p4));
                     }
                 }
+            } else if constexpr (MODE == L6 || MODE == L7) {      // the C3 headline's gather pattern: 8 x 8 pixels per wave, 2 samples per pixel of depth, ~3 per column
+                const uint32_t adh = (((uint32_t)(lane & 7) * 2u + (uint32_t)(lane >> 3) * 3u + (uint32_t)wave * 64u + (uint32_t)(i & 15) * 4u) * 8u) + (u0 & 0u);
+                v2f t[16];
+                if constexpr (MODE == L7) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t[q]) : "v"(adh), "n"((q >> 2) * 2048 + (q & 3) * 8));
+                } else {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    v4f tt[8];
+                    uint32_t wa[4];
+#pragma unroll
+                    for (int wq = 0; wq < 4; ++wq) asm volatile("v_add_u32 %0, %1, %2" : "=v"(wa[wq]) : "v"(adh), "v"((uint32_t)(wq * 2048) + (u1 & 0u)));
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(tt[q]) : "v"(wa[q >> 1]), "n"((q & 1) * 2), "n"((q & 1) * 2 + 1));
+                    asm volatile(R8("v_pk_fma_f32 %0, %0, %2, %1\n v_pk_fma_f32 %1, %1, %2, %0\n") : "+v"(p4), "+v"(p5) : "s"(coef));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tt[0]), "+v"(tt[1]), "+v"(tt[2]), "+v"(tt[3]), "+v"(tt[4]), "+v"(tt[5]), "+v"(tt[6]), "+v"(tt[7]) :: "memory");
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { t[2 * q] = (v2f){tt[q].x, tt[q].y}; t[2 * q + 1] = (v2f){tt[q].z, tt[q].w}; }
+                }
+                if constexpr (MODE == L7) {
+                    asm volatile(R8("v_pk_fma_f32 %0, %0, %2, %1\n v_pk_fma_f32 %1, %1, %2, %0\n") : "+v"(p4), "+v"(p5) : "s"(coef));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { v2f &acc = (q & 4) ? p1 : p0; asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(t[q]), "v"(p4)); }
             } else if constexpr (MODE == L1) {
                 v2f t[16];
 #pragma unroll
@@ -203,7 +230,7 @@ int main() {
     double v[NMODES][3];
     for (int r = 0; r < 3; ++r) {
 #define RUN(M) v[M][r] = run<M>(cus, sink);
-        RUN(PKFMA32) RUN(FMA32) RUN(FMAMIX) RUN(PKFMA16) RUN(DOT2) RUN(DOT2C) RUN(CVT_F32_F16) RUN(CVT_PKRTZ) RUN(PKMUL16) RUN(L0) RUN(L1) RUN(L2) RUN(L3) RUN(L4) RUN(L5)
+        RUN(PKFMA32) RUN(FMA32) RUN(FMAMIX) RUN(PKFMA16) RUN(DOT2) RUN(DOT2C) RUN(CVT_F32_F16) RUN(CVT_PKRTZ) RUN(PKMUL16) RUN(L0) RUN(L1) RUN(L2) RUN(L3) RUN(L4) RUN(L5) RUN(L6) RUN(L7)
 #undef RUN
     }
     for (int m = 0; m < NMODES; ++m) printf(" %8.3f %8.3f %8.3f   %s: %s\n", v[m][0], v[m][1], v[m][2], m >= L0 ? "ns per transmit pair (4 products)" : "ns per wave64 instruction", NAMES[m]);
