@@ -19,6 +19,7 @@
 #include "qdas_device.h"
 #include "qdas_kernels.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace qdas {
 
@@ -279,6 +280,7 @@ hipError_t launch_shift_sum(const ShiftParams &P, int dtype, int cplx, int inter
             const uint64_t tpb = 256ull * tpt, cov = (P.To + tpb - 1) / tpb * tpb - P.To;
             if (cov * 8 < waste * 8 && (waste == ~0ull || (waste - cov) * 16 > P.To)) { waste = cov; best = tpt; }   // a smaller block only if it saves > 6 % of the outputs
         }
+        if (const char *e = getenv("QDAS_SS_TPT")) { const int v = atoi(e); if (v >= 2 && v <= 4) best = v; }      // (experiments)
         if (cplx) return best == 4 ? launch_shift_t<float2, float, 4>(P, interp, sh, w, w_real, s) : best == 3 ? launch_shift_t<float2, float, 3>(P, interp, sh, w, w_real, s)
                                                                                                                  : launch_shift_t<float2, float, 2>(P, interp, sh, w, w_real, s);
         return best == 4 ? launch_shift_t<float, float, 4>(P, interp, sh, w, w_real, s) : best == 3 ? launch_shift_t<float, float, 3>(P, interp, sh, w, w_real, s)

@@ -161,8 +161,9 @@ def test_das_lut_full_sum_runs_the_fused_kernel(interp, seq, tpose, wtab, fm, mo
     assert np.all(a[np.abs(ref) == 0] == 0)
 
 
-@pytest.mark.parametrize("interp,seq,fm", [("cubic", "PW", 0.0), ("lanczos3", "FSA", 0.0), ("linear", "PW", 1.5e6), ("cubic", "DV", 0.0)])
-def test_das_lut_mirror_symmetric_tables_take_the_mirror_mode(interp, seq, fm, monkeypatch):
+@pytest.mark.parametrize("interp,seq,fm,I2,M", [("cubic", "PW", 0.0, 40, 32), ("lanczos3", "FSA", 0.0, 40, 32), ("linear", "PW", 1.5e6, 40, 32), ("cubic", "DV", 0.0, 40, 32),
+                                                 ("cubic", "PW", 0.0, 41, 32), ("cubic", "PW", 0.0, 40, 8)], ids=["pw", "fsa-lanczos", "pw-fmod", "dv", "odd-columns", "few-transmits-roles-swapped"])
+def test_das_lut_mirror_symmetric_tables_take_the_mirror_mode(interp, seq, fm, I2, M, monkeypatch):
     """delay tables that are their own lateral mirror images (a centred scan, a symmetric probe and sequence: what bfDASLUT builds for the BASELINE
     configurations) run the two-window-set build -- a pixel and its image share tap index and weights, as geometry-driven plans do -- and agree with the oracle and
     with the general table-driven kernel (QDAS_LUT_NO_MIRROR=1).  The symmetry is checked PER CALL, bit for bit: ONE table entry one ulp off must NOT take the mode
@@ -170,7 +171,7 @@ def test_das_lut_mirror_symmetric_tables_take_the_mirror_mode(interp, seq, fm, m
     import torch
     from oracle import das_oracle as O
     from qups_amd import das_lut
-    case = make_case(seq=seq, interp=interp, seed=29, N=32, M=32, I1=140, I2=40, data="noise")
+    case = make_case(seq=seq, interp=interp, seed=29, N=32, M=M, I1=140, I2=I2, data="noise")
     N, M = case["N"], case["M"]
     dv, dr = O.tx_rx_distances(case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["VS"], case["DV"])
     c = cinv_f32(case["c"])
@@ -181,10 +182,13 @@ def test_das_lut_mirror_symmetric_tables_take_the_mirror_mode(interp, seq, fm, m
     h = tau_rx.shape[1] // 2
     tau_rx[:, -h:, :] = tau_rx[:, :h, :][:, ::-1, ::-1]
     tau_tx[:, -h:, :] = tau_tx[:, :h, :][:, ::-1, ::-1]
+    if I2 % 2:                                                # the centre column is its own image: its rows must be symmetric in the element index
+        tau_rx[:, h, :] = 0.5 * (tau_rx[:, h, :] + tau_rx[:, h, ::-1])
+        tau_tx[:, h, :] = 0.5 * (tau_tx[:, h, :] + tau_tx[:, h, ::-1])
     omega = 2 * np.pi * fm / case["fs"]
     x = case["x"]
-    ref = np.asarray(O.das_lut(x, tau_rx.astype(np.float64)[:, :, None] / case["fs"], tau_tx.astype(np.float64)[:, :, None] / case["fs"], 0.0, case["fs"], interp=interp, fmod=fm)).reshape(140, 40)
-    run = lambda trx, ttx: _np(das_lut(torch.from_numpy(x), trx, ttx, interp=interp, omega=omega, prec="single")).reshape(140, 40)
+    ref = np.asarray(O.das_lut(x, tau_rx.astype(np.float64)[:, :, None] / case["fs"], tau_tx.astype(np.float64)[:, :, None] / case["fs"], 0.0, case["fs"], interp=interp, fmod=fm)).reshape(140, I2)
+    run = lambda trx, ttx: _np(das_lut(torch.from_numpy(x), trx, ttx, interp=interp, omega=omega, prec="single")).reshape(140, I2)
     monkeypatch.delenv("QDAS_LUT_NO_MIRROR", raising=False)
     a = run(tau_rx, tau_tx)
     if "mirror" not in das_lut.last_kernel:                   # (no hiprtc on this box: the mode exists as a specialised build only)
@@ -203,7 +207,7 @@ def test_das_lut_mirror_symmetric_tables_take_the_mirror_mode(interp, seq, fm, m
     assert das_lut.last_kernel == "tiled"
     assert rel_err(c2, b) <= 1e-5
     t3 = tau_tx.copy()
-    t3[100, 39, M - 1] = np.nextafter(t3[100, 39, M - 1], np.float32(-np.inf))
+    t3[100, I2 - 1, M - 1] = np.nextafter(t3[100, I2 - 1, M - 1], np.float32(-np.inf))
     run(tau_rx, t3)
     assert das_lut.last_kernel == "tiled"
 

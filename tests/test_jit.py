@@ -194,6 +194,54 @@ def test_jit_stage_shapes_of_plans_whose_tiles_fit_128_sample_windows(mode, tmp_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["single", "halfT"])
+@pytest.mark.parametrize("weights", ["array", "generated"])
+def test_jit_long_stages_with_a_pixel_by_receiver_weight(prec, weights, tmp_path, monkeypatch):
+    """round 6: lateral-mirror plans WITH a pixel x receiver weight take the long-stage shape as well -- fp16 data 32 transmits x 2 sets x 256 samples, fp32 data
+    32 x 2 x 128 (one accumulator per pixel made the room for the weighted totals) -- when every tile fits the one-KiB windows.  Against the float64 oracle fed the
+    materialised mask, and against the shape of round 5 (QDAS_NO_STAGE_SHAPE=1: another stage partition, fp32 re-association only); no build may use scratch."""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd import apodization as A
+    monkeypatch.setenv("QDAS_CACHE_DIR", str(tmp_path))
+    N = 64
+    case = make_case(seq="FSA", interp="cubic", seed=8, N=N, I1=128, I2=64, pitch=0.2e-3, zlim=(20e-3, 24e-3), xspan=4e-3)
+    nrm = np.tile(np.array([[0.0], [0.0], [1.0]]), (1, N))
+    mask = A.ap_acceptance_angle(case["Pi"], case["Pr"], nrm, 8.0).astype(np.float32)          # (I1 x I2 x 1 x N: a band of receivers per pixel)
+    assert 0.1 < float((mask != 0).mean()) < 0.9
+    x = torch.from_numpy(case["x"])
+    extra = ["apod", mask] if weights == "array" else ["rx-apod", A.rx_apod_spec("acceptance", normals=nrm, theta=8.0)]
+    opts = parse_options(x, list(case["opt"]) + ["interp", "cubic", "input-precision", prec] + extra)
+    T = case["x"].shape[0]
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], (T, N, N), case["t0"], case["fs"], case["c"], opts)
+    want = ",mirror,mb=32,W=256>" if prec == "halfT" else ",mirror,mb=32,W=128>"
+    ys, names = [], []
+    for shape_off in (False, True):
+        if shape_off:
+            monkeypatch.setenv("QDAS_NO_STAGE_SHAPE", "1")
+        with DasPlan(prob, kernel=2, jit=True, reciprocal=False) as plan:
+            ys.append(plan.feval(x).to(torch.complex64).cpu().numpy())
+            names.append(plan.kernel_name())
+            assert plan.fallback_tiles() == 0 and plan.mirror
+    assert want in names[0] and "[jit " in names[0], names
+    assert want not in names[1], names
+    xo = case["x"] if prec == "single" else case["x"].astype(np.complex64).view(np.float32).astype(np.float16).astype(np.float32).view(np.complex64)
+    mo = mask if prec == "single" else mask.astype(np.float16).astype(np.float32)
+    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], xo, case["t0"], case["fs"], cinv_f32(case["c"]),
+                     VS=case["VS"], DV=case["DV"], interp="cubic", apod=(mo.astype(np.float64).reshape(128, 64, 1, N, 1),)).reshape(-1, order="F")
+    tol = 2e-3 if prec == "halfT" else 3e-5
+    assert rel_err(ys[0].reshape(-1), ref) <= tol, (names[0], rel_err(ys[0].reshape(-1), ref))
+    assert rel_err(ys[1].reshape(-1), ref) <= tol, names[1]
+    assert rel_err(ys[0], ys[1]) <= (1e-3 if prec == "halfT" else 5e-6), names
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_regs
+    rows = [r for fn in os.listdir(tmp_path) if fn.endswith(".hsaco") for r in kernel_regs.kernel_table(str(tmp_path / fn))]
+    built = [r for r in rows if ("mb32_w256" in r["name"] or "mb32_w128" in r["name"])]
+    assert built and any(r["vgpr_spill"] == 0 and r["scratch"] == 0 for r in built), rows       # (the kernel that ran: a first, spilling attempt may sit beside its plain-loop rebuild)
+
+
+@pytest.mark.gpu
 def test_jit_modes_syn_mul_and_pixel_weights(tmp_path, monkeypatch):
     """the specialised kernel also serves kept dimensions (planes) and a pixel x receiver apodization"""
     import torch
