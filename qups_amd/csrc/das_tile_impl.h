@@ -247,7 +247,7 @@ template <class C> struct Tile {
     __device__ __forceinline__ void stage_dma(int bn, int buf);
 
     // pair loops (tile_pairs.h)
-    template <bool CHECK, bool TAILV, bool WZ = true> __device__ __forceinline__ void pairs_plain(uint32_t n, uint32_t m0, int bn, float rb, uint32_t cbase, float phB, uint32_t wbase, uint32_t wmask, uint32_t xmask);
+    template <bool CHECK, bool TAILV, bool WZ = true> __device__ __forceinline__ void pairs_plain(uint32_t n, uint32_t m0, int bn, float rb, uint32_t cbase, float phB, uint32_t wbase, uint64_t wmask, uint64_t xmask);
     __device__ __forceinline__ void pairs_pipelined(float rb, uint32_t cbase);
     template <bool CHECK, bool TAILV> __device__ __forceinline__ void pairs_f64(uint32_t n, uint32_t m0, int bn, double rb, uint32_t cbase);
     __device__ __forceinline__ void frame_sums(v2f (&Sf)[4]) const {
@@ -646,10 +646,12 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
             if (wave == 0 || (C::SYM && wave == 1)) {
                 const uint32_t ln = lane_now();
                 const bool nz = ln < (uint32_t)C::MB && !(wnx.x == 0.f && wnx.y == 0.f);
-                const uint32_t mask = (uint32_t)__ballot(nz);
+                // (64-bit masks: the long-stage one-set builds stage 64 transmits -- round 5 kept 32 bits here, and a zero weight among the first 32 of such a stage
+                //  sent the zero tests of transmits 32..63 to shifted-out bits: found by the fuzz soak of round 6, seed 50160)
+                const uint64_t mask = __ballot(nz);
                 unsigned char *q = wst + (uint32_t)b * WBUF + (wave ? C::MB * 8 : 0);
                 if (ln < (uint32_t)C::MB) ((float2 *)q)[ln] = wnx;
-                if (ln == 0) ((uint32_t *)(wst + (uint32_t)b * WBUF + 2 * C::MB * 8))[wave ? 1 : 0] = mask;
+                if (ln == 0) ((uint64_t *)(wst + (uint32_t)b * WBUF + 2 * C::MB * 8))[wave ? 1 : 0] = mask;
             }
         }
     };
@@ -677,11 +679,11 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
             phB = Bext[n];
             if constexpr (C::MIRQ) phB = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(phB)));   // (uniform: a scalar register -- the one vector register the four window sets are short of)
         }
-        uint32_t wmask = 0xffffffffu, xmask = 0xffffffffu;       // which of this stage's table entries are non-zero (zero weights are skipped, src/bf.cu:122,126)
+        uint64_t wmask = ~0ull, xmask = ~0ull;                   // which of this stage's table entries are non-zero (zero weights are skipped, src/bf.cu:122,126)
         if constexpr (C::WST) {
-            const uint2 mk = *(const uint2 *)(wst + (uint32_t)buf * WBUF + 2 * C::MB * 8);
-            wmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)mk.x);
-            if constexpr (C::SYM) xmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)mk.y);
+            const uint4 mk = *(const uint4 *)(wst + (uint32_t)buf * WBUF + 2 * C::MB * 8);
+            wmask = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)mk.x) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)mk.y) << 32);
+            if constexpr (C::SYM) xmask = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)mk.z) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)mk.w) << 32);
         }
         // The next stage's staging is issued at the start of this stage by the younger half of the waves and AFTER the pair
         // loop by the older half: the hardware favours older waves, they finish their pair loop early and would only wait at
@@ -765,7 +767,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
                     pairs_pipelined(rb, cbase);
                 else
                 {
-                    constexpr uint32_t FULL = C::MB >= 32 ? 0xffffffffu : ((1u << (C::MB & 31)) - 1u);
+                    constexpr uint64_t FULL = C::MB >= 64 ? ~0ull : ((1ull << (C::MB & 63)) - 1ull);
                     bool done = false;
                     if constexpr (C::WST) {
                         if (wmask == FULL && (!C::SYM || xmask == FULL)) {          // no zero weight in this stage: the loop without zero tests

@@ -21,13 +21,13 @@ namespace qdas {
 // CHECK: the tile touches the ends of the record: edge rule per sample (all taps in [0,T) and tau >= 0; select, not multiply).
 // WZ: some table weight of the stage is zero (stage weights from LDS; else: no zero tests at all in the loop).
 template <class C> template <bool CHECK, bool TAILV, bool WZ>
-__device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, int bn, float rb, uint32_t cbase, float phB, uint32_t wbase, uint32_t wmask, uint32_t xmask) {
+__device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, int bn, float rb, uint32_t cbase, float phB, uint32_t wbase, uint64_t wmask, uint64_t xmask) {
     constexpr int K = C::K, MB = C::MB, WB = C::WB, INTERP = C::INTERP, NHP = C::NHP;
     constexpr bool SYM = C::SYM, FB4 = C::QUAD, FBX = C::FBX, TWO = C::TWO, F32 = C::F32, FMOD = C::FMOD, WTAB = C::WTAB, BF = C::BF;     // (FB4 here: four window sets, two passes)
     // (folded data: any N == M -- the last transmit block may be partial AND holds the diagonal: both rules at once)
     constexpr bool TAIL = (!SYM || C::FOLD) && TAILV, DIAG = SYM && TAILV;
     // (stage weights: does any transmit pair of this stage hold exactly one zero weight?)
-    const bool wmixed = C::WST && WZ && ((((wmask ^ (wmask >> 1)) & 0x55555555u) != 0u) || (SYM && C::WTAB && (((xmask ^ (xmask >> 1)) & 0x55555555u) != 0u)));
+    const bool wmixed = C::WST && WZ && ((((wmask ^ (wmask >> 1)) & 0x5555555555555555ull) != 0ull) || (SYM && C::WTAB && (((xmask ^ (xmask >> 1)) & 0x5555555555555555ull) != 0ull)));
     unroll<MB / 2>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
         // Fair progress inside a stage: the hardware issues oldest-wave-first, so without help the four waves of a SIMD finish their
@@ -47,7 +47,7 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
         v4f wv = {1.f, 0.f, 1.f, 0.f}, xv = {1.f, 0.f, 1.f, 0.f};    // stage weights from LDS: {w[n,m], w[n,m+1]} and, reciprocal mode, {w[m,n], w[m+1,n]}
         if constexpr (C::WST) {
             // zero weights: skipped (src/bf.cu:122,126) -- the stage's non-zero masks are uniform, the tests scalar
-            if constexpr (WZ) { if (((wmask >> (2 * p)) & 3u) == 0u && (!SW || ((xmask >> (2 * p)) & 3u) == 0u)) return; }
+            if constexpr (WZ) { if (((wmask >> (2 * p)) & 3ull) == 0ull && (!SW || ((xmask >> (2 * p)) & 3ull) == 0ull)) return; }
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(wv) : "v"(wbase), "n"(2 * p * 8));
             if constexpr (SW) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(xv) : "v"(wbase), "n"(MB * 8 + 2 * p * 8));
         } else if constexpr (WTAB) {
@@ -224,9 +224,9 @@ __device__ __forceinline__ void Tile<C>::pairs_plain(uint32_t n, uint32_t m0, in
                 if constexpr (C::WST && WZ) {         // a zero weight never samples its trace (non-finite data stay out): uniform, scalar tests --
                   if (wmixed) {                       // and only in stages where a zero shares a transmit pair with a non-zero weight
                     const v2f z = {0.f, 0.f};
-                    if (!((wmask >> (2 * p)) & 1u)) { v0 = z; if constexpr (FBX) u0 = z; }
-                    if (!((wmask >> (2 * p + 1)) & 1u)) { v1 = z; if constexpr (FBX) u1 = z; }
-                    if constexpr (SW) { if (!((xmask >> (2 * p)) & 1u)) { u0 = z; } if (!((xmask >> (2 * p + 1)) & 1u)) { u1 = z; } }
+                    if (!((wmask >> (2 * p)) & 1ull)) { v0 = z; if constexpr (FBX) u0 = z; }
+                    if (!((wmask >> (2 * p + 1)) & 1ull)) { v1 = z; if constexpr (FBX) u1 = z; }
+                    if constexpr (SW) { if (!((xmask >> (2 * p)) & 1ull)) { u0 = z; } if (!((xmask >> (2 * p + 1)) & 1ull)) { u1 = z; } }
                   }
                 }
                 wgt_acc(A0, v0, wr0, wi0); wgt_acc(A1, v1, wr1, wi1);             // complex weight folded into the accumulation

@@ -24,6 +24,9 @@ def pytest_collection_finish(session):
     ~2 s each, inside the first plan that needs them.  A stale list only means that a variant is built on demand after all."""
     if os.environ.get("QDAS_NO_WARM") or not any(item.get_closest_marker("gpu") for item in session.items):
         return
+    xw = os.environ.get("PYTEST_XDIST_WORKER")               # pytest -n K (the soak runs): every worker collects; one of them warms the shared variant cache,
+    if xw and xw != "gw0":                                   # the others start at once (K copies of the warm-up were ~9 minutes of a 12-worker soak in round 6)
+        return
     try:
         import torch
         if not torch.cuda.is_available():
@@ -43,7 +46,7 @@ def pytest_collection_finish(session):
         # a quarter of round 5's suite time) go into a read-only warm directory the same way (csrc/jit.hip QDAS_JIT_WARM_DIR: a hit is copied into the cache directory
         # the test watches, as if it had been built there)
         jl = os.path.join(ROOT, "tests", "suite_jit_kernels.txt")
-        if os.path.exists(jl) and not os.environ.get("QDAS_NO_JIT_WARM"):
+        if os.path.exists(jl) and not os.environ.get("QDAS_NO_JIT_WARM") and not xw:      # (the warm directory is per process: not under xdist)
             import tempfile
             t = time.perf_counter()
             wd = tempfile.mkdtemp(prefix="qdas_jit_warm_")

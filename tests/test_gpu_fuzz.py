@@ -72,7 +72,13 @@ ESCAPE_RATE_MAX = 0.05          # of the seeds that ran; rounds 1-3 saw well und
 _SEED0 = int(os.environ.get("QDAS_FUZZ_OFFSET", "0"))          # soak runs: QDAS_FUZZ_OFFSET=2000 QDAS_FUZZ_SEEDS=2000 pytest -n 8 ...
 
 
-@pytest.mark.parametrize("seed", range(_SEED0, _SEED0 + int(os.environ.get("QDAS_FUZZ_SEEDS", "128"))))
+# Seeds that found a bug once, run with every suite whatever the offset.  50160 (round 6): 64-transmit stages of a one-set hiprtc build with a
+# transmit weight table holding a zero and a split aperture -- the stage's non-zero masks were 32 bits wide and the image came out all zero.
+_PINNED = [50160]
+_SEEDS = list(range(_SEED0, _SEED0 + int(os.environ.get("QDAS_FUZZ_SEEDS", "128"))))
+
+
+@pytest.mark.parametrize("seed", _SEEDS + [s for s in _PINNED if s not in _SEEDS])
 def test_tiled_kernel_random_configuration(seed, monkeypatch):
     import torch
     from qups_amd import DasPlan, build_problem, parse_options
@@ -214,7 +220,7 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
             # (focused waves: the delay changes sign with (Pi - Pv).Nv, src/bf.cu:107 -- at the focal depth the fp32 geometry of the kernels and the
             #  float64 oracle may disagree on the sign of a dot product that is ~0: a row of pixels, visible pair by pair in 'BF')
             lim = max(2, e.size // 500) if c["seq"] != "FC" else max(4, e.size // 150)
-            assert bad.size <= lim, (seed, c, f, plan.tile_shape(), plan.wave_shape(), plan.aperture_split(), plan.fallback_tiles(), err, bad.size)
+            assert bad.size <= lim, (plan.kernel_name(), seed, c, f, plan.tile_shape(), plan.wave_shape(), plan.aperture_split(), plan.fallback_tiles(), err, bad.size)
             best = e[bad]
             for sh in (-2e-4, 2e-4):
                 r2 = O.das_spec(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], xs_all[f], np.asarray(t0, np.float64) + sh / case["fs"], case["fs"], c_or,
