@@ -410,7 +410,8 @@ typedef struct qdas_shift_desc {
     int32_t  cplx;      /* samples are interleaved complex         */
     int32_t  w_real;    /* w holds real(dtype) weights             */
     int32_t  device;    /* HIP device ordinal, -1 = current        */
-    int32_t  reserved;
+    int32_t  tpad;      /* the last tpad of the T samples of a trace are ZEROS that are not stored: x holds T - tpad samples per trace (that is its stride);
+                         * a tap in the tail counts as an in-range zero -- ChannelData.zeropad in front of the sampling (src/UltrasoundSystem.m:3479) without the copy */
     const void *shift;
     const void *w;
 } qdas_shift_desc;

@@ -420,6 +420,7 @@ static mxArray *cmd_shiftsum(int nrhs, const mxArray *prhs[]) {
     d.T = (uint64_t)num_at(z, 0, "ssz"); d.To = (uint64_t)num_at(z, 1, "ssz"); d.N = (uint64_t)num_at(z, 2, "ssz"); d.M = (uint64_t)num_at(z, 3, "ssz");
     d.Mo = (uint64_t)num_at(z, 4, "ssz"); d.F = (uint64_t)num_at(z, 5, "ssz"); d.flag = (int32_t)num_at(z, 6, "ssz"); d.dtype = (int32_t)num_at(z, 7, "ssz");
     d.cplx = (int32_t)num_at(z, 8, "ssz"); d.w_real = mxGetNumberOfElements(z) > 9 ? (int32_t)num_at(z, 9, "ssz") : 1;
+    d.tpad = mxGetNumberOfElements(z) > 10 ? (int32_t)num_at(z, 10, "ssz") : 0;      /* zeros behind the record that are not stored (include/qdas.h) */
     d.device = -1;
     if (d.dtype != QDAS_F64 && d.dtype != QDAS_F32) mexErrMsgIdAndTxt("QUPS:das_spec:qdas", "shiftsum: datatype must be double or single");
     const size_t rs = rbytes(d.dtype), es = rs * (d.cplx ? 2 : 1);

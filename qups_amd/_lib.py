@@ -90,7 +90,7 @@ class PreDesc(C.Structure):
 
 class ShiftDesc(C.Structure):
     _fields_ = [("T", C.c_uint64), ("To", C.c_uint64), ("N", C.c_uint64), ("M", C.c_uint64), ("Mo", C.c_uint64), ("F", C.c_uint64),
-                ("flag", C.c_int32), ("dtype", C.c_int32), ("cplx", C.c_int32), ("w_real", C.c_int32), ("device", C.c_int32), ("reserved", C.c_int32),
+                ("flag", C.c_int32), ("dtype", C.c_int32), ("cplx", C.c_int32), ("w_real", C.c_int32), ("device", C.c_int32), ("tpad", C.c_int32),
                 ("shift", C.c_void_p), ("w", C.c_void_p)]
 
 

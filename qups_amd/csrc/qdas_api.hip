@@ -2137,14 +2137,16 @@ extern "C" int qdas_shift_sum(const qdas_shift_desc *d, const void *x, void *y, 
     if ((d->flag & 7) > 5 || (d->flag & ~7)) return fail(QDAS_EINVAL, "Interp option not recognized: %d", d->flag);
     if (!d->cplx && d->w && !d->w_real) return fail(QDAS_EINVAL, "shift_sum: real data take real weights");
     if (d->To == 0 || d->N == 0 || d->Mo == 0 || d->F == 0) return QDAS_OK;
-    if (!d->shift || (!x && d->T && d->M)) return fail(QDAS_EINVAL, "null data / shift pointer");
+    if (!d->shift || (!x && d->T > (uint64_t)(d->tpad > 0 ? d->tpad : 0) && d->M)) return fail(QDAS_EINVAL, "null data / shift pointer");
     if (d->T >= (1ull << 31) || d->To >= (1ull << 31)) return fail(QDAS_EUNSUPPORTED, "shift_sum: at most 2^31 - 1 samples per trace");
     if (d->N > 65535 || ((d->Mo + 7) / 8) * d->F > 65535) return fail(QDAS_EUNSUPPORTED, "shift_sum: too many receivers / synthesised transmits x frames for one launch");
     if (d->M * d->Mo >= (1ull << 31)) return fail(QDAS_EUNSUPPORTED, "shift_sum: too many (element, transmit) pairs");
     DeviceGuard guard(d->device);
     HIPCHK(guard.err);
     ShiftParams p{};
+    if (d->tpad < 0 || (uint64_t)d->tpad > d->T) return fail(QDAS_EINVAL, "shift_sum: tpad must lie in [0, T]");
     p.x = x; p.y = y; p.T = d->T; p.To = d->To; p.N = d->N; p.M = d->M; p.Mo = d->Mo; p.F = d->F;
+    p.Tx = d->T - (uint64_t)d->tpad;
     if (d->M == 0) {                                   // an empty sum
         const size_t bytes = (size_t)d->To * d->N * d->Mo * d->F * (d->dtype == QDAS_F64 ? 8 : 4) * (d->cplx ? 2 : 1);
         HIPCHK(hipMemsetAsync(y, 0, bytes, (hipStream_t)stream));

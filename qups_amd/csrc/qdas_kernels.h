@@ -91,6 +91,7 @@ struct ShiftParams {
     const void *x; void *y; const void *tab, *blk;
     uint64_t T, To, N, M, Mo, F;
     uint32_t mo_blocks;
+    uint64_t Tx;                     // samples per trace actually stored (T - tpad): the rest of [0, T) reads as zero
 };
 hipError_t launch_shift_sum(const ShiftParams &P, int dtype, int cplx, int interp, const void *sh, const void *w, int w_real, hipStream_t s);
 

@@ -77,25 +77,33 @@ constexpr int SS_CAP = 4096;     // samples of one staged window
 // per (block of SS_MOB synthesised transmits, element m): smallest / largest tap offset among the weighted entries (kmin > kmax: none) -- what a
 // workgroup needs BEFORE it stages a window; one 8-byte scalar load per element instead of a scan over the block's entries
 template <typename R>
-__global__ void __launch_bounds__(256) shift_block_kernel(const ShiftEntry<R> *__restrict__ tab, uint64_t M, uint64_t Mo, uint32_t mo_blocks, int2 *__restrict__ blk) {
+__global__ void __launch_bounds__(256) shift_block_kernel(const ShiftEntry<R> *__restrict__ tab, uint64_t M, uint64_t Mo, uint32_t mo_blocks, int4 *__restrict__ blk) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= M * mo_blocks) return;
     const uint64_t m = i % M, mob = i / M;
     int kmin = 0x7fffffff, kmax = -0x7fffffff - 1;
+    // .z / .w (round 6): outputs [z, w] lie in the support of EVERY term of the block, all of them weighted by a real number (z > w: no such range) --
+    // a wave whose outputs lie inside takes the loop without masks (shift_sum_kernel)
+    int lo = 0, hi = 0x7fffffff;
+    bool plain = true;
     for (uint64_t mo = mob * SS_MOB; mo < Mo && mo < (mob + 1) * SS_MOB; ++mo) {
         const ShiftEntry<R> &e = tab[m + M * mo];
         if (e.on) { kmin = e.k0 < kmin ? e.k0 : kmin; kmax = e.k0 > kmax ? e.k0 : kmax; }
+        if (e.on && e.wi == (R)0) { lo = e.tlo > lo ? e.tlo : lo; hi = e.thi < hi ? e.thi : hi; }
+        else plain = false;
     }
-    blk[i] = make_int2(kmin, kmax);
+    blk[i] = plain ? make_int4(kmin, kmax, lo, hi) : make_int4(kmin, kmax, 0x7fffffff, -2);    // (.w == -2: a zero or complex weight among them -- the general loop)
 }
 
 // DT: sample type (float2 / double2 / float / double), R its real type, TPT output samples per lane
 template <int K, typename DT, typename R, int TPT>
 __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ss_lds[];
-    DT *win = (DT *)ss_lds;
+    DT *const win_base = (DT *)ss_lds;
+    DT *win = win_base;                                                          // the window the terms read (class 0: one of two halves, see the element loop)
     constexpr int EW = (int)(sizeof(ShiftEntry<R>) / 4);                         // 32-bit words per table entry
-    uint32_t *ent_w = (uint32_t *)(ss_lds + sizeof(DT) * SS_CAP);                // [SS_MOB] this element's entries, copied next to the window
+    uint32_t *const ent_base = (uint32_t *)(ss_lds + sizeof(DT) * SS_CAP);       // [2][SS_MOB] this element's entries, copied next to the window
+    uint32_t *ent_w = ent_base;
     const ShiftEntry<R> *ent = (const ShiftEntry<R> *)ent_w;
     constexpr bool CPLX = sizeof(DT) == 2 * sizeof(R);
     constexpr int TPB = 256 * TPT;
@@ -107,7 +115,7 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
     const uint64_t f = blockIdx.z / P.mo_blocks;
     const uint64_t mo0 = (uint64_t)mob * SS_MOB;
     const int nmo = (int)((P.Mo - mo0) < (uint64_t)SS_MOB ? (P.Mo - mo0) : (uint64_t)SS_MOB);
-    const int64_t T = (int64_t)P.T;
+    const int64_t T = (int64_t)P.Tx;                                             // (stored samples: what a load may touch; the support rule is in the table)
     R ar[TPT][SS_MOB], ai[TPT][SS_MOB];
 #pragma unroll
     for (int q = 0; q < TPT; ++q)
@@ -126,6 +134,8 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
         }
         __syncthreads();
     };
+    // a wave owns 64 x TPT CONSECUTIVE outputs of the block (lane + 64 q within them): whether a term's support covers them all is a per-wave question
+    const int wv0 = __builtin_amdgcn_readfirstlane((int)(tid / 64) * (64 * TPT)), lt0 = wv0 + (int)(tid % 64);
     // all lanes, their TPT outputs, synthesised transmit j.  rel = (first tap of local output 0) - (window start): every lane's taps lie inside the
     // staged window whether or not its output is in support, so the reads need no guard; 32-bit index math throughout
     auto term = [&](const ShiftEntry<R> &e, int j, int rel) {
@@ -134,7 +144,7 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
         const bool plain = e.wi == (R)0;                                                        // real weight: already in c[]
 #pragma unroll
         for (int q = 0; q < TPT; ++q) {
-            const int lt = (int)tid + 256 * q;
+            const int lt = lt0 + 64 * q;
             const bool ok = lt >= lo && lt <= hi;
             const DT *tp = win + (lt + rel);
             if constexpr (std::is_same<DT, float2>::value) {                                    // packed fp32: one v_pk_fma_f32 per tap
@@ -156,23 +166,59 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
         }
     };
 
+    // the same for a wave INSIDE the support of every term of the block (real weights): no masks, no weight select -- K FMAs per output straight into
+    // the accumulator, every tap an immediate offset from one address per term (fp32 complex data; the table entries are read as in `term`)
+    // MASK: the wave straddles an end of some term's support -- the same chain under the lanes' support mask (one unsigned compare per output)
+    auto lean_term = [&](auto maskc, const ShiftEntry<R> &e, int j, int rel) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(maskc)::value;
+        if constexpr (std::is_same<DT, float2>::value) {
+            const DT *tp = win + (lt0 + rel);
+            float2 sm[TPT][K];
+#pragma unroll
+            for (int q = 0; q < TPT; ++q)
+#pragma unroll
+                for (int k = 0; k < K; ++k) sm[q][k] = tp[64 * q + k];
+            if constexpr (!MASK) {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+#pragma unroll
+                    for (int q = 0; q < TPT; ++q) {
+                        const v2f a = (v2f){sm[q][k].x, sm[q][k].y} * e.c[k] + (v2f){ar[q][j], ai[q][j]};
+                        ar[q][j] = a.x; ai[q][j] = a.y;
+                    }
+            } else {
+                const int lo = e.tlo - (int)tb;                                   // (the launcher keeps To below 2^30 on this path)
+                const uint32_t len = (uint32_t)(e.thi - e.tlo);
+#pragma unroll
+                for (int q = 0; q < TPT; ++q) {
+                    if ((uint32_t)(lt0 + 64 * q - lo) <= len) {
+                        v2f a = {ar[q][j], ai[q][j]};
+#pragma unroll
+                        for (int k = 0; k < K; ++k) a = (v2f){sm[q][k].x, sm[q][k].y} * e.c[k] + a;
+                        ar[q][j] = a.x; ai[q][j] = a.y;
+                    }
+                }
+            }
+        }
+    };
+
     // Element loop, software-pipelined: while the lanes work on element m out of LDS, the window (and the table entries) of the next weighted
     // element are already on their way into registers; they are written to LDS behind the barrier that ends m.  Class 0: the window fits the
     // prefetch registers (offsets of the block within ~500 samples of each other -- the usual case); class 1: one window, staged without
     // prefetch; class 2: offsets too far apart for one window -- a window per synthesised transmit.
-    const int2 *__restrict__ blk = (const int2 *)P.blk + (uint64_t)mob * P.M;
+    const int4 *__restrict__ blk = (const int4 *)P.blk + (uint64_t)mob * P.M;
     constexpr int NPF = TPT + 2;
     DT pre[NPF];
     uint32_t pre_e = 0;
-    auto find = [&](uint64_t from, int &kmin, int &kmax) -> uint64_t {           // next element with a weight in this block (uniform scalar loads)
-        for (uint64_t m = from; m < P.M; ++m) { const int2 kr = blk[m]; if (kr.x <= kr.y) { kmin = kr.x; kmax = kr.y; return m; } }
+    auto find = [&](uint64_t from, int &kmin, int &kmax, int &all_lo, int &all_hi) -> uint64_t {   // next element with a weight in this block (uniform scalar loads)
+        for (uint64_t m = from; m < P.M; ++m) { const int4 kr = blk[m]; if (kr.x <= kr.y) { kmin = kr.x; kmax = kr.y; all_lo = kr.z; all_hi = kr.w; return m; } }
         return P.M;
     };
     auto klass = [&](int kmin, int kmax) -> int {
         const int64_t span = (int64_t)kmax - (int64_t)kmin;
         return span + TPB + K - 1 <= NPF * 256 ? 0 : (span + TPB + K <= SS_CAP ? 1 : 2);
     };
-    auto trace = [&](uint64_t m) -> const DT * { return (const DT *)P.x + ((f * P.M + m) * P.N + n) * P.T; };
+    auto trace = [&](uint64_t m) -> const DT * { return (const DT *)P.x + ((f * P.M + m) * P.N + n) * P.Tx; };
     auto fetch = [&](uint64_t m, int kmin, int wlen) {
         const DT *__restrict__ tr = trace(m);
         const int64_t wlo = tb + kmin;
@@ -186,33 +232,61 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
         }
         if ((int)tid < nmo * EW) pre_e = ((const uint32_t *)(tab + m + P.M * (mo0 + tid / EW)))[tid % EW];
     };
-    int kmin = 0, kmax = -1;
-    uint64_t m = find(0, kmin, kmax);
+    static_assert(NPF * 256 <= SS_CAP / 2, "a class 0 window fits half of the staging area");
+    int kmin = 0, kmax = -1, alo = 0, ahi = -1, cur = 0;
+    bool big_prev = true;                                                        // (nothing to wait for before the first write; harmless)
+    uint64_t m = find(0, kmin, kmax, alo, ahi);
     int kl = m < P.M ? klass(kmin, kmax) : 0;
     if (m < P.M && kl == 0) fetch(m, kmin, (int)((int64_t)kmax - kmin + TPB + K - 1));
     while (m < P.M) {
         const int wl = (int)((int64_t)kmax - (int64_t)kmin + TPB + K - 1);
         if (kl == 0) {
-            __syncthreads();                                                     // the previous element is consumed
+            // two windows (halves of the staging area) take turns: the one written now was last read two elements ago, and every wave has passed a
+            // barrier since -- ONE barrier per element (round 6; the window of a class 1 / 2 element spans both halves: a barrier before reusing them)
+            if (big_prev) __syncthreads();
+            cur ^= 1;
+            win = win_base + cur * (SS_CAP / 2);
+            ent_w = ent_base + cur * (SS_MOB * EW);
+            ent = (const ShiftEntry<R> *)ent_w;
 #pragma unroll
             for (int p = 0; p < NPF; ++p) { const int i = (int)tid + 256 * p; if (i < wl) win[i] = pre[p]; }
             if ((int)tid < nmo * EW) ent_w[tid] = pre_e;
             __syncthreads();
-        } else stage(trace(m), tb + kmin, kl == 1 ? wl : 0, tab + m + P.M * mo0);
-        int kmin2 = 0, kmax2 = -1;
-        const uint64_t m2 = find(m + 1, kmin2, kmax2);
+            big_prev = false;
+        } else {
+            win = win_base; ent_w = ent_base; ent = (const ShiftEntry<R> *)ent_w;
+            stage(trace(m), tb + kmin, kl == 1 ? wl : 0, tab + m + P.M * mo0);
+            big_prev = true;
+        }
+        int kmin2 = 0, kmax2 = -1, alo2 = 0, ahi2 = -1;
+        const uint64_t m2 = find(m + 1, kmin2, kmax2, alo2, ahi2);
         const int kl2 = m2 < P.M ? klass(kmin2, kmax2) : 0;
         if (m2 < P.M && kl2 == 0) fetch(m2, kmin2, (int)((int64_t)kmax2 - kmin2 + TPB + K - 1));       // in flight during the arithmetic below
+        const bool all_plain = std::is_same<DT, float2>::value && kl != 2 && nmo == SS_MOB && ahi != -2 && P.To < (1ull << 30);
+        if (all_plain && (int64_t)alo <= tb + wv0 && (int64_t)ahi >= tb + wv0 + 64 * TPT - 1) {   // (per wave; scalar)
 #pragma unroll
-        for (int j = 0; j < SS_MOB; ++j) {
-            if (j >= nmo) break;
-            const ShiftEntry<R> e = ent[j];                                      // broadcast LDS reads
-            const bool here = e.on && (int64_t)e.thi >= tb && (int64_t)e.tlo < tb + TPB;
-            if (!__builtin_amdgcn_readfirstlane((int)here)) continue;            // (uniform)
-            if (kl == 2) stage(trace(m), tb + e.k0, TPB + K - 1, nullptr);
-            term(e, j, kl == 2 ? 0 : e.k0 - kmin);
+            for (int j = 0; j < SS_MOB; ++j) {                                   // (straight-line code: an exit per term costs a copy of every accumulator)
+                const ShiftEntry<R> e = ent[j];
+                lean_term(std::false_type{}, e, j, e.k0 - kmin);
+            }
+        } else if (all_plain) {
+#pragma unroll
+            for (int j = 0; j < SS_MOB; ++j) {
+                const ShiftEntry<R> e = ent[j];
+                lean_term(std::true_type{}, e, j, e.k0 - kmin);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SS_MOB; ++j) {
+                if (j >= nmo) break;
+                const ShiftEntry<R> e = ent[j];                                  // broadcast LDS reads
+                const bool here = e.on && (int64_t)e.thi >= tb && (int64_t)e.tlo < tb + TPB;
+                if (!__builtin_amdgcn_readfirstlane((int)here)) continue;        // (uniform)
+                if (kl == 2) stage(trace(m), tb + e.k0, TPB + K - 1, nullptr);
+                term(e, j, kl == 2 ? 0 : e.k0 - kmin);
+            }
         }
-        m = m2; kmin = kmin2; kmax = kmax2; kl = kl2;
+        m = m2; kmin = kmin2; kmax = kmax2; kl = kl2; alo = alo2; ahi = ahi2;
     }
 #pragma unroll
     for (int j = 0; j < SS_MOB; ++j) {
@@ -220,7 +294,7 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
         DT *__restrict__ yo = (DT *)P.y + ((f * P.Mo + mo0 + j) * P.N + n) * P.To;
 #pragma unroll
         for (int q = 0; q < TPT; ++q) {
-            const int64_t t = tb + (int64_t)tid + 256 * q;
+            const int64_t t = tb + (int64_t)lt0 + 64 * q;
             if (t < (int64_t)P.To) {
                 if constexpr (CPLX) { DT v; v.x = ar[q][j]; v.y = ai[q][j]; yo[t] = v; }
                 else yo[t] = ar[q][j];
@@ -249,13 +323,13 @@ static hipError_t launch_shift_t(const ShiftParams &P, int interp, const void *s
     ShiftParams p = P;
     p.tab = tab;
     p.mo_blocks = (uint32_t)((P.Mo + SS_MOB - 1) / SS_MOB);
-    int2 *blk = (int2 *)scratch.get(sizeof(int2) * P.M * p.mo_blocks);
+    int4 *blk = (int4 *)scratch.get(sizeof(int4) * P.M * p.mo_blocks);
     if (!blk) return hipErrorOutOfMemory;
     shift_block_kernel<R><<<(unsigned)((P.M * p.mo_blocks + 255) / 256), 256, 0, s>>>(tab, P.M, P.Mo, p.mo_blocks, blk);
     p.blk = blk;
     constexpr int TPB = 256 * TPT;
     const dim3 g((unsigned)((P.To + TPB - 1) / TPB), (unsigned)P.N, (unsigned)(p.mo_blocks * P.F));
-    const size_t lds = sizeof(DT) * SS_CAP + sizeof(ShiftEntry<R>) * SS_MOB;
+    const size_t lds = sizeof(DT) * SS_CAP + 2 * sizeof(ShiftEntry<R>) * SS_MOB;
     const int K = interp_taps(interp);
 #define QSS(KK)                                                                                                                         \
     do {                                                                                                                                \

@@ -118,13 +118,62 @@ def das_lut(x, tau_rx, tau_tx, *, interp="linear", w=None, keep_rx=False, keep_t
     return rev(y.reshape(tuple(reversed(fsz)) + (oM, oN) + tuple(reversed(Isz))))
 
 
-def shift_sum(x, shift, w=None, interp="linear", To=None, device=None):
+_SHIFT_MEMO: "collections.OrderedDict" = None          # device copies of the last few (shift, w) tables handed over as HOST arrays
+
+
+def _shift_tables(shift, w, M, dbl, cplx_data, dev, torch):
+    """``(shift, w, w_real)`` on the device in the kernel's layout (``m`` fastest).  Host (numpy) tables -- what ``focusTx`` computes from the sequence on
+    every call -- are remembered by content: a pageable upload blocks the host until the stream has drained (~0.1 ms each at C1, round 6), and a stream
+    of frames synthesises the same transmits again and again."""
+    global _SHIFT_MEMO
+    rt = torch.float64 if dbl else torch.float32
+    host = not _is_torch(shift) and (w is None or not _is_torch(w))
+    key = None
+    if host:
+        import collections, hashlib
+        sa = np.ascontiguousarray(np.asarray(shift, np.float64))
+        wa = None if w is None else np.ascontiguousarray(np.asarray(w))
+        h = hashlib.blake2b(sa.tobytes(), digest_size=16)
+        if wa is not None:
+            h.update(str((wa.dtype.str, wa.shape)).encode()); h.update(wa.tobytes())
+        key = (h.digest(), sa.shape, bool(dbl), bool(cplx_data), str(dev))
+        if _SHIFT_MEMO is None:
+            _SHIFT_MEMO = collections.OrderedDict()
+        hit = _SHIFT_MEMO.get(key)
+        if hit is not None:
+            _SHIFT_MEMO.move_to_end(key)
+            return hit
+    sh = (shift if _is_torch(shift) else torch.from_numpy(np.asarray(shift, np.float64))).to(dev)
+    if sh.ndim != 2 or sh.shape[0] != M:
+        raise DasError("shift_sum: shift must be M x Mo")
+    Mo = int(sh.shape[1])
+    shc = sh.to(rt).t().contiguous()                                  # memory: m fastest
+    wc, w_real = None, 1
+    if w is not None:
+        wt = (w if _is_torch(w) else torch.from_numpy(np.array(w))).to(dev)
+        wt = torch.broadcast_to(wt, (M, Mo))
+        if wt.is_complex():
+            if not cplx_data:
+                raise DasError("shift_sum: real data take real weights")
+            wc, w_real = wt.to(torch.complex128 if dbl else torch.complex64).t().contiguous(), 0
+        else:
+            wc = wt.to(rt).t().contiguous()
+    out = (shc, wc, w_real)
+    if key is not None:
+        _SHIFT_MEMO[key] = out
+        while len(_SHIFT_MEMO) > 8:
+            _SHIFT_MEMO.popitem(last=False)
+    return out
+
+
+def shift_sum(x, shift, w=None, interp="linear", To=None, device=None, tpad=0):
     """Transmit synthesis: ``y[t', n, m', f] = sum_m w[m, m'] * x(t' + shift[m, m'], n, m, f)`` for ``t' = 0 .. To-1`` (``qdas_shift_sum``,
     ``qups_amd/csrc/shiftsum.hip``) -- what ``UltrasoundSystem.focusTx`` asks of ``sample2sep`` (reference ``src/UltrasoundSystem.m:3498``) with the
     positions written as the record's time grid plus one offset per (element, synthesised transmit).
 
     ``x``: ``T x N x M x F...`` float32 / float64 / complex64 / complex128; ``shift``: ``M x Mo`` in samples; ``w``: ``M x Mo`` (real, or complex for
-    complex data) or ``None``.  Returns ``To x N x Mo x F...`` on the device."""
+    complex data) or ``None``.  ``tpad``: the record counts as followed by ``tpad`` zero samples (``ChannelData.zeropad`` without the copy: a tap in the
+    tail is an in-range zero, ``include/qdas.h``).  Returns ``To x N x Mo x F...`` on the device (``To`` defaults to ``T + tpad``)."""
     torch = _torch()
     L = _lib.lib()
     if not torch.cuda.is_available():
@@ -142,27 +191,16 @@ def shift_sum(x, shift, w=None, interp="linear", To=None, device=None):
     F = int(np.prod(fsz)) if fsz else 1
     dbl = xt.dtype in (torch.float64, torch.complex128)
     rt = torch.float64 if dbl else torch.float32
-    sh = (shift if _is_torch(shift) else torch.from_numpy(np.asarray(shift, np.float64))).to(dev)
-    if sh.ndim != 2 or sh.shape[0] != M:
-        raise DasError("shift_sum: shift must be M x Mo")
-    Mo = int(sh.shape[1])
-    shc = sh.to(rt).t().contiguous()                                  # memory: m fastest
-    wc = None
-    w_real = 1
-    if w is not None:
-        wt = (w if _is_torch(w) else torch.from_numpy(np.asarray(w))).to(dev)
-        wt = torch.broadcast_to(wt, (M, Mo))
-        if wt.is_complex():
-            if not xt.is_complex():
-                raise DasError("shift_sum: real data take real weights")
-            wc, w_real = wt.to(torch.complex128 if dbl else torch.complex64).t().contiguous(), 0
-        else:
-            wc = wt.to(rt).t().contiguous()
-    To = T if To is None else int(To)
+    shc, wc, w_real = _shift_tables(shift, w, M, dbl, xt.is_complex(), dev, torch)
+    Mo = int(shc.shape[0])
+    tpad = int(tpad)
+    if tpad < 0:
+        raise DasError("shift_sum: tpad must not be negative")
+    To = T + tpad if To is None else int(To)
     xc = _colmajor(xt.reshape((T, N, M) if F == 1 else (T, N, M, F)).contiguous())    # (F, M, N, T); three dimensions take the LDS-tiled transpose
     y = torch.empty((F, Mo, N, To), dtype=xt.dtype, device=dev)
-    d = _lib.ShiftDesc(T, To, N, M, Mo, F, _lib.INTERP_FLAGS[interp], 0 if dbl else 1, int(xt.is_complex()), w_real,
-                       dev.index if dev.index is not None else torch.cuda.current_device(), 0, shc.data_ptr(), wc.data_ptr() if wc is not None else None)
+    d = _lib.ShiftDesc(T + tpad, To, N, M, Mo, F, _lib.INTERP_FLAGS[interp], 0 if dbl else 1, int(xt.is_complex()), w_real,
+                       dev.index if dev.index is not None else torch.cuda.current_device(), tpad, shc.data_ptr(), wc.data_ptr() if wc is not None else None)
     with torch.cuda.device(dev):
         _lib.check(L.qdas_shift_sum(C.byref(d), C.c_void_p(xc.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return y.permute(3, 2, 1, 0).reshape((To, N, Mo) + fsz)

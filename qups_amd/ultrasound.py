@@ -408,17 +408,21 @@ class UltrasoundSystem:
         nmax = int(np.ceil(np.nanmax(tau[i]) * chd.fs))
         t0 = float(np.asarray(chd.t0).reshape(-1)[0]) + nmin / chd.fs
         tau = tau - nmin / chd.fs
-        chd = ChannelData(chd.data, t0, chd.fs, "TNM").zeropad(0, (nmax - nmin) + int(buffer))
+        pad = (nmax - nmin) + int(buffer)
+        d = chd._torch_data()
+        if d.dtype in (torch.float32, torch.float64, torch.complex64, torch.complex128):
+            # the positions are the record's own time grid plus ONE offset per (element, synthesised transmit): the shift-and-sum kernel
+            # (qdas_shift_sum: per-pair tap offset and weights, LDS-staged windows, zero weights skipped; round 3).  The zeros the reference appends
+            # (chd = zeropad(chd, 0, nmax - nmin + buffer), :3479) are not stored: `tpad` makes the kernel read them as in-range zeros (round 6)
+            from .interpd import shift_sum
+            dev = d.device if d.is_cuda else torch.device("cuda")
+            z = shift_sum(d.to(dev), -tau * chd.fs, apd, interp, tpad=pad)
+            return ChannelData(z, t0, chd.fs, "TNM")
+        chd = ChannelData(chd.data, t0, chd.fs, "TNM").zeropad(0, pad)
         d = chd._torch_data()
         T2, N, M = d.shape[:3]
         dev = d.device if d.is_cuda else torch.device("cuda")
         Mp = tau.shape[1]
-        if d.dtype in (torch.float32, torch.float64, torch.complex64, torch.complex128):
-            # the positions are the record's own time grid plus ONE offset per (element, synthesised transmit): the shift-and-sum kernel
-            # (qdas_shift_sum: per-pair tap offset and weights, LDS-staged windows, zero weights skipped; round 3)
-            from .interpd import shift_sum
-            z = shift_sum(d.to(dev), -tau * chd.fs, apd, interp)
-            return ChannelData(z, t0, chd.fs, "TNM")
         # other data types: ONE launch of the general single-delay kernel over the index space (t', n, m, m', frames...): the sample index depends
         # on (t', m, m'), the data on (n, m, frames), the weight on (m, m'); the transmit elements m are summed
         ntau = torch.arange(T2, dtype=torch.float64, device=dev).reshape(T2, 1, 1, 1) - torch.from_numpy(tau * chd.fs).to(dev).reshape(1, 1, M, Mp)

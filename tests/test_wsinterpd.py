@@ -261,6 +261,32 @@ def test_shift_sum_offsets_too_far_apart_for_one_window_and_no_weights():
         shift_sum(torch.from_numpy(x.real.copy()), shift, np.ones((M, Mo)) * 1j, "cubic")     # real data take real weights
 
 
+@pytest.mark.parametrize("dtype,interp,Mo", [("complex64", "cubic", 8), ("complex64", "linear", 5), ("float32", "lanczos3", 8), ("complex128", "cubic", 3),
+                                             ("complex64", "nearest", 16)])
+def test_shift_sum_zero_tail_that_is_not_stored(dtype, interp, Mo):
+    """``tpad`` (``include/qdas.h``): the record counts as followed by zeros -- bit for bit what the same call returns on a zero-padded copy
+    (``focusTx`` no longer makes that copy), on the paths with and without support masks; and ``focusTx`` itself against its padded form."""
+    import torch
+    from qups_amd.interpd import shift_sum
+    rng = np.random.default_rng(77)
+    T, N, M, pad = 1500, 3, 6, 211
+    x = rng.standard_normal((T, N, M)).astype(np.float32)
+    if dtype.startswith("complex"):
+        x = x + 1j * rng.standard_normal((T, N, M)).astype(np.float32)
+    x = x.astype(dtype)
+    shift = -rng.uniform(0, pad, (M, Mo))                                              # (focusTx: delays shifted to be non-negative)
+    w = rng.uniform(0.5, 1, (M, Mo))
+    xp = np.concatenate([x, np.zeros((pad, N, M), x.dtype)], 0)
+    a = shift_sum(torch.from_numpy(x), shift, w, interp, tpad=pad)
+    b = shift_sum(torch.from_numpy(xp), shift, w, interp)
+    assert a.shape == b.shape == (T + pad, N, Mo)
+    assert torch.equal(a, b)
+    a = shift_sum(torch.from_numpy(x), shift, w, interp, To=T + 40, tpad=pad)          # fewer outputs than the padded length
+    assert torch.equal(a, b[:T + 40])
+    with pytest.raises(Exception):
+        shift_sum(torch.from_numpy(x), shift, w, interp, tpad=-1)
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("QDAS_SHIFT_FUZZ", "32"))))
 def test_shift_sum_random_configuration(seed):
     """random record / output lengths (around the 256 x {2,3,4}-sample blocks), element and transmit counts (ragged blocks of 8), frames, types,
