@@ -83,6 +83,7 @@ struct WsParams {
     int64_t sts[8], sxs[8], sws[8];
     double omega, extrap;
     int32_t flag, w_real, any_sum;
+    int32_t lanesum_ok;              // one summed dimension, and x is contiguous along it: the lanes of a wave run along the SUM (wsinterpd_lanesum_kernel)
 };
 hipError_t launch_wsinterpd(const WsParams &P, int dtype, hipStream_t s);
 

@@ -128,6 +128,40 @@ def test_wsinterpd_matches_the_oracle_with_phasor_extrapolation_and_sums():
             assert np.nanmax(np.abs(y - ref)) <= 1e-11, (terp, sdim, ev)
 
 
+@pytest.mark.parametrize("prec", ["single", "double", "halfT"])
+@pytest.mark.parametrize("terp", ["nearest", "linear", "cubic", "lanczos3"])
+@pytest.mark.parametrize("M,wkind,ev", [(128, "none", 0.0), (33, "real", np.nan), (200, "complex", 0.0), (64, "real", 2.5), (31, "real", 0.0)])
+def test_wsinterpd_torch_order_record_summed_over_its_fastest_dimension(prec, terp, M, wkind, ev, monkeypatch):
+    """A record in torch order (last dimension fastest) summed over that dimension: the lanes of a wave run along the sum (``wsinterpd_lanesum_kernel``;
+    round 5 transposed the record first).  Against the float64 oracle, and against the transposed form (``QDAS_WS_NO_LANESUM``): the same terms, added in
+    another order.  Delays out of the record, an infinite one and NaN ``extrapval`` (omitted by sums) included; ``M = 31``: below the kernel's 32 terms."""
+    import torch
+    from qups_amd.interpd import wsinterpd
+    rng = np.random.default_rng(19)
+    T, N = 300, 5
+    dbl = prec == "double"
+    ct = np.complex128 if dbl else np.complex64
+    x = (rng.standard_normal((T, N, M)) + 1j * rng.standard_normal((T, N, M))).astype(ct)
+    t = (np.arange(-3, T + 2, 2.5).reshape(-1, 1, 1) + rng.uniform(0, 3, (1, 1, M))).astype(np.float64 if dbl else np.float32)      # I x 1 x M: focusTx-like
+    t[4, 0, M // 2] = np.inf
+    w = None if wkind == "none" else rng.random((1, N, M)) + (1j * rng.random((1, N, M)) if wkind == "complex" else 0)
+    if prec == "halfT":
+        x = (x.real.astype(np.float16).astype(np.float32) + 1j * x.imag.astype(np.float16).astype(np.float32)).astype(np.complex64)
+    wa = 1 if w is None else torch.from_numpy(w.astype(ct if wkind == "complex" else (np.float64 if dbl else np.float32)))
+    om = 0.13j
+    args = (torch.from_numpy(x), torch.from_numpy(t), 1, wa, [3], terp, ev, om)
+    y = _np(wsinterpd(*args, prec=prec))
+    ref = O.wsinterpd(x.astype(np.complex128), t.astype(np.float64), 1, 1 if w is None else w, [3], terp, ev, om)
+    assert y.shape == ref.shape
+    assert np.array_equal(np.isnan(y), np.isnan(ref))
+    tol = 1e-11 if dbl else (2e-3 if prec == "halfT" else 3e-5)
+    assert np.nanmax(np.abs(y - ref)) <= tol * max(1.0, np.nanmax(np.abs(ref))), (terp, M, wkind)
+    monkeypatch.setenv("QDAS_WS_NO_LANESUM", "1")
+    y2 = _np(wsinterpd(*args, prec=prec))
+    assert np.array_equal(np.isnan(y), np.isnan(y2))
+    assert np.nanmax(np.abs(y - y2)) <= tol * max(1.0, np.nanmax(np.abs(ref)))
+
+
 def test_channeldata_sample_rectify_and_focusTx():
     """ChannelData.sample == oracle wsinterpd on (tau - t0) fs; rectifyt0 / rectifyDims; focusTx vs the oracle restatement and the
     physical check: plane-wave transmits synthesised from FSA data of a point target peak where a direct plane-wave simulation does"""

@@ -35,7 +35,7 @@ def line(name, ms, nbytes, note=""):
 g = torch.Generator(device=dev).manual_seed(0)
 rn = lambda *s: torch.view_as_complex(torch.randn(tuple(s) + (2,), generator=g, device=dev, dtype=torch.float32))
 # the same in MATLAB's (column-major) memory order -- time fastest --, which is how the reference hands its records to these kernels; a torch-order
-# (last dimension fastest) record makes `wsinterpd` transpose x and t first when the fastest dimension is the summed one (qups_amd/interpd.py)
+# (last dimension fastest) record summed over its fastest dimension takes the lane-sum kernel (csrc/wsinterpd.hip; QDAS_WS_NO_LANESUM=1: transposed first, round 5)
 rn_cm = lambda *s: rn(*reversed(s)).permute(*reversed(range(len(s))))
 cm = lambda a: a.permute(*reversed(range(a.ndim))).contiguous().permute(*reversed(range(a.ndim)))
 
@@ -52,7 +52,7 @@ for interp in ("linear", "cubic"):
     ms = timed(lambda: wsinterpd(xc_, tc_, 1, 1, [3], interp, 0.0))
     line(f"wsinterpd sum over M  C1 {T}x{N}x{M} {interp}", ms, x.numel() * 8 + T * N * 8 + t.numel() * 4, f"{T * N * M / ms / 1e6:.1f} Gsample/s")
 ms = timed(lambda: wsinterpd(x, t, 1, 1, [3], "cubic", 0.0))
-line(f"  ... torch-order record (transposed first) cubic", ms, x.numel() * 8 + T * N * 8 + t.numel() * 4, f"{T * N * M / ms / 1e6:.1f} Gsample/s")
+line(f"  ... torch-order record (lanes along the sum) cubic", ms, x.numel() * 8 + T * N * 8 + t.numel() * 4, f"{T * N * M / ms / 1e6:.1f} Gsample/s")
 # ---- C2-sized: T x N x M = 2048 x 128 x 128
 T, N, M = 2048, 128, 128
 x = rn(T, N, M)
@@ -63,7 +63,7 @@ xc_, tc_ = cm(x), cm(t)
 ms = timed(lambda: wsinterpd(xc_, tc_, 1, 1, [3], "cubic", 0.0))
 line(f"wsinterpd sum over M  C2 {T}x{N}x{M} cubic", ms, x.numel() * 8 + T * N * 8 + t.numel() * 4, f"{T * N * M / ms / 1e6:.1f} Gsample/s")
 ms = timed(lambda: wsinterpd(x, t, 1, 1, [3], "cubic", 0.0))
-line(f"  ... torch-order record (transposed first) cubic", ms, x.numel() * 8 + T * N * 8 + t.numel() * 4, f"{T * N * M / ms / 1e6:.1f} Gsample/s")
+line(f"  ... torch-order record (lanes along the sum) cubic", ms, x.numel() * 8 + T * N * 8 + t.numel() * 4, f"{T * N * M / ms / 1e6:.1f} Gsample/s")
 del xc_, tc_
 
 # ---- focusTx at C1 (64-element FSA record -> 32 focused transmits): one split-delay launch per synthesised transmit, keep_rx
