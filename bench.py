@@ -534,8 +534,20 @@ def main():
             for name, kw in (("equal_width_each_rank_folds", dict()), ("equal_width_prefolded", dict(prefolded=True)), ("equal_cost_prefolded", dict(prefolded=True, balance="measure"))):
                 if name in layouts:
                     continue
+                # (a plan that one rank alone fails to make -- a compiler cache race, memory -- must not leave the others inside a collective: the ranks agree first)
+                sp2, why = None, ""
                 try:
                     sp2 = ShardedDasPlan(prob, rank, world, device=dev, kernel=args.kernel, reciprocal=True, jit=args.jit, **kw)
+                except Exception as ex:
+                    why = repr(ex)
+                okf = torch.tensor([1 if sp2 is not None else 0], device=dev, dtype=torch.int32)
+                dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+                if int(okf.item()) == 0:
+                    layouts[name] = {"ms_per_step": None, "note": "failed: plan creation on some rank" + (f" (this rank: {why})" if why else "")}
+                    if sp2 is not None:
+                        sp2.close()
+                    continue
+                try:
                     if kw.get("prefolded") and xfold is None:
                         rp = FoldedReplicator(N, T, dev, src=0)
                         sl, wk = rp.send(x_unf if rank == 0 else None, rank, async_op=True)
