@@ -162,6 +162,59 @@ def test_wsinterpd_torch_order_record_summed_over_its_fastest_dimension(prec, te
     assert np.nanmax(np.abs(y - y2)) <= tol * max(1.0, np.nanmax(np.abs(ref)))
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_wsinterpd_lane_sum_random_layouts(seed, monkeypatch):
+    """Random index spaces of 3 - 5 dimensions whose ONE summed dimension is the fastest in memory (32 - 150 terms): broadcast dimensions in x / t / w, any
+    memory order of the others, sampling dimension anywhere -- the lane-sum kernel against the float64 oracle and the one-output-per-lane kernel."""
+    import torch
+    from qups_amd.interpd import wsinterpd
+    r = np.random.default_rng(4100 + seed)
+    nd = int(r.integers(3, 6))
+    dim = int(r.integers(1, nd))                                   # sampling dimension (1-based), not the last one
+    S = int(r.choice([32, 33, 64, 65, 100, 128, 150]))
+    size = [int(r.integers(1, 6)) for _ in range(nd)]
+    size[nd - 1] = S                                                # the summed, fastest dimension
+    T, I = int(r.integers(20, 90)), int(r.integers(1, 40))
+    xs, ts = list(size), list(size)
+    xs[dim - 1], ts[dim - 1] = T, I
+    for k in range(nd - 1):                                         # broadcast some of the other dimensions in x or in t
+        if k != dim - 1 and r.integers(0, 3) == 0:
+            (xs if r.integers(0, 2) else ts)[k] = 1
+    if r.integers(0, 4) == 0:
+        ts[nd - 1] = 1                                              # delays that do not depend on the summed index
+    dbl = bool(r.integers(0, 3) == 0)
+    ct, rt = (np.complex128, np.float64) if dbl else (np.complex64, np.float32)
+    x = (r.standard_normal(xs) + 1j * r.standard_normal(xs)).astype(ct)
+    t = r.uniform(-2, T + 1, ts).astype(rt)
+    terp = str(r.choice(["nearest", "linear", "cubic", "lanczos3"]))
+    wk = int(r.integers(0, 3))
+    w = 1
+    if wk:
+        ws = [size[k] if r.integers(0, 2) else 1 for k in range(nd)]
+        ws[dim - 1] = 1
+        w = r.random(ws) + (1j * r.random(ws) if wk == 2 else 0)
+    ev = float(r.choice([0.0, np.nan]))
+    om = float(r.choice([0.0, 0.2])) * 1j
+    perm = list(r.permutation(nd - 1)) + [nd - 1]                   # memory order of the leading dimensions (the last stays fastest)
+    def lay(a):
+        a = np.ascontiguousarray(np.transpose(a, perm))
+        return torch.from_numpy(a).permute(*np.argsort(perm).tolist())
+    wa = w if isinstance(w, int) else torch.from_numpy(np.asarray(w).astype(ct if wk == 2 else rt))
+    args = (lay(x), lay(t), dim, wa, [nd], terp, ev, om)
+    y = _np(wsinterpd(*args, prec="double" if dbl else "single"))
+    ref = O.wsinterpd(x.astype(np.complex128), t.astype(np.float64), dim, w, [nd], terp, ev, om)
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    assert np.array_equal(np.isnan(y), np.isnan(ref))
+    scale = max(1.0, float(np.nanmax(np.abs(ref))) if np.isfinite(ref).any() else 1.0)
+    tol = (1e-11 if dbl else 5e-5) * scale
+    if not (terp == "nearest" and not dbl):                          # (fp32 delays at .5 may round the other way)
+        assert np.nanmax(np.abs(y - ref), initial=0.0) <= tol, (terp, size, dim)
+    monkeypatch.setenv("QDAS_WS_NO_LANESUM", "1")
+    y2 = _np(wsinterpd(*args, prec="double" if dbl else "single"))
+    assert np.array_equal(np.isnan(y), np.isnan(y2))
+    assert np.nanmax(np.abs(y - y2), initial=0.0) <= tol
+
+
 def test_channeldata_sample_rectify_and_focusTx():
     """ChannelData.sample == oracle wsinterpd on (tau - t0) fs; rectifyt0 / rectifyDims; focusTx vs the oracle restatement and the
     physical check: plane-wave transmits synthesised from FSA data of a point target peak where a direct plane-wave simulation does"""
