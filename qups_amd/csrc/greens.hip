@@ -167,7 +167,10 @@ __global__ void __launch_bounds__(256) greens_bound_kernel(const GreensParams P,
 // element) only -- (N En + M Em) I square roots instead of the N En M Em I x 2 (x blocks per trace) of a scan that recomputes them.
 // One workgroup = one CHUNK of 256 scatterers of one element: it also leaves the chunk's {smallest, largest} distance (fminf / fmaxf: a NaN distance
 // never lands anywhere and is ignored; a chunk of NaNs gets {+inf, -inf}: never visited)
-constexpr int GT_CHUNK = 256;
+#ifndef QDAS_GT_CHUNK
+#define QDAS_GT_CHUNK 256
+#endif
+constexpr int GT_CHUNK = QDAS_GT_CHUNK;          // scatterers per chunk of the lists (a build-time experiment knob: 128 / 256 / 512)
 __global__ void __launch_bounds__(GT_CHUNK) greens_dist_kernel(const float *__restrict__ Ps, const float *__restrict__ Pe, float *__restrict__ R, float2 *__restrict__ cb, uint64_t I) {
     __shared__ float2 part[GT_CHUNK / 64];
     const uint64_t i = (uint64_t)blockIdx.x * GT_CHUNK + threadIdx.x;
@@ -440,7 +443,7 @@ struct TrainBlock {
                 auto load_pass = [&](uint32_t e0) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const uint32_t c = clist[e0 + (uint32_t)q * CGRP + (wave >> 2)];
+                        const uint32_t c = clist[e0 + (uint32_t)q * CGRP + wave / (uint32_t)(GT_CHUNK / 64)];
                         const uint32_t i = c * (uint32_t)GT_CHUNK + (tid & (uint32_t)(GT_CHUNK - 1));
                         const bool in = c != 0xffffffffu && i < I32;
                         ivn[q] = i;
