@@ -377,20 +377,26 @@ template <typename TY> static hipError_t launch_ws_t(const WsParams &P, hipStrea
         }
     }
     if (P.lanesum_ok) {
-        constexpr int RUNW = 4;
-        const uint64_t nb = (P.n_out + 4 * RUNW - 1) / (4 * RUNW);
-        if (nb <= 0x7fffffffull) {
-            const dim3 g((unsigned)nb), b(256);
-            switch (P.flag & 7) {
-                case 0: wsinterpd_lanesum_kernel<0, TY, RUNW><<<g, b, 0, s>>>(P); break;
-                case 1: case 4: wsinterpd_lanesum_kernel<1, TY, RUNW><<<g, b, 0, s>>>(P); break;
-                case 2: wsinterpd_lanesum_kernel<2, TY, RUNW><<<g, b, 0, s>>>(P); break;
-                case 3: wsinterpd_lanesum_kernel<3, TY, RUNW><<<g, b, 0, s>>>(P); break;
-                case 5: wsinterpd_lanesum_kernel<5, TY, RUNW><<<g, b, 0, s>>>(P); break;
-                default: return hipErrorInvalidValue;
-            }
-            return hipGetLastError();
-        }
+        const char *rv = getenv("QDAS_WS_RUNW");                              // (experiments: outputs per wave)
+        const int runw = rv ? atoi(rv) : 4;
+#define QLS(RUNW)                                                                                                          \
+        do {                                                                                                               \
+            const uint64_t nb = (P.n_out + 4 * RUNW - 1) / (4 * RUNW);                                                     \
+            if (nb <= 0x7fffffffull) {                                                                                     \
+                const dim3 g((unsigned)nb), b(256);                                                                        \
+                switch (P.flag & 7) {                                                                                      \
+                    case 0: wsinterpd_lanesum_kernel<0, TY, RUNW><<<g, b, 0, s>>>(P); break;                               \
+                    case 1: case 4: wsinterpd_lanesum_kernel<1, TY, RUNW><<<g, b, 0, s>>>(P); break;                       \
+                    case 2: wsinterpd_lanesum_kernel<2, TY, RUNW><<<g, b, 0, s>>>(P); break;                               \
+                    case 3: wsinterpd_lanesum_kernel<3, TY, RUNW><<<g, b, 0, s>>>(P); break;                               \
+                    case 5: wsinterpd_lanesum_kernel<5, TY, RUNW><<<g, b, 0, s>>>(P); break;                               \
+                    default: return hipErrorInvalidValue;                                                                  \
+                }                                                                                                          \
+                return hipGetLastError();                                                                                  \
+            }                                                                                                              \
+        } while (0)
+        if (runw == 2) QLS(2); else if (runw == 8) QLS(8); else QLS(4);
+#undef QLS
     }
     // grid: x = blocks along the fastest kept dimension, (y, z) = the other kept dimensions flattened
     const uint64_t n0 = P.n_lane, gy = P.n_rest < 65535 ? (P.n_rest ? P.n_rest : 1) : 65535, gz = (P.n_rest + gy - 1) / gy;
