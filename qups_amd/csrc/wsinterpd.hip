@@ -251,17 +251,18 @@ __global__ void __launch_bounds__(256) interpd_stream_kernel(const WsParams P) {
 // out of a few memory rows (neighbouring terms sample neighbouring times), 8 lanes per 64-byte sector, the rows shared with the wave's next output -- and
 // the wave adds up across its lanes (a fixed tree: reproducible).  The one-output-per-lane kernel above reads such a record with every lane in a row of
 // its own; round 5 transposed the record first (0.30 ms at C2 size, against 0.13 ms for the sum itself).
-template <int INTERP, typename TY, int RUNW>
+// LW: lanes per output -- 64, or 32 for sums of at most 32 terms (two outputs side by side in a wave: no idle half)
+template <int INTERP, typename TY, int RUNW, int LW = 64>
 __global__ void __launch_bounds__(256) wsinterpd_lanesum_kernel(const WsParams P) {
     using R  = typename TY::real;
     using ST = typename TY::store;
     using AR = typename TY::apod_real_t;
     const R *__restrict__ t = (const R *)P.t;
     const ST *__restrict__ x = (const ST *)P.x;
-    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint64_t o0 = ((uint64_t)blockIdx.x * 4u + wave) * RUNW;
-    if (o0 >= P.n_out) return;
-    // this wave's first output, decoded once (uniform); the following ones by an odometer over the kept dimensions
+    const uint32_t lane = threadIdx.x & (uint32_t)(LW - 1), grp = LW == 64 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : threadIdx.x / (uint32_t)LW;
+    const uint64_t o0 = ((uint64_t)blockIdx.x * (256u / LW) + grp) * RUNW;
+    if (o0 >= P.n_out) return;                            // (a whole group of LW lanes: the adds across lanes below stay inside it)
+    // this group's first output, decoded once (uniform for LW = 64); the following ones by an odometer over the kept dimensions
     uint32_t idx[8];
     int64_t tb = 0, xb = 0, wb = 0, yo = 0;
     {
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(256) wsinterpd_lanesum_kernel(const WsParams P
     cplx<R> acc[RUNW];
 #pragma unroll
     for (int r = 0; r < RUNW; ++r) acc[r] = {(R)0, (R)0};
-    for (uint32_t j = lane; j < ((S + 63u) & ~63u); j += 64u) {
+    for (uint32_t j = lane; j < ((S + (uint32_t)(LW - 1)) & ~(uint32_t)(LW - 1)); j += (uint32_t)LW) {
         const bool in = j < S;
         R tau[RUNW];
         bool live[RUNW], ok[RUNW];
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(256) wsinterpd_lanesum_kernel(const WsParams P
 #pragma unroll
     for (int r = 0; r < RUNW; ++r) {
 #pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) { acc[r].x += __shfl_xor(acc[r].x, sft, 64); acc[r].y += __shfl_xor(acc[r].y, sft, 64); }
+        for (int sft = LW / 2; sft >= 1; sft >>= 1) { acc[r].x += __shfl_xor(acc[r].x, sft, 64); acc[r].y += __shfl_xor(acc[r].y, sft, 64); }
         if (lane == 0 && have[r]) st((ST *)P.y, (size_t)yor[r], acc[r]);
     }
 }
@@ -379,23 +380,24 @@ template <typename TY> static hipError_t launch_ws_t(const WsParams &P, hipStrea
     if (P.lanesum_ok) {
         const char *rv = getenv("QDAS_WS_RUNW");                              // (experiments: outputs per wave)
         const int runw = rv ? atoi(rv) : 4;
-#define QLS(RUNW)                                                                                                          \
+#define QLS(RUNW, LW)                                                                                                      \
         do {                                                                                                               \
-            const uint64_t nb = (P.n_out + 4 * RUNW - 1) / (4 * RUNW);                                                     \
+            const uint64_t per = (256 / LW) * RUNW, nb = (P.n_out + per - 1) / per;                                        \
             if (nb <= 0x7fffffffull) {                                                                                     \
                 const dim3 g((unsigned)nb), b(256);                                                                        \
                 switch (P.flag & 7) {                                                                                      \
-                    case 0: wsinterpd_lanesum_kernel<0, TY, RUNW><<<g, b, 0, s>>>(P); break;                               \
-                    case 1: case 4: wsinterpd_lanesum_kernel<1, TY, RUNW><<<g, b, 0, s>>>(P); break;                       \
-                    case 2: wsinterpd_lanesum_kernel<2, TY, RUNW><<<g, b, 0, s>>>(P); break;                               \
-                    case 3: wsinterpd_lanesum_kernel<3, TY, RUNW><<<g, b, 0, s>>>(P); break;                               \
-                    case 5: wsinterpd_lanesum_kernel<5, TY, RUNW><<<g, b, 0, s>>>(P); break;                               \
+                    case 0: wsinterpd_lanesum_kernel<0, TY, RUNW, LW><<<g, b, 0, s>>>(P); break;                           \
+                    case 1: case 4: wsinterpd_lanesum_kernel<1, TY, RUNW, LW><<<g, b, 0, s>>>(P); break;                   \
+                    case 2: wsinterpd_lanesum_kernel<2, TY, RUNW, LW><<<g, b, 0, s>>>(P); break;                           \
+                    case 3: wsinterpd_lanesum_kernel<3, TY, RUNW, LW><<<g, b, 0, s>>>(P); break;                           \
+                    case 5: wsinterpd_lanesum_kernel<5, TY, RUNW, LW><<<g, b, 0, s>>>(P); break;                           \
                     default: return hipErrorInvalidValue;                                                                  \
                 }                                                                                                          \
                 return hipGetLastError();                                                                                  \
             }                                                                                                              \
         } while (0)
-        if (runw == 2) QLS(2); else if (runw == 8) QLS(8); else QLS(4);
+        if (P.ssz[0] <= 32) QLS(4, 32);
+        else if (runw == 2) QLS(2, 64); else if (runw == 8) QLS(8, 64); else QLS(4, 64);
 #undef QLS
     }
     // grid: x = blocks along the fastest kept dimension, (y, z) = the other kept dimensions flattened

@@ -364,9 +364,9 @@ def wsinterpd(x, t, dim=1, w=1, sdim=None, interp="linear", extrapval=float("nan
     # row apart -- the column-major copies (time fastest: lanes along the sampled dimension, sums by uniform strides) are the better layout there
     nz = [k for k in range(1, nd) if xd.shape[k] > 1]
     fastest = min(nz, key=lambda k: xd.stride(k)) if nz else 0
-    # (round 6: ONE summed dimension of >= 32 terms, unit stride: the library sums across the lanes of a wave -- csrc/wsinterpd.hip
+    # (round 6: ONE summed dimension of >= 16 terms, unit stride: the library sums across the lanes of a wave -- csrc/wsinterpd.hip
     #  wsinterpd_lanesum_kernel -- and the record is used where it lies; QDAS_WS_NO_LANESUM: the transposed form, for A/B runs)
-    lanesum = (len([k for k in sd if xd.shape[k - 1] > 1 or td.shape[k - 1] > 1]) == 1 and nz and xd.stride(fastest) == 1 and max(xd.shape[fastest], td.shape[fastest]) >= 32
+    lanesum = (len([k for k in sd if xd.shape[k - 1] > 1 or td.shape[k - 1] > 1]) == 1 and nz and xd.stride(fastest) == 1 and max(xd.shape[fastest], td.shape[fastest]) >= 16
                and not os.environ.get("QDAS_WS_NO_LANESUM"))
     if nz and T > 1 and xd.stride(fastest) < xd.stride(0) and (fastest + 1) in sd and not lanesum:
         xd, td = _colmajor(xd).permute(*reversed(range(nd))), _colmajor(td).permute(*reversed(range(nd)))

@@ -130,11 +130,11 @@ def test_wsinterpd_matches_the_oracle_with_phasor_extrapolation_and_sums():
 
 @pytest.mark.parametrize("prec", ["single", "double", "halfT"])
 @pytest.mark.parametrize("terp", ["nearest", "linear", "cubic", "lanczos3"])
-@pytest.mark.parametrize("M,wkind,ev", [(128, "none", 0.0), (33, "real", np.nan), (200, "complex", 0.0), (64, "real", 2.5), (31, "real", 0.0)])
+@pytest.mark.parametrize("M,wkind,ev", [(128, "none", 0.0), (33, "real", np.nan), (200, "complex", 0.0), (64, "real", 2.5), (31, "real", 0.0), (12, "real", 0.0)])
 def test_wsinterpd_torch_order_record_summed_over_its_fastest_dimension(prec, terp, M, wkind, ev, monkeypatch):
     """A record in torch order (last dimension fastest) summed over that dimension: the lanes of a wave run along the sum (``wsinterpd_lanesum_kernel``;
     round 5 transposed the record first).  Against the float64 oracle, and against the transposed form (``QDAS_WS_NO_LANESUM``): the same terms, added in
-    another order.  Delays out of the record, an infinite one and NaN ``extrapval`` (omitted by sums) included; ``M = 31``: below the kernel's 32 terms."""
+    another order.  Delays out of the record, an infinite one and NaN ``extrapval`` (omitted by sums) included; ``M = 31``: two outputs per wave; ``M = 12``: below the kernel's 16 terms."""
     import torch
     from qups_amd.interpd import wsinterpd
     rng = np.random.default_rng(19)
@@ -164,14 +164,14 @@ def test_wsinterpd_torch_order_record_summed_over_its_fastest_dimension(prec, te
 
 @pytest.mark.parametrize("seed", range(24))
 def test_wsinterpd_lane_sum_random_layouts(seed, monkeypatch):
-    """Random index spaces of 3 - 5 dimensions whose ONE summed dimension is the fastest in memory (32 - 150 terms): broadcast dimensions in x / t / w, any
+    """Random index spaces of 3 - 5 dimensions whose ONE summed dimension is the fastest in memory (16 - 150 terms: two outputs per wave up to 32): broadcast dimensions in x / t / w, any
     memory order of the others, sampling dimension anywhere -- the lane-sum kernel against the float64 oracle and the one-output-per-lane kernel."""
     import torch
     from qups_amd.interpd import wsinterpd
     r = np.random.default_rng(4100 + seed)
     nd = int(r.integers(3, 6))
     dim = int(r.integers(1, nd))                                   # sampling dimension (1-based), not the last one
-    S = int(r.choice([32, 33, 64, 65, 100, 128, 150]))
+    S = int(r.choice([16, 17, 31, 32, 33, 64, 65, 100, 128, 150]))
     size = [int(r.integers(1, 6)) for _ in range(nd)]
     size[nd - 1] = S                                                # the summed, fastest dimension
     T, I = int(r.integers(20, 90)), int(r.integers(1, 40))
