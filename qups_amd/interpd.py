@@ -121,6 +121,7 @@ def das_lut(x, tau_rx, tau_tx, *, interp="linear", w=None, keep_rx=False, keep_t
 
 
 _SHIFT_MEMO: "collections.OrderedDict" = None          # device copies of the last few (shift, w) tables handed over as HOST arrays
+_SHIFT_MEMO_LOCK = __import__("threading").Lock()      # (focusTx from several host threads)
 
 
 def _shift_tables(shift, w, M, dbl, cplx_data, dev, torch):
@@ -139,12 +140,13 @@ def _shift_tables(shift, w, M, dbl, cplx_data, dev, torch):
         if wa is not None:
             h.update(str((wa.dtype.str, wa.shape)).encode()); h.update(wa.tobytes())
         key = (h.digest(), sa.shape, bool(dbl), bool(cplx_data), str(dev))
-        if _SHIFT_MEMO is None:
-            _SHIFT_MEMO = collections.OrderedDict()
-        hit = _SHIFT_MEMO.get(key)
-        if hit is not None:
-            _SHIFT_MEMO.move_to_end(key)
-            return hit
+        with _SHIFT_MEMO_LOCK:
+            if _SHIFT_MEMO is None:
+                _SHIFT_MEMO = collections.OrderedDict()
+            hit = _SHIFT_MEMO.get(key)
+            if hit is not None:
+                _SHIFT_MEMO.move_to_end(key)
+                return hit
     sh = (shift if _is_torch(shift) else torch.from_numpy(np.asarray(shift, np.float64))).to(dev)
     if sh.ndim != 2 or sh.shape[0] != M:
         raise DasError("shift_sum: shift must be M x Mo")
@@ -162,9 +164,10 @@ def _shift_tables(shift, w, M, dbl, cplx_data, dev, torch):
             wc = wt.to(rt).t().contiguous()
     out = (shc, wc, w_real)
     if key is not None:
-        _SHIFT_MEMO[key] = out
-        while len(_SHIFT_MEMO) > 8:
-            _SHIFT_MEMO.popitem(last=False)
+        with _SHIFT_MEMO_LOCK:
+            _SHIFT_MEMO[key] = out
+            while len(_SHIFT_MEMO) > 8:
+                _SHIFT_MEMO.popitem(last=False)
     return out
 
 
