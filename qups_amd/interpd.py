@@ -164,6 +164,7 @@ def _shift_tables(shift, w, M, dbl, cplx_data, dev, torch):
             wc = wt.to(rt).t().contiguous()
     out = (shc, wc, w_real)
     if key is not None:
+        torch.cuda.current_stream(dev).synchronize()                  # (once per table: a later call may use the copies from another stream)
         with _SHIFT_MEMO_LOCK:
             _SHIFT_MEMO[key] = out
             while len(_SHIFT_MEMO) > 8:
