@@ -262,17 +262,24 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
         const uint64_t m2 = find(m + 1, kmin2, kmax2, alo2, ahi2);
         const int kl2 = m2 < P.M ? klass(kmin2, kmax2) : 0;
         if (m2 < P.M && kl2 == 0) fetch(m2, kmin2, (int)((int64_t)kmax2 - kmin2 + TPB + K - 1));       // in flight during the arithmetic below
+        // the entries of the mask-free loops come through the SCALAR cache (uniform addresses; the loads of all eight terms are issued together): as broadcast
+        // LDS reads they were a third of the kernel's LDS instructions.  -DQDAS_SS_ENT_LDS: from LDS, for A/B runs
+#ifdef QDAS_SS_ENT_LDS
+#define SS_ENT(j) ent[j]
+#else
+#define SS_ENT(j) tab[m + P.M * (mo0 + (uint64_t)(j))]
+#endif
         const bool all_plain = std::is_same<DT, float2>::value && kl != 2 && nmo == SS_MOB && ahi != -2 && P.To < (1ull << 30);
         if (all_plain && (int64_t)alo <= tb + wv0 && (int64_t)ahi >= tb + wv0 + 64 * TPT - 1) {   // (per wave; scalar)
 #pragma unroll
             for (int j = 0; j < SS_MOB; ++j) {                                   // (straight-line code: an exit per term costs a copy of every accumulator)
-                const ShiftEntry<R> e = ent[j];
+                const ShiftEntry<R> e = SS_ENT(j);
                 lean_term(std::false_type{}, e, j, e.k0 - kmin);
             }
         } else if (all_plain) {
 #pragma unroll
             for (int j = 0; j < SS_MOB; ++j) {
-                const ShiftEntry<R> e = ent[j];
+                const ShiftEntry<R> e = SS_ENT(j);
                 lean_term(std::true_type{}, e, j, e.k0 - kmin);
             }
         } else {
