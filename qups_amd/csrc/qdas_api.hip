@@ -2052,7 +2052,7 @@ extern "C" int qdas_wsinterpd(const qdas_wsinterpd_desc *d, void *y, void *strea
     // one summed dimension along which x is contiguous (a record in torch order -- last dimension fastest -- summed over that dimension): the lanes of a
     // wave take the terms of ONE output and add up across the wave (wsinterpd.hip wsinterpd_lanesum_kernel) instead of one output per lane, every tap a
     // 64-lane gather with one lane per memory row
-    p.lanesum_ok = (p.nsd == 1 && p.sxs[0] == 1 && p.ssz[0] >= 16 && d->T > 1 && p.x_tstride > 1 && p.n_out < (1ull << 32) && !getenv("QDAS_WS_NO_LANESUM")) ? 1 : 0;
+    p.lanesum_ok = (p.nsd == 1 && p.sxs[0] == 1 && p.ssz[0] >= 16 && p.ssz[0] < (1u << 31) && d->T > 1 && p.x_tstride > 1 && p.n_out < (1ull << 32) && !getenv("QDAS_WS_NO_LANESUM")) ? 1 : 0;
     if (p.n_out == 0) return QDAS_OK;
     if (p.n_out >= (1ull << 39)) return fail(QDAS_EUNSUPPORTED, "wsinterpd: too many outputs for one launch");
     hipStream_t s = (hipStream_t)stream;
