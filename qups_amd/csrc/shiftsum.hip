@@ -96,7 +96,10 @@ __global__ void __launch_bounds__(256) shift_block_kernel(const ShiftEntry<R> *_
 }
 
 // DT: sample type (float2 / double2 / float / double), R its real type, TPT output samples per lane
-template <int K, typename DT, typename R, int TPT>
+// GW: outputs of a 64-lane group.  64, or 65 - K (fp32 complex data, round 6): the lanes of a group then read ONE sample each per term and pass it down the
+// wave (v_mov_b32 wave_shl:1, K - 1 times) -- a lane's K taps are its own sample and those of the next K - 1 lanes; the last K - 1 lanes of a group only
+// supply taps.  A quarter of the LDS bytes (the kernel is LDS-bound at K reads per output) for K - 1 lane moves per tap.
+template <int K, typename DT, typename R, int TPT, int GW = 64>
 __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ss_lds[];
     DT *const win_base = (DT *)ss_lds;
@@ -106,7 +109,8 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
     uint32_t *ent_w = ent_base;
     const ShiftEntry<R> *ent = (const ShiftEntry<R> *)ent_w;
     constexpr bool CPLX = sizeof(DT) == 2 * sizeof(R);
-    constexpr int TPB = 256 * TPT;
+    constexpr int TPB = 4 * GW * TPT;                                           // outputs of a workgroup (4 waves)
+    static_assert(GW == 64 || (GW == 65 - K && std::is_same<DT, float2>::value && K > 1), "group width");
     const ShiftEntry<R> *__restrict__ tab = (const ShiftEntry<R> *)P.tab;
     const uint32_t tid = threadIdx.x;
     const int64_t tb = (int64_t)blockIdx.x * TPB;
@@ -135,7 +139,8 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
         __syncthreads();
     };
     // a wave owns 64 x TPT CONSECUTIVE outputs of the block (lane + 64 q within them): whether a term's support covers them all is a per-wave question
-    const int wv0 = __builtin_amdgcn_readfirstlane((int)(tid / 64) * (64 * TPT)), lt0 = wv0 + (int)(tid % 64);
+    const int wv0 = __builtin_amdgcn_readfirstlane((int)(tid / 64) * (GW * TPT)), lt0 = wv0 + (int)(tid % 64);
+    const bool act = GW == 64 || (int)(tid % 64) < GW;                            // (the other lanes of a group only supply taps)
     // all lanes, their TPT outputs, synthesised transmit j.  rel = (first tap of local output 0) - (window start): every lane's taps lie inside the
     // staged window whether or not its output is in support, so the reads need no guard; 32-bit index math throughout
     auto term = [&](const ShiftEntry<R> &e, int j, int rel) {
@@ -144,8 +149,8 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
         const bool plain = e.wi == (R)0;                                                        // real weight: already in c[]
 #pragma unroll
         for (int q = 0; q < TPT; ++q) {
-            const int lt = lt0 + 64 * q;
-            const bool ok = lt >= lo && lt <= hi;
+            const int lt = lt0 + GW * q;
+            const bool ok = act && lt >= lo && lt <= hi;
             const DT *tp = win + (lt + rel);
             if constexpr (std::is_same<DT, float2>::value) {                                    // packed fp32: one v_pk_fma_f32 per tap
                 v2f v = {0.f, 0.f};
@@ -175,9 +180,19 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
             const DT *tp = win + (lt0 + rel);
             float2 sm[TPT][K];
 #pragma unroll
-            for (int q = 0; q < TPT; ++q)
+            for (int q = 0; q < TPT; ++q) {
+                if constexpr (GW == 64) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) sm[q][k] = tp[64 * q + k];
+                    for (int k = 0; k < K; ++k) sm[q][k] = tp[64 * q + k];
+                } else {                                                          // one read; tap k = the sample of lane + k (all lanes active here: a lane move
+                    sm[q][0] = tp[GW * q];                                        //  reads nothing from a lane that is masked off)
+#pragma unroll
+                    for (int k = 1; k < K; ++k) {
+                        sm[q][k].x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm[q][k - 1].x), 0x130, 0xf, 0xf, true));
+                        sm[q][k].y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sm[q][k - 1].y), 0x130, 0xf, 0xf, true));
+                    }
+                }
+            }
             if constexpr (!MASK) {
 #pragma unroll
                 for (int k = 0; k < K; ++k)
@@ -191,7 +206,7 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
                 const uint32_t len = (uint32_t)(e.thi - e.tlo);
 #pragma unroll
                 for (int q = 0; q < TPT; ++q) {
-                    if ((uint32_t)(lt0 + 64 * q - lo) <= len) {
+                    if (act && (uint32_t)(lt0 + GW * q - lo) <= len) {
                         v2f a = {ar[q][j], ai[q][j]};
 #pragma unroll
                         for (int k = 0; k < K; ++k) a = (v2f){sm[q][k].x, sm[q][k].y} * e.c[k] + a;
@@ -270,7 +285,7 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
 #define SS_ENT(j) tab[m + P.M * (mo0 + (uint64_t)(j))]
 #endif
         const bool all_plain = std::is_same<DT, float2>::value && kl != 2 && nmo == SS_MOB && ahi != -2 && P.To < (1ull << 30);
-        if (all_plain && (int64_t)alo <= tb + wv0 && (int64_t)ahi >= tb + wv0 + 64 * TPT - 1) {   // (per wave; scalar)
+        if (all_plain && (int64_t)alo <= tb + wv0 && (int64_t)ahi >= tb + wv0 + GW * TPT - 1) {   // (per wave; scalar)
 #pragma unroll
             for (int j = 0; j < SS_MOB; ++j) {                                   // (straight-line code: an exit per term costs a copy of every accumulator)
                 const ShiftEntry<R> e = SS_ENT(j);
@@ -301,8 +316,8 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
         DT *__restrict__ yo = (DT *)P.y + ((f * P.Mo + mo0 + j) * P.N + n) * P.To;
 #pragma unroll
         for (int q = 0; q < TPT; ++q) {
-            const int64_t t = tb + (int64_t)lt0 + 64 * q;
-            if (t < (int64_t)P.To) {
+            const int64_t t = tb + (int64_t)lt0 + GW * q;
+            if (act && t < (int64_t)P.To) {
                 if constexpr (CPLX) { DT v; v.x = ar[q][j]; v.y = ai[q][j]; yo[t] = v; }
                 else yo[t] = ar[q][j];
             }
@@ -310,7 +325,7 @@ __global__ void __launch_bounds__(256) shift_sum_kernel(const ShiftParams P) {
     }
 }
 
-template <typename DT, typename R, int TPT>
+template <typename DT, typename R, int TPT, bool DPP = false>
 static hipError_t launch_shift_t(const ShiftParams &P, int interp, const void *sh, const void *w, int w_real, hipStream_t s) {
     const uint64_t count = P.M * P.Mo;
     Scratch scratch(s);                                  // (the stream's arena: scratch.hip)
@@ -334,17 +349,20 @@ static hipError_t launch_shift_t(const ShiftParams &P, int interp, const void *s
     if (!blk) return hipErrorOutOfMemory;
     shift_block_kernel<R><<<(unsigned)((P.M * p.mo_blocks + 255) / 256), 256, 0, s>>>(tab, P.M, P.Mo, p.mo_blocks, blk);
     p.blk = blk;
-    constexpr int TPB = 256 * TPT;
+    const int Kt = interp_taps(interp);
+    const int gw = DPP && Kt > 1 ? 65 - Kt : 64;
+    const uint64_t TPB = 4ull * gw * TPT;
     const dim3 g((unsigned)((P.To + TPB - 1) / TPB), (unsigned)P.N, (unsigned)(p.mo_blocks * P.F));
     const size_t lds = sizeof(DT) * SS_CAP + 2 * sizeof(ShiftEntry<R>) * SS_MOB;
     const int K = interp_taps(interp);
-#define QSS(KK)                                                                                                                         \
+#define QSS(KK, GWW)                                                                                                                    \
     do {                                                                                                                                \
-        auto kfn = shift_sum_kernel<KK, DT, R, TPT>;                                                                                     \
+        auto kfn = shift_sum_kernel<KK, DT, R, TPT, GWW>;                                                                                \
         e = hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
         if (e == hipSuccess) kfn<<<g, 256, lds, s>>>(p);                                                                                \
     } while (0)
-    if (K == 1) QSS(1); else if (K == 2) QSS(2); else QSS(4);
+    if constexpr (DPP) { if (K == 1) QSS(1, 64); else if (K == 2) QSS(2, 63); else QSS(4, 61); }
+    else { if (K == 1) QSS(1, 64); else if (K == 2) QSS(2, 64); else QSS(4, 64); }
 #undef QSS
     if (e == hipSuccess) e = hipGetLastError();
     return e;
@@ -362,6 +380,13 @@ hipError_t launch_shift_sum(const ShiftParams &P, int dtype, int cplx, int inter
             if (cov * 8 < waste * 8 && (waste == ~0ull || (waste - cov) * 16 > P.To)) { waste = cov; best = tpt; }   // a smaller block only if it saves > 6 % of the outputs
         }
         if (const char *e = getenv("QDAS_SS_TPT")) { const int v = atoi(e); if (v >= 2 && v <= 4) best = v; }      // (experiments)
+        // taps shared across lanes (groups of 65 - K outputs, shift_sum_kernel GW): measured at 3 outputs per lane, 0.90 of the time per block -- taken when it
+        // needs no more blocks per trace than the 64-wide groups do (C1: 2 190 outputs = 3 x 732 either way).  QDAS_SS_NO_DPP: off; QDAS_SS_DPP=1: always
+        if (cplx && interp_taps(interp) > 1 && !getenv("QDAS_SS_NO_DPP")) {
+            const uint64_t tpd = 12ull * (65 - (uint64_t)interp_taps(interp));
+            const bool force = getenv("QDAS_SS_DPP") != nullptr;
+            if (force || (best == 3 && (P.To + tpd - 1) / tpd <= (P.To + 767) / 768)) return launch_shift_t<float2, float, 3, true>(P, interp, sh, w, w_real, s);
+        }
         if (cplx) return best == 4 ? launch_shift_t<float2, float, 4>(P, interp, sh, w, w_real, s) : best == 3 ? launch_shift_t<float2, float, 3>(P, interp, sh, w, w_real, s)
                                                                                                                  : launch_shift_t<float2, float, 2>(P, interp, sh, w, w_real, s);
         return best == 4 ? launch_shift_t<float, float, 4>(P, interp, sh, w, w_real, s) : best == 3 ? launch_shift_t<float, float, 3>(P, interp, sh, w, w_real, s)

@@ -273,12 +273,17 @@ def _shift_ref(x, shift, w, interp, To):
 
 @pytest.mark.parametrize("interp", ["nearest", "linear", "cubic", "lanczos3", "cubic_dev"])
 @pytest.mark.parametrize("dtype", ["complex64", "complex128", "float32", "float64"])
-def test_shift_sum_matches_the_oracle_and_the_general_kernel(interp, dtype):
+@pytest.mark.parametrize("dpp", [False, True])
+def test_shift_sum_matches_the_oracle_and_the_general_kernel(interp, dtype, dpp, monkeypatch):
     """qdas_shift_sum (transmit synthesis: one offset per (element, synthesised transmit)) against the float64 oracle sampler and against
     the general single-delay kernel fed the materialised positions; offsets beyond both ends of the record, zero and complex weights, an
     odd block of synthesised transmits, frames, more and fewer output samples than the record holds"""
     import torch
     from qups_amd.interpd import shift_sum, wsinterpd
+    if dpp:
+        if dtype != "complex64":
+            pytest.skip("lane-to-lane taps: fp32 complex data only")
+        monkeypatch.setenv("QDAS_SS_DPP", "1")
     rng = np.random.default_rng(31)
     T, N, M, Mo, F = 700, 5, 11, 13, 2
     cplx = dtype.startswith("complex")
@@ -350,11 +355,14 @@ def test_shift_sum_offsets_too_far_apart_for_one_window_and_no_weights():
 
 @pytest.mark.parametrize("dtype,interp,Mo", [("complex64", "cubic", 8), ("complex64", "linear", 5), ("float32", "lanczos3", 8), ("complex128", "cubic", 3),
                                              ("complex64", "nearest", 16)])
-def test_shift_sum_zero_tail_that_is_not_stored(dtype, interp, Mo):
+@pytest.mark.parametrize("dpp", [False, True])
+def test_shift_sum_zero_tail_that_is_not_stored(dtype, interp, Mo, dpp, monkeypatch):
     """``tpad`` (``include/qdas.h``): the record counts as followed by zeros -- bit for bit what the same call returns on a zero-padded copy
     (``focusTx`` no longer makes that copy), on the paths with and without support masks; and ``focusTx`` itself against its padded form."""
     import torch
     from qups_amd.interpd import shift_sum
+    if dpp:
+        monkeypatch.setenv("QDAS_SS_DPP", "1")
     rng = np.random.default_rng(77)
     T, N, M, pad = 1500, 3, 6, 211
     x = rng.standard_normal((T, N, M)).astype(np.float32)
@@ -375,12 +383,14 @@ def test_shift_sum_zero_tail_that_is_not_stored(dtype, interp, Mo):
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("QDAS_SHIFT_FUZZ", "32"))))
-def test_shift_sum_random_configuration(seed):
+def test_shift_sum_random_configuration(seed, monkeypatch):
     """random record / output lengths (around the 256 x {2,3,4}-sample blocks), element and transmit counts (ragged blocks of 8), frames, types,
     interpolators, offsets (clustered: one window per element; scattered: a window per transmit), sparse real / complex weights"""
     import torch
     from qups_amd.interpd import shift_sum
     r = np.random.default_rng(12000 + seed)
+    if seed % 2:                                        # complex64 data: taps passed from lane to lane (groups of 65 - K outputs) whatever the block count says
+        monkeypatch.setenv("QDAS_SS_DPP", "1")
     T = int(r.choice([5, 64, 255, 256, 257, 700, 1023, 1025, 2100, 5000]))
     To = int(r.choice([T, T, max(1, T // 2), T + 37, 1]))
     N, M, Mo, F = int(r.integers(1, 4)), int(r.choice([1, 2, 7, 12])), int(r.choice([1, 3, 8, 9, 17])), int(r.choice([1, 1, 2]))
