@@ -233,3 +233,37 @@ def test_colmajor_layout_kernel(shape, dtype):
     ref = t.permute(*reversed(range(t.ndim))).contiguous()
     assert out.shape == ref.shape and out.is_contiguous() and torch.equal(torch.view_as_real(out) if out.is_complex() else out,
                                                                             torch.view_as_real(ref) if ref.is_complex() else ref)
+
+
+@pytest.mark.parametrize("seq,M", [("FC", 1), ("FC", 2), ("DV", 1)])
+def test_roles_swapped_onto_one_or_two_transmits_is_reproducible(seq, M, monkeypatch):
+    """Round 6, fuzz seed 126301 with hiprtc builds forced: 48 receivers, ONE focused (or diverging) transmit, a coarse pixel grid -- the plan swaps the roles
+    of the apertures (the transmit, listed once per side of its focal plane, becomes the stage side; 16-element stages of 384-sample windows).  The plan-
+    specialised build of that shape gave images that differed from run to run in one wave of a tile; such plans now keep the build on demand
+    (``csrc/qdas_api.hip`` ``plan_jit``).  Here: noise frames (smooth targets hide a wrong sample), six runs bit for bit the same, against the oracle."""
+    import torch
+    from oracle import das_oracle as O
+    from qups_amd import DasPlan, build_problem, parse_options
+    from qups_amd.das_spec import _cast_data, _colmajor
+    monkeypatch.setenv("QDAS_TILE_Z", "8")
+    I1, I2, coarse = 184, 24, 5
+    case = make_case(seq=seq, interp="cubic", seed=126301, N=48, M=M, I1=I1, I2=I2, zlim=(4e-3, 4e-3 + I1 * 0.1e-3 * coarse), xspan=2e-3 * coarse, data="noise")
+    xs = np.swapaxes(case["x"], 1, 2)[..., None]
+    xt = torch.from_numpy(np.ascontiguousarray(xs))
+    opts = list(case["opt"]) + ["interp", "cubic", "input-precision", "single", "transpose", True]
+    prob = build_problem("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), case["t0"], case["fs"], case["c"], parse_options(xt, opts))
+    ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], case["x"], case["t0"], case["fs"], cinv_f32(case["c"]), VS=case["VS"], DV=case["DV"],
+                     interp="cubic", apod=(), fmod=0.0).reshape(-1, order="F")
+    for jit in (True, False):
+        with DasPlan(prob, kernel=2, jit=jit) as plan:
+            assert "roles swapped" in plan.kernel_name(), plan.kernel_name()
+            if jit:
+                assert "[jit " not in plan.kernel_name(), plan.kernel_name()
+            xc = _colmajor(_cast_data(xt, prob.prec, plan.device))
+            ys = [plan.execute_colmajor(xc, 1).clone() for _ in range(6)]
+            torch.cuda.synchronize()
+            for y in ys[1:]:
+                assert torch.equal(y, ys[0]), (jit, plan.kernel_name())
+            out = ys[0].to(torch.complex64).cpu().numpy().reshape(-1)
+            tol = 1e-4 * (2 * coarse if plan.fallback_tiles() else 1)
+            assert rel_err(out, ref) <= tol, (jit, plan.kernel_name(), rel_err(out, ref))

@@ -74,7 +74,7 @@ _SEED0 = int(os.environ.get("QDAS_FUZZ_OFFSET", "0"))          # soak runs: QDAS
 
 # Seeds that found a bug once, run with every suite whatever the offset.  50160 (round 6): 64-transmit stages of a one-set hiprtc build with a
 # transmit weight table holding a zero and a split aperture -- the stage's non-zero masks were 32 bits wide and the image came out all zero.
-_PINNED = [50160]
+_PINNED = [50160]          # (126301 with hiprtc builds forced -- roles swapped onto ONE transmit, images that differed from run to run: tests/test_gpu_edges.py)
 _SEEDS = list(range(_SEED0, _SEED0 + int(os.environ.get("QDAS_FUZZ_SEEDS", "128"))))
 
 
@@ -160,8 +160,10 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
     po = parse_options(xt, opts)
     prob = build_problem(fun, case["Pi"], case["Pr"], case["Pv"], case["Nv"], tuple(xt.shape), t0, case["fs"], cval, po)
     plan = DasPlan(prob, kernel=2, jit=c["jit"], **kw)
-    if c["jit"] and fun != "BF":                                        # ('BF' runs the prebuilt kernel)
-        assert "[jit " in plan.kernel_name(), (c, plan.kernel_name())
+    if os.environ.get("QDAS_FUZZ_DEBUG"):
+        print("plan:", plan.kernel_name(), "tile", plan.tile_shape(), "wave", plan.wave_shape(), "split", plan.aperture_split(), "fallback tiles", plan.fallback_tiles())
+    if c["jit"] and fun != "BF":                                        # ('BF' runs the prebuilt kernel; so do plans whose roles are swapped onto a short stage side)
+        assert "[jit " in plan.kernel_name() or "roles swapped" in plan.kernel_name(), (c, plan.kernel_name())
     if c.get("headline") and not c["t0vec"]:                            # (a per-transmit t0 is not reciprocal: general kernel)
         # (mirror-symmetric draws -- no weights, one t0, the whole image -- run reciprocal + lateral-mirror mode: four sets of 16 transmits)
         # (fp32: the reciprocity-folded frame -- 32-transmit stages with or without the mirror mode (16 when its tiles need 192-sample windows);
@@ -207,7 +209,8 @@ def test_tiled_kernel_random_configuration(seed, monkeypatch):
             e = np.abs(out - refv).max(axis=1) / den
             worst = np.argsort(e)[::-1][:12]
             i0 = kw.get("i_begin", 0)
-            print("bad pixels:", int((e > tol).sum()), "of", e.size)
+            print("bad pixels:", int((e > tol).sum()), "of", e.size, "frame", f, "|", plan.kernel_name(), "tile", plan.tile_shape(), "wave", plan.wave_shape(),
+                  "split", plan.aperture_split(), "fallback tiles", plan.fallback_tiles())
             for w in worst:
                 print("  i1", int((w + i0) % c["I1"]), "col", int((w + i0) // c["I1"]), "err", float(e[w]), "tiled", out[w, 0], "generic", yg[w, 0], "oracle", refv[w, 0])
         if err > tol:
