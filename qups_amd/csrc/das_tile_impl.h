@@ -47,6 +47,9 @@
 //  * Cold fp64 code (transmit-block refresh, generated apodization) is called, not inlined (tile_util.h): no instantiation
 //    uses scratch memory (tests/test_build_regs.py).
 #include "tile_params.h"
+#ifndef QDAS_DBG_SYNC
+#define QDAS_DBG_SYNC 0           // race hunting (hiprtc builds: QDAS_JIT_DEFINES=QDAS_DBG_SYNC=<bits>): extra waits / barriers in the stage loop, see run()
+#endif
 #ifndef QDAS_ONEACC_PLAIN
 #define QDAS_ONEACC_PLAIN 0      // tuning builds: the plain (not software-pipelined) pair loop for the long-stage two-window-set fp32 builds
 #endif
@@ -656,6 +659,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         }
     };
     if (nstage) { wst_load(n_first, blk(0)); wst_store(0); }
+    if constexpr ((QDAS_DBG_SYNC & 16) != 0) __syncthreads();
 #pragma unroll
     for (int b = 0; b < NBUF - 1; ++b)
         if ((uint32_t)b < nstage) dma_next(b);
@@ -666,6 +670,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
     uint32_t cr = 0, k = 0, n = n_first, m0 = blk(0);
     for (uint32_t st = 0; st < nstage; ++st) {
         timer.mark(0);
+        if constexpr ((QDAS_DBG_SYNC & 1) != 0) __syncthreads();
         const bool more = st + (NBUF - 1) < nstage;
         // receiver of the next stage: with one stage of staging in flight that is where the DMA front stands (no LDS round trip)
         const uint32_t n_next = (NBUF == 2 && C::ACT) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)vpn) : nsel(k + 1 == klim(m0) ? 0u : k + 1);
@@ -700,6 +705,8 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
         if constexpr (C::LUT) { if (st + 1 < nstage) tbn = P.lut_rx[ipx + Ilut * n_next]; }
         if (st + 1 < nstage) wst_load(n_next, k + 1 == klim(m0) ? blk(cr + 1) : m0);
         if (dma_now) dma_go((buf + NBUF - 1) % NBUF);            // lands during the next NBUF-1 stages
+        if constexpr ((QDAS_DBG_SYNC & 32) != 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr ((QDAS_DBG_SYNC & 2) != 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); }
         timer.mark(1);
         if constexpr (C::F64) {
             if (k == 0) {                              // new transmit block: refresh the block residuals (cold: once per N stages)
@@ -746,6 +753,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
             }
         }
         timer.mark(2);
+        if constexpr ((QDAS_DBG_SYNC & 4) != 0) __syncthreads();
         if constexpr (C::F64) {                        // everything in fp64; the low word of (t + 1.5*2^52) IS rint(t)
             const int bn = rec_b;
             const double rbd = s_at(n, rec_x, rec_y, rec_z) - (double)bn;
@@ -781,6 +789,7 @@ template <class C> template <bool CHECK> __device__ __forceinline__ void Tile<C>
                 pairs_plain<CHECK, true>(n, m0, bn, rb, cbase, phB, wst_off + (uint32_t)buf * WBUF, wmask, xmask);
             }
         }
+        if constexpr ((QDAS_DBG_SYNC & 8) != 0) __syncthreads();
         if constexpr (!hooks::no_fair_prio) __builtin_amdgcn_s_setprio(3);     // stage epilogue / next preamble at full priority (tile_pairs.h)
         if (!hooks::no_stage_dma && more && dma_late) dma_next((buf + NBUF - 1) % NBUF);
         if (st + 1 < nstage) wst_store((buf + 1) % NBUF);          // (the barrier below publishes it)

@@ -478,6 +478,13 @@ class DasPlan:
         self._lock = threading.RLock()          # execute / delays / close exclude each other: a cached plan evicted by another thread is never freed mid-call
         with torch.cuda.device(dev):
             _lib.check(self.lib.qdas_plan_create(C.byref(self._h), C.byref(d)))
+            # why a plan that asked for a hiprtc build runs the stock kernel after all (no compiler, a build that would spill registers, ...): the
+            # library leaves the reason in qdas_last_error() and carries on
+            self._jit_note = (self.lib.qdas_last_error() or b"").decode(errors="replace") if jit else ""
+
+    def jit_note(self) -> str:
+        """``""``, or why ``jit=True`` did not give a plan-specialised kernel (``QDAS_PLAN_JIT: ... -- using the prebuilt kernel``)."""
+        return self._jit_note if "QDAS_PLAN_JIT" in self._jit_note else ""
 
     # -- introspection
     @property

@@ -238,9 +238,10 @@ def test_colmajor_layout_kernel(shape, dtype):
 @pytest.mark.parametrize("seq,M", [("FC", 1), ("FC", 2), ("DV", 1)])
 def test_roles_swapped_onto_one_or_two_transmits_is_reproducible(seq, M, monkeypatch):
     """Round 6, fuzz seed 126301 with hiprtc builds forced: 48 receivers, ONE focused (or diverging) transmit, a coarse pixel grid -- the plan swaps the roles
-    of the apertures (the transmit, listed once per side of its focal plane, becomes the stage side; 16-element stages of 384-sample windows).  The plan-
-    specialised build of that shape gave images that differed from run to run in one wave of a tile; such plans now keep the build on demand
-    (``csrc/qdas_api.hip`` ``plan_jit``).  Here: noise frames (smooth targets hide a wrong sample), six runs bit for bit the same, against the oracle."""
+    of the apertures (the transmit becomes the stage side; 16-element stages of 384-sample windows).  The plan-specialised build of that shape SPILLED
+    352 registers, and a register spilled between an inline-asm LDS read and the hand-placed wait for it is stored before its data has arrived: images
+    that differed from run to run in one wave of a tile.  A hiprtc build that uses scratch memory is no longer used (``csrc/qdas_api.hip``
+    ``jit_get_kernel_nospill``).  Here: noise frames (smooth targets hide a wrong sample), six runs bit for bit the same, against the oracle."""
     import torch
     from oracle import das_oracle as O
     from qups_amd import DasPlan, build_problem, parse_options
@@ -257,8 +258,6 @@ def test_roles_swapped_onto_one_or_two_transmits_is_reproducible(seq, M, monkeyp
     for jit in (True, False):
         with DasPlan(prob, kernel=2, jit=jit) as plan:
             assert "roles swapped" in plan.kernel_name(), plan.kernel_name()
-            if jit:
-                assert "[jit " not in plan.kernel_name(), plan.kernel_name()
             xc = _colmajor(_cast_data(xt, prob.prec, plan.device))
             ys = [plan.execute_colmajor(xc, 1).clone() for _ in range(6)]
             torch.cuda.synchronize()
