@@ -48,7 +48,7 @@ def test_mirror_mode_matches_oracle_and_plain_plan(seq, interp, prec, extra, jit
     tpose = bool(extra.get("tpose", False))
     (ym, pm), (yp, pp) = _plans(case, interp, prec, fmod, tpose, jit)
     assert pm.mirror and ",mirror" in pm.kernel_name() and not pp.mirror, (pm.kernel_name(), pp.kernel_name())
-    assert ("[jit " in pm.kernel_name()) == jit
+    assert ("[jit " in pm.kernel_name()) == jit or (jit and "scratch" in pm.jit_note()), (pm.kernel_name(), pm.jit_note())   # (a build that would spill is not used)
     assert pm.fallback_tiles() == 0
     ref = O.das_spec("DAS", case["Pi"], case["Pr"], case["Pv"], case["Nv"], np.swapaxes(x, 1, 2) if tpose else x, case["t0"], case["fs"],
                      cinv_f32(case["c"]), VS=case["VS"], DV=case["DV"], interp=interp, fmod=fmod, tpose=tpose).reshape(-1, order="F")
