@@ -364,6 +364,18 @@ def test_bench_and_suite_hiprtc_kernels_do_not_spill(tmp_path, monkeypatch):
     assert len(rows) >= len(set(specs)) + len(vs) - 2, (len(rows), len(specs), len(vs))
     bad = [(r["name"], r["vgpr"], r["vgpr_spill"], r["scratch"]) for r in rows if r["vgpr_spill"] != 0 or r["vgpr"] + r["agpr"] > 128]
     assert not bad, bad
+    # The plan-specialised builds of the GPU SUITE (tests/suite_jit_kernels.txt): a build that spills is refused at run time (csrc/qdas_api.hip
+    # jit_get_kernel_nospill -- its plan runs the stock kernel), so a spill there is a silent loss of the specialisation, not an error.  The three that do
+    # are known (round 6); a fourth would show up here.
+    known = {"qdas_jit_tile__linear_f32_fmod_mirror_mb16_w192_n8_m16_t452", "qdas_jit_tile__lanczos3_f32_lut_fmod_mirror_mb32_w128_n1_m32_t268",
+             "qdas_jit_tile__linear_f32_lut_fmod_mirror_mb32_w128_n2_m32_t534"}
+    suite = tmp_path / "suite_jit"
+    suite.mkdir()
+    sspecs = warm.read_specs([os.path.join(here, "suite_jit_kernels.txt")])
+    assert warm.warm_specs(sspecs, str(suite), jobs=jobs, quiet=True) == 0
+    srows = [r for fn in sorted(os.listdir(suite)) if fn.endswith(".hsaco") for r in kernel_regs.kernel_table(str(suite / fn))]
+    spilling = {r["name"] for r in srows if r["vgpr_spill"] != 0 or r["scratch"] > 32}
+    assert spilling <= known, sorted(spilling - known)
     # a private segment without a spilled register is tolerated only when NO instruction touches it (a dead stack slot of the 2-tap weight array: one
     # on-demand variant of the table-driven kernel has one)
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
