@@ -1878,12 +1878,17 @@ static int lut_tiled(const qdas_lut_desc *d, const void *x, void *y, hipStream_t
                 static std::vector<Hit> hits;
                 bool have = false;
                 { std::lock_guard<std::mutex> lk(mu); for (const Hit &h : hits) if (h.dev == dev && !memcmp(&h.k, &k, sizeof k)) { fn = h.fn; key = h.key; have = true; break; } }
+                if (have && !fn) return 1;               // (remembered: no compiler, or a build that would spill -- the general flavour, without asking again)
                 if (!have) {
                     const JitSpec asked = k;
-                    if (!jit_get_kernel_nospill(k, dev, &fn, &key).empty()) { g_err = keep_err; (void)hipGetLastError(); return 1; }      // (no compiler: not an error)
-                    std::lock_guard<std::mutex> lk(mu);
-                    hits.push_back(Hit{asked, dev, fn, key});
-                    if (hits.size() > 64) hits.erase(hits.begin());
+                    const bool failed = !jit_get_kernel_nospill(k, dev, &fn, &key).empty();      // (no compiler: not an error)
+                    if (failed) { fn = nullptr; g_err = keep_err; (void)hipGetLastError(); }
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        hits.push_back(Hit{asked, dev, fn, key});
+                        if (hits.size() > 64) hits.erase(hits.begin());
+                    }
+                    if (failed) return 1;
                 }
             }
             t.probe = 0; t.probe_w = 0; t.mir = 1; t.ksplit = ks2; t.part = (float2 *)part2;
